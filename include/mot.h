@@ -1,0 +1,223 @@
+/*
+ * mot.h — C-ABI of the MI355X-native LiDAR perception hot path.
+ *
+ * Drop-in boundary: the plain C++ free functions the three reference ROS nodes call
+ * (reference = /root/reference/object_tracking, abbreviated OT/ below):
+ *
+ *   groundRemove()          OT/include/ground_removal.h:62-64   (called OT/src/groundremove/main.cpp:120)
+ *   componentClustering()   OT/include/component_clustering.h:20-22 (called OT/src/cluster/main.cpp:74)
+ *   boxFitting()            OT/include/box_fitting.h:34-36       (called OT/src/cluster/main.cpp:119)
+ *   getOriginPoints()       OT/include/imm_ukf_jpda.h:15         (called OT/tracking/main.cpp:74)
+ *   immUkfJpdaf()           OT/include/imm_ukf_jpda.h:19-22      (called OT/tracking/main.cpp:166)
+ *
+ * The reference has no FFI; these entry points are what a maintainer binds instead of those
+ * functions (see INTEGRATION.md for the C++ adapters with the exact reference signatures).
+ * Plain pointers and sizes only — no torch / PCL / Eigen types cross this boundary.
+ *
+ * Conventions
+ *   - points are 16-byte records (x, y, z, w) fp32 — PCL PointXYZ and KITTI .bin share it;
+ *     w is carried through untouched.
+ *   - every function returns MOT_OK or an error code; mot_last_error() has the text.
+ *     Nothing aborts (the reference asserts / prints instead: OT/tracking/imm_ukf_jpda.cpp:130,159,…).
+ *   - "_dev" variants take DEVICE pointers and leave results on the device, so stages chain
+ *     with no D2H/H2D; they run on the context's HIP stream and do not synchronise.
+ *   - a context owns B = max_batch independent sensor streams ("slots"); batch entry points
+ *     process slot b = 0..B-1 in one launch sequence. The single-frame entry points use slot 0.
+ *   - all device code is HIP for gfx950; there is NO CPU fallback: without a GPU
+ *     mot_create() fails with MOT_E_HIP.
+ */
+#ifndef MOT_H_
+#define MOT_H_
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MOT_ABI_VERSION 1
+
+/* polar grid of the ground stage: compile-time in the reference too
+ * (OT/include/ground_removal.h:16-17) */
+#define MOT_NUM_CHANNEL 80
+#define MOT_NUM_BIN 120
+#define MOT_POLAR_CELLS (MOT_NUM_CHANNEL * MOT_NUM_BIN)
+/* Cartesian grid edge: 250 in OT/ (component_clustering.h:13), 200 in OT0/; runtime, <= 256 */
+#define MOT_MAX_GRID 256
+/* trackbox.box_num is uint8 on the wire (OT/msg/trackbox.msg:2) */
+#define MOT_MAX_BOXES 255
+
+enum {
+  MOT_OK = 0,
+  MOT_E_ARG = 1,      /* bad argument (null pointer, n out of range, …) */
+  MOT_E_CAPACITY = 2, /* more points / clusters / boxes / tracks than the context was created for */
+  MOT_E_HIP = 3,      /* HIP runtime error or no gfx950 device */
+  MOT_E_STATE = 4     /* call sequence error */
+};
+
+enum {
+  MOT_PRESET_OBJECT_TRACKING = 0, /* OT/  constants (the package north_star names) */
+  MOT_PRESET_OBJECT_TRACKING0 = 1 /* OT0/ constants (KITTI-tuned), SURVEY.md §2.1 */
+};
+
+/* per-point classification written by the ground stage */
+enum { MOT_MASK_DROPPED = 0, MOT_MASK_GROUND = 1, MOT_MASK_ELEVATED = 2 };
+
+/* All tunables of the path. The reference keeps them as file-scope globals; file:line in the
+ * comments. mot_params_preset() fills either preset. */
+typedef struct mot_params {
+  /* ---- ground stage: OT/src/groundremove/ground_removal.cpp:24-33 ---- */
+  float r_min;          /* rMin 3.4 */
+  float r_max;          /* rMax 120 */
+  float t_hmin;         /* tHmin -2.0 (OT0 -1.9) */
+  float t_hmax;         /* tHmax -0.4 (OT0 -1.0) */
+  float t_hdiff;        /* tHDiff 0.4 */
+  float h_sensor;       /* hSeonsor 2 (OT0 1.73) */
+  double ground_margin; /* 0.25, ground_removal.cpp:239 (a double literal) */
+  double gauss_sigma;   /* 1, ground_removal.cpp:200 */
+  int32_t gauss_samples; /* 3, ground_removal.cpp:200 (only 3 is supported) */
+  /* node pre-filter of the `ground` node: OT/src/groundremove/main.cpp:56-81,104-112.
+   * crop_enable=0 feeds the full cloud to groundRemove (what OT0/src/main.cpp:57-63 does). */
+  int32_t crop_enable;
+  float crop_z_min, crop_z_max; /* PassThrough: keep z_min <= z <= z_max  (-3, 1) */
+  float crop_x_min, crop_x_max; /* ConditionalRemoval: keep x_min < x < x_max (-15, 5) */
+  float crop_y_min, crop_y_max; /* keep y_min < y < y_max (-50, 50) */
+  /* ---- cluster stage: OT/src/cluster/component_clustering.cpp:11-12,134-214 ---- */
+  int32_t num_grid;      /* numGrid 250 (OT0 200) */
+  float roi_m;           /* roiM 50 (OT0 30) */
+  int32_t occ_min_count; /* OT: cell occupied iff count > 1  => 2 ; OT0: any point => 1 */
+  int32_t dilate;        /* OT: 3x3 dilation of occupied cells => 1 ; OT0 => 0 */
+  /* ---- box stage: OT/src/cluster/box_fitting.cpp:18-44 ---- */
+  float pic_scale;      /* picScale = 900/roiM */
+  int32_t ram_points;   /* ramPoints 80 */
+  int32_t l_slope_dist; /* lSlopeDist (int!) 1 (OT0 3) */
+  int32_t l_num_points; /* lnumPoints 5 (OT0 300) */
+  int32_t lshape_side_cond; /* OT: && (maxMy > 8 || maxMy < -5)  box_fitting.cpp:308 ; OT0: absent */
+  float sensor_height;  /* sensorHeight 2 (OT0 1.73) */
+  float t_height_min, t_height_max; /* 0.8 (OT0 1.0), 2.6 */
+  float t_width_min, t_width_max;   /* 0.2 (OT0 .25), 3.5 */
+  float t_len_min, t_len_max;       /* 0.2 (OT0 .5), 14 */
+  float t_area_max;                 /* 20 */
+  float t_ratio_min, t_ratio_max;   /* 1 (OT0 1.3), 8 (OT0 5) */
+  float min_len_ratio;              /* 3 */
+  float t_pt_per_m3;                /* 8 */
+  int32_t min_points;               /* 30 (OT0 100), box_fitting.cpp:100 */
+  /* ---- tracker: OT/tracking/imm_ukf_jpda.cpp:26-51,70,749-760 ---- */
+  double gamma_g;        /* gammaG_ 9.22 */
+  double p_g, p_d;       /* 0.99, 0.9 */
+  double distance_thres; /* distanceThres_ 99 (OT0 0.25) */
+  int32_t life_time_thres; /* lifeTimeThres_ 3 (OT0 8) */
+  int32_t seed_box_index;  /* first frame seeds a track from box #1 (OT0 #10), :749 */
+  double bb_yaw_change_thres; /* 0.2 */
+  double first_ego_yaw_offset; /* -0.63035 - pi/2 (OT0 1.22191 - pi/2) */
+  double seed_px, seed_py;     /* hard-coded seed position (-1.5125, -8.975), :755-756 */
+} mot_params;
+
+/* one record per track EVER created on a stream (the reference's output vectors are sized that
+ * way: targetPoints / targetVandYaw / trackManage / isStaticVec / isVisVec,
+ * OT/tracking/imm_ukf_jpda.cpp:995-1041). 144 bytes. */
+typedef struct mot_track {
+  int32_t id;           /* index into targets_ */
+  int32_t track_manage; /* trackNumVec_[id] : 0 dead, 1..3 tentative, 5 confirmed, 6..9 coasting */
+  int32_t is_static;    /* isStaticVec[id] */
+  int32_t is_vis;       /* isVisVec[id] */
+  float px, py, pz;     /* targetPoints[id] (pz = -0.865) */
+  int32_t lifetime;     /* UKF::lifetime_ */
+  double v, yaw;        /* targetVandYaw[id] = {x_merge(2), x_merge(3)+egoYaw wrapped} */
+  float vis_box[24];    /* BBox_ (8 corners x,y,z) when is_vis, else zeros */
+} mot_track;
+
+/* full filter state of one track, for parity checks against the reference's targets_[id] */
+typedef struct mot_track_state {
+  double x_merge[5], x_cv[5], x_ctrv[5], x_rm[5];
+  double p_merge[25], p_cv[25], p_ctrv[25], p_rm[25]; /* row-major 5x5 */
+  double mode_prob[3];                                 /* CV, CTRV, RM */
+  double z_pred[3][2], s[3][4], k[3][10];              /* zPred*l_, lS_*_, K_*_ (5x2 row-major) */
+  double init_meas[2], dist_from_init, best_yaw;
+  int32_t lifetime, track_manage, is_static, is_vis, has_best_box, _pad;
+  float bbox[24], best_bbox[24];
+} mot_track_state;
+
+typedef struct mot_ctx mot_ctx;
+
+/* ---------------------------------------------------------------- lifecycle */
+int mot_abi_version(void);
+int mot_params_preset(int preset, mot_params* out);
+/* device: HIP device ordinal. max_points: capacity per frame. max_batch: number of stream slots (>=1).
+ * max_tracks_total: capacity of "tracks ever created" per stream (the reference never frees them). */
+int mot_create(const mot_params* params, int device, int max_points, int max_batch,
+               int max_tracks_total, mot_ctx** out);
+void mot_destroy(mot_ctx* ctx);
+/* forget all tracker state of every slot (the reference cannot: file-scope globals,
+ * OT/tracking/imm_ukf_jpda.cpp:19-24,56-70) */
+int mot_reset(mot_ctx* ctx);
+const char* mot_last_error(const mot_ctx* ctx);
+int mot_synchronize(mot_ctx* ctx);
+/* the HIP stream (hipStream_t) the context launches on, for callers that enqueue their own work */
+void* mot_stream(mot_ctx* ctx);
+
+/* ---------------------------------------------------------------- stage entry points, HOST buffers
+ * (copy in, run, copy out, synchronise — the literal drop-in for the reference call sites) */
+
+/* replaces groundRemove(cloud, elevatedCloud, groundCloud), OT/include/ground_removal.h:62-64.
+ * xyzw: n x 4 floats. elevated/ground: caller buffers of capacity n x 4 floats, filled in input
+ * order (the reference push_backs in input order, ground_removal.cpp:221-247). mask (optional, n bytes). */
+int mot_ground_remove(mot_ctx* ctx, const float* xyzw, int n, float* elevated_xyzw, int* n_elevated,
+                      float* ground_xyzw, int* n_ground, uint8_t* mask);
+
+/* replaces componentClustering(elevatedCloud, cartesianData, numCluster),
+ * OT/include/component_clustering.h:20-22. grid: num_grid x num_grid int32, x-major
+ * (grid[x*num_grid+y] == cartesianData[x][y]); labels 1..num_cluster in raster order of first cell.
+ * point_label (optional, n int32): label of the cell each point falls in, 0 if none / outside ROI. */
+int mot_cluster(mot_ctx* ctx, const float* elevated_xyzw, int n, int32_t* grid, int* num_cluster,
+                int32_t* point_label);
+
+/* replaces boxFitting(elevatedCloud, cartesianData, numCluster, ma), OT/include/box_fitting.h:34-36.
+ * boxes: capacity max_boxes x 8 x 3 floats (4 bottom corners z=-sensor_height, 4 top corners z=maxZ,
+ * box_fitting.cpp:379-389). box_cluster (optional): 1-based cluster id of each emitted box.
+ * n_undefined (optional): clusters whose result is undefined behaviour in the reference
+ * (uninitialised reads); they are rejected here. */
+int mot_box_fit(mot_ctx* ctx, const float* elevated_xyzw, int n, const int32_t* grid, int num_cluster,
+                float* boxes, int max_boxes, int* n_boxes, int32_t* box_cluster, int* n_undefined);
+
+/* replaces getOriginPoints(timestamp, originPoints, v_gps, yaw_gps), OT/include/imm_ukf_jpda.h:15.
+ * origin6 = {x, y, yaw, x, y, yaw + pi/2}. Must be called before mot_track_step of the same frame,
+ * like OT/tracking/main.cpp:74. */
+int mot_ego_update(mot_ctx* ctx, int slot, double timestamp, double v_gps, double yaw_gps, double* origin6);
+
+/* replaces immUkfJpdaf(bBoxes, timestamp, ...), OT/include/imm_ukf_jpda.h:19-22.
+ * boxes_global: m x 8 x 3 floats in the global frame. tracks: capacity max_tracks records. */
+int mot_track_step(mot_ctx* ctx, int slot, const float* boxes_global, int m, double timestamp,
+                   mot_track* tracks, int max_tracks, int* n_tracks);
+/* filter state of track `id` on `slot` (parity/debug) */
+int mot_track_get_state(mot_ctx* ctx, int slot, int id, mot_track_state* out);
+
+/* ---------------------------------------------------------------- fused frame, DEVICE buffers
+ * One sensor frame per slot through ground -> cluster -> box -> (optional) tracker with every
+ * intermediate left in HBM. d_xyzw: max_batch frames, frame b at d_xyzw + b*frame_stride floats.
+ * n_points[b] host array. timestamps/ego (host arrays of length batch) feed the tracker when
+ * run_tracker != 0; boxes are then taken in the sensor frame transformed to the global frame with
+ * the dead-reckoned ego pose (what OT/tracking/main.cpp:143-158 does through tf).
+ * Asynchronous: results are read back with the mot_get_* calls below (which synchronise). */
+int mot_frames_dev(mot_ctx* ctx, const float* d_xyzw, long frame_stride, const int* n_points, int batch,
+                   int run_tracker, const double* timestamps, const double* ego_v, const double* ego_yaw);
+
+/* read back results of the last mot_frames_dev / stage call for `slot` (host buffers; any may be NULL) */
+int mot_get_ground(mot_ctx* ctx, int slot, float* elevated_xyzw, int* n_elevated, float* ground_xyzw,
+                   int* n_ground, uint8_t* mask);
+int mot_get_clusters(mot_ctx* ctx, int slot, int32_t* grid, int* num_cluster, int32_t* point_label);
+int mot_get_boxes(mot_ctx* ctx, int slot, float* boxes, int max_boxes, int* n_boxes, int32_t* box_cluster,
+                  int* n_undefined);
+int mot_get_tracks(mot_ctx* ctx, int slot, mot_track* tracks, int max_tracks, int* n_tracks);
+
+/* ---------------------------------------------------------------- measurement helpers (bench.py) */
+/* Re-runs only the named stage `iters` times on the data resident from the last mot_frames_dev call,
+ * bracketed by hipEvents ON THE CONTEXT STREAM; returns average milliseconds per iteration.
+ * stage: 0 ground, 1 cluster, 2 box, 3 tracker (tracker re-runs are not idempotent and are refused),
+ * 10+k: k-th kernel of the ground stage alone. */
+int mot_time_stage(mot_ctx* ctx, int stage, int batch, int iters, float* ms_per_iter);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MOT_H_ */

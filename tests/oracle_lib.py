@@ -1,0 +1,312 @@
+"""ctypes bindings for the TEST-ONLY oracle libraries.
+
+  oracle/build/libmot_oracle.so  — C restatement (oracle/mot_oracle_*.c)
+  oracle/_ref/libmot_ref.so      — the reference's own sources compiled against a shim (oracle/Makefile)
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this module.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ORACLE_DIR = os.path.join(ROOT, "oracle")
+ORC_SO = os.path.join(ORACLE_DIR, "build", "libmot_oracle.so")
+REF_SO = os.path.join(ORACLE_DIR, "_ref", "libmot_ref.so")
+
+POLAR_CELLS = 80 * 120
+f32p = np.ctypeslib.ndpointer(np.float32, flags="C_CONTIGUOUS")
+i32p = np.ctypeslib.ndpointer(np.int32, flags="C_CONTIGUOUS")
+u8p = np.ctypeslib.ndpointer(np.uint8, flags="C_CONTIGUOUS")
+f64p = np.ctypeslib.ndpointer(np.float64, flags="C_CONTIGUOUS")
+
+
+class MotParams(C.Structure):
+    """mirror of struct mot_params (include/mot.h)"""
+    _fields_ = [
+        ("r_min", C.c_float), ("r_max", C.c_float), ("t_hmin", C.c_float), ("t_hmax", C.c_float),
+        ("t_hdiff", C.c_float), ("h_sensor", C.c_float), ("ground_margin", C.c_double), ("gauss_sigma", C.c_double),
+        ("gauss_samples", C.c_int32), ("crop_enable", C.c_int32),
+        ("crop_z_min", C.c_float), ("crop_z_max", C.c_float), ("crop_x_min", C.c_float), ("crop_x_max", C.c_float),
+        ("crop_y_min", C.c_float), ("crop_y_max", C.c_float),
+        ("num_grid", C.c_int32), ("roi_m", C.c_float), ("occ_min_count", C.c_int32), ("dilate", C.c_int32),
+        ("pic_scale", C.c_float), ("ram_points", C.c_int32), ("l_slope_dist", C.c_int32), ("l_num_points", C.c_int32),
+        ("lshape_side_cond", C.c_int32), ("sensor_height", C.c_float),
+        ("t_height_min", C.c_float), ("t_height_max", C.c_float), ("t_width_min", C.c_float), ("t_width_max", C.c_float),
+        ("t_len_min", C.c_float), ("t_len_max", C.c_float), ("t_area_max", C.c_float),
+        ("t_ratio_min", C.c_float), ("t_ratio_max", C.c_float), ("min_len_ratio", C.c_float), ("t_pt_per_m3", C.c_float),
+        ("min_points", C.c_int32),
+        ("gamma_g", C.c_double), ("p_g", C.c_double), ("p_d", C.c_double), ("distance_thres", C.c_double),
+        ("life_time_thres", C.c_int32), ("seed_box_index", C.c_int32), ("bb_yaw_change_thres", C.c_double),
+        ("first_ego_yaw_offset", C.c_double), ("seed_px", C.c_double), ("seed_py", C.c_double),
+    ]
+
+
+class MotTrack(C.Structure):
+    _fields_ = [("id", C.c_int32), ("track_manage", C.c_int32), ("is_static", C.c_int32), ("is_vis", C.c_int32),
+                ("px", C.c_float), ("py", C.c_float), ("pz", C.c_float), ("lifetime", C.c_int32),
+                ("v", C.c_double), ("yaw", C.c_double), ("vis_box", C.c_float * 24)]
+
+
+class MotTrackState(C.Structure):
+    _fields_ = [("x_merge", C.c_double * 5), ("x_cv", C.c_double * 5), ("x_ctrv", C.c_double * 5), ("x_rm", C.c_double * 5),
+                ("p_merge", C.c_double * 25), ("p_cv", C.c_double * 25), ("p_ctrv", C.c_double * 25), ("p_rm", C.c_double * 25),
+                ("mode_prob", C.c_double * 3), ("z_pred", C.c_double * 6), ("s", C.c_double * 12), ("k", C.c_double * 30),
+                ("init_meas", C.c_double * 2), ("dist_from_init", C.c_double), ("best_yaw", C.c_double),
+                ("lifetime", C.c_int32), ("track_manage", C.c_int32), ("is_static", C.c_int32), ("is_vis", C.c_int32),
+                ("has_best_box", C.c_int32), ("_pad", C.c_int32), ("bbox", C.c_float * 24), ("best_bbox", C.c_float * 24)]
+
+
+class PolarDump(C.Structure):
+    _fields_ = [("min_z", C.c_float * POLAR_CELLS), ("height", C.c_float * POLAR_CELLS), ("smoothed", C.c_float * POLAR_CELLS),
+                ("hdiff", C.c_float * POLAR_CELLS), ("hground", C.c_float * POLAR_CELLS), ("is_ground", C.c_uint8 * POLAR_CELLS)]
+
+
+def build_oracle(force: bool = False) -> None:
+    """compile the C restatement (and oracle/_ref when /root/reference is present)"""
+    if force or not os.path.exists(ORC_SO) or any(
+            os.path.getmtime(os.path.join(ORACLE_DIR, f)) > os.path.getmtime(ORC_SO)
+            for f in os.listdir(ORACLE_DIR) if f.endswith((".c", ".h"))):
+        subprocess.run(["make", "-C", ORACLE_DIR, "build/libmot_oracle.so"], check=True, capture_output=True)
+    if os.path.exists("/root/reference/object_tracking/tracking/ukf.cpp"):
+        subprocess.run(["make", "-C", ORACLE_DIR, "ref"], check=True, capture_output=True)
+
+
+_orc = None
+_ref = None
+
+
+def orc():
+    global _orc
+    if _orc is None:
+        build_oracle()
+        _orc = C.CDLL(ORC_SO)
+    return _orc
+
+
+def ref():
+    """the reference-built library, or None when it has not been built (no /root/reference, no prebuilt .so)"""
+    global _ref
+    if _ref is None:
+        if not os.path.exists(REF_SO):
+            if os.path.exists("/root/reference/object_tracking/tracking/ukf.cpp"):
+                build_oracle()
+            else:
+                return None
+        _ref = C.CDLL(REF_SO)
+    return _ref
+
+
+def params(preset: int = 0, **overrides) -> MotParams:
+    p = MotParams()
+    rc = orc().orc_params_preset(preset, C.byref(p))
+    assert rc == 0
+    for k, v in overrides.items():
+        setattr(p, k, v)
+    return p
+
+
+def _pts(a) -> np.ndarray:
+    a = np.ascontiguousarray(a, dtype=np.float32)
+    assert a.ndim == 2 and a.shape[1] == 4
+    return a
+
+
+# ------------------------------------------------------------------ restatement
+def ground_remove(p: MotParams, xyzw, want_dump: bool = False):
+    a = _pts(xyzw); n = len(a)
+    elev = np.zeros((max(n, 1), 4), np.float32); ground = np.zeros((max(n, 1), 4), np.float32)
+    mask = np.zeros(max(n, 1), np.uint8); ne = C.c_int(0); ng = C.c_int(0)
+    dump = PolarDump() if want_dump else None
+    rc = orc().orc_ground_remove(C.byref(p), a.ctypes.data_as(C.c_void_p), n, elev.ctypes.data_as(C.c_void_p), C.byref(ne),
+                                 ground.ctypes.data_as(C.c_void_p), C.byref(ng), mask.ctypes.data_as(C.c_void_p),
+                                 C.byref(dump) if dump is not None else None)
+    assert rc == 0, rc
+    out = dict(elevated=elev[: ne.value].copy(), ground=ground[: ng.value].copy(), mask=mask[:n].copy())
+    if dump is not None:
+        for k in ("min_z", "height", "smoothed", "hdiff", "hground", "is_ground"):
+            out[k] = np.ctypeslib.as_array(getattr(dump, k)).copy().reshape(80, 120)
+    return out
+
+
+def crop(p: MotParams, xyzw):
+    a = _pts(xyzw); out = np.zeros_like(a)
+    orc().orc_crop.restype = C.c_int
+    k = orc().orc_crop(C.byref(p), a.ctypes.data_as(C.c_void_p), len(a), out.ctypes.data_as(C.c_void_p))
+    return out[:k].copy()
+
+
+def cluster(p: MotParams, elev):
+    a = _pts(elev); n = len(a); G = p.num_grid
+    grid = np.zeros((G, G), np.int32); nc = C.c_int(0); lab = np.zeros(max(n, 1), np.int32)
+    rc = orc().orc_cluster(C.byref(p), a.ctypes.data_as(C.c_void_p), n, grid.ctypes.data_as(C.c_void_p), C.byref(nc),
+                           lab.ctypes.data_as(C.c_void_p))
+    assert rc == 0, rc
+    return dict(grid=grid, num_cluster=nc.value, point_label=lab[:n].copy())
+
+
+class BoxDebug(C.Structure):
+    _fields_ = [("num_points", C.c_int32), ("branch", C.c_int32), ("accepted", C.c_int32), ("undefined", C.c_int32),
+                ("max_z", C.c_float), ("corners", C.c_float * 8)]
+
+
+def box_fit(p: MotParams, elev, grid, num_cluster, max_boxes: int = 4096, debug: bool = False):
+    a = _pts(elev); n = len(a)
+    grid = np.ascontiguousarray(grid, np.int32)
+    boxes = np.zeros((max_boxes, 8, 3), np.float32); nb = C.c_int(0); bc = np.zeros(max_boxes, np.int32); nu = C.c_int(0)
+    dbg = (BoxDebug * max(num_cluster, 1))() if debug else None
+    rc = orc().orc_box_fit(C.byref(p), a.ctypes.data_as(C.c_void_p), n, grid.ctypes.data_as(C.c_void_p), num_cluster,
+                           boxes.ctypes.data_as(C.c_void_p), max_boxes, C.byref(nb), bc.ctypes.data_as(C.c_void_p), C.byref(nu), dbg)
+    assert rc == 0, rc
+    out = dict(boxes=boxes[: nb.value].copy(), box_cluster=bc[: nb.value].copy(), n_undefined=nu.value)
+    if debug:
+        out["debug"] = [dict(num_points=d.num_points, branch=d.branch, accepted=d.accepted, undefined=d.undefined,
+                             max_z=d.max_z, corners=np.array(d.corners[:], np.float32)) for d in dbg[:num_cluster]]
+    return out
+
+
+def min_area_rect_points(xy) -> np.ndarray:
+    xy = np.ascontiguousarray(xy, np.int32); out = np.zeros(8, np.float32)
+    orc().orc_min_area_rect_points(xy.ctypes.data_as(C.c_void_p), len(xy), out.ctypes.data_as(C.c_void_p))
+    return out.reshape(4, 2)
+
+
+def convex_hull(xy) -> np.ndarray:
+    xy = np.ascontiguousarray(xy, np.int32); out = np.zeros((max(len(xy), 1), 2), np.int32)
+    orc().orc_convex_hull.restype = C.c_int
+    k = orc().orc_convex_hull(xy.ctypes.data_as(C.c_void_p), len(xy), out.ctypes.data_as(C.c_void_p))
+    return out[:k].copy()
+
+
+def lshape_indices(num_points: int, count: int = 80) -> np.ndarray:
+    out = np.zeros(count, np.int32)
+    orc().orc_lshape_indices(num_points, count, out.ctypes.data_as(C.c_void_p))
+    return out
+
+
+class Tracker:
+    """restated tracker (oracle/mot_oracle_track.c)"""
+
+    def __init__(self, p: MotParams):
+        o = orc(); o.orc_tracker_create.restype = C.c_void_p
+        self._p = p; self._h = C.c_void_p(o.orc_tracker_create(C.byref(p)))
+
+    def close(self):
+        if self._h:
+            orc().orc_tracker_destroy(self._h); self._h = None
+
+    __del__ = close
+
+    def reset(self):
+        orc().orc_tracker_reset(self._h)
+
+    def ego_update(self, ts, v, yaw):
+        out = np.zeros(6); rc = orc().orc_ego_update(self._h, C.c_double(ts), C.c_double(v), C.c_double(yaw), out.ctypes.data_as(C.c_void_p))
+        assert rc == 0; return out
+
+    def step(self, boxes, ts, max_tracks=8192):
+        b = np.ascontiguousarray(boxes, np.float32).reshape(-1, 8, 3)
+        arr = (MotTrack * max_tracks)(); nt = C.c_int(0)
+        rc = orc().orc_track_step(self._h, b.ctypes.data_as(C.c_void_p), len(b), C.c_double(ts), arr, max_tracks, C.byref(nt))
+        assert rc == 0, rc
+        return tracks_to_dict(arr, nt.value)
+
+    def state(self, i):
+        s = MotTrackState(); rc = orc().orc_track_get_state(self._h, i, C.byref(s)); assert rc == 0
+        return state_to_dict(s)
+
+
+def tracks_to_dict(arr, n):
+    return dict(
+        n=n,
+        track_manage=np.array([arr[i].track_manage for i in range(n)], np.int32),
+        is_static=np.array([arr[i].is_static for i in range(n)], np.int32),
+        is_vis=np.array([arr[i].is_vis for i in range(n)], np.int32),
+        lifetime=np.array([arr[i].lifetime for i in range(n)], np.int32),
+        p=np.array([[arr[i].px, arr[i].py, arr[i].pz] for i in range(n)], np.float32).reshape(n, 3),
+        v_yaw=np.array([[arr[i].v, arr[i].yaw] for i in range(n)], np.float64).reshape(n, 2),
+        vis_box=np.array([arr[i].vis_box[:] for i in range(n)], np.float32).reshape(n, 24))
+
+
+def state_to_dict(s: MotTrackState):
+    d = {}
+    for name, _ in MotTrackState._fields_:
+        v = getattr(s, name)
+        d[name] = np.array(v[:]) if hasattr(v, "__len__") else v
+    return d
+
+
+# ------------------------------------------------------------------ reference build (oracle/_ref)
+def ref_ground_remove(xyzw):
+    a = _pts(xyzw); n = len(a)
+    elev = np.zeros((max(n, 1), 4), np.float32); ground = np.zeros((max(n, 1), 4), np.float32); ne = C.c_int(0); ng = C.c_int(0)
+    ref().ref_ground_remove(a.ctypes.data_as(C.c_void_p), n, elev.ctypes.data_as(C.c_void_p), C.byref(ne),
+                            ground.ctypes.data_as(C.c_void_p), C.byref(ng))
+    return dict(elevated=elev[: ne.value].copy(), ground=ground[: ng.value].copy())
+
+
+def ref_ground_polar(xyzw):
+    a = _pts(xyzw); out = {k: np.zeros((80, 120), np.float32) for k in ("min_z", "height", "smoothed", "hdiff", "hground")}
+    out["is_ground"] = np.zeros((80, 120), np.uint8)
+    ref().ref_ground_polar(a.ctypes.data_as(C.c_void_p), len(a), *[out[k].ctypes.data_as(C.c_void_p) for k in
+                           ("min_z", "height", "smoothed", "hdiff", "hground", "is_ground")])
+    return out
+
+
+def ref_cell_index(x, y):
+    ch = C.c_int(0); b = C.c_int(0)
+    ref().ref_cell_index(C.c_float(x), C.c_float(y), C.byref(ch), C.byref(b))
+    return ch.value, b.value
+
+
+def ref_cluster(elev):
+    a = _pts(elev); G = ref().ref_num_grid()
+    grid = np.zeros((G, G), np.int32); nc = C.c_int(0)
+    ref().ref_cluster(a.ctypes.data_as(C.c_void_p), len(a), grid.ctypes.data_as(C.c_void_p), C.byref(nc))
+    return dict(grid=grid, num_cluster=nc.value)
+
+
+def ref_box_fit(elev, grid, num_cluster, max_boxes=4096):
+    a = _pts(elev); grid = np.ascontiguousarray(grid, np.int32)
+    boxes = np.zeros((max_boxes, 8, 3), np.float32); nb = C.c_int(0)
+    ref().ref_box_fit(a.ctypes.data_as(C.c_void_p), len(a), grid.ctypes.data_as(C.c_void_p), num_cluster,
+                      boxes.ctypes.data_as(C.c_void_p), max_boxes, C.byref(nb))
+    return dict(boxes=boxes[: min(nb.value, max_boxes)].copy(), n=nb.value)
+
+
+class RefTracker:
+    """the reference tracker: file-scope globals => one instance at a time"""
+
+    def reset(self):
+        ref().ref_tracker_reset()
+
+    def ego_update(self, ts, v, yaw):
+        out = np.zeros(6); ref().ref_ego_update(C.c_double(ts), C.c_double(v), C.c_double(yaw), out.ctypes.data_as(C.c_void_p)); return out
+
+    def step(self, boxes, ts, max_tracks=8192):
+        b = np.ascontiguousarray(boxes, np.float32).reshape(-1, 8, 3)
+        xyz = np.zeros((max_tracks, 3), np.float32); vy = np.zeros((max_tracks, 2)); tm = np.zeros(max_tracks, np.int32)
+        st = np.zeros(max_tracks, np.int32); vis = np.zeros(max_tracks, np.int32); vbb = np.zeros((max_tracks, 24), np.float32); nt = C.c_int(0)
+        ref().ref_track_step(b.ctypes.data_as(C.c_void_p), len(b), C.c_double(ts), max_tracks, xyz.ctypes.data_as(C.c_void_p),
+                             vy.ctypes.data_as(C.c_void_p), tm.ctypes.data_as(C.c_void_p), st.ctypes.data_as(C.c_void_p),
+                             vis.ctypes.data_as(C.c_void_p), vbb.ctypes.data_as(C.c_void_p), C.byref(nt))
+        n = nt.value
+        return dict(n=n, track_manage=tm[:n].copy(), is_static=st[:n].copy(), is_vis=vis[:n].copy(), p=xyz[:n].copy(),
+                    v_yaw=vy[:n].copy(), vis_box=vbb[:n].copy())
+
+    def count(self):
+        return ref().ref_track_count()
+
+    def state(self, i):
+        x = np.zeros(20); p = np.zeros(100); mode = np.zeros(3); z = np.zeros(6); s = np.zeros(12); k = np.zeros(30); misc = np.zeros(4)
+        ints = np.zeros(5, np.int32); bb = np.zeros(24, np.float32); best = np.zeros(24, np.float32)
+        rc = ref().ref_track_get_state(i, *[a.ctypes.data_as(C.c_void_p) for a in (x, p, mode, z, s, k, misc, ints, bb, best)])
+        assert rc == 0
+        return dict(x_merge=x[0:5], x_cv=x[5:10], x_ctrv=x[10:15], x_rm=x[15:20], p_merge=p[0:25], p_cv=p[25:50], p_ctrv=p[50:75],
+                    p_rm=p[75:100], mode_prob=mode, z_pred=z, s=s, k=k, init_meas=misc[0:2], dist_from_init=misc[2], best_yaw=misc[3],
+                    lifetime=int(ints[0]), track_manage=int(ints[1]), is_static=int(ints[2]), is_vis=int(ints[3]),
+                    has_best_box=int(ints[4]), bbox=bb, best_bbox=best)
