@@ -1,0 +1,306 @@
+"""MI355X-native LiDAR perception hot path — Python host binding over the C-ABI (include/mot.h).
+
+The product is ``libmot_hip.so`` (hand-written HIP for gfx950, built in-tree by ``build.py``); this module is
+ctypes plumbing plus thin wrappers named after the reference functions they stand in for
+(``groundRemove`` / ``componentClustering`` / ``boxFitting`` / ``getOriginPoints`` / ``immUkfJpdaf`` of
+/root/reference/object_tracking). There is no CPU fallback: loading fails loudly when the extension is
+missing, and ``Context()`` fails when no GPU is present.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libmot_hip.so")
+
+MOT_OK, MOT_E_ARG, MOT_E_CAPACITY, MOT_E_HIP, MOT_E_STATE = 0, 1, 2, 3, 4
+PRESET_OBJECT_TRACKING, PRESET_OBJECT_TRACKING0 = 0, 1
+MASK_DROPPED, MASK_GROUND, MASK_ELEVATED = 0, 1, 2
+NUM_CHANNEL, NUM_BIN = 80, 120
+
+
+class MotParams(C.Structure):
+    """struct mot_params (include/mot.h)"""
+    _fields_ = [
+        ("r_min", C.c_float), ("r_max", C.c_float), ("t_hmin", C.c_float), ("t_hmax", C.c_float),
+        ("t_hdiff", C.c_float), ("h_sensor", C.c_float), ("ground_margin", C.c_double), ("gauss_sigma", C.c_double),
+        ("gauss_samples", C.c_int32), ("crop_enable", C.c_int32),
+        ("crop_z_min", C.c_float), ("crop_z_max", C.c_float), ("crop_x_min", C.c_float), ("crop_x_max", C.c_float),
+        ("crop_y_min", C.c_float), ("crop_y_max", C.c_float),
+        ("num_grid", C.c_int32), ("roi_m", C.c_float), ("occ_min_count", C.c_int32), ("dilate", C.c_int32),
+        ("pic_scale", C.c_float), ("ram_points", C.c_int32), ("l_slope_dist", C.c_int32), ("l_num_points", C.c_int32),
+        ("lshape_side_cond", C.c_int32), ("sensor_height", C.c_float),
+        ("t_height_min", C.c_float), ("t_height_max", C.c_float), ("t_width_min", C.c_float), ("t_width_max", C.c_float),
+        ("t_len_min", C.c_float), ("t_len_max", C.c_float), ("t_area_max", C.c_float),
+        ("t_ratio_min", C.c_float), ("t_ratio_max", C.c_float), ("min_len_ratio", C.c_float), ("t_pt_per_m3", C.c_float),
+        ("min_points", C.c_int32),
+        ("gamma_g", C.c_double), ("p_g", C.c_double), ("p_d", C.c_double), ("distance_thres", C.c_double),
+        ("life_time_thres", C.c_int32), ("seed_box_index", C.c_int32), ("bb_yaw_change_thres", C.c_double),
+        ("first_ego_yaw_offset", C.c_double), ("seed_px", C.c_double), ("seed_py", C.c_double),
+    ]
+
+
+class MotTrack(C.Structure):
+    """struct mot_track"""
+    _fields_ = [("id", C.c_int32), ("track_manage", C.c_int32), ("is_static", C.c_int32), ("is_vis", C.c_int32),
+                ("px", C.c_float), ("py", C.c_float), ("pz", C.c_float), ("lifetime", C.c_int32),
+                ("v", C.c_double), ("yaw", C.c_double), ("vis_box", C.c_float * 24)]
+
+
+class MotTrackState(C.Structure):
+    """struct mot_track_state"""
+    _fields_ = [("x_merge", C.c_double * 5), ("x_cv", C.c_double * 5), ("x_ctrv", C.c_double * 5), ("x_rm", C.c_double * 5),
+                ("p_merge", C.c_double * 25), ("p_cv", C.c_double * 25), ("p_ctrv", C.c_double * 25), ("p_rm", C.c_double * 25),
+                ("mode_prob", C.c_double * 3), ("z_pred", C.c_double * 6), ("s", C.c_double * 12), ("k", C.c_double * 30),
+                ("init_meas", C.c_double * 2), ("dist_from_init", C.c_double), ("best_yaw", C.c_double),
+                ("lifetime", C.c_int32), ("track_manage", C.c_int32), ("is_static", C.c_int32), ("is_vis", C.c_int32),
+                ("has_best_box", C.c_int32), ("_pad", C.c_int32), ("bbox", C.c_float * 24), ("best_bbox", C.c_float * 24)]
+
+
+class MotError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__(f"mot error {code}: {msg}")
+        self.code = code
+
+
+EXPORTS = (
+    "mot_abi_version", "mot_params_preset", "mot_create", "mot_destroy", "mot_reset", "mot_last_error",
+    "mot_synchronize", "mot_stream", "mot_ground_remove", "mot_cluster", "mot_box_fit", "mot_ego_update",
+    "mot_track_step", "mot_track_get_state", "mot_frames_dev", "mot_get_ground", "mot_get_clusters",
+    "mot_get_boxes", "mot_get_tracks", "mot_time_stage",
+)
+
+_libs: dict[str, C.CDLL] = {}
+
+
+def load_library(path: str | None = None) -> C.CDLL:
+    """dlopen the HIP extension (no fallback: a missing library is an error)."""
+    path = path or LIB_PATH
+    if path in _libs:
+        return _libs[path]
+    if not os.path.exists(path):
+        raise ImportError(f"{path} is missing — run `python __graft_entry__.py build` (hipcc, gfx950). "
+                          "There is no CPU fallback for this library.")
+    lib = C.CDLL(path)
+    lib.mot_last_error.restype = C.c_char_p
+    lib.mot_last_error.argtypes = [C.c_void_p]
+    lib.mot_stream.restype = C.c_void_p
+    lib.mot_destroy.restype = None
+    _libs[path] = lib
+    return lib
+
+
+def params(preset: int = PRESET_OBJECT_TRACKING, lib: C.CDLL | None = None, **overrides) -> MotParams:
+    lib = lib or load_library()
+    p = MotParams()
+    rc = lib.mot_params_preset(preset, C.byref(p))
+    if rc:
+        raise MotError(rc, "mot_params_preset")
+    for k, v in overrides.items():
+        setattr(p, k, v)
+    return p
+
+
+def _pts(a) -> np.ndarray:
+    a = np.ascontiguousarray(a, dtype=np.float32)
+    if a.ndim != 2 or a.shape[1] != 4:
+        raise ValueError("points must be (n, 4) float32: x, y, z, w")
+    return a
+
+
+def _vp(a):
+    return a.ctypes.data_as(C.c_void_p) if a is not None else None
+
+
+class Context:
+    """One mot_ctx: ``max_batch`` independent sensor-stream slots on one GPU, one HIP stream."""
+
+    def __init__(self, p: MotParams | None = None, device: int = 0, max_points: int = 131072, max_batch: int = 1,
+                 max_tracks_total: int = 4096, lib_path: str | None = None):
+        self.lib = load_library(lib_path)
+        self.params = p if p is not None else params(lib=self.lib)
+        self.max_points, self.max_batch, self.max_tracks_total = max_points, max_batch, max_tracks_total
+        h = C.c_void_p()
+        rc = self.lib.mot_create(C.byref(self.params), device, max_points, max_batch, max_tracks_total, C.byref(h))
+        if rc:
+            raise MotError(rc, "mot_create failed (no GPU / bad arguments); this library has no CPU fallback")
+        self._h = h
+
+    # ------------------------------------------------------------------ plumbing
+    def close(self):
+        if getattr(self, "_h", None):
+            self.lib.mot_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    def _ck(self, rc):
+        if rc:
+            raise MotError(rc, (self.lib.mot_last_error(self._h) or b"").decode())
+
+    def synchronize(self):
+        self._ck(self.lib.mot_synchronize(self._h))
+
+    def reset(self):
+        self._ck(self.lib.mot_reset(self._h))
+
+    # ------------------------------------------------------------------ stage calls, host buffers
+    def ground_remove(self, xyzw, want_mask: bool = True):
+        """groundRemove(cloud, elevatedCloud, groundCloud) — OT/include/ground_removal.h:62-64"""
+        a = _pts(xyzw); n = len(a)
+        elev = np.empty((max(n, 1), 4), np.float32); ground = np.empty((max(n, 1), 4), np.float32)
+        mask = np.zeros(max(n, 1), np.uint8) if want_mask else None
+        ne, ng = C.c_int(0), C.c_int(0)
+        self._ck(self.lib.mot_ground_remove(self._h, _vp(a), n, _vp(elev), C.byref(ne), _vp(ground), C.byref(ng), _vp(mask)))
+        out = dict(elevated=elev[: ne.value].copy(), ground=ground[: ng.value].copy())
+        if want_mask:
+            out["mask"] = mask[:n].copy()
+        return out
+
+    def cluster(self, elevated_xyzw):
+        """componentClustering(elevatedCloud, cartesianData, numCluster) — OT/include/component_clustering.h:20-22"""
+        a = _pts(elevated_xyzw); n = len(a); G = self.params.num_grid
+        grid = np.zeros((G, G), np.int32); nc = C.c_int(0); lab = np.zeros(max(n, 1), np.int32)
+        self._ck(self.lib.mot_cluster(self._h, _vp(a), n, _vp(grid), C.byref(nc), _vp(lab)))
+        return dict(grid=grid, num_cluster=nc.value, point_label=lab[:n].copy())
+
+    def box_fit(self, elevated_xyzw, grid, num_cluster: int, max_boxes: int = 4096):
+        """boxFitting(elevatedCloud, cartesianData, numCluster, ma) — OT/include/box_fitting.h:34-36"""
+        a = _pts(elevated_xyzw); n = len(a)
+        grid = np.ascontiguousarray(grid, np.int32)
+        boxes = np.zeros((max_boxes, 8, 3), np.float32); nb = C.c_int(0); bc = np.zeros(max_boxes, np.int32); nu = C.c_int(0)
+        self._ck(self.lib.mot_box_fit(self._h, _vp(a), n, _vp(grid), num_cluster, _vp(boxes), max_boxes, C.byref(nb), _vp(bc), C.byref(nu)))
+        return dict(boxes=boxes[: nb.value].copy(), box_cluster=bc[: nb.value].copy(), n_undefined=nu.value)
+
+    def ego_update(self, timestamp: float, v_gps: float, yaw_gps: float, slot: int = 0):
+        """getOriginPoints(timestamp, originPoints, v_gps, yaw_gps) — OT/include/imm_ukf_jpda.h:15"""
+        out = np.zeros(6)
+        self._ck(self.lib.mot_ego_update(self._h, slot, C.c_double(timestamp), C.c_double(v_gps), C.c_double(yaw_gps), _vp(out)))
+        return out
+
+    def track_step(self, boxes_global, timestamp: float, slot: int = 0, max_tracks: int | None = None):
+        """immUkfJpdaf(bBoxes, timestamp, ...) — OT/include/imm_ukf_jpda.h:19-22"""
+        b = np.ascontiguousarray(boxes_global, np.float32).reshape(-1, 8, 3)
+        max_tracks = max_tracks or self.max_tracks_total
+        arr = (MotTrack * max_tracks)(); nt = C.c_int(0)
+        self._ck(self.lib.mot_track_step(self._h, slot, _vp(b), len(b), C.c_double(timestamp), arr, max_tracks, C.byref(nt)))
+        return tracks_to_dict(arr, nt.value)
+
+    def track_state(self, track_id: int, slot: int = 0):
+        s = MotTrackState()
+        self._ck(self.lib.mot_track_get_state(self._h, slot, track_id, C.byref(s)))
+        return state_to_dict(s)
+
+    # ------------------------------------------------------------------ fused frames, device buffers
+    def frames_dev(self, d_ptr: int, frame_stride_floats: int, n_points, run_tracker: bool = False,
+                   timestamps=None, ego_v=None, ego_yaw=None):
+        """ground -> cluster -> box (-> tracker) for one frame per slot; everything stays in HBM. Asynchronous."""
+        n = np.ascontiguousarray(n_points, np.int32); B = len(n)
+        ts = np.ascontiguousarray(timestamps if timestamps is not None else np.zeros(B), np.float64)
+        ev = np.ascontiguousarray(ego_v if ego_v is not None else np.zeros(B), np.float64)
+        ey = np.ascontiguousarray(ego_yaw if ego_yaw is not None else np.zeros(B), np.float64)
+        self._ck(self.lib.mot_frames_dev(self._h, C.c_void_p(d_ptr), C.c_long(frame_stride_floats), _vp(n), B,
+                                         int(run_tracker), _vp(ts), _vp(ev), _vp(ey)))
+
+    def get_ground(self, slot: int = 0, n_hint: int | None = None, want_clouds: bool = True):
+        n = n_hint if n_hint is not None else self.max_points
+        elev = np.empty((max(n, 1), 4), np.float32) if want_clouds else None
+        ground = np.empty((max(n, 1), 4), np.float32) if want_clouds else None
+        mask = np.zeros(max(n, 1), np.uint8) if want_clouds else None
+        ne, ng = C.c_int(0), C.c_int(0)
+        self._ck(self.lib.mot_get_ground(self._h, slot, _vp(elev), C.byref(ne), _vp(ground), C.byref(ng), _vp(mask)))
+        out = dict(n_elevated=ne.value, n_ground=ng.value)
+        if want_clouds:
+            out.update(elevated=elev[: ne.value].copy(), ground=ground[: ng.value].copy(), mask=mask[:n].copy())
+        return out
+
+    def get_clusters(self, slot: int = 0, n_elevated: int = 0):
+        G = self.params.num_grid
+        grid = np.zeros((G, G), np.int32); nc = C.c_int(0); lab = np.zeros(max(n_elevated, 1), np.int32)
+        self._ck(self.lib.mot_get_clusters(self._h, slot, _vp(grid), C.byref(nc), _vp(lab) if n_elevated else None))
+        return dict(grid=grid, num_cluster=nc.value, point_label=lab[:n_elevated].copy())
+
+    def get_boxes(self, slot: int = 0, max_boxes: int = 4096):
+        boxes = np.zeros((max_boxes, 8, 3), np.float32); nb = C.c_int(0); bc = np.zeros(max_boxes, np.int32); nu = C.c_int(0)
+        self._ck(self.lib.mot_get_boxes(self._h, slot, _vp(boxes), max_boxes, C.byref(nb), _vp(bc), C.byref(nu)))
+        return dict(boxes=boxes[: nb.value].copy(), box_cluster=bc[: nb.value].copy(), n_undefined=nu.value)
+
+    def get_tracks(self, slot: int = 0, max_tracks: int | None = None):
+        max_tracks = max_tracks or self.max_tracks_total
+        arr = (MotTrack * max_tracks)(); nt = C.c_int(0)
+        self._ck(self.lib.mot_get_tracks(self._h, slot, arr, max_tracks, C.byref(nt)))
+        return tracks_to_dict(arr, nt.value)
+
+    def time_stage(self, stage: int, batch: int, iters: int) -> float:
+        """average ms per iteration of one stage re-run on resident data, HIP events on the context stream"""
+        ms = C.c_float(0)
+        self._ck(self.lib.mot_time_stage(self._h, stage, batch, iters, C.byref(ms)))
+        return ms.value
+
+
+def tracks_to_dict(arr, n):
+    buf = np.frombuffer(arr, dtype=np.dtype([("id", "i4"), ("track_manage", "i4"), ("is_static", "i4"), ("is_vis", "i4"),
+                                             ("p", "f4", 3), ("lifetime", "i4"), ("v_yaw", "f8", 2), ("vis_box", "f4", 24)]),
+                        count=n) if n else None
+    if n == 0:
+        return dict(n=0, track_manage=np.zeros(0, np.int32), is_static=np.zeros(0, np.int32), is_vis=np.zeros(0, np.int32),
+                    lifetime=np.zeros(0, np.int32), p=np.zeros((0, 3), np.float32), v_yaw=np.zeros((0, 2)), vis_box=np.zeros((0, 24), np.float32))
+    return dict(n=n, track_manage=buf["track_manage"].copy(), is_static=buf["is_static"].copy(), is_vis=buf["is_vis"].copy(),
+                lifetime=buf["lifetime"].copy(), p=buf["p"].copy(), v_yaw=buf["v_yaw"].copy(), vis_box=buf["vis_box"].copy())
+
+
+def state_to_dict(s: MotTrackState):
+    d = {}
+    for name, _ in MotTrackState._fields_:
+        v = getattr(s, name)
+        d[name] = np.array(v[:]) if hasattr(v, "__len__") else v
+    return d
+
+
+# ---------------------------------------------------------------------- reference-named convenience layer
+_default_ctx: Context | None = None
+
+
+def default_context() -> Context:
+    global _default_ctx
+    if _default_ctx is None:
+        _default_ctx = Context()
+    return _default_ctx
+
+
+def groundRemove(cloud):
+    """drop-in for groundRemove(); returns (elevatedCloud, groundCloud)"""
+    r = default_context().ground_remove(cloud, want_mask=False)
+    return r["elevated"], r["ground"]
+
+
+def componentClustering(elevatedCloud):
+    """drop-in for componentClustering(); returns (cartesianData, numCluster)"""
+    r = default_context().cluster(elevatedCloud)
+    return r["grid"], r["num_cluster"]
+
+
+def boxFitting(elevatedCloud, cartesianData, numCluster):
+    """drop-in for boxFitting(); returns the list of 8-corner boxes"""
+    return default_context().box_fit(elevatedCloud, cartesianData, numCluster)["boxes"]
+
+
+def getOriginPoints(timestamp, v_gps, yaw_gps):
+    return default_context().ego_update(timestamp, v_gps, yaw_gps).reshape(2, 3)
+
+
+def immUkfJpdaf(bBoxes, timestamp):
+    return default_context().track_step(bBoxes, timestamp)

@@ -1,0 +1,307 @@
+// ground.hip — polar-grid ground removal on gfx950 (MI355X). Product code (HIP, wave64).
+//
+// Replaces groundRemove() and everything it calls (OT/src/groundremove/ground_removal.cpp:46-249,
+// gaus_blur.cpp:26-68) for a BATCH of frames (one frame per sensor stream / slot):
+//
+//   K1 polar_minz_kernel        N pts  -> 9600 per-cell min z          (filterCloud + createAndMapPolarGrid)
+//   K2 polar_filter_kernel      9600   -> 9600 ground thresholds       (clamp, Gaussian, hDiff, decision, median, outlier)
+//   K3 classify_compact_kernel  N pts  -> elevated / ground clouds     (second loop of groundRemove, order preserving)
+//
+// HBM traffic per point: K1 reads 16 B, K3 reads 16 B and writes 16 B (+1 B mask) = 48(+1) B — the
+// algorithmic minimum of SURVEY.md §8d: the classification needs the complete grid, so the cloud has to
+// be read twice. The polar grid (38 KB per frame) lives in L2.
+//
+// Design notes (MI355X-first, not a translation of the CPU loops):
+//  * K1 has no LDS grid. Lidar clouds are beam-major, so the 64 points of a wave fall into 1–4 polar cells:
+//    the wave finds the distinct cells with ballot + readlane, min-reduces z per cell with a butterfly
+//    over the matching lanes, and ONE lane issues a fire-and-forget global atomic min per (wave, cell).
+//    That is fewer atomics than flushing a per-workgroup LDS grid would need, and no LDS zero/flush pass.
+//  * min z is kept as an order-preserving int key so the integer atomic min is exact.
+//  * K3 preserves input order (the reference push_backs in order and box fitting depends on it,
+//    SURVEY.md H9) with a single-pass chained scan: per-workgroup ballot/popcount ranks + a decoupled
+//    look-back over 8-byte {status,counts} descriptors (one relaxed agent-scope store / load each; chunk
+//    ids come from an atomic ticket so a predecessor is always already running).
+//  * all fp32/fp64 expressions keep the reference's operation order; build with -ffp-contract=off.
+#include "mot_internal.h"
+
+#ifndef MOT_HIPEMU
+#define MOT_LAUNCH_BOUNDS(n) __launch_bounds__(n)
+#else
+#define MOT_LAUNCH_BOUNDS(n)
+#endif
+
+__device__ __forceinline__ int wave_lane() { return (int)(threadIdx.x & 63); }
+
+__device__ __forceinline__ int wave_min_i32(int v) {
+#pragma unroll
+  for (int m = 32; m >= 1; m >>= 1) {
+    int o = __shfl_xor(v, m, 64);
+    v = o < v ? o : v;
+  }
+  return v;
+}
+
+// ------------------------------------------------------------------------------------------ K1
+// filterCloud (:46-64) + createAndMapPolarGrid (:79-92) + Cell::updateMinZ (:40-42)
+__global__ void MOT_LAUNCH_BOUNDS(kGroundBlock)
+polar_minz_kernel(MotDevParams p, GroundBuffers g) {
+  const int b = blockIdx.y;
+  const int n = g.n[b];
+  const long base = (long)blockIdx.x * kGroundChunk;
+  if (base >= n) return;  // whole workgroup leaves together
+  const float4* __restrict__ in = g.in + (long)b * g.in_stride;
+  int* __restrict__ minz = g.minz + (long)b * MOT_POLAR_CELLS;
+  const int lane = wave_lane();
+
+  float4 pt[kGroundItems];
+#pragma unroll
+  for (int k = 0; k < kGroundItems; k++) {
+    long i = base + k * kGroundBlock + threadIdx.x;
+    pt[k] = i < n ? in[i] : make_float4(0.f, 0.f, 0.f, 0.f);  // (0,0): r = 0 <= rMin -> no cell
+  }
+#pragma unroll
+  for (int k = 0; k < kGroundItems; k++) {
+    float x = pt[k].x, y = pt[k].y, z = pt[k].z;
+    int cell = mot_crop_keep(p, x, y, z) ? mot_polar_cell(p, x, y) : -1;
+    if (!(z == z)) cell = -1;                 // `z < minZ` is false for NaN: never updates
+    int key = mot_float_key(z + 0.0f);        // canonical +0
+    unsigned long long active = __ballot(cell >= 0);
+    while (active) {                          // wave-uniform loop: one trip per distinct cell in the wave
+      int leader = __ffsll(active) - 1;
+      int c = __shfl(cell, leader, 64);
+      bool mine = (cell == c);
+      int v = wave_min_i32(mine ? key : 0x7fffffff);
+      if (lane == leader) atomicMin(&minz[c], v);
+      active &= ~__ballot(mine);
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------ K2
+// one workgroup per frame; the 80 x 120 grid sits in LDS (4 x 38 KB arrays would not be needed: the
+// passes are fused so only height / ground flag / smoothed are kept).
+constexpr int kFilterBlock = 960;  // 9600 cells = 10 per thread
+__global__ void MOT_LAUNCH_BOUNDS(kFilterBlock)
+polar_filter_kernel(MotDevParams p, GroundBuffers g, int reset_minz) {
+  __shared__ float s_h[MOT_POLAR_CELLS];       // height
+  __shared__ float s_h2[MOT_POLAR_CELLS];      // height after the median pass
+  __shared__ unsigned char s_g[MOT_POLAR_CELLS];   // ground flag after decision
+  __shared__ unsigned char s_g2[MOT_POLAR_CELLS];  // ground flag after median
+  const int b = blockIdx.x;
+  int* __restrict__ minz = g.minz + (long)b * MOT_POLAR_CELLS;
+  float* __restrict__ hg = g.hg + (long)b * MOT_POLAR_CELLS;
+
+  // height clamp, ground_removal.cpp:191-197
+  for (int i = threadIdx.x; i < MOT_POLAR_CELLS; i += kFilterBlock) {
+    float zi = mot_key_float(minz[i]);
+    if (reset_minz) minz[i] = kMinzInit;  // leave the grid ready for the next frame
+    float h;
+    if (zi > p.t_hmin && zi < p.t_hmax) h = zi;
+    else if (zi > p.t_hmax) h = p.h_sensor;
+    else h = p.t_hmin;
+    s_h[i] = h;
+  }
+  __syncthreads();
+  // gaussSmoothen (gaus_blur.cpp:52-68), computeHDiffAdjacentCell (:95-117), decision (:205-213)
+  for (int i = threadIdx.x; i < MOT_POLAR_CELLS; i += kFilterBlock) {
+    int bin = i % MOT_NUM_BIN;
+    float h = s_h[i];
+    double sm = 0;
+    if (bin > 0) sm += p.gk[0] * (double)s_h[i - 1];
+    sm += p.gk[1] * (double)h;
+    if (bin < MOT_NUM_BIN - 1) sm += p.gk[2] * (double)s_h[i + 1];
+    float smoothed = (float)sm;
+    float hd;
+    if (bin == 0) hd = h - s_h[i + 1];
+    else if (bin == MOT_NUM_BIN - 1) hd = h - s_h[i - 1];
+    else {
+      float pre = h - s_h[i - 1], post = h - s_h[i + 1];
+      hd = pre > post ? pre : post;
+    }
+    bool ground = (smoothed < p.t_hmax && hd < p.t_hdiff) || (h < p.t_hmax && hd < p.t_hdiff);
+    s_g[i] = ground;
+  }
+  __syncthreads();
+  // applyMedianFilter (:120-146). Order independent: a cell flips only when its four
+  // neighbours are ground, so no flipped cell is an input of another flip.
+  for (int i = threadIdx.x; i < MOT_POLAR_CELLS; i += kFilterBlock) {
+    int ch = i / MOT_NUM_BIN, bin = i % MOT_NUM_BIN;
+    float h = s_h[i];
+    bool ground = s_g[i];
+    if (!ground && ch >= 1 && ch < MOT_NUM_CHANNEL - 1 && bin >= 1 && bin < MOT_NUM_BIN - 1 &&
+        s_g[i + 1] && s_g[i - 1] && s_g[i + MOT_NUM_BIN] && s_g[i - MOT_NUM_BIN]) {
+      float a = s_h[i + 1], bb = s_h[i - 1], c = s_h[i + MOT_NUM_BIN], d = s_h[i - MOT_NUM_BIN];
+      // middle two of four = sort()[1], sort()[2]
+      float lo1 = a < bb ? a : bb, hi1 = a < bb ? bb : a;
+      float lo2 = c < d ? c : d, hi2 = c < d ? d : c;
+      float m1 = lo1 > lo2 ? lo1 : lo2;   // larger of the two minima
+      float m2 = hi1 < hi2 ? hi1 : hi2;   // smaller of the two maxima
+      float s1 = m1 < m2 ? m1 : m2, s2 = m1 < m2 ? m2 : m1;
+      h = (s1 + s2) / 2;
+      ground = true;
+    }
+    s_h2[i] = h;
+    s_g2[i] = ground;
+  }
+  __syncthreads();
+  // outlierFilter (:149-174). In-place left-to-right in the reference => a one-step dependency inside a
+  // run of exactly two tHmin cells; evaluated here in closed form on the pre-pass values.
+  for (int i = threadIdx.x; i < MOT_POLAR_CELLS; i += kFilterBlock) {
+    int ch = i / MOT_NUM_BIN, bin = i % MOT_NUM_BIN;
+    float h = s_h2[i];
+    bool ground = s_g2[i];
+    const float T = p.t_hmin;
+    if (ch >= 1 && ch < MOT_NUM_CHANNEL - 1 && bin >= 1 && bin < MOT_NUM_BIN - 2 && h == T &&
+        ground && s_g2[i + 1] && s_g2[i - 1] && s_g2[i + 2]) {
+      float hm1 = s_h2[i - 1], h3 = s_h2[i + 1], h4 = s_h2[i + 2];
+      float h1 = hm1;  // value of cell bin-1 at the time the reference reaches this cell
+      if (hm1 == T && bin - 1 >= 1 && s_g2[i - 2]) {
+        // cell bin-1 may have been rewritten by its own step (flags of bin-2..bin+1 are all set here)
+        float hm2 = s_h2[i - 2];
+        if (hm2 != T) {
+          if (h != T) h1 = (hm2 + h) / 2;                  // case 1 at bin-1 (cannot happen: h == T)
+          else if (h3 != T) h1 = (hm2 + h3) / 2;           // case 2 at bin-1: h3'==T (this cell), h4' = h3
+        }
+      }
+      if (h1 != T && h3 != T) h = (h1 + h3) / 2;
+      else if (h1 != T && h3 == T && h4 != T) h = (h1 + h4) / 2;
+    }
+    hg[i] = ground ? h : -INFINITY;
+  }
+}
+
+// ------------------------------------------------------------------------------------------ K3
+// per-point classification (ground_removal.cpp:221-247) + order-preserving compaction
+__global__ void MOT_LAUNCH_BOUNDS(kGroundBlock)
+classify_compact_kernel(MotDevParams p, GroundBuffers g) {
+  __shared__ int s_chunk;
+  __shared__ int s_cnt_e[kSubTiles], s_cnt_g[kSubTiles];  // per 64-point tile counts -> exclusive prefixes
+  __shared__ int s_base_e, s_base_g;
+  const int b = blockIdx.y;
+  const int n = g.n[b];
+  const int nchunks = (n + kGroundChunk - 1) / kGroundChunk;
+  if ((int)blockIdx.x >= nchunks) {
+    if (nchunks == 0 && blockIdx.x == 0 && threadIdx.x == 0) { g.counts[b * 4 + 0] = 0; g.counts[b * 4 + 1] = 0; g.counts[b * 4 + 2] = 0; }
+    return;
+  }
+  if (threadIdx.x == 0) {
+    int t = atomicAdd(&g.ticket[b], 1);      // chunk id in arrival order: every predecessor is already running
+    if (t == nchunks - 1) g.ticket[b] = 0;   // last ticket of this frame: re-arm for the next launch
+    s_chunk = t;
+  }
+  __syncthreads();
+  const int chunk = s_chunk;
+  const long base = (long)chunk * kGroundChunk;
+  const float4* __restrict__ in = g.in + (long)b * g.in_stride;
+  const float* __restrict__ hg = g.hg + (long)b * MOT_POLAR_CELLS;
+  const int lane = wave_lane(), wave = threadIdx.x >> 6;
+
+  float4 pt[kGroundItems];
+  int cls[kGroundItems];    // MOT_MASK_*
+  int rank[kGroundItems];   // rank inside the 64-point tile, among points of the same class
+#pragma unroll
+  for (int k = 0; k < kGroundItems; k++) {
+    long i = base + k * kGroundBlock + threadIdx.x;
+    pt[k] = i < n ? in[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+  }
+#pragma unroll
+  for (int k = 0; k < kGroundItems; k++) {
+    float x = pt[k].x, y = pt[k].y, z = pt[k].z;
+    int cell = mot_crop_keep(p, x, y, z) ? mot_polar_cell(p, x, y) : -1;
+    int c = MOT_MASK_DROPPED;
+    if (cell >= 0) {
+      float hGround = hg[cell];  // -inf when the cell is not ground
+      c = ((double)z < (double)hGround + p.ground_margin) ? MOT_MASK_GROUND : MOT_MASK_ELEVATED;
+    }
+    cls[k] = c;
+    unsigned long long be = __ballot(c == MOT_MASK_ELEVATED);
+    unsigned long long bg = __ballot(c == MOT_MASK_GROUND);
+    unsigned long long below = (1ull << lane) - 1ull;
+    rank[k] = __popcll((c == MOT_MASK_ELEVATED ? be : bg) & below);
+    if (lane == 0) {
+      s_cnt_e[k * 4 + wave] = __popcll(be);   // tile order inside the chunk: k-major, then wave
+      s_cnt_g[k * 4 + wave] = __popcll(bg);
+    }
+  }
+  __syncthreads();
+  if (wave == 0) {
+    // exclusive scan of the 32 tile counts (lanes >= 32 idle) and the chunk totals
+    int ce = lane < kSubTiles ? s_cnt_e[lane] : 0, cg = lane < kSubTiles ? s_cnt_g[lane] : 0;
+    int ie = ce, ig = cg;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+      int oe = __shfl_up(ie, d, 64), og = __shfl_up(ig, d, 64);
+      if (lane >= d) { ie += oe; ig += og; }
+    }
+    int tot_e = __shfl(ie, 63, 64), tot_g = __shfl(ig, 63, 64);
+    if (lane < kSubTiles) { s_cnt_e[lane] = ie - ce; s_cnt_g[lane] = ig - cg; }
+    // decoupled look-back over the chunks of THIS frame
+    unsigned long long* desc = g.desc + (long)b * g.max_chunks;
+    const unsigned long long ep = (unsigned long long)(g.epoch & kDescEpochMask) << kDescEpochShift;
+    unsigned long long mine = ep | ((unsigned long long)(unsigned)tot_e << kDescCountBits) | (unsigned long long)(unsigned)tot_g;
+    long excl_e = 0, excl_g = 0;
+    if (chunk > 0) {
+      if (lane == 0) __hip_atomic_store(&desc[chunk], kDescAggregate | mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      int win_end = chunk;  // exclusive
+      while (true) {        // wave-uniform
+        int idx = win_end - 1 - lane;
+        unsigned long long d = kDescPrefix | ep;  // lanes before chunk 0 behave as an empty prefix
+        if (idx >= 0) {
+          while (true) {
+            d = __hip_atomic_load(&desc[idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (((d >> kDescEpochShift) & kDescEpochMask) == (g.epoch & kDescEpochMask) && (d >> 62) != 0) break;
+            __builtin_amdgcn_s_sleep(1);
+          }
+        }
+        unsigned long long is_prefix = __ballot((d >> 62) == 2);
+        int first = __ffsll(is_prefix) - 1;          // nearest predecessor holding an inclusive prefix
+        bool take = first < 0 || lane <= first;
+        long ve = take ? (long)((d >> kDescCountBits) & kDescCountMask) : 0, vg = take ? (long)(d & kDescCountMask) : 0;
+#pragma unroll
+        for (int m = 32; m >= 1; m >>= 1) { ve += __shfl_xor(ve, m, 64); vg += __shfl_xor(vg, m, 64); }
+        excl_e += ve; excl_g += vg;
+        if (first >= 0) break;
+        win_end -= 64;
+      }
+    }
+    if (lane == 0) {
+      unsigned long long incl = ep | ((unsigned long long)(excl_e + tot_e) << kDescCountBits) | (unsigned long long)(excl_g + tot_g);
+      __hip_atomic_store(&desc[chunk], kDescPrefix | incl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      s_base_e = (int)excl_e; s_base_g = (int)excl_g;
+      if (chunk == nchunks - 1) {
+        int ne = (int)excl_e + tot_e, ng = (int)excl_g + tot_g;
+        g.counts[b * 4 + 0] = ne; g.counts[b * 4 + 1] = ng; g.counts[b * 4 + 2] = n - ne - ng;
+      }
+    }
+  }
+  __syncthreads();
+  float4* __restrict__ out_e = g.elevated + (long)b * g.cap;
+  float4* __restrict__ out_g = g.ground + (long)b * g.cap;
+  uint8_t* __restrict__ mask = g.mask ? g.mask + (long)b * g.cap : nullptr;
+  const int be0 = s_base_e, bg0 = s_base_g;
+#pragma unroll
+  for (int k = 0; k < kGroundItems; k++) {
+    long i = base + k * kGroundBlock + threadIdx.x;
+    int t = k * 4 + wave;
+    if (cls[k] == MOT_MASK_ELEVATED) out_e[be0 + s_cnt_e[t] + rank[k]] = pt[k];
+    else if (cls[k] == MOT_MASK_GROUND) out_g[bg0 + s_cnt_g[t] + rank[k]] = pt[k];
+    if (mask && i < n) mask[i] = (uint8_t)cls[k];
+  }
+}
+
+// ------------------------------------------------------------------------------------------ host
+void mot_launch_ground_kernel(int which, const MotDevParams& p, const GroundBuffers& g, int batch, int max_n,
+                              hipStream_t stream) {
+  int chunks = (max_n + kGroundChunk - 1) / kGroundChunk;
+  if (chunks < 1) chunks = 1;
+  if (which == 0) hipLaunchKernelGGL(polar_minz_kernel, dim3(chunks, batch), dim3(kGroundBlock), 0, stream, p, g);
+  else if (which == 1) hipLaunchKernelGGL(polar_filter_kernel, dim3(batch), dim3(kFilterBlock), 0, stream, p, g, 1);
+  else if (which == 2) hipLaunchKernelGGL(classify_compact_kernel, dim3(chunks, batch), dim3(kGroundBlock), 0, stream, p, g);
+  else if (which == 3) hipLaunchKernelGGL(polar_filter_kernel, dim3(batch), dim3(kFilterBlock), 0, stream, p, g, 0);
+}
+
+void mot_launch_ground(const MotDevParams& p, const GroundBuffers& g, int batch, int max_n, hipStream_t stream) {
+  mot_launch_ground_kernel(0, p, g, batch, max_n, stream);
+  mot_launch_ground_kernel(1, p, g, batch, max_n, stream);
+  mot_launch_ground_kernel(2, p, g, batch, max_n, stream);
+}

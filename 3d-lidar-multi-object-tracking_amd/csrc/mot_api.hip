@@ -1,0 +1,325 @@
+// mot_api.hip — host side of the C-ABI declared in include/mot.h. Product code.
+// Owns the device buffers, the HIP stream and the launch sequences. There is no CPU fallback:
+// mot_create() fails with MOT_E_HIP when no HIP device is present.
+#include "mot_internal.h"
+
+#include <math.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <string>
+#include <vector>
+
+struct mot_ctx {
+  mot_params params;
+  MotDevParams dp;
+  int device = 0;
+  int cap = 0;        // points per frame
+  int batch = 0;      // slots
+  int max_tracks_total = 0;
+  hipStream_t stream = nullptr;
+  std::string err;
+  // ground stage
+  float4* d_in = nullptr;
+  int* d_n = nullptr;
+  int* d_minz = nullptr;
+  float* d_hg = nullptr;
+  unsigned long long* d_desc = nullptr;
+  int* d_ticket = nullptr;
+  float4* d_elev = nullptr;
+  float4* d_ground = nullptr;
+  uint8_t* d_mask = nullptr;
+  int* d_counts = nullptr;
+  int max_chunks = 0;
+  unsigned epoch = 0;
+  // host mirrors
+  std::vector<int> h_n;
+  int* h_counts = nullptr;  // pinned [batch][4]
+  int last_batch = 0, last_max_n = 0;
+  const float4* last_in = nullptr;
+  long last_in_stride = 0;
+  hipEvent_t ev0 = nullptr, ev1 = nullptr;
+};
+
+#define MOT_HIP(ctx, call)                                                                     \
+  do {                                                                                         \
+    hipError_t e_ = (call);                                                                    \
+    if (e_ != hipSuccess) {                                                                    \
+      (ctx)->err = std::string(#call) + ": " + hipGetErrorString(e_);                          \
+      return MOT_E_HIP;                                                                        \
+    }                                                                                          \
+  } while (0)
+
+static int fail(mot_ctx* c, int code, const char* msg) { if (c) c->err = msg; return code; }
+
+extern "C" int mot_abi_version(void) { return MOT_ABI_VERSION; }
+
+// constants of the two reference packages; file:line in include/mot.h
+extern "C" int mot_params_preset(int preset, mot_params* o) {
+  if (!o) return MOT_E_ARG;
+  if (preset != MOT_PRESET_OBJECT_TRACKING && preset != MOT_PRESET_OBJECT_TRACKING0) return MOT_E_ARG;
+  const bool kitti = preset == MOT_PRESET_OBJECT_TRACKING0;
+  memset(o, 0, sizeof *o);
+  o->r_min = 3.4f; o->r_max = 120.f;
+  o->t_hmin = kitti ? -1.9f : -2.0f;
+  o->t_hmax = kitti ? -1.0f : -0.4f;
+  o->t_hdiff = 0.4f;
+  o->h_sensor = kitti ? 1.73f : 2.0f;
+  o->ground_margin = 0.25; o->gauss_sigma = 1.0; o->gauss_samples = 3;
+  o->crop_enable = 0;
+  o->crop_z_min = -3.0f; o->crop_z_max = 1.0f; o->crop_x_min = -15.f; o->crop_x_max = 5.f;
+  o->crop_y_min = -50.f; o->crop_y_max = 50.f;
+  o->num_grid = kitti ? 200 : 250;
+  o->roi_m = kitti ? 30.f : 50.f;
+  o->occ_min_count = kitti ? 1 : 2;
+  o->dilate = kitti ? 0 : 1;
+  o->pic_scale = 900 / o->roi_m;
+  o->ram_points = 80;
+  o->l_slope_dist = kitti ? 3 : 1;
+  o->l_num_points = kitti ? 300 : 5;
+  o->lshape_side_cond = kitti ? 0 : 1;
+  o->sensor_height = kitti ? 1.73f : 2.0f;
+  o->t_height_min = kitti ? 1.0f : 0.8f; o->t_height_max = 2.6f;
+  o->t_width_min = kitti ? 0.25f : 0.2f; o->t_width_max = 3.5f;
+  o->t_len_min = kitti ? 0.5f : 0.2f; o->t_len_max = 14.0f;
+  o->t_area_max = 20.0f;
+  o->t_ratio_min = kitti ? 1.3f : 1.0f; o->t_ratio_max = kitti ? 5.0f : 8.0f;
+  o->min_len_ratio = 3.0f; o->t_pt_per_m3 = 8.0f;
+  o->min_points = kitti ? 100 : 30;
+  o->gamma_g = 9.22; o->p_g = 0.99; o->p_d = 0.9;
+  o->distance_thres = kitti ? 0.25 : 99.0;
+  o->life_time_thres = kitti ? 8 : 3;
+  o->seed_box_index = kitti ? 10 : 1;
+  o->bb_yaw_change_thres = 0.2;
+  o->first_ego_yaw_offset = (kitti ? 1.22191 : -0.63035) - M_PI / 2;
+  o->seed_px = -1.5125; o->seed_py = -8.975;
+  return MOT_OK;
+}
+
+static int make_dev_params(const mot_params& p, MotDevParams* d, std::string* err) {
+  if (p.gauss_samples != 3) { *err = "gauss_samples must be 3"; return MOT_E_ARG; }
+  if (p.num_grid < 8 || p.num_grid > MOT_MAX_GRID) { *err = "num_grid out of range"; return MOT_E_ARG; }
+  memset(d, 0, sizeof *d);
+  d->r_min = p.r_min; d->r_max = p.r_max; d->r_span = p.r_max - p.r_min;
+  d->t_hmin = p.t_hmin; d->t_hmax = p.t_hmax; d->t_hdiff = p.t_hdiff; d->h_sensor = p.h_sensor;
+  d->ground_margin = p.ground_margin;
+  {  // gaussKernel(samples=3, sigma), gaus_blur.cpp:26-49 — host libm, exactly as the reference evaluates it
+    int samples = p.gauss_samples;
+    double sigma = p.gauss_sigma;
+    double mean = samples / 2;  // integer division
+    double sum = 0.0, k[3];
+    for (int x = 0; x < samples; ++x) {
+      k[x] = exp(-0.5 * (pow((x - mean) / sigma, 2.0))) / (2 * M_PI * sigma * sigma);
+      sum += k[x];
+    }
+    for (int x = 0; x < samples; ++x) d->gk[x] = k[x] / sum;
+  }
+  d->crop_enable = p.crop_enable;
+  d->crop_z_min = p.crop_z_min; d->crop_z_max = p.crop_z_max; d->crop_x_min = p.crop_x_min;
+  d->crop_x_max = p.crop_x_max; d->crop_y_min = p.crop_y_min; d->crop_y_max = p.crop_y_max;
+  d->num_grid = p.num_grid; d->occ_min_count = p.occ_min_count; d->dilate = p.dilate;
+  d->roi_m = p.roi_m; d->roi_half = p.roi_m / 2;
+  d->pic_scale = p.pic_scale; d->pic_full = p.pic_scale * p.roi_m; d->pic_half = p.roi_m * p.pic_scale / 2;
+  d->ram_points = p.ram_points; d->l_slope_dist = p.l_slope_dist; d->l_num_points = p.l_num_points;
+  d->lshape_side_cond = p.lshape_side_cond; d->min_points = p.min_points; d->sensor_height = p.sensor_height;
+  d->t_height_min = p.t_height_min; d->t_height_max = p.t_height_max; d->t_width_min = p.t_width_min;
+  d->t_width_max = p.t_width_max; d->t_len_min = p.t_len_min; d->t_len_max = p.t_len_max;
+  d->t_area_max = p.t_area_max; d->t_ratio_min = p.t_ratio_min; d->t_ratio_max = p.t_ratio_max;
+  d->min_len_ratio = p.min_len_ratio; d->t_pt_per_m3 = p.t_pt_per_m3;
+  return MOT_OK;
+}
+
+extern "C" void mot_destroy(mot_ctx* c) {
+  if (!c) return;
+  void* bufs[] = {c->d_in, c->d_n, c->d_minz, c->d_hg, c->d_desc, c->d_ticket, c->d_elev, c->d_ground, c->d_mask, c->d_counts};
+  for (void* b : bufs) if (b) (void)hipFree(b);
+  if (c->h_counts) (void)hipHostFree(c->h_counts);
+  if (c->ev0) (void)hipEventDestroy(c->ev0);
+  if (c->ev1) (void)hipEventDestroy(c->ev1);
+  if (c->stream) (void)hipStreamDestroy(c->stream);
+  delete c;
+}
+
+static int create_impl(mot_ctx* c) {
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return fail(c, MOT_E_HIP, "no HIP device: this library has no CPU fallback");
+  if (c->device < 0 || c->device >= ndev) return fail(c, MOT_E_ARG, "device ordinal out of range");
+  MOT_HIP(c, hipSetDevice(c->device));
+  MOT_HIP(c, hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+  MOT_HIP(c, hipEventCreate(&c->ev0));
+  MOT_HIP(c, hipEventCreate(&c->ev1));
+  const size_t B = c->batch, N = c->cap;
+  c->max_chunks = (int)((N + kGroundChunk - 1) / kGroundChunk) + 1;
+  MOT_HIP(c, hipMalloc(&c->d_in, B * N * sizeof(float4)));
+  MOT_HIP(c, hipMalloc(&c->d_n, B * sizeof(int)));
+  MOT_HIP(c, hipMalloc(&c->d_minz, B * MOT_POLAR_CELLS * sizeof(int)));
+  MOT_HIP(c, hipMalloc(&c->d_hg, B * MOT_POLAR_CELLS * sizeof(float)));
+  MOT_HIP(c, hipMalloc(&c->d_desc, B * c->max_chunks * sizeof(unsigned long long)));
+  MOT_HIP(c, hipMalloc(&c->d_ticket, B * sizeof(int)));
+  MOT_HIP(c, hipMalloc(&c->d_elev, B * N * sizeof(float4)));
+  MOT_HIP(c, hipMalloc(&c->d_ground, B * N * sizeof(float4)));
+  MOT_HIP(c, hipMalloc(&c->d_mask, B * N));
+  MOT_HIP(c, hipMalloc(&c->d_counts, B * 4 * sizeof(int)));
+  MOT_HIP(c, hipHostMalloc(&c->h_counts, B * 4 * sizeof(int), hipHostMallocDefault));
+  MOT_HIP(c, hipMemsetD32Async(c->d_minz, kMinzInit, B * MOT_POLAR_CELLS, c->stream));
+  MOT_HIP(c, hipMemsetAsync(c->d_counts, 0, B * 4 * sizeof(int), c->stream));
+  MOT_HIP(c, hipMemsetAsync(c->d_n, 0, B * sizeof(int), c->stream));
+  MOT_HIP(c, hipMemsetAsync(c->d_ticket, 0, B * sizeof(int), c->stream));
+  MOT_HIP(c, hipMemsetAsync(c->d_desc, 0, B * c->max_chunks * sizeof(unsigned long long), c->stream));
+  MOT_HIP(c, hipStreamSynchronize(c->stream));
+  c->h_n.assign(B, 0);
+  return MOT_OK;
+}
+
+extern "C" int mot_create(const mot_params* params, int device, int max_points, int max_batch, int max_tracks_total,
+                          mot_ctx** out) {
+  if (!params || !out || max_points < 1 || max_points > kMaxPointsPerFrame || max_batch < 1 || max_tracks_total < 1) return MOT_E_ARG;
+  *out = nullptr;
+  mot_ctx* c = new mot_ctx();
+  c->params = *params; c->device = device; c->cap = max_points; c->batch = max_batch;
+  c->max_tracks_total = max_tracks_total;
+  int rc = make_dev_params(c->params, &c->dp, &c->err);
+  if (rc == MOT_OK) rc = create_impl(c);
+  if (rc != MOT_OK) {
+    fprintf(stderr, "mot_create failed: %s\n", c->err.c_str());
+    mot_destroy(c);
+    return rc;
+  }
+  *out = c;
+  return MOT_OK;
+}
+
+extern "C" const char* mot_last_error(const mot_ctx* c) { return c ? c->err.c_str() : "null context"; }
+extern "C" void* mot_stream(mot_ctx* c) { return c ? (void*)c->stream : nullptr; }
+extern "C" int mot_synchronize(mot_ctx* c) {
+  if (!c) return MOT_E_ARG;
+  MOT_HIP(c, hipStreamSynchronize(c->stream));
+  return MOT_OK;
+}
+extern "C" int mot_reset(mot_ctx* c) {
+  if (!c) return MOT_E_ARG;
+  return MOT_OK;
+}
+
+// every launch of the compaction kernel gets a fresh epoch; on wrap-around the descriptors are cleared so a
+// 2^20-launches-old descriptor can never be mistaken for a current one
+static int next_epoch(mot_ctx* c) {
+  c->epoch++;
+  if (c->epoch > kDescEpochMask) {
+    MOT_HIP(c, hipMemsetAsync(c->d_desc, 0, (size_t)c->batch * c->max_chunks * sizeof(unsigned long long), c->stream));
+    c->epoch = 1;
+  }
+  return MOT_OK;
+}
+
+static GroundBuffers ground_buffers(mot_ctx* c, const float4* in, long stride, bool want_mask) {
+  GroundBuffers g;
+  g.epoch = c->epoch;
+  g.in = in; g.in_stride = stride; g.n = c->d_n; g.minz = c->d_minz; g.hg = c->d_hg; g.desc = c->d_desc;
+  g.ticket = c->d_ticket; g.elevated = c->d_elev; g.ground = c->d_ground; g.mask = want_mask ? c->d_mask : nullptr;
+  g.counts = c->d_counts; g.cap = c->cap; g.max_chunks = c->max_chunks;
+  return g;
+}
+
+// uploads n[] and remembers the launch geometry
+static int set_batch(mot_ctx* c, const int* n_points, int batch, const float4* in, long stride) {
+  if (batch < 1 || batch > c->batch) return fail(c, MOT_E_ARG, "batch out of range");
+  int max_n = 0;
+  for (int b = 0; b < batch; b++) {
+    if (n_points[b] < 0) return fail(c, MOT_E_ARG, "negative point count");
+    if (n_points[b] > c->cap) return fail(c, MOT_E_CAPACITY, "frame has more points than max_points");
+    c->h_n[b] = n_points[b];
+    if (n_points[b] > max_n) max_n = n_points[b];
+  }
+  MOT_HIP(c, hipMemcpyAsync(c->d_n, c->h_n.data(), batch * sizeof(int), hipMemcpyHostToDevice, c->stream));
+  c->last_batch = batch; c->last_max_n = max_n; c->last_in = in; c->last_in_stride = stride;
+  return MOT_OK;
+}
+
+extern "C" int mot_frames_dev(mot_ctx* c, const float* d_xyzw, long frame_stride, const int* n_points, int batch,
+                              int run_tracker, const double* timestamps, const double* ego_v, const double* ego_yaw) {
+  if (!c || !d_xyzw || !n_points) return MOT_E_ARG;
+  if (frame_stride % 4) return fail(c, MOT_E_ARG, "frame_stride must be a multiple of 4 floats");
+  int rc = set_batch(c, n_points, batch, (const float4*)d_xyzw, frame_stride / 4);
+  if (rc) return rc;
+  if ((rc = next_epoch(c))) return rc;
+  GroundBuffers g = ground_buffers(c, c->last_in, c->last_in_stride, true);
+  mot_launch_ground(c->dp, g, batch, c->last_max_n, c->stream);
+  MOT_HIP(c, hipGetLastError());
+  (void)run_tracker; (void)timestamps; (void)ego_v; (void)ego_yaw;
+  return MOT_OK;
+}
+
+extern "C" int mot_get_ground(mot_ctx* c, int slot, float* elev, int* n_elev, float* ground, int* n_ground,
+                              uint8_t* mask) {
+  if (!c || slot < 0 || slot >= c->batch) return MOT_E_ARG;
+  MOT_HIP(c, hipMemcpyAsync(c->h_counts + slot * 4, c->d_counts + slot * 4, 4 * sizeof(int), hipMemcpyDeviceToHost, c->stream));
+  MOT_HIP(c, hipStreamSynchronize(c->stream));
+  int ne = c->h_counts[slot * 4 + 0], ng = c->h_counts[slot * 4 + 1];
+  if (n_elev) *n_elev = ne;
+  if (n_ground) *n_ground = ng;
+  if (elev && ne > 0) MOT_HIP(c, hipMemcpyAsync(elev, c->d_elev + (size_t)slot * c->cap, (size_t)ne * 16, hipMemcpyDeviceToHost, c->stream));
+  if (ground && ng > 0) MOT_HIP(c, hipMemcpyAsync(ground, c->d_ground + (size_t)slot * c->cap, (size_t)ng * 16, hipMemcpyDeviceToHost, c->stream));
+  if (mask && c->h_n[slot] > 0) MOT_HIP(c, hipMemcpyAsync(mask, c->d_mask + (size_t)slot * c->cap, (size_t)c->h_n[slot], hipMemcpyDeviceToHost, c->stream));
+  MOT_HIP(c, hipStreamSynchronize(c->stream));
+  return MOT_OK;
+}
+
+extern "C" int mot_ground_remove(mot_ctx* c, const float* xyzw, int n, float* elev, int* n_elev, float* ground,
+                                 int* n_ground, uint8_t* mask) {
+  if (!c || (!xyzw && n > 0) || n < 0) return MOT_E_ARG;
+  if (n > c->cap) return fail(c, MOT_E_CAPACITY, "frame has more points than max_points");
+  if (n > 0) MOT_HIP(c, hipMemcpyAsync(c->d_in, xyzw, (size_t)n * 16, hipMemcpyHostToDevice, c->stream));
+  int rc = set_batch(c, &n, 1, c->d_in, c->cap);
+  if (rc) return rc;
+  if ((rc = next_epoch(c))) return rc;
+  GroundBuffers g = ground_buffers(c, c->d_in, c->cap, true);
+  mot_launch_ground(c->dp, g, 1, n, c->stream);
+  MOT_HIP(c, hipGetLastError());
+  return mot_get_ground(c, 0, elev, n_elev, ground, n_ground, mask);
+}
+
+extern "C" int mot_time_stage(mot_ctx* c, int stage, int batch, int iters, float* ms_per_iter) {
+  if (!c || !ms_per_iter || iters < 1) return MOT_E_ARG;
+  if (!c->last_in || batch != c->last_batch) return fail(c, MOT_E_STATE, "call mot_frames_dev with the same batch first");
+  if (!(stage == 0 || (stage >= 10 && stage <= 12))) return fail(c, MOT_E_ARG, "unknown stage");
+  int rc;
+  // kernels are idempotent on resident data: K1 re-accumulates the same minima, K2 (without the min-z
+  // reset) recomputes the same thresholds, K3 re-draws tickets under a fresh epoch.
+  MOT_HIP(c, hipEventRecord(c->ev0, c->stream));
+  for (int it = 0; it < iters; it++) {
+    if ((rc = next_epoch(c))) return rc;
+    GroundBuffers g = ground_buffers(c, c->last_in, c->last_in_stride, true);
+    if (stage == 0) mot_launch_ground(c->dp, g, batch, c->last_max_n, c->stream);
+    else if (stage == 10) mot_launch_ground_kernel(0, c->dp, g, batch, c->last_max_n, c->stream);
+    else if (stage == 11) mot_launch_ground_kernel(3, c->dp, g, batch, c->last_max_n, c->stream);
+    else mot_launch_ground_kernel(2, c->dp, g, batch, c->last_max_n, c->stream);
+  }
+  MOT_HIP(c, hipEventRecord(c->ev1, c->stream));
+  MOT_HIP(c, hipEventSynchronize(c->ev1));
+  float ms = 0;
+  MOT_HIP(c, hipEventElapsedTime(&ms, c->ev0, c->ev1));
+  *ms_per_iter = ms / iters;
+  if (stage == 10 || stage == 11) {  // restore the invariant "min-z grid is all-initial between calls" and the thresholds
+    if ((rc = next_epoch(c))) return rc;
+    GroundBuffers g = ground_buffers(c, c->last_in, c->last_in_stride, true);
+    if (stage == 11) mot_launch_ground_kernel(0, c->dp, g, batch, c->last_max_n, c->stream);
+    mot_launch_ground_kernel(1, c->dp, g, batch, c->last_max_n, c->stream);
+    mot_launch_ground_kernel(2, c->dp, g, batch, c->last_max_n, c->stream);
+    MOT_HIP(c, hipStreamSynchronize(c->stream));
+  }
+  MOT_HIP(c, hipGetLastError());
+  return MOT_OK;
+}
+
+// ---- entry points whose device stages are still being brought up (round 1, in order: cluster, box, tracker).
+// They fail loudly; nothing falls back to a CPU path.
+#define MOT_PENDING(c, what) return fail((c), MOT_E_STATE, what " is not built yet in this revision")
+extern "C" int mot_cluster(mot_ctx* c, const float*, int, int32_t*, int*, int32_t*) { if (!c) return MOT_E_ARG; MOT_PENDING(c, "mot_cluster"); }
+extern "C" int mot_box_fit(mot_ctx* c, const float*, int, const int32_t*, int, float*, int, int*, int32_t*, int*) { if (!c) return MOT_E_ARG; MOT_PENDING(c, "mot_box_fit"); }
+extern "C" int mot_ego_update(mot_ctx* c, int, double, double, double, double*) { if (!c) return MOT_E_ARG; MOT_PENDING(c, "mot_ego_update"); }
+extern "C" int mot_track_step(mot_ctx* c, int, const float*, int, double, mot_track*, int, int*) { if (!c) return MOT_E_ARG; MOT_PENDING(c, "mot_track_step"); }
+extern "C" int mot_track_get_state(mot_ctx* c, int, int, mot_track_state*) { if (!c) return MOT_E_ARG; MOT_PENDING(c, "mot_track_get_state"); }
+extern "C" int mot_get_clusters(mot_ctx* c, int, int32_t*, int*, int32_t*) { if (!c) return MOT_E_ARG; MOT_PENDING(c, "mot_get_clusters"); }
+extern "C" int mot_get_boxes(mot_ctx* c, int, float*, int, int*, int32_t*, int*) { if (!c) return MOT_E_ARG; MOT_PENDING(c, "mot_get_boxes"); }
+extern "C" int mot_get_tracks(mot_ctx* c, int, mot_track*, int, int*) { if (!c) return MOT_E_ARG; MOT_PENDING(c, "mot_get_tracks"); }

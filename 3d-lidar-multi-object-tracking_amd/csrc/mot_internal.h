@@ -1,0 +1,101 @@
+// mot_internal.h — shared between the HIP kernels (*.hip) and the host side of the C-ABI (mot_api.hip).
+// Product code. No oracle code is included or linked here.
+#ifndef MOT_INTERNAL_H_
+#define MOT_INTERNAL_H_
+
+#ifndef MOT_HIPEMU
+#include <hip/hip_runtime.h>
+#endif
+#include <stdint.h>
+#include "../../include/mot.h"
+#include "mot_math.h"
+
+// ---- geometry of the launches --------------------------------------------------------------
+constexpr int kGroundBlock = 256;                 // threads per workgroup (4 waves)
+constexpr int kGroundItems = 8;                   // points per thread
+constexpr int kGroundChunk = kGroundBlock * kGroundItems;  // 2048 points = 32 KB per workgroup
+constexpr int kSubTiles = kGroundChunk / 64;      // 64-point wave tiles per chunk (32)
+constexpr int kMinzInit = 0x447A0000;             // ordered key of 1000.0f (Cell::Cell, ground_removal.cpp:35-38)
+
+// descriptor word of the decoupled look-back in the compaction kernel (one 8-byte granule, written
+// by ONE store and read by ONE load, so it can never be seen torn):
+//   [63:62] status 1 = chunk aggregate, 2 = inclusive prefix
+//   [61:42] launch epoch (a descriptor whose epoch is not the current one is "not ready": no reset pass)
+//   [41:21] elevated count, [20:0] ground count   (frames of up to 2^21-1 points)
+constexpr int kDescCountBits = 21;
+constexpr unsigned long long kDescCountMask = (1ull << kDescCountBits) - 1;
+constexpr int kDescEpochShift = 42;
+constexpr unsigned kDescEpochMask = (1u << 20) - 1;
+constexpr unsigned long long kDescAggregate = 1ull << 62;
+constexpr unsigned long long kDescPrefix = 2ull << 62;
+constexpr int kMaxPointsPerFrame = (1 << kDescCountBits) - 1;
+
+// parameters as the kernels want them (floats pre-combined exactly as the reference combines them)
+struct MotDevParams {
+  float r_min, r_max, r_span;                  // r_span = rMax - rMin (fp32, ground_removal.cpp:72)
+  float t_hmin, t_hmax, t_hdiff, h_sensor;
+  double ground_margin;
+  double gk[3];                                // normalised 3-tap Gaussian (gaus_blur.cpp:26-49), host libm
+  int crop_enable;
+  float crop_z_min, crop_z_max, crop_x_min, crop_x_max, crop_y_min, crop_y_max;
+  int num_grid, occ_min_count, dilate;
+  float roi_m, roi_half;                       // roi_half = roiM/2 (fp32)
+  float pic_scale, pic_full, pic_half;         // picScale*roiM and roiM*picScale/2 (fp32 products)
+  int ram_points, l_slope_dist, l_num_points, lshape_side_cond, min_points;
+  float sensor_height;
+  float t_height_min, t_height_max, t_width_min, t_width_max, t_len_min, t_len_max, t_area_max, t_ratio_min,
+      t_ratio_max, min_len_ratio, t_pt_per_m3;
+};
+
+// device buffers of the ground stage for a batch of frames (frame b = slot b)
+struct GroundBuffers {
+  const float4* in;        // [B][in_stride] points
+  long in_stride;          // in points
+  const int* n;            // [B] points per frame (device)
+  int* minz;               // [B][9600] ordered-int min z, all kMinzInit between calls
+  float* hg;               // [B][9600] hGround of ground cells, -inf for non-ground cells
+  unsigned long long* desc;  // [B][max_chunks]
+  int* ticket;             // [B], zero between launches (the workgroup drawing the last ticket re-arms it)
+  unsigned epoch;          // launch epoch, 1..kDescEpochMask
+  float4* elevated;        // [B][cap]
+  float4* ground;          // [B][cap]
+  uint8_t* mask;           // [B][cap] or null
+  int* counts;             // [B][4]: n_elevated, n_ground, n_dropped, spare
+  long cap;                // capacity (points) per frame of the outputs
+  int max_chunks;
+};
+
+void mot_launch_ground(const MotDevParams& p, const GroundBuffers& g, int batch, int max_n, hipStream_t stream);
+// single kernels, for per-kernel timing (mot_time_stage): which = 0 min-z, 1 polar filter, 2 classify+compact
+void mot_launch_ground_kernel(int which, const MotDevParams& p, const GroundBuffers& g, int batch, int max_n,
+                              hipStream_t stream);
+
+// ordered-int key of a float: signed integer compare == float compare
+MOT_HD int mot_float_key(float f) { int k = mot_f2i(f); return k >= 0 ? k : k ^ 0x7fffffff; }
+MOT_HD float mot_key_float(int k) { return mot_i2f(k >= 0 ? k : k ^ 0x7fffffff); }
+
+// getCellIndexFromPoints (ground_removal.cpp:67-76) + filterCloud's range test (:53) + the callers'
+// bounds test (:89,:233). Returns the polar cell (ch*120+bin) or -1 when the point takes no part.
+MOT_HD int mot_polar_cell(const MotDevParams& p, float x, float y) {
+  float distance = sqrtf(x * x + y * y);
+  if (distance <= p.r_min || distance >= p.r_max) return -1;       // filterCloud (NaN passes, as in the reference)
+  float at = mot_atan2f(y, x);
+  float chP = (float)(((double)at + 3.14159265358979323846) / (2 * 3.14159265358979323846));
+  float binP = (distance - p.r_min) / p.r_span;
+  float fc = floorf(chP * MOT_NUM_CHANNEL);
+  float fb = floorf(binP * MOT_NUM_BIN);
+  // (int) of NaN / out-of-range is INT_MIN on the reference's x86 build and is then dropped
+  if (!(fc >= 0.f && fc < (float)MOT_NUM_CHANNEL && fb >= 0.f && fb < (float)MOT_NUM_BIN)) return -1;
+  return (int)fc * MOT_NUM_BIN + (int)fb;
+}
+
+// node pre-filter, OT/src/groundremove/main.cpp:56-81,104-112: PassThrough z (closed, finite) then
+// ConditionalRemoval x,y (strict)
+MOT_HD bool mot_crop_keep(const MotDevParams& p, float x, float y, float z) {
+  if (!p.crop_enable) return true;
+  if (!(x - x == 0.f) || !(y - y == 0.f) || !(z - z == 0.f)) return false;  // non-finite
+  if (z < p.crop_z_min || z > p.crop_z_max) return false;
+  return x > p.crop_x_min && x < p.crop_x_max && y > p.crop_y_min && y < p.crop_y_max;
+}
+
+#endif  // MOT_INTERNAL_H_

@@ -1,0 +1,113 @@
+// mot_math.h — fp32 atan/atan2 whose results are bit-identical to glibc 2.35's atanf/atan2f.
+//
+// Why: the reference bins every point by floor((atan2f(y,x)+pi)/(2pi)*80)
+// (OT/src/groundremove/ground_removal.cpp:67-76). The device math library's atan2f is not
+// bit-identical to glibc's, and a 1-ulp difference flips the channel of points that sit on a
+// channel boundary. glibc 2.35 builds atan2f/atanf from the fdlibm float algorithm
+// (sysdeps/ieee754/flt-32/e_atan2f.c, s_atanf.c: argument reduction to 4 breakpoints +
+// odd/even degree-11 polynomial), with no FMA on x86-64; restating the same operation sequence in
+// IEEE fp32 (compile with -ffp-contract=off, correctly rounded fp32 divide) reproduces it exactly.
+// tests/test_math_exact.py checks this header (compiled for the host) against the C library on
+// >1e8 inputs, including every special-case branch.
+#ifndef MOT_MATH_H_
+#define MOT_MATH_H_
+
+#if defined(__HIPCC__) && !defined(MOT_HIPEMU)
+#define MOT_HD __host__ __device__ __forceinline__
+#else
+#define MOT_HD static inline
+#endif
+
+#include <stdint.h>
+
+MOT_HD int32_t mot_f2i(float f) { union { float f; int32_t i; } u; u.f = f; return u.i; }
+MOT_HD float mot_i2f(int32_t i) { union { float f; int32_t i; } u; u.i = i; return u.f; }
+
+MOT_HD float mot_atanf(float x) {
+  const float atanhi0 = 4.6364760399e-01f, atanhi1 = 7.8539812565e-01f, atanhi2 = 9.8279368877e-01f, atanhi3 = 1.5707962513e+00f;
+  const float atanlo0 = 5.0121582440e-09f, atanlo1 = 3.7748947079e-08f, atanlo2 = 3.4473217170e-08f, atanlo3 = 7.5497894159e-08f;
+  const float aT0 = 3.3333334327e-01f, aT1 = -2.0000000298e-01f, aT2 = 1.4285714924e-01f, aT3 = -1.1111110449e-01f,
+              aT4 = 9.0908870101e-02f, aT5 = -7.6918758452e-02f, aT6 = 6.6610731184e-02f, aT7 = -5.8335702866e-02f,
+              aT8 = 4.9768779427e-02f, aT9 = -3.6531571299e-02f, aT10 = 1.6285819933e-02f;
+  float w, s1, s2, z, hi = 0.f, lo = 0.f;
+  int32_t hx = mot_f2i(x);
+  int32_t ix = hx & 0x7fffffff;
+  int id;
+  if (ix >= 0x4c000000) { /* |x| >= 2^25 */
+    if (ix > 0x7f800000) return x + x; /* NaN */
+    if (hx > 0) return atanhi3 + atanlo3;
+    return -atanhi3 - atanlo3;
+  }
+  if (ix < 0x3ee00000) { /* |x| < 0.4375 */
+    if (ix < 0x31000000) return x; /* |x| < 2^-29 */
+    id = -1;
+  } else {
+    x = mot_i2f(ix); /* fabsf */
+    if (ix < 0x3f980000) {   /* |x| < 1.1875 */
+      if (ix < 0x3f300000) { /* 7/16 <= |x| < 11/16 */
+        id = 0; x = (2.0f * x - 1.0f) / (2.0f + x); hi = atanhi0; lo = atanlo0;
+      } else {               /* 11/16 <= |x| < 19/16 */
+        id = 1; x = (x - 1.0f) / (x + 1.0f); hi = atanhi1; lo = atanlo1;
+      }
+    } else {
+      if (ix < 0x401c0000) { /* |x| < 2.4375 */
+        id = 2; x = (x - 1.5f) / (1.0f + 1.5f * x); hi = atanhi2; lo = atanlo2;
+      } else {               /* 2.4375 <= |x| < 2^25 */
+        id = 3; x = -1.0f / x; hi = atanhi3; lo = atanlo3;
+      }
+    }
+  }
+  z = x * x;
+  w = z * z;
+  s1 = z * (aT0 + w * (aT2 + w * (aT4 + w * (aT6 + w * (aT8 + w * aT10)))));
+  s2 = w * (aT1 + w * (aT3 + w * (aT5 + w * (aT7 + w * aT9))));
+  if (id < 0) return x - x * (s1 + s2);
+  z = hi - ((x * (s1 + s2) - lo) - x);
+  return (hx < 0) ? -z : z;
+}
+
+MOT_HD float mot_atan2f(float y, float x) {
+  const float tiny = 1.0e-30f, pi_o_4 = 7.8539818525e-01f, pi_o_2 = 1.5707963705e+00f, pi = 3.1415927410e+00f,
+              pi_lo = -8.7422776573e-08f;
+  float z;
+  int32_t hx = mot_f2i(x), hy = mot_f2i(y);
+  int32_t ix = hx & 0x7fffffff, iy = hy & 0x7fffffff;
+  if (ix > 0x7f800000 || iy > 0x7f800000) return x + y; /* NaN */
+  if (hx == 0x3f800000) return mot_atanf(y);             /* x == 1.0 */
+  int m = ((hy >> 31) & 1) | ((hx >> 30) & 2);           /* 2*sign(x) + sign(y) */
+  if (iy == 0) {                                          /* y == 0 */
+    if (m < 2) return y;
+    return (m == 2) ? pi + tiny : -pi - tiny;
+  }
+  if (ix == 0) return (hy < 0) ? -pi_o_2 - tiny : pi_o_2 + tiny; /* x == 0 */
+  if (ix == 0x7f800000) {                                 /* x == INF */
+    if (iy == 0x7f800000) {
+      switch (m) {
+        case 0: return pi_o_4 + tiny;
+        case 1: return -pi_o_4 - tiny;
+        case 2: return 3.0f * pi_o_4 + tiny;
+        default: return -3.0f * pi_o_4 - tiny;
+      }
+    } else {
+      switch (m) {
+        case 0: return 0.0f;
+        case 1: return -0.0f;
+        case 2: return pi + tiny;
+        default: return -pi - tiny;
+      }
+    }
+  }
+  if (iy == 0x7f800000) return (hy < 0) ? -pi_o_2 - tiny : pi_o_2 + tiny; /* y == INF */
+  int32_t k = (iy - ix) >> 23;
+  if (k > 60) z = pi_o_2 + 0.5f * pi_lo;       /* |y/x| > 2^60 */
+  else if (hx < 0 && k < -60) z = 0.0f;        /* |y|/x < -2^60 */
+  else z = mot_atanf(mot_i2f(mot_f2i(y / x) & 0x7fffffff));
+  switch (m) {
+    case 0: return z;
+    case 1: return mot_i2f(mot_f2i(z) ^ (int32_t)0x80000000);
+    case 2: return pi - (z - pi_lo);
+    default: return (z - pi_lo) - pi;
+  }
+}
+
+#endif  // MOT_MATH_H_

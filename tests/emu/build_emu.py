@@ -1,0 +1,43 @@
+"""Builds tests/emu/libmot_emu.so: the SAME csrc/*.hip sources compiled by g++ against hipemu.h.
+DEVELOPMENT / CPU-TEST INFRASTRUCTURE ONLY — see hipemu.h. Never used by the product or the parity tests."""
+from __future__ import annotations
+
+import os
+import subprocess
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+CSRC = os.path.join(ROOT, "3d-lidar-multi-object-tracking_amd", "csrc")
+LIB = os.path.join(HERE, "libmot_emu.so")
+
+
+def sources():
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("mot_build", os.path.join(ROOT, "3d-lidar-multi-object-tracking_amd", "build.py"))
+    m = importlib.util.module_from_spec(spec); spec.loader.exec_module(m)
+    return m.SOURCES, m.HEADERS
+
+
+def build(force: bool = False) -> str:
+    srcs, hdrs = sources()
+    deps = [os.path.join(CSRC, s) for s in srcs + hdrs] + [os.path.join(HERE, "hipemu.h"), os.path.abspath(__file__)]
+    if not force and os.path.exists(LIB) and all(os.path.getmtime(d) <= os.path.getmtime(LIB) for d in deps):
+        return LIB
+    objs = []
+    for s in srcs:
+        o = os.path.join(HERE, "obj_" + s.replace(".hip", ".o"))
+        cmd = ["g++", "-std=c++17", "-O1", "-g", "-fPIC", "-ffp-contract=off", "-fno-fast-math", "-DMOT_HIPEMU=1", "-x", "c++",
+               "-include", os.path.join(HERE, "hipemu.h"), "-I", CSRC, "-Wall", "-Wno-unused-function", "-Wno-unknown-pragmas",
+               "-Wno-unused-variable", "-c", os.path.join(CSRC, s), "-o", o]
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        if r.returncode:
+            raise RuntimeError("emu build failed:\n" + r.stderr)
+        objs.append(o)
+    r = subprocess.run(["g++", "-shared", "-o", LIB] + objs, capture_output=True, text=True)
+    if r.returncode:
+        raise RuntimeError("emu link failed:\n" + r.stderr)
+    return LIB
+
+
+if __name__ == "__main__":
+    print(build(force=True))

@@ -1,0 +1,101 @@
+"""Parity of the HIP ground-removal path (through the C-ABI) against the oracle. Bit-exact:
+elevated cloud, ground cloud (order included) and the per-point mask."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ctx(mot, hip_lib):
+    c = mot.Context(max_points=262144, max_batch=8)
+    yield c
+    c.close()
+
+
+def _check(ctx, oracle, p, cloud):
+    r = ctx.ground_remove(cloud)
+    g = oracle.ground_remove(p, cloud)
+    assert len(r["elevated"]) == len(g["elevated"]) and len(r["ground"]) == len(g["ground"])
+    assert np.array_equal(r["mask"], g["mask"])
+    assert np.array_equal(r["elevated"].view(np.uint32), g["elevated"].view(np.uint32))
+    assert np.array_equal(r["ground"].view(np.uint32), g["ground"].view(np.uint32))
+    return r
+
+
+@pytest.mark.parametrize("n,stream", [(0, 0), (1, 0), (63, 1), (64, 1), (2047, 2), (2048, 2), (2049, 2), (5000, 3),
+                                      (120000, 0), (120000, 7), (200000, 4)])
+def test_ground_parity_sizes(ctx, oracle, synth, n, stream):
+    p = oracle.params(0)
+    cloud = synth.make_cloud(max(n, 1), stream, 0)[:n]
+    _check(ctx, oracle, p, cloud)
+
+
+def test_ground_edge_points(ctx, oracle, synth):
+    p = oracle.params(0)
+    cloud = np.concatenate([synth.edge_case_points(), synth.make_cloud(3000, 5, 0), synth.edge_case_points()])
+    nan = cloud[:8].copy(); nan[0, 0] = np.nan; nan[1, 1] = np.inf; nan[2, 2] = np.nan; nan[3, 2] = -np.inf; nan[4, 0] = -np.inf
+    cloud = np.concatenate([cloud, nan])
+    _check(ctx, oracle, p, cloud)
+
+
+def test_ground_random_order_and_boundaries(ctx, oracle, synth):
+    """shuffled cloud (worst case for the per-wave cell matching) + points exactly on polar cell boundaries"""
+    p = oracle.params(0)
+    rng = np.random.default_rng(3)
+    cloud = synth.make_cloud(50000, 6, 1)
+    rng.shuffle(cloud)
+    k = np.arange(0, 80)
+    ang = (k / 80.0) * 2 * np.pi - np.pi
+    ring = np.stack([10 * np.cos(ang), 10 * np.sin(ang), np.full(80, -1.7), np.zeros(80)], 1).astype(np.float32)
+    rad = 3.4 + (120 - 3.4) * np.arange(120) / 120.0
+    spoke = np.stack([rad, np.zeros(120), np.full(120, -1.7), np.zeros(120)], 1).astype(np.float32)
+    _check(ctx, oracle, p, np.concatenate([cloud, ring, spoke]))
+
+
+def test_ground_kitti_preset_and_crop(mot, hip_lib, oracle, synth):
+    cloud = synth.make_cloud(60000, 2, 3)
+    for preset, crop in ((1, 0), (0, 1)):
+        p = oracle.params(preset, crop_enable=crop)
+        mp = mot.params(preset, crop_enable=crop)
+        with mot.Context(mp, max_points=65536) as c:
+            r = c.ground_remove(cloud)
+        src = oracle.crop(p, cloud) if crop else cloud
+        p0 = oracle.params(preset)
+        g = oracle.ground_remove(p0, src)
+        assert np.array_equal(r["elevated"], g["elevated"]) and np.array_equal(r["ground"], g["ground"])
+
+
+def test_ground_batch_dev(ctx, oracle, synth):
+    """8 frames of different sizes in one launch sequence, inputs resident in HBM"""
+    torch = pytest.importorskip("torch")
+    p = oracle.params(0)
+    sizes = [120000, 1, 99999, 0, 200000, 2048, 77777, 131072]
+    stride = 262144
+    host = np.zeros((8, stride, 4), np.float32)
+    clouds = []
+    for b, n in enumerate(sizes):
+        c = synth.make_cloud(max(n, 1), 10 + b, b)[:n]
+        host[b, :n] = c
+        clouds.append(c)
+    dev = torch.from_numpy(host).cuda()
+    torch.cuda.synchronize()
+    for rep in range(3):  # re-running on the same context must give the same answer (state is re-armed)
+        ctx.frames_dev(dev.data_ptr(), stride * 4, sizes)
+        for b, n in enumerate(sizes):
+            r = ctx.get_ground(b, n_hint=n)
+            g = oracle.ground_remove(p, clouds[b])
+            assert r["n_elevated"] == len(g["elevated"]) and r["n_ground"] == len(g["ground"]), (rep, b)
+            assert np.array_equal(r["elevated"], g["elevated"]) and np.array_equal(r["ground"], g["ground"])
+            assert np.array_equal(r["mask"][:n], g["mask"])
+
+
+def test_ground_properties_full_size(ctx, synth):
+    """size-independent properties at 200k points: partition, order preservation, idempotence"""
+    cloud = synth.make_cloud(200000, 9, 0)
+    r = ctx.ground_remove(cloud)
+    m = r["mask"]
+    assert (m == 2).sum() == len(r["elevated"]) and (m == 1).sum() == len(r["ground"])
+    assert np.array_equal(cloud[m == 2], r["elevated"]) and np.array_equal(cloud[m == 1], r["ground"])
+    r2 = ctx.ground_remove(cloud)
+    assert np.array_equal(r2["mask"], m)
