@@ -1,0 +1,134 @@
+"""Pins the C restatement (oracle/mot_oracle_*.c): (a) against the golden vectors generated from the reference's own
+sources (tests/golden/, always), (b) live against oracle/_ref when that library is present (the build container and
+any box the prebuilt .so travelled to)."""
+import numpy as np
+import pytest
+
+import golden_util as G
+
+
+@pytest.mark.parametrize("name", G.FRAMES)
+def test_restatement_matches_golden_frames(oracle, name):
+    fx = G.load(name)
+    p = oracle.params(0)
+    g = oracle.ground_remove(p, fx["cloud"], want_dump=True)
+    cl = oracle.cluster(p, g["elevated"])
+    bx = oracle.box_fit(p, g["elevated"], cl["grid"], cl["num_cluster"])
+    G.check_frame(fx, g, cl, bx["boxes"], polar=g)
+
+
+@pytest.mark.parametrize("name", G.TRACKERS)
+def test_restatement_matches_golden_tracker(oracle, name):
+    fx = G.load(name)
+    T = oracle.Tracker(oracle.params(0))
+    for f in range(len(fx["n_boxes"])):
+        ts = 1.0e9 + f * float(fx["unit"])
+        ego = T.ego_update(ts, 2.0 + 0.05 * f, 0.004 * f)
+        assert np.allclose(ego, fx["ego"][f], rtol=1e-12, atol=1e-12)
+        out = T.step(fx["boxes"][f][: fx["n_boxes"][f]], ts)
+        G.check_tracker_frame(fx, f, out, T.state, rtol=1e-7)
+    T.close()
+
+
+def _need_ref(oracle):
+    if oracle.ref() is None:
+        pytest.skip("oracle/_ref not built on this box")
+
+
+@pytest.mark.parametrize("stream,frame,n", [(0, 0, 120000), (1, 3, 60000), (2, 1, 30000), (4, 0, 200000)])
+def test_restatement_vs_ref_stateless_stages(oracle, synth, stream, frame, n):
+    _need_ref(oracle)
+    p = oracle.params(0)
+    c = np.concatenate([synth.make_cloud(n, stream, frame), synth.edge_case_points()])
+    g = oracle.ground_remove(p, c, want_dump=True)
+    r = oracle.ref_ground_remove(c)
+    assert np.array_equal(g["elevated"][:, :3], r["elevated"][:, :3]) and np.array_equal(g["ground"][:, :3], r["ground"][:, :3])
+    rp = oracle.ref_ground_polar(c)
+    for k in ("min_z", "height", "smoothed", "hdiff", "is_ground"):
+        assert np.array_equal(g[k], rp[k]), k
+    cl = oracle.cluster(p, g["elevated"]); rc = oracle.ref_cluster(g["elevated"])
+    assert cl["num_cluster"] == rc["num_cluster"] and np.array_equal(cl["grid"], rc["grid"])
+    bx = oracle.box_fit(p, g["elevated"], cl["grid"], cl["num_cluster"]); rb = oracle.ref_box_fit(g["elevated"], cl["grid"], cl["num_cluster"])
+    assert bx["n_undefined"] == 0
+    assert bx["boxes"].shape == rb["boxes"].shape and np.array_equal(bx["boxes"], rb["boxes"])
+
+
+def test_restatement_vs_ref_cell_index(oracle):
+    _need_ref(oracle)
+    import ctypes as C
+    p = oracle.params(0)
+    rng = np.random.default_rng(0)
+    xy = rng.uniform(-130, 130, size=(20000, 2)).astype(np.float32)
+    k = np.arange(0, 81); ang = (k / 80.0) * 2 * np.pi - np.pi   # channel boundaries
+    xy = np.concatenate([xy, np.stack([10 * np.cos(ang), 10 * np.sin(ang)], 1).astype(np.float32)])
+    for x, y in xy:
+        ch = C.c_int(0); b = C.c_int(0)
+        oracle.orc().orc_cell_index(C.byref(p), C.c_float(x), C.c_float(y), C.byref(ch), C.byref(b))
+        assert (ch.value, b.value) == oracle.ref_cell_index(float(x), float(y))
+
+
+def test_lshape_rng_matches_libstdcxx(oracle):
+    """mt19937_64(0) + uniform_int_distribution<>(0, n-1): restated generator vs libstdc++ (compiled here)"""
+    import os, subprocess, tempfile
+    src = r'''
+#include <random>
+#include <cstdio>
+int main(){ int ns[]={1,2,6,7,30,31,100,1000,4097,65536,1000003};
+ for(int n: ns){ std::mt19937_64 mt(0); std::uniform_int_distribution<> d(0,n-1); for(int i=0;i<80;i++) printf("%d ", d(mt)); printf("\n"); } }
+'''
+    with tempfile.TemporaryDirectory() as d:
+        open(os.path.join(d, "r.cpp"), "w").write(src)
+        subprocess.run(["g++", "-O1", os.path.join(d, "r.cpp"), "-o", os.path.join(d, "r")], check=True)
+        lines = subprocess.run([os.path.join(d, "r")], capture_output=True, text=True).stdout.strip().split("\n")
+    for n, line in zip([1, 2, 6, 7, 30, 31, 100, 1000, 4097, 65536, 1000003], lines):
+        assert np.array_equal(oracle.lshape_indices(n, 80), np.array(line.split(), np.int32)), n
+
+
+@pytest.mark.parametrize("unit", [1e5, 0.1])
+def test_restatement_vs_ref_tracker(oracle, synth, unit):
+    _need_ref(oracle)
+    p = oracle.params(0)
+    T = oracle.Tracker(p); R = oracle.RefTracker(); R.reset()
+    for f in range(25):
+        c = synth.make_cloud(40000, 2, f)
+        g = oracle.ground_remove(p, c); cl = oracle.cluster(p, g["elevated"]); b = oracle.box_fit(p, g["elevated"], cl["grid"], cl["num_cluster"])["boxes"]
+        ts = 5.0e8 + f * unit
+        assert np.allclose(T.ego_update(ts, 4.0, -0.01 * f), R.ego_update(ts, 4.0, -0.01 * f), rtol=1e-12, atol=1e-12)
+        a = T.step(b, ts); r = R.step(b, ts)
+        assert a["n"] == r["n"] and np.array_equal(a["track_manage"], r["track_manage"])
+        assert np.array_equal(a["is_static"], r["is_static"]) and np.array_equal(a["is_vis"], r["is_vis"])
+        assert np.array_equal(a["vis_box"], r["vis_box"])
+        for i in range(a["n"]):
+            if r["track_manage"][i] == 0:
+                continue
+            sa, sr = T.state(i), R.state(i)
+            assert sa["lifetime"] == sr["lifetime"]
+            for k in ("x_merge", "x_cv", "x_ctrv", "x_rm", "p_merge", "p_cv", "p_ctrv", "p_rm", "mode_prob", "z_pred", "s", "k"):
+                scale = max(np.abs(sr[k]).max(), 1e-300)
+                assert np.abs(sa[k] - sr[k]).max() <= 1e-7 * scale + 1e-12, (f, i, k)
+    T.close()
+
+
+def test_min_area_rect_properties(oracle):
+    """the restated cv::minAreaRect is 'parity unpinned' (no OpenCV here): at least check what a minimum-area
+    rectangle must satisfy — contains every point, area <= axis-aligned bounding box, duplicate invariance."""
+    rng = np.random.default_rng(5)
+    for trial in range(200):
+        n = int(rng.integers(3, 60))
+        pts = rng.integers(-200, 200, size=(n, 2)).astype(np.int32)
+        if trial % 3 == 0:
+            pts[:, 1] = pts[:, 0] // 2 + rng.integers(-3, 3, size=n)   # thin, slanted
+        r = oracle.min_area_rect_points(pts).astype(np.float64)
+        e0, e1 = r[1] - r[0], r[2] - r[1]
+        area = abs(e0[0] * e1[1] - e0[1] * e1[0])
+        aabb = float(np.ptp(pts[:, 0])) * float(np.ptp(pts[:, 1]))
+        assert area <= aabb * (1 + 1e-4) + 1e-3
+        # containment: project on the two edge directions
+        for e, a, b in ((e0, r[0], r[1]), (e1, r[1], r[2])):
+            L = np.linalg.norm(e)
+            if L < 1e-9:
+                continue
+            t = (pts - a) @ (e / L)
+            assert t.min() >= -1e-2 * max(L, 1) - 0.05 and t.max() <= L + 1e-2 * max(L, 1) + 0.05
+        r2 = oracle.min_area_rect_points(np.concatenate([pts, pts[::2]]))
+        assert np.array_equal(r2.astype(np.float32), oracle.min_area_rect_points(pts))
