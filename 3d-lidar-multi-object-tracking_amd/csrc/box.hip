@@ -1,0 +1,601 @@
+// box.hip — per-cluster box fitting on gfx950. Product code (HIP, wave64).
+//
+// Replaces boxFitting() = getClusteredPoints() + getBoundingBox() (+ ruleBasedFilter, getPointsInPcFrame and
+// OpenCV's minAreaRect / RotatedRect::points) — OT/src/cluster/box_fitting.cpp:46-435 — for a batch of frames:
+//
+//   B1 label_stats_kernel   N_e pts  -> per-point label + per-cluster {count, first point, max z, slope extrema}
+//   B2 cluster_box_kernel   clusters -> candidate box per cluster (L-shape fit or min-area rectangle + rule filter)
+//   B3 box_finalize_kernel  clusters -> boxes compacted in cluster order (the order the reference push_backs them)
+//
+// Design notes:
+//  * the reference first copies the cloud into one vector per cluster; nothing here is copied. What the fit
+//    needs per cluster is (a) order-independent reductions — count, max z, slope arg-min/arg-max with
+//    "first occurrence wins" (strict </> in box_fitting.cpp:268-280) — done with wave-level matching on the
+//    label and one 64-bit atomic min/max per (wave, cluster) on keys that carry the point index as tie-break;
+//    (b) the FIRST point of the cluster (pixel re-centring, :218-225) = atomic min of the index; (c) for the
+//    L-shape branch the k-th point of the cluster in input order for 80 seeded k (mt19937_64(0) +
+//    libstdc++'s uniform_int_distribution): one wave walks the label array with ballot/popcount ranks.
+//  * min-area rectangle: pixel coordinates are integers in [0,900], so only the lowest and highest pixel of
+//    every pixel column can be hull vertices; column extents are gathered with LDS atomics and handed — already
+//    sorted by (x,y) — to the same Sklansky scan / rotating calipers OpenCV runs (restated from OpenCV 3.2;
+//    tests/test_oracle_vs_ref.py::test_hull_column_reduction checks the reduction changes nothing).
+//  * fp32 throughout, reference operation order, -ffp-contract=off. Double atan2/cos/sin of the rectangle
+//    angle come from the device math library; they are rounded to fp32 immediately.
+#include "mot_internal.h"
+
+#ifndef MOT_HIPEMU
+#define MOT_LAUNCH_BOUNDS(n) __launch_bounds__(n)
+#else
+#define MOT_LAUNCH_BOUNDS(n)
+#endif
+
+constexpr int kLabelBlock = 256;
+constexpr int kLabelItems = 8;
+constexpr int kLabelChunk = kLabelBlock * kLabelItems;
+constexpr unsigned long long kArgminInit = ~0ull;   // nothing compared below 999 yet
+constexpr unsigned long long kArgmaxInit = 0ull;    // nothing compared above -999 yet
+
+__device__ __forceinline__ int lane_id() { return (int)(threadIdx.x & 63); }
+template <typename T>
+__device__ __forceinline__ T wave_min_t(T v) {
+#pragma unroll
+  for (int m = 32; m >= 1; m >>= 1) { T o = __shfl_xor(v, m, 64); v = o < v ? o : v; }
+  return v;
+}
+template <typename T>
+__device__ __forceinline__ T wave_max_t(T v) {
+#pragma unroll
+  for (int m = 32; m >= 1; m >>= 1) { T o = __shfl_xor(v, m, 64); v = o > v ? o : v; }
+  return v;
+}
+// unsigned order-preserving key of a float (larger float -> larger key)
+__device__ __forceinline__ unsigned ukey(float f) { unsigned u = __float_as_uint(f); return (u & 0x80000000u) ? ~u : (u | 0x80000000u); }
+__device__ __forceinline__ float ukey_inv(unsigned k) { return __uint_as_float((k & 0x80000000u) ? (k & 0x7fffffffu) : ~k); }
+
+__global__ void stats_init_kernel(ClusterBuffers c) {
+  const int b = blockIdx.y;
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < kMaxClusters) {
+    ClusterStats s;
+    s.count = 0; s.first = 0x7fffffff; s.maxz_key = mot_float_key(-99.f); s.pad = 0;
+    s.argmin = kArgminInit; s.argmax = kArgmaxInit;
+    c.stats[(long)b * kMaxClusters + i] = s;
+  }
+}
+
+// ------------------------------------------------------------------------------------------ B1
+// getClusteredPoints :46-72 (label of every point) + the per-point loop of getBoundingBox :239-293
+__global__ void MOT_LAUNCH_BOUNDS(kLabelBlock)
+label_stats_kernel(MotDevParams p, ClusterBuffers c) {
+  const int b = blockIdx.y;
+  const int n = c.counts[b * kCountsStride + kCntElev];
+  const long base = (long)blockIdx.x * kLabelChunk;
+  if (base >= n) return;
+  const int num_cluster = c.counts[b * kCountsStride + kCntClusters];
+  const float4* __restrict__ pts = c.elevated + (long)b * c.cap;
+  const int* __restrict__ grid = c.grid + (long)b * (MOT_MAX_GRID * MOT_MAX_GRID);
+  int* __restrict__ label = c.label + (long)b * c.cap;
+  ClusterStats* __restrict__ stats = c.stats + (long)b * kMaxClusters;
+  const int lane = lane_id();
+#pragma unroll
+  for (int k = 0; k < kLabelItems; k++) {
+    long i = base + k * kLabelBlock + threadIdx.x;
+    int lab = 0;
+    float4 q = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (i < n) {
+      q = pts[i];
+      int xI, yI;
+      if (mot_cart_cell(p, q.x, q.y, &xI, &yI)) lab = grid[xI * p.num_grid + yI];
+      if (lab < 0 || lab > num_cluster) lab = 0;
+      label[i] = lab;
+      if (lab > kMaxClusters) lab = 0;  // no statistics slot: box_finalize_kernel raises the capacity flag
+    }
+    float m = q.y / q.x + 0.0f;  // slope, :264 (+0 makes -0 == +0 for the keyed compare, as `<` does)
+    // `m < minM` with minM = 999 / `m > maxM` with maxM = -999 (NaN never compares)
+    unsigned long long kmin = (m < 999.f) ? (((unsigned long long)ukey(m) << 32) | (unsigned)i) : kArgminInit;
+    unsigned long long kmax = (m > -999.f) ? (((unsigned long long)ukey(m) << 32) | (unsigned)~(unsigned)i) : kArgmaxInit;
+    int zkey = (q.z > -99.f) ? mot_float_key(q.z + 0.0f) : mot_float_key(-99.f);  // `pZ > maxZ`, maxZ = -99
+    unsigned long long active = __ballot(lab > 0);
+    while (active) {  // one trip per distinct cluster among the 64 points of this wave
+      int leader = __ffsll(active) - 1;
+      int l = __shfl(lab, leader, 64);
+      bool mine = (lab == l);
+      unsigned long long mm = __ballot(mine);
+      unsigned long long rmin = wave_min_t<unsigned long long>(mine ? kmin : kArgminInit);
+      unsigned long long rmax = wave_max_t<unsigned long long>(mine ? kmax : kArgmaxInit);
+      int rz = wave_max_t<int>(mine ? zkey : mot_float_key(-99.f));
+      if (lane == leader) {  // the leader is the lowest lane = the smallest index of the group
+        ClusterStats* s = &stats[l - 1];
+        atomicAdd(&s->count, __popcll(mm));
+        atomicMin(&s->first, (int)i);
+        atomicMax(&s->maxz_key, rz);
+        if (rmin != kArgminInit) atomicMin(&s->argmin, rmin);
+        if (rmax != kArgmaxInit) atomicMax(&s->argmax, rmax);
+      }
+      active &= ~mm;
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------ B2
+constexpr int kBoxBlock = 64;        // ONE wave per cluster
+constexpr int kPicCols = 1024;       // pixel columns 0..900
+constexpr int kMaxHullIn = 2 * 901;  // two extreme pixels per column
+constexpr int kMaxHull = 512;        // vertices of a convex lattice polygon in a 900^2 box: < 3.5 * 900^(2/3) ~ 330
+
+// ruleBasedFilter :97-158 (fall-through = false)
+__device__ bool rule_based_filter(const MotDevParams& p, const float* pc, float maxZ, int numPoints) {
+  if (numPoints < p.min_points) return false;
+  float width, length, height, area, ratio, mass;
+  float x1 = pc[0], y1 = pc[1], x2 = pc[2], y2 = pc[3], x3 = pc[4], y3 = pc[5];
+  float dist1 = sqrtf((x1 - x2) * (x1 - x2) + (y1 - y2) * (y1 - y2));
+  float dist2 = sqrtf((x3 - x2) * (x3 - x2) + (y3 - y2) * (y3 - y2));
+  if (dist1 > dist2) { length = dist1; width = dist2; } else { length = dist2; width = dist1; }
+  height = maxZ + p.sensor_height;
+  area = dist1 * dist2;
+  mass = area * height;
+  ratio = length / width;
+  if (height > p.t_height_min && height < p.t_height_max)
+    if (width > p.t_width_min && width < p.t_width_max)
+      if (length > p.t_len_min && length < p.t_len_max)
+        if (area < p.t_area_max)
+          if ((float)numPoints > mass * p.t_pt_per_m3) {
+            if (length > p.min_len_ratio) {
+              if (ratio > p.t_ratio_min && ratio < p.t_ratio_max) return true;
+            } else return true;
+          }
+  return false;
+}
+
+// Sklansky_<int> of OpenCV 3.2 convhull.cpp on points sorted by (x,y)
+__device__ int sklansky(const short* ax, const short* ay, int start, int end, short* stack, int nsign, int sign2) {
+  int incr = end > start ? 1 : -1;
+  int pprev = start, pcur = pprev + incr, pnext = pcur + incr;
+  int stacksize = 3;
+  if (start == end || (ax[start] == ax[end] && ay[start] == ay[end])) { stack[0] = (short)start; return 1; }
+  stack[0] = (short)pprev; stack[1] = (short)pcur; stack[2] = (short)pnext;
+  end += incr;
+  while (pnext != end) {
+    int cury = ay[pcur], nexty = ay[pnext];
+    int by = nexty - cury;
+    int sby = (by > 0) - (by < 0);
+    if (sby != nsign) {
+      int axx = ax[pcur] - ax[pprev];
+      int bx = ax[pnext] - ax[pcur];
+      int ayy = cury - ay[pprev];
+      int convexity = ayy * bx - axx * by;
+      int sc = (convexity > 0) - (convexity < 0);
+      if (sc == sign2 && (axx != 0 || ayy != 0)) {
+        pprev = pcur; pcur = pnext; pnext += incr;
+        stack[stacksize] = (short)pnext; stacksize++;
+      } else {
+        if (pprev == start) {
+          pcur = pnext; stack[1] = (short)pcur; pnext += incr; stack[2] = (short)pnext;
+        } else {
+          stack[stacksize - 2] = (short)pnext; pcur = pprev; pprev = stack[stacksize - 4]; stacksize--;
+        }
+      }
+    } else {
+      pnext += incr; stack[stacksize - 1] = (short)pnext;
+    }
+  }
+  return --stacksize;
+}
+
+__global__ void MOT_LAUNCH_BOUNDS(kBoxBlock)
+cluster_box_kernel(MotDevParams p, ClusterBuffers c) {
+  // LDS carve-up (one wave): column extents, then reused as Sklansky stack
+  __shared__ __attribute__((aligned(16))) unsigned char s_raw[2 * kPicCols * sizeof(int)];
+  int* s_colmin = (int*)s_raw;
+  int* s_colmax = s_colmin + kPicCols;
+  __shared__ short s_px[kMaxHullIn + 2], s_py[kMaxHullIn + 2];  // reduced point set, sorted by (x,y)
+  __shared__ short s_hull[kMaxHullIn + 2];
+  __shared__ float s_hx[kMaxHull], s_hy[kMaxHull], s_vx[kMaxHull], s_vy[kMaxHull], s_inv[kMaxHull];
+  __shared__ int s_rank[128], s_pidx[128];
+  __shared__ int s_total;
+  const int b = blockIdx.y;
+  const int n = c.counts[b * kCountsStride + kCntElev];
+  const int num_cluster = min(c.counts[b * kCountsStride + kCntClusters], kMaxClusters);
+  const float4* __restrict__ pts = c.elevated + (long)b * c.cap;
+  const int* __restrict__ label = c.label + (long)b * c.cap;
+  const int lane = lane_id();
+  short* s_stack = (short*)s_raw;  // 8 KB >= (kMaxHullIn + 2) shorts; the column extents are dead by then
+
+  for (int ci = blockIdx.x; ci < num_cluster; ci += gridDim.x) {
+    const ClusterStats st = c.stats[(long)b * kMaxClusters + ci];
+    BoxCandidate cand;
+    for (int k = 0; k < 8; k++) cand.pc[k] = 0.f;
+    cand.max_z = 0.f; cand.accepted = 0; cand.undefined = 0; cand.branch = -1;
+    const int numPoints = st.count;
+    bool have = numPoints > 0 && st.argmin != kArgminInit && st.argmax != kArgmaxInit;  // SURVEY.md H7 otherwise
+    if (!have) {
+      cand.undefined = 1;
+      if (lane == 0) c.cand[(long)b * kMaxClusters + ci] = cand;
+      continue;
+    }
+    const float4 first = pts[st.first];
+    const float initPX = first.x + p.roi_half, initPY = first.y + p.roi_half;  // :218-225
+    const int initX = (int)floorf(initPX * p.pic_scale), initY = (int)floorf(initPY * p.pic_scale);
+    const int initPicX = initX;
+    const int initPicY = (int)(p.pic_full - (float)initY);
+    const int offsetInitX = (int)(p.pic_half - (float)initPicX);
+    const int offsetInitY = (int)(p.pic_half - (float)initPicY);
+    const float4 pmin = pts[(unsigned)(st.argmin & 0xffffffffull)];
+    const float4 pmax = pts[~(unsigned)(st.argmax & 0xffffffffull)];
+    const float minMx = pmin.x, minMy = pmin.y, maxMx = pmax.x, maxMy = pmax.y;
+    const float maxZ = mot_key_float(st.maxz_key);
+    cand.max_z = maxZ;
+    const float xDist = maxMx - minMx, yDist = maxMy - minMy;  // :296-300
+    const float slopeDist = sqrtf(xDist * xDist + yDist * yDist);
+    const float slope = (maxMy - minMy) / (maxMx - minMx);
+    bool lshape = slopeDist > (float)p.l_slope_dist && numPoints > p.l_num_points;  // :308
+    if (p.lshape_side_cond) lshape = lshape && (maxMy > 8.f || maxMy < -5.f);
+    float pc[8];
+    bool promising = false;
+
+    if (lshape) {  // ---------------------------------------------------------------- L-shape :310-356
+      cand.branch = 0;
+      const int nsamp = p.ram_points < 128 ? p.ram_points : 128;
+      if (lane == 0) {
+        // mt19937_64 mt(0); uniform_int_distribution<>(0, numPoints-1): libstdc++ >= 11 maps the 64-bit draw
+        // with Lemire's multiply-shift + rejection (bits/uniform_int_dist.h _S_nd), SURVEY.md H17
+        int t = 0;
+        unsigned long long range = (unsigned long long)numPoints;
+        bool exhausted = false;
+        for (int i = 0; i < nsamp; i++) {
+          unsigned long long g = c.rng[t < kRngTable ? t : kRngTable - 1]; exhausted |= t >= kRngTable; t++;
+          unsigned long long low = g * range, high = __umul64hi(g, range);
+          if (low < range) {
+            unsigned long long threshold = (0ull - range) % range;
+            while (low < threshold) {
+              g = c.rng[t < kRngTable ? t : kRngTable - 1]; exhausted |= t >= kRngTable; t++;
+              low = g * range; high = __umul64hi(g, range);
+              if (exhausted) break;
+            }
+          }
+          s_rank[i] = (int)high;
+          s_pidx[i] = -1;
+        }
+        if (exhausted) atomicOr(&c.counts[b * kCountsStride + kCntFlags], (int)kFlagRngExhausted);
+      }
+      __syncthreads();
+      // k-th point of the cluster in input order: walk the labels with ballot/popcount ranks
+      int running = 0;
+      for (int base = 0; base < n && running < numPoints; base += 64) {
+        int i = base + lane;
+        bool mine = i < n && label[i] == ci + 1;
+        unsigned long long mm = __ballot(mine);
+        if (mm == 0ull) continue;
+        if (mine) {
+          int r = running + __popcll(mm & ((1ull << lane) - 1ull));
+          for (int j = 0; j < nsamp; j++) if (s_rank[j] == r) s_pidx[j] = i;
+        }
+        running += __popcll(mm);
+      }
+      __syncthreads();
+      // farthest sampled point from the line through the two slope-extreme points; first maximum wins
+      unsigned long long best = 0ull;
+      for (int j = lane; j < nsamp; j += 64) {
+        int pi = s_pidx[j];
+        if (pi >= 0) {
+          float xI = pts[pi].x, yI = pts[pi].y;
+          float dist = fabsf(slope * xI - 1 * yI + maxMy - slope * maxMx) / sqrtf(slope * slope + 1);
+          if (dist > 0.f) {  // `dist > maxDist`, maxDist = 0 (NaN never)
+            unsigned long long key = ((unsigned long long)__float_as_uint(dist) << 32) | (unsigned)(0xffff - j);
+            best = key > best ? key : best;
+          }
+        }
+      }
+      best = wave_max_t<unsigned long long>(best);
+      if (best == 0ull) {
+        cand.undefined = 1;  // maxDx/maxDy would be read uninitialised (H7)
+      } else {
+        int j = 0xffff - (int)(best & 0xffffull);
+        const float maxDx = pts[s_pidx[j]].x, maxDy = pts[s_pidx[j]].y;
+        float maxMvecX = maxMx - maxDx, maxMvecY = maxMy - maxDy;
+        float minMvecX = minMx - maxDx, minMvecY = minMy - maxDy;
+        float lastX = maxDx + maxMvecX + minMvecX;
+        float lastY = maxDy + maxMvecY + minMvecY;
+        pc[0] = minMx; pc[1] = minMy; pc[2] = maxDx; pc[3] = maxDy;
+        pc[4] = maxMx; pc[5] = maxMy; pc[6] = lastX; pc[7] = lastY;
+        promising = rule_based_filter(p, pc, maxZ, numPoints);
+      }
+      __syncthreads();
+    } else {  // ------------------------------------------------------- minAreaRect :358-366
+      cand.branch = 1;
+      for (int i = lane; i < kPicCols; i += 64) { s_colmin[i] = 0x7fffffff; s_colmax[i] = -0x7fffffff - 1; }
+      __syncthreads();
+      int running = 0;
+      for (int base = 0; base < n && running < numPoints; base += 64) {
+        int i = base + lane;
+        bool mine = i < n && label[i] == ci + 1;
+        unsigned long long mm = __ballot(mine);
+        if (mm == 0ull) continue;
+        if (mine) {
+          float4 q = pts[i];
+          float roiX = q.x + p.roi_half, roiY = q.y + p.roi_half;  // :244-254
+          int x = (int)floorf(roiX * p.pic_scale), y = (int)floorf(roiY * p.pic_scale);
+          int picX = x;
+          int picY = (int)(p.pic_full - (float)y);
+          int offsetY = picY + offsetInitY;
+          if (picX >= 0 && picX < kPicCols) { atomicMin(&s_colmin[picX], offsetY); atomicMax(&s_colmax[picX], offsetY); }
+        }
+        running += __popcll(mm);
+      }
+      __syncthreads();
+      // compact the column extents into (x,y)-sorted points: 16 columns per lane, prefix over lanes
+      int cnt = 0;
+      for (int k = 0; k < kPicCols / 64; k++) {
+        int col = lane * (kPicCols / 64) + k;
+        int lo = s_colmin[col], hi = s_colmax[col];
+        if (lo != 0x7fffffff) cnt += (hi != lo) ? 2 : 1;
+      }
+      int incl = cnt;
+#pragma unroll
+      for (int d = 1; d < 64; d <<= 1) { int o = __shfl_up(incl, d, 64); if (lane >= d) incl += o; }
+      int pos = incl - cnt;
+      for (int k = 0; k < kPicCols / 64; k++) {
+        int col = lane * (kPicCols / 64) + k;
+        int lo = s_colmin[col], hi = s_colmax[col];
+        if (lo != 0x7fffffff) {
+          s_px[pos] = (short)(col + offsetInitX); s_py[pos] = (short)lo; pos++;
+          if (hi != lo) { s_px[pos] = (short)(col + offsetInitX); s_py[pos] = (short)hi; pos++; }
+        }
+      }
+      if (lane == 63) s_total = incl;
+      __syncthreads();
+      const int total = s_total;
+      float rect[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+      if (lane == 0) {
+        // ---- cv::convexHull(points, hull, clockwise = true, returnPoints = true), OpenCV 3.2 convhull.cpp
+        const short* ax = s_px; const short* ay = s_py;
+        int nout = 0, miny_ind = 0, maxy_ind = 0;
+        for (int i = 1; i < total; i++) {
+          int y = ay[i];
+          if (ay[miny_ind] > y) miny_ind = i;
+          if (ay[maxy_ind] < y) maxy_ind = i;
+        }
+        if (total > 0) {
+          if (ax[0] == ax[total - 1] && ay[0] == ay[total - 1]) {
+            s_hull[nout++] = 0;
+          } else {
+            short* tl_stack = s_stack;
+            int tl_count = sklansky(ax, ay, 0, maxy_ind, tl_stack, -1, 1);
+            short* tr_stack = s_stack + tl_count;
+            int tr_count = sklansky(ax, ay, total - 1, maxy_ind, tr_stack, -1, -1);
+            for (int i = 0; i < tl_count - 1; i++) s_hull[nout++] = tl_stack[i];
+            for (int i = tr_count - 1; i > 0; i--) s_hull[nout++] = tr_stack[i];
+            int stop_idx = tr_count > 2 ? tr_stack[1] : tl_count > 2 ? tl_stack[tl_count - 2] : -1;
+            short* bl_stack = s_stack;
+            int bl_count = sklansky(ax, ay, 0, miny_ind, bl_stack, 1, -1);
+            short* br_stack = s_stack + bl_count;
+            int br_count = sklansky(ax, ay, total - 1, miny_ind, br_stack, 1, 1);
+            { short* t = bl_stack; bl_stack = br_stack; br_stack = t; int cc = bl_count; bl_count = br_count; br_count = cc; }
+            if (stop_idx >= 0) {
+              int check_idx = bl_count > 2 ? bl_stack[1] : bl_count + br_count > 2 ? br_stack[2 - bl_count] : -1;
+              if (check_idx == stop_idx || (check_idx >= 0 && ax[check_idx] == ax[stop_idx] && ay[check_idx] == ay[stop_idx])) {
+                bl_count = bl_count < 2 ? bl_count : 2;
+                br_count = br_count < 2 ? br_count : 2;
+              }
+            }
+            for (int i = 0; i < bl_count - 1; i++) s_hull[nout++] = bl_stack[i];
+            for (int i = br_count - 1; i > 0; i--) s_hull[nout++] = br_stack[i];
+          }
+        }
+        const int hn = nout;
+        float cx = 0, cy = 0, w = 0, h = 0, angle = 0;
+        if (hn > kMaxHull) {
+          atomicOr(&c.counts[b * kCountsStride + kCntFlags], (int)kFlagHullOverflow);
+          cand.undefined = 1;
+        } else {
+          for (int i = 0; i < hn; i++) { s_hx[i] = (float)ax[s_hull[i]]; s_hy[i] = (float)ay[s_hull[i]]; }
+          if (hn > 2) {
+            // ---- rotatingCalipers(points, n, CALIPERS_MINAREARECT, out), OpenCV 3.2 rotcalipers.cpp
+            float minarea = 3.402823466e+38f;
+            int bi0 = 0, bi5 = 0; float b1 = 0, b2 = 0, b3 = 0, b4 = 0;
+            int left = 0, bottom = 0, right = 0, top = 0;
+            int seq[4] = {-1, -1, -1, -1};
+            float orientation = 0, base_a, base_b = 0;
+            float pt0x = s_hx[0], pt0y = s_hy[0];
+            float left_x = pt0x, right_x = pt0x, top_y = pt0y, bottom_y = pt0y;
+            for (int i = 0; i < hn; i++) {
+              if (pt0x < left_x) left_x = pt0x, left = i;
+              if (pt0x > right_x) right_x = pt0x, right = i;
+              if (pt0y > top_y) top_y = pt0y, top = i;
+              if (pt0y < bottom_y) bottom_y = pt0y, bottom = i;
+              int nx = (i + 1 < hn) ? i + 1 : 0;
+              float ptx = s_hx[nx], pty = s_hy[nx];
+              double dx = ptx - pt0x, dy = pty - pt0y;
+              s_vx[i] = (float)dx; s_vy[i] = (float)dy;
+              s_inv[i] = (float)(1. / sqrt(dx * dx + dy * dy));
+              pt0x = ptx; pt0y = pty;
+            }
+            {
+              double ax2 = s_vx[hn - 1], ay2 = s_vy[hn - 1];
+              for (int i = 0; i < hn; i++) {
+                double bx = s_vx[i], by = s_vy[i];
+                double convexity = ax2 * by - ay2 * bx;
+                if (convexity != 0) { orientation = (convexity > 0) ? 1.f : (-1.f); break; }
+                ax2 = bx; ay2 = by;
+              }
+            }
+            if (orientation != 0) {  // OpenCV asserts otherwise
+              base_a = orientation;
+              seq[0] = bottom; seq[1] = right; seq[2] = top; seq[3] = left;
+              for (int k = 0; k < hn; k++) {
+                float dp0 = +base_a * s_vx[seq[0]] + base_b * s_vy[seq[0]];
+                float dp1 = -base_b * s_vx[seq[1]] + base_a * s_vy[seq[1]];
+                float dp2 = -base_a * s_vx[seq[2]] - base_b * s_vy[seq[2]];
+                float dp3 = +base_b * s_vx[seq[3]] - base_a * s_vy[seq[3]];
+                float maxcos = dp0 * s_inv[seq[0]];
+                int main_element = 0;
+                float cosalpha = dp1 * s_inv[seq[1]];
+                if (cosalpha > maxcos) { main_element = 1; maxcos = cosalpha; }
+                cosalpha = dp2 * s_inv[seq[2]];
+                if (cosalpha > maxcos) { main_element = 2; maxcos = cosalpha; }
+                cosalpha = dp3 * s_inv[seq[3]];
+                if (cosalpha > maxcos) { main_element = 3; maxcos = cosalpha; }
+                {
+                  int pindex = seq[main_element];
+                  float lead_x = s_vx[pindex] * s_inv[pindex];
+                  float lead_y = s_vy[pindex] * s_inv[pindex];
+                  switch (main_element) {
+                    case 0: base_a = lead_x; base_b = lead_y; break;
+                    case 1: base_a = lead_y; base_b = -lead_x; break;
+                    case 2: base_a = -lead_x; base_b = -lead_y; break;
+                    default: base_a = -lead_y; base_b = lead_x; break;
+                  }
+                }
+                seq[main_element] += 1;
+                seq[main_element] = (seq[main_element] == hn) ? 0 : seq[main_element];
+                {
+                  float dx = s_hx[seq[1]] - s_hx[seq[3]];
+                  float dy = s_hy[seq[1]] - s_hy[seq[3]];
+                  float width = dx * base_a + dy * base_b;
+                  dx = s_hx[seq[2]] - s_hx[seq[0]];
+                  dy = s_hy[seq[2]] - s_hy[seq[0]];
+                  float height = -dx * base_b + dy * base_a;
+                  float area = width * height;
+                  if (area <= minarea) {
+                    minarea = area;
+                    bi0 = seq[3]; b1 = base_a; b2 = width; b3 = base_b; b4 = height; bi5 = seq[0];
+                  }
+                }
+              }
+              float A1 = b1, B1 = b3, A2 = -b3, B2 = b1;
+              float C1 = A1 * s_hx[bi0] + s_hy[bi0] * B1;
+              float C2 = A2 * s_hx[bi5] + s_hy[bi5] * B2;
+              float idet = 1.f / (A1 * B2 - A2 * B1);
+              float qx = (C1 * B2 - C2 * B1) * idet;
+              float qy = (A1 * C2 - A2 * C1) * idet;
+              float o2 = A1 * b2, o3 = B1 * b2, o4 = A2 * b4, o5 = B2 * b4;
+              // cv::minAreaRect
+              cx = qx + (o2 + o4) * 0.5f;
+              cy = qy + (o3 + o5) * 0.5f;
+              w = (float)sqrt((double)o2 * o2 + (double)o3 * o3);
+              h = (float)sqrt((double)o4 * o4 + (double)o5 * o5);
+              angle = (float)atan2((double)o3, (double)o2);
+            }
+          } else if (hn == 2) {
+            cx = (s_hx[0] + s_hx[1]) * 0.5f;
+            cy = (s_hy[0] + s_hy[1]) * 0.5f;
+            double dx = s_hx[1] - s_hx[0], dy = s_hy[1] - s_hy[0];
+            w = (float)sqrt(dx * dx + dy * dy);
+            h = 0;
+            angle = (float)atan2(dy, dx);
+          } else if (hn == 1) {
+            cx = s_hx[0]; cy = s_hy[0];
+          }
+          angle = (float)(angle * 180 / 3.1415926535897932384626433832795);
+          // RotatedRect::points
+          double _angle = angle * 3.1415926535897932384626433832795 / 180.;
+          float bb = (float)cos(_angle) * 0.5f;
+          float aa = (float)sin(_angle) * 0.5f;
+          rect[0] = cx - aa * h - bb * w;
+          rect[1] = cy + bb * h - aa * w;
+          rect[2] = cx + aa * h - bb * w;
+          rect[3] = cy - bb * h - aa * w;
+          rect[4] = 2 * cx - rect[0];
+          rect[5] = 2 * cy - rect[1];
+          rect[6] = 2 * cx - rect[2];
+          rect[7] = 2 * cy - rect[3];
+        }
+        // getPointsInPcFrame :75-95
+        for (int i = 0; i < 4; i++) {
+          float picX = rect[2 * i], picY = rect[2 * i + 1];
+          float rOffsetX = picX - (float)offsetInitX;
+          float rOffsetY = picY - (float)offsetInitY;
+          float rX = rOffsetX;
+          float rY = p.pic_full - rOffsetY;
+          float rmX = rX / p.pic_scale;
+          float rmY = rY / p.pic_scale;
+          pc[2 * i] = rmX - p.roi_half;
+          pc[2 * i + 1] = rmY - p.roi_half;
+        }
+        promising = !cand.undefined && rule_based_filter(p, pc, maxZ, numPoints);
+      }
+      __syncthreads();
+    }
+    if (lane == 0) {
+      if (!cand.undefined) for (int k = 0; k < 8; k++) cand.pc[k] = pc[k];
+      cand.accepted = promising ? 1 : 0;
+      c.cand[(long)b * kMaxClusters + ci] = cand;
+    }
+    __syncthreads();
+  }
+}
+
+// ------------------------------------------------------------------------------------------ B3
+constexpr int kFinalBlock = 256;
+__global__ void MOT_LAUNCH_BOUNDS(kFinalBlock)
+box_finalize_kernel(MotDevParams p, ClusterBuffers c) {
+  __shared__ int s_wave[kFinalBlock / 64];
+  __shared__ int s_base, s_undef;
+  const int b = blockIdx.x;
+  const int num_cluster = min(c.counts[b * kCountsStride + kCntClusters], kMaxClusters);
+  const int lane = lane_id(), wave = threadIdx.x >> 6;
+  if (threadIdx.x == 0) {
+    s_base = 0; s_undef = 0;
+    if (c.counts[b * kCountsStride + kCntClusters] > kMaxClusters) atomicOr(&c.counts[b * kCountsStride + kCntFlags], (int)kFlagClusterOverflow);
+  }
+  __syncthreads();
+  for (int base = 0; base < num_cluster; base += kFinalBlock) {
+    int ci = base + threadIdx.x;
+    BoxCandidate cand; cand.accepted = 0; cand.undefined = 0;
+    if (ci < num_cluster) cand = c.cand[(long)b * kMaxClusters + ci];
+    unsigned long long acc = __ballot(cand.accepted != 0);
+    unsigned long long und = __ballot(cand.undefined != 0);
+    if (lane == 0) { s_wave[wave] = __popcll(acc); if (und) atomicAdd(&s_undef, __popcll(und)); }
+    __syncthreads();
+    int off = s_base;
+    for (int w2 = 0; w2 < wave; w2++) off += s_wave[w2];
+    if (cand.accepted) {
+      int slot = off + __popcll(acc & ((1ull << lane) - 1ull));
+      if (slot < kMaxBoxesPerFrame) {
+        float* o = c.boxes + ((long)b * kMaxBoxesPerFrame + slot) * 24;  // :379-389: 4 bottom, 4 top corners
+        for (int hh = 0; hh < 2; hh++)
+          for (int q = 0; q < 4; q++) {
+            o[(hh * 4 + q) * 3 + 0] = cand.pc[2 * q];
+            o[(hh * 4 + q) * 3 + 1] = cand.pc[2 * q + 1];
+            o[(hh * 4 + q) * 3 + 2] = hh == 0 ? -p.sensor_height : cand.max_z;
+          }
+        c.box_cluster[(long)b * kMaxBoxesPerFrame + slot] = ci + 1;
+      }
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) { int t = 0; for (int w2 = 0; w2 < kFinalBlock / 64; w2++) t += s_wave[w2]; s_base += t; }
+    // re-arm the statistics of the clusters just consumed
+    if (ci < num_cluster) {
+      ClusterStats s;
+      s.count = 0; s.first = 0x7fffffff; s.maxz_key = mot_float_key(-99.f); s.pad = 0;
+      s.argmin = kArgminInit; s.argmax = kArgmaxInit;
+      c.stats[(long)b * kMaxClusters + ci] = s;
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    int nb = s_base;
+    if (nb > kMaxBoxesPerFrame) { atomicOr(&c.counts[b * kCountsStride + kCntFlags], (int)kFlagBoxOverflow); nb = kMaxBoxesPerFrame; }
+    c.counts[b * kCountsStride + kCntBoxes] = nb;
+    c.counts[b * kCountsStride + kCntUndef] = s_undef;
+  }
+}
+
+// ------------------------------------------------------------------------------------------ host
+void mot_launch_stats_init(const ClusterBuffers& c, int batch, hipStream_t stream) {
+  hipLaunchKernelGGL(stats_init_kernel, dim3((kMaxClusters + 255) / 256, batch), dim3(256), 0, stream, c);
+}
+
+void mot_launch_box_kernel(int which, const MotDevParams& p, const ClusterBuffers& c, int batch, int max_n, hipStream_t stream) {
+  int chunks = (max_n + kLabelChunk - 1) / kLabelChunk;
+  if (chunks < 1) chunks = 1;
+  if (which == 0) hipLaunchKernelGGL(label_stats_kernel, dim3(chunks, batch), dim3(kLabelBlock), 0, stream, p, c);
+  else if (which == 1) hipLaunchKernelGGL(cluster_box_kernel, dim3(64, batch), dim3(kBoxBlock), 0, stream, p, c);
+  else if (which == 2) hipLaunchKernelGGL(box_finalize_kernel, dim3(batch), dim3(kFinalBlock), 0, stream, p, c);
+}
+
+void mot_launch_box(const MotDevParams& p, const ClusterBuffers& c, int batch, int max_n, hipStream_t stream) {
+  mot_launch_box_kernel(0, p, c, batch, max_n, stream);
+  mot_launch_box_kernel(1, p, c, batch, max_n, stream);
+  mot_launch_box_kernel(2, p, c, batch, max_n, stream);
+}

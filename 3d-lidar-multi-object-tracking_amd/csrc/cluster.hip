@@ -1,0 +1,277 @@
+// cluster.hip — 2-D grid connected-component clustering on gfx950. Product code (HIP, wave64).
+//
+// Replaces componentClustering() = mapCartesianGrid() + findComponent()/search()
+// (OT/src/cluster/component_clustering.cpp:28-268) for a batch of frames:
+//
+//   C1 cart_occupancy_kernel   N_e pts -> two bit-planes per frame ("cell seen >= 1", "seen >= 2")
+//   C2 ccl_kernel              bit-plane -> 3x3 dilation -> connected components -> int32 label grid
+//
+// Design (not a translation of the recursive flood fill):
+//  * the reference only needs "count > 1" per cell, so the 250 x 250 counter histogram collapses to two
+//    bit-planes (2 x 8 KB) that live in LDS per workgroup; points set bits with LDS atomicOr, and a workgroup
+//    merges into the frame's planes in L2 with one returning atomicOr per non-zero word (a bit that two
+//    workgroups both saw once is promoted to the ">= 2" plane by whoever merges second).
+//  * one workgroup labels a whole frame from LDS: rows are 256-bit words, dilation is shifts and ORs,
+//    components are found over RUNS of set bits (not cells) with a lock-free union-find hooked by
+//    atomicCAS towards the smaller run ordinal; run ordinals are in raster order, so the root of a component
+//    is its first cell in the reference's scan order (for x { for y }), and the reference's cluster id is
+//    1 + (number of roots before it) — a popcount prefix. No recursion, no iteration-until-convergence.
+#include "mot_internal.h"
+
+#ifndef MOT_HIPEMU
+#define MOT_LAUNCH_BOUNDS(n) __launch_bounds__(n)
+#else
+#define MOT_LAUNCH_BOUNDS(n)
+#endif
+
+constexpr int kOccBlock = 256;
+constexpr int kOccItems = 8;
+constexpr int kOccChunk = kOccBlock * kOccItems;
+
+// ------------------------------------------------------------------------------------------ C1
+// mapCartesianGrid :36-50 (the histogram) — the threshold (:136) is applied by choosing the plane in C2
+__global__ void MOT_LAUNCH_BOUNDS(kOccBlock)
+cart_occupancy_kernel(MotDevParams p, ClusterBuffers c) {
+  __shared__ unsigned s_a[kPlaneWords];
+  __shared__ unsigned s_b[kPlaneWords];
+  const int b = blockIdx.y;
+  const int n = c.counts[b * kCountsStride + kCntElev];
+  const long base = (long)blockIdx.x * kOccChunk;
+  if (base >= n) return;
+  for (int i = threadIdx.x; i < kPlaneWords; i += kOccBlock) { s_a[i] = 0u; s_b[i] = 0u; }
+  __syncthreads();
+  const float4* __restrict__ pts = c.elevated + (long)b * c.cap;
+#pragma unroll
+  for (int k = 0; k < kOccItems; k++) {
+    long i = base + k * kOccBlock + threadIdx.x;
+    if (i < n) {
+      float4 q = pts[i];
+      int xI, yI;
+      if (mot_cart_cell(p, q.x, q.y, &xI, &yI)) {
+        int bit = xI * MOT_MAX_GRID + yI;
+        unsigned m = 1u << (bit & 31);
+        unsigned old = atomicOr(&s_a[bit >> 5], m);
+        if (old & m) atomicOr(&s_b[bit >> 5], m);
+      }
+    }
+  }
+  __syncthreads();
+  unsigned* __restrict__ ga = c.plane_a + (long)b * kPlaneWords;
+  unsigned* __restrict__ gb = c.plane_b + (long)b * kPlaneWords;
+  for (int i = threadIdx.x; i < kPlaneWords; i += kOccBlock) {
+    unsigned a = s_a[i];
+    if (a) {
+      unsigned old = atomicOr(&ga[i], a);
+      unsigned twice = s_b[i] | (old & a);
+      if (twice) atomicOr(&gb[i], twice);
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------ C2
+constexpr int kCclBlock = 1024;
+
+// helpers on a 256-bit row stored as 8 words in LDS (bits >= num_grid are always 0)
+__device__ __forceinline__ int row_next_set(const unsigned* row, int p) {   // smallest q >= p with bit set, or 256
+  if (p >= 256) return 256;
+  int w = p >> 5;
+  unsigned v = row[w] & (0xffffffffu << (p & 31));
+  while (true) {
+    if (v) return (w << 5) + __ffs(v) - 1;
+    if (++w == kRowWords) return 256;
+    v = row[w];
+  }
+}
+__device__ __forceinline__ int row_next_clear(const unsigned* row, int p) { // smallest q >= p with bit clear, or 256
+  if (p >= 256) return 256;
+  int w = p >> 5;
+  unsigned v = ~row[w] & (0xffffffffu << (p & 31));
+  while (true) {
+    if (v) return (w << 5) + __ffs(v) - 1;
+    if (++w == kRowWords) return 256;
+    v = ~row[w];
+  }
+}
+__device__ __forceinline__ int row_run_start(const unsigned* row, int q) {  // bit q is set: first bit of its run
+  int w = q >> 5;
+  // clear bits at or below q, looking downwards
+  unsigned v = ~row[w] & (0xffffffffu >> (31 - (q & 31)));
+  while (true) {
+    if (v) return (w << 5) + (32 - __clz((int)v));  // one above the highest clear bit below q
+    if (w == 0) return 0;
+    --w;
+    v = ~row[w];
+  }
+}
+
+__global__ void MOT_LAUNCH_BOUNDS(kCclBlock)
+ccl_kernel(MotDevParams p, ClusterBuffers c) {
+  __shared__ unsigned s_occ[kPlaneWords];        // occupancy after dilation
+  __shared__ unsigned s_aux[kPlaneWords];        // horizontal dilation, then run-start bits
+  __shared__ unsigned s_parent[kMaxRuns];        // union-find over runs
+  __shared__ int s_rowbase[MOT_MAX_GRID + 1];    // exclusive prefix of runs per row
+  __shared__ unsigned s_isroot[kMaxRuns / 32];
+  __shared__ int s_rootpre[kMaxRuns / 32 + 1];
+  const int b = blockIdx.x;
+  const int G = p.num_grid;
+  const int tid = threadIdx.x;
+  unsigned* __restrict__ ga = c.plane_a + (long)b * kPlaneWords;
+  unsigned* __restrict__ gb = c.plane_b + (long)b * kPlaneWords;
+
+  // occupied cells: count > 1 (OT) or any point (OT0); consume and clear the frame's planes
+  for (int i = tid; i < kPlaneWords; i += kCclBlock) {
+    unsigned a = ga[i], bb = gb[i];
+    if (a) ga[i] = 0u;
+    if (bb) gb[i] = 0u;
+    s_occ[i] = p.occ_min_count >= 2 ? bb : a;
+  }
+  for (int i = tid; i <= MOT_MAX_GRID; i += kCclBlock) s_rowbase[i] = 0;
+  __syncthreads();
+  if (p.dilate) {  // clipped 3x3 dilation, component_clustering.cpp:134-214 (separable)
+    for (int i = tid; i < kPlaneWords; i += kCclBlock) {
+      int x = i >> 3, w = i & 7;
+      unsigned v = s_occ[i];
+      unsigned prev = w > 0 ? s_occ[i - 1] : 0u, next = w < kRowWords - 1 ? s_occ[i + 1] : 0u;
+      unsigned h = v | (v << 1) | (v >> 1) | (prev >> 31) | (next << 31);
+      int lo = w << 5;  // mask columns >= G
+      unsigned keep = (G - lo >= 32) ? 0xffffffffu : (G - lo <= 0 ? 0u : ((1u << (G - lo)) - 1u));
+      s_aux[i] = (x < G) ? (h & keep) : 0u;
+    }
+    __syncthreads();
+    for (int i = tid; i < kPlaneWords; i += kCclBlock) {
+      int x = i >> 3;
+      unsigned v = s_aux[i];
+      if (x > 0) v |= s_aux[i - kRowWords];
+      if (x < G - 1) v |= s_aux[i + kRowWords];
+      s_occ[i] = (x < G) ? v : 0u;
+    }
+    __syncthreads();
+  }
+  // run starts: set bit whose lower neighbour (same row) is clear
+  for (int i = tid; i < kPlaneWords; i += kCclBlock) {
+    int x = i >> 3, w = i & 7;
+    unsigned v = s_occ[i];
+    unsigned carry = w > 0 ? (s_occ[i - 1] >> 31) : 0u;
+    unsigned st = v & ~((v << 1) | carry);
+    s_aux[i] = st;
+    if (st) atomicAdd(&s_rowbase[x + 1], __popc(st));
+  }
+  __syncthreads();
+  if (tid < 64) {  // exclusive scan of the per-row run counts (257 entries, 5 per lane)
+    int v[5], sum = 0;
+#pragma unroll
+    for (int k = 0; k < 5; k++) { int idx = tid * 5 + k; v[k] = idx <= MOT_MAX_GRID ? s_rowbase[idx] : 0; sum += v[k]; }
+    int incl = sum;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) { int o = __shfl_up(incl, d, 64); if (tid >= d) incl += o; }
+    int run = incl - sum;
+#pragma unroll
+    for (int k = 0; k < 5; k++) { int idx = tid * 5 + k; run += v[k]; if (idx <= MOT_MAX_GRID) s_rowbase[idx] = run; }
+  }
+  __syncthreads();
+  // after the scan s_rowbase[x+1] = number of runs in rows 0..x, i.e. base of row x is s_rowbase[x]
+  const int R = s_rowbase[MOT_MAX_GRID];
+  for (int r = tid; r < R; r += kCclBlock) s_parent[r] = (unsigned)r;
+  __syncthreads();
+
+  // ordinal of the run that starts at bit s of row x
+#define RUN_ORDINAL(x, s)                                                                              \
+  ({ int ord_ = s_rowbase[(x)]; const unsigned* st_ = &s_aux[(x) * kRowWords];                          \
+     for (int w_ = 0; w_ < ((s) >> 5); w_++) ord_ += __popc(st_[w_]);                                   \
+     ord_ + __popc(st_[(s) >> 5] & ((1u << ((s) & 31)) - 1u)); })
+
+  // union every run with the runs of the previous row it touches (8-connectivity: columns s-1 .. e+1)
+  for (int i = tid; i < kPlaneWords; i += kCclBlock) {
+    int x = i >> 3, w = i & 7;
+    unsigned st = s_aux[i];
+    if (x == 0 || x >= G) st = 0u;
+    const unsigned* row = &s_occ[x * kRowWords];
+    const unsigned* up = &s_occ[(x > 0 ? x - 1 : 0) * kRowWords];
+    int ord = 0;
+    if (st) { ord = s_rowbase[x]; for (int w2 = 0; w2 < w; w2++) ord += __popc(s_aux[x * kRowWords + w2]); }
+    while (st) {
+      int bit = __ffs(st) - 1;
+      st &= st - 1u;
+      int s = (w << 5) + bit;
+      int e = row_next_clear(row, s) - 1;
+      int lo = s > 0 ? s - 1 : 0, hi = e + 1 < G ? e + 1 : G - 1;
+      unsigned a = (unsigned)ord++;
+      int q = row_next_set(up, lo);
+      while (q <= hi) {
+        int s2 = row_run_start(up, q);
+        unsigned bb = (unsigned)RUN_ORDINAL(x - 1, s2);
+        // lock-free union, hook the larger root under the smaller one
+        unsigned ra = a, rb = bb;
+        while (s_parent[ra] != ra) ra = s_parent[ra];
+        while (s_parent[rb] != rb) rb = s_parent[rb];
+        while (ra != rb) {
+          if (ra < rb) { unsigned t = ra; ra = rb; rb = t; }
+          unsigned old = atomicCAS(&s_parent[ra], ra, rb);
+          if (old == ra) break;
+          ra = old;
+          while (s_parent[ra] != ra) ra = s_parent[ra];
+          while (s_parent[rb] != rb) rb = s_parent[rb];
+        }
+        q = row_next_set(up, row_next_clear(up, q));
+      }
+    }
+  }
+  __syncthreads();
+  for (int r = tid; r < R; r += kCclBlock) {  // flatten (only roots are ever written)
+    unsigned v = (unsigned)r;
+    while (s_parent[v] != v) v = s_parent[v];
+    s_parent[r] = v;
+  }
+  __syncthreads();
+  for (int j = tid; j < kMaxRuns / 32; j += kCclBlock) {
+    unsigned bits = 0u;
+    int r0 = j << 5;
+    if (r0 < R)
+      for (int k = 0; k < 32 && r0 + k < R; k++)
+        if (s_parent[r0 + k] == (unsigned)(r0 + k)) bits |= 1u << k;
+    s_isroot[j] = bits;
+    s_rootpre[j + 1] = __popc(bits);
+  }
+  if (tid == 0) s_rootpre[0] = 0;
+  __syncthreads();
+  if (tid < 64) {  // inclusive scan of 1024 word counts, 16 per lane
+    int sum = 0;
+    for (int k = 0; k < 16; k++) sum += s_rootpre[1 + tid * 16 + k];
+    int incl = sum;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) { int o = __shfl_up(incl, d, 64); if (tid >= d) incl += o; }
+    int run = incl - sum;
+    for (int k = 0; k < 16; k++) { run += s_rootpre[1 + tid * 16 + k]; s_rootpre[1 + tid * 16 + k] = run; }
+  }
+  __syncthreads();
+  const int num_cluster = s_rootpre[kMaxRuns / 32];
+  if (tid == 0) c.counts[b * kCountsStride + kCntClusters] = num_cluster;
+  // label grid, x-major with stride G (cartesianData[x][y]); ids in raster order of each component's first cell
+  int* __restrict__ grid = c.grid + (long)b * (MOT_MAX_GRID * MOT_MAX_GRID);
+  for (int cell = tid; cell < G * G; cell += kCclBlock) {
+    int x = cell / G, y = cell - x * G;
+    const unsigned* row = &s_occ[x * kRowWords];
+    int label = 0;
+    if ((row[y >> 5] >> (y & 31)) & 1u) {
+      int s = row_run_start(row, y);
+      unsigned root = s_parent[RUN_ORDINAL(x, s)];
+      label = 1 + s_rootpre[root >> 5] + __popc(s_isroot[root >> 5] & ((1u << (root & 31)) - 1u));
+    }
+    grid[cell] = label;
+  }
+#undef RUN_ORDINAL
+}
+
+// ------------------------------------------------------------------------------------------ host
+void mot_launch_cluster_kernel(int which, const MotDevParams& p, const ClusterBuffers& c, int batch, int max_n,
+                               hipStream_t stream) {
+  int chunks = (max_n + kOccChunk - 1) / kOccChunk;
+  if (chunks < 1) chunks = 1;
+  if (which == 0) hipLaunchKernelGGL(cart_occupancy_kernel, dim3(chunks, batch), dim3(kOccBlock), 0, stream, p, c);
+  else if (which == 1) hipLaunchKernelGGL(ccl_kernel, dim3(batch), dim3(kCclBlock), 0, stream, p, c);
+}
+
+void mot_launch_cluster(const MotDevParams& p, const ClusterBuffers& c, int batch, int max_n, hipStream_t stream) {
+  mot_launch_cluster_kernel(0, p, c, batch, max_n, stream);
+  mot_launch_cluster_kernel(1, p, c, batch, max_n, stream);
+}

@@ -181,7 +181,7 @@ classify_compact_kernel(MotDevParams p, GroundBuffers g) {
   const int n = g.n[b];
   const int nchunks = (n + kGroundChunk - 1) / kGroundChunk;
   if ((int)blockIdx.x >= nchunks) {
-    if (nchunks == 0 && blockIdx.x == 0 && threadIdx.x == 0) { g.counts[b * 4 + 0] = 0; g.counts[b * 4 + 1] = 0; g.counts[b * 4 + 2] = 0; }
+    if (nchunks == 0 && blockIdx.x == 0 && threadIdx.x == 0) { g.counts[b * kCountsStride + kCntElev] = 0; g.counts[b * kCountsStride + kCntGround] = 0; g.counts[b * kCountsStride + kCntDropped] = 0; }
     return;
   }
   if (threadIdx.x == 0) {
@@ -270,7 +270,7 @@ classify_compact_kernel(MotDevParams p, GroundBuffers g) {
       s_base_e = (int)excl_e; s_base_g = (int)excl_g;
       if (chunk == nchunks - 1) {
         int ne = (int)excl_e + tot_e, ng = (int)excl_g + tot_g;
-        g.counts[b * 4 + 0] = ne; g.counts[b * 4 + 1] = ng; g.counts[b * 4 + 2] = n - ne - ng;
+        g.counts[b * kCountsStride + kCntElev] = ne; g.counts[b * kCountsStride + kCntGround] = ng; g.counts[b * kCountsStride + kCntDropped] = n - ne - ng;
       }
     }
   }

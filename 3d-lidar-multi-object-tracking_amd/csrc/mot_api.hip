@@ -7,6 +7,7 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <random>
 #include <string>
 #include <vector>
 
@@ -32,6 +33,16 @@ struct mot_ctx {
   int* d_counts = nullptr;
   int max_chunks = 0;
   unsigned epoch = 0;
+  // cluster + box stages
+  unsigned* d_plane_a = nullptr;
+  unsigned* d_plane_b = nullptr;
+  int* d_grid = nullptr;
+  int* d_label = nullptr;
+  ClusterStats* d_stats = nullptr;
+  BoxCandidate* d_cand = nullptr;
+  float* d_boxes = nullptr;
+  int* d_box_cluster = nullptr;
+  unsigned long long* d_rng = nullptr;
   // host mirrors
   std::vector<int> h_n;
   int* h_counts = nullptr;  // pinned [batch][4]
@@ -99,6 +110,8 @@ extern "C" int mot_params_preset(int preset, mot_params* o) {
 static int make_dev_params(const mot_params& p, MotDevParams* d, std::string* err) {
   if (p.gauss_samples != 3) { *err = "gauss_samples must be 3"; return MOT_E_ARG; }
   if (p.num_grid < 8 || p.num_grid > MOT_MAX_GRID) { *err = "num_grid out of range"; return MOT_E_ARG; }
+  if (p.ram_points < 1 || p.ram_points > 128) { *err = "ram_points must be in 1..128"; return MOT_E_ARG; }
+  if (!(p.pic_scale * p.roi_m <= 1000.f)) { *err = "pic_scale * roi_m must be <= 1000 pixels"; return MOT_E_ARG; }
   memset(d, 0, sizeof *d);
   d->r_min = p.r_min; d->r_max = p.r_max; d->r_span = p.r_max - p.r_min;
   d->t_hmin = p.t_hmin; d->t_hmax = p.t_hmax; d->t_hdiff = p.t_hdiff; d->h_sensor = p.h_sensor;
@@ -131,13 +144,22 @@ static int make_dev_params(const mot_params& p, MotDevParams* d, std::string* er
 
 extern "C" void mot_destroy(mot_ctx* c) {
   if (!c) return;
-  void* bufs[] = {c->d_in, c->d_n, c->d_minz, c->d_hg, c->d_desc, c->d_ticket, c->d_elev, c->d_ground, c->d_mask, c->d_counts};
+  void* bufs[] = {c->d_in, c->d_n, c->d_minz, c->d_hg, c->d_desc, c->d_ticket, c->d_elev, c->d_ground, c->d_mask, c->d_counts,
+                  c->d_plane_a, c->d_plane_b, c->d_grid, c->d_label, c->d_stats, c->d_cand, c->d_boxes, c->d_box_cluster, c->d_rng};
   for (void* b : bufs) if (b) (void)hipFree(b);
   if (c->h_counts) (void)hipHostFree(c->h_counts);
   if (c->ev0) (void)hipEventDestroy(c->ev0);
   if (c->ev1) (void)hipEventDestroy(c->ev1);
   if (c->stream) (void)hipStreamDestroy(c->stream);
   delete c;
+}
+
+static ClusterBuffers cluster_buffers(mot_ctx* c) {
+  ClusterBuffers b;
+  b.elevated = c->d_elev; b.cap = c->cap; b.counts = c->d_counts; b.plane_a = c->d_plane_a; b.plane_b = c->d_plane_b;
+  b.grid = c->d_grid; b.label = c->d_label; b.stats = c->d_stats; b.cand = c->d_cand; b.boxes = c->d_boxes;
+  b.box_cluster = c->d_box_cluster; b.rng = c->d_rng;
+  return b;
 }
 
 static int create_impl(mot_ctx* c) {
@@ -159,10 +181,33 @@ static int create_impl(mot_ctx* c) {
   MOT_HIP(c, hipMalloc(&c->d_elev, B * N * sizeof(float4)));
   MOT_HIP(c, hipMalloc(&c->d_ground, B * N * sizeof(float4)));
   MOT_HIP(c, hipMalloc(&c->d_mask, B * N));
-  MOT_HIP(c, hipMalloc(&c->d_counts, B * 4 * sizeof(int)));
-  MOT_HIP(c, hipHostMalloc(&c->h_counts, B * 4 * sizeof(int), hipHostMallocDefault));
+  MOT_HIP(c, hipMalloc(&c->d_counts, B * kCountsStride * sizeof(int)));
+  MOT_HIP(c, hipHostMalloc(&c->h_counts, B * kCountsStride * sizeof(int), hipHostMallocDefault));
+  MOT_HIP(c, hipMalloc(&c->d_plane_a, B * kPlaneWords * sizeof(unsigned)));
+  MOT_HIP(c, hipMalloc(&c->d_plane_b, B * kPlaneWords * sizeof(unsigned)));
+  MOT_HIP(c, hipMalloc(&c->d_grid, B * MOT_MAX_GRID * MOT_MAX_GRID * sizeof(int)));
+  MOT_HIP(c, hipMalloc(&c->d_label, B * N * sizeof(int)));
+  MOT_HIP(c, hipMalloc(&c->d_stats, B * kMaxClusters * sizeof(ClusterStats)));
+  MOT_HIP(c, hipMalloc(&c->d_cand, B * kMaxClusters * sizeof(BoxCandidate)));
+  MOT_HIP(c, hipMalloc(&c->d_boxes, B * kMaxBoxesPerFrame * 24 * sizeof(float)));
+  MOT_HIP(c, hipMalloc(&c->d_box_cluster, B * kMaxBoxesPerFrame * sizeof(int)));
+  MOT_HIP(c, hipMalloc(&c->d_rng, kRngTable * sizeof(unsigned long long)));
+  {  // mt19937_64 mt(0), box_fitting.cpp:303 — raw draws; the libstdc++ range mapping is applied on the device
+    std::mt19937_64 mt(0);
+    unsigned long long raw[kRngTable];
+    for (int i = 0; i < kRngTable; i++) raw[i] = mt();
+    MOT_HIP(c, hipMemcpyAsync(c->d_rng, raw, sizeof raw, hipMemcpyHostToDevice, c->stream));
+    MOT_HIP(c, hipStreamSynchronize(c->stream));
+  }
+  MOT_HIP(c, hipMemsetAsync(c->d_plane_a, 0, B * kPlaneWords * sizeof(unsigned), c->stream));
+  MOT_HIP(c, hipMemsetAsync(c->d_plane_b, 0, B * kPlaneWords * sizeof(unsigned), c->stream));
+  MOT_HIP(c, hipMemsetAsync(c->d_grid, 0, B * MOT_MAX_GRID * MOT_MAX_GRID * sizeof(int), c->stream));
+  {
+    ClusterBuffers cb = cluster_buffers(c);
+    mot_launch_stats_init(cb, (int)B, c->stream);
+  }
   MOT_HIP(c, hipMemsetD32Async(c->d_minz, kMinzInit, B * MOT_POLAR_CELLS, c->stream));
-  MOT_HIP(c, hipMemsetAsync(c->d_counts, 0, B * 4 * sizeof(int), c->stream));
+  MOT_HIP(c, hipMemsetAsync(c->d_counts, 0, B * kCountsStride * sizeof(int), c->stream));
   MOT_HIP(c, hipMemsetAsync(c->d_n, 0, B * sizeof(int), c->stream));
   MOT_HIP(c, hipMemsetAsync(c->d_ticket, 0, B * sizeof(int), c->stream));
   MOT_HIP(c, hipMemsetAsync(c->d_desc, 0, B * c->max_chunks * sizeof(unsigned long long), c->stream));
@@ -245,17 +290,103 @@ extern "C" int mot_frames_dev(mot_ctx* c, const float* d_xyzw, long frame_stride
   if ((rc = next_epoch(c))) return rc;
   GroundBuffers g = ground_buffers(c, c->last_in, c->last_in_stride, true);
   mot_launch_ground(c->dp, g, batch, c->last_max_n, c->stream);
+  ClusterBuffers cb = cluster_buffers(c);
+  mot_launch_cluster(c->dp, cb, batch, c->last_max_n, c->stream);
+  mot_launch_box(c->dp, cb, batch, c->last_max_n, c->stream);
   MOT_HIP(c, hipGetLastError());
   (void)run_tracker; (void)timestamps; (void)ego_v; (void)ego_yaw;
   return MOT_OK;
 }
 
+// D2H of the per-frame counters (synchronises); device-side capacity flags become MOT_E_CAPACITY
+static int fetch_counts(mot_ctx* c, int slot) {
+  int* h = c->h_counts + slot * kCountsStride;
+  MOT_HIP(c, hipMemcpyAsync(h, c->d_counts + slot * kCountsStride, kCountsStride * sizeof(int), hipMemcpyDeviceToHost, c->stream));
+  MOT_HIP(c, hipStreamSynchronize(c->stream));
+  if (h[kCntFlags]) {
+    int f = h[kCntFlags];
+    MOT_HIP(c, hipMemsetAsync(c->d_counts + slot * kCountsStride + kCntFlags, 0, sizeof(int), c->stream));
+    if (f & kFlagClusterOverflow) return fail(c, MOT_E_CAPACITY, "more clusters in a frame than the library supports (4096)");
+    if (f & kFlagBoxOverflow) return fail(c, MOT_E_CAPACITY, "more boxes in a frame than the library supports (1024)");
+    if (f & kFlagHullOverflow) return fail(c, MOT_E_CAPACITY, "convex hull larger than 512 vertices");
+    if (f & kFlagRngExhausted) return fail(c, MOT_E_CAPACITY, "L-shape sampling ran out of pre-generated random draws");
+  }
+  return MOT_OK;
+}
+
+static int set_count(mot_ctx* c, int slot, int which, int value) {
+  c->h_counts[slot * kCountsStride + which] = value;
+  MOT_HIP(c, hipMemcpyAsync(c->d_counts + slot * kCountsStride + which, c->h_counts + slot * kCountsStride + which, sizeof(int),
+                            hipMemcpyHostToDevice, c->stream));
+  return MOT_OK;
+}
+
+extern "C" int mot_get_clusters(mot_ctx* c, int slot, int32_t* grid, int* num_cluster, int32_t* point_label) {
+  if (!c || slot < 0 || slot >= c->batch) return MOT_E_ARG;
+  int rc = fetch_counts(c, slot);
+  if (rc) return rc;
+  const int G = c->params.num_grid;
+  if (num_cluster) *num_cluster = c->h_counts[slot * kCountsStride + kCntClusters];
+  if (grid) MOT_HIP(c, hipMemcpyAsync(grid, c->d_grid + (size_t)slot * MOT_MAX_GRID * MOT_MAX_GRID, (size_t)G * G * sizeof(int), hipMemcpyDeviceToHost, c->stream));
+  int ne = c->h_counts[slot * kCountsStride + kCntElev];
+  if (point_label && ne > 0) MOT_HIP(c, hipMemcpyAsync(point_label, c->d_label + (size_t)slot * c->cap, (size_t)ne * sizeof(int), hipMemcpyDeviceToHost, c->stream));
+  MOT_HIP(c, hipStreamSynchronize(c->stream));
+  return MOT_OK;
+}
+
+extern "C" int mot_get_boxes(mot_ctx* c, int slot, float* boxes, int max_boxes, int* n_boxes, int32_t* box_cluster, int* n_undefined) {
+  if (!c || slot < 0 || slot >= c->batch || max_boxes < 0) return MOT_E_ARG;
+  int rc = fetch_counts(c, slot);
+  if (rc) return rc;
+  int nb = c->h_counts[slot * kCountsStride + kCntBoxes];
+  if (n_boxes) *n_boxes = nb;
+  if (n_undefined) *n_undefined = c->h_counts[slot * kCountsStride + kCntUndef];
+  if (nb > max_boxes) return fail(c, MOT_E_CAPACITY, "more boxes than the caller's buffer holds");
+  if (boxes && nb > 0) MOT_HIP(c, hipMemcpyAsync(boxes, c->d_boxes + (size_t)slot * kMaxBoxesPerFrame * 24, (size_t)nb * 24 * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+  if (box_cluster && nb > 0) MOT_HIP(c, hipMemcpyAsync(box_cluster, c->d_box_cluster + (size_t)slot * kMaxBoxesPerFrame, (size_t)nb * sizeof(int), hipMemcpyDeviceToHost, c->stream));
+  MOT_HIP(c, hipStreamSynchronize(c->stream));
+  return MOT_OK;
+}
+
+extern "C" int mot_cluster(mot_ctx* c, const float* elev, int n, int32_t* grid, int* num_cluster, int32_t* point_label) {
+  if (!c || (!elev && n > 0) || n < 0 || !grid || !num_cluster) return MOT_E_ARG;
+  if (n > c->cap) return fail(c, MOT_E_CAPACITY, "cloud has more points than max_points");
+  int rc;
+  if (n > 0) MOT_HIP(c, hipMemcpyAsync(c->d_elev, elev, (size_t)n * 16, hipMemcpyHostToDevice, c->stream));
+  if ((rc = set_count(c, 0, kCntElev, n))) return rc;
+  ClusterBuffers cb = cluster_buffers(c);
+  mot_launch_cluster(c->dp, cb, 1, n, c->stream);
+  if (point_label) {  // getClusteredPoints' per-point lookup; the statistics it also gathers are discarded
+    mot_launch_box_kernel(0, c->dp, cb, 1, n, c->stream);
+    mot_launch_stats_init(cb, 1, c->stream);
+  }
+  MOT_HIP(c, hipGetLastError());
+  return mot_get_clusters(c, 0, grid, num_cluster, point_label);
+}
+
+extern "C" int mot_box_fit(mot_ctx* c, const float* elev, int n, const int32_t* grid, int num_cluster, float* boxes, int max_boxes,
+                           int* n_boxes, int32_t* box_cluster, int* n_undefined) {
+  if (!c || (!elev && n > 0) || n < 0 || !grid || num_cluster < 0 || !n_boxes) return MOT_E_ARG;
+  if (n > c->cap) return fail(c, MOT_E_CAPACITY, "cloud has more points than max_points");
+  if (num_cluster > kMaxClusters) return fail(c, MOT_E_CAPACITY, "more clusters than the library supports (4096)");
+  int rc;
+  const int G = c->params.num_grid;
+  if (n > 0) MOT_HIP(c, hipMemcpyAsync(c->d_elev, elev, (size_t)n * 16, hipMemcpyHostToDevice, c->stream));
+  MOT_HIP(c, hipMemcpyAsync(c->d_grid, grid, (size_t)G * G * sizeof(int), hipMemcpyHostToDevice, c->stream));
+  if ((rc = set_count(c, 0, kCntElev, n))) return rc;
+  if ((rc = set_count(c, 0, kCntClusters, num_cluster))) return rc;
+  ClusterBuffers cb = cluster_buffers(c);
+  mot_launch_box(c->dp, cb, 1, n, c->stream);
+  MOT_HIP(c, hipGetLastError());
+  return mot_get_boxes(c, 0, boxes, max_boxes, n_boxes, box_cluster, n_undefined);
+}
+
 extern "C" int mot_get_ground(mot_ctx* c, int slot, float* elev, int* n_elev, float* ground, int* n_ground,
                               uint8_t* mask) {
   if (!c || slot < 0 || slot >= c->batch) return MOT_E_ARG;
-  MOT_HIP(c, hipMemcpyAsync(c->h_counts + slot * 4, c->d_counts + slot * 4, 4 * sizeof(int), hipMemcpyDeviceToHost, c->stream));
-  MOT_HIP(c, hipStreamSynchronize(c->stream));
-  int ne = c->h_counts[slot * 4 + 0], ng = c->h_counts[slot * 4 + 1];
+  int rc = fetch_counts(c, slot);
+  if (rc) return rc;
+  int ne = c->h_counts[slot * kCountsStride + kCntElev], ng = c->h_counts[slot * kCountsStride + kCntGround];
   if (n_elev) *n_elev = ne;
   if (n_ground) *n_ground = ng;
   if (elev && ne > 0) MOT_HIP(c, hipMemcpyAsync(elev, c->d_elev + (size_t)slot * c->cap, (size_t)ne * 16, hipMemcpyDeviceToHost, c->stream));
@@ -279,47 +410,77 @@ extern "C" int mot_ground_remove(mot_ctx* c, const float* xyzw, int n, float* el
   return mot_get_ground(c, 0, elev, n_elev, ground, n_ground, mask);
 }
 
+// kernel ids used by mot_time_stage
+enum { kK1 = 10, kK2 = 11, kK3 = 12, kC1 = 20, kC2 = 21, kB1 = 30, kB2 = 31, kB3 = 32 };
+
+static int launch_one(mot_ctx* c, int id, int batch) {
+  int rc;
+  const int max_n = c->last_max_n;
+  if (id == kK3 && (rc = next_epoch(c))) return rc;
+  GroundBuffers g = ground_buffers(c, c->last_in, c->last_in_stride, true);
+  ClusterBuffers cb = cluster_buffers(c);
+  switch (id) {
+    case kK1: mot_launch_ground_kernel(0, c->dp, g, batch, max_n, c->stream); break;
+    case kK2: mot_launch_ground_kernel(1, c->dp, g, batch, max_n, c->stream); break;
+    case kK3: mot_launch_ground_kernel(2, c->dp, g, batch, max_n, c->stream); break;
+    case kC1: mot_launch_cluster_kernel(0, c->dp, cb, batch, max_n, c->stream); break;
+    case kC2: mot_launch_cluster_kernel(1, c->dp, cb, batch, max_n, c->stream); break;
+    case kB1: mot_launch_box_kernel(0, c->dp, cb, batch, max_n, c->stream); break;
+    case kB2: mot_launch_box_kernel(1, c->dp, cb, batch, max_n, c->stream); break;
+    case kB3: mot_launch_box_kernel(2, c->dp, cb, batch, max_n, c->stream); break;
+    default: return fail(c, MOT_E_ARG, "unknown kernel id");
+  }
+  return MOT_OK;
+}
+
+// Re-runs a stage (0 ground, 1 cluster, 2 box, 100 all three) or one kernel (10-12, 20-21, 30-32) on the data
+// resident from the last mot_frames_dev call. Each iteration launches the untimed kernels the timed ones need
+// (e.g. the occupancy kernel before the labelling kernel, which consumes and clears the bit-planes), records a
+// HIP event on the context stream, launches the timed kernels, records a second event, and synchronises;
+// the result is the mean of the event-to-event times. Every sequence leaves the context in its between-calls state.
 extern "C" int mot_time_stage(mot_ctx* c, int stage, int batch, int iters, float* ms_per_iter) {
   if (!c || !ms_per_iter || iters < 1) return MOT_E_ARG;
   if (!c->last_in || batch != c->last_batch) return fail(c, MOT_E_STATE, "call mot_frames_dev with the same batch first");
-  if (!(stage == 0 || (stage >= 10 && stage <= 12))) return fail(c, MOT_E_ARG, "unknown stage");
+  struct Seq { int pre[3], timed[8], post[3]; };
+  Seq s = {{0, 0, 0}, {0, 0, 0, 0, 0, 0, 0, 0}, {0, 0, 0}};
+  switch (stage) {
+    case 0: s = {{0}, {kK1, kK2, kK3}, {0}}; break;
+    case 1: s = {{0}, {kC1, kC2}, {0}}; break;
+    case 2: s = {{0}, {kB1, kB2, kB3}, {0}}; break;
+    case 100: s = {{0}, {kK1, kK2, kK3, kC1, kC2, kB1, kB2, kB3}, {0}}; break;
+    case kK1: s = {{0}, {kK1}, {kK2}}; break;
+    case kK2: s = {{kK1}, {kK2}, {0}}; break;
+    case kK3: s = {{0}, {kK3}, {0}}; break;
+    case kC1: s = {{0}, {kC1}, {kC2}}; break;
+    case kC2: s = {{kC1}, {kC2}, {0}}; break;
+    case kB1: s = {{0}, {kB1}, {kB3}}; break;
+    case kB2: s = {{kB1}, {kB2}, {kB3}}; break;
+    case kB3: s = {{kB1, kB2}, {kB3}, {0}}; break;
+    default: return fail(c, MOT_E_ARG, "unknown stage");
+  }
+  double total = 0;
   int rc;
-  // kernels are idempotent on resident data: K1 re-accumulates the same minima, K2 (without the min-z
-  // reset) recomputes the same thresholds, K3 re-draws tickets under a fresh epoch.
-  MOT_HIP(c, hipEventRecord(c->ev0, c->stream));
   for (int it = 0; it < iters; it++) {
-    if ((rc = next_epoch(c))) return rc;
-    GroundBuffers g = ground_buffers(c, c->last_in, c->last_in_stride, true);
-    if (stage == 0) mot_launch_ground(c->dp, g, batch, c->last_max_n, c->stream);
-    else if (stage == 10) mot_launch_ground_kernel(0, c->dp, g, batch, c->last_max_n, c->stream);
-    else if (stage == 11) mot_launch_ground_kernel(3, c->dp, g, batch, c->last_max_n, c->stream);
-    else mot_launch_ground_kernel(2, c->dp, g, batch, c->last_max_n, c->stream);
+    for (int k = 0; k < 3 && s.pre[k]; k++) if ((rc = launch_one(c, s.pre[k], batch))) return rc;
+    MOT_HIP(c, hipEventRecord(c->ev0, c->stream));
+    for (int k = 0; k < 8 && s.timed[k]; k++) if ((rc = launch_one(c, s.timed[k], batch))) return rc;
+    MOT_HIP(c, hipEventRecord(c->ev1, c->stream));
+    for (int k = 0; k < 3 && s.post[k]; k++) if ((rc = launch_one(c, s.post[k], batch))) return rc;
+    MOT_HIP(c, hipEventSynchronize(c->ev1));
+    float ms = 0;
+    MOT_HIP(c, hipEventElapsedTime(&ms, c->ev0, c->ev1));
+    total += ms;
   }
-  MOT_HIP(c, hipEventRecord(c->ev1, c->stream));
-  MOT_HIP(c, hipEventSynchronize(c->ev1));
-  float ms = 0;
-  MOT_HIP(c, hipEventElapsedTime(&ms, c->ev0, c->ev1));
-  *ms_per_iter = ms / iters;
-  if (stage == 10 || stage == 11) {  // restore the invariant "min-z grid is all-initial between calls" and the thresholds
-    if ((rc = next_epoch(c))) return rc;
-    GroundBuffers g = ground_buffers(c, c->last_in, c->last_in_stride, true);
-    if (stage == 11) mot_launch_ground_kernel(0, c->dp, g, batch, c->last_max_n, c->stream);
-    mot_launch_ground_kernel(1, c->dp, g, batch, c->last_max_n, c->stream);
-    mot_launch_ground_kernel(2, c->dp, g, batch, c->last_max_n, c->stream);
-    MOT_HIP(c, hipStreamSynchronize(c->stream));
-  }
+  MOT_HIP(c, hipStreamSynchronize(c->stream));
   MOT_HIP(c, hipGetLastError());
+  *ms_per_iter = (float)(total / iters);
   return MOT_OK;
 }
 
 // ---- entry points whose device stages are still being brought up (round 1, in order: cluster, box, tracker).
 // They fail loudly; nothing falls back to a CPU path.
 #define MOT_PENDING(c, what) return fail((c), MOT_E_STATE, what " is not built yet in this revision")
-extern "C" int mot_cluster(mot_ctx* c, const float*, int, int32_t*, int*, int32_t*) { if (!c) return MOT_E_ARG; MOT_PENDING(c, "mot_cluster"); }
-extern "C" int mot_box_fit(mot_ctx* c, const float*, int, const int32_t*, int, float*, int, int*, int32_t*, int*) { if (!c) return MOT_E_ARG; MOT_PENDING(c, "mot_box_fit"); }
 extern "C" int mot_ego_update(mot_ctx* c, int, double, double, double, double*) { if (!c) return MOT_E_ARG; MOT_PENDING(c, "mot_ego_update"); }
 extern "C" int mot_track_step(mot_ctx* c, int, const float*, int, double, mot_track*, int, int*) { if (!c) return MOT_E_ARG; MOT_PENDING(c, "mot_track_step"); }
 extern "C" int mot_track_get_state(mot_ctx* c, int, int, mot_track_state*) { if (!c) return MOT_E_ARG; MOT_PENDING(c, "mot_track_get_state"); }
-extern "C" int mot_get_clusters(mot_ctx* c, int, int32_t*, int*, int32_t*) { if (!c) return MOT_E_ARG; MOT_PENDING(c, "mot_get_clusters"); }
-extern "C" int mot_get_boxes(mot_ctx* c, int, float*, int, int*, int32_t*, int*) { if (!c) return MOT_E_ARG; MOT_PENDING(c, "mot_get_boxes"); }
 extern "C" int mot_get_tracks(mot_ctx* c, int, mot_track*, int, int*) { if (!c) return MOT_E_ARG; MOT_PENDING(c, "mot_get_tracks"); }

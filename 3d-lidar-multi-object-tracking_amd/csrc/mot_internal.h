@@ -60,10 +60,57 @@ struct GroundBuffers {
   float4* elevated;        // [B][cap]
   float4* ground;          // [B][cap]
   uint8_t* mask;           // [B][cap] or null
-  int* counts;             // [B][4]: n_elevated, n_ground, n_dropped, spare
+  int* counts;             // [B][kCountsStride]: n_elevated, n_ground, n_dropped, ...
   long cap;                // capacity (points) per frame of the outputs
   int max_chunks;
 };
+
+// ---- cluster + box stages ------------------------------------------------------------------
+constexpr int kRowWords = 8;                       // a grid row (<= 256 cells) as 8 x 32 bits
+constexpr int kPlaneWords = MOT_MAX_GRID * kRowWords;  // 2048 words: bit (x*256 + y)
+constexpr int kMaxRuns = 32768;                    // 128 runs per row x 256 rows
+constexpr int kMaxClusters = 4096;                 // per frame (MOT_E_CAPACITY beyond)
+constexpr int kMaxBoxesPerFrame = 1024;
+constexpr int kRngTable = 128;                     // raw mt19937_64(0) outputs kept on the device
+constexpr int kCountsStride = 8;                   // ints per frame in `counts`
+enum { kCntElev = 0, kCntGround = 1, kCntDropped = 2, kCntClusters = 3, kCntBoxes = 4, kCntUndef = 5, kCntFlags = 6 };
+enum { kFlagClusterOverflow = 1, kFlagBoxOverflow = 2, kFlagRngExhausted = 4, kFlagHullOverflow = 8 };
+
+struct ClusterStats {          // per cluster, accumulated by the label kernel, reset by the finalize kernel
+  int count;                   // numPoints
+  int first;                   // smallest point index (clusteredPoints[i][0])
+  int maxz_key;                // ordered key of max z (init key(-99))
+  int pad;
+  unsigned long long argmin;   // (key(m) << 32) | idx        -> minimum = smallest slope, first occurrence
+  unsigned long long argmax;   // (key(m) << 32) | ~idx       -> maximum = largest slope, first occurrence
+};
+struct BoxCandidate {          // per cluster, written by the box kernel
+  float pc[8];                 // 4 corners (x,y)
+  float max_z;
+  int accepted, undefined, branch;
+};
+
+struct ClusterBuffers {
+  const float4* elevated;      // [B][cap]
+  long cap;
+  int* counts;                 // [B][kCountsStride]
+  unsigned* plane_a;           // [B][2048] cell seen >= 1
+  unsigned* plane_b;           // [B][2048] cell seen >= 2
+  int* grid;                   // [B][65536] labels, x-major with stride num_grid
+  int* label;                  // [B][cap] label of each elevated point
+  ClusterStats* stats;         // [B][kMaxClusters]
+  BoxCandidate* cand;          // [B][kMaxClusters]
+  float* boxes;                // [B][kMaxBoxesPerFrame][24]
+  int* box_cluster;            // [B][kMaxBoxesPerFrame]
+  const unsigned long long* rng;  // [kRngTable]
+};
+
+void mot_launch_cluster(const MotDevParams& p, const ClusterBuffers& c, int batch, int max_n, hipStream_t stream);
+void mot_launch_box(const MotDevParams& p, const ClusterBuffers& c, int batch, int max_n, hipStream_t stream);
+// pieces, for the stage-wise host entry points and per-kernel timing
+void mot_launch_cluster_kernel(int which, const MotDevParams& p, const ClusterBuffers& c, int batch, int max_n, hipStream_t stream);
+void mot_launch_stats_init(const ClusterBuffers& c, int batch, hipStream_t stream);
+void mot_launch_box_kernel(int which, const MotDevParams& p, const ClusterBuffers& c, int batch, int max_n, hipStream_t stream);
 
 void mot_launch_ground(const MotDevParams& p, const GroundBuffers& g, int batch, int max_n, hipStream_t stream);
 // single kernels, for per-kernel timing (mot_time_stage): which = 0 min-z, 1 polar filter, 2 classify+compact
@@ -73,6 +120,19 @@ void mot_launch_ground_kernel(int which, const MotDevParams& p, const GroundBuff
 // ordered-int key of a float: signed integer compare == float compare
 MOT_HD int mot_float_key(float f) { int k = mot_f2i(f); return k >= 0 ? k : k ^ 0x7fffffff; }
 MOT_HD float mot_key_float(int k) { return mot_i2f(k >= 0 ? k : k ^ 0x7fffffff); }
+
+// Cartesian cell of a point: component_clustering.cpp:42-48 (same expression at :318-324 and
+// box_fitting.cpp:52-58). fp32: int*float, then /float, floor. Returns false outside the ROI.
+MOT_HD bool mot_cart_cell(const MotDevParams& p, float x, float y, int* xI, int* yI) {
+  float xC = x + p.roi_half;
+  float yC = y + p.roi_half;
+  if (xC < 0 || xC >= p.roi_m || yC < 0 || yC >= p.roi_m) return false;
+  float fx = floorf(p.num_grid * xC / p.roi_m), fy = floorf(p.num_grid * yC / p.roi_m);
+  // NaN slips through the ROI test in the reference and indexes out of bounds (UB); dropped here
+  if (!(fx >= 0.f && fx < (float)p.num_grid && fy >= 0.f && fy < (float)p.num_grid)) return false;
+  *xI = (int)fx; *yI = (int)fy;
+  return true;
+}
 
 // getCellIndexFromPoints (ground_removal.cpp:67-76) + filterCloud's range test (:53) + the callers'
 // bounds test (:89,:233). Returns the polar cell (ch*120+bin) or -1 when the point takes no part.

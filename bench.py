@@ -133,35 +133,49 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
 
-    # ---- per-kernel timing on the resident data (HIP events on the context's stream)
+    # ---- per-kernel timing on the resident data (HIP events on the context's stream, see mot_time_stage)
     it = 20
-    k_ms = {"polar_minz_kernel": ctx.time_stage(10, B, it), "polar_filter_kernel": ctx.time_stage(11, B, it),
-            "classify_compact_kernel": ctx.time_stage(12, B, it)}
-    g0 = ctx.get_ground(0, want_clouds=False)
-    ne, ng = g0["n_elevated"], g0["n_ground"]
+    kernels = {"polar_minz_kernel": 10, "polar_filter_kernel": 11, "classify_compact_kernel": 12,
+               "cart_occupancy_kernel": 20, "ccl_kernel": 21, "label_stats_kernel": 30, "cluster_box_kernel": 31,
+               "box_finalize_kernel": 32}
+    k_ms = {k: ctx.time_stage(v, B, it) for k, v in kernels.items()}
+    stage_ms = {"ground": ctx.time_stage(0, B, it), "cluster": ctx.time_stage(1, B, it), "box": ctx.time_stage(2, B, it),
+                "all": ctx.time_stage(100, B, it)}
     counts = [ctx.get_ground(b, want_clouds=False) for b in range(B)]
-    tot_out = sum(c["n_elevated"] + c["n_ground"] for c in counts)
+    ne_tot = sum(c["n_elevated"] for c in counts); ng_tot = sum(c["n_ground"] for c in counts)
+    cl0 = ctx.get_clusters(0); bx0 = ctx.get_boxes(0)
+    G = ctx.params.num_grid
+    # algorithmic HBM bytes per launch (DESIGN.md "bytes per unit"): what the kernel must read and write once
     alg_bytes = {"polar_minz_kernel": 16.0 * N * B,
                  "polar_filter_kernel": 8.0 * 9600 * B,
-                 "classify_compact_kernel": 16.0 * N * B + 16.0 * tot_out + 1.0 * N * B}
+                 "classify_compact_kernel": 16.0 * N * B + 16.0 * (ne_tot + ng_tot) + 1.0 * N * B,
+                 "cart_occupancy_kernel": 16.0 * ne_tot,
+                 "ccl_kernel": (2 * 2048 * 4 + 4.0 * G * G) * B,
+                 "label_stats_kernel": (16.0 + 4.0) * ne_tot,
+                 "cluster_box_kernel": 4.0 * ne_tot,
+                 "box_finalize_kernel": 96.0 * B}
     dom = max(k_ms, key=lambda k: k_ms[k])
     achieved = alg_bytes[dom] / (k_ms[dom] * 1e-3) / 1e9
-    stage_ms = ctx.time_stage(0, B, it)
+    frame_bytes = sum(alg_bytes.values()) / B
 
     if rank == 0:
         frames = B * args.steps * world
         out = {
-            "metric": "LiDAR frames/sec (120k-pt 64-beam cloud), ground removal stage (configs[1]) — cluster/box/track stages not yet on device",
+            "metric": "LiDAR frames/sec (120k-pt 64-beam cloud) end-to-end ground->cluster->box on device (tracker stage pending)",
             "value": round(frames / dt, 1), "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(dt / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32 (polar index fp32/fp64 as the reference, min-z int32 keys)", "data": "synthetic",
-            "config": {"workload": "configs[1]: ground removal + Gaussian blur on one MI355X, 120k-pt synthetic HDL-64E cloud",
+            "dtype": "f32 (fp32 indices / fp64 intermediates exactly as the reference; int32 grids and labels)", "data": "synthetic",
+            "config": {"workload": "configs[2]: full ground->CCL->box-fit pipeline on one MI355X, 120k-pt synthetic HDL-64E cloud",
                        "points_per_frame": N, "frames_per_step_per_gpu": B, "streams": B * world,
-                       "elevated_pts_frame0": ne, "ground_pts_frame0": ng, "parallelism": f"frame-sharded x{world}"},
+                       "elevated_pts_per_frame": ne_tot // B, "clusters_frame0": cl0["num_cluster"], "boxes_frame0": len(bx0["boxes"]),
+                       "parallelism": f"frame-sharded x{world}"},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
-                         "kernel_ms": {k: round(v, 5) for k, v in k_ms.items()}, "stage_ms": round(stage_ms, 5),
-                         "algorithmic_bytes_per_launch": {k: int(v) for k, v in alg_bytes.items()}},
+                         "kernel_ms": {k: round(v, 5) for k, v in k_ms.items()},
+                         "stage_ms": {k: round(v, 5) for k, v in stage_ms.items()},
+                         "algorithmic_bytes_per_launch": {k: int(v) for k, v in alg_bytes.items()},
+                         "pipeline_bytes_per_frame": int(frame_bytes),
+                         "pipeline_frac": round(frame_bytes * B / (stage_ms["all"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)},
         }
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(synth, N)

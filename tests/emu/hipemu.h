@@ -224,6 +224,8 @@ static inline double __longlong_as_double(long long i) { double d; memcpy(&d, &i
 static inline void __threadfence() {}
 static inline void __threadfence_block() {}
 static inline unsigned long long __umul64hi(unsigned long long a, unsigned long long b) { return (unsigned long long)(((unsigned __int128)a * b) >> 64); }
+static inline int min(int a, int b) { return a < b ? a : b; }
+static inline int max(int a, int b) { return a > b ? a : b; }
 static inline void __builtin_amdgcn_s_sleep(int) { if (hipemu::S().cur) hipemu::yield(); }
 
 // atomics (single OS thread: plain read-modify-write)

@@ -1,0 +1,128 @@
+"""Parity of the HIP clustering and box-fitting stages (through the C-ABI) against the oracle and the golden
+vectors. Bit-exact: label grid, cluster count, per-point labels, box corners, box order."""
+import numpy as np
+import pytest
+
+import golden_util as G
+import patterns
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ctx(mot, hip_lib):
+    c = mot.Context(max_points=262144, max_batch=8)
+    yield c
+    c.close()
+
+
+def _stage_parity(ctx, oracle, p, elev):
+    r = ctx.cluster(elev)
+    o = oracle.cluster(p, elev)
+    assert r["num_cluster"] == o["num_cluster"]
+    assert np.array_equal(r["grid"], o["grid"])
+    assert np.array_equal(r["point_label"], o["point_label"])
+    b = ctx.box_fit(elev, o["grid"], o["num_cluster"])
+    ob = oracle.box_fit(p, elev, o["grid"], o["num_cluster"])
+    assert b["n_undefined"] == ob["n_undefined"]
+    assert np.array_equal(b["box_cluster"], ob["box_cluster"])
+    assert b["boxes"].shape == ob["boxes"].shape and np.array_equal(b["boxes"].view(np.uint32), ob["boxes"].view(np.uint32))
+    return r, b
+
+
+@pytest.mark.parametrize("n,stream,frame", [(120000, 0, 0), (120000, 1, 4), (120000, 2, 9), (200000, 4, 1), (30000, 5, 0), (5000, 6, 2)])
+def test_cluster_box_parity(ctx, oracle, synth, n, stream, frame):
+    p = oracle.params(0)
+    cloud = synth.make_cloud(n, stream, frame)
+    elev = oracle.ground_remove(p, cloud)["elevated"]
+    _stage_parity(ctx, oracle, p, elev)
+
+
+def test_cluster_box_small_and_empty(ctx, oracle, synth):
+    p = oracle.params(0)
+    _stage_parity(ctx, oracle, p, np.zeros((0, 4), np.float32))
+    _stage_parity(ctx, oracle, p, np.array([[1, 1, 0, 0]], np.float32))
+    two = np.array([[1, 1, 0, 0], [1.01, 1.01, 0.5, 0]], np.float32)   # one cell with 2 points -> 3x3 cluster, 2 pts < 30
+    _stage_parity(ctx, oracle, p, two)
+    edge = synth.edge_case_points()
+    _stage_parity(ctx, oracle, p, np.concatenate([edge, edge]))
+
+
+def test_ccl_adversarial_patterns(mot, hip_lib, oracle):
+    rng = np.random.default_rng(0)
+    for preset in (0, 1):
+        p = oracle.params(preset)
+        with mot.Context(mot.params(preset), max_points=150000) as c:
+            for name, cells in patterns.occupancy_cases(p.num_grid, rng):
+                pts = patterns.case_points(cells, p, rng)
+                r = c.cluster(pts)
+                o = oracle.cluster(p, pts)
+                assert r["num_cluster"] == o["num_cluster"], (preset, name)
+                assert np.array_equal(r["grid"], o["grid"]), (preset, name)
+                assert np.array_equal(r["point_label"], o["point_label"]), (preset, name)
+
+
+def test_box_kitti_preset(mot, hip_lib, oracle, synth):
+    p = oracle.params(1)
+    with mot.Context(mot.params(1), max_points=131072) as c:
+        for stream in (0, 3):
+            elev = oracle.ground_remove(p, synth.make_cloud(120000, stream, 0))["elevated"]
+            _stage_parity(c, oracle, p, elev)
+
+
+@pytest.mark.parametrize("name", G.FRAMES)
+def test_golden_frames(ctx, name):
+    """fixtures produced by the reference's own sources (tests/golden/make_golden.py)"""
+    fx = G.load(name)
+    g = ctx.ground_remove(fx["cloud"])
+    cl = ctx.cluster(g["elevated"])
+    bx = ctx.box_fit(g["elevated"], cl["grid"], cl["num_cluster"])
+    G.check_frame(fx, g, cl, bx["boxes"])
+
+
+def test_fused_frames_dev(ctx, oracle, synth):
+    """ground -> cluster -> box for 8 frames in one launch sequence, everything resident in HBM"""
+    import hiprt
+    p = oracle.params(0)
+    sizes = [120000, 1, 99999, 0, 200000, 2048, 77777, 131072]
+    stride = 262144
+    host = np.zeros((8, stride, 4), np.float32)
+    clouds = []
+    for b, n in enumerate(sizes):
+        c = synth.make_cloud(max(n, 1), 20 + b, b)[:n]
+        host[b, :n] = c
+        clouds.append(c)
+    dev = hiprt.DeviceBuffer(host)
+    for rep in range(2):
+        ctx.frames_dev(dev.ptr, stride * 4, sizes)
+        for b, n in enumerate(sizes):
+            g = oracle.ground_remove(p, clouds[b])
+            r = ctx.get_ground(b, n_hint=n)
+            assert np.array_equal(r["elevated"], g["elevated"]) and np.array_equal(r["ground"], g["ground"])
+            assert np.array_equal(r["mask"][:n], g["mask"])
+            o = oracle.cluster(p, g["elevated"])
+            cl = ctx.get_clusters(b, n_elevated=len(g["elevated"]))
+            assert cl["num_cluster"] == o["num_cluster"] and np.array_equal(cl["grid"], o["grid"])
+            assert np.array_equal(cl["point_label"], o["point_label"])
+            ob = oracle.box_fit(p, g["elevated"], o["grid"], o["num_cluster"])
+            bx = ctx.get_boxes(b)
+            assert np.array_equal(bx["boxes"], ob["boxes"]) and np.array_equal(bx["box_cluster"], ob["box_cluster"])
+    dev.free()
+
+
+def test_full_size_properties(ctx, synth):
+    """200k-point frame: labels only on occupied cells, ids contiguous, boxes in cluster order, idempotent"""
+    cloud = synth.make_cloud(200000, 11, 0)
+    g = ctx.ground_remove(cloud)
+    cl = ctx.cluster(g["elevated"])
+    ids = np.unique(cl["grid"])
+    assert ids[0] == 0 and np.array_equal(ids[1:], np.arange(1, cl["num_cluster"] + 1))
+    flat = cl["grid"].ravel()
+    first = [np.argmax(flat == k) for k in range(1, cl["num_cluster"] + 1)]
+    assert all(a < b for a, b in zip(first, first[1:]))
+    bx = ctx.box_fit(g["elevated"], cl["grid"], cl["num_cluster"])
+    assert np.all(np.diff(bx["box_cluster"]) > 0)
+    cl2 = ctx.cluster(g["elevated"])
+    assert np.array_equal(cl2["grid"], cl["grid"])
+    bx2 = ctx.box_fit(g["elevated"], cl["grid"], cl["num_cluster"])
+    assert np.array_equal(bx2["boxes"], bx["boxes"])

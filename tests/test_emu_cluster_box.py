@@ -1,0 +1,43 @@
+"""CPU-only development check of the clustering / box kernels' LOGIC under tests/emu/hipemu.h (see that header:
+not a product path, not a parity claim)."""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+import patterns
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "emu"))
+
+
+@pytest.fixture(scope="module")
+def emu_lib():
+    import build_emu
+    return build_emu.build()
+
+
+def test_emu_cluster_box_pipeline(mot, emu_lib, oracle, synth):
+    p = oracle.params(0)
+    with mot.Context(lib_path=emu_lib, max_points=40000) as c:
+        for stream in (1, 2):
+            cloud = synth.make_cloud(36000, stream, 0)
+            g = c.ground_remove(cloud)
+            og = oracle.ground_remove(p, cloud)
+            assert np.array_equal(g["elevated"], og["elevated"])
+            r = c.cluster(g["elevated"]); o = oracle.cluster(p, og["elevated"])
+            assert r["num_cluster"] == o["num_cluster"] and np.array_equal(r["grid"], o["grid"]) and np.array_equal(r["point_label"], o["point_label"])
+            b = c.box_fit(g["elevated"], r["grid"], r["num_cluster"]); ob = oracle.box_fit(p, og["elevated"], o["grid"], o["num_cluster"])
+            assert np.array_equal(b["boxes"], ob["boxes"]) and np.array_equal(b["box_cluster"], ob["box_cluster"])
+
+
+@pytest.mark.parametrize("preset", [0, 1])
+def test_emu_ccl_patterns(mot, emu_lib, oracle, preset):
+    rng = np.random.default_rng(1)
+    p = oracle.params(preset)
+    with mot.Context(mot.params(preset, lib=mot.load_library(emu_lib)), lib_path=emu_lib, max_points=150000) as c:
+        for name, cells in patterns.occupancy_cases(p.num_grid, rng, dense=False):
+            pts = patterns.case_points(cells, p, rng)
+            r = c.cluster(pts); o = oracle.cluster(p, pts)
+            assert r["num_cluster"] == o["num_cluster"] and np.array_equal(r["grid"], o["grid"]), name
+            assert np.array_equal(r["point_label"], o["point_label"]), name

@@ -132,3 +132,38 @@ def test_min_area_rect_properties(oracle):
             assert t.min() >= -1e-2 * max(L, 1) - 0.05 and t.max() <= L + 1e-2 * max(L, 1) + 0.05
         r2 = oracle.min_area_rect_points(np.concatenate([pts, pts[::2]]))
         assert np.array_equal(r2.astype(np.float32), oracle.min_area_rect_points(pts))
+
+
+def test_hull_column_reduction(oracle):
+    """the device path feeds cv::convexHull only the lowest / highest pixel of every pixel column (already sorted);
+    the restated OpenCV hull and min-area rectangle must be unchanged by that reduction"""
+    rng = np.random.default_rng(1)
+
+    def reduce_cols(pts):
+        d = {}
+        for x, y in pts:
+            d[x] = (min(d[x][0], y), max(d[x][1], y)) if x in d else (y, y)
+        out = []
+        for x in sorted(d):
+            lo, hi = d[x]
+            out.append((x, lo))
+            if hi != lo:
+                out.append((x, hi))
+        return np.array(out, np.int32)
+
+    for trial in range(6000):
+        n = int(rng.integers(1, 80)); mode = trial % 6
+        if mode == 0: pts = rng.integers(-30, 30, size=(n, 2))
+        elif mode == 1: pts = rng.integers(-5, 5, size=(n, 2))
+        elif mode == 2:
+            x = rng.integers(-40, 40, size=n); pts = np.stack([x, x // 2 + rng.integers(-2, 2, size=n)], 1)
+        elif mode == 3:
+            x = rng.integers(-40, 40, size=n); pts = np.stack([x, 3 * x + 7], 1)
+        elif mode == 4: pts = np.stack([np.full(n, 5), rng.integers(-20, 20, size=n)], 1)
+        else: pts = np.stack([rng.integers(-20, 20, size=n), np.full(n, -3)], 1)
+        pts = pts.astype(np.int32)
+        if trial % 2:
+            pts = np.concatenate([pts, pts[rng.integers(0, n, size=n // 2 + 1)]])
+        red = reduce_cols(pts)
+        assert np.array_equal(oracle.convex_hull(pts), oracle.convex_hull(red))
+        assert np.array_equal(oracle.min_area_rect_points(pts), oracle.min_area_rect_points(red))
