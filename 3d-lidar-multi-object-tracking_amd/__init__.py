@@ -70,7 +70,7 @@ EXPORTS = (
     "mot_abi_version", "mot_params_preset", "mot_create", "mot_destroy", "mot_reset", "mot_last_error",
     "mot_synchronize", "mot_stream", "mot_ground_remove", "mot_cluster", "mot_box_fit", "mot_ego_update",
     "mot_track_step", "mot_track_get_state", "mot_frames_dev", "mot_get_ground", "mot_get_clusters",
-    "mot_get_boxes", "mot_get_tracks", "mot_time_stage",
+    "mot_get_boxes", "mot_get_tracks", "mot_export_tracks_dev", "mot_time_stage",
 )
 
 _libs: dict[str, C.CDLL] = {}
@@ -243,6 +243,10 @@ class Context:
         arr = (MotTrack * max_tracks)(); nt = C.c_int(0)
         self._ck(self.lib.mot_get_tracks(self._h, slot, arr, max_tracks, C.byref(nt)))
         return tracks_to_dict(arr, nt.value)
+
+    def export_tracks_dev(self, batch: int, d_tracks_ptr: int, max_per_slot: int, d_counts_ptr: int):
+        """live tracks of every slot -> caller's device buffer (the block that is all-gathered across GPUs)"""
+        self._ck(self.lib.mot_export_tracks_dev(self._h, batch, C.c_void_p(d_tracks_ptr), max_per_slot, C.c_void_p(d_counts_ptr)))
 
     def time_stage(self, stage: int, batch: int, iters: int) -> float:
         """average ms per iteration of one stage re-run on resident data, HIP events on the context stream"""

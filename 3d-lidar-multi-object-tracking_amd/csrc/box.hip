@@ -121,6 +121,7 @@ label_stats_kernel(MotDevParams p, ClusterBuffers c) {
 constexpr int kBoxBlock = 64;        // ONE wave per cluster
 constexpr int kPicCols = 1024;       // pixel columns 0..900
 constexpr int kMaxHullIn = 2 * 901;  // two extreme pixels per column
+constexpr int kScanDepth = 16;      // label loads kept in flight per lane while walking a frame's labels
 constexpr int kMaxHull = 512;        // vertices of a convex lattice polygon in a 900^2 box: < 3.5 * 900^(2/3) ~ 330
 
 // ruleBasedFilter :97-158 (fall-through = false)
@@ -261,16 +262,22 @@ cluster_box_kernel(MotDevParams p, ClusterBuffers c) {
       __syncthreads();
       // k-th point of the cluster in input order: walk the labels with ballot/popcount ranks
       int running = 0;
-      for (int base = 0; base < n && running < numPoints; base += 64) {
-        int i = base + lane;
-        bool mine = i < n && label[i] == ci + 1;
-        unsigned long long mm = __ballot(mine);
-        if (mm == 0ull) continue;
-        if (mine) {
-          int r = running + __popcll(mm & ((1ull << lane) - 1ull));
-          for (int j = 0; j < nsamp; j++) if (s_rank[j] == r) s_pidx[j] = i;
+      for (int base0 = 0; base0 < n && running < numPoints; base0 += 64 * kScanDepth) {
+        int lab[kScanDepth];  // kScanDepth independent loads in flight per lane: the walk is latency-bound otherwise
+#pragma unroll
+        for (int k = 0; k < kScanDepth; k++) { int i = base0 + k * 64 + lane; lab[k] = i < n ? label[i] : 0; }
+#pragma unroll
+        for (int k = 0; k < kScanDepth; k++) {
+          int i = base0 + k * 64 + lane;
+          bool mine = lab[k] == ci + 1;
+          unsigned long long mm = __ballot(mine);
+          if (mm == 0ull) continue;
+          if (mine) {
+            int r = running + __popcll(mm & ((1ull << lane) - 1ull));
+            for (int j = 0; j < nsamp; j++) if (s_rank[j] == r) s_pidx[j] = i;
+          }
+          running += __popcll(mm);
         }
-        running += __popcll(mm);
       }
       __syncthreads();
       // farthest sampled point from the line through the two slope-extreme points; first maximum wins
@@ -306,9 +313,14 @@ cluster_box_kernel(MotDevParams p, ClusterBuffers c) {
       for (int i = lane; i < kPicCols; i += 64) { s_colmin[i] = 0x7fffffff; s_colmax[i] = -0x7fffffff - 1; }
       __syncthreads();
       int running = 0;
-      for (int base = 0; base < n && running < numPoints; base += 64) {
-        int i = base + lane;
-        bool mine = i < n && label[i] == ci + 1;
+      for (int base0 = 0; base0 < n && running < numPoints; base0 += 64 * kScanDepth) {
+        int lab[kScanDepth];
+#pragma unroll
+        for (int k = 0; k < kScanDepth; k++) { int i = base0 + k * 64 + lane; lab[k] = i < n ? label[i] : 0; }
+#pragma unroll
+        for (int k = 0; k < kScanDepth; k++) {
+        int i = base0 + k * 64 + lane;
+        bool mine = lab[k] == ci + 1;
         unsigned long long mm = __ballot(mine);
         if (mm == 0ull) continue;
         if (mine) {
@@ -321,6 +333,7 @@ cluster_box_kernel(MotDevParams p, ClusterBuffers c) {
           if (picX >= 0 && picX < kPicCols) { atomicMin(&s_colmin[picX], offsetY); atomicMax(&s_colmax[picX], offsetY); }
         }
         running += __popcll(mm);
+        }
       }
       __syncthreads();
       // compact the column extents into (x,y)-sorted points: 16 columns per lane, prefix over lanes

@@ -43,6 +43,27 @@ struct mot_ctx {
   float* d_boxes = nullptr;
   int* d_box_cluster = nullptr;
   unsigned long long* d_rng = nullptr;
+  // tracker stage
+  DevTrack* d_tracks = nullptr;
+  int* d_nt = nullptr;
+  float* d_tboxes = nullptr;
+  TrackFrameArgs* d_targs = nullptr;
+  unsigned long long* d_gate = nullptr;
+  unsigned long long* d_prog = nullptr;
+  int* d_live = nullptr;
+  mot_track* d_tout = nullptr;
+  int* d_tflags = nullptr;
+  EgoPose* d_ego = nullptr;
+  struct SlotEgo {  // file-scope globals of OT/tracking/imm_ukf_jpda.cpp:19-24,56-70, one set per stream
+    bool init = false, ego_called = false;
+    double timestamp = 0, egoVelo = 0, egoYaw = 0, egoPreYaw = 0;
+    double rx = 0, ry = 0, ryaw = -M_PI / 2;   // running result of the ego-history replay (:137-151)
+    double egoPoint[3] = {0, 0, 0};
+    int nt = 0;
+  };
+  std::vector<SlotEgo> ego;
+  std::vector<TrackFrameArgs> h_targs;
+  std::vector<EgoPose> h_ego;
   // host mirrors
   std::vector<int> h_n;
   int* h_counts = nullptr;  // pinned [batch][4]
@@ -145,7 +166,8 @@ static int make_dev_params(const mot_params& p, MotDevParams* d, std::string* er
 extern "C" void mot_destroy(mot_ctx* c) {
   if (!c) return;
   void* bufs[] = {c->d_in, c->d_n, c->d_minz, c->d_hg, c->d_desc, c->d_ticket, c->d_elev, c->d_ground, c->d_mask, c->d_counts,
-                  c->d_plane_a, c->d_plane_b, c->d_grid, c->d_label, c->d_stats, c->d_cand, c->d_boxes, c->d_box_cluster, c->d_rng};
+                  c->d_plane_a, c->d_plane_b, c->d_grid, c->d_label, c->d_stats, c->d_cand, c->d_boxes, c->d_box_cluster, c->d_rng,
+                  c->d_tracks, c->d_nt, c->d_tboxes, c->d_targs, c->d_gate, c->d_prog, c->d_live, c->d_tout, c->d_tflags, c->d_ego};
   for (void* b : bufs) if (b) (void)hipFree(b);
   if (c->h_counts) (void)hipHostFree(c->h_counts);
   if (c->ev0) (void)hipEventDestroy(c->ev0);
@@ -153,6 +175,9 @@ extern "C" void mot_destroy(mot_ctx* c) {
   if (c->stream) (void)hipStreamDestroy(c->stream);
   delete c;
 }
+
+static TrackBuffers track_buffers(mot_ctx* c, bool fused);
+static void prepare_track_args(mot_ctx* c, int slot, int m, double timestamp, bool run);
 
 static ClusterBuffers cluster_buffers(mot_ctx* c) {
   ClusterBuffers b;
@@ -206,6 +231,22 @@ static int create_impl(mot_ctx* c) {
     ClusterBuffers cb = cluster_buffers(c);
     mot_launch_stats_init(cb, (int)B, c->stream);
   }
+  const size_t T = c->max_tracks_total;
+  MOT_HIP(c, hipMalloc(&c->d_tracks, B * T * sizeof(DevTrack)));
+  MOT_HIP(c, hipMalloc(&c->d_nt, B * sizeof(int)));
+  MOT_HIP(c, hipMalloc(&c->d_tboxes, B * kMaxBoxesPerFrame * 24 * sizeof(float)));
+  MOT_HIP(c, hipMalloc(&c->d_targs, B * sizeof(TrackFrameArgs)));
+  MOT_HIP(c, hipMalloc(&c->d_gate, B * T * kGateWords * sizeof(unsigned long long)));
+  MOT_HIP(c, hipMalloc(&c->d_prog, B * T * kGateWords * sizeof(unsigned long long)));
+  MOT_HIP(c, hipMalloc(&c->d_live, B * 2 * T * sizeof(int)));
+  MOT_HIP(c, hipMalloc(&c->d_tout, B * T * sizeof(mot_track)));
+  MOT_HIP(c, hipMalloc(&c->d_tflags, B * sizeof(int)));
+  MOT_HIP(c, hipMalloc(&c->d_ego, B * sizeof(EgoPose)));
+  MOT_HIP(c, hipMemsetAsync(c->d_nt, 0, B * sizeof(int), c->stream));
+  MOT_HIP(c, hipMemsetAsync(c->d_tflags, 0, B * sizeof(int), c->stream));
+  c->ego.assign(B, mot_ctx::SlotEgo());
+  c->h_targs.assign(B, TrackFrameArgs());
+  c->h_ego.assign(B, EgoPose());
   MOT_HIP(c, hipMemsetD32Async(c->d_minz, kMinzInit, B * MOT_POLAR_CELLS, c->stream));
   MOT_HIP(c, hipMemsetAsync(c->d_counts, 0, B * kCountsStride * sizeof(int), c->stream));
   MOT_HIP(c, hipMemsetAsync(c->d_n, 0, B * sizeof(int), c->stream));
@@ -243,6 +284,10 @@ extern "C" int mot_synchronize(mot_ctx* c) {
 }
 extern "C" int mot_reset(mot_ctx* c) {
   if (!c) return MOT_E_ARG;
+  MOT_HIP(c, hipMemsetAsync(c->d_nt, 0, c->batch * sizeof(int), c->stream));
+  MOT_HIP(c, hipMemsetAsync(c->d_tflags, 0, c->batch * sizeof(int), c->stream));
+  MOT_HIP(c, hipStreamSynchronize(c->stream));
+  c->ego.assign(c->batch, mot_ctx::SlotEgo());
   return MOT_OK;
 }
 
@@ -293,8 +338,21 @@ extern "C" int mot_frames_dev(mot_ctx* c, const float* d_xyzw, long frame_stride
   ClusterBuffers cb = cluster_buffers(c);
   mot_launch_cluster(c->dp, cb, batch, c->last_max_n, c->stream);
   mot_launch_box(c->dp, cb, batch, c->last_max_n, c->stream);
+  if (run_tracker) {
+    if (!timestamps || !ego_v || !ego_yaw) return fail(c, MOT_E_ARG, "run_tracker needs timestamps, ego_v and ego_yaw");
+    for (int b = 0; b < c->batch; b++) c->h_targs[b].run = 0;
+    for (int b = 0; b < batch; b++) {
+      // the tracking node's per-frame sequence (OT/tracking/main.cpp:72-166): ego pose, boxes -> global frame, tracker
+      if ((rc = mot_ego_update(c, b, timestamps[b], ego_v[b], ego_yaw[b], nullptr))) return rc;
+      c->h_ego[b].x = c->ego[b].egoPoint[0]; c->h_ego[b].y = c->ego[b].egoPoint[1]; c->h_ego[b].yaw = c->ego[b].egoPoint[2];
+      prepare_track_args(c, b, 0, timestamps[b], true);
+    }
+    MOT_HIP(c, hipMemcpyAsync(c->d_ego, c->h_ego.data(), batch * sizeof(EgoPose), hipMemcpyHostToDevice, c->stream));
+    MOT_HIP(c, hipMemcpyAsync(c->d_targs, c->h_targs.data(), c->batch * sizeof(TrackFrameArgs), hipMemcpyHostToDevice, c->stream));
+    mot_launch_boxes_to_global(c->d_boxes, c->d_counts, c->d_ego, c->d_tboxes, batch, c->stream);
+    mot_launch_track(track_buffers(c, true), batch, c->stream);
+  }
   MOT_HIP(c, hipGetLastError());
-  (void)run_tracker; (void)timestamps; (void)ego_v; (void)ego_yaw;
   return MOT_OK;
 }
 
@@ -411,7 +469,7 @@ extern "C" int mot_ground_remove(mot_ctx* c, const float* xyzw, int n, float* el
 }
 
 // kernel ids used by mot_time_stage
-enum { kK1 = 10, kK2 = 11, kK3 = 12, kC1 = 20, kC2 = 21, kB1 = 30, kB2 = 31, kB3 = 32 };
+enum { kK1 = 10, kK2 = 11, kK3 = 12, kC1 = 20, kC2 = 21, kB1 = 30, kB2 = 31, kB3 = 32, kT1 = 40 };
 
 static int launch_one(mot_ctx* c, int id, int batch) {
   int rc;
@@ -428,6 +486,7 @@ static int launch_one(mot_ctx* c, int id, int batch) {
     case kB1: mot_launch_box_kernel(0, c->dp, cb, batch, max_n, c->stream); break;
     case kB2: mot_launch_box_kernel(1, c->dp, cb, batch, max_n, c->stream); break;
     case kB3: mot_launch_box_kernel(2, c->dp, cb, batch, max_n, c->stream); break;
+    case kT1: mot_launch_track(track_buffers(c, true), batch, c->stream); break;  // last frame's arguments again
     default: return fail(c, MOT_E_ARG, "unknown kernel id");
   }
   return MOT_OK;
@@ -456,6 +515,7 @@ extern "C" int mot_time_stage(mot_ctx* c, int stage, int batch, int iters, float
     case kB1: s = {{0}, {kB1}, {kB3}}; break;
     case kB2: s = {{kB1}, {kB2}, {kB3}}; break;
     case kB3: s = {{kB1, kB2}, {kB3}, {0}}; break;
+    case kT1: s = {{0}, {kT1}, {0}}; break;
     default: return fail(c, MOT_E_ARG, "unknown stage");
   }
   double total = 0;
@@ -477,10 +537,120 @@ extern "C" int mot_time_stage(mot_ctx* c, int stage, int batch, int iters, float
   return MOT_OK;
 }
 
-// ---- entry points whose device stages are still being brought up (round 1, in order: cluster, box, tracker).
-// They fail loudly; nothing falls back to a CPU path.
-#define MOT_PENDING(c, what) return fail((c), MOT_E_STATE, what " is not built yet in this revision")
-extern "C" int mot_ego_update(mot_ctx* c, int, double, double, double, double*) { if (!c) return MOT_E_ARG; MOT_PENDING(c, "mot_ego_update"); }
-extern "C" int mot_track_step(mot_ctx* c, int, const float*, int, double, mot_track*, int, int*) { if (!c) return MOT_E_ARG; MOT_PENDING(c, "mot_track_step"); }
-extern "C" int mot_track_get_state(mot_ctx* c, int, int, mot_track_state*) { if (!c) return MOT_E_ARG; MOT_PENDING(c, "mot_track_get_state"); }
-extern "C" int mot_get_tracks(mot_ctx* c, int, mot_track*, int, int*) { if (!c) return MOT_E_ARG; MOT_PENDING(c, "mot_get_tracks"); }
+// ------------------------------------------------------------------------------------------ tracker
+static TrackBuffers track_buffers(mot_ctx* c, bool fused) {
+  TrackBuffers t;
+  t.tracks = c->d_tracks; t.nt = c->d_nt; t.boxes = c->d_tboxes; t.args = c->d_targs; t.gate = c->d_gate; t.prog = c->d_prog;
+  t.live = c->d_live; t.out = c->d_tout; t.flags = c->d_tflags; t.m_dev = fused ? c->d_counts : nullptr; t.T = c->max_tracks_total;
+  t.tp.gamma_g = c->params.gamma_g; t.tp.p_g = c->params.p_g; t.tp.p_d = c->params.p_d; t.tp.distance_thres = c->params.distance_thres;
+  t.tp.bb_yaw_change_thres = c->params.bb_yaw_change_thres; t.tp.seed_px = c->params.seed_px; t.tp.seed_py = c->params.seed_py;
+  t.tp.life_time_thres = c->params.life_time_thres; t.tp.seed_box_index = c->params.seed_box_index;
+  return t;
+}
+
+// getOriginPoints(), OT/tracking/imm_ukf_jpda.cpp:74-172. Scalar dead reckoning, kept on the host (its cos/sin are the
+// same libm calls the reference makes). The reference replays the whole delta history every frame (:137-151); every
+// replay repeats the previous one and appends one step, so the running state is carried instead — same operations,
+// same values.
+extern "C" int mot_ego_update(mot_ctx* c, int slot, double timestamp, double v_gps, double yaw_gps, double* origin6) {
+  if (!c || slot < 0 || slot >= c->batch) return MOT_E_ARG;
+  mot_ctx::SlotEgo& e = c->ego[slot];
+  double dt = (timestamp - e.timestamp) / 1000000.0;
+  e.egoVelo = v_gps;
+  e.egoYaw = yaw_gps;
+  e.egoYaw += c->params.first_ego_yaw_offset;
+  e.ego_called = true;
+  if (!e.init) {
+    e.egoPoint[0] = 0; e.egoPoint[1] = 0; e.egoPoint[2] = e.egoYaw;
+    if (origin6) { origin6[0] = 0; origin6[1] = 0; origin6[2] = e.egoYaw; origin6[3] = 0; origin6[4] = 0; origin6[5] = e.egoYaw + M_PI / 2; }
+    return MOT_OK;
+  }
+  double diffYaw = (e.egoYaw - e.egoPreYaw);
+  double dX = dt * e.egoVelo * cos(diffYaw);
+  double dY = dt * e.egoVelo * sin(diffYaw);
+  double x = e.rx, y = e.ry, egoYaw = e.ryaw;
+  x -= dX;
+  y -= dY;
+  double preX = x, preY = y;
+  double yaw = diffYaw * -1;
+  egoYaw += yaw;
+  x = cos(yaw) * preX - sin(yaw) * preY;
+  y = sin(yaw) * preX + cos(yaw) * preY;
+  e.rx = x; e.ry = y; e.ryaw = egoYaw;
+  e.egoPoint[0] = x; e.egoPoint[1] = y; e.egoPoint[2] = egoYaw;
+  if (origin6) { origin6[0] = x; origin6[1] = y; origin6[2] = egoYaw; origin6[3] = x; origin6[4] = y; origin6[5] = egoYaw + M_PI / 2; }
+  return MOT_OK;
+}
+
+// fills the per-slot launch arguments and advances the host-side copies of timestamp_ / egoPreYaw_ / init_
+static void prepare_track_args(mot_ctx* c, int slot, int m, double timestamp, bool run) {
+  mot_ctx::SlotEgo& e = c->ego[slot];
+  TrackFrameArgs& a = c->h_targs[slot];
+  a.m = m; a.run = run ? 1 : 0; a.pad = 0;
+  a.first_frame = e.init ? 0 : 1;
+  a.dt = (timestamp - e.timestamp) / 1000000.0;
+  a.ego_yaw = e.egoPoint[2];
+  if (run) { e.timestamp = timestamp; e.egoPreYaw = e.egoYaw; e.init = true; }
+}
+
+extern "C" int mot_get_tracks(mot_ctx* c, int slot, mot_track* tracks, int max_tracks, int* n_tracks) {
+  if (!c || slot < 0 || slot >= c->batch || !n_tracks || max_tracks < 0) return MOT_E_ARG;
+  int meta[2] = {0, 0};
+  MOT_HIP(c, hipMemcpyAsync(&meta[0], c->d_nt + slot, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+  MOT_HIP(c, hipMemcpyAsync(&meta[1], c->d_tflags + slot, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+  MOT_HIP(c, hipStreamSynchronize(c->stream));
+  c->ego[slot].nt = meta[0];
+  *n_tracks = meta[0];
+  if (meta[1]) {
+    MOT_HIP(c, hipMemsetAsync(c->d_tflags + slot, 0, sizeof(int), c->stream));
+    return fail(c, MOT_E_CAPACITY, "more tracks were created on this stream than max_tracks_total (the reference never frees a track)");
+  }
+  if (meta[0] > max_tracks) return fail(c, MOT_E_CAPACITY, "more tracks than the caller's buffer holds");
+  if (tracks && meta[0] > 0) {
+    MOT_HIP(c, hipMemcpyAsync(tracks, c->d_tout + (size_t)slot * c->max_tracks_total, (size_t)meta[0] * sizeof(mot_track), hipMemcpyDeviceToHost, c->stream));
+    MOT_HIP(c, hipStreamSynchronize(c->stream));
+  }
+  return MOT_OK;
+}
+
+// immUkfJpdaf(), OT/tracking/imm_ukf_jpda.cpp:704
+extern "C" int mot_track_step(mot_ctx* c, int slot, const float* boxes_global, int m, double timestamp, mot_track* tracks,
+                              int max_tracks, int* n_tracks) {
+  if (!c || slot < 0 || slot >= c->batch || m < 0 || (!boxes_global && m > 0) || !n_tracks) return MOT_E_ARG;
+  if (m > kMaxBoxesPerFrame) return fail(c, MOT_E_CAPACITY, "more boxes in a frame than the library supports (1024)");
+  if (!c->ego[slot].ego_called) return fail(c, MOT_E_STATE, "mot_ego_update must precede mot_track_step (getOriginPoints precedes immUkfJpdaf, OT/tracking/main.cpp:74,166)");
+  for (int b = 0; b < c->batch; b++) c->h_targs[b].run = 0;
+  prepare_track_args(c, slot, m, timestamp, true);
+  if (m > 0) MOT_HIP(c, hipMemcpyAsync(c->d_tboxes + (size_t)slot * kMaxBoxesPerFrame * 24, boxes_global, (size_t)m * 24 * sizeof(float), hipMemcpyHostToDevice, c->stream));
+  MOT_HIP(c, hipMemcpyAsync(c->d_targs, c->h_targs.data(), c->batch * sizeof(TrackFrameArgs), hipMemcpyHostToDevice, c->stream));
+  mot_launch_track(track_buffers(c, false), c->batch, c->stream);
+  MOT_HIP(c, hipGetLastError());
+  return mot_get_tracks(c, slot, tracks, max_tracks, n_tracks);
+}
+
+extern "C" int mot_export_tracks_dev(mot_ctx* c, int batch, void* d_tracks, int max_per_slot, int32_t* d_counts) {
+  if (!c || !d_tracks || !d_counts || batch < 1 || batch > c->batch || max_per_slot < 1) return MOT_E_ARG;
+  mot_launch_export_tracks(track_buffers(c, false), batch, (mot_track*)d_tracks, max_per_slot, (int*)d_counts, c->stream);
+  MOT_HIP(c, hipGetLastError());
+  return MOT_OK;
+}
+
+extern "C" int mot_track_get_state(mot_ctx* c, int slot, int id, mot_track_state* o) {
+  if (!c || slot < 0 || slot >= c->batch || !o || id < 0) return MOT_E_ARG;
+  int nt = 0;
+  MOT_HIP(c, hipMemcpyAsync(&nt, c->d_nt + slot, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+  MOT_HIP(c, hipStreamSynchronize(c->stream));
+  if (id >= nt) return fail(c, MOT_E_ARG, "no such track");
+  DevTrack t;
+  MOT_HIP(c, hipMemcpyAsync(&t, c->d_tracks + (size_t)slot * c->max_tracks_total + id, sizeof t, hipMemcpyDeviceToHost, c->stream));
+  MOT_HIP(c, hipStreamSynchronize(c->stream));
+  memset(o, 0, sizeof *o);
+  memcpy(o->x_merge, t.x[0], 40); memcpy(o->x_cv, t.x[1], 40); memcpy(o->x_ctrv, t.x[2], 40); memcpy(o->x_rm, t.x[3], 40);
+  memcpy(o->p_merge, t.P[0], 200); memcpy(o->p_cv, t.P[1], 200); memcpy(o->p_ctrv, t.P[2], 200); memcpy(o->p_rm, t.P[3], 200);
+  memcpy(o->mode_prob, t.mode, 24); memcpy(o->z_pred, t.zpred, sizeof t.zpred); memcpy(o->s, t.S, sizeof t.S); memcpy(o->k, t.K, sizeof t.K);
+  o->init_meas[0] = t.init_meas[0]; o->init_meas[1] = t.init_meas[1]; o->dist_from_init = t.dist_from_init; o->best_yaw = t.best_yaw;
+  o->lifetime = t.lifetime; o->track_manage = t.track_num; o->is_static = t.is_static; o->is_vis = t.is_vis; o->has_best_box = t.has_best;
+  if (t.has_bbox) memcpy(o->bbox, t.bbox, sizeof t.bbox);
+  if (t.has_best) memcpy(o->best_bbox, t.best_bbox, sizeof t.best_bbox);
+  return MOT_OK;
+}

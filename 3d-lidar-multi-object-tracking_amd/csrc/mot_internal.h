@@ -112,6 +112,68 @@ void mot_launch_cluster_kernel(int which, const MotDevParams& p, const ClusterBu
 void mot_launch_stats_init(const ClusterBuffers& c, int batch, hipStream_t stream);
 void mot_launch_box_kernel(int which, const MotDevParams& p, const ClusterBuffers& c, int batch, int max_n, hipStream_t stream);
 
+// ---- tracker stage ---------------------------------------------------------------------------
+constexpr int kTrackBlock = 1024;                 // one workgroup (16 waves) steps one sensor stream
+constexpr int kTrackWaves = kTrackBlock / 64;
+constexpr int kGateWords = kMaxBoxesPerFrame / 64;  // gate bit-mask of one track over the frame's boxes
+
+struct DevTrack {               // filter state of one track (the reference's class UKF, OT/include/ukf.h:15-263)
+  double x[4][5];               // x_merge_, x_cv_, x_ctrv_, x_rm_
+  double P[4][25];              // P_merge_, P_cv_, P_ctrv_, P_rm_ (row-major)
+  double mode[3];               // modeProbCV_, modeProbCTRV_, modeProbRM_
+  double zpred[3][2], S[3][4], K[3][10];
+  double init_meas[2], dist_from_init, best_yaw;
+  int lifetime, track_num, is_static, is_vis, has_bbox, has_best, pad0, pad1;
+  float bbox[24], best_bbox[24];
+};
+
+struct TrackFrameArgs {         // per slot and step, written by the host
+  int m;                        // boxes this frame
+  int first_frame;              // !init_  (imm_ukf_jpda.cpp:741)
+  int run;                      // 0: leave this slot untouched
+  int pad;
+  double dt;                    // (timestamp - timestamp_) / 1e6   (:807)
+  double ego_yaw;               // egoPoints_[0][2]                 (:1010)
+};
+
+struct MotTrackParams {
+  double gamma_g, p_g, p_d, distance_thres, bb_yaw_change_thres, seed_px, seed_py;
+  int life_time_thres, seed_box_index;
+};
+
+struct TrackBuffers {
+  DevTrack* tracks;             // [B][T]
+  int* nt;                      // [B] tracks ever created
+  const float* boxes;           // [B][kMaxBoxesPerFrame][24], global frame
+  const TrackFrameArgs* args;   // [B]
+  unsigned long long* gate;     // [B][T][kGateWords]
+  unsigned long long* prog;     // [B][T][kGateWords]
+  int* live;                    // [B][2*T]: compact list of live tracks, then their "reached gating" flags
+  mot_track* out;               // [B][T]
+  int* flags;                   // [B] capacity flags
+  const int* m_dev;             // optional: boxes per frame read from counts[b*kCountsStride + kCntBoxes] (fused path)
+  int T;
+  MotTrackParams tp;
+};
+enum { kTrackFlagCapacity = 1 };
+
+void mot_launch_track(const TrackBuffers& t, int batch, hipStream_t stream);
+void mot_launch_export_tracks(const TrackBuffers& t, int batch, mot_track* dst, int max_per_slot, int* dst_counts, hipStream_t stream);
+// boxes of the box stage (sensor frame) -> tracker input (global frame): p_global = R(-yaw) (p - (x, y))
+struct EgoPose { double x, y, yaw; };
+void mot_launch_boxes_to_global(const float* boxes_sensor, const int* counts, const EgoPose* ego, float* boxes_global, int batch, hipStream_t stream);
+
+#ifdef MOT_HIPEMU
+#define MOT_WAVE_SYNC() ((void)__ballot(1))
+#else
+#define MOT_WAVE_SYNC()                                       \
+  do {                                                        \
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");    \
+    __builtin_amdgcn_wave_barrier();                          \
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");    \
+  } while (0)
+#endif
+
 void mot_launch_ground(const MotDevParams& p, const GroundBuffers& g, int batch, int max_n, hipStream_t stream);
 // single kernels, for per-kernel timing (mot_time_stage): which = 0 min-z, 1 polar filter, 2 classify+compact
 void mot_launch_ground_kernel(int which, const MotDevParams& p, const GroundBuffers& g, int batch, int max_n,

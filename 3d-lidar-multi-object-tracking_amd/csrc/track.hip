@@ -1,0 +1,769 @@
+// track.hip — IMM-UKF-PDA multi-object tracker step on gfx950. Product code (HIP, wave64, fp64).
+//
+// Replaces immUkfJpdaf() (OT/tracking/imm_ukf_jpda.cpp:704-1112) and the class UKF it drives
+// (OT/tracking/ukf.cpp) for a batch of independent sensor streams: ONE workgroup steps one stream, ONE wave owns
+// one track at a time ("one warp per track" of BASELINE.json's north_star). The reference walks its tracks one
+// after the other and lets them interact through shared vectors; here the frame step is cut into phases:
+//
+//   P0  clear isVis, compact the live tracks (trackNum != 0) in index order                      (all threads)
+//   PA  per live track (a wave): divergence guard, IMM mixing, 3 x sigma-point prediction, 3 x lidar
+//       measurement prediction, pick the max-det(S) model, gate every box of the frame (NIS < 9.22)
+//       -> bit-mask per track; lanes = sigma points / matrix entries / boxes
+//   PB  one wave, tracks in index order: lifetime += #gated boxes nobody claimed before           (SURVEY.md H12:
+//       matchingVec is shared across the reference's track loop — the only true cross-track order dependence)
+//   PC  per track (a wave): box association + best-box upkeep, second initialisation, track-management state
+//       machine, PDA update of the three models, mode probabilities, merge
+//   PD  over-segmentation merge in closed form (last write of the reference's (i,j) double loop wins)
+//   PE  birth of a track from every unclaimed box, in box order
+//   PF  per-track outputs and the sticky static classification
+//
+// fp64 like the reference; operation order follows the reference except inside reductions over sigma points /
+// measurements (Eigen's own reductions are vectorised, so that order is not defined by the source either).
+// Parity bar: track sets and integer state exact, continuous state <= 1e-4 relative (BASELINE.json).
+#include "mot_internal.h"
+
+#ifndef MOT_HIPEMU
+#define MOT_LAUNCH_BOUNDS(n) __launch_bounds__(n)
+#else
+#define MOT_LAUNCH_BOUNDS(n)
+#endif
+
+#define PI_D 3.14159265358979323846
+
+struct WaveScratch {
+  double x[3][5], P[3][25];      // per-model state being advanced
+  double xo[3][5], Po[3][25];    // copies (mixing inputs)
+  double xm[5], Pm[25];          // merged
+  double mode[3], mm[3][3];
+  double L[3][49];               // Cholesky factors of the augmented covariances
+  double Xs[3][75];              // predicted sigma points, 5 x 15 per model
+  double z[3][2], S[3][4], K[3][10], Tc[3][10];
+  double red[64];                // scratch for reductions
+};
+
+__device__ __forceinline__ int tlane() { return (int)(threadIdx.x & 63); }
+__device__ __forceinline__ double wrap_pi(double a) { while (a > PI_D) a -= 2. * PI_D; while (a < -PI_D) a += 2. * PI_D; return a; }
+__device__ __forceinline__ double det2(const double* m) { return m[0] * m[3] - m[1] * m[2]; }
+__device__ __forceinline__ void inv2(const double* m, double* o) { double d = det2(m); o[0] = m[3] / d; o[1] = -m[1] / d; o[2] = -m[2] / d; o[3] = m[0] / d; }
+__device__ __forceinline__ double wave_sum_d(double v) {
+#pragma unroll
+  for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m, 64);
+  return v;
+}
+
+// determinant of a 5x5 (partial-pivot elimination, what Eigen's PartialPivLU::determinant amounts to)
+__device__ double det5(const double* a) {
+  double m[25];
+  for (int i = 0; i < 25; i++) m[i] = a[i];
+  double det = 1;
+  for (int k = 0; k < 5; k++) {
+    int piv = k; double best = fabs(m[k * 5 + k]);
+    for (int r = k + 1; r < 5; r++) { double v = fabs(m[r * 5 + k]); if (v > best) { best = v; piv = r; } }
+    if (piv != k) { for (int c = 0; c < 5; c++) { double t = m[k * 5 + c]; m[k * 5 + c] = m[piv * 5 + c]; m[piv * 5 + c] = t; } det = -det; }
+    double d = m[k * 5 + k];
+    det *= d;
+    if (d == 0) return det;
+    for (int r = k + 1; r < 5; r++) {
+      double f = m[r * 5 + k] / d;
+      for (int c = k + 1; c < 5; c++) m[r * 5 + c] -= f * m[k * 5 + c];
+    }
+  }
+  return det;
+}
+
+// UKF::UKF + UKF::Initialize, ukf.cpp:20-249, 257-322
+__device__ void track_init(DevTrack* t, double zx, double zy) {
+  for (int a = 0; a < 4; a++) {
+    t->x[a][0] = zx; t->x[a][1] = zy; t->x[a][2] = 0; t->x[a][3] = 0; t->x[a][4] = 0.1;
+    for (int i = 0; i < 25; i++) t->P[a][i] = 0;
+    t->P[a][0] = 0.5; t->P[a][6] = 0.5; t->P[a][12] = 3; t->P[a][18] = 10; t->P[a][24] = 1;
+  }
+  for (int m = 0; m < 3; m++) {
+    t->mode[m] = 0.33; t->zpred[m][0] = zx; t->zpred[m][1] = zy;
+    t->S[m][0] = 1; t->S[m][1] = 0; t->S[m][2] = 0; t->S[m][3] = 1;
+    for (int i = 0; i < 10; i++) t->K[m][i] = 0;
+  }
+  t->init_meas[0] = 0; t->init_meas[1] = 0; t->dist_from_init = 0; t->best_yaw = 0;
+  t->lifetime = 0; t->track_num = 1; t->is_static = 0; t->is_vis = 0; t->has_bbox = 0; t->has_best = 0; t->pad0 = 0; t->pad1 = 0;
+  for (int i = 0; i < 24; i++) { t->bbox[i] = 0.f; t->best_bbox[i] = 0.f; }
+}
+
+// sigma-point weights, ukf.cpp:268-274: lambda_aug = 3 - 7
+__device__ __forceinline__ double ukf_w(int i) { return i == 0 ? (-4.0 / (-4.0 + 7.0)) : (0.5 / (7.0 + -4.0)); }
+
+// ProcessIMMUKF(dt), ukf.cpp:507-527 — whole wave, state in ws
+__device__ void process_imm_ukf(WaveScratch* ws, double dt) {
+  const int lane = tlane();
+  // MixingProbability :439-456 (p1_,p2_,p3_ = rows of the transition matrix :139-154)
+  if (lane < 3) {
+    const int j = lane;
+    const double pj[3] = {j == 0 ? 0.9 : 0.05, j == 1 ? 0.9 : 0.05, j == 2 ? 0.9 : 0.05};  // p[i][j]
+    double sum = ws->mode[0] * pj[0] + ws->mode[1] * pj[1] + ws->mode[2] * pj[2];
+    for (int i = 0; i < 3; i++) ws->mm[i][j] = ws->mode[i] * pj[i] / sum;
+  }
+  for (int e = lane; e < 15; e += 64) ws->xo[e / 5][e % 5] = ws->x[e / 5][e % 5];
+  for (int e = lane; e < 75; e += 64) ws->Po[e / 25][e % 25] = ws->P[e / 25][e % 25];
+  MOT_WAVE_SYNC();
+  // Interaction :458-500
+  if (lane < 15) {
+    int j = lane / 5, r = lane % 5;
+    double v = ws->mm[0][j] * ws->xo[0][r] + ws->mm[1][j] * ws->xo[1][r] + ws->mm[2][j] * ws->xo[2][r];
+    if (r == 3) v = wrap_pi(ws->xo[j][3]);  // yaw is not mixed
+    ws->x[j][r] = v;
+  }
+  MOT_WAVE_SYNC();
+  for (int e = lane; e < 75; e += 64) {
+    int j = e / 25, r = (e % 25) / 5, c = e % 5;
+    double acc = 0;
+    for (int i = 0; i < 3; i++) acc = acc + ws->mm[i][j] * (ws->Po[i][r * 5 + c] + (ws->xo[i][r] - ws->x[j][r]) * (ws->xo[i][c] - ws->x[j][c]));
+    ws->P[j][r * 5 + c] = acc;
+  }
+  MOT_WAVE_SYNC();
+  // Prediction(dt, m) :630-772. Augmented covariance, Eigen 3.2.10 LLT::unblocked semantics: a non-positive pivot
+  // stops the factorisation and matrixL() returns the partially overwritten lower triangle.
+  if (lane < 3) {
+    const int m = lane;
+    const double std_a = m == 2 ? 3. : 2., std_yawdd = m == 2 ? 3. : 2.;  // ukf.cpp:68-73
+    double* a = ws->L[m];
+    for (int i = 0; i < 49; i++) a[i] = 0;
+    for (int r = 0; r < 5; r++) for (int c = 0; c < 5; c++) a[r * 7 + c] = ws->P[m][r * 5 + c];
+    a[5 * 7 + 5] = std_a * std_a;
+    a[6 * 7 + 6] = std_yawdd * std_yawdd;
+    for (int k = 0; k < 7; k++) {
+      double xk = a[k * 7 + k];
+      for (int j = 0; j < k; j++) xk -= a[k * 7 + j] * a[k * 7 + j];
+      if (xk <= 0) break;
+      a[k * 7 + k] = xk = sqrt(xk);
+      for (int r = k + 1; r < 7; r++) {
+        double s = 0;
+        for (int j = 0; j < k; j++) s += a[r * 7 + j] * a[k * 7 + j];
+        a[r * 7 + k] -= s;
+      }
+      double inv = 1.0 / xk;  // Eigen 3.2: `A21 /= x` multiplies by the reciprocal
+      for (int r = k + 1; r < 7; r++) a[r * 7 + k] *= inv;
+    }
+    for (int r = 0; r < 7; r++) for (int c = r + 1; c < 7; c++) a[r * 7 + c] = 0;
+  }
+  MOT_WAVE_SYNC();
+  if (lane < 45) {  // one lane per (model, sigma point): Cv :573, Ctrv :539, randomMotion :602
+    const int m = lane / 15, i = lane % 15;
+    const double sc = sqrt(-4.0 + 7.0);
+    double xa[7];
+    for (int r = 0; r < 7; r++) {
+      double base = r < 5 ? ws->x[m][r] : 0.0;
+      if (i == 0) xa[r] = base;
+      else if (i <= 7) xa[r] = base + sc * ws->L[m][r * 7 + (i - 1)];
+      else xa[r] = base - sc * ws->L[m][r * 7 + (i - 8)];
+    }
+    const double p_x = xa[0], p_y = xa[1], v = xa[2], yaw = xa[3], yawd = xa[4], nu_a = xa[5], nu_yawdd = xa[6];
+    double s[5];
+    if (m == 2) { s[0] = p_x; s[1] = p_y; s[2] = v; s[3] = yaw; s[4] = yawd; }
+    else {
+      double px_p, py_p;
+      if (m == 0) { px_p = p_x + v * cos(yaw) * dt; py_p = p_y + v * sin(yaw) * dt; }
+      else if (fabs(yawd) > 0.001) {
+        px_p = p_x + v / yawd * (sin(yaw + yawd * dt) - sin(yaw));
+        py_p = p_y + v / yawd * (cos(yaw) - cos(yaw + yawd * dt));
+      } else { px_p = p_x + v * dt * cos(yaw); py_p = p_y + v * dt * sin(yaw); }
+      double v_p = v;
+      double yaw_p = m == 0 ? yaw : yaw + yawd * dt;
+      double yawd_p = yawd;
+      px_p = px_p + 0.5 * nu_a * dt * dt * cos(yaw);
+      py_p = py_p + 0.5 * nu_a * dt * dt * sin(yaw);
+      v_p = v_p + nu_a * dt;
+      yaw_p = yaw_p + 0.5 * nu_yawdd * dt * dt;
+      yawd_p = yawd_p + nu_yawdd * dt;
+      s[0] = px_p; s[1] = py_p; s[2] = v_p; s[3] = yaw_p; s[4] = yawd_p;
+    }
+    for (int r = 0; r < 5; r++) ws->Xs[m][r * 15 + i] = s[r];
+  }
+  MOT_WAVE_SYNC();
+  if (lane < 15) {  // predicted mean :736-742
+    int m = lane / 5, r = lane % 5;
+    double acc = 0;
+    for (int i = 0; i < 15; i++) acc = acc + ukf_w(i) * ws->Xs[m][r * 15 + i];
+    if (r == 3) acc = wrap_pi(acc);
+    ws->x[m][r] = acc;
+  }
+  MOT_WAVE_SYNC();
+  for (int e = lane; e < 75; e += 64) {  // predicted covariance :743-749
+    int m = e / 25, r = (e % 25) / 5, c = e % 5;
+    double acc = 0;
+    for (int i = 0; i < 15; i++) {
+      double dr = ws->Xs[m][r * 15 + i] - ws->x[m][r], dc = ws->Xs[m][c * 15 + i] - ws->x[m][c];
+      if (r == 3) dr = wrap_pi(dr);
+      if (c == 3) dc = wrap_pi(dc);
+      acc = acc + (ukf_w(i) * dr) * dc;
+    }
+    ws->P[m][r * 5 + c] = acc;
+  }
+  // UpdateLidar(m) :778-902
+  if (lane < 6) {
+    int m = lane / 2, c = lane % 2;
+    double acc = 0;
+    for (int i = 0; i < 15; i++) acc = acc + ukf_w(i) * ws->Xs[m][c * 15 + i];
+    ws->z[m][c] = acc;
+  }
+  MOT_WAVE_SYNC();
+  if (lane < 12) {
+    int m = lane / 4, r = (lane % 4) / 2, c = lane % 2;
+    double acc = 0;
+    for (int i = 0; i < 15; i++) acc = acc + (ukf_w(i) * (ws->Xs[m][r * 15 + i] - ws->z[m][r])) * (ws->Xs[m][c * 15 + i] - ws->z[m][c]);
+    if (r == c) acc = acc + 0.15 * 0.15;  // R, ukf.cpp:91-94
+    ws->S[m][r * 2 + c] = acc;
+  }
+  if (lane >= 16 && lane < 46) {
+    int e = lane - 16, m = e / 10, r = (e % 10) / 2, c = e % 2;
+    double acc = 0;
+    for (int i = 0; i < 15; i++) acc = acc + (ukf_w(i) * (ws->Xs[m][r * 15 + i] - ws->x[m][r])) * (ws->Xs[m][c * 15 + i] - ws->z[m][c]);
+    ws->Tc[m][r * 2 + c] = acc;
+  }
+  MOT_WAVE_SYNC();
+  if (lane < 30) {
+    int m = lane / 10, r = (lane % 10) / 2, c = lane % 2;
+    double Si[4]; inv2(ws->S[m], Si);
+    ws->K[m][r * 2 + c] = ws->Tc[m][r * 2 + 0] * Si[0 * 2 + c] + ws->Tc[m][r * 2 + 1] * Si[1 * 2 + c];
+  }
+  MOT_WAVE_SYNC();
+}
+
+// findMaxZandS :176-203
+__device__ __forceinline__ int find_max_model(const double S[3][4]) {
+  double cv = det2(S[0]), ctrv = det2(S[1]), rm = det2(S[2]);
+  if (cv > ctrv) return (cv > rm) ? 0 : 2;
+  return (ctrv > rm) ? 1 : 2;
+}
+
+// getCpFromBbox :465-479 — fp32 products, then fp64
+__device__ void cp_from_bbox(const float* b, double* cx, double* cy) {
+  float p1x = b[0], p1y = b[1], p2x = b[3], p2y = b[4], p3x = b[6], p3y = b[7], p4x = b[9], p4y = b[10];
+  double S1 = ((p4x - p2x) * (p1y - p2y) - (p4y - p2y) * (p1x - p2x)) / 2;
+  double S2 = ((p4x - p2x) * (p2y - p3y) - (p4y - p2y) * (p2x - p3x)) / 2;
+  *cx = p1x + (p3x - p1x) * S1 / (S1 + S2);
+  *cy = p1y + (p3y - p1y) * S1 / (S1 + S2);
+}
+// getBboxArea :482-494
+__device__ double bbox_area(const float* b) {
+  float p1x = b[0], p1y = b[1], p2x = b[3], p2y = b[4], p3x = b[6], p3y = b[7], p4x = b[9], p4y = b[10];
+  double tri1 = 0.5 * fabsf((p1x - p3x) * (p2y - p3y) - (p2x - p3x) * (p1y - p3y));
+  double tri2 = 0.5 * fabsf((p1x - p4x) * (p3y - p4y) - (p3x - p4x) * (p1y - p4y));
+  return tri1 + tri2;
+}
+// getBBoxYaw :535-563 — fp32 sqrt / atan2 (glibc-exact atan2f, mot_math.h)
+__device__ double bbox_yaw(const float* b, double ukfYaw) {
+  float p1x = b[0], p1y = b[1], p2x = b[3], p2y = b[4], p3x = b[6], p3y = b[7];
+  double dist1 = sqrtf((p1x - p2x) * (p1x - p2x) + (p1y - p2y) * (p1y - p2y));
+  double dist2 = sqrtf((p3x - p2x) * (p3x - p2x) + (p3y - p2y) * (p3y - p2y));
+  double yaw;
+  if (dist1 > dist2) yaw = mot_atan2f(p1y - p2y, p1x - p2x);
+  else yaw = mot_atan2f(p3y - p2y, p3x - p2x);
+  double diffYaw = fabs(yaw - ukfYaw);
+  if (diffYaw < PI_D * 0.5) return yaw;
+  yaw += PI_D;
+  return wrap_pi(yaw);
+}
+// updateBoxYaw :512-532
+__device__ void rotate_box(float* b, const double* cp, double a) {
+  for (int i = 0; i < 8; i++) {
+    double preX = b[3 * i], preY = b[3 * i + 1];
+    b[3 * i] = (float)(cos(a) * (preX - cp[0]) - sin(a) * (preY - cp[1]) + cp[0]);
+    b[3 * i + 1] = (float)(sin(a) * (preX - cp[0]) + cos(a) * (preY - cp[1]) + cp[1]);
+  }
+}
+// updateBB :565-653 (single lane)
+__device__ void update_bb(const MotTrackParams& tp, DevTrack* u) {
+  if (!u->is_vis) return;
+  if (!u->has_best) {
+    for (int i = 0; i < 24; i++) u->best_bbox[i] = u->bbox[i];
+    u->has_best = 1; u->best_yaw = bbox_yaw(u->bbox, u->x[0][3]);
+    return;
+  }
+  double cp[2], bestCP[2];
+  cp_from_bbox(u->bbox, &cp[0], &cp[1]);
+  cp_from_bbox(u->best_bbox, &bestCP[0], &bestCP[1]);
+  double dt0 = cp[0] - bestCP[0], dt1 = cp[1] - bestCP[1];
+  double yaw = bbox_yaw(u->bbox, u->x[0][3]);
+  double area = bbox_area(u->bbox), bestArea = bbox_area(u->best_bbox);
+  double deltaArea = area - bestArea;
+  if (deltaArea < 0) {  // updateVisBoxArea :496-510
+    for (int i = 0; i < 8; i++) { u->bbox[3 * i] = (float)(u->best_bbox[3 * i] + dt0); u->bbox[3 * i + 1] = (float)(u->best_bbox[3 * i + 1] + dt1); }
+  } else if (deltaArea > 0) {
+    for (int i = 0; i < 24; i++) u->best_bbox[i] = u->bbox[i];
+  }
+  double currentYaw = bbox_yaw(u->bbox, u->x[0][3]);
+  double DiffYaw = yaw - currentYaw;
+  if (fabs(DiffYaw) > tp.bb_yaw_change_thres) {
+  } else if (fabs(DiffYaw) < tp.bb_yaw_change_thres) {
+    rotate_box(u->bbox, cp, DiffYaw);
+    rotate_box(u->best_bbox, cp, DiffYaw);
+    u->best_yaw = yaw;
+  }
+}
+
+__device__ void load_track(WaveScratch* ws, const DevTrack* t) {
+  const int lane = tlane();
+  for (int e = lane; e < 15; e += 64) ws->x[e / 5][e % 5] = t->x[1 + e / 5][e % 5];
+  for (int e = lane; e < 75; e += 64) ws->P[e / 25][e % 25] = t->P[1 + e / 25][e % 25];
+  if (lane < 5) ws->xm[lane] = t->x[0][lane];
+  if (lane < 25) ws->Pm[lane] = t->P[0][lane];
+  if (lane < 3) ws->mode[lane] = t->mode[lane];
+  if (lane < 6) ws->z[lane / 2][lane % 2] = t->zpred[lane / 2][lane % 2];
+  if (lane < 12) ws->S[lane / 4][lane % 4] = t->S[lane / 4][lane % 4];
+  if (lane < 30) ws->K[lane / 10][lane % 10] = t->K[lane / 10][lane % 10];
+  MOT_WAVE_SYNC();
+}
+__device__ void store_models(const WaveScratch* ws, DevTrack* t) {
+  const int lane = tlane();
+  for (int e = lane; e < 15; e += 64) t->x[1 + e / 5][e % 5] = ws->x[e / 5][e % 5];
+  for (int e = lane; e < 75; e += 64) t->P[1 + e / 25][e % 25] = ws->P[e / 25][e % 25];
+  if (lane < 6) t->zpred[lane / 2][lane % 2] = ws->z[lane / 2][lane % 2];
+  if (lane < 12) t->S[lane / 4][lane % 4] = ws->S[lane / 4][lane % 4];
+  if (lane < 30) t->K[lane / 10][lane % 10] = ws->K[lane / 10][lane % 10];
+}
+
+__global__ void MOT_LAUNCH_BOUNDS(kTrackBlock)
+track_step_kernel(TrackBuffers tb) {
+  __shared__ WaveScratch s_ws[kTrackWaves];
+  __shared__ double s_cpx[kMaxBoxesPerFrame], s_cpy[kMaxBoxesPerFrame];  // box centres (trackPoints[k][0..1])
+  __shared__ unsigned long long s_matched[kGateWords];
+  __shared__ int s_wcount[kTrackWaves];
+  __shared__ int s_nlive, s_born;
+  const int b = blockIdx.x;
+  const TrackFrameArgs args = tb.args[b];
+  if (!args.run) return;
+  const MotTrackParams tp = tb.tp;
+  const int tid = threadIdx.x, lane = tlane(), wave = tid >> 6;
+  const int M = tb.m_dev ? min(tb.m_dev[b * kCountsStride + kCntBoxes], kMaxBoxesPerFrame) : args.m;
+  DevTrack* __restrict__ tracks = tb.tracks + (long)b * tb.T;
+  const float* __restrict__ boxes = tb.boxes + (long)b * kMaxBoxesPerFrame * 24;
+  unsigned long long* __restrict__ gate = tb.gate + (long)b * tb.T * kGateWords;
+  unsigned long long* __restrict__ prog = tb.prog + (long)b * tb.T * kGateWords;
+  int* __restrict__ live = tb.live + (long)b * 2 * tb.T;
+  int* __restrict__ liveok = live + tb.T;
+  mot_track* __restrict__ out = tb.out + (long)b * tb.T;
+  WaveScratch* ws = &s_ws[wave];
+  const int nt0 = tb.nt[b];
+
+  // trackPoints :713-736 — centre of every box
+  for (int k = tid; k < M; k += kTrackBlock) cp_from_bbox(boxes + (long)k * 24, &s_cpx[k], &s_cpy[k]);
+
+  if (args.first_frame) {  // :741-795 — seed exactly one track at a hard-coded position
+    if (tid == 0) {
+      int n = 0;
+      if (M > tp.seed_box_index && tb.T >= 1) {
+        track_init(&tracks[0], tp.seed_px, tp.seed_py);
+        mot_track o;
+        o.id = 0; o.track_manage = 1; o.is_static = 0; o.is_vis = 0;
+        o.px = (float)tp.seed_px; o.py = (float)tp.seed_py; o.pz = (float)(-1.73 / 2); o.lifetime = 0; o.v = 0; o.yaw = 0;
+        for (int i = 0; i < 24; i++) o.vis_box[i] = 0.f;
+        out[0] = o;
+        n = 1;
+      }
+      tb.nt[b] = n;
+    }
+    return;
+  }
+
+  // ---- P0: isVisBB_ = false for every track (:813); compact the live ones in index order
+  if (tid == 0) { s_nlive = 0; s_born = 0; }
+  for (int w = tid; w < kGateWords; w += kTrackBlock) s_matched[w] = 0ull;
+  __syncthreads();
+  for (int base = 0; base < nt0; base += kTrackBlock) {
+    int t = base + tid;
+    bool alive = false;
+    if (t < nt0) { tracks[t].is_vis = 0; alive = tracks[t].track_num != 0; }
+    unsigned long long bm = __ballot(alive);
+    if (lane == 0) s_wcount[wave] = __popcll(bm);
+    __syncthreads();
+    int off = s_nlive;
+    for (int w = 0; w < wave; w++) off += s_wcount[w];
+    if (alive) live[off + __popcll(bm & ((1ull << lane) - 1ull))] = t;
+    __syncthreads();
+    if (tid == 0) { int s = 0; for (int w = 0; w < kTrackWaves; w++) s += s_wcount[w]; s_nlive += s; }
+    __syncthreads();
+  }
+  const int nlive = s_nlive;
+
+  // ---- PA: prediction + gating, one wave per live track
+  for (int li = wave; li < nlive; li += kTrackWaves) {
+    const int t = live[li];
+    DevTrack* u = &tracks[t];
+    load_track(ws, u);
+    bool ok = true;
+    if (det5(ws->Pm) > 10 || ws->Pm[24] > 1000) ok = false;  // divergence guard :828-831
+    if (ok) {
+      process_imm_ukf(ws, args.dt);  // :840
+      store_models(ws, u);
+      int mx = find_max_model(ws->S);
+      double maxS[4];
+      for (int k = 0; k < 4; k++) maxS[k] = ws->S[mx][k] * 4;  // :844
+      double detS = det2(maxS);
+      if (detS != detS || detS > 10) ok = false;  // :848-851
+      if (ok) {
+        // measurementValidation :205-257 as a bit-mask over the boxes; second-init keeps the running minimum
+        const bool secondInit = u->track_num == 1;
+        double Si[4]; inv2(maxS, Si);
+        const double zx = ws->z[mx][0], zy = ws->z[mx][1];
+        double run_min = 999;  // smallestNIS
+        for (int w = 0; w < kGateWords; w++) {
+          int k = w * 64 + lane;
+          bool g = false; double nis = 1e300;
+          if (w * 64 < M) {
+            if (k < M) {
+              double d0 = s_cpx[k] - zx, d1 = s_cpy[k] - zy;
+              double t0 = d0 * Si[0] + d1 * Si[2], t1 = d0 * Si[1] + d1 * Si[3];
+              nis = t0 * d0 + t1 * d1;
+              g = nis < tp.gamma_g;
+            }
+          }
+          unsigned long long gm = (w * 64 < M) ? __ballot(g) : 0ull;
+          unsigned long long pm = 0ull;
+          if (secondInit && gm) {
+            // `nis < smallestNIS` evaluated box by box: a box is kept iff it beats every earlier gated box
+            double v = g ? nis : 1e300, pre = v;
+#pragma unroll
+            for (int d = 1; d < 64; d <<= 1) { double o = __shfl_up(pre, d, 64); if (lane >= d) pre = o < pre ? o : pre; }
+            double excl = __shfl_up(pre, 1, 64);
+            if (lane == 0) excl = 1e300;
+            excl = excl < run_min ? excl : run_min;
+            pm = __ballot(g && nis < excl);
+            double tile_min = __shfl(pre, 63, 64);
+            run_min = tile_min < run_min ? tile_min : run_min;
+          }
+          if (lane == 0) { gate[(long)t * kGateWords + w] = gm; prog[(long)t * kGateWords + w] = pm; }
+        }
+      }
+    }
+    if (lane == 0) {
+      liveok[li] = ok ? 1 : 0;
+      if (!ok) u->track_num = 0;
+    }
+    MOT_WAVE_SYNC();
+  }
+  __syncthreads();
+
+  // ---- PB: matchingVec / lifetime_ bookkeeping in track order (:232)
+  if (wave == 0) {
+    unsigned long long matched = 0ull;  // lane w holds word w
+    for (int li = 0; li < nlive; li++) {
+      if (!liveok[li]) continue;
+      const int t = live[li];
+      unsigned long long g = lane < kGateWords ? gate[(long)t * kGateWords + lane] : 0ull;
+      unsigned long long pg = lane < kGateWords ? prog[(long)t * kGateWords + lane] : 0ull;
+      int fresh = __popcll(g & ~matched);
+#pragma unroll
+      for (int m = 32; m >= 1; m >>= 1) fresh += __shfl_xor(fresh, m, 64);
+      const bool secondInit = tracks[t].track_num == 1;
+      if (lane == 0 && fresh) tracks[t].lifetime += fresh;
+      matched |= secondInit ? pg : g;
+    }
+    if (lane < kGateWords) s_matched[lane] = matched;
+  }
+  __syncthreads();
+
+  // ---- PC: association, state machine, PDA update
+  for (int li = wave; li < nlive; li += kTrackWaves) {
+    if (!liveok[li]) continue;
+    const int t = live[li];
+    DevTrack* u = &tracks[t];
+    load_track(ws, u);
+    const unsigned long long* gt = gate + (long)t * kGateWords;
+    const unsigned long long* pt = prog + (long)t * kGateWords;
+    int track_num = u->track_num;
+    const bool secondInit = track_num == 1;
+    int ngate = 0;
+    for (int w = 0; w < kGateWords; w++) ngate += __popcll(gt[w]);
+    int nm = ngate;
+    int last_prog = -1;  // second init: the box that finally holds smallestNIS = the last progressive minimum
+    if (secondInit) {
+      for (int w = 0; w < kGateWords; w++) if (pt[w]) last_prog = w * 64 + 63 - __clzll((long long)pt[w]);
+      nm = last_prog >= 0 ? 1 : 0;
+    }
+    // associateBB :416-463 + getNearestEuclidBBox :396-413 (int minDist, truncated on assignment)
+    if (!secondInit && ngate > 0 && track_num == 5 && u->lifetime > tp.life_time_thres) {
+      // sequential semantics: scan gated boxes in order, keep (minDist:int, minInd); reproduced by one lane
+      if (lane == 0) {
+        int minDist = 999, minBox = -1, first = -1;
+        double px = ws->xm[0], py = ws->xm[1];
+        for (int w = 0; w < kGateWords; w++) {
+          unsigned long long g = gt[w];
+          while (g) {
+            int k = w * 64 + __ffsll(g) - 1;
+            g &= g - 1ull;
+            if (first < 0) first = k;
+            double dist = sqrt((px - s_cpx[k]) * (px - s_cpx[k]) + (py - s_cpy[k]) * (py - s_cpy[k]));
+            if (dist < minDist) { minDist = (int)dist; minBox = k; }
+          }
+        }
+        if (minBox < 0) minBox = first;  // minInd stays 0 = first gated box
+        if (minDist < tp.distance_thres) {
+          const float* bx = boxes + (long)minBox * 24;
+          for (int h = 0; h < 2; h++)
+            for (int q = 0; q < 4; q++) {
+              u->bbox[(h * 4 + q) * 3] = bx[3 * q];
+              u->bbox[(h * 4 + q) * 3 + 1] = bx[3 * q + 1];
+              u->bbox[(h * 4 + q) * 3 + 2] = (float)(h == 0 ? -1.73 : 0);
+            }
+          u->is_vis = 1; u->has_bbox = 1;
+        }
+      }
+    }
+    if (lane == 0) update_bb(tp, u);
+    MOT_WAVE_SYNC();
+    if (secondInit) {  // :882-921
+      if (lane == 0) {
+        if (nm == 0) u->track_num = 0;
+        else {
+          u->init_meas[0] = ws->xm[0]; u->init_meas[1] = ws->xm[1];
+          double targetX = s_cpx[last_prog], targetY = s_cpy[last_prog];
+          double dX = targetX - ws->xm[0], dY = targetY - ws->xm[1];
+          double targetYaw = wrap_pi(atan2(dY, dX));
+          for (int a = 0; a < 4; a++) { u->x[a][0] = targetX; u->x[a][1] = targetY; u->x[a][2] = 2; u->x[a][3] = targetYaw; }
+          u->track_num = track_num + 1;
+        }
+      }
+      MOT_WAVE_SYNC();
+      continue;
+    }
+    // track management :924-944
+    if (nm > 0) {
+      if (track_num < 3) track_num++;
+      else if (track_num == 3) track_num = 5;
+      else if (track_num >= 5) track_num = 5;
+    } else {
+      if (track_num < 5) track_num = 0;
+      else if (track_num >= 5 && track_num < 10) track_num++;
+      else track_num = 0;  // `else if(trackNumVec_[i] = 10)` assigns, is true, then sets 0
+    }
+    if (lane == 0) u->track_num = track_num;
+    if (track_num == 0) { MOT_WAVE_SYNC(); continue; }
+
+    // filterPDA :259-394 — lanes over the gated measurements
+    {
+      const double numMeas = nm;
+      const double bpda = 2 * numMeas * (1 - tp.p_d * tp.p_g) / (tp.gamma_g * tp.p_d);
+      double Si[3][4];
+      for (int m = 0; m < 3; m++) inv2(ws->S[m], Si[m]);
+      double eSum[3] = {0, 0, 0};
+      for (int w = 0; w * 64 < M; w++) {
+        int k = w * 64 + lane;
+        bool g = (gt[w] >> lane) & 1ull;
+        for (int m = 0; m < 3; m++) {
+          double e = 0;
+          if (g) {
+            double d0 = s_cpx[k] - ws->z[m][0], d1 = s_cpy[k] - ws->z[m][1];
+            double h0 = -0.5 * d0, h1 = -0.5 * d1;
+            double t0 = h0 * Si[m][0] + h1 * Si[m][2], t1 = h0 * Si[m][1] + h1 * Si[m][3];
+            e = exp(t0 * d0 + t1 * d1);
+          }
+          eSum[m] += wave_sum_d(e);
+        }
+      }
+      double sx[3][2] = {{0, 0}, {0, 0}, {0, 0}};
+      for (int w = 0; w * 64 < M; w++) {
+        int k = w * 64 + lane;
+        bool g = (gt[w] >> lane) & 1ull;
+        for (int m = 0; m < 3; m++) {
+          double a0 = 0, a1 = 0;
+          if (g) {
+            double d0 = s_cpx[k] - ws->z[m][0], d1 = s_cpy[k] - ws->z[m][1];
+            double h0 = -0.5 * d0, h1 = -0.5 * d1;
+            double t0 = h0 * Si[m][0] + h1 * Si[m][2], t1 = h0 * Si[m][1] + h1 * Si[m][3];
+            double beta = exp(t0 * d0 + t1 * d1) / (bpda + eSum[m]);
+            a0 = beta * d0; a1 = beta * d1;
+          }
+          sx[m][0] += wave_sum_d(a0); sx[m][1] += wave_sum_d(a1);
+        }
+      }
+      double sp[3][4] = {{0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}};
+      for (int w = 0; w * 64 < M; w++) {
+        int k = w * 64 + lane;
+        bool g = (gt[w] >> lane) & 1ull;
+        for (int m = 0; m < 3; m++) {
+          double q[4] = {0, 0, 0, 0};
+          if (g) {
+            double d[2] = {s_cpx[k] - ws->z[m][0], s_cpy[k] - ws->z[m][1]};
+            double h0 = -0.5 * d[0], h1 = -0.5 * d[1];
+            double t0 = h0 * Si[m][0] + h1 * Si[m][2], t1 = h0 * Si[m][1] + h1 * Si[m][3];
+            double beta = exp(t0 * d[0] + t1 * d[1]) / (bpda + eSum[m]);
+            for (int r = 0; r < 2; r++) for (int c = 0; c < 2; c++) q[r * 2 + c] = (beta * d[r]) * d[c] - sx[m][r] * sx[m][c];
+          }
+          for (int e2 = 0; e2 < 4; e2++) sp[m][e2] += wave_sum_d(q[e2]);
+        }
+      }
+      // x += K*sigmaX ; P update (:341-367) — one lane per matrix entry
+      MOT_WAVE_SYNC();
+      if (lane < 15) {
+        int m = lane / 5, r = lane % 5;
+        double v = ws->x[m][r] + (ws->K[m][r * 2] * sx[m][0] + ws->K[m][r * 2 + 1] * sx[m][1]);
+        ws->xo[m][r] = r == 3 ? wrap_pi(v) : v;
+      }
+      for (int e = lane; e < 75; e += 64) {
+        int m = e / 25, r = (e % 25) / 5, c = e % 5;
+        const double* K = ws->K[m];
+        double ks0 = K[r * 2] * ws->S[m][0] + K[r * 2 + 1] * ws->S[m][2], ks1 = K[r * 2] * ws->S[m][1] + K[r * 2 + 1] * ws->S[m][3];
+        double kp0 = K[r * 2] * sp[m][0] + K[r * 2 + 1] * sp[m][2], kp1 = K[r * 2] * sp[m][1] + K[r * 2 + 1] * sp[m][3];
+        double kskt = ks0 * K[c * 2] + ks1 * K[c * 2 + 1];
+        double kpk = kp0 * K[c * 2] + kp1 * K[c * 2 + 1];
+        double P = ws->P[m][r * 5 + c];
+        double betaZero = bpda / (bpda + eSum[m]);
+        ws->Po[m][r * 5 + c] = nm != 0 ? betaZero * P + (1 - betaZero) * (P - kskt) + kpk : P - kskt;
+      }
+      MOT_WAVE_SYNC();
+      // likelihoods :369-393, UpdateModeProb ukf.cpp:384-397, merge :419-437
+      int mx = find_max_model(ws->S);
+      double Vk = PI_D * sqrt(tp.gamma_g * det2(ws->S[mx]));
+      double lambda[3];
+      for (int m = 0; m < 3; m++) {
+        if (nm != 0) lambda[m] = (1 - tp.p_g * tp.p_d) / pow(Vk, numMeas) + tp.p_d * pow(Vk, 1 - numMeas) * eSum[m] / (numMeas * sqrt(2 * PI_D * det2(ws->S[m])));
+        else lambda[m] = (1 - tp.p_g * tp.p_d) / pow(Vk, numMeas);
+      }
+      double mode[3];
+      double sum = lambda[0] * ws->mode[0] + lambda[1] * ws->mode[1] + lambda[2] * ws->mode[2];
+      for (int m = 0; m < 3; m++) { mode[m] = (lambda[m] * ws->mode[m]) / sum; if (fabs(mode[m]) < 0.0001) mode[m] = 0.0001; }
+      double xmv[5];
+      for (int r = 0; r < 5; r++) xmv[r] = mode[0] * ws->xo[0][r] + mode[1] * ws->xo[1][r] + mode[2] * ws->xo[2][r];
+      xmv[3] = wrap_pi(xmv[3]);
+      double yaw;  // UpdateYawWithHighProb :399-417
+      if (mode[0] > mode[1]) yaw = (mode[0] > mode[2]) ? ws->xo[0][3] : ws->xo[2][3];
+      else yaw = (mode[1] > mode[2]) ? ws->xo[1][3] : ws->xo[2][3];
+      xmv[3] = yaw;
+      if (lane < 25) {
+        int r = lane / 5, c = lane % 5;
+        double acc = 0;
+        for (int m = 0; m < 3; m++) acc = acc + mode[m] * (ws->Po[m][r * 5 + c] + (ws->xo[m][r] - xmv[r]) * (ws->xo[m][c] - xmv[c]));
+        u->P[0][r * 5 + c] = acc;
+      }
+      if (lane < 5) u->x[0][lane] = xmv[lane];
+      if (lane < 3) u->mode[lane] = mode[lane];
+      for (int e = lane; e < 15; e += 64) u->x[1 + e / 5][e % 5] = ws->xo[e / 5][e % 5];
+      for (int e = lane; e < 75; e += 64) u->P[1 + e / 25][e % 25] = ws->Po[e / 25][e % 25];
+    }
+    MOT_WAVE_SYNC();
+  }
+  __syncthreads();
+
+  // ---- PD: mergeOverSegmentation :666-700. The reference runs `for i { for j { if inside(j, box_i) {trackNum[i]=5; trackNum[j]=0;} } }`
+  // over ALL tracks; the value a track ends with is decided by the last (i,j) pair that writes it.
+  for (int t = tid; t < nt0; t += kTrackBlock) { gate[(long)t * kGateWords] = 0ull; prog[(long)t * kGateWords] = 0ull; }  // reuse: [t] -> has_a / max_b+1
+  __syncthreads();
+  for (int i = wave; i < nt0; i += kTrackWaves) {
+    const DevTrack* a = &tracks[i];
+    if (!a->is_vis) continue;
+    const double v1x = a->bbox[0], v1y = a->bbox[1], v2x = a->bbox[3], v2y = a->bbox[4], v3x = a->bbox[6], v3y = a->bbox[7], v4x = a->bbox[9], v4y = a->bbox[10];
+    const double cp1x = (v1x + v2x + v3x) / 3, cp1y = (v1y + v2y + v3y) / 3, cp2x = (v1x + v4x + v3x) / 3, cp2y = (v1y + v4y + v3y) / 3;
+#define ICOEF(ax, ay, bx, by, px, py, cx, cy) ((((ax) - (bx)) * ((py) - (ay)) + ((ay) - (by)) * ((ax) - (px))) * (((ax) - (bx)) * ((cy) - (ay)) + ((ay) - (by)) * ((ax) - (cx))))
+    bool any = false;
+    for (int j = lane; j < nt0; j += 64) {
+      if (j == i) continue;
+      double px = tracks[j].x[0][0], py = tracks[j].x[0][1];
+      double c1 = ICOEF(v1x, v1y, v2x, v2y, px, py, cp1x, cp1y), c2 = ICOEF(v1x, v1y, v3x, v3y, px, py, cp1x, cp1y),
+             c3 = ICOEF(v3x, v3y, v2x, v2y, px, py, cp1x, cp1y), c4 = ICOEF(v1x, v1y, v4x, v4y, px, py, cp2x, cp2y),
+             c5 = ICOEF(v1x, v1y, v3x, v3y, px, py, cp2x, cp2y), c6 = ICOEF(v3x, v3y, v4x, v4y, px, py, cp2x, cp2y);
+      if ((c1 > 0 && c2 > 0 && c3 > 0) || (c4 > 0 && c5 > 0 && c6 > 0)) {
+        any = true;
+        atomicMax(&prog[(long)j * kGateWords], (unsigned long long)(i + 1));  // j is zeroed by (i, j)
+      }
+    }
+#undef ICOEF
+    if (__any(any) && lane == 0) gate[(long)i * kGateWords] = 1ull;  // i is set to 5 by some (i, j)
+  }
+  __syncthreads();
+  for (int t = tid; t < nt0; t += kTrackBlock) {
+    bool has_a = gate[(long)t * kGateWords] != 0ull;
+    int bmax = (int)prog[(long)t * kGateWords] - 1;  // largest i whose box contains t, or -1
+    if (bmax >= 0 && (!has_a || bmax > t)) tracks[t].track_num = 0;
+    else if (has_a) tracks[t].track_num = 5;
+  }
+  __syncthreads();
+
+  // ---- PE: birth :972-989 — one new track per unclaimed box, in box order
+  if (wave == 0) {
+    int born = 0;
+    for (int w = 0; w * 64 < M; w++) {
+      int k = w * 64 + lane;
+      bool un = k < M && !((s_matched[w] >> lane) & 1ull);
+      unsigned long long um = __ballot(un);
+      if (un) {
+        int idx = nt0 + born + __popcll(um & ((1ull << lane) - 1ull));
+        if (idx < tb.T) track_init(&tracks[idx], s_cpx[k], s_cpy[k]);
+      }
+      born += __popcll(um);
+    }
+    if (lane == 0) {
+      int n = nt0 + born;
+      if (n > tb.T) { n = tb.T; atomicOr(&tb.flags[b], (int)kTrackFlagCapacity); }
+      tb.nt[b] = n; s_born = n;
+    }
+  }
+  __syncthreads();
+  const int nt1 = s_born;
+
+  // ---- PF: outputs + static classification :995-1081
+  for (int t = tid; t < nt1; t += kTrackBlock) {
+    DevTrack* u = &tracks[t];
+    double tx = u->x[0][0], ty = u->x[0][1], mx = u->init_meas[0], my = u->init_meas[1];
+    u->dist_from_init = sqrt((tx - mx) * (tx - mx) + (ty - my) * (ty - my));
+    if (!u->is_static && u->track_num == 5 && u->lifetime > 8) {
+      if (u->dist_from_init < 3.0 && (u->mode[2] > u->mode[0] || u->mode[2] > u->mode[1])) u->is_static = 1;
+    }
+    mot_track o;
+    o.id = t; o.track_manage = u->track_num; o.is_static = u->is_static; o.is_vis = u->is_vis;
+    o.px = (float)tx; o.py = (float)ty; o.pz = (float)(-1.73 / 2); o.lifetime = u->lifetime;
+    o.v = u->x[0][2];
+    o.yaw = wrap_pi(u->x[0][3] + args.ego_yaw);
+    for (int i = 0; i < 24; i++) o.vis_box[i] = u->is_vis ? u->bbox[i] : 0.f;
+    out[t] = o;
+  }
+}
+
+// the tf step of the tracking node (OT/tracking/main.cpp:143-158): boxes arrive in the sensor frame, the tracker
+// works in the global frame. tf is not part of the reference tree; a plain fp64 rigid transform rounded to fp32.
+__global__ void boxes_to_global_kernel(const float* src, const int* counts, const EgoPose* ego, float* dst) {
+  const int b = blockIdx.y;
+  const int nb = min(counts[b * kCountsStride + kCntBoxes], kMaxBoxesPerFrame);
+  const EgoPose e = ego[b];
+  const double c = cos(-e.yaw), s = sin(-e.yaw);
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < nb * 8; i += gridDim.x * blockDim.x) {
+    const float* p = src + ((long)b * kMaxBoxesPerFrame * 8 + i) * 3;
+    float* q = dst + ((long)b * kMaxBoxesPerFrame * 8 + i) * 3;
+    double dx = (double)p[0] - e.x, dy = (double)p[1] - e.y;
+    q[0] = (float)(c * dx - s * dy); q[1] = (float)(s * dx + c * dy); q[2] = p[2];
+  }
+}
+void mot_launch_boxes_to_global(const float* boxes_sensor, const int* counts, const EgoPose* ego, float* boxes_global, int batch, hipStream_t stream) {
+  hipLaunchKernelGGL(boxes_to_global_kernel, dim3(4, batch), dim3(256), 0, stream, boxes_sensor, counts, ego, boxes_global);
+}
+
+// live tracks of a stream, in id order, into the caller's fixed-size record block
+__global__ void export_tracks_kernel(const mot_track* out, const int* nt, int T, mot_track* dst, int max_per_slot, int* dst_counts) {
+  __shared__ int s_w[kTrackWaves];
+  __shared__ int s_off;
+  const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const mot_track* src = out + (long)b * T;
+  const int n = nt[b];
+  if (tid == 0) s_off = 0;
+  __syncthreads();
+  for (int base = 0; base < n; base += kTrackBlock) {
+    int t = base + tid;
+    bool alive = t < n && src[t].track_manage != 0;
+    unsigned long long bm = __ballot(alive);
+    if (lane == 0) s_w[wave] = __popcll(bm);
+    __syncthreads();
+    int off = s_off;
+    for (int w = 0; w < wave; w++) off += s_w[w];
+    int pos = off + __popcll(bm & ((1ull << lane) - 1ull));
+    if (alive && pos < max_per_slot) dst[(long)b * max_per_slot + pos] = src[t];
+    __syncthreads();
+    if (tid == 0) { int s2 = 0; for (int w = 0; w < kTrackWaves; w++) s2 += s_w[w]; s_off += s2; }
+    __syncthreads();
+  }
+  if (tid == 0) dst_counts[b] = s_off < max_per_slot ? s_off : max_per_slot;
+}
+void mot_launch_export_tracks(const TrackBuffers& t, int batch, mot_track* dst, int max_per_slot, int* dst_counts, hipStream_t stream) {
+  hipLaunchKernelGGL(export_tracks_kernel, dim3(batch), dim3(kTrackBlock), 0, stream, t.out, t.nt, t.T, dst, max_per_slot, dst_counts);
+}
+
+void mot_launch_track(const TrackBuffers& t, int batch, hipStream_t stream) {
+  hipLaunchKernelGGL(track_step_kernel, dim3(batch), dim3(kTrackBlock), 0, stream, t);
+}

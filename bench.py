@@ -1,14 +1,17 @@
 #!/usr/bin/env python3
 """bench.py — frames/s of the LiDAR perception hot path on MI355X (metric of BASELINE.json).
 
-One "step" = one pass of the hot path over one batch of synthetic frames: B independent 64-beam sensor
-streams (slots), one ~120k-point frame each, inputs already resident in HBM when the timed region starts.
-N GPUs = N processes (torch.distributed / RCCL), each with its own B streams (weak scaling); the per-step
-results that cross GPUs are the fixed-size per-stream records gathered with all_gather.
+One "step" = one pass of the whole hot path (ground removal -> grid clustering -> box fit -> IMM-UKF-PDA tracker
+step) over one batch of synthetic frames: B independent 64-beam sensor streams ("slots"), one ~120k-point frame
+per stream, inputs already resident in HBM when the timed region starts. Consecutive steps feed consecutive frames
+of each stream (moving obstacles), so the trackers really run. N GPUs = N processes (torch.distributed over RCCL),
+each with its own B streams (weak scaling); what crosses GPUs each step is the fixed-size block of live-track
+records per stream, all-gathered over xGMI.
 
-Prints ONE JSON line (rank 0) with the contract fields plus `roofline` (dominant kernel, algorithmic bytes /
-HIP-event time, HBM peak 8 TB/s) and `cpu_baseline` (the reference's own sources — oracle/_ref — or the C
-restatement, timed on this box's host cores on a bounded sample).
+Prints ONE JSON line (rank 0) with the contract fields plus
+  roofline      dominant kernel: algorithmic HBM bytes per launch / mean HIP-event time, vs 8 TB/s
+  cpu_baseline  the reference's own sources (oracle/_ref) — or the C restatement if that library is absent —
+                timed on this box's host cores on a bounded sample (1 thread: the reference is single-threaded).
 """
 from __future__ import annotations
 
@@ -24,6 +27,8 @@ import numpy as np
 ROOT = os.path.dirname(os.path.abspath(__file__))
 PKG_DIR = os.path.join(ROOT, "3d-lidar-multi-object-tracking_amd")
 HBM_PEAK_GBS = 8000.0
+TRACK_RECORD_BYTES = 144
+GATHER_TRACKS = 64  # live tracks per stream in the all-gathered block (BASELINE.json configs[3]: <= 64 tracks)
 
 
 def _load(name, path):
@@ -35,7 +40,7 @@ def _load(name, path):
 
 
 def cpu_baseline(synth, n_points, budget_s=12.0):
-    """reference CPU path (oracle/_ref if present, else the C restatement) on a bounded sample, 1 thread"""
+    """reference CPU path on a bounded sample: ground -> cluster -> box -> tracker, single thread"""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import oracle_lib as O
     try:
@@ -43,28 +48,35 @@ def cpu_baseline(synth, n_points, budget_s=12.0):
     except Exception:
         use_ref = False
     p = O.params(0)
-    frames = [synth.make_cloud(n_points, 900 + i, 0) for i in range(4)]
+    frames = [synth.make_cloud(n_points, 900, f) for f in range(6)]
+    trk = O.RefTracker() if use_ref else O.Tracker(p)
+    trk.reset()
+    state = {"f": 0}
 
     def one(c):
+        f = state["f"]; state["f"] += 1
         if use_ref:
             g = O.ref_ground_remove(c)
             cl = O.ref_cluster(g["elevated"])
-            O.ref_box_fit(g["elevated"], cl["grid"], cl["num_cluster"])
+            bx = O.ref_box_fit(g["elevated"], cl["grid"], cl["num_cluster"])["boxes"]
         else:
             g = O.ground_remove(p, c)
             cl = O.cluster(p, g["elevated"])
-            O.box_fit(p, g["elevated"], cl["grid"], cl["num_cluster"])
+            bx = O.box_fit(p, g["elevated"], cl["grid"], cl["num_cluster"])["boxes"]
+        ts = 1.0e9 + f * 1e5
+        trk.ego_update(ts, 0.0, 0.0)
+        trk.step(bx, ts, max_tracks=65536)
 
     one(frames[0])  # warm-up
     t0 = time.perf_counter(); k = 0
     while True:
         one(frames[k % len(frames)]); k += 1
         dt = time.perf_counter() - t0
-        if dt > budget_s or k >= 400:
+        if dt > budget_s or k >= 300:
             break
     return {"value": round(k / dt, 2), "unit": "frames/s", "cores": 1, "kind": "reference" if use_ref else "port",
-            "sample": f"{k} frames x {n_points} pts (ground+cluster+box, stateless stages), single thread, "
-                      f"{os.cpu_count()} host cores present"}
+            "sample": f"{k} frames x {n_points} pts, ground+cluster+box+tracker, single thread "
+                      f"({os.cpu_count()} host cores present; the reference is single-threaded)"}
 
 
 def main():
@@ -72,18 +84,19 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--batch", type=int, default=64, help="sensor streams (frames) per GPU per step")
+    ap.add_argument("--batch", type=int, default=64, help="sensor streams (one frame each) per GPU per step")
     ap.add_argument("--points", type=int, default=120000)
+    ap.add_argument("--frames", type=int, default=4, help="distinct consecutive frames resident per stream")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
-    import torch
+    import torch  # torch first: it brings its own HIP runtime, which libmot_hip.so then shares
     import torch.distributed as dist
 
     rank = int(os.environ.get("RANK", "0")); world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
-        print("bench.py needs a GPU (no CPU fallback)", file=sys.stderr); sys.exit(2)
+        print("bench.py needs a GPU (the library has no CPU fallback)", file=sys.stderr); sys.exit(2)
     torch.cuda.set_device(local)
     if world > 1:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
@@ -95,24 +108,37 @@ def main():
     if not os.path.exists(build.LIB):
         build.build()
 
-    B, N = args.batch, args.points
+    B, N, F = args.batch, args.points, args.frames
     stride = ((N + 2047) // 2048) * 2048
-    # synthetic streams: 8 distinct frames per rank, tiled over the B slots
-    base = [synth.make_cloud(N, 100 * rank + i, 0) for i in range(min(B, 8))]
-    host = np.zeros((B, stride, 4), np.float32)
-    for b in range(B):
-        host[b, :N] = base[b % len(base)]
-    dev = torch.from_numpy(host).cuda()
+    # synthetic streams: 8 distinct scenes per rank tiled over the B slots, F consecutive frames of each
+    n_scene = min(B, 8)
+    scenes = [[synth.make_cloud(N, 100 * rank + s, f) for f in range(F)] for s in range(n_scene)]
+    dev_frames = []
+    for f in range(F):
+        host = np.zeros((B, stride, 4), np.float32)
+        for b in range(B):
+            host[b, :N] = scenes[b % n_scene][f]
+        dev_frames.append(torch.from_numpy(host).cuda())
     sizes = [N] * B
-    ctx = mot.Context(device=local, max_points=stride, max_batch=B)
+    ctx = mot.Context(device=local, max_points=stride, max_batch=B, max_tracks_total=8192)
+    gather_src = torch.zeros(B, GATHER_TRACKS, TRACK_RECORD_BYTES // 4, dtype=torch.int32, device="cuda")
+    gather_cnt = torch.zeros(B, dtype=torch.int32, device="cuda")
+    gather_dst = [torch.zeros_like(gather_src) for _ in range(world)] if world > 1 else None
     torch.cuda.synchronize()
 
-    def step():
-        ctx.frames_dev(dev.data_ptr(), stride * 4, sizes)
+    step_no = [0]
 
-    gather_buf = None
-    if world > 1:
-        gather_buf = [torch.zeros(B, 4, dtype=torch.int32, device="cuda") for _ in range(world)]
+    def step():
+        k = step_no[0]; step_no[0] += 1
+        if k % 200 == 0:
+            ctx.reset()  # a stream restarts: the reference never frees tracks, so long runs are cut into sequences
+        ts = [1.0e9 + (k % 200) * 1.0e5] * B  # microsecond stamps => dt = 0.1 s
+        ctx.frames_dev(dev_frames[k % F].data_ptr(), stride * 4, sizes, run_tracker=True, timestamps=ts,
+                       ego_v=[0.0] * B, ego_yaw=[0.0] * B)
+        if world > 1:  # the per-step result block crosses GPUs over RCCL / xGMI
+            ctx.export_tracks_dev(B, gather_src.data_ptr(), GATHER_TRACKS, gather_cnt.data_ptr())
+            ctx.synchronize()
+            dist.all_gather(gather_dst, gather_src)
 
     for _ in range(args.warmup):
         step()
@@ -133,54 +159,59 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
 
-    # ---- per-kernel timing on the resident data (HIP events on the context's stream, see mot_time_stage)
-    it = 20
-    kernels = {"polar_minz_kernel": 10, "polar_filter_kernel": 11, "classify_compact_kernel": 12,
-               "cart_occupancy_kernel": 20, "ccl_kernel": 21, "label_stats_kernel": 30, "cluster_box_kernel": 31,
-               "box_finalize_kernel": 32}
-    k_ms = {k: ctx.time_stage(v, B, it) for k, v in kernels.items()}
-    stage_ms = {"ground": ctx.time_stage(0, B, it), "cluster": ctx.time_stage(1, B, it), "box": ctx.time_stage(2, B, it),
-                "all": ctx.time_stage(100, B, it)}
-    counts = [ctx.get_ground(b, want_clouds=False) for b in range(B)]
-    ne_tot = sum(c["n_elevated"] for c in counts); ng_tot = sum(c["n_ground"] for c in counts)
-    cl0 = ctx.get_clusters(0); bx0 = ctx.get_boxes(0)
-    G = ctx.params.num_grid
-    # algorithmic HBM bytes per launch (DESIGN.md "bytes per unit"): what the kernel must read and write once
-    alg_bytes = {"polar_minz_kernel": 16.0 * N * B,
-                 "polar_filter_kernel": 8.0 * 9600 * B,
-                 "classify_compact_kernel": 16.0 * N * B + 16.0 * (ne_tot + ng_tot) + 1.0 * N * B,
-                 "cart_occupancy_kernel": 16.0 * ne_tot,
-                 "ccl_kernel": (2 * 2048 * 4 + 4.0 * G * G) * B,
-                 "label_stats_kernel": (16.0 + 4.0) * ne_tot,
-                 "cluster_box_kernel": 4.0 * ne_tot,
-                 "box_finalize_kernel": 96.0 * B}
-    dom = max(k_ms, key=lambda k: k_ms[k])
-    achieved = alg_bytes[dom] / (k_ms[dom] * 1e-3) / 1e9
-    frame_bytes = sum(alg_bytes.values()) / B
-
     if rank == 0:
+        # ---- per-kernel timing on the resident data (HIP events on the context's stream, see mot_time_stage)
+        it = 20
+        tr0 = ctx.get_tracks(0)
+        kernels = {"polar_minz_kernel": 10, "polar_filter_kernel": 11, "classify_compact_kernel": 12,
+                   "cart_occupancy_kernel": 20, "ccl_kernel": 21, "label_stats_kernel": 30, "cluster_box_kernel": 31,
+                   "box_finalize_kernel": 32, "track_step_kernel": 40}
+        k_ms = {k: ctx.time_stage(v, B, it if v != 40 else 5) for k, v in kernels.items()}
+        stage_ms = {"ground": ctx.time_stage(0, B, it), "cluster": ctx.time_stage(1, B, it), "box": ctx.time_stage(2, B, it),
+                    "stateless": ctx.time_stage(100, B, it)}
+        counts = [ctx.get_ground(b, want_clouds=False) for b in range(B)]
+        ne_tot = sum(c["n_elevated"] for c in counts); ng_tot = sum(c["n_ground"] for c in counts)
+        cl0 = ctx.get_clusters(0); bx0 = ctx.get_boxes(0)
+        G = ctx.params.num_grid
+        # algorithmic HBM bytes per launch (DESIGN.md §"bytes per unit"): what a kernel must read and write once
+        alg_bytes = {"polar_minz_kernel": 16.0 * N * B,
+                     "polar_filter_kernel": 8.0 * 9600 * B,
+                     "classify_compact_kernel": 16.0 * N * B + 16.0 * (ne_tot + ng_tot) + 1.0 * N * B,
+                     "cart_occupancy_kernel": 16.0 * ne_tot,
+                     "ccl_kernel": (2 * 2048 * 4 + 4.0 * G * G) * B,
+                     "label_stats_kernel": (16.0 + 4.0) * ne_tot,
+                     "cluster_box_kernel": 4.0 * ne_tot,
+                     "box_finalize_kernel": 96.0 * B,
+                     "track_step_kernel": (2 * 1624.0 + 144.0) * max(tr0["n"], 1) * B}
+        dom = max(k_ms, key=lambda k: k_ms[k])
+        achieved = alg_bytes[dom] / (k_ms[dom] * 1e-3) / 1e9
+        frame_bytes = sum(alg_bytes.values()) / B
         frames = B * args.steps * world
         out = {
-            "metric": "LiDAR frames/sec (120k-pt 64-beam cloud) end-to-end ground->cluster->box on device (tracker stage pending)",
+            "metric": "LiDAR frames/sec (120k-pt 64-beam cloud) end-to-end ground->cluster->track",
             "value": round(frames / dt, 1), "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(dt / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32 (fp32 indices / fp64 intermediates exactly as the reference; int32 grids and labels)", "data": "synthetic",
-            "config": {"workload": "configs[2]: full ground->CCL->box-fit pipeline on one MI355X, 120k-pt synthetic HDL-64E cloud",
+            "dtype": "f32/f64 (fp32 grid indices with fp64 intermediates, int32 grids/labels, fp64 tracker — the reference's types)",
+            "data": "synthetic",
+            "config": {"workload": "configs[3]: ground removal -> CCL -> box fit -> batched IMM-UKF-PDA tracker on one MI355X, "
+                                   "120k-pt synthetic HDL-64E clouds, one frame per stream per step",
                        "points_per_frame": N, "frames_per_step_per_gpu": B, "streams": B * world,
                        "elevated_pts_per_frame": ne_tot // B, "clusters_frame0": cl0["num_cluster"], "boxes_frame0": len(bx0["boxes"]),
-                       "parallelism": f"frame-sharded x{world}"},
+                       "tracks_stream0": int(tr0["n"]), "live_tracks_stream0": int((tr0["track_manage"] > 0).sum()),
+                       "parallelism": f"stream-sharded x{world}" + (", all_gather of live-track records (RCCL)" if world > 1 else "")},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
                          "kernel_ms": {k: round(v, 5) for k, v in k_ms.items()},
                          "stage_ms": {k: round(v, 5) for k, v in stage_ms.items()},
                          "algorithmic_bytes_per_launch": {k: int(v) for k, v in alg_bytes.items()},
                          "pipeline_bytes_per_frame": int(frame_bytes),
-                         "pipeline_frac": round(frame_bytes * B / (stage_ms["all"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)},
+                         "pipeline_frac": round(frame_bytes * B / (dt / args.steps) / 1e9 / HBM_PEAK_GBS, 4)},
         }
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(synth, N)
         print(json.dumps(out))
     if world > 1:
+        dist.barrier()
         dist.destroy_process_group()
 
 

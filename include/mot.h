@@ -210,11 +210,16 @@ int mot_get_boxes(mot_ctx* ctx, int slot, float* boxes, int max_boxes, int* n_bo
                   int* n_undefined);
 int mot_get_tracks(mot_ctx* ctx, int slot, mot_track* tracks, int max_tracks, int* n_tracks);
 
+/* packs the LIVE tracks (track_manage != 0) of every slot, in track-id order, into a caller-owned DEVICE buffer
+ * d_tracks[batch][max_per_slot] (mot_track records) and their number into d_counts[batch] (int32) — the fixed-size
+ * per-stream record block that the multi-GPU harness all-gathers over RCCL. Asynchronous on the context stream. */
+int mot_export_tracks_dev(mot_ctx* ctx, int batch, void* d_tracks, int max_per_slot, int32_t* d_counts);
+
 /* ---------------------------------------------------------------- measurement helpers (bench.py) */
 /* Re-runs only the named stage `iters` times on the data resident from the last mot_frames_dev call,
  * bracketed by hipEvents ON THE CONTEXT STREAM; returns average milliseconds per iteration.
- * stage: 0 ground, 1 cluster, 2 box, 3 tracker (tracker re-runs are not idempotent and are refused),
- * 10+k: k-th kernel of the ground stage alone. */
+ * stage: 0 ground, 1 cluster, 2 box, 100 the three stateless stages; single kernels: 10-12 ground, 20-21 cluster,
+ * 30-32 box; 40 re-runs the tracker kernel with the last frame's arguments (that ADVANCES tracker state: bench only). */
 int mot_time_stage(mot_ctx* ctx, int stage, int batch, int iters, float* ms_per_iter);
 
 #ifdef __cplusplus

@@ -1,0 +1,146 @@
+"""Parity of the HIP IMM-UKF-PDA tracker (through the C-ABI) against the golden vectors produced by the reference's own
+sources and against the oracle. Bar (BASELINE.json): track sets / track-management states exact, continuous state
+<= 1e-4 relative."""
+import numpy as np
+import pytest
+
+import golden_util as G
+
+pytestmark = pytest.mark.gpu
+RTOL = 1e-4
+
+
+@pytest.fixture(scope="module")
+def ctx(mot, hip_lib):
+    c = mot.Context(max_points=131072, max_batch=4, max_tracks_total=2048)
+    yield c
+    c.close()
+
+
+@pytest.mark.parametrize("name", G.TRACKERS)
+def test_golden_tracker_sequences(ctx, name):
+    fx = G.load(name)
+    ctx.reset()
+    for f in range(len(fx["n_boxes"])):
+        ts = 1.0e9 + f * float(fx["unit"])
+        ego = ctx.ego_update(ts, 2.0 + 0.05 * f, 0.004 * f)
+        assert np.allclose(ego, fx["ego"][f], rtol=1e-12, atol=1e-12)
+        out = ctx.track_step(fx["boxes"][f][: fx["n_boxes"][f]], ts)
+        G.check_tracker_frame(fx, f, out, lambda i: ctx.track_state(i), rtol=RTOL)
+
+
+def _boxes_sequence(oracle, synth, p, stream, nframes, npts):
+    seq = []
+    for f in range(nframes):
+        c = synth.make_cloud(npts, stream, f)
+        g = oracle.ground_remove(p, c); cl = oracle.cluster(p, g["elevated"])
+        seq.append(oracle.box_fit(p, g["elevated"], cl["grid"], cl["num_cluster"])["boxes"])
+    return seq
+
+
+def _compare_step(a, o, state_dev, state_orc, f):
+    assert a["n"] == o["n"], f
+    assert np.array_equal(a["track_manage"], o["track_manage"]), f
+    assert np.array_equal(a["is_static"], o["is_static"]) and np.array_equal(a["is_vis"], o["is_vis"]), f
+    assert np.array_equal(a["lifetime"], o["lifetime"]), f
+    live = o["track_manage"] > 0
+    assert np.allclose(a["p"][live], o["p"][live], rtol=RTOL, atol=1e-6)
+    assert np.allclose(a["v_yaw"][live], o["v_yaw"][live], rtol=RTOL, atol=1e-7)
+    assert np.allclose(a["vis_box"], o["vis_box"], rtol=RTOL, atol=1e-5)
+    for i in np.nonzero(live)[0]:
+        sd, so = state_dev(int(i)), state_orc(int(i))
+        for k in ("x_merge", "x_cv", "x_ctrv", "x_rm", "p_merge", "p_cv", "p_ctrv", "p_rm", "mode_prob", "z_pred", "s", "k"):
+            scale = max(np.abs(so[k]).max(), 1e-300)
+            assert np.abs(sd[k] - so[k]).max() <= RTOL * scale + 1e-9, (f, i, k)
+
+
+@pytest.mark.parametrize("unit,stream", [(1e5, 3), (0.1, 3), (1e5, 6)])
+def test_tracker_vs_oracle_long_sequence(ctx, oracle, synth, unit, stream):
+    p = oracle.params(0)
+    seq = _boxes_sequence(oracle, synth, p, stream, 60, 40000)
+    ctx.reset()
+    T = oracle.Tracker(p)
+    for f, b in enumerate(seq):
+        ts = 2.0e8 + f * unit
+        v, yaw = 5.0, 0.01 * f
+        assert np.allclose(ctx.ego_update(ts, v, yaw), T.ego_update(ts, v, yaw), rtol=1e-12, atol=1e-12)
+        a = ctx.track_step(b, ts); o = T.step(b, ts)
+        _compare_step(a, o, ctx.track_state, T.state, f)
+    assert (o["track_manage"] >= 5).sum() >= 3  # the sequence really exercises confirmed tracks
+    T.close()
+
+
+def test_tracker_slots_are_independent_and_reset_works(ctx, oracle, synth):
+    p = oracle.params(0)
+    seqs = [_boxes_sequence(oracle, synth, p, s, 15, 30000) for s in (1, 2)]
+    ctx.reset()
+    Ts = [oracle.Tracker(p), oracle.Tracker(p)]
+    for f in range(15):
+        for slot in (1, 0):  # interleaved, different slots
+            ts = 1.0e8 + f * 1e5 + slot
+            ctx.ego_update(ts, 1.0 + slot, 0.0, slot=slot); Ts[slot].ego_update(ts, 1.0 + slot, 0.0)
+            a = ctx.track_step(seqs[slot][f], ts, slot=slot); o = Ts[slot].step(seqs[slot][f], ts)
+            _compare_step(a, o, lambda i: ctx.track_state(i, slot=slot), Ts[slot].state, (f, slot))
+    ctx.reset()
+    T = oracle.Tracker(p)
+    for f in range(5):
+        ts = 1.0e8 + f * 1e5
+        ctx.ego_update(ts, 0.0, 0.0); T.ego_update(ts, 0.0, 0.0)
+        _compare_step(ctx.track_step(seqs[0][f], ts), T.step(seqs[0][f], ts), ctx.track_state, T.state, f)
+
+
+def test_tracker_edge_cases(mot, hip_lib, oracle):
+    p = oracle.params(0)
+    with mot.Context(max_points=1024, max_tracks_total=8) as c:
+        with pytest.raises(mot.MotError) as e:   # ego update must come first (getOriginPoints precedes immUkfJpdaf)
+            c.track_step(np.zeros((0, 8, 3), np.float32), 0.0)
+        assert e.value.code == mot.MOT_E_STATE
+        T = oracle.Tracker(p)
+        # first frame with fewer boxes than the seed index: no track is seeded, init_ still flips
+        c.ego_update(1e6, 0, 0); T.ego_update(1e6, 0, 0)
+        box = np.zeros((1, 8, 3), np.float32); box[0, :, :2] = [[0, 0], [1, 0], [1, 1], [0, 1]] * 2
+        a = c.track_step(box, 1e6); o = T.step(box, 1e6)
+        assert a["n"] == o["n"] == 0
+        rng = np.random.default_rng(0)
+        with pytest.raises(mot.MotError) as e:   # the reference never frees tracks: capacity is an error, not a drop
+            for f in range(1, 6):
+                ts = 1e6 + f * 1e5
+                c.ego_update(ts, 0, 0)
+                b = np.zeros((4, 8, 3), np.float32)
+                for k in range(4):
+                    cx, cy = rng.uniform(-20, 20, 2)
+                    b[k, :, :2] = (np.array([[0, 0], [2, 0], [2, 1], [0, 1]] * 2) + [cx, cy])
+                c.track_step(b, ts)
+        assert e.value.code == mot.MOT_E_CAPACITY
+
+
+def test_fused_frames_with_tracker(mot, hip_lib, oracle, synth):
+    """ground -> cluster -> box -> tracker per frame with everything on the device, 2 streams, 12 frames"""
+    import hiprt
+    p = oracle.params(0)
+    B, N, stride = 2, 40000, 40960
+    with mot.Context(max_points=stride, max_batch=B, max_tracks_total=1024) as c:
+        Ts = [oracle.Tracker(p) for _ in range(B)]
+        for f in range(12):
+            host = np.zeros((B, stride, 4), np.float32)
+            clouds = [synth.make_cloud(N, 30 + b, f) for b in range(B)]
+            for b in range(B):
+                host[b, :N] = clouds[b]
+            dev = hiprt.DeviceBuffer(host)
+            ts = [3.0e8 + f * 1e5] * B; ev = [2.0, 0.0]; ey = [0.002 * f, 0.0]
+            c.frames_dev(dev.ptr, stride * 4, [N] * B, run_tracker=True, timestamps=ts, ego_v=ev, ego_yaw=ey)
+            for b in range(B):
+                g = oracle.ground_remove(p, clouds[b]); cl = oracle.cluster(p, g["elevated"])
+                bx = oracle.box_fit(p, g["elevated"], cl["grid"], cl["num_cluster"])["boxes"]
+                assert np.array_equal(c.get_boxes(b)["boxes"], bx)
+                ego = Ts[b].ego_update(ts[b], ev[b], ey[b])
+                co, si = np.cos(-ego[2]), np.sin(-ego[2])
+                gb = bx.astype(np.float64).copy()
+                dx, dy = gb[..., 0] - ego[0], gb[..., 1] - ego[1]
+                gb[..., 0] = co * dx - si * dy; gb[..., 1] = si * dx + co * dy
+                o = Ts[b].step(gb.astype(np.float32), ts[b])
+                a = c.get_tracks(b)
+                assert a["n"] == o["n"] and np.array_equal(a["track_manage"], o["track_manage"]), (f, b)
+                live = o["track_manage"] > 0
+                assert np.allclose(a["p"][live], o["p"][live], rtol=1e-3, atol=1e-4)
+            dev.free()
