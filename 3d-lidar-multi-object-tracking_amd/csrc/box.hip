@@ -122,6 +122,8 @@ constexpr int kBoxBlock = 64;        // ONE wave per cluster
 constexpr int kPicCols = 1024;       // pixel columns 0..900
 constexpr int kMaxHullIn = 2 * 901;  // two extreme pixels per column
 constexpr int kScanDepth = 16;      // label loads kept in flight per lane while walking a frame's labels
+constexpr int kStackStride = 2048;  // shorts per Sklansky stack (>= kMaxHullIn + 2)
+constexpr int kNeedWords = 2048;    // bitmap of sampled ranks for clusters of up to 65536 points (larger: no shortcut)
 constexpr int kMaxHull = 512;        // vertices of a convex lattice polygon in a 900^2 box: < 3.5 * 900^(2/3) ~ 330
 
 // ruleBasedFilter :97-158 (fall-through = false)
@@ -183,24 +185,35 @@ __device__ int sklansky(const short* ax, const short* ay, int start, int end, sh
   return --stacksize;
 }
 
+// 32 integer directions (16*cos, 16*sin rounded), counter-clockwise: the extreme point of the set in each of them
+// is on the convex hull, and a point strictly inside the polygon they span cannot be a hull vertex
+__constant__ signed char kDirX[32] = {16, 16, 15, 13, 11, 9, 6, 3, 0, -3, -6, -9, -11, -13, -15, -16,
+                                                 -16, -16, -15, -13, -11, -9, -6, -3, 0, 3, 6, 9, 11, 13, 15, 16};
+__constant__ signed char kDirY[32] = {0, 3, 6, 9, 11, 13, 15, 16, 16, 16, 15, 13, 11, 9, 6, 3,
+                                                 0, -3, -6, -9, -11, -13, -15, -16, -16, -16, -15, -13, -11, -9, -6, -3};
+
 __global__ void MOT_LAUNCH_BOUNDS(kBoxBlock)
 cluster_box_kernel(MotDevParams p, ClusterBuffers c) {
-  // LDS carve-up (one wave): column extents, then reused as Sklansky stack
-  __shared__ __attribute__((aligned(16))) unsigned char s_raw[2 * kPicCols * sizeof(int)];
-  int* s_colmin = (int*)s_raw;
-  int* s_colmax = s_colmin + kPicCols;
-  __shared__ short s_px[kMaxHullIn + 2], s_py[kMaxHullIn + 2];  // reduced point set, sorted by (x,y)
+  // LDS of ONE wave. s_raw: column extents while gathering, then the four Sklansky stacks.
+  __shared__ __attribute__((aligned(16))) unsigned char s_raw[4 * kStackStride * sizeof(short)];
+  __shared__ short s_px[kMaxHullIn + 2], s_py[kMaxHullIn + 2];  // candidate points, sorted by (x,y)
+  __shared__ short s_qx[kMaxHullIn + 2], s_qy[kMaxHullIn + 2];  // ... after the interior filter
   __shared__ short s_hull[kMaxHullIn + 2];
   __shared__ float s_hx[kMaxHull], s_hy[kMaxHull], s_vx[kMaxHull], s_vy[kMaxHull], s_inv[kMaxHull];
   __shared__ int s_rank[128], s_pidx[128];
-  __shared__ int s_total;
+  __shared__ unsigned s_need[kNeedWords];      // L-shape: bit r set <=> the r-th point of the cluster is sampled
+  __shared__ int s_buf[64 * kScanDepth];       // indices of this cluster's points found in the current stretch
+  __shared__ int s_ext[32 * 2];                // extreme point per direction
+  __shared__ int s_cnt[4];
+  int* s_colmin = (int*)s_raw;
+  int* s_colmax = s_colmin + kPicCols;
+  short* s_stack = (short*)s_raw;
   const int b = blockIdx.y;
   const int n = c.counts[b * kCountsStride + kCntElev];
   const int num_cluster = min(c.counts[b * kCountsStride + kCntClusters], kMaxClusters);
   const float4* __restrict__ pts = c.elevated + (long)b * c.cap;
   const int* __restrict__ label = c.label + (long)b * c.cap;
   const int lane = lane_id();
-  short* s_stack = (short*)s_raw;  // 8 KB >= (kMaxHullIn + 2) shorts; the column extents are dead by then
 
   for (int ci = blockIdx.x; ci < num_cluster; ci += gridDim.x) {
     const ClusterStats st = c.stats[(long)b * kMaxClusters + ci];
@@ -237,6 +250,8 @@ cluster_box_kernel(MotDevParams p, ClusterBuffers c) {
     if (lshape) {  // ---------------------------------------------------------------- L-shape :310-356
       cand.branch = 0;
       const int nsamp = p.ram_points < 128 ? p.ram_points : 128;
+      for (int i = lane; i < kNeedWords; i += 64) s_need[i] = 0u;
+      __syncthreads();
       if (lane == 0) {
         // mt19937_64 mt(0); uniform_int_distribution<>(0, numPoints-1): libstdc++ >= 11 maps the 64-bit draw
         // with Lemire's multiply-shift + rejection (bits/uniform_int_dist.h _S_nd), SURVEY.md H17
@@ -256,6 +271,7 @@ cluster_box_kernel(MotDevParams p, ClusterBuffers c) {
           }
           s_rank[i] = (int)high;
           s_pidx[i] = -1;
+          if ((int)high < kNeedWords * 32) s_need[(int)high >> 5] |= 1u << ((int)high & 31);
         }
         if (exhausted) atomicOr(&c.counts[b * kCountsStride + kCntFlags], (int)kFlagRngExhausted);
       }
@@ -274,7 +290,8 @@ cluster_box_kernel(MotDevParams p, ClusterBuffers c) {
           if (mm == 0ull) continue;
           if (mine) {
             int r = running + __popcll(mm & ((1ull << lane) - 1ull));
-            for (int j = 0; j < nsamp; j++) if (s_rank[j] == r) s_pidx[j] = i;
+            bool need = r >= kNeedWords * 32 || ((s_need[r >> 5] >> (r & 31)) & 1u);
+            if (need) for (int j = 0; j < nsamp; j++) if (s_rank[j] == r) s_pidx[j] = i;
           }
           running += __popcll(mm);
         }
@@ -317,25 +334,36 @@ cluster_box_kernel(MotDevParams p, ClusterBuffers c) {
         int lab[kScanDepth];
 #pragma unroll
         for (int k = 0; k < kScanDepth; k++) { int i = base0 + k * 64 + lane; lab[k] = i < n ? label[i] : 0; }
+        int found = 0;  // wave-uniform
 #pragma unroll
         for (int k = 0; k < kScanDepth; k++) {
-        int i = base0 + k * 64 + lane;
-        bool mine = lab[k] == ci + 1;
-        unsigned long long mm = __ballot(mine);
-        if (mm == 0ull) continue;
-        if (mine) {
-          float4 q = pts[i];
-          float roiX = q.x + p.roi_half, roiY = q.y + p.roi_half;  // :244-254
-          int x = (int)floorf(roiX * p.pic_scale), y = (int)floorf(roiY * p.pic_scale);
-          int picX = x;
-          int picY = (int)(p.pic_full - (float)y);
-          int offsetY = picY + offsetInitY;
-          if (picX >= 0 && picX < kPicCols) { atomicMin(&s_colmin[picX], offsetY); atomicMax(&s_colmax[picX], offsetY); }
+          bool mine = lab[k] == ci + 1;
+          unsigned long long mm = __ballot(mine);
+          if (mine) s_buf[found + __popcll(mm & ((1ull << lane) - 1ull))] = base0 + k * 64 + lane;
+          found += __popcll(mm);
         }
-        running += __popcll(mm);
+        running += found;
+        __syncthreads();
+        // the points themselves: independent gathers, so many are in flight at once
+        for (int j0 = 0; j0 < found; j0 += 256) {
+          float4 q[4];
+#pragma unroll
+          for (int u = 0; u < 4; u++) { int j = j0 + u * 64 + lane; q[u] = j < found ? pts[s_buf[j]] : make_float4(0.f, 0.f, 0.f, 0.f); }
+#pragma unroll
+          for (int u = 0; u < 4; u++) {
+            int j = j0 + u * 64 + lane;
+            if (j < found) {
+              float roiX = q[u].x + p.roi_half, roiY = q[u].y + p.roi_half;  // :244-254
+              int x = (int)floorf(roiX * p.pic_scale), y = (int)floorf(roiY * p.pic_scale);
+              int picX = x;
+              int picY = (int)(p.pic_full - (float)y);
+              int offsetY = picY + offsetInitY;
+              if (picX >= 0 && picX < kPicCols) { atomicMin(&s_colmin[picX], offsetY); atomicMax(&s_colmax[picX], offsetY); }
+            }
+          }
         }
+        __syncthreads();
       }
-      __syncthreads();
       // compact the column extents into (x,y)-sorted points: 16 columns per lane, prefix over lanes
       int cnt = 0;
       for (int k = 0; k < kPicCols / 64; k++) {
@@ -355,35 +383,83 @@ cluster_box_kernel(MotDevParams p, ClusterBuffers c) {
           if (hi != lo) { s_px[pos] = (short)(col + offsetInitX); s_py[pos] = (short)hi; pos++; }
         }
       }
-      if (lane == 63) s_total = incl;
+      int total = __shfl(incl, 63, 64);
       __syncthreads();
-      const int total = s_total;
+      // ---- drop points strictly inside the polygon of 32 directional extremes (exact integer tests); what is
+      //      left still contains every hull vertex, in (x,y) order
+      if (total > 48) {
+        for (int d = 0; d < 32; d++) {
+          int best = -0x7fffffff - 1, bi = 0;
+          for (int j = lane; j < total; j += 64) { int v = kDirX[d] * (int)s_px[j] + kDirY[d] * (int)s_py[j]; if (v > best) { best = v; bi = j; } }
+          long long key = ((long long)best << 32) | (unsigned)(0xffff - bi);
+          key = wave_max_t<long long>(key);
+          if (lane == 0) { int w = 0xffff - (int)(key & 0xffff); s_ext[2 * d] = s_px[w]; s_ext[2 * d + 1] = s_py[w]; }
+        }
+        __syncthreads();
+        int kept_total = 0;
+        for (int j0 = 0; j0 < total; j0 += 64) {
+          int j = j0 + lane;
+          bool keep = false;
+          if (j < total) {
+            int qx = s_px[j], qy = s_py[j];
+            bool inside = true; int edges = 0;
+            for (int d = 0; d < 32; d++) {
+              int ax = s_ext[2 * d], ay = s_ext[2 * d + 1], bx = s_ext[2 * ((d + 1) & 31)], by = s_ext[2 * ((d + 1) & 31) + 1];
+              if (ax == bx && ay == by) continue;
+              edges++;
+              int cr = (bx - ax) * (qy - ay) - (by - ay) * (qx - ax);
+              if (cr <= 0) { inside = false; break; }
+            }
+            keep = !(inside && edges >= 3);
+          }
+          unsigned long long km = __ballot(keep);
+          if (keep) { int o = kept_total + __popcll(km & ((1ull << lane) - 1ull)); s_qx[o] = s_px[j]; s_qy[o] = s_py[j]; }
+          kept_total += __popcll(km);
+        }
+        total = kept_total;
+      } else {
+        for (int j = lane; j < total; j += 64) { s_qx[j] = s_px[j]; s_qy[j] = s_py[j]; }
+      }
+      __syncthreads();
+      const short* ax = s_qx; const short* ay = s_qy;
+      // first index holding the minimum / maximum y (strict compares in cv::convexHull)
+      int miny_ind = 0, maxy_ind = 0;
+      {
+        long long kmin = 0x7fffffffffffffffll, kmax = -0x7fffffffffffffffll - 1;
+        for (int j = lane; j < total; j += 64) {
+          long long a = ((long long)ay[j] << 32) | (unsigned)j;            // min: smallest y, then smallest index
+          long long bq = ((long long)ay[j] << 32) | (unsigned)(0xffff - j);  // max: largest y, then smallest index
+          kmin = a < kmin ? a : kmin; kmax = bq > kmax ? bq : kmax;
+        }
+        kmin = wave_min_t<long long>(kmin); kmax = wave_max_t<long long>(kmax);
+        if (total > 0) { miny_ind = (int)(kmin & 0xffff); maxy_ind = 0xffff - (int)(kmax & 0xffff); }
+      }
+      // ---- cv::convexHull(points, hull, clockwise = true, returnPoints = true), OpenCV 3.2 convhull.cpp:
+      //      the four Sklansky scans are independent — lanes 0..3 run one each
+      bool degenerate = total > 0 && ax[0] == ax[total - 1] && ay[0] == ay[total - 1];
+      if (total > 0 && !degenerate && lane < 4) {
+        int start = (lane & 1) ? total - 1 : 0;
+        int end = lane < 2 ? maxy_ind : miny_ind;
+        int nsign = lane < 2 ? -1 : 1;
+        int sign2 = (lane == 0 || lane == 3) ? 1 : -1;
+        s_cnt[lane] = sklansky(ax, ay, start, end, s_stack + lane * kStackStride, nsign, sign2);
+      }
+      __syncthreads();
       float rect[8] = {0, 0, 0, 0, 0, 0, 0, 0};
       if (lane == 0) {
-        // ---- cv::convexHull(points, hull, clockwise = true, returnPoints = true), OpenCV 3.2 convhull.cpp
-        const short* ax = s_px; const short* ay = s_py;
-        int nout = 0, miny_ind = 0, maxy_ind = 0;
-        for (int i = 1; i < total; i++) {
-          int y = ay[i];
-          if (ay[miny_ind] > y) miny_ind = i;
-          if (ay[maxy_ind] < y) maxy_ind = i;
-        }
+        int nout = 0;
         if (total > 0) {
-          if (ax[0] == ax[total - 1] && ay[0] == ay[total - 1]) {
+          if (degenerate) {
             s_hull[nout++] = 0;
           } else {
-            short* tl_stack = s_stack;
-            int tl_count = sklansky(ax, ay, 0, maxy_ind, tl_stack, -1, 1);
-            short* tr_stack = s_stack + tl_count;
-            int tr_count = sklansky(ax, ay, total - 1, maxy_ind, tr_stack, -1, -1);
+            short* tl_stack = s_stack; int tl_count = s_cnt[0];
+            short* tr_stack = s_stack + kStackStride; int tr_count = s_cnt[1];
             for (int i = 0; i < tl_count - 1; i++) s_hull[nout++] = tl_stack[i];
             for (int i = tr_count - 1; i > 0; i--) s_hull[nout++] = tr_stack[i];
             int stop_idx = tr_count > 2 ? tr_stack[1] : tl_count > 2 ? tl_stack[tl_count - 2] : -1;
-            short* bl_stack = s_stack;
-            int bl_count = sklansky(ax, ay, 0, miny_ind, bl_stack, 1, -1);
-            short* br_stack = s_stack + bl_count;
-            int br_count = sklansky(ax, ay, total - 1, miny_ind, br_stack, 1, 1);
-            { short* t = bl_stack; bl_stack = br_stack; br_stack = t; int cc = bl_count; bl_count = br_count; br_count = cc; }
+            // clockwise: the bottom-left / bottom-right stacks swap roles
+            short* bl_stack = s_stack + 3 * kStackStride; int bl_count = s_cnt[3];
+            short* br_stack = s_stack + 2 * kStackStride; int br_count = s_cnt[2];
             if (stop_idx >= 0) {
               int check_idx = bl_count > 2 ? bl_stack[1] : bl_count + br_count > 2 ? br_stack[2 - bl_count] : -1;
               if (check_idx == stop_idx || (check_idx >= 0 && ax[check_idx] == ax[stop_idx] && ay[check_idx] == ay[stop_idx])) {

@@ -29,6 +29,7 @@
 #define __device__
 #define __host__
 #define __shared__ static
+#define __constant__ static const
 #define __forceinline__ inline
 #define __launch_bounds__(...)
 #define __restrict__

@@ -167,3 +167,48 @@ def test_hull_column_reduction(oracle):
         red = reduce_cols(pts)
         assert np.array_equal(oracle.convex_hull(pts), oracle.convex_hull(red))
         assert np.array_equal(oracle.min_area_rect_points(pts), oracle.min_area_rect_points(red))
+
+
+def test_hull_interior_prefilter(oracle):
+    """the device path also drops candidates strictly inside the polygon of the 32 directional extremes before the
+    (sequential) Sklansky scans; the restated OpenCV hull / rectangle must not notice"""
+    dirx = np.array([16, 16, 15, 13, 11, 9, 6, 3, 0, -3, -6, -9, -11, -13, -15, -16, -16, -16, -15, -13, -11, -9, -6, -3, 0, 3, 6, 9, 11, 13, 15, 16])
+    diry = np.array([0, 3, 6, 9, 11, 13, 15, 16, 16, 16, 15, 13, 11, 9, 6, 3, 0, -3, -6, -9, -11, -13, -15, -16, -16, -16, -15, -13, -11, -9, -6, -3])
+    rng = np.random.default_rng(2)
+
+    def prefilter(pts):
+        pts = pts[np.lexsort((pts[:, 1], pts[:, 0]))]
+        if len(pts) <= 48:
+            return pts
+        ext = []
+        for d in range(32):
+            v = dirx[d] * pts[:, 0] + diry[d] * pts[:, 1]
+            ext.append(pts[np.argmax(v)])      # first maximum in (x,y) order, as the kernel's tie-break
+        ext = np.array(ext)
+        keep = np.ones(len(pts), bool)
+        for j, (qx, qy) in enumerate(pts):
+            inside, edges = True, 0
+            for d in range(32):
+                a, b = ext[d], ext[(d + 1) % 32]
+                if a[0] == b[0] and a[1] == b[1]:
+                    continue
+                edges += 1
+                if (b[0] - a[0]) * (qy - a[1]) - (b[1] - a[1]) * (qx - a[0]) <= 0:
+                    inside = False
+                    break
+            keep[j] = not (inside and edges >= 3)
+        return pts[keep]
+
+    for trial in range(300):
+        n = int(rng.integers(49, 400)); mode = trial % 4
+        if mode == 0: pts = rng.integers(-200, 200, size=(n, 2))
+        elif mode == 1: pts = np.stack([rng.integers(-300, 300, size=n), rng.integers(-6, 6, size=n)], 1)      # wall
+        elif mode == 2:
+            t = rng.uniform(0, 2 * np.pi, n); r = rng.uniform(0, 150, n); pts = np.stack([r * np.cos(t), r * np.sin(t)], 1).astype(int)
+        else:
+            x = rng.integers(-200, 200, size=n); pts = np.stack([x, x // 3 + rng.integers(-4, 4, size=n)], 1)
+        pts = np.unique(pts.astype(np.int32), axis=0)
+        f = prefilter(pts)
+        assert len(f) <= len(pts)
+        assert np.array_equal(oracle.convex_hull(pts), oracle.convex_hull(f))
+        assert np.array_equal(oracle.min_area_rect_points(pts), oracle.min_area_rect_points(f))
