@@ -40,10 +40,12 @@ def needs_build() -> bool:
     return any(os.path.getmtime(d) > t for d in deps)
 
 
-def build(force: bool = False, verbose: bool = False) -> str:
-    if not force and not needs_build():
+def build(force: bool = False, verbose: bool = False, extra_flags=(), out: str | None = None) -> str:
+    """extra_flags / out: experiment builds (e.g. -DMOT_DBG_* ablations written next to gpurun_out/), never the product"""
+    if out is None and not force and not needs_build():
         return LIB
-    cmd = [hipcc()] + HIPCC_FLAGS + [os.path.join(CSRC, s) for s in SOURCES] + ["-o", LIB + ".tmp"]
+    out = out or LIB
+    cmd = [hipcc()] + HIPCC_FLAGS + list(extra_flags) + [os.path.join(CSRC, s) for s in SOURCES] + ["-o", out + ".tmp"]
     if verbose:
         print(" ".join(cmd), file=sys.stderr)
     r = subprocess.run(cmd, capture_output=True, text=True)
@@ -51,8 +53,8 @@ def build(force: bool = False, verbose: bool = False) -> str:
         raise RuntimeError("hipcc failed:\n" + r.stdout + r.stderr)
     if verbose and r.stderr:
         print(r.stderr, file=sys.stderr)
-    os.replace(LIB + ".tmp", LIB)
-    return LIB
+    os.replace(out + ".tmp", out)
+    return out
 
 
 if __name__ == "__main__":

@@ -118,7 +118,8 @@ label_stats_kernel(MotDevParams p, ClusterBuffers c) {
 }
 
 // ------------------------------------------------------------------------------------------ B2
-constexpr int kBoxBlock = 64;        // ONE wave per cluster
+constexpr int kBoxBlock = 512;       // one workgroup (8 waves) per cluster: the waves share the label walk
+constexpr int kBoxWaves = kBoxBlock / 64;
 constexpr int kPicCols = 1024;       // pixel columns 0..900
 constexpr int kMaxHullIn = 2 * 901;  // two extreme pixels per column
 constexpr int kScanDepth = 16;      // label loads kept in flight per lane while walking a frame's labels
@@ -194,7 +195,7 @@ __constant__ signed char kDirY[32] = {0, 3, 6, 9, 11, 13, 15, 16, 16, 16, 15, 13
 
 __global__ void MOT_LAUNCH_BOUNDS(kBoxBlock)
 cluster_box_kernel(MotDevParams p, ClusterBuffers c) {
-  // LDS of ONE wave. s_raw: column extents while gathering, then the four Sklansky stacks.
+  // s_raw: column extents while gathering (all waves), then the four Sklansky stacks (wave 0).
   __shared__ __attribute__((aligned(16))) unsigned char s_raw[4 * kStackStride * sizeof(short)];
   __shared__ short s_px[kMaxHullIn + 2], s_py[kMaxHullIn + 2];  // candidate points, sorted by (x,y)
   __shared__ short s_qx[kMaxHullIn + 2], s_qy[kMaxHullIn + 2];  // ... after the interior filter
@@ -202,7 +203,8 @@ cluster_box_kernel(MotDevParams p, ClusterBuffers c) {
   __shared__ float s_hx[kMaxHull], s_hy[kMaxHull], s_vx[kMaxHull], s_vy[kMaxHull], s_inv[kMaxHull];
   __shared__ int s_rank[128], s_pidx[128];
   __shared__ unsigned s_need[kNeedWords];      // L-shape: bit r set <=> the r-th point of the cluster is sampled
-  __shared__ int s_buf[64 * kScanDepth];       // indices of this cluster's points found in the current stretch
+  __shared__ int s_buf[kBoxWaves][64 * kScanDepth];  // per wave: indices of this cluster's points found in the current stretch
+  __shared__ int s_wcnt[kBoxWaves];
   __shared__ int s_ext[32 * 2];                // extreme point per direction
   __shared__ int s_cnt[4];
   int* s_colmin = (int*)s_raw;
@@ -213,7 +215,10 @@ cluster_box_kernel(MotDevParams p, ClusterBuffers c) {
   const int num_cluster = min(c.counts[b * kCountsStride + kCntClusters], kMaxClusters);
   const float4* __restrict__ pts = c.elevated + (long)b * c.cap;
   const int* __restrict__ label = c.label + (long)b * c.cap;
-  const int lane = lane_id();
+  const int lane = lane_id(), wave = (int)(threadIdx.x >> 6);
+  // every wave walks its own slice of the frame's labels (slices are multiples of 64 points)
+  const int slice = ((n + kBoxWaves * 64 - 1) / (kBoxWaves * 64)) * 64;
+  const int s_begin = wave * slice, s_end = min(n, s_begin + slice);
 
   for (int ci = blockIdx.x; ci < num_cluster; ci += gridDim.x) {
     const ClusterStats st = c.stats[(long)b * kMaxClusters + ci];
@@ -224,7 +229,7 @@ cluster_box_kernel(MotDevParams p, ClusterBuffers c) {
     bool have = numPoints > 0 && st.argmin != kArgminInit && st.argmax != kArgmaxInit;  // SURVEY.md H7 otherwise
     if (!have) {
       cand.undefined = 1;
-      if (lane == 0) c.cand[(long)b * kMaxClusters + ci] = cand;
+      if (threadIdx.x == 0) c.cand[(long)b * kMaxClusters + ci] = cand;
       continue;
     }
     const float4 first = pts[st.first];
@@ -250,9 +255,9 @@ cluster_box_kernel(MotDevParams p, ClusterBuffers c) {
     if (lshape) {  // ---------------------------------------------------------------- L-shape :310-356
       cand.branch = 0;
       const int nsamp = p.ram_points < 128 ? p.ram_points : 128;
-      for (int i = lane; i < kNeedWords; i += 64) s_need[i] = 0u;
+      for (int i = threadIdx.x; i < kNeedWords; i += kBoxBlock) s_need[i] = 0u;
       __syncthreads();
-      if (lane == 0) {
+      if (threadIdx.x == 0) {
         // mt19937_64 mt(0); uniform_int_distribution<>(0, numPoints-1): libstdc++ >= 11 maps the 64-bit draw
         // with Lemire's multiply-shift + rejection (bits/uniform_int_dist.h _S_nd), SURVEY.md H17
         int t = 0;
@@ -276,12 +281,29 @@ cluster_box_kernel(MotDevParams p, ClusterBuffers c) {
         if (exhausted) atomicOr(&c.counts[b * kCountsStride + kCntFlags], (int)kFlagRngExhausted);
       }
       __syncthreads();
-      // k-th point of the cluster in input order: walk the labels with ballot/popcount ranks
+      // k-th point of the cluster in input order. Pass 1: every wave counts the cluster's points in its slice;
+      // pass 2: with the exclusive prefix of those counts as base rank, it walks the slice again with
+      // ballot/popcount ranks and records the sampled ones.
+      int mycount = 0;
+      for (int base0 = s_begin; base0 < s_end; base0 += 64 * kScanDepth) {
+        int lab[kScanDepth];
+#pragma unroll
+        for (int k = 0; k < kScanDepth; k++) { int i = base0 + k * 64 + lane; lab[k] = i < s_end ? label[i] : 0; }
+#pragma unroll
+        for (int k = 0; k < kScanDepth; k++) mycount += __popcll(__ballot(lab[k] == ci + 1));
+      }
+      if (lane == 0) s_wcnt[wave] = mycount;
+      __syncthreads();
       int running = 0;
-      for (int base0 = 0; base0 < n && running < numPoints; base0 += 64 * kScanDepth) {
+      for (int w2 = 0; w2 < wave; w2++) running += s_wcnt[w2];
+      const int my_end = running + mycount;
+      bool wanted = false;  // does any sampled rank fall into this wave's range?
+      for (int j = lane; j < nsamp; j += 64) wanted |= s_rank[j] >= running && s_rank[j] < my_end;
+      wanted = __any(wanted);
+      for (int base0 = s_begin; wanted && base0 < s_end && running < my_end; base0 += 64 * kScanDepth) {
         int lab[kScanDepth];  // kScanDepth independent loads in flight per lane: the walk is latency-bound otherwise
 #pragma unroll
-        for (int k = 0; k < kScanDepth; k++) { int i = base0 + k * 64 + lane; lab[k] = i < n ? label[i] : 0; }
+        for (int k = 0; k < kScanDepth; k++) { int i = base0 + k * 64 + lane; lab[k] = i < s_end ? label[i] : 0; }
 #pragma unroll
         for (int k = 0; k < kScanDepth; k++) {
           int i = base0 + k * 64 + lane;
@@ -327,28 +349,28 @@ cluster_box_kernel(MotDevParams p, ClusterBuffers c) {
       __syncthreads();
     } else {  // ------------------------------------------------------- minAreaRect :358-366
       cand.branch = 1;
-      for (int i = lane; i < kPicCols; i += 64) { s_colmin[i] = 0x7fffffff; s_colmax[i] = -0x7fffffff - 1; }
+      for (int i = threadIdx.x; i < kPicCols; i += kBoxBlock) { s_colmin[i] = 0x7fffffff; s_colmax[i] = -0x7fffffff - 1; }
       __syncthreads();
-      int running = 0;
-      for (int base0 = 0; base0 < n && running < numPoints; base0 += 64 * kScanDepth) {
+      int* mybuf = s_buf[wave];
+#ifndef MOT_DBG_SKIP_WALK
+      for (int base0 = s_begin; base0 < s_end; base0 += 64 * kScanDepth) {
         int lab[kScanDepth];
 #pragma unroll
-        for (int k = 0; k < kScanDepth; k++) { int i = base0 + k * 64 + lane; lab[k] = i < n ? label[i] : 0; }
+        for (int k = 0; k < kScanDepth; k++) { int i = base0 + k * 64 + lane; lab[k] = i < s_end ? label[i] : 0; }
         int found = 0;  // wave-uniform
 #pragma unroll
         for (int k = 0; k < kScanDepth; k++) {
           bool mine = lab[k] == ci + 1;
           unsigned long long mm = __ballot(mine);
-          if (mine) s_buf[found + __popcll(mm & ((1ull << lane) - 1ull))] = base0 + k * 64 + lane;
+          if (mine) mybuf[found + __popcll(mm & ((1ull << lane) - 1ull))] = base0 + k * 64 + lane;
           found += __popcll(mm);
         }
-        running += found;
-        __syncthreads();
+        MOT_WAVE_SYNC();
         // the points themselves: independent gathers, so many are in flight at once
         for (int j0 = 0; j0 < found; j0 += 256) {
           float4 q[4];
 #pragma unroll
-          for (int u = 0; u < 4; u++) { int j = j0 + u * 64 + lane; q[u] = j < found ? pts[s_buf[j]] : make_float4(0.f, 0.f, 0.f, 0.f); }
+          for (int u = 0; u < 4; u++) { int j = j0 + u * 64 + lane; q[u] = j < found ? pts[mybuf[j]] : make_float4(0.f, 0.f, 0.f, 0.f); }
 #pragma unroll
           for (int u = 0; u < 4; u++) {
             int j = j0 + u * 64 + lane;
@@ -358,12 +380,19 @@ cluster_box_kernel(MotDevParams p, ClusterBuffers c) {
               int picX = x;
               int picY = (int)(p.pic_full - (float)y);
               int offsetY = picY + offsetInitY;
-              if (picX >= 0 && picX < kPicCols) { atomicMin(&s_colmin[picX], offsetY); atomicMax(&s_colmax[picX], offsetY); }
+              if (picX >= 0 && picX < kPicCols) {  // look before the atomic: most points do not move an extreme
+                if (offsetY < s_colmin[picX]) atomicMin(&s_colmin[picX], offsetY);
+                if (offsetY > s_colmax[picX]) atomicMax(&s_colmax[picX], offsetY);
+              }
             }
           }
         }
-        __syncthreads();
+        MOT_WAVE_SYNC();
       }
+#endif
+      __syncthreads();
+#ifndef MOT_DBG_SKIP_HULL
+      if (wave == 0) {  // ---- from here on the cluster is one small polygon problem: wave 0 finishes it
       // compact the column extents into (x,y)-sorted points: 16 columns per lane, prefix over lanes
       int cnt = 0;
       for (int k = 0; k < kPicCols / 64; k++) {
@@ -384,7 +413,7 @@ cluster_box_kernel(MotDevParams p, ClusterBuffers c) {
         }
       }
       int total = __shfl(incl, 63, 64);
-      __syncthreads();
+      MOT_WAVE_SYNC();
       // ---- drop points strictly inside the polygon of 32 directional extremes (exact integer tests); what is
       //      left still contains every hull vertex, in (x,y) order
       if (total > 48) {
@@ -395,7 +424,7 @@ cluster_box_kernel(MotDevParams p, ClusterBuffers c) {
           key = wave_max_t<long long>(key);
           if (lane == 0) { int w = 0xffff - (int)(key & 0xffff); s_ext[2 * d] = s_px[w]; s_ext[2 * d + 1] = s_py[w]; }
         }
-        __syncthreads();
+        MOT_WAVE_SYNC();
         int kept_total = 0;
         for (int j0 = 0; j0 < total; j0 += 64) {
           int j = j0 + lane;
@@ -420,7 +449,7 @@ cluster_box_kernel(MotDevParams p, ClusterBuffers c) {
       } else {
         for (int j = lane; j < total; j += 64) { s_qx[j] = s_px[j]; s_qy[j] = s_py[j]; }
       }
-      __syncthreads();
+      MOT_WAVE_SYNC();
       const short* ax = s_qx; const short* ay = s_qy;
       // first index holding the minimum / maximum y (strict compares in cv::convexHull)
       int miny_ind = 0, maxy_ind = 0;
@@ -444,7 +473,7 @@ cluster_box_kernel(MotDevParams p, ClusterBuffers c) {
         int sign2 = (lane == 0 || lane == 3) ? 1 : -1;
         s_cnt[lane] = sklansky(ax, ay, start, end, s_stack + lane * kStackStride, nsign, sign2);
       }
-      __syncthreads();
+      MOT_WAVE_SYNC();
       float rect[8] = {0, 0, 0, 0, 0, 0, 0, 0};
       if (lane == 0) {
         int nout = 0;
@@ -603,9 +632,11 @@ cluster_box_kernel(MotDevParams p, ClusterBuffers c) {
         }
         promising = !cand.undefined && rule_based_filter(p, pc, maxZ, numPoints);
       }
+      }  // wave 0
+#endif
       __syncthreads();
     }
-    if (lane == 0) {
+    if (threadIdx.x == 0) {
       if (!cand.undefined) for (int k = 0; k < 8; k++) cand.pc[k] = pc[k];
       cand.accepted = promising ? 1 : 0;
       c.cand[(long)b * kMaxClusters + ci] = cand;
@@ -679,7 +710,7 @@ void mot_launch_box_kernel(int which, const MotDevParams& p, const ClusterBuffer
   int chunks = (max_n + kLabelChunk - 1) / kLabelChunk;
   if (chunks < 1) chunks = 1;
   if (which == 0) hipLaunchKernelGGL(label_stats_kernel, dim3(chunks, batch), dim3(kLabelBlock), 0, stream, p, c);
-  else if (which == 1) hipLaunchKernelGGL(cluster_box_kernel, dim3(64, batch), dim3(kBoxBlock), 0, stream, p, c);
+  else if (which == 1) hipLaunchKernelGGL(cluster_box_kernel, dim3(48, batch), dim3(kBoxBlock), 0, stream, p, c);
   else if (which == 2) hipLaunchKernelGGL(box_finalize_kernel, dim3(batch), dim3(kFinalBlock), 0, stream, p, c);
 }
 
