@@ -122,7 +122,7 @@ constexpr int kBoxBlock = 512;       // one workgroup (8 waves) per cluster: the
 constexpr int kBoxWaves = kBoxBlock / 64;
 constexpr int kPicCols = 1024;       // pixel columns 0..900
 constexpr int kMaxHullIn = 2 * 901;  // two extreme pixels per column
-constexpr int kScanDepth = 16;      // label loads kept in flight per lane while walking a frame's labels
+constexpr int kScanDepth = 8;       // label loads kept in flight per lane while walking a frame's labels
 constexpr int kStackStride = 2048;  // shorts per Sklansky stack (>= kMaxHullIn + 2)
 constexpr int kNeedWords = 2048;    // bitmap of sampled ranks for clusters of up to 65536 points (larger: no shortcut)
 constexpr int kMaxHull = 512;        // vertices of a convex lattice polygon in a 900^2 box: < 3.5 * 900^(2/3) ~ 330
@@ -207,6 +207,7 @@ cluster_box_kernel(MotDevParams p, ClusterBuffers c) {
   __shared__ int s_wcnt[kBoxWaves];
   __shared__ int s_ext[32 * 2];                // extreme point per direction
   __shared__ int s_cnt[4];
+  __shared__ int s_total;
   int* s_colmin = (int*)s_raw;
   int* s_colmax = s_colmin + kPicCols;
   short* s_stack = (short*)s_raw;
@@ -257,28 +258,46 @@ cluster_box_kernel(MotDevParams p, ClusterBuffers c) {
       const int nsamp = p.ram_points < 128 ? p.ram_points : 128;
       for (int i = threadIdx.x; i < kNeedWords; i += kBoxBlock) s_need[i] = 0u;
       __syncthreads();
-      if (threadIdx.x == 0) {
-        // mt19937_64 mt(0); uniform_int_distribution<>(0, numPoints-1): libstdc++ >= 11 maps the 64-bit draw
-        // with Lemire's multiply-shift + rejection (bits/uniform_int_dist.h _S_nd), SURVEY.md H17
-        int t = 0;
-        unsigned long long range = (unsigned long long)numPoints;
-        bool exhausted = false;
-        for (int i = 0; i < nsamp; i++) {
-          unsigned long long g = c.rng[t < kRngTable ? t : kRngTable - 1]; exhausted |= t >= kRngTable; t++;
+      {
+        // mt19937_64 mt(0); uniform_int_distribution<>(0, numPoints-1): libstdc++ >= 11 maps the 64-bit draw with
+        // Lemire's multiply-shift + rejection (bits/uniform_int_dist.h _S_nd), SURVEY.md H17. A rejection (probability
+        // numPoints / 2^64 per draw) shifts every later draw, so the draws are mapped in parallel and the rare
+        // rejection is replayed sequentially.
+        const unsigned long long range = (unsigned long long)numPoints;
+        bool reject = false;
+        for (int i = threadIdx.x; i < nsamp; i += kBoxBlock) {
+          unsigned long long g = c.rng[i < kRngTable ? i : kRngTable - 1];
           unsigned long long low = g * range, high = __umul64hi(g, range);
-          if (low < range) {
-            unsigned long long threshold = (0ull - range) % range;
-            while (low < threshold) {
-              g = c.rng[t < kRngTable ? t : kRngTable - 1]; exhausted |= t >= kRngTable; t++;
-              low = g * range; high = __umul64hi(g, range);
-              if (exhausted) break;
-            }
-          }
+          if (low < range && low < (0ull - range) % range) reject = true;
           s_rank[i] = (int)high;
           s_pidx[i] = -1;
-          if ((int)high < kNeedWords * 32) s_need[(int)high >> 5] |= 1u << ((int)high & 31);
         }
-        if (exhausted) atomicOr(&c.counts[b * kCountsStride + kCntFlags], (int)kFlagRngExhausted);
+        if (threadIdx.x == 0) s_total = 0;
+        __syncthreads();
+        if (reject) s_total = 1;
+        __syncthreads();
+        if (s_total != 0 && threadIdx.x == 0) {
+          int t = 0;
+          bool exhausted = false;
+          for (int i = 0; i < nsamp; i++) {
+            unsigned long long g = c.rng[t < kRngTable ? t : kRngTable - 1]; exhausted |= t >= kRngTable; t++;
+            unsigned long long low = g * range, high = __umul64hi(g, range);
+            if (low < range) {
+              unsigned long long threshold = (0ull - range) % range;
+              while (low < threshold && !exhausted) {
+                g = c.rng[t < kRngTable ? t : kRngTable - 1]; exhausted |= t >= kRngTable; t++;
+                low = g * range; high = __umul64hi(g, range);
+              }
+            }
+            s_rank[i] = (int)high;
+          }
+          if (exhausted) atomicOr(&c.counts[b * kCountsStride + kCntFlags], (int)kFlagRngExhausted);
+        }
+        __syncthreads();
+        for (int i = threadIdx.x; i < nsamp; i += kBoxBlock) {
+          int r = s_rank[i];
+          if (r < kNeedWords * 32) atomicOr(&s_need[r >> 5], 1u << (r & 31));
+        }
       }
       __syncthreads();
       // k-th point of the cluster in input order. Pass 1: every wave counts the cluster's points in its slice;
@@ -474,164 +493,205 @@ cluster_box_kernel(MotDevParams p, ClusterBuffers c) {
         s_cnt[lane] = sklansky(ax, ay, start, end, s_stack + lane * kStackStride, nsign, sign2);
       }
       MOT_WAVE_SYNC();
-      float rect[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-      if (lane == 0) {
-        int nout = 0;
-        if (total > 0) {
-          if (degenerate) {
-            s_hull[nout++] = 0;
-          } else {
-            short* tl_stack = s_stack; int tl_count = s_cnt[0];
-            short* tr_stack = s_stack + kStackStride; int tr_count = s_cnt[1];
-            for (int i = 0; i < tl_count - 1; i++) s_hull[nout++] = tl_stack[i];
-            for (int i = tr_count - 1; i > 0; i--) s_hull[nout++] = tr_stack[i];
-            int stop_idx = tr_count > 2 ? tr_stack[1] : tl_count > 2 ? tl_stack[tl_count - 2] : -1;
-            // clockwise: the bottom-left / bottom-right stacks swap roles
-            short* bl_stack = s_stack + 3 * kStackStride; int bl_count = s_cnt[3];
-            short* br_stack = s_stack + 2 * kStackStride; int br_count = s_cnt[2];
-            if (stop_idx >= 0) {
-              int check_idx = bl_count > 2 ? bl_stack[1] : bl_count + br_count > 2 ? br_stack[2 - bl_count] : -1;
-              if (check_idx == stop_idx || (check_idx >= 0 && ax[check_idx] == ax[stop_idx] && ay[check_idx] == ay[stop_idx])) {
-                bl_count = bl_count < 2 ? bl_count : 2;
-                br_count = br_count < 2 ? br_count : 2;
-              }
-            }
-            for (int i = 0; i < bl_count - 1; i++) s_hull[nout++] = bl_stack[i];
-            for (int i = br_count - 1; i > 0; i--) s_hull[nout++] = br_stack[i];
-          }
-        }
-        const int hn = nout;
-        float cx = 0, cy = 0, w = 0, h = 0, angle = 0;
-        if (hn > kMaxHull) {
-          atomicOr(&c.counts[b * kCountsStride + kCntFlags], (int)kFlagHullOverflow);
-          cand.undefined = 1;
+      // assemble the hull from the four stacks (OpenCV's order: top-left chain, top-right chain reversed, then the
+      // bottom chains with their roles swapped because clockwise == true); every lane copies a strided share
+      int hn = 0;
+      if (total > 0) {
+        if (degenerate) {
+          if (lane == 0) s_hull[0] = 0;
+          hn = 1;
         } else {
-          for (int i = 0; i < hn; i++) { s_hx[i] = (float)ax[s_hull[i]]; s_hy[i] = (float)ay[s_hull[i]]; }
-          if (hn > 2) {
-            // ---- rotatingCalipers(points, n, CALIPERS_MINAREARECT, out), OpenCV 3.2 rotcalipers.cpp
+          const short* tl_stack = s_stack; const int tl_count = s_cnt[0];
+          const short* tr_stack = s_stack + kStackStride; const int tr_count = s_cnt[1];
+          const short* bl_stack = s_stack + 3 * kStackStride; int bl_count = s_cnt[3];
+          const short* br_stack = s_stack + 2 * kStackStride; int br_count = s_cnt[2];
+          int stop_idx = tr_count > 2 ? tr_stack[1] : tl_count > 2 ? tl_stack[tl_count - 2] : -1;
+          if (stop_idx >= 0) {
+            int check_idx = bl_count > 2 ? bl_stack[1] : bl_count + br_count > 2 ? br_stack[2 - bl_count] : -1;
+            if (check_idx == stop_idx || (check_idx >= 0 && ax[check_idx] == ax[stop_idx] && ay[check_idx] == ay[stop_idx])) {
+              bl_count = bl_count < 2 ? bl_count : 2;
+              br_count = br_count < 2 ? br_count : 2;
+            }
+          }
+          const int n0 = tl_count - 1, n1 = tr_count - 1, n2 = bl_count - 1, n3 = br_count - 1;
+          for (int i = lane; i < n0; i += 64) s_hull[i] = tl_stack[i];
+          for (int i = lane; i < n1; i += 64) s_hull[n0 + i] = tr_stack[tr_count - 1 - i];
+          for (int i = lane; i < n2; i += 64) s_hull[n0 + n1 + i] = bl_stack[i];
+          for (int i = lane; i < n3; i += 64) s_hull[n0 + n1 + n2 + i] = br_stack[br_count - 1 - i];
+          hn = n0 + n1 + n2 + n3;
+        }
+      }
+      MOT_WAVE_SYNC();
+      float rect[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+      float cx = 0, cy = 0, w = 0, h = 0, angle = 0;
+      if (hn > kMaxHull) {
+        if (lane == 0) atomicOr(&c.counts[b * kCountsStride + kCntFlags], (int)kFlagHullOverflow);
+        cand.undefined = 1;
+      } else {
+        for (int i = lane; i < hn; i += 64) { s_hx[i] = (float)ax[s_hull[i]]; s_hy[i] = (float)ay[s_hull[i]]; }
+        MOT_WAVE_SYNC();
+        if (hn > 2) {
+          // ---- rotatingCalipers(points, n, CALIPERS_MINAREARECT, out), OpenCV 3.2 rotcalipers.cpp.
+          // Set-up (edge vectors, 1/length, extreme vertices, orientation) is data parallel; the caliper walk
+          // itself is a dependent chain over the hull and runs with the hull held in registers (one vertex per
+          // lane, v_readlane instead of LDS round trips) whenever it has at most 64 vertices.
+          long long kl = 0x7fffffffffffffffll, kr = -0x7fffffffffffffffll - 1, kt = -0x7fffffffffffffffll - 1, kb = 0x7fffffffffffffffll;
+          for (int i = lane; i < hn; i += 64) {
+            int nx = (i + 1 < hn) ? i + 1 : 0;
+            float p0x = s_hx[i], p0y = s_hy[i], ptx = s_hx[nx], pty = s_hy[nx];
+            double dx = ptx - p0x, dy = pty - p0y;
+            s_vx[i] = (float)dx; s_vy[i] = (float)dy;
+            s_inv[i] = (float)(1. / sqrt(dx * dx + dy * dy));
+            // `if (pt0.x < left_x) left = i` etc.: strict compares => the FIRST vertex holding the extreme value
+            long long ix = (long long)(int)p0x, iy = (long long)(int)p0y;  // vertices are integers
+            long long a_ = (ix << 32) | (unsigned)i, b_ = (ix << 32) | (unsigned)(0xffff - i);
+            long long c_ = (iy << 32) | (unsigned)(0xffff - i), d_ = (iy << 32) | (unsigned)i;
+            kl = a_ < kl ? a_ : kl; kr = b_ > kr ? b_ : kr; kt = c_ > kt ? c_ : kt; kb = d_ < kb ? d_ : kb;
+          }
+          kl = wave_min_t<long long>(kl); kr = wave_max_t<long long>(kr); kt = wave_max_t<long long>(kt); kb = wave_min_t<long long>(kb);
+          const int left = (int)(kl & 0xffff), right = 0xffff - (int)(kr & 0xffff), top = 0xffff - (int)(kt & 0xffff), bottom = (int)(kb & 0xffff);
+          MOT_WAVE_SYNC();
+          // hull orientation: sign of the first non-zero cross product of consecutive edges
+          float orientation = 0;
+          for (int i0 = 0; i0 < hn && orientation == 0; i0 += 64) {
+            int i = i0 + lane;
+            double convexity = 0;
+            if (i < hn) {
+              int pi = i == 0 ? hn - 1 : i - 1;
+              convexity = (double)s_vx[pi] * (double)s_vy[i] - (double)s_vy[pi] * (double)s_vx[i];
+            }
+            unsigned long long nz = __ballot(convexity != 0);
+            if (nz) { int f = __ffsll(nz) - 1; double cv = __shfl(convexity, f, 64); orientation = cv > 0 ? 1.f : -1.f; }
+          }
+          if (orientation != 0) {  // OpenCV asserts otherwise
             float minarea = 3.402823466e+38f;
             int bi0 = 0, bi5 = 0; float b1 = 0, b2 = 0, b3 = 0, b4 = 0;
-            int left = 0, bottom = 0, right = 0, top = 0;
-            int seq[4] = {-1, -1, -1, -1};
-            float orientation = 0, base_a, base_b = 0;
-            float pt0x = s_hx[0], pt0y = s_hy[0];
-            float left_x = pt0x, right_x = pt0x, top_y = pt0y, bottom_y = pt0y;
-            for (int i = 0; i < hn; i++) {
-              if (pt0x < left_x) left_x = pt0x, left = i;
-              if (pt0x > right_x) right_x = pt0x, right = i;
-              if (pt0y > top_y) top_y = pt0y, top = i;
-              if (pt0y < bottom_y) bottom_y = pt0y, bottom = i;
-              int nx = (i + 1 < hn) ? i + 1 : 0;
-              float ptx = s_hx[nx], pty = s_hy[nx];
-              double dx = ptx - pt0x, dy = pty - pt0y;
-              s_vx[i] = (float)dx; s_vy[i] = (float)dy;
-              s_inv[i] = (float)(1. / sqrt(dx * dx + dy * dy));
-              pt0x = ptx; pt0y = pty;
-            }
-            {
-              double ax2 = s_vx[hn - 1], ay2 = s_vy[hn - 1];
-              for (int i = 0; i < hn; i++) {
-                double bx = s_vx[i], by = s_vy[i];
-                double convexity = ax2 * by - ay2 * bx;
-                if (convexity != 0) { orientation = (convexity > 0) ? 1.f : (-1.f); break; }
-                ax2 = bx; ay2 = by;
-              }
-            }
-            if (orientation != 0) {  // OpenCV asserts otherwise
-              base_a = orientation;
-              seq[0] = bottom; seq[1] = right; seq[2] = top; seq[3] = left;
+            float base_a = orientation, base_b = 0;
+            int seq0 = bottom, seq1 = right, seq2 = top, seq3 = left;
+#ifndef MOT_HIPEMU
+#define RLF(v, idx) __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(v), (idx)))
+#else
+#define RLF(v, idx) __shfl((v), (idx), 64)
+#endif
+            if (hn <= 64) {
+              const float rhx = lane < hn ? s_hx[lane] : 0.f, rhy = lane < hn ? s_hy[lane] : 0.f;
+              const float rvx = lane < hn ? s_vx[lane] : 0.f, rvy = lane < hn ? s_vy[lane] : 0.f, rinv = lane < hn ? s_inv[lane] : 0.f;
               for (int k = 0; k < hn; k++) {
-                float dp0 = +base_a * s_vx[seq[0]] + base_b * s_vy[seq[0]];
-                float dp1 = -base_b * s_vx[seq[1]] + base_a * s_vy[seq[1]];
-                float dp2 = -base_a * s_vx[seq[2]] - base_b * s_vy[seq[2]];
-                float dp3 = +base_b * s_vx[seq[3]] - base_a * s_vy[seq[3]];
-                float maxcos = dp0 * s_inv[seq[0]];
+                float dp0 = +base_a * RLF(rvx, seq0) + base_b * RLF(rvy, seq0);
+                float dp1 = -base_b * RLF(rvx, seq1) + base_a * RLF(rvy, seq1);
+                float dp2 = -base_a * RLF(rvx, seq2) - base_b * RLF(rvy, seq2);
+                float dp3 = +base_b * RLF(rvx, seq3) - base_a * RLF(rvy, seq3);
+                float maxcos = dp0 * RLF(rinv, seq0);
                 int main_element = 0;
-                float cosalpha = dp1 * s_inv[seq[1]];
+                float cosalpha = dp1 * RLF(rinv, seq1);
                 if (cosalpha > maxcos) { main_element = 1; maxcos = cosalpha; }
-                cosalpha = dp2 * s_inv[seq[2]];
+                cosalpha = dp2 * RLF(rinv, seq2);
                 if (cosalpha > maxcos) { main_element = 2; maxcos = cosalpha; }
-                cosalpha = dp3 * s_inv[seq[3]];
+                cosalpha = dp3 * RLF(rinv, seq3);
                 if (cosalpha > maxcos) { main_element = 3; maxcos = cosalpha; }
-                {
-                  int pindex = seq[main_element];
-                  float lead_x = s_vx[pindex] * s_inv[pindex];
-                  float lead_y = s_vy[pindex] * s_inv[pindex];
-                  switch (main_element) {
-                    case 0: base_a = lead_x; base_b = lead_y; break;
-                    case 1: base_a = lead_y; base_b = -lead_x; break;
-                    case 2: base_a = -lead_x; base_b = -lead_y; break;
-                    default: base_a = -lead_y; base_b = lead_x; break;
-                  }
+                int pindex = main_element == 0 ? seq0 : main_element == 1 ? seq1 : main_element == 2 ? seq2 : seq3;
+                float lead_x = RLF(rvx, pindex) * RLF(rinv, pindex);
+                float lead_y = RLF(rvy, pindex) * RLF(rinv, pindex);
+                switch (main_element) {
+                  case 0: base_a = lead_x; base_b = lead_y; seq0 = seq0 + 1 == hn ? 0 : seq0 + 1; break;
+                  case 1: base_a = lead_y; base_b = -lead_x; seq1 = seq1 + 1 == hn ? 0 : seq1 + 1; break;
+                  case 2: base_a = -lead_x; base_b = -lead_y; seq2 = seq2 + 1 == hn ? 0 : seq2 + 1; break;
+                  default: base_a = -lead_y; base_b = lead_x; seq3 = seq3 + 1 == hn ? 0 : seq3 + 1; break;
                 }
-                seq[main_element] += 1;
-                seq[main_element] = (seq[main_element] == hn) ? 0 : seq[main_element];
-                {
-                  float dx = s_hx[seq[1]] - s_hx[seq[3]];
-                  float dy = s_hy[seq[1]] - s_hy[seq[3]];
-                  float width = dx * base_a + dy * base_b;
-                  dx = s_hx[seq[2]] - s_hx[seq[0]];
-                  dy = s_hy[seq[2]] - s_hy[seq[0]];
-                  float height = -dx * base_b + dy * base_a;
-                  float area = width * height;
-                  if (area <= minarea) {
-                    minarea = area;
-                    bi0 = seq[3]; b1 = base_a; b2 = width; b3 = base_b; b4 = height; bi5 = seq[0];
-                  }
-                }
+                float dx = RLF(rhx, seq1) - RLF(rhx, seq3);
+                float dy = RLF(rhy, seq1) - RLF(rhy, seq3);
+                float width = dx * base_a + dy * base_b;
+                dx = RLF(rhx, seq2) - RLF(rhx, seq0);
+                dy = RLF(rhy, seq2) - RLF(rhy, seq0);
+                float height = -dx * base_b + dy * base_a;
+                float area = width * height;
+                if (area <= minarea) { minarea = area; bi0 = seq3; b1 = base_a; b2 = width; b3 = base_b; b4 = height; bi5 = seq0; }
               }
-              float A1 = b1, B1 = b3, A2 = -b3, B2 = b1;
-              float C1 = A1 * s_hx[bi0] + s_hy[bi0] * B1;
-              float C2 = A2 * s_hx[bi5] + s_hy[bi5] * B2;
-              float idet = 1.f / (A1 * B2 - A2 * B1);
-              float qx = (C1 * B2 - C2 * B1) * idet;
-              float qy = (A1 * C2 - A2 * C1) * idet;
-              float o2 = A1 * b2, o3 = B1 * b2, o4 = A2 * b4, o5 = B2 * b4;
-              // cv::minAreaRect
-              cx = qx + (o2 + o4) * 0.5f;
-              cy = qy + (o3 + o5) * 0.5f;
-              w = (float)sqrt((double)o2 * o2 + (double)o3 * o3);
-              h = (float)sqrt((double)o4 * o4 + (double)o5 * o5);
-              angle = (float)atan2((double)o3, (double)o2);
+            } else {
+              for (int k = 0; k < hn; k++) {
+                float dp0 = +base_a * s_vx[seq0] + base_b * s_vy[seq0];
+                float dp1 = -base_b * s_vx[seq1] + base_a * s_vy[seq1];
+                float dp2 = -base_a * s_vx[seq2] - base_b * s_vy[seq2];
+                float dp3 = +base_b * s_vx[seq3] - base_a * s_vy[seq3];
+                float maxcos = dp0 * s_inv[seq0];
+                int main_element = 0;
+                float cosalpha = dp1 * s_inv[seq1];
+                if (cosalpha > maxcos) { main_element = 1; maxcos = cosalpha; }
+                cosalpha = dp2 * s_inv[seq2];
+                if (cosalpha > maxcos) { main_element = 2; maxcos = cosalpha; }
+                cosalpha = dp3 * s_inv[seq3];
+                if (cosalpha > maxcos) { main_element = 3; maxcos = cosalpha; }
+                int pindex = main_element == 0 ? seq0 : main_element == 1 ? seq1 : main_element == 2 ? seq2 : seq3;
+                float lead_x = s_vx[pindex] * s_inv[pindex];
+                float lead_y = s_vy[pindex] * s_inv[pindex];
+                switch (main_element) {
+                  case 0: base_a = lead_x; base_b = lead_y; seq0 = seq0 + 1 == hn ? 0 : seq0 + 1; break;
+                  case 1: base_a = lead_y; base_b = -lead_x; seq1 = seq1 + 1 == hn ? 0 : seq1 + 1; break;
+                  case 2: base_a = -lead_x; base_b = -lead_y; seq2 = seq2 + 1 == hn ? 0 : seq2 + 1; break;
+                  default: base_a = -lead_y; base_b = lead_x; seq3 = seq3 + 1 == hn ? 0 : seq3 + 1; break;
+                }
+                float dx = s_hx[seq1] - s_hx[seq3];
+                float dy = s_hy[seq1] - s_hy[seq3];
+                float width = dx * base_a + dy * base_b;
+                dx = s_hx[seq2] - s_hx[seq0];
+                dy = s_hy[seq2] - s_hy[seq0];
+                float height = -dx * base_b + dy * base_a;
+                float area = width * height;
+                if (area <= minarea) { minarea = area; bi0 = seq3; b1 = base_a; b2 = width; b3 = base_b; b4 = height; bi5 = seq0; }
+              }
             }
-          } else if (hn == 2) {
-            cx = (s_hx[0] + s_hx[1]) * 0.5f;
-            cy = (s_hy[0] + s_hy[1]) * 0.5f;
-            double dx = s_hx[1] - s_hx[0], dy = s_hy[1] - s_hy[0];
-            w = (float)sqrt(dx * dx + dy * dy);
-            h = 0;
-            angle = (float)atan2(dy, dx);
-          } else if (hn == 1) {
-            cx = s_hx[0]; cy = s_hy[0];
+#undef RLF
+            float A1 = b1, B1 = b3, A2 = -b3, B2 = b1;
+            float C1 = A1 * s_hx[bi0] + s_hy[bi0] * B1;
+            float C2 = A2 * s_hx[bi5] + s_hy[bi5] * B2;
+            float idet = 1.f / (A1 * B2 - A2 * B1);
+            float qx = (C1 * B2 - C2 * B1) * idet;
+            float qy = (A1 * C2 - A2 * C1) * idet;
+            float o2 = A1 * b2, o3 = B1 * b2, o4 = A2 * b4, o5 = B2 * b4;
+            // cv::minAreaRect
+            cx = qx + (o2 + o4) * 0.5f;
+            cy = qy + (o3 + o5) * 0.5f;
+            w = (float)sqrt((double)o2 * o2 + (double)o3 * o3);
+            h = (float)sqrt((double)o4 * o4 + (double)o5 * o5);
+            angle = (float)atan2((double)o3, (double)o2);
           }
-          angle = (float)(angle * 180 / 3.1415926535897932384626433832795);
-          // RotatedRect::points
-          double _angle = angle * 3.1415926535897932384626433832795 / 180.;
-          float bb = (float)cos(_angle) * 0.5f;
-          float aa = (float)sin(_angle) * 0.5f;
-          rect[0] = cx - aa * h - bb * w;
-          rect[1] = cy + bb * h - aa * w;
-          rect[2] = cx + aa * h - bb * w;
-          rect[3] = cy - bb * h - aa * w;
-          rect[4] = 2 * cx - rect[0];
-          rect[5] = 2 * cy - rect[1];
-          rect[6] = 2 * cx - rect[2];
-          rect[7] = 2 * cy - rect[3];
+        } else if (hn == 2) {
+          cx = (s_hx[0] + s_hx[1]) * 0.5f;
+          cy = (s_hy[0] + s_hy[1]) * 0.5f;
+          double dx = s_hx[1] - s_hx[0], dy = s_hy[1] - s_hy[0];
+          w = (float)sqrt(dx * dx + dy * dy);
+          h = 0;
+          angle = (float)atan2(dy, dx);
+        } else if (hn == 1) {
+          cx = s_hx[0]; cy = s_hy[0];
         }
-        // getPointsInPcFrame :75-95
-        for (int i = 0; i < 4; i++) {
-          float picX = rect[2 * i], picY = rect[2 * i + 1];
-          float rOffsetX = picX - (float)offsetInitX;
-          float rOffsetY = picY - (float)offsetInitY;
-          float rX = rOffsetX;
-          float rY = p.pic_full - rOffsetY;
-          float rmX = rX / p.pic_scale;
-          float rmY = rY / p.pic_scale;
-          pc[2 * i] = rmX - p.roi_half;
-          pc[2 * i + 1] = rmY - p.roi_half;
-        }
-        promising = !cand.undefined && rule_based_filter(p, pc, maxZ, numPoints);
+        angle = (float)(angle * 180 / 3.1415926535897932384626433832795);
+        // RotatedRect::points
+        double _angle = angle * 3.1415926535897932384626433832795 / 180.;
+        float bb = (float)cos(_angle) * 0.5f;
+        float aa = (float)sin(_angle) * 0.5f;
+        rect[0] = cx - aa * h - bb * w;
+        rect[1] = cy + bb * h - aa * w;
+        rect[2] = cx + aa * h - bb * w;
+        rect[3] = cy - bb * h - aa * w;
+        rect[4] = 2 * cx - rect[0];
+        rect[5] = 2 * cy - rect[1];
+        rect[6] = 2 * cx - rect[2];
+        rect[7] = 2 * cy - rect[3];
       }
+      // getPointsInPcFrame :75-95
+      for (int i = 0; i < 4; i++) {
+        float picX = rect[2 * i], picY = rect[2 * i + 1];
+        float rOffsetX = picX - (float)offsetInitX;
+        float rOffsetY = picY - (float)offsetInitY;
+        float rX = rOffsetX;
+        float rY = p.pic_full - rOffsetY;
+        float rmX = rX / p.pic_scale;
+        float rmY = rY / p.pic_scale;
+        pc[2 * i] = rmX - p.roi_half;
+        pc[2 * i + 1] = rmY - p.roi_half;
+      }
+      promising = !cand.undefined && rule_based_filter(p, pc, maxZ, numPoints);
       }  // wave 0
 #endif
       __syncthreads();

@@ -213,6 +213,8 @@ static inline int __ffsll(unsigned long long v) { return __builtin_ffsll((long l
 static inline int __ffs(unsigned v) { return __builtin_ffs((int)v); }
 static inline int __clz(int v) { return v ? __builtin_clz((unsigned)v) : 32; }
 static inline int __clzll(long long v) { return v ? __builtin_clzll((unsigned long long)v) : 64; }
+static inline unsigned __builtin_amdgcn_readlane(unsigned v, int l) { return hipemu::shfl(v, l); }
+static inline unsigned __builtin_amdgcn_readfirstlane(unsigned v) { return hipemu::shfl(v, 0); }
 static inline int __lane_id() { return hipemu::lane(); }
 static inline unsigned __builtin_amdgcn_mbcnt_lo(unsigned mask, unsigned base) { int l = hipemu::lane(); unsigned m = l >= 32 ? mask : (mask & ((1u << l) - 1)); return base + __builtin_popcount(m); }
 static inline unsigned __builtin_amdgcn_mbcnt_hi(unsigned mask, unsigned base) { int l = hipemu::lane(); unsigned m = l <= 32 ? 0u : (mask & ((1u << (l - 32)) - 1)); return base + __builtin_popcount(m); }
