@@ -4,7 +4,8 @@
 // OpenCV's minAreaRect / RotatedRect::points) — OT/src/cluster/box_fitting.cpp:46-435 — for a batch of frames:
 //
 //   B1 label_stats_kernel   N_e pts  -> per-point label + per-cluster {count, first point, max z, slope extrema}
-//   B2 cluster_box_kernel   clusters -> candidate box per cluster (L-shape fit or min-area rectangle + rule filter)
+//   B2 cluster_gather_kernel  clusters -> L-shape fit, or the candidate hull points of the cluster (8 waves per cluster)
+//   B2b cluster_rect_kernel  clusters -> min-area rectangle + rule filter (one wave per cluster)
 //   B3 box_finalize_kernel  clusters -> boxes compacted in cluster order (the order the reference push_backs them)
 //
 // Design notes:
@@ -123,9 +124,9 @@ constexpr int kBoxWaves = kBoxBlock / 64;
 constexpr int kPicCols = 1024;       // pixel columns 0..900
 constexpr int kMaxHullIn = 2 * 901;  // two extreme pixels per column
 constexpr int kScanDepth = 8;       // label loads kept in flight per lane while walking a frame's labels
-constexpr int kStackStride = 2048;  // shorts per Sklansky stack (>= kMaxHullIn + 2)
+constexpr int kStackStride = 2 * 901 + 2;  // shorts per Sklansky stack (= kMaxHullIn + 2)
 constexpr int kNeedWords = 2048;    // bitmap of sampled ranks for clusters of up to 65536 points (larger: no shortcut)
-constexpr int kMaxHull = 512;        // vertices of a convex lattice polygon in a 900^2 box: < 3.5 * 900^(2/3) ~ 330
+constexpr int kMaxHull = 384;        // vertices of a convex lattice polygon in a 900^2 box: < 3.5 * 900^(2/3) ~ 330
 
 // ruleBasedFilter :97-158 (fall-through = false)
 __device__ bool rule_based_filter(const MotDevParams& p, const float* pc, float maxZ, int numPoints) {
@@ -194,23 +195,16 @@ __constant__ signed char kDirY[32] = {0, 3, 6, 9, 11, 13, 15, 16, 16, 16, 15, 13
                                                  0, -3, -6, -9, -11, -13, -15, -16, -16, -16, -15, -13, -11, -9, -6, -3};
 
 __global__ void MOT_LAUNCH_BOUNDS(kBoxBlock)
-cluster_box_kernel(MotDevParams p, ClusterBuffers c) {
-  // s_raw: column extents while gathering (all waves), then the four Sklansky stacks (wave 0).
-  __shared__ __attribute__((aligned(16))) unsigned char s_raw[4 * kStackStride * sizeof(short)];
+cluster_gather_kernel(MotDevParams p, ClusterBuffers c) {
+  __shared__ __attribute__((aligned(16))) unsigned char s_raw[2 * kPicCols * sizeof(int)];  // column extents
   __shared__ short s_px[kMaxHullIn + 2], s_py[kMaxHullIn + 2];  // candidate points, sorted by (x,y)
-  __shared__ short s_qx[kMaxHullIn + 2], s_qy[kMaxHullIn + 2];  // ... after the interior filter
-  __shared__ short s_hull[kMaxHullIn + 2];
-  __shared__ float s_hx[kMaxHull], s_hy[kMaxHull], s_vx[kMaxHull], s_vy[kMaxHull], s_inv[kMaxHull];
   __shared__ int s_rank[128], s_pidx[128];
   __shared__ unsigned s_need[kNeedWords];      // L-shape: bit r set <=> the r-th point of the cluster is sampled
   __shared__ int s_buf[kBoxWaves][64 * kScanDepth];  // per wave: indices of this cluster's points found in the current stretch
   __shared__ int s_wcnt[kBoxWaves];
-  __shared__ int s_ext[32 * 2];                // extreme point per direction
-  __shared__ int s_cnt[4];
   __shared__ int s_total;
   int* s_colmin = (int*)s_raw;
   int* s_colmax = s_colmin + kPicCols;
-  short* s_stack = (short*)s_raw;
   const int b = blockIdx.y;
   const int n = c.counts[b * kCountsStride + kCntElev];
   const int num_cluster = min(c.counts[b * kCountsStride + kCntClusters], kMaxClusters);
@@ -433,6 +427,62 @@ cluster_box_kernel(MotDevParams p, ClusterBuffers c) {
       }
       int total = __shfl(incl, 63, 64);
       MOT_WAVE_SYNC();
+      // hand the candidates to the polygon kernel through the frame's pool
+      int off = 0;
+      if (lane == 0) off = atomicAdd(&c.counts[b * kCountsStride + kCntPoly], total);
+      off = __shfl(off, 0, 64);
+      int* pool = c.poly + (long)b * c.cap;
+      for (int j = lane; j < total; j += 64) if (off + j < c.cap) pool[off + j] = ((int)(unsigned short)s_px[j]) | ((int)s_py[j] << 16);
+      if (lane == 0) {
+        cand.poly_off = off; cand.poly_n = total; cand.off_x = offsetInitX; cand.off_y = offsetInitY; cand.num_points = numPoints;
+        c.cand[(long)b * kMaxClusters + ci] = cand;
+      }
+      }  // wave 0
+#endif
+      __syncthreads();
+      continue;
+    }
+    if (threadIdx.x == 0) {
+      if (!cand.undefined) for (int k = 0; k < 8; k++) cand.pc[k] = pc[k];
+      cand.accepted = promising ? 1 : 0;
+      c.cand[(long)b * kMaxClusters + ci] = cand;
+    }
+    __syncthreads();
+  }
+}
+
+// ------------------------------------------------------------------------------------------ B2b
+// one WAVE per min-area-rectangle cluster: interior prefilter, cv::convexHull, rotating calipers, rule filter
+constexpr int kRectBlock = 64;
+__global__ void MOT_LAUNCH_BOUNDS(kRectBlock)
+cluster_rect_kernel(MotDevParams p, ClusterBuffers c) {
+  // candidate points sorted by (x,y); dead after the interior filter, when the same storage becomes the four
+  // Sklansky stacks (kStackStride = kMaxHullIn + 2 shorts each)
+  __shared__ short s_arena[4 * kStackStride];
+  short* s_px = s_arena; short* s_py = s_arena + kStackStride;
+  __shared__ short s_qx[kMaxHullIn + 2], s_qy[kMaxHullIn + 2];  // ... after the interior filter
+  __shared__ short s_hull[kMaxHullIn + 2];
+  __shared__ float s_hx[kMaxHull], s_hy[kMaxHull], s_vx[kMaxHull], s_vy[kMaxHull], s_inv[kMaxHull];
+  __shared__ int s_ext[32 * 2];                // extreme point per direction
+  __shared__ int s_cnt[4];
+  short* s_stack = s_arena;
+  const int b = blockIdx.y;
+  const int num_cluster = min(c.counts[b * kCountsStride + kCntClusters], kMaxClusters);
+  const int lane = lane_id();
+  const int* pool = c.poly + (long)b * c.cap;
+  for (int ci = blockIdx.x; ci < num_cluster; ci += gridDim.x) {
+    BoxCandidate cand = c.cand[(long)b * kMaxClusters + ci];
+    if (cand.branch != 1 || cand.undefined) continue;  // L-shape clusters are complete already
+    const int offsetInitX = cand.off_x, offsetInitY = cand.off_y, numPoints = cand.num_points;
+    const float maxZ = cand.max_z;
+    int total = cand.poly_n;
+    if (cand.poly_off + total > c.cap) total = 0;
+    for (int j = lane; j < total; j += 64) { int v = pool[cand.poly_off + j]; s_px[j] = (short)(v & 0xffff); s_py[j] = (short)(v >> 16); }
+    MOT_WAVE_SYNC();
+    float pc[8];
+    bool promising = false;
+    {
+      {
       // ---- drop points strictly inside the polygon of 32 directional extremes (exact integer tests); what is
       //      left still contains every hull vertex, in (x,y) order
       if (total > 48) {
@@ -444,26 +494,36 @@ cluster_box_kernel(MotDevParams p, ClusterBuffers c) {
           if (lane == 0) { int w = 0xffff - (int)(key & 0xffff); s_ext[2 * d] = s_px[w]; s_ext[2 * d + 1] = s_py[w]; }
         }
         MOT_WAVE_SYNC();
+        // edge d of the polygon lives in lane d; the edge loop below is wave-uniform, so its operands are fetched
+        // with v_readlane (scalar) instead of LDS reads
+        const int e_ax = s_ext[2 * (lane & 31)], e_ay = s_ext[2 * (lane & 31) + 1];
+        const int e_bx = s_ext[2 * ((lane + 1) & 31)], e_by = s_ext[2 * ((lane + 1) & 31) + 1];
+        const unsigned long long real_edges = __ballot(lane < 32 && !(e_ax == e_bx && e_ay == e_by));
+        const int n_edges = __popcll(real_edges);
+#ifndef MOT_HIPEMU
+#define RLI(v, idx) ((int)__builtin_amdgcn_readlane((unsigned)(v), (idx)))
+#else
+#define RLI(v, idx) __shfl((v), (idx), 64)
+#endif
         int kept_total = 0;
         for (int j0 = 0; j0 < total; j0 += 64) {
           int j = j0 + lane;
-          bool keep = false;
-          if (j < total) {
-            int qx = s_px[j], qy = s_py[j];
-            bool inside = true; int edges = 0;
-            for (int d = 0; d < 32; d++) {
-              int ax = s_ext[2 * d], ay = s_ext[2 * d + 1], bx = s_ext[2 * ((d + 1) & 31)], by = s_ext[2 * ((d + 1) & 31) + 1];
-              if (ax == bx && ay == by) continue;
-              edges++;
-              int cr = (bx - ax) * (qy - ay) - (by - ay) * (qx - ax);
-              if (cr <= 0) { inside = false; break; }
-            }
-            keep = !(inside && edges >= 3);
+          const int qx = j < total ? s_px[j] : 0, qy = j < total ? s_py[j] : 0;
+          bool inside = true;
+          unsigned long long em = real_edges;
+          while (em) {  // wave-uniform loop over the non-degenerate edges
+            int d = __ffsll(em) - 1;
+            em &= em - 1ull;
+            int ax = RLI(e_ax, d), ay = RLI(e_ay, d), bx = RLI(e_bx, d), by = RLI(e_by, d);
+            int cr = (bx - ax) * (qy - ay) - (by - ay) * (qx - ax);
+            inside = inside && cr > 0;
           }
+          bool keep = j < total && !(inside && n_edges >= 3);
           unsigned long long km = __ballot(keep);
           if (keep) { int o = kept_total + __popcll(km & ((1ull << lane) - 1ull)); s_qx[o] = s_px[j]; s_qy[o] = s_py[j]; }
           kept_total += __popcll(km);
         }
+#undef RLI
         total = kept_total;
       } else {
         for (int j = lane; j < total; j += 64) { s_qx[j] = s_px[j]; s_qy[j] = s_py[j]; }
@@ -692,16 +752,14 @@ cluster_box_kernel(MotDevParams p, ClusterBuffers c) {
         pc[2 * i + 1] = rmY - p.roi_half;
       }
       promising = !cand.undefined && rule_based_filter(p, pc, maxZ, numPoints);
-      }  // wave 0
-#endif
-      __syncthreads();
+      }
     }
-    if (threadIdx.x == 0) {
+    if (lane == 0) {
       if (!cand.undefined) for (int k = 0; k < 8; k++) cand.pc[k] = pc[k];
       cand.accepted = promising ? 1 : 0;
       c.cand[(long)b * kMaxClusters + ci] = cand;
     }
-    __syncthreads();
+    MOT_WAVE_SYNC();
   }
 }
 
@@ -758,6 +816,7 @@ box_finalize_kernel(MotDevParams p, ClusterBuffers c) {
     if (nb > kMaxBoxesPerFrame) { atomicOr(&c.counts[b * kCountsStride + kCntFlags], (int)kFlagBoxOverflow); nb = kMaxBoxesPerFrame; }
     c.counts[b * kCountsStride + kCntBoxes] = nb;
     c.counts[b * kCountsStride + kCntUndef] = s_undef;
+    c.counts[b * kCountsStride + kCntPoly] = 0;  // re-arm the polygon pool
   }
 }
 
@@ -770,12 +829,14 @@ void mot_launch_box_kernel(int which, const MotDevParams& p, const ClusterBuffer
   int chunks = (max_n + kLabelChunk - 1) / kLabelChunk;
   if (chunks < 1) chunks = 1;
   if (which == 0) hipLaunchKernelGGL(label_stats_kernel, dim3(chunks, batch), dim3(kLabelBlock), 0, stream, p, c);
-  else if (which == 1) hipLaunchKernelGGL(cluster_box_kernel, dim3(48, batch), dim3(kBoxBlock), 0, stream, p, c);
+  else if (which == 1) hipLaunchKernelGGL(cluster_gather_kernel, dim3(48, batch), dim3(kBoxBlock), 0, stream, p, c);
+  else if (which == 3) hipLaunchKernelGGL(cluster_rect_kernel, dim3(96, batch), dim3(kRectBlock), 0, stream, p, c);
   else if (which == 2) hipLaunchKernelGGL(box_finalize_kernel, dim3(batch), dim3(kFinalBlock), 0, stream, p, c);
 }
 
 void mot_launch_box(const MotDevParams& p, const ClusterBuffers& c, int batch, int max_n, hipStream_t stream) {
   mot_launch_box_kernel(0, p, c, batch, max_n, stream);
   mot_launch_box_kernel(1, p, c, batch, max_n, stream);
+  mot_launch_box_kernel(3, p, c, batch, max_n, stream);
   mot_launch_box_kernel(2, p, c, batch, max_n, stream);
 }

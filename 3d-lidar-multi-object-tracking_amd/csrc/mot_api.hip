@@ -43,6 +43,7 @@ struct mot_ctx {
   float* d_boxes = nullptr;
   int* d_box_cluster = nullptr;
   unsigned long long* d_rng = nullptr;
+  int* d_poly = nullptr;
   // tracker stage
   DevTrack* d_tracks = nullptr;
   int* d_nt = nullptr;
@@ -166,7 +167,7 @@ static int make_dev_params(const mot_params& p, MotDevParams* d, std::string* er
 extern "C" void mot_destroy(mot_ctx* c) {
   if (!c) return;
   void* bufs[] = {c->d_in, c->d_n, c->d_minz, c->d_hg, c->d_desc, c->d_ticket, c->d_elev, c->d_ground, c->d_mask, c->d_counts,
-                  c->d_plane_a, c->d_plane_b, c->d_grid, c->d_label, c->d_stats, c->d_cand, c->d_boxes, c->d_box_cluster, c->d_rng,
+                  c->d_plane_a, c->d_plane_b, c->d_grid, c->d_label, c->d_stats, c->d_cand, c->d_boxes, c->d_box_cluster, c->d_rng, c->d_poly,
                   c->d_tracks, c->d_nt, c->d_tboxes, c->d_targs, c->d_gate, c->d_prog, c->d_live, c->d_tout, c->d_tflags, c->d_ego};
   for (void* b : bufs) if (b) (void)hipFree(b);
   if (c->h_counts) (void)hipHostFree(c->h_counts);
@@ -183,7 +184,7 @@ static ClusterBuffers cluster_buffers(mot_ctx* c) {
   ClusterBuffers b;
   b.elevated = c->d_elev; b.cap = c->cap; b.counts = c->d_counts; b.plane_a = c->d_plane_a; b.plane_b = c->d_plane_b;
   b.grid = c->d_grid; b.label = c->d_label; b.stats = c->d_stats; b.cand = c->d_cand; b.boxes = c->d_boxes;
-  b.box_cluster = c->d_box_cluster; b.rng = c->d_rng;
+  b.box_cluster = c->d_box_cluster; b.rng = c->d_rng; b.poly = c->d_poly;
   return b;
 }
 
@@ -217,6 +218,7 @@ static int create_impl(mot_ctx* c) {
   MOT_HIP(c, hipMalloc(&c->d_boxes, B * kMaxBoxesPerFrame * 24 * sizeof(float)));
   MOT_HIP(c, hipMalloc(&c->d_box_cluster, B * kMaxBoxesPerFrame * sizeof(int)));
   MOT_HIP(c, hipMalloc(&c->d_rng, kRngTable * sizeof(unsigned long long)));
+  MOT_HIP(c, hipMalloc(&c->d_poly, B * N * sizeof(int)));
   {  // mt19937_64 mt(0), box_fitting.cpp:303 — raw draws; the libstdc++ range mapping is applied on the device
     std::mt19937_64 mt(0);
     unsigned long long raw[kRngTable];
@@ -469,7 +471,7 @@ extern "C" int mot_ground_remove(mot_ctx* c, const float* xyzw, int n, float* el
 }
 
 // kernel ids used by mot_time_stage
-enum { kK1 = 10, kK2 = 11, kK3 = 12, kC1 = 20, kC2 = 21, kB1 = 30, kB2 = 31, kB3 = 32, kT1 = 40 };
+enum { kK1 = 10, kK2 = 11, kK3 = 12, kC1 = 20, kC2 = 21, kB1 = 30, kB2 = 31, kB3 = 32, kB2b = 33, kT1 = 40 };
 
 static int launch_one(mot_ctx* c, int id, int batch) {
   int rc;
@@ -486,6 +488,7 @@ static int launch_one(mot_ctx* c, int id, int batch) {
     case kB1: mot_launch_box_kernel(0, c->dp, cb, batch, max_n, c->stream); break;
     case kB2: mot_launch_box_kernel(1, c->dp, cb, batch, max_n, c->stream); break;
     case kB3: mot_launch_box_kernel(2, c->dp, cb, batch, max_n, c->stream); break;
+    case kB2b: mot_launch_box_kernel(3, c->dp, cb, batch, max_n, c->stream); break;
     case kT1: mot_launch_track(track_buffers(c, true), batch, c->stream); break;  // last frame's arguments again
     default: return fail(c, MOT_E_ARG, "unknown kernel id");
   }
@@ -500,13 +503,13 @@ static int launch_one(mot_ctx* c, int id, int batch) {
 extern "C" int mot_time_stage(mot_ctx* c, int stage, int batch, int iters, float* ms_per_iter) {
   if (!c || !ms_per_iter || iters < 1) return MOT_E_ARG;
   if (!c->last_in || batch != c->last_batch) return fail(c, MOT_E_STATE, "call mot_frames_dev with the same batch first");
-  struct Seq { int pre[3], timed[8], post[3]; };
-  Seq s = {{0, 0, 0}, {0, 0, 0, 0, 0, 0, 0, 0}, {0, 0, 0}};
+  struct Seq { int pre[3], timed[10], post[3]; };
+  Seq s = {{0, 0, 0}, {0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, {0, 0, 0}};
   switch (stage) {
     case 0: s = {{0}, {kK1, kK2, kK3}, {0}}; break;
     case 1: s = {{0}, {kC1, kC2}, {0}}; break;
-    case 2: s = {{0}, {kB1, kB2, kB3}, {0}}; break;
-    case 100: s = {{0}, {kK1, kK2, kK3, kC1, kC2, kB1, kB2, kB3}, {0}}; break;
+    case 2: s = {{0}, {kB1, kB2, kB2b, kB3}, {0}}; break;
+    case 100: s = {{0}, {kK1, kK2, kK3, kC1, kC2, kB1, kB2, kB2b, kB3}, {0}}; break;
     case kK1: s = {{0}, {kK1}, {kK2}}; break;
     case kK2: s = {{kK1}, {kK2}, {0}}; break;
     case kK3: s = {{0}, {kK3}, {0}}; break;
@@ -514,7 +517,8 @@ extern "C" int mot_time_stage(mot_ctx* c, int stage, int batch, int iters, float
     case kC2: s = {{kC1}, {kC2}, {0}}; break;
     case kB1: s = {{0}, {kB1}, {kB3}}; break;
     case kB2: s = {{kB1}, {kB2}, {kB3}}; break;
-    case kB3: s = {{kB1, kB2}, {kB3}, {0}}; break;
+    case kB2b: s = {{kB1, kB2}, {kB2b}, {kB3}}; break;
+    case kB3: s = {{kB1, kB2, kB2b}, {kB3}, {0}}; break;
     case kT1: s = {{0}, {kT1}, {0}}; break;
     default: return fail(c, MOT_E_ARG, "unknown stage");
   }
@@ -523,7 +527,7 @@ extern "C" int mot_time_stage(mot_ctx* c, int stage, int batch, int iters, float
   for (int it = 0; it < iters; it++) {
     for (int k = 0; k < 3 && s.pre[k]; k++) if ((rc = launch_one(c, s.pre[k], batch))) return rc;
     MOT_HIP(c, hipEventRecord(c->ev0, c->stream));
-    for (int k = 0; k < 8 && s.timed[k]; k++) if ((rc = launch_one(c, s.timed[k], batch))) return rc;
+    for (int k = 0; k < 10 && s.timed[k]; k++) if ((rc = launch_one(c, s.timed[k], batch))) return rc;
     MOT_HIP(c, hipEventRecord(c->ev1, c->stream));
     for (int k = 0; k < 3 && s.post[k]; k++) if ((rc = launch_one(c, s.post[k], batch))) return rc;
     MOT_HIP(c, hipEventSynchronize(c->ev1));

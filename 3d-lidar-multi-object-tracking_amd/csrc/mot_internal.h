@@ -73,7 +73,7 @@ constexpr int kMaxClusters = 4096;                 // per frame (MOT_E_CAPACITY 
 constexpr int kMaxBoxesPerFrame = 1024;
 constexpr int kRngTable = 128;                     // raw mt19937_64(0) outputs kept on the device
 constexpr int kCountsStride = 8;                   // ints per frame in `counts`
-enum { kCntElev = 0, kCntGround = 1, kCntDropped = 2, kCntClusters = 3, kCntBoxes = 4, kCntUndef = 5, kCntFlags = 6 };
+enum { kCntElev = 0, kCntGround = 1, kCntDropped = 2, kCntClusters = 3, kCntBoxes = 4, kCntUndef = 5, kCntFlags = 6, kCntPoly = 7 };
 enum { kFlagClusterOverflow = 1, kFlagBoxOverflow = 2, kFlagRngExhausted = 4, kFlagHullOverflow = 8 };
 
 struct ClusterStats {          // per cluster, accumulated by the label kernel, reset by the finalize kernel
@@ -84,10 +84,13 @@ struct ClusterStats {          // per cluster, accumulated by the label kernel, 
   unsigned long long argmin;   // (key(m) << 32) | idx        -> minimum = smallest slope, first occurrence
   unsigned long long argmax;   // (key(m) << 32) | ~idx       -> maximum = largest slope, first occurrence
 };
-struct BoxCandidate {          // per cluster, written by the box kernel
+struct BoxCandidate {          // per cluster, written by the box kernels
   float pc[8];                 // 4 corners (x,y)
   float max_z;
-  int accepted, undefined, branch;
+  int accepted, undefined, branch;   // branch: 0 L-shape (complete), 1 min-area rectangle (polygon pending / done)
+  int poly_off, poly_n;        // candidate hull points of the cluster in the frame's polygon pool
+  int off_x, off_y;            // offsetInitX / offsetInitY (box_fitting.cpp:224-225)
+  int num_points, pad;
 };
 
 struct ClusterBuffers {
@@ -103,6 +106,7 @@ struct ClusterBuffers {
   float* boxes;                // [B][kMaxBoxesPerFrame][24]
   int* box_cluster;            // [B][kMaxBoxesPerFrame]
   const unsigned long long* rng;  // [kRngTable]
+  int* poly;                   // [B][cap] candidate hull points (x | y << 16) of the min-area-rectangle clusters
 };
 
 void mot_launch_cluster(const MotDevParams& p, const ClusterBuffers& c, int batch, int max_n, hipStream_t stream);

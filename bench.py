@@ -164,8 +164,8 @@ def main():
         it = 20
         tr0 = ctx.get_tracks(0)
         kernels = {"polar_minz_kernel": 10, "polar_filter_kernel": 11, "classify_compact_kernel": 12,
-                   "cart_occupancy_kernel": 20, "ccl_kernel": 21, "label_stats_kernel": 30, "cluster_box_kernel": 31,
-                   "box_finalize_kernel": 32, "track_step_kernel": 40}
+                   "cart_occupancy_kernel": 20, "ccl_kernel": 21, "label_stats_kernel": 30, "cluster_gather_kernel": 31,
+                   "cluster_rect_kernel": 33, "box_finalize_kernel": 32, "track_step_kernel": 40}
         k_ms = {k: ctx.time_stage(v, B, it if v != 40 else 5) for k, v in kernels.items()}
         stage_ms = {"ground": ctx.time_stage(0, B, it), "cluster": ctx.time_stage(1, B, it), "box": ctx.time_stage(2, B, it),
                     "stateless": ctx.time_stage(100, B, it)}
@@ -180,7 +180,8 @@ def main():
                      "cart_occupancy_kernel": 16.0 * ne_tot,
                      "ccl_kernel": (2 * 2048 * 4 + 4.0 * G * G) * B,
                      "label_stats_kernel": (16.0 + 4.0) * ne_tot,
-                     "cluster_box_kernel": 4.0 * ne_tot,
+                     "cluster_gather_kernel": (4.0 + 16.0) * ne_tot,
+                     "cluster_rect_kernel": 4.0 * ne_tot / 8,
                      "box_finalize_kernel": 96.0 * B,
                      "track_step_kernel": (2 * 1624.0 + 144.0) * max(tr0["n"], 1) * B}
         dom = max(k_ms, key=lambda k: k_ms[k])
