@@ -104,6 +104,7 @@ def main():
 
     mot = _load("mot_amd", os.path.join(PKG_DIR, "__init__.py"))
     synth = _load("mot_amd.synth", os.path.join(PKG_DIR, "synth.py"))
+    multi = _load("mot_amd.multi", os.path.join(PKG_DIR, "multi.py"))
     build = _load("mot_amd.build", os.path.join(PKG_DIR, "build.py"))
     if not os.path.exists(build.LIB):
         build.build()
@@ -112,7 +113,7 @@ def main():
     stride = ((N + 2047) // 2048) * 2048
     # synthetic streams: 8 distinct scenes per rank tiled over the B slots, F consecutive frames of each
     n_scene = min(B, 8)
-    scenes = [[synth.make_cloud(N, 100 * rank + s, f) for f in range(F)] for s in range(n_scene)]
+    scenes = [[synth.make_cloud(N, multi.scene_of(rank, s, n_scene), f) for f in range(F)] for s in range(n_scene)]
     dev_frames = []
     for f in range(F):
         host = np.zeros((B, stride, 4), np.float32)
@@ -121,9 +122,7 @@ def main():
         dev_frames.append(torch.from_numpy(host).cuda())
     sizes = [N] * B
     ctx = mot.Context(device=local, max_points=stride, max_batch=B, max_tracks_total=8192)
-    gather_src = torch.zeros(B, GATHER_TRACKS, TRACK_RECORD_BYTES // 4, dtype=torch.int32, device="cuda")
-    gather_cnt = torch.zeros(B, dtype=torch.int32, device="cuda")
-    gather_dst = [torch.zeros_like(gather_src) for _ in range(world)] if world > 1 else None
+    gather = multi.TrackGather(B, GATHER_TRACKS, world, "cuda") if world > 1 else None
     torch.cuda.synchronize()
 
     step_no = [0]
@@ -136,9 +135,7 @@ def main():
         ctx.frames_dev(dev_frames[k % F].data_ptr(), stride * 4, sizes, run_tracker=True, timestamps=ts,
                        ego_v=[0.0] * B, ego_yaw=[0.0] * B)
         if world > 1:  # the per-step result block crosses GPUs over RCCL / xGMI
-            ctx.export_tracks_dev(B, gather_src.data_ptr(), GATHER_TRACKS, gather_cnt.data_ptr())
-            ctx.synchronize()
-            dist.all_gather(gather_dst, gather_src)
+            gather.step(ctx)
 
     for _ in range(args.warmup):
         step()

@@ -1,0 +1,136 @@
+// mot_adapters.hpp — the reference's own function signatures on top of the C-ABI (include/mot.h).
+//
+// Drop this header (and libmot_hip.so) into the reference's catkin package and the three node sources
+// (OT/src/groundremove/main.cpp, OT/src/cluster/main.cpp, OT/tracking/main.cpp) compile unchanged: the functions below
+// have exactly the signatures of OT/include/ground_removal.h:62-64, component_clustering.h:20-22, box_fitting.h:34-36 and
+// imm_ukf_jpda.h:15-22, and forward to the GPU library. Only PCL container types are used (header-only here: the
+// library itself never sees PCL/Eigen/ROS types).
+//
+// Differences a maintainer should know about (also in INTEGRATION.md):
+//   * one process-wide context is created lazily (mot_adapters::context()); tune it with mot_adapters::configure()
+//     before the first call. The reference's tracker state is file-scope globals; here it lives in the context
+//     (mot_reset() forgets it — the reference cannot).
+//   * errors raise std::runtime_error with mot_last_error() instead of assert()/abort().
+//   * boxFitting() does not fill the rviz CUBE markers (`ma`): visualisation is outside the hot path.
+#ifndef MOT_ADAPTERS_HPP_
+#define MOT_ADAPTERS_HPP_
+
+#include <array>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include <pcl/point_cloud.h>
+#include <pcl/point_types.h>
+
+#include "mot.h"
+
+namespace mot_adapters {
+
+struct Config {
+  int preset = MOT_PRESET_OBJECT_TRACKING;
+  int device = 0;
+  int max_points = 262144;
+  int max_tracks_total = 16384;
+};
+inline Config& config() { static Config c; return c; }
+inline void configure(const Config& c) { config() = c; }
+
+inline mot_ctx* context() {
+  static mot_ctx* ctx = nullptr;
+  if (!ctx) {
+    mot_params p;
+    if (mot_params_preset(config().preset, &p) != MOT_OK) throw std::runtime_error("mot_params_preset failed");
+    if (mot_create(&p, config().device, config().max_points, 1, config().max_tracks_total, &ctx) != MOT_OK)
+      throw std::runtime_error("mot_create failed (no MI355X / HIP device?) — this library has no CPU fallback");
+  }
+  return ctx;
+}
+inline void check(int rc) {
+  if (rc != MOT_OK) throw std::runtime_error(std::string("mot: ") + mot_last_error(context()));
+}
+inline std::vector<float> pack(const pcl::PointCloud<pcl::PointXYZ>& c) {
+  std::vector<float> v(c.size() * 4 + 4);
+  for (size_t i = 0; i < c.size(); i++) { v[4 * i] = c[i].x; v[4 * i + 1] = c[i].y; v[4 * i + 2] = c[i].z; v[4 * i + 3] = 0.f; }
+  return v;
+}
+}  // namespace mot_adapters
+
+// OT/include/ground_removal.h:62-64 — appends to elevatedCloud / groundCloud in input order, like the reference
+inline void groundRemove(pcl::PointCloud<pcl::PointXYZ>::Ptr cloud, pcl::PointCloud<pcl::PointXYZ>::Ptr elevatedCloud,
+                         pcl::PointCloud<pcl::PointXYZ>::Ptr groundCloud) {
+  using namespace mot_adapters;
+  const int n = (int)cloud->size();
+  std::vector<float> in = pack(*cloud), e((size_t)n * 4 + 4), g((size_t)n * 4 + 4);
+  int ne = 0, ng = 0;
+  check(mot_ground_remove(context(), in.data(), n, e.data(), &ne, g.data(), &ng, nullptr));
+  for (int i = 0; i < ne; i++) elevatedCloud->push_back(pcl::PointXYZ(e[4 * i], e[4 * i + 1], e[4 * i + 2]));
+  for (int i = 0; i < ng; i++) groundCloud->push_back(pcl::PointXYZ(g[4 * i], g[4 * i + 1], g[4 * i + 2]));
+}
+
+// OT/include/component_clustering.h:20-22 (numGrid = 250 in OT/, 200 in OT0/: template on the array size)
+template <size_t G>
+inline void componentClustering(pcl::PointCloud<pcl::PointXYZ>::Ptr elevatedCloud, std::array<std::array<int, G>, G>& cartesianData,
+                                int& numCluster) {
+  using namespace mot_adapters;
+  std::vector<float> in = pack(*elevatedCloud);
+  std::vector<int32_t> grid(G * G);
+  int nc = 0;
+  check(mot_cluster(context(), in.data(), (int)elevatedCloud->size(), grid.data(), &nc, nullptr));
+  for (size_t x = 0; x < G; x++) for (size_t y = 0; y < G; y++) cartesianData[x][y] = grid[x * G + y];
+  numCluster = nc;
+}
+
+// OT/include/box_fitting.h:34-36 (the MarkerArray argument is accepted and left untouched: any type)
+template <size_t G, typename MarkerArrayT>
+inline std::vector<pcl::PointCloud<pcl::PointXYZ>> boxFitting(pcl::PointCloud<pcl::PointXYZ>::Ptr elevatedCloud,
+                                                              std::array<std::array<int, G>, G> cartesianData, int numCluster,
+                                                              MarkerArrayT& /*ma*/) {
+  using namespace mot_adapters;
+  std::vector<float> in = pack(*elevatedCloud);
+  std::vector<int32_t> grid(G * G);
+  for (size_t x = 0; x < G; x++) for (size_t y = 0; y < G; y++) grid[x * G + y] = cartesianData[x][y];
+  std::vector<float> boxes(1024 * 24);
+  int nb = 0;
+  check(mot_box_fit(context(), in.data(), (int)elevatedCloud->size(), grid.data(), numCluster, boxes.data(), 1024, &nb, nullptr, nullptr));
+  std::vector<pcl::PointCloud<pcl::PointXYZ>> out(nb);
+  for (int b = 0; b < nb; b++)
+    for (int k = 0; k < 8; k++) out[b].push_back(pcl::PointXYZ(boxes[(b * 8 + k) * 3], boxes[(b * 8 + k) * 3 + 1], boxes[(b * 8 + k) * 3 + 2]));
+  return out;
+}
+
+// OT/include/imm_ukf_jpda.h:15
+inline void getOriginPoints(double timestamp, std::vector<std::vector<double>>& originPoints, double v_gps, double yaw_gps) {
+  using namespace mot_adapters;
+  double o[6];
+  check(mot_ego_update(context(), 0, timestamp, v_gps, yaw_gps, o));
+  originPoints = {{o[0], o[1], o[2]}, {o[3], o[4], o[5]}};
+}
+
+// OT/include/imm_ukf_jpda.h:19-22 — appends to the output containers exactly as the reference does
+inline void immUkfJpdaf(std::vector<pcl::PointCloud<pcl::PointXYZ>> bBoxes, double timestamp, pcl::PointCloud<pcl::PointXYZ>& targets,
+                        std::vector<std::vector<double>>& targetVandYaw, std::vector<int>& trackManage, std::vector<bool>& isStaticVec,
+                        std::vector<bool>& isVisVec, std::vector<pcl::PointCloud<pcl::PointXYZ>>& visBB) {
+  using namespace mot_adapters;
+  std::vector<float> boxes(bBoxes.size() * 24 + 24);
+  for (size_t b = 0; b < bBoxes.size(); b++)
+    for (int k = 0; k < 8; k++) { boxes[(b * 8 + k) * 3] = bBoxes[b][k].x; boxes[(b * 8 + k) * 3 + 1] = bBoxes[b][k].y; boxes[(b * 8 + k) * 3 + 2] = bBoxes[b][k].z; }
+  std::vector<mot_track> tr(config().max_tracks_total);
+  int nt = 0;
+  check(mot_track_step(context(), 0, boxes.data(), (int)bBoxes.size(), timestamp, tr.data(), (int)tr.size(), &nt));
+  for (int i = 0; i < nt; i++) {
+    targets.push_back(pcl::PointXYZ(tr[i].px, tr[i].py, tr[i].pz));
+    targetVandYaw.push_back({tr[i].v, tr[i].yaw});
+    isStaticVec.push_back(tr[i].is_static != 0);
+    isVisVec.push_back(tr[i].is_vis != 0);
+    if (tr[i].is_vis) {
+      pcl::PointCloud<pcl::PointXYZ> bb;
+      for (int k = 0; k < 8; k++) bb.push_back(pcl::PointXYZ(tr[i].vis_box[3 * k], tr[i].vis_box[3 * k + 1], tr[i].vis_box[3 * k + 2]));
+      visBB.push_back(bb);
+    }
+  }
+  trackManage.clear();
+  for (int i = 0; i < nt; i++) trackManage.push_back(tr[i].track_manage);
+}
+
+#endif  // MOT_ADAPTERS_HPP_

@@ -1,0 +1,81 @@
+"""N > 1 harness logic on CPU: 2 processes, gloo, 127.0.0.1. Each rank drives its own streams through the (emulated —
+see tests/emu/hipemu.h) kernels, exports its live-track block and all-gathers; every rank must end up with every
+rank's block, equal to what the oracle computes for those streams. Covers: stream sharding, export, the collective."""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, HERE)
+sys.path.insert(0, os.path.join(HERE, "emu"))
+
+
+def _worker(rank, world, port, lib, q):
+    try:
+        os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+        import torch.distributed as dist
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        from conftest import load_pkg, load_sub
+        import oracle_lib as O
+        mot = load_pkg(); synth = load_sub("synth"); multi = load_sub("multi")
+        B, N, stride, K = 2, 6000, 6144, 16
+        p = O.params(0)
+        ctx = mot.Context(lib_path=lib, max_points=stride, max_batch=B, max_tracks_total=256)
+        tg = multi.TrackGather(B, K, world, "cpu")
+        expect = {}
+        trackers = {(r, b): O.Tracker(p) for r in range(world) for b in range(B)}
+        for f in range(4):
+            host = np.zeros((B, stride, 4), np.float32)
+            for b in range(B):
+                host[b, :N] = synth.make_cloud(N, multi.scene_of(rank, b), f)
+            ts = [1.0e9 + f * 1e5] * B
+            ctx.frames_dev(host.ctypes.data, stride * 4, [N] * B, run_tracker=True, timestamps=ts, ego_v=[0.0] * B, ego_yaw=[0.0] * B)
+            tg.step(ctx)
+            # oracle for EVERY rank's streams (each rank checks the whole gathered result)
+            for r in range(world):
+                for b in range(B):
+                    c = synth.make_cloud(N, multi.scene_of(r, b), f)
+                    g = O.ground_remove(p, c); cl = O.cluster(p, g["elevated"])
+                    bx = O.box_fit(p, g["elevated"], cl["grid"], cl["num_cluster"])["boxes"]
+                    T = trackers[(r, b)]
+                    ego = T.ego_update(ts[b], 0.0, 0.0)
+                    co, si = np.cos(-ego[2]), np.sin(-ego[2])
+                    gb = bx.astype(np.float64).copy()
+                    dx, dy = gb[..., 0] - ego[0], gb[..., 1] - ego[1]
+                    gb[..., 0] = co * dx - si * dy; gb[..., 1] = si * dx + co * dy
+                    expect[(r, b)] = T.step(gb.astype(np.float32), ts[b])
+        blocks = tg.blocks_as_numpy()
+        assert len(blocks) == world
+        for r, (cnt, rec) in enumerate(blocks):
+            for b in range(B):
+                o = expect[(r, b)]
+                live = np.nonzero(o["track_manage"] > 0)[0][:K]
+                assert cnt[b] == len(live), (rank, r, b, cnt[b], len(live))
+                assert np.array_equal(rec[b]["id"][: cnt[b]], live)
+                assert np.array_equal(rec[b]["track_manage"][: cnt[b]], o["track_manage"][live])
+                assert np.allclose(rec[b]["p"][: cnt[b]], o["p"][live], rtol=1e-3, atol=1e-4)
+        dist.barrier()
+        dist.destroy_process_group()
+        q.put((rank, "ok"))
+    except Exception as e:  # pragma: no cover
+        import traceback
+        q.put((rank, "FAIL: " + traceback.format_exc()[-1500:]))
+
+
+def test_two_rank_stream_sharding_and_track_gather():
+    torch = pytest.importorskip("torch")
+    import torch.multiprocessing as mp
+    import build_emu
+    lib = build_emu.build()
+    ctxm = mp.get_context("spawn")
+    q = ctxm.Queue()
+    port = 29500 + os.getpid() % 500
+    procs = [ctxm.Process(target=_worker, args=(r, 2, port, lib, q)) for r in range(2)]
+    for pr in procs:
+        pr.start()
+    res = [q.get(timeout=600) for _ in procs]
+    for pr in procs:
+        pr.join(timeout=60)
+    assert all(r[1] == "ok" for r in res), res
