@@ -97,6 +97,8 @@ label_stats_kernel(MotDevParams p, ClusterBuffers c) {
     unsigned long long kmax = (m > -999.f) ? (((unsigned long long)ukey(m) << 32) | (unsigned)~(unsigned)i) : kArgmaxInit;
     int zkey = (q.z > -99.f) ? mot_float_key(q.z + 0.0f) : mot_float_key(-99.f);  // `pZ > maxZ`, maxZ = -99
     unsigned long long active = __ballot(lab > 0);
+    TileSummary* ts = c.tiles + (long)b * ((c.cap + 63) / 64) + (base + k * kLabelBlock + (threadIdx.x & ~63)) / 64;
+    int entry = 0;  // wave-uniform
     while (active) {  // one trip per distinct cluster among the 64 points of this wave
       int leader = __ffsll(active) - 1;
       int l = __shfl(lab, leader, 64);
@@ -112,14 +114,17 @@ label_stats_kernel(MotDevParams p, ClusterBuffers c) {
         atomicMax(&s->maxz_key, rz);
         if (rmin != kArgminInit) atomicMin(&s->argmin, rmin);
         if (rmax != kArgmaxInit) atomicMax(&s->argmax, rmax);
+        if (entry < 4) { ts->mask[entry] = mm; ts->label[entry] = l; }
       }
+      entry++;
       active &= ~mm;
     }
+    if (lane == 0 && base + k * kLabelBlock + (threadIdx.x & ~63) < n) ts->n = entry <= 4 ? entry : 5;
   }
 }
 
 // ------------------------------------------------------------------------------------------ B2
-constexpr int kBoxBlock = 512;       // one workgroup (8 waves) per cluster: the waves share the label walk
+constexpr int kBoxBlock = 256;       // one workgroup (4 waves) per cluster, threads over the frame's 64-point tiles
 constexpr int kBoxWaves = kBoxBlock / 64;
 constexpr int kPicCols = 1024;       // pixel columns 0..900
 constexpr int kMaxHullIn = 2 * 901;  // two extreme pixels per column
@@ -152,79 +157,63 @@ __device__ bool rule_based_filter(const MotDevParams& p, const float* pc, float 
   return false;
 }
 
-// Sklansky_<int> of OpenCV 3.2 convhull.cpp on points sorted by (x,y)
-__device__ int sklansky(const short* ax, const short* ay, int start, int end, short* stack, int nsign, int sign2) {
-  int incr = end > start ? 1 : -1;
-  int pprev = start, pcur = pprev + incr, pnext = pcur + incr;
-  int stacksize = 3;
-  if (start == end || (ax[start] == ax[end] && ay[start] == ay[end])) { stack[0] = (short)start; return 1; }
-  stack[0] = (short)pprev; stack[1] = (short)pcur; stack[2] = (short)pnext;
-  end += incr;
-  while (pnext != end) {
-    int cury = ay[pcur], nexty = ay[pnext];
-    int by = nexty - cury;
-    int sby = (by > 0) - (by < 0);
-    if (sby != nsign) {
-      int axx = ax[pcur] - ax[pprev];
-      int bx = ax[pnext] - ax[pcur];
-      int ayy = cury - ay[pprev];
-      int convexity = ayy * bx - axx * by;
-      int sc = (convexity > 0) - (convexity < 0);
-      if (sc == sign2 && (axx != 0 || ayy != 0)) {
-        pprev = pcur; pcur = pnext; pnext += incr;
-        stack[stacksize] = (short)pnext; stacksize++;
-      } else {
-        if (pprev == start) {
-          pcur = pnext; stack[1] = (short)pcur; pnext += incr; stack[2] = (short)pnext;
-        } else {
-          stack[stacksize - 2] = (short)pnext; pcur = pprev; pprev = stack[stacksize - 4]; stacksize--;
-        }
-      }
-    } else {
-      pnext += incr; stack[stacksize - 1] = (short)pnext;
-    }
+// 64 integer directions (32*cos, 32*sin rounded), counter-clockwise: the extreme point of a set in each of them is a
+// hull vertex, and a point strictly inside the polygon they span cannot be one
+__constant__ signed char kDirX[64] = {32, 32, 31, 31, 30, 28, 27, 25, 23, 20, 18, 15, 12, 9, 6, 3, 0, -3, -6, -9, -12, -15, -18, -20, -23, -25, -27, -28, -30, -31, -31, -32,
+                                      -32, -32, -31, -31, -30, -28, -27, -25, -23, -20, -18, -15, -12, -9, -6, -3, 0, 3, 6, 9, 12, 15, 18, 20, 23, 25, 27, 28, 30, 31, 31, 32};
+__constant__ signed char kDirY[64] = {0, 3, 6, 9, 12, 15, 18, 20, 23, 25, 27, 28, 30, 31, 31, 32, 32, 32, 31, 31, 30, 28, 27, 25, 23, 20, 18, 15, 12, 9, 6, 3,
+                                      0, -3, -6, -9, -12, -15, -18, -20, -23, -25, -27, -28, -30, -31, -31, -32, -32, -32, -31, -31, -30, -28, -27, -25, -23, -20, -18, -15, -12, -9, -6, -3};
+
+// lanes of tile t (points 64 t .. 64 t + 63) that belong to cluster `want`
+__device__ __forceinline__ unsigned long long tile_mask(const TileSummary* __restrict__ tiles, const int* __restrict__ label,
+                                                        int t, int n, int want) {
+  const TileSummary* ts = &tiles[t];
+  const int ne = ts->n;
+  if (ne <= 4) {
+    unsigned long long m = 0ull;
+    for (int e = 0; e < ne; e++) if (ts->label[e] == want) m = ts->mask[e];
+    return m;
   }
-  return --stacksize;
+  unsigned long long m = 0ull;  // more than four clusters meet in this tile: read the labels
+  for (int l = 0; l < 64; l++) { int i = t * 64 + l; if (i < n && label[i] == want) m |= 1ull << l; }
+  return m;
+}
+__device__ __forceinline__ int nth_set_bit(unsigned long long m, int k) {  // position of the k-th (0-based) set bit
+  for (int j = 0; j < k; j++) m &= m - 1ull;
+  return __ffsll(m) - 1;
 }
 
-// 32 integer directions (16*cos, 16*sin rounded), counter-clockwise: the extreme point of the set in each of them
-// is on the convex hull, and a point strictly inside the polygon they span cannot be a hull vertex
-__constant__ signed char kDirX[32] = {16, 16, 15, 13, 11, 9, 6, 3, 0, -3, -6, -9, -11, -13, -15, -16,
-                                                 -16, -16, -15, -13, -11, -9, -6, -3, 0, 3, 6, 9, 11, 13, 15, 16};
-__constant__ signed char kDirY[32] = {0, 3, 6, 9, 11, 13, 15, 16, 16, 16, 15, 13, 11, 9, 6, 3,
-                                                 0, -3, -6, -9, -11, -13, -15, -16, -16, -16, -15, -13, -11, -9, -6, -3};
-
+// ------------------------------------------------------------------------------------------ B2
+// one workgroup per cluster, threads over the frame's 64-point tiles (the label kernel left, per tile, which clusters
+// it touches and where): no walk over the points. L-shape branch completes here; the rectangle branch leaves the
+// cluster's candidate hull points (lowest / highest pixel of every pixel column) in the polygon pool.
 __global__ void MOT_LAUNCH_BOUNDS(kBoxBlock)
 cluster_gather_kernel(MotDevParams p, ClusterBuffers c) {
-  __shared__ __attribute__((aligned(16))) unsigned char s_raw[2 * kPicCols * sizeof(int)];  // column extents
-  __shared__ short s_px[kMaxHullIn + 2], s_py[kMaxHullIn + 2];  // candidate points, sorted by (x,y)
+  __shared__ int s_colmin[kPicCols], s_colmax[kPicCols];
+  __shared__ short s_px[kMaxHullIn + 2], s_py[kMaxHullIn + 2];
   __shared__ int s_rank[128], s_pidx[128];
-  __shared__ unsigned s_need[kNeedWords];      // L-shape: bit r set <=> the r-th point of the cluster is sampled
-  __shared__ int s_buf[kBoxWaves][64 * kScanDepth];  // per wave: indices of this cluster's points found in the current stretch
-  __shared__ int s_wcnt[kBoxWaves];
-  __shared__ int s_total;
-  int* s_colmin = (int*)s_raw;
-  int* s_colmax = s_colmin + kPicCols;
+  __shared__ int s_wsum[kBoxWaves];
+  __shared__ int s_flag;
   const int b = blockIdx.y;
   const int n = c.counts[b * kCountsStride + kCntElev];
   const int num_cluster = min(c.counts[b * kCountsStride + kCntClusters], kMaxClusters);
   const float4* __restrict__ pts = c.elevated + (long)b * c.cap;
   const int* __restrict__ label = c.label + (long)b * c.cap;
-  const int lane = lane_id(), wave = (int)(threadIdx.x >> 6);
-  // every wave walks its own slice of the frame's labels (slices are multiples of 64 points)
-  const int slice = ((n + kBoxWaves * 64 - 1) / (kBoxWaves * 64)) * 64;
-  const int s_begin = wave * slice, s_end = min(n, s_begin + slice);
+  const TileSummary* __restrict__ tiles = c.tiles + (long)b * ((c.cap + 63) / 64);
+  const int lane = lane_id(), wave = (int)(threadIdx.x >> 6), tid = (int)threadIdx.x;
+  const int ntiles = (n + 63) / 64;
 
   for (int ci = blockIdx.x; ci < num_cluster; ci += gridDim.x) {
     const ClusterStats st = c.stats[(long)b * kMaxClusters + ci];
     BoxCandidate cand;
     for (int k = 0; k < 8; k++) cand.pc[k] = 0.f;
     cand.max_z = 0.f; cand.accepted = 0; cand.undefined = 0; cand.branch = -1;
+    cand.poly_off = 0; cand.poly_n = 0; cand.off_x = 0; cand.off_y = 0; cand.num_points = st.count; cand.pad = 0;
     const int numPoints = st.count;
     bool have = numPoints > 0 && st.argmin != kArgminInit && st.argmax != kArgmaxInit;  // SURVEY.md H7 otherwise
     if (!have) {
       cand.undefined = 1;
-      if (threadIdx.x == 0) c.cand[(long)b * kMaxClusters + ci] = cand;
+      if (tid == 0) c.cand[(long)b * kMaxClusters + ci] = cand;
       continue;
     }
     const float4 first = pts[st.first];
@@ -244,14 +233,10 @@ cluster_gather_kernel(MotDevParams p, ClusterBuffers c) {
     const float slope = (maxMy - minMy) / (maxMx - minMx);
     bool lshape = slopeDist > (float)p.l_slope_dist && numPoints > p.l_num_points;  // :308
     if (p.lshape_side_cond) lshape = lshape && (maxMy > 8.f || maxMy < -5.f);
-    float pc[8];
-    bool promising = false;
 
     if (lshape) {  // ---------------------------------------------------------------- L-shape :310-356
       cand.branch = 0;
       const int nsamp = p.ram_points < 128 ? p.ram_points : 128;
-      for (int i = threadIdx.x; i < kNeedWords; i += kBoxBlock) s_need[i] = 0u;
-      __syncthreads();
       {
         // mt19937_64 mt(0); uniform_int_distribution<>(0, numPoints-1): libstdc++ >= 11 maps the 64-bit draw with
         // Lemire's multiply-shift + rejection (bits/uniform_int_dist.h _S_nd), SURVEY.md H17. A rejection (probability
@@ -259,18 +244,18 @@ cluster_gather_kernel(MotDevParams p, ClusterBuffers c) {
         // rejection is replayed sequentially.
         const unsigned long long range = (unsigned long long)numPoints;
         bool reject = false;
-        for (int i = threadIdx.x; i < nsamp; i += kBoxBlock) {
+        for (int i = tid; i < nsamp; i += kBoxBlock) {
           unsigned long long g = c.rng[i < kRngTable ? i : kRngTable - 1];
           unsigned long long low = g * range, high = __umul64hi(g, range);
           if (low < range && low < (0ull - range) % range) reject = true;
           s_rank[i] = (int)high;
           s_pidx[i] = -1;
         }
-        if (threadIdx.x == 0) s_total = 0;
+        if (tid == 0) s_flag = 0;
         __syncthreads();
-        if (reject) s_total = 1;
+        if (reject) s_flag = 1;
         __syncthreads();
-        if (s_total != 0 && threadIdx.x == 0) {
+        if (s_flag != 0 && tid == 0) {
           int t = 0;
           bool exhausted = false;
           for (int i = 0; i < nsamp; i++) {
@@ -288,51 +273,33 @@ cluster_gather_kernel(MotDevParams p, ClusterBuffers c) {
           if (exhausted) atomicOr(&c.counts[b * kCountsStride + kCntFlags], (int)kFlagRngExhausted);
         }
         __syncthreads();
-        for (int i = threadIdx.x; i < nsamp; i += kBoxBlock) {
-          int r = s_rank[i];
-          if (r < kNeedWords * 32) atomicOr(&s_need[r >> 5], 1u << (r & 31));
-        }
       }
-      __syncthreads();
-      // k-th point of the cluster in input order. Pass 1: every wave counts the cluster's points in its slice;
-      // pass 2: with the exclusive prefix of those counts as base rank, it walks the slice again with
-      // ballot/popcount ranks and records the sampled ones.
-      int mycount = 0;
-      for (int base0 = s_begin; base0 < s_end; base0 += 64 * kScanDepth) {
-        int lab[kScanDepth];
-#pragma unroll
-        for (int k = 0; k < kScanDepth; k++) { int i = base0 + k * 64 + lane; lab[k] = i < s_end ? label[i] : 0; }
-#pragma unroll
-        for (int k = 0; k < kScanDepth; k++) mycount += __popcll(__ballot(lab[k] == ci + 1));
-      }
-      if (lane == 0) s_wcnt[wave] = mycount;
-      __syncthreads();
+      // the k-th point of the cluster in input order: exclusive prefix of the per-tile counts gives every tile its
+      // first rank; a sampled rank is then a bit position inside one tile's mask
       int running = 0;
-      for (int w2 = 0; w2 < wave; w2++) running += s_wcnt[w2];
-      const int my_end = running + mycount;
-      bool wanted = false;  // does any sampled rank fall into this wave's range?
-      for (int j = lane; j < nsamp; j += 64) wanted |= s_rank[j] >= running && s_rank[j] < my_end;
-      wanted = __any(wanted);
-      for (int base0 = s_begin; wanted && base0 < s_end && running < my_end; base0 += 64 * kScanDepth) {
-        int lab[kScanDepth];  // kScanDepth independent loads in flight per lane: the walk is latency-bound otherwise
+      for (int t0 = 0; t0 < ntiles; t0 += kBoxBlock) {
+        const int t = t0 + tid;
+        unsigned long long m = t < ntiles ? tile_mask(tiles, label, t, n, ci + 1) : 0ull;
+        int cnt = __popcll(m), incl = cnt;
 #pragma unroll
-        for (int k = 0; k < kScanDepth; k++) { int i = base0 + k * 64 + lane; lab[k] = i < s_end ? label[i] : 0; }
-#pragma unroll
-        for (int k = 0; k < kScanDepth; k++) {
-          int i = base0 + k * 64 + lane;
-          bool mine = lab[k] == ci + 1;
-          unsigned long long mm = __ballot(mine);
-          if (mm == 0ull) continue;
-          if (mine) {
-            int r = running + __popcll(mm & ((1ull << lane) - 1ull));
-            bool need = r >= kNeedWords * 32 || ((s_need[r >> 5] >> (r & 31)) & 1u);
-            if (need) for (int j = 0; j < nsamp; j++) if (s_rank[j] == r) s_pidx[j] = i;
+        for (int d = 1; d < 64; d <<= 1) { int o = __shfl_up(incl, d, 64); if (lane >= d) incl += o; }
+        if (lane == 63) s_wsum[wave] = incl;
+        __syncthreads();
+        int base = running + incl - cnt;
+        for (int w2 = 0; w2 < wave; w2++) base += s_wsum[w2];
+        int round_total = 0;
+        for (int w2 = 0; w2 < kBoxWaves; w2++) round_total += s_wsum[w2];
+        if (cnt > 0)
+          for (int j = 0; j < nsamp; j++) {
+            int r = s_rank[j];
+            if (r >= base && r < base + cnt) s_pidx[j] = t * 64 + nth_set_bit(m, r - base);
           }
-          running += __popcll(mm);
-        }
+        running += round_total;
+        __syncthreads();
       }
-      __syncthreads();
       // farthest sampled point from the line through the two slope-extreme points; first maximum wins
+      float pc[8];
+      bool promising = false;
       unsigned long long best = 0ull;
       for (int j = lane; j < nsamp; j += 64) {
         int pi = s_pidx[j];
@@ -359,35 +326,28 @@ cluster_gather_kernel(MotDevParams p, ClusterBuffers c) {
         pc[4] = maxMx; pc[5] = maxMy; pc[6] = lastX; pc[7] = lastY;
         promising = rule_based_filter(p, pc, maxZ, numPoints);
       }
+      if (tid == 0) {
+        if (!cand.undefined) for (int k = 0; k < 8; k++) cand.pc[k] = pc[k];
+        cand.accepted = promising ? 1 : 0;
+        c.cand[(long)b * kMaxClusters + ci] = cand;
+      }
       __syncthreads();
-    } else {  // ------------------------------------------------------- minAreaRect :358-366
+    } else {  // ------------------------------------------------------- minAreaRect :358-366, part 1
       cand.branch = 1;
-      for (int i = threadIdx.x; i < kPicCols; i += kBoxBlock) { s_colmin[i] = 0x7fffffff; s_colmax[i] = -0x7fffffff - 1; }
+      for (int i = tid; i < kPicCols; i += kBoxBlock) { s_colmin[i] = 0x7fffffff; s_colmax[i] = -0x7fffffff - 1; }
       __syncthreads();
-      int* mybuf = s_buf[wave];
-#ifndef MOT_DBG_SKIP_WALK
-      for (int base0 = s_begin; base0 < s_end; base0 += 64 * kScanDepth) {
-        int lab[kScanDepth];
+      for (int t0 = 0; t0 < ntiles; t0 += kBoxBlock) {
+        const int t = t0 + tid;
+        unsigned long long m = t < ntiles ? tile_mask(tiles, label, t, n, ci + 1) : 0ull;
+        while (m) {  // up to four independent gathers per trip
+          int idx[4]; float4 q[4]; int cntq = 0;
 #pragma unroll
-        for (int k = 0; k < kScanDepth; k++) { int i = base0 + k * 64 + lane; lab[k] = i < s_end ? label[i] : 0; }
-        int found = 0;  // wave-uniform
+          for (int u = 0; u < 4; u++) if (m) { idx[u] = t * 64 + __ffsll(m) - 1; m &= m - 1ull; cntq = u + 1; } else idx[u] = -1;
 #pragma unroll
-        for (int k = 0; k < kScanDepth; k++) {
-          bool mine = lab[k] == ci + 1;
-          unsigned long long mm = __ballot(mine);
-          if (mine) mybuf[found + __popcll(mm & ((1ull << lane) - 1ull))] = base0 + k * 64 + lane;
-          found += __popcll(mm);
-        }
-        MOT_WAVE_SYNC();
-        // the points themselves: independent gathers, so many are in flight at once
-        for (int j0 = 0; j0 < found; j0 += 256) {
-          float4 q[4];
-#pragma unroll
-          for (int u = 0; u < 4; u++) { int j = j0 + u * 64 + lane; q[u] = j < found ? pts[mybuf[j]] : make_float4(0.f, 0.f, 0.f, 0.f); }
+          for (int u = 0; u < 4; u++) q[u] = idx[u] >= 0 ? pts[idx[u]] : make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
           for (int u = 0; u < 4; u++) {
-            int j = j0 + u * 64 + lane;
-            if (j < found) {
+            if (u < cntq) {
               float roiX = q[u].x + p.roi_half, roiY = q[u].y + p.roi_half;  // :244-254
               int x = (int)floorf(roiX * p.pic_scale), y = (int)floorf(roiY * p.pic_scale);
               int picX = x;
@@ -400,76 +360,72 @@ cluster_gather_kernel(MotDevParams p, ClusterBuffers c) {
             }
           }
         }
-        MOT_WAVE_SYNC();
       }
-#endif
       __syncthreads();
-#ifndef MOT_DBG_SKIP_HULL
-      if (wave == 0) {  // ---- from here on the cluster is one small polygon problem: wave 0 finishes it
-      // compact the column extents into (x,y)-sorted points: 16 columns per lane, prefix over lanes
-      int cnt = 0;
-      for (int k = 0; k < kPicCols / 64; k++) {
-        int col = lane * (kPicCols / 64) + k;
-        int lo = s_colmin[col], hi = s_colmax[col];
-        if (lo != 0x7fffffff) cnt += (hi != lo) ? 2 : 1;
-      }
-      int incl = cnt;
+      if (wave == 0) {
+        // compact the column extents into (x,y)-sorted points: 16 columns per lane, prefix over lanes
+        int cnt = 0;
+        for (int k = 0; k < kPicCols / 64; k++) {
+          int col = lane * (kPicCols / 64) + k;
+          int lo = s_colmin[col], hi = s_colmax[col];
+          if (lo != 0x7fffffff) cnt += (hi != lo) ? 2 : 1;
+        }
+        int incl = cnt;
 #pragma unroll
-      for (int d = 1; d < 64; d <<= 1) { int o = __shfl_up(incl, d, 64); if (lane >= d) incl += o; }
-      int pos = incl - cnt;
-      for (int k = 0; k < kPicCols / 64; k++) {
-        int col = lane * (kPicCols / 64) + k;
-        int lo = s_colmin[col], hi = s_colmax[col];
-        if (lo != 0x7fffffff) {
-          s_px[pos] = (short)(col + offsetInitX); s_py[pos] = (short)lo; pos++;
-          if (hi != lo) { s_px[pos] = (short)(col + offsetInitX); s_py[pos] = (short)hi; pos++; }
+        for (int d = 1; d < 64; d <<= 1) { int o = __shfl_up(incl, d, 64); if (lane >= d) incl += o; }
+        int pos = incl - cnt;
+        for (int k = 0; k < kPicCols / 64; k++) {
+          int col = lane * (kPicCols / 64) + k;
+          int lo = s_colmin[col], hi = s_colmax[col];
+          if (lo != 0x7fffffff) {
+            s_px[pos] = (short)(col + offsetInitX); s_py[pos] = (short)lo; pos++;
+            if (hi != lo) { s_px[pos] = (short)(col + offsetInitX); s_py[pos] = (short)hi; pos++; }
+          }
+        }
+        int total = __shfl(incl, 63, 64);
+        MOT_WAVE_SYNC();
+        int off = 0;
+        if (lane == 0) off = atomicAdd(&c.counts[b * kCountsStride + kCntPoly], total);
+        off = __shfl(off, 0, 64);
+        int* pool = c.poly + (long)b * c.cap;
+        for (int j = lane; j < total; j += 64) if (off + j < c.cap) pool[off + j] = ((int)(unsigned short)s_px[j]) | ((int)s_py[j] << 16);
+        if (lane == 0) {
+          cand.poly_off = off; cand.poly_n = total; cand.off_x = offsetInitX; cand.off_y = offsetInitY;
+          c.cand[(long)b * kMaxClusters + ci] = cand;
         }
       }
-      int total = __shfl(incl, 63, 64);
-      MOT_WAVE_SYNC();
-      // hand the candidates to the polygon kernel through the frame's pool
-      int off = 0;
-      if (lane == 0) off = atomicAdd(&c.counts[b * kCountsStride + kCntPoly], total);
-      off = __shfl(off, 0, 64);
-      int* pool = c.poly + (long)b * c.cap;
-      for (int j = lane; j < total; j += 64) if (off + j < c.cap) pool[off + j] = ((int)(unsigned short)s_px[j]) | ((int)s_py[j] << 16);
-      if (lane == 0) {
-        cand.poly_off = off; cand.poly_n = total; cand.off_x = offsetInitX; cand.off_y = offsetInitY; cand.num_points = numPoints;
-        c.cand[(long)b * kMaxClusters + ci] = cand;
-      }
-      }  // wave 0
-#endif
       __syncthreads();
-      continue;
     }
-    if (threadIdx.x == 0) {
-      if (!cand.undefined) for (int k = 0; k < 8; k++) cand.pc[k] = pc[k];
-      cand.accepted = promising ? 1 : 0;
-      c.cand[(long)b * kMaxClusters + ci] = cand;
-    }
-    __syncthreads();
   }
 }
 
 // ------------------------------------------------------------------------------------------ B2b
-// one WAVE per min-area-rectangle cluster: interior prefilter, cv::convexHull, rotating calipers, rule filter
+// one WAVE per rectangle cluster. cv::minAreaRect(points) = convexHull + rotatingCalipers (OpenCV 3.2), restated so
+// that the parallel steps give the sequential algorithm's exact result:
+//  * the hull of lattice points is unique: points strictly inside the polygon of 64 directional extremes are dropped;
+//    a survivor is a hull vertex iff all other survivors lie in an open half-plane through it (exact integer
+//    tournament + check, one lane per point); OpenCV's output order is [first point in (x,y) order, the vertices on
+//    the larger-y side by increasing (x,y), last point, the vertices on the smaller-y side by decreasing (x,y)]
+//    (tests/test_oracle_vs_ref.py::test_parallel_hull_construction checks this against the restated Sklansky scan);
+//  * caliper set-up is data parallel, the caliper walk (a dependent chain over the hull) runs on registers.
 constexpr int kRectBlock = 64;
 __global__ void MOT_LAUNCH_BOUNDS(kRectBlock)
 cluster_rect_kernel(MotDevParams p, ClusterBuffers c) {
-  // candidate points sorted by (x,y); dead after the interior filter, when the same storage becomes the four
-  // Sklansky stacks (kStackStride = kMaxHullIn + 2 shorts each)
-  __shared__ short s_arena[4 * kStackStride];
-  short* s_px = s_arena; short* s_py = s_arena + kStackStride;
+  __shared__ short s_px[kMaxHullIn + 2], s_py[kMaxHullIn + 2];  // candidate points, sorted by (x,y)
   __shared__ short s_qx[kMaxHullIn + 2], s_qy[kMaxHullIn + 2];  // ... after the interior filter
   __shared__ short s_hull[kMaxHullIn + 2];
   __shared__ float s_hx[kMaxHull], s_hy[kMaxHull], s_vx[kMaxHull], s_vy[kMaxHull], s_inv[kMaxHull];
-  __shared__ int s_ext[32 * 2];                // extreme point per direction
-  __shared__ int s_cnt[4];
-  short* s_stack = s_arena;
   const int b = blockIdx.y;
   const int num_cluster = min(c.counts[b * kCountsStride + kCntClusters], kMaxClusters);
   const int lane = lane_id();
   const int* pool = c.poly + (long)b * c.cap;
+#ifndef MOT_HIPEMU
+#define RLI(v, idx) ((int)__builtin_amdgcn_readlane((unsigned)(v), (idx)))
+#define RLF(v, idx) __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(v), (idx)))
+#else
+#define RLI(v, idx) __shfl((v), (idx), 64)
+#define RLF(v, idx) __shfl((v), (idx), 64)
+#endif
   for (int ci = blockIdx.x; ci < num_cluster; ci += gridDim.x) {
     BoxCandidate cand = c.cand[(long)b * kMaxClusters + ci];
     if (cand.branch != 1 || cand.undefined) continue;  // L-shape clusters are complete already
@@ -479,281 +435,268 @@ cluster_rect_kernel(MotDevParams p, ClusterBuffers c) {
     if (cand.poly_off + total > c.cap) total = 0;
     for (int j = lane; j < total; j += 64) { int v = pool[cand.poly_off + j]; s_px[j] = (short)(v & 0xffff); s_py[j] = (short)(v >> 16); }
     MOT_WAVE_SYNC();
+    // ---- interior prefilter
+    if (total > 24) {
+      unsigned best[64];
+#pragma unroll
+      for (int d = 0; d < 64; d++) best[d] = 0u;
+      for (int j = lane; j < total; j += 64) {
+        const int x = s_px[j], y = s_py[j];
+#pragma unroll
+        for (int d = 0; d < 64; d++) {  // key: dot product (biased), then the smaller index
+          unsigned key = ((unsigned)(kDirX[d] * x + kDirY[d] * y + 131072) << 11) | (unsigned)(2047 - j);
+          best[d] = key > best[d] ? key : best[d];
+        }
+      }
+      int ex = 0, ey = 0;  // lane d: extreme point of direction d
+#pragma unroll
+      for (int d = 0; d < 64; d++) {
+        unsigned k2 = wave_max_t<unsigned>(best[d]);
+        if (lane == d) { int w = 2047 - (int)(k2 & 2047u); ex = s_px[w]; ey = s_py[w]; }
+      }
+      // edge d: extreme d -> extreme d+1; a point is strictly inside iff it is strictly left of every real edge
+      const int nx = __shfl(ex, (lane + 1) & 63, 64), ny = __shfl(ey, (lane + 1) & 63, 64);
+      const int edx = nx - ex, edy = ny - ey, ec = edx * ey - edy * ex;
+      const unsigned long long real_edges = __ballot(!(edx == 0 && edy == 0));
+      const int n_edges = __popcll(real_edges);
+      int kept_total = 0;
+      for (int j0 = 0; j0 < total; j0 += 64) {
+        int j = j0 + lane;
+        const int qx = j < total ? s_px[j] : 0, qy = j < total ? s_py[j] : 0;
+        bool inside = true;
+        unsigned long long em = real_edges;
+        while (em) {  // wave-uniform
+          int d = __ffsll(em) - 1;
+          em &= em - 1ull;
+          int cr = RLI(edx, d) * qy - RLI(edy, d) * qx - RLI(ec, d);  // cross(edge, q - a)
+          inside = inside && cr > 0;
+        }
+        bool keep = j < total && !(inside && n_edges >= 3);
+        unsigned long long km = __ballot(keep);
+        if (keep) { int o = kept_total + __popcll(km & ((1ull << lane) - 1ull)); s_qx[o] = s_px[j]; s_qy[o] = s_py[j]; }
+        kept_total += __popcll(km);
+      }
+      total = kept_total;
+    } else {
+      for (int j = lane; j < total; j += 64) { s_qx[j] = s_px[j]; s_qy[j] = s_py[j]; }
+    }
+    MOT_WAVE_SYNC();
+    // ---- cv::convexHull: strict hull vertices, in OpenCV's output order
+    int hn = 0;
+    if (total == 1) { if (lane == 0) s_hull[0] = 0; hn = 1; }
+    else if (total >= 2) {
+      const int Fx = s_qx[0], Fy = s_qy[0], Lx = s_qx[total - 1], Ly = s_qy[total - 1];
+      const int ldx = Lx - Fx, ldy = Ly - Fy;
+      int n_up = 0;
+      // pass A: upper side (larger y) in increasing order; pass B: lower side in decreasing order
+      for (int pass = 0; pass < 2; pass++) {
+        if (pass == 1) { if (lane == 0) s_hull[1 + n_up] = (short)(total - 1); }
+        int emitted = 0;
+        for (int j0 = 0; j0 < total; j0 += 64) {
+          // pass 1 walks the tiles from the top so that ranks come out in decreasing index order
+          const int jj = j0 + lane;
+          const int j = pass == 0 ? jj : (total - 1 - jj);
+          bool is_vertex = false;
+          if (jj < total && j > 0 && j < total - 1) {
+            const int qx = s_qx[j], qy = s_qy[j];
+            const int side = ldx * (qy - Fy) - ldy * (qx - Fx);
+            if ((pass == 0 && side > 0) || (pass == 1 && side < 0)) {
+              // all other points in an open half-plane through q?  tournament for the most clockwise direction, then check
+              int vx = 0, vy = 0; bool havev = false, ok = true;
+              for (int pp = 0; pp < total; pp++) {
+                if (pp == j) continue;
+                int wx = s_qx[pp] - qx, wy = s_qy[pp] - qy;
+                if (!havev) { vx = wx; vy = wy; havev = true; }
+                else {
+                  int cr = vx * wy - vy * wx;
+                  if (cr < 0) { vx = wx; vy = wy; }
+                  else if (cr == 0 && (vx * wx + vy * wy) < 0) ok = false;
+                }
+              }
+              for (int pp = 0; ok && pp < total; pp++) {
+                if (pp == j) continue;
+                int wx = s_qx[pp] - qx, wy = s_qy[pp] - qy;
+                int cr = vx * wy - vy * wx;
+                if (cr < 0 || (cr == 0 && (vx * wx + vy * wy) < 0)) ok = false;
+              }
+              is_vertex = ok;
+            }
+          }
+          unsigned long long vm = __ballot(is_vertex);
+          if (is_vertex) {
+            int r = emitted + __popcll(vm & ((1ull << lane) - 1ull));
+            s_hull[(pass == 0 ? 1 : 2 + n_up) + r] = (short)j;
+          }
+          emitted += __popcll(vm);
+        }
+        if (pass == 0) n_up = emitted; else hn = 2 + n_up + emitted;
+      }
+      if (lane == 0) s_hull[0] = 0;
+    }
+    MOT_WAVE_SYNC();
+    const short* ax = s_qx; const short* ay = s_qy;
     float pc[8];
     bool promising = false;
-    {
-      {
-      // ---- drop points strictly inside the polygon of 32 directional extremes (exact integer tests); what is
-      //      left still contains every hull vertex, in (x,y) order
-      if (total > 48) {
-        for (int d = 0; d < 32; d++) {
-          int best = -0x7fffffff - 1, bi = 0;
-          for (int j = lane; j < total; j += 64) { int v = kDirX[d] * (int)s_px[j] + kDirY[d] * (int)s_py[j]; if (v > best) { best = v; bi = j; } }
-          long long key = ((long long)best << 32) | (unsigned)(0xffff - bi);
-          key = wave_max_t<long long>(key);
-          if (lane == 0) { int w = 0xffff - (int)(key & 0xffff); s_ext[2 * d] = s_px[w]; s_ext[2 * d + 1] = s_py[w]; }
+    float rect[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    float cx = 0, cy = 0, w = 0, h = 0, angle = 0;
+    if (hn > kMaxHull) {
+      if (lane == 0) atomicOr(&c.counts[b * kCountsStride + kCntFlags], (int)kFlagHullOverflow);
+      cand.undefined = 1;
+    } else {
+      for (int i = lane; i < hn; i += 64) { s_hx[i] = (float)ax[s_hull[i]]; s_hy[i] = (float)ay[s_hull[i]]; }
+      MOT_WAVE_SYNC();
+      if (hn > 2) {
+        // ---- rotatingCalipers(points, n, CALIPERS_MINAREARECT, out), OpenCV 3.2 rotcalipers.cpp
+        long long kl = 0x7fffffffffffffffll, kr = -0x7fffffffffffffffll - 1, kt = -0x7fffffffffffffffll - 1, kb = 0x7fffffffffffffffll;
+        for (int i = lane; i < hn; i += 64) {
+          int nx = (i + 1 < hn) ? i + 1 : 0;
+          float p0x = s_hx[i], p0y = s_hy[i], ptx = s_hx[nx], pty = s_hy[nx];
+          double dx = ptx - p0x, dy = pty - p0y;
+          s_vx[i] = (float)dx; s_vy[i] = (float)dy;
+          s_inv[i] = (float)(1. / sqrt(dx * dx + dy * dy));
+          // `if (pt0.x < left_x) left = i` etc.: strict compares => the FIRST vertex holding the extreme value
+          long long ix = (long long)(int)p0x, iy = (long long)(int)p0y;  // vertices are integers
+          long long a_ = (ix << 32) | (unsigned)i, b_ = (ix << 32) | (unsigned)(0xffff - i);
+          long long c_ = (iy << 32) | (unsigned)(0xffff - i), d_ = (iy << 32) | (unsigned)i;
+          kl = a_ < kl ? a_ : kl; kr = b_ > kr ? b_ : kr; kt = c_ > kt ? c_ : kt; kb = d_ < kb ? d_ : kb;
         }
+        kl = wave_min_t<long long>(kl); kr = wave_max_t<long long>(kr); kt = wave_max_t<long long>(kt); kb = wave_min_t<long long>(kb);
+        const int left = (int)(kl & 0xffff), right = 0xffff - (int)(kr & 0xffff), top = 0xffff - (int)(kt & 0xffff), bottom = (int)(kb & 0xffff);
         MOT_WAVE_SYNC();
-        // edge d of the polygon lives in lane d; the edge loop below is wave-uniform, so its operands are fetched
-        // with v_readlane (scalar) instead of LDS reads
-        const int e_ax = s_ext[2 * (lane & 31)], e_ay = s_ext[2 * (lane & 31) + 1];
-        const int e_bx = s_ext[2 * ((lane + 1) & 31)], e_by = s_ext[2 * ((lane + 1) & 31) + 1];
-        const unsigned long long real_edges = __ballot(lane < 32 && !(e_ax == e_bx && e_ay == e_by));
-        const int n_edges = __popcll(real_edges);
-#ifndef MOT_HIPEMU
-#define RLI(v, idx) ((int)__builtin_amdgcn_readlane((unsigned)(v), (idx)))
-#else
-#define RLI(v, idx) __shfl((v), (idx), 64)
-#endif
-        int kept_total = 0;
-        for (int j0 = 0; j0 < total; j0 += 64) {
-          int j = j0 + lane;
-          const int qx = j < total ? s_px[j] : 0, qy = j < total ? s_py[j] : 0;
-          bool inside = true;
-          unsigned long long em = real_edges;
-          while (em) {  // wave-uniform loop over the non-degenerate edges
-            int d = __ffsll(em) - 1;
-            em &= em - 1ull;
-            int ax = RLI(e_ax, d), ay = RLI(e_ay, d), bx = RLI(e_bx, d), by = RLI(e_by, d);
-            int cr = (bx - ax) * (qy - ay) - (by - ay) * (qx - ax);
-            inside = inside && cr > 0;
+        float orientation = 0;  // sign of the first non-zero cross product of consecutive edges
+        for (int i0 = 0; i0 < hn && orientation == 0; i0 += 64) {
+          int i = i0 + lane;
+          double convexity = 0;
+          if (i < hn) {
+            int pi = i == 0 ? hn - 1 : i - 1;
+            convexity = (double)s_vx[pi] * (double)s_vy[i] - (double)s_vy[pi] * (double)s_vx[i];
           }
-          bool keep = j < total && !(inside && n_edges >= 3);
-          unsigned long long km = __ballot(keep);
-          if (keep) { int o = kept_total + __popcll(km & ((1ull << lane) - 1ull)); s_qx[o] = s_px[j]; s_qy[o] = s_py[j]; }
-          kept_total += __popcll(km);
+          unsigned long long nz = __ballot(convexity != 0);
+          if (nz) { int f = __ffsll(nz) - 1; double cv = __shfl(convexity, f, 64); orientation = cv > 0 ? 1.f : -1.f; }
         }
-#undef RLI
-        total = kept_total;
-      } else {
-        for (int j = lane; j < total; j += 64) { s_qx[j] = s_px[j]; s_qy[j] = s_py[j]; }
-      }
-      MOT_WAVE_SYNC();
-      const short* ax = s_qx; const short* ay = s_qy;
-      // first index holding the minimum / maximum y (strict compares in cv::convexHull)
-      int miny_ind = 0, maxy_ind = 0;
-      {
-        long long kmin = 0x7fffffffffffffffll, kmax = -0x7fffffffffffffffll - 1;
-        for (int j = lane; j < total; j += 64) {
-          long long a = ((long long)ay[j] << 32) | (unsigned)j;            // min: smallest y, then smallest index
-          long long bq = ((long long)ay[j] << 32) | (unsigned)(0xffff - j);  // max: largest y, then smallest index
-          kmin = a < kmin ? a : kmin; kmax = bq > kmax ? bq : kmax;
-        }
-        kmin = wave_min_t<long long>(kmin); kmax = wave_max_t<long long>(kmax);
-        if (total > 0) { miny_ind = (int)(kmin & 0xffff); maxy_ind = 0xffff - (int)(kmax & 0xffff); }
-      }
-      // ---- cv::convexHull(points, hull, clockwise = true, returnPoints = true), OpenCV 3.2 convhull.cpp:
-      //      the four Sklansky scans are independent — lanes 0..3 run one each
-      bool degenerate = total > 0 && ax[0] == ax[total - 1] && ay[0] == ay[total - 1];
-      if (total > 0 && !degenerate && lane < 4) {
-        int start = (lane & 1) ? total - 1 : 0;
-        int end = lane < 2 ? maxy_ind : miny_ind;
-        int nsign = lane < 2 ? -1 : 1;
-        int sign2 = (lane == 0 || lane == 3) ? 1 : -1;
-        s_cnt[lane] = sklansky(ax, ay, start, end, s_stack + lane * kStackStride, nsign, sign2);
-      }
-      MOT_WAVE_SYNC();
-      // assemble the hull from the four stacks (OpenCV's order: top-left chain, top-right chain reversed, then the
-      // bottom chains with their roles swapped because clockwise == true); every lane copies a strided share
-      int hn = 0;
-      if (total > 0) {
-        if (degenerate) {
-          if (lane == 0) s_hull[0] = 0;
-          hn = 1;
-        } else {
-          const short* tl_stack = s_stack; const int tl_count = s_cnt[0];
-          const short* tr_stack = s_stack + kStackStride; const int tr_count = s_cnt[1];
-          const short* bl_stack = s_stack + 3 * kStackStride; int bl_count = s_cnt[3];
-          const short* br_stack = s_stack + 2 * kStackStride; int br_count = s_cnt[2];
-          int stop_idx = tr_count > 2 ? tr_stack[1] : tl_count > 2 ? tl_stack[tl_count - 2] : -1;
-          if (stop_idx >= 0) {
-            int check_idx = bl_count > 2 ? bl_stack[1] : bl_count + br_count > 2 ? br_stack[2 - bl_count] : -1;
-            if (check_idx == stop_idx || (check_idx >= 0 && ax[check_idx] == ax[stop_idx] && ay[check_idx] == ay[stop_idx])) {
-              bl_count = bl_count < 2 ? bl_count : 2;
-              br_count = br_count < 2 ? br_count : 2;
-            }
-          }
-          const int n0 = tl_count - 1, n1 = tr_count - 1, n2 = bl_count - 1, n3 = br_count - 1;
-          for (int i = lane; i < n0; i += 64) s_hull[i] = tl_stack[i];
-          for (int i = lane; i < n1; i += 64) s_hull[n0 + i] = tr_stack[tr_count - 1 - i];
-          for (int i = lane; i < n2; i += 64) s_hull[n0 + n1 + i] = bl_stack[i];
-          for (int i = lane; i < n3; i += 64) s_hull[n0 + n1 + n2 + i] = br_stack[br_count - 1 - i];
-          hn = n0 + n1 + n2 + n3;
-        }
-      }
-      MOT_WAVE_SYNC();
-      float rect[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-      float cx = 0, cy = 0, w = 0, h = 0, angle = 0;
-      if (hn > kMaxHull) {
-        if (lane == 0) atomicOr(&c.counts[b * kCountsStride + kCntFlags], (int)kFlagHullOverflow);
-        cand.undefined = 1;
-      } else {
-        for (int i = lane; i < hn; i += 64) { s_hx[i] = (float)ax[s_hull[i]]; s_hy[i] = (float)ay[s_hull[i]]; }
-        MOT_WAVE_SYNC();
-        if (hn > 2) {
-          // ---- rotatingCalipers(points, n, CALIPERS_MINAREARECT, out), OpenCV 3.2 rotcalipers.cpp.
-          // Set-up (edge vectors, 1/length, extreme vertices, orientation) is data parallel; the caliper walk
-          // itself is a dependent chain over the hull and runs with the hull held in registers (one vertex per
-          // lane, v_readlane instead of LDS round trips) whenever it has at most 64 vertices.
-          long long kl = 0x7fffffffffffffffll, kr = -0x7fffffffffffffffll - 1, kt = -0x7fffffffffffffffll - 1, kb = 0x7fffffffffffffffll;
-          for (int i = lane; i < hn; i += 64) {
-            int nx = (i + 1 < hn) ? i + 1 : 0;
-            float p0x = s_hx[i], p0y = s_hy[i], ptx = s_hx[nx], pty = s_hy[nx];
-            double dx = ptx - p0x, dy = pty - p0y;
-            s_vx[i] = (float)dx; s_vy[i] = (float)dy;
-            s_inv[i] = (float)(1. / sqrt(dx * dx + dy * dy));
-            // `if (pt0.x < left_x) left = i` etc.: strict compares => the FIRST vertex holding the extreme value
-            long long ix = (long long)(int)p0x, iy = (long long)(int)p0y;  // vertices are integers
-            long long a_ = (ix << 32) | (unsigned)i, b_ = (ix << 32) | (unsigned)(0xffff - i);
-            long long c_ = (iy << 32) | (unsigned)(0xffff - i), d_ = (iy << 32) | (unsigned)i;
-            kl = a_ < kl ? a_ : kl; kr = b_ > kr ? b_ : kr; kt = c_ > kt ? c_ : kt; kb = d_ < kb ? d_ : kb;
-          }
-          kl = wave_min_t<long long>(kl); kr = wave_max_t<long long>(kr); kt = wave_max_t<long long>(kt); kb = wave_min_t<long long>(kb);
-          const int left = (int)(kl & 0xffff), right = 0xffff - (int)(kr & 0xffff), top = 0xffff - (int)(kt & 0xffff), bottom = (int)(kb & 0xffff);
-          MOT_WAVE_SYNC();
-          // hull orientation: sign of the first non-zero cross product of consecutive edges
-          float orientation = 0;
-          for (int i0 = 0; i0 < hn && orientation == 0; i0 += 64) {
-            int i = i0 + lane;
-            double convexity = 0;
-            if (i < hn) {
-              int pi = i == 0 ? hn - 1 : i - 1;
-              convexity = (double)s_vx[pi] * (double)s_vy[i] - (double)s_vy[pi] * (double)s_vx[i];
-            }
-            unsigned long long nz = __ballot(convexity != 0);
-            if (nz) { int f = __ffsll(nz) - 1; double cv = __shfl(convexity, f, 64); orientation = cv > 0 ? 1.f : -1.f; }
-          }
-          if (orientation != 0) {  // OpenCV asserts otherwise
-            float minarea = 3.402823466e+38f;
-            int bi0 = 0, bi5 = 0; float b1 = 0, b2 = 0, b3 = 0, b4 = 0;
-            float base_a = orientation, base_b = 0;
-            int seq0 = bottom, seq1 = right, seq2 = top, seq3 = left;
-#ifndef MOT_HIPEMU
-#define RLF(v, idx) __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(v), (idx)))
-#else
-#define RLF(v, idx) __shfl((v), (idx), 64)
-#endif
-            if (hn <= 64) {
-              const float rhx = lane < hn ? s_hx[lane] : 0.f, rhy = lane < hn ? s_hy[lane] : 0.f;
-              const float rvx = lane < hn ? s_vx[lane] : 0.f, rvy = lane < hn ? s_vy[lane] : 0.f, rinv = lane < hn ? s_inv[lane] : 0.f;
-              for (int k = 0; k < hn; k++) {
-                float dp0 = +base_a * RLF(rvx, seq0) + base_b * RLF(rvy, seq0);
-                float dp1 = -base_b * RLF(rvx, seq1) + base_a * RLF(rvy, seq1);
-                float dp2 = -base_a * RLF(rvx, seq2) - base_b * RLF(rvy, seq2);
-                float dp3 = +base_b * RLF(rvx, seq3) - base_a * RLF(rvy, seq3);
-                float maxcos = dp0 * RLF(rinv, seq0);
-                int main_element = 0;
-                float cosalpha = dp1 * RLF(rinv, seq1);
-                if (cosalpha > maxcos) { main_element = 1; maxcos = cosalpha; }
-                cosalpha = dp2 * RLF(rinv, seq2);
-                if (cosalpha > maxcos) { main_element = 2; maxcos = cosalpha; }
-                cosalpha = dp3 * RLF(rinv, seq3);
-                if (cosalpha > maxcos) { main_element = 3; maxcos = cosalpha; }
-                int pindex = main_element == 0 ? seq0 : main_element == 1 ? seq1 : main_element == 2 ? seq2 : seq3;
-                float lead_x = RLF(rvx, pindex) * RLF(rinv, pindex);
-                float lead_y = RLF(rvy, pindex) * RLF(rinv, pindex);
-                switch (main_element) {
-                  case 0: base_a = lead_x; base_b = lead_y; seq0 = seq0 + 1 == hn ? 0 : seq0 + 1; break;
-                  case 1: base_a = lead_y; base_b = -lead_x; seq1 = seq1 + 1 == hn ? 0 : seq1 + 1; break;
-                  case 2: base_a = -lead_x; base_b = -lead_y; seq2 = seq2 + 1 == hn ? 0 : seq2 + 1; break;
-                  default: base_a = -lead_y; base_b = lead_x; seq3 = seq3 + 1 == hn ? 0 : seq3 + 1; break;
-                }
-                float dx = RLF(rhx, seq1) - RLF(rhx, seq3);
-                float dy = RLF(rhy, seq1) - RLF(rhy, seq3);
-                float width = dx * base_a + dy * base_b;
-                dx = RLF(rhx, seq2) - RLF(rhx, seq0);
-                dy = RLF(rhy, seq2) - RLF(rhy, seq0);
-                float height = -dx * base_b + dy * base_a;
-                float area = width * height;
-                if (area <= minarea) { minarea = area; bi0 = seq3; b1 = base_a; b2 = width; b3 = base_b; b4 = height; bi5 = seq0; }
+        if (orientation != 0) {  // OpenCV asserts otherwise
+          float minarea = 3.402823466e+38f;
+          int bi0 = 0, bi5 = 0; float b1 = 0, b2 = 0, b3 = 0, b4 = 0;
+          float base_a = orientation, base_b = 0;
+          int seq0 = bottom, seq1 = right, seq2 = top, seq3 = left;
+          if (hn <= 64) {
+            const float rhx = lane < hn ? s_hx[lane] : 0.f, rhy = lane < hn ? s_hy[lane] : 0.f;
+            const float rvx = lane < hn ? s_vx[lane] : 0.f, rvy = lane < hn ? s_vy[lane] : 0.f, rinv = lane < hn ? s_inv[lane] : 0.f;
+            for (int k = 0; k < hn; k++) {
+              float dp0 = +base_a * RLF(rvx, seq0) + base_b * RLF(rvy, seq0);
+              float dp1 = -base_b * RLF(rvx, seq1) + base_a * RLF(rvy, seq1);
+              float dp2 = -base_a * RLF(rvx, seq2) - base_b * RLF(rvy, seq2);
+              float dp3 = +base_b * RLF(rvx, seq3) - base_a * RLF(rvy, seq3);
+              float maxcos = dp0 * RLF(rinv, seq0);
+              int main_element = 0;
+              float cosalpha = dp1 * RLF(rinv, seq1);
+              if (cosalpha > maxcos) { main_element = 1; maxcos = cosalpha; }
+              cosalpha = dp2 * RLF(rinv, seq2);
+              if (cosalpha > maxcos) { main_element = 2; maxcos = cosalpha; }
+              cosalpha = dp3 * RLF(rinv, seq3);
+              if (cosalpha > maxcos) { main_element = 3; maxcos = cosalpha; }
+              int pindex = main_element == 0 ? seq0 : main_element == 1 ? seq1 : main_element == 2 ? seq2 : seq3;
+              float lead_x = RLF(rvx, pindex) * RLF(rinv, pindex);
+              float lead_y = RLF(rvy, pindex) * RLF(rinv, pindex);
+              switch (main_element) {
+                case 0: base_a = lead_x; base_b = lead_y; seq0 = seq0 + 1 == hn ? 0 : seq0 + 1; break;
+                case 1: base_a = lead_y; base_b = -lead_x; seq1 = seq1 + 1 == hn ? 0 : seq1 + 1; break;
+                case 2: base_a = -lead_x; base_b = -lead_y; seq2 = seq2 + 1 == hn ? 0 : seq2 + 1; break;
+                default: base_a = -lead_y; base_b = lead_x; seq3 = seq3 + 1 == hn ? 0 : seq3 + 1; break;
               }
-            } else {
-              for (int k = 0; k < hn; k++) {
-                float dp0 = +base_a * s_vx[seq0] + base_b * s_vy[seq0];
-                float dp1 = -base_b * s_vx[seq1] + base_a * s_vy[seq1];
-                float dp2 = -base_a * s_vx[seq2] - base_b * s_vy[seq2];
-                float dp3 = +base_b * s_vx[seq3] - base_a * s_vy[seq3];
-                float maxcos = dp0 * s_inv[seq0];
-                int main_element = 0;
-                float cosalpha = dp1 * s_inv[seq1];
-                if (cosalpha > maxcos) { main_element = 1; maxcos = cosalpha; }
-                cosalpha = dp2 * s_inv[seq2];
-                if (cosalpha > maxcos) { main_element = 2; maxcos = cosalpha; }
-                cosalpha = dp3 * s_inv[seq3];
-                if (cosalpha > maxcos) { main_element = 3; maxcos = cosalpha; }
-                int pindex = main_element == 0 ? seq0 : main_element == 1 ? seq1 : main_element == 2 ? seq2 : seq3;
-                float lead_x = s_vx[pindex] * s_inv[pindex];
-                float lead_y = s_vy[pindex] * s_inv[pindex];
-                switch (main_element) {
-                  case 0: base_a = lead_x; base_b = lead_y; seq0 = seq0 + 1 == hn ? 0 : seq0 + 1; break;
-                  case 1: base_a = lead_y; base_b = -lead_x; seq1 = seq1 + 1 == hn ? 0 : seq1 + 1; break;
-                  case 2: base_a = -lead_x; base_b = -lead_y; seq2 = seq2 + 1 == hn ? 0 : seq2 + 1; break;
-                  default: base_a = -lead_y; base_b = lead_x; seq3 = seq3 + 1 == hn ? 0 : seq3 + 1; break;
-                }
-                float dx = s_hx[seq1] - s_hx[seq3];
-                float dy = s_hy[seq1] - s_hy[seq3];
-                float width = dx * base_a + dy * base_b;
-                dx = s_hx[seq2] - s_hx[seq0];
-                dy = s_hy[seq2] - s_hy[seq0];
-                float height = -dx * base_b + dy * base_a;
-                float area = width * height;
-                if (area <= minarea) { minarea = area; bi0 = seq3; b1 = base_a; b2 = width; b3 = base_b; b4 = height; bi5 = seq0; }
-              }
+              float dx = RLF(rhx, seq1) - RLF(rhx, seq3);
+              float dy = RLF(rhy, seq1) - RLF(rhy, seq3);
+              float width = dx * base_a + dy * base_b;
+              dx = RLF(rhx, seq2) - RLF(rhx, seq0);
+              dy = RLF(rhy, seq2) - RLF(rhy, seq0);
+              float height = -dx * base_b + dy * base_a;
+              float area = width * height;
+              if (area <= minarea) { minarea = area; bi0 = seq3; b1 = base_a; b2 = width; b3 = base_b; b4 = height; bi5 = seq0; }
             }
-#undef RLF
-            float A1 = b1, B1 = b3, A2 = -b3, B2 = b1;
-            float C1 = A1 * s_hx[bi0] + s_hy[bi0] * B1;
-            float C2 = A2 * s_hx[bi5] + s_hy[bi5] * B2;
-            float idet = 1.f / (A1 * B2 - A2 * B1);
-            float qx = (C1 * B2 - C2 * B1) * idet;
-            float qy = (A1 * C2 - A2 * C1) * idet;
-            float o2 = A1 * b2, o3 = B1 * b2, o4 = A2 * b4, o5 = B2 * b4;
-            // cv::minAreaRect
-            cx = qx + (o2 + o4) * 0.5f;
-            cy = qy + (o3 + o5) * 0.5f;
-            w = (float)sqrt((double)o2 * o2 + (double)o3 * o3);
-            h = (float)sqrt((double)o4 * o4 + (double)o5 * o5);
-            angle = (float)atan2((double)o3, (double)o2);
+          } else {
+            for (int k = 0; k < hn; k++) {
+              float dp0 = +base_a * s_vx[seq0] + base_b * s_vy[seq0];
+              float dp1 = -base_b * s_vx[seq1] + base_a * s_vy[seq1];
+              float dp2 = -base_a * s_vx[seq2] - base_b * s_vy[seq2];
+              float dp3 = +base_b * s_vx[seq3] - base_a * s_vy[seq3];
+              float maxcos = dp0 * s_inv[seq0];
+              int main_element = 0;
+              float cosalpha = dp1 * s_inv[seq1];
+              if (cosalpha > maxcos) { main_element = 1; maxcos = cosalpha; }
+              cosalpha = dp2 * s_inv[seq2];
+              if (cosalpha > maxcos) { main_element = 2; maxcos = cosalpha; }
+              cosalpha = dp3 * s_inv[seq3];
+              if (cosalpha > maxcos) { main_element = 3; maxcos = cosalpha; }
+              int pindex = main_element == 0 ? seq0 : main_element == 1 ? seq1 : main_element == 2 ? seq2 : seq3;
+              float lead_x = s_vx[pindex] * s_inv[pindex];
+              float lead_y = s_vy[pindex] * s_inv[pindex];
+              switch (main_element) {
+                case 0: base_a = lead_x; base_b = lead_y; seq0 = seq0 + 1 == hn ? 0 : seq0 + 1; break;
+                case 1: base_a = lead_y; base_b = -lead_x; seq1 = seq1 + 1 == hn ? 0 : seq1 + 1; break;
+                case 2: base_a = -lead_x; base_b = -lead_y; seq2 = seq2 + 1 == hn ? 0 : seq2 + 1; break;
+                default: base_a = -lead_y; base_b = lead_x; seq3 = seq3 + 1 == hn ? 0 : seq3 + 1; break;
+              }
+              float dx = s_hx[seq1] - s_hx[seq3];
+              float dy = s_hy[seq1] - s_hy[seq3];
+              float width = dx * base_a + dy * base_b;
+              dx = s_hx[seq2] - s_hx[seq0];
+              dy = s_hy[seq2] - s_hy[seq0];
+              float height = -dx * base_b + dy * base_a;
+              float area = width * height;
+              if (area <= minarea) { minarea = area; bi0 = seq3; b1 = base_a; b2 = width; b3 = base_b; b4 = height; bi5 = seq0; }
+            }
           }
-        } else if (hn == 2) {
-          cx = (s_hx[0] + s_hx[1]) * 0.5f;
-          cy = (s_hy[0] + s_hy[1]) * 0.5f;
-          double dx = s_hx[1] - s_hx[0], dy = s_hy[1] - s_hy[0];
-          w = (float)sqrt(dx * dx + dy * dy);
-          h = 0;
-          angle = (float)atan2(dy, dx);
-        } else if (hn == 1) {
-          cx = s_hx[0]; cy = s_hy[0];
+          float A1 = b1, B1 = b3, A2 = -b3, B2 = b1;
+          float C1 = A1 * s_hx[bi0] + s_hy[bi0] * B1;
+          float C2 = A2 * s_hx[bi5] + s_hy[bi5] * B2;
+          float idet = 1.f / (A1 * B2 - A2 * B1);
+          float qx = (C1 * B2 - C2 * B1) * idet;
+          float qy = (A1 * C2 - A2 * C1) * idet;
+          float o2 = A1 * b2, o3 = B1 * b2, o4 = A2 * b4, o5 = B2 * b4;
+          // cv::minAreaRect
+          cx = qx + (o2 + o4) * 0.5f;
+          cy = qy + (o3 + o5) * 0.5f;
+          w = (float)sqrt((double)o2 * o2 + (double)o3 * o3);
+          h = (float)sqrt((double)o4 * o4 + (double)o5 * o5);
+          angle = (float)atan2((double)o3, (double)o2);
         }
-        angle = (float)(angle * 180 / 3.1415926535897932384626433832795);
-        // RotatedRect::points
-        double _angle = angle * 3.1415926535897932384626433832795 / 180.;
-        float bb = (float)cos(_angle) * 0.5f;
-        float aa = (float)sin(_angle) * 0.5f;
-        rect[0] = cx - aa * h - bb * w;
-        rect[1] = cy + bb * h - aa * w;
-        rect[2] = cx + aa * h - bb * w;
-        rect[3] = cy - bb * h - aa * w;
-        rect[4] = 2 * cx - rect[0];
-        rect[5] = 2 * cy - rect[1];
-        rect[6] = 2 * cx - rect[2];
-        rect[7] = 2 * cy - rect[3];
+      } else if (hn == 2) {
+        cx = (s_hx[0] + s_hx[1]) * 0.5f;
+        cy = (s_hy[0] + s_hy[1]) * 0.5f;
+        double dx = s_hx[1] - s_hx[0], dy = s_hy[1] - s_hy[0];
+        w = (float)sqrt(dx * dx + dy * dy);
+        h = 0;
+        angle = (float)atan2(dy, dx);
+      } else if (hn == 1) {
+        cx = s_hx[0]; cy = s_hy[0];
       }
-      // getPointsInPcFrame :75-95
-      for (int i = 0; i < 4; i++) {
-        float picX = rect[2 * i], picY = rect[2 * i + 1];
-        float rOffsetX = picX - (float)offsetInitX;
-        float rOffsetY = picY - (float)offsetInitY;
-        float rX = rOffsetX;
-        float rY = p.pic_full - rOffsetY;
-        float rmX = rX / p.pic_scale;
-        float rmY = rY / p.pic_scale;
-        pc[2 * i] = rmX - p.roi_half;
-        pc[2 * i + 1] = rmY - p.roi_half;
-      }
-      promising = !cand.undefined && rule_based_filter(p, pc, maxZ, numPoints);
-      }
+      angle = (float)(angle * 180 / 3.1415926535897932384626433832795);
+      // RotatedRect::points
+      double _angle = angle * 3.1415926535897932384626433832795 / 180.;
+      float bb = (float)cos(_angle) * 0.5f;
+      float aa = (float)sin(_angle) * 0.5f;
+      rect[0] = cx - aa * h - bb * w;
+      rect[1] = cy + bb * h - aa * w;
+      rect[2] = cx + aa * h - bb * w;
+      rect[3] = cy - bb * h - aa * w;
+      rect[4] = 2 * cx - rect[0];
+      rect[5] = 2 * cy - rect[1];
+      rect[6] = 2 * cx - rect[2];
+      rect[7] = 2 * cy - rect[3];
     }
+    // getPointsInPcFrame :75-95
+    for (int i = 0; i < 4; i++) {
+      float picX = rect[2 * i], picY = rect[2 * i + 1];
+      float rOffsetX = picX - (float)offsetInitX;
+      float rOffsetY = picY - (float)offsetInitY;
+      float rX = rOffsetX;
+      float rY = p.pic_full - rOffsetY;
+      float rmX = rX / p.pic_scale;
+      float rmY = rY / p.pic_scale;
+      pc[2 * i] = rmX - p.roi_half;
+      pc[2 * i + 1] = rmY - p.roi_half;
+    }
+    promising = !cand.undefined && rule_based_filter(p, pc, maxZ, numPoints);
     if (lane == 0) {
       if (!cand.undefined) for (int k = 0; k < 8; k++) cand.pc[k] = pc[k];
       cand.accepted = promising ? 1 : 0;
@@ -761,6 +704,8 @@ cluster_rect_kernel(MotDevParams p, ClusterBuffers c) {
     }
     MOT_WAVE_SYNC();
   }
+#undef RLI
+#undef RLF
 }
 
 // ------------------------------------------------------------------------------------------ B3

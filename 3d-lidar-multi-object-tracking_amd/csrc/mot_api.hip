@@ -44,6 +44,7 @@ struct mot_ctx {
   int* d_box_cluster = nullptr;
   unsigned long long* d_rng = nullptr;
   int* d_poly = nullptr;
+  TileSummary* d_tiles = nullptr;
   // tracker stage
   DevTrack* d_tracks = nullptr;
   int* d_nt = nullptr;
@@ -167,7 +168,7 @@ static int make_dev_params(const mot_params& p, MotDevParams* d, std::string* er
 extern "C" void mot_destroy(mot_ctx* c) {
   if (!c) return;
   void* bufs[] = {c->d_in, c->d_n, c->d_minz, c->d_hg, c->d_desc, c->d_ticket, c->d_elev, c->d_ground, c->d_mask, c->d_counts,
-                  c->d_plane_a, c->d_plane_b, c->d_grid, c->d_label, c->d_stats, c->d_cand, c->d_boxes, c->d_box_cluster, c->d_rng, c->d_poly,
+                  c->d_plane_a, c->d_plane_b, c->d_grid, c->d_label, c->d_stats, c->d_cand, c->d_boxes, c->d_box_cluster, c->d_rng, c->d_poly, c->d_tiles,
                   c->d_tracks, c->d_nt, c->d_tboxes, c->d_targs, c->d_gate, c->d_prog, c->d_live, c->d_tout, c->d_tflags, c->d_ego};
   for (void* b : bufs) if (b) (void)hipFree(b);
   if (c->h_counts) (void)hipHostFree(c->h_counts);
@@ -184,7 +185,7 @@ static ClusterBuffers cluster_buffers(mot_ctx* c) {
   ClusterBuffers b;
   b.elevated = c->d_elev; b.cap = c->cap; b.counts = c->d_counts; b.plane_a = c->d_plane_a; b.plane_b = c->d_plane_b;
   b.grid = c->d_grid; b.label = c->d_label; b.stats = c->d_stats; b.cand = c->d_cand; b.boxes = c->d_boxes;
-  b.box_cluster = c->d_box_cluster; b.rng = c->d_rng; b.poly = c->d_poly;
+  b.box_cluster = c->d_box_cluster; b.rng = c->d_rng; b.poly = c->d_poly; b.tiles = c->d_tiles;
   return b;
 }
 
@@ -219,6 +220,7 @@ static int create_impl(mot_ctx* c) {
   MOT_HIP(c, hipMalloc(&c->d_box_cluster, B * kMaxBoxesPerFrame * sizeof(int)));
   MOT_HIP(c, hipMalloc(&c->d_rng, kRngTable * sizeof(unsigned long long)));
   MOT_HIP(c, hipMalloc(&c->d_poly, B * N * sizeof(int)));
+  MOT_HIP(c, hipMalloc(&c->d_tiles, B * ((N + 63) / 64) * sizeof(TileSummary)));
   {  // mt19937_64 mt(0), box_fitting.cpp:303 — raw draws; the libstdc++ range mapping is applied on the device
     std::mt19937_64 mt(0);
     unsigned long long raw[kRngTable];

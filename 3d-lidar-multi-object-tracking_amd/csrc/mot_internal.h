@@ -84,6 +84,12 @@ struct ClusterStats {          // per cluster, accumulated by the label kernel, 
   unsigned long long argmin;   // (key(m) << 32) | idx        -> minimum = smallest slope, first occurrence
   unsigned long long argmax;   // (key(m) << 32) | ~idx       -> maximum = largest slope, first occurrence
 };
+struct TileSummary {           // which clusters the 64 points [64 t, 64 t + 64) of a frame belong to (label kernel)
+  unsigned long long mask[4];  // lanes of the tile holding label[k]
+  int label[4];
+  int n;                       // entries used; 5 = more than 4 distinct clusters in the tile (consumers read `label[]`)
+  int pad[3];
+};
 struct BoxCandidate {          // per cluster, written by the box kernels
   float pc[8];                 // 4 corners (x,y)
   float max_z;
@@ -107,6 +113,7 @@ struct ClusterBuffers {
   int* box_cluster;            // [B][kMaxBoxesPerFrame]
   const unsigned long long* rng;  // [kRngTable]
   int* poly;                   // [B][cap] candidate hull points (x | y << 16) of the min-area-rectangle clusters
+  TileSummary* tiles;          // [B][cap / 64]
 };
 
 void mot_launch_cluster(const MotDevParams& p, const ClusterBuffers& c, int batch, int max_n, hipStream_t stream);

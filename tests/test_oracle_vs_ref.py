@@ -170,26 +170,26 @@ def test_hull_column_reduction(oracle):
 
 
 def test_hull_interior_prefilter(oracle):
-    """the device path also drops candidates strictly inside the polygon of the 32 directional extremes before the
+    """the device path also drops candidates strictly inside the polygon of the 64 directional extremes before the
     (sequential) Sklansky scans; the restated OpenCV hull / rectangle must not notice"""
-    dirx = np.array([16, 16, 15, 13, 11, 9, 6, 3, 0, -3, -6, -9, -11, -13, -15, -16, -16, -16, -15, -13, -11, -9, -6, -3, 0, 3, 6, 9, 11, 13, 15, 16])
-    diry = np.array([0, 3, 6, 9, 11, 13, 15, 16, 16, 16, 15, 13, 11, 9, 6, 3, 0, -3, -6, -9, -11, -13, -15, -16, -16, -16, -15, -13, -11, -9, -6, -3])
+    ang = 2 * np.pi * np.arange(64) / 64
+    dirx = np.round(32 * np.cos(ang)).astype(int); diry = np.round(32 * np.sin(ang)).astype(int)   # the kernel's table
     rng = np.random.default_rng(2)
 
     def prefilter(pts):
         pts = pts[np.lexsort((pts[:, 1], pts[:, 0]))]
-        if len(pts) <= 48:
+        if len(pts) <= 24:
             return pts
         ext = []
-        for d in range(32):
+        for d in range(64):
             v = dirx[d] * pts[:, 0] + diry[d] * pts[:, 1]
             ext.append(pts[np.argmax(v)])      # first maximum in (x,y) order, as the kernel's tie-break
         ext = np.array(ext)
         keep = np.ones(len(pts), bool)
         for j, (qx, qy) in enumerate(pts):
             inside, edges = True, 0
-            for d in range(32):
-                a, b = ext[d], ext[(d + 1) % 32]
+            for d in range(64):
+                a, b = ext[d], ext[(d + 1) % 64]
                 if a[0] == b[0] and a[1] == b[1]:
                     continue
                 edges += 1
@@ -200,7 +200,7 @@ def test_hull_interior_prefilter(oracle):
         return pts[keep]
 
     for trial in range(300):
-        n = int(rng.integers(49, 400)); mode = trial % 4
+        n = int(rng.integers(25, 400)); mode = trial % 4
         if mode == 0: pts = rng.integers(-200, 200, size=(n, 2))
         elif mode == 1: pts = np.stack([rng.integers(-300, 300, size=n), rng.integers(-6, 6, size=n)], 1)      # wall
         elif mode == 2:
@@ -212,3 +212,53 @@ def test_hull_interior_prefilter(oracle):
         assert len(f) <= len(pts)
         assert np.array_equal(oracle.convex_hull(pts), oracle.convex_hull(f))
         assert np.array_equal(oracle.min_area_rect_points(pts), oracle.min_area_rect_points(f))
+
+
+def test_parallel_hull_construction(oracle):
+    """cluster_rect_kernel builds cv::convexHull's output without the sequential Sklansky scan: strict hull vertices
+    (all other points in an open half-plane through the vertex — integer tournament + check), emitted as
+    [first point, larger-y side by increasing (x,y), last point, smaller-y side by decreasing (x,y)].
+    The same construction in numpy must reproduce the restated OpenCV scan, degenerate inputs included."""
+    rng = np.random.default_rng(3)
+
+    def strict(pts, j):
+        q = pts[j]; v = None
+        for k in range(len(pts)):
+            if k == j: continue
+            w = pts[k] - q
+            if v is None: v = w
+            else:
+                cr = v[0] * w[1] - v[1] * w[0]
+                if cr < 0: v = w
+                elif cr == 0 and v[0] * w[0] + v[1] * w[1] < 0: return False
+        if v is None: return True
+        for k in range(len(pts)):
+            if k == j: continue
+            w = pts[k] - q
+            cr = v[0] * w[1] - v[1] * w[0]
+            if cr < 0 or (cr == 0 and v[0] * w[0] + v[1] * w[1] < 0): return False
+        return True
+
+    def par_hull(pts):
+        s = len(pts)
+        if s <= 1: return pts[:s]
+        F, L = pts[0], pts[-1]; d = L - F
+        side = lambda j: d[0] * (pts[j][1] - F[1]) - d[1] * (pts[j][0] - F[0])
+        up = [j for j in range(1, s - 1) if side(j) > 0 and strict(pts, j)]
+        lo = [j for j in range(s - 2, 0, -1) if side(j) < 0 and strict(pts, j)]
+        return pts[[0] + up + [s - 1] + lo]
+
+    for trial in range(2100):
+        n = int(rng.integers(1, 40)); mode = trial % 7
+        if mode == 0: pts = rng.integers(-30, 30, size=(n, 2))
+        elif mode == 1: pts = rng.integers(-4, 4, size=(n, 2))
+        elif mode == 2:
+            x = rng.integers(-40, 40, size=n); pts = np.stack([x, x // 2 + rng.integers(-2, 2, size=n)], 1)
+        elif mode == 3:
+            x = rng.integers(-40, 40, size=n); pts = np.stack([x, 3 * x + 7], 1)
+        elif mode == 4: pts = np.stack([np.full(n, 5), rng.integers(-20, 20, size=n)], 1)
+        elif mode == 5: pts = np.stack([rng.integers(-20, 20, size=n), np.full(n, -3)], 1)
+        else:
+            x = rng.integers(-10, 10, size=n); pts = np.stack([x, -2 * x + 1], 1)
+        pts = np.unique(pts.astype(np.int64), axis=0)
+        assert np.array_equal(oracle.convex_hull(pts.astype(np.int32)), par_hull(pts))
