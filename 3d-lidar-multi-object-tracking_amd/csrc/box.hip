@@ -128,9 +128,6 @@ constexpr int kBoxBlock = 256;       // one workgroup (4 waves) per cluster, thr
 constexpr int kBoxWaves = kBoxBlock / 64;
 constexpr int kPicCols = 1024;       // pixel columns 0..900
 constexpr int kMaxHullIn = 2 * 901;  // two extreme pixels per column
-constexpr int kScanDepth = 8;       // label loads kept in flight per lane while walking a frame's labels
-constexpr int kStackStride = 2 * 901 + 2;  // shorts per Sklansky stack (= kMaxHullIn + 2)
-constexpr int kNeedWords = 2048;    // bitmap of sampled ranks for clusters of up to 65536 points (larger: no shortcut)
 constexpr int kMaxHull = 384;        // vertices of a convex lattice polygon in a 900^2 box: < 3.5 * 900^(2/3) ~ 330
 
 // ruleBasedFilter :97-158 (fall-through = false)
@@ -156,13 +153,6 @@ __device__ bool rule_based_filter(const MotDevParams& p, const float* pc, float 
           }
   return false;
 }
-
-// 64 integer directions (32*cos, 32*sin rounded), counter-clockwise: the extreme point of a set in each of them is a
-// hull vertex, and a point strictly inside the polygon they span cannot be one
-__constant__ signed char kDirX[64] = {32, 32, 31, 31, 30, 28, 27, 25, 23, 20, 18, 15, 12, 9, 6, 3, 0, -3, -6, -9, -12, -15, -18, -20, -23, -25, -27, -28, -30, -31, -31, -32,
-                                      -32, -32, -31, -31, -30, -28, -27, -25, -23, -20, -18, -15, -12, -9, -6, -3, 0, 3, 6, 9, 12, 15, 18, 20, 23, 25, 27, 28, 30, 31, 31, 32};
-__constant__ signed char kDirY[64] = {0, 3, 6, 9, 12, 15, 18, 20, 23, 25, 27, 28, 30, 31, 31, 32, 32, 32, 31, 31, 30, 28, 27, 25, 23, 20, 18, 15, 12, 9, 6, 3,
-                                      0, -3, -6, -9, -12, -15, -18, -20, -23, -25, -27, -28, -30, -31, -31, -32, -32, -32, -31, -31, -30, -28, -27, -25, -23, -20, -18, -15, -12, -9, -6, -3};
 
 // lanes of tile t (points 64 t .. 64 t + 63) that belong to cluster `want`
 __device__ __forceinline__ unsigned long long tile_mask(const TileSummary* __restrict__ tiles, const int* __restrict__ label,
@@ -402,28 +392,62 @@ cluster_gather_kernel(MotDevParams p, ClusterBuffers c) {
 // ------------------------------------------------------------------------------------------ B2b
 // one WAVE per rectangle cluster. cv::minAreaRect(points) = convexHull + rotatingCalipers (OpenCV 3.2), restated so
 // that the parallel steps give the sequential algorithm's exact result:
-//  * the hull of lattice points is unique: points strictly inside the polygon of 64 directional extremes are dropped;
-//    a survivor is a hull vertex iff all other survivors lie in an open half-plane through it (exact integer
-//    tournament + check, one lane per point); OpenCV's output order is [first point in (x,y) order, the vertices on
-//    the larger-y side by increasing (x,y), last point, the vertices on the smaller-y side by decreasing (x,y)]
-//    (tests/test_oracle_vs_ref.py::test_parallel_hull_construction checks this against the restated Sklansky scan);
+//  * the strict convex hull of lattice points is unique, and OpenCV's output order is [first point in (x,y) order,
+//    the vertices on the larger-y side by increasing (x,y), last point, the vertices on the smaller-y side by decreasing
+//    (x,y)]. Each side is found by PEELING the (x,y)-sorted point list: every interior point that does not make a
+//    strict turn with its current neighbours is dropped, all at once, until nothing changes (exact integer cross
+//    products; O(log n) rounds in practice). tests/test_oracle_vs_ref.py::test_parallel_hull_construction checks the
+//    construction against the restated Sklansky scan, degenerate inputs included;
 //  * caliper set-up is data parallel, the caliper walk (a dependent chain over the hull) runs on registers.
 constexpr int kRectBlock = 64;
+
+// one peeling pass structure: src (m packed points x | y << 16) -> fixed point; sign = +1 larger-y side, -1 smaller-y side
+__device__ int peel_chain(const int* src, int m, int* b0, int* b1, int sign, const int** out) {
+  const int lane = lane_id();
+  const int* cur = src;
+  int* nxt = b0;
+  while (true) {
+    int kept = 0;
+    for (int j0 = 0; j0 < m; j0 += 64) {
+      const int j = j0 + lane;
+      bool keep = false;
+      int pb = 0;
+      if (j < m) {
+        pb = cur[j];
+        if (j == 0 || j == m - 1) keep = true;
+        else {
+          const int pa = cur[j - 1], pc = cur[j + 1];
+          const int ax = (short)(pa & 0xffff), ay = pa >> 16, bx = (short)(pb & 0xffff), by = pb >> 16, cx = (short)(pc & 0xffff), cy = pc >> 16;
+          const int cr = (bx - ax) * (cy - by) - (by - ay) * (cx - bx);
+          keep = sign > 0 ? (cr < 0) : (cr > 0);
+        }
+      }
+      unsigned long long km = __ballot(keep);
+      if (keep) nxt[kept + __popcll(km & ((1ull << lane) - 1ull))] = pb;
+      kept += __popcll(km);
+    }
+    MOT_WAVE_SYNC();
+    if (kept == m) break;  // nothing was dropped: `cur` is the chain
+    m = kept;
+    cur = nxt;
+    nxt = (nxt == b0) ? b1 : b0;
+  }
+  *out = cur;
+  return m;
+}
+
 __global__ void MOT_LAUNCH_BOUNDS(kRectBlock)
 cluster_rect_kernel(MotDevParams p, ClusterBuffers c) {
-  __shared__ short s_px[kMaxHullIn + 2], s_py[kMaxHullIn + 2];  // candidate points, sorted by (x,y)
-  __shared__ short s_qx[kMaxHullIn + 2], s_qy[kMaxHullIn + 2];  // ... after the interior filter
-  __shared__ short s_hull[kMaxHullIn + 2];
+  __shared__ int s_in[kMaxHullIn + 2];                        // candidate points (x | y << 16), sorted by (x,y)
+  __shared__ int s_b0[kMaxHullIn + 2], s_b1[kMaxHullIn + 2];  // peeling ping-pong
   __shared__ float s_hx[kMaxHull], s_hy[kMaxHull], s_vx[kMaxHull], s_vy[kMaxHull], s_inv[kMaxHull];
   const int b = blockIdx.y;
   const int num_cluster = min(c.counts[b * kCountsStride + kCntClusters], kMaxClusters);
   const int lane = lane_id();
   const int* pool = c.poly + (long)b * c.cap;
 #ifndef MOT_HIPEMU
-#define RLI(v, idx) ((int)__builtin_amdgcn_readlane((unsigned)(v), (idx)))
 #define RLF(v, idx) __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(v), (idx)))
 #else
-#define RLI(v, idx) __shfl((v), (idx), 64)
 #define RLF(v, idx) __shfl((v), (idx), 64)
 #endif
   for (int ci = blockIdx.x; ci < num_cluster; ci += gridDim.x) {
@@ -432,119 +456,35 @@ cluster_rect_kernel(MotDevParams p, ClusterBuffers c) {
     const int offsetInitX = cand.off_x, offsetInitY = cand.off_y, numPoints = cand.num_points;
     const float maxZ = cand.max_z;
     int total = cand.poly_n;
-    if (cand.poly_off + total > c.cap) total = 0;
-    for (int j = lane; j < total; j += 64) { int v = pool[cand.poly_off + j]; s_px[j] = (short)(v & 0xffff); s_py[j] = (short)(v >> 16); }
+    if (cand.poly_off + total > c.cap || total > kMaxHullIn) total = 0;
+    for (int j = lane; j < total; j += 64) s_in[j] = pool[cand.poly_off + j];
     MOT_WAVE_SYNC();
-    // ---- interior prefilter
-    if (total > 24) {
-      unsigned best[64];
-#pragma unroll
-      for (int d = 0; d < 64; d++) best[d] = 0u;
-      for (int j = lane; j < total; j += 64) {
-        const int x = s_px[j], y = s_py[j];
-#pragma unroll
-        for (int d = 0; d < 64; d++) {  // key: dot product (biased), then the smaller index
-          unsigned key = ((unsigned)(kDirX[d] * x + kDirY[d] * y + 131072) << 11) | (unsigned)(2047 - j);
-          best[d] = key > best[d] ? key : best[d];
-        }
-      }
-      int ex = 0, ey = 0;  // lane d: extreme point of direction d
-#pragma unroll
-      for (int d = 0; d < 64; d++) {
-        unsigned k2 = wave_max_t<unsigned>(best[d]);
-        if (lane == d) { int w = 2047 - (int)(k2 & 2047u); ex = s_px[w]; ey = s_py[w]; }
-      }
-      // edge d: extreme d -> extreme d+1; a point is strictly inside iff it is strictly left of every real edge
-      const int nx = __shfl(ex, (lane + 1) & 63, 64), ny = __shfl(ey, (lane + 1) & 63, 64);
-      const int edx = nx - ex, edy = ny - ey, ec = edx * ey - edy * ex;
-      const unsigned long long real_edges = __ballot(!(edx == 0 && edy == 0));
-      const int n_edges = __popcll(real_edges);
-      int kept_total = 0;
-      for (int j0 = 0; j0 < total; j0 += 64) {
-        int j = j0 + lane;
-        const int qx = j < total ? s_px[j] : 0, qy = j < total ? s_py[j] : 0;
-        bool inside = true;
-        unsigned long long em = real_edges;
-        while (em) {  // wave-uniform
-          int d = __ffsll(em) - 1;
-          em &= em - 1ull;
-          int cr = RLI(edx, d) * qy - RLI(edy, d) * qx - RLI(ec, d);  // cross(edge, q - a)
-          inside = inside && cr > 0;
-        }
-        bool keep = j < total && !(inside && n_edges >= 3);
-        unsigned long long km = __ballot(keep);
-        if (keep) { int o = kept_total + __popcll(km & ((1ull << lane) - 1ull)); s_qx[o] = s_px[j]; s_qy[o] = s_py[j]; }
-        kept_total += __popcll(km);
-      }
-      total = kept_total;
-    } else {
-      for (int j = lane; j < total; j += 64) { s_qx[j] = s_px[j]; s_qy[j] = s_py[j]; }
-    }
-    MOT_WAVE_SYNC();
-    // ---- cv::convexHull: strict hull vertices, in OpenCV's output order
+    // ---- cv::convexHull
     int hn = 0;
-    if (total == 1) { if (lane == 0) s_hull[0] = 0; hn = 1; }
-    else if (total >= 2) {
-      const int Fx = s_qx[0], Fy = s_qy[0], Lx = s_qx[total - 1], Ly = s_qy[total - 1];
-      const int ldx = Lx - Fx, ldy = Ly - Fy;
-      int n_up = 0;
-      // pass A: upper side (larger y) in increasing order; pass B: lower side in decreasing order
-      for (int pass = 0; pass < 2; pass++) {
-        if (pass == 1) { if (lane == 0) s_hull[1 + n_up] = (short)(total - 1); }
-        int emitted = 0;
-        for (int j0 = 0; j0 < total; j0 += 64) {
-          // pass 1 walks the tiles from the top so that ranks come out in decreasing index order
-          const int jj = j0 + lane;
-          const int j = pass == 0 ? jj : (total - 1 - jj);
-          bool is_vertex = false;
-          if (jj < total && j > 0 && j < total - 1) {
-            const int qx = s_qx[j], qy = s_qy[j];
-            const int side = ldx * (qy - Fy) - ldy * (qx - Fx);
-            if ((pass == 0 && side > 0) || (pass == 1 && side < 0)) {
-              // all other points in an open half-plane through q?  tournament for the most clockwise direction, then check
-              int vx = 0, vy = 0; bool havev = false, ok = true;
-              for (int pp = 0; pp < total; pp++) {
-                if (pp == j) continue;
-                int wx = s_qx[pp] - qx, wy = s_qy[pp] - qy;
-                if (!havev) { vx = wx; vy = wy; havev = true; }
-                else {
-                  int cr = vx * wy - vy * wx;
-                  if (cr < 0) { vx = wx; vy = wy; }
-                  else if (cr == 0 && (vx * wx + vy * wy) < 0) ok = false;
-                }
-              }
-              for (int pp = 0; ok && pp < total; pp++) {
-                if (pp == j) continue;
-                int wx = s_qx[pp] - qx, wy = s_qy[pp] - qy;
-                int cr = vx * wy - vy * wx;
-                if (cr < 0 || (cr == 0 && (vx * wx + vy * wy) < 0)) ok = false;
-              }
-              is_vertex = ok;
-            }
-          }
-          unsigned long long vm = __ballot(is_vertex);
-          if (is_vertex) {
-            int r = emitted + __popcll(vm & ((1ull << lane) - 1ull));
-            s_hull[(pass == 0 ? 1 : 2 + n_up) + r] = (short)j;
-          }
-          emitted += __popcll(vm);
-        }
-        if (pass == 0) n_up = emitted; else hn = 2 + n_up + emitted;
-      }
-      if (lane == 0) s_hull[0] = 0;
+    bool hull_overflow = false;
+    if (total == 1) {
+      if (lane == 0) { int v = s_in[0]; s_hx[0] = (float)(short)(v & 0xffff); s_hy[0] = (float)(v >> 16); }
+      hn = 1;
+    } else if (total >= 2) {
+      const int* ch;
+      int mu = peel_chain(s_in, total, s_b0, s_b1, +1, &ch);  // F, larger-y side ..., L
+      if (mu > kMaxHull) hull_overflow = true;
+      else for (int i = lane; i < mu; i += 64) { int v = ch[i]; s_hx[i] = (float)(short)(v & 0xffff); s_hy[i] = (float)(v >> 16); }
+      MOT_WAVE_SYNC();
+      int ml = peel_chain(s_in, total, s_b0, s_b1, -1, &ch);  // F, smaller-y side ..., L
+      hn = mu + ml - 2;
+      if (hn > kMaxHull) hull_overflow = true;
+      else for (int i = lane; i < ml - 2; i += 64) { int v = ch[ml - 2 - i]; s_hx[mu + i] = (float)(short)(v & 0xffff); s_hy[mu + i] = (float)(v >> 16); }  // decreasing order
     }
     MOT_WAVE_SYNC();
-    const short* ax = s_qx; const short* ay = s_qy;
     float pc[8];
     bool promising = false;
     float rect[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     float cx = 0, cy = 0, w = 0, h = 0, angle = 0;
-    if (hn > kMaxHull) {
+    if (hull_overflow) {
       if (lane == 0) atomicOr(&c.counts[b * kCountsStride + kCntFlags], (int)kFlagHullOverflow);
       cand.undefined = 1;
     } else {
-      for (int i = lane; i < hn; i += 64) { s_hx[i] = (float)ax[s_hull[i]]; s_hy[i] = (float)ay[s_hull[i]]; }
-      MOT_WAVE_SYNC();
       if (hn > 2) {
         // ---- rotatingCalipers(points, n, CALIPERS_MINAREARECT, out), OpenCV 3.2 rotcalipers.cpp
         long long kl = 0x7fffffffffffffffll, kr = -0x7fffffffffffffffll - 1, kt = -0x7fffffffffffffffll - 1, kb = 0x7fffffffffffffffll;
@@ -704,7 +644,6 @@ cluster_rect_kernel(MotDevParams p, ClusterBuffers c) {
     }
     MOT_WAVE_SYNC();
   }
-#undef RLI
 #undef RLF
 }
 
