@@ -114,18 +114,19 @@ label_stats_kernel(MotDevParams p, ClusterBuffers c) {
         atomicMax(&s->maxz_key, rz);
         if (rmin != kArgminInit) atomicMin(&s->argmin, rmin);
         if (rmax != kArgmaxInit) atomicMax(&s->argmax, rmax);
-        if (entry < 4) { ts->mask[entry] = mm; ts->label[entry] = l; }
+        if (entry < kTileEntries) { ts->mask[entry] = mm; ts->label[entry] = l; }
       }
       entry++;
       active &= ~mm;
     }
-    if (lane == 0 && base + k * kLabelBlock + (threadIdx.x & ~63) < n) ts->n = entry <= 4 ? entry : 5;
+    if (lane == 0 && base + k * kLabelBlock + (threadIdx.x & ~63) < n) ts->n = entry <= kTileEntries ? entry : kTileEntries + 1;
   }
 }
 
 // ------------------------------------------------------------------------------------------ B2
 constexpr int kBoxBlock = 256;       // one workgroup (4 waves) per cluster, threads over the frame's 64-point tiles
 constexpr int kBoxWaves = kBoxBlock / 64;
+constexpr int kGatherDepth = 8;
 constexpr int kPicCols = 1024;       // pixel columns 0..900
 constexpr int kMaxHullIn = 2 * 901;  // two extreme pixels per column
 constexpr int kMaxHull = 384;        // vertices of a convex lattice polygon in a 900^2 box: < 3.5 * 900^(2/3) ~ 330
@@ -158,14 +159,26 @@ __device__ bool rule_based_filter(const MotDevParams& p, const float* pc, float 
 __device__ __forceinline__ unsigned long long tile_mask(const TileSummary* __restrict__ tiles, const int* __restrict__ label,
                                                         int t, int n, int want) {
   const TileSummary* ts = &tiles[t];
+  const int4 l0 = *(const int4*)&ts->label[0], l1 = *(const int4*)&ts->label[4];  // independent 16-byte loads
   const int ne = ts->n;
-  if (ne <= 4) {
-    unsigned long long m = 0ull;
-    for (int e = 0; e < ne; e++) if (ts->label[e] == want) m = ts->mask[e];
-    return m;
+  if (ne <= kTileEntries) {
+    int e = l0.x == want ? 0 : l0.y == want ? 1 : l0.z == want ? 2 : l0.w == want ? 3 : l1.x == want ? 4 : l1.y == want ? 5 : l1.z == want ? 6 : l1.w == want ? 7 : -1;
+    return (e >= 0 && e < ne) ? ts->mask[e] : 0ull;
   }
-  unsigned long long m = 0ull;  // more than four clusters meet in this tile: read the labels
-  for (int l = 0; l < 64; l++) { int i = t * 64 + l; if (i < n && label[i] == want) m |= 1ull << l; }
+  unsigned long long m = 0ull;  // more than kTileEntries clusters meet in this tile (rare): read the 64 labels
+  int4 v[16];
+#pragma unroll
+  for (int k = 0; k < 16; k++) {
+    int i = t * 64 + 4 * k;
+    v[k] = (i + 3 < n) ? *(const int4*)&label[i] : make_int4(i < n ? label[i] : 0, i + 1 < n ? label[i + 1] : 0, i + 2 < n ? label[i + 2] : 0, 0);
+  }
+#pragma unroll
+  for (int k = 0; k < 16; k++) {
+    if (v[k].x == want) m |= 1ull << (4 * k);
+    if (v[k].y == want) m |= 1ull << (4 * k + 1);
+    if (v[k].z == want) m |= 1ull << (4 * k + 2);
+    if (v[k].w == want) m |= 1ull << (4 * k + 3);
+  }
   return m;
 }
 __device__ __forceinline__ int nth_set_bit(unsigned long long m, int k) {  // position of the k-th (0-based) set bit
@@ -267,6 +280,7 @@ cluster_gather_kernel(MotDevParams p, ClusterBuffers c) {
       // the k-th point of the cluster in input order: exclusive prefix of the per-tile counts gives every tile its
       // first rank; a sampled rank is then a bit position inside one tile's mask
       int running = 0;
+#ifndef MOT_DBG_SKIP_LSHAPE_TILES
       for (int t0 = 0; t0 < ntiles; t0 += kBoxBlock) {
         const int t = t0 + tid;
         unsigned long long m = t < ntiles ? tile_mask(tiles, label, t, n, ci + 1) : 0ull;
@@ -287,6 +301,7 @@ cluster_gather_kernel(MotDevParams p, ClusterBuffers c) {
         running += round_total;
         __syncthreads();
       }
+#endif
       // farthest sampled point from the line through the two slope-extreme points; first maximum wins
       float pc[8];
       bool promising = false;
@@ -326,18 +341,22 @@ cluster_gather_kernel(MotDevParams p, ClusterBuffers c) {
       cand.branch = 1;
       for (int i = tid; i < kPicCols; i += kBoxBlock) { s_colmin[i] = 0x7fffffff; s_colmax[i] = -0x7fffffff - 1; }
       __syncthreads();
-      for (int t0 = 0; t0 < ntiles; t0 += kBoxBlock) {
-        const int t = t0 + tid;
+      // work item = half a tile (32 points): keeps the threads of a workgroup evenly loaded when one cluster owns most
+      // of the frame; up to kGatherDepth independent point loads are in flight per thread
+#ifndef MOT_DBG_SKIP_MAR_TILES
+      for (int w0 = 0; w0 < 2 * ntiles; w0 += kBoxBlock) {
+        const int item = w0 + tid, t = item >> 1;
         unsigned long long m = t < ntiles ? tile_mask(tiles, label, t, n, ci + 1) : 0ull;
-        while (m) {  // up to four independent gathers per trip
-          int idx[4]; float4 q[4]; int cntq = 0;
+        m &= (item & 1) ? 0xffffffff00000000ull : 0x00000000ffffffffull;
+        while (m) {
+          int idx[kGatherDepth]; float4 q[kGatherDepth];
 #pragma unroll
-          for (int u = 0; u < 4; u++) if (m) { idx[u] = t * 64 + __ffsll(m) - 1; m &= m - 1ull; cntq = u + 1; } else idx[u] = -1;
+          for (int u = 0; u < kGatherDepth; u++) if (m) { idx[u] = t * 64 + __ffsll(m) - 1; m &= m - 1ull; } else idx[u] = -1;
 #pragma unroll
-          for (int u = 0; u < 4; u++) q[u] = idx[u] >= 0 ? pts[idx[u]] : make_float4(0.f, 0.f, 0.f, 0.f);
+          for (int u = 0; u < kGatherDepth; u++) q[u] = idx[u] >= 0 ? pts[idx[u]] : make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
-          for (int u = 0; u < 4; u++) {
-            if (u < cntq) {
+          for (int u = 0; u < kGatherDepth; u++) {
+            if (idx[u] >= 0) {
               float roiX = q[u].x + p.roi_half, roiY = q[u].y + p.roi_half;  // :244-254
               int x = (int)floorf(roiX * p.pic_scale), y = (int)floorf(roiY * p.pic_scale);
               int picX = x;
@@ -351,6 +370,7 @@ cluster_gather_kernel(MotDevParams p, ClusterBuffers c) {
           }
         }
       }
+#endif
       __syncthreads();
       if (wave == 0) {
         // compact the column extents into (x,y)-sorted points: 16 columns per lane, prefix over lanes

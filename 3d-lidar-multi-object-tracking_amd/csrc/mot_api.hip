@@ -137,6 +137,7 @@ static int make_dev_params(const mot_params& p, MotDevParams* d, std::string* er
   if (!(p.pic_scale * p.roi_m <= 1000.f)) { *err = "pic_scale * roi_m must be <= 1000 pixels"; return MOT_E_ARG; }
   memset(d, 0, sizeof *d);
   d->r_min = p.r_min; d->r_max = p.r_max; d->r_span = p.r_max - p.r_min;
+  d->k_bin = (float)MOT_NUM_BIN / d->r_span;
   d->t_hmin = p.t_hmin; d->t_hmax = p.t_hmax; d->t_hdiff = p.t_hdiff; d->h_sensor = p.h_sensor;
   d->ground_margin = p.ground_margin;
   {  // gaussKernel(samples=3, sigma), gaus_blur.cpp:26-49 — host libm, exactly as the reference evaluates it
@@ -266,7 +267,8 @@ extern "C" int mot_create(const mot_params* params, int device, int max_points, 
   if (!params || !out || max_points < 1 || max_points > kMaxPointsPerFrame || max_batch < 1 || max_tracks_total < 1) return MOT_E_ARG;
   *out = nullptr;
   mot_ctx* c = new mot_ctx();
-  c->params = *params; c->device = device; c->cap = max_points; c->batch = max_batch;
+  c->params = *params; c->device = device; c->batch = max_batch;
+  c->cap = (max_points + 63) / 64 * 64;  // per-slot stride of every per-point buffer: keeps 16-byte vector loads aligned
   c->max_tracks_total = max_tracks_total;
   int rc = make_dev_params(c->params, &c->dp, &c->err);
   if (rc == MOT_OK) rc = create_impl(c);

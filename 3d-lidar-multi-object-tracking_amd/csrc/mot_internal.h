@@ -33,6 +33,7 @@ constexpr int kMaxPointsPerFrame = (1 << kDescCountBits) - 1;
 // parameters as the kernels want them (floats pre-combined exactly as the reference combines them)
 struct MotDevParams {
   float r_min, r_max, r_span;                  // r_span = rMax - rMin (fp32, ground_removal.cpp:72)
+  float k_bin;                                 // 120 / r_span, for the guarded fast path only
   float t_hmin, t_hmax, t_hdiff, h_sensor;
   double ground_margin;
   double gk[3];                                // normalised 3-tap Gaussian (gaus_blur.cpp:26-49), host libm
@@ -84,11 +85,12 @@ struct ClusterStats {          // per cluster, accumulated by the label kernel, 
   unsigned long long argmin;   // (key(m) << 32) | idx        -> minimum = smallest slope, first occurrence
   unsigned long long argmax;   // (key(m) << 32) | ~idx       -> maximum = largest slope, first occurrence
 };
+constexpr int kTileEntries = 8;
 struct TileSummary {           // which clusters the 64 points [64 t, 64 t + 64) of a frame belong to (label kernel)
-  unsigned long long mask[4];  // lanes of the tile holding label[k]
-  int label[4];
-  int n;                       // entries used; 5 = more than 4 distinct clusters in the tile (consumers read `label[]`)
-  int pad[3];
+  unsigned long long mask[kTileEntries];  // lanes of the tile holding label[k]
+  int label[kTileEntries];
+  int n;                       // entries used; kTileEntries + 1 = more distinct clusters in the tile (consumers read `label[]`)
+  int pad[7];
 };
 struct BoxCandidate {          // per cluster, written by the box kernels
   float pc[8];                 // 4 corners (x,y)
@@ -208,10 +210,9 @@ MOT_HD bool mot_cart_cell(const MotDevParams& p, float x, float y, int* xI, int*
 }
 
 // getCellIndexFromPoints (ground_removal.cpp:67-76) + filterCloud's range test (:53) + the callers'
-// bounds test (:89,:233). Returns the polar cell (ch*120+bin) or -1 when the point takes no part.
-MOT_HD int mot_polar_cell(const MotDevParams& p, float x, float y) {
-  float distance = sqrtf(x * x + y * y);
-  if (distance <= p.r_min || distance >= p.r_max) return -1;       // filterCloud (NaN passes, as in the reference)
+// bounds test (:89,:233), evaluated exactly as the reference does (bit-exact atan2f, fp64 intermediate, IEEE divide).
+// Returns the polar cell (ch*120+bin) or -1 when the point takes no part. `distance` = sqrtf(x*x+y*y), already in range.
+MOT_HD int mot_polar_cell_exact(const MotDevParams& p, float x, float y, float distance) {
   float at = mot_atan2f(y, x);
   float chP = (float)(((double)at + 3.14159265358979323846) / (2 * 3.14159265358979323846));
   float binP = (distance - p.r_min) / p.r_span;
@@ -220,6 +221,58 @@ MOT_HD int mot_polar_cell(const MotDevParams& p, float x, float y) {
   // (int) of NaN / out-of-range is INT_MIN on the reference's x86 build and is then dropped
   if (!(fc >= 0.f && fc < (float)MOT_NUM_CHANNEL && fb >= 0.f && fb < (float)MOT_NUM_BIN)) return -1;
   return (int)fc * MOT_NUM_BIN + (int)fb;
+}
+
+// Guarded fast path. The cell is floor() of two quantities; floor only depends on them to within the distance to the
+// nearest integer. Both are first estimated cheaply (degree-13 odd polynomial for atan on [0,1] with a hardware
+// reciprocal, absolute error < 1e-6 rad => < 2e-5 channels; one multiply instead of the IEEE divide for the bin,
+// error < 3e-5 bins). If either estimate is within kCellGuard of an integer — or anything is NaN — the exact evaluation
+// decides; otherwise the estimate's floor IS the exact floor. ~4e-4 of the points take the exact path.
+// tests/test_math_exact.py::test_fast_cell_agrees checks the claim on 2e8 points (with the reciprocal perturbed by
+// +-1 ulp to cover the hardware's v_rcp_f32), the -m gpu parity tests check it end to end.
+constexpr float kCellGuard = 1.0e-4f;
+MOT_HD float mot_rcp_approx(float v) {
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(MOT_HIPEMU)
+  return __builtin_amdgcn_rcpf(v);
+#else
+  return 1.0f / v;
+#endif
+}
+MOT_HD int mot_polar_cell_fast(const MotDevParams& p, float x, float y, float distance, float rcp_mx) {
+  // bin
+  const float tb = (distance - p.r_min) * p.k_bin;
+  const float fb = floorf(tb), rb = tb - fb;
+  // channel: atan2 by octant reduction
+  const float ax = fabsf(x), ay = fabsf(y);
+  const float mn = ax < ay ? ax : ay;
+  const float q = mn * rcp_mx;
+  const float s = q * q;
+  float a = 0.006658289581537247f;
+  a = a * s + -0.03310525044798851f;
+  a = a * s + 0.0789998322725296f;
+  a = a * s + -0.13195902109146118f;
+  a = a * s + 0.19796891510486603f;
+  a = a * s + -0.33316001296043396f;
+  a = a * s + 0.9999956488609314f;
+  a = a * q;
+  if (ay > ax) a = 1.57079632679489662f - a;
+  if (x < 0.f) a = 3.14159265358979324f - a;
+  if (y < 0.f) a = -a;
+  const float tc = (a + 3.14159265358979324f) * (MOT_NUM_CHANNEL / 6.28318530717958648f);
+  const float fc = floorf(tc), rc = tc - fc;
+  const bool safe = rb > kCellGuard && rb < 1.f - kCellGuard && rc > kCellGuard && rc < 1.f - kCellGuard;  // false on NaN
+  if (!safe) return -2;
+  if (!(fc >= 0.f && fc < (float)MOT_NUM_CHANNEL && fb >= 0.f && fb < (float)MOT_NUM_BIN)) return -1;
+  return (int)fc * MOT_NUM_BIN + (int)fb;
+}
+
+MOT_HD int mot_polar_cell(const MotDevParams& p, float x, float y) {
+  float distance = sqrtf(x * x + y * y);
+  if (distance <= p.r_min || distance >= p.r_max) return -1;       // filterCloud (NaN passes, as in the reference)
+  const float ax = fabsf(x), ay = fabsf(y);
+  int cell = mot_polar_cell_fast(p, x, y, distance, mot_rcp_approx(ax > ay ? ax : ay));
+  if (cell == -2) cell = mot_polar_cell_exact(p, x, y, distance);
+  return cell;
 }
 
 // node pre-filter, OT/src/groundremove/main.cpp:56-81,104-112: PassThrough z (closed, finite) then

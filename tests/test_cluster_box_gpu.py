@@ -48,6 +48,24 @@ def test_cluster_box_small_and_empty(ctx, oracle, synth):
     _stage_parity(ctx, oracle, p, np.concatenate([edge, edge]))
 
 
+def interleaved_clusters_cloud(n_clusters=12, reps=40):
+    """consecutive points hop between many small clusters: more distinct clusters per 64-point tile than the label
+    kernel's per-tile summary holds, so the consumers' fallback path runs"""
+    rng = np.random.default_rng(4)
+    centres = [(-20 + 3.5 * k, -18 + 3.1 * k) for k in range(n_clusters)]
+    pts = []
+    for r in range(reps):
+        for k, (cx, cy) in enumerate(centres):
+            pts.append((cx + rng.uniform(-0.6, 0.6), cy + rng.uniform(-0.25, 0.25), rng.uniform(-1.0, 0.4), 0.0))
+    return np.array(pts, np.float32)
+
+
+def test_many_clusters_per_tile(ctx, oracle):
+    p = oracle.params(0)
+    _stage_parity(ctx, oracle, p, interleaved_clusters_cloud())
+    _stage_parity(ctx, oracle, p, interleaved_clusters_cloud(20, 25))
+
+
 def test_ccl_adversarial_patterns(mot, hip_lib, oracle):
     rng = np.random.default_rng(0)
     for preset in (0, 1):

@@ -41,3 +41,14 @@ def test_emu_ccl_patterns(mot, emu_lib, oracle, preset):
             r = c.cluster(pts); o = oracle.cluster(p, pts)
             assert r["num_cluster"] == o["num_cluster"] and np.array_equal(r["grid"], o["grid"]), name
             assert np.array_equal(r["point_label"], o["point_label"]), name
+
+
+def test_emu_many_clusters_per_tile(mot, emu_lib, oracle):
+    from test_cluster_box_gpu import interleaved_clusters_cloud
+    p = oracle.params(0)
+    with mot.Context(lib_path=emu_lib, max_points=4096) as c:
+        for cloud in (interleaved_clusters_cloud(), interleaved_clusters_cloud(20, 25)):
+            r = c.cluster(cloud); o = oracle.cluster(p, cloud)
+            assert r["num_cluster"] == o["num_cluster"] >= 10 and np.array_equal(r["grid"], o["grid"])
+            b = c.box_fit(cloud, o["grid"], o["num_cluster"]); ob = oracle.box_fit(p, cloud, o["grid"], o["num_cluster"])
+            assert np.array_equal(b["boxes"], ob["boxes"]) and np.array_equal(b["box_cluster"], ob["box_cluster"])

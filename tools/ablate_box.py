@@ -16,11 +16,11 @@ base = [synth.make_cloud(N, s, 0) for s in range(8)]
 for b in range(B): host[b, :N] = base[b % 8]
 dev = torch.from_numpy(host).cuda(); torch.cuda.synchronize()
 out = {}
-for name, flags in (("full", []), ("skip_hull", ["-DMOT_DBG_SKIP_HULL"]), ("skip_walk", ["-DMOT_DBG_SKIP_WALK"]), ("skip_both", ["-DMOT_DBG_SKIP_HULL", "-DMOT_DBG_SKIP_WALK"])):
+for name, flags in (("full", []), ("skip_lshape_tiles", ["-DMOT_DBG_SKIP_LSHAPE_TILES"]), ("skip_mar_tiles", ["-DMOT_DBG_SKIP_MAR_TILES"]), ("skip_both", ["-DMOT_DBG_SKIP_LSHAPE_TILES", "-DMOT_DBG_SKIP_MAR_TILES"])):
     lib = build.build(extra_flags=flags, out=os.path.join(ROOT, "gpurun_out", f"libmot_{name}.so"))
     ctx = mot.Context(max_points=stride, max_batch=B, lib_path=lib)
     ctx.frames_dev(dev.data_ptr(), stride * 4, [N] * B); ctx.synchronize()
-    out[name] = {"cluster_box_ms": ctx.time_stage(31, B, 10), "label_stats_ms": ctx.time_stage(30, B, 10)}
+    out[name] = {"gather_ms": ctx.time_stage(31, B, 10), "rect_ms": ctx.time_stage(33, B, 10)}
     ctx.close()
 cl = None
 print(json.dumps(out))
