@@ -124,7 +124,7 @@ label_stats_kernel(MotDevParams p, ClusterBuffers c) {
 }
 
 // ------------------------------------------------------------------------------------------ B2
-constexpr int kBoxBlock = 256;       // one workgroup (4 waves) per cluster, threads over the frame's 64-point tiles
+constexpr int kBoxBlock = 1024;      // one workgroup (16 waves) per cluster, threads over the frame's 64-point tiles
 constexpr int kBoxWaves = kBoxBlock / 64;
 constexpr int kGatherDepth = 8;
 constexpr int kPicCols = 1024;       // pixel columns 0..900

@@ -12,11 +12,13 @@
 // be read twice. The polar grid (38 KB per frame) lives in L2.
 //
 // Design notes (MI355X-first, not a translation of the CPU loops):
-//  * K1 has no LDS grid. Lidar clouds are beam-major, so the 64 points of a wave fall into 1–4 polar cells:
-//    the wave finds the distinct cells with ballot + readlane, min-reduces z per cell with a butterfly
-//    over the matching lanes, and ONE lane issues a fire-and-forget global atomic min per (wave, cell).
-//    That is fewer atomics than flushing a per-workgroup LDS grid would need, and no LDS zero/flush pass.
-//  * min z is kept as an order-preserving int key so the integer atomic min is exact.
+//  * K1 has no grid at all and issues NO global atomics. Lidar clouds are beam-major, so the 64 points of a wave
+//    fall into 1–4 polar cells: the wave finds the distinct cells with ballot + readlane, min-reduces z per cell
+//    with a butterfly over the matching lanes, and ONE lane appends {cell, min} to the workgroup's list in LDS;
+//    the list (≈140 entries per 2048 points) leaves with plain coalesced stores. K2 folds every list of a frame
+//    into its LDS grid with LDS atomics. (A first version used one global atomicMin per (wave, cell): rocprof showed
+//    8.2k device-scope atomics per frame, each a memory-side transaction — they, not HBM or the ALU, bounded K1.)
+//  * min z travels as an order-preserving int key so integer min is exact.
 //  * K3 preserves input order (the reference push_backs in order and box fitting depends on it,
 //    SURVEY.md H9) with a single-pass chained scan: per-workgroup ballot/popcount ranks + a decoupled
 //    look-back over 8-byte {status,counts} descriptors (one relaxed agent-scope store / load each; chunk
@@ -45,13 +47,16 @@ __device__ __forceinline__ int wave_min_i32(int v) {
 // filterCloud (:46-64) + createAndMapPolarGrid (:79-92) + Cell::updateMinZ (:40-42)
 __global__ void MOT_LAUNCH_BOUNDS(kGroundBlock)
 polar_minz_kernel(MotDevParams p, GroundBuffers g) {
+  __shared__ uint2 s_pairs[kGroundChunk];
+  __shared__ int s_count;
   const int b = blockIdx.y;
   const int n = g.n[b];
   const long base = (long)blockIdx.x * kGroundChunk;
   if (base >= n) return;  // whole workgroup leaves together
   const float4* __restrict__ in = g.in + (long)b * g.in_stride;
-  int* __restrict__ minz = g.minz + (long)b * MOT_POLAR_CELLS;
   const int lane = wave_lane();
+  if (threadIdx.x == 0) s_count = 0;
+  __syncthreads();
 
   float4 pt[kGroundItems];
 #pragma unroll
@@ -71,10 +76,15 @@ polar_minz_kernel(MotDevParams p, GroundBuffers g) {
       int c = __shfl(cell, leader, 64);
       bool mine = (cell == c);
       int v = wave_min_i32(mine ? key : 0x7fffffff);
-      if (lane == leader) atomicMin(&minz[c], v);
+      if (lane == leader) { int pos = atomicAdd(&s_count, 1); s_pairs[pos] = make_uint2((unsigned)c, (unsigned)v); }
       active &= ~__ballot(mine);
     }
   }
+  __syncthreads();
+  const int cnt = s_count;  // <= kGroundChunk: at most one entry per point
+  uint2* __restrict__ out = g.pairs + ((long)b * g.max_chunks + blockIdx.x) * kGroundChunk;
+  for (int i = threadIdx.x; i < cnt; i += kGroundBlock) out[i] = s_pairs[i];
+  if (threadIdx.x == 0) g.pair_count[(long)b * g.max_chunks + blockIdx.x] = cnt;
 }
 
 // ------------------------------------------------------------------------------------------ K2
@@ -82,19 +92,35 @@ polar_minz_kernel(MotDevParams p, GroundBuffers g) {
 // passes are fused so only height / ground flag / smoothed are kept).
 constexpr int kFilterBlock = 960;  // 9600 cells = 10 per thread
 __global__ void MOT_LAUNCH_BOUNDS(kFilterBlock)
-polar_filter_kernel(MotDevParams p, GroundBuffers g, int reset_minz) {
+polar_filter_kernel(MotDevParams p, GroundBuffers g) {
   __shared__ float s_h[MOT_POLAR_CELLS];       // height
   __shared__ float s_h2[MOT_POLAR_CELLS];      // height after the median pass
   __shared__ unsigned char s_g[MOT_POLAR_CELLS];   // ground flag after decision
   __shared__ unsigned char s_g2[MOT_POLAR_CELLS];  // ground flag after median
+  __shared__ int s_minz[MOT_POLAR_CELLS];        // createAndMapPolarGrid's per-cell min z (ordered keys)
+  __shared__ int s_pcnt[256];
   const int b = blockIdx.x;
-  int* __restrict__ minz = g.minz + (long)b * MOT_POLAR_CELLS;
   float* __restrict__ hg = g.hg + (long)b * MOT_POLAR_CELLS;
+  // fold the partial minima of every min-z workgroup of this frame (Cell::Cell: minZ = 1000, ground_removal.cpp:35-38)
+  const int nchunks = (g.n[b] + kGroundChunk - 1) / kGroundChunk;
+  for (int i = threadIdx.x; i < MOT_POLAR_CELLS; i += kFilterBlock) s_minz[i] = kMinzInit;
+  for (int c0 = 0; c0 < nchunks; c0 += 256) {
+    __syncthreads();
+    if ((int)threadIdx.x < 256 && c0 + (int)threadIdx.x < nchunks) s_pcnt[threadIdx.x] = g.pair_count[(long)b * g.max_chunks + c0 + threadIdx.x];
+    __syncthreads();
+    const int wv = threadIdx.x >> 6, ln = threadIdx.x & 63, nwv = kFilterBlock / 64;
+    const int lim = nchunks - c0 < 256 ? nchunks - c0 : 256;
+    for (int ch = wv; ch < lim; ch += nwv) {   // a wave per workgroup list; the loads of successive lists are independent
+      const int cnt = s_pcnt[ch];
+      const uint2* __restrict__ src = g.pairs + ((long)b * g.max_chunks + c0 + ch) * kGroundChunk;
+      for (int e = ln; e < cnt; e += 64) { uint2 q = src[e]; atomicMin(&s_minz[q.x], (int)q.y); }
+    }
+  }
+  __syncthreads();
 
   // height clamp, ground_removal.cpp:191-197
   for (int i = threadIdx.x; i < MOT_POLAR_CELLS; i += kFilterBlock) {
-    float zi = mot_key_float(minz[i]);
-    if (reset_minz) minz[i] = kMinzInit;  // leave the grid ready for the next frame
+    float zi = mot_key_float(s_minz[i]);
     float h;
     if (zi > p.t_hmin && zi < p.t_hmax) h = zi;
     else if (zi > p.t_hmax) h = p.h_sensor;
@@ -295,9 +321,8 @@ void mot_launch_ground_kernel(int which, const MotDevParams& p, const GroundBuff
   int chunks = (max_n + kGroundChunk - 1) / kGroundChunk;
   if (chunks < 1) chunks = 1;
   if (which == 0) hipLaunchKernelGGL(polar_minz_kernel, dim3(chunks, batch), dim3(kGroundBlock), 0, stream, p, g);
-  else if (which == 1) hipLaunchKernelGGL(polar_filter_kernel, dim3(batch), dim3(kFilterBlock), 0, stream, p, g, 1);
+  else if (which == 1) hipLaunchKernelGGL(polar_filter_kernel, dim3(batch), dim3(kFilterBlock), 0, stream, p, g);
   else if (which == 2) hipLaunchKernelGGL(classify_compact_kernel, dim3(chunks, batch), dim3(kGroundBlock), 0, stream, p, g);
-  else if (which == 3) hipLaunchKernelGGL(polar_filter_kernel, dim3(batch), dim3(kFilterBlock), 0, stream, p, g, 0);
 }
 
 void mot_launch_ground(const MotDevParams& p, const GroundBuffers& g, int batch, int max_n, hipStream_t stream) {

@@ -23,7 +23,8 @@ struct mot_ctx {
   // ground stage
   float4* d_in = nullptr;
   int* d_n = nullptr;
-  int* d_minz = nullptr;
+  uint2* d_pairs = nullptr;
+  int* d_pair_count = nullptr;
   float* d_hg = nullptr;
   unsigned long long* d_desc = nullptr;
   int* d_ticket = nullptr;
@@ -168,7 +169,7 @@ static int make_dev_params(const mot_params& p, MotDevParams* d, std::string* er
 
 extern "C" void mot_destroy(mot_ctx* c) {
   if (!c) return;
-  void* bufs[] = {c->d_in, c->d_n, c->d_minz, c->d_hg, c->d_desc, c->d_ticket, c->d_elev, c->d_ground, c->d_mask, c->d_counts,
+  void* bufs[] = {c->d_in, c->d_n, c->d_pairs, c->d_pair_count, c->d_hg, c->d_desc, c->d_ticket, c->d_elev, c->d_ground, c->d_mask, c->d_counts,
                   c->d_plane_a, c->d_plane_b, c->d_grid, c->d_label, c->d_stats, c->d_cand, c->d_boxes, c->d_box_cluster, c->d_rng, c->d_poly, c->d_tiles,
                   c->d_tracks, c->d_nt, c->d_tboxes, c->d_targs, c->d_gate, c->d_prog, c->d_live, c->d_tout, c->d_tflags, c->d_ego};
   for (void* b : bufs) if (b) (void)hipFree(b);
@@ -202,7 +203,8 @@ static int create_impl(mot_ctx* c) {
   c->max_chunks = (int)((N + kGroundChunk - 1) / kGroundChunk) + 1;
   MOT_HIP(c, hipMalloc(&c->d_in, B * N * sizeof(float4)));
   MOT_HIP(c, hipMalloc(&c->d_n, B * sizeof(int)));
-  MOT_HIP(c, hipMalloc(&c->d_minz, B * MOT_POLAR_CELLS * sizeof(int)));
+  MOT_HIP(c, hipMalloc(&c->d_pairs, B * c->max_chunks * kGroundChunk * sizeof(uint2)));
+  MOT_HIP(c, hipMalloc(&c->d_pair_count, B * c->max_chunks * sizeof(int)));
   MOT_HIP(c, hipMalloc(&c->d_hg, B * MOT_POLAR_CELLS * sizeof(float)));
   MOT_HIP(c, hipMalloc(&c->d_desc, B * c->max_chunks * sizeof(unsigned long long)));
   MOT_HIP(c, hipMalloc(&c->d_ticket, B * sizeof(int)));
@@ -252,7 +254,7 @@ static int create_impl(mot_ctx* c) {
   c->ego.assign(B, mot_ctx::SlotEgo());
   c->h_targs.assign(B, TrackFrameArgs());
   c->h_ego.assign(B, EgoPose());
-  MOT_HIP(c, hipMemsetD32Async(c->d_minz, kMinzInit, B * MOT_POLAR_CELLS, c->stream));
+  MOT_HIP(c, hipMemsetAsync(c->d_pair_count, 0, B * c->max_chunks * sizeof(int), c->stream));
   MOT_HIP(c, hipMemsetAsync(c->d_counts, 0, B * kCountsStride * sizeof(int), c->stream));
   MOT_HIP(c, hipMemsetAsync(c->d_n, 0, B * sizeof(int), c->stream));
   MOT_HIP(c, hipMemsetAsync(c->d_ticket, 0, B * sizeof(int), c->stream));
@@ -311,7 +313,7 @@ static int next_epoch(mot_ctx* c) {
 static GroundBuffers ground_buffers(mot_ctx* c, const float4* in, long stride, bool want_mask) {
   GroundBuffers g;
   g.epoch = c->epoch;
-  g.in = in; g.in_stride = stride; g.n = c->d_n; g.minz = c->d_minz; g.hg = c->d_hg; g.desc = c->d_desc;
+  g.in = in; g.in_stride = stride; g.n = c->d_n; g.pairs = c->d_pairs; g.pair_count = c->d_pair_count; g.hg = c->d_hg; g.desc = c->d_desc;
   g.ticket = c->d_ticket; g.elevated = c->d_elev; g.ground = c->d_ground; g.mask = want_mask ? c->d_mask : nullptr;
   g.counts = c->d_counts; g.cap = c->cap; g.max_chunks = c->max_chunks;
   return g;
@@ -514,8 +516,8 @@ extern "C" int mot_time_stage(mot_ctx* c, int stage, int batch, int iters, float
     case 1: s = {{0}, {kC1, kC2}, {0}}; break;
     case 2: s = {{0}, {kB1, kB2, kB2b, kB3}, {0}}; break;
     case 100: s = {{0}, {kK1, kK2, kK3, kC1, kC2, kB1, kB2, kB2b, kB3}, {0}}; break;
-    case kK1: s = {{0}, {kK1}, {kK2}}; break;
-    case kK2: s = {{kK1}, {kK2}, {0}}; break;
+    case kK1: s = {{0}, {kK1}, {0}}; break;
+    case kK2: s = {{0}, {kK2}, {0}}; break;
     case kK3: s = {{0}, {kK3}, {0}}; break;
     case kC1: s = {{0}, {kC1}, {kC2}}; break;
     case kC2: s = {{kC1}, {kC2}, {0}}; break;

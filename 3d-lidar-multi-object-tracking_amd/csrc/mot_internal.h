@@ -53,7 +53,8 @@ struct GroundBuffers {
   const float4* in;        // [B][in_stride] points
   long in_stride;          // in points
   const int* n;            // [B] points per frame (device)
-  int* minz;               // [B][9600] ordered-int min z, all kMinzInit between calls
+  uint2* pairs;            // [B][max_chunks][kGroundChunk] {polar cell, ordered-int key of a partial min z}
+  int* pair_count;         // [B][max_chunks] entries each workgroup of the min-z kernel produced
   float* hg;               // [B][9600] hGround of ground cells, -inf for non-ground cells
   unsigned long long* desc;  // [B][max_chunks]
   int* ticket;             // [B], zero between launches (the workgroup drawing the last ticket re-arms it)

@@ -87,6 +87,8 @@ def main():
     ap.add_argument("--batch", type=int, default=64, help="sensor streams (one frame each) per GPU per step")
     ap.add_argument("--points", type=int, default=120000)
     ap.add_argument("--frames", type=int, default=4, help="distinct consecutive frames resident per stream")
+    ap.add_argument("--contexts", type=int, default=2, help="contexts (HIP streams) per GPU the streams are split over: the "
+                    "latency-bound kernels of one (CCL, polygon, tracker: one workgroup per stream) overlap the streaming kernels of the other")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -120,33 +122,43 @@ def main():
         for b in range(B):
             host[b, :N] = scenes[b % n_scene][f]
         dev_frames.append(torch.from_numpy(host).cuda())
-    sizes = [N] * B
-    ctx = mot.Context(device=local, max_points=stride, max_batch=B, max_tracks_total=8192)
-    gather = multi.TrackGather(B, GATHER_TRACKS, world, "cuda") if world > 1 else None
+    NC = max(1, min(args.contexts, B))
+    assert B % NC == 0, "--batch must be divisible by --contexts"
+    Bc = B // NC
+    sizes = [N] * Bc
+    ctxs = [mot.Context(device=local, max_points=stride, max_batch=Bc, max_tracks_total=8192) for _ in range(NC)]
+    ctx = ctxs[0]
+    gathers = [multi.TrackGather(Bc, GATHER_TRACKS, world, "cuda") for _ in range(NC)] if world > 1 else None
     torch.cuda.synchronize()
 
     step_no = [0]
 
     def step():
         k = step_no[0]; step_no[0] += 1
-        if k % 200 == 0:
-            ctx.reset()  # a stream restarts: the reference never frees tracks, so long runs are cut into sequences
-        ts = [1.0e9 + (k % 200) * 1.0e5] * B  # microsecond stamps => dt = 0.1 s
-        ctx.frames_dev(dev_frames[k % F].data_ptr(), stride * 4, sizes, run_tracker=True, timestamps=ts,
-                       ego_v=[0.0] * B, ego_yaw=[0.0] * B)
-        if world > 1:  # the per-step result block crosses GPUs over RCCL / xGMI
-            gather.step(ctx)
+        ts = [1.0e9 + (k % 200) * 1.0e5] * Bc  # microsecond stamps => dt = 0.1 s
+        for ci, cx in enumerate(ctxs):  # asynchronous launches on NC HIP streams
+            if k % 200 == 0:
+                cx.reset()  # a stream restarts: the reference never frees tracks, so long runs are cut into sequences
+            cx.frames_dev(dev_frames[k % F].data_ptr() + ci * Bc * stride * 16, stride * 4, sizes, run_tracker=True, timestamps=ts,
+                          ego_v=[0.0] * Bc, ego_yaw=[0.0] * Bc)
+        if world > 1:  # the per-step result blocks cross GPUs over RCCL / xGMI
+            for ci, cx in enumerate(ctxs):
+                gathers[ci].step(cx)
+
+    def sync_all():
+        for cx in ctxs:
+            cx.synchronize()
 
     for _ in range(args.warmup):
         step()
-    ctx.synchronize()
+    sync_all()
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
-    ctx.synchronize()
+    sync_all()
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -163,27 +175,28 @@ def main():
         kernels = {"polar_minz_kernel": 10, "polar_filter_kernel": 11, "classify_compact_kernel": 12,
                    "cart_occupancy_kernel": 20, "ccl_kernel": 21, "label_stats_kernel": 30, "cluster_gather_kernel": 31,
                    "cluster_rect_kernel": 33, "box_finalize_kernel": 32, "track_step_kernel": 40}
-        k_ms = {k: ctx.time_stage(v, B, it if v != 40 else 5) for k, v in kernels.items()}
-        stage_ms = {"ground": ctx.time_stage(0, B, it), "cluster": ctx.time_stage(1, B, it), "box": ctx.time_stage(2, B, it),
-                    "stateless": ctx.time_stage(100, B, it)}
-        counts = [ctx.get_ground(b, want_clouds=False) for b in range(B)]
+        k_ms = {k: ctx.time_stage(v, Bc, it if v != 40 else 5) for k, v in kernels.items()}
+        stage_ms = {"ground": ctx.time_stage(0, Bc, it), "cluster": ctx.time_stage(1, Bc, it), "box": ctx.time_stage(2, Bc, it),
+                    "stateless": ctx.time_stage(100, Bc, it)}
+        counts = [ctx.get_ground(b, want_clouds=False) for b in range(Bc)]
         ne_tot = sum(c["n_elevated"] for c in counts); ng_tot = sum(c["n_ground"] for c in counts)
         cl0 = ctx.get_clusters(0); bx0 = ctx.get_boxes(0)
         G = ctx.params.num_grid
         # algorithmic HBM bytes per launch (DESIGN.md §"bytes per unit"): what a kernel must read and write once
-        alg_bytes = {"polar_minz_kernel": 16.0 * N * B,
-                     "polar_filter_kernel": 8.0 * 9600 * B,
-                     "classify_compact_kernel": 16.0 * N * B + 16.0 * (ne_tot + ng_tot) + 1.0 * N * B,
+        BL = Bc  # frames per launch (one context)
+        alg_bytes = {"polar_minz_kernel": 16.0 * N * BL,
+                     "polar_filter_kernel": 8.0 * 9600 * BL,
+                     "classify_compact_kernel": 16.0 * N * BL + 16.0 * (ne_tot + ng_tot) + 1.0 * N * BL,
                      "cart_occupancy_kernel": 16.0 * ne_tot,
-                     "ccl_kernel": (2 * 2048 * 4 + 4.0 * G * G) * B,
+                     "ccl_kernel": (2 * 2048 * 4 + 4.0 * G * G) * BL,
                      "label_stats_kernel": (16.0 + 4.0) * ne_tot,
                      "cluster_gather_kernel": (4.0 + 16.0) * ne_tot,
                      "cluster_rect_kernel": 4.0 * ne_tot / 8,
-                     "box_finalize_kernel": 96.0 * B,
-                     "track_step_kernel": (2 * 1624.0 + 144.0) * max(tr0["n"], 1) * B}
+                     "box_finalize_kernel": 96.0 * BL,
+                     "track_step_kernel": (2 * 1624.0 + 144.0) * max(tr0["n"], 1) * BL}
         dom = max(k_ms, key=lambda k: k_ms[k])
         achieved = alg_bytes[dom] / (k_ms[dom] * 1e-3) / 1e9
-        frame_bytes = sum(alg_bytes.values()) / B
+        frame_bytes = sum(alg_bytes.values()) / BL
         frames = B * args.steps * world
         out = {
             "metric": "LiDAR frames/sec (120k-pt 64-beam cloud) end-to-end ground->cluster->track",
@@ -194,7 +207,7 @@ def main():
             "config": {"workload": "configs[3]: ground removal -> CCL -> box fit -> batched IMM-UKF-PDA tracker on one MI355X, "
                                    "120k-pt synthetic HDL-64E clouds, one frame per stream per step",
                        "points_per_frame": N, "frames_per_step_per_gpu": B, "streams": B * world,
-                       "elevated_pts_per_frame": ne_tot // B, "clusters_frame0": cl0["num_cluster"], "boxes_frame0": len(bx0["boxes"]),
+                       "contexts_per_gpu": NC, "frames_per_launch": BL, "elevated_pts_per_frame": ne_tot // BL, "clusters_frame0": cl0["num_cluster"], "boxes_frame0": len(bx0["boxes"]),
                        "tracks_stream0": int(tr0["n"]), "live_tracks_stream0": int((tr0["track_manage"] > 0).sum()),
                        "parallelism": f"stream-sharded x{world}" + (", all_gather of live-track records (RCCL)" if world > 1 else "")},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
