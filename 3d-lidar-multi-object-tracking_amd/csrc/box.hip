@@ -23,6 +23,7 @@
 //  * fp32 throughout, reference operation order, -ffp-contract=off. Double atan2/cos/sin of the rectangle
 //    angle come from the device math library; they are rounded to fp32 immediately.
 #include "mot_internal.h"
+#include "mot_wave.h"
 
 #ifndef MOT_HIPEMU
 #define MOT_LAUNCH_BOUNDS(n) __launch_bounds__(n)
@@ -101,12 +102,12 @@ label_stats_kernel(MotDevParams p, ClusterBuffers c) {
     int entry = 0;  // wave-uniform
     while (active) {  // one trip per distinct cluster among the 64 points of this wave
       int leader = __ffsll(active) - 1;
-      int l = __shfl(lab, leader, 64);
+      int l = wave_bcast_i32(lab, leader);
       bool mine = (lab == l);
       unsigned long long mm = __ballot(mine);
-      unsigned long long rmin = wave_min_t<unsigned long long>(mine ? kmin : kArgminInit);
-      unsigned long long rmax = wave_max_t<unsigned long long>(mine ? kmax : kArgmaxInit);
-      int rz = wave_max_t<int>(mine ? zkey : mot_float_key(-99.f));
+      unsigned long long rmin = wave_reduce_u64(mine ? kmin : kArgminInit, OpMinU64());
+      unsigned long long rmax = wave_reduce_u64(mine ? kmax : kArgmaxInit, OpMaxU64());
+      int rz = wave_reduce_i32(mine ? zkey : mot_float_key(-99.f), OpMaxI());
       if (lane == leader) {  // the leader is the lowest lane = the smallest index of the group
         ClusterStats* s = &stats[l - 1];
         atomicAdd(&s->count, __popcll(mm));
@@ -733,8 +734,8 @@ void mot_launch_box_kernel(int which, const MotDevParams& p, const ClusterBuffer
   int chunks = (max_n + kLabelChunk - 1) / kLabelChunk;
   if (chunks < 1) chunks = 1;
   if (which == 0) hipLaunchKernelGGL(label_stats_kernel, dim3(chunks, batch), dim3(kLabelBlock), 0, stream, p, c);
-  else if (which == 1) hipLaunchKernelGGL(cluster_gather_kernel, dim3(48, batch), dim3(kBoxBlock), 0, stream, p, c);
-  else if (which == 3) hipLaunchKernelGGL(cluster_rect_kernel, dim3(96, batch), dim3(kRectBlock), 0, stream, p, c);
+  else if (which == 1) hipLaunchKernelGGL(cluster_gather_kernel, dim3(12, batch), dim3(kBoxBlock), 0, stream, p, c);  // clusters beyond 12 per frame loop
+  else if (which == 3) hipLaunchKernelGGL(cluster_rect_kernel, dim3(24, batch), dim3(kRectBlock), 0, stream, p, c);
   else if (which == 2) hipLaunchKernelGGL(box_finalize_kernel, dim3(batch), dim3(kFinalBlock), 0, stream, p, c);
 }
 

@@ -25,6 +25,7 @@
 //    ids come from an atomic ticket so a predecessor is always already running).
 //  * all fp32/fp64 expressions keep the reference's operation order; build with -ffp-contract=off.
 #include "mot_internal.h"
+#include "mot_wave.h"
 
 #ifndef MOT_HIPEMU
 #define MOT_LAUNCH_BOUNDS(n) __launch_bounds__(n)
@@ -34,14 +35,7 @@
 
 __device__ __forceinline__ int wave_lane() { return (int)(threadIdx.x & 63); }
 
-__device__ __forceinline__ int wave_min_i32(int v) {
-#pragma unroll
-  for (int m = 32; m >= 1; m >>= 1) {
-    int o = __shfl_xor(v, m, 64);
-    v = o < v ? o : v;
-  }
-  return v;
-}
+__device__ __forceinline__ int wave_min_i32(int v) { return wave_reduce_i32(v, OpMinI()); }
 
 // ------------------------------------------------------------------------------------------ K1
 // filterCloud (:46-64) + createAndMapPolarGrid (:79-92) + Cell::updateMinZ (:40-42)
@@ -73,7 +67,7 @@ polar_minz_kernel(MotDevParams p, GroundBuffers g) {
     unsigned long long active = __ballot(cell >= 0);
     while (active) {                          // wave-uniform loop: one trip per distinct cell in the wave
       int leader = __ffsll(active) - 1;
-      int c = __shfl(cell, leader, 64);
+      int c = wave_bcast_i32(cell, leader);
       bool mine = (cell == c);
       int v = wave_min_i32(mine ? key : 0x7fffffff);
       if (lane == leader) { int pos = atomicAdd(&s_count, 1); s_pairs[pos] = make_uint2((unsigned)c, (unsigned)v); }

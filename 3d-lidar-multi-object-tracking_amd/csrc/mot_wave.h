@@ -1,0 +1,58 @@
+// mot_wave.h — wave64 reductions on DPP (data-parallel primitives) instead of ds_bpermute shuffles. Product code.
+// A butterfly over __shfl_xor costs six LDS-crossbar round trips per reduction on gfx950; the match loops of the
+// min-z and label kernels run one to three reductions per distinct key per wave, and rocprof showed them LDS-issue
+// bound. DPP row operations are plain VALU instructions with a lane-permute modifier.
+#ifndef MOT_WAVE_H_
+#define MOT_WAVE_H_
+
+#ifndef MOT_HIPEMU
+// v' = op(v, v permuted by ctrl); lanes whose source is invalid keep v (bound_ctrl off, old = v)
+#define MOT_DPP_I32(v, ctrl, rmask) __builtin_amdgcn_update_dpp((v), (v), (ctrl), (rmask), 0xf, false)
+// DPP controls (GCN3/CDNA ISA): quad_perm [1,0,3,2] = 0xB1, [2,3,0,1] = 0x4E, row_half_mirror = 0x141,
+// row_mirror = 0x140, row_bcast15 = 0x142 (row_mask 0xA), row_bcast31 = 0x143 (row_mask 0xC)
+template <typename Op>
+__device__ __forceinline__ int wave_reduce_i32(int v, Op op) {
+  v = op(v, MOT_DPP_I32(v, 0xB1, 0xf));
+  v = op(v, MOT_DPP_I32(v, 0x4E, 0xf));
+  v = op(v, MOT_DPP_I32(v, 0x141, 0xf));
+  v = op(v, MOT_DPP_I32(v, 0x140, 0xf));
+  v = op(v, MOT_DPP_I32(v, 0x142, 0xa));
+  v = op(v, MOT_DPP_I32(v, 0x143, 0xc));
+  return __builtin_amdgcn_readlane(v, 63);  // the last lane holds the reduction of all 64
+}
+template <typename Op>
+__device__ __forceinline__ unsigned long long wave_reduce_u64(unsigned long long v, Op op) {
+#define MOT_DPP_U64(x, ctrl, rmask)                                                                               \
+  (((unsigned long long)(unsigned)__builtin_amdgcn_update_dpp((int)((x) >> 32), (int)((x) >> 32), (ctrl), (rmask), 0xf, false) << 32) | \
+   (unsigned)__builtin_amdgcn_update_dpp((int)(x), (int)(x), (ctrl), (rmask), 0xf, false))
+  v = op(v, MOT_DPP_U64(v, 0xB1, 0xf));
+  v = op(v, MOT_DPP_U64(v, 0x4E, 0xf));
+  v = op(v, MOT_DPP_U64(v, 0x141, 0xf));
+  v = op(v, MOT_DPP_U64(v, 0x140, 0xf));
+  v = op(v, MOT_DPP_U64(v, 0x142, 0xa));
+  v = op(v, MOT_DPP_U64(v, 0x143, 0xc));
+#undef MOT_DPP_U64
+  unsigned lo = __builtin_amdgcn_readlane((unsigned)v, 63), hi = __builtin_amdgcn_readlane((unsigned)(v >> 32), 63);
+  return ((unsigned long long)hi << 32) | lo;
+}
+__device__ __forceinline__ int wave_bcast_i32(int v, int lane) { return __builtin_amdgcn_readlane(v, lane); }
+#else
+template <typename Op>
+__device__ __forceinline__ int wave_reduce_i32(int v, Op op) {
+  for (int m = 32; m >= 1; m >>= 1) v = op(v, __shfl_xor(v, m, 64));
+  return v;
+}
+template <typename Op>
+__device__ __forceinline__ unsigned long long wave_reduce_u64(unsigned long long v, Op op) {
+  for (int m = 32; m >= 1; m >>= 1) v = op(v, __shfl_xor(v, m, 64));
+  return v;
+}
+__device__ __forceinline__ int wave_bcast_i32(int v, int lane) { return __shfl(v, lane, 64); }
+#endif
+
+struct OpMinI { __device__ __forceinline__ int operator()(int a, int b) const { return a < b ? a : b; } };
+struct OpMaxI { __device__ __forceinline__ int operator()(int a, int b) const { return a > b ? a : b; } };
+struct OpMinU64 { __device__ __forceinline__ unsigned long long operator()(unsigned long long a, unsigned long long b) const { return a < b ? a : b; } };
+struct OpMaxU64 { __device__ __forceinline__ unsigned long long operator()(unsigned long long a, unsigned long long b) const { return a > b ? a : b; } };
+
+#endif  // MOT_WAVE_H_

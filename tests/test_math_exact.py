@@ -54,6 +54,7 @@ FAST_SRC = r"""
 #include <cstdlib>
 #include <cstring>
 struct float4 { float x, y, z, w; };
+struct uint2 { unsigned x, y; };
 typedef void* hipStream_t;
 #include "mot_internal.h"
 static unsigned long long s = 88172645463325252ULL;
