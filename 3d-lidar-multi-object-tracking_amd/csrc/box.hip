@@ -69,10 +69,14 @@ __global__ void stats_init_kernel(ClusterBuffers c) {
 // getClusteredPoints :46-72 (label of every point) + the per-point loop of getBoundingBox :239-293
 __global__ void MOT_LAUNCH_BOUNDS(kLabelBlock)
 label_stats_kernel(MotDevParams p, ClusterBuffers c) {
+  __shared__ PointGroup s_groups[kLabelChunk];  // at most one group per point
+  __shared__ int s_ngroups, s_gbase;
   const int b = blockIdx.y;
   const int n = c.counts[b * kCountsStride + kCntElev];
   const long base = (long)blockIdx.x * kLabelChunk;
   if (base >= n) return;
+  if (threadIdx.x == 0) s_ngroups = 0;
+  __syncthreads();
   const int num_cluster = c.counts[b * kCountsStride + kCntClusters];
   const float4* __restrict__ pts = c.elevated + (long)b * c.cap;
   const int* __restrict__ grid = c.grid + (long)b * (MOT_MAX_GRID * MOT_MAX_GRID);
@@ -98,8 +102,7 @@ label_stats_kernel(MotDevParams p, ClusterBuffers c) {
     unsigned long long kmax = (m > -999.f) ? (((unsigned long long)ukey(m) << 32) | (unsigned)~(unsigned)i) : kArgmaxInit;
     int zkey = (q.z > -99.f) ? mot_float_key(q.z + 0.0f) : mot_float_key(-99.f);  // `pZ > maxZ`, maxZ = -99
     unsigned long long active = __ballot(lab > 0);
-    TileSummary* ts = c.tiles + (long)b * ((c.cap + 63) / 64) + (base + k * kLabelBlock + (threadIdx.x & ~63)) / 64;
-    int entry = 0;  // wave-uniform
+    const int tile = (int)((base + k * kLabelBlock + (threadIdx.x & ~63)) / 64);
     while (active) {  // one trip per distinct cluster among the 64 points of this wave
       int leader = __ffsll(active) - 1;
       int l = wave_bcast_i32(lab, leader);
@@ -115,17 +118,78 @@ label_stats_kernel(MotDevParams p, ClusterBuffers c) {
         atomicMax(&s->maxz_key, rz);
         if (rmin != kArgminInit) atomicMin(&s->argmin, rmin);
         if (rmax != kArgmaxInit) atomicMax(&s->argmax, rmax);
-        if (entry < kTileEntries) { ts->mask[entry] = mm; ts->label[entry] = l; }
+        PointGroup g; g.mask = mm; g.label = l; g.tile = tile;
+        s_groups[atomicAdd(&s_ngroups, 1)] = g;
       }
-      entry++;
       active &= ~mm;
     }
-    if (lane == 0 && base + k * kLabelBlock + (threadIdx.x & ~63) < n) ts->n = entry <= kTileEntries ? entry : kTileEntries + 1;
   }
+  // the workgroup's (tile, cluster) groups leave with ONE returning global atomic (a slot reservation)
+  __syncthreads();
+  const int ng = s_ngroups;
+  if (threadIdx.x == 0) s_gbase = ng ? atomicAdd(&c.counts[b * kCountsStride + kCntGroups], ng) : 0;
+  __syncthreads();
+  const int gb = s_gbase;
+  PointGroup* __restrict__ out = c.groups + (long)b * c.group_cap;
+  for (int i = threadIdx.x; i < ng; i += kLabelBlock) if (gb + i < c.group_cap) out[gb + i] = s_groups[i];
+}
+
+// ------------------------------------------------------------------------------------------ B1b
+// one workgroup per frame: turns the (tile, cluster) groups into the cluster-sorted point index
+//   sorted[cluster_start[c] + r] = index of the r-th point of cluster c in input order
+// (the reference's getClusteredPoints, box_fitting.cpp:46-72, without copying a point). The first slot of a group is
+// cluster_start + the number of the cluster's points in EARLIER tiles = a sum over the other groups of the cluster.
+constexpr int kIndexBlock = 1024;
+constexpr int kGroupsLds = 8192;
+__global__ void MOT_LAUNCH_BOUNDS(kIndexBlock)
+cluster_index_kernel(ClusterBuffers c) {
+  __shared__ uint2 s_key[kGroupsLds];          // {label << 16 | tile (when both fit) ..., points} -- see below
+  __shared__ int s_start[kMaxClusters + 1];
+  __shared__ int s_part[kIndexBlock / 64];
+  const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int num_cluster = min(c.counts[b * kCountsStride + kCntClusters], kMaxClusters);
+  int E = c.counts[b * kCountsStride + kCntGroups];
+  if (E > c.group_cap) { E = c.group_cap; if (tid == 0) atomicOr(&c.counts[b * kCountsStride + kCntFlags], (int)kFlagGroupOverflow); }
+  const PointGroup* __restrict__ groups = c.groups + (long)b * c.group_cap;
+  const ClusterStats* __restrict__ stats = c.stats + (long)b * kMaxClusters;
+  // exclusive scan of the cluster sizes (4 per thread)
+  {
+    int v[4], sum = 0;
+#pragma unroll
+    for (int k = 0; k < 4; k++) { int ci = tid * 4 + k; v[k] = ci < num_cluster ? stats[ci].count : 0; sum += v[k]; }
+    int incl = sum;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) { int o = __shfl_up(incl, d, 64); if (lane >= d) incl += o; }
+    if (lane == 63) s_part[wave] = incl;
+    __syncthreads();
+    int run = incl - sum;
+    for (int w2 = 0; w2 < wave; w2++) run += s_part[w2];
+#pragma unroll
+    for (int k = 0; k < 4; k++) { int ci = tid * 4 + k; if (ci <= kMaxClusters) s_start[ci] = run; run += v[k]; }
+  }
+  const bool in_lds = E <= kGroupsLds;
+  if (in_lds) for (int e = tid; e < E; e += kIndexBlock) { PointGroup g = groups[e]; s_key[e] = make_uint2((unsigned)g.label, ((unsigned)g.tile << 8) | (unsigned)__popcll(g.mask)); }
+  __syncthreads();
+  int* __restrict__ cstart = c.cluster_start + (long)b * (kMaxClusters + 1);
+  for (int ci = tid; ci <= num_cluster; ci += kIndexBlock) cstart[ci] = s_start[ci];
+  int* __restrict__ sorted = c.sorted + (long)b * c.cap;
+  for (int e = tid; e < E; e += kIndexBlock) {
+    const PointGroup g = groups[e];
+    int before = 0;  // points of the same cluster in earlier tiles
+    if (in_lds) {
+      for (int f = 0; f < E; f++) { uint2 q = s_key[f]; if ((int)q.x == g.label && (int)(q.y >> 8) < g.tile) before += (int)(q.y & 0xffu); }
+    } else {  // more groups than fit in LDS (heavily interleaved clusters): same sum straight from L2
+      for (int f = 0; f < E; f++) { PointGroup h = groups[f]; if (h.label == g.label && h.tile < g.tile) before += __popcll(h.mask); }
+    }
+    int pos = s_start[g.label - 1] + before;
+    unsigned long long m = g.mask;
+    while (m) { sorted[pos++] = g.tile * 64 + __ffsll(m) - 1; m &= m - 1ull; }
+  }
+  if (tid == 0) c.counts[b * kCountsStride + kCntGroups] = 0;  // re-arm
 }
 
 // ------------------------------------------------------------------------------------------ B2
-constexpr int kBoxBlock = 1024;      // one workgroup (16 waves) per cluster, threads over the frame's 64-point tiles
+constexpr int kBoxBlock = 256;       // one workgroup (4 waves) per cluster
 constexpr int kBoxWaves = kBoxBlock / 64;
 constexpr int kGatherDepth = 8;
 constexpr int kPicCols = 1024;       // pixel columns 0..900
@@ -156,41 +220,10 @@ __device__ bool rule_based_filter(const MotDevParams& p, const float* pc, float 
   return false;
 }
 
-// lanes of tile t (points 64 t .. 64 t + 63) that belong to cluster `want`
-__device__ __forceinline__ unsigned long long tile_mask(const TileSummary* __restrict__ tiles, const int* __restrict__ label,
-                                                        int t, int n, int want) {
-  const TileSummary* ts = &tiles[t];
-  const int4 l0 = *(const int4*)&ts->label[0], l1 = *(const int4*)&ts->label[4];  // independent 16-byte loads
-  const int ne = ts->n;
-  if (ne <= kTileEntries) {
-    int e = l0.x == want ? 0 : l0.y == want ? 1 : l0.z == want ? 2 : l0.w == want ? 3 : l1.x == want ? 4 : l1.y == want ? 5 : l1.z == want ? 6 : l1.w == want ? 7 : -1;
-    return (e >= 0 && e < ne) ? ts->mask[e] : 0ull;
-  }
-  unsigned long long m = 0ull;  // more than kTileEntries clusters meet in this tile (rare): read the 64 labels
-  int4 v[16];
-#pragma unroll
-  for (int k = 0; k < 16; k++) {
-    int i = t * 64 + 4 * k;
-    v[k] = (i + 3 < n) ? *(const int4*)&label[i] : make_int4(i < n ? label[i] : 0, i + 1 < n ? label[i + 1] : 0, i + 2 < n ? label[i + 2] : 0, 0);
-  }
-#pragma unroll
-  for (int k = 0; k < 16; k++) {
-    if (v[k].x == want) m |= 1ull << (4 * k);
-    if (v[k].y == want) m |= 1ull << (4 * k + 1);
-    if (v[k].z == want) m |= 1ull << (4 * k + 2);
-    if (v[k].w == want) m |= 1ull << (4 * k + 3);
-  }
-  return m;
-}
-__device__ __forceinline__ int nth_set_bit(unsigned long long m, int k) {  // position of the k-th (0-based) set bit
-  for (int j = 0; j < k; j++) m &= m - 1ull;
-  return __ffsll(m) - 1;
-}
-
 // ------------------------------------------------------------------------------------------ B2
-// one workgroup per cluster, threads over the frame's 64-point tiles (the label kernel left, per tile, which clusters
-// it touches and where): no walk over the points. L-shape branch completes here; the rectangle branch leaves the
-// cluster's candidate hull points (lowest / highest pixel of every pixel column) in the polygon pool.
+// one workgroup per cluster, threads over the cluster's OWN points through the cluster-sorted index (no walk over the
+// frame). L-shape branch completes here; the rectangle branch leaves the cluster's candidate hull points (lowest /
+// highest pixel of every pixel column) in the polygon pool.
 __global__ void MOT_LAUNCH_BOUNDS(kBoxBlock)
 cluster_gather_kernel(MotDevParams p, ClusterBuffers c) {
   __shared__ int s_colmin[kPicCols], s_colmax[kPicCols];
@@ -202,12 +235,19 @@ cluster_gather_kernel(MotDevParams p, ClusterBuffers c) {
   const int n = c.counts[b * kCountsStride + kCntElev];
   const int num_cluster = min(c.counts[b * kCountsStride + kCntClusters], kMaxClusters);
   const float4* __restrict__ pts = c.elevated + (long)b * c.cap;
-  const int* __restrict__ label = c.label + (long)b * c.cap;
-  const TileSummary* __restrict__ tiles = c.tiles + (long)b * ((c.cap + 63) / 64);
+  const int* __restrict__ sorted = c.sorted + (long)b * c.cap;
+  const int* __restrict__ cstart = c.cluster_start + (long)b * (kMaxClusters + 1);
   const int lane = lane_id(), wave = (int)(threadIdx.x >> 6), tid = (int)threadIdx.x;
-  const int ntiles = (n + 63) / 64;
+  (void)n;
 
   for (int ci = blockIdx.x; ci < num_cluster; ci += gridDim.x) {
+#ifdef MOT_DBG_TIMING
+    const long long t_start = clock64();
+#define MOT_T(slot) if (tid == 0) dbg_t[slot] = (int)(clock64() - t_start)
+    int dbg_t[6] = {0, 0, 0, 0, 0, 0};
+#else
+#define MOT_T(slot)
+#endif
     const ClusterStats st = c.stats[(long)b * kMaxClusters + ci];
     BoxCandidate cand;
     for (int k = 0; k < 8; k++) cand.pc[k] = 0.f;
@@ -237,6 +277,7 @@ cluster_gather_kernel(MotDevParams p, ClusterBuffers c) {
     const float slope = (maxMy - minMy) / (maxMx - minMx);
     bool lshape = slopeDist > (float)p.l_slope_dist && numPoints > p.l_num_points;  // :308
     if (p.lshape_side_cond) lshape = lshape && (maxMy > 8.f || maxMy < -5.f);
+    MOT_T(0);
 
     if (lshape) {  // ---------------------------------------------------------------- L-shape :310-356
       cand.branch = 0;
@@ -278,31 +319,12 @@ cluster_gather_kernel(MotDevParams p, ClusterBuffers c) {
         }
         __syncthreads();
       }
-      // the k-th point of the cluster in input order: exclusive prefix of the per-tile counts gives every tile its
-      // first rank; a sampled rank is then a bit position inside one tile's mask
-      int running = 0;
-#ifndef MOT_DBG_SKIP_LSHAPE_TILES
-      for (int t0 = 0; t0 < ntiles; t0 += kBoxBlock) {
-        const int t = t0 + tid;
-        unsigned long long m = t < ntiles ? tile_mask(tiles, label, t, n, ci + 1) : 0ull;
-        int cnt = __popcll(m), incl = cnt;
-#pragma unroll
-        for (int d = 1; d < 64; d <<= 1) { int o = __shfl_up(incl, d, 64); if (lane >= d) incl += o; }
-        if (lane == 63) s_wsum[wave] = incl;
-        __syncthreads();
-        int base = running + incl - cnt;
-        for (int w2 = 0; w2 < wave; w2++) base += s_wsum[w2];
-        int round_total = 0;
-        for (int w2 = 0; w2 < kBoxWaves; w2++) round_total += s_wsum[w2];
-        if (cnt > 0)
-          for (int j = 0; j < nsamp; j++) {
-            int r = s_rank[j];
-            if (r >= base && r < base + cnt) s_pidx[j] = t * 64 + nth_set_bit(m, r - base);
-          }
-        running += round_total;
-        __syncthreads();
-      }
-#endif
+      MOT_T(1);
+      // the k-th point of the cluster in input order is one lookup in the cluster-sorted index
+      const int first_slot = cstart[ci];
+      for (int j = tid; j < nsamp; j += kBoxBlock) s_pidx[j] = sorted[first_slot + s_rank[j]];
+      __syncthreads();
+      MOT_T(2);
       // farthest sampled point from the line through the two slope-extreme points; first maximum wins
       float pc[8];
       bool promising = false;
@@ -332,9 +354,13 @@ cluster_gather_kernel(MotDevParams p, ClusterBuffers c) {
         pc[4] = maxMx; pc[5] = maxMy; pc[6] = lastX; pc[7] = lastY;
         promising = rule_based_filter(p, pc, maxZ, numPoints);
       }
+      MOT_T(3);
       if (tid == 0) {
         if (!cand.undefined) for (int k = 0; k < 8; k++) cand.pc[k] = pc[k];
         cand.accepted = promising ? 1 : 0;
+#ifdef MOT_DBG_TIMING
+        cand.poly_off = dbg_t[0]; cand.poly_n = dbg_t[1]; cand.off_x = dbg_t[2]; cand.off_y = dbg_t[3];
+#endif
         c.cand[(long)b * kMaxClusters + ci] = cand;
       }
       __syncthreads();
@@ -342,37 +368,30 @@ cluster_gather_kernel(MotDevParams p, ClusterBuffers c) {
       cand.branch = 1;
       for (int i = tid; i < kPicCols; i += kBoxBlock) { s_colmin[i] = 0x7fffffff; s_colmax[i] = -0x7fffffff - 1; }
       __syncthreads();
-      // work item = half a tile (32 points): keeps the threads of a workgroup evenly loaded when one cluster owns most
-      // of the frame; up to kGatherDepth independent point loads are in flight per thread
-#ifndef MOT_DBG_SKIP_MAR_TILES
-      for (int w0 = 0; w0 < 2 * ntiles; w0 += kBoxBlock) {
-        const int item = w0 + tid, t = item >> 1;
-        unsigned long long m = t < ntiles ? tile_mask(tiles, label, t, n, ci + 1) : 0ull;
-        m &= (item & 1) ? 0xffffffff00000000ull : 0x00000000ffffffffull;
-        while (m) {
-          int idx[kGatherDepth]; float4 q[kGatherDepth];
+      const int first_slot = cstart[ci];
+      for (int j0 = 0; j0 < numPoints; j0 += kBoxBlock * kGatherDepth) {
+        int idx[kGatherDepth]; float4 q[kGatherDepth];  // kGatherDepth independent index loads, then point loads, in flight
 #pragma unroll
-          for (int u = 0; u < kGatherDepth; u++) if (m) { idx[u] = t * 64 + __ffsll(m) - 1; m &= m - 1ull; } else idx[u] = -1;
+        for (int u = 0; u < kGatherDepth; u++) { int j = j0 + u * kBoxBlock + tid; idx[u] = j < numPoints ? sorted[first_slot + j] : -1; }
 #pragma unroll
-          for (int u = 0; u < kGatherDepth; u++) q[u] = idx[u] >= 0 ? pts[idx[u]] : make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int u = 0; u < kGatherDepth; u++) q[u] = idx[u] >= 0 ? pts[idx[u]] : make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
-          for (int u = 0; u < kGatherDepth; u++) {
-            if (idx[u] >= 0) {
-              float roiX = q[u].x + p.roi_half, roiY = q[u].y + p.roi_half;  // :244-254
-              int x = (int)floorf(roiX * p.pic_scale), y = (int)floorf(roiY * p.pic_scale);
-              int picX = x;
-              int picY = (int)(p.pic_full - (float)y);
-              int offsetY = picY + offsetInitY;
-              if (picX >= 0 && picX < kPicCols) {  // look before the atomic: most points do not move an extreme
-                if (offsetY < s_colmin[picX]) atomicMin(&s_colmin[picX], offsetY);
-                if (offsetY > s_colmax[picX]) atomicMax(&s_colmax[picX], offsetY);
-              }
+        for (int u = 0; u < kGatherDepth; u++) {
+          if (idx[u] >= 0) {
+            float roiX = q[u].x + p.roi_half, roiY = q[u].y + p.roi_half;  // :244-254
+            int x = (int)floorf(roiX * p.pic_scale), y = (int)floorf(roiY * p.pic_scale);
+            int picX = x;
+            int picY = (int)(p.pic_full - (float)y);
+            int offsetY = picY + offsetInitY;
+            if (picX >= 0 && picX < kPicCols) {  // look before the atomic: most points do not move an extreme
+              if (offsetY < s_colmin[picX]) atomicMin(&s_colmin[picX], offsetY);
+              if (offsetY > s_colmax[picX]) atomicMax(&s_colmax[picX], offsetY);
             }
           }
         }
       }
-#endif
       __syncthreads();
+      MOT_T(1);
       if (wave == 0) {
         // compact the column extents into (x,y)-sorted points: 16 columns per lane, prefix over lanes
         int cnt = 0;
@@ -400,8 +419,12 @@ cluster_gather_kernel(MotDevParams p, ClusterBuffers c) {
         off = __shfl(off, 0, 64);
         int* pool = c.poly + (long)b * c.cap;
         for (int j = lane; j < total; j += 64) if (off + j < c.cap) pool[off + j] = ((int)(unsigned short)s_px[j]) | ((int)s_py[j] << 16);
+        MOT_T(2);
         if (lane == 0) {
           cand.poly_off = off; cand.poly_n = total; cand.off_x = offsetInitX; cand.off_y = offsetInitY;
+#ifdef MOT_DBG_TIMING
+          cand.pad = dbg_t[0]; cand.poly_off = dbg_t[1]; cand.poly_n = dbg_t[2];
+#endif
           c.cand[(long)b * kMaxClusters + ci] = cand;
         }
       }
@@ -734,13 +757,15 @@ void mot_launch_box_kernel(int which, const MotDevParams& p, const ClusterBuffer
   int chunks = (max_n + kLabelChunk - 1) / kLabelChunk;
   if (chunks < 1) chunks = 1;
   if (which == 0) hipLaunchKernelGGL(label_stats_kernel, dim3(chunks, batch), dim3(kLabelBlock), 0, stream, p, c);
-  else if (which == 1) hipLaunchKernelGGL(cluster_gather_kernel, dim3(12, batch), dim3(kBoxBlock), 0, stream, p, c);  // clusters beyond 12 per frame loop
+  else if (which == 1) hipLaunchKernelGGL(cluster_gather_kernel, dim3(32, batch), dim3(kBoxBlock), 0, stream, p, c);  // clusters beyond 32 per frame loop
   else if (which == 3) hipLaunchKernelGGL(cluster_rect_kernel, dim3(24, batch), dim3(kRectBlock), 0, stream, p, c);
+  else if (which == 4) hipLaunchKernelGGL(cluster_index_kernel, dim3(batch), dim3(kIndexBlock), 0, stream, c);
   else if (which == 2) hipLaunchKernelGGL(box_finalize_kernel, dim3(batch), dim3(kFinalBlock), 0, stream, p, c);
 }
 
 void mot_launch_box(const MotDevParams& p, const ClusterBuffers& c, int batch, int max_n, hipStream_t stream) {
   mot_launch_box_kernel(0, p, c, batch, max_n, stream);
+  mot_launch_box_kernel(4, p, c, batch, max_n, stream);
   mot_launch_box_kernel(1, p, c, batch, max_n, stream);
   mot_launch_box_kernel(3, p, c, batch, max_n, stream);
   mot_launch_box_kernel(2, p, c, batch, max_n, stream);

@@ -45,7 +45,9 @@ struct mot_ctx {
   int* d_box_cluster = nullptr;
   unsigned long long* d_rng = nullptr;
   int* d_poly = nullptr;
-  TileSummary* d_tiles = nullptr;
+  PointGroup* d_groups = nullptr;
+  int* d_cluster_start = nullptr;
+  int* d_sorted = nullptr;
   // tracker stage
   DevTrack* d_tracks = nullptr;
   int* d_nt = nullptr;
@@ -170,7 +172,7 @@ static int make_dev_params(const mot_params& p, MotDevParams* d, std::string* er
 extern "C" void mot_destroy(mot_ctx* c) {
   if (!c) return;
   void* bufs[] = {c->d_in, c->d_n, c->d_pairs, c->d_pair_count, c->d_hg, c->d_desc, c->d_ticket, c->d_elev, c->d_ground, c->d_mask, c->d_counts,
-                  c->d_plane_a, c->d_plane_b, c->d_grid, c->d_label, c->d_stats, c->d_cand, c->d_boxes, c->d_box_cluster, c->d_rng, c->d_poly, c->d_tiles,
+                  c->d_plane_a, c->d_plane_b, c->d_grid, c->d_label, c->d_stats, c->d_cand, c->d_boxes, c->d_box_cluster, c->d_rng, c->d_poly, c->d_groups, c->d_cluster_start, c->d_sorted,
                   c->d_tracks, c->d_nt, c->d_tboxes, c->d_targs, c->d_gate, c->d_prog, c->d_live, c->d_tout, c->d_tflags, c->d_ego};
   for (void* b : bufs) if (b) (void)hipFree(b);
   if (c->h_counts) (void)hipHostFree(c->h_counts);
@@ -187,7 +189,7 @@ static ClusterBuffers cluster_buffers(mot_ctx* c) {
   ClusterBuffers b;
   b.elevated = c->d_elev; b.cap = c->cap; b.counts = c->d_counts; b.plane_a = c->d_plane_a; b.plane_b = c->d_plane_b;
   b.grid = c->d_grid; b.label = c->d_label; b.stats = c->d_stats; b.cand = c->d_cand; b.boxes = c->d_boxes;
-  b.box_cluster = c->d_box_cluster; b.rng = c->d_rng; b.poly = c->d_poly; b.tiles = c->d_tiles;
+  b.box_cluster = c->d_box_cluster; b.rng = c->d_rng; b.poly = c->d_poly; b.groups = c->d_groups; b.group_cap = c->cap / 2; b.cluster_start = c->d_cluster_start; b.sorted = c->d_sorted;
   return b;
 }
 
@@ -223,7 +225,9 @@ static int create_impl(mot_ctx* c) {
   MOT_HIP(c, hipMalloc(&c->d_box_cluster, B * kMaxBoxesPerFrame * sizeof(int)));
   MOT_HIP(c, hipMalloc(&c->d_rng, kRngTable * sizeof(unsigned long long)));
   MOT_HIP(c, hipMalloc(&c->d_poly, B * N * sizeof(int)));
-  MOT_HIP(c, hipMalloc(&c->d_tiles, B * ((N + 63) / 64) * sizeof(TileSummary)));
+  MOT_HIP(c, hipMalloc(&c->d_groups, B * (N / 2) * sizeof(PointGroup)));
+  MOT_HIP(c, hipMalloc(&c->d_cluster_start, B * (kMaxClusters + 1) * sizeof(int)));
+  MOT_HIP(c, hipMalloc(&c->d_sorted, B * N * sizeof(int)));
   {  // mt19937_64 mt(0), box_fitting.cpp:303 — raw draws; the libstdc++ range mapping is applied on the device
     std::mt19937_64 mt(0);
     unsigned long long raw[kRngTable];
@@ -374,7 +378,8 @@ static int fetch_counts(mot_ctx* c, int slot) {
     MOT_HIP(c, hipMemsetAsync(c->d_counts + slot * kCountsStride + kCntFlags, 0, sizeof(int), c->stream));
     if (f & kFlagClusterOverflow) return fail(c, MOT_E_CAPACITY, "more clusters in a frame than the library supports (4096)");
     if (f & kFlagBoxOverflow) return fail(c, MOT_E_CAPACITY, "more boxes in a frame than the library supports (1024)");
-    if (f & kFlagHullOverflow) return fail(c, MOT_E_CAPACITY, "convex hull larger than 512 vertices");
+    if (f & kFlagHullOverflow) return fail(c, MOT_E_CAPACITY, "convex hull larger than 384 vertices");
+    if (f & kFlagGroupOverflow) return fail(c, MOT_E_CAPACITY, "cloud too fragmented: more than max_points/2 (tile, cluster) groups in a frame");
     if (f & kFlagRngExhausted) return fail(c, MOT_E_CAPACITY, "L-shape sampling ran out of pre-generated random draws");
   }
   return MOT_OK;
@@ -425,6 +430,7 @@ extern "C" int mot_cluster(mot_ctx* c, const float* elev, int n, int32_t* grid, 
   if (point_label) {  // getClusteredPoints' per-point lookup; the statistics it also gathers are discarded
     mot_launch_box_kernel(0, c->dp, cb, 1, n, c->stream);
     mot_launch_stats_init(cb, 1, c->stream);
+    MOT_HIP(c, hipMemsetAsync(c->d_counts + kCntGroups, 0, sizeof(int), c->stream));
   }
   MOT_HIP(c, hipGetLastError());
   return mot_get_clusters(c, 0, grid, num_cluster, point_label);
@@ -477,7 +483,7 @@ extern "C" int mot_ground_remove(mot_ctx* c, const float* xyzw, int n, float* el
 }
 
 // kernel ids used by mot_time_stage
-enum { kK1 = 10, kK2 = 11, kK3 = 12, kC1 = 20, kC2 = 21, kB1 = 30, kB2 = 31, kB3 = 32, kB2b = 33, kT1 = 40 };
+enum { kK1 = 10, kK2 = 11, kK3 = 12, kC1 = 20, kC2 = 21, kB1 = 30, kB2 = 31, kB3 = 32, kB2b = 33, kB1b = 34, kT1 = 40 };
 
 static int launch_one(mot_ctx* c, int id, int batch) {
   int rc;
@@ -495,6 +501,7 @@ static int launch_one(mot_ctx* c, int id, int batch) {
     case kB2: mot_launch_box_kernel(1, c->dp, cb, batch, max_n, c->stream); break;
     case kB3: mot_launch_box_kernel(2, c->dp, cb, batch, max_n, c->stream); break;
     case kB2b: mot_launch_box_kernel(3, c->dp, cb, batch, max_n, c->stream); break;
+    case kB1b: mot_launch_box_kernel(4, c->dp, cb, batch, max_n, c->stream); break;
     case kT1: mot_launch_track(track_buffers(c, true), batch, c->stream); break;  // last frame's arguments again
     default: return fail(c, MOT_E_ARG, "unknown kernel id");
   }
@@ -509,31 +516,32 @@ static int launch_one(mot_ctx* c, int id, int batch) {
 extern "C" int mot_time_stage(mot_ctx* c, int stage, int batch, int iters, float* ms_per_iter) {
   if (!c || !ms_per_iter || iters < 1) return MOT_E_ARG;
   if (!c->last_in || batch != c->last_batch) return fail(c, MOT_E_STATE, "call mot_frames_dev with the same batch first");
-  struct Seq { int pre[3], timed[10], post[3]; };
-  Seq s = {{0, 0, 0}, {0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, {0, 0, 0}};
+  struct Seq { int pre[4], timed[12], post[3]; };
+  Seq s = {{0, 0, 0, 0}, {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, {0, 0, 0}};
   switch (stage) {
     case 0: s = {{0}, {kK1, kK2, kK3}, {0}}; break;
     case 1: s = {{0}, {kC1, kC2}, {0}}; break;
-    case 2: s = {{0}, {kB1, kB2, kB2b, kB3}, {0}}; break;
-    case 100: s = {{0}, {kK1, kK2, kK3, kC1, kC2, kB1, kB2, kB2b, kB3}, {0}}; break;
+    case 2: s = {{0}, {kB1, kB1b, kB2, kB2b, kB3}, {0}}; break;
+    case 100: s = {{0}, {kK1, kK2, kK3, kC1, kC2, kB1, kB1b, kB2, kB2b, kB3}, {0}}; break;
     case kK1: s = {{0}, {kK1}, {0}}; break;
     case kK2: s = {{0}, {kK2}, {0}}; break;
     case kK3: s = {{0}, {kK3}, {0}}; break;
     case kC1: s = {{0}, {kC1}, {kC2}}; break;
     case kC2: s = {{kC1}, {kC2}, {0}}; break;
-    case kB1: s = {{0}, {kB1}, {kB3}}; break;
-    case kB2: s = {{kB1}, {kB2}, {kB3}}; break;
-    case kB2b: s = {{kB1, kB2}, {kB2b}, {kB3}}; break;
-    case kB3: s = {{kB1, kB2, kB2b}, {kB3}, {0}}; break;
+    case kB1: s = {{0}, {kB1}, {kB1b, kB3}}; break;
+    case kB1b: s = {{kB1}, {kB1b}, {kB3}}; break;
+    case kB2: s = {{kB1, kB1b}, {kB2}, {kB3}}; break;
+    case kB2b: s = {{kB1, kB1b, kB2}, {kB2b}, {kB3}}; break;
+    case kB3: s = {{kB1, kB1b, kB2, kB2b}, {kB3}, {0}}; break;
     case kT1: s = {{0}, {kT1}, {0}}; break;
     default: return fail(c, MOT_E_ARG, "unknown stage");
   }
   double total = 0;
   int rc;
   for (int it = 0; it < iters; it++) {
-    for (int k = 0; k < 3 && s.pre[k]; k++) if ((rc = launch_one(c, s.pre[k], batch))) return rc;
+    for (int k = 0; k < 4 && s.pre[k]; k++) if ((rc = launch_one(c, s.pre[k], batch))) return rc;
     MOT_HIP(c, hipEventRecord(c->ev0, c->stream));
-    for (int k = 0; k < 10 && s.timed[k]; k++) if ((rc = launch_one(c, s.timed[k], batch))) return rc;
+    for (int k = 0; k < 12 && s.timed[k]; k++) if ((rc = launch_one(c, s.timed[k], batch))) return rc;
     MOT_HIP(c, hipEventRecord(c->ev1, c->stream));
     for (int k = 0; k < 3 && s.post[k]; k++) if ((rc = launch_one(c, s.post[k], batch))) return rc;
     MOT_HIP(c, hipEventSynchronize(c->ev1));
@@ -662,5 +670,17 @@ extern "C" int mot_track_get_state(mot_ctx* c, int slot, int id, mot_track_state
   o->lifetime = t.lifetime; o->track_manage = t.track_num; o->is_static = t.is_static; o->is_vis = t.is_vis; o->has_best_box = t.has_best;
   if (t.has_bbox) memcpy(o->bbox, t.bbox, sizeof t.bbox);
   if (t.has_best) memcpy(o->best_bbox, t.best_bbox, sizeof t.best_bbox);
+  return MOT_OK;
+}
+
+// internal debugging aid (not part of include/mot.h): raw copy of a per-slot device array to the host
+extern "C" int mot_debug_copy(mot_ctx* c, int which, int slot, void* dst, size_t bytes) {
+  if (!c || !dst || slot < 0 || slot >= c->batch) return MOT_E_ARG;
+  const void* src = nullptr;
+  if (which == 0) src = c->d_cand + (size_t)slot * kMaxClusters;
+  else if (which == 1) src = c->d_stats + (size_t)slot * kMaxClusters;
+  else return MOT_E_ARG;
+  MOT_HIP(c, hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, c->stream));
+  MOT_HIP(c, hipStreamSynchronize(c->stream));
   return MOT_OK;
 }

@@ -74,9 +74,9 @@ constexpr int kMaxRuns = 32768;                    // 128 runs per row x 256 row
 constexpr int kMaxClusters = 4096;                 // per frame (MOT_E_CAPACITY beyond)
 constexpr int kMaxBoxesPerFrame = 1024;
 constexpr int kRngTable = 128;                     // raw mt19937_64(0) outputs kept on the device
-constexpr int kCountsStride = 8;                   // ints per frame in `counts`
-enum { kCntElev = 0, kCntGround = 1, kCntDropped = 2, kCntClusters = 3, kCntBoxes = 4, kCntUndef = 5, kCntFlags = 6, kCntPoly = 7 };
-enum { kFlagClusterOverflow = 1, kFlagBoxOverflow = 2, kFlagRngExhausted = 4, kFlagHullOverflow = 8 };
+constexpr int kCountsStride = 12;                  // ints per frame in `counts`
+enum { kCntElev = 0, kCntGround = 1, kCntDropped = 2, kCntClusters = 3, kCntBoxes = 4, kCntUndef = 5, kCntFlags = 6, kCntPoly = 7, kCntGroups = 8 };
+enum { kFlagClusterOverflow = 1, kFlagBoxOverflow = 2, kFlagRngExhausted = 4, kFlagHullOverflow = 8, kFlagGroupOverflow = 16 };
 
 struct ClusterStats {          // per cluster, accumulated by the label kernel, reset by the finalize kernel
   int count;                   // numPoints
@@ -86,12 +86,10 @@ struct ClusterStats {          // per cluster, accumulated by the label kernel, 
   unsigned long long argmin;   // (key(m) << 32) | idx        -> minimum = smallest slope, first occurrence
   unsigned long long argmax;   // (key(m) << 32) | ~idx       -> maximum = largest slope, first occurrence
 };
-constexpr int kTileEntries = 8;
-struct TileSummary {           // which clusters the 64 points [64 t, 64 t + 64) of a frame belong to (label kernel)
-  unsigned long long mask[kTileEntries];  // lanes of the tile holding label[k]
-  int label[kTileEntries];
-  int n;                       // entries used; kTileEntries + 1 = more distinct clusters in the tile (consumers read `label[]`)
-  int pad[7];
+struct PointGroup {            // the points of one 64-point tile that belong to one cluster (label kernel)
+  unsigned long long mask;     // lanes of the tile
+  int label;                   // 1-based cluster id
+  int tile;                    // points 64*tile .. 64*tile + 63
 };
 struct BoxCandidate {          // per cluster, written by the box kernels
   float pc[8];                 // 4 corners (x,y)
@@ -116,7 +114,10 @@ struct ClusterBuffers {
   int* box_cluster;            // [B][kMaxBoxesPerFrame]
   const unsigned long long* rng;  // [kRngTable]
   int* poly;                   // [B][cap] candidate hull points (x | y << 16) of the min-area-rectangle clusters
-  TileSummary* tiles;          // [B][cap / 64]
+  PointGroup* groups;          // [B][cap / 2] (tile, cluster) groups of the frame, any order
+  int group_cap;               // cap / 2
+  int* cluster_start;          // [B][kMaxClusters + 1] first slot of every cluster in `sorted`
+  int* sorted;                 // [B][cap] point indices grouped by cluster, input order inside a cluster
 };
 
 void mot_launch_cluster(const MotDevParams& p, const ClusterBuffers& c, int batch, int max_n, hipStream_t stream);

@@ -173,7 +173,7 @@ def main():
         it = 20
         tr0 = ctx.get_tracks(0)
         kernels = {"polar_minz_kernel": 10, "polar_filter_kernel": 11, "classify_compact_kernel": 12,
-                   "cart_occupancy_kernel": 20, "ccl_kernel": 21, "label_stats_kernel": 30, "cluster_gather_kernel": 31,
+                   "cart_occupancy_kernel": 20, "ccl_kernel": 21, "label_stats_kernel": 30, "cluster_index_kernel": 34, "cluster_gather_kernel": 31,
                    "cluster_rect_kernel": 33, "box_finalize_kernel": 32, "track_step_kernel": 40}
         k_ms = {k: ctx.time_stage(v, Bc, it if v != 40 else 5) for k, v in kernels.items()}
         stage_ms = {"ground": ctx.time_stage(0, Bc, it), "cluster": ctx.time_stage(1, Bc, it), "box": ctx.time_stage(2, Bc, it),
@@ -190,6 +190,7 @@ def main():
                      "cart_occupancy_kernel": 16.0 * ne_tot,
                      "ccl_kernel": (2 * 2048 * 4 + 4.0 * G * G) * BL,
                      "label_stats_kernel": (16.0 + 4.0) * ne_tot,
+                     "cluster_index_kernel": 4.0 * ne_tot,
                      "cluster_gather_kernel": (4.0 + 16.0) * ne_tot,
                      "cluster_rect_kernel": 4.0 * ne_tot / 8,
                      "box_finalize_kernel": 96.0 * BL,

@@ -60,6 +60,27 @@ def interleaved_clusters_cloud(n_clusters=12, reps=40):
     return np.array(pts, np.float32)
 
 
+def shuffled_many_clusters_cloud(n_clusters=60, per=340, seed=9):
+    """random point order over many clusters: far more (tile, cluster) groups than the index kernel keeps in LDS"""
+    rng = np.random.default_rng(seed)
+    pts = []
+    for k in range(n_clusters):
+        cx, cy = -22 + 5.5 * (k % 8), -22 + 5.5 * (k // 8)
+        p = np.zeros((per, 4), np.float32)
+        p[:, 0] = cx + rng.uniform(-0.9, 0.9, per); p[:, 1] = cy + rng.uniform(-0.5, 0.5, per); p[:, 2] = rng.uniform(-1.2, 0.3, per)
+        pts.append(p)
+    pts = np.concatenate(pts)
+    rng.shuffle(pts)
+    return pts
+
+
+def test_shuffled_many_clusters(ctx, oracle):
+    p = oracle.params(0)
+    cloud = shuffled_many_clusters_cloud()
+    r, b = _stage_parity(ctx, oracle, p, cloud)
+    assert r["num_cluster"] >= 40 and len(b["boxes"]) >= 10
+
+
 def test_many_clusters_per_tile(ctx, oracle):
     p = oracle.params(0)
     _stage_parity(ctx, oracle, p, interleaved_clusters_cloud())

@@ -52,3 +52,14 @@ def test_emu_many_clusters_per_tile(mot, emu_lib, oracle):
             assert r["num_cluster"] == o["num_cluster"] >= 10 and np.array_equal(r["grid"], o["grid"])
             b = c.box_fit(cloud, o["grid"], o["num_cluster"]); ob = oracle.box_fit(p, cloud, o["grid"], o["num_cluster"])
             assert np.array_equal(b["boxes"], ob["boxes"]) and np.array_equal(b["box_cluster"], ob["box_cluster"])
+
+
+def test_emu_shuffled_many_clusters(mot, emu_lib, oracle):
+    from test_cluster_box_gpu import shuffled_many_clusters_cloud
+    p = oracle.params(0)
+    cloud = shuffled_many_clusters_cloud(40, 300)
+    with mot.Context(lib_path=emu_lib, max_points=32768) as c:
+        r = c.cluster(cloud); o = oracle.cluster(p, cloud)
+        assert r["num_cluster"] == o["num_cluster"] and np.array_equal(r["grid"], o["grid"])
+        b = c.box_fit(cloud, o["grid"], o["num_cluster"]); ob = oracle.box_fit(p, cloud, o["grid"], o["num_cluster"])
+        assert np.array_equal(b["boxes"], ob["boxes"]) and np.array_equal(b["box_cluster"], ob["box_cluster"])
