@@ -214,7 +214,13 @@ MOT_HD bool mot_cart_cell(const MotDevParams& p, float x, float y, int* xI, int*
 // getCellIndexFromPoints (ground_removal.cpp:67-76) + filterCloud's range test (:53) + the callers'
 // bounds test (:89,:233), evaluated exactly as the reference does (bit-exact atan2f, fp64 intermediate, IEEE divide).
 // Returns the polar cell (ch*120+bin) or -1 when the point takes no part. `distance` = sqrtf(x*x+y*y), already in range.
-MOT_HD int mot_polar_cell_exact(const MotDevParams& p, float x, float y, float distance) {
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(MOT_HIPEMU)
+#define MOT_COLD __device__ __attribute__((noinline))
+#else
+#define MOT_COLD static inline
+#endif
+// rarely executed (about 4e-4 of the points): kept out of line so the unrolled hot loops stay small
+MOT_COLD int mot_polar_cell_exact(const MotDevParams& p, float x, float y, float distance) {
   float at = mot_atan2f(y, x);
   float chP = (float)(((double)at + 3.14159265358979323846) / (2 * 3.14159265358979323846));
   float binP = (distance - p.r_min) / p.r_span;
