@@ -63,16 +63,26 @@ polar_minz_kernel(MotDevParams p, GroundBuffers g) {
     float x = pt[k].x, y = pt[k].y, z = pt[k].z;
     int cell = mot_crop_keep(p, x, y, z) ? mot_polar_cell(p, x, y) : -1;
     if (!(z == z)) cell = -1;                 // `z < minZ` is false for NaN: never updates
-    int key = mot_float_key(z + 0.0f);        // canonical +0
-    unsigned long long active = __ballot(cell >= 0);
-    while (active) {                          // wave-uniform loop: one trip per distinct cell in the wave
-      int leader = __ffsll(active) - 1;
-      int c = wave_bcast_i32(cell, leader);
-      bool mine = (cell == c);
-      int v = wave_min_i32(mine ? key : 0x7fffffff);
-      if (lane == leader) { int pos = atomicAdd(&s_count, 1); s_pairs[pos] = make_uint2((unsigned)c, (unsigned)v); }
-      active &= ~__ballot(mine);
+    int v = mot_float_key(z + 0.0f);          // canonical +0
+    // Segmented min over RUNS of equal cells (beam-major clouds put a cell's points in consecutive lanes): one
+    // log-step scan serves every run of the tile at once — no loop over distinct cells. A cell that shows up in two
+    // separate runs just yields two entries; the filter kernel's LDS atomicMin does not mind.
+    const int prev = __shfl_up(cell, 1, 64);
+    const bool head = lane == 0 || cell != prev;
+    const unsigned long long H = __ballot(head);
+    const int hd = lane - (63 - __clzll((long long)(H & ((2ull << lane) - 1ull))));  // distance to the run's first lane
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+      int o = __shfl_up(v, d, 64);
+      if (hd >= d) v = o < v ? o : v;
     }
+    const bool tail = lane == 63 || ((H >> (lane + 1)) & 1ull);  // last lane of its run holds the run's minimum
+    const bool emit = tail && cell >= 0;
+    const unsigned long long em = __ballot(emit);
+    int slot = 0;
+    if (lane == 0 && em) slot = atomicAdd(&s_count, __popcll(em));
+    slot = wave_bcast_i32(slot, 0);
+    if (emit) s_pairs[slot + __popcll(em & ((1ull << lane) - 1ull))] = make_uint2((unsigned)cell, (unsigned)v);
   }
   __syncthreads();
   const int cnt = s_count;  // <= kGroundChunk: at most one entry per point
