@@ -209,7 +209,7 @@ classify_compact_kernel(MotDevParams p, GroundBuffers g) {
   __shared__ int s_base_e, s_base_g;
   const int b = blockIdx.y;
   const int n = g.n[b];
-  const int nchunks = (n + kGroundChunk - 1) / kGroundChunk;
+  const int nchunks = (n + kCompactChunk - 1) / kCompactChunk;
   if ((int)blockIdx.x >= nchunks) {
     if (nchunks == 0 && blockIdx.x == 0 && threadIdx.x == 0) { g.counts[b * kCountsStride + kCntElev] = 0; g.counts[b * kCountsStride + kCntGround] = 0; g.counts[b * kCountsStride + kCntDropped] = 0; }
     return;
@@ -221,23 +221,27 @@ classify_compact_kernel(MotDevParams p, GroundBuffers g) {
   }
   __syncthreads();
   const int chunk = s_chunk;
-  const long base = (long)chunk * kGroundChunk;
+  const long base = (long)chunk * kCompactChunk;
   const float4* __restrict__ in = g.in + (long)b * g.in_stride;
   const float* __restrict__ hg = g.hg + (long)b * MOT_POLAR_CELLS;
   const int lane = wave_lane(), wave = threadIdx.x >> 6;
 
-  float4 pt[kGroundItems];
-  int cls[kGroundItems];    // MOT_MASK_*
-  int rank[kGroundItems];   // rank inside the 64-point tile, among points of the same class
+  float4 pt[kCompactItems];
+  int cls[kCompactItems];    // MOT_MASK_*
+  int rank[kCompactItems];   // rank inside the 64-point tile, among points of the same class
 #pragma unroll
-  for (int k = 0; k < kGroundItems; k++) {
+  for (int k = 0; k < kCompactItems; k++) {
     long i = base + k * kGroundBlock + threadIdx.x;
     pt[k] = i < n ? in[i] : make_float4(0.f, 0.f, 0.f, 0.f);
   }
 #pragma unroll
-  for (int k = 0; k < kGroundItems; k++) {
+  for (int k = 0; k < kCompactItems; k++) {
     float x = pt[k].x, y = pt[k].y, z = pt[k].z;
+#ifdef MOT_DBG_K3_CHEAPCELL
+    int cell = ((int)(x * 0.5f) & 63) * MOT_NUM_BIN + ((int)(y * 0.5f) & 63);
+#else
     int cell = mot_crop_keep(p, x, y, z) ? mot_polar_cell(p, x, y) : -1;
+#endif
     int c = MOT_MASK_DROPPED;
     if (cell >= 0) {
       float hGround = hg[cell];  // -inf when the cell is not ground
@@ -255,7 +259,7 @@ classify_compact_kernel(MotDevParams p, GroundBuffers g) {
   }
   __syncthreads();
   if (wave == 0) {
-    // exclusive scan of the 32 tile counts (lanes >= 32 idle) and the chunk totals
+    // exclusive scan of the 64 tile counts and the chunk totals
     int ce = lane < kSubTiles ? s_cnt_e[lane] : 0, cg = lane < kSubTiles ? s_cnt_g[lane] : 0;
     int ie = ce, ig = cg;
 #pragma unroll
@@ -270,7 +274,12 @@ classify_compact_kernel(MotDevParams p, GroundBuffers g) {
     const unsigned long long ep = (unsigned long long)(g.epoch & kDescEpochMask) << kDescEpochShift;
     unsigned long long mine = ep | ((unsigned long long)(unsigned)tot_e << kDescCountBits) | (unsigned long long)(unsigned)tot_g;
     long excl_e = 0, excl_g = 0;
+#ifdef MOT_DBG_K3_NOLOOKBACK
+    excl_e = (long)chunk * 600; excl_g = (long)chunk * 1448;
+    if (false) {
+#else
     if (chunk > 0) {
+#endif
       if (lane == 0) __hip_atomic_store(&desc[chunk], kDescAggregate | mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       int win_end = chunk;  // exclusive
       while (true) {        // wave-uniform
@@ -310,7 +319,7 @@ classify_compact_kernel(MotDevParams p, GroundBuffers g) {
   uint8_t* __restrict__ mask = g.mask ? g.mask + (long)b * g.cap : nullptr;
   const int be0 = s_base_e, bg0 = s_base_g;
 #pragma unroll
-  for (int k = 0; k < kGroundItems; k++) {
+  for (int k = 0; k < kCompactItems; k++) {
     long i = base + k * kGroundBlock + threadIdx.x;
     int t = k * 4 + wave;
     if (cls[k] == MOT_MASK_ELEVATED) out_e[be0 + s_cnt_e[t] + rank[k]] = pt[k];
@@ -324,9 +333,11 @@ void mot_launch_ground_kernel(int which, const MotDevParams& p, const GroundBuff
                               hipStream_t stream) {
   int chunks = (max_n + kGroundChunk - 1) / kGroundChunk;
   if (chunks < 1) chunks = 1;
+  int cchunks = (max_n + kCompactChunk - 1) / kCompactChunk;
+  if (cchunks < 1) cchunks = 1;
   if (which == 0) hipLaunchKernelGGL(polar_minz_kernel, dim3(chunks, batch), dim3(kGroundBlock), 0, stream, p, g);
   else if (which == 1) hipLaunchKernelGGL(polar_filter_kernel, dim3(batch), dim3(kFilterBlock), 0, stream, p, g);
-  else if (which == 2) hipLaunchKernelGGL(classify_compact_kernel, dim3(chunks, batch), dim3(kGroundBlock), 0, stream, p, g);
+  else if (which == 2) hipLaunchKernelGGL(classify_compact_kernel, dim3(cchunks, batch), dim3(kGroundBlock), 0, stream, p, g);
 }
 
 void mot_launch_ground(const MotDevParams& p, const GroundBuffers& g, int batch, int max_n, hipStream_t stream) {

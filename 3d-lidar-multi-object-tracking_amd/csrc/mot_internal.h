@@ -14,7 +14,9 @@
 constexpr int kGroundBlock = 256;                 // threads per workgroup (4 waves)
 constexpr int kGroundItems = 8;                   // points per thread
 constexpr int kGroundChunk = kGroundBlock * kGroundItems;  // 2048 points = 32 KB per workgroup
-constexpr int kSubTiles = kGroundChunk / 64;      // 64-point wave tiles per chunk (32)
+constexpr int kCompactItems = 16;                 // points per thread in the compaction kernel
+constexpr int kCompactChunk = kGroundBlock * kCompactItems;  // 4096 points = 64 KB per workgroup
+constexpr int kSubTiles = kCompactChunk / 64;     // 64-point wave tiles per chunk (64: one lane each in the tile scan)
 constexpr int kMinzInit = 0x447A0000;             // ordered key of 1000.0f (Cell::Cell, ground_removal.cpp:35-38)
 
 // descriptor word of the decoupled look-back in the compaction kernel (one 8-byte granule, written
