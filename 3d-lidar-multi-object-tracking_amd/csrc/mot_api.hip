@@ -59,6 +59,7 @@ struct mot_ctx {
   mot_track* d_tout = nullptr;
   int* d_tflags = nullptr;
   EgoPose* d_ego = nullptr;
+  long long* d_phase = nullptr;
   struct SlotEgo {  // file-scope globals of OT/tracking/imm_ukf_jpda.cpp:19-24,56-70, one set per stream
     bool init = false, ego_called = false;
     double timestamp = 0, egoVelo = 0, egoYaw = 0, egoPreYaw = 0;
@@ -173,7 +174,7 @@ extern "C" void mot_destroy(mot_ctx* c) {
   if (!c) return;
   void* bufs[] = {c->d_in, c->d_n, c->d_pairs, c->d_pair_count, c->d_hg, c->d_desc, c->d_ticket, c->d_elev, c->d_ground, c->d_mask, c->d_counts,
                   c->d_plane_a, c->d_plane_b, c->d_grid, c->d_label, c->d_stats, c->d_cand, c->d_boxes, c->d_box_cluster, c->d_rng, c->d_poly, c->d_groups, c->d_cluster_start, c->d_sorted,
-                  c->d_tracks, c->d_nt, c->d_tboxes, c->d_targs, c->d_gate, c->d_prog, c->d_live, c->d_tout, c->d_tflags, c->d_ego};
+                  c->d_tracks, c->d_nt, c->d_tboxes, c->d_targs, c->d_gate, c->d_prog, c->d_live, c->d_tout, c->d_tflags, c->d_ego, c->d_phase};
   for (void* b : bufs) if (b) (void)hipFree(b);
   if (c->h_counts) (void)hipHostFree(c->h_counts);
   if (c->ev0) (void)hipEventDestroy(c->ev0);
@@ -253,6 +254,8 @@ static int create_impl(mot_ctx* c) {
   MOT_HIP(c, hipMalloc(&c->d_tout, B * T * sizeof(mot_track)));
   MOT_HIP(c, hipMalloc(&c->d_tflags, B * sizeof(int)));
   MOT_HIP(c, hipMalloc(&c->d_ego, B * sizeof(EgoPose)));
+  MOT_HIP(c, hipMalloc(&c->d_phase, B * 16 * sizeof(long long)));
+  MOT_HIP(c, hipMemsetAsync(c->d_phase, 0, B * 16 * sizeof(long long), c->stream));
   MOT_HIP(c, hipMemsetAsync(c->d_nt, 0, B * sizeof(int), c->stream));
   MOT_HIP(c, hipMemsetAsync(c->d_tflags, 0, B * sizeof(int), c->stream));
   c->ego.assign(B, mot_ctx::SlotEgo());
@@ -559,7 +562,7 @@ extern "C" int mot_time_stage(mot_ctx* c, int stage, int batch, int iters, float
 static TrackBuffers track_buffers(mot_ctx* c, bool fused) {
   TrackBuffers t;
   t.tracks = c->d_tracks; t.nt = c->d_nt; t.boxes = c->d_tboxes; t.args = c->d_targs; t.gate = c->d_gate; t.prog = c->d_prog;
-  t.live = c->d_live; t.out = c->d_tout; t.flags = c->d_tflags; t.m_dev = fused ? c->d_counts : nullptr; t.T = c->max_tracks_total;
+  t.live = c->d_live; t.out = c->d_tout; t.flags = c->d_tflags; t.phase_clock = c->d_phase; t.m_dev = fused ? c->d_counts : nullptr; t.T = c->max_tracks_total;
   t.tp.gamma_g = c->params.gamma_g; t.tp.p_g = c->params.p_g; t.tp.p_d = c->params.p_d; t.tp.distance_thres = c->params.distance_thres;
   t.tp.bb_yaw_change_thres = c->params.bb_yaw_change_thres; t.tp.seed_px = c->params.seed_px; t.tp.seed_py = c->params.seed_py;
   t.tp.life_time_thres = c->params.life_time_thres; t.tp.seed_box_index = c->params.seed_box_index;
@@ -679,6 +682,7 @@ extern "C" int mot_debug_copy(mot_ctx* c, int which, int slot, void* dst, size_t
   const void* src = nullptr;
   if (which == 0) src = c->d_cand + (size_t)slot * kMaxClusters;
   else if (which == 1) src = c->d_stats + (size_t)slot * kMaxClusters;
+  else if (which == 2) src = c->d_phase + (size_t)slot * 16;
   else return MOT_E_ARG;
   MOT_HIP(c, hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, c->stream));
   MOT_HIP(c, hipStreamSynchronize(c->stream));

@@ -168,6 +168,7 @@ struct TrackBuffers {
   int* live;                    // [B][2*T]: compact list of live tracks, then their "reached gating" flags
   mot_track* out;               // [B][T]
   int* flags;                   // [B] capacity flags
+  long long* phase_clock;       // [B][16] shader-clock stamps of the phase boundaries of the last step (diagnostics)
   const int* m_dev;             // optional: boxes per frame read from counts[b*kCountsStride + kCntBoxes] (fused path)
   int T;
   MotTrackParams tp;

@@ -50,6 +50,30 @@ __device__ __forceinline__ unsigned long long wave_reduce_u64(unsigned long long
 __device__ __forceinline__ int wave_bcast_i32(int v, int lane) { return __shfl(v, lane, 64); }
 #endif
 
+// sum of a double over the wave (all lanes receive it)
+__device__ __forceinline__ double wave_sum_f64(double v) {
+#ifndef MOT_HIPEMU
+#define MOT_DPP_F64(x, ctrl, rmask)                                                                          \
+  __hiloint2double(__builtin_amdgcn_update_dpp(0, __double2hiint(x), (ctrl), (rmask), 0xf, true),             \
+                   __builtin_amdgcn_update_dpp(0, __double2loint(x), (ctrl), (rmask), 0xf, true))
+  // lanes without a valid source read 0 (bound_ctrl): adding 0.0 leaves the partial sums intact
+  v += MOT_DPP_F64(v, 0xB1, 0xf);
+  v += MOT_DPP_F64(v, 0x4E, 0xf);
+  v += MOT_DPP_F64(v, 0x141, 0xf);
+  v += MOT_DPP_F64(v, 0x140, 0xf);
+  // after the mirrors every lane of a 16-lane row holds the row's sum; combine the four rows through readlane
+#undef MOT_DPP_F64
+  double r0 = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), 0), __builtin_amdgcn_readlane(__double2loint(v), 0));
+  double r1 = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), 16), __builtin_amdgcn_readlane(__double2loint(v), 16));
+  double r2 = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), 32), __builtin_amdgcn_readlane(__double2loint(v), 32));
+  double r3 = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), 48), __builtin_amdgcn_readlane(__double2loint(v), 48));
+  return (r0 + r1) + (r2 + r3);
+#else
+  for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m, 64);
+  return v;
+#endif
+}
+
 struct OpMinI { __device__ __forceinline__ int operator()(int a, int b) const { return a < b ? a : b; } };
 struct OpMaxI { __device__ __forceinline__ int operator()(int a, int b) const { return a > b ? a : b; } };
 struct OpMinU64 { __device__ __forceinline__ unsigned long long operator()(unsigned long long a, unsigned long long b) const { return a < b ? a : b; } };

@@ -21,6 +21,7 @@
 // measurements (Eigen's own reductions are vectorised, so that order is not defined by the source either).
 // Parity bar: track sets and integer state exact, continuous state <= 1e-4 relative (BASELINE.json).
 #include "mot_internal.h"
+#include "mot_wave.h"
 
 #ifndef MOT_HIPEMU
 #define MOT_LAUNCH_BOUNDS(n) __launch_bounds__(n)
@@ -45,11 +46,7 @@ __device__ __forceinline__ int tlane() { return (int)(threadIdx.x & 63); }
 __device__ __forceinline__ double wrap_pi(double a) { while (a > PI_D) a -= 2. * PI_D; while (a < -PI_D) a += 2. * PI_D; return a; }
 __device__ __forceinline__ double det2(const double* m) { return m[0] * m[3] - m[1] * m[2]; }
 __device__ __forceinline__ void inv2(const double* m, double* o) { double d = det2(m); o[0] = m[3] / d; o[1] = -m[1] / d; o[2] = -m[2] / d; o[3] = m[0] / d; }
-__device__ __forceinline__ double wave_sum_d(double v) {
-#pragma unroll
-  for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m, 64);
-  return v;
-}
+__device__ __forceinline__ double wave_sum_d(double v) { return wave_sum_f64(v); }
 
 // determinant of a 5x5 (partial-pivot elimination, what Eigen's PartialPivLU::determinant amounts to)
 __device__ double det5(const double* a) {
@@ -122,27 +119,49 @@ __device__ void process_imm_ukf(WaveScratch* ws, double dt) {
   // Prediction(dt, m) :630-772. Augmented covariance, Eigen 3.2.10 LLT::unblocked semantics: a non-positive pivot
   // stops the factorisation and matrixL() returns the partially overwritten lower triangle.
   if (lane < 3) {
+    // P_aug = blockdiag(P, std_a^2, std_yawdd^2): rows 5 and 6 have no off-diagonal entries, so the 7x7 factorisation is
+    // the 5x5 one of P (kept in registers) plus two square roots — unless an earlier pivot already failed, in which case
+    // Eigen's loop has stopped and those diagonal entries are still the un-rooted inputs.
     const int m = lane;
     const double std_a = m == 2 ? 3. : 2., std_yawdd = m == 2 ? 3. : 2.;  // ukf.cpp:68-73
-    double* a = ws->L[m];
-    for (int i = 0; i < 49; i++) a[i] = 0;
-    for (int r = 0; r < 5; r++) for (int c = 0; c < 5; c++) a[r * 7 + c] = ws->P[m][r * 5 + c];
-    a[5 * 7 + 5] = std_a * std_a;
-    a[6 * 7 + 6] = std_yawdd * std_yawdd;
-    for (int k = 0; k < 7; k++) {
-      double xk = a[k * 7 + k];
-      for (int j = 0; j < k; j++) xk -= a[k * 7 + j] * a[k * 7 + j];
-      if (xk <= 0) break;
-      a[k * 7 + k] = xk = sqrt(xk);
-      for (int r = k + 1; r < 7; r++) {
-        double s = 0;
-        for (int j = 0; j < k; j++) s += a[r * 7 + j] * a[k * 7 + j];
-        a[r * 7 + k] -= s;
+    double a[25];
+#pragma unroll
+    for (int i = 0; i < 25; i++) a[i] = ws->P[m][i];
+    bool ok = true;
+#pragma unroll
+    for (int k = 0; k < 5; k++) {
+      if (ok) {
+        double xk = a[k * 5 + k];
+#pragma unroll
+        for (int j = 0; j < 5; j++) if (j < k) xk -= a[k * 5 + j] * a[k * 5 + j];
+        if (xk <= 0) ok = false;
+        else {
+          a[k * 5 + k] = xk = sqrt(xk);
+#pragma unroll
+          for (int r = 0; r < 5; r++)
+            if (r > k) {
+              double s = 0;
+#pragma unroll
+              for (int j = 0; j < 5; j++) if (j < k) s += a[r * 5 + j] * a[k * 5 + j];
+              a[r * 5 + k] -= s;
+            }
+          double inv = 1.0 / xk;  // Eigen 3.2: `A21 /= x` multiplies by the reciprocal
+#pragma unroll
+          for (int r = 0; r < 5; r++) if (r > k) a[r * 5 + k] *= inv;
+        }
       }
-      double inv = 1.0 / xk;  // Eigen 3.2: `A21 /= x` multiplies by the reciprocal
-      for (int r = k + 1; r < 7; r++) a[r * 7 + k] *= inv;
     }
-    for (int r = 0; r < 7; r++) for (int c = r + 1; c < 7; c++) a[r * 7 + c] = 0;
+    double* L = ws->L[m];
+#pragma unroll
+    for (int r = 0; r < 7; r++)
+#pragma unroll
+      for (int c = 0; c < 7; c++) {
+        double v = 0;
+        if (r < 5 && c <= r) v = a[r * 5 + c];
+        else if (r == 5 && c == 5) v = ok ? std_a : std_a * std_a;
+        else if (r == 6 && c == 6) v = ok ? std_yawdd : std_yawdd * std_yawdd;
+        L[r * 7 + c] = v;
+      }
   }
   MOT_WAVE_SYNC();
   if (lane < 45) {  // one lane per (model, sigma point): Cv :573, Ctrv :539, randomMotion :602
@@ -364,6 +383,8 @@ track_step_kernel(TrackBuffers tb) {
     return;
   }
 
+#define MOT_PHASE(k) if (tid == 0 && tb.phase_clock) tb.phase_clock[b * 16 + (k)] = clock64()
+  MOT_PHASE(0);
   // ---- P0: isVisBB_ = false for every track (:813); compact the live ones in index order
   if (tid == 0) { s_nlive = 0; s_born = 0; }
   for (int w = tid; w < kGateWords; w += kTrackBlock) s_matched[w] = 0ull;
@@ -383,6 +404,7 @@ track_step_kernel(TrackBuffers tb) {
     __syncthreads();
   }
   const int nlive = s_nlive;
+  MOT_PHASE(1);
 
   // ---- PA: prediction + gating, one wave per live track
   for (int li = wave; li < nlive; li += kTrackWaves) {
@@ -441,6 +463,7 @@ track_step_kernel(TrackBuffers tb) {
     MOT_WAVE_SYNC();
   }
   __syncthreads();
+  MOT_PHASE(2);
 
   // ---- PB: matchingVec / lifetime_ bookkeeping in track order (:232)
   if (wave == 0) {
@@ -460,6 +483,7 @@ track_step_kernel(TrackBuffers tb) {
     if (lane < kGateWords) s_matched[lane] = matched;
   }
   __syncthreads();
+  MOT_PHASE(3);
 
   // ---- PC: association, state machine, PDA update
   for (int li = wave; li < nlive; li += kTrackWaves) {
@@ -544,6 +568,7 @@ track_step_kernel(TrackBuffers tb) {
       const double bpda = 2 * numMeas * (1 - tp.p_d * tp.p_g) / (tp.gamma_g * tp.p_d);
       double Si[3][4];
       for (int m = 0; m < 3; m++) inv2(ws->S[m], Si[m]);
+      // lanes over the boxes (one 64-box tile at a time); e and the residuals of a lane's box are kept for the three sums
       double eSum[3] = {0, 0, 0};
       for (int w = 0; w * 64 < M; w++) {
         int k = w * 64 + lane;
@@ -560,35 +585,24 @@ track_step_kernel(TrackBuffers tb) {
         }
       }
       double sx[3][2] = {{0, 0}, {0, 0}, {0, 0}};
-      for (int w = 0; w * 64 < M; w++) {
-        int k = w * 64 + lane;
-        bool g = (gt[w] >> lane) & 1ull;
-        for (int m = 0; m < 3; m++) {
-          double a0 = 0, a1 = 0;
-          if (g) {
-            double d0 = s_cpx[k] - ws->z[m][0], d1 = s_cpy[k] - ws->z[m][1];
-            double h0 = -0.5 * d0, h1 = -0.5 * d1;
-            double t0 = h0 * Si[m][0] + h1 * Si[m][2], t1 = h0 * Si[m][1] + h1 * Si[m][3];
-            double beta = exp(t0 * d0 + t1 * d1) / (bpda + eSum[m]);
-            a0 = beta * d0; a1 = beta * d1;
-          }
-          sx[m][0] += wave_sum_d(a0); sx[m][1] += wave_sum_d(a1);
-        }
-      }
       double sp[3][4] = {{0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}};
-      for (int w = 0; w * 64 < M; w++) {
-        int k = w * 64 + lane;
-        bool g = (gt[w] >> lane) & 1ull;
-        for (int m = 0; m < 3; m++) {
-          double q[4] = {0, 0, 0, 0};
-          if (g) {
-            double d[2] = {s_cpx[k] - ws->z[m][0], s_cpy[k] - ws->z[m][1]};
-            double h0 = -0.5 * d[0], h1 = -0.5 * d[1];
-            double t0 = h0 * Si[m][0] + h1 * Si[m][2], t1 = h0 * Si[m][1] + h1 * Si[m][3];
-            double beta = exp(t0 * d[0] + t1 * d[1]) / (bpda + eSum[m]);
-            for (int r = 0; r < 2; r++) for (int c = 0; c < 2; c++) q[r * 2 + c] = (beta * d[r]) * d[c] - sx[m][r] * sx[m][c];
+      for (int pass = 0; pass < 2; pass++) {  // pass 0: sigmaX, pass 1: sigmaP (needs the complete sigmaX)
+        for (int w = 0; w * 64 < M; w++) {
+          int k = w * 64 + lane;
+          bool g = (gt[w] >> lane) & 1ull;
+          for (int m = 0; m < 3; m++) {
+            double d[2] = {0, 0}, beta = 0;
+            if (g) {
+              d[0] = s_cpx[k] - ws->z[m][0]; d[1] = s_cpy[k] - ws->z[m][1];
+              double h0 = -0.5 * d[0], h1 = -0.5 * d[1];
+              double t0 = h0 * Si[m][0] + h1 * Si[m][2], t1 = h0 * Si[m][1] + h1 * Si[m][3];
+              beta = exp(t0 * d[0] + t1 * d[1]) / (bpda + eSum[m]);
+            }
+            if (pass == 0) { sx[m][0] += wave_sum_d(beta * d[0]); sx[m][1] += wave_sum_d(beta * d[1]); }
+            else
+              for (int r = 0; r < 2; r++) for (int c = 0; c < 2; c++)
+                sp[m][r * 2 + c] += wave_sum_d(g ? (beta * d[r]) * d[c] - sx[m][r] * sx[m][c] : 0.0);
           }
-          for (int e2 = 0; e2 < 4; e2++) sp[m][e2] += wave_sum_d(q[e2]);
         }
       }
       // x += K*sigmaX ; P update (:341-367) — one lane per matrix entry
@@ -642,6 +656,7 @@ track_step_kernel(TrackBuffers tb) {
     MOT_WAVE_SYNC();
   }
   __syncthreads();
+  MOT_PHASE(4);
 
   // ---- PD: mergeOverSegmentation :666-700. The reference runs `for i { for j { if inside(j, box_i) {trackNum[i]=5; trackNum[j]=0;} } }`
   // over ALL tracks; the value a track ends with is decided by the last (i,j) pair that writes it.
@@ -676,6 +691,7 @@ track_step_kernel(TrackBuffers tb) {
     else if (has_a) tracks[t].track_num = 5;
   }
   __syncthreads();
+  MOT_PHASE(5);
 
   // ---- PE: birth :972-989 — one new track per unclaimed box, in box order
   if (wave == 0) {
@@ -698,6 +714,7 @@ track_step_kernel(TrackBuffers tb) {
   }
   __syncthreads();
   const int nt1 = s_born;
+  MOT_PHASE(6);
 
   // ---- PF: outputs + static classification :995-1081
   for (int t = tid; t < nt1; t += kTrackBlock) {
@@ -715,6 +732,10 @@ track_step_kernel(TrackBuffers tb) {
     for (int i = 0; i < 24; i++) o.vis_box[i] = u->is_vis ? u->bbox[i] : 0.f;
     out[t] = o;
   }
+  __syncthreads();
+  MOT_PHASE(7);
+  if (tid == 0 && tb.phase_clock) { tb.phase_clock[b * 16 + 8] = nlive; tb.phase_clock[b * 16 + 9] = nt1; tb.phase_clock[b * 16 + 10] = M; }
+#undef MOT_PHASE
 }
 
 // the tf step of the tracking node (OT/tracking/main.cpp:143-158): boxes arrive in the sensor frame, the tracker

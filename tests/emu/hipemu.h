@@ -55,6 +55,8 @@ typedef struct hipemu_event { double t; }* hipEvent_t;
 enum hipMemcpyKind { hipMemcpyHostToHost, hipMemcpyHostToDevice, hipMemcpyDeviceToHost, hipMemcpyDeviceToDevice, hipMemcpyDefault };
 struct hipDeviceProp_t { char name[256]; char gcnArchName[256]; int multiProcessorCount; size_t totalGlobalMem; };
 
+#include <time.h>
+static inline long long hipemu_now_ns();
 namespace hipemu {
 constexpr int kWave = 64;
 constexpr size_t kStack = 128 * 1024;
@@ -215,6 +217,7 @@ static inline int __clz(int v) { return v ? __builtin_clz((unsigned)v) : 32; }
 static inline int __clzll(long long v) { return v ? __builtin_clzll((unsigned long long)v) : 64; }
 static inline unsigned __builtin_amdgcn_readlane(unsigned v, int l) { return hipemu::shfl(v, l); }
 static inline unsigned __builtin_amdgcn_readfirstlane(unsigned v) { return hipemu::shfl(v, 0); }
+static inline long long clock64() { return (long long)(hipemu_now_ns()); }
 static inline int __lane_id() { return hipemu::lane(); }
 static inline unsigned __builtin_amdgcn_mbcnt_lo(unsigned mask, unsigned base) { int l = hipemu::lane(); unsigned m = l >= 32 ? mask : (mask & ((1u << l) - 1)); return base + __builtin_popcount(m); }
 static inline unsigned __builtin_amdgcn_mbcnt_hi(unsigned mask, unsigned base) { int l = hipemu::lane(); unsigned m = l <= 32 ? 0u : (mask & ((1u << (l - 32)) - 1)); return base + __builtin_popcount(m); }
@@ -275,7 +278,9 @@ static inline hipError_t hipStreamDestroy(hipStream_t) { return hipSuccess; }
 static inline hipError_t hipStreamSynchronize(hipStream_t) { return hipSuccess; }
 static inline hipError_t hipDeviceSynchronize() { return hipSuccess; }
 #include <time.h>
+static inline long long hipemu_now_ns();
 static inline double hipemu_now() { timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return ts.tv_sec * 1e3 + ts.tv_nsec * 1e-6; }
+static inline long long hipemu_now_ns() { timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return ts.tv_sec * 1000000000ll + ts.tv_nsec; }
 static inline hipError_t hipEventCreate(hipEvent_t* e) { *e = new hipemu_event{0}; return hipSuccess; }
 static inline hipError_t hipEventDestroy(hipEvent_t e) { delete e; return hipSuccess; }
 static inline hipError_t hipEventRecord(hipEvent_t e, hipStream_t) { e->t = hipemu_now(); return hipSuccess; }
