@@ -84,7 +84,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--batch", type=int, default=64, help="sensor streams (one frame each) per GPU per step")
+    ap.add_argument("--batch", type=int, default=256, help="sensor streams (one frame each) per GPU per step")
     ap.add_argument("--points", type=int, default=120000)
     ap.add_argument("--frames", type=int, default=4, help="distinct consecutive frames resident per stream")
     ap.add_argument("--contexts", type=int, default=2, help="contexts (HIP streams) per GPU the streams are split over: the "
@@ -126,7 +126,7 @@ def main():
     assert B % NC == 0, "--batch must be divisible by --contexts"
     Bc = B // NC
     sizes = [N] * Bc
-    ctxs = [mot.Context(device=local, max_points=stride, max_batch=Bc, max_tracks_total=8192) for _ in range(NC)]
+    ctxs = [mot.Context(device=local, max_points=stride, max_batch=Bc, max_tracks_total=4096) for _ in range(NC)]
     ctx = ctxs[0]
     gathers = [multi.TrackGather(Bc, GATHER_TRACKS, world, "cuda") for _ in range(NC)] if world > 1 else None
     torch.cuda.synchronize()
