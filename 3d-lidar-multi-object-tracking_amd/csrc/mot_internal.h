@@ -215,15 +215,11 @@ MOT_HD bool mot_cart_cell(const MotDevParams& p, float x, float y, int* xI, int*
 }
 
 // getCellIndexFromPoints (ground_removal.cpp:67-76) + filterCloud's range test (:53) + the callers'
-// bounds test (:89,:233), evaluated exactly as the reference does (bit-exact atan2f, fp64 intermediate, IEEE divide).
-// Returns the polar cell (ch*120+bin) or -1 when the point takes no part. `distance` = sqrtf(x*x+y*y), already in range.
-#if defined(__HIP_DEVICE_COMPILE__) && !defined(MOT_HIPEMU)
-#define MOT_COLD __device__ __attribute__((noinline))
-#else
-#define MOT_COLD static inline
-#endif
-// rarely executed (about 4e-4 of the points): kept out of line so the unrolled hot loops stay small
-MOT_COLD int mot_polar_cell_exact(const MotDevParams& p, float x, float y, float distance) {
+// bounds test (:89,:233), evaluated exactly as the reference does (correctly rounded sqrtf, bit-exact atan2f, fp64
+// intermediate, IEEE divide). Returns the polar cell (ch*120+bin) or -1 when the point takes no part.
+MOT_HD int mot_polar_cell_exact(const MotDevParams& p, float x, float y) {
+  float distance = sqrtf(x * x + y * y);
+  if (distance <= p.r_min || distance >= p.r_max) return -1;       // filterCloud (NaN passes, as in the reference)
   float at = mot_atan2f(y, x);
   float chP = (float)(((double)at + 3.14159265358979323846) / (2 * 3.14159265358979323846));
   float binP = (distance - p.r_min) / p.r_span;
@@ -235,24 +231,21 @@ MOT_COLD int mot_polar_cell_exact(const MotDevParams& p, float x, float y, float
 }
 
 // Guarded fast path. The cell is floor() of two quantities; floor only depends on them to within the distance to the
-// nearest integer. Both are first estimated cheaply (degree-13 odd polynomial for atan on [0,1] with a hardware
-// reciprocal, absolute error < 1e-6 rad => < 2e-5 channels; one multiply instead of the IEEE divide for the bin,
-// error < 3e-5 bins). If either estimate is within kCellGuard of an integer — or anything is NaN — the exact evaluation
-// decides; otherwise the estimate's floor IS the exact floor. ~4e-4 of the points take the exact path.
-// tests/test_math_exact.py::test_fast_cell_agrees checks the claim on 2e8 points (with the reciprocal perturbed by
-// +-1 ulp to cover the hardware's v_rcp_f32), the -m gpu parity tests check it end to end.
+// nearest integer. Both are first estimated cheaply: the hardware's 1-ulp square root and one multiply instead of the
+// correctly rounded sqrtf and the IEEE divide for the bin (error < 4e-5 bins); a degree-13 odd polynomial for atan on
+// [0,1] with a hardware reciprocal for the channel (absolute error < 1e-6 rad => < 2e-5 channels). If either estimate is
+// within kCellGuard of an integer — or anything is NaN/Inf — the answer is -2 and the exact evaluation decides;
+// otherwise the estimate's floor IS the exact floor, and the range filter rMin < d < rMax is the test 0 <= bin < 120
+// (a distance within an ulp of either limit lands inside the guard). ~4e-4 of the points need the exact path.
+// tests/test_math_exact.py::test_fast_cell_agrees checks the claim on 2e8 points (square root and reciprocal perturbed by
+// +-1 ulp to cover v_sqrt_f32 / v_rcp_f32), the -m gpu parity tests check it end to end.
 constexpr float kCellGuard = 1.0e-4f;
-MOT_HD float mot_rcp_approx(float v) {
-#if defined(__HIP_DEVICE_COMPILE__) && !defined(MOT_HIPEMU)
-  return __builtin_amdgcn_rcpf(v);
-#else
-  return 1.0f / v;
-#endif
-}
-MOT_HD int mot_polar_cell_fast(const MotDevParams& p, float x, float y, float distance, float rcp_mx) {
+MOT_HD int mot_polar_cell_fast(const MotDevParams& p, float x, float y, float distance_approx, float rcp_mx) {
   // bin
-  const float tb = (distance - p.r_min) * p.k_bin;
+  const float tb = (distance_approx - p.r_min) * p.k_bin;
   const float fb = floorf(tb), rb = tb - fb;
+  const bool bin_safe = rb > kCellGuard && rb < 1.f - kCellGuard;  // false on NaN
+  if (bin_safe && !(fb >= 0.f && fb < (float)MOT_NUM_BIN)) return -1;  // clearly outside rMin..rMax: no channel needed
   // channel: atan2 by octant reduction
   const float ax = fabsf(x), ay = fabsf(y);
   const float mn = ax < ay ? ax : ay;
@@ -271,18 +264,26 @@ MOT_HD int mot_polar_cell_fast(const MotDevParams& p, float x, float y, float di
   if (y < 0.f) a = -a;
   const float tc = (a + 3.14159265358979324f) * (MOT_NUM_CHANNEL / 6.28318530717958648f);
   const float fc = floorf(tc), rc = tc - fc;
-  const bool safe = rb > kCellGuard && rb < 1.f - kCellGuard && rc > kCellGuard && rc < 1.f - kCellGuard;  // false on NaN
+  const bool safe = bin_safe && rc > kCellGuard && rc < 1.f - kCellGuard;  // false on NaN
   if (!safe) return -2;
-  if (!(fc >= 0.f && fc < (float)MOT_NUM_CHANNEL && fb >= 0.f && fb < (float)MOT_NUM_BIN)) return -1;
+  if (!(fc >= 0.f && fc < (float)MOT_NUM_CHANNEL)) return -1;
   return (int)fc * MOT_NUM_BIN + (int)fb;
 }
 
-MOT_HD int mot_polar_cell(const MotDevParams& p, float x, float y) {
-  float distance = sqrtf(x * x + y * y);
-  if (distance <= p.r_min || distance >= p.r_max) return -1;       // filterCloud (NaN passes, as in the reference)
+// the fast path with the hardware estimates; -2 = undecided (call mot_polar_cell_exact)
+MOT_HD int mot_polar_cell_try(const MotDevParams& p, float x, float y) {
   const float ax = fabsf(x), ay = fabsf(y);
-  int cell = mot_polar_cell_fast(p, x, y, distance, mot_rcp_approx(ax > ay ? ax : ay));
-  if (cell == -2) cell = mot_polar_cell_exact(p, x, y, distance);
+  const float d2 = x * x + y * y, mx = ax > ay ? ax : ay;
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(MOT_HIPEMU)
+  return mot_polar_cell_fast(p, x, y, __builtin_amdgcn_sqrtf(d2), __builtin_amdgcn_rcpf(mx));
+#else
+  return mot_polar_cell_fast(p, x, y, sqrtf(d2), 1.0f / mx);
+#endif
+}
+
+MOT_HD int mot_polar_cell(const MotDevParams& p, float x, float y) {
+  int cell = mot_polar_cell_try(p, x, y);
+  if (cell == -2) cell = mot_polar_cell_exact(p, x, y);
   return cell;
 }
 

@@ -259,7 +259,8 @@ static inline hipError_t hipGetLastError() { return hipSuccess; }
 static inline hipError_t hipGetDeviceCount(int* n) { *n = 1; return hipSuccess; }
 static inline hipError_t hipSetDevice(int) { return hipSuccess; }
 static inline hipError_t hipGetDeviceProperties(hipDeviceProp_t* p, int) { memset(p, 0, sizeof *p); strcpy(p->name, "hipemu"); strcpy(p->gcnArchName, "gfx950:emulated"); p->multiProcessorCount = 256; return hipSuccess; }
-static inline hipError_t hipMalloc(void** p, size_t n) { *p = calloc(1, n ? n : 1); return *p ? hipSuccess : 2; }
+// device memory arrives poisoned (0xFF: NaN floats, -1 ints) so that reads of never-written memory show up in the tests
+static inline hipError_t hipMalloc(void** p, size_t n) { *p = malloc(n ? n : 1); if (*p) memset(*p, 0xFF, n ? n : 1); return *p ? hipSuccess : 2; }
 template <typename T> static inline hipError_t hipMalloc(T** p, size_t n) { return hipMalloc((void**)p, n); }
 static inline hipError_t hipHostMalloc(void** p, size_t n, unsigned = 0) { return hipMalloc(p, n); }
 template <typename T> static inline hipError_t hipHostMalloc(T** p, size_t n, unsigned f = 0) { return hipHostMalloc((void**)p, n, f); }
@@ -282,6 +283,9 @@ static inline long long hipemu_now_ns();
 static inline double hipemu_now() { timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return ts.tv_sec * 1e3 + ts.tv_nsec * 1e-6; }
 static inline long long hipemu_now_ns() { timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return ts.tv_sec * 1000000000ll + ts.tv_nsec; }
 static inline hipError_t hipEventCreate(hipEvent_t* e) { *e = new hipemu_event{0}; return hipSuccess; }
+constexpr unsigned hipEventDisableTiming = 2;
+static inline hipError_t hipEventCreateWithFlags(hipEvent_t* e, unsigned) { *e = new hipemu_event{0}; return hipSuccess; }
+static inline hipError_t hipStreamWaitEvent(hipStream_t, hipEvent_t, unsigned) { return hipSuccess; }  // the emulator is synchronous
 static inline hipError_t hipEventDestroy(hipEvent_t e) { delete e; return hipSuccess; }
 static inline hipError_t hipEventRecord(hipEvent_t e, hipStream_t) { e->t = hipemu_now(); return hipSuccess; }
 static inline hipError_t hipEventSynchronize(hipEvent_t) { return hipSuccess; }

@@ -46,8 +46,8 @@ def test_atan2f_matches_glibc_bit_for_bit():
 
 
 FAST_SRC = r"""
-// whenever the guarded fast path of mot_polar_cell answers, the answer equals the exact evaluation; the reciprocal is
-// perturbed by +-1 ulp to cover the hardware's v_rcp_f32
+// whenever the guarded fast path of mot_polar_cell answers, the answer equals the exact evaluation (range filter
+// included); square root and reciprocal are perturbed by +-1 ulp to cover the hardware's v_sqrt_f32 / v_rcp_f32
 #define MOT_HIPEMU 1
 #include <cmath>
 #include <cstdio>
@@ -72,18 +72,26 @@ int main(int argc, char** argv) {
     else if (mode == 3) { double th = (r & 0xffffff) / (double)0x1000000 * 6.283185307179586, rr = 3.4 + ((r >> 24) & 0xffffff) / (double)0x1000000 * 117; x = (float)(rr * cos(th)); y = (float)(rr * sin(th)); }
     else { int k = (r & 0xff) % 80; double th = k / 80.0 * 6.283185307179586 - 3.14159265358979 + (((r >> 8) & 0xff) - 128) * 1e-7; double rr = 3.4 + ((r >> 24) & 0xffffff) / (double)0x1000000 * 117; x = (float)(rr * cos(th)); y = (float)(rr * sin(th)); }
     float d = sqrtf(x * x + y * y);
-    if (d <= p.r_min || d >= p.r_max) continue;
+    const bool near = i % 7 == 0;
+    if (near) {  // distances within a few ulps of the range limits: the range filter must come out the same
+      float lim = (r >> 60) & 1 ? p.r_max : p.r_min;
+      float want = lim; int steps = (int)((r >> 56) & 7) - 3;
+      for (int q = 0; q < (steps < 0 ? -steps : steps); q++) want = nextafterf(want, steps < 0 ? 0.f : INFINITY);
+      float sc = want / d; x *= sc; y *= sc; d = sqrtf(x * x + y * y);
+    }
+    if (!(d < 1e6f)) continue;
     tot++;
-    int ex = mot_polar_cell_exact(p, x, y, d);
+    int ex = mot_polar_cell_exact(p, x, y);
     float mx = fabsf(x) > fabsf(y) ? fabsf(x) : fabsf(y);
     float rc = 1.0f / mx;
     float cand[3] = {rc, nextafterf(rc, 0.f), nextafterf(rc, INFINITY)};
-    for (int k = 0; k < 3; k++) {
-      int f = mot_polar_cell_fast(p, x, y, d, cand[k]);
-      if (f == -2) { if (k == 0) { slow++; if (mode == 3) plain_slow++; } continue; }
+    float dd[3] = {d, nextafterf(d, 0.f), nextafterf(d, INFINITY)};
+    for (int k = 0; k < 9; k++) {
+      int f = mot_polar_cell_fast(p, x, y, dd[k / 3], cand[k % 3]);
+      if (f == -2) { if (k == 0) { slow++; if (mode == 3 && !near) plain_slow++; } continue; }
       if (f != ex) bad++;
     }
-    if (mode == 3) plain++;
+    if (mode == 3 && !near) plain++;
   }
   printf("%ld %ld %ld %ld %ld\n", bad, slow, tot, plain_slow, plain);
   return bad ? 1 : 0;
