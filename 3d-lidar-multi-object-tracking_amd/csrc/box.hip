@@ -32,7 +32,10 @@
 #endif
 
 constexpr int kLabelBlock = 256;
-constexpr int kLabelItems = 8;
+#ifndef MOT_LABEL_ITEMS
+#define MOT_LABEL_ITEMS 8
+#endif
+constexpr int kLabelItems = MOT_LABEL_ITEMS;
 constexpr int kLabelChunk = kLabelBlock * kLabelItems;
 constexpr unsigned long long kArgminInit = ~0ull;   // nothing compared below 999 yet
 constexpr unsigned long long kArgmaxInit = 0ull;    // nothing compared above -999 yet
@@ -67,22 +70,51 @@ __global__ void stats_init_kernel(ClusterBuffers c) {
 
 // ------------------------------------------------------------------------------------------ B1
 // getClusteredPoints :46-72 (label of every point) + the per-point loop of getBoundingBox :239-293
+constexpr int kGroupsPerWg = 512;   // (tile, cluster) groups a workgroup stages in LDS; any beyond go straight to global memory
+constexpr int kWgClusters = 64;     // distinct clusters a workgroup merges in LDS before touching the global statistics
+__device__ __forceinline__ void stats_commit(ClusterStats* s, int count, int first, int rz, unsigned long long rmin, unsigned long long rmax) {
+  atomicAdd(&s->count, count);
+  atomicMin(&s->first, first);
+  atomicMax(&s->maxz_key, rz);
+  if (rmin != kArgminInit) atomicMin(&s->argmin, rmin);
+  if (rmax != kArgmaxInit) atomicMax(&s->argmax, rmax);
+}
+
 __global__ void MOT_LAUNCH_BOUNDS(kLabelBlock)
 label_stats_kernel(MotDevParams p, ClusterBuffers c) {
-  __shared__ PointGroup s_groups[kLabelChunk];  // at most one group per point
-  __shared__ int s_ngroups, s_gbase;
+  constexpr int kWaves = kLabelBlock / 64, kPerWave = kGroupsPerWg / kWaves;
+  // (tile, cluster) groups with their partial statistics, one region per wave (no atomics while they are produced)
+  __shared__ PointGroup s_groups[kGroupsPerWg];
+  __shared__ unsigned long long s_rmin[kGroupsPerWg], s_rmax[kGroupsPerWg];
+  __shared__ int s_rz[kGroupsPerWg];
+  // open-addressed table cluster -> statistics of this workgroup
+  __shared__ int s_tab_label[kWgClusters], s_tab_count[kWgClusters], s_tab_first[kWgClusters], s_tab_rz[kWgClusters];
+  __shared__ unsigned long long s_tab_rmin[kWgClusters], s_tab_rmax[kWgClusters];
+  __shared__ int s_wcount[kWaves], s_gbase;
   const int b = blockIdx.y;
   const int n = c.counts[b * kCountsStride + kCntElev];
   const long base = (long)blockIdx.x * kLabelChunk;
   if (base >= n) return;
-  if (threadIdx.x == 0) s_ngroups = 0;
-  __syncthreads();
+  if (threadIdx.x < kWgClusters) {
+    s_tab_label[threadIdx.x] = 0; s_tab_count[threadIdx.x] = 0; s_tab_first[threadIdx.x] = 0x7fffffff;
+    s_tab_rz[threadIdx.x] = mot_float_key(-99.f); s_tab_rmin[threadIdx.x] = kArgminInit; s_tab_rmax[threadIdx.x] = kArgmaxInit;
+  }
+#ifdef MOT_DBG_B1_TIMING
+  const long long t_start = clock64();
+  int* dbg = c.poly + (long)b * c.cap + blockIdx.x * 8;
+#define B1_T(slot) if (threadIdx.x == 0) dbg[slot] = (int)(clock64() - t_start)
+#else
+#define B1_T(slot)
+#endif
   const int num_cluster = c.counts[b * kCountsStride + kCntClusters];
   const float4* __restrict__ pts = c.elevated + (long)b * c.cap;
   const int* __restrict__ grid = c.grid + (long)b * (MOT_MAX_GRID * MOT_MAX_GRID);
   int* __restrict__ label = c.label + (long)b * c.cap;
   ClusterStats* __restrict__ stats = c.stats + (long)b * kMaxClusters;
-  const int lane = lane_id();
+  PointGroup* __restrict__ out = c.groups + (long)b * c.group_cap;
+  const int lane = lane_id(), wave = threadIdx.x >> 6;
+  constexpr int kNoMin = 0x7fffffff, kNoMax = (int)0x80000000;
+  int wn = 0;   // groups this wave has produced (wave-uniform)
 #pragma unroll
   for (int k = 0; k < kLabelItems; k++) {
     long i = base + k * kLabelBlock + threadIdx.x;
@@ -97,41 +129,95 @@ label_stats_kernel(MotDevParams p, ClusterBuffers c) {
       if (lab > kMaxClusters) lab = 0;  // no statistics slot: box_finalize_kernel raises the capacity flag
     }
     float m = q.y / q.x + 0.0f;  // slope, :264 (+0 makes -0 == +0 for the keyed compare, as `<` does)
-    // `m < minM` with minM = 999 / `m > maxM` with maxM = -999 (NaN never compares)
-    unsigned long long kmin = (m < 999.f) ? (((unsigned long long)ukey(m) << 32) | (unsigned)i) : kArgminInit;
-    unsigned long long kmax = (m > -999.f) ? (((unsigned long long)ukey(m) << 32) | (unsigned)~(unsigned)i) : kArgmaxInit;
-    int zkey = (q.z > -99.f) ? mot_float_key(q.z + 0.0f) : mot_float_key(-99.f);  // `pZ > maxZ`, maxZ = -99
+    // `m < minM` with minM = 999 / `m > maxM` with maxM = -999 (NaN never compares); "first occurrence wins" (strict
+    // compares, :268-280) = the lowest lane among those holding the extreme key
+    const int skey = mot_float_key(m);
+    const int kmin = (m < 999.f) ? skey : kNoMin;
+    const int kmax = (m > -999.f) ? skey : kNoMax;
+    const int zkey = (q.z > -99.f) ? mot_float_key(q.z + 0.0f) : mot_float_key(-99.f);  // `pZ > maxZ`, maxZ = -99
     unsigned long long active = __ballot(lab > 0);
+    if (k == 0) { B1_T(0); }
     const int tile = (int)((base + k * kLabelBlock + (threadIdx.x & ~63)) / 64);
     while (active) {  // one trip per distinct cluster among the 64 points of this wave
-      int leader = __ffsll(active) - 1;
-      int l = wave_bcast_i32(lab, leader);
-      bool mine = (lab == l);
-      unsigned long long mm = __ballot(mine);
-      unsigned long long rmin = wave_reduce_u64(mine ? kmin : kArgminInit, OpMinU64());
-      unsigned long long rmax = wave_reduce_u64(mine ? kmax : kArgmaxInit, OpMaxU64());
-      int rz = wave_reduce_i32(mine ? zkey : mot_float_key(-99.f), OpMaxI());
+      const int leader = __ffsll(active) - 1;
+      const int l = wave_bcast_i32(lab, leader);
+      const bool mine = (lab == l);
+      const unsigned long long mm = __ballot(mine);
+      const int rmin_k = wave_reduce_i32_id(mine ? kmin : kNoMin, OpMinI(), kNoMin);
+      const int rmax_k = wave_reduce_i32_id(mine ? kmax : kNoMax, OpMaxI(), kNoMax);
+      const int rz = wave_reduce_i32_id(mine ? zkey : kNoMax, OpMaxI(), kNoMax);   // every real key exceeds kNoMax
+      const unsigned long long at_min = __ballot(mine && kmin == rmin_k), at_max = __ballot(mine && kmax == rmax_k);
       if (lane == leader) {  // the leader is the lowest lane = the smallest index of the group
-        ClusterStats* s = &stats[l - 1];
-        atomicAdd(&s->count, __popcll(mm));
-        atomicMin(&s->first, (int)i);
-        atomicMax(&s->maxz_key, rz);
-        if (rmin != kArgminInit) atomicMin(&s->argmin, rmin);
-        if (rmax != kArgmaxInit) atomicMax(&s->argmax, rmax);
+        const unsigned i0 = (unsigned)tile * 64u;
+        // keys as this file's consumers decode them: high word = unsigned ordered slope, low word = index (min) / ~index (max)
+        const unsigned long long rmin = rmin_k == kNoMin ? kArgminInit
+            : (((unsigned long long)((unsigned)rmin_k ^ 0x80000000u) << 32) | (i0 + (unsigned)(__ffsll(at_min) - 1)));
+        const unsigned long long rmax = rmax_k == kNoMax ? kArgmaxInit
+            : (((unsigned long long)((unsigned)rmax_k ^ 0x80000000u) << 32) | (unsigned)~(i0 + (unsigned)(__ffsll(at_max) - 1)));
         PointGroup g; g.mask = mm; g.label = l; g.tile = tile;
-        s_groups[atomicAdd(&s_ngroups, 1)] = g;
+        if (wn < kPerWave) {
+          const int e = wave * kPerWave + wn;
+          s_groups[e] = g; s_rmin[e] = rmin; s_rmax[e] = rmax; s_rz[e] = rz;
+        } else {  // more groups than the LDS stage holds (a badly fragmented chunk): this one goes out on its own
+          stats_commit(&stats[l - 1], __popcll(mm), (int)i, rz, rmin, rmax);
+          const int gs = atomicAdd(&c.counts[b * kCountsStride + kCntGroups], 1);
+          if (gs < c.group_cap) out[gs] = g;
+        }
       }
+      wn++;
       active &= ~mm;
     }
   }
-  // the workgroup's (tile, cluster) groups leave with ONE returning global atomic (a slot reservation)
+  if (lane == 0) s_wcount[wave] = wn < kPerWave ? wn : kPerWave;
+  B1_T(1);
   __syncthreads();
-  const int ng = s_ngroups;
+  B1_T(2);
+  // Statistics are merged per (workgroup, cluster) in an LDS table — all groups in parallel — before they touch global
+  // memory: a large cluster spans hundreds of tiles, and one device-scope atomic per tile on the same five words
+  // serialises in L2.
+  int ng = 0, wbase[kWaves];
+#pragma unroll
+  for (int w = 0; w < kWaves; w++) { wbase[w] = ng; ng += s_wcount[w]; }
   if (threadIdx.x == 0) s_gbase = ng ? atomicAdd(&c.counts[b * kCountsStride + kCntGroups], ng) : 0;
+  for (int t = threadIdx.x; t < ng; t += kLabelBlock) {
+    int w = 0;
+#pragma unroll
+    for (int x = 1; x < kWaves; x++) if (t >= wbase[x]) w = x;
+    const int e = w * kPerWave + (t - wbase[w]);
+    const PointGroup g = s_groups[e];
+    unsigned h = ((unsigned)g.label * 0x9E3779B1u) >> 26;
+    int slot = -1;
+#pragma unroll 1
+    for (int probe = 0; probe < kWgClusters; probe++) {
+      const int cur = atomicCAS(&s_tab_label[h], 0, g.label);
+      if (cur == 0 || cur == g.label) { slot = (int)h; break; }
+      h = (h + 1) & (kWgClusters - 1);
+    }
+    const int cnt = __popcll(g.mask), first = g.tile * 64 + (__ffsll(g.mask) - 1);
+    if (slot >= 0) {
+      atomicAdd(&s_tab_count[slot], cnt); atomicMin(&s_tab_first[slot], first); atomicMax(&s_tab_rz[slot], s_rz[e]);
+      atomicMin(&s_tab_rmin[slot], s_rmin[e]); atomicMax(&s_tab_rmax[slot], s_rmax[e]);
+    } else {
+      stats_commit(&stats[g.label - 1], cnt, first, s_rz[e], s_rmin[e], s_rmax[e]);   // more than 64 clusters in this chunk
+    }
+  }
   __syncthreads();
+  B1_T(3);
+  if (threadIdx.x < kWgClusters && s_tab_label[threadIdx.x])
+    stats_commit(&stats[s_tab_label[threadIdx.x] - 1], s_tab_count[threadIdx.x], s_tab_first[threadIdx.x], s_tab_rz[threadIdx.x],
+                 s_tab_rmin[threadIdx.x], s_tab_rmax[threadIdx.x]);
+  // the (tile, cluster) groups leave with ONE returning global atomic (a slot reservation)
   const int gb = s_gbase;
-  PointGroup* __restrict__ out = c.groups + (long)b * c.group_cap;
-  for (int i = threadIdx.x; i < ng; i += kLabelBlock) if (gb + i < c.group_cap) out[gb + i] = s_groups[i];
+  for (int t = threadIdx.x; t < ng; t += kLabelBlock) {
+    int w = 0;
+#pragma unroll
+    for (int x = 1; x < kWaves; x++) if (t >= wbase[x]) w = x;
+    if (gb + t < c.group_cap) out[gb + t] = s_groups[w * kPerWave + (t - wbase[w])];
+  }
+  B1_T(5);
+#ifdef MOT_DBG_B1_TIMING
+  if (threadIdx.x == 0) dbg[6] = ng;
+#endif
 }
 
 // ------------------------------------------------------------------------------------------ B1b

@@ -683,6 +683,7 @@ extern "C" int mot_debug_copy(mot_ctx* c, int which, int slot, void* dst, size_t
   if (which == 0) src = c->d_cand + (size_t)slot * kMaxClusters;
   else if (which == 1) src = c->d_stats + (size_t)slot * kMaxClusters;
   else if (which == 2) src = c->d_phase + (size_t)slot * 16;
+  else if (which == 3) src = c->d_poly + (size_t)slot * c->cap;
   else return MOT_E_ARG;
   MOT_HIP(c, hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, c->stream));
   MOT_HIP(c, hipStreamSynchronize(c->stream));

@@ -10,6 +10,19 @@
 #define MOT_DPP_I32(v, ctrl, rmask) __builtin_amdgcn_update_dpp((v), (v), (ctrl), (rmask), 0xf, false)
 // DPP controls (GCN3/CDNA ISA): quad_perm [1,0,3,2] = 0xB1, [2,3,0,1] = 0x4E, row_half_mirror = 0x141,
 // row_mirror = 0x140, row_bcast15 = 0x142 (row_mask 0xA), row_bcast31 = 0x143 (row_mask 0xC)
+// same reduction with the operator's identity as the value of lanes that have no source: lets the compiler fold the
+// permute into the min/max instruction (v_min_i32_dpp) instead of a v_mov_b32_dpp + v_min_i32 pair
+#define MOT_DPP_ID(v, id, ctrl, rmask) __builtin_amdgcn_update_dpp((id), (v), (ctrl), (rmask), 0xf, false)
+template <typename Op>
+__device__ __forceinline__ int wave_reduce_i32_id(int v, Op op, int identity) {
+  v = op(v, MOT_DPP_ID(v, identity, 0xB1, 0xf));
+  v = op(v, MOT_DPP_ID(v, identity, 0x4E, 0xf));
+  v = op(v, MOT_DPP_ID(v, identity, 0x141, 0xf));
+  v = op(v, MOT_DPP_ID(v, identity, 0x140, 0xf));
+  v = op(v, MOT_DPP_ID(v, identity, 0x142, 0xa));
+  v = op(v, MOT_DPP_ID(v, identity, 0x143, 0xc));
+  return __builtin_amdgcn_readlane(v, 63);
+}
 template <typename Op>
 __device__ __forceinline__ int wave_reduce_i32(int v, Op op) {
   v = op(v, MOT_DPP_I32(v, 0xB1, 0xf));
@@ -42,6 +55,8 @@ __device__ __forceinline__ int wave_reduce_i32(int v, Op op) {
   for (int m = 32; m >= 1; m >>= 1) v = op(v, __shfl_xor(v, m, 64));
   return v;
 }
+template <typename Op>
+__device__ __forceinline__ int wave_reduce_i32_id(int v, Op op, int) { return wave_reduce_i32(v, op); }
 template <typename Op>
 __device__ __forceinline__ unsigned long long wave_reduce_u64(unsigned long long v, Op op) {
   for (int m = 32; m >= 1; m >>= 1) v = op(v, __shfl_xor(v, m, 64));
