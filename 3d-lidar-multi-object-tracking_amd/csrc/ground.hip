@@ -77,28 +77,32 @@ __device__ __forceinline__ int wave_min_i32(int v) { return wave_reduce_i32(v, O
 
 // ------------------------------------------------------------------------------------------ K1
 // filterCloud (:46-64) + createAndMapPolarGrid (:79-92) + Cell::updateMinZ (:40-42)
+//
+// Lidar clouds are beam-major, so a cell's points are CONSECUTIVE in the input. The loads are coalesced (lane = point
+// modulo 256); {cell, z key} then goes through LDS so that every thread owns 8 consecutive points and folds their runs
+// of equal cells serially in registers: no cross-lane operation per point at all, one wave prefix sum per thread to place
+// its 1-2 {cell, min} entries in the workgroup's list. A cell whose run continues into the next thread's points just
+// yields two entries; the filter kernel's LDS atomicMin does not mind. (Earlier versions: one global atomicMin per point
+// run — 8.2k memory-side atomics per frame; then a log-step segmented scan per 64 points — 7 LDS-crossbar shuffles per
+// point; both were bound by those, not by HBM.)
+constexpr int kStagePad(int e) { return e + (e >> 3); }   // 8-byte entries: a 9-entry stride per thread keeps ds_read_b64 conflict-free
 __global__ void MOT_LAUNCH_BOUNDS(kGroundBlock)
 polar_minz_kernel(MotDevParams p, GroundBuffers g) {
-  __shared__ uint2 s_pairs[kGroundChunk];
-  __shared__ int s_count;
+  __shared__ uint2 s_stage[kGroundChunk + kGroundChunk / 8];
+  uint2* const s_pairs = s_stage;   // the list (at most one entry per point) reuses the stage: a barrier separates the two uses
+  __shared__ int s_wsum[kGroundBlock / 64];
   const int b = blockIdx.y;
   const int n = g.n[b];
   const long base = (long)blockIdx.x * kGroundChunk;
   if (base >= n) return;  // whole workgroup leaves together
   const float4* __restrict__ in = g.in + (long)b * g.in_stride;
-  const int lane = wave_lane();
-  if (threadIdx.x == 0) s_count = 0;
-  __syncthreads();
+  const int lane = wave_lane(), wave = threadIdx.x >> 6;
 
   float4 pt[kGroundItems];
 #pragma unroll
   for (int k = 0; k < kGroundItems; k++) {
     long i = base + k * kGroundBlock + threadIdx.x;
-#ifdef MOT_DBG_K1_NT
-    pt[k] = i < n ? load_stream(&in[i]) : make_float4(0.f, 0.f, 0.f, 0.f);
-#else
     pt[k] = i < n ? in[i] : make_float4(0.f, 0.f, 0.f, 0.f);  // (0,0): r = 0 <= rMin -> no cell
-#endif
   }
   int cells[kGroundItems];
   polar_cells<kGroundItems>(p, pt, in, base, n, cells);
@@ -107,32 +111,41 @@ polar_minz_kernel(MotDevParams p, GroundBuffers g) {
     const float z = pt[k].z;
     int cell = cells[k];
     if (!(z == z)) cell = -1;                 // `z < minZ` is false for NaN: never updates
-    int v = mot_float_key(z + 0.0f);          // canonical +0
-    // Segmented min over RUNS of equal cells (beam-major clouds put a cell's points in consecutive lanes): one
-    // log-step scan serves every run of the tile at once — no loop over distinct cells. A cell that shows up in two
-    // separate runs just yields two entries; the filter kernel's LDS atomicMin does not mind.
-    const int prev = __shfl_up(cell, 1, 64);
-    const bool head = lane == 0 || cell != prev;
-    const unsigned long long H = __ballot(head);
-    const int hd = lane - (63 - __clzll((long long)(H & ((2ull << lane) - 1ull))));  // distance to the run's first lane
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-      int o = __shfl_up(v, d, 64);
-      if (hd >= d) v = o < v ? o : v;
-    }
-    const bool tail = lane == 63 || ((H >> (lane + 1)) & 1ull);  // last lane of its run holds the run's minimum
-    const bool emit = tail && cell >= 0;
-    const unsigned long long em = __ballot(emit);
-    int slot = 0;
-    if (lane == 0 && em) slot = atomicAdd(&s_count, __popcll(em));
-    slot = wave_bcast_i32(slot, 0);
-    if (emit) s_pairs[slot + __popcll(em & ((1ull << lane) - 1ull))] = make_uint2((unsigned)cell, (unsigned)v);
+    s_stage[kStagePad(k * kGroundBlock + (int)threadIdx.x)] = make_uint2((unsigned)cell, (unsigned)mot_float_key(z + 0.0f));  // canonical +0
   }
   __syncthreads();
-  const int cnt = s_count;  // <= kGroundChunk: at most one entry per point
+  uint2 e[kGroundItems];
+#pragma unroll
+  for (int j = 0; j < kGroundItems; j++) e[j] = s_stage[(int)threadIdx.x * (kGroundItems + 1) + j];   // = kStagePad(8 * tid + j)
+  int cnt = 0;   // runs of a real cell among my 8 points
+#pragma unroll
+  for (int j = 0; j < kGroundItems; j++) cnt += ((int)e[j].x >= 0 && (j == 0 || e[j].x != e[j - 1].x)) ? 1 : 0;
+  // exclusive prefix of cnt over the workgroup
+  int incl = cnt;
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) { int o = __shfl_up(incl, d, 64); if (lane >= d) incl += o; }
+  if (lane == 63) s_wsum[wave] = incl;
+  __syncthreads();
+  int slot = incl - cnt, total = 0;
+#pragma unroll
+  for (int w = 0; w < kGroundBlock / 64; w++) { const int ws = s_wsum[w]; if (w < wave) slot += ws; total += ws; }
+  unsigned cur = e[0].x;
+  int mn = (int)e[0].y;
+#pragma unroll
+  for (int j = 1; j < kGroundItems; j++) {
+    if (e[j].x == cur) mn = (int)e[j].y < mn ? (int)e[j].y : mn;
+    else {
+      if ((int)cur >= 0) s_pairs[slot++] = make_uint2(cur, (unsigned)mn);
+      cur = e[j].x; mn = (int)e[j].y;
+    }
+  }
+  if ((int)cur >= 0) s_pairs[slot] = make_uint2(cur, (unsigned)mn);
+  __syncthreads();
+  // (one dense list per frame behind a returning global atomicAdd per workgroup was tried: 54 -> 79 us, the 60 reservations
+  // per frame serialise in L2)
   uint2* __restrict__ out = g.pairs + ((long)b * g.max_chunks + blockIdx.x) * kGroundChunk;
-  for (int i = threadIdx.x; i < cnt; i += kGroundBlock) out[i] = s_pairs[i];
-  if (threadIdx.x == 0) g.pair_count[(long)b * g.max_chunks + blockIdx.x] = cnt;
+  for (int i = threadIdx.x; i < total; i += kGroundBlock) out[i] = s_pairs[i];
+  if (threadIdx.x == 0) g.pair_count[(long)b * g.max_chunks + blockIdx.x] = total;
 }
 
 // ------------------------------------------------------------------------------------------ K2
@@ -149,7 +162,8 @@ polar_filter_kernel(MotDevParams p, GroundBuffers g) {
   __shared__ int s_pcnt[256];
   const int b = blockIdx.x;
   float* __restrict__ hg = g.hg + (long)b * MOT_POLAR_CELLS;
-  // fold the partial minima of every min-z workgroup of this frame (Cell::Cell: minZ = 1000, ground_removal.cpp:35-38)
+  // fold the partial minima of every min-z workgroup of this frame (Cell::Cell: minZ = 1000, ground_removal.cpp:35-38):
+  // a wave per workgroup list, eight independent loads in flight per lane
   const int nchunks = (g.n[b] + kGroundChunk - 1) / kGroundChunk;
   for (int i = threadIdx.x; i < MOT_POLAR_CELLS; i += kFilterBlock) s_minz[i] = kMinzInit;
   for (int c0 = 0; c0 < nchunks; c0 += 256) {
@@ -158,10 +172,52 @@ polar_filter_kernel(MotDevParams p, GroundBuffers g) {
     __syncthreads();
     const int wv = threadIdx.x >> 6, ln = threadIdx.x & 63, nwv = kFilterBlock / 64;
     const int lim = nchunks - c0 < 256 ? nchunks - c0 : 256;
-    for (int ch = wv; ch < lim; ch += nwv) {   // a wave per workgroup list; the loads of successive lists are independent
-      const int cnt = s_pcnt[ch];
-      const uint2* __restrict__ src = g.pairs + ((long)b * g.max_chunks + c0 + ch) * kGroundChunk;
-      for (int e = ln; e < cnt; e += 64) { uint2 q = src[e]; atomicMin(&s_minz[q.x], (int)q.y); }
+    // A lane takes 8 CONSECUTIVE entries (64 bytes: the wave still reads one contiguous 4 KB block) and merges equal
+    // neighbours in registers first: a cell's run that the min-z kernel split across threads comes back together, and the
+    // lanes of one LDS atomic instruction no longer hit the same cell. Four lists per wave are loaded before any is folded,
+    // so a wave pays one memory round trip for its share of the frame instead of one per list.
+    auto fold8 = [&](const uint2 (&q)[8]) {
+      unsigned cur = q[0].x;
+      int mn = (int)q[0].y;
+#pragma unroll
+      for (int u = 1; u < 8; u++) {
+        if (q[u].x == cur) mn = (int)q[u].y < mn ? (int)q[u].y : mn;
+        else {
+          if (cur != 0xffffffffu) atomicMin(&s_minz[cur], mn);
+          cur = q[u].x; mn = (int)q[u].y;
+        }
+      }
+      if (cur != 0xffffffffu) atomicMin(&s_minz[cur], mn);
+    };
+    auto load8 = [&](const uint2* __restrict__ src, int eb, int cnt, uint2 (&q)[8]) {
+      if (eb + 8 <= cnt) {
+        const uint4* __restrict__ s4 = reinterpret_cast<const uint4*>(src + eb);
+#pragma unroll
+        for (int u = 0; u < 4; u++) { const uint4 v = s4[u]; q[2 * u] = make_uint2(v.x, v.y); q[2 * u + 1] = make_uint2(v.z, v.w); }
+      } else {
+#pragma unroll
+        for (int u = 0; u < 8; u++) q[u] = eb + u < cnt ? src[eb + u] : make_uint2(0xffffffffu, 0u);
+      }
+    };
+    for (int ch0 = wv; ch0 < lim; ch0 += 4 * nwv) {
+      uint2 q[4][8];
+      int cnt[4];
+#pragma unroll
+      for (int l = 0; l < 4; l++) {
+        const int ch = ch0 + l * nwv;
+        cnt[l] = ch < lim ? s_pcnt[ch] : 0;
+        load8(g.pairs + ((long)b * g.max_chunks + c0 + ch) * kGroundChunk, ln * 8, cnt[l], q[l]);
+      }
+#pragma unroll
+      for (int l = 0; l < 4; l++) {
+        fold8(q[l]);
+        const uint2* __restrict__ src = g.pairs + ((long)b * g.max_chunks + c0 + ch0 + l * nwv) * kGroundChunk;
+        for (int e0 = 512; e0 < cnt[l]; e0 += 512) {   // a list longer than 512 entries: a badly fragmented chunk
+          uint2 r[8];
+          load8(src, e0 + ln * 8, cnt[l], r);
+          fold8(r);
+        }
+      }
     }
   }
   __syncthreads();
