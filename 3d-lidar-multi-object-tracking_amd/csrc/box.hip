@@ -4,7 +4,8 @@
 // OpenCV's minAreaRect / RotatedRect::points) — OT/src/cluster/box_fitting.cpp:46-435 — for a batch of frames:
 //
 //   B1 label_stats_kernel   N_e pts  -> per-point label + per-cluster {count, first point, max z, slope extrema}
-//   B2 cluster_gather_kernel  clusters -> L-shape fit, or the candidate hull points of the cluster (8 waves per cluster)
+//   B1b cluster_index_kernel groups  -> cluster-sorted stable point index
+//   B2 cluster_gather_kernel  clusters -> L-shape fit, or the candidate hull points of the cluster (4 waves per cluster)
 //   B2b cluster_rect_kernel  clusters -> min-area rectangle + rule filter (one wave per cluster)
 //   B3 box_finalize_kernel  clusters -> boxes compacted in cluster order (the order the reference push_backs them)
 //
@@ -12,14 +13,15 @@
 //  * the reference first copies the cloud into one vector per cluster; nothing here is copied. What the fit
 //    needs per cluster is (a) order-independent reductions — count, max z, slope arg-min/arg-max with
 //    "first occurrence wins" (strict </> in box_fitting.cpp:268-280) — done with wave-level matching on the
-//    label and one 64-bit atomic min/max per (wave, cluster) on keys that carry the point index as tie-break;
-//    (b) the FIRST point of the cluster (pixel re-centring, :218-225) = atomic min of the index; (c) for the
-//    L-shape branch the k-th point of the cluster in input order for 80 seeded k (mt19937_64(0) +
-//    libstdc++'s uniform_int_distribution): one wave walks the label array with ballot/popcount ranks.
+//    label, merged per workgroup in LDS, and one 64-bit atomic min/max per (workgroup, cluster) on keys that carry the
+//    point index as tie-break; (b) the FIRST point of the cluster (pixel re-centring, :218-225) = atomic min of the
+//    index; (c) for the L-shape branch the k-th point of the cluster in input order for 80 seeded k (mt19937_64(0) +
+//    libstdc++'s uniform_int_distribution): a lookup in the cluster-sorted index.
 //  * min-area rectangle: pixel coordinates are integers in [0,900], so only the lowest and highest pixel of
 //    every pixel column can be hull vertices; column extents are gathered with LDS atomics and handed — already
-//    sorted by (x,y) — to the same Sklansky scan / rotating calipers OpenCV runs (restated from OpenCV 3.2;
-//    tests/test_oracle_vs_ref.py::test_hull_column_reduction checks the reduction changes nothing).
+//    sorted by (x,y) — to a parallel peeling of the upper / lower chains that yields exactly the vertex list and order
+//    of OpenCV 3.2's convexHull, then to its rotating calipers (tests/test_oracle_vs_ref.py::test_hull_column_reduction
+//    and ::test_parallel_hull_construction check that neither step changes anything).
 //  * fp32 throughout, reference operation order, -ffp-contract=off. Double atan2/cos/sin of the rectangle
 //    angle come from the device math library; they are rounded to fp32 immediately.
 #include "mot_internal.h"
@@ -226,7 +228,10 @@ label_stats_kernel(MotDevParams p, ClusterBuffers c) {
 // (the reference's getClusteredPoints, box_fitting.cpp:46-72, without copying a point). The first slot of a group is
 // cluster_start + the number of the cluster's points in EARLIER tiles = a sum over the other groups of the cluster.
 constexpr int kIndexBlock = 1024;
-constexpr int kGroupsLds = 8192;
+#ifndef MOT_GROUPS_LDS
+#define MOT_GROUPS_LDS 8192
+#endif
+constexpr int kGroupsLds = MOT_GROUPS_LDS;
 __global__ void MOT_LAUNCH_BOUNDS(kIndexBlock)
 cluster_index_kernel(ClusterBuffers c) {
   __shared__ uint2 s_key[kGroupsLds];          // {label << 16 | tile (when both fit) ..., points} -- see below

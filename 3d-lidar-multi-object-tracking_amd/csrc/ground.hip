@@ -12,18 +12,19 @@
 // be read twice. The polar grid (38 KB per frame) lives in L2.
 //
 // Design notes (MI355X-first, not a translation of the CPU loops):
-//  * K1 has no grid at all and issues NO global atomics. Lidar clouds are beam-major, so the 64 points of a wave
-//    fall into 1–4 polar cells: the wave finds the distinct cells with ballot + readlane, min-reduces z per cell
-//    with a butterfly over the matching lanes, and ONE lane appends {cell, min} to the workgroup's list in LDS;
-//    the list (≈140 entries per 2048 points) leaves with plain coalesced stores. K2 folds every list of a frame
-//    into its LDS grid with LDS atomics. (A first version used one global atomicMin per (wave, cell): rocprof showed
-//    8.2k device-scope atomics per frame, each a memory-side transaction — they, not HBM or the ALU, bounded K1.)
+//  * K1 has no grid at all and issues NO atomics: beam-major clouds put a cell's points next to each other, so every
+//    thread folds the runs of equal cells among 8 consecutive points in registers and appends {cell, min} entries to the
+//    workgroup's list, which leaves with plain coalesced stores; K2 folds every list of a frame into its LDS grid.
+//  * the polar cell is computed by a guarded fast path (mot_internal.h): hardware sqrt/rcp + an atan polynomial, exact
+//    whenever the estimate is not within 1e-4 of a cell boundary; the bit-exact evaluation (correctly rounded sqrtf,
+//    glibc's atan2f, IEEE divide) decides the remaining 4e-4 of the points. Per-point instruction count is what bounds
+//    K1/K3 after HBM (a wave64 VALU instruction holds its SIMD for 4 cycles).
 //  * min z travels as an order-preserving int key so integer min is exact.
 //  * K3 preserves input order (the reference push_backs in order and box fitting depends on it,
 //    SURVEY.md H9) with a single-pass chained scan: per-workgroup ballot/popcount ranks + a decoupled
 //    look-back over 8-byte {status,counts} descriptors (one relaxed agent-scope store / load each; chunk
 //    ids come from an atomic ticket so a predecessor is always already running).
-//  * all fp32/fp64 expressions keep the reference's operation order; build with -ffp-contract=off.
+//  * all fp32/fp64 expressions that decide a result keep the reference's operation order; build with -ffp-contract=off.
 #include "mot_internal.h"
 #include "mot_wave.h"
 
@@ -51,10 +52,16 @@ __device__ __forceinline__ float4 load_stream(const float4* p) { return *p; }
 template <int ITEMS>
 __device__ __forceinline__ void polar_cells(const MotDevParams& p, const float4 (&pt)[ITEMS], const float4* __restrict__ in, long base, int n,
                                             int (&cell)[ITEMS]) {
-  unsigned undecided = 0;
+  unsigned undecided = 0, keep = ~0u;
+  if (p.crop_enable) {   // the node's pre-filter (uniform): kept out of the straight-line pass below
+    keep = 0;
+#pragma unroll
+    for (int k = 0; k < ITEMS; k++) keep |= mot_crop_keep(p, pt[k].x, pt[k].y, pt[k].z) ? 1u << k : 0u;
+  }
 #pragma unroll
   for (int k = 0; k < ITEMS; k++) {
-    int c = mot_crop_keep(p, pt[k].x, pt[k].y, pt[k].z) ? mot_polar_cell_try(p, pt[k].x, pt[k].y) : -1;
+    int c = mot_polar_cell_try(p, pt[k].x, pt[k].y);
+    if (!((keep >> k) & 1u)) c = -1;
     cell[k] = c;
     if (c == -2) undecided |= 1u << k;
   }
@@ -174,49 +181,32 @@ polar_filter_kernel(MotDevParams p, GroundBuffers g) {
     const int lim = nchunks - c0 < 256 ? nchunks - c0 : 256;
     // A lane takes 8 CONSECUTIVE entries (64 bytes: the wave still reads one contiguous 4 KB block) and merges equal
     // neighbours in registers first: a cell's run that the min-z kernel split across threads comes back together, and the
-    // lanes of one LDS atomic instruction no longer hit the same cell. Four lists per wave are loaded before any is folded,
-    // so a wave pays one memory round trip for its share of the frame instead of one per list.
-    auto fold8 = [&](const uint2 (&q)[8]) {
-      unsigned cur = q[0].x;
-      int mn = (int)q[0].y;
+    // lanes of one LDS atomic instruction no longer hit the same cell.
+    for (int ch = wv; ch < lim; ch += nwv) {
+      const int cnt = s_pcnt[ch];
+      const uint2* __restrict__ src = g.pairs + ((long)b * g.max_chunks + c0 + ch) * kGroundChunk;
+      for (int e0 = 0; e0 < cnt; e0 += 512) {
+        const int eb = e0 + ln * 8;
+        uint2 q[8];
+        if (eb + 8 <= cnt) {
+          const uint4* __restrict__ s4 = reinterpret_cast<const uint4*>(src + eb);
 #pragma unroll
-      for (int u = 1; u < 8; u++) {
-        if (q[u].x == cur) mn = (int)q[u].y < mn ? (int)q[u].y : mn;
-        else {
-          if (cur != 0xffffffffu) atomicMin(&s_minz[cur], mn);
-          cur = q[u].x; mn = (int)q[u].y;
+          for (int u = 0; u < 4; u++) { const uint4 v = s4[u]; q[2 * u] = make_uint2(v.x, v.y); q[2 * u + 1] = make_uint2(v.z, v.w); }
+        } else {
+#pragma unroll
+          for (int u = 0; u < 8; u++) q[u] = eb + u < cnt ? src[eb + u] : make_uint2(0xffffffffu, 0u);
         }
-      }
-      if (cur != 0xffffffffu) atomicMin(&s_minz[cur], mn);
-    };
-    auto load8 = [&](const uint2* __restrict__ src, int eb, int cnt, uint2 (&q)[8]) {
-      if (eb + 8 <= cnt) {
-        const uint4* __restrict__ s4 = reinterpret_cast<const uint4*>(src + eb);
+        unsigned cur = q[0].x;
+        int mn = (int)q[0].y;
 #pragma unroll
-        for (int u = 0; u < 4; u++) { const uint4 v = s4[u]; q[2 * u] = make_uint2(v.x, v.y); q[2 * u + 1] = make_uint2(v.z, v.w); }
-      } else {
-#pragma unroll
-        for (int u = 0; u < 8; u++) q[u] = eb + u < cnt ? src[eb + u] : make_uint2(0xffffffffu, 0u);
-      }
-    };
-    for (int ch0 = wv; ch0 < lim; ch0 += 4 * nwv) {
-      uint2 q[4][8];
-      int cnt[4];
-#pragma unroll
-      for (int l = 0; l < 4; l++) {
-        const int ch = ch0 + l * nwv;
-        cnt[l] = ch < lim ? s_pcnt[ch] : 0;
-        load8(g.pairs + ((long)b * g.max_chunks + c0 + ch) * kGroundChunk, ln * 8, cnt[l], q[l]);
-      }
-#pragma unroll
-      for (int l = 0; l < 4; l++) {
-        fold8(q[l]);
-        const uint2* __restrict__ src = g.pairs + ((long)b * g.max_chunks + c0 + ch0 + l * nwv) * kGroundChunk;
-        for (int e0 = 512; e0 < cnt[l]; e0 += 512) {   // a list longer than 512 entries: a badly fragmented chunk
-          uint2 r[8];
-          load8(src, e0 + ln * 8, cnt[l], r);
-          fold8(r);
+        for (int u = 1; u < 8; u++) {
+          if (q[u].x == cur) mn = (int)q[u].y < mn ? (int)q[u].y : mn;
+          else {
+            if (cur != 0xffffffffu) atomicMin(&s_minz[cur], mn);
+            cur = q[u].x; mn = (int)q[u].y;
+          }
         }
+        if (cur != 0xffffffffu) atomicMin(&s_minz[cur], mn);
       }
     }
   }
@@ -305,7 +295,7 @@ polar_filter_kernel(MotDevParams p, GroundBuffers g) {
 __global__ void MOT_LAUNCH_BOUNDS(kGroundBlock)
 classify_compact_kernel(MotDevParams p, GroundBuffers g) {
   __shared__ int s_chunk;
-  __shared__ int s_cnt_e[kSubTiles], s_cnt_g[kSubTiles];  // per 64-point tile counts -> exclusive prefixes
+  __shared__ int s_cnt[kSubTiles];  // per 64-point tile counts (elevated << 16 | ground) -> exclusive prefixes
   __shared__ int s_base_e, s_base_g;
   const int b = blockIdx.y;
   const int n = g.n[b];
@@ -329,48 +319,48 @@ classify_compact_kernel(MotDevParams p, GroundBuffers g) {
   float4 pt[kCompactItems];
   int cls[kCompactItems];    // MOT_MASK_*
   int rank[kCompactItems];   // rank inside the 64-point tile, among points of the same class
+  const bool full = base + kCompactChunk <= n;   // all but the frame's last chunk: no per-point bounds test
+  if (full) {
 #pragma unroll
-  for (int k = 0; k < kCompactItems; k++) {
-    long i = base + k * kGroundBlock + threadIdx.x;
-    pt[k] = i < n ? load_stream(&in[i]) : make_float4(0.f, 0.f, 0.f, 0.f);  // last use of the input cloud
+    for (int k = 0; k < kCompactItems; k++) pt[k] = load_stream(&in[base + k * kGroundBlock + threadIdx.x]);  // last use of the input cloud
+  } else {
+#pragma unroll
+    for (int k = 0; k < kCompactItems; k++) {
+      long i = base + k * kGroundBlock + threadIdx.x;
+      pt[k] = i < n ? load_stream(&in[i]) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
   }
   polar_cells<kCompactItems>(p, pt, in, base, n, cls);
   float hgv[kCompactItems];
 #pragma unroll
   for (int k = 0; k < kCompactItems; k++) hgv[k] = cls[k] >= 0 ? hg[cls[k]] : 0.f;   // 16 independent gathers (L2): -inf when the cell is not ground
+  const unsigned long long below = (1ull << lane) - 1ull;
 #pragma unroll
   for (int k = 0; k < kCompactItems; k++) {
     int c = MOT_MASK_DROPPED;
     if (cls[k] >= 0) c = ((double)pt[k].z < (double)hgv[k] + p.ground_margin) ? MOT_MASK_GROUND : MOT_MASK_ELEVATED;
     cls[k] = c;
-    unsigned long long be = __ballot(c == MOT_MASK_ELEVATED);
-    unsigned long long bg = __ballot(c == MOT_MASK_GROUND);
-    unsigned long long below = (1ull << lane) - 1ull;
+    const unsigned long long be = __ballot(c == MOT_MASK_ELEVATED);
+    const unsigned long long bg = __ballot(c == MOT_MASK_GROUND);
     rank[k] = __popcll((c == MOT_MASK_ELEVATED ? be : bg) & below);
-    if (lane == 0) {
-      s_cnt_e[k * 4 + wave] = __popcll(be);   // tile order inside the chunk: k-major, then wave
-      s_cnt_g[k * 4 + wave] = __popcll(bg);
-    }
+    if (lane == 0) s_cnt[k * 4 + wave] = (__popcll(be) << 16) | __popcll(bg);   // tile order inside the chunk: k-major, then wave
   }
   __syncthreads();
   if (wave == 0) {
-    // exclusive scan of the 64 tile counts and the chunk totals
-    int ce = lane < kSubTiles ? s_cnt_e[lane] : 0, cg = lane < kSubTiles ? s_cnt_g[lane] : 0;
-    int ie = ce, ig = cg;
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-      int oe = __shfl_up(ie, d, 64), og = __shfl_up(ig, d, 64);
-      if (lane >= d) { ie += oe; ig += og; }
-    }
-    int tot_e = __shfl(ie, 63, 64), tot_g = __shfl(ig, 63, 64);
-    if (lane < kSubTiles) { s_cnt_e[lane] = ie - ce; s_cnt_g[lane] = ig - cg; }
+    // exclusive scan of the 64 tile counts (elevated in the high half-word, ground in the low one; a chunk holds at most
+    // 4096 of either) and the chunk totals
+    const int cnt = s_cnt[lane];
+    const int incl = wave_scan_incl_i32(cnt);
+    const int tot = wave_bcast_i32(incl, 63);
+    const int tot_e = tot >> 16, tot_g = tot & 0xffff;
+    s_cnt[lane] = incl - cnt;
     // decoupled look-back over the chunks of THIS frame
     unsigned long long* desc = g.desc + (long)b * g.max_chunks;
     const unsigned long long ep = (unsigned long long)(g.epoch & kDescEpochMask) << kDescEpochShift;
     unsigned long long mine = ep | ((unsigned long long)(unsigned)tot_e << kDescCountBits) | (unsigned long long)(unsigned)tot_g;
-    long excl_e = 0, excl_g = 0;
+    int excl_e = 0, excl_g = 0;
 #ifdef MOT_DBG_K3_NOLOOKBACK
-    excl_e = (long)chunk * 600; excl_g = (long)chunk * 1448;
+    excl_e = chunk * 1200; excl_g = chunk * 2896;
     if (false) {
 #else
     if (chunk > 0) {
@@ -390,20 +380,18 @@ classify_compact_kernel(MotDevParams p, GroundBuffers g) {
         unsigned long long is_prefix = __ballot((d >> 62) == 2);
         int first = __ffsll(is_prefix) - 1;          // nearest predecessor holding an inclusive prefix
         bool take = first < 0 || lane <= first;
-        long ve = take ? (long)((d >> kDescCountBits) & kDescCountMask) : 0, vg = take ? (long)(d & kDescCountMask) : 0;
-#pragma unroll
-        for (int m = 32; m >= 1; m >>= 1) { ve += __shfl_xor(ve, m, 64); vg += __shfl_xor(vg, m, 64); }
-        excl_e += ve; excl_g += vg;
+        excl_e += wave_sum_i32(take ? (int)((d >> kDescCountBits) & kDescCountMask) : 0);   // a frame holds < 2^21 points
+        excl_g += wave_sum_i32(take ? (int)(d & kDescCountMask) : 0);
         if (first >= 0) break;
         win_end -= 64;
       }
     }
     if (lane == 0) {
-      unsigned long long incl = ep | ((unsigned long long)(excl_e + tot_e) << kDescCountBits) | (unsigned long long)(excl_g + tot_g);
-      __hip_atomic_store(&desc[chunk], kDescPrefix | incl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      s_base_e = (int)excl_e; s_base_g = (int)excl_g;
+      unsigned long long incl_d = ep | ((unsigned long long)(unsigned)(excl_e + tot_e) << kDescCountBits) | (unsigned long long)(unsigned)(excl_g + tot_g);
+      __hip_atomic_store(&desc[chunk], kDescPrefix | incl_d, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      s_base_e = excl_e; s_base_g = excl_g;
       if (chunk == nchunks - 1) {
-        int ne = (int)excl_e + tot_e, ng = (int)excl_g + tot_g;
+        int ne = excl_e + tot_e, ng = excl_g + tot_g;
         g.counts[b * kCountsStride + kCntElev] = ne; g.counts[b * kCountsStride + kCntGround] = ng; g.counts[b * kCountsStride + kCntDropped] = n - ne - ng;
       }
     }
@@ -415,11 +403,23 @@ classify_compact_kernel(MotDevParams p, GroundBuffers g) {
   const int be0 = s_base_e, bg0 = s_base_g;
 #pragma unroll
   for (int k = 0; k < kCompactItems; k++) {
-    long i = base + k * kGroundBlock + threadIdx.x;
-    int t = k * 4 + wave;
-    if (cls[k] == MOT_MASK_ELEVATED) out_e[be0 + s_cnt_e[t] + rank[k]] = pt[k];
-    else if (cls[k] == MOT_MASK_GROUND) out_g[bg0 + s_cnt_g[t] + rank[k]] = pt[k];
-    if (mask && i < n) mask[i] = (uint8_t)cls[k];
+    const int ex = s_cnt[k * 4 + wave];   // the tile's exclusive prefixes (wave-uniform)
+    const bool is_e = cls[k] == MOT_MASK_ELEVATED;
+    float4* __restrict__ dst = is_e ? out_e : out_g;
+    const int at = (is_e ? be0 + (ex >> 16) : bg0 + (ex & 0xffff)) + rank[k];
+    if (cls[k] != MOT_MASK_DROPPED) dst[at] = pt[k];
+  }
+  if (mask) {
+    if (full) {
+#pragma unroll
+      for (int k = 0; k < kCompactItems; k++) mask[base + k * kGroundBlock + threadIdx.x] = (uint8_t)cls[k];
+    } else {
+#pragma unroll
+      for (int k = 0; k < kCompactItems; k++) {
+        long i = base + k * kGroundBlock + threadIdx.x;
+        if (i < n) mask[i] = (uint8_t)cls[k];
+      }
+    }
   }
 }
 

@@ -130,7 +130,10 @@ void mot_launch_stats_init(const ClusterBuffers& c, int batch, hipStream_t strea
 void mot_launch_box_kernel(int which, const MotDevParams& p, const ClusterBuffers& c, int batch, int max_n, hipStream_t stream);
 
 // ---- tracker stage ---------------------------------------------------------------------------
-constexpr int kTrackBlock = 1024;                 // one workgroup (16 waves) steps one sensor stream
+#ifndef MOT_TRACK_BLOCK
+#define MOT_TRACK_BLOCK 1024
+#endif
+constexpr int kTrackBlock = MOT_TRACK_BLOCK;      // one workgroup (a wave per live track at a time) steps one sensor stream
 constexpr int kTrackWaves = kTrackBlock / 64;
 constexpr int kGateWords = kMaxBoxesPerFrame / 64;  // gate bit-mask of one track over the frame's boxes
 
@@ -251,18 +254,20 @@ MOT_HD int mot_polar_cell_fast(const MotDevParams& p, float x, float y, float di
   const float mn = ax < ay ? ax : ay;
   const float q = mn * rcp_mx;
   const float s = q * q;
+  // an estimate: fused multiply-adds are welcome here (the build has -ffp-contract=off for everything that must round
+  // as the reference does)
   float a = 0.006658289581537247f;
-  a = a * s + -0.03310525044798851f;
-  a = a * s + 0.0789998322725296f;
-  a = a * s + -0.13195902109146118f;
-  a = a * s + 0.19796891510486603f;
-  a = a * s + -0.33316001296043396f;
-  a = a * s + 0.9999956488609314f;
+  a = __builtin_fmaf(a, s, -0.03310525044798851f);
+  a = __builtin_fmaf(a, s, 0.0789998322725296f);
+  a = __builtin_fmaf(a, s, -0.13195902109146118f);
+  a = __builtin_fmaf(a, s, 0.19796891510486603f);
+  a = __builtin_fmaf(a, s, -0.33316001296043396f);
+  a = __builtin_fmaf(a, s, 0.9999956488609314f);
   a = a * q;
   if (ay > ax) a = 1.57079632679489662f - a;
   if (x < 0.f) a = 3.14159265358979324f - a;
   if (y < 0.f) a = -a;
-  const float tc = (a + 3.14159265358979324f) * (MOT_NUM_CHANNEL / 6.28318530717958648f);
+  const float tc = __builtin_fmaf(a, MOT_NUM_CHANNEL / 6.28318530717958648f, MOT_NUM_CHANNEL / 2.0f);
   const float fc = floorf(tc), rc = tc - fc;
   const bool safe = bin_safe && rc > kCellGuard && rc < 1.f - kCellGuard;  // false on NaN
   if (!safe) return -2;

@@ -49,6 +49,19 @@ __device__ __forceinline__ unsigned long long wave_reduce_u64(unsigned long long
   return ((unsigned long long)hi << 32) | lo;
 }
 __device__ __forceinline__ int wave_bcast_i32(int v, int lane) { return __builtin_amdgcn_readlane(v, lane); }
+// inclusive prefix sum over the 64 lanes: Kogge-Stone inside each row of 16 (row_shr:1,2,4,8, zero fill), then the row
+// totals ripple with row_bcast:15 / row_bcast:31 — eight v_add_u32_dpp, no LDS
+#define MOT_DPP_Z(v, ctrl, rmask) __builtin_amdgcn_update_dpp(0, (v), (ctrl), (rmask), 0xf, true)
+__device__ __forceinline__ int wave_scan_incl_i32(int v) {
+  v += MOT_DPP_Z(v, 0x111, 0xf);
+  v += MOT_DPP_Z(v, 0x112, 0xf);
+  v += MOT_DPP_Z(v, 0x114, 0xf);
+  v += MOT_DPP_Z(v, 0x118, 0xf);
+  v += MOT_DPP_Z(v, 0x142, 0xa);
+  v += MOT_DPP_Z(v, 0x143, 0xc);
+  return v;
+}
+__device__ __forceinline__ int wave_sum_i32(int v) { return __builtin_amdgcn_readlane(wave_scan_incl_i32(v), 63); }
 #else
 template <typename Op>
 __device__ __forceinline__ int wave_reduce_i32(int v, Op op) {
@@ -63,6 +76,12 @@ __device__ __forceinline__ unsigned long long wave_reduce_u64(unsigned long long
   return v;
 }
 __device__ __forceinline__ int wave_bcast_i32(int v, int lane) { return __shfl(v, lane, 64); }
+__device__ __forceinline__ int wave_scan_incl_i32(int v) {
+  const int lane = (int)(threadIdx.x & 63);
+  for (int d = 1; d < 64; d <<= 1) { int o = __shfl_up(v, d, 64); if (lane >= d) v += o; }
+  return v;
+}
+__device__ __forceinline__ int wave_sum_i32(int v) { return __shfl(wave_scan_incl_i32(v), 63, 64); }
 #endif
 
 // sum of a double over the wave (all lanes receive it)

@@ -84,10 +84,10 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--batch", type=int, default=256, help="sensor streams (one frame each) per GPU per step")
+    ap.add_argument("--batch", type=int, default=384, help="sensor streams (one frame each) per GPU per step")
     ap.add_argument("--points", type=int, default=120000)
     ap.add_argument("--frames", type=int, default=4, help="distinct consecutive frames resident per stream")
-    ap.add_argument("--contexts", type=int, default=2, help="contexts (HIP streams) per GPU the streams are split over: the "
+    ap.add_argument("--contexts", type=int, default=3, help="contexts (HIP streams) per GPU the streams are split over: the "
                     "latency-bound kernels of one (CCL, polygon, tracker: one workgroup per stream) overlap the streaming kernels of the other")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
