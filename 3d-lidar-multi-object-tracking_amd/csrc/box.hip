@@ -73,7 +73,6 @@ __global__ void stats_init_kernel(ClusterBuffers c) {
 // ------------------------------------------------------------------------------------------ B1
 // getClusteredPoints :46-72 (label of every point) + the per-point loop of getBoundingBox :239-293
 constexpr int kGroupsPerWg = 512;   // (tile, cluster) groups a workgroup stages in LDS; any beyond go straight to global memory
-constexpr int kWgClusters = 64;     // distinct clusters a workgroup merges in LDS before touching the global statistics
 __device__ __forceinline__ void stats_commit(ClusterStats* s, int count, int first, int rz, unsigned long long rmin, unsigned long long rmax) {
   atomicAdd(&s->count, count);
   atomicMin(&s->first, first);
@@ -93,6 +92,9 @@ label_stats_kernel(MotDevParams p, ClusterBuffers c) {
   __shared__ int s_tab_label[kWgClusters], s_tab_count[kWgClusters], s_tab_first[kWgClusters], s_tab_rz[kWgClusters];
   __shared__ unsigned long long s_tab_rmin[kWgClusters], s_tab_rmax[kWgClusters];
   __shared__ int s_wcount[kWaves], s_gbase;
+  constexpr int kTilesPerChunk = kLabelChunk / 64;
+  __shared__ int s_slot[kGroupsPerWg];
+  __shared__ int s_tilecnt[kWgClusters][kTilesPerChunk + 1];   // +1: the 64 scanning threads walk different banks
   const int b = blockIdx.y;
   const int n = c.counts[b * kCountsStride + kCntElev];
   const long base = (long)blockIdx.x * kLabelChunk;
@@ -101,6 +103,7 @@ label_stats_kernel(MotDevParams p, ClusterBuffers c) {
     s_tab_label[threadIdx.x] = 0; s_tab_count[threadIdx.x] = 0; s_tab_first[threadIdx.x] = 0x7fffffff;
     s_tab_rz[threadIdx.x] = mot_float_key(-99.f); s_tab_rmin[threadIdx.x] = kArgminInit; s_tab_rmax[threadIdx.x] = kArgmaxInit;
   }
+  for (int i = threadIdx.x; i < kWgClusters * (kLabelChunk / 64 + 1); i += kLabelBlock) (&s_tilecnt[0][0])[i] = 0;
 #ifdef MOT_DBG_B1_TIMING
   const long long t_start = clock64();
   int* dbg = c.poly + (long)b * c.cap + blockIdx.x * 8;
@@ -112,24 +115,43 @@ label_stats_kernel(MotDevParams p, ClusterBuffers c) {
   const float4* __restrict__ pts = c.elevated + (long)b * c.cap;
   const int* __restrict__ grid = c.grid + (long)b * (MOT_MAX_GRID * MOT_MAX_GRID);
   int* __restrict__ label = c.label + (long)b * c.cap;
+  int* __restrict__ pix = c.pix + (long)b * c.cap;
   ClusterStats* __restrict__ stats = c.stats + (long)b * kMaxClusters;
   PointGroup* __restrict__ out = c.groups + (long)b * c.group_cap;
   const int lane = lane_id(), wave = threadIdx.x >> 6;
   constexpr int kNoMin = 0x7fffffff, kNoMax = (int)0x80000000;
   int wn = 0;   // groups this wave has produced (wave-uniform)
+  // all loads first, then all label gathers: 8 + 8 independent requests in flight instead of 16 dependent round trips
+  float4 qs[kLabelItems];
+  int labs[kLabelItems];
 #pragma unroll
   for (int k = 0; k < kLabelItems; k++) {
     long i = base + k * kLabelBlock + threadIdx.x;
-    int lab = 0;
-    float4 q = make_float4(0.f, 0.f, 0.f, 0.f);
+    qs[k] = i < n ? pts[i] : make_float4(1.0e9f, 1.0e9f, 0.f, 0.f);   // outside every ROI
+  }
+#pragma unroll
+  for (int k = 0; k < kLabelItems; k++) {
+    int xI, yI;
+    labs[k] = mot_cart_cell(p, qs[k].x, qs[k].y, &xI, &yI) ? xI * p.num_grid + yI : -1;
+  }
+#pragma unroll
+  for (int k = 0; k < kLabelItems; k++) labs[k] = labs[k] >= 0 ? grid[labs[k]] : 0;
+#pragma unroll
+  for (int k = 0; k < kLabelItems; k++) {
+    long i = base + k * kLabelBlock + threadIdx.x;
+    int lab = labs[k];
+    const float4 q = qs[k];
+    if (lab < 0 || lab > num_cluster) lab = 0;
     if (i < n) {
-      q = pts[i];
-      int xI, yI;
-      if (mot_cart_cell(p, q.x, q.y, &xI, &yI)) lab = grid[xI * p.num_grid + yI];
-      if (lab < 0 || lab > num_cluster) lab = 0;
       label[i] = lab;
-      if (lab > kMaxClusters) lab = 0;  // no statistics slot: box_finalize_kernel raises the capacity flag
+      // picture pixel of the point (box_fitting.cpp:244-254, before the per-cluster re-centring): the rectangle branch of
+      // the gather kernel works on these, read in cluster-sorted order, instead of fetching every point again
+      const float roiX = q.x + p.roi_half, roiY = q.y + p.roi_half;
+      const int picX = (int)floorf(roiX * p.pic_scale), y = (int)floorf(roiY * p.pic_scale);
+      const int picY = (int)(p.pic_full - (float)y);
+      pix[i] = ((picX >= 0 && picX < 1024) ? picX : 0xffff) | (picY << 16);
     }
+    if (lab > kMaxClusters) lab = 0;  // no statistics slot: box_finalize_kernel raises the capacity flag
     float m = q.y / q.x + 0.0f;  // slope, :264 (+0 makes -0 == +0 for the keyed compare, as `<` does)
     // `m < minM` with minM = 999 / `m > maxM` with maxM = -999 (NaN never compares); "first occurrence wins" (strict
     // compares, :268-280) = the lowest lane among those holding the extreme key
@@ -160,10 +182,12 @@ label_stats_kernel(MotDevParams p, ClusterBuffers c) {
         if (wn < kPerWave) {
           const int e = wave * kPerWave + wn;
           s_groups[e] = g; s_rmin[e] = rmin; s_rmax[e] = rmax; s_rz[e] = rz;
-        } else {  // more groups than the LDS stage holds (a badly fragmented chunk): this one goes out on its own
+        } else {  // more groups than the LDS stage holds (a badly fragmented chunk): this one goes out on its own,
+          // and the index kernel falls back to its general path for this frame
           stats_commit(&stats[l - 1], __popcll(mm), (int)i, rz, rmin, rmax);
           const int gs = atomicAdd(&c.counts[b * kCountsStride + kCntGroups], 1);
           if (gs < c.group_cap) out[gs] = g;
+          c.counts[b * kCountsStride + kCntIrregular] = 1;
         }
       }
       wn++;
@@ -187,7 +211,7 @@ label_stats_kernel(MotDevParams p, ClusterBuffers c) {
     for (int x = 1; x < kWaves; x++) if (t >= wbase[x]) w = x;
     const int e = w * kPerWave + (t - wbase[w]);
     const PointGroup g = s_groups[e];
-    unsigned h = ((unsigned)g.label * 0x9E3779B1u) >> 26;
+    unsigned h = mot_label_hash(g.label);
     int slot = -1;
 #pragma unroll 1
     for (int probe = 0; probe < kWgClusters; probe++) {
@@ -201,20 +225,37 @@ label_stats_kernel(MotDevParams p, ClusterBuffers c) {
       atomicMin(&s_tab_rmin[slot], s_rmin[e]); atomicMax(&s_tab_rmax[slot], s_rmax[e]);
     } else {
       stats_commit(&stats[g.label - 1], cnt, first, s_rz[e], s_rmin[e], s_rmax[e]);   // more than 64 clusters in this chunk
+      c.counts[b * kCountsStride + kCntIrregular] = 1;
     }
+    // this group's points, filed under (table slot, tile of the chunk): the prefix over tiles below gives the number of the
+    // cluster's points in earlier tiles of this chunk (the index kernel adds the earlier chunks' totals)
+    s_slot[e] = slot;
+    if (slot >= 0) s_tilecnt[slot][g.tile & (kTilesPerChunk - 1)] = cnt;
   }
   __syncthreads();
   B1_T(3);
+  if (threadIdx.x < kWgClusters && s_tab_label[threadIdx.x]) {   // exclusive prefix over the 32 tiles of the chunk, one table slot per thread
+    int run = 0;
+#pragma unroll
+    for (int t2 = 0; t2 < kTilesPerChunk; t2++) { const int v = s_tilecnt[threadIdx.x][t2]; s_tilecnt[threadIdx.x][t2] = run; run += v; }
+  }
   if (threadIdx.x < kWgClusters && s_tab_label[threadIdx.x])
     stats_commit(&stats[s_tab_label[threadIdx.x] - 1], s_tab_count[threadIdx.x], s_tab_first[threadIdx.x], s_tab_rz[threadIdx.x],
                  s_tab_rmin[threadIdx.x], s_tab_rmax[threadIdx.x]);
+  __syncthreads();
+  // the workgroup's table, for the index kernel's cross-chunk prefix
+  if (threadIdx.x < kWgClusters && (int)blockIdx.x < c.max_wg)
+    c.wgtab[((long)b * c.max_wg + blockIdx.x) * kWgClusters + threadIdx.x] = make_int2(s_tab_label[threadIdx.x], s_tab_count[threadIdx.x]);
   // the (tile, cluster) groups leave with ONE returning global atomic (a slot reservation)
   const int gb = s_gbase;
   for (int t = threadIdx.x; t < ng; t += kLabelBlock) {
     int w = 0;
 #pragma unroll
     for (int x = 1; x < kWaves; x++) if (t >= wbase[x]) w = x;
-    if (gb + t < c.group_cap) out[gb + t] = s_groups[w * kPerWave + (t - wbase[w])];
+    const int e = w * kPerWave + (t - wbase[w]);
+    PointGroup g = s_groups[e];
+    if (s_slot[e] >= 0) g.tile |= s_tilecnt[s_slot[e]][g.tile & (kTilesPerChunk - 1)] << kGroupTileBits;   // < 2048 points per chunk
+    if (gb + t < c.group_cap) out[gb + t] = g;
   }
   B1_T(5);
 #ifdef MOT_DBG_B1_TIMING
@@ -226,31 +267,46 @@ label_stats_kernel(MotDevParams p, ClusterBuffers c) {
 // one workgroup per frame: turns the (tile, cluster) groups into the cluster-sorted point index
 //   sorted[cluster_start[c] + r] = index of the r-th point of cluster c in input order
 // (the reference's getClusteredPoints, box_fitting.cpp:46-72, without copying a point). The first slot of a group is
-// cluster_start + the number of the cluster's points in EARLIER tiles = a sum over the other groups of the cluster.
+//   cluster_start[c] + (points of c in earlier 2048-point chunks) + (points of c in earlier tiles of its own chunk);
+// the last term comes with the group from the label kernel, the middle one is a prefix over the label kernel's
+// per-workgroup tables — O(groups) work here. A frame the label kernel flagged irregular (a chunk with more than 64
+// clusters or more than 128 groups per wave) or with more than 64 chunks of elevated points takes the general path: the
+// sum over all the other groups of the cluster.
 constexpr int kIndexBlock = 1024;
+constexpr int kIndexWaves = kIndexBlock / 64;
 #ifndef MOT_GROUPS_LDS
-#define MOT_GROUPS_LDS 8192
+#define MOT_GROUPS_LDS 6144
 #endif
-constexpr int kGroupsLds = MOT_GROUPS_LDS;
+constexpr int kGroupsLds = MOT_GROUPS_LDS;    // general path: groups whose keys fit in LDS
+constexpr int kIndexWgLds = 64;               // fast path: label-kernel workgroups whose tables fit in LDS
 __global__ void MOT_LAUNCH_BOUNDS(kIndexBlock)
 cluster_index_kernel(ClusterBuffers c) {
-  __shared__ uint2 s_key[kGroupsLds];          // {label << 16 | tile (when both fit) ..., points} -- see below
   __shared__ int s_start[kMaxClusters + 1];
-  __shared__ int s_part[kIndexBlock / 64];
+  __shared__ int s_part[kIndexWaves];
+  __shared__ uint2 s_raw[kGroupsLds];   // fast path: {cluster, points} tables [wg][64] then their prefixes; general path: group keys
+  static_assert(kGroupsLds * sizeof(uint2) >= kIndexWgLds * kWgClusters * (sizeof(int2) + sizeof(int)), "LDS union too small");
   const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int num_cluster = min(c.counts[b * kCountsStride + kCntClusters], kMaxClusters);
+  const int n = c.counts[b * kCountsStride + kCntElev];
   int E = c.counts[b * kCountsStride + kCntGroups];
   if (E > c.group_cap) { E = c.group_cap; if (tid == 0) atomicOr(&c.counts[b * kCountsStride + kCntFlags], (int)kFlagGroupOverflow); }
+  const int nwg = (n + kLabelChunk - 1) / kLabelChunk;
+  const bool fast = c.counts[b * kCountsStride + kCntIrregular] == 0 && nwg <= kIndexWgLds && nwg <= c.max_wg;
   const PointGroup* __restrict__ groups = c.groups + (long)b * c.group_cap;
   const ClusterStats* __restrict__ stats = c.stats + (long)b * kMaxClusters;
+#ifdef MOT_DBG_B1B_TIMING
+  const long long t_start = clock64();
+  int* dbg = c.poly + (long)b * c.cap;
+#define B1B_T(slot) if (tid == 0) dbg[slot] = (int)(clock64() - t_start)
+#else
+#define B1B_T(slot)
+#endif
   // exclusive scan of the cluster sizes (4 per thread)
   {
     int v[4], sum = 0;
 #pragma unroll
     for (int k = 0; k < 4; k++) { int ci = tid * 4 + k; v[k] = ci < num_cluster ? stats[ci].count : 0; sum += v[k]; }
-    int incl = sum;
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) { int o = __shfl_up(incl, d, 64); if (lane >= d) incl += o; }
+    const int incl = wave_scan_incl_i32(sum);
     if (lane == 63) s_part[wave] = incl;
     __syncthreads();
     int run = incl - sum;
@@ -258,25 +314,92 @@ cluster_index_kernel(ClusterBuffers c) {
 #pragma unroll
     for (int k = 0; k < 4; k++) { int ci = tid * 4 + k; if (ci <= kMaxClusters) s_start[ci] = run; run += v[k]; }
   }
-  const bool in_lds = E <= kGroupsLds;
-  if (in_lds) for (int e = tid; e < E; e += kIndexBlock) { PointGroup g = groups[e]; s_key[e] = make_uint2((unsigned)g.label, ((unsigned)g.tile << 8) | (unsigned)__popcll(g.mask)); }
-  __syncthreads();
+  B1B_T(0);
   int* __restrict__ cstart = c.cluster_start + (long)b * (kMaxClusters + 1);
-  for (int ci = tid; ci <= num_cluster; ci += kIndexBlock) cstart[ci] = s_start[ci];
   int* __restrict__ sorted = c.sorted + (long)b * c.cap;
-  for (int e = tid; e < E; e += kIndexBlock) {
-    const PointGroup g = groups[e];
-    int before = 0;  // points of the same cluster in earlier tiles
-    if (in_lds) {
-      for (int f = 0; f < E; f++) { uint2 q = s_key[f]; if ((int)q.x == g.label && (int)(q.y >> 8) < g.tile) before += (int)(q.y & 0xffu); }
-    } else {  // more groups than fit in LDS (heavily interleaved clusters): same sum straight from L2
-      for (int f = 0; f < E; f++) { PointGroup h = groups[f]; if (h.label == g.label && h.tile < g.tile) before += __popcll(h.mask); }
+  if (fast) {
+    int2* s_tab = reinterpret_cast<int2*>(s_raw);                       // [nwg][64] {cluster, points}
+    int* s_pref = reinterpret_cast<int*>(s_tab + kIndexWgLds * kWgClusters);   // [nwg][64] points of the cluster in earlier chunks
+    const int2* __restrict__ gtab = c.wgtab + (long)b * c.max_wg * kWgClusters;
+    const int entries = nwg * kWgClusters;
+    for (int i = tid; i < entries; i += kIndexBlock) s_tab[i] = gtab[i];
+    __syncthreads();
+    B1B_T(1);
+    for (int ci = tid; ci <= num_cluster; ci += kIndexBlock) cstart[ci] = s_start[ci];
+    for (int i = tid; i < entries; i += kIndexBlock) {
+      const int2 t = s_tab[i];
+      int pref = 0;
+      if (t.x) {
+        const int wg = i / kWgClusters;
+        for (int w2 = 0; w2 < wg; w2++) {   // the cluster's entry in every earlier chunk's table (same hash, linear probing)
+          unsigned h = mot_label_hash(t.x);
+#pragma unroll 1
+          for (int probe = 0; probe < kWgClusters; probe++) {
+            const int2 o = s_tab[w2 * kWgClusters + (int)h];
+            if (o.x == t.x) { pref += o.y; break; }
+            if (o.x == 0) break;
+            h = (h + 1) & (kWgClusters - 1);
+          }
+        }
+      }
+      s_pref[i] = pref;
     }
-    int pos = s_start[g.label - 1] + before;
-    unsigned long long m = g.mask;
-    while (m) { sorted[pos++] = g.tile * 64 + __ffsll(m) - 1; m &= m - 1ull; }
+    __syncthreads();
+    B1B_T(2);
+    // 64 groups per wave at a time: every lane works out the first slot of ITS group from the tables, then the wave walks
+    // the 64 groups with one lane per point of the tile (four readlanes and a store per group)
+    for (int g0 = wave * 64; g0 < E; g0 += kIndexBlock) {
+      PointGroup mine;
+      mine.mask = 0ull; mine.label = 0; mine.tile = 0;
+      int mypos = 0;
+      if (g0 + lane < E) {
+        mine = groups[g0 + lane];
+        const int tile = mine.tile & kGroupTileMask, within = (int)((unsigned)mine.tile >> kGroupTileBits);
+        const int wg = tile / (kLabelChunk / 64);
+        unsigned h = mot_label_hash(mine.label);
+        int pref = 0;
+#pragma unroll 1
+        for (int probe = 0; probe < kWgClusters; probe++) {
+          const int2 o = s_tab[wg * kWgClusters + (int)h];
+          if (o.x == mine.label) { pref = s_pref[wg * kWgClusters + (int)h]; break; }
+          if (o.x == 0) break;
+          h = (h + 1) & (kWgClusters - 1);
+        }
+        mypos = s_start[mine.label - 1] + pref + within;
+      }
+      const int cnt = E - g0 < 64 ? E - g0 : 64;
+      for (int j = 0; j < cnt; j++) {
+        const unsigned mlo = (unsigned)wave_bcast_i32((int)(unsigned)mine.mask, j), mhi = (unsigned)wave_bcast_i32((int)(unsigned)(mine.mask >> 32), j);
+        const unsigned long long m = ((unsigned long long)mhi << 32) | mlo;
+        const int tile = wave_bcast_i32(mine.tile, j) & kGroupTileMask, pos = wave_bcast_i32(mypos, j);
+        if ((m >> lane) & 1ull) sorted[pos + __popcll(m & ((1ull << lane) - 1ull))] = tile * 64 + lane;
+      }
+    }
+  } else {
+    uint2* s_key = s_raw;   // {cluster, tile << 8 | points}
+    const bool in_lds = E <= kGroupsLds;
+    if (in_lds) for (int e = tid; e < E; e += kIndexBlock) { PointGroup g = groups[e]; s_key[e] = make_uint2((unsigned)g.label, ((unsigned)(g.tile & kGroupTileMask) << 8) | (unsigned)__popcll(g.mask)); }
+    __syncthreads();
+    for (int ci = tid; ci <= num_cluster; ci += kIndexBlock) cstart[ci] = s_start[ci];
+    for (int e = tid; e < E; e += kIndexBlock) {
+      const PointGroup g = groups[e];
+      const int gtile = g.tile & kGroupTileMask;
+      int before = 0;  // points of the same cluster in earlier tiles
+      if (in_lds) {
+        for (int f = 0; f < E; f++) { uint2 q = s_key[f]; if ((int)q.x == g.label && (int)(q.y >> 8) < gtile) before += (int)(q.y & 0xffu); }
+      } else {  // more groups than fit in LDS (heavily interleaved clusters): same sum straight from L2
+        for (int f = 0; f < E; f++) { PointGroup h = groups[f]; if (h.label == g.label && (h.tile & kGroupTileMask) < gtile) before += __popcll(h.mask); }
+      }
+      int pos = s_start[g.label - 1] + before;
+      unsigned long long m = g.mask;
+      while (m) { sorted[pos++] = gtile * 64 + __ffsll(m) - 1; m &= m - 1ull; }
+    }
   }
-  if (tid == 0) c.counts[b * kCountsStride + kCntGroups] = 0;  // re-arm
+  B1B_T(3);
+#ifdef MOT_DBG_B1B_TIMING
+  if (tid == 0) { dbg[4] = E; dbg[5] = nwg; dbg[6] = fast; }
+#endif
+  if (tid == 0) { c.counts[b * kCountsStride + kCntGroups] = 0; c.counts[b * kCountsStride + kCntIrregular] = 0; }  // re-arm
 }
 
 // ------------------------------------------------------------------------------------------ B2
@@ -460,24 +583,21 @@ cluster_gather_kernel(MotDevParams p, ClusterBuffers c) {
       for (int i = tid; i < kPicCols; i += kBoxBlock) { s_colmin[i] = 0x7fffffff; s_colmax[i] = -0x7fffffff - 1; }
       __syncthreads();
       const int first_slot = cstart[ci];
+      // the cluster's points through the sorted index; what is fetched per point is its 4-byte picture pixel (label kernel)
+      const int* __restrict__ pix = c.pix + (long)b * c.cap;
       for (int j0 = 0; j0 < numPoints; j0 += kBoxBlock * kGatherDepth) {
-        int idx[kGatherDepth]; float4 q[kGatherDepth];  // kGatherDepth independent index loads, then point loads, in flight
+        int v[kGatherDepth];
 #pragma unroll
-        for (int u = 0; u < kGatherDepth; u++) { int j = j0 + u * kBoxBlock + tid; idx[u] = j < numPoints ? sorted[first_slot + j] : -1; }
+        for (int u = 0; u < kGatherDepth; u++) { int j = j0 + u * kBoxBlock + tid; v[u] = j < numPoints ? sorted[first_slot + j] : -1; }
 #pragma unroll
-        for (int u = 0; u < kGatherDepth; u++) q[u] = idx[u] >= 0 ? pts[idx[u]] : make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int u = 0; u < kGatherDepth; u++) v[u] = v[u] >= 0 ? pix[v[u]] : 0xffff;
 #pragma unroll
         for (int u = 0; u < kGatherDepth; u++) {
-          if (idx[u] >= 0) {
-            float roiX = q[u].x + p.roi_half, roiY = q[u].y + p.roi_half;  // :244-254
-            int x = (int)floorf(roiX * p.pic_scale), y = (int)floorf(roiY * p.pic_scale);
-            int picX = x;
-            int picY = (int)(p.pic_full - (float)y);
-            int offsetY = picY + offsetInitY;
-            if (picX >= 0 && picX < kPicCols) {  // look before the atomic: most points do not move an extreme
-              if (offsetY < s_colmin[picX]) atomicMin(&s_colmin[picX], offsetY);
-              if (offsetY > s_colmax[picX]) atomicMax(&s_colmax[picX], offsetY);
-            }
+          const int picX = v[u] & 0xffff;
+          if (picX != 0xffff) {  // look before the atomic: most points do not move an extreme
+            const int offsetY = (v[u] >> 16) + offsetInitY;
+            if (offsetY < s_colmin[picX]) atomicMin(&s_colmin[picX], offsetY);
+            if (offsetY > s_colmax[picX]) atomicMax(&s_colmax[picX], offsetY);
           }
         }
       }

@@ -41,18 +41,20 @@ cart_occupancy_kernel(MotDevParams p, ClusterBuffers c) {
   for (int i = threadIdx.x; i < kPlaneWords; i += kOccBlock) { s_a[i] = 0u; s_b[i] = 0u; }
   __syncthreads();
   const float4* __restrict__ pts = c.elevated + (long)b * c.cap;
+  float4 q[kOccItems];   // all loads first: eight independent requests in flight instead of eight round trips
 #pragma unroll
   for (int k = 0; k < kOccItems; k++) {
     long i = base + k * kOccBlock + threadIdx.x;
-    if (i < n) {
-      float4 q = pts[i];
-      int xI, yI;
-      if (mot_cart_cell(p, q.x, q.y, &xI, &yI)) {
-        int bit = xI * MOT_MAX_GRID + yI;
-        unsigned m = 1u << (bit & 31);
-        unsigned old = atomicOr(&s_a[bit >> 5], m);
-        if (old & m) atomicOr(&s_b[bit >> 5], m);
-      }
+    q[k] = i < n ? pts[i] : make_float4(1.0e9f, 1.0e9f, 0.f, 0.f);   // outside every ROI
+  }
+#pragma unroll
+  for (int k = 0; k < kOccItems; k++) {
+    int xI, yI;
+    if (mot_cart_cell(p, q[k].x, q[k].y, &xI, &yI)) {
+      int bit = xI * MOT_MAX_GRID + yI;
+      unsigned m = 1u << (bit & 31);
+      unsigned old = atomicOr(&s_a[bit >> 5], m);
+      if (old & m) atomicOr(&s_b[bit >> 5], m);
     }
   }
   __syncthreads();

@@ -48,6 +48,9 @@ struct mot_ctx {
   PointGroup* d_groups = nullptr;
   int* d_cluster_start = nullptr;
   int* d_sorted = nullptr;
+  int* d_pix = nullptr;
+  int2* d_wgtab = nullptr;
+  int max_wg = 0;
   // tracker stage
   DevTrack* d_tracks = nullptr;
   int* d_nt = nullptr;
@@ -173,7 +176,7 @@ static int make_dev_params(const mot_params& p, MotDevParams* d, std::string* er
 extern "C" void mot_destroy(mot_ctx* c) {
   if (!c) return;
   void* bufs[] = {c->d_in, c->d_n, c->d_pairs, c->d_pair_count, c->d_hg, c->d_desc, c->d_ticket, c->d_elev, c->d_ground, c->d_mask, c->d_counts,
-                  c->d_plane_a, c->d_plane_b, c->d_grid, c->d_label, c->d_stats, c->d_cand, c->d_boxes, c->d_box_cluster, c->d_rng, c->d_poly, c->d_groups, c->d_cluster_start, c->d_sorted,
+                  c->d_plane_a, c->d_plane_b, c->d_grid, c->d_label, c->d_stats, c->d_cand, c->d_boxes, c->d_box_cluster, c->d_rng, c->d_poly, c->d_groups, c->d_cluster_start, c->d_sorted, c->d_pix, c->d_wgtab,
                   c->d_tracks, c->d_nt, c->d_tboxes, c->d_targs, c->d_gate, c->d_prog, c->d_live, c->d_tout, c->d_tflags, c->d_ego, c->d_phase};
   for (void* b : bufs) if (b) (void)hipFree(b);
   if (c->h_counts) (void)hipHostFree(c->h_counts);
@@ -191,6 +194,7 @@ static ClusterBuffers cluster_buffers(mot_ctx* c) {
   b.elevated = c->d_elev; b.cap = c->cap; b.counts = c->d_counts; b.plane_a = c->d_plane_a; b.plane_b = c->d_plane_b;
   b.grid = c->d_grid; b.label = c->d_label; b.stats = c->d_stats; b.cand = c->d_cand; b.boxes = c->d_boxes;
   b.box_cluster = c->d_box_cluster; b.rng = c->d_rng; b.poly = c->d_poly; b.groups = c->d_groups; b.group_cap = c->cap / 2; b.cluster_start = c->d_cluster_start; b.sorted = c->d_sorted;
+  b.pix = c->d_pix; b.wgtab = c->d_wgtab; b.max_wg = c->max_wg;
   return b;
 }
 
@@ -229,6 +233,9 @@ static int create_impl(mot_ctx* c) {
   MOT_HIP(c, hipMalloc(&c->d_groups, B * (N / 2) * sizeof(PointGroup)));
   MOT_HIP(c, hipMalloc(&c->d_cluster_start, B * (kMaxClusters + 1) * sizeof(int)));
   MOT_HIP(c, hipMalloc(&c->d_sorted, B * N * sizeof(int)));
+  MOT_HIP(c, hipMalloc(&c->d_pix, B * N * sizeof(int)));
+  c->max_wg = (int)((N + 2047) / 2048);
+  MOT_HIP(c, hipMalloc(&c->d_wgtab, B * c->max_wg * kWgClusters * sizeof(int2)));
   {  // mt19937_64 mt(0), box_fitting.cpp:303 — raw draws; the libstdc++ range mapping is applied on the device
     std::mt19937_64 mt(0);
     unsigned long long raw[kRngTable];
@@ -433,7 +440,7 @@ extern "C" int mot_cluster(mot_ctx* c, const float* elev, int n, int32_t* grid, 
   if (point_label) {  // getClusteredPoints' per-point lookup; the statistics it also gathers are discarded
     mot_launch_box_kernel(0, c->dp, cb, 1, n, c->stream);
     mot_launch_stats_init(cb, 1, c->stream);
-    MOT_HIP(c, hipMemsetAsync(c->d_counts + kCntGroups, 0, sizeof(int), c->stream));
+    MOT_HIP(c, hipMemsetAsync(c->d_counts + kCntGroups, 0, 2 * sizeof(int), c->stream));   // kCntGroups, kCntIrregular
   }
   MOT_HIP(c, hipGetLastError());
   return mot_get_clusters(c, 0, grid, num_cluster, point_label);
@@ -684,6 +691,10 @@ extern "C" int mot_debug_copy(mot_ctx* c, int which, int slot, void* dst, size_t
   else if (which == 1) src = c->d_stats + (size_t)slot * kMaxClusters;
   else if (which == 2) src = c->d_phase + (size_t)slot * 16;
   else if (which == 3) src = c->d_poly + (size_t)slot * c->cap;
+  else if (which == 5) src = c->d_sorted + (size_t)slot * c->cap;
+  else if (which == 7) src = c->d_cluster_start + (size_t)slot * (kMaxClusters + 1);
+  else if (which == 8) src = c->d_pix + (size_t)slot * c->cap;
+  else if (which == 9) src = c->d_groups + (size_t)slot * (c->cap / 2);
   else return MOT_E_ARG;
   MOT_HIP(c, hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, c->stream));
   MOT_HIP(c, hipStreamSynchronize(c->stream));

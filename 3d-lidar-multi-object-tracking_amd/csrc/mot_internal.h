@@ -77,7 +77,8 @@ constexpr int kMaxClusters = 4096;                 // per frame (MOT_E_CAPACITY 
 constexpr int kMaxBoxesPerFrame = 1024;
 constexpr int kRngTable = 128;                     // raw mt19937_64(0) outputs kept on the device
 constexpr int kCountsStride = 12;                  // ints per frame in `counts`
-enum { kCntElev = 0, kCntGround = 1, kCntDropped = 2, kCntClusters = 3, kCntBoxes = 4, kCntUndef = 5, kCntFlags = 6, kCntPoly = 7, kCntGroups = 8 };
+enum { kCntElev = 0, kCntGround = 1, kCntDropped = 2, kCntClusters = 3, kCntBoxes = 4, kCntUndef = 5, kCntFlags = 6, kCntPoly = 7, kCntGroups = 8,
+       kCntIrregular = 9 };   // kCntGroups, kCntIrregular: label kernel -> index kernel, zero between launches
 enum { kFlagClusterOverflow = 1, kFlagBoxOverflow = 2, kFlagRngExhausted = 4, kFlagHullOverflow = 8, kFlagGroupOverflow = 16 };
 
 struct ClusterStats {          // per cluster, accumulated by the label kernel, reset by the finalize kernel
@@ -91,8 +92,12 @@ struct ClusterStats {          // per cluster, accumulated by the label kernel, 
 struct PointGroup {            // the points of one 64-point tile that belong to one cluster (label kernel)
   unsigned long long mask;     // lanes of the tile
   int label;                   // 1-based cluster id
-  int tile;                    // points 64*tile .. 64*tile + 63
+  int tile;                    // bits 0-19: points 64*tile .. 64*tile + 63; bits 20-31: points of the cluster in EARLIER tiles of the
+                               // same label-kernel workgroup (2048-point chunk)
 };
+constexpr int kGroupTileBits = 20;
+constexpr int kGroupTileMask = (1 << kGroupTileBits) - 1;
+constexpr int kWgClusters = 64;     // distinct clusters a label-kernel workgroup merges in LDS (its open-addressed table)
 struct BoxCandidate {          // per cluster, written by the box kernels
   float pc[8];                 // 4 corners (x,y)
   float max_z;
@@ -120,6 +125,9 @@ struct ClusterBuffers {
   int group_cap;               // cap / 2
   int* cluster_start;          // [B][kMaxClusters + 1] first slot of every cluster in `sorted`
   int* sorted;                 // [B][cap] point indices grouped by cluster, input order inside a cluster
+  int* pix;                    // [B][cap] picture pixel of every elevated point (x | y << 16, x = 0xffff outside), box_fitting.cpp:244-254
+  int2* wgtab;                 // [B][max_wg][kWgClusters] {cluster, points} per label-kernel workgroup (its LDS table, empty = {0,0})
+  int max_wg;                  // cap / 2048 rounded up
 };
 
 void mot_launch_cluster(const MotDevParams& p, const ClusterBuffers& c, int batch, int max_n, hipStream_t stream);
@@ -201,6 +209,8 @@ void mot_launch_ground_kernel(int which, const MotDevParams& p, const GroundBuff
                               hipStream_t stream);
 
 // ordered-int key of a float: signed integer compare == float compare
+// slot of a cluster in a label-kernel workgroup's 64-entry table (linear probing from here)
+MOT_HD unsigned mot_label_hash(int label) { return ((unsigned)label * 0x9E3779B1u) >> 26; }
 MOT_HD int mot_float_key(float f) { int k = mot_f2i(f); return k >= 0 ? k : k ^ 0x7fffffff; }
 MOT_HD float mot_key_float(int k) { return mot_i2f(k >= 0 ? k : k ^ 0x7fffffff); }
 

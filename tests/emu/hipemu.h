@@ -138,12 +138,14 @@ inline T shfl(T v, int src) {
   int b = w.gen & 1;
   uint64_t raw = 0; memcpy(&raw, &v, sizeof(T));
   w.buf[b][lane()] = raw;
-  int r = wave_rendezvous(w);
   State& s = S();
   int base = (s.cur->lin / kWave) * kWave;
   int srcl = src & (kWave - 1);
-  // a lane that has exited or does not exist returns the caller's own value
-  if (base + srcl >= s.nthreads || s.threads[base + srcl].done) return v;
+  // a lane that has exited or does not exist returns the caller's own value. Decided BEFORE the rendezvous: a lane that
+  // takes part in this exchange may run on and finish before the others get to read its slot.
+  const bool absent = base + srcl >= s.nthreads || s.threads[base + srcl].done;
+  int r = wave_rendezvous(w);
+  if (absent) return v;
   T out; memcpy(&out, &w.buf[r][srcl], sizeof(T));
   return out;
 }

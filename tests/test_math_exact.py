@@ -55,6 +55,7 @@ FAST_SRC = r"""
 #include <cstring>
 struct float4 { float x, y, z, w; };
 struct uint2 { unsigned x, y; };
+struct int2 { int x, y; };
 typedef void* hipStream_t;
 #include "mot_internal.h"
 static unsigned long long s = 88172645463325252ULL;

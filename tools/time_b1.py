@@ -15,11 +15,18 @@ host = np.zeros((B, stride, 4), np.float32)
 base = [synth.make_cloud(N, s, 0) for s in range(8)]
 for b in range(B): host[b, :N] = base[b % 8]
 dev = torch.from_numpy(host).cuda(); torch.cuda.synchronize()
-lib = build.build(extra_flags=["-DMOT_DBG_B1_TIMING"], out=os.path.join(ROOT, "gpurun_out", "libmot_b1t.so"))
+lib = build.build(extra_flags=["-DMOT_DBG_B1_TIMING", "-DMOT_DBG_B1B_TIMING"], out=os.path.join(ROOT, "gpurun_out", "libmot_b1t.so"))
 ctx = mot.Context(max_points=stride, max_batch=B, lib_path=lib)
 ctx.frames_dev(dev.data_ptr(), stride * 4, [N] * B); ctx.synchronize()
 ms = ctx.time_stage(30, B, 3)
 print("label_stats ms", ms)
+if len(sys.argv) > 1:
+    print("index ms", ctx.time_stage(34, B, 3))
+    for slot in (0, 5, 77):
+        buf = np.zeros(8, np.int32)
+        ctx.lib.mot_debug_copy(ctx._h, 3, slot, buf.ctypes.data_as(ctypes.c_void_p), ctypes.c_size_t(buf.nbytes))
+        print(slot, "index kernel cycles [scan, tables, prefixes, scatter, E, nwg, fast]:", buf[:7])
+    sys.exit(0)
 for slot in (0, 5, 77):
     ne = ctx.get_ground(slot, want_clouds=False)["n_elevated"]
     nwg = (ne + 2047) // 2048

@@ -23,12 +23,12 @@ import ctypes
 l = ctx.lib
 ms = ctx.time_stage(31, B, 3)   # leaves cand from gather overwritten by finalize? sequence: pre B1, timed B2, post B3 (B3 does not clear cand)
 cand_dt = np.dtype([("pc", "f4", 8), ("max_z", "f4"), ("accepted", "i4"), ("undefined", "i4"), ("branch", "i4"), ("poly_off", "i4"), ("poly_n", "i4"), ("off_x", "i4"), ("off_y", "i4"), ("num_points", "i4"), ("pad", "i4")])
-for slot in (0, 5, 7):
+for slot in (0, 7):
     buf = np.zeros(32, cand_dt)
     rc = l.mot_debug_copy(ctx._h, 0, slot, buf.ctypes.data_as(ctypes.c_void_p), ctypes.c_size_t(buf.nbytes))
     ncl = ctx.get_clusters(slot)["num_cluster"]
     for i in range(ncl):
         c = buf[i]
         if c["branch"] == 0: print(slot, i, "L  n=%d  t_prologue=%d t_rng=%d t_tiles=%d t_end=%d" % (c["num_points"], c["poly_off"], c["poly_n"], c["off_x"], c["off_y"]))
-        else: print(slot, i, "MAR n=%d  t_prologue=%d t_tiles=%d t_compact=%d" % (c["num_points"], c["pad"], c["poly_off"], c["poly_n"]))
+        else: print(slot, i, "MAR n=%d  t_prologue=%d t_tiles=%d t_compact=%d  wait=%d process=%d" % (c["num_points"], c["pad"], c["poly_off"], c["poly_n"], c["off_x"], c["off_y"]))
 print("gather ms", ms)
