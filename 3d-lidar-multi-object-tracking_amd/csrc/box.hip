@@ -403,9 +403,14 @@ cluster_index_kernel(ClusterBuffers c) {
 }
 
 // ------------------------------------------------------------------------------------------ B2
-constexpr int kBoxBlock = 256;       // one workgroup (4 waves) per cluster
-constexpr int kBoxWaves = kBoxBlock / 64;
-constexpr int kGatherDepth = 8;
+#ifndef MOT_BOX_BLOCK
+#define MOT_BOX_BLOCK 256
+#endif
+constexpr int kBoxBlock = MOT_BOX_BLOCK;       // one workgroup per cluster
+#ifndef MOT_GATHER_DEPTH
+#define MOT_GATHER_DEPTH 8
+#endif
+constexpr int kGatherDepth = MOT_GATHER_DEPTH;
 constexpr int kPicCols = 1024;       // pixel columns 0..900
 constexpr int kMaxHullIn = 2 * 901;  // two extreme pixels per column
 constexpr int kMaxHull = 384;        // vertices of a convex lattice polygon in a 900^2 box: < 3.5 * 900^(2/3) ~ 330
@@ -443,7 +448,6 @@ cluster_gather_kernel(MotDevParams p, ClusterBuffers c) {
   __shared__ int s_colmin[kPicCols], s_colmax[kPicCols];
   __shared__ short s_px[kMaxHullIn + 2], s_py[kMaxHullIn + 2];
   __shared__ int s_rank[128], s_pidx[128];
-  __shared__ int s_wsum[kBoxWaves];
   __shared__ int s_flag;
   const int b = blockIdx.y;
   const int n = c.counts[b * kCountsStride + kCntElev];
@@ -596,7 +600,7 @@ cluster_gather_kernel(MotDevParams p, ClusterBuffers c) {
           const int picX = v[u] & 0xffff;
           if (picX != 0xffff) {  // look before the atomic: most points do not move an extreme
             const int offsetY = (v[u] >> 16) + offsetInitY;
-            if (offsetY < s_colmin[picX]) atomicMin(&s_colmin[picX], offsetY);
+            if (offsetY < s_colmin[picX]) atomicMin(&s_colmin[picX], offsetY);   // (unconditional atomics: 60 -> 74 us)
             if (offsetY > s_colmax[picX]) atomicMax(&s_colmax[picX], offsetY);
           }
         }

@@ -25,7 +25,10 @@
 #endif
 
 constexpr int kOccBlock = 256;
-constexpr int kOccItems = 8;
+#ifndef MOT_OCC_ITEMS
+#define MOT_OCC_ITEMS 8
+#endif
+constexpr int kOccItems = MOT_OCC_ITEMS;
 constexpr int kOccChunk = kOccBlock * kOccItems;
 
 // ------------------------------------------------------------------------------------------ C1

@@ -60,7 +60,11 @@ __device__ __forceinline__ void polar_cells(const MotDevParams& p, const float4 
   }
 #pragma unroll
   for (int k = 0; k < ITEMS; k++) {
+#ifdef MOT_DBG_CHEAPCELL   // timing ablation only (tools/ablate_k3.py): a trivial cell function, wrong results
+    int c = ((int)(pt[k].x * 0.5f) & 63) * MOT_NUM_BIN + ((int)(pt[k].y * 0.5f) & 63);
+#else
     int c = mot_polar_cell_try(p, pt[k].x, pt[k].y);
+#endif
     if (!((keep >> k) & 1u)) c = -1;
     cell[k] = c;
     if (c == -2) undecided |= 1u << k;

@@ -199,8 +199,18 @@ def main():
                      "cluster_rect_kernel": 4.0 * ne_tot / 8,
                      "box_finalize_kernel": 96.0 * BL,
                      "track_step_kernel": (2 * 1624.0 + 144.0) * max(tr0["n"], 1) * BL}
-        dom = max(k_ms, key=lambda k: k_ms[k])
+        # the dominant kernel of an HBM roofline is the one that moves the most bytes (it also has the largest share of GPU
+        # time in the rocprofv3 trace of this command, profiles/); the longest single launch is reported next to it
+        dom = max(alg_bytes, key=lambda k: alg_bytes[k])
+        longest = max(k_ms, key=lambda k: k_ms[k])
         achieved = alg_bytes[dom] / (k_ms[dom] * 1e-3) / 1e9
+        # HBM bytes per launch from the committed PMC passes (FETCH_SIZE x2 on gfx950 + WRITE_SIZE, KB), same launch size only
+        traffic = None
+        pmc_path = os.path.join(ROOT, "profiles", "r01_pmc_B128.json")
+        if BL == 128 and N == 120000 and os.path.exists(pmc_path):
+            pmc = json.load(open(pmc_path)).get(dom)
+            if pmc and "FETCH_SIZE" in pmc and "WRITE_SIZE" in pmc:
+                traffic = int((2.0 * pmc["FETCH_SIZE"] + pmc["WRITE_SIZE"]) * 1024)
         frame_bytes = sum(alg_bytes.values()) / BL
         frames = B * args.steps * world
         out = {
@@ -216,7 +226,9 @@ def main():
                        "tracks_stream0": int(tr0["n"]), "live_tracks_stream0": int((tr0["track_manage"] > 0).sum()),
                        "parallelism": f"stream-sharded x{world}" + (", all_gather of live-track records (RCCL)" if world > 1 else "")},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
+                         "traffic_source": "profiles/r01_pmc_B128.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command at 128 frames per launch)" if traffic else None,
+                         "longest_launch": {"kernel": longest, "ms": round(k_ms[longest], 5)},
                          "kernel_ms": {k: round(v, 5) for k, v in k_ms.items()},
                          "stage_ms": {k: round(v, 5) for k, v in stage_ms.items()},
                          "algorithmic_bytes_per_launch": {k: int(v) for k, v in alg_bytes.items()},

@@ -32,8 +32,8 @@ e1.record(); torch.cuda.synchronize()
 ms = e0.elapsed_time(e1) / 20
 out["torch_sum_read"] = {"ms": ms, "GBps": dev.numel() * 4 / ms / 1e6}
 del dst
-variants = [("full", []), ("nolookback", ["-DMOT_DBG_K3_NOLOOKBACK"]), ("cheapcell", ["-DMOT_DBG_K3_CHEAPCELL"]),
-            ("both", ["-DMOT_DBG_K3_NOLOOKBACK", "-DMOT_DBG_K3_CHEAPCELL"]), ("k1nt", ["-DMOT_DBG_K1_NT"])]
+variants = [("full", []), ("nolookback", ["-DMOT_DBG_K3_NOLOOKBACK"]), ("cheapcell", ["-DMOT_DBG_CHEAPCELL"]),
+            ("both", ["-DMOT_DBG_K3_NOLOOKBACK", "-DMOT_DBG_CHEAPCELL"])]
 for name, flags in variants:
     lib = build.build(extra_flags=flags, out=os.path.join(ROOT, "gpurun_out", f"libmot_{name}.so"))
     ctx = mot.Context(max_points=stride, max_batch=B, lib_path=lib)
