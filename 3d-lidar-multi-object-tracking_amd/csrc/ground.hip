@@ -49,7 +49,7 @@ __device__ __forceinline__ float4 load_stream(const float4* p) { return *p; }
 // Polar cells of a thread's ITEMS points (filterCloud + getCellIndexFromPoints, ground_removal.cpp:46-76). Pass 1 is the
 // guarded fast path only, straight-line code; the few points it cannot decide (~4e-4) are resolved afterwards by ONE
 // copy of the exact evaluation inside a loop (re-reading the point: a register array cannot be indexed dynamically).
-template <int ITEMS>
+template <int ITEMS, int BLOCK>
 __device__ __forceinline__ void polar_cells(const MotDevParams& p, const float4 (&pt)[ITEMS], const float4* __restrict__ in, long base, int n,
                                             int (&cell)[ITEMS]) {
   unsigned undecided = 0, keep = ~0u;
@@ -73,7 +73,7 @@ __device__ __forceinline__ void polar_cells(const MotDevParams& p, const float4 
     while (undecided) {
       const int k = __ffs(undecided) - 1;
       undecided &= undecided - 1;
-      const long i = base + k * kGroundBlock + threadIdx.x;
+      const long i = base + k * BLOCK + threadIdx.x;
       int r = -1;
       if (i < n) { const float4 q = in[i]; r = mot_polar_cell_exact(p, q.x, q.y); }  // (padding lanes never get here: (0,0) is decided)
 #pragma unroll
@@ -116,7 +116,7 @@ polar_minz_kernel(MotDevParams p, GroundBuffers g) {
     pt[k] = i < n ? in[i] : make_float4(0.f, 0.f, 0.f, 0.f);  // (0,0): r = 0 <= rMin -> no cell
   }
   int cells[kGroundItems];
-  polar_cells<kGroundItems>(p, pt, in, base, n, cells);
+  polar_cells<kGroundItems, kGroundBlock>(p, pt, in, base, n, cells);
 #pragma unroll
   for (int k = 0; k < kGroundItems; k++) {
     const float z = pt[k].z;
@@ -296,7 +296,7 @@ polar_filter_kernel(MotDevParams p, GroundBuffers g) {
 
 // ------------------------------------------------------------------------------------------ K3
 // per-point classification (ground_removal.cpp:221-247) + order-preserving compaction
-__global__ void MOT_LAUNCH_BOUNDS(kGroundBlock)
+__global__ void MOT_LAUNCH_BOUNDS(kCompactBlock)
 classify_compact_kernel(MotDevParams p, GroundBuffers g) {
   __shared__ int s_chunk;
   __shared__ int s_cnt[kSubTiles];  // per 64-point tile counts (elevated << 16 | ground) -> exclusive prefixes
@@ -326,18 +326,18 @@ classify_compact_kernel(MotDevParams p, GroundBuffers g) {
   const bool full = base + kCompactChunk <= n;   // all but the frame's last chunk: no per-point bounds test
   if (full) {
 #pragma unroll
-    for (int k = 0; k < kCompactItems; k++) pt[k] = load_stream(&in[base + k * kGroundBlock + threadIdx.x]);  // last use of the input cloud
+    for (int k = 0; k < kCompactItems; k++) pt[k] = load_stream(&in[base + k * kCompactBlock + threadIdx.x]);  // last use of the input cloud
   } else {
 #pragma unroll
     for (int k = 0; k < kCompactItems; k++) {
-      long i = base + k * kGroundBlock + threadIdx.x;
+      long i = base + k * kCompactBlock + threadIdx.x;
       pt[k] = i < n ? load_stream(&in[i]) : make_float4(0.f, 0.f, 0.f, 0.f);
     }
   }
-  polar_cells<kCompactItems>(p, pt, in, base, n, cls);
+  polar_cells<kCompactItems, kCompactBlock>(p, pt, in, base, n, cls);
   float hgv[kCompactItems];
 #pragma unroll
-  for (int k = 0; k < kCompactItems; k++) hgv[k] = cls[k] >= 0 ? hg[cls[k]] : 0.f;   // 16 independent gathers (L2): -inf when the cell is not ground
+  for (int k = 0; k < kCompactItems; k++) hgv[k] = cls[k] >= 0 ? hg[cls[k]] : 0.f;   // independent gathers (L2), all in flight: -inf when the cell is not ground
   const unsigned long long below = (1ull << lane) - 1ull;
 #pragma unroll
   for (int k = 0; k < kCompactItems; k++) {
@@ -347,7 +347,7 @@ classify_compact_kernel(MotDevParams p, GroundBuffers g) {
     const unsigned long long be = __ballot(c == MOT_MASK_ELEVATED);
     const unsigned long long bg = __ballot(c == MOT_MASK_GROUND);
     rank[k] = __popcll((c == MOT_MASK_ELEVATED ? be : bg) & below);
-    if (lane == 0) s_cnt[k * 4 + wave] = (__popcll(be) << 16) | __popcll(bg);   // tile order inside the chunk: k-major, then wave
+    if (lane == 0) s_cnt[k * (kCompactBlock / 64) + wave] = (__popcll(be) << 16) | __popcll(bg);   // tile order inside the chunk: k-major, then wave
   }
   __syncthreads();
   if (wave == 0) {
@@ -407,7 +407,7 @@ classify_compact_kernel(MotDevParams p, GroundBuffers g) {
   const int be0 = s_base_e, bg0 = s_base_g;
 #pragma unroll
   for (int k = 0; k < kCompactItems; k++) {
-    const int ex = s_cnt[k * 4 + wave];   // the tile's exclusive prefixes (wave-uniform)
+    const int ex = s_cnt[k * (kCompactBlock / 64) + wave];   // the tile's exclusive prefixes (wave-uniform)
     const bool is_e = cls[k] == MOT_MASK_ELEVATED;
     float4* __restrict__ dst = is_e ? out_e : out_g;
     const int at = (is_e ? be0 + (ex >> 16) : bg0 + (ex & 0xffff)) + rank[k];
@@ -416,11 +416,11 @@ classify_compact_kernel(MotDevParams p, GroundBuffers g) {
   if (mask) {
     if (full) {
 #pragma unroll
-      for (int k = 0; k < kCompactItems; k++) mask[base + k * kGroundBlock + threadIdx.x] = (uint8_t)cls[k];
+      for (int k = 0; k < kCompactItems; k++) mask[base + k * kCompactBlock + threadIdx.x] = (uint8_t)cls[k];
     } else {
 #pragma unroll
       for (int k = 0; k < kCompactItems; k++) {
-        long i = base + k * kGroundBlock + threadIdx.x;
+        long i = base + k * kCompactBlock + threadIdx.x;
         if (i < n) mask[i] = (uint8_t)cls[k];
       }
     }
@@ -436,7 +436,7 @@ void mot_launch_ground_kernel(int which, const MotDevParams& p, const GroundBuff
   if (cchunks < 1) cchunks = 1;
   if (which == 0) hipLaunchKernelGGL(polar_minz_kernel, dim3(chunks, batch), dim3(kGroundBlock), 0, stream, p, g);
   else if (which == 1) hipLaunchKernelGGL(polar_filter_kernel, dim3(batch), dim3(kFilterBlock), 0, stream, p, g);
-  else if (which == 2) hipLaunchKernelGGL(classify_compact_kernel, dim3(cchunks, batch), dim3(kGroundBlock), 0, stream, p, g);
+  else if (which == 2) hipLaunchKernelGGL(classify_compact_kernel, dim3(cchunks, batch), dim3(kCompactBlock), 0, stream, p, g);
 }
 
 void mot_launch_ground(const MotDevParams& p, const GroundBuffers& g, int batch, int max_n, hipStream_t stream) {

@@ -14,8 +14,12 @@
 constexpr int kGroundBlock = 256;                 // threads per workgroup (4 waves)
 constexpr int kGroundItems = 8;                   // points per thread
 constexpr int kGroundChunk = kGroundBlock * kGroundItems;  // 2048 points = 32 KB per workgroup
-constexpr int kCompactItems = 16;                 // points per thread in the compaction kernel
-constexpr int kCompactChunk = kGroundBlock * kCompactItems;  // 4096 points = 64 KB per workgroup
+#ifndef MOT_COMPACT_BLOCK
+#define MOT_COMPACT_BLOCK 512
+#endif
+constexpr int kCompactBlock = MOT_COMPACT_BLOCK;  // threads per workgroup of the compaction kernel
+constexpr int kCompactChunk = 4096;               // points per workgroup = 64 KB in flight
+constexpr int kCompactItems = kCompactChunk / kCompactBlock;  // points per thread
 constexpr int kSubTiles = kCompactChunk / 64;     // 64-point wave tiles per chunk (64: one lane each in the tile scan)
 constexpr int kMinzInit = 0x447A0000;             // ordered key of 1000.0f (Cell::Cell, ground_removal.cpp:35-38)
 
