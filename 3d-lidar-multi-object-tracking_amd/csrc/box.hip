@@ -33,9 +33,12 @@
 #define MOT_LAUNCH_BOUNDS(n)
 #endif
 
-constexpr int kLabelBlock = 256;
+#ifndef MOT_LABEL_BLOCK
+#define MOT_LABEL_BLOCK 512
+#endif
+constexpr int kLabelBlock = MOT_LABEL_BLOCK;
 #ifndef MOT_LABEL_ITEMS
-#define MOT_LABEL_ITEMS 8
+#define MOT_LABEL_ITEMS 4
 #endif
 constexpr int kLabelItems = MOT_LABEL_ITEMS;
 constexpr int kLabelChunk = kLabelBlock * kLabelItems;
@@ -270,7 +273,7 @@ label_stats_kernel(MotDevParams p, ClusterBuffers c) {
 //   cluster_start[c] + (points of c in earlier 2048-point chunks) + (points of c in earlier tiles of its own chunk);
 // the last term comes with the group from the label kernel, the middle one is a prefix over the label kernel's
 // per-workgroup tables — O(groups) work here. A frame the label kernel flagged irregular (a chunk with more than 64
-// clusters or more than 128 groups per wave) or with more than 64 chunks of elevated points takes the general path: the
+// clusters or more than 64 groups in the four tiles of one wave) or with more than 64 chunks of elevated points takes the general path: the
 // sum over all the other groups of the cluster.
 constexpr int kIndexBlock = 1024;
 constexpr int kIndexWaves = kIndexBlock / 64;

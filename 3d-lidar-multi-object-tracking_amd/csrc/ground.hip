@@ -96,10 +96,10 @@ __device__ __forceinline__ int wave_min_i32(int v) { return wave_reduce_i32(v, O
 // yields two entries; the filter kernel's LDS atomicMin does not mind. (Earlier versions: one global atomicMin per point
 // run — 8.2k memory-side atomics per frame; then a log-step segmented scan per 64 points — 7 LDS-crossbar shuffles per
 // point; both were bound by those, not by HBM.)
-constexpr int kStagePad(int e) { return e + (e >> 3); }   // 8-byte entries: a 9-entry stride per thread keeps ds_read_b64 conflict-free
+constexpr int kStagePad(int e) { return e + e / kGroundItems; }   // 8-byte entries: an odd (items + 1)-entry stride per thread keeps ds_read_b64 conflict-free
 __global__ void MOT_LAUNCH_BOUNDS(kGroundBlock)
 polar_minz_kernel(MotDevParams p, GroundBuffers g) {
-  __shared__ uint2 s_stage[kGroundChunk + kGroundChunk / 8];
+  __shared__ uint2 s_stage[kGroundChunk + kGroundChunk / kGroundItems];
   uint2* const s_pairs = s_stage;   // the list (at most one entry per point) reuses the stage: a barrier separates the two uses
   __shared__ int s_wsum[kGroundBlock / 64];
   const int b = blockIdx.y;

@@ -11,8 +11,14 @@
 #include "mot_math.h"
 
 // ---- geometry of the launches --------------------------------------------------------------
-constexpr int kGroundBlock = 256;                 // threads per workgroup (4 waves)
-constexpr int kGroundItems = 8;                   // points per thread
+#ifndef MOT_GROUND_BLOCK
+#define MOT_GROUND_BLOCK 256
+#endif
+constexpr int kGroundBlock = MOT_GROUND_BLOCK;    // threads per workgroup of the min-z kernel
+#ifndef MOT_GROUND_ITEMS
+#define MOT_GROUND_ITEMS 8
+#endif
+constexpr int kGroundItems = MOT_GROUND_ITEMS;    // points per thread
 constexpr int kGroundChunk = kGroundBlock * kGroundItems;  // 2048 points = 32 KB per workgroup
 #ifndef MOT_COMPACT_BLOCK
 #define MOT_COMPACT_BLOCK 512
