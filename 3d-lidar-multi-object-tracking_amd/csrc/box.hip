@@ -275,7 +275,10 @@ label_stats_kernel(MotDevParams p, ClusterBuffers c) {
 // per-workgroup tables — O(groups) work here. A frame the label kernel flagged irregular (a chunk with more than 64
 // clusters or more than 64 groups in the four tiles of one wave) or with more than 64 chunks of elevated points takes the general path: the
 // sum over all the other groups of the cluster.
-constexpr int kIndexBlock = 1024;
+#ifndef MOT_INDEX_BLOCK
+#define MOT_INDEX_BLOCK 1024
+#endif
+constexpr int kIndexBlock = MOT_INDEX_BLOCK;
 constexpr int kIndexWaves = kIndexBlock / 64;
 #ifndef MOT_GROUPS_LDS
 #define MOT_GROUPS_LDS 6144
@@ -304,18 +307,20 @@ cluster_index_kernel(ClusterBuffers c) {
 #else
 #define B1B_T(slot)
 #endif
-  // exclusive scan of the cluster sizes (4 per thread)
+  // exclusive scan of the cluster sizes (kMaxClusters / kIndexBlock per thread)
   {
-    int v[4], sum = 0;
+    constexpr int kPer = kMaxClusters / kIndexBlock;
+    int v[kPer], sum = 0;
 #pragma unroll
-    for (int k = 0; k < 4; k++) { int ci = tid * 4 + k; v[k] = ci < num_cluster ? stats[ci].count : 0; sum += v[k]; }
+    for (int k = 0; k < kPer; k++) { int ci = tid * kPer + k; v[k] = ci < num_cluster ? stats[ci].count : 0; sum += v[k]; }
     const int incl = wave_scan_incl_i32(sum);
     if (lane == 63) s_part[wave] = incl;
     __syncthreads();
     int run = incl - sum;
     for (int w2 = 0; w2 < wave; w2++) run += s_part[w2];
 #pragma unroll
-    for (int k = 0; k < 4; k++) { int ci = tid * 4 + k; if (ci <= kMaxClusters) s_start[ci] = run; run += v[k]; }
+    for (int k = 0; k < kPer; k++) { s_start[tid * kPer + k] = run; run += v[k]; }
+    if (tid == kIndexBlock - 1) s_start[kMaxClusters] = run;
   }
   B1B_T(0);
   int* __restrict__ cstart = c.cluster_start + (long)b * (kMaxClusters + 1);

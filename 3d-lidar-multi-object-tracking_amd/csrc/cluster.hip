@@ -24,9 +24,12 @@
 #define MOT_LAUNCH_BOUNDS(n)
 #endif
 
-constexpr int kOccBlock = 256;
+#ifndef MOT_OCC_BLOCK
+#define MOT_OCC_BLOCK 512
+#endif
+constexpr int kOccBlock = MOT_OCC_BLOCK;
 #ifndef MOT_OCC_ITEMS
-#define MOT_OCC_ITEMS 8
+#define MOT_OCC_ITEMS 4
 #endif
 constexpr int kOccItems = MOT_OCC_ITEMS;
 constexpr int kOccChunk = kOccBlock * kOccItems;
