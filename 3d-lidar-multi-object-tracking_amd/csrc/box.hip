@@ -597,12 +597,17 @@ cluster_gather_kernel(MotDevParams p, ClusterBuffers c) {
       const int first_slot = cstart[ci];
       // the cluster's points through the sorted index; what is fetched per point is its 4-byte picture pixel (label kernel)
       const int* __restrict__ pix = c.pix + (long)b * c.cap;
+      // two dependent loads per point (sorted index -> pixel): the indices of the NEXT trip are requested right behind the
+      // pixel loads of this one (loads return in order), so a trip costs one memory round trip instead of two
+      int nxt[kGatherDepth];
+#pragma unroll
+      for (int u = 0; u < kGatherDepth; u++) { int j = u * kBoxBlock + tid; nxt[u] = j < numPoints ? sorted[first_slot + j] : -1; }
       for (int j0 = 0; j0 < numPoints; j0 += kBoxBlock * kGatherDepth) {
         int v[kGatherDepth];
 #pragma unroll
-        for (int u = 0; u < kGatherDepth; u++) { int j = j0 + u * kBoxBlock + tid; v[u] = j < numPoints ? sorted[first_slot + j] : -1; }
+        for (int u = 0; u < kGatherDepth; u++) v[u] = nxt[u] >= 0 ? pix[nxt[u]] : 0xffff;
 #pragma unroll
-        for (int u = 0; u < kGatherDepth; u++) v[u] = v[u] >= 0 ? pix[v[u]] : 0xffff;
+        for (int u = 0; u < kGatherDepth; u++) { int j = j0 + kBoxBlock * kGatherDepth + u * kBoxBlock + tid; nxt[u] = j < numPoints ? sorted[first_slot + j] : -1; }
 #pragma unroll
         for (int u = 0; u < kGatherDepth; u++) {
           const int picX = v[u] & 0xffff;
