@@ -149,7 +149,7 @@ void mot_launch_box_kernel(int which, const MotDevParams& p, const ClusterBuffer
 
 // ---- tracker stage ---------------------------------------------------------------------------
 #ifndef MOT_TRACK_BLOCK
-#define MOT_TRACK_BLOCK 1024
+#define MOT_TRACK_BLOCK 512
 #endif
 constexpr int kTrackBlock = MOT_TRACK_BLOCK;      // one workgroup (a wave per live track at a time) steps one sensor stream
 constexpr int kTrackWaves = kTrackBlock / 64;

@@ -48,20 +48,35 @@ __device__ __forceinline__ double det2(const double* m) { return m[0] * m[3] - m
 __device__ __forceinline__ void inv2(const double* m, double* o) { double d = det2(m); o[0] = m[3] / d; o[1] = -m[1] / d; o[2] = -m[2] / d; o[3] = m[0] / d; }
 __device__ __forceinline__ double wave_sum_d(double v) { return wave_sum_f64(v); }
 
-// determinant of a 5x5 (partial-pivot elimination, what Eigen's PartialPivLU::determinant amounts to)
+// determinant of a 5x5 (partial-pivot elimination, what Eigen's PartialPivLU::determinant amounts to). Every index below
+// is a compile-time constant: the pivot row is brought up by conditional swaps against each candidate row, never by
+// indexing the register array with the pivot (a dynamically indexed array lives in scratch memory — the first version
+// of this function alone took 22-55 k cycles per track, as long as the whole IMM-UKF prediction).
 __device__ double det5(const double* a) {
   double m[25];
+#pragma unroll
   for (int i = 0; i < 25; i++) m[i] = a[i];
   double det = 1;
+  bool done = false;
+#pragma unroll
   for (int k = 0; k < 5; k++) {
     int piv = k; double best = fabs(m[k * 5 + k]);
+#pragma unroll
     for (int r = k + 1; r < 5; r++) { double v = fabs(m[r * 5 + k]); if (v > best) { best = v; piv = r; } }
-    if (piv != k) { for (int c = 0; c < 5; c++) { double t = m[k * 5 + c]; m[k * 5 + c] = m[piv * 5 + c]; m[piv * 5 + c] = t; } det = -det; }
-    double d = m[k * 5 + k];
-    det *= d;
-    if (d == 0) return det;
+#pragma unroll
     for (int r = k + 1; r < 5; r++) {
-      double f = m[r * 5 + k] / d;
+      const bool sw = piv == r;
+#pragma unroll
+      for (int c = 0; c < 5; c++) { const double t = m[k * 5 + c], q = m[r * 5 + c]; m[k * 5 + c] = sw ? q : t; m[r * 5 + c] = sw ? t : q; }
+    }
+    if (piv != k) det = done ? det : -det;
+    const double d = m[k * 5 + k];
+    if (!done) det *= d;
+    if (d == 0) done = true;   // the reference returns here: det is already 0 (or NaN) and stays
+#pragma unroll
+    for (int r = k + 1; r < 5; r++) {
+      const double f = m[r * 5 + k] / d;
+#pragma unroll
       for (int c = k + 1; c < 5; c++) m[r * 5 + c] -= f * m[k * 5 + c];
     }
   }
@@ -254,7 +269,7 @@ __device__ __forceinline__ int find_max_model(const double S[3][4]) {
 }
 
 // getCpFromBbox :465-479 — fp32 products, then fp64
-__device__ void cp_from_bbox(const float* b, double* cx, double* cy) {
+__device__ __forceinline__ void cp_from_bbox(const float* b, double* cx, double* cy) {
   float p1x = b[0], p1y = b[1], p2x = b[3], p2y = b[4], p3x = b[6], p3y = b[7], p4x = b[9], p4y = b[10];
   double S1 = ((p4x - p2x) * (p1y - p2y) - (p4y - p2y) * (p1x - p2x)) / 2;
   double S2 = ((p4x - p2x) * (p2y - p3y) - (p4y - p2y) * (p2x - p3x)) / 2;
@@ -262,14 +277,14 @@ __device__ void cp_from_bbox(const float* b, double* cx, double* cy) {
   *cy = p1y + (p3y - p1y) * S1 / (S1 + S2);
 }
 // getBboxArea :482-494
-__device__ double bbox_area(const float* b) {
+__device__ __forceinline__ double bbox_area(const float* b) {
   float p1x = b[0], p1y = b[1], p2x = b[3], p2y = b[4], p3x = b[6], p3y = b[7], p4x = b[9], p4y = b[10];
   double tri1 = 0.5 * fabsf((p1x - p3x) * (p2y - p3y) - (p2x - p3x) * (p1y - p3y));
   double tri2 = 0.5 * fabsf((p1x - p4x) * (p3y - p4y) - (p3x - p4x) * (p1y - p4y));
   return tri1 + tri2;
 }
 // getBBoxYaw :535-563 — fp32 sqrt / atan2 (glibc-exact atan2f, mot_math.h)
-__device__ double bbox_yaw(const float* b, double ukfYaw) {
+__device__ __forceinline__ double bbox_yaw(const float* b, double ukfYaw) {
   float p1x = b[0], p1y = b[1], p2x = b[3], p2y = b[4], p3x = b[6], p3y = b[7];
   double dist1 = sqrtf((p1x - p2x) * (p1x - p2x) + (p1y - p2y) * (p1y - p2y));
   double dist2 = sqrtf((p3x - p2x) * (p3x - p2x) + (p3y - p2y) * (p3y - p2y));
@@ -282,41 +297,55 @@ __device__ double bbox_yaw(const float* b, double ukfYaw) {
   return wrap_pi(yaw);
 }
 // updateBoxYaw :512-532
-__device__ void rotate_box(float* b, const double* cp, double a) {
+__device__ __forceinline__ void rotate_box(float* b, const double* cp, double a) {
+  const double ca = cos(a), sa = sin(a);
+#pragma unroll
   for (int i = 0; i < 8; i++) {
     double preX = b[3 * i], preY = b[3 * i + 1];
-    b[3 * i] = (float)(cos(a) * (preX - cp[0]) - sin(a) * (preY - cp[1]) + cp[0]);
-    b[3 * i + 1] = (float)(sin(a) * (preX - cp[0]) + cos(a) * (preY - cp[1]) + cp[1]);
+    b[3 * i] = (float)(ca * (preX - cp[0]) - sa * (preY - cp[1]) + cp[0]);
+    b[3 * i + 1] = (float)(sa * (preX - cp[0]) + ca * (preY - cp[1]) + cp[1]);
   }
 }
-// updateBB :565-653 (single lane)
+// updateBB :565-653 (single lane). The two boxes are worked on in registers and written back once: every access to the
+// track record is a global-memory round trip, and this function is a chain of dependent reads and writes of it.
 __device__ void update_bb(const MotTrackParams& tp, DevTrack* u) {
   if (!u->is_vis) return;
+  float bb[24], best[24];
+#pragma unroll
+  for (int i = 0; i < 24; i++) bb[i] = u->bbox[i];
+  const double ukfYaw = u->x[0][3];
   if (!u->has_best) {
-    for (int i = 0; i < 24; i++) u->best_bbox[i] = u->bbox[i];
-    u->has_best = 1; u->best_yaw = bbox_yaw(u->bbox, u->x[0][3]);
+#pragma unroll
+    for (int i = 0; i < 24; i++) u->best_bbox[i] = bb[i];
+    u->has_best = 1; u->best_yaw = bbox_yaw(bb, ukfYaw);
     return;
   }
+#pragma unroll
+  for (int i = 0; i < 24; i++) best[i] = u->best_bbox[i];
   double cp[2], bestCP[2];
-  cp_from_bbox(u->bbox, &cp[0], &cp[1]);
-  cp_from_bbox(u->best_bbox, &bestCP[0], &bestCP[1]);
+  cp_from_bbox(bb, &cp[0], &cp[1]);
+  cp_from_bbox(best, &bestCP[0], &bestCP[1]);
   double dt0 = cp[0] - bestCP[0], dt1 = cp[1] - bestCP[1];
-  double yaw = bbox_yaw(u->bbox, u->x[0][3]);
-  double area = bbox_area(u->bbox), bestArea = bbox_area(u->best_bbox);
+  double yaw = bbox_yaw(bb, ukfYaw);
+  double area = bbox_area(bb), bestArea = bbox_area(best);
   double deltaArea = area - bestArea;
   if (deltaArea < 0) {  // updateVisBoxArea :496-510
-    for (int i = 0; i < 8; i++) { u->bbox[3 * i] = (float)(u->best_bbox[3 * i] + dt0); u->bbox[3 * i + 1] = (float)(u->best_bbox[3 * i + 1] + dt1); }
+#pragma unroll
+    for (int i = 0; i < 8; i++) { bb[3 * i] = (float)(best[3 * i] + dt0); bb[3 * i + 1] = (float)(best[3 * i + 1] + dt1); }
   } else if (deltaArea > 0) {
-    for (int i = 0; i < 24; i++) u->best_bbox[i] = u->bbox[i];
+#pragma unroll
+    for (int i = 0; i < 24; i++) best[i] = bb[i];
   }
-  double currentYaw = bbox_yaw(u->bbox, u->x[0][3]);
+  double currentYaw = bbox_yaw(bb, ukfYaw);
   double DiffYaw = yaw - currentYaw;
   if (fabs(DiffYaw) > tp.bb_yaw_change_thres) {
   } else if (fabs(DiffYaw) < tp.bb_yaw_change_thres) {
-    rotate_box(u->bbox, cp, DiffYaw);
-    rotate_box(u->best_bbox, cp, DiffYaw);
+    rotate_box(bb, cp, DiffYaw);
+    rotate_box(best, cp, DiffYaw);
     u->best_yaw = yaw;
   }
+#pragma unroll
+  for (int i = 0; i < 24; i++) { u->bbox[i] = bb[i]; u->best_bbox[i] = best[i]; }
 }
 
 __device__ void load_track(WaveScratch* ws, const DevTrack* t) {
@@ -362,6 +391,7 @@ track_step_kernel(TrackBuffers tb) {
   mot_track* __restrict__ out = tb.out + (long)b * tb.T;
   WaveScratch* ws = &s_ws[wave];
   const int nt0 = tb.nt[b];
+  const int nW = (M + 63) >> 6;   // 64-box words of the gate bit-masks in use this frame (the rest is neither written nor read)
 
   // trackPoints :713-736 — centre of every box
   for (int k = tid; k < M; k += kTrackBlock) cp_from_bbox(boxes + (long)k * 24, &s_cpx[k], &s_cpy[k]);
@@ -410,13 +440,18 @@ track_step_kernel(TrackBuffers tb) {
   for (int li = wave; li < nlive; li += kTrackWaves) {
     const int t = live[li];
     DevTrack* u = &tracks[t];
+#ifdef MOT_DBG_TRACK_SUB
+#define MOT_SUB(k) if (tid == 0 && tb.phase_clock) tb.phase_clock[b * 16 + (k)] = clock64()
+#else
+#define MOT_SUB(k)
+#endif
     load_track(ws, u);
     bool ok = true;
     if (det5(ws->Pm) > 10 || ws->Pm[24] > 1000) ok = false;  // divergence guard :828-831
     if (ok) {
       process_imm_ukf(ws, args.dt);  // :840
-      store_models(ws, u);
-      int mx = find_max_model(ws->S);
+        store_models(ws, u);
+        int mx = find_max_model(ws->S);
       double maxS[4];
       for (int k = 0; k < 4; k++) maxS[k] = ws->S[mx][k] * 4;  // :844
       double detS = det2(maxS);
@@ -427,7 +462,7 @@ track_step_kernel(TrackBuffers tb) {
         double Si[4]; inv2(maxS, Si);
         const double zx = ws->z[mx][0], zy = ws->z[mx][1];
         double run_min = 999;  // smallestNIS
-        for (int w = 0; w < kGateWords; w++) {
+        for (int w = 0; w < nW; w++) {
           int k = w * 64 + lane;
           bool g = false; double nis = 1e300;
           if (w * 64 < M) {
@@ -471,8 +506,8 @@ track_step_kernel(TrackBuffers tb) {
     for (int li = 0; li < nlive; li++) {
       if (!liveok[li]) continue;
       const int t = live[li];
-      unsigned long long g = lane < kGateWords ? gate[(long)t * kGateWords + lane] : 0ull;
-      unsigned long long pg = lane < kGateWords ? prog[(long)t * kGateWords + lane] : 0ull;
+      unsigned long long g = lane < nW ? gate[(long)t * kGateWords + lane] : 0ull;
+      unsigned long long pg = lane < nW ? prog[(long)t * kGateWords + lane] : 0ull;
       int fresh = __popcll(g & ~matched);
 #pragma unroll
       for (int m = 32; m >= 1; m >>= 1) fresh += __shfl_xor(fresh, m, 64);
@@ -491,25 +526,27 @@ track_step_kernel(TrackBuffers tb) {
     const int t = live[li];
     DevTrack* u = &tracks[t];
     load_track(ws, u);
+    MOT_SUB(11);
     const unsigned long long* gt = gate + (long)t * kGateWords;
     const unsigned long long* pt = prog + (long)t * kGateWords;
     int track_num = u->track_num;
     const bool secondInit = track_num == 1;
     int ngate = 0;
-    for (int w = 0; w < kGateWords; w++) ngate += __popcll(gt[w]);
+    for (int w = 0; w < nW; w++) ngate += __popcll(gt[w]);
     int nm = ngate;
     int last_prog = -1;  // second init: the box that finally holds smallestNIS = the last progressive minimum
     if (secondInit) {
-      for (int w = 0; w < kGateWords; w++) if (pt[w]) last_prog = w * 64 + 63 - __clzll((long long)pt[w]);
+      for (int w = 0; w < nW; w++) if (pt[w]) last_prog = w * 64 + 63 - __clzll((long long)pt[w]);
       nm = last_prog >= 0 ? 1 : 0;
     }
+    MOT_SUB(12);
     // associateBB :416-463 + getNearestEuclidBBox :396-413 (int minDist, truncated on assignment)
     if (!secondInit && ngate > 0 && track_num == 5 && u->lifetime > tp.life_time_thres) {
       // sequential semantics: scan gated boxes in order, keep (minDist:int, minInd); reproduced by one lane
       if (lane == 0) {
         int minDist = 999, minBox = -1, first = -1;
         double px = ws->xm[0], py = ws->xm[1];
-        for (int w = 0; w < kGateWords; w++) {
+        for (int w = 0; w < nW; w++) {
           unsigned long long g = gt[w];
           while (g) {
             int k = w * 64 + __ffsll(g) - 1;
@@ -532,8 +569,10 @@ track_step_kernel(TrackBuffers tb) {
         }
       }
     }
+    MOT_SUB(13);
     if (lane == 0) update_bb(tp, u);
     MOT_WAVE_SYNC();
+    MOT_SUB(14);
     if (secondInit) {  // :882-921
       if (lane == 0) {
         if (nm == 0) u->track_num = 0;
@@ -562,6 +601,7 @@ track_step_kernel(TrackBuffers tb) {
     if (lane == 0) u->track_num = track_num;
     if (track_num == 0) { MOT_WAVE_SYNC(); continue; }
 
+    MOT_SUB(15);
     // filterPDA :259-394 — lanes over the gated measurements
     {
       const double numMeas = nm;
@@ -584,7 +624,7 @@ track_step_kernel(TrackBuffers tb) {
           eSum[m] += wave_sum_d(e);
         }
       }
-      double sx[3][2] = {{0, 0}, {0, 0}, {0, 0}};
+        double sx[3][2] = {{0, 0}, {0, 0}, {0, 0}};
       double sp[3][4] = {{0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}};
       for (int pass = 0; pass < 2; pass++) {  // pass 0: sigmaX, pass 1: sigmaP (needs the complete sigmaX)
         for (int w = 0; w * 64 < M; w++) {
@@ -605,7 +645,7 @@ track_step_kernel(TrackBuffers tb) {
           }
         }
       }
-      // x += K*sigmaX ; P update (:341-367) — one lane per matrix entry
+        // x += K*sigmaX ; P update (:341-367) — one lane per matrix entry
       MOT_WAVE_SYNC();
       if (lane < 15) {
         int m = lane / 5, r = lane % 5;
@@ -624,7 +664,7 @@ track_step_kernel(TrackBuffers tb) {
         ws->Po[m][r * 5 + c] = nm != 0 ? betaZero * P + (1 - betaZero) * (P - kskt) + kpk : P - kskt;
       }
       MOT_WAVE_SYNC();
-      // likelihoods :369-393, UpdateModeProb ukf.cpp:384-397, merge :419-437
+        // likelihoods :369-393, UpdateModeProb ukf.cpp:384-397, merge :419-437
       int mx = find_max_model(ws->S);
       double Vk = PI_D * sqrt(tp.gamma_g * det2(ws->S[mx]));
       double lambda[3];
@@ -632,7 +672,7 @@ track_step_kernel(TrackBuffers tb) {
         if (nm != 0) lambda[m] = (1 - tp.p_g * tp.p_d) / pow(Vk, numMeas) + tp.p_d * pow(Vk, 1 - numMeas) * eSum[m] / (numMeas * sqrt(2 * PI_D * det2(ws->S[m])));
         else lambda[m] = (1 - tp.p_g * tp.p_d) / pow(Vk, numMeas);
       }
-      double mode[3];
+        double mode[3];
       double sum = lambda[0] * ws->mode[0] + lambda[1] * ws->mode[1] + lambda[2] * ws->mode[2];
       for (int m = 0; m < 3; m++) { mode[m] = (lambda[m] * ws->mode[m]) / sum; if (fabs(mode[m]) < 0.0001) mode[m] = 0.0001; }
       double xmv[5];

@@ -87,6 +87,14 @@ def test_many_clusters_per_tile(ctx, oracle):
     _stage_parity(ctx, oracle, p, interleaved_clusters_cloud(20, 25))
 
 
+def test_more_than_64_label_chunks(ctx, oracle, synth):
+    """> 131072 elevated points = more 2048-point chunks than the index kernel's table prefix holds in LDS: general path"""
+    p = oracle.params(0)
+    elev = np.concatenate([oracle.ground_remove(p, synth.make_cloud(120000, s, f))["elevated"] for s, f in ((0, 0), (0, 1), (1, 0), (1, 2), (2, 1), (2, 3), (3, 0))])
+    assert 131072 < len(elev) <= 262144
+    _stage_parity(ctx, oracle, p, elev)
+
+
 def test_ccl_adversarial_patterns(mot, hip_lib, oracle):
     rng = np.random.default_rng(0)
     for preset in (0, 1):
