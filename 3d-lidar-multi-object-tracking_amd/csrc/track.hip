@@ -194,16 +194,20 @@ __device__ void process_imm_ukf(WaveScratch* ws, double dt) {
     if (m == 2) { s[0] = p_x; s[1] = p_y; s[2] = v; s[3] = yaw; s[4] = yawd; }
     else {
       double px_p, py_p;
-      if (m == 0) { px_p = p_x + v * cos(yaw) * dt; py_p = p_y + v * sin(yaw) * dt; }
+      double sy, cy;   // every sin(yaw) / cos(yaw) of the reference's expressions: evaluated once
+      sincos(yaw, &sy, &cy);
+      if (m == 0) { px_p = p_x + v * cy * dt; py_p = p_y + v * sy * dt; }
       else if (fabs(yawd) > 0.001) {
-        px_p = p_x + v / yawd * (sin(yaw + yawd * dt) - sin(yaw));
-        py_p = p_y + v / yawd * (cos(yaw) - cos(yaw + yawd * dt));
-      } else { px_p = p_x + v * dt * cos(yaw); py_p = p_y + v * dt * sin(yaw); }
+        double s2, c2;
+        sincos(yaw + yawd * dt, &s2, &c2);
+        px_p = p_x + v / yawd * (s2 - sy);
+        py_p = p_y + v / yawd * (cy - c2);
+      } else { px_p = p_x + v * dt * cy; py_p = p_y + v * dt * sy; }
       double v_p = v;
       double yaw_p = m == 0 ? yaw : yaw + yawd * dt;
       double yawd_p = yawd;
-      px_p = px_p + 0.5 * nu_a * dt * dt * cos(yaw);
-      py_p = py_p + 0.5 * nu_a * dt * dt * sin(yaw);
+      px_p = px_p + 0.5 * nu_a * dt * dt * cy;
+      py_p = py_p + 0.5 * nu_a * dt * dt * sy;
       v_p = v_p + nu_a * dt;
       yaw_p = yaw_p + 0.5 * nu_yawdd * dt * dt;
       yawd_p = yawd_p + nu_yawdd * dt;
@@ -610,9 +614,12 @@ track_step_kernel(TrackBuffers tb) {
       for (int m = 0; m < 3; m++) inv2(ws->S[m], Si[m]);
       // lanes over the boxes (one 64-box tile at a time); e and the residuals of a lane's box are kept for the three sums
       double eSum[3] = {0, 0, 0};
+      double ce[3] = {0, 0, 0};   // exp() of this lane's box in the first 64-box tile, reused by the two passes below (all tiles but the
+                                  // first recompute it: more than 64 boxes in a frame is rare)
       for (int w = 0; w * 64 < M; w++) {
         int k = w * 64 + lane;
         bool g = (gt[w] >> lane) & 1ull;
+#pragma unroll
         for (int m = 0; m < 3; m++) {
           double e = 0;
           if (g) {
@@ -621,22 +628,28 @@ track_step_kernel(TrackBuffers tb) {
             double t0 = h0 * Si[m][0] + h1 * Si[m][2], t1 = h0 * Si[m][1] + h1 * Si[m][3];
             e = exp(t0 * d0 + t1 * d1);
           }
+          if (w == 0) ce[m] = e;
           eSum[m] += wave_sum_d(e);
         }
       }
-        double sx[3][2] = {{0, 0}, {0, 0}, {0, 0}};
+      double sx[3][2] = {{0, 0}, {0, 0}, {0, 0}};
       double sp[3][4] = {{0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}};
       for (int pass = 0; pass < 2; pass++) {  // pass 0: sigmaX, pass 1: sigmaP (needs the complete sigmaX)
         for (int w = 0; w * 64 < M; w++) {
           int k = w * 64 + lane;
           bool g = (gt[w] >> lane) & 1ull;
+#pragma unroll
           for (int m = 0; m < 3; m++) {
             double d[2] = {0, 0}, beta = 0;
             if (g) {
               d[0] = s_cpx[k] - ws->z[m][0]; d[1] = s_cpy[k] - ws->z[m][1];
-              double h0 = -0.5 * d[0], h1 = -0.5 * d[1];
-              double t0 = h0 * Si[m][0] + h1 * Si[m][2], t1 = h0 * Si[m][1] + h1 * Si[m][3];
-              beta = exp(t0 * d[0] + t1 * d[1]) / (bpda + eSum[m]);
+              double e = ce[m];
+              if (w > 0) {
+                double h0 = -0.5 * d[0], h1 = -0.5 * d[1];
+                double t0 = h0 * Si[m][0] + h1 * Si[m][2], t1 = h0 * Si[m][1] + h1 * Si[m][3];
+                e = exp(t0 * d[0] + t1 * d[1]);
+              }
+              beta = e / (bpda + eSum[m]);
             }
             if (pass == 0) { sx[m][0] += wave_sum_d(beta * d[0]); sx[m][1] += wave_sum_d(beta * d[1]); }
             else
@@ -645,7 +658,7 @@ track_step_kernel(TrackBuffers tb) {
           }
         }
       }
-        // x += K*sigmaX ; P update (:341-367) — one lane per matrix entry
+      // x += K*sigmaX ; P update (:341-367) — one lane per matrix entry
       MOT_WAVE_SYNC();
       if (lane < 15) {
         int m = lane / 5, r = lane % 5;
@@ -668,9 +681,11 @@ track_step_kernel(TrackBuffers tb) {
       int mx = find_max_model(ws->S);
       double Vk = PI_D * sqrt(tp.gamma_g * det2(ws->S[mx]));
       double lambda[3];
+      const double pw = pow(Vk, numMeas), pw1 = nm != 0 ? pow(Vk, 1 - numMeas) : 0.0;   // the same two powers in all three models
+#pragma unroll
       for (int m = 0; m < 3; m++) {
-        if (nm != 0) lambda[m] = (1 - tp.p_g * tp.p_d) / pow(Vk, numMeas) + tp.p_d * pow(Vk, 1 - numMeas) * eSum[m] / (numMeas * sqrt(2 * PI_D * det2(ws->S[m])));
-        else lambda[m] = (1 - tp.p_g * tp.p_d) / pow(Vk, numMeas);
+        if (nm != 0) lambda[m] = (1 - tp.p_g * tp.p_d) / pw + tp.p_d * pw1 * eSum[m] / (numMeas * sqrt(2 * PI_D * det2(ws->S[m])));
+        else lambda[m] = (1 - tp.p_g * tp.p_d) / pw;
       }
         double mode[3];
       double sum = lambda[0] * ws->mode[0] + lambda[1] * ws->mode[1] + lambda[2] * ws->mode[2];
