@@ -104,13 +104,20 @@ __device__ void track_init(DevTrack* t, double zx, double zy) {
 __device__ __forceinline__ double ukf_w(int i) { return i == 0 ? (-4.0 / (-4.0 + 7.0)) : (0.5 / (7.0 + -4.0)); }
 
 // ProcessIMMUKF(dt), ukf.cpp:507-527 — whole wave, state in ws
-__device__ void process_imm_ukf(WaveScratch* ws, double dt) {
+__device__ void process_imm_ukf(WaveScratch* ws, double dt, long long* dbgclk = nullptr) {
   const int lane = tlane();
+#ifdef MOT_DBG_TRACK_UKF
+#define UKF_T(k) if (dbgclk && threadIdx.x == 0) dbgclk[k] = clock64()
+#else
+#define UKF_T(k)
+#endif
+  UKF_T(11);
   // MixingProbability :439-456 (p1_,p2_,p3_ = rows of the transition matrix :139-154)
   if (lane < 3) {
     const int j = lane;
     const double pj[3] = {j == 0 ? 0.9 : 0.05, j == 1 ? 0.9 : 0.05, j == 2 ? 0.9 : 0.05};  // p[i][j]
     double sum = ws->mode[0] * pj[0] + ws->mode[1] * pj[1] + ws->mode[2] * pj[2];
+#pragma unroll
     for (int i = 0; i < 3; i++) ws->mm[i][j] = ws->mode[i] * pj[i] / sum;
   }
   for (int e = lane; e < 15; e += 64) ws->xo[e / 5][e % 5] = ws->x[e / 5][e % 5];
@@ -127,10 +134,12 @@ __device__ void process_imm_ukf(WaveScratch* ws, double dt) {
   for (int e = lane; e < 75; e += 64) {
     int j = e / 25, r = (e % 25) / 5, c = e % 5;
     double acc = 0;
+#pragma unroll
     for (int i = 0; i < 3; i++) acc = acc + ws->mm[i][j] * (ws->Po[i][r * 5 + c] + (ws->xo[i][r] - ws->x[j][r]) * (ws->xo[i][c] - ws->x[j][c]));
     ws->P[j][r * 5 + c] = acc;
   }
   MOT_WAVE_SYNC();
+  UKF_T(12);
   // Prediction(dt, m) :630-772. Augmented covariance, Eigen 3.2.10 LLT::unblocked semantics: a non-positive pivot
   // stops the factorisation and matrixL() returns the partially overwritten lower triangle.
   if (lane < 3) {
@@ -179,10 +188,12 @@ __device__ void process_imm_ukf(WaveScratch* ws, double dt) {
       }
   }
   MOT_WAVE_SYNC();
+  UKF_T(13);
   if (lane < 45) {  // one lane per (model, sigma point): Cv :573, Ctrv :539, randomMotion :602
     const int m = lane / 15, i = lane % 15;
     const double sc = sqrt(-4.0 + 7.0);
     double xa[7];
+#pragma unroll
     for (int r = 0; r < 7; r++) {
       double base = r < 5 ? ws->x[m][r] : 0.0;
       if (i == 0) xa[r] = base;
@@ -213,12 +224,15 @@ __device__ void process_imm_ukf(WaveScratch* ws, double dt) {
       yawd_p = yawd_p + nu_yawdd * dt;
       s[0] = px_p; s[1] = py_p; s[2] = v_p; s[3] = yaw_p; s[4] = yawd_p;
     }
+#pragma unroll
     for (int r = 0; r < 5; r++) ws->Xs[m][r * 15 + i] = s[r];
   }
   MOT_WAVE_SYNC();
+  UKF_T(14);
   if (lane < 15) {  // predicted mean :736-742
     int m = lane / 5, r = lane % 5;
     double acc = 0;
+#pragma unroll
     for (int i = 0; i < 15; i++) acc = acc + ukf_w(i) * ws->Xs[m][r * 15 + i];
     if (r == 3) acc = wrap_pi(acc);
     ws->x[m][r] = acc;
@@ -227,6 +241,7 @@ __device__ void process_imm_ukf(WaveScratch* ws, double dt) {
   for (int e = lane; e < 75; e += 64) {  // predicted covariance :743-749
     int m = e / 25, r = (e % 25) / 5, c = e % 5;
     double acc = 0;
+#pragma unroll
     for (int i = 0; i < 15; i++) {
       double dr = ws->Xs[m][r * 15 + i] - ws->x[m][r], dc = ws->Xs[m][c * 15 + i] - ws->x[m][c];
       if (r == 3) dr = wrap_pi(dr);
@@ -235,10 +250,12 @@ __device__ void process_imm_ukf(WaveScratch* ws, double dt) {
     }
     ws->P[m][r * 5 + c] = acc;
   }
+  UKF_T(15);
   // UpdateLidar(m) :778-902
   if (lane < 6) {
     int m = lane / 2, c = lane % 2;
     double acc = 0;
+#pragma unroll
     for (int i = 0; i < 15; i++) acc = acc + ukf_w(i) * ws->Xs[m][c * 15 + i];
     ws->z[m][c] = acc;
   }
@@ -246,6 +263,7 @@ __device__ void process_imm_ukf(WaveScratch* ws, double dt) {
   if (lane < 12) {
     int m = lane / 4, r = (lane % 4) / 2, c = lane % 2;
     double acc = 0;
+#pragma unroll
     for (int i = 0; i < 15; i++) acc = acc + (ukf_w(i) * (ws->Xs[m][r * 15 + i] - ws->z[m][r])) * (ws->Xs[m][c * 15 + i] - ws->z[m][c]);
     if (r == c) acc = acc + 0.15 * 0.15;  // R, ukf.cpp:91-94
     ws->S[m][r * 2 + c] = acc;
@@ -253,6 +271,7 @@ __device__ void process_imm_ukf(WaveScratch* ws, double dt) {
   if (lane >= 16 && lane < 46) {
     int e = lane - 16, m = e / 10, r = (e % 10) / 2, c = e % 2;
     double acc = 0;
+#pragma unroll
     for (int i = 0; i < 15; i++) acc = acc + (ukf_w(i) * (ws->Xs[m][r * 15 + i] - ws->x[m][r])) * (ws->Xs[m][c * 15 + i] - ws->z[m][c]);
     ws->Tc[m][r * 2 + c] = acc;
   }
@@ -453,7 +472,11 @@ track_step_kernel(TrackBuffers tb) {
     bool ok = true;
     if (det5(ws->Pm) > 10 || ws->Pm[24] > 1000) ok = false;  // divergence guard :828-831
     if (ok) {
+#ifdef MOT_DBG_TRACK_UKF
+      process_imm_ukf(ws, args.dt, tb.phase_clock ? tb.phase_clock + b * 16 : nullptr);
+#else
       process_imm_ukf(ws, args.dt);  // :840
+#endif
         store_models(ws, u);
         int mx = find_max_model(ws->S);
       double maxS[4];

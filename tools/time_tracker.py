@@ -18,7 +18,7 @@ for f in range(F):
     devs.append(torch.from_numpy(host).cuda())
 torch.cuda.synchronize()
 build = _load("mot_amd.build", os.path.join(PKG, "build.py"))
-lib = build.build(extra_flags=["-DMOT_DBG_TRACK_SUB"], out=os.path.join(ROOT, "gpurun_out", "libmot_tsub.so"))
+lib = build.build(extra_flags=[sys.argv[1] if len(sys.argv) > 1 else "-DMOT_DBG_TRACK_SUB"], out=os.path.join(ROOT, "gpurun_out", "libmot_tsub.so"))
 ctx = mot.Context(max_points=stride, max_batch=B, max_tracks_total=8192, lib_path=lib)
 for k in range(24):
     ts = [1e9 + k * 1e5] * B
@@ -29,6 +29,8 @@ for slot in (0, 3, 5, 7):
     buf = np.zeros(16, np.int64)
     ctx.lib.mot_debug_copy(ctx._h, 2, slot, buf.ctypes.data_as(ctypes.c_void_p), ctypes.c_size_t(buf.nbytes))
     d = np.diff(buf[:8])
-    print("   PC sub (last track of wave 0): load_track %d | gate words %d | association %d | update_bb %d | management %d | PDA+rest %d" % (buf[11] - buf[3], buf[12] - buf[11], buf[13] - buf[12], buf[14] - buf[13], buf[15] - buf[14], buf[4] - buf[15]))
+    if len(sys.argv) > 1 and "UKF" in sys.argv[1]:
+        print("   imm_ukf (last track of wave 0): mixing %d | cholesky %d | sigma points %d | mean+cov %d | update-lidar part .. PA end %d" % (buf[12] - buf[11], buf[13] - buf[12], buf[14] - buf[13], buf[15] - buf[14], buf[2] - buf[15]))
+    else: print("   PC sub (last track of wave 0): load_track %d | gate words %d | association %d | update_bb %d | management %d | PDA+rest %d" % (buf[11] - buf[3], buf[12] - buf[11], buf[13] - buf[12], buf[14] - buf[13], buf[15] - buf[14], buf[4] - buf[15]))
     print("slot", slot, "nlive", buf[8], "ntracks", buf[9], "boxes", buf[10], {n: int(v) for n, v in zip(names, d)}, "total", int(buf[7] - buf[0]))
 print("tracker kernel ms", ctx.time_stage(40, B, 3))
