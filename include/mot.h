@@ -215,6 +215,30 @@ int mot_get_tracks(mot_ctx* ctx, int slot, mot_track* tracks, int max_tracks, in
  * per-stream record block that the multi-GPU harness all-gathers over RCCL. Asynchronous on the context stream. */
 int mot_export_tracks_dev(mot_ctx* ctx, int batch, void* d_tracks, int max_per_slot, int32_t* d_counts);
 
+/* ---------------------------------------------------------------- cluster-node side products
+ * What OT/src/cluster/main.cpp publishes besides the boxes, computed from the elevated cloud and the label grid resident in
+ * `slot` (after mot_cluster / mot_box_fit on slot 0, or mot_frames_dev on any slot). SURVEY.md 8(f) rank 3.
+ *   clustered cloud  makeClusteredCloud(), component_clustering.cpp:311-339 — for every elevated point whose cell carries a
+ *                    cluster: the CELL CENTRE (cell_size*xI - roiM/2 + cell_size/2, same for y, z = -1), in input order
+ *   obstacle list    setObsMsg(), :341-379 — the same point for the FIRST elevated point of every labelled cell (the
+ *                    function zeroes the cell in its by-value copy of the grid), in input order, with the cluster id
+ *   cost map         createCostMap(), :425-457 — cost_width x cost_height ints, 15 per elevated point (z <= height_limit,
+ *                    outside the car footprint) saturating at 100
+ * The constants are file-scope globals of the reference (component_clustering.h:15, component_clustering.cpp:15-24). */
+typedef struct mot_side_params {
+  float cell_size;                 /* grid_size 0.2 */
+  int32_t cost_width, cost_height; /* g_cell_width, g_cell_height 50, 50 */
+  double cost_resolution;          /* g_resolution 1.0 */
+  double cost_offset_x, cost_offset_y; /* g_offset_x, g_offset_y 0, 25 */
+  double height_limit;             /* HEIGHT_LIMIT 0.1 */
+  double car_length, car_width;    /* CAR_LENGTH 4.5, CAR_WIDTH 2 */
+} mot_side_params;
+int mot_side_params_default(mot_side_params* out);
+/* every output may be NULL; clustered_xyzw: max_clustered x 4 floats (x, y, z, 0); obstacles_xyzc: max_obstacles x 4 floats
+ * (x, y, z, cluster id); cost_map: cost_width*cost_height int32 (<= 65536 cells). MOT_E_CAPACITY when a list does not fit. */
+int mot_cluster_products(mot_ctx* ctx, int slot, const mot_side_params* sp, float* clustered_xyzw, int max_clustered,
+                         int* n_clustered, float* obstacles_xyzc, int max_obstacles, int* n_obstacles, int32_t* cost_map);
+
 /* ---------------------------------------------------------------- measurement helpers (bench.py) */
 /* Re-runs only the named stage `iters` times on the data resident from the last mot_frames_dev call,
  * bracketed by hipEvents ON THE CONTEXT STREAM; returns average milliseconds per iteration.

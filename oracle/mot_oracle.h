@@ -45,6 +45,11 @@ int orc_ground_remove(const mot_params* p, const float* xyzw, int n, float* elev
 int orc_cluster(const mot_params* p, const float* elevated_xyzw, int n, int32_t* grid, int* num_cluster,
                 int32_t* point_label);
 
+/* ---- cluster-node side products (component_clustering.cpp:311-379, 425-457); outputs may be NULL ---- */
+int orc_side_params_default(mot_side_params* out);
+int orc_cluster_products(const mot_params* p, const mot_side_params* sp, const float* elevated_xyzw, int n, const int32_t* grid,
+                         float* clustered_xyzw, int* n_clustered, float* obstacles_xyzc, int* n_obstacles, int32_t* cost_map);
+
 /* ---- box (OT/src/cluster/box_fitting.cpp + restated cv::minAreaRect) ---- */
 typedef struct orc_box_debug { /* per cluster, optional */
   int32_t num_points, branch /*0 L-shape, 1 min-area-rect*/, accepted, undefined;

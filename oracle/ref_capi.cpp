@@ -123,6 +123,30 @@ int ref_cluster(const float* elev, int n, int32_t* grid, int* num_cluster) {
   return 0;
 }
 
+// makeClusteredCloud / setObsMsg / createCostMap, OT/src/cluster/component_clustering.cpp:311-379, 425-457
+// (what OT/src/cluster/main.cpp:81,96,110 call). Outputs: clustered [n][4] (x,y,z,0), obstacles [n][4] (x,y,z,cluster),
+// cost g_cell_width*g_cell_height ints.
+int ref_cluster_products(const float* elev, int n, const int32_t* grid, float* clustered, int* n_clustered, float* obstacles,
+                         int* n_obstacles, int32_t* cost_map) {
+  Quiet q;
+  auto cloud = to_cloud(elev, n);
+  for (int x = 0; x < numGrid; x++) memcpy(g_grid[x].data(), grid + x * numGrid, sizeof(int) * numGrid);
+  PointCloud<PointXYZ>::Ptr cc(new PointCloud<PointXYZ>);
+  makeClusteredCloud(cloud, g_grid, cc);
+  for (size_t i = 0; i < cc->size(); i++) { clustered[4 * i] = (*cc)[i].x; clustered[4 * i + 1] = (*cc)[i].y; clustered[4 * i + 2] = (*cc)[i].z; clustered[4 * i + 3] = 0.f; }
+  *n_clustered = (int)cc->size();
+  object_tracking::ObstacleList ol;
+  setObsMsg(cloud, g_grid, ol);
+  for (size_t i = 0; i < ol.obstacles.size(); i++) {
+    obstacles[4 * i] = (float)ol.obstacles[i].x; obstacles[4 * i + 1] = (float)ol.obstacles[i].y; obstacles[4 * i + 2] = (float)ol.obstacles[i].z;
+    obstacles[4 * i + 3] = (float)ol.obstacles[i].cluster;
+  }
+  *n_obstacles = (int)ol.obstacles.size();
+  std::vector<int> cm = createCostMap(*cloud);
+  for (size_t i = 0; i < cm.size(); i++) cost_map[i] = cm[i];
+  return (int)cm.size();
+}
+
 // boxFitting(), OT/src/cluster/box_fitting.cpp:422
 int ref_box_fit(const float* elev, int n, const int32_t* grid, int num_cluster, float* boxes, int max_boxes, int* n_boxes) {
   Quiet q;

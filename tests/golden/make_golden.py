@@ -36,6 +36,14 @@ def frame_fixture(n, stream, frame):
                 grid=cl["grid"].astype(np.int16), num_cluster=cl["num_cluster"], boxes=bx["boxes"])
 
 
+def side_fixture(n, stream, frame):
+    """cluster-node side products (makeClusteredCloud / setObsMsg / createCostMap) of one small frame"""
+    elev = np.concatenate([O.ref_ground_remove(S.make_cloud(n, stream, frame))["elevated"], S.edge_case_points()])
+    cl = O.ref_cluster(elev)
+    r = O.ref_cluster_products(elev, cl["grid"])
+    return dict(elevated=elev, grid=cl["grid"].astype(np.int16), clustered=r["clustered"], obstacles=r["obstacles"], cost_map=r["cost_map"])
+
+
 def tracker_fixture(stream, nframes, npts, unit):
     R = O.RefTracker(); R.reset()
     p = O.params(0)
@@ -73,6 +81,7 @@ if __name__ == "__main__":
     np.savez_compressed(os.path.join(HERE, "frame_ot_9k.npz"), **fx)
     fx = frame_fixture(24000, 5, 2)
     np.savez_compressed(os.path.join(HERE, "frame_ot_24k.npz"), **fx)
+    np.savez_compressed(os.path.join(HERE, "side_ot_9k.npz"), **side_fixture(9000, 3, 0))
     for unit, name in ((1e5, "us"), (0.1, "sec")):
         np.savez_compressed(os.path.join(HERE, f"tracker_ot_{name}.npz"), **tracker_fixture(1, 30, 40000, unit))
     for f in sorted(os.listdir(HERE)):

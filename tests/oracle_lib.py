@@ -149,6 +149,32 @@ def cluster(p: MotParams, elev):
     return dict(grid=grid, num_cluster=nc.value, point_label=lab[:n].copy())
 
 
+class MotSideParams(C.Structure):
+    """mirror of struct mot_side_params (include/mot.h)"""
+    _fields_ = [("cell_size", C.c_float), ("cost_width", C.c_int32), ("cost_height", C.c_int32), ("cost_resolution", C.c_double),
+                ("cost_offset_x", C.c_double), ("cost_offset_y", C.c_double), ("height_limit", C.c_double),
+                ("car_length", C.c_double), ("car_width", C.c_double)]
+
+
+def side_params() -> MotSideParams:
+    sp = MotSideParams()
+    assert orc().orc_side_params_default(C.byref(sp)) == 0
+    return sp
+
+
+def cluster_products(p: MotParams, elev, grid, sp: MotSideParams | None = None):
+    """makeClusteredCloud / setObsMsg / createCostMap restated (oracle/mot_oracle_side.c)"""
+    a = _pts(elev); n = len(a); sp = sp or side_params()
+    grid = np.ascontiguousarray(grid, np.int32)
+    cc = np.zeros((max(n, 1), 4), np.float32); ob = np.zeros((max(n, 1), 4), np.float32)
+    cm = np.zeros(sp.cost_width * sp.cost_height, np.int32); ncc = C.c_int(0); nob = C.c_int(0)
+    rc = orc().orc_cluster_products(C.byref(p), C.byref(sp), a.ctypes.data_as(C.c_void_p), n, grid.ctypes.data_as(C.c_void_p),
+                                    cc.ctypes.data_as(C.c_void_p), C.byref(ncc), ob.ctypes.data_as(C.c_void_p), C.byref(nob),
+                                    cm.ctypes.data_as(C.c_void_p))
+    assert rc == 0, rc
+    return dict(clustered=cc[: ncc.value].copy(), obstacles=ob[: nob.value].copy(), cost_map=cm.reshape(sp.cost_height, sp.cost_width))
+
+
 class BoxDebug(C.Structure):
     _fields_ = [("num_points", C.c_int32), ("branch", C.c_int32), ("accepted", C.c_int32), ("undefined", C.c_int32),
                 ("max_z", C.c_float), ("corners", C.c_float * 8)]
@@ -276,6 +302,16 @@ def ref_box_fit(elev, grid, num_cluster, max_boxes=4096):
     ref().ref_box_fit(a.ctypes.data_as(C.c_void_p), len(a), grid.ctypes.data_as(C.c_void_p), num_cluster,
                       boxes.ctypes.data_as(C.c_void_p), max_boxes, C.byref(nb))
     return dict(boxes=boxes[: min(nb.value, max_boxes)].copy(), n=nb.value)
+
+
+def ref_cluster_products(elev, grid):
+    """the reference's own makeClusteredCloud / setObsMsg / createCostMap (OT preset; 50 x 50 cost map)"""
+    a = _pts(elev); n = len(a); grid = np.ascontiguousarray(grid, np.int32)
+    cc = np.zeros((max(n, 1), 4), np.float32); ob = np.zeros((max(n, 1), 4), np.float32)
+    cm = np.zeros(65536, np.int32); ncc = C.c_int(0); nob = C.c_int(0)
+    ncell = ref().ref_cluster_products(a.ctypes.data_as(C.c_void_p), n, grid.ctypes.data_as(C.c_void_p), cc.ctypes.data_as(C.c_void_p),
+                                       C.byref(ncc), ob.ctypes.data_as(C.c_void_p), C.byref(nob), cm.ctypes.data_as(C.c_void_p))
+    return dict(clustered=cc[: ncc.value].copy(), obstacles=ob[: nob.value].copy(), cost_map=cm[:ncell].reshape(50, 50))
 
 
 class RefTracker:

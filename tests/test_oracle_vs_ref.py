@@ -53,6 +53,29 @@ def test_restatement_vs_ref_stateless_stages(oracle, synth, stream, frame, n):
     assert bx["boxes"].shape == rb["boxes"].shape and np.array_equal(bx["boxes"], rb["boxes"])
 
 
+@pytest.mark.parametrize("stream,frame,n", [(0, 0, 120000), (3, 2, 40000), (6, 1, 9000)])
+def test_side_products_vs_ref(oracle, synth, stream, frame, n):
+    """makeClusteredCloud / setObsMsg / createCostMap: the restatement against the reference's own functions"""
+    _need_ref(oracle)
+    p = oracle.params(0)
+    elev = oracle.ref_ground_remove(synth.make_cloud(n, stream, frame))["elevated"]
+    elev = np.concatenate([elev, synth.edge_case_points()])   # ROI edges, the car footprint, huge coordinates
+    cl = oracle.ref_cluster(elev)
+    r = oracle.ref_cluster_products(elev, cl["grid"])
+    o = oracle.cluster_products(p, elev, cl["grid"])
+    assert len(r["clustered"]) > 100 and len(r["obstacles"]) > 10 and r["cost_map"].max() == 100
+    for k in ("clustered", "obstacles", "cost_map"):
+        assert r[k].shape == o[k].shape and np.array_equal(r[k], o[k]), k
+
+
+def test_side_products_golden(oracle):
+    """the same, against the fixture generated from the reference (runs where oracle/_ref is absent)"""
+    fx = G.load("side_ot_9k.npz")
+    o = oracle.cluster_products(oracle.params(0), fx["elevated"], fx["grid"].astype(np.int32))
+    for k in ("clustered", "obstacles", "cost_map"):
+        assert np.array_equal(o[k], fx[k]), k
+
+
 def test_restatement_vs_ref_cell_index(oracle):
     _need_ref(oracle)
     import ctypes as C
