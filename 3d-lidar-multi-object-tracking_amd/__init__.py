@@ -70,7 +70,7 @@ EXPORTS = (
     "mot_abi_version", "mot_params_preset", "mot_create", "mot_destroy", "mot_reset", "mot_last_error",
     "mot_synchronize", "mot_stream", "mot_ground_remove", "mot_cluster", "mot_box_fit", "mot_ego_update",
     "mot_track_step", "mot_track_get_state", "mot_frames_dev", "mot_get_ground", "mot_get_clusters",
-    "mot_get_boxes", "mot_get_tracks", "mot_export_tracks_dev", "mot_time_stage",
+    "mot_get_boxes", "mot_get_tracks", "mot_export_tracks_dev", "mot_side_params_default", "mot_cluster_products", "mot_cluster_products_host", "mot_time_stage",
 )
 
 _libs: dict[str, C.CDLL] = {}
@@ -102,6 +102,13 @@ def params(preset: int = PRESET_OBJECT_TRACKING, lib: C.CDLL | None = None, **ov
     for k, v in overrides.items():
         setattr(p, k, v)
     return p
+
+
+class MotSideParams(C.Structure):
+    """mirror of struct mot_side_params (include/mot.h)"""
+    _fields_ = [("cell_size", C.c_float), ("cost_width", C.c_int32), ("cost_height", C.c_int32), ("cost_resolution", C.c_double),
+                ("cost_offset_x", C.c_double), ("cost_offset_y", C.c_double), ("height_limit", C.c_double),
+                ("car_length", C.c_double), ("car_width", C.c_double)]
 
 
 def _pts(a) -> np.ndarray:
@@ -232,6 +239,29 @@ class Context:
         grid = np.zeros((G, G), np.int32); nc = C.c_int(0); lab = np.zeros(max(n_elevated, 1), np.int32)
         self._ck(self.lib.mot_get_clusters(self._h, slot, _vp(grid), C.byref(nc), _vp(lab) if n_elevated else None))
         return dict(grid=grid, num_cluster=nc.value, point_label=lab[:n_elevated].copy())
+
+    def cluster_products(self, slot: int = 0, sp: "MotSideParams | None" = None):
+        """makeClusteredCloud / setObsMsg / createCostMap of the cluster node (component_clustering.cpp:311-379, 425-457) on the
+        elevated cloud and label grid resident in ``slot``"""
+        if sp is None:
+            sp = MotSideParams(); self._ck(self.lib.mot_side_params_default(C.byref(sp)))
+        n = self.max_points; G = self.params.num_grid
+        cc = np.zeros((n, 4), np.float32); ob = np.zeros((G * G, 4), np.float32)
+        cm = np.zeros(sp.cost_width * sp.cost_height, np.int32); ncc = C.c_int(0); nob = C.c_int(0)
+        self._ck(self.lib.mot_cluster_products(self._h, slot, C.byref(sp), _vp(cc), n, C.byref(ncc), _vp(ob), G * G, C.byref(nob), _vp(cm)))
+        return dict(clustered=cc[: ncc.value].copy(), obstacles=ob[: nob.value].copy(), cost_map=cm.reshape(sp.cost_height, sp.cost_width))
+
+    def cluster_products_host(self, elev, grid, sp: "MotSideParams | None" = None):
+        """the same on a caller-supplied cloud and label grid (the reference functions' argument lists)"""
+        if sp is None:
+            sp = MotSideParams(); self._ck(self.lib.mot_side_params_default(C.byref(sp)))
+        a = _pts(elev); n = len(a); G = self.params.num_grid
+        grid = np.ascontiguousarray(grid, np.int32)
+        cc = np.zeros((max(n, 1), 4), np.float32); ob = np.zeros((G * G, 4), np.float32)
+        cm = np.zeros(sp.cost_width * sp.cost_height, np.int32); ncc = C.c_int(0); nob = C.c_int(0)
+        self._ck(self.lib.mot_cluster_products_host(self._h, _vp(a), n, _vp(grid), C.byref(sp), _vp(cc), max(n, 1), C.byref(ncc), _vp(ob), G * G,
+                                                    C.byref(nob), _vp(cm)))
+        return dict(clustered=cc[: ncc.value].copy(), obstacles=ob[: nob.value].copy(), cost_map=cm.reshape(sp.cost_height, sp.cost_width))
 
     def get_boxes(self, slot: int = 0, max_boxes: int = 4096):
         boxes = np.zeros((max_boxes, 8, 3), np.float32); nb = C.c_int(0); bc = np.zeros(max_boxes, np.int32); nu = C.c_int(0)

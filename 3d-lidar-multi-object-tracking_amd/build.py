@@ -14,7 +14,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libmot_hip.so")
-SOURCES = ["ground.hip", "cluster.hip", "box.hip", "track.hip", "mot_api.hip"]
+SOURCES = ["ground.hip", "cluster.hip", "box.hip", "side.hip", "track.hip", "mot_api.hip"]
 HEADERS = ["mot_internal.h", "mot_math.h", "mot_wave.h", os.path.join("..", "..", "include", "mot.h")]
 
 HIPCC_FLAGS = [

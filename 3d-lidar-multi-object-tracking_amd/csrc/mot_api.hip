@@ -49,6 +49,12 @@ struct mot_ctx {
   int* d_cluster_start = nullptr;
   int* d_sorted = nullptr;
   int* d_pix = nullptr;
+  // cluster-node side products (allocated on first use)
+  int* d_side_cell = nullptr;
+  float4* d_side_cloud = nullptr;
+  float4* d_side_obs = nullptr;
+  int* d_side_cost = nullptr;
+  int* d_side_counts = nullptr;
   int2* d_wgtab = nullptr;
   int max_wg = 0;
   // tracker stage
@@ -176,7 +182,7 @@ static int make_dev_params(const mot_params& p, MotDevParams* d, std::string* er
 extern "C" void mot_destroy(mot_ctx* c) {
   if (!c) return;
   void* bufs[] = {c->d_in, c->d_n, c->d_pairs, c->d_pair_count, c->d_hg, c->d_desc, c->d_ticket, c->d_elev, c->d_ground, c->d_mask, c->d_counts,
-                  c->d_plane_a, c->d_plane_b, c->d_grid, c->d_label, c->d_stats, c->d_cand, c->d_boxes, c->d_box_cluster, c->d_rng, c->d_poly, c->d_groups, c->d_cluster_start, c->d_sorted, c->d_pix, c->d_wgtab,
+                  c->d_plane_a, c->d_plane_b, c->d_grid, c->d_label, c->d_stats, c->d_cand, c->d_boxes, c->d_box_cluster, c->d_rng, c->d_poly, c->d_groups, c->d_cluster_start, c->d_sorted, c->d_pix, c->d_wgtab, c->d_side_cell, c->d_side_cloud, c->d_side_obs, c->d_side_cost, c->d_side_counts,
                   c->d_tracks, c->d_nt, c->d_tboxes, c->d_targs, c->d_gate, c->d_prog, c->d_live, c->d_tout, c->d_tflags, c->d_ego, c->d_phase};
   for (void* b : bufs) if (b) (void)hipFree(b);
   if (c->h_counts) (void)hipHostFree(c->h_counts);
@@ -461,6 +467,72 @@ extern "C" int mot_box_fit(mot_ctx* c, const float* elev, int n, const int32_t* 
   mot_launch_box(c->dp, cb, 1, n, c->stream);
   MOT_HIP(c, hipGetLastError());
   return mot_get_boxes(c, 0, boxes, max_boxes, n_boxes, box_cluster, n_undefined);
+}
+
+// ------------------------------------------------------------------------------------------ side products
+extern "C" int mot_side_params_default(mot_side_params* o) {
+  if (!o) return MOT_E_ARG;
+  memset(o, 0, sizeof *o);
+  o->cell_size = 0.2f;                                                 // component_clustering.h:15
+  o->cost_resolution = 1.0; o->cost_width = 50; o->cost_height = 50;   // component_clustering.cpp:15-17
+  o->cost_offset_x = 0; o->cost_offset_y = 25;                         // :18-19
+  o->height_limit = 0.1; o->car_length = 4.5; o->car_width = 2;        // :22-24
+  return MOT_OK;
+}
+
+constexpr int kMaxCostCells = 65536;
+
+// makeClusteredCloud / setObsMsg / createCostMap, OT/src/cluster/component_clustering.cpp:311-379, 425-457
+extern "C" int mot_cluster_products(mot_ctx* c, int slot, const mot_side_params* sp, float* clustered_xyzw, int max_clustered,
+                                    int* n_clustered, float* obstacles_xyzc, int max_obstacles, int* n_obstacles, int32_t* cost_map) {
+  if (!c || !sp || slot < 0 || slot >= c->batch || max_clustered < 0 || max_obstacles < 0) return MOT_E_ARG;
+  if ((clustered_xyzw && !n_clustered) || (obstacles_xyzc && !n_obstacles)) return MOT_E_ARG;
+  if (sp->cost_width < 1 || sp->cost_height < 1 || (long)sp->cost_width * sp->cost_height > kMaxCostCells || !(sp->cost_resolution > 0))
+    return fail(c, MOT_E_ARG, "cost map must have 1..65536 cells and a positive resolution");
+  if (!c->d_side_cell) {
+    MOT_HIP(c, hipMalloc(&c->d_side_cell, (size_t)MOT_MAX_GRID * MOT_MAX_GRID * sizeof(int)));
+    MOT_HIP(c, hipMalloc(&c->d_side_cloud, (size_t)c->cap * sizeof(float4)));
+    MOT_HIP(c, hipMalloc(&c->d_side_obs, (size_t)MOT_MAX_GRID * MOT_MAX_GRID * sizeof(float4)));
+    MOT_HIP(c, hipMalloc(&c->d_side_cost, (size_t)kMaxCostCells * sizeof(int)));
+    MOT_HIP(c, hipMalloc(&c->d_side_counts, 2 * sizeof(int)));
+  }
+  SideDevParams d;
+  d.cell_size = sp->cell_size; d.cost_width = sp->cost_width; d.cost_height = sp->cost_height; d.cost_resolution = sp->cost_resolution;
+  d.center_x = (sp->cost_width / 2.0) * sp->cost_resolution - sp->cost_offset_x;    // map_center_x, :428
+  d.center_y = (sp->cost_height / 2.0) * sp->cost_resolution - sp->cost_offset_y;   // map_center_y, :429
+  d.height_limit = sp->height_limit; d.car_length = sp->car_length; d.car_width = sp->car_width;
+  SideBuffers s;
+  s.elevated = c->d_elev + (size_t)slot * c->cap; s.grid = c->d_grid + (size_t)slot * MOT_MAX_GRID * MOT_MAX_GRID;
+  s.counts = c->d_counts + (size_t)slot * kCountsStride; s.cell_first = c->d_side_cell; s.clustered = c->d_side_cloud;
+  s.obstacles = c->d_side_obs; s.cost = c->d_side_cost; s.out_counts = c->d_side_counts;
+  s.max_clustered = c->cap; s.max_obstacles = MOT_MAX_GRID * MOT_MAX_GRID;
+  mot_launch_side_products(c->dp, d, s, c->stream);
+  MOT_HIP(c, hipGetLastError());
+  int h[2] = {0, 0};
+  MOT_HIP(c, hipMemcpyAsync(h, c->d_side_counts, sizeof h, hipMemcpyDeviceToHost, c->stream));
+  MOT_HIP(c, hipStreamSynchronize(c->stream));
+  if (n_clustered) *n_clustered = h[0];
+  if (n_obstacles) *n_obstacles = h[1];
+  if ((clustered_xyzw && h[0] > max_clustered) || (obstacles_xyzc && h[1] > max_obstacles))
+    return fail(c, MOT_E_CAPACITY, "more clustered points / obstacles than the caller's buffer holds");
+  if (clustered_xyzw && h[0] > 0) MOT_HIP(c, hipMemcpyAsync(clustered_xyzw, c->d_side_cloud, (size_t)h[0] * 16, hipMemcpyDeviceToHost, c->stream));
+  if (obstacles_xyzc && h[1] > 0) MOT_HIP(c, hipMemcpyAsync(obstacles_xyzc, c->d_side_obs, (size_t)h[1] * 16, hipMemcpyDeviceToHost, c->stream));
+  if (cost_map) MOT_HIP(c, hipMemcpyAsync(cost_map, c->d_side_cost, (size_t)sp->cost_width * sp->cost_height * sizeof(int), hipMemcpyDeviceToHost, c->stream));
+  MOT_HIP(c, hipStreamSynchronize(c->stream));
+  return MOT_OK;
+}
+
+extern "C" int mot_cluster_products_host(mot_ctx* c, const float* elev, int n, const int32_t* grid, const mot_side_params* sp,
+                                         float* clustered_xyzw, int max_clustered, int* n_clustered, float* obstacles_xyzc,
+                                         int max_obstacles, int* n_obstacles, int32_t* cost_map) {
+  if (!c || (!elev && n > 0) || n < 0 || !grid) return MOT_E_ARG;
+  if (n > c->cap) return fail(c, MOT_E_CAPACITY, "cloud has more points than max_points");
+  const int G = c->params.num_grid;
+  if (n > 0) MOT_HIP(c, hipMemcpyAsync(c->d_elev, elev, (size_t)n * 16, hipMemcpyHostToDevice, c->stream));
+  MOT_HIP(c, hipMemcpyAsync(c->d_grid, grid, (size_t)G * G * sizeof(int), hipMemcpyHostToDevice, c->stream));
+  int rc = set_count(c, 0, kCntElev, n);
+  if (rc) return rc;
+  return mot_cluster_products(c, 0, sp, clustered_xyzw, max_clustered, n_clustered, obstacles_xyzc, max_obstacles, n_obstacles, cost_map);
 }
 
 extern "C" int mot_get_ground(mot_ctx* c, int slot, float* elev, int* n_elev, float* ground, int* n_ground,

@@ -147,6 +147,26 @@ void mot_launch_cluster_kernel(int which, const MotDevParams& p, const ClusterBu
 void mot_launch_stats_init(const ClusterBuffers& c, int batch, hipStream_t stream);
 void mot_launch_box_kernel(int which, const MotDevParams& p, const ClusterBuffers& c, int batch, int max_n, hipStream_t stream);
 
+// ---- cluster-node side products (side.hip) ------------------------------------------------------
+struct SideDevParams {
+  float cell_size;
+  int cost_width, cost_height;
+  double cost_resolution, center_x, center_y;   // map_center_x/y, component_clustering.cpp:428-429
+  double height_limit, car_length, car_width;
+};
+struct SideBuffers {
+  const float4* elevated;   // the slot's elevated cloud
+  const int* grid;          // the slot's label grid, x-major with stride num_grid
+  const int* counts;        // the slot's counters (kCntElev)
+  int* cell_first;          // [MOT_MAX_GRID^2] scratch: first point of every labelled cell
+  float4* clustered;        // [max_clustered]
+  float4* obstacles;        // [max_obstacles] (x, y, z, cluster)
+  int* cost;                // [cost_width * cost_height]
+  int* out_counts;          // [2] clustered points, obstacles
+  int max_clustered, max_obstacles;
+};
+void mot_launch_side_products(const MotDevParams& p, const SideDevParams& sp, const SideBuffers& s, hipStream_t stream);
+
 // ---- tracker stage ---------------------------------------------------------------------------
 #ifndef MOT_TRACK_BLOCK
 #define MOT_TRACK_BLOCK 512

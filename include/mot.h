@@ -238,6 +238,11 @@ int mot_side_params_default(mot_side_params* out);
  * (x, y, z, cluster id); cost_map: cost_width*cost_height int32 (<= 65536 cells). MOT_E_CAPACITY when a list does not fit. */
 int mot_cluster_products(mot_ctx* ctx, int slot, const mot_side_params* sp, float* clustered_xyzw, int max_clustered,
                          int* n_clustered, float* obstacles_xyzc, int max_obstacles, int* n_obstacles, int32_t* cost_map);
+/* the same on a caller-supplied cloud and label grid (the argument lists of the three reference functions): uploads them
+ * into slot 0 first. elevated_xyzw: n x 4 floats; grid: num_grid x num_grid int32, x-major. */
+int mot_cluster_products_host(mot_ctx* ctx, const float* elevated_xyzw, int n, const int32_t* grid, const mot_side_params* sp,
+                              float* clustered_xyzw, int max_clustered, int* n_clustered, float* obstacles_xyzc,
+                              int max_obstacles, int* n_obstacles, int32_t* cost_map);
 
 /* ---------------------------------------------------------------- measurement helpers (bench.py) */
 /* Re-runs only the named stage `iters` times on the data resident from the last mot_frames_dev call,

@@ -2,7 +2,7 @@
 //
 // Drop this header (and libmot_hip.so) into the reference's catkin package and the three node sources
 // (OT/src/groundremove/main.cpp, OT/src/cluster/main.cpp, OT/tracking/main.cpp) compile unchanged: the functions below
-// have exactly the signatures of OT/include/ground_removal.h:62-64, component_clustering.h:20-22, box_fitting.h:34-36 and
+// have exactly the signatures of OT/include/ground_removal.h:62-64, component_clustering.h:20-37, box_fitting.h:34-36 and
 // imm_ukf_jpda.h:15-22, and forward to the GPU library. Only PCL container types are used (header-only here: the
 // library itself never sees PCL/Eigen/ROS types).
 //
@@ -79,6 +79,55 @@ inline void componentClustering(pcl::PointCloud<pcl::PointXYZ>::Ptr elevatedClou
   check(mot_cluster(context(), in.data(), (int)elevatedCloud->size(), grid.data(), &nc, nullptr));
   for (size_t x = 0; x < G; x++) for (size_t y = 0; y < G; y++) cartesianData[x][y] = grid[x * G + y];
   numCluster = nc;
+}
+
+// OT/include/component_clustering.h:27-29 — appends the cell-centre point of every clustered elevated point, in input order
+template <size_t G>
+inline void makeClusteredCloud(pcl::PointCloud<pcl::PointXYZ>::Ptr& elevatedCloud, std::array<std::array<int, G>, G> cartesianData,
+                               pcl::PointCloud<pcl::PointXYZ>::Ptr& clusterCloud) {
+  using namespace mot_adapters;
+  std::vector<float> in = pack(*elevatedCloud);
+  std::vector<int32_t> grid(G * G);
+  for (size_t x = 0; x < G; x++) for (size_t y = 0; y < G; y++) grid[x * G + y] = cartesianData[x][y];
+  mot_side_params sp; mot_side_params_default(&sp);
+  std::vector<float> out(elevatedCloud->size() * 4 + 4);
+  int n = 0;
+  check(mot_cluster_products_host(context(), in.data(), (int)elevatedCloud->size(), grid.data(), &sp, out.data(), (int)elevatedCloud->size(), &n,
+                                  nullptr, 0, nullptr, nullptr));
+  for (int i = 0; i < n; i++) clusterCloud->push_back(pcl::PointXYZ(out[4 * i], out[4 * i + 1], out[4 * i + 2]));
+}
+
+// OT/include/component_clustering.h:35-37 — ObstacleListT = object_tracking::ObstacleList (any type with the same members:
+// header.frame_id, cellLength, cellWidth, obstacles of a value_type with x, y, z, cluster)
+template <size_t G, typename ObstacleListT>
+inline void setObsMsg(pcl::PointCloud<pcl::PointXYZ>::Ptr& elevatedCloud, std::array<std::array<int, G>, G> cartesianData, ObstacleListT& clu_obs) {
+  using namespace mot_adapters;
+  std::vector<float> in = pack(*elevatedCloud);
+  std::vector<int32_t> grid(G * G);
+  for (size_t x = 0; x < G; x++) for (size_t y = 0; y < G; y++) grid[x * G + y] = cartesianData[x][y];
+  mot_side_params sp; mot_side_params_default(&sp);
+  std::vector<float> out(G * G * 4);
+  int n = 0;
+  check(mot_cluster_products_host(context(), in.data(), (int)elevatedCloud->size(), grid.data(), &sp, nullptr, 0, nullptr, out.data(), (int)(G * G), &n, nullptr));
+  for (int i = 0; i < n; i++) {
+    typename decltype(clu_obs.obstacles)::value_type o{};
+    o.x = out[4 * i]; o.y = out[4 * i + 1]; o.z = out[4 * i + 2]; o.cluster = (int)out[4 * i + 3];
+    clu_obs.header.frame_id = elevatedCloud->header.frame_id;   // the reference sets these per obstacle, :372-374
+    clu_obs.cellLength = sp.cell_size; clu_obs.cellWidth = sp.cell_size;
+    clu_obs.obstacles.push_back(o);
+  }
+}
+
+// OT/include/component_clustering.h:33
+inline std::vector<int> createCostMap(const pcl::PointCloud<pcl::PointXYZ>& scan) {
+  using namespace mot_adapters;
+  std::vector<float> in = pack(scan);
+  mot_params p; mot_params_preset(config().preset, &p);
+  std::vector<int32_t> grid((size_t)p.num_grid * p.num_grid, 0);   // the cost map does not look at the label grid
+  mot_side_params sp; mot_side_params_default(&sp);
+  std::vector<int32_t> cost((size_t)sp.cost_width * sp.cost_height);
+  check(mot_cluster_products_host(context(), in.data(), (int)scan.size(), grid.data(), &sp, nullptr, 0, nullptr, nullptr, 0, nullptr, cost.data()));
+  return std::vector<int>(cost.begin(), cost.end());
 }
 
 // OT/include/box_fitting.h:34-36 (the MarkerArray argument is accepted and left untouched: any type)

@@ -9,6 +9,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 SRC = r'''
 #include <array>
 #include <vector>
+#include <object_tracking/ObstacleList.h>
 #include "mot_adapters.hpp"
 using namespace std; using namespace pcl;
 const int numGrid = 250;
@@ -19,6 +20,11 @@ int use_like_the_reference_nodes() {
   array<array<int, numGrid>, numGrid> cartesianData{};
   int numCluster = 0;
   componentClustering(elevatedCloud, cartesianData, numCluster);         // OT/src/cluster/main.cpp:74
+  PointCloud<PointXYZ>::Ptr clusteredCloud(new PointCloud<PointXYZ>);
+  makeClusteredCloud(elevatedCloud, cartesianData, clusteredCloud);      // :81
+  vector<int> cost_map = createCostMap(*elevatedCloud);                  // :96
+  object_tracking::ObstacleList clu_obs;
+  setObsMsg(elevatedCloud, cartesianData, clu_obs);                      // :110
   MarkerArray ma;
   vector<PointCloud<PointXYZ>> bBoxes = boxFitting(elevatedCloud, cartesianData, numCluster, ma);  // :119
   vector<vector<double>> egoPoints;

@@ -95,6 +95,38 @@ def test_more_than_64_label_chunks(ctx, oracle, synth):
     _stage_parity(ctx, oracle, p, elev)
 
 
+@pytest.mark.parametrize("n,stream,frame", [(120000, 0, 0), (200000, 4, 1), (9000, 6, 2)])
+def test_side_products(ctx, oracle, synth, n, stream, frame):
+    """cluster-node side products (clustered cloud, obstacle list, cost map): bit-exact against the restatement"""
+    p = oracle.params(0)
+    elev = np.concatenate([oracle.ground_remove(p, synth.make_cloud(n, stream, frame))["elevated"], synth.edge_case_points()])
+    r = ctx.cluster(elev)
+    a = ctx.cluster_products(0); o = oracle.cluster_products(p, elev, r["grid"])
+    assert len(o["clustered"]) > 100 and len(o["obstacles"]) > 10
+    for k in ("clustered", "obstacles", "cost_map"):
+        assert a[k].shape == o[k].shape and np.array_equal(a[k], o[k]), k
+
+
+def test_side_products_golden_and_empty(ctx, oracle):
+    fx = G.load("side_ot_9k.npz")
+    ctx.cluster(fx["elevated"])
+    a = ctx.cluster_products(0)
+    for k in ("clustered", "obstacles", "cost_map"):
+        assert np.array_equal(a[k], fx[k]), k
+    ctx.cluster(np.zeros((0, 4), np.float32))
+    a = ctx.cluster_products(0)
+    assert len(a["clustered"]) == 0 and len(a["obstacles"]) == 0 and not a["cost_map"].any()
+    # the host-input form (the reference functions' own argument lists), with a non-default cost map
+    sp = oracle.side_params(); sp.cost_width = 64; sp.cost_height = 40; sp.cost_resolution = 0.5; sp.cost_offset_x = 3.0
+    import ctypes as C
+    msp = type(ctx).cluster_products_host.__globals__["MotSideParams"]()
+    C.memmove(C.byref(msp), C.byref(sp), C.sizeof(sp))
+    a = ctx.cluster_products_host(fx["elevated"], fx["grid"].astype(np.int32), msp)
+    o = oracle.cluster_products(oracle.params(0), fx["elevated"], fx["grid"].astype(np.int32), sp)
+    for k in ("clustered", "obstacles", "cost_map"):
+        assert a[k].shape == o[k].shape and np.array_equal(a[k], o[k]), k
+
+
 def test_ccl_adversarial_patterns(mot, hip_lib, oracle):
     rng = np.random.default_rng(0)
     for preset in (0, 1):

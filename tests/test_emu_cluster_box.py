@@ -31,6 +31,21 @@ def test_emu_cluster_box_pipeline(mot, emu_lib, oracle, synth):
             assert np.array_equal(b["boxes"], ob["boxes"]) and np.array_equal(b["box_cluster"], ob["box_cluster"])
 
 
+def test_emu_side_products(mot, emu_lib, oracle, synth):
+    """makeClusteredCloud / setObsMsg / createCostMap kernel under the emulator against the restatement"""
+    p = oracle.params(0)
+    with mot.Context(lib_path=emu_lib, max_points=40000) as c:
+        elev = np.concatenate([oracle.ground_remove(p, synth.make_cloud(36000, 2, 1))["elevated"], synth.edge_case_points()])
+        r = c.cluster(elev)
+        a = c.cluster_products(0); o = oracle.cluster_products(p, elev, r["grid"])
+        assert len(o["clustered"]) > 100 and len(o["obstacles"]) > 10
+        for k in ("clustered", "obstacles", "cost_map"):
+            assert a[k].shape == o[k].shape and np.array_equal(a[k], o[k]), k
+        h = c.cluster_products_host(elev[:5000], r["grid"]); oh = oracle.cluster_products(p, elev[:5000], r["grid"])
+        for k in ("clustered", "obstacles", "cost_map"):
+            assert np.array_equal(h[k], oh[k]), k
+
+
 @pytest.mark.parametrize("preset", [0, 1])
 def test_emu_ccl_patterns(mot, emu_lib, oracle, preset):
     rng = np.random.default_rng(1)
