@@ -70,7 +70,7 @@ EXPORTS = (
     "mot_abi_version", "mot_params_preset", "mot_create", "mot_destroy", "mot_reset", "mot_last_error",
     "mot_synchronize", "mot_stream", "mot_ground_remove", "mot_cluster", "mot_box_fit", "mot_ego_update",
     "mot_track_step", "mot_track_get_state", "mot_frames_dev", "mot_get_ground", "mot_get_clusters",
-    "mot_get_boxes", "mot_get_tracks", "mot_export_tracks_dev", "mot_side_params_default", "mot_cluster_products", "mot_cluster_products_host", "mot_time_stage",
+    "mot_get_boxes", "mot_get_tracks", "mot_export_tracks_dev", "mot_side_params_default", "mot_cluster_products", "mot_cluster_products_host", "mot_decode_pointcloud2_dev", "mot_time_stage",
 )
 
 _libs: dict[str, C.CDLL] = {}
@@ -239,6 +239,10 @@ class Context:
         grid = np.zeros((G, G), np.int32); nc = C.c_int(0); lab = np.zeros(max(n_elevated, 1), np.int32)
         self._ck(self.lib.mot_get_clusters(self._h, slot, _vp(grid), C.byref(nc), _vp(lab) if n_elevated else None))
         return dict(grid=grid, num_cluster=nc.value, point_label=lab[:n_elevated].copy())
+
+    def decode_pointcloud2_dev(self, d_data_ptr: int, n: int, point_step: int, off_x: int, off_y: int, off_z: int, off_w: int, d_xyzw_ptr: int):
+        """PointCloud2 payload (device) -> float4 points (device), asynchronous on the context stream"""
+        self._ck(self.lib.mot_decode_pointcloud2_dev(self._h, C.c_void_p(d_data_ptr), n, point_step, off_x, off_y, off_z, off_w, C.c_void_p(d_xyzw_ptr)))
 
     def cluster_products(self, slot: int = 0, sp: "MotSideParams | None" = None):
         """makeClusteredCloud / setObsMsg / createCostMap of the cluster node (component_clustering.cpp:311-379, 425-457) on the

@@ -427,6 +427,29 @@ classify_compact_kernel(MotDevParams p, GroundBuffers g) {
   }
 }
 
+// ------------------------------------------------------------------------------------------ input decode
+// PointCloud2 records -> float4 (include/mot.h, mot_decode_pointcloud2_dev). HBM-bound gather: point_step bytes read,
+// 16 written per point. Records whose fields are 4-byte aligned take dword loads; anything else is assembled from bytes.
+__global__ void MOT_LAUNCH_BOUNDS(256)
+decode_pointcloud2_kernel(const unsigned char* __restrict__ data, int n, int step, int ox, int oy, int oz, int ow, int aligned, float4* __restrict__ out) {
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  const unsigned char* rec = data + i * step;
+  auto field = [&](int off) -> float {
+    unsigned u;
+    if (aligned) u = *reinterpret_cast<const unsigned*>(rec + off);
+    else u = (unsigned)rec[off] | ((unsigned)rec[off + 1] << 8) | ((unsigned)rec[off + 2] << 16) | ((unsigned)rec[off + 3] << 24);
+    return __uint_as_float(u);
+  };
+  out[i] = make_float4(field(ox), field(oy), field(oz), ow >= 0 ? field(ow) : 1.0f);
+}
+
+void mot_launch_decode_pointcloud2(const void* data, int n, int step, int ox, int oy, int oz, int ow, float4* out, hipStream_t stream) {
+  if (n <= 0) return;
+  const int aligned = (((size_t)data | (size_t)step | (size_t)ox | (size_t)oy | (size_t)oz | (size_t)(ow >= 0 ? ow : 0)) & 3) == 0;
+  hipLaunchKernelGGL(decode_pointcloud2_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, (const unsigned char*)data, n, step, ox, oy, oz, ow, aligned, out);
+}
+
 // ------------------------------------------------------------------------------------------ host
 void mot_launch_ground_kernel(int which, const MotDevParams& p, const GroundBuffers& g, int batch, int max_n,
                               hipStream_t stream) {

@@ -469,6 +469,19 @@ extern "C" int mot_box_fit(mot_ctx* c, const float* elev, int n, const int32_t* 
   return mot_get_boxes(c, 0, boxes, max_boxes, n_boxes, box_cluster, n_undefined);
 }
 
+// fromROSMsg for PointXYZ (OT/src/groundremove/main.cpp:100), device to device
+extern "C" int mot_decode_pointcloud2_dev(mot_ctx* c, const void* d_data, int n, int point_step, int off_x, int off_y, int off_z,
+                                          int off_w, float* d_xyzw) {
+  if (!c || n < 0 || (n > 0 && (!d_data || !d_xyzw)) || point_step < 12) return MOT_E_ARG;
+  const int offs[4] = {off_x, off_y, off_z, off_w};
+  for (int k = 0; k < 4; k++)
+    if ((k < 3 || offs[k] >= 0) && (offs[k] < 0 || offs[k] + 4 > point_step)) return fail(c, MOT_E_ARG, "field offset outside the point record");
+  if (((size_t)d_xyzw & 15) != 0) return fail(c, MOT_E_ARG, "d_xyzw must be 16-byte aligned");
+  mot_launch_decode_pointcloud2(d_data, n, point_step, off_x, off_y, off_z, off_w, (float4*)d_xyzw, c->stream);
+  MOT_HIP(c, hipGetLastError());
+  return MOT_OK;
+}
+
 // ------------------------------------------------------------------------------------------ side products
 extern "C" int mot_side_params_default(mot_side_params* o) {
   if (!o) return MOT_E_ARG;

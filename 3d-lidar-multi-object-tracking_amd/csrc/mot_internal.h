@@ -234,6 +234,7 @@ void mot_launch_boxes_to_global(const float* boxes_sensor, const int* counts, co
 #endif
 
 void mot_launch_ground(const MotDevParams& p, const GroundBuffers& g, int batch, int max_n, hipStream_t stream);
+void mot_launch_decode_pointcloud2(const void* data, int n, int step, int ox, int oy, int oz, int ow, float4* out, hipStream_t stream);
 // single kernels, for per-kernel timing (mot_time_stage): which = 0 min-z, 1 polar filter, 2 classify+compact
 void mot_launch_ground_kernel(int which, const MotDevParams& p, const GroundBuffers& g, int batch, int max_n,
                               hipStream_t stream);

@@ -244,6 +244,18 @@ int mot_cluster_products_host(mot_ctx* ctx, const float* elevated_xyzw, int n, c
                               float* clustered_xyzw, int max_clustered, int* n_clustered, float* obstacles_xyzc,
                               int max_obstacles, int* n_obstacles, int32_t* cost_map);
 
+/* ---------------------------------------------------------------- input decode
+ * sensor_msgs/PointCloud2 payload -> the float4 (x, y, z, w) layout of this library, on the device: what
+ * `fromROSMsg(*input, *cloud)` (OT/src/groundremove/main.cpp:100; pcl_conversions + pcl::fromPCLPointCloud2, not part of
+ * the reference tree) does for PointXYZ — copy the FLOAT32 fields named x, y, z of every point (NaN points included), at
+ * their byte offsets inside a record of `point_step` bytes, little endian. w = the FLOAT32 at `off_w`, or 1.0f (what
+ * PointXYZ's padding holds) when off_w < 0. A KITTI velodyne .bin file is the case point_step = 16, offsets 0/4/8/12.
+ * d_data and d_xyzw are DEVICE pointers (d_data only byte aligned is fine); asynchronous on the context stream, so the
+ * result can be handed straight to mot_frames_dev. Parity: restated from the PCL documentation, pinned against a numpy
+ * structured-array view in tests/ (PCL itself is not available here). */
+int mot_decode_pointcloud2_dev(mot_ctx* ctx, const void* d_data, int n_points, int point_step, int off_x, int off_y, int off_z,
+                               int off_w, float* d_xyzw);
+
 /* ---------------------------------------------------------------- measurement helpers (bench.py) */
 /* Re-runs only the named stage `iters` times on the data resident from the last mot_frames_dev call,
  * bracketed by hipEvents ON THE CONTEXT STREAM; returns average milliseconds per iteration.

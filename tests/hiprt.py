@@ -31,6 +31,13 @@ class DeviceBuffer:
         self.ptr = p.value
         self.nbytes = host.nbytes
 
+    def to_host(self, dtype, shape) -> np.ndarray:
+        out = np.empty(shape, dtype)
+        assert out.nbytes <= self.nbytes
+        assert hip().hipDeviceSynchronize() == 0
+        assert hip().hipMemcpy(out.ctypes.data_as(C.c_void_p), C.c_void_p(self.ptr), C.c_size_t(out.nbytes), 2) == 0  # D2H
+        return out
+
     def free(self):
         if self.ptr:
             hip().hipFree(C.c_void_p(self.ptr))

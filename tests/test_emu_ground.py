@@ -28,3 +28,16 @@ def test_emu_ground(emu_ctx, oracle, synth, n, stream):
     g = oracle.ground_remove(p, cloud)
     assert np.array_equal(r["mask"], g["mask"])
     assert np.array_equal(r["elevated"], g["elevated"]) and np.array_equal(r["ground"], g["ground"])
+
+
+def test_emu_decode_pointcloud2(emu_ctx, synth):
+    """the PointCloud2 -> float4 kernel under the emulator ("device" pointers are host arrays there)"""
+    n, step = 5000, 22
+    cloud = synth.make_cloud(n, 2, 0)
+    raw = np.random.default_rng(1).integers(0, 256, size=(n, step), dtype=np.uint8)
+    for k, off in enumerate((0, 4, 8, 12)):
+        raw[:, off:off + 4] = cloud[:, k].copy().view(np.uint8).reshape(n, 4)
+    out = np.zeros((n, 4), np.float32)
+    emu_ctx.decode_pointcloud2_dev(raw.ctypes.data, n, step, 0, 4, 8, 12, out.ctypes.data)
+    emu_ctx.synchronize()
+    assert np.array_equal(out, cloud)

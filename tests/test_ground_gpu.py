@@ -99,3 +99,36 @@ def test_ground_properties_full_size(ctx, synth):
     assert np.array_equal(cloud[m == 2], r["elevated"]) and np.array_equal(cloud[m == 1], r["ground"])
     r2 = ctx.ground_remove(cloud)
     assert np.array_equal(r2["mask"], m)
+
+
+@pytest.mark.parametrize("step,offs,shift", [(16, (0, 4, 8, 12), 0), (32, (0, 4, 8, -1), 0), (32, (4, 8, 12, 16), 0), (22, (0, 4, 8, 12), 0),
+                                             (18, (2, 6, 10, -1), 0), (16, (0, 4, 8, 12), 2)])
+def test_decode_pointcloud2(mot, hip_lib, oracle, synth, step, offs, shift):
+    """sensor_msgs/PointCloud2 records -> float4 on the device (fromROSMsg for PointXYZ): against a numpy byte-level restatement,
+    aligned and unaligned records, NaN points kept; the decoded buffer then feeds the fused path"""
+    import hiprt
+    n = 30000
+    cloud = synth.make_cloud(n, 7, 0)
+    cloud[5, 0] = np.nan; cloud[6, 2] = np.inf
+    raw = np.random.default_rng(step).integers(0, 256, size=(n, step), dtype=np.uint8)   # other fields: ring, time, padding
+    names = ("x", "y", "z", "w")
+    for k, off in enumerate(offs):
+        if off >= 0:
+            raw[:, off:off + 4] = cloud[:, k].copy().view(np.uint8).reshape(n, 4)
+    expect = np.ones((n, 4), np.float32)
+    for k, off in enumerate(offs):
+        if off >= 0:
+            expect[:, k] = raw[:, off:off + 4].copy().view(np.float32).reshape(n)
+    payload = np.concatenate([np.zeros(shift, np.uint8), raw.reshape(-1)])
+    stride = 30720
+    with mot.Context(max_points=stride, max_batch=1) as c:
+        src = hiprt.DeviceBuffer(payload); dst = hiprt.DeviceBuffer(np.zeros((stride, 4), np.float32))
+        c.decode_pointcloud2_dev(src.ptr + shift, n, step, offs[0], offs[1], offs[2], offs[3], dst.ptr)
+        c.synchronize()
+        got = dst.to_host(np.float32, (n, 4))
+        assert np.array_equal(got.view(np.uint32), expect.view(np.uint32))
+        p = oracle.params(0)
+        c.frames_dev(dst.ptr, stride * 4, [n])
+        g = c.get_ground(0, n_hint=n); o = oracle.ground_remove(p, expect)
+        assert np.array_equal(g["elevated"], o["elevated"]) and np.array_equal(g["ground"], o["ground"])
+        src.free(); dst.free()
