@@ -186,6 +186,10 @@ def test_fused_frames_dev(ctx, oracle, synth):
             ob = oracle.box_fit(p, g["elevated"], o["grid"], o["num_cluster"])
             bx = ctx.get_boxes(b)
             assert np.array_equal(bx["boxes"], ob["boxes"]) and np.array_equal(bx["box_cluster"], ob["box_cluster"])
+            if rep == 1 and b in (0, 3, 4):   # the cluster node's side products of a slot of the fused path
+                sd = ctx.cluster_products(b); osd = oracle.cluster_products(p, g["elevated"], o["grid"])
+                for k in ("clustered", "obstacles", "cost_map"):
+                    assert sd[k].shape == osd[k].shape and np.array_equal(sd[k], osd[k]), (b, k)
     dev.free()
 
 
