@@ -353,11 +353,16 @@ classify_compact_kernel(MotDevParams p, GroundBuffers g) {
   if (wave == 0) {
     // exclusive scan of the 64 tile counts (elevated in the high half-word, ground in the low one; a chunk holds at most
     // 4096 of either) and the chunk totals
-    const int cnt = s_cnt[lane];
+    constexpr int kPerLane = kSubTiles / 64;
+    int cnt = 0, c[kPerLane];
+#pragma unroll
+    for (int j = 0; j < kPerLane; j++) { c[j] = s_cnt[lane * kPerLane + j]; cnt += c[j]; }
     const int incl = wave_scan_incl_i32(cnt);
     const int tot = wave_bcast_i32(incl, 63);
     const int tot_e = tot >> 16, tot_g = tot & 0xffff;
-    s_cnt[lane] = incl - cnt;
+    int run = incl - cnt;
+#pragma unroll
+    for (int j = 0; j < kPerLane; j++) { s_cnt[lane * kPerLane + j] = run; run += c[j]; }
     // decoupled look-back over the chunks of THIS frame
     unsigned long long* desc = g.desc + (long)b * g.max_chunks;
     const unsigned long long ep = (unsigned long long)(g.epoch & kDescEpochMask) << kDescEpochShift;

@@ -24,9 +24,12 @@ constexpr int kGroundChunk = kGroundBlock * kGroundItems;  // 2048 points = 32 K
 #define MOT_COMPACT_BLOCK 512
 #endif
 constexpr int kCompactBlock = MOT_COMPACT_BLOCK;  // threads per workgroup of the compaction kernel
-constexpr int kCompactChunk = 4096;               // points per workgroup = 64 KB in flight
+#ifndef MOT_COMPACT_CHUNK
+#define MOT_COMPACT_CHUNK 4096
+#endif
+constexpr int kCompactChunk = MOT_COMPACT_CHUNK;  // points per workgroup (4096 = 64 KB in flight); a multiple of 4096
 constexpr int kCompactItems = kCompactChunk / kCompactBlock;  // points per thread
-constexpr int kSubTiles = kCompactChunk / 64;     // 64-point wave tiles per chunk (64: one lane each in the tile scan)
+constexpr int kSubTiles = kCompactChunk / 64;     // 64-point wave tiles per chunk, kSubTiles / 64 per lane in the tile scan
 constexpr int kMinzInit = 0x447A0000;             // ordered key of 1000.0f (Cell::Cell, ground_removal.cpp:35-38)
 
 // descriptor word of the decoupled look-back in the compaction kernel (one 8-byte granule, written
