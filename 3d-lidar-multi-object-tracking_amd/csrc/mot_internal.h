@@ -292,7 +292,7 @@ MOT_HD int mot_polar_cell_fast(const MotDevParams& p, float x, float y, float di
   const float tb = (distance_approx - p.r_min) * p.k_bin;
   const float fb = floorf(tb), rb = tb - fb;
   const bool bin_safe = rb > kCellGuard && rb < 1.f - kCellGuard;  // false on NaN
-  if (bin_safe && !(fb >= 0.f && fb < (float)MOT_NUM_BIN)) return -1;  // clearly outside rMin..rMax: no channel needed
+  const bool bin_in = fb >= 0.f && fb < (float)MOT_NUM_BIN;
   // channel: atan2 by octant reduction
   const float ax = fabsf(x), ay = fabsf(y);
   const float mn = ax < ay ? ax : ay;
@@ -308,15 +308,18 @@ MOT_HD int mot_polar_cell_fast(const MotDevParams& p, float x, float y, float di
   a = __builtin_fmaf(a, s, -0.33316001296043396f);
   a = __builtin_fmaf(a, s, 0.9999956488609314f);
   a = a * q;
-  if (ay > ax) a = 1.57079632679489662f - a;
-  if (x < 0.f) a = 3.14159265358979324f - a;
-  if (y < 0.f) a = -a;
+  a = ay > ax ? 1.57079632679489662f - a : a;
+  a = x < 0.f ? 3.14159265358979324f - a : a;
+  a = y < 0.f ? -a : a;
   const float tc = __builtin_fmaf(a, MOT_NUM_CHANNEL / 6.28318530717958648f, MOT_NUM_CHANNEL / 2.0f);
   const float fc = floorf(tc), rc = tc - fc;
-  const bool safe = bin_safe && rc > kCellGuard && rc < 1.f - kCellGuard;  // false on NaN
-  if (!safe) return -2;
-  if (!(fc >= 0.f && fc < (float)MOT_NUM_CHANNEL)) return -1;
-  return (int)fc * MOT_NUM_BIN + (int)fb;
+  const bool ch_safe = rc > kCellGuard && rc < 1.f - kCellGuard;  // false on NaN
+  const bool ch_in = fc >= 0.f && fc < (float)MOT_NUM_CHANNEL;
+  // straight-line selects, no branches: clearly outside rMin..rMax needs no channel; otherwise both estimates must be safe
+  const int idx = (int)fc * MOT_NUM_BIN + (int)fb;
+  int cell = (bin_safe && ch_safe) ? (ch_in ? idx : -1) : -2;
+  cell = (bin_safe && !bin_in) ? -1 : cell;
+  return cell;
 }
 
 // the fast path with the hardware estimates; -2 = undecided (call mot_polar_cell_exact)
