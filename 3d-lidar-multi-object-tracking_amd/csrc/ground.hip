@@ -337,7 +337,7 @@ classify_compact_kernel(MotDevParams p, GroundBuffers g) {
   polar_cells<kCompactItems, kCompactBlock>(p, pt, in, base, n, cls);
   float hgv[kCompactItems];
 #pragma unroll
-  for (int k = 0; k < kCompactItems; k++) hgv[k] = cls[k] >= 0 ? hg[cls[k]] : 0.f;   // independent gathers (L2), all in flight: -inf when the cell is not ground
+  for (int k = 0; k < kCompactItems; k++) hgv[k] = hg[cls[k] > 0 ? cls[k] : 0];   // unpredicated independent gathers (L2), all in flight: -inf when the cell is not ground
   const unsigned long long below = (1ull << lane) - 1ull;
 #pragma unroll
   for (int k = 0; k < kCompactItems; k++) {
