@@ -110,10 +110,15 @@ polar_minz_kernel(MotDevParams p, GroundBuffers g) {
   const int lane = wave_lane(), wave = threadIdx.x >> 6;
 
   float4 pt[kGroundItems];
+  if (base + kGroundChunk <= n) {   // all but the frame's last chunk: unpredicated loads (a predicated load is an exec-mask region each)
 #pragma unroll
-  for (int k = 0; k < kGroundItems; k++) {
-    long i = base + k * kGroundBlock + threadIdx.x;
-    pt[k] = i < n ? in[i] : make_float4(0.f, 0.f, 0.f, 0.f);  // (0,0): r = 0 <= rMin -> no cell
+    for (int k = 0; k < kGroundItems; k++) pt[k] = in[base + k * kGroundBlock + threadIdx.x];
+  } else {
+#pragma unroll
+    for (int k = 0; k < kGroundItems; k++) {
+      long i = base + k * kGroundBlock + threadIdx.x;
+      pt[k] = i < n ? in[i] : make_float4(0.f, 0.f, 0.f, 0.f);  // (0,0): r = 0 <= rMin -> no cell
+    }
   }
   int cells[kGroundItems];
   polar_cells<kGroundItems, kGroundBlock>(p, pt, in, base, n, cells);
