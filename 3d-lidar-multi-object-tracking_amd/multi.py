@@ -25,12 +25,29 @@ class TrackGather:
         self.cnt = torch.zeros(batch, dtype=torch.int32, device=device)
         self.dst = [torch.zeros_like(self.src) for _ in range(world)] if world > 1 else [self.src]
         self.dst_cnt = [torch.zeros_like(self.cnt) for _ in range(world)] if world > 1 else [self.cnt]
+        self._ext = {}   # context -> torch view of its HIP stream
 
-    def step(self, ctx):
-        """export this rank's block (async on the context stream), then exchange"""
+    def step(self, ctx, force_collective: bool = False):
+        """export this rank's block (async on the context stream), then exchange.
+
+        On GPUs nothing here blocks the host: the context's HIP stream is wrapped as a torch ExternalStream, the export
+        waits for the previous step's collective (which still reads the block), the collective waits for the export —
+        stream ordering only, so the next step's kernels are already queued behind it. On the CPU (gloo test) the
+        emulated library is synchronous anyway."""
+        torch = self.torch
+        gpu = self.src.is_cuda
+        if gpu:
+            ext = self._ext.get(id(ctx))
+            if ext is None:
+                ext = self._ext[id(ctx)] = torch.cuda.ExternalStream(ctx.lib.mot_stream(ctx._h))
+            cur = torch.cuda.current_stream()
+            ext.wait_stream(cur)      # the previous collective has consumed self.src / self.cnt
         ctx.export_tracks_dev(self.batch, self.src.data_ptr(), self.max_tracks, self.cnt.data_ptr())
-        ctx.synchronize()  # the block must be complete before the collective reads it (different stream)
-        if self.world > 1:
+        if gpu:
+            cur.wait_stream(ext)      # the block is complete before the collective reads it
+        else:
+            ctx.synchronize()
+        if self.world > 1 or force_collective:
             import torch.distributed as dist
             dist.all_gather(self.dst, self.src)
             dist.all_gather(self.dst_cnt, self.cnt)
