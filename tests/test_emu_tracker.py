@@ -23,3 +23,34 @@ def test_emu_tracker_golden(mot, name):
             assert np.allclose(ego, fx["ego"][f], rtol=1e-12, atol=1e-12)
             out = c.track_step(fx["boxes"][f][: fx["n_boxes"][f]], ts)
             G.check_tracker_frame(fx, f, out, lambda i: c.track_state(i), rtol=1e-6)
+
+
+def test_sequence_player_kitti_layout(mot, oracle, synth, tmp_path):
+    """the rosbag-free player (sequence.py) on a KITTI-raw-shaped directory of synthetic scans: every frame equals the oracle's
+    ground -> cluster -> box -> tracker chain (kernels emulated here; test_tracker_gpu.py runs the same check on the GPU)"""
+    import build_emu
+    import conftest
+    seq = conftest.load_sub("sequence")
+    lib = build_emu.build()
+    d = tmp_path / "2011_09_26_drive_0005_sync"
+    (d / "velodyne_points" / "data").mkdir(parents=True); (d / "oxts" / "data").mkdir(parents=True)
+    for f in range(4):
+        synth.make_cloud(12000, 3, f).tofile(d / "velodyne_points" / "data" / f"{f:010d}.bin")
+        ox = np.zeros(30); ox[8] = 1.5 + 0.1 * f; ox[5] = 0.002 * f
+        np.savetxt(d / "oxts" / "data" / f"{f:010d}.txt", ox[None])
+    p = oracle.params(0)
+    T = oracle.Tracker(p)
+    with mot.Context(lib_path=lib, max_points=16384, max_tracks_total=256) as c:
+        n = 0
+        for k, r in enumerate(seq.play(c, seq.kitti_frames(str(d)))):
+            cloud = synth.make_cloud(12000, 3, k); ts = 1.0e9 + k * 1.0e5
+            g = oracle.ground_remove(p, cloud); cl = oracle.cluster(p, g["elevated"])
+            bx = oracle.box_fit(p, g["elevated"], cl["grid"], cl["num_cluster"])["boxes"]
+            assert r["n_elevated"] == len(g["elevated"]) and np.array_equal(r["boxes"], bx)
+            ego = T.ego_update(ts, 1.5 + 0.1 * k, 0.002 * k)
+            assert np.allclose(r["ego"], ego, rtol=1e-12, atol=1e-12)
+            o = T.step(seq.boxes_to_global(bx, ego), ts)
+            assert r["tracks"]["n"] == o["n"] and np.array_equal(r["tracks"]["track_manage"], o["track_manage"])
+            n += 1
+        assert n == 4
+    T.close()
