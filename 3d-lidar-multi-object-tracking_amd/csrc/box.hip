@@ -152,7 +152,7 @@ label_stats_kernel(MotDevParams p, ClusterBuffers c) {
       const float roiX = q.x + p.roi_half, roiY = q.y + p.roi_half;
       const int picX = (int)floorf(roiX * p.pic_scale), y = (int)floorf(roiY * p.pic_scale);
       const int picY = (int)(p.pic_full - (float)y);
-      pix[i] = ((picX >= 0 && picX < 1024) ? picX : 0xffff) | (picY << 16);
+      pix[i] = (int)((unsigned)((picX >= 0 && picX < 1024) ? picX : 0xffff) | ((unsigned)picY << 16));   // only points inside the ROI (0 <= picY <= 900) are ever read back
     }
     if (lab > kMaxClusters) lab = 0;  // no statistics slot: box_finalize_kernel raises the capacity flag
     float m = q.y / q.x + 0.0f;  // slope, :264 (+0 makes -0 == +0 for the keyed compare, as `<` does)

@@ -8,7 +8,13 @@ import subprocess
 HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(os.path.dirname(HERE))
 CSRC = os.path.join(ROOT, "3d-lidar-multi-object-tracking_amd", "csrc")
-LIB = os.path.join(HERE, "libmot_emu.so")
+# MOT_EMU_SANITIZE=1: the same sources under UBSan (shifts, signed overflow, misaligned / out-of-bounds object accesses, …) —
+#   MOT_EMU_SANITIZE=1 python -m pytest tests/test_emu_*.py tests/test_distributed_cpu.py
+# float-cast-overflow is excluded: (int) of a NaN / huge float is defined on the GPU (saturating) and every such result is
+# discarded by a range test before use.
+SANITIZE = bool(os.environ.get("MOT_EMU_SANITIZE"))
+SAN_FLAGS = ["-fsanitize=undefined", "-fno-sanitize=float-cast-overflow", "-fno-sanitize-recover=undefined"] if SANITIZE else []
+LIB = os.path.join(HERE, "libmot_emu_ubsan.so" if SANITIZE else "libmot_emu.so")
 
 
 def sources():
@@ -25,15 +31,15 @@ def build(force: bool = False) -> str:
         return LIB
     objs = []
     for s in srcs:
-        o = os.path.join(HERE, "obj_" + s.replace(".hip", ".o"))
-        cmd = ["g++", "-std=c++17", "-O1", "-g", "-fPIC", "-ffp-contract=off", "-fno-fast-math", "-DMOT_HIPEMU=1", "-x", "c++",
+        o = os.path.join(HERE, ("objsan_" if SANITIZE else "obj_") + s.replace(".hip", ".o"))
+        cmd = ["g++", "-std=c++17", "-O1", "-g", "-fPIC"] + SAN_FLAGS + [ "-ffp-contract=off", "-fno-fast-math", "-DMOT_HIPEMU=1", "-x", "c++",
                "-include", os.path.join(HERE, "hipemu.h"), "-I", CSRC, "-Wall", "-Wno-unused-function", "-Wno-unknown-pragmas",
                "-Wno-unused-variable", "-c", os.path.join(CSRC, s), "-o", o]
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode:
             raise RuntimeError("emu build failed:\n" + r.stderr)
         objs.append(o)
-    r = subprocess.run(["g++", "-shared", "-o", LIB] + objs, capture_output=True, text=True)
+    r = subprocess.run(["g++", "-shared"] + SAN_FLAGS + ["-o", LIB] + objs, capture_output=True, text=True)
     if r.returncode:
         raise RuntimeError("emu link failed:\n" + r.stderr)
     return LIB
