@@ -120,9 +120,17 @@ ccl_kernel(MotDevParams p, ClusterBuffers c) {
   __shared__ int s_rowbase[MOT_MAX_GRID + 1];    // exclusive prefix of runs per row
   __shared__ unsigned s_isroot[kMaxRuns / 32];
   __shared__ int s_rootpre[kMaxRuns / 32 + 1];
+  __shared__ unsigned char s_wpre[kPlaneWords];  // per (row, word): run starts of the row before the word
   const int b = blockIdx.x;
   const int G = p.num_grid;
   const int tid = threadIdx.x;
+#ifdef MOT_DBG_CCL_TIMING   // phase clocks into the (idle at this point) polygon pool: tools/time_ccl.py
+  const long long t_start = clock64();
+  int* dbg = c.poly + (long)b * c.cap;
+#define CCL_T(slot) if (tid == 0) dbg[slot] = (int)(clock64() - t_start)
+#else
+#define CCL_T(slot)
+#endif
   unsigned* __restrict__ ga = c.plane_a + (long)b * kPlaneWords;
   unsigned* __restrict__ gb = c.plane_b + (long)b * kPlaneWords;
 
@@ -135,6 +143,7 @@ ccl_kernel(MotDevParams p, ClusterBuffers c) {
   }
   for (int i = tid; i <= MOT_MAX_GRID; i += kCclBlock) s_rowbase[i] = 0;
   __syncthreads();
+  CCL_T(0);
   if (p.dilate) {  // clipped 3x3 dilation, component_clustering.cpp:134-214 (separable)
     for (int i = tid; i < kPlaneWords; i += kCclBlock) {
       int x = i >> 3, w = i & 7;
@@ -154,6 +163,7 @@ ccl_kernel(MotDevParams p, ClusterBuffers c) {
       s_occ[i] = (x < G) ? v : 0u;
     }
     __syncthreads();
+  CCL_T(1);
   }
   // run starts: set bit whose lower neighbour (same row) is clear
   for (int i = tid; i < kPlaneWords; i += kCclBlock) {
@@ -165,6 +175,7 @@ ccl_kernel(MotDevParams p, ClusterBuffers c) {
     if (st) atomicAdd(&s_rowbase[x + 1], __popc(st));
   }
   __syncthreads();
+  CCL_T(2);
   if (tid < 64) {  // exclusive scan of the per-row run counts (257 entries, 5 per lane)
     int v[5], sum = 0;
 #pragma unroll
@@ -177,10 +188,12 @@ ccl_kernel(MotDevParams p, ClusterBuffers c) {
     for (int k = 0; k < 5; k++) { int idx = tid * 5 + k; run += v[k]; if (idx <= MOT_MAX_GRID) s_rowbase[idx] = run; }
   }
   __syncthreads();
+  CCL_T(3);
   // after the scan s_rowbase[x+1] = number of runs in rows 0..x, i.e. base of row x is s_rowbase[x]
   const int R = s_rowbase[MOT_MAX_GRID];
   for (int r = tid; r < R; r += kCclBlock) s_parent[r] = (unsigned)r;
   __syncthreads();
+  CCL_T(4);
 
   // ordinal of the run that starts at bit s of row x
 #define RUN_ORDINAL(x, s)                                                                              \
@@ -195,8 +208,10 @@ ccl_kernel(MotDevParams p, ClusterBuffers c) {
     if (x == 0 || x >= G) st = 0u;
     const unsigned* row = &s_occ[x * kRowWords];
     const unsigned* up = &s_occ[(x > 0 ? x - 1 : 0) * kRowWords];
-    int ord = 0;
-    if (st) { ord = s_rowbase[x]; for (int w2 = 0; w2 < w; w2++) ord += __popc(s_aux[x * kRowWords + w2]); }
+    int wpre = 0;   // run starts of this row in the words before this one
+    for (int w2 = 0; w2 < w; w2++) wpre += __popc(s_aux[x * kRowWords + w2]);
+    s_wpre[i] = (unsigned char)wpre;   // <= 128 runs per row
+    int ord = s_rowbase[x] + wpre;
     while (st) {
       int bit = __ffs(st) - 1;
       st &= st - 1u;
@@ -225,12 +240,14 @@ ccl_kernel(MotDevParams p, ClusterBuffers c) {
     }
   }
   __syncthreads();
+  CCL_T(5);
   for (int r = tid; r < R; r += kCclBlock) {  // flatten (only roots are ever written)
     unsigned v = (unsigned)r;
     while (s_parent[v] != v) v = s_parent[v];
     s_parent[r] = v;
   }
   __syncthreads();
+  CCL_T(6);
   for (int j = tid; j < kMaxRuns / 32; j += kCclBlock) {
     unsigned bits = 0u;
     int r0 = j << 5;
@@ -242,6 +259,7 @@ ccl_kernel(MotDevParams p, ClusterBuffers c) {
   }
   if (tid == 0) s_rootpre[0] = 0;
   __syncthreads();
+  CCL_T(7);
   if (tid < 64) {  // inclusive scan of 1024 word counts, 16 per lane
     int sum = 0;
     for (int k = 0; k < 16; k++) sum += s_rootpre[1 + tid * 16 + k];
@@ -252,21 +270,47 @@ ccl_kernel(MotDevParams p, ClusterBuffers c) {
     for (int k = 0; k < 16; k++) { run += s_rootpre[1 + tid * 16 + k]; s_rootpre[1 + tid * 16 + k] = run; }
   }
   __syncthreads();
+  CCL_T(8);
   const int num_cluster = s_rootpre[kMaxRuns / 32];
   if (tid == 0) c.counts[b * kCountsStride + kCntClusters] = num_cluster;
   // label grid, x-major with stride G (cartesianData[x][y]); ids in raster order of each component's first cell
   int* __restrict__ grid = c.grid + (long)b * (MOT_MAX_GRID * MOT_MAX_GRID);
-  for (int cell = tid; cell < G * G; cell += kCclBlock) {
-    int x = cell / G, y = cell - x * G;
-    const unsigned* row = &s_occ[x * kRowWords];
-    int label = 0;
-    if ((row[y >> 5] >> (y & 31)) & 1u) {
-      int s = row_run_start(row, y);
-      unsigned root = s_parent[RUN_ORDINAL(x, s)];
-      label = 1 + s_rootpre[root >> 5] + __popc(s_isroot[root >> 5] & ((1u << (root & 31)) - 1u));
-    }
-    grid[cell] = label;
+  // every run's root becomes its cluster id (each thread reads only the entries it rewrites)
+  for (int r = tid; r < R; r += kCclBlock) {
+    const unsigned root = s_parent[r];
+    s_parent[r] = 1u + (unsigned)s_rootpre[root >> 5] + (unsigned)__popc(s_isroot[root >> 5] & ((1u << (root & 31)) - 1u));
   }
+  __syncthreads();
+  // A wave per row, four consecutive cells per lane. The run of a set cell y is the (number of run starts at or before y)-th
+  // of its row: rowbase + word prefix + a popcount — two LDS levels to the label instead of a backwards scan for the run
+  // start, a popcount loop, the parent and two prefix tables per cell (that version of the pass was 46 % of the kernel).
+  {
+    const int lane = tid & 63, wave = tid >> 6;
+    const bool pairs = (G & 1) == 0;   // rows start 8-byte aligned
+    for (int x = wave; x < G; x += kCclBlock / 64) {
+      const int y0 = lane * 4;
+      if (y0 >= G) continue;
+      const int wi = x * kRowWords + (y0 >> 5), sh = y0 & 31;   // y0 is a multiple of 4: the quad never straddles a word
+      const unsigned bits = (s_occ[wi] >> sh) & 0xfu;
+      int lab[4] = {0, 0, 0, 0};
+      if (bits) {
+        const unsigned st = s_aux[wi];
+        const int before = s_rowbase[x] + (int)s_wpre[wi] - 1;
+#pragma unroll
+        for (int j = 0; j < 4; j++)
+          if ((bits >> j) & 1u) lab[j] = (int)s_parent[before + __popc(st & ((2u << (sh + j)) - 1u))];
+      }
+      int* dst = grid + x * G + y0;
+      if (pairs && y0 + 4 <= G) {
+        reinterpret_cast<int2*>(dst)[0] = make_int2(lab[0], lab[1]);
+        reinterpret_cast<int2*>(dst)[1] = make_int2(lab[2], lab[3]);
+      } else {
+#pragma unroll
+        for (int j = 0; j < 4; j++) if (y0 + j < G) dst[j] = lab[j];
+      }
+    }
+  }
+  CCL_T(9);
 #undef RUN_ORDINAL
 }
 

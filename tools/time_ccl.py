@@ -1,0 +1,27 @@
+"""phase clocks of ccl_kernel (experiment build with -DMOT_DBG_CCL_TIMING)"""
+import importlib.util, os, sys, ctypes
+import numpy as np
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+def _load(name, path):
+    spec = importlib.util.spec_from_file_location(name, path, submodule_search_locations=[os.path.dirname(path)])
+    m = importlib.util.module_from_spec(spec); sys.modules[name] = m; spec.loader.exec_module(m); return m
+import torch
+torch.cuda.init()
+PKG = os.path.join(ROOT, "3d-lidar-multi-object-tracking_amd")
+mot = _load("mot_amd", os.path.join(PKG, "__init__.py")); synth = _load("mot_amd.synth", os.path.join(PKG, "synth.py")); build = _load("mot_amd.build", os.path.join(PKG, "build.py"))
+B, N = 128, 120000
+stride = ((N + 2047) // 2048) * 2048
+host = np.zeros((B, stride, 4), np.float32)
+base = [synth.make_cloud(N, s, 0) for s in range(8)]
+for b in range(B): host[b, :N] = base[b % 8]
+dev = torch.from_numpy(host).cuda(); torch.cuda.synchronize()
+lib = build.build(extra_flags=["-DMOT_DBG_CCL_TIMING"], out=os.path.join(ROOT, "gpurun_out", "libmot_cclt.so"))
+ctx = mot.Context(max_points=stride, max_batch=B, lib_path=lib)
+ctx.frames_dev(dev.data_ptr(), stride * 4, [N] * B); ctx.synchronize()
+print("ccl ms", ctx.time_stage(21, B, 3))
+names = ["planes read+clear", "dilation", "run starts", "row scan", "parent init", "unions", "flatten", "root bits", "root scan", "label grid"]
+for slot in (0, 5, 77):
+    buf = np.zeros(10, np.int32)
+    ctx.lib.mot_debug_copy(ctx._h, 3, slot, buf.ctypes.data_as(ctypes.c_void_p), ctypes.c_size_t(buf.nbytes))
+    d = np.diff(np.concatenate([[0], buf]))
+    print(slot, {n: int(v) for n, v in zip(names, d)}, "total", int(buf[9]))
