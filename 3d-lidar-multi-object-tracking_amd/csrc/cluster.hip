@@ -192,14 +192,16 @@ ccl_kernel(MotDevParams p, ClusterBuffers c) {
   // after the scan s_rowbase[x+1] = number of runs in rows 0..x, i.e. base of row x is s_rowbase[x]
   const int R = s_rowbase[MOT_MAX_GRID];
   for (int r = tid; r < R; r += kCclBlock) s_parent[r] = (unsigned)r;
+  // per (row, word): run starts of the row before the word. With the row bases this gives the ordinal of the run that
+  // contains ANY set cell y by popcounts alone: rowbase[x] + wpre[x][y / 32] + popc(starts[x][y / 32] & bits <= y) - 1
+  for (int i = tid; i < kPlaneWords; i += kCclBlock) {
+    const int x = i >> 3, w = i & 7;
+    int wpre = 0;
+    for (int w2 = 0; w2 < w; w2++) wpre += __popc(s_aux[x * kRowWords + w2]);
+    s_wpre[i] = (unsigned char)wpre;   // <= 128 runs per row
+  }
   __syncthreads();
   CCL_T(4);
-
-  // ordinal of the run that starts at bit s of row x
-#define RUN_ORDINAL(x, s)                                                                              \
-  ({ int ord_ = s_rowbase[(x)]; const unsigned* st_ = &s_aux[(x) * kRowWords];                          \
-     for (int w_ = 0; w_ < ((s) >> 5); w_++) ord_ += __popc(st_[w_]);                                   \
-     ord_ + __popc(st_[(s) >> 5] & ((1u << ((s) & 31)) - 1u)); })
 
   // union every run with the runs of the previous row it touches (8-connectivity: columns s-1 .. e+1)
   for (int i = tid; i < kPlaneWords; i += kCclBlock) {
@@ -208,10 +210,8 @@ ccl_kernel(MotDevParams p, ClusterBuffers c) {
     if (x == 0 || x >= G) st = 0u;
     const unsigned* row = &s_occ[x * kRowWords];
     const unsigned* up = &s_occ[(x > 0 ? x - 1 : 0) * kRowWords];
-    int wpre = 0;   // run starts of this row in the words before this one
-    for (int w2 = 0; w2 < w; w2++) wpre += __popc(s_aux[x * kRowWords + w2]);
-    s_wpre[i] = (unsigned char)wpre;   // <= 128 runs per row
-    int ord = s_rowbase[x] + wpre;
+    int ord = s_rowbase[x] + (int)s_wpre[i];
+    const int upbase = s_rowbase[x > 0 ? x - 1 : 0] - 1, upw = (x > 0 ? x - 1 : 0) * kRowWords;
     while (st) {
       int bit = __ffs(st) - 1;
       st &= st - 1u;
@@ -221,8 +221,7 @@ ccl_kernel(MotDevParams p, ClusterBuffers c) {
       unsigned a = (unsigned)ord++;
       int q = row_next_set(up, lo);
       while (q <= hi) {
-        int s2 = row_run_start(up, q);
-        unsigned bb = (unsigned)RUN_ORDINAL(x - 1, s2);
+        const unsigned bb = (unsigned)(upbase + (int)s_wpre[upw + (q >> 5)] + __popc(s_aux[upw + (q >> 5)] & ((2u << (q & 31)) - 1u)));
         // lock-free union, hook the larger root under the smaller one
         unsigned ra = a, rb = bb;
         while (s_parent[ra] != ra) ra = s_parent[ra];
@@ -311,7 +310,6 @@ ccl_kernel(MotDevParams p, ClusterBuffers c) {
     }
   }
   CCL_T(9);
-#undef RUN_ORDINAL
 }
 
 // ------------------------------------------------------------------------------------------ host
