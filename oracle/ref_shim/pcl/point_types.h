@@ -32,6 +32,13 @@ struct alignas(16) PointXYZ {
 
 struct PointXY { float x, y; };
 
+// used by OT0/src/component_clustering.cpp:73-100 (makeClusteredCloud colours the clustered points)
+struct alignas(16) PointXYZRGB {
+  float x, y, z, _pad;
+  uint8_t b, g, r, a;
+  PointXYZRGB() : x(0.f), y(0.f), z(0.f), _pad(1.f), b(0), g(0), r(0), a(255) {}
+};
+
 template <typename PointT>
 class PointCloud {
  public:

@@ -36,6 +36,16 @@ def frame_fixture(n, stream, frame):
                 grid=cl["grid"].astype(np.int16), num_cluster=cl["num_cluster"], boxes=bx["boxes"])
 
 
+def frame0_fixture(n, stream, frame):
+    """one frame through the SECOND package's own sources (object_tracking0: KITTI constants, oracle/_ref/libmot_ref0.so)"""
+    c = np.concatenate([S.make_cloud(n, stream, frame), S.edge_case_points()])
+    r = O.ref0_frame(c)
+    return dict(cloud=c, n_elevated=len(r["elevated"]), n_ground=len(r["ground"]), elevated_head=r["elevated"][:64, :3],
+                ground_head=r["ground"][:64, :3], elevated_xyz_sum=r["elevated"][:, :3].astype(np.float64).sum(0),
+                ground_xyz_sum=r["ground"][:, :3].astype(np.float64).sum(0), grid=r["grid"].astype(np.int16),
+                num_cluster=r["num_cluster"], boxes=r["boxes"])
+
+
 def side_fixture(n, stream, frame):
     """cluster-node side products (makeClusteredCloud / setObsMsg / createCostMap) of one small frame"""
     elev = np.concatenate([O.ref_ground_remove(S.make_cloud(n, stream, frame))["elevated"], S.edge_case_points()])
@@ -82,6 +92,8 @@ if __name__ == "__main__":
     fx = frame_fixture(24000, 5, 2)
     np.savez_compressed(os.path.join(HERE, "frame_ot_24k.npz"), **fx)
     np.savez_compressed(os.path.join(HERE, "side_ot_9k.npz"), **side_fixture(9000, 3, 0))
+    assert O.ref0() is not None, "oracle/_ref/libmot_ref0.so is not built"
+    np.savez_compressed(os.path.join(HERE, "frame_ot0_60k.npz"), **frame0_fixture(60000, 4, 1))
     for unit, name in ((1e5, "us"), (0.1, "sec")):
         np.savez_compressed(os.path.join(HERE, f"tracker_ot_{name}.npz"), **tracker_fixture(1, 30, 40000, unit))
     for f in sorted(os.listdir(HERE)):

@@ -289,6 +289,37 @@ def ref_cell_index(x, y):
     return ch.value, b.value
 
 
+REF0_SO = os.path.join(ORACLE_DIR, "_ref", "libmot_ref0.so")
+_ref0 = None
+
+
+def ref0():
+    """the reference's second package (object_tracking0: KITTI constants) built from its own sources, or None"""
+    global _ref0
+    if _ref0 is None:
+        if not os.path.exists(REF0_SO):
+            if os.path.exists("/root/reference/object_tracking0/src/ground_removal.cpp"):
+                build_oracle()
+            if not os.path.exists(REF0_SO):
+                return None
+        _ref0 = C.CDLL(REF0_SO)
+    return _ref0
+
+
+def ref0_frame(cloud, max_boxes=4096):
+    """ground removal -> clustering -> box fit through OT0's own functions"""
+    a = _pts(cloud); n = len(a); L = ref0()
+    e = np.zeros((max(n, 1), 4), np.float32); g = np.zeros((max(n, 1), 4), np.float32); ne = C.c_int(0); ng = C.c_int(0)
+    L.ref0_ground_remove(a.ctypes.data_as(C.c_void_p), n, e.ctypes.data_as(C.c_void_p), C.byref(ne), g.ctypes.data_as(C.c_void_p), C.byref(ng))
+    elev = e[: ne.value].copy()
+    G = L.ref0_num_grid()
+    grid = np.zeros((G, G), np.int32); nc = C.c_int(0)
+    L.ref0_cluster(elev.ctypes.data_as(C.c_void_p), len(elev), grid.ctypes.data_as(C.c_void_p), C.byref(nc))
+    boxes = np.zeros((max_boxes, 8, 3), np.float32); nb = C.c_int(0)
+    L.ref0_box_fit(elev.ctypes.data_as(C.c_void_p), len(elev), grid.ctypes.data_as(C.c_void_p), nc.value, boxes.ctypes.data_as(C.c_void_p), max_boxes, C.byref(nb))
+    return dict(elevated=elev, ground=g[: ng.value].copy(), grid=grid, num_cluster=nc.value, boxes=boxes[: nb.value].copy())
+
+
 def ref_cluster(elev):
     a = _pts(elev); G = ref().ref_num_grid()
     grid = np.zeros((G, G), np.int32); nc = C.c_int(0)

@@ -159,6 +159,17 @@ def test_golden_frames(ctx, name):
     G.check_frame(fx, g, cl, bx["boxes"])
 
 
+@pytest.mark.parametrize("name", G.FRAMES_OT0)
+def test_golden_frames_ot0(mot, hip_lib, name):
+    """the KITTI-tuned preset against the fixture produced by object_tracking0's own sources"""
+    fx = G.load(name)
+    with mot.Context(mot.params(1), max_points=65536) as c:
+        g = c.ground_remove(fx["cloud"])
+        cl = c.cluster(g["elevated"])
+        bx = c.box_fit(g["elevated"], cl["grid"], cl["num_cluster"])
+        G.check_frame(fx, g, cl, bx["boxes"])
+
+
 def test_fused_frames_dev(ctx, oracle, synth):
     """ground -> cluster -> box for 8 frames in one launch sequence, everything resident in HBM"""
     import hiprt

@@ -31,6 +31,17 @@ def test_emu_cluster_box_pipeline(mot, emu_lib, oracle, synth):
             assert np.array_equal(b["boxes"], ob["boxes"]) and np.array_equal(b["box_cluster"], ob["box_cluster"])
 
 
+def test_emu_golden_frame_ot0(mot, emu_lib):
+    """the KITTI-tuned preset end to end under the emulator against the fixture from object_tracking0's own sources"""
+    import golden_util as G
+    fx = G.load(G.FRAMES_OT0[0])
+    with mot.Context(mot.params(1, lib=mot.load_library(emu_lib)), lib_path=emu_lib, max_points=65536) as c:
+        g = c.ground_remove(fx["cloud"])
+        cl = c.cluster(g["elevated"])
+        bx = c.box_fit(g["elevated"], cl["grid"], cl["num_cluster"])
+        G.check_frame(fx, g, cl, bx["boxes"])
+
+
 def test_emu_side_products(mot, emu_lib, oracle, synth):
     """makeClusteredCloud / setObsMsg / createCostMap kernel under the emulator against the restatement"""
     p = oracle.params(0)

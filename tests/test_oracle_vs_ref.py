@@ -17,6 +17,17 @@ def test_restatement_matches_golden_frames(oracle, name):
     G.check_frame(fx, g, cl, bx["boxes"], polar=g)
 
 
+@pytest.mark.parametrize("name", G.FRAMES_OT0)
+def test_restatement_matches_golden_frames_ot0(oracle, name):
+    """preset 1 against the fixture generated from object_tracking0's own sources"""
+    fx = G.load(name)
+    p = oracle.params(1)
+    g = oracle.ground_remove(p, fx["cloud"])
+    cl = oracle.cluster(p, g["elevated"])
+    bx = oracle.box_fit(p, g["elevated"], cl["grid"], cl["num_cluster"])
+    G.check_frame(fx, g, cl, bx["boxes"])
+
+
 @pytest.mark.parametrize("name", G.TRACKERS)
 def test_restatement_matches_golden_tracker(oracle, name):
     fx = G.load(name)
@@ -66,6 +77,23 @@ def test_side_products_vs_ref(oracle, synth, stream, frame, n):
     assert len(r["clustered"]) > 100 and len(r["obstacles"]) > 10 and r["cost_map"].max() == 100
     for k in ("clustered", "obstacles", "cost_map"):
         assert r[k].shape == o[k].shape and np.array_equal(r[k], o[k]), k
+
+
+@pytest.mark.parametrize("stream,frame,n", [(0, 0, 120000), (1, 3, 60000), (5, 2, 24000), (4, 0, 200000)])
+def test_preset_ot0_vs_ref0(oracle, synth, stream, frame, n):
+    """preset 1 (the KITTI-tuned constants and rules of object_tracking0) against that package's own sources"""
+    if oracle.ref0() is None:
+        pytest.skip("oracle/_ref/libmot_ref0.so not built on this box")
+    p = oracle.params(1)
+    cloud = np.concatenate([synth.make_cloud(n, stream, frame), synth.edge_case_points()])
+    r = oracle.ref0_frame(cloud)
+    g = oracle.ground_remove(p, cloud)
+    assert np.array_equal(g["elevated"][:, :3], r["elevated"][:, :3]) and np.array_equal(g["ground"][:, :3], r["ground"][:, :3])
+    cl = oracle.cluster(p, g["elevated"])
+    assert cl["num_cluster"] == r["num_cluster"] and np.array_equal(cl["grid"], r["grid"])
+    bx = oracle.box_fit(p, g["elevated"], cl["grid"], cl["num_cluster"])
+    assert bx["boxes"].shape == r["boxes"].shape and np.array_equal(bx["boxes"], r["boxes"])
+    assert r["num_cluster"] > 3
 
 
 def test_side_products_golden(oracle):
