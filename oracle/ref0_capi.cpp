@@ -1,8 +1,10 @@
 // TEST INFRASTRUCTURE ONLY — flat C API around the UNMODIFIED sources of the reference's second package
 // (/root/reference/object_tracking0/src/{ground_removal,gaus_blur,component_clustering,box_fitting}.cpp: the KITTI-tuned
 // constants, the "any point" occupancy rule without dilation, the L-shape condition without the side test), compiled by
-// oracle/Makefile from where they lie against oracle/ref_shim. Output: oracle/_ref/libmot_ref0.so. Pins preset 1
-// (MOT_PRESET_OBJECT_TRACKING0) of the restatement: tests/test_oracle_vs_ref.py::test_preset_ot0_vs_ref0.
+// oracle/Makefile from where they lie against oracle/ref_shim, plus that package's tracker (ukf.cpp, imm_ukf_jpda.cpp:
+// distanceThres_ 0.25, lifeTimeThres_ 8, first-yaw offset 1.22191 - pi/2, ego motion read from two text files relative
+// to the working directory). Output: oracle/_ref/libmot_ref0.so. Pins preset 1 (MOT_PRESET_OBJECT_TRACKING0) of the
+// restatement: tests/test_oracle_vs_ref.py::test_preset_ot0_vs_ref0, ::test_tracker_ot0_vs_ref0.
 #include <cstdint>
 #include <cstring>
 #include <sstream>
@@ -14,9 +16,28 @@
 #include "gaus_blur.h"
 #include "component_clustering.h"
 #include "box_fitting.h"
+#include "ukf.h"
+#include "imm_ukf_jpda.h"
+
+#include <cstdio>
+#include <fstream>
+#include <string>
+#include <sys/stat.h>
+#include <unistd.h>
 
 using namespace std;
 using namespace pcl;
+
+// externally-linked internals of OT0/src/imm_ukf_jpda.cpp:19-62 (none are static)
+extern bool init_;
+extern double timestamp_, egoVelo_, egoYaw_, egoPreYaw_;
+extern int countIt;
+extern vector<UKF> targets_;
+extern vector<int> trackNumVec_;
+extern vector<vector<double>> egoPoints_, egoDeltaHis_;
+extern vector<double> egoDiffYaw_;
+extern ifstream inFile_, yawFile_;
+#include "ref_track_common.h"
 
 namespace {
 struct Quiet {
@@ -73,6 +94,48 @@ int ref0_box_fit(const float* elev, int n, const int32_t* grid, int num_cluster,
   for (int b = 0; b < (int)bb.size() && b < max_boxes; b++)
     for (int k = 0; k < 8; k++) { boxes[(b * 8 + k) * 3] = bb[b][k].x; boxes[(b * 8 + k) * 3 + 1] = bb[b][k].y; boxes[(b * 8 + k) * 3 + 2] = bb[b][k].z; }
   return 0;
+}
+
+// ---- tracker ----
+// OT0's getOriginPoints() opens ./src/object_tracking/src/ego_{velo,yaw}.txt on its first call and reads one number from
+// each per frame (OT0/src/imm_ukf_jpda.cpp:65-72). The wrapper writes the caller's per-frame values (17 significant digits:
+// the text round trip is exact) under `workdir` and makes it the working directory; the reference closes both files at frame
+// 154 (:756), so n must stay below that.
+int ref0_tracker_reset(const char* workdir, const double* velo, const double* yaw, int n) {
+  inFile_.close(); inFile_.clear(); yawFile_.close(); yawFile_.clear();
+  init_ = false; timestamp_ = 0; egoVelo_ = 0; egoYaw_ = 0; egoPreYaw_ = 0; countIt = 0;
+  targets_.clear(); trackNumVec_.clear(); egoPoints_.clear(); egoDeltaHis_.clear(); egoDiffYaw_.clear();
+  if (n >= 154) return 2;
+  string d(workdir);
+  const char* parts[] = {"/src", "/object_tracking", "/src"};
+  for (auto p : parts) { d += p; mkdir(d.c_str(), 0755); }
+  const double* vals[2] = {velo, yaw};
+  const char* names[2] = {"/ego_velo.txt", "/ego_yaw.txt"};
+  for (int k = 0; k < 2; k++) {
+    FILE* f = fopen((d + names[k]).c_str(), "w");
+    if (!f) return 1;
+    for (int i = 0; i < n; i++) fprintf(f, "%.17g\n", vals[k][i]);
+    fclose(f);
+  }
+  return chdir(workdir) ? 1 : 0;
+}
+// getOriginPoints(timestamp, originPoints), OT0/src/imm_ukf_jpda.cpp:65 (what OT0/src/main.cpp:94 calls)
+int ref0_ego_update(double timestamp, double* origin6) {
+  vector<vector<double>> o;
+  getOriginPoints(timestamp, o);
+  for (int i = 0; i < 2 && i < (int)o.size(); i++) for (int k = 0; k < 3; k++) origin6[3 * i + k] = o[i][k];
+  return 0;
+}
+// immUkfJpdaf(), OT0/src/imm_ukf_jpda.cpp:664 (OT0/src/main.cpp:121)
+int ref0_track_step(const float* boxes, int m, double timestamp, int max_tracks, float* target_xyz, double* v_yaw,
+                    int* track_manage, int* is_static, int* is_vis, float* vis_bb, int* n_tracks) {
+  Quiet q;
+  return trk_step(boxes, m, timestamp, max_tracks, target_xyz, v_yaw, track_manage, is_static, is_vis, vis_bb, n_tracks);
+}
+int ref0_track_count() { return (int)targets_.size(); }
+int ref0_track_get_state(int id, double* x4x5, double* p4x25, double* mode3, double* zpred6, double* s12, double* k30,
+                         double* misc4, int* ints5, float* bbox24, float* best24) {
+  return trk_get_state(id, x4x5, p4x25, mode3, zpred6, s12, k30, misc4, ints5, bbox24, best24);
 }
 
 }  // extern "C"

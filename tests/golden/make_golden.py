@@ -54,9 +54,14 @@ def side_fixture(n, stream, frame):
     return dict(elevated=elev, grid=cl["grid"].astype(np.int16), clustered=r["clustered"], obstacles=r["obstacles"], cost_map=r["cost_map"])
 
 
-def tracker_fixture(stream, nframes, npts, unit):
-    R = O.RefTracker(); R.reset()
-    p = O.params(0)
+def tracker_fixture(stream, nframes, npts, unit, ot0_workdir=None):
+    """ot0_workdir: run object_tracking0's tracker instead (KITTI constants; it reads the ego motion from text files that
+    Ref0Tracker writes under that directory); the boxes still come from the first package's chain (more of them)."""
+    vs, yaws = 2.0 + 0.05 * np.arange(nframes), 0.004 * np.arange(nframes)
+    if ot0_workdir is None:
+        R = O.RefTracker(); R.reset()
+    else:
+        R = O.Ref0Tracker(); R.reset(ot0_workdir, vs, yaws)
     boxes, n_boxes, tm, st, vis, pos, vyaw, ego = [], [], [], [], [], [], [], []
     states = []
     for f in range(nframes):
@@ -64,8 +69,7 @@ def tracker_fixture(stream, nframes, npts, unit):
         g = O.ref_ground_remove(c); cl = O.ref_cluster(g["elevated"]); bx = O.ref_box_fit(g["elevated"], cl["grid"], cl["num_cluster"])
         b = bx["boxes"]
         ts = 1.0e9 + f * unit
-        v, yaw = 2.0 + 0.05 * f, 0.004 * f
-        ego.append(R.ego_update(ts, v, yaw))
+        ego.append(R.ego_update(ts, vs[f], yaws[f]) if ot0_workdir is None else R.ego_update(ts))
         r = R.step(b, ts)
         pad = np.zeros((32, 8, 3), np.float32); pad[: len(b)] = b
         boxes.append(pad); n_boxes.append(len(b))
@@ -78,6 +82,8 @@ def tracker_fixture(stream, nframes, npts, unit):
         for i in range(r["n"]):
             s = R.state(i); xs[i] = s["x_merge"]; ps[i] = s["p_merge"]; mp[i] = s["mode_prob"]; lt[i] = s["lifetime"]
         states.append((xs, ps, mp, lt, r["n"]))
+    if ot0_workdir is not None:
+        R.close()
     return dict(boxes=np.stack(boxes), n_boxes=np.array(n_boxes, np.int32), track_manage=np.stack(tm), is_static=np.stack(st),
                 is_vis=np.stack(vis), pos=np.stack(pos), v_yaw=np.stack(vyaw), ego=np.stack(ego),
                 x_merge=np.stack([s[0] for s in states]), p_merge=np.stack([s[1] for s in states]),
@@ -96,6 +102,9 @@ if __name__ == "__main__":
     np.savez_compressed(os.path.join(HERE, "frame_ot0_60k.npz"), **frame0_fixture(60000, 4, 1))
     for unit, name in ((1e5, "us"), (0.1, "sec")):
         np.savez_compressed(os.path.join(HERE, f"tracker_ot_{name}.npz"), **tracker_fixture(1, 30, 40000, unit))
+    import tempfile
+    with tempfile.TemporaryDirectory() as d:
+        np.savez_compressed(os.path.join(HERE, "tracker_ot0_us.npz"), **tracker_fixture(3, 30, 40000, 1e5, ot0_workdir=d))
     for f in sorted(os.listdir(HERE)):
         if f.endswith(".npz"):
             print(f, os.path.getsize(os.path.join(HERE, f)))

@@ -7,6 +7,7 @@ GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 FRAMES = ("frame_ot_9k.npz", "frame_ot_24k.npz")
 FRAMES_OT0 = ("frame_ot0_60k.npz",)   # the KITTI-tuned package (preset 1)
 TRACKERS = ("tracker_ot_us.npz", "tracker_ot_sec.npz")
+TRACKERS_OT0 = ("tracker_ot0_us.npz",)   # object_tracking0's tracker (preset 1)
 
 
 def load(name):

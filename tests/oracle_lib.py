@@ -347,6 +347,10 @@ def ref_cluster_products(elev, grid):
 
 class RefTracker:
     """the reference tracker: file-scope globals => one instance at a time"""
+    _pre = "ref_"
+
+    def _lib(self):
+        return ref()
 
     def reset(self):
         ref().ref_tracker_reset()
@@ -358,7 +362,7 @@ class RefTracker:
         b = np.ascontiguousarray(boxes, np.float32).reshape(-1, 8, 3)
         xyz = np.zeros((max_tracks, 3), np.float32); vy = np.zeros((max_tracks, 2)); tm = np.zeros(max_tracks, np.int32)
         st = np.zeros(max_tracks, np.int32); vis = np.zeros(max_tracks, np.int32); vbb = np.zeros((max_tracks, 24), np.float32); nt = C.c_int(0)
-        ref().ref_track_step(b.ctypes.data_as(C.c_void_p), len(b), C.c_double(ts), max_tracks, xyz.ctypes.data_as(C.c_void_p),
+        getattr(self._lib(), self._pre + "track_step")(b.ctypes.data_as(C.c_void_p), len(b), C.c_double(ts), max_tracks, xyz.ctypes.data_as(C.c_void_p),
                              vy.ctypes.data_as(C.c_void_p), tm.ctypes.data_as(C.c_void_p), st.ctypes.data_as(C.c_void_p),
                              vis.ctypes.data_as(C.c_void_p), vbb.ctypes.data_as(C.c_void_p), C.byref(nt))
         n = nt.value
@@ -366,14 +370,37 @@ class RefTracker:
                     v_yaw=vy[:n].copy(), vis_box=vbb[:n].copy())
 
     def count(self):
-        return ref().ref_track_count()
+        return getattr(self._lib(), self._pre + "track_count")()
 
     def state(self, i):
         x = np.zeros(20); p = np.zeros(100); mode = np.zeros(3); z = np.zeros(6); s = np.zeros(12); k = np.zeros(30); misc = np.zeros(4)
         ints = np.zeros(5, np.int32); bb = np.zeros(24, np.float32); best = np.zeros(24, np.float32)
-        rc = ref().ref_track_get_state(i, *[a.ctypes.data_as(C.c_void_p) for a in (x, p, mode, z, s, k, misc, ints, bb, best)])
+        rc = getattr(self._lib(), self._pre + "track_get_state")(i, *[a.ctypes.data_as(C.c_void_p) for a in (x, p, mode, z, s, k, misc, ints, bb, best)])
         assert rc == 0
         return dict(x_merge=x[0:5], x_cv=x[5:10], x_ctrv=x[10:15], x_rm=x[15:20], p_merge=p[0:25], p_cv=p[25:50], p_ctrv=p[50:75],
                     p_rm=p[75:100], mode_prob=mode, z_pred=z, s=s, k=k, init_meas=misc[0:2], dist_from_init=misc[2], best_yaw=misc[3],
                     lifetime=int(ints[0]), track_manage=int(ints[1]), is_static=int(ints[2]), is_vis=int(ints[3]),
                     has_best_box=int(ints[4]), bbox=bb, best_bbox=best)
+
+
+class Ref0Tracker(RefTracker):
+    """object_tracking0's tracker (oracle/_ref/libmot_ref0.so). It reads the ego speed / yaw of every frame from two text
+    files relative to the working directory: reset() takes the whole sequence, writes them under `workdir` and chdirs
+    there (restored by close())."""
+    _pre = "ref0_"
+
+    def _lib(self):
+        return ref0()
+
+    def reset(self, workdir, velo, yaw):
+        v = np.ascontiguousarray(velo, np.float64); y = np.ascontiguousarray(yaw, np.float64)
+        assert len(v) == len(y)
+        self._cwd = os.getcwd()
+        rc = ref0().ref0_tracker_reset(str(workdir).encode(), v.ctypes.data_as(C.c_void_p), y.ctypes.data_as(C.c_void_p), len(v))
+        assert rc == 0, rc
+
+    def close(self):
+        os.chdir(self._cwd)
+
+    def ego_update(self, ts):
+        out = np.zeros(6); ref0().ref0_ego_update(C.c_double(ts), out.ctypes.data_as(C.c_void_p)); return out

@@ -11,13 +11,14 @@ import golden_util as G
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "emu"))
 
 
-@pytest.mark.parametrize("name", G.TRACKERS)
+@pytest.mark.parametrize("name", G.TRACKERS + G.TRACKERS_OT0)
 def test_emu_tracker_golden(mot, name):
     import build_emu
     lib = build_emu.build()
     fx = G.load(name)
-    with mot.Context(lib_path=lib, max_points=4096, max_tracks_total=256) as c:
-        for f in range(14):
+    ot0 = name in G.TRACKERS_OT0   # object_tracking0's tracker: preset 1; boxes are only shown after lifetime 8
+    with mot.Context(mot.params(int(ot0), lib=mot.load_library(lib)), lib_path=lib, max_points=4096, max_tracks_total=256) as c:
+        for f in range(18 if ot0 else 14):
             ts = 1.0e9 + f * float(fx["unit"])
             ego = c.ego_update(ts, 2.0 + 0.05 * f, 0.004 * f)
             assert np.allclose(ego, fx["ego"][f], rtol=1e-12, atol=1e-12)

@@ -28,10 +28,10 @@ def test_restatement_matches_golden_frames_ot0(oracle, name):
     G.check_frame(fx, g, cl, bx["boxes"])
 
 
-@pytest.mark.parametrize("name", G.TRACKERS)
+@pytest.mark.parametrize("name", G.TRACKERS + G.TRACKERS_OT0)
 def test_restatement_matches_golden_tracker(oracle, name):
     fx = G.load(name)
-    T = oracle.Tracker(oracle.params(0))
+    T = oracle.Tracker(oracle.params(int(name in G.TRACKERS_OT0)))
     for f in range(len(fx["n_boxes"])):
         ts = 1.0e9 + f * float(fx["unit"])
         ego = T.ego_update(ts, 2.0 + 0.05 * f, 0.004 * f)
@@ -158,6 +158,39 @@ def test_restatement_vs_ref_tracker(oracle, synth, unit):
                 scale = max(np.abs(sr[k]).max(), 1e-300)
                 assert np.abs(sa[k] - sr[k]).max() <= 1e-7 * scale + 1e-12, (f, i, k)
     T.close()
+
+
+def test_tracker_ot0_vs_ref0(oracle, synth, tmp_path):
+    """preset 1 of the restated tracker (distanceThres_ 0.25, lifeTimeThres_ 8, first-yaw offset 1.22191 - pi/2) against
+    object_tracking0's own ukf.cpp / imm_ukf_jpda.cpp, which read the ego motion from text files"""
+    _need_ref(oracle)
+    p0, p1 = oracle.params(0), oracle.params(1)
+    nf = 40
+    velo = 4.0 + 0.05 * np.arange(nf); yaw = 1.22191 - 0.012 * np.arange(nf)
+    T = oracle.Tracker(p1); R = oracle.Ref0Tracker(); R.reset(tmp_path, velo, yaw)
+    try:
+        seen = 0
+        for f in range(nf):
+            c = synth.make_cloud(40000, 2, f)
+            g = oracle.ground_remove(p0, c); cl = oracle.cluster(p0, g["elevated"]); b = oracle.box_fit(p0, g["elevated"], cl["grid"], cl["num_cluster"])["boxes"]
+            ts = 5.0e8 + f * 1e5
+            assert np.allclose(T.ego_update(ts, velo[f], yaw[f]), R.ego_update(ts), rtol=1e-12, atol=1e-12)
+            a = T.step(b, ts); r = R.step(b, ts)
+            assert a["n"] == r["n"] and np.array_equal(a["track_manage"], r["track_manage"])
+            assert np.array_equal(a["is_static"], r["is_static"]) and np.array_equal(a["is_vis"], r["is_vis"])
+            assert np.array_equal(a["vis_box"], r["vis_box"])
+            seen = max(seen, int(a["is_vis"].sum()))
+            for i in range(a["n"]):
+                if r["track_manage"][i] == 0:
+                    continue
+                sa, sr = T.state(i), R.state(i)
+                assert sa["lifetime"] == sr["lifetime"]
+                for k in ("x_merge", "x_cv", "x_ctrv", "x_rm", "p_merge", "p_cv", "p_ctrv", "p_rm", "mode_prob", "z_pred", "s", "k"):
+                    scale = max(np.abs(sr[k]).max(), 1e-300)
+                    assert np.abs(sa[k] - sr[k]).max() <= 1e-7 * scale + 1e-12, (f, i, k)
+        assert seen > 0   # the lifetime-8 / 0.25 m association path was exercised
+    finally:
+        R.close(); T.close()
 
 
 def test_min_area_rect_properties(oracle):

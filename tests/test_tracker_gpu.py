@@ -29,6 +29,19 @@ def test_golden_tracker_sequences(ctx, name):
         G.check_tracker_frame(fx, f, out, lambda i: ctx.track_state(i), rtol=RTOL)
 
 
+@pytest.mark.parametrize("name", G.TRACKERS_OT0)
+def test_golden_tracker_sequences_ot0(mot, hip_lib, name):
+    """object_tracking0's tracker (its own ukf.cpp / imm_ukf_jpda.cpp built into oracle/_ref/libmot_ref0.so): preset 1"""
+    fx = G.load(name)
+    with mot.Context(mot.params(1), max_points=4096, max_tracks_total=512) as c:
+        for f in range(len(fx["n_boxes"])):
+            ts = 1.0e9 + f * float(fx["unit"])
+            ego = c.ego_update(ts, 2.0 + 0.05 * f, 0.004 * f)
+            assert np.allclose(ego, fx["ego"][f], rtol=1e-12, atol=1e-12)
+            out = c.track_step(fx["boxes"][f][: fx["n_boxes"][f]], ts)
+            G.check_tracker_frame(fx, f, out, lambda i: c.track_state(i), rtol=RTOL)
+
+
 def _boxes_sequence(oracle, synth, p, stream, nframes, npts):
     seq = []
     for f in range(nframes):
