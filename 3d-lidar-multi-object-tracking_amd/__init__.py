@@ -71,6 +71,7 @@ EXPORTS = (
     "mot_synchronize", "mot_stream", "mot_ground_remove", "mot_cluster", "mot_box_fit", "mot_ego_update",
     "mot_track_step", "mot_track_get_state", "mot_frames_dev", "mot_get_ground", "mot_get_clusters",
     "mot_get_boxes", "mot_get_tracks", "mot_export_tracks_dev", "mot_side_params_default", "mot_cluster_products", "mot_cluster_products_host", "mot_decode_pointcloud2_dev", "mot_time_stage",
+    "mot_ground_remove_pointcloud2", "mot_box_fit_resident",
 )
 
 _libs: dict[str, C.CDLL] = {}
@@ -108,7 +109,7 @@ class MotSideParams(C.Structure):
     """mirror of struct mot_side_params (include/mot.h)"""
     _fields_ = [("cell_size", C.c_float), ("cost_width", C.c_int32), ("cost_height", C.c_int32), ("cost_resolution", C.c_double),
                 ("cost_offset_x", C.c_double), ("cost_offset_y", C.c_double), ("height_limit", C.c_double),
-                ("car_length", C.c_double), ("car_width", C.c_double)]
+                ("car_length", C.c_double), ("car_width", C.c_double), ("cost_offset_z", C.c_double)]
 
 
 def _pts(a) -> np.ndarray:
@@ -176,6 +177,26 @@ class Context:
         if want_mask:
             out["mask"] = mask[:n].copy()
         return out
+
+    def ground_remove_pointcloud2(self, payload, n: int, point_step: int, off_x: int, off_y: int, off_z: int, want_mask: bool = True):
+        """fromROSMsg + groundRemove on a sensor_msgs/PointCloud2 payload in host memory (one H2D of the raw records)"""
+        raw = np.ascontiguousarray(payload, np.uint8).reshape(-1)
+        assert raw.size >= n * point_step
+        elev = np.empty((max(n, 1), 4), np.float32); ground = np.empty((max(n, 1), 4), np.float32)
+        mask = np.zeros(max(n, 1), np.uint8) if want_mask else None
+        ne, ng = C.c_int(0), C.c_int(0)
+        self._ck(self.lib.mot_ground_remove_pointcloud2(self._h, _vp(raw), n, point_step, off_x, off_y, off_z, _vp(elev), C.byref(ne),
+                                                        _vp(ground), C.byref(ng), _vp(mask)))
+        out = dict(elevated=elev[: ne.value].copy(), ground=ground[: ng.value].copy())
+        if want_mask:
+            out["mask"] = mask[:n].copy()
+        return out
+
+    def box_fit_resident(self, max_boxes: int = 4096):
+        """boxFitting on the cloud and label grid that cluster() left resident in slot 0"""
+        boxes = np.zeros((max_boxes, 8, 3), np.float32); nb = C.c_int(0); bc = np.zeros(max_boxes, np.int32); nu = C.c_int(0)
+        self._ck(self.lib.mot_box_fit_resident(self._h, _vp(boxes), max_boxes, C.byref(nb), _vp(bc), C.byref(nu)))
+        return dict(boxes=boxes[: nb.value].copy(), box_cluster=bc[: nb.value].copy(), n_undefined=nu.value)
 
     def cluster(self, elevated_xyzw):
         """componentClustering(elevatedCloud, cartesianData, numCluster) — OT/include/component_clustering.h:20-22"""

@@ -57,6 +57,9 @@ struct mot_ctx {
   int* d_side_counts = nullptr;
   int2* d_wgtab = nullptr;
   int max_wg = 0;
+  // staging buffer of mot_ground_remove_pointcloud2 (grow-only, allocated on first use)
+  void* d_raw = nullptr;
+  size_t raw_bytes = 0;
   // tracker stage
   DevTrack* d_tracks = nullptr;
   int* d_nt = nullptr;
@@ -182,7 +185,7 @@ static int make_dev_params(const mot_params& p, MotDevParams* d, std::string* er
 extern "C" void mot_destroy(mot_ctx* c) {
   if (!c) return;
   void* bufs[] = {c->d_in, c->d_n, c->d_pairs, c->d_pair_count, c->d_hg, c->d_desc, c->d_ticket, c->d_elev, c->d_ground, c->d_mask, c->d_counts,
-                  c->d_plane_a, c->d_plane_b, c->d_grid, c->d_label, c->d_stats, c->d_cand, c->d_boxes, c->d_box_cluster, c->d_rng, c->d_poly, c->d_groups, c->d_cluster_start, c->d_sorted, c->d_pix, c->d_wgtab, c->d_side_cell, c->d_side_cloud, c->d_side_obs, c->d_side_cost, c->d_side_counts,
+                  c->d_plane_a, c->d_plane_b, c->d_grid, c->d_label, c->d_stats, c->d_cand, c->d_boxes, c->d_box_cluster, c->d_rng, c->d_poly, c->d_groups, c->d_cluster_start, c->d_sorted, c->d_pix, c->d_wgtab, c->d_side_cell, c->d_side_cloud, c->d_side_obs, c->d_side_cost, c->d_side_counts, c->d_raw,
                   c->d_tracks, c->d_nt, c->d_tboxes, c->d_targs, c->d_gate, c->d_prog, c->d_live, c->d_tout, c->d_tflags, c->d_ego, c->d_phase};
   for (void* b : bufs) if (b) (void)hipFree(b);
   if (c->h_counts) (void)hipHostFree(c->h_counts);
@@ -436,7 +439,7 @@ extern "C" int mot_get_boxes(mot_ctx* c, int slot, float* boxes, int max_boxes, 
 }
 
 extern "C" int mot_cluster(mot_ctx* c, const float* elev, int n, int32_t* grid, int* num_cluster, int32_t* point_label) {
-  if (!c || (!elev && n > 0) || n < 0 || !grid || !num_cluster) return MOT_E_ARG;
+  if (!c || (!elev && n > 0) || n < 0 || !num_cluster) return MOT_E_ARG;   // grid may be NULL: nothing but the count is read back
   if (n > c->cap) return fail(c, MOT_E_CAPACITY, "cloud has more points than max_points");
   int rc;
   if (n > 0) MOT_HIP(c, hipMemcpyAsync(c->d_elev, elev, (size_t)n * 16, hipMemcpyHostToDevice, c->stream));
@@ -469,6 +472,20 @@ extern "C" int mot_box_fit(mot_ctx* c, const float* elev, int n, const int32_t* 
   return mot_get_boxes(c, 0, boxes, max_boxes, n_boxes, box_cluster, n_undefined);
 }
 
+// boxFitting on the elevated cloud and label grid resident in slot 0 after mot_cluster (the host-buffer stage calls work on
+// slot 0): no second upload of the cloud and the grid between the two stages of the cluster node
+extern "C" int mot_box_fit_resident(mot_ctx* c, float* boxes, int max_boxes, int* n_boxes, int32_t* box_cluster, int* n_undefined) {
+  if (!c || !n_boxes || max_boxes < 0) return MOT_E_ARG;
+  int rc = fetch_counts(c, 0);
+  if (rc) return rc;
+  const int n = c->h_counts[kCntElev];
+  if (n < 0 || n > c->cap) return fail(c, MOT_E_STATE, "mot_box_fit_resident: no cloud resident in slot 0");
+  if (c->h_counts[kCntClusters] > kMaxClusters) return fail(c, MOT_E_CAPACITY, "more clusters than the library supports (4096)");
+  mot_launch_box(c->dp, cluster_buffers(c), 1, n, c->stream);
+  MOT_HIP(c, hipGetLastError());
+  return mot_get_boxes(c, 0, boxes, max_boxes, n_boxes, box_cluster, n_undefined);
+}
+
 // fromROSMsg for PointXYZ (OT/src/groundremove/main.cpp:100), device to device
 extern "C" int mot_decode_pointcloud2_dev(mot_ctx* c, const void* d_data, int n, int point_step, int off_x, int off_y, int off_z,
                                           int off_w, float* d_xyzw) {
@@ -490,6 +507,7 @@ extern "C" int mot_side_params_default(mot_side_params* o) {
   o->cost_resolution = 1.0; o->cost_width = 50; o->cost_height = 50;   // component_clustering.cpp:15-17
   o->cost_offset_x = 0; o->cost_offset_y = 25;                         // :18-19
   o->height_limit = 0.1; o->car_length = 4.5; o->car_width = 2;        // :22-24
+  o->cost_offset_z = -2;                                               // :20
   return MOT_OK;
 }
 
@@ -568,6 +586,33 @@ extern "C" int mot_ground_remove(mot_ctx* c, const float* xyzw, int n, float* el
   if (!c || (!xyzw && n > 0) || n < 0) return MOT_E_ARG;
   if (n > c->cap) return fail(c, MOT_E_CAPACITY, "frame has more points than max_points");
   if (n > 0) MOT_HIP(c, hipMemcpyAsync(c->d_in, xyzw, (size_t)n * 16, hipMemcpyHostToDevice, c->stream));
+  int rc = set_batch(c, &n, 1, c->d_in, c->cap);
+  if (rc) return rc;
+  if ((rc = next_epoch(c))) return rc;
+  GroundBuffers g = ground_buffers(c, c->d_in, c->cap, true);
+  mot_launch_ground(c->dp, g, 1, n, c->stream);
+  MOT_HIP(c, hipGetLastError());
+  return mot_get_ground(c, 0, elev, n_elev, ground, n_ground, mask);
+}
+
+// fromROSMsg + groundRemove for a message payload in host memory: one H2D of the raw records, unpacked on the device
+extern "C" int mot_ground_remove_pointcloud2(mot_ctx* c, const void* data, int n, int point_step, int off_x, int off_y, int off_z,
+                                             float* elev, int* n_elev, float* ground, int* n_ground, uint8_t* mask) {
+  if (!c || n < 0 || (n > 0 && !data) || point_step < 12) return MOT_E_ARG;
+  if (n > c->cap) return fail(c, MOT_E_CAPACITY, "frame has more points than max_points");
+  const int offs[3] = {off_x, off_y, off_z};
+  for (int k = 0; k < 3; k++)
+    if (offs[k] < 0 || offs[k] + 4 > point_step) return fail(c, MOT_E_ARG, "field offset outside the point record");
+  const size_t bytes = (size_t)n * (size_t)point_step;
+  if (bytes > c->raw_bytes) {
+    if (c->d_raw) { MOT_HIP(c, hipStreamSynchronize(c->stream)); MOT_HIP(c, hipFree(c->d_raw)); c->d_raw = nullptr; c->raw_bytes = 0; }
+    MOT_HIP(c, hipMalloc(&c->d_raw, bytes));
+    c->raw_bytes = bytes;
+  }
+  if (n > 0) {
+    MOT_HIP(c, hipMemcpyAsync(c->d_raw, data, bytes, hipMemcpyHostToDevice, c->stream));
+    mot_launch_decode_pointcloud2(c->d_raw, n, point_step, off_x, off_y, off_z, -1, (float4*)c->d_in, c->stream);
+  }
   int rc = set_batch(c, &n, 1, c->d_in, c->cap);
   if (rc) return rc;
   if ((rc = next_epoch(c))) return rc;

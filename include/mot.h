@@ -168,7 +168,8 @@ int mot_ground_remove(mot_ctx* ctx, const float* xyzw, int n, float* elevated_xy
 /* replaces componentClustering(elevatedCloud, cartesianData, numCluster),
  * OT/include/component_clustering.h:20-22. grid: num_grid x num_grid int32, x-major
  * (grid[x*num_grid+y] == cartesianData[x][y]); labels 1..num_cluster in raster order of first cell.
- * point_label (optional, n int32): label of the cell each point falls in, 0 if none / outside ROI. */
+ * point_label (optional, n int32): label of the cell each point falls in, 0 if none / outside ROI.
+ * grid may be NULL when only the resident result is needed (mot_box_fit_resident, mot_cluster_products). */
 int mot_cluster(mot_ctx* ctx, const float* elevated_xyzw, int n, int32_t* grid, int* num_cluster,
                 int32_t* point_label);
 
@@ -179,6 +180,18 @@ int mot_cluster(mot_ctx* ctx, const float* elevated_xyzw, int n, int32_t* grid, 
  * (uninitialised reads); they are rejected here. */
 int mot_box_fit(mot_ctx* ctx, const float* elevated_xyzw, int n, const int32_t* grid, int num_cluster,
                 float* boxes, int max_boxes, int* n_boxes, int32_t* box_cluster, int* n_undefined);
+
+/* mot_box_fit on the elevated cloud and label grid that mot_cluster left resident (slot 0): the cluster node calls
+ * componentClustering and boxFitting back to back on the same cloud (OT/src/cluster/main.cpp:74,119) — one upload serves both. */
+int mot_box_fit_resident(mot_ctx* ctx, float* boxes, int max_boxes, int* n_boxes, int32_t* box_cluster, int* n_undefined);
+
+/* fromROSMsg(*input, *cloud) + groundRemove (OT/src/groundremove/main.cpp:100,120) for a sensor_msgs/PointCloud2 payload in
+ * HOST memory: data = n_points records of point_step bytes, the FLOAT32 fields x, y, z at the given byte offsets. One H2D
+ * copy of the raw records, unpacked on the device (mot_decode_pointcloud2_dev), then exactly mot_ground_remove; with
+ * params.crop_enable the node's PassThrough / ConditionalRemoval pre-filter runs fused in the first kernel. The 4th float
+ * of every output point is 1.0f — what pcl::PointXYZ's padding holds — so the outputs are toROSMsg payloads as they are. */
+int mot_ground_remove_pointcloud2(mot_ctx* ctx, const void* data, int n_points, int point_step, int off_x, int off_y, int off_z,
+                                  float* elevated_xyzw, int* n_elevated, float* ground_xyzw, int* n_ground, uint8_t* mask);
 
 /* replaces getOriginPoints(timestamp, originPoints, v_gps, yaw_gps), OT/include/imm_ukf_jpda.h:15.
  * origin6 = {x, y, yaw, x, y, yaw + pi/2}. Must be called before mot_track_step of the same frame,
@@ -232,6 +245,7 @@ typedef struct mot_side_params {
   double cost_offset_x, cost_offset_y; /* g_offset_x, g_offset_y 0, 25 */
   double height_limit;             /* HEIGHT_LIMIT 0.1 */
   double car_length, car_width;    /* CAR_LENGTH 4.5, CAR_WIDTH 2 */
+  double cost_offset_z;            /* g_offset_z -2: only the OccupancyGrid origin (setOccupancyGrid, :410-422) uses it */
 } mot_side_params;
 int mot_side_params_default(mot_side_params* out);
 /* every output may be NULL; clustered_xyzw: max_clustered x 4 floats (x, y, z, 0); obstacles_xyzc: max_obstacles x 4 floats

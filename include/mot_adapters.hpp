@@ -11,19 +11,47 @@
 //     before the first call. The reference's tracker state is file-scope globals; here it lives in the context
 //     (mot_reset() forgets it — the reference cannot).
 //   * errors raise std::runtime_error with mot_last_error() instead of assert()/abort().
-//   * boxFitting() does not fill the rviz CUBE markers (`ma`): visualisation is outside the hot path.
+//   * boxFitting() fills the rviz CUBE markers (`ma`, box_fitting.cpp:161-209,404-405) on the host from the per-point
+//     cluster labels the library returns: centroid and extent are sequential float sums in input order, as PCL computes them.
+//   * the header defines `numGrid` (component_clustering.h:15) because OT/src/cluster/main.cpp:73 needs it once the
+//     reference header is gone; define MOT_ADAPTERS_NO_REFERENCE_CONSTANTS to keep it out, MOT_ADAPTERS_NUM_GRID=200 for OT0.
 #ifndef MOT_ADAPTERS_HPP_
 #define MOT_ADAPTERS_HPP_
 
 #include <array>
+#include <cfloat>
 #include <stdexcept>
 #include <string>
+#include <type_traits>
 #include <vector>
 
 #include <pcl/point_cloud.h>
 #include <pcl/point_types.h>
 
+// the ROS message headers the reference's algorithm headers pull in for the node sources (component_clustering.h:7-9,
+// box_fitting.h:8-9); only when they exist, so the header also serves ROS-free callers
+#if defined(__has_include)
+#if __has_include(<nav_msgs/OccupancyGrid.h>)
+#include <nav_msgs/OccupancyGrid.h>
+#endif
+#if __has_include(<object_tracking/ObstacleList.h>)
+#include <object_tracking/Obstacle.h>
+#include <object_tracking/ObstacleList.h>
+#endif
+#if __has_include(<visualization_msgs/MarkerArray.h>)
+#include <visualization_msgs/Marker.h>
+#include <visualization_msgs/MarkerArray.h>
+#endif
+#endif
+
 #include "mot.h"
+
+#ifndef MOT_ADAPTERS_NO_REFERENCE_CONSTANTS
+#ifndef MOT_ADAPTERS_NUM_GRID
+#define MOT_ADAPTERS_NUM_GRID 250
+#endif
+const int numGrid = MOT_ADAPTERS_NUM_GRID;   // OT/include/component_clustering.h:15 (OT0: 200)
+#endif
 
 namespace mot_adapters {
 
@@ -54,6 +82,45 @@ inline std::vector<float> pack(const pcl::PointCloud<pcl::PointXYZ>& c) {
   for (size_t i = 0; i < c.size(); i++) { v[4 * i] = c[i].x; v[4 * i + 1] = c[i].y; v[4 * i + 2] = c[i].z; v[4 * i + 3] = 0.f; }
   return v;
 }
+
+// mark_cluster(), OT/src/cluster/box_fitting.cpp:161-209, for every emitted box (getBoundingBox pushes one marker per box,
+// :404-405). label[i] = cluster of elevated point i (0 = none), box_cluster[b] = 1-based cluster of box b. Centroid =
+// pcl::compute3DCentroid (float accumulation in point order, then a float division), extent = pcl::getMinMax3D.
+// Compiled only for MarkerArray types that have a `markers` member (any other type is left untouched).
+template <typename MarkerArrayT>
+inline auto fill_cube_markers(MarkerArrayT& ma, const pcl::PointCloud<pcl::PointXYZ>& cloud, const std::vector<int32_t>& label,
+                              const std::vector<int32_t>& box_cluster, int num_cluster, int) -> decltype(ma.markers, void()) {
+  typedef typename std::decay<decltype(ma.markers)>::type::value_type Marker;
+  struct Acc { float sx = 0, sy = 0, sz = 0, lo[3] = {FLT_MAX, FLT_MAX, FLT_MAX}, hi[3] = {-FLT_MAX, -FLT_MAX, -FLT_MAX}; unsigned n = 0; };
+  std::vector<Acc> acc((size_t)num_cluster + 1);
+  for (size_t i = 0; i < cloud.size(); i++) {
+    int c = label[i];
+    if (c <= 0 || c > num_cluster) continue;
+    Acc& a = acc[c];
+    const float v[3] = {cloud[i].x, cloud[i].y, cloud[i].z};
+    a.sx += v[0]; a.sy += v[1]; a.sz += v[2]; a.n++;
+    for (int k = 0; k < 3; k++) { a.lo[k] = v[k] < a.lo[k] ? v[k] : a.lo[k]; a.hi[k] = v[k] > a.hi[k] ? v[k] : a.hi[k]; }
+  }
+  for (int32_t c : box_cluster) {
+    const Acc& a = acc[c];
+    Marker m;
+    m.header.frame_id = "/velodyne";
+    m.header.stamp = std::decay<decltype(m.header.stamp)>::type::now();
+    m.ns = "cube"; m.id = 0; m.type = Marker::CUBE; m.action = Marker::ADD;
+    const float n = static_cast<float>(a.n);
+    m.pose.position.x = a.sx / n; m.pose.position.y = a.sy / n; m.pose.position.z = a.sz / n;
+    m.pose.orientation.x = 0.0; m.pose.orientation.y = 0.0; m.pose.orientation.z = 0.0; m.pose.orientation.w = 1.0;
+    m.scale.x = a.hi[0] - a.lo[0]; m.scale.y = a.hi[1] - a.lo[1]; m.scale.z = a.hi[2] - a.lo[2];
+    if (m.scale.x == 0) m.scale.x = 0.1;
+    if (m.scale.y == 0) m.scale.y = 0.1;
+    if (m.scale.z == 0) m.scale.z = 0.1;
+    m.color.g = 1.0f; m.color.a = 1.0;
+    m.lifetime = typename std::decay<decltype(m.lifetime)>::type(1.0);
+    ma.markers.push_back(m);
+  }
+}
+template <typename MarkerArrayT>
+inline void fill_cube_markers(MarkerArrayT&, const pcl::PointCloud<pcl::PointXYZ>&, const std::vector<int32_t>&, const std::vector<int32_t>&, int, long) {}
 }  // namespace mot_adapters
 
 // OT/include/ground_removal.h:62-64 — appends to elevatedCloud / groundCloud in input order, like the reference
@@ -130,18 +197,38 @@ inline std::vector<int> createCostMap(const pcl::PointCloud<pcl::PointXYZ>& scan
   return std::vector<int>(cost.begin(), cost.end());
 }
 
-// OT/include/box_fitting.h:34-36 (the MarkerArray argument is accepted and left untouched: any type)
+// OT/include/component_clustering.h:31, component_clustering.cpp:410-422 — OccupancyGridT = nav_msgs::OccupancyGrid
+template <typename OccupancyGridT>
+inline void setOccupancyGrid(OccupancyGridT* og) {
+  mot_side_params sp; mot_side_params_default(&sp);
+  og->info.resolution = sp.cost_resolution;
+  og->info.width = sp.cost_width;
+  og->info.height = sp.cost_height;
+  og->info.origin.position.x = (-1) * (sp.cost_width / 2.0) * sp.cost_resolution + sp.cost_offset_x;
+  og->info.origin.position.y = (-1) * (sp.cost_height / 2.0) * sp.cost_resolution + sp.cost_offset_y;
+  og->info.origin.position.z = sp.cost_offset_z;
+  og->info.origin.orientation.x = 0.0; og->info.origin.orientation.y = 0.0; og->info.origin.orientation.z = 0.0;
+  og->info.origin.orientation.w = 1.0;
+}
+
+// OT/include/box_fitting.h:34-36 — MarkerArrayT = visualization_msgs::MarkerArray (a type without `markers` is left untouched)
 template <size_t G, typename MarkerArrayT>
 inline std::vector<pcl::PointCloud<pcl::PointXYZ>> boxFitting(pcl::PointCloud<pcl::PointXYZ>::Ptr elevatedCloud,
                                                               std::array<std::array<int, G>, G> cartesianData, int numCluster,
-                                                              MarkerArrayT& /*ma*/) {
+                                                              MarkerArrayT& ma) {
   using namespace mot_adapters;
   std::vector<float> in = pack(*elevatedCloud);
   std::vector<int32_t> grid(G * G);
   for (size_t x = 0; x < G; x++) for (size_t y = 0; y < G; y++) grid[x * G + y] = cartesianData[x][y];
   std::vector<float> boxes(1024 * 24);
+  std::vector<int32_t> box_cluster(1024), label(elevatedCloud->size() + 1);
   int nb = 0;
-  check(mot_box_fit(context(), in.data(), (int)elevatedCloud->size(), grid.data(), numCluster, boxes.data(), 1024, &nb, nullptr, nullptr));
+  check(mot_box_fit(context(), in.data(), (int)elevatedCloud->size(), grid.data(), numCluster, boxes.data(), 1024, &nb, box_cluster.data(), nullptr));
+  box_cluster.resize(nb);
+  if (nb > 0) {   // the per-point labels the box stage left in slot 0 (getClusteredPoints' lookup, box_fitting.cpp:46-72)
+    check(mot_get_clusters(context(), 0, nullptr, nullptr, label.data()));
+    fill_cube_markers(ma, *elevatedCloud, label, box_cluster, numCluster, 0);
+  }
   std::vector<pcl::PointCloud<pcl::PointXYZ>> out(nb);
   for (int b = 0; b < nb; b++)
     for (int k = 0; k < 8; k++) out[b].push_back(pcl::PointXYZ(boxes[(b * 8 + k) * 3], boxes[(b * 8 + k) * 3 + 1], boxes[(b * 8 + k) * 3 + 2]));

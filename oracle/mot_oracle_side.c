@@ -14,6 +14,7 @@ int orc_side_params_default(mot_side_params* o) {
   o->cost_resolution = 1.0; o->cost_width = 50; o->cost_height = 50;  /* component_clustering.cpp:15-17 */
   o->cost_offset_x = 0; o->cost_offset_y = 25;   /* :18-19 */
   o->height_limit = 0.1; o->car_length = 4.5; o->car_width = 2;  /* :22-24 */
+  o->cost_offset_z = -2;                         /* :20 */
   return 0;
 }
 

@@ -92,10 +92,23 @@ class NodeHandle {
     });
     return Subscriber();
   }
+  template <class P, class T> Subscriber subscribe(const std::string& topic, uint32_t /*queue*/, void (T::*fp)(P), T* obj) {
+    typedef typename shim::Arg<P>::M M;
+    shim::state().subs[shim::plain(topic)].push_back([fp, obj](const void* d, size_t n) {
+      std::shared_ptr<M> m(new M);
+      wire::In in(d, n); wire::Codec<M>::read(in, *m);
+      std::shared_ptr<const M> cm = m;
+      (obj->*fp)(shim::Arg<P>::pass(cm));
+    });
+    return Subscriber();
+  }
+  template <class T> static void read_param(const std::string& text, T& val) { std::istringstream is(text); is >> val; }
+  static void read_param(const std::string& text, bool& val) { val = text == "true" || text == "1"; }
+  static void read_param(const std::string& text, std::string& val) { val = text; }
   template <class T> bool param(const std::string& name, T& val, const T& def) const {
     auto it = shim::state().params.find(name);
     if (it == shim::state().params.end()) { val = def; return false; }
-    std::istringstream is(it->second); is >> val; return true;
+    read_param(it->second, val); return true;
   }
   template <class T> T param(const std::string& name, const T& def) const { T v; param(name, v, def); return v; }
   bool ok() const { return true; }

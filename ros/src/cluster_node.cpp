@@ -1,0 +1,194 @@
+// `cluster` node of package object_tracking on the MI355X library: same topics and message contents as
+// OT/src/cluster/main.cpp (subscribes none_ground_topic; publishes realtime_cost_map, cluster_obs, output, track_box,
+// cluster_ma, visualization_marker).
+//
+// Data path: the elevated cloud is uploaded ONCE (the payload of none_ground_topic already is the library's float4 layout
+// when it comes from the ground node); connected-component labelling, the three side products (cell-centre cloud,
+// obstacle list, cost map) and the box fit all run on that resident copy (mot_cluster -> mot_cluster_products ->
+// mot_box_fit_resident). The host only assembles messages. The rviz CUBE markers need each boxed cluster's centroid and
+// extent exactly as PCL accumulates them (float sums in point order), so they are folded on the host from the per-point
+// labels the library returns — a few tens of microseconds on data the node holds anyway.
+#include <cfloat>
+
+#include <nav_msgs/OccupancyGrid.h>
+#include <object_tracking/ObstacleList.h>
+#include <object_tracking/trackbox.h>
+#include <visualization_msgs/Marker.h>
+#include <visualization_msgs/MarkerArray.h>
+
+#include "mot_ros_common.hpp"
+
+namespace {
+
+const int kMaxBoxes = 1024;   // the library's per-frame limit
+
+class ClusterNode {
+ public:
+  explicit ClusterNode(ros::NodeHandle& nh) {
+    mot_ros::Settings s = mot_ros::settings(nh);
+    if (mot_params_preset(s.preset, &prm_) != MOT_OK) throw std::runtime_error("unknown preset");
+    mot_side_params_default(&side_);
+    ctx_ = mot_ros::create(prm_, s);
+    cloud_pub_ = nh.advertise<sensor_msgs::PointCloud2>("output", 1);
+    lines_pub_ = nh.advertise<visualization_msgs::Marker>("visualization_marker", 0);
+    cubes_pub_ = nh.advertise<visualization_msgs::MarkerArray>("cluster_ma", 10);
+    costmap_pub_ = nh.advertise<nav_msgs::OccupancyGrid>("realtime_cost_map", 10);
+    obstacles_pub_ = nh.advertise<object_tracking::ObstacleList>("cluster_obs", 10);
+    boxes_pub_ = nh.advertise<object_tracking::trackbox>("track_box", 10);
+    // the fixed part of the cost map message (setOccupancyGrid, component_clustering.cpp:410-422)
+    grid_msg_.info.resolution = side_.cost_resolution;
+    grid_msg_.info.width = side_.cost_width;
+    grid_msg_.info.height = side_.cost_height;
+    grid_msg_.info.origin.position.x = (-1) * (side_.cost_width / 2.0) * side_.cost_resolution + side_.cost_offset_x;
+    grid_msg_.info.origin.position.y = (-1) * (side_.cost_height / 2.0) * side_.cost_resolution + side_.cost_offset_y;
+    grid_msg_.info.origin.position.z = side_.cost_offset_z;
+    grid_msg_.info.origin.orientation.w = 1.0;
+    boxes_.resize((size_t)kMaxBoxes * 24); box_cluster_.resize(kMaxBoxes);
+    cost_.resize((size_t)side_.cost_width * side_.cost_height);
+    obstacles_.resize((size_t)prm_.num_grid * prm_.num_grid * 4);
+    sub_ = nh.subscribe("none_ground_topic", 160, &ClusterNode::on_cloud, this);
+  }
+  ~ClusterNode() { mot_destroy(ctx_); }
+
+ private:
+  // the cloud as n x (x, y, z, *) floats; the payload itself when it already has that layout
+  const float* as_float4(const sensor_msgs::PointCloud2& m, size_t n) {
+    int off[3];
+    if (!mot_ros::xyz_offsets(m, off)) throw std::runtime_error("cluster: the cloud has no float32 x/y/z fields");
+    const uint8_t* rec = mot_ros::records(m, scratch_);
+    if (m.point_step == 16 && off[0] == 0 && off[1] == 4 && off[2] == 8 && ((size_t)rec & 3) == 0) return reinterpret_cast<const float*>(rec);
+    repacked_.assign(4 * n + 4, 1.0f);
+    for (size_t i = 0; i < n; i++)
+      for (int k = 0; k < 3; k++) std::memcpy(&repacked_[4 * i + k], rec + i * m.point_step + off[k], 4);
+    return repacked_.data();
+  }
+
+  void on_cloud(const sensor_msgs::PointCloud2ConstPtr& input) {
+    const size_t n = (size_t)input->width * input->height;
+    const float* elevated = as_float4(*input, n);
+    if (clustered_.size() < 4 * n + 4) { clustered_.resize(4 * n + 4); label_.resize(n + 1); }
+
+    int num_cluster = 0, n_clustered = 0, n_obstacles = 0, n_boxes = 0;
+    mot_ros::check(ctx_, mot_cluster(ctx_, elevated, (int)n, nullptr, &num_cluster, nullptr), "mot_cluster");
+    mot_ros::check(ctx_, mot_cluster_products(ctx_, 0, &side_, clustered_.data(), (int)n, &n_clustered, obstacles_.data(), prm_.num_grid * prm_.num_grid,
+                                              &n_obstacles, cost_.data()), "mot_cluster_products");
+    mot_ros::check(ctx_, mot_box_fit_resident(ctx_, boxes_.data(), kMaxBoxes, &n_boxes, box_cluster_.data(), nullptr), "mot_box_fit_resident");
+
+    // realtime_cost_map
+    grid_msg_.header.frame_id = input->header.frame_id;
+    grid_msg_.data.assign(cost_.begin(), cost_.end());
+    costmap_pub_.publish(grid_msg_);
+    grid_msg_.data.clear();
+
+    // cluster_obs: first elevated point of every labelled cell, at the cell centre (setObsMsg)
+    object_tracking::ObstacleList obstacle_msg;
+    if (n_obstacles > 0) { obstacle_msg.header.frame_id = input->header.frame_id; obstacle_msg.cellLength = obstacle_msg.cellWidth = side_.cell_size; }
+    obstacle_msg.obstacles.resize(n_obstacles);
+    for (int i = 0; i < n_obstacles; i++) {
+      object_tracking::Obstacle& o = obstacle_msg.obstacles[i];
+      o.x = obstacles_[4 * i]; o.y = obstacles_[4 * i + 1]; o.z = obstacles_[4 * i + 2]; o.cluster = (int32_t)obstacles_[4 * i + 3];
+    }
+    obstacles_pub_.publish(obstacle_msg);
+
+    // output: every clustered point moved to its cell centre (makeClusteredCloud)
+    for (int i = 0; i < n_clustered; i++) clustered_[4 * i + 3] = 1.0f;   // pcl::PointXYZ's padding
+    sensor_msgs::PointCloud2 cloud_msg;
+    mot_ros::fill_xyz_cloud(cloud_msg, clustered_.data(), (size_t)n_clustered);
+    cloud_msg.header.frame_id = input->header.frame_id;
+    cloud_pub_.publish(cloud_msg);
+
+    // track_box: corner k of box b at boxes_[b*24 + 3*k ..]; x1..x4 = the bottom face, y1..y4 = the top face
+    object_tracking::trackbox box_msg;
+    box_msg.header = input->header;
+    box_msg.box_num = (uint8_t)n_boxes;
+    std::vector<float>* corner[8] = {&box_msg.x1, &box_msg.x2, &box_msg.x3, &box_msg.x4, &box_msg.y1, &box_msg.y2, &box_msg.y3, &box_msg.y4};
+    for (int k = 0; k < 8; k++) {
+      corner[k]->resize(3 * (size_t)n_boxes);
+      for (int b = 0; b < n_boxes; b++) std::memcpy(&(*corner[k])[3 * b], &boxes_[(size_t)b * 24 + 3 * k], 12);
+    }
+    boxes_pub_.publish(box_msg);
+
+    cubes_pub_.publish(cube_markers(elevated, n, num_cluster, n_boxes));
+    lines_pub_.publish(edge_marker(n_boxes));
+  }
+
+  // one CUBE per box: centroid and axis-aligned extent of the cluster's points (mark_cluster, box_fitting.cpp:161-209)
+  visualization_msgs::MarkerArray cube_markers(const float* elevated, size_t n, int num_cluster, int n_boxes) {
+    visualization_msgs::MarkerArray out;
+    if (n_boxes == 0) return out;
+    mot_ros::check(ctx_, mot_get_clusters(ctx_, 0, nullptr, nullptr, label_.data()), "mot_get_clusters");
+    struct Fold { float sum[3] = {0, 0, 0}, lo[3] = {FLT_MAX, FLT_MAX, FLT_MAX}, hi[3] = {-FLT_MAX, -FLT_MAX, -FLT_MAX}; unsigned count = 0; };
+    std::vector<Fold> fold((size_t)num_cluster + 1);
+    for (size_t i = 0; i < n; i++) {
+      const int c = label_[i];
+      if (c <= 0 || c > num_cluster) continue;
+      Fold& f = fold[c];
+      for (int k = 0; k < 3; k++) {
+        const float v = elevated[4 * i + k];
+        f.sum[k] += v;
+        if (v < f.lo[k]) f.lo[k] = v;
+        if (v > f.hi[k]) f.hi[k] = v;
+      }
+      f.count++;
+    }
+    for (int b = 0; b < n_boxes; b++) {
+      const Fold& f = fold[box_cluster_[b]];
+      visualization_msgs::Marker m;
+      m.header.frame_id = "/velodyne";
+      m.header.stamp = ros::Time::now();
+      m.ns = "cube"; m.id = 0;
+      m.type = visualization_msgs::Marker::CUBE; m.action = visualization_msgs::Marker::ADD;
+      const float count = static_cast<float>(f.count);
+      m.pose.position.x = f.sum[0] / count; m.pose.position.y = f.sum[1] / count; m.pose.position.z = f.sum[2] / count;
+      m.pose.orientation.w = 1.0;
+      const float extent[3] = {f.hi[0] - f.lo[0], f.hi[1] - f.lo[1], f.hi[2] - f.lo[2]};
+      m.scale.x = extent[0] == 0 ? 0.1 : extent[0]; m.scale.y = extent[1] == 0 ? 0.1 : extent[1]; m.scale.z = extent[2] == 0 ? 0.1 : extent[2];
+      m.color.g = 1.0f; m.color.a = 1.0;
+      m.lifetime = ros::Duration(1.0);
+      out.markers.push_back(m);
+    }
+    return out;
+  }
+
+  // the 12 edges of every box as one LINE_LIST: per bottom corner k, (k, k+1), (k, k+4), (k+4, k+1+4) (main.cpp:178-231)
+  visualization_msgs::Marker edge_marker(int n_boxes) const {
+    visualization_msgs::Marker m;
+    m.header.frame_id = "velodyne";
+    m.header.stamp = ros::Time::now();
+    m.ns = "boxes"; m.id = 0;
+    m.type = visualization_msgs::Marker::LINE_LIST; m.action = visualization_msgs::Marker::ADD;
+    m.pose.orientation.w = 1.0;
+    m.scale.x = 0.1;
+    m.color.g = 1.0f; m.color.a = 1.0;
+    m.points.reserve(24 * (size_t)n_boxes);
+    for (int b = 0; b < n_boxes; b++) {
+      const float* c = &boxes_[(size_t)b * 24];
+      for (int k = 0; k < 4; k++) {
+        const int next = (k + 1) % 4;
+        const int ends[6] = {k, next, k, k + 4, k + 4, next + 4};
+        for (int e : ends) { geometry_msgs::Point p; p.x = c[3 * e]; p.y = c[3 * e + 1]; p.z = c[3 * e + 2]; m.points.push_back(p); }
+      }
+    }
+    return m;
+  }
+
+  mot_ctx* ctx_ = nullptr;
+  mot_params prm_;
+  mot_side_params side_;
+  ros::Publisher cloud_pub_, lines_pub_, cubes_pub_, costmap_pub_, obstacles_pub_, boxes_pub_;
+  ros::Subscriber sub_;
+  nav_msgs::OccupancyGrid grid_msg_;
+  std::vector<float> clustered_, obstacles_, boxes_, repacked_;
+  std::vector<int32_t> cost_, box_cluster_, label_;
+  std::vector<uint8_t> scratch_;
+};
+
+}  // namespace
+
+int main(int argc, char** argv) {
+  ros::init(argc, argv, "cluster");
+  ros::NodeHandle nh;
+  ClusterNode node(nh);
+  ros::spin();
+  return 0;
+}

@@ -1,0 +1,71 @@
+// Shared pieces of the three node shells (ros/src/*_node.cpp): context set-up from ROS parameters, sensor_msgs/PointCloud2
+// field lookup and assembly straight from / into the float4 arrays of the C-ABI (include/mot.h). No PCL types: a message
+// payload goes to the library as it arrived and the library's arrays become message payloads with one memcpy.
+#ifndef MOT_ROS_COMMON_HPP_
+#define MOT_ROS_COMMON_HPP_
+#include <cstring>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include <ros/ros.h>
+#include <sensor_msgs/PointCloud2.h>
+
+#include "mot.h"
+
+namespace mot_ros {
+
+inline void check(mot_ctx* ctx, int rc, const char* what) {
+  if (rc != MOT_OK) throw std::runtime_error(std::string(what) + ": " + mot_last_error(ctx));
+}
+
+// private parameters common to the three nodes: ~device (HIP ordinal), ~max_points, ~preset (0 = object_tracking, 1 = object_tracking0)
+struct Settings { int device = 0, max_points = 262144, preset = MOT_PRESET_OBJECT_TRACKING, max_tracks_total = 16384; };
+inline Settings settings(const ros::NodeHandle& nh) {
+  Settings s;
+  nh.param<int>("device", s.device, s.device);
+  nh.param<int>("max_points", s.max_points, s.max_points);
+  nh.param<int>("preset", s.preset, s.preset);
+  nh.param<int>("max_tracks_total", s.max_tracks_total, s.max_tracks_total);
+  return s;
+}
+inline mot_ctx* create(const mot_params& p, const Settings& s) {
+  mot_ctx* ctx = nullptr;
+  if (mot_create(&p, s.device, s.max_points, 1, s.max_tracks_total, &ctx) != MOT_OK)
+    throw std::runtime_error("mot_create failed: no MI355X / HIP device? (this library has no CPU path)");
+  return ctx;
+}
+
+// byte offsets of the FLOAT32 fields x, y, z (what pcl::fromROSMsg maps for PointXYZ); false when one is missing
+inline bool xyz_offsets(const sensor_msgs::PointCloud2& m, int off[3]) {
+  off[0] = off[1] = off[2] = -1;
+  for (const auto& f : m.fields) {
+    if (f.datatype != sensor_msgs::PointField::FLOAT32 || f.count > 1) continue;
+    if (f.name == "x") off[0] = (int)f.offset; else if (f.name == "y") off[1] = (int)f.offset; else if (f.name == "z") off[2] = (int)f.offset;
+  }
+  return off[0] >= 0 && off[1] >= 0 && off[2] >= 0;
+}
+
+// the records of a (possibly organised, possibly row-padded) cloud as one contiguous run of width*height records
+inline const uint8_t* records(const sensor_msgs::PointCloud2& m, std::vector<uint8_t>& scratch) {
+  const size_t row = (size_t)m.width * m.point_step;
+  if (m.height <= 1 || m.row_step == row) return m.data.data();
+  scratch.resize(row * m.height);
+  for (uint32_t r = 0; r < m.height; r++) std::memcpy(scratch.data() + r * row, m.data.data() + (size_t)r * m.row_step, row);
+  return scratch.data();
+}
+
+// what pcl::toROSMsg makes of a PointCloud<PointXYZ> of n points: fields x, y, z, 16-byte records (the 4th float is the
+// point type's padding, 1.0f), one row. xyz1: n x 4 floats, copied as they are.
+inline void fill_xyz_cloud(sensor_msgs::PointCloud2& out, const float* xyz1, size_t n, bool is_dense = true) {
+  out.height = 1; out.width = (uint32_t)n;
+  out.fields.resize(3);
+  const char* names[3] = {"x", "y", "z"};
+  for (int k = 0; k < 3; k++) { out.fields[k].name = names[k]; out.fields[k].offset = 4u * k; out.fields[k].datatype = sensor_msgs::PointField::FLOAT32; out.fields[k].count = 1; }
+  out.is_bigendian = false; out.point_step = 16; out.row_step = (uint32_t)(16 * n); out.is_dense = is_dense;
+  out.data.resize(16 * n);
+  if (n) std::memcpy(out.data.data(), xyz1, 16 * n);
+}
+
+}  // namespace mot_ros
+#endif

@@ -1,0 +1,103 @@
+"""Builds the node executables that tests/test_nodes.py compares (TEST INFRASTRUCTURE, CPU only):
+
+  reference  oracle/_ref/bin/{ground,cluster,tracking}      the reference's main.cpp + its own algorithm sources (oracle/Makefile)
+  recipe     oracle/_ref/bin/recipe_{ground,cluster,tracking}   the reference's main.cpp with the ONE edit INTEGRATION.md prescribes
+             (the include of the algorithm header replaced by "mot_adapters.hpp", written by sed into the git-ignored
+             oracle/_ref/gen/), linked against the C-ABI library
+  own        tests/emu/bin/{ground,cluster,tracking}        this repository's ros/src/*_node.cpp, linked against the C-ABI library
+
+All of them are compiled against the file-backed mini-ROS of oracle/ref_shim and run as `<node> --in IN.log --out OUT.log`.
+The C-ABI library is the CPU emulator build (tests/emu) here; on a ROS machine the same sources link libmot_hip.so."""
+from __future__ import annotations
+
+import os
+import re
+import subprocess
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+REF = "/root/reference/object_tracking"
+SHIM = os.path.join(ROOT, "oracle", "ref_shim")
+REF_BIN = os.path.join(ROOT, "oracle", "_ref", "bin")
+GEN = os.path.join(ROOT, "oracle", "_ref", "gen")
+OWN_BIN = os.path.join(HERE, "emu", "bin")
+NODES = {"ground": "src/groundremove/main.cpp", "cluster": "src/cluster/main.cpp", "tracking": "tracking/main.cpp"}
+ALGO_HEADERS = ("ground_removal.h", "component_clustering.h", "box_fitting.h", "imm_ukf_jpda.h")
+FLAGS = ["-std=c++14", "-O2", "-ffp-contract=off", "-fno-fast-math", "-w"]
+
+
+def have_reference() -> bool:
+    return os.path.isfile(os.path.join(REF, "tracking", "main.cpp"))
+
+
+def _newer(target, deps):
+    return os.path.exists(target) and all(os.path.getmtime(d) <= os.path.getmtime(target) for d in deps if os.path.exists(d))
+
+
+def _shim_files():
+    return [os.path.join(d, f) for d, _, fs in os.walk(SHIM) for f in fs]
+
+
+def _link_args(lib):
+    d, f = os.path.split(lib)
+    return ["-L", d, "-l:" + f, "-Wl,-rpath," + d]
+
+
+def _cxx(args, what):
+    r = subprocess.run(["g++"] + FLAGS + args, capture_output=True, text=True)
+    if r.returncode:
+        raise RuntimeError(f"building {what} failed:\n{r.stderr[-4000:]}")
+
+
+def reference_nodes() -> dict:
+    subprocess.run(["make", "-C", os.path.join(ROOT, "oracle"), "ref"], check=True, capture_output=True)
+    return {n: os.path.join(REF_BIN, n) for n in NODES}
+
+
+def recipe_nodes(lib: str) -> dict:
+    """the reference's node sources with only their algorithm includes swapped for the adapter header"""
+    os.makedirs(GEN, exist_ok=True); os.makedirs(REF_BIN, exist_ok=True)
+    out = {}
+    for n, rel in NODES.items():
+        src = open(os.path.join(REF, rel), encoding="utf-8", errors="replace").read()
+        pat = re.compile(r'^#include "(%s)"\s*$' % "|".join(re.escape(h) for h in ALGO_HEADERS), re.M)
+        assert pat.search(src), rel
+        first = [True]
+        def swap(m):
+            if first[0]:
+                first[0] = False; return '#include "mot_adapters.hpp"'
+            return ""
+        gen = os.path.join(GEN, f"recipe_{n}.cpp")
+        new = pat.sub(swap, src)
+        if not os.path.exists(gen) or open(gen, encoding="utf-8").read() != new:
+            open(gen, "w", encoding="utf-8").write(new)
+        exe = os.path.join(REF_BIN, "recipe_" + n)
+        deps = [gen, lib, os.path.join(ROOT, "include", "mot_adapters.hpp"), os.path.join(ROOT, "include", "mot.h")] + _shim_files()
+        if not _newer(exe, deps):
+            _cxx(["-I", SHIM, "-I", os.path.join(REF, "tracking"), "-I", os.path.join(ROOT, "include"), gen, "-o", exe] + _link_args(lib), exe)
+        out[n] = exe
+    return out
+
+
+def own_nodes(lib: str) -> dict:
+    """ros/src/<node>_node.cpp of this repository"""
+    os.makedirs(OWN_BIN, exist_ok=True)
+    out = {}
+    common = [os.path.join(ROOT, "ros", "src", f) for f in os.listdir(os.path.join(ROOT, "ros", "src")) if f.endswith((".hpp", ".h"))]
+    for n in NODES:
+        src = os.path.join(ROOT, "ros", "src", f"{n}_node.cpp")
+        exe = os.path.join(OWN_BIN, n)
+        deps = [src, lib, os.path.join(ROOT, "include", "mot.h")] + common + _shim_files()
+        if not _newer(exe, deps):
+            _cxx(["-I", SHIM, "-I", os.path.join(REF, "tracking"), "-I", os.path.join(ROOT, "include"), "-I", os.path.join(ROOT, "ros", "src"),
+                  src, "-o", exe] + _link_args(lib), exe)
+        out[n] = exe
+    return out
+
+
+def run_node(exe: str, in_log: str, out_log: str, params: dict | None = None, timeout: int = 600):
+    args = [exe, "--in", in_log, "--out", out_log] + [f"{k}:={v}" for k, v in (params or {}).items()]
+    r = subprocess.run(args, capture_output=True, text=True, timeout=timeout, errors="replace")
+    if r.returncode:
+        raise RuntimeError(f"{exe} exited with {r.returncode}:\n{r.stderr[-2000:]}")
+    return r

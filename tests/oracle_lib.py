@@ -153,7 +153,7 @@ class MotSideParams(C.Structure):
     """mirror of struct mot_side_params (include/mot.h)"""
     _fields_ = [("cell_size", C.c_float), ("cost_width", C.c_int32), ("cost_height", C.c_int32), ("cost_resolution", C.c_double),
                 ("cost_offset_x", C.c_double), ("cost_offset_y", C.c_double), ("height_limit", C.c_double),
-                ("car_length", C.c_double), ("car_width", C.c_double)]
+                ("car_length", C.c_double), ("car_width", C.c_double), ("cost_offset_z", C.c_double)]
 
 
 def side_params() -> MotSideParams:

@@ -10,9 +10,10 @@ SRC = r'''
 #include <array>
 #include <vector>
 #include <object_tracking/ObstacleList.h>
+#include <visualization_msgs/MarkerArray.h>
+#include <nav_msgs/OccupancyGrid.h>
 #include "mot_adapters.hpp"
 using namespace std; using namespace pcl;
-const int numGrid = 250;
 struct MarkerArray { int dummy; };
 int use_like_the_reference_nodes() {
   PointCloud<PointXYZ>::Ptr cloud(new PointCloud<PointXYZ>), elevatedCloud(new PointCloud<PointXYZ>), groundCloud(new PointCloud<PointXYZ>);
@@ -25,8 +26,12 @@ int use_like_the_reference_nodes() {
   vector<int> cost_map = createCostMap(*elevatedCloud);                  // :96
   object_tracking::ObstacleList clu_obs;
   setObsMsg(elevatedCloud, cartesianData, clu_obs);                      // :110
-  MarkerArray ma;
+  static nav_msgs::OccupancyGrid og;
+  setOccupancyGrid(&og);                                                 // :90
+  visualization_msgs::MarkerArray ma;
   vector<PointCloud<PointXYZ>> bBoxes = boxFitting(elevatedCloud, cartesianData, numCluster, ma);  // :119
+  MarkerArray untouched;                                                 // a type without `markers` still compiles
+  boxFitting(elevatedCloud, cartesianData, numCluster, untouched);
   vector<vector<double>> egoPoints;
   getOriginPoints(0.0, egoPoints, 1.0, 0.0);                             // OT/tracking/main.cpp:74
   PointCloud<PointXYZ> targetPoints; vector<vector<double>> targetVandYaw; vector<int> trackManage;

@@ -41,3 +41,28 @@ def test_emu_decode_pointcloud2(emu_ctx, synth):
     emu_ctx.decode_pointcloud2_dev(raw.ctypes.data, n, step, 0, 4, 8, 12, out.ctypes.data)
     emu_ctx.synchronize()
     assert np.array_equal(out, cloud)
+
+
+def test_emu_ground_remove_pointcloud2_and_resident_box_fit(mot, oracle, synth):
+    """the two entry points the node shells use: raw PointCloud2 records in (unpacked on the device, pre-filter fused), and
+    the box stage on what the cluster stage left resident"""
+    import build_emu
+    lib = build_emu.build()
+    n, step = 9000, 32
+    cloud = np.concatenate([synth.make_cloud(n, 1, 0), synth.edge_case_points()]); n = len(cloud)
+    raw = np.random.default_rng(2).integers(0, 256, size=(n, step), dtype=np.uint8)
+    for k, off in enumerate((4, 8, 16)):
+        raw[:, off:off + 4] = cloud[:, k].copy().view(np.uint8).reshape(n, 4)
+    for crop in (0, 1):
+        p = oracle.params(0, crop_enable=crop)
+        with mot.Context(mot.params(0, lib=mot.load_library(lib), crop_enable=crop), lib_path=lib, max_points=16384) as c:
+            r = c.ground_remove_pointcloud2(raw, n, step, 4, 8, 16)
+            g = oracle.ground_remove(p, oracle.crop(p, cloud) if crop else cloud)
+            assert np.array_equal(r["elevated"][:, :3], g["elevated"][:, :3]) and np.array_equal(r["ground"][:, :3], g["ground"][:, :3])
+            assert np.all(r["elevated"][:, 3] == 1.0) and np.all(r["ground"][:, 3] == 1.0)   # pcl::PointXYZ's padding
+            assert np.array_equal(c.ground_remove_pointcloud2(raw, 0, step, 4, 8, 16)["elevated"], np.zeros((0, 4), np.float32))
+            cl = c.cluster(r["elevated"])
+            bx = c.box_fit_resident()
+            ob = oracle.box_fit(p, g["elevated"], oracle.cluster(p, g["elevated"])["grid"], cl["num_cluster"])
+            assert np.array_equal(bx["boxes"], ob["boxes"]) and len(bx["boxes"]) > 0
+            assert np.array_equal(bx["boxes"], c.box_fit(r["elevated"], cl["grid"], cl["num_cluster"])["boxes"])
