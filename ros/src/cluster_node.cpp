@@ -188,7 +188,12 @@ class ClusterNode {
 int main(int argc, char** argv) {
   ros::init(argc, argv, "cluster");
   ros::NodeHandle nh;
-  ClusterNode node(nh);
-  ros::spin();
+  try {
+    ClusterNode node(nh);
+    ros::spin();
+  } catch (const std::exception& e) {   // no GPU, a capacity limit, a malformed message: say so and stop (required="true" in the launch file)
+    std::cerr << "cluster: " << e.what() << std::endl;
+    return 1;
+  }
   return 0;
 }

@@ -89,7 +89,12 @@ class GroundNode {
 int main(int argc, char** argv) {
   ros::init(argc, argv, "ground");
   ros::NodeHandle nh;
-  GroundNode node(nh);
-  ros::spin();
+  try {
+    GroundNode node(nh);
+    ros::spin();
+  } catch (const std::exception& e) {   // no GPU, a capacity limit, a malformed message: say so and stop (required="true" in the launch file)
+    std::cerr << "ground: " << e.what() << std::endl;
+    return 1;
+  }
   return 0;
 }

@@ -152,7 +152,12 @@ class TrackingNode {
 int main(int argc, char** argv) {
   ros::init(argc, argv, "obj_track");
   ros::NodeHandle nh;
-  TrackingNode node(nh);
-  ros::spin();
+  try {
+    TrackingNode node(nh);
+    ros::spin();
+  } catch (const std::exception& e) {   // no GPU, a capacity limit, a malformed message: say so and stop (required="true" in the launch file)
+    std::cerr << "obj_track: " << e.what() << std::endl;
+    return 1;
+  }
   return 0;
 }

@@ -21,6 +21,8 @@ SHIM = os.path.join(ROOT, "oracle", "ref_shim")
 REF_BIN = os.path.join(ROOT, "oracle", "_ref", "bin")
 GEN = os.path.join(ROOT, "oracle", "_ref", "gen")
 OWN_BIN = os.path.join(HERE, "emu", "bin")
+HIP_BIN = os.path.join(ROOT, "ros", "bin")     # the same node sources linked against libmot_hip.so: prebuilt here, run on the GPU box
+HIP_LIB = os.path.join(ROOT, "3d-lidar-multi-object-tracking_amd", "libmot_hip.so")
 NODES = {"ground": "src/groundremove/main.cpp", "cluster": "src/cluster/main.cpp", "tracking": "tracking/main.cpp"}
 ALGO_HEADERS = ("ground_removal.h", "component_clustering.h", "box_fitting.h", "imm_ukf_jpda.h")
 FLAGS = ["-std=c++14", "-O2", "-ffp-contract=off", "-fno-fast-math", "-w"]
@@ -79,20 +81,34 @@ def recipe_nodes(lib: str) -> dict:
     return out
 
 
-def own_nodes(lib: str) -> dict:
+def own_nodes(lib: str, out_dir: str = OWN_BIN, link_extra=()) -> dict:
     """ros/src/<node>_node.cpp of this repository"""
-    os.makedirs(OWN_BIN, exist_ok=True)
+    os.makedirs(out_dir, exist_ok=True)
     out = {}
     common = [os.path.join(ROOT, "ros", "src", f) for f in os.listdir(os.path.join(ROOT, "ros", "src")) if f.endswith((".hpp", ".h"))]
     for n in NODES:
         src = os.path.join(ROOT, "ros", "src", f"{n}_node.cpp")
-        exe = os.path.join(OWN_BIN, n)
+        exe = os.path.join(out_dir, n)
         deps = [src, lib, os.path.join(ROOT, "include", "mot.h")] + common + _shim_files()
         if not _newer(exe, deps):
             _cxx(["-I", SHIM, "-I", os.path.join(REF, "tracking"), "-I", os.path.join(ROOT, "include"), "-I", os.path.join(ROOT, "ros", "src"),
-                  src, "-o", exe] + _link_args(lib), exe)
+                  src, "-o", exe] + _link_args(lib) + list(link_extra), exe)
         out[n] = exe
     return out
+
+
+def hip_nodes() -> dict:
+    """the node shells linked against the real library (needs the reference's vendored Eigen for the tf / pcl_ros shim, so it
+    is built in the container that has /root/reference — __graft_entry__.build() — and travels to the GPU box prebuilt).
+    The run path is relative to the executable, the HIP runtime is found through the library's own run path."""
+    rel = os.path.relpath(os.path.dirname(HIP_LIB), HIP_BIN)
+    return own_nodes(HIP_LIB, HIP_BIN, ["-Wl,-rpath,$ORIGIN/" + rel, "-Wl,-rpath-link,/opt/rocm/lib", "-Wl,--allow-shlib-undefined"])
+
+
+def prebuilt(dirname: str):
+    """{node: path} when all three executables exist in dirname, else None"""
+    out = {n: os.path.join(dirname, n) for n in NODES}
+    return out if all(os.path.isfile(p) and os.access(p, os.X_OK) for p in out.values()) else None
 
 
 def run_node(exe: str, in_log: str, out_log: str, params: dict | None = None, timeout: int = 600):

@@ -220,3 +220,15 @@ def test_full_size_properties(ctx, synth):
     assert np.array_equal(cl2["grid"], cl["grid"])
     bx2 = ctx.box_fit(g["elevated"], cl["grid"], cl["num_cluster"])
     assert np.array_equal(bx2["boxes"], bx["boxes"])
+
+
+def test_box_fit_resident(ctx, oracle, synth):
+    """the box stage on what mot_cluster left resident (the `cluster` node shell: one upload for both stages)"""
+    p = oracle.params(0)
+    e = oracle.ground_remove(p, synth.make_cloud(120000, 3, 1))["elevated"]
+    cl = ctx.cluster(e)
+    a = ctx.box_fit_resident()
+    b = ctx.box_fit(e, cl["grid"], cl["num_cluster"])
+    o = oracle.box_fit(p, e, oracle.cluster(p, e)["grid"], cl["num_cluster"])
+    assert len(o["boxes"]) > 0 and np.array_equal(a["boxes"], o["boxes"]) and np.array_equal(b["boxes"], o["boxes"])
+    assert np.array_equal(a["box_cluster"], b["box_cluster"])

@@ -132,3 +132,22 @@ def test_decode_pointcloud2(mot, hip_lib, oracle, synth, step, offs, shift):
         g = c.get_ground(0, n_hint=n); o = oracle.ground_remove(p, expect)
         assert np.array_equal(g["elevated"], o["elevated"]) and np.array_equal(g["ground"], o["ground"])
         src.free(); dst.free()
+
+
+def test_ground_remove_pointcloud2(mot, hip_lib, oracle, synth):
+    """raw PointCloud2 records in host memory -> device unpack -> (fused pre-filter) -> ground removal: what the `ground` node
+    shell calls. Outputs are toROSMsg payloads: 4th float 1.0f."""
+    n, step = 120000, 32
+    cloud = np.concatenate([synth.make_cloud(n, 1, 0), synth.edge_case_points()]); n = len(cloud)
+    raw = np.random.default_rng(2).integers(0, 256, size=(n, step), dtype=np.uint8)
+    for k, off in enumerate((4, 8, 16)):
+        raw[:, off:off + 4] = cloud[:, k].copy().view(np.uint8).reshape(n, 4)
+    for crop in (0, 1):
+        p = oracle.params(0, crop_enable=crop)
+        with mot.Context(mot.params(0, crop_enable=crop), max_points=131072) as c:
+            for _ in range(2):   # second call reuses the staging buffer
+                r = c.ground_remove_pointcloud2(raw, n, step, 4, 8, 16)
+                g = oracle.ground_remove(p, oracle.crop(p, cloud) if crop else cloud)
+                assert np.array_equal(r["elevated"][:, :3], g["elevated"][:, :3]) and np.array_equal(r["ground"][:, :3], g["ground"][:, :3])
+                assert np.all(r["elevated"][:, 3] == 1.0) and np.all(r["ground"][:, 3] == 1.0)
+            assert len(c.ground_remove_pointcloud2(raw, 0, step, 4, 8, 16)["elevated"]) == 0
