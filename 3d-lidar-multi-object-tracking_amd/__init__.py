@@ -71,7 +71,7 @@ EXPORTS = (
     "mot_synchronize", "mot_stream", "mot_ground_remove", "mot_cluster", "mot_box_fit", "mot_ego_update",
     "mot_track_step", "mot_track_get_state", "mot_frames_dev", "mot_get_ground", "mot_get_clusters",
     "mot_get_boxes", "mot_get_tracks", "mot_export_tracks_dev", "mot_side_params_default", "mot_cluster_products", "mot_cluster_products_host", "mot_decode_pointcloud2_dev", "mot_time_stage",
-    "mot_ground_remove_pointcloud2", "mot_box_fit_resident",
+    "mot_ground_remove_pointcloud2", "mot_box_fit_resident", "mot_frame_pointcloud2",
 )
 
 _libs: dict[str, C.CDLL] = {}
@@ -191,6 +191,12 @@ class Context:
         if want_mask:
             out["mask"] = mask[:n].copy()
         return out
+
+    def frame_pointcloud2(self, payload, n: int, point_step: int, off_x: int, off_y: int, off_z: int):
+        """ground -> cluster -> box on a PointCloud2 payload in host memory, everything resident in slot 0 (asynchronous)"""
+        raw = np.ascontiguousarray(payload, np.uint8).reshape(-1)
+        assert raw.size >= n * point_step
+        self._ck(self.lib.mot_frame_pointcloud2(self._h, _vp(raw), n, point_step, off_x, off_y, off_z))
 
     def box_fit_resident(self, max_boxes: int = 4096):
         """boxFitting on the cloud and label grid that cluster() left resident in slot 0"""

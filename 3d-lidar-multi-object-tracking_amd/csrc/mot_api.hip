@@ -595,9 +595,9 @@ extern "C" int mot_ground_remove(mot_ctx* c, const float* xyzw, int n, float* el
   return mot_get_ground(c, 0, elev, n_elev, ground, n_ground, mask);
 }
 
-// fromROSMsg + groundRemove for a message payload in host memory: one H2D of the raw records, unpacked on the device
-extern "C" int mot_ground_remove_pointcloud2(mot_ctx* c, const void* data, int n, int point_step, int off_x, int off_y, int off_z,
-                                             float* elev, int* n_elev, float* ground, int* n_ground, uint8_t* mask) {
+// one H2D of the raw PointCloud2 records of a frame into the staging buffer, unpacked on the device into the context's own
+// input buffer (slot 0), 4th float = 1.0f
+static int upload_pointcloud2(mot_ctx* c, const void* data, int n, int point_step, int off_x, int off_y, int off_z) {
   if (!c || n < 0 || (n > 0 && !data) || point_step < 12) return MOT_E_ARG;
   if (n > c->cap) return fail(c, MOT_E_CAPACITY, "frame has more points than max_points");
   const int offs[3] = {off_x, off_y, off_z};
@@ -613,13 +613,29 @@ extern "C" int mot_ground_remove_pointcloud2(mot_ctx* c, const void* data, int n
     MOT_HIP(c, hipMemcpyAsync(c->d_raw, data, bytes, hipMemcpyHostToDevice, c->stream));
     mot_launch_decode_pointcloud2(c->d_raw, n, point_step, off_x, off_y, off_z, -1, (float4*)c->d_in, c->stream);
   }
-  int rc = set_batch(c, &n, 1, c->d_in, c->cap);
+  return MOT_OK;
+}
+
+// fromROSMsg + groundRemove for a message payload in host memory
+extern "C" int mot_ground_remove_pointcloud2(mot_ctx* c, const void* data, int n, int point_step, int off_x, int off_y, int off_z,
+                                             float* elev, int* n_elev, float* ground, int* n_ground, uint8_t* mask) {
+  int rc = upload_pointcloud2(c, data, n, point_step, off_x, off_y, off_z);
+  if (rc) return rc;
+  rc = set_batch(c, &n, 1, c->d_in, c->cap);
   if (rc) return rc;
   if ((rc = next_epoch(c))) return rc;
   GroundBuffers g = ground_buffers(c, c->d_in, c->cap, true);
   mot_launch_ground(c->dp, g, 1, n, c->stream);
   MOT_HIP(c, hipGetLastError());
   return mot_get_ground(c, 0, elev, n_elev, ground, n_ground, mask);
+}
+
+// the whole stateless chain of a frame (what OT0/src/main.cpp:57-88 runs in one process) on a message payload in host memory:
+// the cloud is uploaded once and never leaves HBM between the stages
+extern "C" int mot_frame_pointcloud2(mot_ctx* c, const void* data, int n, int point_step, int off_x, int off_y, int off_z) {
+  int rc = upload_pointcloud2(c, data, n, point_step, off_x, off_y, off_z);
+  if (rc) return rc;
+  return mot_frames_dev(c, (const float*)c->d_in, (long)c->cap * 4, &n, 1, 0, nullptr, nullptr, nullptr);
 }
 
 // kernel ids used by mot_time_stage

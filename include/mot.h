@@ -193,6 +193,11 @@ int mot_box_fit_resident(mot_ctx* ctx, float* boxes, int max_boxes, int* n_boxes
 int mot_ground_remove_pointcloud2(mot_ctx* ctx, const void* data, int n_points, int point_step, int off_x, int off_y, int off_z,
                                   float* elevated_xyzw, int* n_elevated, float* ground_xyzw, int* n_ground, uint8_t* mask);
 
+/* The stateless chain of one frame — fromROSMsg, groundRemove, componentClustering, boxFitting, as OT0/src/main.cpp:57-88 runs
+ * them in a single process — on a PointCloud2 payload in HOST memory: one upload, every intermediate stays in HBM (slot 0).
+ * Asynchronous; read the results back with mot_get_ground / mot_get_clusters / mot_get_boxes / mot_cluster_products(slot 0). */
+int mot_frame_pointcloud2(mot_ctx* ctx, const void* data, int n_points, int point_step, int off_x, int off_y, int off_z);
+
 /* replaces getOriginPoints(timestamp, originPoints, v_gps, yaw_gps), OT/include/imm_ukf_jpda.h:15.
  * origin6 = {x, y, yaw, x, y, yaw + pi/2}. Must be called before mot_track_step of the same frame,
  * like OT/tracking/main.cpp:74. */

@@ -17,6 +17,7 @@
 #include <visualization_msgs/MarkerArray.h>
 
 #include "mot_ros_common.hpp"
+#include "mot_ros_markers.hpp"
 
 namespace {
 
@@ -109,7 +110,7 @@ class ClusterNode {
     boxes_pub_.publish(box_msg);
 
     cubes_pub_.publish(cube_markers(elevated, n, num_cluster, n_boxes));
-    lines_pub_.publish(edge_marker(n_boxes));
+    lines_pub_.publish(mot_ros::box_edges("velodyne", boxes_.data(), n_boxes));
   }
 
   // one CUBE per box: centroid and axis-aligned extent of the cluster's points (mark_cluster, box_fitting.cpp:161-209)
@@ -148,28 +149,6 @@ class ClusterNode {
       out.markers.push_back(m);
     }
     return out;
-  }
-
-  // the 12 edges of every box as one LINE_LIST: per bottom corner k, (k, k+1), (k, k+4), (k+4, k+1+4) (main.cpp:178-231)
-  visualization_msgs::Marker edge_marker(int n_boxes) const {
-    visualization_msgs::Marker m;
-    m.header.frame_id = "velodyne";
-    m.header.stamp = ros::Time::now();
-    m.ns = "boxes"; m.id = 0;
-    m.type = visualization_msgs::Marker::LINE_LIST; m.action = visualization_msgs::Marker::ADD;
-    m.pose.orientation.w = 1.0;
-    m.scale.x = 0.1;
-    m.color.g = 1.0f; m.color.a = 1.0;
-    m.points.reserve(24 * (size_t)n_boxes);
-    for (int b = 0; b < n_boxes; b++) {
-      const float* c = &boxes_[(size_t)b * 24];
-      for (int k = 0; k < 4; k++) {
-        const int next = (k + 1) % 4;
-        const int ends[6] = {k, next, k, k + 4, k + 4, next + 4};
-        for (int e : ends) { geometry_msgs::Point p; p.x = c[3 * e]; p.y = c[3 * e + 1]; p.z = c[3 * e + 2]; m.points.push_back(p); }
-      }
-    }
-    return m;
   }
 
   mot_ctx* ctx_ = nullptr;

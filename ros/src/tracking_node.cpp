@@ -17,10 +17,9 @@
 #include <visualization_msgs/Marker.h>
 
 #include "mot_ros_common.hpp"
+#include "mot_ros_markers.hpp"
 
 namespace {
-
-const double kMarkerHeight = -1.73 / 2;   // where arrows and dots are drawn (main.cpp:232,300)
 
 class TrackingNode {
  public:
@@ -83,57 +82,11 @@ class TrackingNode {
     for (int i = 0; i < n_tracks; i++) targets.push_back(pcl::PointXYZ(tracks_[i].px, tracks_[i].py, tracks_[i].pz));
     pcl_ros::transformPointCloud("/velodyne", targets, targets_local, listener_);
 
-    publish_arrows(targets_local, n_tracks);
-    publish_dots(targets_local, n_tracks);
-  }
-
-  // a green arrow along the heading, as long as the speed, for every moving track whose box is shown (main.cpp:200-257)
-  void publish_arrows(const pcl::PointCloud<pcl::PointXYZ>& local, int n_tracks) {
-    for (int i = 0; i < n_tracks; i++) {
-      const mot_track& t = tracks_[i];
-      if (t.track_manage == 0 || !t.is_vis || t.is_static) continue;
-      visualization_msgs::Marker m;
-      m.lifetime = ros::Duration(0.1);
-      m.header.frame_id = "/velodyne";
-      m.header.stamp = ros::Time::now();
-      m.ns = "arrows"; m.id = i;
-      m.type = visualization_msgs::Marker::ARROW; m.action = visualization_msgs::Marker::ADD;
-      m.color.g = 1.0f; m.color.a = 1.0;
-      m.pose.position.x = local[i].x; m.pose.position.y = local[i].y; m.pose.position.z = kMarkerHeight;
-      tf::Matrix3x3 rotation;
-      rotation.setEulerYPR(t.yaw, 0, 0);
-      tf::Quaternion q;
-      rotation.getRotation(q);
-      m.pose.orientation.x = q.getX(); m.pose.orientation.y = q.getY(); m.pose.orientation.z = q.getZ(); m.pose.orientation.w = q.getW();
-      m.scale.x = t.v; m.scale.y = 0.1; m.scale.z = 0.1;
-      marker_pub_.publish(m);
-    }
-  }
-
-  // one POINTS marker per colour: blue = static, yellow = tentative (< 5), green = confirmed (5), red = coasting (> 5); ids 1-4
-  void publish_dots(const pcl::PointCloud<pcl::PointXYZ>& local, int n_tracks) {
-    enum { kYellow, kGreen, kRed, kBlue };
-    const float rgb[4][3] = {{1, 1, 0}, {0, 1, 0}, {1, 0, 0}, {0, 0, 1}};
-    visualization_msgs::Marker dots[4];
-    const ros::Time now = ros::Time::now();
-    for (int c = 0; c < 4; c++) {
-      visualization_msgs::Marker& m = dots[c];
-      m.header.frame_id = "velodyne"; m.header.stamp = now;
-      m.ns = "points"; m.id = c + 1;
-      m.type = visualization_msgs::Marker::POINTS; m.action = visualization_msgs::Marker::ADD;
-      m.pose.orientation.w = 1.0;
-      m.scale.x = 0.5; m.scale.y = 0.5;
-      m.color.r = rgb[c][0]; m.color.g = rgb[c][1]; m.color.b = rgb[c][2]; m.color.a = 1.0;
-    }
-    for (int i = 0; i < n_tracks; i++) {
-      const mot_track& t = tracks_[i];
-      if (t.track_manage == 0) continue;
-      geometry_msgs::Point p;
-      p.x = local[i].x; p.y = local[i].y; p.z = kMarkerHeight;
-      const int colour = t.is_static ? kBlue : t.track_manage < 5 ? kYellow : t.track_manage == 5 ? kGreen : kRed;
-      dots[colour].points.push_back(p);
-    }
-    for (int c = 0; c < 4; c++) marker_pub_.publish(dots[c]);
+    local_xy_.resize(2 * (size_t)n_tracks + 2);
+    for (int i = 0; i < n_tracks; i++) { local_xy_[2 * i] = targets_local[i].x; local_xy_[2 * i + 1] = targets_local[i].y; }
+    for (int i = 0; i < n_tracks; i++)
+      if (mot_ros::wants_arrow(tracks_[i])) marker_pub_.publish(mot_ros::track_arrow("/velodyne", tracks_[i], i, local_xy_[2 * i], local_xy_[2 * i + 1]));
+    for (const auto& m : mot_ros::track_dots("velodyne", tracks_.data(), n_tracks, local_xy_.data())) marker_pub_.publish(m);
   }
 
   mot_ros::Settings settings_;
@@ -144,7 +97,7 @@ class TrackingNode {
   ros::Publisher cloud_pub_, marker_pub_, marker2_pub_;
   ros::Subscriber boxes_sub_, odom_sub_;
   std::vector<mot_track> tracks_;
-  std::vector<float> boxes_global_;
+  std::vector<float> boxes_global_, local_xy_;
 };
 
 }  // namespace

@@ -52,8 +52,9 @@ def _cxx(args, what):
 
 
 def reference_nodes() -> dict:
+    """the three nodes of OT/ plus `pipeline0`, the single-process node of OT0/ (OT0/src/main.cpp)"""
     subprocess.run(["make", "-C", os.path.join(ROOT, "oracle"), "ref"], check=True, capture_output=True)
-    return {n: os.path.join(REF_BIN, n) for n in NODES}
+    return {n: os.path.join(REF_BIN, n) for n in list(NODES) + ["pipeline0"]}
 
 
 def recipe_nodes(lib: str) -> dict:
@@ -86,7 +87,7 @@ def own_nodes(lib: str, out_dir: str = OWN_BIN, link_extra=()) -> dict:
     os.makedirs(out_dir, exist_ok=True)
     out = {}
     common = [os.path.join(ROOT, "ros", "src", f) for f in os.listdir(os.path.join(ROOT, "ros", "src")) if f.endswith((".hpp", ".h"))]
-    for n in NODES:
+    for n in list(NODES) + ["pipeline"]:
         src = os.path.join(ROOT, "ros", "src", f"{n}_node.cpp")
         exe = os.path.join(out_dir, n)
         deps = [src, lib, os.path.join(ROOT, "include", "mot.h")] + common + _shim_files()
@@ -107,13 +108,13 @@ def hip_nodes() -> dict:
 
 def prebuilt(dirname: str):
     """{node: path} when all three executables exist in dirname, else None"""
-    out = {n: os.path.join(dirname, n) for n in NODES}
+    out = {n: os.path.join(dirname, n) for n in list(NODES) + ["pipeline0" if dirname == REF_BIN else "pipeline"]}
     return out if all(os.path.isfile(p) and os.access(p, os.X_OK) for p in out.values()) else None
 
 
-def run_node(exe: str, in_log: str, out_log: str, params: dict | None = None, timeout: int = 600):
+def run_node(exe: str, in_log: str, out_log: str, params: dict | None = None, timeout: int = 600, cwd: str | None = None):
     args = [exe, "--in", in_log, "--out", out_log] + [f"{k}:={v}" for k, v in (params or {}).items()]
-    r = subprocess.run(args, capture_output=True, text=True, timeout=timeout, errors="replace")
+    r = subprocess.run(args, capture_output=True, text=True, timeout=timeout, errors="replace", cwd=cwd)
     if r.returncode:
         raise RuntimeError(f"{exe} exited with {r.returncode}:\n{r.stderr[-2000:]}")
     return r

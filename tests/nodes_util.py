@@ -42,10 +42,10 @@ def relay(out, topic, dt):
     return recs
 
 
-def run(exe, recs, tmp, name, params=None):
+def run(exe, recs, tmp, name, params=None, cwd=None):
     i, o = str(tmp / (name + "_in.log")), str(tmp / (name + "_out.log"))
     R.write_log(i, recs)
-    NB.run_node(exe, i, o, params)
+    NB.run_node(exe, i, o, params, cwd=cwd)
     return R.read_log(o)
 
 
@@ -111,3 +111,35 @@ def check_against_reference(nodes, ref, synth, tmp):
     markers_close(ref["tracking_chain"], t0)
     t1 = run(nodes["tracking"], tracking_log(ref["cluster"]), tmp, "tracking_stamped")
     markers_close(ref["tracking_stamped"], t1)
+
+
+# ---------------------------------------------------------------- the single-process node of object_tracking0
+NF0 = 14
+
+
+def pipeline_setup(synth, tmp, n=60000):
+    """input log (`input` topic) and the working directory with the two ego-motion text files OT0 reads relative to it"""
+    import os
+    d = tmp / "src" / "object_tracking" / "src"
+    os.makedirs(d, exist_ok=True)
+    open(d / "ego_velo.txt", "w").write("".join("%.17g\n" % (3.0 + 0.05 * f) for f in range(NF0)))
+    open(d / "ego_yaw.txt", "w").write("".join("%.17g\n" % (1.22191 - 0.01 * f) for f in range(NF0)))
+    recs = []
+    for f in range(NF0):
+        c = np.concatenate([synth.make_cloud(n, 4, f), synth.edge_case_points()]).astype(np.float32)
+        recs += [("__now__", T0 + 0.1 * f + 0.01), ("input", "sensor_msgs/PointCloud2", R.pointcloud2(c, T0 + 0.1 * f, frame_id="velo_link", seq=f))]
+    return recs
+
+
+def check_pipeline(ref_exe, own_exe, synth, tmp):
+    import os
+    recs = pipeline_setup(synth, tmp)
+    os.makedirs(tmp / "a", exist_ok=True); os.makedirs(tmp / "b", exist_ok=True)
+    a = run(ref_exe, recs, tmp / "a", "pipeline", cwd=str(tmp))
+    b = run(own_exe, recs, tmp / "b", "pipeline", {"ego": "files"}, cwd=str(tmp))
+    same([r for r in a if r[0] == "output"], [r for r in b if r[0] == "output"])
+    ma, mb = [r for r in a if r[0] != "output"], [r for r in b if r[0] != "output"]
+    markers_close(ma, mb)
+    ns = [R.decode(ty, x)["ns"] for _, ty, x in ma]
+    assert ns.count("boxes") == NF0 and ns.count("points") == 4 * NF0
+    return ma

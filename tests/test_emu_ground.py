@@ -66,3 +66,6 @@ def test_emu_ground_remove_pointcloud2_and_resident_box_fit(mot, oracle, synth):
             ob = oracle.box_fit(p, g["elevated"], oracle.cluster(p, g["elevated"])["grid"], cl["num_cluster"])
             assert np.array_equal(bx["boxes"], ob["boxes"]) and len(bx["boxes"]) > 0
             assert np.array_equal(bx["boxes"], c.box_fit(r["elevated"], cl["grid"], cl["num_cluster"])["boxes"])
+            c.frame_pointcloud2(raw, n, step, 4, 8, 16)     # the three stages in one call, cloud resident throughout
+            assert np.array_equal(c.get_boxes(0)["boxes"], ob["boxes"])
+            assert np.array_equal(c.get_ground(0)["elevated"][:, :3], g["elevated"][:, :3])

@@ -50,3 +50,12 @@ def test_ground_node_parameters(emu_lib, ref_nodes, synth, tmp_path):
     prm = {"filter_z_max": 0.4, "filter_z_min": -1.9}
     recs = U.ground_log(synth)[:4]
     U.same(U.run(ref_nodes["ground"], recs, tmp_path, "ref", prm), U.run(own["ground"], recs, tmp_path, "own", prm))
+
+
+def test_pipeline_node_publishes_what_ot0_main_publishes(emu_lib, ref_nodes, synth, tmp_path):
+    """the single-process node (ros/src/pipeline_node.cpp: one upload, stages chained on the resident cloud) against
+    object_tracking0's own main.cpp (its four stages + tracker in one callback, ego motion from text files)"""
+    ma = U.check_pipeline(ref_nodes["pipeline0"], NB.own_nodes(emu_lib)["pipeline"], synth, tmp_path)
+    import roslog as R
+    shown = [len(R.decode(ty, x)["points"]) for _, ty, x in ma if R.decode(ty, x)["ns"] == "boxes"]
+    assert max(shown) > 0    # boxes of tracks older than lifeTimeThres_ = 8 were drawn
