@@ -151,3 +151,7 @@ def test_ground_remove_pointcloud2(mot, hip_lib, oracle, synth):
                 assert np.array_equal(r["elevated"][:, :3], g["elevated"][:, :3]) and np.array_equal(r["ground"][:, :3], g["ground"][:, :3])
                 assert np.all(r["elevated"][:, 3] == 1.0) and np.all(r["ground"][:, 3] == 1.0)
             assert len(c.ground_remove_pointcloud2(raw, 0, step, 4, 8, 16)["elevated"]) == 0
+            c.frame_pointcloud2(raw, n, step, 4, 8, 16)     # ground -> cluster -> box in one call on the resident cloud
+            cl = oracle.cluster(p, g["elevated"])
+            assert np.array_equal(c.get_boxes(0)["boxes"], oracle.box_fit(p, g["elevated"], cl["grid"], cl["num_cluster"])["boxes"])
+            assert np.array_equal(c.get_ground(0)["elevated"][:, :3], g["elevated"][:, :3])
