@@ -32,8 +32,16 @@ def have_reference() -> bool:
     return os.path.isfile(os.path.join(REF, "tracking", "main.cpp"))
 
 
-def _newer(target, deps):
+def _newer(target, deps, lib=None):
+    """up to date w.r.t. deps AND linked against the same library as last time (emulator vs its UBSan build vs libmot_hip.so)"""
+    stamp = target + ".lib"
+    if lib is not None and (not os.path.exists(stamp) or open(stamp).read() != lib):
+        return False
     return os.path.exists(target) and all(os.path.getmtime(d) <= os.path.getmtime(target) for d in deps if os.path.exists(d))
+
+
+def _stamp(target, lib):
+    open(target + ".lib", "w").write(lib)
 
 
 def _shim_files():
@@ -76,8 +84,9 @@ def recipe_nodes(lib: str) -> dict:
             open(gen, "w", encoding="utf-8").write(new)
         exe = os.path.join(REF_BIN, "recipe_" + n)
         deps = [gen, lib, os.path.join(ROOT, "include", "mot_adapters.hpp"), os.path.join(ROOT, "include", "mot.h")] + _shim_files()
-        if not _newer(exe, deps):
+        if not _newer(exe, deps, lib):
             _cxx(["-I", SHIM, "-I", os.path.join(REF, "tracking"), "-I", os.path.join(ROOT, "include"), gen, "-o", exe] + _link_args(lib), exe)
+            _stamp(exe, lib)
         out[n] = exe
     return out
 
@@ -91,9 +100,10 @@ def own_nodes(lib: str, out_dir: str = OWN_BIN, link_extra=()) -> dict:
         src = os.path.join(ROOT, "ros", "src", f"{n}_node.cpp")
         exe = os.path.join(out_dir, n)
         deps = [src, lib, os.path.join(ROOT, "include", "mot.h")] + common + _shim_files()
-        if not _newer(exe, deps):
+        if not _newer(exe, deps, lib):
             _cxx(["-I", SHIM, "-I", os.path.join(REF, "tracking"), "-I", os.path.join(ROOT, "include"), "-I", os.path.join(ROOT, "ros", "src"),
                   src, "-o", exe] + _link_args(lib) + list(link_extra), exe)
+            _stamp(exe, lib)
         out[n] = exe
     return out
 
