@@ -79,6 +79,32 @@ def cpu_baseline(synth, n_points, budget_s=12.0):
                       f"({os.cpu_count()} host cores present; the reference is single-threaded)"}
 
 
+def host_boundary(mot, synth, n_points, frames=40, lib_path=None, device=0):
+    """PCIe-INCLUSIVE rate of the host-buffer boundary (never the headline value): one stream, every frame starts as a
+    PointCloud2-style payload in pageable host memory, is uploaded (mot_frame_pointcloud2: unpack, ground removal, clustering,
+    box fit on the resident copy), its boxes are read back and the tracker steps on them — the per-frame sequence of the
+    single-process node (ros/src/pipeline_node.cpp) without the ROS glue. Wall clock per frame, synchronous."""
+    clouds = [np.ascontiguousarray(synth.make_cloud(n_points, 950, f)) for f in range(4)]
+    payload = [c.view(np.uint8).reshape(-1) for c in clouds]
+    kw = dict(lib_path=lib_path) if lib_path else dict(device=device)
+    with mot.Context(max_points=((n_points + 2047) // 2048) * 2048, max_batch=1, max_tracks_total=4096, **kw) as c:
+        def one(f):
+            c.frame_pointcloud2(payload[f % 4], n_points, 16, 0, 4, 8)
+            bx = c.get_boxes(0)["boxes"]
+            ts = 1.0e9 + f * 1.0e5
+            c.ego_update(ts, 0.0, 0.0)
+            return c.track_step(bx, ts)["n"]
+        for f in range(3):
+            one(f)
+        t0 = time.perf_counter()
+        for f in range(3, 3 + frames):
+            one(f)
+        dt = time.perf_counter() - t0
+    return {"value": round(frames / dt, 1), "unit": "frames/s", "ms_per_frame": round(dt / frames * 1e3, 4),
+            "what": f"1 stream, {frames} frames x {n_points} pts from pageable host memory: H2D of the raw records + ground/cluster/box + "
+                    "D2H of the boxes + tracker step + D2H of the tracks, synchronous per frame (PCIe-inclusive; not the headline value)"}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -238,6 +264,12 @@ def main():
                          "pipeline_bytes_per_frame": int(frame_bytes),
                          "pipeline_frac": round(frame_bytes * B / (dt / args.steps) / 1e9 / HBM_PEAK_GBS, 4)},
         }
+        if world == 1:
+            try:
+                out["host_boundary"] = host_boundary(mot, synth, N, device=local)
+            except Exception as e:   # an auxiliary figure must never cost the bench line
+                out["host_boundary"] = None
+                print(f"host_boundary measurement failed: {e}", file=sys.stderr)
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(synth, N)
         print(json.dumps(out))

@@ -69,3 +69,14 @@ def test_emu_ground_remove_pointcloud2_and_resident_box_fit(mot, oracle, synth):
             c.frame_pointcloud2(raw, n, step, 4, 8, 16)     # the three stages in one call, cloud resident throughout
             assert np.array_equal(c.get_boxes(0)["boxes"], ob["boxes"])
             assert np.array_equal(c.get_ground(0)["elevated"][:, :3], g["elevated"][:, :3])
+
+
+def test_bench_host_boundary_helper(mot, synth):
+    """bench.py's PCIe-inclusive side measurement, run here on the emulator library (small frames) so that the code path is
+    exercised before it meets a GPU"""
+    import importlib.util
+    import build_emu
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "bench.py"))
+    b = importlib.util.module_from_spec(spec); spec.loader.exec_module(b)
+    r = b.host_boundary(mot, synth, 6000, frames=3, lib_path=build_emu.build())
+    assert r["value"] > 0 and r["unit"] == "frames/s"
