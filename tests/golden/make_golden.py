@@ -58,6 +58,9 @@ def tracker_fixture(stream, nframes, npts, unit, ot0_workdir=None):
     """ot0_workdir: run object_tracking0's tracker instead (KITTI constants; it reads the ego motion from text files that
     Ref0Tracker writes under that directory); the boxes still come from the first package's chain (more of them)."""
     vs, yaws = 2.0 + 0.05 * np.arange(nframes), 0.004 * np.arange(nframes)
+    if ot0_workdir is not None:   # the package's own fixtures: ego speed / yaw of KITTI 2011_09_26_drive_0005, one value per frame
+        vs = np.loadtxt("/root/reference/object_tracking0/src/ego_velo.txt")[:nframes]
+        yaws = np.loadtxt("/root/reference/object_tracking0/src/ego_yaw.txt")[:nframes]
     if ot0_workdir is None:
         R = O.RefTracker(); R.reset()
     else:
@@ -88,7 +91,7 @@ def tracker_fixture(stream, nframes, npts, unit, ot0_workdir=None):
                 is_vis=np.stack(vis), pos=np.stack(pos), v_yaw=np.stack(vyaw), ego=np.stack(ego),
                 x_merge=np.stack([s[0] for s in states]), p_merge=np.stack([s[1] for s in states]),
                 mode_prob=np.stack([s[2] for s in states]), lifetime=np.stack([s[3] for s in states]),
-                n_tracks=np.array([s[4] for s in states], np.int32), unit=unit)
+                n_tracks=np.array([s[4] for s in states], np.int32), unit=unit, ego_v=vs, ego_yaw=yaws)
 
 
 if __name__ == "__main__":

@@ -10,6 +10,11 @@ TRACKERS = ("tracker_ot_us.npz", "tracker_ot_sec.npz")
 TRACKERS_OT0 = ("tracker_ot0_us.npz",)   # object_tracking0's tracker (preset 1)
 
 
+def ego_of(fx, f):
+    """ego speed and yaw fed to frame f when the fixture was generated"""
+    return float(fx["ego_v"][f]), float(fx["ego_yaw"][f])
+
+
 def load(name):
     return dict(np.load(os.path.join(GOLDEN, name)))
 

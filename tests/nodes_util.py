@@ -122,8 +122,12 @@ def pipeline_setup(synth, tmp, n=60000):
     import os
     d = tmp / "src" / "object_tracking" / "src"
     os.makedirs(d, exist_ok=True)
-    open(d / "ego_velo.txt", "w").write("".join("%.17g\n" % (3.0 + 0.05 * f) for f in range(NF0)))
-    open(d / "ego_yaw.txt", "w").write("".join("%.17g\n" % (1.22191 - 0.01 * f) for f in range(NF0)))
+    # the first values of the package's own fixtures OT0/src/ego_velo.txt / ego_yaw.txt (KITTI drive_0005)
+    velo = (3.51477, 3.48864, 3.46854, 3.40843, 3.34564, 3.30648, 3.28052, 3.23173, 3.20755, 3.18877, 3.16731, 3.16198, 3.14918, 3.12115)
+    yaw = (-1.22191, -1.20608, -1.19362, -1.18118, -1.16722, -1.1547, -1.14217, -1.1288, -1.11721, -1.10575, -1.09323, -1.08131, -1.07012, -1.05775)
+    assert len(velo) == NF0 and len(yaw) == NF0
+    open(d / "ego_velo.txt", "w").write("".join("%.17g\n" % v for v in velo))
+    open(d / "ego_yaw.txt", "w").write("".join("%.17g\n" % v for v in yaw))
     recs = []
     for f in range(NF0):
         c = np.concatenate([synth.make_cloud(n, 4, f), synth.edge_case_points()]).astype(np.float32)

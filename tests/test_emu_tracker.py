@@ -20,7 +20,7 @@ def test_emu_tracker_golden(mot, name):
     with mot.Context(mot.params(int(ot0), lib=mot.load_library(lib)), lib_path=lib, max_points=4096, max_tracks_total=256) as c:
         for f in range(18 if ot0 else 14):
             ts = 1.0e9 + f * float(fx["unit"])
-            ego = c.ego_update(ts, 2.0 + 0.05 * f, 0.004 * f)
+            ego = c.ego_update(ts, *G.ego_of(fx, f))
             assert np.allclose(ego, fx["ego"][f], rtol=1e-12, atol=1e-12)
             out = c.track_step(fx["boxes"][f][: fx["n_boxes"][f]], ts)
             G.check_tracker_frame(fx, f, out, lambda i: c.track_state(i), rtol=1e-6)

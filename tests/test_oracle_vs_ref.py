@@ -34,7 +34,7 @@ def test_restatement_matches_golden_tracker(oracle, name):
     T = oracle.Tracker(oracle.params(int(name in G.TRACKERS_OT0)))
     for f in range(len(fx["n_boxes"])):
         ts = 1.0e9 + f * float(fx["unit"])
-        ego = T.ego_update(ts, 2.0 + 0.05 * f, 0.004 * f)
+        ego = T.ego_update(ts, *G.ego_of(fx, f))
         assert np.allclose(ego, fx["ego"][f], rtol=1e-12, atol=1e-12)
         out = T.step(fx["boxes"][f][: fx["n_boxes"][f]], ts)
         G.check_tracker_frame(fx, f, out, T.state, rtol=1e-7)
@@ -166,7 +166,8 @@ def test_tracker_ot0_vs_ref0(oracle, synth, tmp_path):
     _need_ref(oracle)
     p0, p1 = oracle.params(0), oracle.params(1)
     nf = 40
-    velo = 4.0 + 0.05 * np.arange(nf); yaw = 1.22191 - 0.012 * np.arange(nf)
+    # the package's own fixtures (ego motion of KITTI drive_0005, one value per frame)
+    velo = np.loadtxt("/root/reference/object_tracking0/src/ego_velo.txt")[:nf]; yaw = np.loadtxt("/root/reference/object_tracking0/src/ego_yaw.txt")[:nf]
     T = oracle.Tracker(p1); R = oracle.Ref0Tracker(); R.reset(tmp_path, velo, yaw)
     try:
         seen = 0

@@ -23,7 +23,7 @@ def test_golden_tracker_sequences(ctx, name):
     ctx.reset()
     for f in range(len(fx["n_boxes"])):
         ts = 1.0e9 + f * float(fx["unit"])
-        ego = ctx.ego_update(ts, 2.0 + 0.05 * f, 0.004 * f)
+        ego = ctx.ego_update(ts, *G.ego_of(fx, f))
         assert np.allclose(ego, fx["ego"][f], rtol=1e-12, atol=1e-12)
         out = ctx.track_step(fx["boxes"][f][: fx["n_boxes"][f]], ts)
         G.check_tracker_frame(fx, f, out, lambda i: ctx.track_state(i), rtol=RTOL)
@@ -36,7 +36,7 @@ def test_golden_tracker_sequences_ot0(mot, hip_lib, name):
     with mot.Context(mot.params(1), max_points=4096, max_tracks_total=512) as c:
         for f in range(len(fx["n_boxes"])):
             ts = 1.0e9 + f * float(fx["unit"])
-            ego = c.ego_update(ts, 2.0 + 0.05 * f, 0.004 * f)
+            ego = c.ego_update(ts, *G.ego_of(fx, f))
             assert np.allclose(ego, fx["ego"][f], rtol=1e-12, atol=1e-12)
             out = c.track_step(fx["boxes"][f][: fx["n_boxes"][f]], ts)
             G.check_tracker_frame(fx, f, out, lambda i: c.track_state(i), rtol=RTOL)
