@@ -46,9 +46,13 @@ inline bool xyz_offsets(const sensor_msgs::PointCloud2& m, int off[3]) {
   return off[0] >= 0 && off[1] >= 0 && off[2] >= 0;
 }
 
-// the records of a (possibly organised, possibly row-padded) cloud as one contiguous run of width*height records
+// the records of a (possibly organised, possibly row-padded) cloud as one contiguous run of width*height records;
+// throws when the message's sizes do not add up (a truncated payload must not become an out-of-bounds read)
 inline const uint8_t* records(const sensor_msgs::PointCloud2& m, std::vector<uint8_t>& scratch) {
   const size_t row = (size_t)m.width * m.point_step;
+  const size_t need = m.height <= 1 ? row * m.height : (size_t)(m.height - 1) * m.row_step + row;
+  if (m.point_step < 12 || (m.height > 1 && m.row_step < row) || m.data.size() < need)
+    throw std::runtime_error("malformed PointCloud2: width/height/point_step/row_step do not fit the payload");
   if (m.height <= 1 || m.row_step == row) return m.data.data();
   scratch.resize(row * m.height);
   for (uint32_t r = 0; r < m.height; r++) std::memcpy(scratch.data() + r * row, m.data.data() + (size_t)r * m.row_step, row);

@@ -59,3 +59,25 @@ def test_pipeline_node_publishes_what_ot0_main_publishes(emu_lib, ref_nodes, syn
     import roslog as R
     shown = [len(R.decode(ty, x)["points"]) for _, ty, x in ma if R.decode(ty, x)["ns"] == "boxes"]
     assert max(shown) > 0    # boxes of tracks older than lifeTimeThres_ = 8 were drawn
+
+
+def test_nodes_edge_messages(emu_lib, ref_nodes, synth, tmp_path):
+    """an empty scan, an organised scan (2 rows, padded rows) and a truncated one"""
+    import numpy as np
+    import roslog as R
+    own = NB.own_nodes(emu_lib)
+    c = synth.make_cloud(8000, 5, 0).astype(np.float32)
+    empty = R.pointcloud2(c[:0], U.T0)
+    org = R.pointcloud2(c, U.T0 + 0.1)
+    rows = np.zeros((2, 4000 * 16 + 48), np.uint8)
+    rows[:, :4000 * 16] = org["data"].reshape(2, -1)
+    org.update(height=2, width=4000, row_step=4000 * 16 + 48, data=rows.reshape(-1))
+    recs = [("__now__", U.T0), ("velodyne_points", "sensor_msgs/PointCloud2", empty), ("__now__", U.T0 + 0.1), ("velodyne_points", "sensor_msgs/PointCloud2", org)]
+    g_ref, g_own = U.run(ref_nodes["ground"], recs, tmp_path, "g_ref"), U.run(own["ground"], recs, tmp_path, "g_own")
+    U.same(g_ref, g_own)
+    relay = U.relay(g_ref, "none_ground_topic", 0.02)
+    U.same(U.run(ref_nodes["cluster"], relay, tmp_path, "c_ref"), U.run(own["cluster"], relay, tmp_path, "c_own"))
+    bad = dict(org); bad["data"] = org["data"][:1000]
+    R.write_log(str(tmp_path / "bad.log"), [("velodyne_points", "sensor_msgs/PointCloud2", bad)])
+    with pytest.raises(RuntimeError, match="malformed PointCloud2"):
+        NB.run_node(own["ground"], str(tmp_path / "bad.log"), str(tmp_path / "bad_out.log"))
