@@ -81,3 +81,47 @@ def test_nodes_edge_messages(emu_lib, ref_nodes, synth, tmp_path):
     R.write_log(str(tmp_path / "bad.log"), [("velodyne_points", "sensor_msgs/PointCloud2", bad)])
     with pytest.raises(RuntimeError, match="malformed PointCloud2"):
         NB.run_node(own["ground"], str(tmp_path / "bad.log"), str(tmp_path / "bad_out.log"))
+
+
+def test_nodes_on_adversarial_clouds(emu_lib, ref_nodes, oracle, tmp_path):
+    """small hostile scans through the ground and cluster nodes, one message each: NaN / Inf / denormal / huge coordinates,
+    points on cell, ring and crop boundaries, duplicates, single points. Frames on which the REFERENCE box fit reads
+    uninitialised memory (the library rejects such clusters and reports them) are screened out with the
+    restatement's `n_undefined` count — the reference's output is not defined there."""
+    import numpy as np
+    import roslog as R
+    own = NB.own_nodes(emu_lib)
+    rng = np.random.default_rng(2024)
+    special = np.array([0.0, -0.0, np.nan, np.inf, -np.inf, 1e-40, -1e-40, 3.4, -3.4, 120.0, -120.0, 25.0, -25.0, 24.999998, -24.999998, 1e9,
+                        3.4028235e38, 0.2, 0.1, 8.0, -5.0, 4.5, 2.0, -15.0, 5.0, -50.0, 50.0, 4.9999995, -14.999999], np.float32)
+    zs = np.array([np.nan, np.inf, -2.0, -0.4, -1.75, 0.1, 1.0, -3.0, 1.0000001, -3.0000002, -99.0], np.float32)
+
+    def cloud(k):
+        n = int(rng.integers(0, 160))
+        a = np.zeros((n, 4), np.float32)
+        for col in (0, 1):
+            pick = rng.random(n)
+            a[:, col] = np.where(pick < 0.3, rng.choice(special, n), np.where(pick < 0.65, rng.uniform(-130, 130, n), rng.uniform(-30, 30, n))).astype(np.float32)
+        a[:, 2] = np.where(rng.random(n) < 0.3, rng.choice(zs, n), rng.uniform(-4, 3, n)).astype(np.float32)
+        return np.repeat(a, int(rng.integers(1, 40 if k % 2 else 4)), axis=0)
+
+    clouds = [cloud(k) for k in range(80)]
+    recs = []
+    for k, c in enumerate(clouds):
+        recs += [("__now__", U.T0 + k), ("velodyne_points", "sensor_msgs/PointCloud2", R.pointcloud2(c, U.T0 + k, seq=k))]
+    g_ref = U.run(ref_nodes["ground"], recs, tmp_path, "g_ref")
+    U.same(g_ref, U.run(own["ground"], recs, tmp_path, "g_own"))
+    # cluster node: the same clouds as elevated clouds (so that clusters exist), restricted to what a ground node can emit
+    # (finite, inside the 120 m ring: the reference's cost map indexes with unchecked casts of the coordinates), minus
+    # the frames with undefined reference behaviour in the box fit
+    p = oracle.params(0)
+    recs, kept = [], 0
+    for k, c in enumerate(clouds):
+        c = c[np.isfinite(c[:, :3]).all(1) & (np.abs(c[:, :2]) <= 120).all(1)]
+        cl = oracle.cluster(p, c)
+        if oracle.box_fit(p, c, cl["grid"], cl["num_cluster"])["n_undefined"]:
+            continue
+        kept += 1
+        recs += [("__now__", U.T0 + k), ("none_ground_topic", "sensor_msgs/PointCloud2", R.pointcloud2(c[:, :3], 0.0, seq=0))]
+    assert kept > 20
+    U.same(U.run(ref_nodes["cluster"], recs, tmp_path, "c_ref"), U.run(own["cluster"], recs, tmp_path, "c_own"))
