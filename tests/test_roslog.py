@@ -70,3 +70,18 @@ def test_cxx_codecs_match_python_codec(tmp_path):
     for (t, ty, b), (t2, ty2, b2) in zip(recs, out):
         assert (t, ty) == (t2, ty2) and b == b2, t
         assert R.encode(ty, R.decode(ty, b)) == b
+
+
+def test_tf_shim_identities(tmp_path):
+    """the restated tf / pcl_ros slice (oracle/ref_shim/tf, pcl_ros): rotation matrices, quaternion round trips, both lookup
+    directions of the node's one edge, ros::Time / Duration conversions"""
+    import pytest
+    eigen = "/root/reference/object_tracking/tracking"
+    if not os.path.isdir(eigen):
+        pytest.skip("needs the reference's vendored Eigen")
+    exe = str(tmp_path / "selftest_tf")
+    r = subprocess.run(["g++", "-std=c++14", "-O1", "-ffp-contract=off", "-w", "-I", os.path.join(ROOT, "oracle", "ref_shim"), "-I", eigen,
+                        os.path.join(ROOT, "oracle", "ref_shim", "selftest_tf.cpp"), "-o", exe], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-3000:]
+    r = subprocess.run([exe], capture_output=True, text=True)
+    assert r.returncode == 0 and r.stdout.strip() == "ok", r.stdout[-2000:]
