@@ -2,8 +2,8 @@
 
   reference  oracle/_ref/bin/{ground,cluster,tracking}      the reference's main.cpp + its own algorithm sources (oracle/Makefile)
   recipe     oracle/_ref/bin/recipe_{ground,cluster,tracking}   the reference's main.cpp with the ONE edit INTEGRATION.md prescribes
-             (the include of the algorithm header replaced by "mot_adapters.hpp", written by sed into the git-ignored
-             oracle/_ref/gen/), linked against the C-ABI library
+             (the include of the algorithm header replaced by "mot_adapters.hpp"; the edited text goes to the compiler through
+             a pipe — no copy of a reference source is ever written into this repository), linked against the C-ABI library
   own        tests/emu/bin/{ground,cluster,tracking}        this repository's ros/src/*_node.cpp, linked against the C-ABI library
 
 All of them are compiled against the file-backed mini-ROS of oracle/ref_shim and run as `<node> --in IN.log --out OUT.log`.
@@ -19,7 +19,6 @@ ROOT = os.path.dirname(HERE)
 REF = "/root/reference/object_tracking"
 SHIM = os.path.join(ROOT, "oracle", "ref_shim")
 REF_BIN = os.path.join(ROOT, "oracle", "_ref", "bin")
-GEN = os.path.join(ROOT, "oracle", "_ref", "gen")
 OWN_BIN = os.path.join(HERE, "emu", "bin")
 HIP_BIN = os.path.join(ROOT, "ros", "bin")     # the same node sources linked against libmot_hip.so: prebuilt here, run on the GPU box
 HIP_LIB = os.path.join(ROOT, "3d-lidar-multi-object-tracking_amd", "libmot_hip.so")
@@ -53,8 +52,8 @@ def _link_args(lib):
     return ["-L", d, "-l:" + f, "-Wl,-rpath," + d]
 
 
-def _cxx(args, what):
-    r = subprocess.run(["g++"] + FLAGS + args, capture_output=True, text=True)
+def _cxx(args, what, stdin_source=None):
+    r = subprocess.run(["g++"] + FLAGS + args, capture_output=True, text=True, input=stdin_source)
     if r.returncode:
         raise RuntimeError(f"building {what} failed:\n{r.stderr[-4000:]}")
 
@@ -67,25 +66,23 @@ def reference_nodes() -> dict:
 
 def recipe_nodes(lib: str) -> dict:
     """the reference's node sources with only their algorithm includes swapped for the adapter header"""
-    os.makedirs(GEN, exist_ok=True); os.makedirs(REF_BIN, exist_ok=True)
+    os.makedirs(REF_BIN, exist_ok=True)
     out = {}
+    pat = re.compile(r'^#include "(%s)"\s*$' % "|".join(re.escape(h) for h in ALGO_HEADERS), re.M)
     for n, rel in NODES.items():
-        src = open(os.path.join(REF, rel), encoding="utf-8", errors="replace").read()
-        pat = re.compile(r'^#include "(%s)"\s*$' % "|".join(re.escape(h) for h in ALGO_HEADERS), re.M)
-        assert pat.search(src), rel
-        first = [True]
-        def swap(m):
-            if first[0]:
-                first[0] = False; return '#include "mot_adapters.hpp"'
-            return ""
-        gen = os.path.join(GEN, f"recipe_{n}.cpp")
-        new = pat.sub(swap, src)
-        if not os.path.exists(gen) or open(gen, encoding="utf-8").read() != new:
-            open(gen, "w", encoding="utf-8").write(new)
+        path = os.path.join(REF, rel)
         exe = os.path.join(REF_BIN, "recipe_" + n)
-        deps = [gen, lib, os.path.join(ROOT, "include", "mot_adapters.hpp"), os.path.join(ROOT, "include", "mot.h")] + _shim_files()
+        deps = [path, lib, os.path.join(ROOT, "include", "mot_adapters.hpp"), os.path.join(ROOT, "include", "mot.h"), os.path.abspath(__file__)] + _shim_files()
         if not _newer(exe, deps, lib):
-            _cxx(["-I", SHIM, "-I", os.path.join(REF, "tracking"), "-I", os.path.join(ROOT, "include"), gen, "-o", exe] + _link_args(lib), exe)
+            src = open(path, encoding="utf-8", errors="replace").read()
+            assert pat.search(src), rel
+            first = [True]
+            def swap(m):
+                if first[0]:
+                    first[0] = False; return '#include "mot_adapters.hpp"'
+                return ""
+            _cxx(["-I", SHIM, "-I", os.path.join(REF, "tracking"), "-I", os.path.join(ROOT, "include"), "-x", "c++", "-", "-o", exe] + _link_args(lib),
+                 exe, stdin_source=pat.sub(swap, src))
             _stamp(exe, lib)
         out[n] = exe
     return out
