@@ -219,6 +219,53 @@ def test_min_area_rect_properties(oracle):
         assert np.array_equal(r2.astype(np.float32), oracle.min_area_rect_points(pts))
 
 
+def test_min_area_rect_is_the_exact_minimum(oracle):
+    """the restated cv::minAreaRect against the DEFINITION: for integer points the minimum-area enclosing rectangle has a
+    side on a hull edge, and its area over every hull edge is computable exactly in rationals. The restatement's rectangle
+    must have that area (to float32 rounding). This pins the function mathematically; OpenCV's own rounding and corner
+    order stay unpinned (no OpenCV here)."""
+    from fractions import Fraction
+
+    def hull(pts):
+        pts = sorted(set((int(x), int(y)) for x, y in pts))
+        if len(pts) <= 2:
+            return pts
+        cross = lambda o, a, b: (a[0] - o[0]) * (b[1] - o[1]) - (a[1] - o[1]) * (b[0] - o[0])
+        lo, up = [], []
+        for q in pts:
+            while len(lo) >= 2 and cross(lo[-2], lo[-1], q) <= 0: lo.pop()
+            lo.append(q)
+        for q in reversed(pts):
+            while len(up) >= 2 and cross(up[-2], up[-1], q) <= 0: up.pop()
+            up.append(q)
+        return lo[:-1] + up[:-1]
+
+    def exact_min_area(pts):
+        h = hull(pts)
+        if len(h) < 3:
+            return Fraction(0)
+        best = None
+        for i in range(len(h)):
+            a, b = h[i], h[(i + 1) % len(h)]
+            ex, ey = b[0] - a[0], b[1] - a[1]
+            us = [(q[0] - a[0]) * ex + (q[1] - a[1]) * ey for q in h]; vs = [-(q[0] - a[0]) * ey + (q[1] - a[1]) * ex for q in h]
+            area = Fraction((max(us) - min(us)) * (max(vs) - min(vs)), ex * ex + ey * ey)
+            best = area if best is None or area < best else best
+        return best
+
+    rng = np.random.default_rng(5)
+    for trial in range(600):
+        n = int(rng.integers(3, 60))
+        pts = rng.integers(-200, 200, size=(n, 2)).astype(np.int32)
+        if trial % 3 == 0:
+            pts[:, 1] = pts[:, 0] // 2 + rng.integers(-3, 3, size=n)   # thin, slanted
+        r = oracle.min_area_rect_points(pts).astype(np.float64)
+        e0, e1 = r[1] - r[0], r[2] - r[1]
+        area = abs(e0[0] * e1[1] - e0[1] * e1[0])
+        exact = float(exact_min_area(pts))
+        assert abs(area - exact) <= 1e-4 * max(exact, 1.0), (trial, area, exact)
+
+
 def test_hull_column_reduction(oracle):
     """the device path feeds cv::convexHull only the lowest / highest pixel of every pixel column (already sorted);
     the restated OpenCV hull and min-area rectangle must be unchanged by that reduction"""
