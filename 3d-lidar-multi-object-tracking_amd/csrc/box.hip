@@ -67,7 +67,7 @@ __global__ void stats_init_kernel(ClusterBuffers c) {
   int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i < kMaxClusters) {
     ClusterStats s;
-    s.count = 0; s.first = 0x7fffffff; s.maxz_key = mot_float_key(-99.f); s.pad = 0;
+    s.count = 0; s.first = 0x7fffffff; s.maxz_key = mot_float_key(-99.f); s.first_zero = 0x7fffffff;
     s.argmin = kArgminInit; s.argmax = kArgmaxInit;
     c.stats[(long)b * kMaxClusters + i] = s;
   }
@@ -155,6 +155,9 @@ label_stats_kernel(MotDevParams p, ClusterBuffers c) {
       pix[i] = (int)((unsigned)((picX >= 0 && picX < 1024) ? picX : 0xffff) | ((unsigned)picY << 16));   // only points inside the ROI (0 <= picY <= 900) are ever read back
     }
     if (lab > kMaxClusters) lab = 0;  // no statistics slot: box_finalize_kernel raises the capacity flag
+    // `if (pZ > maxZ) maxZ = pZ` (:286) keeps the FIRST of equal maxima, and equal maxima can differ only as -0 / +0: the keyed
+    // maximum below folds both onto +0, so the (rare) zero heights leave the index of their first occurrence behind
+    if (lab > 0 && q.z == 0.0f) atomicMin(&stats[lab - 1].first_zero, (int)i);
     float m = q.y / q.x + 0.0f;  // slope, :264 (+0 makes -0 == +0 for the keyed compare, as `<` does)
     // `m < minM` with minM = 999 / `m > maxM` with maxM = -999 (NaN never compares); "first occurrence wins" (strict
     // compares, :268-280) = the lowest lane among those holding the extreme key
@@ -496,7 +499,8 @@ cluster_gather_kernel(MotDevParams p, ClusterBuffers c) {
     const float4 pmin = pts[(unsigned)(st.argmin & 0xffffffffull)];
     const float4 pmax = pts[~(unsigned)(st.argmax & 0xffffffffull)];
     const float minMx = pmin.x, minMy = pmin.y, maxMx = pmax.x, maxMy = pmax.y;
-    const float maxZ = mot_key_float(st.maxz_key);
+    float maxZ = mot_key_float(st.maxz_key);
+    if (maxZ == 0.0f && st.first_zero != 0x7fffffff) maxZ = pts[st.first_zero].z;   // -0 or +0, whichever came first
     cand.max_z = maxZ;
     const float xDist = maxMx - minMx, yDist = maxMy - minMy;  // :296-300
     const float slopeDist = sqrtf(xDist * xDist + yDist * yDist);
@@ -961,7 +965,7 @@ box_finalize_kernel(MotDevParams p, ClusterBuffers c) {
     // re-arm the statistics of the clusters just consumed
     if (ci < num_cluster) {
       ClusterStats s;
-      s.count = 0; s.first = 0x7fffffff; s.maxz_key = mot_float_key(-99.f); s.pad = 0;
+      s.count = 0; s.first = 0x7fffffff; s.maxz_key = mot_float_key(-99.f); s.first_zero = 0x7fffffff;
       s.argmin = kArgminInit; s.argmax = kArgmaxInit;
       c.stats[(long)b * kMaxClusters + ci] = s;
     }

@@ -97,8 +97,8 @@ enum { kFlagClusterOverflow = 1, kFlagBoxOverflow = 2, kFlagRngExhausted = 4, kF
 struct ClusterStats {          // per cluster, accumulated by the label kernel, reset by the finalize kernel
   int count;                   // numPoints
   int first;                   // smallest point index (clusteredPoints[i][0])
-  int maxz_key;                // ordered key of max z (init key(-99))
-  int pad;
+  int maxz_key;                // ordered key of max z (init key(-99)); -0 and +0 share the key of +0
+  int first_zero;              // smallest index of a point with z == +-0 (0x7fffffff if none): the sign of a zero maximum
   unsigned long long argmin;   // (key(m) << 32) | idx        -> minimum = smallest slope, first occurrence
   unsigned long long argmax;   // (key(m) << 32) | ~idx       -> maximum = largest slope, first occurrence
 };

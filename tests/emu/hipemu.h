@@ -7,7 +7,12 @@
 // parity claim rests on it — the parity tests are the `-m gpu` tests that run the real kernels.
 //
 // Model: blocks run one after another; the threads of a block are ucontext fibers scheduled round-robin;
-// __syncthreads() and the wave-collective operations (64-lane waves) are rendezvous points. Because IEEE
+// __syncthreads() and the wave-collective operations (64-lane waves) are rendezvous points.
+// A fiber runs until its next rendezvous, so in the default (ascending) order a thread always sees what lower-numbered
+// threads wrote before THEIR next rendezvous — a missing barrier between such a write and read goes unnoticed. The
+// environment variable MOT_EMU_SCHED changes the order in which the fibers of a block are resumed: "rev" (descending) or
+// "rand:<seed>" (a fresh permutation on every sweep). A kernel whose result depends on that order has a race (or relies on
+// intra-wave lockstep without a wave-level synchronisation); the emulator tests are run in all three modes. Because IEEE
 // fp32/fp64 +,-,*,/,sqrt are identical on x86-64 (no FMA contraction) and gfx950 (-ffp-contract=off,
 // correctly rounded divide/sqrt), arithmetic results under emulation equal the device's.
 #ifndef HIPEMU_H_
@@ -22,6 +27,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <algorithm>
 #include <functional>
 #include <vector>
 
@@ -150,6 +156,20 @@ inline T shfl(T v, int src) {
   return out;
 }
 
+// 0 = ascending, 1 = descending, 2 = random (seeded)
+struct Sched { int mode = 0; uint64_t rng = 0x9E3779B97F4A7C15ull; };
+inline Sched& sched_cfg() {
+  static Sched c = [] {
+    Sched k;
+    const char* e = getenv("MOT_EMU_SCHED");
+    if (e && !strncmp(e, "rev", 3)) k.mode = 1;
+    else if (e && !strncmp(e, "rand", 4)) { k.mode = 2; const char* c = strchr(e, ':'); if (c) k.rng ^= strtoull(c + 1, nullptr, 10) * 0xD1342543DE82EF95ull + 1; }
+    return k;
+  }();
+  return c;
+}
+inline uint64_t sched_next(Sched& c) { c.rng ^= c.rng << 13; c.rng ^= c.rng >> 7; c.rng ^= c.rng << 17; return c.rng; }
+
 template <typename F>
 inline void launch(dim3 grid, dim3 block, F&& f) {
   State& s = S();
@@ -178,9 +198,14 @@ inline void launch(dim3 grid, dim3 block, F&& f) {
         }
         int live = s.nthreads;
         long spins = 0;
+        Sched& sc = sched_cfg();
+        std::vector<int> order(s.nthreads);
+        for (int t = 0; t < s.nthreads; t++) order[t] = sc.mode == 1 ? s.nthreads - 1 - t : t;
         while (live > 0) {
           live = 0;
-          for (int t = 0; t < s.nthreads; t++) {
+          if (sc.mode == 2) for (int t = s.nthreads - 1; t > 0; t--) std::swap(order[t], order[sched_next(sc) % (uint64_t)(t + 1)]);
+          for (int k = 0; k < s.nthreads; k++) {
+            const int t = order[k];
             Thread& th = s.threads[t];
             if (th.done) continue;
             s.cur = &th;

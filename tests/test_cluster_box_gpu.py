@@ -232,3 +232,23 @@ def test_box_fit_resident(ctx, oracle, synth):
     o = oracle.box_fit(p, e, oracle.cluster(p, e)["grid"], cl["num_cluster"])
     assert len(o["boxes"]) > 0 and np.array_equal(a["boxes"], o["boxes"]) and np.array_equal(b["boxes"], o["boxes"])
     assert np.array_equal(a["box_cluster"], b["box_cluster"])
+
+ZERO_HEIGHT_CASES = ([np.nan, np.nan, np.nan, -0.0, np.nan, np.nan], [np.nan, 0.0, np.nan, -0.0, np.nan, np.nan], [-1.0, -0.0, 0.0, -0.5, np.nan, np.nan],
+                     [-1.0, -2.0, -0.0, -0.0, 0.0, np.nan], [0.5, -0.0, 0.0, np.nan, np.nan, np.nan], [-0.0] * 6, [0.0] + [-0.0] * 5)
+
+
+def _zero_height_cloud(zs):
+    pts = [(0.0, 0.0, z) for z in zs[:4]] + [(0.0, 0.5, zs[4]), (0.5, 0.0, zs[5])]
+    a = np.zeros((len(pts), 4), np.float32); a[:, :3] = np.array(pts, np.float32)
+    return np.repeat(a, 5, axis=0)
+
+
+def test_box_height_sign_of_zero(ctx, oracle):
+    """`if (pZ > maxZ) maxZ = pZ` keeps the first of equal maxima; -0 and +0 are equal: the box's top face carries the sign of
+    the FIRST zero of the cluster"""
+    p = oracle.params(0)
+    for zs in ZERO_HEIGHT_CASES:
+        e = _zero_height_cloud(zs)
+        o = oracle.cluster(p, e)
+        b = ctx.box_fit(e, o["grid"], o["num_cluster"]); ob = oracle.box_fit(p, e, o["grid"], o["num_cluster"])
+        assert len(ob["boxes"]) == 1 and np.array_equal(b["boxes"].view(np.uint32), ob["boxes"].view(np.uint32)), zs

@@ -89,3 +89,24 @@ def test_emu_shuffled_many_clusters(mot, emu_lib, oracle):
         assert r["num_cluster"] == o["num_cluster"] and np.array_equal(r["grid"], o["grid"])
         b = c.box_fit(cloud, o["grid"], o["num_cluster"]); ob = oracle.box_fit(p, cloud, o["grid"], o["num_cluster"])
         assert np.array_equal(b["boxes"], ob["boxes"]) and np.array_equal(b["box_cluster"], ob["box_cluster"])
+
+ZERO_HEIGHT_CASES = ([np.nan, np.nan, np.nan, -0.0, np.nan, np.nan], [np.nan, 0.0, np.nan, -0.0, np.nan, np.nan], [-1.0, -0.0, 0.0, -0.5, np.nan, np.nan],
+                     [-1.0, -2.0, -0.0, -0.0, 0.0, np.nan], [0.5, -0.0, 0.0, np.nan, np.nan, np.nan], [-0.0] * 6, [0.0] + [-0.0] * 5)
+
+
+def _zero_height_cloud(zs):
+    pts = [(0.0, 0.0, z) for z in zs[:4]] + [(0.0, 0.5, zs[4]), (0.5, 0.0, zs[5])]
+    a = np.zeros((len(pts), 4), np.float32); a[:, :3] = np.array(pts, np.float32)
+    return np.repeat(a, 5, axis=0)
+
+
+def test_emu_box_height_sign_of_zero(mot, emu_lib, oracle):
+    """`if (pZ > maxZ) maxZ = pZ` keeps the first of equal maxima; -0 and +0 are equal: the box's top face must carry the sign
+    of the FIRST zero of the cluster (found by the hypothesis tests: the keyed maximum alone returned +0)"""
+    p = oracle.params(0)
+    with mot.Context(lib_path=emu_lib, max_points=4096) as c:
+        for zs in ZERO_HEIGHT_CASES:
+            e = _zero_height_cloud(zs)
+            o = oracle.cluster(p, e)
+            b = c.box_fit(e, o["grid"], o["num_cluster"]); ob = oracle.box_fit(p, e, o["grid"], o["num_cluster"])
+            assert len(ob["boxes"]) == 1 and np.array_equal(b["boxes"].view(np.uint32), ob["boxes"].view(np.uint32)), zs
