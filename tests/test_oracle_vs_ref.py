@@ -194,6 +194,45 @@ def test_tracker_ot0_vs_ref0(oracle, synth, tmp_path):
         R.close(); T.close()
 
 
+@pytest.mark.parametrize("preset", [0, 1])
+def test_restatement_vs_ref_tracker_random_sequences(oracle, preset, tmp_path):
+    """the restated tracker against the reference's own tracker sources (object_tracking for preset 0, object_tracking0 for
+    preset 1) on randomised box sequences: moving / stopping / vanishing objects, over-segmentation, crowded gates, clutter —
+    the branches the synthetic scenes rarely reach"""
+    _need_ref(oracle)
+    import test_emu_tracker_random as RS
+    p = oracle.params(preset)
+    for seed in range(5000 * preset, 5000 * preset + 25 * RS.SCALE):
+        seq = RS.sequence(seed)
+        T = oracle.Tracker(p)
+        if preset == 0:
+            R = oracle.RefTracker(); R.reset()
+        else:
+            R = oracle.Ref0Tracker(); R.reset(tmp_path, [s[2] for s in seq], [s[3] for s in seq])
+        try:
+            for f, (boxes, ts, v, yaw) in enumerate(seq):
+                ea = T.ego_update(ts, v, yaw); er = R.ego_update(ts, v, yaw) if preset == 0 else R.ego_update(ts)
+                assert np.allclose(ea, er, rtol=1e-12, atol=1e-12)
+                a = T.step(boxes, ts); r = R.step(boxes, ts)
+                assert a["n"] == r["n"] and np.array_equal(a["track_manage"], r["track_manage"]), (seed, f)
+                assert np.array_equal(a["is_static"], r["is_static"]) and np.array_equal(a["is_vis"], r["is_vis"]), (seed, f)
+                assert np.array_equal(a["vis_box"], r["vis_box"]), (seed, f)
+                for i in range(a["n"]):
+                    if r["track_manage"][i] == 0:
+                        continue
+                    sa, sr = T.state(i), R.state(i)
+                    assert sa["lifetime"] == sr["lifetime"]
+                    if not RS.well_conditioned(sr):
+                        continue
+                    for k in ("x_merge", "p_merge", "mode_prob"):
+                        scale = max(np.abs(sr[k]).max(), 1e-300)
+                        assert np.abs(sa[k] - sr[k]).max() <= 1e-6 * scale + 1e-12, (seed, f, i, k)
+        finally:
+            T.close()
+            if preset == 1:
+                R.close()
+
+
 def test_min_area_rect_properties(oracle):
     """the restated cv::minAreaRect is 'parity unpinned' (no OpenCV here): at least check what a minimum-area
     rectangle must satisfy — contains every point, area <= axis-aligned bounding box, duplicate invariance."""
