@@ -61,3 +61,59 @@ def test_cluster_box_side_match_oracle(emu_ctx, oracle, pts, reps):
     sd = emu_ctx.cluster_products_host(elev, o["grid"]); osd = oracle.cluster_products(p, elev, o["grid"])
     for k in ("clustered", "obstacles", "cost_map"):
         assert sd[k].shape == osd[k].shape and np.array_equal(sd[k], osd[k]), k
+
+
+# ---------------------------------------------------------------- the other configurations: pre-filter on, KITTI-tuned preset
+CROP_SPECIAL = [-15.0, 5.0, -50.0, 50.0, -14.999999, 4.9999995, -49.999996, 49.999996, -15.000001, 5.0000005]
+crop_coord = st.one_of(st.sampled_from(SPECIAL + CROP_SPECIAL), st.floats(-60, 60, width=32), st.floats(-16, 6, width=32))
+crop_z = st.one_of(st.sampled_from([np.nan, np.inf, -3.0, 1.0, -3.0000002, 1.0000001, -2.9999998, 0.99999994, -2.0, -0.4, 0.0, -0.0]), st.floats(-4, 2, width=32))
+
+
+@pytest.fixture(scope="module")
+def emu_ctx_crop(mot):
+    import build_emu
+    lib = build_emu.build()
+    c = mot.Context(mot.params(0, lib=mot.load_library(lib), crop_enable=1), lib_path=lib, max_points=8192, max_batch=1)
+    yield c
+    c.close()
+
+
+@pytest.fixture(scope="module")
+def emu_ctx_ot0(mot):
+    import build_emu
+    lib = build_emu.build()
+    c = mot.Context(mot.params(1, lib=mot.load_library(lib)), lib_path=lib, max_points=8192, max_batch=1)
+    yield c
+    c.close()
+
+
+@settings(max_examples=150 * SCALE, deadline=None, suppress_health_check=[HealthCheck.function_scoped_fixture, HealthCheck.too_slow])
+@given(pts=st.lists(st.tuples(crop_coord, crop_coord, crop_z), min_size=0, max_size=120), reps=st.integers(1, 3), step=st.sampled_from([16, 20, 32]))
+def test_ground_stage_with_prefilter_from_raw_records(emu_ctx_crop, oracle, pts, reps, step):
+    """the `ground` node's path: raw PointCloud2 records -> device unpack -> PassThrough / ConditionalRemoval fused -> ground removal"""
+    p = oracle.params(0, crop_enable=1)
+    cloud = _cloud(pts, reps); n = len(cloud)
+    raw = np.full((max(n, 1), step), 0xA5, np.uint8)
+    offs = (0, 4, 8) if step == 16 else (step - 12, step - 8, step - 4)
+    for k, off in enumerate(offs):
+        raw[:n, off:off + 4] = cloud[:, k].copy().view(np.uint8).reshape(n, 4)
+    r = emu_ctx_crop.ground_remove_pointcloud2(raw, n, step, *offs)
+    g = oracle.ground_remove(p, oracle.crop(p, cloud))
+    assert np.array_equal(r["elevated"][:, :3].view(np.uint32), g["elevated"][:, :3].view(np.uint32))
+    assert np.array_equal(r["ground"][:, :3].view(np.uint32), g["ground"][:, :3].view(np.uint32))
+
+
+@settings(max_examples=150 * SCALE, deadline=None, suppress_health_check=[HealthCheck.function_scoped_fixture, HealthCheck.too_slow])
+@given(pts=st.lists(point, min_size=0, max_size=150), reps=st.integers(1, 120))
+def test_ot0_preset_matches_oracle(emu_ctx_ot0, oracle, pts, reps):
+    """object_tracking0's constants: 200 x 200 grid over 30 m, any-point occupancy without dilation, 100-point clusters"""
+    p = oracle.params(1)
+    cloud = _cloud(pts, min(reps, 3))
+    r = emu_ctx_ot0.ground_remove(cloud); g = oracle.ground_remove(p, cloud)
+    assert np.array_equal(r["mask"], g["mask"]) and np.array_equal(r["elevated"].view(np.uint32), g["elevated"].view(np.uint32))
+    elev = _cloud(pts, reps)
+    c = emu_ctx_ot0.cluster(elev); o = oracle.cluster(p, elev)
+    assert c["num_cluster"] == o["num_cluster"] and np.array_equal(c["grid"], o["grid"]) and np.array_equal(c["point_label"], o["point_label"])
+    b = emu_ctx_ot0.box_fit(elev, o["grid"], o["num_cluster"]); ob = oracle.box_fit(p, elev, o["grid"], o["num_cluster"])
+    assert b["n_undefined"] == ob["n_undefined"] and np.array_equal(b["box_cluster"], ob["box_cluster"])
+    assert np.array_equal(b["boxes"].view(np.uint32), ob["boxes"].view(np.uint32))
