@@ -233,6 +233,45 @@ def test_restatement_vs_ref_tracker_random_sequences(oracle, preset, tmp_path):
                 R.close()
 
 
+def test_restatement_vs_ref_on_adversarial_clouds(oracle):
+    """the stateless stages of the restatement against the reference's own sources on small hostile clouds (NaN / Inf /
+    denormal / huge coordinates, ring and cell boundaries, duplicates, signed zeros). The cluster and box stages get finite
+    points only — what a ground stage can emit; box fits in which the reference reads uninitialised memory (SURVEY.md H7,
+    counted by the restatement) are skipped."""
+    _need_ref(oracle)
+    import test_emu_tracker_random as RS
+    rng = np.random.default_rng(99)
+    special = np.array([0.0, -0.0, np.nan, np.inf, -np.inf, 1e-40, -1e-40, 3.4, -3.4, 120.0, -120.0, 25.0, -25.0, 24.999998, -24.999998, 1e9,
+                        3.4028235e38, 0.2, 0.1, 8.0, -5.0, 4.5, 2.0], np.float32)
+    zs = np.array([np.nan, np.inf, -np.inf, -2.0, -0.4, -1.75, 0.1, 1000.0, -99.0, 0.0, -0.0], np.float32)
+    p = oracle.params(0)
+
+    def cloud():
+        n = int(rng.integers(0, 150)); a = np.zeros((n, 4), np.float32)
+        for col in (0, 1):
+            pick = rng.random(n)
+            a[:, col] = np.where(pick < 0.3, rng.choice(special, n), np.where(pick < 0.65, rng.uniform(-130, 130, n), rng.uniform(-30, 30, n))).astype(np.float32)
+        a[:, 2] = np.where(rng.random(n) < 0.3, rng.choice(zs, n), rng.uniform(-4, 3, n)).astype(np.float32)
+        return a
+
+    boxes_checked = 0
+    for it in range(300 * RS.SCALE):
+        c = np.repeat(cloud(), int(rng.integers(1, 4)), axis=0)
+        g = oracle.ground_remove(p, c); r = oracle.ref_ground_remove(c)
+        assert np.array_equal(g["elevated"][:, :3].view(np.uint32), r["elevated"][:, :3].view(np.uint32)), it
+        assert np.array_equal(g["ground"][:, :3].view(np.uint32), r["ground"][:, :3].view(np.uint32)), it
+        e = np.repeat(cloud(), int(rng.integers(1, 40)), axis=0)
+        e = e[np.isfinite(e[:, :3]).all(1)]
+        o = oracle.cluster(p, e); rc = oracle.ref_cluster(e)
+        assert o["num_cluster"] == rc["num_cluster"] and np.array_equal(o["grid"], rc["grid"]), it
+        ob = oracle.box_fit(p, e, o["grid"], o["num_cluster"])
+        if ob["n_undefined"] == 0:
+            rb = oracle.ref_box_fit(e, o["grid"], o["num_cluster"])
+            assert np.array_equal(ob["boxes"].view(np.uint32), rb["boxes"].view(np.uint32)), it
+            boxes_checked += 1   # frames whose box stage was compared (most of these small clouds yield candidates that the size rules reject: also compared)
+    assert boxes_checked > 50
+
+
 def test_min_area_rect_properties(oracle):
     """the restated cv::minAreaRect is 'parity unpinned' (no OpenCV here): at least check what a minimum-area
     rectangle must satisfy — contains every point, area <= axis-aligned bounding box, duplicate invariance."""
