@@ -57,3 +57,34 @@ def test_emu_large_irregular_clouds(mot, oracle, preset):
             sd = c.cluster_products(0); osd = oracle.cluster_products(p, og["elevated"], ocl["grid"])
             for k in ("clustered", "obstacles", "cost_map"):
                 assert sd[k].shape == osd[k].shape and np.array_equal(sd[k], osd[k]), (seed, k)
+
+
+def test_emu_ragged_batch_of_irregular_clouds(mot, oracle):
+    """mot_frames_dev on a batch of frames of very different sizes (one of them empty, one tiny) with the tracker on: every
+    slot must equal the restatement run on that frame alone"""
+    import build_emu
+    lib = build_emu.build()
+    p = oracle.params(0)
+    B, stride = 4, 65536
+    with mot.Context(lib_path=lib, max_points=stride, max_batch=B, max_tracks_total=512) as c:
+        Ts = [oracle.Tracker(p) for _ in range(B)]
+        for f in range(2 * SCALE):
+            clouds = [big_cloud(700 + 10 * f + b)[: [stride, 0, 37, 9000][b]] for b in range(B)]
+            host = np.zeros((B, stride, 4), np.float32)
+            for b in range(B):
+                host[b, : len(clouds[b])] = clouds[b]
+            ts = [2.0e8 + f * 1e5] * B
+            c.frames_dev(host.ctypes.data, stride * 4, [len(x) for x in clouds], run_tracker=True, timestamps=ts, ego_v=[1.0] * B, ego_yaw=[0.0] * B)
+            for b in range(B):
+                og = oracle.ground_remove(p, clouds[b]); ocl = oracle.cluster(p, og["elevated"])
+                obx = oracle.box_fit(p, og["elevated"], ocl["grid"], ocl["num_cluster"])["boxes"]
+                g = c.get_ground(b)
+                assert np.array_equal(g["elevated"], og["elevated"]) and np.array_equal(g["ground"], og["ground"]), (f, b)
+                assert np.array_equal(c.get_boxes(b)["boxes"], obx), (f, b)
+                ego = Ts[b].ego_update(ts[b], 1.0, 0.0)
+                co, si = np.cos(-ego[2]), np.sin(-ego[2])
+                gb = obx.astype(np.float64).copy()
+                dx, dy = gb[..., 0] - ego[0], gb[..., 1] - ego[1]
+                gb[..., 0] = co * dx - si * dy; gb[..., 1] = si * dx + co * dy
+                o = Ts[b].step(gb.astype(np.float32), ts[b]); a = c.get_tracks(b)
+                assert a["n"] == o["n"] and np.array_equal(a["track_manage"], o["track_manage"]), (f, b)
