@@ -1,0 +1,69 @@
+"""Error convention of the C-ABI (int status + mot_last_error, never abort), exercised on the emulator build:
+argument checks and capacity limits are host code shared with the GPU build."""
+import ctypes as C
+import os
+import sys
+
+import numpy as np
+import pytest
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "emu"))
+
+
+@pytest.fixture(scope="module")
+def emu(mot):
+    import build_emu
+    lib = build_emu.build()
+    return lib, mot.load_library(lib)
+
+
+def test_create_rejects_bad_arguments(mot, emu):
+    lib, L = emu
+    h = C.c_void_p()
+    p = mot.params(0, lib=L)
+    assert L.mot_create(None, 0, 1024, 1, 16, C.byref(h)) == mot.MOT_E_ARG
+    assert L.mot_create(C.byref(p), 0, 0, 1, 16, C.byref(h)) == mot.MOT_E_ARG          # no capacity
+    assert L.mot_create(C.byref(p), 0, 1024, 0, 16, C.byref(h)) == mot.MOT_E_ARG       # no stream slot
+    assert L.mot_create(C.byref(p), 7, 1024, 1, 16, C.byref(h)) == mot.MOT_E_ARG       # device ordinal out of range
+    for field, value in (("num_grid", 4), ("num_grid", 100000), ("gauss_samples", 5), ("ram_points", 0), ("pic_scale", 1000.0)):
+        q = mot.params(0, lib=L, **{field: value})
+        assert L.mot_create(C.byref(q), 0, 1024, 1, 16, C.byref(h)) == mot.MOT_E_ARG, field
+    assert not h.value
+
+
+def test_calls_report_capacity_and_argument_errors(mot, emu, synth):
+    lib, L = emu
+    with mot.Context(lib_path=lib, max_points=2048, max_batch=2, max_tracks_total=4) as c:
+        big = synth.make_cloud(5000, 1, 0)
+        with pytest.raises(mot.MotError) as e:
+            c.ground_remove(big)
+        assert e.value.code == mot.MOT_E_CAPACITY and "max_points" in str(e.value)
+        with pytest.raises(mot.MotError) as e:
+            c.cluster(big)
+        assert e.value.code == mot.MOT_E_CAPACITY
+        with pytest.raises(mot.MotError) as e:
+            c.ground_remove_pointcloud2(np.zeros(16 * 10, np.uint8), 10, 16, 0, 4, 14)     # z field sticks out of the record
+        assert e.value.code == mot.MOT_E_ARG
+        with pytest.raises(mot.MotError) as e:
+            c.track_state(0)                                                              # no such track yet
+        assert e.value.code == mot.MOT_E_ARG
+        with pytest.raises(mot.MotError) as e:
+            c.frames_dev(big.ctypes.data, 2048 * 4, [100, 100, 100])                      # more frames than slots
+        assert e.value.code == mot.MOT_E_ARG
+        n1 = np.array([100], np.int32)   # tracker without stamps / ego motion (the Python wrapper always passes them: call the ABI)
+        assert L.mot_frames_dev(c._h, C.c_void_p(big.ctypes.data), C.c_long(2048 * 4), n1.ctypes.data_as(C.c_void_p), 1, 1, None, None, None) == mot.MOT_E_ARG
+        assert b"run_tracker needs" in L.mot_last_error(c._h)
+        # more tracks than provisioned: the reference never frees a track, so births beyond max_tracks_total are a capacity error
+        boxes = np.zeros((12, 8, 3), np.float32)
+        for k in range(12):
+            boxes[k, :, :2] = np.array([[0, 0], [2, 0], [2, 1], [0, 1]] * 2) + [6.0 * k - 30, 5.0]
+            boxes[k, 4:, 2] = 1.0; boxes[k, :4, 2] = -2.0
+        with pytest.raises(mot.MotError) as e:
+            for f in range(6):
+                ts = 1.0e9 + f * 1e5
+                c.ego_update(ts, 0.0, 0.0); c.track_step(boxes, ts)
+        assert e.value.code == mot.MOT_E_CAPACITY
+        # the context stays usable after an error
+        c.reset()
+        small = synth.make_cloud(1500, 1, 0)
+        assert len(c.ground_remove(small)["mask"]) == 1500
