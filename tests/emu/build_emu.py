@@ -12,9 +12,14 @@ CSRC = os.path.join(ROOT, "3d-lidar-multi-object-tracking_amd", "csrc")
 #   MOT_EMU_SANITIZE=1 python -m pytest tests/test_emu_*.py tests/test_distributed_cpu.py
 # float-cast-overflow is excluded: (int) of a NaN / huge float is defined on the GPU (saturating) and every such result is
 # discarded by a range test before use.
-SANITIZE = bool(os.environ.get("MOT_EMU_SANITIZE"))
-SAN_FLAGS = ["-fsanitize=undefined", "-fno-sanitize=float-cast-overflow", "-fno-sanitize-recover=undefined"] if SANITIZE else []
-LIB = os.path.join(HERE, "libmot_emu_ubsan.so" if SANITIZE else "libmot_emu.so")
+SANITIZE = os.environ.get("MOT_EMU_SANITIZE", "")
+# MOT_EMU_SANITIZE=address: AddressSanitizer instead — every "device" buffer is a heap allocation, so an out-of-bounds global
+# load / store of a kernel (silent on the GPU until it faults) is reported with the kernel's source line. Needs the runtime
+# preloaded into python:  LD_PRELOAD=$(gcc -print-file-name=libasan.so) ASAN_OPTIONS=detect_leaks=0 MOT_EMU_SANITIZE=address pytest ...
+ASAN = SANITIZE == "address"
+SAN_FLAGS = (["-fsanitize=address", "-fno-omit-frame-pointer"] if ASAN else
+             ["-fsanitize=undefined", "-fno-sanitize=float-cast-overflow", "-fno-sanitize-recover=undefined"] if SANITIZE else [])
+LIB = os.path.join(HERE, "libmot_emu_asan.so" if ASAN else "libmot_emu_ubsan.so" if SANITIZE else "libmot_emu.so")
 
 
 def sources():
@@ -31,7 +36,7 @@ def build(force: bool = False) -> str:
         return LIB
     objs = []
     for s in srcs:
-        o = os.path.join(HERE, ("objsan_" if SANITIZE else "obj_") + s.replace(".hip", ".o"))
+        o = os.path.join(HERE, ("objasan_" if ASAN else "objsan_" if SANITIZE else "obj_") + s.replace(".hip", ".o"))
         cmd = ["g++", "-std=c++17", "-O1", "-g", "-fPIC"] + SAN_FLAGS + [ "-ffp-contract=off", "-fno-fast-math", "-DMOT_HIPEMU=1", "-x", "c++",
                "-include", os.path.join(HERE, "hipemu.h"), "-I", CSRC, "-Wall", "-Wno-unused-function", "-Wno-unknown-pragmas",
                "-Wno-unused-variable", "-c", os.path.join(CSRC, s), "-o", o]

@@ -80,3 +80,26 @@ def test_bench_host_boundary_helper(mot, synth):
     b = importlib.util.module_from_spec(spec); spec.loader.exec_module(b)
     r = b.host_boundary(mot, synth, 6000, frames=3, lib_path=build_emu.build())
     assert r["value"] > 0 and r["unit"] == "frames/s"
+
+
+@pytest.mark.parametrize("cap", [1, 63, 64, 65, 4095, 4096, 4097, 8191])
+def test_emu_frames_that_fill_the_capacity_exactly(mot, oracle, synth, cap):
+    """n == max_points for capacities around the 64-point and 4096-point granularities of the kernels (under
+    MOT_EMU_SANITIZE=address an out-of-bounds access of the padded tails would be reported)"""
+    import build_emu
+    lib = build_emu.build()
+    p = oracle.params(0)
+    cloud = synth.make_cloud(max(cap, 64), 6, 0)[:cap]
+    with mot.Context(lib_path=lib, max_points=cap, max_batch=2, max_tracks_total=64) as c:
+        r = c.ground_remove(cloud); g = oracle.ground_remove(p, cloud)
+        assert np.array_equal(r["mask"], g["mask"]) and np.array_equal(r["elevated"], g["elevated"]) and np.array_equal(r["ground"], g["ground"])
+        e = np.repeat(cloud[: max(cap // 4, 1)], 4, axis=0)[:cap]; e[:, 2] = 0.0   # an elevated cloud that also fills the capacity
+        cl = c.cluster(e); ocl = oracle.cluster(p, e)
+        assert cl["num_cluster"] == ocl["num_cluster"] and np.array_equal(cl["grid"], ocl["grid"]) and np.array_equal(cl["point_label"], ocl["point_label"])
+        assert np.array_equal(c.box_fit_resident()["boxes"], oracle.box_fit(p, e, ocl["grid"], ocl["num_cluster"])["boxes"])
+        host = np.zeros((2, c.max_points if hasattr(c, "max_points") else cap, 4), np.float32)
+        stride = host.shape[1]
+        host[0, :cap] = cloud; host[1, :cap] = cloud[::-1]
+        c.frames_dev(host.ctypes.data, stride * 4, [cap, cap])
+        assert np.array_equal(c.get_ground(0)["elevated"], g["elevated"])
+        assert np.array_equal(c.get_ground(1)["elevated"], oracle.ground_remove(p, cloud[::-1])["elevated"])
