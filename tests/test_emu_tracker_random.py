@@ -59,6 +59,43 @@ def sequence(seed, frames=14):
     return out
 
 
+def hostile_sequence(seed, frames=16):
+    """four steady objects plus, per frame, one degenerate input: an exact duplicate measurement, a zero-area box, a box
+    10 km away, an empty frame, every box three times, a near-duplicate 0.1 mm off"""
+    rng = np.random.default_rng(seed); out = []
+    base = [box(rng.uniform(-20, 20), rng.uniform(-20, 20), rng.uniform(0.5, 3), rng.uniform(0.5, 5), rng.uniform(-3, 3), 0.3) for _ in range(4)]
+    for f in range(frames):
+        bs = [b.copy() for b in base]
+        for b in bs:
+            b[:, :2] += f * 0.2
+        kind = int(rng.integers(0, 6))
+        if kind == 0: bs.append(bs[0].copy())
+        if kind == 1: z = bs[1].copy(); z[:, :2] = z[0, :2]; bs.append(z)
+        if kind == 2: h = bs[2].copy(); h[:, :2] *= 1e4; bs.append(h)
+        if kind == 3: bs = []
+        if kind == 4: bs = bs * 3
+        if kind == 5: t = bs[3].copy(); t[:, :2] += 1e-4; bs.append(t)
+        out.append((np.array(bs, np.float32).reshape(-1, 8, 3), 1e9 + f * 1e5, 1.0, 0.0))
+    return out
+
+
+@pytest.mark.parametrize("preset", [0, 1])
+def test_emu_tracker_degenerate_measurements(mot, oracle, preset):
+    import build_emu
+    lib = build_emu.build()
+    p = oracle.params(preset)
+    with mot.Context(mot.params(preset, lib=mot.load_library(lib)), lib_path=lib, max_points=4096, max_tracks_total=2048) as c:
+        for seed in range(8 * SCALE):
+            c.reset(); T = oracle.Tracker(p)
+            for f, (boxes, ts, v, yaw) in enumerate(hostile_sequence(seed)):
+                c.ego_update(ts, v, yaw); T.ego_update(ts, v, yaw)
+                a = c.track_step(boxes, ts); o = T.step(boxes, ts)
+                assert a["n"] == o["n"], (seed, f)
+                for k in ("track_manage", "is_static", "is_vis", "lifetime", "vis_box"):
+                    assert np.array_equal(a[k], o[k]), (seed, f, k)
+            T.close()
+
+
 @pytest.mark.parametrize("preset", [0, 1])
 def test_emu_tracker_random_sequences(mot, oracle, preset):
     import build_emu

@@ -206,8 +206,8 @@ def test_restatement_vs_ref_tracker_random_sequences(oracle, preset, tmp_path):
     _need_ref(oracle)
     import test_emu_tracker_random as RS
     p = oracle.params(preset)
-    for seed in range(5000 * preset, 5000 * preset + 25 * RS.SCALE):
-        seq = RS.sequence(seed)
+    for seed in range(5000 * preset, 5000 * preset + 30 * RS.SCALE):
+        seq = RS.sequence(seed) if seed % 6 else RS.hostile_sequence(seed)   # every sixth: degenerate measurements
         T = oracle.Tracker(p)
         if preset == 0:
             R = oracle.RefTracker(); R.reset()
