@@ -155,5 +155,5 @@ def test_fused_frames_with_tracker(mot, hip_lib, oracle, synth):
                 a = c.get_tracks(b)
                 assert a["n"] == o["n"] and np.array_equal(a["track_manage"], o["track_manage"]), (f, b)
                 live = o["track_manage"] > 0
-                assert np.allclose(a["p"][live], o["p"][live], rtol=1e-3, atol=1e-4)
+                assert np.allclose(a["p"][live], o["p"][live], rtol=RTOL, atol=1e-5)   # the 1e-4 bar; the box transform is the same fp64 expression on both sides
             dev.free()
