@@ -34,7 +34,11 @@
 #define __global__
 #define __device__
 #define __host__
-#define __shared__ static
+// every __shared__ variable lands in one ELF section, which launch() fills with 0xFF before each workgroup starts: on the GPU
+// LDS holds whatever the previous workgroup left there, so a kernel that reads LDS it has not written must not get zeros here
+#define __shared__ __attribute__((section("mot_lds"))) static
+extern "C" __attribute__((visibility("hidden"))) char __start_mot_lds[];
+extern "C" __attribute__((visibility("hidden"))) char __stop_mot_lds[];
 #define __constant__ static const
 #define __forceinline__ inline
 #define __launch_bounds__(...)
@@ -184,6 +188,7 @@ inline void launch(dim3 grid, dim3 block, F&& f) {
     for (unsigned by = 0; by < grid.y; by++)
       for (unsigned bx = 0; bx < grid.x; bx++) {
         s.bid = dim3(bx, by, bz);
+        memset(__start_mot_lds, 0xFF, (size_t)(__stop_mot_lds - __start_mot_lds));   // LDS arrives dirty
         s.alive = s.nthreads; s.bar_count = 0; s.bar_gen = 0;
         for (int w = 0; w < nw; w++) { s.waves[w] = Wave(); s.waves[w].alive = std::min(kWave, s.nthreads - w * kWave); }
         for (int t = 0; t < s.nthreads; t++) {
