@@ -184,9 +184,15 @@ inline void launch(dim3 grid, dim3 block, F&& f) {
   int nw = (s.nthreads + kWave - 1) / kWave;
   s.waves.assign(nw, Wave());
   s.body = f;
-  for (unsigned bz = 0; bz < grid.z; bz++)
-    for (unsigned by = 0; by < grid.y; by++)
-      for (unsigned bx = 0; bx < grid.x; bx++) {
+  // workgroups run one after another; MOT_EMU_SCHED=rev / rand also reverses / shuffles the order in which they are started (the
+  // GPU promises none: a kernel whose workgroups wait for each other by blockIdx instead of by an arrival ticket would hang here)
+  const unsigned long nblocks = (unsigned long)grid.x * grid.y * grid.z;
+  std::vector<unsigned long> border(nblocks);
+  for (unsigned long i = 0; i < nblocks; i++) border[i] = sched_cfg().mode == 1 ? nblocks - 1 - i : i;
+  if (sched_cfg().mode == 2) for (unsigned long i = nblocks; i > 1; i--) std::swap(border[i - 1], border[sched_next(sched_cfg()) % i]);
+  for (unsigned long bi = 0; bi < nblocks; bi++) {
+      {
+        const unsigned bx = (unsigned)(border[bi] % grid.x), by = (unsigned)((border[bi] / grid.x) % grid.y), bz = (unsigned)(border[bi] / ((unsigned long)grid.x * grid.y));
         s.bid = dim3(bx, by, bz);
         memset(__start_mot_lds, 0xFF, (size_t)(__stop_mot_lds - __start_mot_lds));   // LDS arrives dirty
         s.alive = s.nthreads; s.bar_count = 0; s.bar_gen = 0;
@@ -220,6 +226,7 @@ inline void launch(dim3 grid, dim3 block, F&& f) {
           if (++spins > 50000000L) { fprintf(stderr, "hipemu: block (%u,%u,%u) appears deadlocked\n", bx, by, bz); abort(); }
         }
       }
+  }
   s.cur = nullptr;
 }
 }  // namespace hipemu
