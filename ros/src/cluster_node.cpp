@@ -25,8 +25,8 @@ const int kMaxBoxes = 1024;   // the library's per-frame limit
 
 class ClusterNode {
  public:
-  explicit ClusterNode(ros::NodeHandle& nh) {
-    mot_ros::Settings s = mot_ros::settings(nh);
+  ClusterNode(ros::NodeHandle& nh, ros::NodeHandle& pnh) {
+    mot_ros::Settings s = mot_ros::settings(pnh);
     if (mot_params_preset(s.preset, &prm_) != MOT_OK) throw std::runtime_error("unknown preset");
     mot_side_params_default(&side_);
     ctx_ = mot_ros::create(prm_, s);
@@ -166,9 +166,9 @@ class ClusterNode {
 
 int main(int argc, char** argv) {
   ros::init(argc, argv, "cluster");
-  ros::NodeHandle nh;
+  ros::NodeHandle nh, private_nh("~");   // topics and the reference's own parameters: public names; this node's extras: ~device, ~preset, ...
   try {
-    ClusterNode node(nh);
+    ClusterNode node(nh, private_nh);
     ros::spin();
   } catch (const std::exception& e) {   // no GPU, a capacity limit, a malformed message: say so and stop (required="true" in the launch file)
     std::cerr << "cluster: " << e.what() << std::endl;

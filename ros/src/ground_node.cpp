@@ -19,12 +19,12 @@ namespace {
 
 class GroundNode {
  public:
-  explicit GroundNode(ros::NodeHandle& nh) {
-    mot_ros::Settings s = mot_ros::settings(nh);
+  GroundNode(ros::NodeHandle& nh, ros::NodeHandle& pnh) {
+    mot_ros::Settings s = mot_ros::settings(pnh);
     float z_max, z_min;
     nh.param<float>("filter_z_max", z_max, 1.0);
     nh.param<float>("filter_z_min", z_min, -3.0);
-    nh.param<bool>("propagate_stamp", propagate_stamp_, false);
+    pnh.param<bool>("propagate_stamp", propagate_stamp_, false);
     if (mot_params_preset(s.preset, &prm_) != MOT_OK) throw std::runtime_error("unknown preset");
     prm_.crop_enable = 1; prm_.crop_z_min = z_min; prm_.crop_z_max = z_max;   // x in (-15, 5), y in (-50, 50): the preset's values
     ctx_ = mot_ros::create(prm_, s);
@@ -88,9 +88,9 @@ class GroundNode {
 
 int main(int argc, char** argv) {
   ros::init(argc, argv, "ground");
-  ros::NodeHandle nh;
+  ros::NodeHandle nh, private_nh("~");   // topics and the reference's own parameters: public names; this node's extras: ~device, ~preset, ...
   try {
-    GroundNode node(nh);
+    GroundNode node(nh, private_nh);
     ros::spin();
   } catch (const std::exception& e) {   // no GPU, a capacity limit, a malformed message: say so and stop (required="true" in the launch file)
     std::cerr << "ground: " << e.what() << std::endl;

@@ -19,7 +19,8 @@ inline void check(mot_ctx* ctx, int rc, const char* what) {
   if (rc != MOT_OK) throw std::runtime_error(std::string(what) + ": " + mot_last_error(ctx));
 }
 
-// private parameters common to the three nodes: ~device (HIP ordinal), ~max_points, ~preset (0 = object_tracking, 1 = object_tracking0)
+// private parameters common to the nodes (read from a NodeHandle("~")): ~device (HIP ordinal), ~max_points, ~preset
+// (0 = object_tracking, 1 = object_tracking0), ~max_tracks_total
 struct Settings { int device = 0, max_points = 262144, preset = MOT_PRESET_OBJECT_TRACKING, max_tracks_total = 16384; };
 inline Settings settings(const ros::NodeHandle& nh) {
   Settings s;

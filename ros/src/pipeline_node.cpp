@@ -29,16 +29,16 @@ const int kMaxBoxes = 1024;
 
 class PipelineNode {
  public:
-  explicit PipelineNode(ros::NodeHandle& nh) : listener_(ros::Duration(10)) {
-    mot_ros::Settings s = mot_ros::settings(nh);
-    nh.param<int>("preset", s.preset, MOT_PRESET_OBJECT_TRACKING0);
-    nh.param<std::string>("frame", frame_, "velo_link");
+  PipelineNode(ros::NodeHandle& nh, ros::NodeHandle& pnh) : listener_(ros::Duration(10)) {
+    mot_ros::Settings s = mot_ros::settings(pnh);
+    pnh.param<int>("preset", s.preset, MOT_PRESET_OBJECT_TRACKING0);
+    pnh.param<std::string>("frame", frame_, "velo_link");
     std::string ego;
-    nh.param<std::string>("ego", ego, "odom");
+    pnh.param<std::string>("ego", ego, "odom");
     if (ego == "files") {
       std::string velo, yaw;
-      nh.param<std::string>("ego_velo_file", velo, "./src/object_tracking/src/ego_velo.txt");
-      nh.param<std::string>("ego_yaw_file", yaw, "./src/object_tracking/src/ego_yaw.txt");
+      pnh.param<std::string>("ego_velo_file", velo, "./src/object_tracking/src/ego_velo.txt");
+      pnh.param<std::string>("ego_yaw_file", yaw, "./src/object_tracking/src/ego_yaw.txt");
       velo_file_.open(velo.c_str()); yaw_file_.open(yaw.c_str());
       if (!velo_file_ || !yaw_file_) throw std::runtime_error("ego:=files but " + velo + " / " + yaw + " cannot be read");
       ego_from_files_ = true;
@@ -147,9 +147,9 @@ class PipelineNode {
 
 int main(int argc, char** argv) {
   ros::init(argc, argv, "my_pcl_tutorial");
-  ros::NodeHandle nh;
+  ros::NodeHandle nh, private_nh("~");   // topics and the reference's own parameters: public names; this node's extras: ~device, ~preset, ...
   try {
-    PipelineNode node(nh);
+    PipelineNode node(nh, private_nh);
     ros::spin();
   } catch (const std::exception& e) {
     std::cerr << "my_pcl_tutorial: " << e.what() << std::endl;

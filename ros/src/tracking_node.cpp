@@ -23,8 +23,8 @@ namespace {
 
 class TrackingNode {
  public:
-  explicit TrackingNode(ros::NodeHandle& nh) : listener_(ros::Duration(100)) {
-    settings_ = mot_ros::settings(nh);
+  TrackingNode(ros::NodeHandle& nh, ros::NodeHandle& pnh) : listener_(ros::Duration(100)) {
+    settings_ = mot_ros::settings(pnh);
     mot_params prm;
     if (mot_params_preset(settings_.preset, &prm) != MOT_OK) throw std::runtime_error("unknown preset");
     ctx_ = mot_ros::create(prm, settings_);
@@ -104,9 +104,9 @@ class TrackingNode {
 
 int main(int argc, char** argv) {
   ros::init(argc, argv, "obj_track");
-  ros::NodeHandle nh;
+  ros::NodeHandle nh, private_nh("~");   // topics and the reference's own parameters: public names; this node's extras: ~device, ~preset, ...
   try {
-    TrackingNode node(nh);
+    TrackingNode node(nh, private_nh);
     ros::spin();
   } catch (const std::exception& e) {   // no GPU, a capacity limit, a malformed message: say so and stop (required="true" in the launch file)
     std::cerr << "obj_track: " << e.what() << std::endl;
