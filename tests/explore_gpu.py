@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """Exploration runs on the REAL kernels (the CPU suite does the same on the emulator): randomised tracker sequences and large
 irregular clouds through libmot_hip.so against the restatement, reporting — not asserting — what differs.
-    python tools/explore_gpu.py [n_tracker_sequences] [n_clouds]
+    python tests/explore_gpu.py [n_tracker_sequences] [n_clouds]
+(lives in tests/ because it calls the oracle: test infrastructure, like everything that does)
 Tracker: discrete outputs must match; continuous states are compared while the filter is well conditioned (see
 tests/test_emu_tracker_random.py). A discrete mismatch on the GPU that the emulator does not show points at the device math
 library (sin / cos / exp / atan2 differ from glibc in the last bit) meeting a threshold — worth a look, not necessarily a bug."""
@@ -10,8 +11,7 @@ import sys
 
 import numpy as np
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-sys.path.insert(0, os.path.join(ROOT, "tests"))
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 from conftest import load_pkg  # noqa: E402
 import oracle_lib as O  # noqa: E402
 import test_emu_large_random as LR  # noqa: E402

@@ -5,4 +5,4 @@ timeout 120 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')
 timeout 400 python bench.py > gpurun_out/bench_default.json 2> gpurun_out/bench_default.err; tail -c 400 gpurun_out/bench_default.json
 timeout -k 5 200 rocprofv3 --kernel-trace --stats -d gpurun_out/prof_kt -o kt -- python bench.py --steps 10 --warmup 3 --no-cpu-baseline > gpurun_out/prof_kt.log 2>&1
 ls gpurun_out/prof_kt
-timeout 300 python tools/explore_gpu.py 60 10 2>&1 | tail -8          # randomised tracker sequences / irregular clouds on the real kernels
+timeout 300 python tests/explore_gpu.py 60 10 2>&1 | tail -8          # randomised tracker sequences / irregular clouds on the real kernels
