@@ -125,3 +125,30 @@ def test_nodes_on_adversarial_clouds(emu_lib, ref_nodes, oracle, tmp_path):
         recs += [("__now__", U.T0 + k), ("none_ground_topic", "sensor_msgs/PointCloud2", R.pointcloud2(c[:, :3], 0.0, seq=0))]
     assert kept > 20
     U.same(U.run(ref_nodes["cluster"], recs, tmp_path, "c_ref"), U.run(own["cluster"], recs, tmp_path, "c_own"))
+
+
+def test_tracking_node_on_random_sequences(emu_lib, ref_nodes, tmp_path):
+    """randomised box sequences with a wandering ego pose through the `tracking` node shell and the reference's node: the tf
+    round trip (sensor -> global -> sensor), the tracker and the marker assembly together"""
+    import numpy as np
+    import roslog as R
+    import test_emu_tracker_random as TR
+    own = NB.own_nodes(emu_lib)
+
+    def trackbox(boxes, t, seq):
+        m = dict(header=dict(seq=seq, stamp=R.stamp(t), frame_id="velodyne"), box_num=len(boxes) & 255)
+        for k, name in enumerate(("x1", "x2", "x3", "x4", "y1", "y2", "y3", "y4")):
+            m[name] = boxes[:, k, :].reshape(-1).astype(np.float32)
+        return m
+
+    for seed in range(6 * TR.SCALE):
+        recs = []
+        for f, (boxes, ts, v, yaw) in enumerate(TR.sequence(90000 + seed)):
+            t = U.T0 + 0.1 * f
+            odom = dict(header=dict(seq=f, stamp=R.stamp(t), frame_id="gps"), child_frame_id="base_link",
+                        pose=dict(pose=dict(orientation=dict(x=0.0, y=0.0, z=float(yaw) + 0.3, w=1.0))),
+                        twist=dict(twist=dict(linear=dict(x=float(v), y=0.2, z=0.0))))
+            recs += [("__now__", t + 0.01), ("/gps/odom", "nav_msgs/Odometry", odom), ("track_box", "object_tracking/trackbox", trackbox(boxes[:255], t, f))]
+        a = U.run(ref_nodes["tracking"], recs, tmp_path, f"ref{seed}"); b = U.run(own["tracking"], recs, tmp_path, f"own{seed}")
+        assert len(a) >= 4 * 14
+        U.markers_close(a, b)
