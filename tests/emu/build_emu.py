@@ -19,7 +19,10 @@ SANITIZE = os.environ.get("MOT_EMU_SANITIZE", "")
 ASAN = SANITIZE == "address"
 SAN_FLAGS = (["-fsanitize=address", "-fno-omit-frame-pointer"] if ASAN else
              ["-fsanitize=undefined", "-fno-sanitize=float-cast-overflow", "-fno-sanitize-recover=undefined"] if SANITIZE else [])
-LIB = os.path.join(HERE, "libmot_emu_asan.so" if ASAN else "libmot_emu_ubsan.so" if SANITIZE else "libmot_emu.so")
+# MOT_EMU_PERTURB=1: sin / cos / exp / atan2 / pow of the kernels answer one ulp off now and then (see hipemu.h) — what the
+# device math library is allowed to do; the host side of the library (mot_api.hip: the reference's libm calls) is not touched
+PERTURB = bool(os.environ.get("MOT_EMU_PERTURB"))
+LIB = os.path.join(HERE, "libmot_emu_asan.so" if ASAN else "libmot_emu_ubsan.so" if SANITIZE else "libmot_emu_ulp.so" if PERTURB else "libmot_emu.so")
 
 
 def sources():
@@ -36,8 +39,9 @@ def build(force: bool = False) -> str:
         return LIB
     objs = []
     for s in srcs:
-        o = os.path.join(HERE, ("objasan_" if ASAN else "objsan_" if SANITIZE else "obj_") + s.replace(".hip", ".o"))
-        cmd = ["g++", "-std=c++17", "-O1", "-g", "-fPIC"] + SAN_FLAGS + [ "-ffp-contract=off", "-fno-fast-math", "-DMOT_HIPEMU=1", "-x", "c++",
+        o = os.path.join(HERE, ("objasan_" if ASAN else "objsan_" if SANITIZE else "objulp_" if PERTURB else "obj_") + s.replace(".hip", ".o"))
+        perturb = ["-DMOT_EMU_PERTURB=1"] if PERTURB and s != "mot_api.hip" else []
+        cmd = ["g++", "-std=c++17", "-O1", "-g", "-fPIC"] + SAN_FLAGS + [ "-ffp-contract=off", "-fno-fast-math", "-DMOT_HIPEMU=1"] + perturb + [ "-x", "c++",
                "-include", os.path.join(HERE, "hipemu.h"), "-I", CSRC, "-Wall", "-Wno-unused-function", "-Wno-unknown-pragmas",
                "-Wno-unused-variable", "-c", os.path.join(CSRC, s), "-o", o]
         r = subprocess.run(cmd, capture_output=True, text=True)

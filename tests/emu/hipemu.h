@@ -330,4 +330,33 @@ static inline hipError_t hipEventRecord(hipEvent_t e, hipStream_t) { e->t = hipe
 static inline hipError_t hipEventSynchronize(hipEvent_t) { return hipSuccess; }
 static inline hipError_t hipEventElapsedTime(float* ms, hipEvent_t a, hipEvent_t b) { *ms = (float)(b->t - a->t); return hipSuccess; }
 
+// ---- optional: device-math-library stand-in (-DMOT_EMU_PERTURB, built by MOT_EMU_PERTURB=1) -------------------------------
+// sin / cos / sincos / exp / atan2 / pow of the device math library are correctly rounded in most cases, not all: they may
+// differ from glibc in the last bit. This mode moves each result of these functions by one ulp up, down or not at all
+// (chosen by a hash of the argument bits, so the same call gives the same answer), to see on the CPU whether anything
+// discrete — a box corner after its rounding to fp32, a gate decision, a track state — depends on such a bit.
+#ifdef MOT_EMU_PERTURB
+namespace hipemu {
+inline double nudge(double r, double a, double b = 0.0) {
+  uint64_t x, y; memcpy(&x, &a, 8); memcpy(&y, &b, 8);
+  uint64_t h = (x ^ (y * 0x9E3779B97F4A7C15ull)) * 0xD1342543DE82EF95ull; h ^= h >> 29; h *= 0xBF58476D1CE4E5B9ull; h ^= h >> 32;
+  const unsigned k = (unsigned)(h % 3u);
+  if (!std::isfinite(r) || k == 0) return r;
+  return std::nextafter(r, k == 1 ? INFINITY : -INFINITY);
+}
+inline double p_sin(double a) { return nudge(std::sin(a), a); }
+inline double p_cos(double a) { return nudge(std::cos(a), a, 1.0); }
+inline double p_exp(double a) { return nudge(std::exp(a), a, 2.0); }
+inline double p_atan2(double a, double b) { return nudge(std::atan2(a, b), a, b); }
+inline double p_pow(double a, double b) { return nudge(std::pow(a, b), a, b); }
+inline void p_sincos(double a, double* s, double* c) { *s = p_sin(a); *c = p_cos(a); }
+}  // namespace hipemu
+#define sin(x) hipemu::p_sin(x)
+#define cos(x) hipemu::p_cos(x)
+#define exp(x) hipemu::p_exp(x)
+#define atan2(y, x) hipemu::p_atan2((y), (x))
+#define pow(x, y) hipemu::p_pow((x), (y))
+#define sincos(x, s, c) hipemu::p_sincos((x), (s), (c))
+#endif
+
 #endif  // HIPEMU_H_
