@@ -157,3 +157,34 @@ def test_fused_frames_with_tracker(mot, hip_lib, oracle, synth):
                 live = o["track_manage"] > 0
                 assert np.allclose(a["p"][live], o["p"][live], rtol=RTOL, atol=1e-5)   # the 1e-4 bar; the box transform is the same fp64 expression on both sides
             dev.free()
+
+
+@pytest.mark.parametrize("preset", [0, 1])
+def test_tracker_random_and_degenerate_sequences(mot, hip_lib, oracle, preset):
+    """the generators of tests/test_emu_tracker_random.py on the real kernel: objects that move, stop, vanish, split into two
+    boxes, crowd each other, clutter, duplicate / zero-area / far-away measurements, a wandering ego pose. Discrete outputs
+    exact; continuous state to the 1e-4 bar while the filter is well conditioned (a diverging track amplifies last-bit
+    differences by decades per frame — see well_conditioned). On the CPU the same sequences pass with the kernels' sin / cos /
+    exp / atan2 / pow results moved by an ulp (MOT_EMU_PERTURB), i.e. they do not hang on the device math library's last bit."""
+    import test_emu_tracker_random as TR
+    p = oracle.params(preset)
+    with mot.Context(mot.params(preset), max_points=4096, max_tracks_total=512) as c:
+        for seed in range(1000 * preset, 1000 * preset + 14):
+            c.reset(); T = oracle.Tracker(p)
+            seq = TR.sequence(seed) if seed % 4 else TR.hostile_sequence(seed)
+            for f, (boxes, ts, v, yaw) in enumerate(seq):
+                c.ego_update(ts, v, yaw); T.ego_update(ts, v, yaw)
+                a = c.track_step(boxes, ts); o = T.step(boxes, ts)
+                assert a["n"] == o["n"], (seed, f)
+                for k in ("track_manage", "is_static", "is_vis", "lifetime"):
+                    assert np.array_equal(a[k], o[k]), (seed, f, k)
+                for i in np.nonzero(o["track_manage"] > 0)[0]:
+                    so = T.state(int(i))
+                    if not TR.well_conditioned(so):
+                        continue
+                    sa = c.track_state(int(i))
+                    assert np.allclose(a["p"][i], o["p"][i], rtol=RTOL, atol=1e-5), (seed, f, int(i))
+                    for k in ("x_merge", "p_merge", "mode_prob"):
+                        scale = max(np.abs(so[k]).max(), 1e-300)
+                        assert np.abs(np.asarray(sa[k]) - so[k]).max() <= RTOL * scale + 1e-9, (seed, f, int(i), k)
+            T.close()
