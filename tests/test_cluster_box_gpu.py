@@ -252,3 +252,26 @@ def test_box_height_sign_of_zero(ctx, oracle):
         o = oracle.cluster(p, e)
         b = ctx.box_fit(e, o["grid"], o["num_cluster"]); ob = oracle.box_fit(p, e, o["grid"], o["num_cluster"])
         assert len(ob["boxes"]) == 1 and np.array_equal(b["boxes"].view(np.uint32), ob["boxes"].view(np.uint32)), zs
+
+
+@pytest.mark.parametrize("preset", [0, 1])
+def test_large_irregular_clouds(mot, hip_lib, oracle, preset):
+    """tests/test_emu_large_random.py's generator on the real kernels: scatter, blobs, walls, exact duplicates, boundary-snapped
+    points, shuffled order — the multi-chunk machinery on data the HDL-64E scenes do not produce"""
+    import test_emu_large_random as LR
+    p = oracle.params(preset)
+    with mot.Context(mot.params(preset), max_points=131072) as c:
+        for seed in range(100 * preset, 100 * preset + 3):
+            cloud = LR.big_cloud(seed)
+            g = c.ground_remove(cloud); og = oracle.ground_remove(p, cloud)
+            assert np.array_equal(g["mask"], og["mask"]) and np.array_equal(g["elevated"], og["elevated"]) and np.array_equal(g["ground"], og["ground"]), seed
+            cl = c.cluster(og["elevated"]); ocl = oracle.cluster(p, og["elevated"])
+            assert cl["num_cluster"] == ocl["num_cluster"] and np.array_equal(cl["grid"], ocl["grid"]) and np.array_equal(cl["point_label"], ocl["point_label"]), seed
+            if ocl["num_cluster"] > 4096:
+                continue
+            bx = c.box_fit_resident(); obx = oracle.box_fit(p, og["elevated"], ocl["grid"], ocl["num_cluster"])
+            assert bx["n_undefined"] == obx["n_undefined"] and np.array_equal(bx["box_cluster"], obx["box_cluster"]), seed
+            assert np.array_equal(bx["boxes"].view(np.uint32), obx["boxes"].view(np.uint32)), seed
+            sd = c.cluster_products(0); osd = oracle.cluster_products(p, og["elevated"], ocl["grid"])
+            for k in ("clustered", "obstacles", "cost_map"):
+                assert sd[k].shape == osd[k].shape and np.array_equal(sd[k], osd[k]), (seed, k)
