@@ -72,7 +72,10 @@ EXPORTS = (
     "mot_track_step", "mot_track_get_state", "mot_frames_dev", "mot_get_ground", "mot_get_clusters",
     "mot_get_boxes", "mot_get_tracks", "mot_export_tracks_dev", "mot_side_params_default", "mot_cluster_products", "mot_cluster_products_host", "mot_decode_pointcloud2_dev", "mot_time_stage",
     "mot_ground_remove_pointcloud2", "mot_box_fit_resident", "mot_frame_pointcloud2",
+    "mot_reset_slot", "mot_frames_host", "mot_wait_uploads", "mot_host_alloc", "mot_host_free", "mot_fetch_tracks_async",
+    "mot_track_steps_dev", "mot_profile_kernel", "mot_profile_read",
 )
+ABI_VERSION = 2
 
 _libs: dict[str, C.CDLL] = {}
 
@@ -90,6 +93,10 @@ def load_library(path: str | None = None) -> C.CDLL:
     lib.mot_last_error.argtypes = [C.c_void_p]
     lib.mot_stream.restype = C.c_void_p
     lib.mot_destroy.restype = None
+    lib.mot_host_alloc.argtypes = [C.c_size_t, C.POINTER(C.c_void_p)]
+    lib.mot_host_free.argtypes = [C.c_void_p]
+    if lib.mot_abi_version() != ABI_VERSION:
+        raise ImportError(f"{path}: ABI version {lib.mot_abi_version()}, this binding is for {ABI_VERSION} — rebuild the library")
     _libs[path] = lib
     return lib
 
@@ -164,6 +171,9 @@ class Context:
 
     def reset(self):
         self._ck(self.lib.mot_reset(self._h))
+
+    def reset_slot(self, slot: int):
+        self._ck(self.lib.mot_reset_slot(self._h, slot))
 
     # ------------------------------------------------------------------ stage calls, host buffers
     def ground_remove(self, xyzw, want_mask: bool = True):
@@ -250,22 +260,26 @@ class Context:
                                          int(run_tracker), _vp(ts), _vp(ev), _vp(ey)))
 
     def get_ground(self, slot: int = 0, n_hint: int | None = None, want_clouds: bool = True):
-        n = n_hint if n_hint is not None else self.max_points
-        elev = np.empty((max(n, 1), 4), np.float32) if want_clouds else None
-        ground = np.empty((max(n, 1), 4), np.float32) if want_clouds else None
-        mask = np.zeros(max(n, 1), np.uint8) if want_clouds else None
+        """n_hint: number of input points of the frame (length of the returned mask); the buffers are sized by max_points"""
+        cap = self.max_points
+        n = min(n_hint, cap) if n_hint is not None else cap
+        elev = np.empty((cap, 4), np.float32) if want_clouds else None
+        ground = np.empty((cap, 4), np.float32) if want_clouds else None
+        mask = np.zeros(cap, np.uint8) if want_clouds else None
         ne, ng = C.c_int(0), C.c_int(0)
-        self._ck(self.lib.mot_get_ground(self._h, slot, _vp(elev), C.byref(ne), _vp(ground), C.byref(ng), _vp(mask)))
+        self._ck(self.lib.mot_get_ground(self._h, slot, _vp(elev), C.byref(ne), _vp(ground), C.byref(ng), _vp(mask), cap))
         out = dict(n_elevated=ne.value, n_ground=ng.value)
         if want_clouds:
             out.update(elevated=elev[: ne.value].copy(), ground=ground[: ng.value].copy(), mask=mask[:n].copy())
         return out
 
     def get_clusters(self, slot: int = 0, n_elevated: int = 0):
+        """n_elevated > 0: also return the per-point labels (the resident count is what is delivered; the hint only switches them on)"""
         G = self.params.num_grid
-        grid = np.zeros((G, G), np.int32); nc = C.c_int(0); lab = np.zeros(max(n_elevated, 1), np.int32)
-        self._ck(self.lib.mot_get_clusters(self._h, slot, _vp(grid), C.byref(nc), _vp(lab) if n_elevated else None))
-        return dict(grid=grid, num_cluster=nc.value, point_label=lab[:n_elevated].copy())
+        grid = np.zeros((G, G), np.int32); nc = C.c_int(0)
+        lab = np.zeros(self.max_points, np.int32) if n_elevated else None
+        self._ck(self.lib.mot_get_clusters(self._h, slot, _vp(grid), C.byref(nc), _vp(lab), self.max_points if n_elevated else 0))
+        return dict(grid=grid, num_cluster=nc.value, point_label=lab[:n_elevated].copy() if n_elevated else np.zeros(0, np.int32))
 
     def decode_pointcloud2_dev(self, d_data_ptr: int, n: int, point_step: int, off_x: int, off_y: int, off_z: int, off_w: int, d_xyzw_ptr: int):
         """PointCloud2 payload (device) -> float4 points (device), asynchronous on the context stream"""
@@ -304,6 +318,35 @@ class Context:
         arr = (MotTrack * max_tracks)(); nt = C.c_int(0)
         self._ck(self.lib.mot_get_tracks(self._h, slot, arr, max_tracks, C.byref(nt)))
         return tracks_to_dict(arr, nt.value)
+
+    def frames_host(self, h_ptr: int, frame_stride_floats: int, n_points, run_tracker: bool = False,
+                    timestamps=None, ego_v=None, ego_yaw=None):
+        """frames_dev for frames in (page-locked) HOST memory: the upload of this batch overlaps the previous batch's kernels"""
+        n = np.ascontiguousarray(n_points, np.int32); B = len(n)
+        ts = np.ascontiguousarray(timestamps if timestamps is not None else np.zeros(B), np.float64)
+        ev = np.ascontiguousarray(ego_v if ego_v is not None else np.zeros(B), np.float64)
+        ey = np.ascontiguousarray(ego_yaw if ego_yaw is not None else np.zeros(B), np.float64)
+        self._ck(self.lib.mot_frames_host(self._h, C.c_void_p(h_ptr), C.c_long(frame_stride_floats), _vp(n), B,
+                                          int(run_tracker), _vp(ts), _vp(ev), _vp(ey)))
+
+    def wait_uploads(self):
+        self._ck(self.lib.mot_wait_uploads(self._h))
+
+    def fetch_tracks_async(self, batch: int, h_tracks_ptr: int, max_per_slot: int, h_counts_ptr: int):
+        self._ck(self.lib.mot_fetch_tracks_async(self._h, batch, C.c_void_p(h_tracks_ptr), max_per_slot, C.c_void_p(h_counts_ptr)))
+
+    def track_steps_dev(self, d_boxes_ptr: int, box_stride_floats: int, m, timestamps):
+        """immUkfJpdaf for one frame of every slot, boxes (global frame) already on the device"""
+        mm = np.ascontiguousarray(m, np.int32); ts = np.ascontiguousarray(timestamps, np.float64)
+        self._ck(self.lib.mot_track_steps_dev(self._h, C.c_void_p(d_boxes_ptr), C.c_long(box_stride_floats), _vp(mm), len(mm), _vp(ts)))
+
+    def profile_kernel(self, kernel_id: int):
+        self._ck(self.lib.mot_profile_kernel(self._h, kernel_id))
+
+    def profile_read(self):
+        mean, mn, mx, k = C.c_float(0), C.c_float(0), C.c_float(0), C.c_int(0)
+        self._ck(self.lib.mot_profile_read(self._h, C.byref(mean), C.byref(mn), C.byref(mx), C.byref(k)))
+        return dict(mean_ms=mean.value, min_ms=mn.value, max_ms=mx.value, samples=k.value)
 
     def export_tracks_dev(self, batch: int, d_tracks_ptr: int, max_per_slot: int, d_counts_ptr: int):
         """live tracks of every slot -> caller's device buffer (the block that is all-gathered across GPUs)"""

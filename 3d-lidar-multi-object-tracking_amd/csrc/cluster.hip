@@ -3,7 +3,8 @@
 // Replaces componentClustering() = mapCartesianGrid() + findComponent()/search()
 // (OT/src/cluster/component_clustering.cpp:28-268) for a batch of frames:
 //
-//   C1 cart_occupancy_kernel   N_e pts -> two bit-planes per frame ("cell seen >= 1", "seen >= 2")
+//   C1 cart_occupancy_kernel   N_e pts -> two bit-planes per frame ("cell seen >= 1", "seen >= 2"); stage-wise entry
+//                              points only — in the fused path classify_compact_kernel (ground.hip) fills the planes
 //   C2 ccl_kernel              bit-plane -> 3x3 dilation -> connected components -> int32 label grid
 //
 // Design (not a translation of the recursive flood fill):
@@ -321,7 +322,7 @@ void mot_launch_cluster_kernel(int which, const MotDevParams& p, const ClusterBu
   else if (which == 1) hipLaunchKernelGGL(ccl_kernel, dim3(batch), dim3(kCclBlock), 0, stream, p, c);
 }
 
-void mot_launch_cluster(const MotDevParams& p, const ClusterBuffers& c, int batch, int max_n, hipStream_t stream) {
-  mot_launch_cluster_kernel(0, p, c, batch, max_n, stream);
+void mot_launch_cluster(const MotDevParams& p, const ClusterBuffers& c, int batch, int max_n, hipStream_t stream, bool occupancy_done) {
+  if (!occupancy_done) mot_launch_cluster_kernel(0, p, c, batch, max_n, stream);
   mot_launch_cluster_kernel(1, p, c, batch, max_n, stream);
 }

@@ -6,6 +6,7 @@
 //   K1 polar_minz_kernel        N pts  -> 9600 per-cell min z          (filterCloud + createAndMapPolarGrid)
 //   K2 polar_filter_kernel      9600   -> 9600 ground thresholds       (clamp, Gaussian, hDiff, decision, median, outlier)
 //   K3 classify_compact_kernel  N pts  -> elevated / ground clouds     (second loop of groundRemove, order preserving)
+//                                         (+ in the fused path the occupancy bit-planes of the cluster stage)
 //
 // HBM traffic per point: K1 reads 16 B, K3 reads 16 B and writes 16 B (+1 B mask) = 48(+1) B — the
 // algorithmic minimum of SURVEY.md §8d: the classification needs the complete grid, so the cloud has to
@@ -306,6 +307,8 @@ classify_compact_kernel(MotDevParams p, GroundBuffers g) {
   __shared__ int s_chunk;
   __shared__ int s_cnt[kSubTiles];  // per 64-point tile counts (elevated << 16 | ground) -> exclusive prefixes
   __shared__ int s_base_e, s_base_g;
+  // occupancy of the cluster stage's Cartesian grid by this chunk's elevated points: "cell seen >= 1" / "seen >= 2"
+  __shared__ unsigned s_occ_a[kPlaneWords], s_occ_b[kPlaneWords];
   const int b = blockIdx.y;
   const int n = g.n[b];
   const int nchunks = (n + kCompactChunk - 1) / kCompactChunk;
@@ -313,11 +316,14 @@ classify_compact_kernel(MotDevParams p, GroundBuffers g) {
     if (nchunks == 0 && blockIdx.x == 0 && threadIdx.x == 0) { g.counts[b * kCountsStride + kCntElev] = 0; g.counts[b * kCountsStride + kCntGround] = 0; g.counts[b * kCountsStride + kCntDropped] = 0; }
     return;
   }
+  const bool occupancy = g.plane_a != nullptr;   // uniform
   if (threadIdx.x == 0) {
     int t = atomicAdd(&g.ticket[b], 1);      // chunk id in arrival order: every predecessor is already running
     if (t == nchunks - 1) g.ticket[b] = 0;   // last ticket of this frame: re-arm for the next launch
     s_chunk = t;
   }
+  if (occupancy)
+    for (int i = threadIdx.x; i < kPlaneWords; i += kCompactBlock) { s_occ_a[i] = 0u; s_occ_b[i] = 0u; }
   __syncthreads();
   const int chunk = s_chunk;
   const long base = (long)chunk * kCompactChunk;
@@ -353,6 +359,38 @@ classify_compact_kernel(MotDevParams p, GroundBuffers g) {
     const unsigned long long bg = __ballot(c == MOT_MASK_GROUND);
     rank[k] = __popcll((c == MOT_MASK_ELEVATED ? be : bg) & below);
     if (lane == 0) s_cnt[k * (kCompactBlock / 64) + wave] = (__popcll(be) << 16) | __popcll(bg);   // tile order inside the chunk: k-major, then wave
+  }
+  if (occupancy) {
+    // mapCartesianGrid's histogram (component_clustering.cpp:36-50) for the elevated points, from registers: this is what
+    // cart_occupancy_kernel did with a second pass over the elevated cloud (16 N_e bytes and a launch per batch).
+    // Guarded fast cell first; the few undecided points go through ONE copy of the exact evaluation.
+    int bits[kCompactItems];
+    unsigned undecided = 0;
+#pragma unroll
+    for (int k = 0; k < kCompactItems; k++) {
+      int bit = cls[k] == MOT_MASK_ELEVATED ? mot_cart_bit_try(p, pt[k].x, pt[k].y) : -1;
+      if (bit == -2) undecided |= 1u << k;
+      bits[k] = bit;
+    }
+    while (undecided) {
+      const int k = __ffs(undecided) - 1;
+      undecided &= undecided - 1;
+      float qx = pt[0].x, qy = pt[0].y;
+#pragma unroll
+      for (int kk = 1; kk < kCompactItems; kk++) { qx = kk == k ? pt[kk].x : qx; qy = kk == k ? pt[kk].y : qy; }
+      int xI, yI;
+      const int r = mot_cart_cell(p, qx, qy, &xI, &yI) ? xI * MOT_MAX_GRID + yI : -1;
+#pragma unroll
+      for (int kk = 0; kk < kCompactItems; kk++) bits[kk] = kk == k ? r : bits[kk];
+    }
+#pragma unroll
+    for (int k = 0; k < kCompactItems; k++) {
+      if (bits[k] >= 0) {
+        const unsigned m = 1u << (bits[k] & 31);
+        const unsigned old = atomicOr(&s_occ_a[bits[k] >> 5], m);
+        if (old & m) atomicOr(&s_occ_b[bits[k] >> 5], m);
+      }
+    }
   }
   __syncthreads();
   if (wave == 0) {
@@ -432,6 +470,21 @@ classify_compact_kernel(MotDevParams p, GroundBuffers g) {
       for (int k = 0; k < kCompactItems; k++) {
         long i = base + k * kCompactBlock + threadIdx.x;
         if (i < n) mask[i] = (uint8_t)cls[k];
+      }
+    }
+  }
+  if (occupancy) {
+    // merge into the frame's planes (L2) with one returning atomicOr per non-zero word; a bit that two workgroups both
+    // saw once is promoted to the ">= 2" plane by whoever merges second (the barrier after the look-back ordered every
+    // LDS atomic of this workgroup before these reads)
+    unsigned* __restrict__ ga = g.plane_a + (long)b * kPlaneWords;
+    unsigned* __restrict__ gb = g.plane_b + (long)b * kPlaneWords;
+    for (int i = threadIdx.x; i < kPlaneWords; i += kCompactBlock) {
+      const unsigned a = s_occ_a[i];
+      if (a) {
+        const unsigned old = atomicOr(&ga[i], a);
+        const unsigned twice = s_occ_b[i] | (old & a);
+        if (twice) atomicOr(&gb[i], twice);
       }
     }
   }

@@ -2,6 +2,7 @@
 // Owns the device buffers, the HIP stream and the launch sequences. There is no CPU fallback:
 // mot_create() fails with MOT_E_HIP when no HIP device is present.
 #include "mot_internal.h"
+#include "mot_debug_api.h"
 
 #include <math.h>
 #include <stdio.h>
@@ -15,7 +16,8 @@ struct mot_ctx {
   mot_params params;
   MotDevParams dp;
   int device = 0;
-  int cap = 0;        // points per frame
+  int cap = 0;        // per-slot stride of the per-point buffers (max_points rounded up to 64)
+  int max_points = 0; // points per frame the caller asked for: the limit every entry point enforces
   int batch = 0;      // slots
   int max_tracks_total = 0;
   hipStream_t stream = nullptr;
@@ -89,7 +91,36 @@ struct mot_ctx {
   const float4* last_in = nullptr;
   long last_in_stride = 0;
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  // pipelined host ingest (mot_frames_host): a copy stream and two staging copies of the input batch
+  hipStream_t copy_stream = nullptr;
+  float4* d_stage[2] = {nullptr, nullptr};
+  hipEvent_t ev_copied[2] = {nullptr, nullptr};    // H2D of stage[i] complete (copy stream)
+  hipEvent_t ev_consumed[2] = {nullptr, nullptr};  // last kernel reading stage[i] launched and done (compute stream)
+  bool stage_used[2] = {false, false};
+  int stage_next = 0;
+  // device block of mot_fetch_tracks_async
+  mot_track* d_fetch = nullptr;
+  int* d_fetch_counts = nullptr;
+  int fetch_cap = 0;
+  // in-run kernel timing (mot_profile_kernel): event pairs around one kernel inside mot_frames_dev / mot_frames_host
+  int prof_kernel = 0;
+  static constexpr int kProfRing = 64;
+  hipEvent_t prof_ev[kProfRing][2] = {};
+  int prof_n = 0;
+  bool prof_created = false;
 };
+
+// every entry point runs with the context's device current and puts the caller's device back afterwards: contexts on
+// different GPUs in one process, callback threads, torch.cuda.set_device after mot_create all work
+struct DevGuard {
+  int prev = -1;
+  bool changed = false;
+  explicit DevGuard(int dev) {
+    if (hipGetDevice(&prev) == hipSuccess && prev != dev) changed = hipSetDevice(dev) == hipSuccess;
+  }
+  ~DevGuard() { if (changed) (void)hipSetDevice(prev); }
+};
+#define MOT_GUARD(c) DevGuard guard_((c)->device)
 
 #define MOT_HIP(ctx, call)                                                                     \
   do {                                                                                         \
@@ -172,6 +203,7 @@ static int make_dev_params(const mot_params& p, MotDevParams* d, std::string* er
   d->crop_x_max = p.crop_x_max; d->crop_y_min = p.crop_y_min; d->crop_y_max = p.crop_y_max;
   d->num_grid = p.num_grid; d->occ_min_count = p.occ_min_count; d->dilate = p.dilate;
   d->roi_m = p.roi_m; d->roi_half = p.roi_m / 2;
+  d->k_grid = (float)p.num_grid / p.roi_m;
   d->pic_scale = p.pic_scale; d->pic_full = p.pic_scale * p.roi_m; d->pic_half = p.roi_m * p.pic_scale / 2;
   d->ram_points = p.ram_points; d->l_slope_dist = p.l_slope_dist; d->l_num_points = p.l_num_points;
   d->lshape_side_cond = p.lshape_side_cond; d->min_points = p.min_points; d->sensor_height = p.sensor_height;
@@ -184,6 +216,18 @@ static int make_dev_params(const mot_params& p, MotDevParams* d, std::string* er
 
 extern "C" void mot_destroy(mot_ctx* c) {
   if (!c) return;
+  MOT_GUARD(c);
+  if (c->stream) (void)hipStreamSynchronize(c->stream);
+  if (c->copy_stream) { (void)hipStreamSynchronize(c->copy_stream); (void)hipStreamDestroy(c->copy_stream); }
+  for (int i = 0; i < 2; i++) {
+    if (c->d_stage[i]) (void)hipFree(c->d_stage[i]);
+    if (c->ev_copied[i]) (void)hipEventDestroy(c->ev_copied[i]);
+    if (c->ev_consumed[i]) (void)hipEventDestroy(c->ev_consumed[i]);
+  }
+  if (c->d_fetch) (void)hipFree(c->d_fetch);
+  if (c->d_fetch_counts) (void)hipFree(c->d_fetch_counts);
+  if (c->prof_created)
+    for (int i = 0; i < mot_ctx::kProfRing; i++) { (void)hipEventDestroy(c->prof_ev[i][0]); (void)hipEventDestroy(c->prof_ev[i][1]); }
   void* bufs[] = {c->d_in, c->d_n, c->d_pairs, c->d_pair_count, c->d_hg, c->d_desc, c->d_ticket, c->d_elev, c->d_ground, c->d_mask, c->d_counts,
                   c->d_plane_a, c->d_plane_b, c->d_grid, c->d_label, c->d_stats, c->d_cand, c->d_boxes, c->d_box_cluster, c->d_rng, c->d_poly, c->d_groups, c->d_cluster_start, c->d_sorted, c->d_pix, c->d_wgtab, c->d_side_cell, c->d_side_cloud, c->d_side_obs, c->d_side_cost, c->d_side_counts, c->d_raw,
                   c->d_tracks, c->d_nt, c->d_tboxes, c->d_targs, c->d_gate, c->d_prog, c->d_live, c->d_tout, c->d_tflags, c->d_ego, c->d_phase};
@@ -211,7 +255,15 @@ static int create_impl(mot_ctx* c) {
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return fail(c, MOT_E_HIP, "no HIP device: this library has no CPU fallback");
   if (c->device < 0 || c->device >= ndev) return fail(c, MOT_E_ARG, "device ordinal out of range");
-  MOT_HIP(c, hipSetDevice(c->device));
+  MOT_HIP(c, hipSetDevice(c->device));   // mot_create restores the caller's device (DevGuard)
+  {
+    hipDeviceProp_t prop;
+    MOT_HIP(c, hipGetDeviceProperties(&prop, c->device));
+    if (strncmp(prop.gcnArchName, "gfx950", 6) != 0) {
+      c->err = std::string("device is ") + prop.gcnArchName + ": this library contains gfx950 (MI355X) code only";
+      return MOT_E_HIP;
+    }
+  }
   MOT_HIP(c, hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
   MOT_HIP(c, hipEventCreate(&c->ev0));
   MOT_HIP(c, hipEventCreate(&c->ev1));
@@ -258,6 +310,7 @@ static int create_impl(mot_ctx* c) {
   {
     ClusterBuffers cb = cluster_buffers(c);
     mot_launch_stats_init(cb, (int)B, c->stream);
+    MOT_HIP(c, hipGetLastError());
   }
   const size_t T = c->max_tracks_total;
   MOT_HIP(c, hipMalloc(&c->d_tracks, B * T * sizeof(DevTrack)));
@@ -292,7 +345,11 @@ extern "C" int mot_create(const mot_params* params, int device, int max_points, 
   if (!params || !out || max_points < 1 || max_points > kMaxPointsPerFrame || max_batch < 1 || max_tracks_total < 1) return MOT_E_ARG;
   *out = nullptr;
   mot_ctx* c = new mot_ctx();
+  int prev_device = -1;
+  (void)hipGetDevice(&prev_device);
+  struct Restore { int d; ~Restore() { if (d >= 0) (void)hipSetDevice(d); } } restore{prev_device};
   c->params = *params; c->device = device; c->batch = max_batch;
+  c->max_points = max_points;
   c->cap = (max_points + 63) / 64 * 64;  // per-slot stride of every per-point buffer: keeps 16-byte vector loads aligned
   c->max_tracks_total = max_tracks_total;
   int rc = make_dev_params(c->params, &c->dp, &c->err);
@@ -310,11 +367,14 @@ extern "C" const char* mot_last_error(const mot_ctx* c) { return c ? c->err.c_st
 extern "C" void* mot_stream(mot_ctx* c) { return c ? (void*)c->stream : nullptr; }
 extern "C" int mot_synchronize(mot_ctx* c) {
   if (!c) return MOT_E_ARG;
+  MOT_GUARD(c);
+  if (c->copy_stream) MOT_HIP(c, hipStreamSynchronize(c->copy_stream));
   MOT_HIP(c, hipStreamSynchronize(c->stream));
   return MOT_OK;
 }
 extern "C" int mot_reset(mot_ctx* c) {
   if (!c) return MOT_E_ARG;
+  MOT_GUARD(c);
   MOT_HIP(c, hipMemsetAsync(c->d_nt, 0, c->batch * sizeof(int), c->stream));
   MOT_HIP(c, hipMemsetAsync(c->d_tflags, 0, c->batch * sizeof(int), c->stream));
   MOT_HIP(c, hipStreamSynchronize(c->stream));
@@ -333,12 +393,13 @@ static int next_epoch(mot_ctx* c) {
   return MOT_OK;
 }
 
-static GroundBuffers ground_buffers(mot_ctx* c, const float4* in, long stride, bool want_mask) {
+static GroundBuffers ground_buffers(mot_ctx* c, const float4* in, long stride, bool want_mask, bool planes = false) {
   GroundBuffers g;
   g.epoch = c->epoch;
   g.in = in; g.in_stride = stride; g.n = c->d_n; g.pairs = c->d_pairs; g.pair_count = c->d_pair_count; g.hg = c->d_hg; g.desc = c->d_desc;
   g.ticket = c->d_ticket; g.elevated = c->d_elev; g.ground = c->d_ground; g.mask = want_mask ? c->d_mask : nullptr;
   g.counts = c->d_counts; g.cap = c->cap; g.max_chunks = c->max_chunks;
+  g.plane_a = planes ? c->d_plane_a : nullptr; g.plane_b = planes ? c->d_plane_b : nullptr;
   return g;
 }
 
@@ -348,29 +409,45 @@ static int set_batch(mot_ctx* c, const int* n_points, int batch, const float4* i
   int max_n = 0;
   for (int b = 0; b < batch; b++) {
     if (n_points[b] < 0) return fail(c, MOT_E_ARG, "negative point count");
-    if (n_points[b] > c->cap) return fail(c, MOT_E_CAPACITY, "frame has more points than max_points");
-    c->h_n[b] = n_points[b];
+    if (n_points[b] > c->max_points) return fail(c, MOT_E_CAPACITY, "frame has more points than max_points");
     if (n_points[b] > max_n) max_n = n_points[b];
   }
+  if (stride < max_n && batch > 1) return fail(c, MOT_E_ARG, "frame_stride is smaller than a frame");
+  for (int b = 0; b < batch; b++) c->h_n[b] = n_points[b];
   MOT_HIP(c, hipMemcpyAsync(c->d_n, c->h_n.data(), batch * sizeof(int), hipMemcpyHostToDevice, c->stream));
   c->last_batch = batch; c->last_max_n = max_n; c->last_in = in; c->last_in_stride = stride;
   return MOT_OK;
 }
 
-extern "C" int mot_frames_dev(mot_ctx* c, const float* d_xyzw, long frame_stride, const int* n_points, int batch,
-                              int run_tracker, const double* timestamps, const double* ego_v, const double* ego_yaw) {
-  if (!c || !d_xyzw || !n_points) return MOT_E_ARG;
-  if (frame_stride % 4) return fail(c, MOT_E_ARG, "frame_stride must be a multiple of 4 floats");
-  int rc = set_batch(c, n_points, batch, (const float4*)d_xyzw, frame_stride / 4);
-  if (rc) return rc;
+// kernel ids used by mot_time_stage and mot_profile_kernel
+enum { kK1 = 10, kK2 = 11, kK3 = 12, kC1 = 20, kC2 = 21, kB1 = 30, kB2 = 31, kB3 = 32, kB2b = 33, kB1b = 34, kT1 = 40 };
+
+// in-run timing of one kernel: an event pair around its launch, on the context stream, while the ring has room
+struct ProfScope {
+  mot_ctx* c; bool on;
+  ProfScope(mot_ctx* ctx, int id) : c(ctx), on(ctx->prof_kernel == id && ctx->prof_n < mot_ctx::kProfRing) {
+    if (on) (void)hipEventRecord(c->prof_ev[c->prof_n][0], c->stream);
+  }
+  ~ProfScope() { if (on) { (void)hipEventRecord(c->prof_ev[c->prof_n][1], c->stream); c->prof_n++; } }
+};
+
+// the fused launch sequence of one batch on the context stream; every argument has been validated
+static int launch_frames(mot_ctx* c, int batch, int run_tracker, const double* timestamps, const double* ego_v, const double* ego_yaw) {
+  int rc;
   if ((rc = next_epoch(c))) return rc;
-  GroundBuffers g = ground_buffers(c, c->last_in, c->last_in_stride, true);
-  mot_launch_ground(c->dp, g, batch, c->last_max_n, c->stream);
+  const int max_n = c->last_max_n;
+  GroundBuffers g = ground_buffers(c, c->last_in, c->last_in_stride, true, true);
+  { ProfScope ps(c, kK1); mot_launch_ground_kernel(0, c->dp, g, batch, max_n, c->stream); }
+  { ProfScope ps(c, kK2); mot_launch_ground_kernel(1, c->dp, g, batch, max_n, c->stream); }
+  { ProfScope ps(c, kK3); mot_launch_ground_kernel(2, c->dp, g, batch, max_n, c->stream); }
   ClusterBuffers cb = cluster_buffers(c);
-  mot_launch_cluster(c->dp, cb, batch, c->last_max_n, c->stream);
-  mot_launch_box(c->dp, cb, batch, c->last_max_n, c->stream);
+  { ProfScope ps(c, kC2); mot_launch_cluster(c->dp, cb, batch, max_n, c->stream, true); }   // occupancy planes filled by the compaction kernel
+  { ProfScope ps(c, kB1); mot_launch_box_kernel(0, c->dp, cb, batch, max_n, c->stream); }
+  { ProfScope ps(c, kB1b); mot_launch_box_kernel(4, c->dp, cb, batch, max_n, c->stream); }
+  { ProfScope ps(c, kB2); mot_launch_box_kernel(1, c->dp, cb, batch, max_n, c->stream); }
+  { ProfScope ps(c, kB2b); mot_launch_box_kernel(3, c->dp, cb, batch, max_n, c->stream); }
+  { ProfScope ps(c, kB3); mot_launch_box_kernel(2, c->dp, cb, batch, max_n, c->stream); }
   if (run_tracker) {
-    if (!timestamps || !ego_v || !ego_yaw) return fail(c, MOT_E_ARG, "run_tracker needs timestamps, ego_v and ego_yaw");
     for (int b = 0; b < c->batch; b++) c->h_targs[b].run = 0;
     for (int b = 0; b < batch; b++) {
       // the tracking node's per-frame sequence (OT/tracking/main.cpp:72-166): ego pose, boxes -> global frame, tracker
@@ -381,9 +458,145 @@ extern "C" int mot_frames_dev(mot_ctx* c, const float* d_xyzw, long frame_stride
     MOT_HIP(c, hipMemcpyAsync(c->d_ego, c->h_ego.data(), batch * sizeof(EgoPose), hipMemcpyHostToDevice, c->stream));
     MOT_HIP(c, hipMemcpyAsync(c->d_targs, c->h_targs.data(), c->batch * sizeof(TrackFrameArgs), hipMemcpyHostToDevice, c->stream));
     mot_launch_boxes_to_global(c->d_boxes, c->d_counts, c->d_ego, c->d_tboxes, batch, c->stream);
-    mot_launch_track(track_buffers(c, true), batch, c->stream);
+    { ProfScope ps(c, kT1); mot_launch_track(track_buffers(c, true), batch, c->stream); }
   }
   MOT_HIP(c, hipGetLastError());
+  return MOT_OK;
+}
+
+static int check_frames_args(mot_ctx* c, const void* xyzw, long frame_stride, const int* n_points, int batch, int run_tracker,
+                             const double* timestamps, const double* ego_v, const double* ego_yaw) {
+  if (!xyzw || !n_points) return fail(c, MOT_E_ARG, "null cloud or point-count pointer");
+  if (frame_stride < 0 || frame_stride % 4) return fail(c, MOT_E_ARG, "frame_stride must be a non-negative multiple of 4 floats");
+  if (((size_t)xyzw & 15) != 0 || (batch > 1 && (frame_stride * 4) % 16 != 0)) return fail(c, MOT_E_ARG, "clouds must be 16-byte aligned");
+  if (run_tracker && (!timestamps || !ego_v || !ego_yaw)) return fail(c, MOT_E_ARG, "run_tracker needs timestamps, ego_v and ego_yaw");
+  return MOT_OK;
+}
+
+extern "C" int mot_frames_dev(mot_ctx* c, const float* d_xyzw, long frame_stride, const int* n_points, int batch,
+                              int run_tracker, const double* timestamps, const double* ego_v, const double* ego_yaw) {
+  if (!c) return MOT_E_ARG;
+  MOT_GUARD(c);
+  // every argument is checked before the first launch or state change
+  int rc = check_frames_args(c, d_xyzw, frame_stride, n_points, batch, run_tracker, timestamps, ego_v, ego_yaw);
+  if (rc) return rc;
+  if ((rc = set_batch(c, n_points, batch, (const float4*)d_xyzw, frame_stride / 4))) return rc;
+  return launch_frames(c, batch, run_tracker, timestamps, ego_v, ego_yaw);
+}
+
+// ---------------------------------------------------------------------------------------- pipelined host ingest
+static int ensure_copy_path(mot_ctx* c) {
+  if (c->copy_stream) return MOT_OK;
+  MOT_HIP(c, hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking));
+  for (int i = 0; i < 2; i++) {
+    MOT_HIP(c, hipMalloc(&c->d_stage[i], (size_t)c->batch * c->cap * sizeof(float4)));
+    MOT_HIP(c, hipEventCreateWithFlags(&c->ev_copied[i], hipEventDisableTiming));
+    MOT_HIP(c, hipEventCreateWithFlags(&c->ev_consumed[i], hipEventDisableTiming));
+  }
+  return MOT_OK;
+}
+
+// One sensor frame per slot from HOST memory (what the reference's nodes receive per message: OT/src/groundremove/main.cpp:91-136,
+// OT0/src/main.cpp:51-95), pipelined: the H2D copy of this batch runs on the context's copy stream into one of two staging
+// buffers while the kernels of the previous batch run on the compute stream. Returns as soon as everything is queued.
+extern "C" int mot_frames_host(mot_ctx* c, const float* h_xyzw, long frame_stride, const int* n_points, int batch,
+                               int run_tracker, const double* timestamps, const double* ego_v, const double* ego_yaw) {
+  if (!c) return MOT_E_ARG;
+  MOT_GUARD(c);
+  int rc = check_frames_args(c, h_xyzw, frame_stride, n_points, batch, run_tracker, timestamps, ego_v, ego_yaw);
+  if (rc) return rc;
+  if (batch < 1 || batch > c->batch) return fail(c, MOT_E_ARG, "batch out of range");
+  for (int b = 0; b < batch; b++) {
+    if (n_points[b] < 0) return fail(c, MOT_E_ARG, "negative point count");
+    if (n_points[b] > c->max_points) return fail(c, MOT_E_CAPACITY, "frame has more points than max_points");
+    if (batch > 1 && frame_stride / 4 < n_points[b]) return fail(c, MOT_E_ARG, "frame_stride is smaller than a frame");
+  }
+  if ((rc = ensure_copy_path(c))) return rc;
+  const int s = c->stage_next;
+  c->stage_next ^= 1;
+  // the staging buffer is free once the compaction kernel of the batch that used it last has run
+  if (c->stage_used[s]) MOT_HIP(c, hipStreamWaitEvent(c->copy_stream, c->ev_consumed[s], 0));
+  const bool dense = frame_stride / 4 == c->cap;   // host frames already at the staging stride: one copy for the whole batch
+  if (dense) {
+    size_t bytes = ((size_t)(batch - 1) * c->cap + (size_t)n_points[batch - 1]) * sizeof(float4);
+    if (bytes) MOT_HIP(c, hipMemcpyAsync(c->d_stage[s], h_xyzw, bytes, hipMemcpyHostToDevice, c->copy_stream));
+  } else {
+    for (int b = 0; b < batch; b++)
+      if (n_points[b] > 0)
+        MOT_HIP(c, hipMemcpyAsync(c->d_stage[s] + (size_t)b * c->cap, h_xyzw + (size_t)b * frame_stride, (size_t)n_points[b] * sizeof(float4),
+                                  hipMemcpyHostToDevice, c->copy_stream));
+  }
+  MOT_HIP(c, hipEventRecord(c->ev_copied[s], c->copy_stream));
+  MOT_HIP(c, hipStreamWaitEvent(c->stream, c->ev_copied[s], 0));
+  if ((rc = set_batch(c, n_points, batch, c->d_stage[s], c->cap))) return rc;
+  rc = launch_frames(c, batch, run_tracker, timestamps, ego_v, ego_yaw);
+  // (recorded after the whole sequence: the input is last read by the compaction kernel, but mot_time_stage may re-read it)
+  MOT_HIP(c, hipEventRecord(c->ev_consumed[s], c->stream));
+  c->stage_used[s] = true;
+  return rc;
+}
+
+// blocks until every H2D copy queued by mot_frames_host has completed: the caller's host buffers may be reused
+extern "C" int mot_wait_uploads(mot_ctx* c) {
+  if (!c) return MOT_E_ARG;
+  MOT_GUARD(c);
+  if (c->copy_stream) MOT_HIP(c, hipStreamSynchronize(c->copy_stream));
+  return MOT_OK;
+}
+
+// page-locked host memory for mot_frames_host / mot_fetch_tracks_async (pageable memory works too, but its copies are
+// staged by the runtime and do not overlap)
+extern "C" int mot_host_alloc(size_t bytes, void** out) {
+  if (!out || bytes == 0) return MOT_E_ARG;
+  *out = nullptr;
+  return hipHostMalloc(out, bytes, hipHostMallocDefault) == hipSuccess ? MOT_OK : MOT_E_HIP;
+}
+extern "C" int mot_host_free(void* p) { return (!p || hipHostFree(p) == hipSuccess) ? MOT_OK : MOT_E_HIP; }
+
+// live tracks of every slot -> the caller's HOST block, asynchronously on the context stream (read after mot_synchronize)
+extern "C" int mot_fetch_tracks_async(mot_ctx* c, int batch, void* h_tracks, int max_per_slot, int32_t* h_counts) {
+  if (!c) return MOT_E_ARG;
+  MOT_GUARD(c);
+  if (!h_tracks || !h_counts || batch < 1 || batch > c->batch || max_per_slot < 1) return fail(c, MOT_E_ARG, "mot_fetch_tracks_async: bad argument");
+  if (c->fetch_cap < max_per_slot) {
+    if (c->d_fetch) { MOT_HIP(c, hipStreamSynchronize(c->stream)); MOT_HIP(c, hipFree(c->d_fetch)); c->d_fetch = nullptr; }
+    MOT_HIP(c, hipMalloc(&c->d_fetch, (size_t)c->batch * max_per_slot * sizeof(mot_track)));
+    if (!c->d_fetch_counts) MOT_HIP(c, hipMalloc(&c->d_fetch_counts, (size_t)c->batch * sizeof(int)));
+    c->fetch_cap = max_per_slot;
+  }
+  mot_launch_export_tracks(track_buffers(c, false), batch, c->d_fetch, max_per_slot, c->d_fetch_counts, c->stream);
+  MOT_HIP(c, hipGetLastError());
+  MOT_HIP(c, hipMemcpyAsync(h_tracks, c->d_fetch, (size_t)batch * max_per_slot * sizeof(mot_track), hipMemcpyDeviceToHost, c->stream));
+  MOT_HIP(c, hipMemcpyAsync(h_counts, c->d_fetch_counts, (size_t)batch * sizeof(int), hipMemcpyDeviceToHost, c->stream));
+  return MOT_OK;
+}
+
+// ---------------------------------------------------------------------------------------- in-run kernel timing
+extern "C" int mot_profile_kernel(mot_ctx* c, int kernel_id) {
+  if (!c) return MOT_E_ARG;
+  MOT_GUARD(c);
+  if (!c->prof_created) {
+    for (int i = 0; i < mot_ctx::kProfRing; i++) { MOT_HIP(c, hipEventCreate(&c->prof_ev[i][0])); MOT_HIP(c, hipEventCreate(&c->prof_ev[i][1])); }
+    c->prof_created = true;
+  }
+  c->prof_kernel = kernel_id; c->prof_n = 0;
+  return MOT_OK;
+}
+extern "C" int mot_profile_read(mot_ctx* c, float* mean_ms, float* min_ms, float* max_ms, int* samples) {
+  if (!c || !mean_ms || !samples) return MOT_E_ARG;
+  MOT_GUARD(c);
+  MOT_HIP(c, hipStreamSynchronize(c->stream));
+  double tot = 0; float mn = 1e30f, mx = 0;
+  for (int i = 0; i < c->prof_n; i++) {
+    float ms = 0;
+    MOT_HIP(c, hipEventElapsedTime(&ms, c->prof_ev[i][0], c->prof_ev[i][1]));
+    tot += ms; mn = ms < mn ? ms : mn; mx = ms > mx ? ms : mx;
+  }
+  *samples = c->prof_n;
+  *mean_ms = c->prof_n ? (float)(tot / c->prof_n) : 0.f;
+  if (min_ms) *min_ms = c->prof_n ? mn : 0.f;
+  if (max_ms) *max_ms = mx;
+  c->prof_n = 0;   // the ring fills again
   return MOT_OK;
 }
 
@@ -411,21 +624,26 @@ static int set_count(mot_ctx* c, int slot, int which, int value) {
   return MOT_OK;
 }
 
-extern "C" int mot_get_clusters(mot_ctx* c, int slot, int32_t* grid, int* num_cluster, int32_t* point_label) {
-  if (!c || slot < 0 || slot >= c->batch) return MOT_E_ARG;
+extern "C" int mot_get_clusters(mot_ctx* c, int slot, int32_t* grid, int* num_cluster, int32_t* point_label, int label_capacity) {
+  if (!c) return MOT_E_ARG;
+  MOT_GUARD(c);
+  if (slot < 0 || slot >= c->batch) return fail(c, MOT_E_ARG, "slot out of range");
   int rc = fetch_counts(c, slot);
   if (rc) return rc;
   const int G = c->params.num_grid;
   if (num_cluster) *num_cluster = c->h_counts[slot * kCountsStride + kCntClusters];
   if (grid) MOT_HIP(c, hipMemcpyAsync(grid, c->d_grid + (size_t)slot * MOT_MAX_GRID * MOT_MAX_GRID, (size_t)G * G * sizeof(int), hipMemcpyDeviceToHost, c->stream));
   int ne = c->h_counts[slot * kCountsStride + kCntElev];
+  if (point_label && ne > label_capacity) return fail(c, MOT_E_CAPACITY, "more elevated points than the caller's label buffer holds");
   if (point_label && ne > 0) MOT_HIP(c, hipMemcpyAsync(point_label, c->d_label + (size_t)slot * c->cap, (size_t)ne * sizeof(int), hipMemcpyDeviceToHost, c->stream));
   MOT_HIP(c, hipStreamSynchronize(c->stream));
   return MOT_OK;
 }
 
 extern "C" int mot_get_boxes(mot_ctx* c, int slot, float* boxes, int max_boxes, int* n_boxes, int32_t* box_cluster, int* n_undefined) {
-  if (!c || slot < 0 || slot >= c->batch || max_boxes < 0) return MOT_E_ARG;
+  if (!c) return MOT_E_ARG;
+  MOT_GUARD(c);
+  if (slot < 0 || slot >= c->batch || max_boxes < 0) return fail(c, MOT_E_ARG, "mot_get_boxes: slot or max_boxes out of range");
   int rc = fetch_counts(c, slot);
   if (rc) return rc;
   int nb = c->h_counts[slot * kCountsStride + kCntBoxes];
@@ -439,8 +657,10 @@ extern "C" int mot_get_boxes(mot_ctx* c, int slot, float* boxes, int max_boxes, 
 }
 
 extern "C" int mot_cluster(mot_ctx* c, const float* elev, int n, int32_t* grid, int* num_cluster, int32_t* point_label) {
-  if (!c || (!elev && n > 0) || n < 0 || !num_cluster) return MOT_E_ARG;   // grid may be NULL: nothing but the count is read back
-  if (n > c->cap) return fail(c, MOT_E_CAPACITY, "cloud has more points than max_points");
+  if (!c) return MOT_E_ARG;
+  MOT_GUARD(c);
+  if ((!elev && n > 0) || n < 0 || !num_cluster) return fail(c, MOT_E_ARG, "mot_cluster: null cloud / negative n / null num_cluster");   // grid may be NULL: nothing but the count is read back
+  if (n > c->max_points) return fail(c, MOT_E_CAPACITY, "cloud has more points than max_points");
   int rc;
   if (n > 0) MOT_HIP(c, hipMemcpyAsync(c->d_elev, elev, (size_t)n * 16, hipMemcpyHostToDevice, c->stream));
   if ((rc = set_count(c, 0, kCntElev, n))) return rc;
@@ -452,13 +672,15 @@ extern "C" int mot_cluster(mot_ctx* c, const float* elev, int n, int32_t* grid, 
     MOT_HIP(c, hipMemsetAsync(c->d_counts + kCntGroups, 0, 2 * sizeof(int), c->stream));   // kCntGroups, kCntIrregular
   }
   MOT_HIP(c, hipGetLastError());
-  return mot_get_clusters(c, 0, grid, num_cluster, point_label);
+  return mot_get_clusters(c, 0, grid, num_cluster, point_label, n);
 }
 
 extern "C" int mot_box_fit(mot_ctx* c, const float* elev, int n, const int32_t* grid, int num_cluster, float* boxes, int max_boxes,
                            int* n_boxes, int32_t* box_cluster, int* n_undefined) {
-  if (!c || (!elev && n > 0) || n < 0 || !grid || num_cluster < 0 || !n_boxes) return MOT_E_ARG;
-  if (n > c->cap) return fail(c, MOT_E_CAPACITY, "cloud has more points than max_points");
+  if (!c) return MOT_E_ARG;
+  MOT_GUARD(c);
+  if ((!elev && n > 0) || n < 0 || !grid || num_cluster < 0 || !n_boxes) return fail(c, MOT_E_ARG, "mot_box_fit: null cloud / grid / n_boxes or a negative count");
+  if (n > c->max_points) return fail(c, MOT_E_CAPACITY, "cloud has more points than max_points");
   if (num_cluster > kMaxClusters) return fail(c, MOT_E_CAPACITY, "more clusters than the library supports (4096)");
   int rc;
   const int G = c->params.num_grid;
@@ -475,7 +697,9 @@ extern "C" int mot_box_fit(mot_ctx* c, const float* elev, int n, const int32_t* 
 // boxFitting on the elevated cloud and label grid resident in slot 0 after mot_cluster (the host-buffer stage calls work on
 // slot 0): no second upload of the cloud and the grid between the two stages of the cluster node
 extern "C" int mot_box_fit_resident(mot_ctx* c, float* boxes, int max_boxes, int* n_boxes, int32_t* box_cluster, int* n_undefined) {
-  if (!c || !n_boxes || max_boxes < 0) return MOT_E_ARG;
+  if (!c) return MOT_E_ARG;
+  MOT_GUARD(c);
+  if (!n_boxes || max_boxes < 0) return fail(c, MOT_E_ARG, "mot_box_fit_resident: null n_boxes or negative max_boxes");
   int rc = fetch_counts(c, 0);
   if (rc) return rc;
   const int n = c->h_counts[kCntElev];
@@ -489,7 +713,9 @@ extern "C" int mot_box_fit_resident(mot_ctx* c, float* boxes, int max_boxes, int
 // fromROSMsg for PointXYZ (OT/src/groundremove/main.cpp:100), device to device
 extern "C" int mot_decode_pointcloud2_dev(mot_ctx* c, const void* d_data, int n, int point_step, int off_x, int off_y, int off_z,
                                           int off_w, float* d_xyzw) {
-  if (!c || n < 0 || (n > 0 && (!d_data || !d_xyzw)) || point_step < 12) return MOT_E_ARG;
+  if (!c) return MOT_E_ARG;
+  MOT_GUARD(c);
+  if (n < 0 || (n > 0 && (!d_data || !d_xyzw)) || point_step < 12) return fail(c, MOT_E_ARG, "mot_decode_pointcloud2_dev: null buffer, negative n or point_step < 12");
   const int offs[4] = {off_x, off_y, off_z, off_w};
   for (int k = 0; k < 4; k++)
     if ((k < 3 || offs[k] >= 0) && (offs[k] < 0 || offs[k] + 4 > point_step)) return fail(c, MOT_E_ARG, "field offset outside the point record");
@@ -516,8 +742,10 @@ constexpr int kMaxCostCells = 65536;
 // makeClusteredCloud / setObsMsg / createCostMap, OT/src/cluster/component_clustering.cpp:311-379, 425-457
 extern "C" int mot_cluster_products(mot_ctx* c, int slot, const mot_side_params* sp, float* clustered_xyzw, int max_clustered,
                                     int* n_clustered, float* obstacles_xyzc, int max_obstacles, int* n_obstacles, int32_t* cost_map) {
-  if (!c || !sp || slot < 0 || slot >= c->batch || max_clustered < 0 || max_obstacles < 0) return MOT_E_ARG;
-  if ((clustered_xyzw && !n_clustered) || (obstacles_xyzc && !n_obstacles)) return MOT_E_ARG;
+  if (!c) return MOT_E_ARG;
+  MOT_GUARD(c);
+  if (!sp || slot < 0 || slot >= c->batch || max_clustered < 0 || max_obstacles < 0) return fail(c, MOT_E_ARG, "mot_cluster_products: null parameters, slot or a capacity out of range");
+  if ((clustered_xyzw && !n_clustered) || (obstacles_xyzc && !n_obstacles)) return fail(c, MOT_E_ARG, "mot_cluster_products: an output list needs its count pointer");
   if (sp->cost_width < 1 || sp->cost_height < 1 || (long)sp->cost_width * sp->cost_height > kMaxCostCells || !(sp->cost_resolution > 0))
     return fail(c, MOT_E_ARG, "cost map must have 1..65536 cells and a positive resolution");
   if (!c->d_side_cell) {
@@ -556,8 +784,10 @@ extern "C" int mot_cluster_products(mot_ctx* c, int slot, const mot_side_params*
 extern "C" int mot_cluster_products_host(mot_ctx* c, const float* elev, int n, const int32_t* grid, const mot_side_params* sp,
                                          float* clustered_xyzw, int max_clustered, int* n_clustered, float* obstacles_xyzc,
                                          int max_obstacles, int* n_obstacles, int32_t* cost_map) {
-  if (!c || (!elev && n > 0) || n < 0 || !grid) return MOT_E_ARG;
-  if (n > c->cap) return fail(c, MOT_E_CAPACITY, "cloud has more points than max_points");
+  if (!c) return MOT_E_ARG;
+  MOT_GUARD(c);
+  if ((!elev && n > 0) || n < 0 || !grid) return fail(c, MOT_E_ARG, "mot_cluster_products_host: null cloud / grid or negative n");
+  if (n > c->max_points) return fail(c, MOT_E_CAPACITY, "cloud has more points than max_points");
   const int G = c->params.num_grid;
   if (n > 0) MOT_HIP(c, hipMemcpyAsync(c->d_elev, elev, (size_t)n * 16, hipMemcpyHostToDevice, c->stream));
   MOT_HIP(c, hipMemcpyAsync(c->d_grid, grid, (size_t)G * G * sizeof(int), hipMemcpyHostToDevice, c->stream));
@@ -567,13 +797,17 @@ extern "C" int mot_cluster_products_host(mot_ctx* c, const float* elev, int n, c
 }
 
 extern "C" int mot_get_ground(mot_ctx* c, int slot, float* elev, int* n_elev, float* ground, int* n_ground,
-                              uint8_t* mask) {
-  if (!c || slot < 0 || slot >= c->batch) return MOT_E_ARG;
+                              uint8_t* mask, int capacity_points) {
+  if (!c) return MOT_E_ARG;
+  MOT_GUARD(c);
+  if (slot < 0 || slot >= c->batch) return fail(c, MOT_E_ARG, "slot out of range");
   int rc = fetch_counts(c, slot);
   if (rc) return rc;
   int ne = c->h_counts[slot * kCountsStride + kCntElev], ng = c->h_counts[slot * kCountsStride + kCntGround];
   if (n_elev) *n_elev = ne;
   if (n_ground) *n_ground = ng;
+  if ((elev && ne > capacity_points) || (ground && ng > capacity_points) || (mask && c->h_n[slot] > capacity_points))
+    return fail(c, MOT_E_CAPACITY, "more points resident than the caller's buffers hold (capacity_points)");
   if (elev && ne > 0) MOT_HIP(c, hipMemcpyAsync(elev, c->d_elev + (size_t)slot * c->cap, (size_t)ne * 16, hipMemcpyDeviceToHost, c->stream));
   if (ground && ng > 0) MOT_HIP(c, hipMemcpyAsync(ground, c->d_ground + (size_t)slot * c->cap, (size_t)ng * 16, hipMemcpyDeviceToHost, c->stream));
   if (mask && c->h_n[slot] > 0) MOT_HIP(c, hipMemcpyAsync(mask, c->d_mask + (size_t)slot * c->cap, (size_t)c->h_n[slot], hipMemcpyDeviceToHost, c->stream));
@@ -583,8 +817,10 @@ extern "C" int mot_get_ground(mot_ctx* c, int slot, float* elev, int* n_elev, fl
 
 extern "C" int mot_ground_remove(mot_ctx* c, const float* xyzw, int n, float* elev, int* n_elev, float* ground,
                                  int* n_ground, uint8_t* mask) {
-  if (!c || (!xyzw && n > 0) || n < 0) return MOT_E_ARG;
-  if (n > c->cap) return fail(c, MOT_E_CAPACITY, "frame has more points than max_points");
+  if (!c) return MOT_E_ARG;
+  MOT_GUARD(c);
+  if ((!xyzw && n > 0) || n < 0) return fail(c, MOT_E_ARG, "mot_ground_remove: null cloud or negative n");
+  if (n > c->max_points) return fail(c, MOT_E_CAPACITY, "frame has more points than max_points");
   if (n > 0) MOT_HIP(c, hipMemcpyAsync(c->d_in, xyzw, (size_t)n * 16, hipMemcpyHostToDevice, c->stream));
   int rc = set_batch(c, &n, 1, c->d_in, c->cap);
   if (rc) return rc;
@@ -592,14 +828,14 @@ extern "C" int mot_ground_remove(mot_ctx* c, const float* xyzw, int n, float* el
   GroundBuffers g = ground_buffers(c, c->d_in, c->cap, true);
   mot_launch_ground(c->dp, g, 1, n, c->stream);
   MOT_HIP(c, hipGetLastError());
-  return mot_get_ground(c, 0, elev, n_elev, ground, n_ground, mask);
+  return mot_get_ground(c, 0, elev, n_elev, ground, n_ground, mask, n);
 }
 
 // one H2D of the raw PointCloud2 records of a frame into the staging buffer, unpacked on the device into the context's own
 // input buffer (slot 0), 4th float = 1.0f
 static int upload_pointcloud2(mot_ctx* c, const void* data, int n, int point_step, int off_x, int off_y, int off_z) {
-  if (!c || n < 0 || (n > 0 && !data) || point_step < 12) return MOT_E_ARG;
-  if (n > c->cap) return fail(c, MOT_E_CAPACITY, "frame has more points than max_points");
+  if (n < 0 || (n > 0 && !data) || point_step < 12) return fail(c, MOT_E_ARG, "PointCloud2 payload: null data, negative n or point_step < 12");
+  if (n > c->max_points) return fail(c, MOT_E_CAPACITY, "frame has more points than max_points");
   const int offs[3] = {off_x, off_y, off_z};
   for (int k = 0; k < 3; k++)
     if (offs[k] < 0 || offs[k] + 4 > point_step) return fail(c, MOT_E_ARG, "field offset outside the point record");
@@ -619,6 +855,8 @@ static int upload_pointcloud2(mot_ctx* c, const void* data, int n, int point_ste
 // fromROSMsg + groundRemove for a message payload in host memory
 extern "C" int mot_ground_remove_pointcloud2(mot_ctx* c, const void* data, int n, int point_step, int off_x, int off_y, int off_z,
                                              float* elev, int* n_elev, float* ground, int* n_ground, uint8_t* mask) {
+  if (!c) return MOT_E_ARG;
+  MOT_GUARD(c);
   int rc = upload_pointcloud2(c, data, n, point_step, off_x, off_y, off_z);
   if (rc) return rc;
   rc = set_batch(c, &n, 1, c->d_in, c->cap);
@@ -627,25 +865,24 @@ extern "C" int mot_ground_remove_pointcloud2(mot_ctx* c, const void* data, int n
   GroundBuffers g = ground_buffers(c, c->d_in, c->cap, true);
   mot_launch_ground(c->dp, g, 1, n, c->stream);
   MOT_HIP(c, hipGetLastError());
-  return mot_get_ground(c, 0, elev, n_elev, ground, n_ground, mask);
+  return mot_get_ground(c, 0, elev, n_elev, ground, n_ground, mask, n);
 }
 
 // the whole stateless chain of a frame (what OT0/src/main.cpp:57-88 runs in one process) on a message payload in host memory:
 // the cloud is uploaded once and never leaves HBM between the stages
 extern "C" int mot_frame_pointcloud2(mot_ctx* c, const void* data, int n, int point_step, int off_x, int off_y, int off_z) {
+  if (!c) return MOT_E_ARG;
+  MOT_GUARD(c);
   int rc = upload_pointcloud2(c, data, n, point_step, off_x, off_y, off_z);
   if (rc) return rc;
   return mot_frames_dev(c, (const float*)c->d_in, (long)c->cap * 4, &n, 1, 0, nullptr, nullptr, nullptr);
 }
 
-// kernel ids used by mot_time_stage
-enum { kK1 = 10, kK2 = 11, kK3 = 12, kC1 = 20, kC2 = 21, kB1 = 30, kB2 = 31, kB3 = 32, kB2b = 33, kB1b = 34, kT1 = 40 };
-
 static int launch_one(mot_ctx* c, int id, int batch) {
   int rc;
   const int max_n = c->last_max_n;
   if (id == kK3 && (rc = next_epoch(c))) return rc;
-  GroundBuffers g = ground_buffers(c, c->last_in, c->last_in_stride, true);
+  GroundBuffers g = ground_buffers(c, c->last_in, c->last_in_stride, true, true);   // as in the fused path: the compaction kernel fills the occupancy planes
   ClusterBuffers cb = cluster_buffers(c);
   switch (id) {
     case kK1: mot_launch_ground_kernel(0, c->dp, g, batch, max_n, c->stream); break;
@@ -670,20 +907,24 @@ static int launch_one(mot_ctx* c, int id, int batch) {
 // HIP event on the context stream, launches the timed kernels, records a second event, and synchronises;
 // the result is the mean of the event-to-event times. Every sequence leaves the context in its between-calls state.
 extern "C" int mot_time_stage(mot_ctx* c, int stage, int batch, int iters, float* ms_per_iter) {
-  if (!c || !ms_per_iter || iters < 1) return MOT_E_ARG;
+  if (!c) return MOT_E_ARG;
+  MOT_GUARD(c);
+  if (!ms_per_iter || iters < 1) return fail(c, MOT_E_ARG, "mot_time_stage: null result pointer or iters < 1");
   if (!c->last_in || batch != c->last_batch) return fail(c, MOT_E_STATE, "call mot_frames_dev with the same batch first");
   struct Seq { int pre[4], timed[12], post[3]; };
   Seq s = {{0, 0, 0, 0}, {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, {0, 0, 0}};
   switch (stage) {
-    case 0: s = {{0}, {kK1, kK2, kK3}, {0}}; break;
-    case 1: s = {{0}, {kC1, kC2}, {0}}; break;
+    // (the compaction kernel K3 fills the occupancy planes, the labelling kernel C2 consumes and clears them: the two
+    // always run as a pair; C1, the stand-alone occupancy kernel of the stage-wise mot_cluster, is timed the same way)
+    case 0: s = {{0}, {kK1, kK2, kK3}, {kC2}}; break;
+    case 1: s = {{kK3}, {kC2}, {0}}; break;
     case 2: s = {{0}, {kB1, kB1b, kB2, kB2b, kB3}, {0}}; break;
-    case 100: s = {{0}, {kK1, kK2, kK3, kC1, kC2, kB1, kB1b, kB2, kB2b, kB3}, {0}}; break;
+    case 100: s = {{0}, {kK1, kK2, kK3, kC2, kB1, kB1b, kB2, kB2b, kB3}, {0}}; break;
     case kK1: s = {{0}, {kK1}, {0}}; break;
     case kK2: s = {{0}, {kK2}, {0}}; break;
-    case kK3: s = {{0}, {kK3}, {0}}; break;
+    case kK3: s = {{0}, {kK3}, {kC2}}; break;
     case kC1: s = {{0}, {kC1}, {kC2}}; break;
-    case kC2: s = {{kC1}, {kC2}, {0}}; break;
+    case kC2: s = {{kK3}, {kC2}, {0}}; break;
     case kB1: s = {{0}, {kB1}, {kB1b, kB3}}; break;
     case kB1b: s = {{kB1}, {kB1b}, {kB3}}; break;
     case kB2: s = {{kB1, kB1b}, {kB2}, {kB3}}; break;
@@ -716,6 +957,7 @@ static TrackBuffers track_buffers(mot_ctx* c, bool fused) {
   TrackBuffers t;
   t.tracks = c->d_tracks; t.nt = c->d_nt; t.boxes = c->d_tboxes; t.args = c->d_targs; t.gate = c->d_gate; t.prog = c->d_prog;
   t.live = c->d_live; t.out = c->d_tout; t.flags = c->d_tflags; t.phase_clock = c->d_phase; t.m_dev = fused ? c->d_counts : nullptr; t.T = c->max_tracks_total;
+  t.box_stride = (long)kMaxBoxesPerFrame * 24;
   t.tp.gamma_g = c->params.gamma_g; t.tp.p_g = c->params.p_g; t.tp.p_d = c->params.p_d; t.tp.distance_thres = c->params.distance_thres;
   t.tp.bb_yaw_change_thres = c->params.bb_yaw_change_thres; t.tp.seed_px = c->params.seed_px; t.tp.seed_py = c->params.seed_py;
   t.tp.life_time_thres = c->params.life_time_thres; t.tp.seed_box_index = c->params.seed_box_index;
@@ -727,7 +969,8 @@ static TrackBuffers track_buffers(mot_ctx* c, bool fused) {
 // replay repeats the previous one and appends one step, so the running state is carried instead — same operations,
 // same values.
 extern "C" int mot_ego_update(mot_ctx* c, int slot, double timestamp, double v_gps, double yaw_gps, double* origin6) {
-  if (!c || slot < 0 || slot >= c->batch) return MOT_E_ARG;
+  if (!c) return MOT_E_ARG;
+  if (slot < 0 || slot >= c->batch) return fail(c, MOT_E_ARG, "slot out of range");
   mot_ctx::SlotEgo& e = c->ego[slot];
   double dt = (timestamp - e.timestamp) / 1000000.0;
   e.egoVelo = v_gps;
@@ -768,29 +1011,47 @@ static void prepare_track_args(mot_ctx* c, int slot, int m, double timestamp, bo
 }
 
 extern "C" int mot_get_tracks(mot_ctx* c, int slot, mot_track* tracks, int max_tracks, int* n_tracks) {
-  if (!c || slot < 0 || slot >= c->batch || !n_tracks || max_tracks < 0) return MOT_E_ARG;
+  if (!c) return MOT_E_ARG;
+  MOT_GUARD(c);
+  if (slot < 0 || slot >= c->batch || !n_tracks || max_tracks < 0) return fail(c, MOT_E_ARG, "mot_get_tracks: slot out of range, null n_tracks or negative max_tracks");
   int meta[2] = {0, 0};
   MOT_HIP(c, hipMemcpyAsync(&meta[0], c->d_nt + slot, sizeof(int), hipMemcpyDeviceToHost, c->stream));
   MOT_HIP(c, hipMemcpyAsync(&meta[1], c->d_tflags + slot, sizeof(int), hipMemcpyDeviceToHost, c->stream));
   MOT_HIP(c, hipStreamSynchronize(c->stream));
   c->ego[slot].nt = meta[0];
   *n_tracks = meta[0];
-  if (meta[1]) {
-    MOT_HIP(c, hipMemsetAsync(c->d_tflags + slot, 0, sizeof(int), c->stream));
-    return fail(c, MOT_E_CAPACITY, "more tracks were created on this stream than max_tracks_total (the reference never frees a track)");
-  }
   if (meta[0] > max_tracks) return fail(c, MOT_E_CAPACITY, "more tracks than the caller's buffer holds");
   if (tracks && meta[0] > 0) {
     MOT_HIP(c, hipMemcpyAsync(tracks, c->d_tout + (size_t)slot * c->max_tracks_total, (size_t)meta[0] * sizeof(mot_track), hipMemcpyDeviceToHost, c->stream));
     MOT_HIP(c, hipStreamSynchronize(c->stream));
   }
+  // The capacity flag is STICKY: once a birth has been dropped the stream keeps answering MOT_E_CAPACITY (the records above
+  // are still delivered) until the caller starts it over with mot_reset / mot_reset_slot — a caller that ignores one error
+  // is told again on every call, not only at the next dropped birth.
+  if (meta[1])
+    return fail(c, MOT_E_CAPACITY, "more tracks were created on this stream than max_tracks_total (the reference never frees a track): "
+                                   "births are being dropped; mot_reset_slot() starts the stream over");
+  return MOT_OK;
+}
+
+// forget the tracker state of ONE stream (mot_reset does it for all of them)
+extern "C" int mot_reset_slot(mot_ctx* c, int slot) {
+  if (!c) return MOT_E_ARG;
+  MOT_GUARD(c);
+  if (slot < 0 || slot >= c->batch) return fail(c, MOT_E_ARG, "slot out of range");
+  MOT_HIP(c, hipMemsetAsync(c->d_nt + slot, 0, sizeof(int), c->stream));
+  MOT_HIP(c, hipMemsetAsync(c->d_tflags + slot, 0, sizeof(int), c->stream));
+  MOT_HIP(c, hipStreamSynchronize(c->stream));
+  c->ego[slot] = mot_ctx::SlotEgo();
   return MOT_OK;
 }
 
 // immUkfJpdaf(), OT/tracking/imm_ukf_jpda.cpp:704
 extern "C" int mot_track_step(mot_ctx* c, int slot, const float* boxes_global, int m, double timestamp, mot_track* tracks,
                               int max_tracks, int* n_tracks) {
-  if (!c || slot < 0 || slot >= c->batch || m < 0 || (!boxes_global && m > 0) || !n_tracks) return MOT_E_ARG;
+  if (!c) return MOT_E_ARG;
+  MOT_GUARD(c);
+  if (slot < 0 || slot >= c->batch || m < 0 || (!boxes_global && m > 0) || !n_tracks) return fail(c, MOT_E_ARG, "mot_track_step: slot out of range, negative m, null boxes or null n_tracks");
   if (m > kMaxBoxesPerFrame) return fail(c, MOT_E_CAPACITY, "more boxes in a frame than the library supports (1024)");
   if (!c->ego[slot].ego_called) return fail(c, MOT_E_STATE, "mot_ego_update must precede mot_track_step (getOriginPoints precedes immUkfJpdaf, OT/tracking/main.cpp:74,166)");
   for (int b = 0; b < c->batch; b++) c->h_targs[b].run = 0;
@@ -802,15 +1063,41 @@ extern "C" int mot_track_step(mot_ctx* c, int slot, const float* boxes_global, i
   return mot_get_tracks(c, slot, tracks, max_tracks, n_tracks);
 }
 
+// immUkfJpdaf for one frame of EVERY slot 0..batch-1 with the boxes already on the device (global frame): d_boxes_global holds
+// box_stride_floats floats per slot (>= 24 * m[b]), m[] (host) the number of boxes per slot. Callers with their own detector,
+// and the tracker's load measurements, enter here; mot_ego_update(slot) must have been called for the frame as usual.
+extern "C" int mot_track_steps_dev(mot_ctx* c, const float* d_boxes_global, long box_stride_floats, const int* m, int batch, const double* timestamps) {
+  if (!c) return MOT_E_ARG;
+  MOT_GUARD(c);
+  if (!d_boxes_global || !m || !timestamps || batch < 1 || batch > c->batch || box_stride_floats < 0) return fail(c, MOT_E_ARG, "mot_track_steps_dev: bad argument");
+  for (int b = 0; b < batch; b++) {
+    if (m[b] < 0 || (long)m[b] * 24 > box_stride_floats) return fail(c, MOT_E_ARG, "mot_track_steps_dev: m[b] boxes do not fit box_stride_floats");
+    if (m[b] > kMaxBoxesPerFrame) return fail(c, MOT_E_CAPACITY, "more boxes in a frame than the library supports (1024)");
+    if (!c->ego[b].ego_called) return fail(c, MOT_E_STATE, "mot_ego_update must precede the tracker step of a slot");
+  }
+  for (int b = 0; b < c->batch; b++) c->h_targs[b].run = 0;
+  for (int b = 0; b < batch; b++) prepare_track_args(c, b, m[b], timestamps[b], true);
+  MOT_HIP(c, hipMemcpyAsync(c->d_targs, c->h_targs.data(), c->batch * sizeof(TrackFrameArgs), hipMemcpyHostToDevice, c->stream));
+  TrackBuffers t = track_buffers(c, false);
+  t.boxes = d_boxes_global; t.box_stride = box_stride_floats;
+  mot_launch_track(t, batch, c->stream);
+  MOT_HIP(c, hipGetLastError());
+  return MOT_OK;
+}
+
 extern "C" int mot_export_tracks_dev(mot_ctx* c, int batch, void* d_tracks, int max_per_slot, int32_t* d_counts) {
-  if (!c || !d_tracks || !d_counts || batch < 1 || batch > c->batch || max_per_slot < 1) return MOT_E_ARG;
+  if (!c) return MOT_E_ARG;
+  MOT_GUARD(c);
+  if (!d_tracks || !d_counts || batch < 1 || batch > c->batch || max_per_slot < 1) return fail(c, MOT_E_ARG, "mot_export_tracks_dev: bad argument");
   mot_launch_export_tracks(track_buffers(c, false), batch, (mot_track*)d_tracks, max_per_slot, (int*)d_counts, c->stream);
   MOT_HIP(c, hipGetLastError());
   return MOT_OK;
 }
 
 extern "C" int mot_track_get_state(mot_ctx* c, int slot, int id, mot_track_state* o) {
-  if (!c || slot < 0 || slot >= c->batch || !o || id < 0) return MOT_E_ARG;
+  if (!c) return MOT_E_ARG;
+  MOT_GUARD(c);
+  if (slot < 0 || slot >= c->batch || !o || id < 0) return fail(c, MOT_E_ARG, "mot_track_get_state: slot / id out of range or null result");
   int nt = 0;
   MOT_HIP(c, hipMemcpyAsync(&nt, c->d_nt + slot, sizeof(int), hipMemcpyDeviceToHost, c->stream));
   MOT_HIP(c, hipStreamSynchronize(c->stream));
@@ -832,6 +1119,7 @@ extern "C" int mot_track_get_state(mot_ctx* c, int slot, int id, mot_track_state
 // internal debugging aid (not part of include/mot.h): raw copy of a per-slot device array to the host
 extern "C" int mot_debug_copy(mot_ctx* c, int which, int slot, void* dst, size_t bytes) {
   if (!c || !dst || slot < 0 || slot >= c->batch) return MOT_E_ARG;
+  MOT_GUARD(c);
   const void* src = nullptr;
   if (which == 0) src = c->d_cand + (size_t)slot * kMaxClusters;
   else if (which == 1) src = c->d_stats + (size_t)slot * kMaxClusters;
@@ -841,8 +1129,26 @@ extern "C" int mot_debug_copy(mot_ctx* c, int which, int slot, void* dst, size_t
   else if (which == 7) src = c->d_cluster_start + (size_t)slot * (kMaxClusters + 1);
   else if (which == 8) src = c->d_pix + (size_t)slot * c->cap;
   else if (which == 9) src = c->d_groups + (size_t)slot * (c->cap / 2);
+  else if (which == 10) src = c->d_hg + (size_t)slot * MOT_POLAR_CELLS;
   else return MOT_E_ARG;
   MOT_HIP(c, hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, c->stream));
   MOT_HIP(c, hipStreamSynchronize(c->stream));
+  return MOT_OK;
+}
+
+void mot_launch_sweep(const MotDevParams& p, int what, int mode, unsigned long long seed, unsigned long long count, void* d_stats, hipStream_t stream);
+
+// test hook (mot_debug_api.h): the guarded fast cells against their exact evaluation, on the device
+extern "C" int mot_debug_sweep(mot_ctx* c, int what, int mode, unsigned long long seed, unsigned long long count, unsigned long long* stats8) {
+  if (!c || !stats8 || what < 0 || what > 1 || mode < 0 || mode > 2) return MOT_E_ARG;
+  MOT_GUARD(c);
+  void* d = nullptr;
+  MOT_HIP(c, hipMalloc(&d, 8 * sizeof(unsigned long long)));
+  MOT_HIP(c, hipMemsetAsync(d, 0, 8 * sizeof(unsigned long long), c->stream));
+  mot_launch_sweep(c->dp, what, mode, seed, count, d, c->stream);
+  MOT_HIP(c, hipGetLastError());
+  MOT_HIP(c, hipMemcpyAsync(stats8, d, 8 * sizeof(unsigned long long), hipMemcpyDeviceToHost, c->stream));
+  MOT_HIP(c, hipStreamSynchronize(c->stream));
+  MOT_HIP(c, hipFree(d));
   return MOT_OK;
 }

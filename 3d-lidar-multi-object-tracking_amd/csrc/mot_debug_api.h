@@ -1,0 +1,21 @@
+// mot_debug_api.h — test / measurement hooks exported by libmot_hip.so that are NOT part of the drop-in C-ABI (include/mot.h).
+// Used by tests/ and tools/ only.
+#ifndef MOT_DEBUG_API_H_
+#define MOT_DEBUG_API_H_
+#include <stddef.h>
+#include <stdint.h>
+#include "../../include/mot.h"
+#ifdef __cplusplus
+extern "C" {
+#endif
+/* raw copy of a per-slot device array to the host (which: 0 box candidates, 1 cluster statistics, 2 tracker phase clocks,
+ * 3 polygon pool, 5 cluster-sorted index, 7 cluster starts, 8 pixels, 9 (tile, cluster) groups, 10 polar thresholds hGround) */
+int mot_debug_copy(mot_ctx* ctx, int which, int slot, void* dst, size_t bytes);
+/* on-device sweep of a guarded fast path against its exact evaluation with the REAL hardware instructions (debug.hip):
+ * what 0 polar cell, 1 Cartesian cell; mode 0 random, 1 lattice, 2 cell boundaries +-3 ulp. stats[0..4] = points, undecided,
+ * mismatches, first mismatch (x bits | y bits << 32), its (fast | exact << 32). Synchronous. */
+int mot_debug_sweep(mot_ctx* ctx, int what, int mode, unsigned long long seed, unsigned long long count, unsigned long long* stats8);
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -56,6 +56,7 @@ struct MotDevParams {
   float crop_z_min, crop_z_max, crop_x_min, crop_x_max, crop_y_min, crop_y_max;
   int num_grid, occ_min_count, dilate;
   float roi_m, roi_half;                       // roi_half = roiM/2 (fp32)
+  float k_grid;                                // numGrid / roiM, for the guarded fast path of the Cartesian cell only
   float pic_scale, pic_full, pic_half;         // picScale*roiM and roiM*picScale/2 (fp32 products)
   int ram_points, l_slope_dist, l_num_points, lshape_side_cond, min_points;
   float sensor_height;
@@ -80,6 +81,11 @@ struct GroundBuffers {
   int* counts;             // [B][kCountsStride]: n_elevated, n_ground, n_dropped, ...
   long cap;                // capacity (points) per frame of the outputs
   int max_chunks;
+  // occupancy bit-planes of the cluster stage ([B][kPlaneWords] each, see ClusterBuffers), or null: when set, the
+  // compaction kernel also files every elevated point under its Cartesian cell (mapCartesianGrid's histogram,
+  // component_clustering.cpp:36-50) while the point is still in registers, and the fused path skips cart_occupancy_kernel
+  unsigned* plane_a;
+  unsigned* plane_b;
 };
 
 // ---- cluster + box stages ------------------------------------------------------------------
@@ -143,7 +149,8 @@ struct ClusterBuffers {
   int max_wg;                  // cap / 2048 rounded up
 };
 
-void mot_launch_cluster(const MotDevParams& p, const ClusterBuffers& c, int batch, int max_n, hipStream_t stream);
+// occupancy_done: the compaction kernel of the ground stage already filled the bit-planes (fused path)
+void mot_launch_cluster(const MotDevParams& p, const ClusterBuffers& c, int batch, int max_n, hipStream_t stream, bool occupancy_done = false);
 void mot_launch_box(const MotDevParams& p, const ClusterBuffers& c, int batch, int max_n, hipStream_t stream);
 // pieces, for the stage-wise host entry points and per-kernel timing
 void mot_launch_cluster_kernel(int which, const MotDevParams& p, const ClusterBuffers& c, int batch, int max_n, hipStream_t stream);
@@ -205,7 +212,8 @@ struct MotTrackParams {
 struct TrackBuffers {
   DevTrack* tracks;             // [B][T]
   int* nt;                      // [B] tracks ever created
-  const float* boxes;           // [B][kMaxBoxesPerFrame][24], global frame
+  const float* boxes;           // [B][box_stride] floats, 24 per box, global frame
+  long box_stride;              // floats per slot (kMaxBoxesPerFrame * 24 for the library's own buffer)
   const TrackFrameArgs* args;   // [B]
   unsigned long long* gate;     // [B][T][kGateWords]
   unsigned long long* prog;     // [B][T][kGateWords]
@@ -259,6 +267,28 @@ MOT_HD bool mot_cart_cell(const MotDevParams& p, float x, float y, int* xI, int*
   if (!(fx >= 0.f && fx < (float)p.num_grid && fy >= 0.f && fy < (float)p.num_grid)) return false;
   *xI = (int)fx; *yI = (int)fy;
   return true;
+}
+
+// Guarded fast path of mot_cart_cell for the streaming kernels: bit index xI * 256 + yI of the cell, -1 outside the ROI,
+// -2 undecided (call mot_cart_cell). The exact index is floor(fl(fl(G * xC) / roiM)); the estimate xC * fl(G / roiM)
+// differs from that quotient by at most 4 roundings of a value below 256 (< 6.2e-5), so whenever the estimate is farther
+// than kCartGuard from an integer both floors agree. NaN fails every guard compare and lands in the exact path, which
+// drops it. tests/test_math_exact.py::test_fast_cart_cell_agrees checks the claim.
+constexpr float kCartGuard = 2.5e-4f;
+MOT_HD int mot_cart_bit_try(const MotDevParams& p, float x, float y) {
+  const float xC = x + p.roi_half, yC = y + p.roi_half;
+  const bool outside = xC < 0 || xC >= p.roi_m || yC < 0 || yC >= p.roi_m;
+  const float tx = xC * p.k_grid, ty = yC * p.k_grid;
+  const float fx = floorf(tx), fy = floorf(ty);
+  const float rx = tx - fx, ry = ty - fy;
+  const bool safe = rx > kCartGuard && rx < 1.f - kCartGuard && ry > kCartGuard && ry < 1.f - kCartGuard;   // false on NaN
+  const int bit = (int)fx * MOT_MAX_GRID + (int)fy;
+  return outside ? -1 : (safe ? bit : -2);
+}
+MOT_HD int mot_cart_bit(const MotDevParams& p, float x, float y) {
+  int bit = mot_cart_bit_try(p, x, y);
+  if (bit == -2) { int xI, yI; bit = mot_cart_cell(p, x, y, &xI, &yI) ? xI * MOT_MAX_GRID + yI : -1; }
+  return bit;
 }
 
 // getCellIndexFromPoints (ground_removal.cpp:67-76) + filterCloud's range test (:53) + the callers'

@@ -9,6 +9,20 @@
 // IEEE fp32 (compile with -ffp-contract=off, correctly rounded fp32 divide) reproduces it exactly.
 // tests/test_math_exact.py checks this header (compiled for the host) against the C library on
 // >1e8 inputs, including every special-case branch.
+//
+// mot_atanf / mot_atan2f follow the algorithm, breakpoints and coefficient table of fdlibm's s_atanf.c / e_atan2f.c
+// (as shipped in glibc); the notice that code carries is reproduced here as its licence requires:
+//
+//   ====================================================
+//   Copyright (C) 1993 by Sun Microsystems, Inc. All rights reserved.
+//
+//   Developed at SunPro, a Sun Microsystems, Inc. business.
+//   Permission to use, copy, modify, and distribute this
+//   software is freely granted, provided that this notice
+//   is preserved.
+//   ====================================================
+//
+//   (float versions: conversion to float by Ian Lance Taylor, Cygnus Support, ian@cygnus.com)
 #ifndef MOT_MATH_H_
 #define MOT_MATH_H_
 

@@ -406,7 +406,7 @@ track_step_kernel(TrackBuffers tb) {
   const int tid = threadIdx.x, lane = tlane(), wave = tid >> 6;
   const int M = tb.m_dev ? min(tb.m_dev[b * kCountsStride + kCntBoxes], kMaxBoxesPerFrame) : args.m;
   DevTrack* __restrict__ tracks = tb.tracks + (long)b * tb.T;
-  const float* __restrict__ boxes = tb.boxes + (long)b * kMaxBoxesPerFrame * 24;
+  const float* __restrict__ boxes = tb.boxes + (long)b * tb.box_stride;
   unsigned long long* __restrict__ gate = tb.gate + (long)b * tb.T * kGateWords;
   unsigned long long* __restrict__ prog = tb.prog + (long)b * tb.T * kGateWords;
   int* __restrict__ live = tb.live + (long)b * 2 * tb.T;

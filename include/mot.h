@@ -23,19 +23,22 @@
  *     with no D2H/H2D; they run on the context's HIP stream and do not synchronise.
  *   - a context owns B = max_batch independent sensor streams ("slots"); batch entry points
  *     process slot b = 0..B-1 in one launch sequence. The single-frame entry points use slot 0.
- *   - all device code is HIP for gfx950; there is NO CPU fallback: without a GPU
- *     mot_create() fails with MOT_E_HIP.
+ *   - all device code is HIP for gfx950; there is NO CPU fallback: without a GPU (or on a
+ *     device that is not gfx950) mot_create() fails with MOT_E_HIP.
+ *   - every entry point makes the context's device current for its own duration and restores the
+ *     caller's: contexts on different GPUs may be used from one thread, and from any thread.
  */
 #ifndef MOT_H_
 #define MOT_H_
 
+#include <stddef.h>
 #include <stdint.h>
 
 #ifdef __cplusplus
 extern "C" {
 #endif
 
-#define MOT_ABI_VERSION 1
+#define MOT_ABI_VERSION 2
 
 /* polar grid of the ground stage: compile-time in the reference too
  * (OT/include/ground_removal.h:16-17) */
@@ -151,6 +154,8 @@ void mot_destroy(mot_ctx* ctx);
 /* forget all tracker state of every slot (the reference cannot: file-scope globals,
  * OT/tracking/imm_ukf_jpda.cpp:19-24,56-70) */
 int mot_reset(mot_ctx* ctx);
+/* the same for one stream */
+int mot_reset_slot(mot_ctx* ctx, int slot);
 const char* mot_last_error(const mot_ctx* ctx);
 int mot_synchronize(mot_ctx* ctx);
 /* the HIP stream (hipStream_t) the context launches on, for callers that enqueue their own work */
@@ -220,13 +225,37 @@ int mot_track_get_state(mot_ctx* ctx, int slot, int id, mot_track_state* out);
 int mot_frames_dev(mot_ctx* ctx, const float* d_xyzw, long frame_stride, const int* n_points, int batch,
                    int run_tracker, const double* timestamps, const double* ego_v, const double* ego_yaw);
 
-/* read back results of the last mot_frames_dev / stage call for `slot` (host buffers; any may be NULL) */
+/* The same for frames in HOST memory — what the reference's nodes receive, one message per frame
+ * (OT/src/groundremove/main.cpp:91-136, OT0/src/main.cpp:51-95) — pipelined: the H2D copy of this batch runs on the
+ * context's copy stream into one of two staging buffers while the kernels of the previous batch run. Returns when
+ * everything is queued. h_xyzw should be page-locked (mot_host_alloc): copies from pageable memory are staged by the
+ * runtime and do not overlap. The host buffer may be reused after mot_wait_uploads (or mot_synchronize). */
+int mot_frames_host(mot_ctx* ctx, const float* h_xyzw, long frame_stride, const int* n_points, int batch,
+                    int run_tracker, const double* timestamps, const double* ego_v, const double* ego_yaw);
+int mot_wait_uploads(mot_ctx* ctx);
+int mot_host_alloc(size_t bytes, void** out);
+int mot_host_free(void* p);
+/* live tracks of slots 0..batch-1 (mot_export_tracks_dev's block) into HOST memory h_tracks[batch][max_per_slot] /
+ * h_counts[batch], asynchronously on the context stream: valid after mot_synchronize */
+int mot_fetch_tracks_async(mot_ctx* ctx, int batch, void* h_tracks, int max_per_slot, int32_t* h_counts);
+
+/* read back results of the last mot_frames_dev / stage call for `slot` (host buffers; any may be NULL).
+ * capacity_points: points each of elevated_xyzw / ground_xyzw / mask can hold; label_capacity: ints point_label can hold.
+ * The counts are always delivered; MOT_E_CAPACITY (nothing copied) when a requested buffer is too small. */
 int mot_get_ground(mot_ctx* ctx, int slot, float* elevated_xyzw, int* n_elevated, float* ground_xyzw,
-                   int* n_ground, uint8_t* mask);
-int mot_get_clusters(mot_ctx* ctx, int slot, int32_t* grid, int* num_cluster, int32_t* point_label);
+                   int* n_ground, uint8_t* mask, int capacity_points);
+int mot_get_clusters(mot_ctx* ctx, int slot, int32_t* grid, int* num_cluster, int32_t* point_label, int label_capacity);
 int mot_get_boxes(mot_ctx* ctx, int slot, float* boxes, int max_boxes, int* n_boxes, int32_t* box_cluster,
                   int* n_undefined);
+/* MOT_E_CAPACITY with the records still delivered when births were dropped on this stream (more tracks ever created than
+ * max_tracks_total; the reference never frees a track): the condition is STICKY until mot_reset / mot_reset_slot. */
 int mot_get_tracks(mot_ctx* ctx, int slot, mot_track* tracks, int max_tracks, int* n_tracks);
+
+/* immUkfJpdaf for one frame of every slot 0..batch-1 with the boxes already on the DEVICE (global frame):
+ * d_boxes_global holds box_stride_floats floats per slot (24 per box), m[b] (host) boxes per slot. mot_ego_update(slot)
+ * precedes it as for mot_track_step. Asynchronous; read with mot_get_tracks / mot_export_tracks_dev. */
+int mot_track_steps_dev(mot_ctx* ctx, const float* d_boxes_global, long box_stride_floats, const int* m, int batch,
+                        const double* timestamps);
 
 /* packs the LIVE tracks (track_manage != 0) of every slot, in track-id order, into a caller-owned DEVICE buffer
  * d_tracks[batch][max_per_slot] (mot_track records) and their number into d_counts[batch] (int32) — the fixed-size
@@ -279,8 +308,14 @@ int mot_decode_pointcloud2_dev(mot_ctx* ctx, const void* d_data, int n_points, i
 /* Re-runs only the named stage `iters` times on the data resident from the last mot_frames_dev call,
  * bracketed by hipEvents ON THE CONTEXT STREAM; returns average milliseconds per iteration.
  * stage: 0 ground, 1 cluster, 2 box, 100 the three stateless stages; single kernels: 10-12 ground, 20-21 cluster,
- * 30-32 box; 40 re-runs the tracker kernel with the last frame's arguments (that ADVANCES tracker state: bench only). */
+ * 30-34 box; 40 re-runs the tracker kernel with the last frame's arguments (that ADVANCES tracker state: bench only). */
 int mot_time_stage(mot_ctx* ctx, int stage, int batch, int iters, float* ms_per_iter);
+/* In-run timing: from now on every mot_frames_dev / mot_frames_host call brackets its launch of kernel `kernel_id` (ids as
+ * for mot_time_stage; 0 = off) with a HIP event pair on the context stream, up to 64 launches; mot_profile_read synchronises,
+ * returns mean / min / max of the recorded durations in milliseconds and re-arms. This is the kernel's duration INSIDE the
+ * running pipeline (other contexts' kernels overlapping it), the number a rocprofv3 kernel trace of the same run reports. */
+int mot_profile_kernel(mot_ctx* ctx, int kernel_id);
+int mot_profile_read(mot_ctx* ctx, float* mean_ms, float* min_ms, float* max_ms, int* samples);
 
 #ifdef __cplusplus
 }

@@ -226,7 +226,7 @@ inline std::vector<pcl::PointCloud<pcl::PointXYZ>> boxFitting(pcl::PointCloud<pc
   check(mot_box_fit(context(), in.data(), (int)elevatedCloud->size(), grid.data(), numCluster, boxes.data(), 1024, &nb, box_cluster.data(), nullptr));
   box_cluster.resize(nb);
   if (nb > 0) {   // the per-point labels the box stage left in slot 0 (getClusteredPoints' lookup, box_fitting.cpp:46-72)
-    check(mot_get_clusters(context(), 0, nullptr, nullptr, label.data()));
+    check(mot_get_clusters(context(), 0, nullptr, nullptr, label.data(), (int)label.size()));
     fill_cube_markers(ma, *elevatedCloud, label, box_cluster, numCluster, 0);
   }
   std::vector<pcl::PointCloud<pcl::PointXYZ>> out(nb);

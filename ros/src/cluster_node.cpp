@@ -117,7 +117,7 @@ class ClusterNode {
   visualization_msgs::MarkerArray cube_markers(const float* elevated, size_t n, int num_cluster, int n_boxes) {
     visualization_msgs::MarkerArray out;
     if (n_boxes == 0) return out;
-    mot_ros::check(ctx_, mot_get_clusters(ctx_, 0, nullptr, nullptr, label_.data()), "mot_get_clusters");
+    mot_ros::check(ctx_, mot_get_clusters(ctx_, 0, nullptr, nullptr, label_.data(), (int)label_.size()), "mot_get_clusters");
     struct Fold { float sum[3] = {0, 0, 0}, lo[3] = {FLT_MAX, FLT_MAX, FLT_MAX}, hi[3] = {-FLT_MAX, -FLT_MAX, -FLT_MAX}; unsigned count = 0; };
     std::vector<Fold> fold((size_t)num_cluster + 1);
     for (size_t i = 0; i < n; i++) {

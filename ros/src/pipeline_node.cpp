@@ -73,7 +73,7 @@ class PipelineNode {
     int n_elevated = 0, n_boxes = 0;
     if (cloud_pub_.getNumSubscribers() > 0) {
       if (elevated_.size() < 4 * n + 4) elevated_.resize(4 * n + 4);
-      mot_ros::check(ctx_, mot_get_ground(ctx_, 0, elevated_.data(), &n_elevated, nullptr, nullptr, nullptr), "mot_get_ground");
+      mot_ros::check(ctx_, mot_get_ground(ctx_, 0, elevated_.data(), &n_elevated, nullptr, nullptr, nullptr, (int)(elevated_.size() / 4)), "mot_get_ground");
       sensor_msgs::PointCloud2 msg;
       mot_ros::fill_xyz_cloud(msg, elevated_.data(), (size_t)n_elevated);
       msg.header.frame_id = scan->header.frame_id;

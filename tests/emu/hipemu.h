@@ -297,6 +297,7 @@ static inline const char* hipGetErrorString(hipError_t e) { return e == hipSucce
 static inline hipError_t hipGetLastError() { return hipSuccess; }
 static inline hipError_t hipGetDeviceCount(int* n) { *n = 1; return hipSuccess; }
 static inline hipError_t hipSetDevice(int) { return hipSuccess; }
+static inline hipError_t hipGetDevice(int* d) { *d = 0; return hipSuccess; }
 static inline hipError_t hipGetDeviceProperties(hipDeviceProp_t* p, int) { memset(p, 0, sizeof *p); strcpy(p->name, "hipemu"); strcpy(p->gcnArchName, "gfx950:emulated"); p->multiProcessorCount = 256; return hipSuccess; }
 // device memory arrives poisoned (0xFF: NaN floats, -1 ints) so that reads of never-written memory show up in the tests
 static inline hipError_t hipMalloc(void** p, size_t n) { *p = malloc(n ? n : 1); if (*p) memset(*p, 0xFF, n ? n : 1); return *p ? hipSuccess : 2; }
