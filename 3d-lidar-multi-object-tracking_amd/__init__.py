@@ -340,8 +340,9 @@ class Context:
         mm = np.ascontiguousarray(m, np.int32); ts = np.ascontiguousarray(timestamps, np.float64)
         self._ck(self.lib.mot_track_steps_dev(self._h, C.c_void_p(d_boxes_ptr), C.c_long(box_stride_floats), _vp(mm), len(mm), _vp(ts)))
 
-    def profile_kernel(self, kernel_id: int):
-        self._ck(self.lib.mot_profile_kernel(self._h, kernel_id))
+    def profile_kernel(self, kernel_id: int, every: int = 1):
+        """time every `every`-th launch of kernel `kernel_id` inside frames_dev / frames_host (0 = off); see profile_read"""
+        self._ck(self.lib.mot_profile_kernel(self._h, kernel_id, every))
 
     def profile_read(self):
         mean, mn, mx, k = C.c_float(0), C.c_float(0), C.c_float(0), C.c_int(0)

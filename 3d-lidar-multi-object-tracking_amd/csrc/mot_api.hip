@@ -104,6 +104,7 @@ struct mot_ctx {
   int fetch_cap = 0;
   // in-run kernel timing (mot_profile_kernel): event pairs around one kernel inside mot_frames_dev / mot_frames_host
   int prof_kernel = 0;
+  int prof_every = 1, prof_seen = 0;   // every prof_every-th launch of the kernel is recorded
   static constexpr int kProfRing = 64;
   hipEvent_t prof_ev[kProfRing][2] = {};
   int prof_n = 0;
@@ -375,9 +376,9 @@ extern "C" int mot_synchronize(mot_ctx* c) {
 extern "C" int mot_reset(mot_ctx* c) {
   if (!c) return MOT_E_ARG;
   MOT_GUARD(c);
+  // stream-ordered: takes effect after the steps already queued, before the next one (no host synchronisation)
   MOT_HIP(c, hipMemsetAsync(c->d_nt, 0, c->batch * sizeof(int), c->stream));
   MOT_HIP(c, hipMemsetAsync(c->d_tflags, 0, c->batch * sizeof(int), c->stream));
-  MOT_HIP(c, hipStreamSynchronize(c->stream));
   c->ego.assign(c->batch, mot_ctx::SlotEgo());
   return MOT_OK;
 }
@@ -425,7 +426,9 @@ enum { kK1 = 10, kK2 = 11, kK3 = 12, kC1 = 20, kC2 = 21, kB1 = 30, kB2 = 31, kB3
 // in-run timing of one kernel: an event pair around its launch, on the context stream, while the ring has room
 struct ProfScope {
   mot_ctx* c; bool on;
-  ProfScope(mot_ctx* ctx, int id) : c(ctx), on(ctx->prof_kernel == id && ctx->prof_n < mot_ctx::kProfRing) {
+  ProfScope(mot_ctx* ctx, int id) : c(ctx), on(false) {
+    if (ctx->prof_kernel != id || ctx->prof_n >= mot_ctx::kProfRing) return;
+    on = (ctx->prof_seen++ % ctx->prof_every) == 0;
     if (on) (void)hipEventRecord(c->prof_ev[c->prof_n][0], c->stream);
   }
   ~ProfScope() { if (on) { (void)hipEventRecord(c->prof_ev[c->prof_n][1], c->stream); c->prof_n++; } }
@@ -572,14 +575,15 @@ extern "C" int mot_fetch_tracks_async(mot_ctx* c, int batch, void* h_tracks, int
 }
 
 // ---------------------------------------------------------------------------------------- in-run kernel timing
-extern "C" int mot_profile_kernel(mot_ctx* c, int kernel_id) {
+extern "C" int mot_profile_kernel(mot_ctx* c, int kernel_id, int every) {
   if (!c) return MOT_E_ARG;
   MOT_GUARD(c);
+  if (every < 1) return fail(c, MOT_E_ARG, "mot_profile_kernel: every must be >= 1");
   if (!c->prof_created) {
     for (int i = 0; i < mot_ctx::kProfRing; i++) { MOT_HIP(c, hipEventCreate(&c->prof_ev[i][0])); MOT_HIP(c, hipEventCreate(&c->prof_ev[i][1])); }
     c->prof_created = true;
   }
-  c->prof_kernel = kernel_id; c->prof_n = 0;
+  c->prof_kernel = kernel_id; c->prof_n = 0; c->prof_every = every; c->prof_seen = 0;
   return MOT_OK;
 }
 extern "C" int mot_profile_read(mot_ctx* c, float* mean_ms, float* min_ms, float* max_ms, int* samples) {
@@ -1041,7 +1045,6 @@ extern "C" int mot_reset_slot(mot_ctx* c, int slot) {
   if (slot < 0 || slot >= c->batch) return fail(c, MOT_E_ARG, "slot out of range");
   MOT_HIP(c, hipMemsetAsync(c->d_nt + slot, 0, sizeof(int), c->stream));
   MOT_HIP(c, hipMemsetAsync(c->d_tflags + slot, 0, sizeof(int), c->stream));
-  MOT_HIP(c, hipStreamSynchronize(c->stream));
   c->ego[slot] = mot_ctx::SlotEgo();
   return MOT_OK;
 }
@@ -1080,7 +1083,7 @@ extern "C" int mot_track_steps_dev(mot_ctx* c, const float* d_boxes_global, long
   MOT_HIP(c, hipMemcpyAsync(c->d_targs, c->h_targs.data(), c->batch * sizeof(TrackFrameArgs), hipMemcpyHostToDevice, c->stream));
   TrackBuffers t = track_buffers(c, false);
   t.boxes = d_boxes_global; t.box_stride = box_stride_floats;
-  mot_launch_track(t, batch, c->stream);
+  { ProfScope ps(c, kT1); mot_launch_track(t, batch, c->stream); }
   MOT_HIP(c, hipGetLastError());
   return MOT_OK;
 }

@@ -1,0 +1,170 @@
+"""Synthetic lidar SEQUENCES rendered on the GPU (bench / test data; csrc/synth.hip -> libmot_synth.so).
+
+BASELINE.json's sequence configuration is the 154-frame KITTI drive_0005; no KITTI data exists here, so a
+street of oriented boxes — parked and moving cars, pedestrians, walls, poles — is laid out along the path the ego vehicle
+drives when it is fed the reference's own ego-motion fixture (OT0/src/ego_velo.txt / ego_yaw.txt, committed as
+tests/golden/ego_drive0005.npz by tests/golden/make_golden.py), and every frame is ray-cast in the sensor's pose of that
+frame. The sensor's motion follows the tracker's dead reckoning exactly (getOriginPoints, OT/tracking/imm_ukf_jpda.cpp:
+74-172: heading = yaw - yaw_0, step = dt * v along the new heading), so static objects stand still in the tracker's global
+frame and moving ones move with constant velocity — the tracker sees what it would see on a real drive.
+
+torch is plumbing here (device memory, a cumulative sum, a scatter); the rays are cast by the HIP kernel.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+SYNTH_LIB = os.path.join(_HERE, "libmot_synth.so")
+EGO_FIXTURE = os.path.join(os.path.dirname(_HERE), "tests", "golden", "ego_drive0005.npz")
+MAX_OBJECTS = 256
+
+_KINDS = {  # half length, half width, height
+    "car": (2.25, 0.9, 1.5), "ped": (0.3, 0.3, 1.7), "wall": (10.0, 0.15, 3.0), "pole": (0.15, 0.15, 3.0), "van": (2.6, 1.0, 2.1),
+}
+
+
+def load_ego(n_frames: int | None = None):
+    """(v[F], yaw[F]): the ego motion of KITTI drive_0005 as the reference's second package ships it (154 frames);
+    longer sequences continue the last speed and yaw rate."""
+    d = np.load(EGO_FIXTURE)
+    v, yaw = d["ego_v"].astype(np.float64), d["ego_yaw"].astype(np.float64)
+    if n_frames is not None and n_frames > len(v):
+        k = n_frames - len(v)
+        rate = yaw[-1] - yaw[-2]
+        v = np.concatenate([v, np.full(k, v[-1])]); yaw = np.concatenate([yaw, yaw[-1] + rate * np.arange(1, k + 1)])
+    if n_frames is not None:
+        v, yaw = v[:n_frames], yaw[:n_frames]
+    return v, yaw
+
+
+def ego_path(v, yaw, dt: float = 0.1):
+    """world pose (x, y, heading) of the sensor per frame: the tracker's dead reckoning, integrated"""
+    th = yaw - yaw[0]
+    step = dt * v * np.stack([np.cos(th), np.sin(th)], axis=1)
+    step[0] = 0.0
+    pos = np.cumsum(step, axis=0)
+    return np.concatenate([pos, th[:, None], np.zeros((len(v), 1))], axis=1).astype(np.float32)
+
+
+def street_scene(seed: int, path: np.ndarray, dt: float = 0.1, density: float = 1.0) -> np.ndarray:
+    """objects [K, 8] (cx, cy, yaw, half length, half width, height, vx, vy) along the driven path; K <= MAX_OBJECTS.
+    density scales the number of cars and pedestrians (the tracker-load knob)."""
+    rng = np.random.default_rng(9_000_017 + seed)
+    # arc length parametrisation of the path, extended by straight run-in / run-out
+    p = path[:, :2].astype(np.float64); th = path[:, 2].astype(np.float64)
+    pre = p[0] - np.outer(np.arange(40, 0, -1), [np.cos(th[0]), np.sin(th[0])])
+    post = p[-1] + np.outer(np.arange(1, 61), [np.cos(th[-1]), np.sin(th[-1])])
+    pts = np.concatenate([pre, p, post]); hd = np.concatenate([np.full(40, th[0]), th, np.full(60, th[-1])])
+    seg = np.hypot(*np.diff(pts, axis=0).T); s = np.concatenate([[0.0], np.cumsum(seg)])
+    keep = np.concatenate([[True], seg > 1e-6]); pts, hd, s = pts[keep], hd[keep], s[keep]
+    L = s[-1]
+
+    def at(sv, lat):
+        x = np.interp(sv, s, pts[:, 0]); y = np.interp(sv, s, pts[:, 1]); h = np.interp(sv, s, hd)
+        return x - lat * np.sin(h), y + lat * np.cos(h), h
+
+    objs = []
+
+    def add(kind, sv, lat, yaw_off=0.0, speed=0.0):
+        hl, hw, h = _KINDS[kind]
+        x, y, hh = at(sv, lat)
+        yw = hh + yaw_off
+        objs.append((x, y, yw, hl, hw, h, speed * np.cos(yw), speed * np.sin(yw)))
+
+    for side in (-1, 1):                                     # parked cars / vans along both kerbs
+        sv = rng.uniform(0, 6)
+        while sv < L:
+            if rng.random() < 0.75 * min(density, 1.3):
+                add("van" if rng.random() < 0.15 else "car", sv, side * rng.uniform(3.6, 4.4), rng.normal(0, 0.03))
+            sv += rng.uniform(5.5, 9.0) / max(density, 0.5)
+    for _ in range(int(10 * density)):                       # traffic: same direction and oncoming
+        oncoming = rng.random() < 0.5
+        add("car", rng.uniform(0, L), (-1.8 if oncoming else 1.8) + rng.normal(0, 0.15), np.pi if oncoming else 0.0, rng.uniform(3.0, 10.0))
+    for _ in range(int(22 * density)):                       # pedestrians on the pavements, a few crossing
+        crossing = rng.random() < 0.15
+        add("ped", rng.uniform(20, L - 20), rng.choice([-1, 1]) * rng.uniform(5.5, 8.0), np.pi / 2 * rng.choice([-1, 1]) if crossing else rng.choice([0.0, np.pi]),
+            rng.uniform(0.4, 1.6))
+    for side in (-1, 1):                                     # building fronts and street furniture
+        sv = rng.uniform(0, 10)
+        while sv < L:
+            if rng.random() < 0.7:
+                add("wall", sv, side * rng.uniform(10.0, 13.0), rng.normal(0, 0.02))
+            sv += 22.0
+        sv = rng.uniform(0, 15)
+        while sv < L:
+            add("pole", sv, side * rng.uniform(5.0, 5.4))
+            sv += rng.uniform(18, 30)
+    a = np.array(objs, np.float32)
+    if len(a) > MAX_OBJECTS:   # keep the ones nearest to the driven part of the path
+        mid = pts[len(pts) // 2]
+        a = a[np.argsort(np.hypot(a[:, 0] - mid[0], a[:, 1] - mid[1]))[:MAX_OBJECTS]]
+    out = np.zeros((MAX_OBJECTS, 8), np.float32)
+    out[: len(a)] = a
+    return out
+
+
+class SequenceRenderer:
+    """renders [frames][scenes][stride] float4 clouds into HBM; torch tensors on `device`"""
+
+    def __init__(self, device="cuda", lib_path: str | None = None):
+        import torch
+        self.torch = torch
+        self.device = torch.device(device)
+        path = lib_path or SYNTH_LIB
+        if not os.path.exists(path):
+            raise ImportError(f"{path} is missing — run `python __graft_entry__.py build`")
+        self.lib = C.CDLL(path)
+        self.lib.mot_synth_raycast.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float,
+                                               C.c_ulonglong, C.c_void_p, C.c_void_p]
+
+    def render(self, scene_ids, n_frames: int, n_points: int, stride: int, v=None, yaw=None, dt: float = 0.1, seed: int = 2025,
+               density: float = 1.0, oversample: float = 1.25, frame_chunk: int = 32):
+        """-> (clouds [F][S][stride][4] float32 on the device, n [F][S] int32 numpy, objects list). Every frame is thinned
+        uniformly (order preserved, beam-major) to n_points returns; a frame with fewer returns keeps them all."""
+        torch = self.torch
+        if v is None or yaw is None:
+            v, yaw = load_ego(n_frames)
+        path = ego_path(np.asarray(v[:n_frames], np.float64), np.asarray(yaw[:n_frames], np.float64), dt)
+        S, F = len(scene_ids), n_frames
+        n_az = -(-int(n_points * oversample) // 64)
+        n_rays = 64 * n_az
+        out = torch.empty((F, S, stride, 4), dtype=torch.float32, device=self.device)
+        if stride > n_points:
+            out[:, :, n_points:] = 0.0
+        counts = torch.zeros((F, S), dtype=torch.int32, device=self.device)
+        ego_d = torch.from_numpy(path).to(self.device).contiguous()
+        stream = torch.cuda.current_stream().cuda_stream
+        objs_all = []
+        for si, sid in enumerate(scene_ids):
+            objs = street_scene(int(sid), path, dt, density)
+            objs_all.append(objs)
+            K = int((objs[:, 5] > 0).sum())
+            objs_d = torch.from_numpy(objs[: max(K, 1)]).to(self.device).contiguous()
+            for f0 in range(0, F, frame_chunk):
+                fc = min(frame_chunk, F - f0)
+                raw = torch.empty((fc, n_rays, 4), dtype=torch.float32, device=self.device)
+                rc = self.lib.mot_synth_raycast(objs_d.data_ptr(), K, ego_d.data_ptr(), F, f0, fc, 1, int(sid), n_az, C.c_float(dt),
+                                                C.c_ulonglong(seed), raw.data_ptr(), C.c_void_p(stream))
+                if rc:
+                    raise RuntimeError(f"mot_synth_raycast failed ({rc})")
+                valid = ~torch.isnan(raw[:, :, 0])
+                c = torch.cumsum(valid.to(torch.int64), dim=1)
+                total = c[:, -1:].clamp(min=1)
+                nt = torch.minimum(total, torch.full_like(total, n_points))
+                j = (c * nt) // total
+                jp = ((c - 1) * nt) // total
+                sel = valid & (j > jp)
+                fidx = torch.arange(f0, f0 + fc, device=self.device, dtype=torch.int64)[:, None]
+                dest = ((fidx * S + si) * stride + (j - 1))[sel]
+                out.view(-1, 4)[dest] = raw[sel]
+                nf = torch.where(c[:, -1] > 0, nt[:, 0], torch.zeros_like(nt[:, 0])).to(torch.int32)
+                counts[f0:f0 + fc, si] = nf
+                if (nf < n_points).any():   # frames with fewer returns than asked for: zero their tails
+                    for k in torch.nonzero(nf < n_points).flatten().tolist():
+                        out[f0 + k, si, int(nf[k]):n_points] = 0.0
+        torch.cuda.synchronize()
+        return out, counts.cpu().numpy(), objs_all, path

@@ -1,17 +1,25 @@
 #!/usr/bin/env python3
 """bench.py — frames/s of the LiDAR perception hot path on MI355X (metric of BASELINE.json).
 
-One "step" = one pass of the whole hot path (ground removal -> grid clustering -> box fit -> IMM-UKF-PDA tracker
-step) over one batch of synthetic frames: B independent 64-beam sensor streams ("slots"), one ~120k-point frame
-per stream, inputs already resident in HBM when the timed region starts. Consecutive steps feed consecutive frames
-of each stream (moving obstacles), so the trackers really run. N GPUs = N processes (torch.distributed over RCCL),
-each with its own B streams (weak scaling); what crosses GPUs each step is the fixed-size block of live-track
-records per stream, all-gathered over xGMI.
+One "step" = one pass of the whole hot path (ground removal -> grid clustering -> box fit -> IMM-UKF-PDA tracker) over one
+batch of synthetic input: B independent 64-beam sensor streams x one 154-frame sequence each (BASELINE.json configs[3]: the
+length of KITTI drive_0005), ~120 k points per frame, every frame of every stream rendered once into HBM before the timed
+region starts (288 GB of HBM hold it) and none of it reused within a sequence: obstacles move with constant velocity
+through a world the sensor drives through with the ego motion of drive_0005 (the reference's only data fixture), so the
+trackers run on coherent tracks. A stream restarts (mot_reset) at the start of every step.
 
-Prints ONE JSON line (rank 0) with the contract fields plus
-  roofline      dominant kernel: algorithmic HBM bytes per launch / mean HIP-event time, vs 8 TB/s
-  cpu_baseline  the reference's own sources (oracle/_ref) — or the C restatement if that library is absent —
-                timed on this box's host cores on a bounded sample (1 thread: the reference is single-threaded).
+N GPUs = N processes (torch.distributed over RCCL), launched by the driver with torch.distributed.run — or by this script
+itself when it is started as plain `python bench.py --gpus N`. Each rank owns B streams (weak scaling, stream-sharded, no
+collective in the data path); what crosses GPUs each frame is the fixed-size block of live-track records per stream,
+all-gathered over xGMI.
+
+Prints ONE JSON line (rank 0): the contract fields plus
+  roofline           dominant kernel: algorithmic HBM bytes per launch / its mean launch duration measured IN THE TIMED REGION
+                     with HIP event pairs on the launching stream (mot_profile_kernel), vs 8 TB/s
+  cpu_baseline       the reference's own sources (oracle/_ref) on this box's host cores: single thread (median / p95 per
+                     stage), frame-parallel over all cores, and the -O0 build the reference's CMakeLists produces by default
+  tracker_stress     tracker kernel at 8 / 32 / 64 live tracks per stream
+  host_boundary_pipelined   PCIe-inclusive rate through mot_frames_host (pinned, double-buffered, several contexts)
 """
 from __future__ import annotations
 
@@ -19,6 +27,8 @@ import argparse
 import importlib.util
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -29,9 +39,13 @@ PKG_DIR = os.path.join(ROOT, "3d-lidar-multi-object-tracking_amd")
 HBM_PEAK_GBS = 8000.0
 TRACK_RECORD_BYTES = 144
 GATHER_TRACKS = 64  # live tracks per stream in the all-gathered block (BASELINE.json configs[3]: <= 64 tracks)
+K_IDS = {"polar_minz_kernel": 10, "polar_filter_kernel": 11, "classify_compact_kernel": 12, "ccl_kernel": 21, "label_stats_kernel": 30,
+         "cluster_index_kernel": 34, "cluster_gather_kernel": 31, "cluster_rect_kernel": 33, "box_finalize_kernel": 32, "track_step_kernel": 40}
 
 
 def _load(name, path):
+    if name in sys.modules:
+        return sys.modules[name]
     spec = importlib.util.spec_from_file_location(name, path, submodule_search_locations=[os.path.dirname(path)])
     m = importlib.util.module_from_spec(spec)
     sys.modules[name] = m
@@ -39,84 +53,275 @@ def _load(name, path):
     return m
 
 
-def cpu_baseline(synth, n_points, budget_s=12.0):
-    """reference CPU path on a bounded sample: ground -> cluster -> box -> tracker, single thread"""
+def self_spawn(args) -> int:
+    """`python bench.py --gpus N` without a launcher: re-exec under torch.distributed.run, one rank per GPU"""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ); env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0"); env.setdefault("OMP_NUM_THREADS", "8")
+    return subprocess.run(cmd, env=env).returncode
+
+
+# ------------------------------------------------------------------------------------------------ CPU baseline
+def _pct(a, q):
+    return float(np.percentile(np.asarray(a), q)) if len(a) else 0.0
+
+
+def _cpu_worker_init(path, shape):
+    global _W
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import oracle_lib as O
+    _W = dict(O=O, frames=np.load(path, mmap_mode="r"), shape=shape)
+    O.ref()
+
+
+def _cpu_worker(idx):
+    O = _W["O"]
+    t0 = time.perf_counter(); k = 0
+    for i in idx:
+        c = np.ascontiguousarray(_W["frames"][i])
+        g = O.ref_ground_remove(c); cl = O.ref_cluster(g["elevated"]); O.ref_box_fit(g["elevated"], cl["grid"], cl["num_cluster"]); k += 1
+    return k, time.perf_counter() - t0
+
+
+def cpu_baseline(frames: np.ndarray, ego_v, ego_yaw, n_points: int, budget_s: float = 10.0):
+    """the reference CPU path (its own sources, oracle/_ref) on consecutive frames of one stream of the bench workload.
+    BASELINE.md §2 protocol: single thread with per-stage median / p95, frame-parallel over the host cores for the stateless
+    stages, and the -O0 build (the reference's CMakeLists sets no build type)."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import oracle_lib as O
+    seq = _load("mot_amd.sequence", os.path.join(PKG_DIR, "sequence.py"))
     try:
         use_ref = O.ref() is not None
     except Exception:
         use_ref = False
     p = O.params(0)
-    frames = [synth.make_cloud(n_points, 900, f) for f in range(6)]
-    trk = O.RefTracker() if use_ref else O.Tracker(p)
-    trk.reset()
-    state = {"f": 0}
+    nF = len(frames)
 
-    def one(c):
-        f = state["f"]; state["f"] += 1
-        if use_ref:
-            g = O.ref_ground_remove(c)
-            cl = O.ref_cluster(g["elevated"])
-            bx = O.ref_box_fit(g["elevated"], cl["grid"], cl["num_cluster"])["boxes"]
-        else:
-            g = O.ground_remove(p, c)
-            cl = O.cluster(p, g["elevated"])
-            bx = O.box_fit(p, g["elevated"], cl["grid"], cl["num_cluster"])["boxes"]
-        ts = 1.0e9 + f * 1e5
-        trk.ego_update(ts, 0.0, 0.0)
-        trk.step(bx, ts, max_tracks=65536)
+    def run_single(max_frames, budget):
+        trk = O.RefTracker() if use_ref else O.Tracker(p)
+        trk.reset()
+        st = {"ground": [], "cluster": [], "box": [], "tracker": []}
+        t_all = time.perf_counter(); k = 0
+        for f in range(min(max_frames, nF)):
+            c = frames[f]
+            t0 = time.perf_counter()
+            g = O.ref_ground_remove(c) if use_ref else O.ground_remove(p, c)
+            t1 = time.perf_counter()
+            cl = O.ref_cluster(g["elevated"]) if use_ref else O.cluster(p, g["elevated"])
+            t2 = time.perf_counter()
+            bx = (O.ref_box_fit(g["elevated"], cl["grid"], cl["num_cluster"]) if use_ref else O.box_fit(p, g["elevated"], cl["grid"], cl["num_cluster"]))["boxes"]
+            t3 = time.perf_counter()
+            ts = 1.0e9 + f * 1e5
+            ego = trk.ego_update(ts, float(ego_v[f]), float(ego_yaw[f]))
+            trk.step(seq.boxes_to_global(bx, ego), ts, max_tracks=65536)
+            t4 = time.perf_counter()
+            for name, d in zip(("ground", "cluster", "box", "tracker"), (t1 - t0, t2 - t1, t3 - t2, t4 - t3)):
+                st[name].append(d * 1e3)
+            k += 1
+            if time.perf_counter() - t_all > budget:
+                break
+        wall = time.perf_counter() - t_all
+        if hasattr(trk, "close"):
+            trk.close()
+        return k, wall, st
 
-    one(frames[0])  # warm-up
-    t0 = time.perf_counter(); k = 0
-    while True:
-        one(frames[k % len(frames)]); k += 1
-        dt = time.perf_counter() - t0
-        if dt > budget_s or k >= 300:
-            break
-    return {"value": round(k / dt, 2), "unit": "frames/s", "cores": 1, "kind": "reference" if use_ref else "port",
-            "sample": f"{k} frames x {n_points} pts, ground+cluster+box+tracker, single thread "
-                      f"({os.cpu_count()} host cores present; the reference is single-threaded)"}
+    run_single(2, 5.0)  # warm-up
+    k, wall, st = run_single(nF, budget_s * 0.5)
+    out = {"value": round(k / wall, 2), "unit": "frames/s", "cores": 1, "kind": "reference" if use_ref else "port",
+           "sample": f"{k} consecutive frames x {n_points} pts of one bench stream: ground + cluster + box + tracker, one thread "
+                     f"({os.cpu_count()} host cores present; the reference is single-threaded)",
+           "single": {"frames": k, "frames_per_s": round(k / wall, 2),
+                      "stage_ms": {n: {"median": round(_pct(v, 50), 4), "p95": round(_pct(v, 95), 4)} for n, v in st.items()}}}
+    # ---- frame-parallel: N processes, the stateless stages (the tracker is sequential per stream)
+    if use_ref:
+        try:
+            import multiprocessing as mp
+            ncpu = os.cpu_count() or 1
+            path = f"/dev/shm/mot_bench_frames_{os.getpid()}.npy" if os.path.isdir("/dev/shm") else f"/tmp/mot_bench_frames_{os.getpid()}.npy"
+            np.save(path, frames)
+            per = 6
+            idx = [[(w * per + j) % nF for j in range(per)] for w in range(ncpu)]
+            with mp.get_context("spawn").Pool(ncpu, initializer=_cpu_worker_init, initargs=(path, frames.shape)) as pool:   # spawn: the parent holds a HIP runtime
+                pool.map(_cpu_worker, [[w % nF] for w in range(ncpu)])   # warm-up: library loaded, pages touched
+                t0 = time.perf_counter()
+                res = pool.map(_cpu_worker, idx, chunksize=1)
+                wall = time.perf_counter() - t0
+            os.unlink(path)
+            done = sum(r[0] for r in res)
+            out["parallel"] = {"frames_per_s": round(done / wall, 1), "cores": ncpu, "frames": done,
+                               "what": "ground + cluster + box, one process per host core, each on its own frames (the tracker is sequential per stream)"}
+        except Exception as e:   # an auxiliary figure must never cost the bench line
+            out["parallel"] = {"error": str(e)[:200]}
+        # ---- the -O0 build
+        o0 = os.path.join(ROOT, "oracle", "_ref", "libmot_ref_O0.so")
+        if os.path.exists(o0):
+            try:
+                O.set_ref_library(o0)
+                run_single(1, 5.0)
+                k0, w0, st0 = run_single(nF, budget_s * 0.3)
+                out["O0"] = {"frames_per_s": round(k0 / w0, 2), "frames": k0, "cores": 1,
+                             "stage_ms": {n: {"median": round(_pct(v, 50), 4), "p95": round(_pct(v, 95), 4)} for n, v in st0.items()},
+                             "what": "the same sources at -O0 (OT/CMakeLists.txt sets no build type)"}
+            finally:
+                O.set_ref_library(None)
+    return out
 
 
-def host_boundary(mot, synth, n_points, frames=40, lib_path=None, device=0):
-    """PCIe-INCLUSIVE rate of the host-buffer boundary (never the headline value): one stream, every frame starts as a
-    PointCloud2-style payload in pageable host memory, is uploaded (mot_frame_pointcloud2: unpack, ground removal, clustering,
-    box fit on the resident copy), its boxes are read back and the tracker steps on them — the per-frame sequence of the
-    single-process node (ros/src/pipeline_node.cpp) without the ROS glue. Wall clock per frame, synchronous."""
-    clouds = [np.ascontiguousarray(synth.make_cloud(n_points, 950, f)) for f in range(4)]
-    payload = [c.view(np.uint8).reshape(-1) for c in clouds]
-    kw = dict(lib_path=lib_path) if lib_path else dict(device=device)
-    with mot.Context(max_points=((n_points + 2047) // 2048) * 2048, max_batch=1, max_tracks_total=4096, **kw) as c:
-        def one(f):
-            c.frame_pointcloud2(payload[f % 4], n_points, 16, 0, 4, 8)
-            bx = c.get_boxes(0)["boxes"]
-            ts = 1.0e9 + f * 1.0e5
-            c.ego_update(ts, 0.0, 0.0)
-            return c.track_step(bx, ts)["n"]
-        for f in range(3):
-            one(f)
-        t0 = time.perf_counter()
-        for f in range(3, 3 + frames):
-            one(f)
-        dt = time.perf_counter() - t0
-    return {"value": round(frames / dt, 1), "unit": "frames/s", "ms_per_frame": round(dt / frames * 1e3, 4),
-            "what": f"1 stream, {frames} frames x {n_points} pts from pageable host memory: H2D of the raw records + ground/cluster/box + "
-                    "D2H of the boxes + tracker step + D2H of the tracks, synchronous per frame (PCIe-inclusive; not the headline value)"}
+# ------------------------------------------------------------------------------------------------ auxiliary GPU lines
+def tracker_stress(mot, torch, device, streams=128, loads=(8, 32, 64), frames=40):
+    """the tracker kernel under load: `streams` streams x T slowly moving boxes each, fed as device boxes (mot_track_steps_dev);
+    after 12 frames every box carries a confirmed track. Mean kernel duration over the remaining frames (HIP events)."""
+    out = {}
+    rng = np.random.default_rng(11)
+    for T in loads:
+        with mot.Context(device=device, max_points=1024, max_batch=streams, max_tracks_total=1024) as c:
+            side = int(np.ceil(np.sqrt(T)))
+            centres = np.stack(np.meshgrid(np.arange(side), np.arange(side)), -1).reshape(-1, 2)[:T] * 9.0 - side * 4.5
+            vel = rng.uniform(-1.0, 1.0, size=(streams, T, 2))
+            stride = T * 24
+            live = 0
+            for f in range(frames):
+                ts = 1.0e9 + f * 1e5
+                ctr = centres[None] + vel * (0.1 * f) + rng.normal(0, 0.02, size=(streams, T, 2))
+                bx = np.zeros((streams, T, 8, 3), np.float32)
+                bx[..., :2] = ctr[:, :, None, :] + np.array([[0, 0], [3.8, 0], [3.8, 1.7], [0, 1.7]] * 2)[None, None]
+                bx[:, :, :4, 2] = -2.0; bx[:, :, 4:, 2] = -0.4
+                d = torch.from_numpy(bx.reshape(streams, stride)).to(f"cuda:{device}")
+                for s in range(streams):
+                    c.ego_update(ts, 0.0, 0.0, s)
+                if f == 14:
+                    c.synchronize(); c.profile_kernel(40, 1)
+                c.track_steps_dev(d.data_ptr(), stride, [T] * streams, [ts] * streams)
+                c.synchronize()
+            r = c.profile_read()
+            tr = c.get_tracks(0)
+            live = int((tr["track_manage"] > 0).sum())
+            out[str(T)] = {"us_per_launch": round(r["mean_ms"] * 1e3, 2), "min_us": round(r["min_ms"] * 1e3, 2), "max_us": round(r["max_ms"] * 1e3, 2),
+                           "samples": r["samples"], "streams": streams, "boxes_per_stream": T, "live_tracks_stream0": live,
+                           "tracks_ever_stream0": int(tr["n"])}
+    return out
+
+
+def host_boundary_pipelined(mot, torch, device, seq_dev, n_seq, stride, n_points, ego_v, ego_yaw, contexts=4, slots=16, batches=48, lib=None):
+    """PCIe-INCLUSIVE rate (never the headline value): every frame starts in page-locked HOST memory, as a message in the
+    reference's nodes does (OT/src/groundremove/main.cpp:91-136). `contexts` contexts x `slots` streams; mot_frames_host copies
+    batch k+1 on the context's copy stream while the kernels of batch k run; the live-track block of every batch comes back to
+    pinned host memory. Wall clock over all batches / frames."""
+    import ctypes as C
+    F = min(8, seq_dev.shape[0])
+    nbytes = F * slots * stride * 16
+    hp = C.c_void_p()
+    assert lib.mot_host_alloc(C.c_size_t(nbytes), C.byref(hp)) == 0
+    pinned = np.ctypeslib.as_array(C.cast(hp, C.POINTER(C.c_float)), shape=(F, slots, stride, 4))
+    pinned[:] = seq_dev[:F, :slots].cpu().numpy()
+    K = GATHER_TRACKS
+    tp = C.c_void_p(); cp = C.c_void_p()
+    assert lib.mot_host_alloc(C.c_size_t(contexts * slots * K * TRACK_RECORD_BYTES), C.byref(tp)) == 0
+    assert lib.mot_host_alloc(C.c_size_t(contexts * slots * 4), C.byref(cp)) == 0
+    ctxs = [mot.Context(device=device, max_points=stride, max_batch=slots, max_tracks_total=2048) for _ in range(contexts)]
+    frame_bytes = slots * stride * 16
+
+    def run(nb):
+        for k in range(nb):
+            f = k % F
+            ts = [1.0e9 + k * 1e5] * slots
+            for ci, cx in enumerate(ctxs):
+                cx.frames_host(hp.value + f * frame_bytes, stride * 4, n_seq[f, :slots], run_tracker=True, timestamps=ts,
+                               ego_v=[float(ego_v[k % len(ego_v)])] * slots, ego_yaw=[float(ego_yaw[k % len(ego_yaw)])] * slots)
+                cx.fetch_tracks_async(slots, tp.value + ci * slots * K * TRACK_RECORD_BYTES, K, cp.value + ci * slots * 4)
+        for cx in ctxs:
+            cx.synchronize()
+
+    run(4)
+    for cx in ctxs:
+        cx.reset()
+    t0 = time.perf_counter()
+    run(batches)
+    dt = time.perf_counter() - t0
+    for cx in ctxs:
+        cx.close()
+    for q in (hp, tp, cp):
+        lib.mot_host_free(q)
+    frames = batches * contexts * slots
+    return {"value": round(frames / dt, 1), "unit": "frames/s", "h2d_GBps": round(frames * n_points * 16 / dt / 1e9, 2),
+            "contexts": contexts, "streams_per_context": slots, "batches": batches,
+            "what": f"{contexts} contexts x {slots} streams, {batches} batches: frames in page-locked host memory -> H2D on a copy stream per context, "
+                    "double-buffered staging (copy of batch k+1 under the kernels of batch k) -> ground/cluster/box/tracker -> live-track block "
+                    "D2H to pinned memory; wall clock (PCIe-inclusive; not the headline value)"}
+
+
+# ------------------------------------------------------------------------------------------------ CPU self-test of the launch logic
+def selftest_cpu(args, rank, world):
+    """`--selftest-cpu`: the launch / sharding / gather logic of this script on CPU — gloo, the emulator build of the kernels
+    (tests/emu, a development harness), tiny clouds. NOT a measurement: the line says so."""
+    import torch.distributed as dist
+    sys.path.insert(0, os.path.join(ROOT, "tests")); sys.path.insert(0, os.path.join(ROOT, "tests", "emu"))
+    import build_emu
+    lib = build_emu.build()
+    mot = _load("mot_amd", os.path.join(PKG_DIR, "__init__.py"))
+    synth = _load("mot_amd.synth", os.path.join(PKG_DIR, "synth.py"))
+    multi = _load("mot_amd.multi", os.path.join(PKG_DIR, "multi.py"))
+    if world > 1:
+        dist.init_process_group("gloo")
+        assert dist.get_world_size() == args.gpus, (dist.get_world_size(), args.gpus)
+    B, N, stride, F = 2, 3000, 3072, 3
+    ctx = mot.Context(lib_path=lib, max_points=stride, max_batch=B, max_tracks_total=128)
+    tg = multi.TrackGather(B, 8, world, "cpu") if world > 1 else None
+    clouds = np.zeros((F, B, stride, 4), np.float32)
+    for f in range(F):
+        for b in range(B):
+            clouds[f, b, :N] = synth.make_cloud(N, multi.scene_of(rank, b), f)
+    t0 = time.perf_counter()
+    for k in range(args.warmup + args.steps):
+        if k == args.warmup:
+            if world > 1:
+                dist.barrier()
+            t0 = time.perf_counter()
+        ctx.reset()
+        for f in range(F):
+            ctx.frames_dev(clouds[f].ctypes.data, stride * 4, [N] * B, run_tracker=True, timestamps=[1.0e9 + f * 1e5] * B, ego_v=[0.0] * B, ego_yaw=[0.0] * B)
+            if tg:
+                tg.step(ctx)
+    ctx.synchronize()
+    if world > 1:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    if rank == 0:
+        frames = B * F * args.steps * world
+        print(json.dumps({"metric": "LiDAR frames/sec (120k-pt 64-beam cloud) end-to-end ground->cluster->track", "value": round(frames / dt, 2),
+                          "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / max(args.steps, 1) * 1e3, 3),
+                          "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32/f64", "data": "SELFTEST: emulated kernels on CPU, gloo — not a measurement",
+                          "config": {"workload": "launch-logic self-test", "streams": B * world, "frames_per_stream_per_step": F, "points_per_frame": N}}))
+    if world > 1:
+        dist.barrier(); dist.destroy_process_group()
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=50)
-    ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--batch", type=int, default=512, help="sensor streams (one frame each) per GPU per step")
+    ap.add_argument("--steps", type=int, default=12, help="timed steps; one step = every stream's whole --frames sequence")
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--batch", type=int, default=512, help="sensor streams per GPU")
     ap.add_argument("--points", type=int, default=120000)
-    ap.add_argument("--frames", type=int, default=4, help="distinct consecutive frames resident per stream")
-    ap.add_argument("--contexts", type=int, default=4, help="contexts (HIP streams) per GPU the streams are split over: the "
-                    "latency-bound kernels of one (CCL, polygon, tracker: one workgroup per stream) overlap the streaming kernels of the other")
+    ap.add_argument("--frames", type=int, default=154, help="frames per stream per step (BASELINE.json configs[3]: the 154 frames of drive_0005)")
+    ap.add_argument("--contexts", type=int, default=4, help="contexts (HIP streams) per GPU the streams are split over: the latency-bound "
+                    "kernels of one (CCL, polygon, tracker: one workgroup per stream) overlap the streaming kernels of the others")
+    ap.add_argument("--density", type=float, default=1.0, help="scene density (cars / pedestrians) of the synthetic street")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-aux", action="store_true", help="skip tracker_stress / host_boundary / per-kernel isolated timings")
+    ap.add_argument("--selftest-cpu", action="store_true", help="launch-logic self-test on CPU (gloo + emulated kernels); not a measurement")
     args = ap.parse_args()
+
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        sys.exit(self_spawn(args))
+    rank = int(os.environ.get("RANK", "0")); world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}", file=sys.stderr); sys.exit(2)
+    if args.selftest_cpu:
+        return selftest_cpu(args, rank, world)
 
     # one hardware queue per context stream (HIP's default is 4 queues per process, shared with its own null stream:
     # with 4 contexts two of them would share a queue and serialise — measured 319 k vs 402 k frames/s)
@@ -124,58 +329,55 @@ def main():
     import torch  # torch first: it brings its own HIP runtime, which libmot_hip.so then shares
     import torch.distributed as dist
 
-    rank = int(os.environ.get("RANK", "0")); world = int(os.environ.get("WORLD_SIZE", "1"))
-    local = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         print("bench.py needs a GPU (the library has no CPU fallback)", file=sys.stderr); sys.exit(2)
     torch.cuda.set_device(local)
     if world > 1:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        assert dist.get_world_size() == args.gpus, (dist.get_world_size(), args.gpus)
 
-    mot = _load("mot_amd", os.path.join(PKG_DIR, "__init__.py"))
-    synth = _load("mot_amd.synth", os.path.join(PKG_DIR, "synth.py"))
-    multi = _load("mot_amd.multi", os.path.join(PKG_DIR, "multi.py"))
     build = _load("mot_amd.build", os.path.join(PKG_DIR, "build.py"))
     if not os.path.exists(build.LIB):
         build.build()
+    if not os.path.exists(build.SYNTH_LIB):
+        build.build_synth()
+    mot = _load("mot_amd", os.path.join(PKG_DIR, "__init__.py"))
+    multi = _load("mot_amd.multi", os.path.join(PKG_DIR, "multi.py"))
+    sdev = _load("mot_amd.synth_dev", os.path.join(PKG_DIR, "synth_dev.py"))
 
     B, N, F = args.batch, args.points, args.frames
     stride = ((N + 2047) // 2048) * 2048
-    # synthetic streams: 8 distinct scenes per rank tiled over the B slots, F consecutive frames of each
-    n_scene = min(B, 8)
-    scenes = [[synth.make_cloud(N, multi.scene_of(rank, s, n_scene), f) for f in range(F)] for s in range(n_scene)]
-    dev_frames = []
-    for f in range(F):
-        host = np.zeros((B, stride, 4), np.float32)
-        for b in range(B):
-            host[b, :N] = scenes[b % n_scene][f]
-        dev_frames.append(torch.from_numpy(host).cuda())
     NC = max(1, min(args.contexts, B))
     assert B % NC == 0, "--batch must be divisible by --contexts"
     Bc = B // NC
+    # ---- the workload, rendered into HBM: Bc distinct streams (scenes) x F frames; every context replays these Bc streams
+    t_r = time.perf_counter()
+    ego_v, ego_yaw = sdev.load_ego(F)
+    renderer = sdev.SequenceRenderer(f"cuda:{local}")
+    seq_dev, n_seq, _objs, _path = renderer.render([1000 * rank + s for s in range(Bc)], F, N, stride, ego_v, ego_yaw, density=args.density)
+    render_s = time.perf_counter() - t_r
+    n_seq = np.ascontiguousarray(n_seq, np.int32)
     ctxs = [mot.Context(device=local, max_points=stride, max_batch=Bc, max_tracks_total=4096) for _ in range(NC)]
     ctx = ctxs[0]
     gathers = [multi.TrackGather(Bc, GATHER_TRACKS, world, "cuda") for _ in range(NC)] if world > 1 else None
     torch.cuda.synchronize()
-
-    step_no = [0]
+    frame_ptr = [seq_dev[f].data_ptr() for f in range(F)]
+    ts_f = [np.full(Bc, 1.0e9 + f * 1.0e5, np.float64) for f in range(F)]   # microsecond stamps => dt = 0.1 s
+    ev_f = [np.full(Bc, ego_v[f], np.float64) for f in range(F)]
+    ey_f = [np.full(Bc, ego_yaw[f], np.float64) for f in range(F)]
     host_issue = [0.0]   # seconds the host spent inside the asynchronous launch calls (if this approaches the step time, the host bounds the pipeline)
-    sizes = np.full(Bc, N, np.int32); zeros = np.zeros(Bc, np.float64)
 
     def step():
-        k = step_no[0]; step_no[0] += 1
-        ts = np.full(Bc, 1.0e9 + (k % 200) * 1.0e5, np.float64)  # microsecond stamps => dt = 0.1 s
         t_h = time.perf_counter()
-        for ci, cx in enumerate(ctxs):  # asynchronous launches on NC HIP streams
-            if k % 200 == 0:
-                cx.reset()  # a stream restarts: the reference never frees tracks, so long runs are cut into sequences
-            cx.frames_dev(dev_frames[k % F].data_ptr() + ci * Bc * stride * 16, stride * 4, sizes, run_tracker=True, timestamps=ts,
-                          ego_v=zeros, ego_yaw=zeros)
+        for cx in ctxs:
+            cx.reset()   # every stream starts its sequence over (stream-ordered, no host synchronisation)
+        for f in range(F):
+            for ci, cx in enumerate(ctxs):  # asynchronous launches on NC HIP streams
+                cx.frames_dev(frame_ptr[f], stride * 4, n_seq[f], run_tracker=True, timestamps=ts_f[f], ego_v=ev_f[f], ego_yaw=ey_f[f])
+                if world > 1:  # the per-frame result blocks cross GPUs over RCCL / xGMI
+                    gathers[ci].step(cx)
         host_issue[0] += time.perf_counter() - t_h
-        if world > 1:  # the per-step result blocks cross GPUs over RCCL / xGMI
-            for ci, cx in enumerate(ctxs):
-                gathers[ci].step(cx)
 
     def sync_all():
         for cx in ctxs:
@@ -184,6 +386,11 @@ def main():
     for _ in range(args.warmup):
         step()
     sync_all()
+    # in-run timing of the dominant kernel: <= 64 event pairs per context, spread over the timed region
+    dom = "classify_compact_kernel"
+    every = max(1, -(-args.steps * F // 60))
+    for cx in ctxs:
+        cx.profile_kernel(K_IDS[dom], every)
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
@@ -202,76 +409,90 @@ def main():
         dt = float(t.item())
 
     if rank == 0:
-        # ---- per-kernel timing on the resident data (HIP events on the context's stream, see mot_time_stage)
-        it = 20
-        tr0 = ctx.get_tracks(0)
-        kernels = {"polar_minz_kernel": 10, "polar_filter_kernel": 11, "classify_compact_kernel": 12,
-                   "cart_occupancy_kernel": 20, "ccl_kernel": 21, "label_stats_kernel": 30, "cluster_index_kernel": 34, "cluster_gather_kernel": 31,
-                   "cluster_rect_kernel": 33, "box_finalize_kernel": 32, "track_step_kernel": 40}
-        k_ms = {k: ctx.time_stage(v, Bc, it if v != 40 else 5) for k, v in kernels.items()}
-        stage_ms = {"ground": ctx.time_stage(0, Bc, it), "cluster": ctx.time_stage(1, Bc, it), "box": ctx.time_stage(2, Bc, it),
-                    "stateless": ctx.time_stage(100, Bc, it)}
+        prof = [cx.profile_read() for cx in ctxs]
+        nsamp = sum(p["samples"] for p in prof)
+        dom_ms = sum(p["mean_ms"] * p["samples"] for p in prof) / max(nsamp, 1)
+        # ---- bytes: the state after the last frame of the sequence is resident in every context
+        f_last = F - 1
         counts = [ctx.get_ground(b, want_clouds=False) for b in range(Bc)]
         ne_tot = sum(c["n_elevated"] for c in counts); ng_tot = sum(c["n_ground"] for c in counts)
-        cl0 = ctx.get_clusters(0); bx0 = ctx.get_boxes(0)
+        n_tot = int(n_seq[f_last].sum())
+        cl0 = ctx.get_clusters(0); bx0 = ctx.get_boxes(0); tr0 = ctx.get_tracks(0)
+        live = [int((ctx.get_tracks(b)["track_manage"] > 0).sum()) for b in range(min(Bc, 16))]
         G = ctx.params.num_grid
-        # algorithmic HBM bytes per launch (DESIGN.md §"bytes per unit"): what a kernel must read and write once
         BL = Bc  # frames per launch (one context)
-        alg_bytes = {"polar_minz_kernel": 16.0 * N * BL,
+        # algorithmic HBM bytes per launch (what a kernel must read and write once), at the last frame's counts
+        alg_bytes = {"polar_minz_kernel": 16.0 * n_tot,
                      "polar_filter_kernel": 8.0 * 9600 * BL,
-                     "classify_compact_kernel": 16.0 * N * BL + 16.0 * (ne_tot + ng_tot) + 1.0 * N * BL,
-                     "cart_occupancy_kernel": 16.0 * ne_tot,
+                     "classify_compact_kernel": 16.0 * n_tot + 16.0 * (ne_tot + ng_tot) + 1.0 * n_tot,
                      "ccl_kernel": (2 * 2048 * 4 + 4.0 * G * G) * BL,
-                     "label_stats_kernel": (16.0 + 4.0) * ne_tot,
+                     "label_stats_kernel": (16.0 + 4.0 + 4.0) * ne_tot,
                      "cluster_index_kernel": 4.0 * ne_tot,
-                     "cluster_gather_kernel": (4.0 + 16.0) * ne_tot,
+                     "cluster_gather_kernel": (4.0 + 4.0) * ne_tot,
                      "cluster_rect_kernel": 4.0 * ne_tot / 8,
                      "box_finalize_kernel": 96.0 * BL,
-                     "track_step_kernel": (2 * 1624.0 + 144.0) * max(tr0["n"], 1) * BL}
-        # the dominant kernel of an HBM roofline is the one that moves the most bytes (it also has the largest share of GPU
-        # time in the rocprofv3 trace of this command, profiles/); the longest single launch is reported next to it
-        dom = max(alg_bytes, key=lambda k: alg_bytes[k])
-        longest = max(k_ms, key=lambda k: k_ms[k])
-        achieved = alg_bytes[dom] / (k_ms[dom] * 1e-3) / 1e9
-        # HBM bytes per launch from the committed PMC passes (FETCH_SIZE x2 on gfx950 + WRITE_SIZE, KB), same launch size only
-        traffic = None
-        pmc_path = os.path.join(ROOT, "profiles", "r01_pmc_B128.json")
+                     "track_step_kernel": (2 * 1624.0 + 144.0) * max(int(np.mean(live)), 1) * BL}
+        achieved = alg_bytes[dom] / (dom_ms * 1e-3) / 1e9 if dom_ms > 0 else 0.0
+        frame_bytes = sum(alg_bytes.values()) / BL
+        frames = B * F * args.steps * world
+        # HBM bytes per launch from the committed PMC passes of this command (FETCH_SIZE x2 on gfx950 + WRITE_SIZE, KB), same launch size only
+        traffic, traffic_src = None, None
+        pmc_path = os.path.join(ROOT, "profiles", "r02_pmc_B128.json")
         if BL == 128 and N == 120000 and os.path.exists(pmc_path):
             pmc = json.load(open(pmc_path)).get(dom)
             if pmc and "FETCH_SIZE" in pmc and "WRITE_SIZE" in pmc:
                 traffic = int((2.0 * pmc["FETCH_SIZE"] + pmc["WRITE_SIZE"]) * 1024)
-        frame_bytes = sum(alg_bytes.values()) / BL
-        frames = B * args.steps * world
+                traffic_src = "profiles/r02_pmc_B128.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command at 128 frames per launch)"
         out = {
             "metric": "LiDAR frames/sec (120k-pt 64-beam cloud) end-to-end ground->cluster->track",
             "value": round(frames / dt, 1), "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(dt / args.steps * 1e3, 4), "host_issue_ms_per_step": round(host_issue[0] / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "ms_per_step": round(dt / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32/f64 (fp32 grid indices with fp64 intermediates, int32 grids/labels, fp64 tracker — the reference's types)",
-            "data": "synthetic",
-            "config": {"workload": "configs[3]: ground removal -> CCL -> box fit -> batched IMM-UKF-PDA tracker on one MI355X, "
-                                   "120k-pt synthetic HDL-64E clouds, one frame per stream per step",
-                       "points_per_frame": N, "frames_per_step_per_gpu": B, "streams": B * world,
-                       "contexts_per_gpu": NC, "frames_per_launch": BL, "elevated_pts_per_frame": ne_tot // BL, "clusters_frame0": cl0["num_cluster"], "boxes_frame0": len(bx0["boxes"]),
-                       "tracks_stream0": int(tr0["n"]), "live_tracks_stream0": int((tr0["track_manage"] > 0).sum()),
-                       "parallelism": f"stream-sharded x{world}" + (", all_gather of live-track records (RCCL)" if world > 1 else "")},
+            "data": "synthetic", "inputs": "hbm-resident (rendered into HBM before the timed region; see host_boundary_pipelined for the PCIe-inclusive rate)",
+            "timed_region_s": round(dt, 3), "host_issue_ms_per_step": round(host_issue[0] / args.steps * 1e3, 3),
+            "config": {"workload": f"configs[3]: ground removal -> CCL -> box fit -> batched IMM-UKF-PDA tracker on one MI355X per rank; one step = {F}-frame "
+                                   f"sequence (ego motion of KITTI drive_0005) of every stream, {N}-pt synthetic HDL-64E clouds, no frame repeated within a sequence",
+                       "points_per_frame": N, "frames_per_stream_per_step": F, "streams_per_gpu": B, "streams": B * world, "distinct_scenes_per_gpu": Bc,
+                       "frames_per_step_per_gpu": B * F, "contexts_per_gpu": NC, "frames_per_launch": BL,
+                       "elevated_pts_per_frame": ne_tot // BL, "clusters_last_frame_stream0": cl0["num_cluster"], "boxes_last_frame_stream0": len(bx0["boxes"]),
+                       "tracks_ever_stream0": int(tr0["n"]), "live_tracks_per_stream": {"mean": round(float(np.mean(live)), 1), "max": int(np.max(live)), "streams_sampled": len(live)},
+                       "render_s": round(render_s, 1), "scene_density": args.density,
+                       "parallelism": f"stream-sharded x{world}" + (", all_gather of live-track records per frame (RCCL)" if world > 1 else "")},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
-                         "traffic_source": "profiles/r01_pmc_B128.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command at 128 frames per launch)" if traffic else None,
-                         "longest_launch": {"kernel": longest, "ms": round(k_ms[longest], 5)},
-                         "kernel_ms": {k: round(v, 5) for k, v in k_ms.items()},
-                         "stage_ms": {k: round(v, 5) for k, v in stage_ms.items()},
+                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_src,
+                         "kernel_ms_in_run": {"mean": round(dom_ms, 5), "min": round(min(p["min_ms"] for p in prof), 5), "max": round(max(p["max_ms"] for p in prof), 5), "samples": nsamp,
+                                              "how": f"HIP event pairs around the kernel's launch on its own stream inside the timed region, {NC} contexts running (mot_profile_kernel)"},
                          "algorithmic_bytes_per_launch": {k: int(v) for k, v in alg_bytes.items()},
                          "pipeline_bytes_per_frame": int(frame_bytes),
-                         "pipeline_frac": round(frame_bytes * B / (dt / args.steps) / 1e9 / HBM_PEAK_GBS, 4)},
+                         "pipeline_frac": round(frame_bytes * B * F / (dt / args.steps) / 1e9 / HBM_PEAK_GBS, 4)},
         }
-        if world == 1:
+        if not args.no_aux and world == 1:
+            try:   # per-kernel timing ISOLATED (one context, nothing else running) on the resident last frame
+                it = 10
+                k_ms = {k: ctx.time_stage(v, Bc, it if v != 40 else 3) for k, v in K_IDS.items()}
+                out["roofline"]["kernel_ms_isolated"] = {k: round(v, 5) for k, v in k_ms.items()}
+                out["roofline"]["stage_ms_isolated"] = {k: round(ctx.time_stage(v, Bc, it), 5) for k, v in (("ground", 0), ("cluster", 1), ("box", 2), ("stateless", 100))}
+                longest = max(k_ms, key=lambda k: k_ms[k])
+                out["roofline"]["longest_launch_isolated"] = {"kernel": longest, "ms": round(k_ms[longest], 5)}
+            except Exception as e:
+                print(f"isolated kernel timing failed: {e}", file=sys.stderr)
+        frames_host = seq_dev[:, 0, :N].cpu().numpy() if (not args.no_cpu_baseline and world == 1) else None
+        for cx in ctxs:
+            cx.close()
+        if not args.no_aux and world == 1:
             try:
-                out["host_boundary"] = host_boundary(mot, synth, N, device=local)
+                out["tracker_stress"] = tracker_stress(mot, torch, local)
             except Exception as e:   # an auxiliary figure must never cost the bench line
-                out["host_boundary"] = None
-                print(f"host_boundary measurement failed: {e}", file=sys.stderr)
-        if not args.no_cpu_baseline and world == 1:
-            out["cpu_baseline"] = cpu_baseline(synth, N)
+                out["tracker_stress"] = None
+                print(f"tracker_stress failed: {e}", file=sys.stderr)
+            try:
+                out["host_boundary_pipelined"] = host_boundary_pipelined(mot, torch, local, seq_dev, n_seq, stride, N, ego_v, ego_yaw, lib=ctx.lib)
+            except Exception as e:
+                out["host_boundary_pipelined"] = None
+                print(f"host_boundary_pipelined failed: {e}", file=sys.stderr)
+        del seq_dev
+        if frames_host is not None:
+            out["cpu_baseline"] = cpu_baseline(frames_host, ego_v, ego_yaw, N)
         print(json.dumps(out))
     if world > 1:
         dist.barrier()

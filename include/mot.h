@@ -310,11 +310,11 @@ int mot_decode_pointcloud2_dev(mot_ctx* ctx, const void* d_data, int n_points, i
  * stage: 0 ground, 1 cluster, 2 box, 100 the three stateless stages; single kernels: 10-12 ground, 20-21 cluster,
  * 30-34 box; 40 re-runs the tracker kernel with the last frame's arguments (that ADVANCES tracker state: bench only). */
 int mot_time_stage(mot_ctx* ctx, int stage, int batch, int iters, float* ms_per_iter);
-/* In-run timing: from now on every mot_frames_dev / mot_frames_host call brackets its launch of kernel `kernel_id` (ids as
- * for mot_time_stage; 0 = off) with a HIP event pair on the context stream, up to 64 launches; mot_profile_read synchronises,
+/* In-run timing: from now on every `every`-th mot_frames_dev / mot_frames_host call brackets its launch of kernel `kernel_id`
+ * (ids as for mot_time_stage; 0 = off) with a HIP event pair on the context stream, up to 64 launches; mot_profile_read synchronises,
  * returns mean / min / max of the recorded durations in milliseconds and re-arms. This is the kernel's duration INSIDE the
  * running pipeline (other contexts' kernels overlapping it), the number a rocprofv3 kernel trace of the same run reports. */
-int mot_profile_kernel(mot_ctx* ctx, int kernel_id);
+int mot_profile_kernel(mot_ctx* ctx, int kernel_id, int every);
 int mot_profile_read(mot_ctx* ctx, float* mean_ms, float* min_ms, float* max_ms, int* samples);
 
 #ifdef __cplusplus

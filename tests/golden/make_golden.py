@@ -108,6 +108,11 @@ if __name__ == "__main__":
     import tempfile
     with tempfile.TemporaryDirectory() as d:
         np.savez_compressed(os.path.join(HERE, "tracker_ot0_us.npz"), **tracker_fixture(3, 30, 40000, 1e5, ot0_workdir=d))
+    # the reference's only data fixture: the ego motion of KITTI drive_0005 its second package reads frame by frame
+    # (OT0/src/imm_ukf_jpda.cpp:65-72). bench.py drives its synthetic 154-frame sequences with it.
+    np.savez_compressed(os.path.join(HERE, "ego_drive0005.npz"),
+                        ego_v=np.loadtxt("/root/reference/object_tracking0/src/ego_velo.txt"),
+                        ego_yaw=np.loadtxt("/root/reference/object_tracking0/src/ego_yaw.txt"))
     for f in sorted(os.listdir(HERE)):
         if f.endswith(".npz"):
             print(f, os.path.getsize(os.path.join(HERE, f)))

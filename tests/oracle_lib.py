@@ -88,6 +88,13 @@ def orc():
     return _orc
 
 
+def set_ref_library(path):
+    """route the ref_* bindings to another build of the reference's sources (bench.py's -O0 baseline: oracle/_ref/libmot_ref_O0.so);
+    None restores the default"""
+    global _ref
+    _ref = C.CDLL(path) if path else None
+
+
 def ref():
     """the reference-built library, or None when it has not been built (no /root/reference, no prebuilt .so)"""
     global _ref

@@ -1,0 +1,112 @@
+"""ABI-v2 entry points on the MI355X, through the C-ABI: the on-device proof of the guarded fast cells (real v_sqrt_f32 /
+v_rcp_f32), pipelined host ingest == resident path == oracle, batched device-box tracker step, polar-grid intermediates."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+import hiprt
+
+pytestmark = pytest.mark.gpu
+
+
+def test_fast_cells_agree_with_exact_on_device(mot, hip_lib):
+    """getCellIndexFromPoints (ground_removal.cpp:67-76) and mapCartesianGrid's index
+    (component_clustering.cpp:42-48). The streaming kernels answer from estimates built on the hardware's 1-ulp v_sqrt_f32 /
+    v_rcp_f32; whenever they answer (not -2) the answer must be the exact evaluation's. > 4e9 points: uniform random, a
+    2^16 x 2^16 lattice, and every channel spoke / bin ring / grid line moved by -3..+3 ulp in x and y, both presets."""
+    total = 0
+    for preset in (0, 1):
+        with mot.Context(mot.params(preset), max_points=1024) as c:
+            st = (C.c_ulonglong * 8)()
+            for what, mode, count in ((0, 0, 1 << 30), (0, 1, 1 << 30), (0, 2, 1 << 29), (1, 0, 1 << 28), (1, 1, 1 << 28), (1, 2, 1 << 28)):
+                if preset == 1 and what == 0 and mode < 2:
+                    continue   # the polar grid does not depend on the preset: boundaries only
+                rc = hip_lib.mot_debug_sweep(c._h, what, mode, C.c_ulonglong(1234567 + 17 * mode + preset), C.c_ulonglong(count), st)
+                assert rc == 0
+                assert st[0] == count
+                x = np.array([st[3] & 0xffffffff], np.uint32).view(np.float32)[0]; y = np.array([st[3] >> 32], np.uint32).view(np.float32)[0]
+                assert st[2] == 0, f"what={what} mode={mode} preset={preset}: {st[2]} mismatches, first at ({x!r}, {y!r}) fast/exact {st[4] & 0xffffffff:#x}/{st[4] >> 32:#x}"
+                und = st[1] / count
+                assert und < (0.5 if mode == 2 else 3e-3), (what, mode, und)   # the exact path stays rare away from boundaries
+                total += count
+    assert total > 4e9
+
+
+def test_polar_grid_intermediates_on_device(mot, hip_lib, oracle, synth):
+    """a4-a8 (clamp, Gaussian, hDiff, decision, median, outlier): the per-cell ground thresholds the filter kernel leaves in
+    HBM equal the oracle's hGround on ground cells and are -inf elsewhere"""
+    p = oracle.params(0)
+    with mot.Context(max_points=131072) as c:
+        for stream in (0, 3, 9):
+            cloud = synth.make_cloud(120000, stream, 1)
+            c.ground_remove(cloud)
+            hg = np.zeros(80 * 120, np.float32)
+            assert hip_lib.mot_debug_copy(c._h, 10, 0, hg.ctypes.data_as(C.c_void_p), C.c_size_t(hg.nbytes)) == 0
+            d = oracle.ground_remove(p, cloud, want_dump=True)
+            isg = d["is_ground"].reshape(-1).astype(bool)
+            assert np.array_equal(np.isfinite(hg), isg)
+            assert np.array_equal(hg[isg].view(np.uint32), d["hground"].astype(np.float32).reshape(-1)[isg].view(np.uint32))
+
+
+def test_frames_host_equals_resident_path_and_oracle(mot, hip_lib, oracle, synth):
+    B, N, stride = 4, 60000, 61440
+    p = oracle.params(0)
+    hp = C.c_void_p()
+    assert hip_lib.mot_host_alloc(C.c_size_t(B * stride * 16), C.byref(hp)) == 0
+    pinned = np.ctypeslib.as_array(C.cast(hp, C.POINTER(C.c_float)), shape=(B, stride, 4))
+    with mot.Context(max_points=stride, max_batch=B, max_tracks_total=256) as a, mot.Context(max_points=stride, max_batch=B, max_tracks_total=256) as b:
+        T = oracle.Tracker(p)
+        for f in range(6):
+            n = [N, N - 1234, 2048, 7]
+            host = np.zeros((B, stride, 4), np.float32)
+            for s in range(B):
+                host[s, : n[s]] = synth.make_cloud(N, 70 + s, f)[: n[s]]
+            ts = [1.0e9 + f * 1e5] * B
+            kw = dict(run_tracker=True, timestamps=ts, ego_v=[2.0] * B, ego_yaw=[0.002 * f] * B)
+            dev = hiprt.DeviceBuffer(host)
+            a.frames_dev(dev.ptr, stride * 4, n, **kw)
+            b.wait_uploads()          # the pinned block is refilled: the previous upload must have left it
+            pinned[:] = host
+            b.frames_host(hp.value, stride * 4, n, **kw)
+            for s in range(B):
+                ga, gb = a.get_ground(s, n_hint=n[s]), b.get_ground(s, n_hint=n[s])
+                assert np.array_equal(ga["elevated"].view(np.uint32), gb["elevated"].view(np.uint32)) and np.array_equal(ga["mask"], gb["mask"])
+                assert np.array_equal(a.get_boxes(s)["boxes"], b.get_boxes(s)["boxes"])
+                ta, tb = a.get_tracks(s), b.get_tracks(s)
+                assert ta["n"] == tb["n"] and np.array_equal(ta["track_manage"], tb["track_manage"]) and np.array_equal(ta["p"], tb["p"])
+            g = oracle.ground_remove(p, host[0, : n[0]]); cl = oracle.cluster(p, g["elevated"])
+            bx = oracle.box_fit(p, g["elevated"], cl["grid"], cl["num_cluster"])["boxes"]
+            assert np.array_equal(b.get_ground(0, n_hint=n[0])["elevated"].view(np.uint32), g["elevated"].view(np.uint32))
+            assert np.array_equal(b.get_clusters(0)["grid"], cl["grid"]) and np.array_equal(b.get_boxes(0)["boxes"], bx)
+            a.synchronize()
+    T.close()
+    assert hip_lib.mot_host_free(hp) == 0
+
+
+def test_track_steps_dev_equals_track_step(mot, hip_lib):
+    B = 8
+    rng = np.random.default_rng(5)
+    with mot.Context(max_points=1024, max_batch=B, max_tracks_total=512) as a, mot.Context(max_points=1024, max_batch=B, max_tracks_total=512) as b:
+        centres = [rng.uniform(-30, 30, size=(40, 2)) for _ in range(B)]
+        vel = [rng.uniform(-1, 1, size=(40, 2)) for _ in range(B)]
+        stride = 48 * 24
+        for f in range(12):
+            ts = 1.0e9 + f * 1e5
+            blk = np.zeros((B, stride), np.float32); m = []
+            for s in range(B):
+                k = 40 - (s + f) % 5
+                c = centres[s][:k] + vel[s][:k] * (0.1 * f)
+                bx = np.zeros((k, 8, 3), np.float32)
+                bx[:, :, :2] = c[:, None, :] + np.array([[0, 0], [1.8, 0], [1.8, 0.9], [0, 0.9]] * 2)[None]
+                bx[:, :4, 2] = -2.0; bx[:, 4:, 2] = 0.4
+                blk[s, : k * 24] = bx.reshape(-1); m.append(k)
+                a.ego_update(ts, 0.0, 0.0, s); b.ego_update(ts, 0.0, 0.0, s)
+                a.track_step(bx, ts, s)
+            dev = hiprt.DeviceBuffer(blk)
+            b.track_steps_dev(dev.ptr, stride, m, [ts] * B)
+            for s in range(B):
+                ta, tb = a.get_tracks(s), b.get_tracks(s)
+                assert ta["n"] == tb["n"] and np.array_equal(ta["track_manage"], tb["track_manage"]) and np.array_equal(ta["lifetime"], tb["lifetime"])
+                assert np.array_equal(ta["p"], tb["p"]) and np.array_equal(ta["v_yaw"], tb["v_yaw"])
+        assert (a.get_tracks(0)["track_manage"] > 0).sum() >= 30    # the tracker really runs with tens of live tracks

@@ -1,0 +1,166 @@
+"""Host logic of the ABI-v2 entry points, exercised on the emulator build (tests/emu/hipemu.h: the same csrc/*.hip compiled by
+g++; development check of LOGIC, not a parity claim — the -m gpu tests repeat the comparisons on the MI355X):
+pipelined host ingest, batched device-box tracker step, in-run kernel timing, per-slot reset, sticky track capacity,
+capacity-checked getters."""
+import ctypes as C
+import os
+import sys
+
+import numpy as np
+import pytest
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "emu"))
+
+
+@pytest.fixture(scope="module")
+def emu(mot):
+    import build_emu
+    lib = build_emu.build()
+    return lib, mot.load_library(lib)
+
+
+def _moving_boxes(f, m=6):
+    b = np.zeros((m, 8, 3), np.float32)
+    for k in range(m):
+        b[k, :, :2] = np.array([[0, 0], [2, 0], [2, 1], [0, 1]] * 2) + [6.0 * k - 15 + 0.3 * f, 4.0 + 0.1 * f * (k % 3)]
+        b[k, :4, 2] = -2.0; b[k, 4:, 2] = 0.5
+    return b
+
+
+def test_frames_host_equals_frames_dev(mot, emu, synth, oracle):
+    lib, L = emu
+    B, N, stride = 3, 5000, 5120
+    p = oracle.params(0)
+    with mot.Context(lib_path=lib, max_points=stride, max_batch=B, max_tracks_total=128) as a, \
+         mot.Context(lib_path=lib, max_points=stride, max_batch=B, max_tracks_total=128) as b:
+        for f in range(5):   # more calls than staging buffers: both are reused
+            n = [N, N - 777, 64 + f]
+            host = np.zeros((B, stride, 4), np.float32)
+            for s in range(B):
+                host[s, : n[s]] = synth.make_cloud(N, 40 + s, f)[: n[s]]
+            ts = [1.0e9 + f * 1e5] * B
+            kw = dict(run_tracker=True, timestamps=ts, ego_v=[1.0] * B, ego_yaw=[0.01 * f] * B)
+            a.frames_dev(host.ctypes.data, stride * 4, n, **kw)
+            # once dense (frames at the staging stride: one copy), once ragged (per-frame copies)
+            if f % 2 == 0:
+                b.frames_host(host.ctypes.data, stride * 4, n, **kw)
+            else:
+                wide = np.zeros((B, stride + 64, 4), np.float32); wide[:, :stride] = host
+                b.frames_host(wide.ctypes.data, (stride + 64) * 4, n, **kw)
+            b.wait_uploads()
+            for s in range(B):
+                ga, gb = a.get_ground(s, n_hint=n[s]), b.get_ground(s, n_hint=n[s])
+                assert np.array_equal(ga["elevated"], gb["elevated"]) and np.array_equal(ga["mask"], gb["mask"])
+                assert np.array_equal(a.get_boxes(s)["boxes"], b.get_boxes(s)["boxes"])
+                ta, tb = a.get_tracks(s), b.get_tracks(s)
+                assert ta["n"] == tb["n"] and np.array_equal(ta["track_manage"], tb["track_manage"]) and np.array_equal(ta["p"], tb["p"])
+            # and against the oracle for one stream
+            g = oracle.ground_remove(p, host[0, : n[0]])
+            assert np.array_equal(b.get_ground(0, n_hint=n[0])["elevated"], g["elevated"])
+        # the fetched host block = the live tracks of get_tracks
+        K = 16
+        rec = np.zeros((B, K, 36), np.int32); cnt = np.zeros(B, np.int32)
+        b.fetch_tracks_async(B, rec.ctypes.data, K, cnt.ctypes.data); b.synchronize()
+        for s in range(B):
+            t = b.get_tracks(s)
+            live = np.nonzero(t["track_manage"] > 0)[0][:K]
+            assert cnt[s] == len(live) and np.array_equal(rec[s, : cnt[s], 0], live)
+
+
+def test_track_steps_dev_equals_track_step(mot, emu):
+    lib, L = emu
+    B = 3
+    with mot.Context(lib_path=lib, max_points=1024, max_batch=B, max_tracks_total=64) as a, \
+         mot.Context(lib_path=lib, max_points=1024, max_batch=B, max_tracks_total=64) as b:
+        for f in range(8):
+            ts = 1.0e9 + f * 1e5
+            m = [6, 3 + f % 3, 0 if f == 4 else 5]
+            stride = 8 * 24
+            blk = np.zeros((B, stride), np.float32)
+            for s in range(B):
+                bx = _moving_boxes(f + s)[: m[s]]
+                blk[s, : m[s] * 24] = bx.reshape(-1)
+                a.ego_update(ts, 0.5, 0.0, s); b.ego_update(ts, 0.5, 0.0, s)
+                a.track_step(bx, ts, s)
+            b.track_steps_dev(blk.ctypes.data, stride, m, [ts] * B)
+            for s in range(B):
+                ta, tb = a.get_tracks(s), b.get_tracks(s)
+                assert ta["n"] == tb["n"] and np.array_equal(ta["track_manage"], tb["track_manage"])
+                assert np.array_equal(ta["p"], tb["p"]) and np.array_equal(ta["v_yaw"], tb["v_yaw"])
+        with pytest.raises(mot.MotError) as e:
+            b.track_steps_dev(blk.ctypes.data, 24, [2, 0, 0], [ts + 1e5] * B)   # two boxes do not fit a 24-float stride
+        assert e.value.code == mot.MOT_E_ARG
+
+
+def test_reset_slot_and_sticky_capacity(mot, emu):
+    lib, L = emu
+    with mot.Context(lib_path=lib, max_points=1024, max_batch=2, max_tracks_total=4) as c:
+        hit = 0
+        for f in range(6):
+            ts = 1.0e9 + f * 1e5
+            for s in range(2):
+                c.ego_update(ts, 0.0, 0.0, s)
+                try:
+                    c.track_step(_moving_boxes(f, 12), ts, s)
+                except mot.MotError as e:
+                    assert e.code == mot.MOT_E_CAPACITY
+                    hit += 1
+        assert hit >= 6                      # told again on every call once births are being dropped (both streams)
+        with pytest.raises(mot.MotError):
+            c.get_tracks(0)                  # ... also by the getter, until the stream is started over
+        c.reset_slot(0)
+        assert c.get_tracks(0)["n"] == 0     # slot 0 forgot everything
+        with pytest.raises(mot.MotError):
+            c.get_tracks(1)                  # slot 1 did not
+        with pytest.raises(mot.MotError) as e:
+            c.reset_slot(5)
+        assert e.value.code == mot.MOT_E_ARG and "slot" in str(e.value)
+
+
+def test_getters_check_caller_capacity(mot, emu, synth):
+    lib, L = emu
+    with mot.Context(lib_path=lib, max_points=4096, max_batch=1, max_tracks_total=8) as c:
+        cloud = synth.make_cloud(4000, 2, 0)
+        c.frames_dev(cloud.ctypes.data, 4096 * 4, [4000])
+        ne = c.get_ground(0, want_clouds=False)["n_elevated"]
+        assert ne > 10
+        small = np.zeros((ne - 1, 4), np.float32); n_e = C.c_int(0)
+        rc = L.mot_get_ground(c._h, 0, small.ctypes.data_as(C.c_void_p), C.byref(n_e), None, None, None, ne - 1)
+        assert rc == mot.MOT_E_CAPACITY and n_e.value == ne and b"capacity_points" in L.mot_last_error(c._h)
+        lab = np.zeros(ne - 1, np.int32)
+        rc = L.mot_get_clusters(c._h, 0, None, None, lab.ctypes.data_as(C.c_void_p), ne - 1)
+        assert rc == mot.MOT_E_CAPACITY
+        lab = np.zeros(ne, np.int32)
+        assert L.mot_get_clusters(c._h, 0, None, None, lab.ctypes.data_as(C.c_void_p), ne) == mot.MOT_OK
+        # a cloud that is not 16-byte aligned is refused before anything is launched
+        raw = np.zeros(4096 * 4 + 1, np.float32)
+        off = raw[1:] if raw.ctypes.data % 16 == 0 else raw[:-1]
+        if off.ctypes.data % 16:
+            rc = L.mot_frames_dev(c._h, C.c_void_p(off.ctypes.data), C.c_long(4096 * 4), np.array([10], np.int32).ctypes.data_as(C.c_void_p), 1, 0, None, None, None)
+            assert rc == mot.MOT_E_ARG and b"aligned" in L.mot_last_error(c._h)
+
+
+def test_profile_ring(mot, emu, synth):
+    lib, L = emu
+    with mot.Context(lib_path=lib, max_points=2048, max_batch=1, max_tracks_total=8) as c:
+        cloud = synth.make_cloud(2000, 2, 0)
+        c.profile_kernel(12)                 # the compaction kernel
+        for _ in range(3):
+            c.frames_dev(cloud.ctypes.data, 2048 * 4, [2000])
+        r = c.profile_read()
+        assert r["samples"] == 3 and r["mean_ms"] >= 0 and r["min_ms"] <= r["mean_ms"] <= r["max_ms"]
+        assert c.profile_read()["samples"] == 0
+        c.profile_kernel(0)
+        c.frames_dev(cloud.ctypes.data, 2048 * 4, [2000])
+        assert c.profile_read()["samples"] == 0
+
+
+def test_fast_path_sweeps_on_the_emulator(mot, emu):
+    """the sweep hook itself (the real check needs the hardware's v_sqrt / v_rcp: tests/test_ground_gpu.py)"""
+    lib, L = emu
+    with mot.Context(lib_path=lib, max_points=1024) as c:
+        st = (C.c_ulonglong * 8)()
+        for what in (0, 1):
+            for mode in (0, 1, 2):
+                assert L.mot_debug_sweep(c._h, what, mode, C.c_ulonglong(7), C.c_ulonglong(200000), st) == 0
+                assert st[0] == 200000 and st[2] == 0, (what, mode, list(st))
