@@ -32,7 +32,7 @@ __device__ __forceinline__ float ulp_step(float f, int k) {   // k representable
 
 // mode 0: uniform random in [-R, R]^2     (R = 130 polar / 1.2 * roi_half Cartesian)
 // mode 1: regular lattice over the same square (index -> (i % side, i / side))
-// mode 2: points ON the cell boundaries, moved by -3..+3 ulps in x and in y:
+// mode 2: points ON the cell boundaries, moved by -3..+3 steps of 1..64 ulp in x and in y:
 //           polar: every channel spoke (k * 2 pi / 80) at random radii, and every bin ring (rMin + k * span / 120) at random angles
 //           Cartesian: every grid line x = -roi/2 + k * roi / G (and y), random along the line
 // what = 0 polar cell, 1 Cartesian cell
@@ -52,7 +52,8 @@ sweep_kernel(MotDevParams p, int what, int mode, unsigned long long seed, unsign
     } else if (mode == 1) {
       x = ((float)(i % side) + 0.5f) * (2.f * R / (float)side) - R; y = ((float)((i / side) % side) + 0.5f) * (2.f * R / (float)side) - R;
     } else {
-      const int dx = (int)(h2 % 7) - 3, dy = (int)((h2 >> 8) % 7) - 3;
+      // -3..+3 steps of 1, 2, 4, ... 64 ulp: from exactly on the boundary to just outside the guard band on either side
+      const int dx = ((int)(h2 % 7) - 3) << (int)((h2 >> 3) % 7), dy = ((int)((h2 >> 8) % 7) - 3) << (int)((h2 >> 11) % 7);
       if (what == 0) {
         if (h2 & (1ull << 40)) {   // a channel spoke
           const int k = (int)((h2 >> 16) % (MOT_NUM_CHANNEL + 1));

@@ -73,7 +73,11 @@ struct mot_ctx {
   mot_track* d_tout = nullptr;
   int* d_tflags = nullptr;
   EgoPose* d_ego = nullptr;
-  long long* d_phase = nullptr;
+  int* d_nlive = nullptr;
+  Vec2d* d_pos = nullptr;
+  Vec2d* d_cp = nullptr;
+  TrackItem* d_items = nullptr;
+  int* d_nitems = nullptr;
   struct SlotEgo {  // file-scope globals of OT/tracking/imm_ukf_jpda.cpp:19-24,56-70, one set per stream
     bool init = false, ego_called = false;
     double timestamp = 0, egoVelo = 0, egoYaw = 0, egoPreYaw = 0;
@@ -231,7 +235,7 @@ extern "C" void mot_destroy(mot_ctx* c) {
     for (int i = 0; i < mot_ctx::kProfRing; i++) { (void)hipEventDestroy(c->prof_ev[i][0]); (void)hipEventDestroy(c->prof_ev[i][1]); }
   void* bufs[] = {c->d_in, c->d_n, c->d_pairs, c->d_pair_count, c->d_hg, c->d_desc, c->d_ticket, c->d_elev, c->d_ground, c->d_mask, c->d_counts,
                   c->d_plane_a, c->d_plane_b, c->d_grid, c->d_label, c->d_stats, c->d_cand, c->d_boxes, c->d_box_cluster, c->d_rng, c->d_poly, c->d_groups, c->d_cluster_start, c->d_sorted, c->d_pix, c->d_wgtab, c->d_side_cell, c->d_side_cloud, c->d_side_obs, c->d_side_cost, c->d_side_counts, c->d_raw,
-                  c->d_tracks, c->d_nt, c->d_tboxes, c->d_targs, c->d_gate, c->d_prog, c->d_live, c->d_tout, c->d_tflags, c->d_ego, c->d_phase};
+                  c->d_tracks, c->d_nt, c->d_tboxes, c->d_targs, c->d_gate, c->d_prog, c->d_live, c->d_tout, c->d_tflags, c->d_ego, c->d_nlive, c->d_pos, c->d_cp, c->d_items, c->d_nitems};
   for (void* b : bufs) if (b) (void)hipFree(b);
   if (c->h_counts) (void)hipHostFree(c->h_counts);
   if (c->ev0) (void)hipEventDestroy(c->ev0);
@@ -324,8 +328,13 @@ static int create_impl(mot_ctx* c) {
   MOT_HIP(c, hipMalloc(&c->d_tout, B * T * sizeof(mot_track)));
   MOT_HIP(c, hipMalloc(&c->d_tflags, B * sizeof(int)));
   MOT_HIP(c, hipMalloc(&c->d_ego, B * sizeof(EgoPose)));
-  MOT_HIP(c, hipMalloc(&c->d_phase, B * 16 * sizeof(long long)));
-  MOT_HIP(c, hipMemsetAsync(c->d_phase, 0, B * 16 * sizeof(long long), c->stream));
+  MOT_HIP(c, hipMalloc(&c->d_nlive, B * sizeof(int)));
+  MOT_HIP(c, hipMalloc(&c->d_pos, B * T * sizeof(Vec2d)));
+  MOT_HIP(c, hipMalloc(&c->d_cp, B * kMaxBoxesPerFrame * sizeof(Vec2d)));
+  MOT_HIP(c, hipMalloc(&c->d_items, B * T * sizeof(TrackItem)));
+  MOT_HIP(c, hipMalloc(&c->d_nitems, sizeof(int)));
+  MOT_HIP(c, hipMemsetAsync(c->d_nlive, 0, B * sizeof(int), c->stream));
+  MOT_HIP(c, hipMemsetAsync(c->d_nitems, 0, sizeof(int), c->stream));
   MOT_HIP(c, hipMemsetAsync(c->d_nt, 0, B * sizeof(int), c->stream));
   MOT_HIP(c, hipMemsetAsync(c->d_tflags, 0, B * sizeof(int), c->stream));
   c->ego.assign(B, mot_ctx::SlotEgo());
@@ -378,6 +387,7 @@ extern "C" int mot_reset(mot_ctx* c) {
   MOT_GUARD(c);
   // stream-ordered: takes effect after the steps already queued, before the next one (no host synchronisation)
   MOT_HIP(c, hipMemsetAsync(c->d_nt, 0, c->batch * sizeof(int), c->stream));
+  MOT_HIP(c, hipMemsetAsync(c->d_nlive, 0, c->batch * sizeof(int), c->stream));
   MOT_HIP(c, hipMemsetAsync(c->d_tflags, 0, c->batch * sizeof(int), c->stream));
   c->ego.assign(c->batch, mot_ctx::SlotEgo());
   return MOT_OK;
@@ -460,7 +470,6 @@ static int launch_frames(mot_ctx* c, int batch, int run_tracker, const double* t
     }
     MOT_HIP(c, hipMemcpyAsync(c->d_ego, c->h_ego.data(), batch * sizeof(EgoPose), hipMemcpyHostToDevice, c->stream));
     MOT_HIP(c, hipMemcpyAsync(c->d_targs, c->h_targs.data(), c->batch * sizeof(TrackFrameArgs), hipMemcpyHostToDevice, c->stream));
-    mot_launch_boxes_to_global(c->d_boxes, c->d_counts, c->d_ego, c->d_tboxes, batch, c->stream);
     { ProfScope ps(c, kT1); mot_launch_track(track_buffers(c, true), batch, c->stream); }
   }
   MOT_HIP(c, hipGetLastError());
@@ -960,8 +969,11 @@ extern "C" int mot_time_stage(mot_ctx* c, int stage, int batch, int iters, float
 static TrackBuffers track_buffers(mot_ctx* c, bool fused) {
   TrackBuffers t;
   t.tracks = c->d_tracks; t.nt = c->d_nt; t.boxes = c->d_tboxes; t.args = c->d_targs; t.gate = c->d_gate; t.prog = c->d_prog;
-  t.live = c->d_live; t.out = c->d_tout; t.flags = c->d_tflags; t.phase_clock = c->d_phase; t.m_dev = fused ? c->d_counts : nullptr; t.T = c->max_tracks_total;
+  t.live = c->d_live; t.out = c->d_tout; t.flags = c->d_tflags; t.m_dev = fused ? c->d_counts : nullptr; t.T = c->max_tracks_total;
   t.box_stride = (long)kMaxBoxesPerFrame * 24;
+  t.nlive = c->d_nlive; t.pos = c->d_pos; t.cp = c->d_cp; t.items = c->d_items; t.n_items = c->d_nitems;
+  // fused path: the box stage's boxes (sensor frame) become the tracker's input through the dead-reckoned ego pose
+  t.boxes_sensor = fused ? c->d_boxes : nullptr; t.ego = fused ? c->d_ego : nullptr; t.boxes_out = fused ? c->d_tboxes : nullptr;
   t.tp.gamma_g = c->params.gamma_g; t.tp.p_g = c->params.p_g; t.tp.p_d = c->params.p_d; t.tp.distance_thres = c->params.distance_thres;
   t.tp.bb_yaw_change_thres = c->params.bb_yaw_change_thres; t.tp.seed_px = c->params.seed_px; t.tp.seed_py = c->params.seed_py;
   t.tp.life_time_thres = c->params.life_time_thres; t.tp.seed_box_index = c->params.seed_box_index;
@@ -1044,6 +1056,7 @@ extern "C" int mot_reset_slot(mot_ctx* c, int slot) {
   MOT_GUARD(c);
   if (slot < 0 || slot >= c->batch) return fail(c, MOT_E_ARG, "slot out of range");
   MOT_HIP(c, hipMemsetAsync(c->d_nt + slot, 0, sizeof(int), c->stream));
+  MOT_HIP(c, hipMemsetAsync(c->d_nlive + slot, 0, sizeof(int), c->stream));
   MOT_HIP(c, hipMemsetAsync(c->d_tflags + slot, 0, sizeof(int), c->stream));
   c->ego[slot] = mot_ctx::SlotEgo();
   return MOT_OK;
@@ -1126,7 +1139,6 @@ extern "C" int mot_debug_copy(mot_ctx* c, int which, int slot, void* dst, size_t
   const void* src = nullptr;
   if (which == 0) src = c->d_cand + (size_t)slot * kMaxClusters;
   else if (which == 1) src = c->d_stats + (size_t)slot * kMaxClusters;
-  else if (which == 2) src = c->d_phase + (size_t)slot * 16;
   else if (which == 3) src = c->d_poly + (size_t)slot * c->cap;
   else if (which == 5) src = c->d_sorted + (size_t)slot * c->cap;
   else if (which == 7) src = c->d_cluster_start + (size_t)slot * (kMaxClusters + 1);

@@ -8,7 +8,7 @@
 #ifdef __cplusplus
 extern "C" {
 #endif
-/* raw copy of a per-slot device array to the host (which: 0 box candidates, 1 cluster statistics, 2 tracker phase clocks,
+/* raw copy of a per-slot device array to the host (which: 0 box candidates, 1 cluster statistics,
  * 3 polygon pool, 5 cluster-sorted index, 7 cluster starts, 8 pixels, 9 (tile, cluster) groups, 10 polar thresholds hGround) */
 int mot_debug_copy(mot_ctx* ctx, int which, int slot, void* dst, size_t bytes);
 /* on-device sweep of a guarded fast path against its exact evaluation with the REAL hardware instructions (debug.hip):

@@ -209,18 +209,30 @@ struct MotTrackParams {
   int life_time_thres, seed_box_index;
 };
 
+struct Vec2d { double x, y; };
+struct TrackItem { int b, li; };  // one unit of per-track work: live track `li` (index into the stream's live list) of stream `b`
+struct EgoPose { double x, y, yaw; };
+
 struct TrackBuffers {
   DevTrack* tracks;             // [B][T]
   int* nt;                      // [B] tracks ever created
-  const float* boxes;           // [B][box_stride] floats, 24 per box, global frame
+  const float* boxes;           // [B][box_stride] floats, 24 per box, global frame: what the tracker reads
   long box_stride;              // floats per slot (kMaxBoxesPerFrame * 24 for the library's own buffer)
+  const float* boxes_sensor;    // fused path: [B][kMaxBoxesPerFrame][24] boxes of the box stage in the sensor frame, or null
+  const EgoPose* ego;           //   ... the dead-reckoned ego pose per slot: the prep kernel writes their global-frame image
+  float* boxes_out;             //   ... into this buffer (= boxes)
   const TrackFrameArgs* args;   // [B]
   unsigned long long* gate;     // [B][T][kGateWords]
   unsigned long long* prog;     // [B][T][kGateWords]
-  int* live;                    // [B][2*T]: compact list of live tracks, then their "reached gating" flags
+  int* live;                    // [B][2*T]: compact list of the tracks alive at the start of the step, then their flags (0 killed by a
+                                // guard, 1 reached gating, 2 reached gating in second initialisation)
+  int* nlive;                   // [B] length of that list (written by the previous step's finish kernel)
+  Vec2d* pos;                   // [B][T] merged position (x_merge_(0..1)) of every track ever created, mirrored for the merge phase
+  Vec2d* cp;                    // [B][kMaxBoxesPerFrame] box centres of the frame (trackPoints)
+  TrackItem* items;             // [B*T] work list of the two per-track kernels, any order
+  int* n_items;                 // its length; zero between steps
   mot_track* out;               // [B][T]
   int* flags;                   // [B] capacity flags
-  long long* phase_clock;       // [B][16] shader-clock stamps of the phase boundaries of the last step (diagnostics)
   const int* m_dev;             // optional: boxes per frame read from counts[b*kCountsStride + kCntBoxes] (fused path)
   int T;
   MotTrackParams tp;
@@ -229,9 +241,6 @@ enum { kTrackFlagCapacity = 1 };
 
 void mot_launch_track(const TrackBuffers& t, int batch, hipStream_t stream);
 void mot_launch_export_tracks(const TrackBuffers& t, int batch, mot_track* dst, int max_per_slot, int* dst_counts, hipStream_t stream);
-// boxes of the box stage (sensor frame) -> tracker input (global frame): p_global = R(-yaw) (p - (x, y))
-struct EgoPose { double x, y, yaw; };
-void mot_launch_boxes_to_global(const float* boxes_sensor, const int* counts, const EgoPose* ego, float* boxes_global, int batch, hipStream_t stream);
 
 #ifdef MOT_HIPEMU
 #define MOT_WAVE_SYNC() ((void)__ballot(1))

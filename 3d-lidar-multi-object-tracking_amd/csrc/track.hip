@@ -1,21 +1,21 @@
 // track.hip — IMM-UKF-PDA multi-object tracker step on gfx950. Product code (HIP, wave64, fp64).
 //
 // Replaces immUkfJpdaf() (OT/tracking/imm_ukf_jpda.cpp:704-1112) and the class UKF it drives
-// (OT/tracking/ukf.cpp) for a batch of independent sensor streams: ONE workgroup steps one stream, ONE wave owns
-// one track at a time ("one warp per track" of BASELINE.json's north_star). The reference walks its tracks one
-// after the other and lets them interact through shared vectors; here the frame step is cut into phases:
+// (OT/tracking/ukf.cpp) for a batch of independent sensor streams. ONE wave owns one track at a time ("one warp per track"
+// of BASELINE.json's north_star). The reference walks its tracks one after the other and lets them interact through shared
+// vectors; here the frame step is cut into phases, spread over four launches (see "the frame step" below):
 //
-//   P0  clear isVis, compact the live tracks (trackNum != 0) in index order                      (all threads)
-//   PA  per live track (a wave): divergence guard, IMM mixing, 3 x sigma-point prediction, 3 x lidar
+//   PA  per live track (a wave): clear isVis, divergence guard, IMM mixing, 3 x sigma-point prediction, 3 x lidar
 //       measurement prediction, pick the max-det(S) model, gate every box of the frame (NIS < 9.22)
 //       -> bit-mask per track; lanes = sigma points / matrix entries / boxes
-//   PB  one wave, tracks in index order: lifetime += #gated boxes nobody claimed before           (SURVEY.md H12:
-//       matchingVec is shared across the reference's track loop — the only true cross-track order dependence)
+//   PB  lifetime += #gated boxes no EARLIER track of the stream claimed                            (SURVEY.md H12:
+//       matchingVec is shared across the reference's track loop — the only true cross-track order dependence); every
+//       track's wave ORs the masks of its predecessors itself, so no sequential pass over the tracks is left
 //   PC  per track (a wave): box association + best-box upkeep, second initialisation, track-management state
 //       machine, PDA update of the three models, mode probabilities, merge
 //   PD  over-segmentation merge in closed form (last write of the reference's (i,j) double loop wins)
 //   PE  birth of a track from every unclaimed box, in box order
-//   PF  per-track outputs and the sticky static classification
+//   PF  per-track outputs, the sticky static classification, the compact list of the tracks alive for the next step
 //
 // fp64 like the reference; operation order follows the reference except inside reductions over sigma points /
 // measurements (Eigen's own reductions are vectorised, so that order is not defined by the source either).
@@ -25,8 +25,16 @@
 
 #ifndef MOT_HIPEMU
 #define MOT_LAUNCH_BOUNDS(n) __launch_bounds__(n)
+#define MOT_LAUNCH_BOUNDS2(n, waves_per_simd) __launch_bounds__(n, waves_per_simd)
 #else
 #define MOT_LAUNCH_BOUNDS(n)
+#define MOT_LAUNCH_BOUNDS2(n, waves_per_simd)
+#endif
+#ifndef MOT_PREDICT_WAVES
+#define MOT_PREDICT_WAVES 3
+#endif
+#ifndef MOT_UPDATE_WAVES
+#define MOT_UPDATE_WAVES 2
 #endif
 
 #define PI_D 3.14159265358979323846
@@ -43,7 +51,19 @@ struct WaveScratch {
 };
 
 __device__ __forceinline__ int tlane() { return (int)(threadIdx.x & 63); }
-__device__ __forceinline__ double wrap_pi(double a) { while (a > PI_D) a -= 2. * PI_D; while (a < -PI_D) a += 2. * PI_D; return a; }
+// `while (a > M_PI) a -= 2. * M_PI; while (a < -M_PI) a += 2. * M_PI;` — the reference's angle normalisation (ukf.cpp, imm_ukf_jpda.cpp
+// passim). Its cost is |a| / 2 pi iterations: a diverging track (a failed Cholesky leaves un-rooted covariance entries in the
+// sigma-point spread, ukf.cpp:651-662) drives |a| to 1e5..1e8 and ONE such track held a whole launch for 10-160 ms on the
+// MI355X (profiles/r02_tracker_outliers.md). Up to 32 turns the loop runs as written (bit-identical to the reference);
+// beyond that the whole turns come off in one step first — the result differs from the loop's by the roundings the loop
+// would have accumulated (< 1e-9 for |a| < 1e4), on tracks whose state is garbage already and which the reference's own
+// guards (:828-851) are about to kill. Inf, which hangs the reference, becomes NaN here.
+__device__ __forceinline__ double wrap_pi(double a) {
+  if (fabs(a) > 64. * PI_D) a = a - trunc(a / (2. * PI_D)) * (2. * PI_D);
+  while (a > PI_D) a -= 2. * PI_D;
+  while (a < -PI_D) a += 2. * PI_D;
+  return a;
+}
 __device__ __forceinline__ double det2(const double* m) { return m[0] * m[3] - m[1] * m[2]; }
 __device__ __forceinline__ void inv2(const double* m, double* o) { double d = det2(m); o[0] = m[3] / d; o[1] = -m[1] / d; o[2] = -m[2] / d; o[3] = m[0] / d; }
 __device__ __forceinline__ double wave_sum_d(double v) { return wave_sum_f64(v); }
@@ -104,14 +124,8 @@ __device__ void track_init(DevTrack* t, double zx, double zy) {
 __device__ __forceinline__ double ukf_w(int i) { return i == 0 ? (-4.0 / (-4.0 + 7.0)) : (0.5 / (7.0 + -4.0)); }
 
 // ProcessIMMUKF(dt), ukf.cpp:507-527 — whole wave, state in ws
-__device__ void process_imm_ukf(WaveScratch* ws, double dt, long long* dbgclk = nullptr) {
+__device__ void process_imm_ukf(WaveScratch* ws, double dt) {
   const int lane = tlane();
-#ifdef MOT_DBG_TRACK_UKF
-#define UKF_T(k) if (dbgclk && threadIdx.x == 0) dbgclk[k] = clock64()
-#else
-#define UKF_T(k)
-#endif
-  UKF_T(11);
   // MixingProbability :439-456 (p1_,p2_,p3_ = rows of the transition matrix :139-154)
   if (lane < 3) {
     const int j = lane;
@@ -139,7 +153,6 @@ __device__ void process_imm_ukf(WaveScratch* ws, double dt, long long* dbgclk = 
     ws->P[j][r * 5 + c] = acc;
   }
   MOT_WAVE_SYNC();
-  UKF_T(12);
   // Prediction(dt, m) :630-772. Augmented covariance, Eigen 3.2.10 LLT::unblocked semantics: a non-positive pivot
   // stops the factorisation and matrixL() returns the partially overwritten lower triangle.
   if (lane < 3) {
@@ -188,7 +201,6 @@ __device__ void process_imm_ukf(WaveScratch* ws, double dt, long long* dbgclk = 
       }
   }
   MOT_WAVE_SYNC();
-  UKF_T(13);
   if (lane < 45) {  // one lane per (model, sigma point): Cv :573, Ctrv :539, randomMotion :602
     const int m = lane / 15, i = lane % 15;
     const double sc = sqrt(-4.0 + 7.0);
@@ -228,7 +240,6 @@ __device__ void process_imm_ukf(WaveScratch* ws, double dt, long long* dbgclk = 
     for (int r = 0; r < 5; r++) ws->Xs[m][r * 15 + i] = s[r];
   }
   MOT_WAVE_SYNC();
-  UKF_T(14);
   if (lane < 15) {  // predicted mean :736-742
     int m = lane / 5, r = lane % 5;
     double acc = 0;
@@ -250,7 +261,6 @@ __device__ void process_imm_ukf(WaveScratch* ws, double dt, long long* dbgclk = 
     }
     ws->P[m][r * 5 + c] = acc;
   }
-  UKF_T(15);
   // UpdateLidar(m) :778-902
   if (lane < 6) {
     int m = lane / 2, c = lane % 2;
@@ -392,355 +402,439 @@ __device__ void store_models(const WaveScratch* ws, DevTrack* t) {
   if (lane < 30) t->K[lane / 10][lane % 10] = ws->K[lane / 10][lane % 10];
 }
 
+// =============================================================================================== the frame step
+// Four launches per step and context, all stream-ordered:
+//   T0 track_prep_kernel     (B workgroups)  boxes -> global frame, box centres, first-frame seed, work list of (stream, live track)
+//   T1 track_predict_kernel  (persistent)    phase PA, one wave per work item
+//   T2 track_update_kernel   (persistent)    phases PB (per-track share) + PC, one wave per work item
+//   T3 track_finish_kernel   (B workgroups)  phases PD, PE, PF, the live list of the next step
+// The first version ran all phases in ONE workgroup per stream (8 waves): 128 streams kept half the chip idle and a stream
+// with 64 live tracks walked them 8 at a time (745 k cycles per step). The per-track phases now draw (stream, track) items
+// from one list across all streams of the context, so every CU works whatever the split of tracks over streams.
+
+// ---- T0
+__global__ void MOT_LAUNCH_BOUNDS(256)
+track_prep_kernel(TrackBuffers tb) {
+  const int b = blockIdx.x, tid = threadIdx.x;
+  const TrackFrameArgs args = tb.args[b];
+  if (!args.run) return;
+  const MotTrackParams tp = tb.tp;
+  const int M = tb.m_dev ? min(tb.m_dev[b * kCountsStride + kCntBoxes], kMaxBoxesPerFrame) : args.m;
+  const float* __restrict__ boxes = tb.boxes + (long)b * tb.box_stride;
+  if (tb.boxes_sensor) {
+    // the tf step of the tracking node (OT/tracking/main.cpp:143-158): boxes arrive in the sensor frame, the tracker works in
+    // the global frame. tf is not part of the reference tree; a plain fp64 rigid transform rounded to fp32.
+    const EgoPose e = tb.ego[b];
+    const double c = cos(-e.yaw), s = sin(-e.yaw);
+    const float* __restrict__ src = tb.boxes_sensor + (long)b * kMaxBoxesPerFrame * 24;
+    float* __restrict__ dst = tb.boxes_out + (long)b * tb.box_stride;
+    for (int i = tid; i < M * 8; i += 256) {
+      const float* p = src + (long)i * 3;
+      float* q = dst + (long)i * 3;
+      const double dx = (double)p[0] - e.x, dy = (double)p[1] - e.y;
+      q[0] = (float)(c * dx - s * dy); q[1] = (float)(s * dx + c * dy); q[2] = p[2];
+    }
+    __syncthreads();
+  }
+  // trackPoints :713-736 — centre of every box
+  Vec2d* __restrict__ cp = tb.cp + (long)b * kMaxBoxesPerFrame;
+  for (int k = tid; k < M; k += 256) { double x, y; cp_from_bbox(boxes + (long)k * 24, &x, &y); cp[k].x = x; cp[k].y = y; }
+  if (args.first_frame) {  // :741-795 — seed exactly one track at a hard-coded position; nothing else happens in this frame
+    if (tid == 0) {
+      int n = 0;
+      if (M > tp.seed_box_index && tb.T >= 1) {
+        DevTrack* tracks = tb.tracks + (long)b * tb.T;
+        track_init(&tracks[0], tp.seed_px, tp.seed_py);
+        tb.pos[(long)b * tb.T].x = tp.seed_px; tb.pos[(long)b * tb.T].y = tp.seed_py;
+        mot_track o;
+        o.id = 0; o.track_manage = 1; o.is_static = 0; o.is_vis = 0;
+        o.px = (float)tp.seed_px; o.py = (float)tp.seed_py; o.pz = (float)(-1.73 / 2); o.lifetime = 0; o.v = 0; o.yaw = 0;
+        for (int i = 0; i < 24; i++) o.vis_box[i] = 0.f;
+        tb.out[(long)b * tb.T] = o;
+        tb.live[(long)b * 2 * tb.T] = 0;
+        n = 1;
+      }
+      tb.nt[b] = n; tb.nlive[b] = n;
+    }
+    return;
+  }
+  // work items of this stream: its live tracks (list left by the previous step's finish kernel), in any order
+  __shared__ int s_base;
+  const int nlive = tb.nlive[b];
+  if (tid == 0) s_base = nlive ? atomicAdd(tb.n_items, nlive) : 0;
+  __syncthreads();
+  TrackItem* __restrict__ items = tb.items + s_base;
+  for (int i = tid; i < nlive; i += 256) { TrackItem it; it.b = b; it.li = i; items[i] = it; }
+}
+
+// ---- T1: PA — prediction + gating of one live track by one wave
+__device__ void predict_item(const TrackBuffers& tb, WaveScratch* ws, int b, int li) {
+  const int lane = tlane();
+  const TrackFrameArgs args = tb.args[b];
+  const MotTrackParams& tp = tb.tp;
+  const int M = tb.m_dev ? min(tb.m_dev[b * kCountsStride + kCntBoxes], kMaxBoxesPerFrame) : args.m;
+  const int nW = (M + 63) >> 6;   // 64-box words of the gate bit-masks in use this frame (the rest is neither written nor read)
+  int* __restrict__ live = tb.live + (long)b * 2 * tb.T;
+  int* __restrict__ liveok = live + tb.T;
+  const int t = live[li];
+  DevTrack* u = tb.tracks + (long)b * tb.T + t;
+  unsigned long long* __restrict__ gate = tb.gate + ((long)b * tb.T + t) * kGateWords;
+  unsigned long long* __restrict__ prog = tb.prog + ((long)b * tb.T + t) * kGateWords;
+  const Vec2d* __restrict__ cp = tb.cp + (long)b * kMaxBoxesPerFrame;
+  const bool secondInit = u->track_num == 1;
+  if (lane == 0) u->is_vis = 0;   // isVisBB_ = false (:813); tracks that are dead already are cleared by the finish kernel
+  load_track(ws, u);
+  bool ok = true;
+  if (det5(ws->Pm) > 10 || ws->Pm[24] > 1000) ok = false;  // divergence guard :828-831
+  if (ok) {
+    process_imm_ukf(ws, args.dt);  // :840
+    store_models(ws, u);
+    int mx = find_max_model(ws->S);
+    double maxS[4];
+    for (int k = 0; k < 4; k++) maxS[k] = ws->S[mx][k] * 4;  // :844
+    double detS = det2(maxS);
+    if (detS != detS || detS > 10) ok = false;  // :848-851
+    if (ok) {
+      // measurementValidation :205-257 as a bit-mask over the boxes; second-init keeps the running minimum
+      double Si[4]; inv2(maxS, Si);
+      const double zx = ws->z[mx][0], zy = ws->z[mx][1];
+      double run_min = 999;  // smallestNIS
+      for (int w = 0; w < nW; w++) {
+        int k = w * 64 + lane;
+        bool g = false; double nis = 1e300;
+        if (k < M) {
+          const Vec2d c = cp[k];
+          double d0 = c.x - zx, d1 = c.y - zy;
+          double t0 = d0 * Si[0] + d1 * Si[2], t1 = d0 * Si[1] + d1 * Si[3];
+          nis = t0 * d0 + t1 * d1;
+          g = nis < tp.gamma_g;
+        }
+        unsigned long long gm = __ballot(g);
+        unsigned long long pm = 0ull;
+        if (secondInit && gm) {
+          // `nis < smallestNIS` evaluated box by box: a box is kept iff it beats every earlier gated box
+          double v = g ? nis : 1e300, pre = v;
+#pragma unroll
+          for (int d = 1; d < 64; d <<= 1) { double o = __shfl_up(pre, d, 64); if (lane >= d) pre = o < pre ? o : pre; }
+          double excl = __shfl_up(pre, 1, 64);
+          if (lane == 0) excl = 1e300;
+          excl = excl < run_min ? excl : run_min;
+          pm = __ballot(g && nis < excl);
+          double tile_min = __shfl(pre, 63, 64);
+          run_min = tile_min < run_min ? tile_min : run_min;
+        }
+        if (lane == 0) { gate[w] = gm; prog[w] = pm; }
+      }
+    }
+  }
+  if (lane == 0) {
+    liveok[li] = ok ? (secondInit ? 2 : 1) : 0;   // 2: the track is in its second initialisation (trackNum 1 at the start of the step)
+    if (!ok) u->track_num = 0;
+  }
+  MOT_WAVE_SYNC();
+}
+
+#ifndef MOT_TRACK_ITEM_WAVES
+#define MOT_TRACK_ITEM_WAVES 4
+#endif
+constexpr int kItemWaves = MOT_TRACK_ITEM_WAVES;     // waves (work items in flight) per workgroup of the two per-track kernels
+__global__ void MOT_LAUNCH_BOUNDS2(kItemWaves * 64, MOT_PREDICT_WAVES)
+track_predict_kernel(TrackBuffers tb) {
+  __shared__ WaveScratch s_ws[kItemWaves];
+  const int wave = threadIdx.x >> 6;
+  const int n = *tb.n_items;
+  for (int i = blockIdx.x * kItemWaves + wave; i < n; i += gridDim.x * kItemWaves) {
+    const TrackItem it = tb.items[i];
+    predict_item(tb, &s_ws[wave], it.b, it.li);
+  }
+}
+
+// ---- T2: PB (this track's share) + PC — association, state machine, PDA update of one live track by one wave
+__device__ void update_item(const TrackBuffers& tb, WaveScratch* ws, int b, int li) {
+  const int lane = tlane();
+  const TrackFrameArgs args = tb.args[b];
+  const MotTrackParams& tp = tb.tp;
+  const int M = tb.m_dev ? min(tb.m_dev[b * kCountsStride + kCntBoxes], kMaxBoxesPerFrame) : args.m;
+  const int nW = (M + 63) >> 6;
+  const int* __restrict__ live = tb.live + (long)b * 2 * tb.T;
+  const int* __restrict__ liveok = live + tb.T;
+  const int okflag = liveok[li];
+  if (!okflag) return;
+  const int t = live[li];
+  DevTrack* u = tb.tracks + (long)b * tb.T + t;
+  const unsigned long long* __restrict__ gate_b = tb.gate + (long)b * tb.T * kGateWords;
+  const unsigned long long* __restrict__ prog_b = tb.prog + (long)b * tb.T * kGateWords;
+  const unsigned long long* gt = gate_b + (long)t * kGateWords;
+  const unsigned long long* pt = prog_b + (long)t * kGateWords;
+  const float* __restrict__ boxes = tb.boxes + (long)b * tb.box_stride;
+  const Vec2d* __restrict__ cp = tb.cp + (long)b * kMaxBoxesPerFrame;
+  // ---- PB: matchingVec / lifetime_ bookkeeping (:232). The reference walks the tracks in index order and counts, per track,
+  // the gated boxes nobody claimed before. What the EARLIER live tracks of the stream claimed is the OR of
+  // their gate masks (second-initialisation tracks claim only their progressive minima): lanes over the earlier tracks.
+  {
+    int fresh = 0;
+    for (int w = 0; w < nW; w++) {
+      unsigned long long before = 0ull;
+      for (int j0 = 0; j0 < li; j0 += 64) {
+        const int lj = j0 + lane;
+        unsigned long long m = 0ull;
+        if (lj < li) {
+          const int f = liveok[lj];
+          if (f) { const int tj = live[lj]; m = f == 2 ? prog_b[(long)tj * kGateWords + w] : gate_b[(long)tj * kGateWords + w]; }
+        }
+        before |= wave_reduce_u64(m, OpOrU64());
+      }
+      fresh += __popcll(gt[w] & ~before);
+    }
+    if (lane == 0 && fresh) u->lifetime += fresh;
+  }
+  MOT_WAVE_SYNC();
+  load_track(ws, u);
+  int track_num = u->track_num;
+  const bool secondInit = okflag == 2;
+  int ngate = 0;
+  for (int w = 0; w < nW; w++) ngate += __popcll(gt[w]);
+  int nm = ngate;
+  int last_prog = -1;  // second init: the box that finally holds smallestNIS = the last progressive minimum
+  if (secondInit) {
+    for (int w = 0; w < nW; w++) if (pt[w]) last_prog = w * 64 + 63 - __clzll((long long)pt[w]);
+    nm = last_prog >= 0 ? 1 : 0;
+  }
+  // associateBB :416-463 + getNearestEuclidBBox :396-413 (int minDist, truncated on assignment)
+  if (!secondInit && ngate > 0 && track_num == 5 && u->lifetime > tp.life_time_thres) {
+    // sequential semantics: scan gated boxes in order, keep (minDist:int, minInd); reproduced by one lane
+    if (lane == 0) {
+      int minDist = 999, minBox = -1, first = -1;
+      double px = ws->xm[0], py = ws->xm[1];
+      for (int w = 0; w < nW; w++) {
+        unsigned long long g = gt[w];
+        while (g) {
+          int k = w * 64 + __ffsll(g) - 1;
+          g &= g - 1ull;
+          if (first < 0) first = k;
+          const Vec2d c = cp[k];
+          double dist = sqrt((px - c.x) * (px - c.x) + (py - c.y) * (py - c.y));
+          if (dist < minDist) { minDist = (int)dist; minBox = k; }
+        }
+      }
+      if (minBox < 0) minBox = first;  // minInd stays 0 = first gated box
+      if (minDist < tp.distance_thres) {
+        const float* bx = boxes + (long)minBox * 24;
+        for (int h = 0; h < 2; h++)
+          for (int q = 0; q < 4; q++) {
+            u->bbox[(h * 4 + q) * 3] = bx[3 * q];
+            u->bbox[(h * 4 + q) * 3 + 1] = bx[3 * q + 1];
+            u->bbox[(h * 4 + q) * 3 + 2] = (float)(h == 0 ? -1.73 : 0);
+          }
+        u->is_vis = 1; u->has_bbox = 1;
+      }
+    }
+  }
+  if (lane == 0) update_bb(tp, u);
+  MOT_WAVE_SYNC();
+  Vec2d* pos = tb.pos + (long)b * tb.T + t;
+  if (secondInit) {  // :882-921
+    if (lane == 0) {
+      if (nm == 0) u->track_num = 0;
+      else {
+        u->init_meas[0] = ws->xm[0]; u->init_meas[1] = ws->xm[1];
+        const Vec2d c = cp[last_prog];
+        double targetX = c.x, targetY = c.y;
+        double dX = targetX - ws->xm[0], dY = targetY - ws->xm[1];
+        double targetYaw = wrap_pi(atan2(dY, dX));
+        for (int a = 0; a < 4; a++) { u->x[a][0] = targetX; u->x[a][1] = targetY; u->x[a][2] = 2; u->x[a][3] = targetYaw; }
+        pos->x = targetX; pos->y = targetY;
+        u->track_num = track_num + 1;
+      }
+    }
+    MOT_WAVE_SYNC();
+    return;
+  }
+  // track management :924-944
+  if (nm > 0) {
+    if (track_num < 3) track_num++;
+    else if (track_num == 3) track_num = 5;
+    else if (track_num >= 5) track_num = 5;
+  } else {
+    if (track_num < 5) track_num = 0;
+    else if (track_num >= 5 && track_num < 10) track_num++;
+    else track_num = 0;  // `else if(trackNumVec_[i] = 10)` assigns, is true, then sets 0
+  }
+  if (lane == 0) u->track_num = track_num;
+  if (track_num == 0) { MOT_WAVE_SYNC(); return; }
+
+  // filterPDA :259-394 — lanes over the gated measurements
+  {
+    const double numMeas = nm;
+    const double bpda = 2 * numMeas * (1 - tp.p_d * tp.p_g) / (tp.gamma_g * tp.p_d);
+    double Si[3][4];
+    for (int m = 0; m < 3; m++) inv2(ws->S[m], Si[m]);
+    // lanes over the boxes (one 64-box tile at a time); e and the residuals of a lane's box are kept for the three sums
+    double eSum[3] = {0, 0, 0};
+    double ce[3] = {0, 0, 0};   // exp() of this lane's box in the first 64-box tile, reused by the two passes below (all tiles but the
+                                // first recompute it: more than 64 boxes in a frame is rare)
+    Vec2d c0; c0.x = 0; c0.y = 0;   // this lane's box centre in the first tile
+    if (lane < M) c0 = cp[lane];
+    for (int w = 0; w * 64 < M; w++) {
+      int k = w * 64 + lane;
+      bool g = (gt[w] >> lane) & 1ull;
+      Vec2d c = c0;
+      if (w > 0 && g) c = cp[k];
+#pragma unroll
+      for (int m = 0; m < 3; m++) {
+        double e = 0;
+        if (g) {
+          double d0 = c.x - ws->z[m][0], d1 = c.y - ws->z[m][1];
+          double h0 = -0.5 * d0, h1 = -0.5 * d1;
+          double t0 = h0 * Si[m][0] + h1 * Si[m][2], t1 = h0 * Si[m][1] + h1 * Si[m][3];
+          e = exp(t0 * d0 + t1 * d1);
+        }
+        if (w == 0) ce[m] = e;
+        eSum[m] += wave_sum_d(e);
+      }
+    }
+    double sx[3][2] = {{0, 0}, {0, 0}, {0, 0}};
+    double sp[3][4] = {{0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}};
+    for (int pass = 0; pass < 2; pass++) {  // pass 0: sigmaX, pass 1: sigmaP (needs the complete sigmaX)
+      for (int w = 0; w * 64 < M; w++) {
+        int k = w * 64 + lane;
+        bool g = (gt[w] >> lane) & 1ull;
+        Vec2d c = c0;
+        if (w > 0 && g) c = cp[k];
+#pragma unroll
+        for (int m = 0; m < 3; m++) {
+          double d[2] = {0, 0}, beta = 0;
+          if (g) {
+            d[0] = c.x - ws->z[m][0]; d[1] = c.y - ws->z[m][1];
+            double e = ce[m];
+            if (w > 0) {
+              double h0 = -0.5 * d[0], h1 = -0.5 * d[1];
+              double t0 = h0 * Si[m][0] + h1 * Si[m][2], t1 = h0 * Si[m][1] + h1 * Si[m][3];
+              e = exp(t0 * d[0] + t1 * d[1]);
+            }
+            beta = e / (bpda + eSum[m]);
+          }
+          if (pass == 0) { sx[m][0] += wave_sum_d(beta * d[0]); sx[m][1] += wave_sum_d(beta * d[1]); }
+          else
+            for (int r = 0; r < 2; r++) for (int c2 = 0; c2 < 2; c2++)
+              sp[m][r * 2 + c2] += wave_sum_d(g ? (beta * d[r]) * d[c2] - sx[m][r] * sx[m][c2] : 0.0);
+        }
+      }
+    }
+    // x += K*sigmaX ; P update (:341-367) — one lane per matrix entry
+    MOT_WAVE_SYNC();
+    if (lane < 15) {
+      int m = lane / 5, r = lane % 5;
+      double v = ws->x[m][r] + (ws->K[m][r * 2] * sx[m][0] + ws->K[m][r * 2 + 1] * sx[m][1]);
+      ws->xo[m][r] = r == 3 ? wrap_pi(v) : v;
+    }
+    for (int e = lane; e < 75; e += 64) {
+      int m = e / 25, r = (e % 25) / 5, c = e % 5;
+      const double* K = ws->K[m];
+      double ks0 = K[r * 2] * ws->S[m][0] + K[r * 2 + 1] * ws->S[m][2], ks1 = K[r * 2] * ws->S[m][1] + K[r * 2 + 1] * ws->S[m][3];
+      double kp0 = K[r * 2] * sp[m][0] + K[r * 2 + 1] * sp[m][2], kp1 = K[r * 2] * sp[m][1] + K[r * 2 + 1] * sp[m][3];
+      double kskt = ks0 * K[c * 2] + ks1 * K[c * 2 + 1];
+      double kpk = kp0 * K[c * 2] + kp1 * K[c * 2 + 1];
+      double P = ws->P[m][r * 5 + c];
+      double betaZero = bpda / (bpda + eSum[m]);
+      ws->Po[m][r * 5 + c] = nm != 0 ? betaZero * P + (1 - betaZero) * (P - kskt) + kpk : P - kskt;
+    }
+    MOT_WAVE_SYNC();
+    // likelihoods :369-393, UpdateModeProb ukf.cpp:384-397, merge :419-437
+    int mx = find_max_model(ws->S);
+    double Vk = PI_D * sqrt(tp.gamma_g * det2(ws->S[mx]));
+    double lambda[3];
+    const double pw = pow(Vk, numMeas), pw1 = nm != 0 ? pow(Vk, 1 - numMeas) : 0.0;   // the same two powers in all three models
+#pragma unroll
+    for (int m = 0; m < 3; m++) {
+      if (nm != 0) lambda[m] = (1 - tp.p_g * tp.p_d) / pw + tp.p_d * pw1 * eSum[m] / (numMeas * sqrt(2 * PI_D * det2(ws->S[m])));
+      else lambda[m] = (1 - tp.p_g * tp.p_d) / pw;
+    }
+    double mode[3];
+    double sum = lambda[0] * ws->mode[0] + lambda[1] * ws->mode[1] + lambda[2] * ws->mode[2];
+    for (int m = 0; m < 3; m++) { mode[m] = (lambda[m] * ws->mode[m]) / sum; if (fabs(mode[m]) < 0.0001) mode[m] = 0.0001; }
+    double xmv[5];
+    for (int r = 0; r < 5; r++) xmv[r] = mode[0] * ws->xo[0][r] + mode[1] * ws->xo[1][r] + mode[2] * ws->xo[2][r];
+    xmv[3] = wrap_pi(xmv[3]);
+    double yaw;  // UpdateYawWithHighProb :399-417
+    if (mode[0] > mode[1]) yaw = (mode[0] > mode[2]) ? ws->xo[0][3] : ws->xo[2][3];
+    else yaw = (mode[1] > mode[2]) ? ws->xo[1][3] : ws->xo[2][3];
+    xmv[3] = yaw;
+    if (lane < 25) {
+      int r = lane / 5, c = lane % 5;
+      double acc = 0;
+      for (int m = 0; m < 3; m++) acc = acc + mode[m] * (ws->Po[m][r * 5 + c] + (ws->xo[m][r] - xmv[r]) * (ws->xo[m][c] - xmv[c]));
+      u->P[0][r * 5 + c] = acc;
+    }
+    if (lane < 5) u->x[0][lane] = xmv[lane];
+    if (lane == 0) { pos->x = xmv[0]; pos->y = xmv[1]; }
+    if (lane < 3) u->mode[lane] = mode[lane];
+    for (int e = lane; e < 15; e += 64) u->x[1 + e / 5][e % 5] = ws->xo[e / 5][e % 5];
+    for (int e = lane; e < 75; e += 64) u->P[1 + e / 25][e % 25] = ws->Po[e / 25][e % 25];
+  }
+  MOT_WAVE_SYNC();
+}
+
+__global__ void MOT_LAUNCH_BOUNDS2(kItemWaves * 64, MOT_UPDATE_WAVES)
+track_update_kernel(TrackBuffers tb) {
+  __shared__ WaveScratch s_ws[kItemWaves];
+  const int wave = threadIdx.x >> 6;
+  const int n = *tb.n_items;
+  for (int i = blockIdx.x * kItemWaves + wave; i < n; i += gridDim.x * kItemWaves) {
+    const TrackItem it = tb.items[i];
+    update_item(tb, &s_ws[wave], it.b, it.li);
+  }
+}
+
+// ---- T3: PD merge, PE birth, PF outputs, the live list of the next step — one workgroup per stream
 __global__ void MOT_LAUNCH_BOUNDS(kTrackBlock)
-track_step_kernel(TrackBuffers tb) {
-  __shared__ WaveScratch s_ws[kTrackWaves];
-  __shared__ double s_cpx[kMaxBoxesPerFrame], s_cpy[kMaxBoxesPerFrame];  // box centres (trackPoints[k][0..1])
+track_finish_kernel(TrackBuffers tb) {
   __shared__ unsigned long long s_matched[kGateWords];
   __shared__ int s_wcount[kTrackWaves];
   __shared__ int s_nlive, s_born;
   const int b = blockIdx.x;
-  const TrackFrameArgs args = tb.args[b];
-  if (!args.run) return;
-  const MotTrackParams tp = tb.tp;
   const int tid = threadIdx.x, lane = tlane(), wave = tid >> 6;
+  if (b == 0 && tid == 0) *tb.n_items = 0;   // every per-track wave of this step has finished: re-arm the work list
+  const TrackFrameArgs args = tb.args[b];
+  if (!args.run || args.first_frame) return;
   const int M = tb.m_dev ? min(tb.m_dev[b * kCountsStride + kCntBoxes], kMaxBoxesPerFrame) : args.m;
+  const int nW = (M + 63) >> 6;
   DevTrack* __restrict__ tracks = tb.tracks + (long)b * tb.T;
-  const float* __restrict__ boxes = tb.boxes + (long)b * tb.box_stride;
+  Vec2d* __restrict__ pos = tb.pos + (long)b * tb.T;
   unsigned long long* __restrict__ gate = tb.gate + (long)b * tb.T * kGateWords;
   unsigned long long* __restrict__ prog = tb.prog + (long)b * tb.T * kGateWords;
   int* __restrict__ live = tb.live + (long)b * 2 * tb.T;
   int* __restrict__ liveok = live + tb.T;
   mot_track* __restrict__ out = tb.out + (long)b * tb.T;
-  WaveScratch* ws = &s_ws[wave];
+  const Vec2d* __restrict__ cp = tb.cp + (long)b * kMaxBoxesPerFrame;
   const int nt0 = tb.nt[b];
-  const int nW = (M + 63) >> 6;   // 64-box words of the gate bit-masks in use this frame (the rest is neither written nor read)
+  const int nlive = tb.nlive[b];
 
-  // trackPoints :713-736 — centre of every box
-  for (int k = tid; k < M; k += kTrackBlock) cp_from_bbox(boxes + (long)k * 24, &s_cpx[k], &s_cpy[k]);
-
-  if (args.first_frame) {  // :741-795 — seed exactly one track at a hard-coded position
-    if (tid == 0) {
-      int n = 0;
-      if (M > tp.seed_box_index && tb.T >= 1) {
-        track_init(&tracks[0], tp.seed_px, tp.seed_py);
-        mot_track o;
-        o.id = 0; o.track_manage = 1; o.is_static = 0; o.is_vis = 0;
-        o.px = (float)tp.seed_px; o.py = (float)tp.seed_py; o.pz = (float)(-1.73 / 2); o.lifetime = 0; o.v = 0; o.yaw = 0;
-        for (int i = 0; i < 24; i++) o.vis_box[i] = 0.f;
-        out[0] = o;
-        n = 1;
-      }
-      tb.nt[b] = n;
-    }
-    return;
-  }
-
-#define MOT_PHASE(k) if (tid == 0 && tb.phase_clock) tb.phase_clock[b * 16 + (k)] = clock64()
-  MOT_PHASE(0);
-  // ---- P0: isVisBB_ = false for every track (:813); compact the live ones in index order
-  if (tid == 0) { s_nlive = 0; s_born = 0; }
-  for (int w = tid; w < kGateWords; w += kTrackBlock) s_matched[w] = 0ull;
-  __syncthreads();
-  for (int base = 0; base < nt0; base += kTrackBlock) {
-    int t = base + tid;
-    bool alive = false;
-    if (t < nt0) { tracks[t].is_vis = 0; alive = tracks[t].track_num != 0; }
-    unsigned long long bm = __ballot(alive);
-    if (lane == 0) s_wcount[wave] = __popcll(bm);
-    __syncthreads();
-    int off = s_nlive;
-    for (int w = 0; w < wave; w++) off += s_wcount[w];
-    if (alive) live[off + __popcll(bm & ((1ull << lane) - 1ull))] = t;
-    __syncthreads();
-    if (tid == 0) { int s = 0; for (int w = 0; w < kTrackWaves; w++) s += s_wcount[w]; s_nlive += s; }
-    __syncthreads();
-  }
-  const int nlive = s_nlive;
-  MOT_PHASE(1);
-
-  // ---- PA: prediction + gating, one wave per live track
-  for (int li = wave; li < nlive; li += kTrackWaves) {
-    const int t = live[li];
-    DevTrack* u = &tracks[t];
-#ifdef MOT_DBG_TRACK_SUB
-#define MOT_SUB(k) if (tid == 0 && tb.phase_clock) tb.phase_clock[b * 16 + (k)] = clock64()
-#else
-#define MOT_SUB(k)
-#endif
-    load_track(ws, u);
-    bool ok = true;
-    if (det5(ws->Pm) > 10 || ws->Pm[24] > 1000) ok = false;  // divergence guard :828-831
-    if (ok) {
-#ifdef MOT_DBG_TRACK_UKF
-      process_imm_ukf(ws, args.dt, tb.phase_clock ? tb.phase_clock + b * 16 : nullptr);
-#else
-      process_imm_ukf(ws, args.dt);  // :840
-#endif
-        store_models(ws, u);
-        int mx = find_max_model(ws->S);
-      double maxS[4];
-      for (int k = 0; k < 4; k++) maxS[k] = ws->S[mx][k] * 4;  // :844
-      double detS = det2(maxS);
-      if (detS != detS || detS > 10) ok = false;  // :848-851
-      if (ok) {
-        // measurementValidation :205-257 as a bit-mask over the boxes; second-init keeps the running minimum
-        const bool secondInit = u->track_num == 1;
-        double Si[4]; inv2(maxS, Si);
-        const double zx = ws->z[mx][0], zy = ws->z[mx][1];
-        double run_min = 999;  // smallestNIS
-        for (int w = 0; w < nW; w++) {
-          int k = w * 64 + lane;
-          bool g = false; double nis = 1e300;
-          if (w * 64 < M) {
-            if (k < M) {
-              double d0 = s_cpx[k] - zx, d1 = s_cpy[k] - zy;
-              double t0 = d0 * Si[0] + d1 * Si[2], t1 = d0 * Si[1] + d1 * Si[3];
-              nis = t0 * d0 + t1 * d1;
-              g = nis < tp.gamma_g;
-            }
-          }
-          unsigned long long gm = (w * 64 < M) ? __ballot(g) : 0ull;
-          unsigned long long pm = 0ull;
-          if (secondInit && gm) {
-            // `nis < smallestNIS` evaluated box by box: a box is kept iff it beats every earlier gated box
-            double v = g ? nis : 1e300, pre = v;
-#pragma unroll
-            for (int d = 1; d < 64; d <<= 1) { double o = __shfl_up(pre, d, 64); if (lane >= d) pre = o < pre ? o : pre; }
-            double excl = __shfl_up(pre, 1, 64);
-            if (lane == 0) excl = 1e300;
-            excl = excl < run_min ? excl : run_min;
-            pm = __ballot(g && nis < excl);
-            double tile_min = __shfl(pre, 63, 64);
-            run_min = tile_min < run_min ? tile_min : run_min;
-          }
-          if (lane == 0) { gate[(long)t * kGateWords + w] = gm; prog[(long)t * kGateWords + w] = pm; }
-        }
-      }
-    }
-    if (lane == 0) {
-      liveok[li] = ok ? 1 : 0;
-      if (!ok) u->track_num = 0;
-    }
-    MOT_WAVE_SYNC();
-  }
-  __syncthreads();
-  MOT_PHASE(2);
-
-  // ---- PB: matchingVec / lifetime_ bookkeeping in track order (:232)
+  // isVisBB_ = false for every track (:813): the live ones were cleared by their prediction wave; a track that is dead has
+  // either been cleared there too, or died in an earlier step with the flag of that step still set
+  for (int t = tid; t < nt0; t += kTrackBlock) if (tracks[t].track_num == 0) tracks[t].is_vis = 0;
+  // matchingVec after the whole track loop: everything a live track claimed (see update_item)
   if (wave == 0) {
-    unsigned long long matched = 0ull;  // lane w holds word w
-    for (int li = 0; li < nlive; li++) {
-      if (!liveok[li]) continue;
-      const int t = live[li];
-      unsigned long long g = lane < nW ? gate[(long)t * kGateWords + lane] : 0ull;
-      unsigned long long pg = lane < nW ? prog[(long)t * kGateWords + lane] : 0ull;
-      int fresh = __popcll(g & ~matched);
-#pragma unroll
-      for (int m = 32; m >= 1; m >>= 1) fresh += __shfl_xor(fresh, m, 64);
-      const bool secondInit = tracks[t].track_num == 1;
-      if (lane == 0 && fresh) tracks[t].lifetime += fresh;
-      matched |= secondInit ? pg : g;
+    for (int w = 0; w < kGateWords; w++) {
+      unsigned long long m = 0ull;
+      if (w < nW)
+        for (int lj = lane; lj < nlive; lj += 64) {
+          const int f = liveok[lj];
+          if (f) { const int tj = live[lj]; m |= f == 2 ? prog[(long)tj * kGateWords + w] : gate[(long)tj * kGateWords + w]; }
+        }
+      m = wave_reduce_u64(m, OpOrU64());
+      if (lane == 0) s_matched[w] = m;
     }
-    if (lane < kGateWords) s_matched[lane] = matched;
   }
   __syncthreads();
-  MOT_PHASE(3);
-
-  // ---- PC: association, state machine, PDA update
-  for (int li = wave; li < nlive; li += kTrackWaves) {
-    if (!liveok[li]) continue;
-    const int t = live[li];
-    DevTrack* u = &tracks[t];
-    load_track(ws, u);
-    MOT_SUB(11);
-    const unsigned long long* gt = gate + (long)t * kGateWords;
-    const unsigned long long* pt = prog + (long)t * kGateWords;
-    int track_num = u->track_num;
-    const bool secondInit = track_num == 1;
-    int ngate = 0;
-    for (int w = 0; w < nW; w++) ngate += __popcll(gt[w]);
-    int nm = ngate;
-    int last_prog = -1;  // second init: the box that finally holds smallestNIS = the last progressive minimum
-    if (secondInit) {
-      for (int w = 0; w < nW; w++) if (pt[w]) last_prog = w * 64 + 63 - __clzll((long long)pt[w]);
-      nm = last_prog >= 0 ? 1 : 0;
-    }
-    MOT_SUB(12);
-    // associateBB :416-463 + getNearestEuclidBBox :396-413 (int minDist, truncated on assignment)
-    if (!secondInit && ngate > 0 && track_num == 5 && u->lifetime > tp.life_time_thres) {
-      // sequential semantics: scan gated boxes in order, keep (minDist:int, minInd); reproduced by one lane
-      if (lane == 0) {
-        int minDist = 999, minBox = -1, first = -1;
-        double px = ws->xm[0], py = ws->xm[1];
-        for (int w = 0; w < nW; w++) {
-          unsigned long long g = gt[w];
-          while (g) {
-            int k = w * 64 + __ffsll(g) - 1;
-            g &= g - 1ull;
-            if (first < 0) first = k;
-            double dist = sqrt((px - s_cpx[k]) * (px - s_cpx[k]) + (py - s_cpy[k]) * (py - s_cpy[k]));
-            if (dist < minDist) { minDist = (int)dist; minBox = k; }
-          }
-        }
-        if (minBox < 0) minBox = first;  // minInd stays 0 = first gated box
-        if (minDist < tp.distance_thres) {
-          const float* bx = boxes + (long)minBox * 24;
-          for (int h = 0; h < 2; h++)
-            for (int q = 0; q < 4; q++) {
-              u->bbox[(h * 4 + q) * 3] = bx[3 * q];
-              u->bbox[(h * 4 + q) * 3 + 1] = bx[3 * q + 1];
-              u->bbox[(h * 4 + q) * 3 + 2] = (float)(h == 0 ? -1.73 : 0);
-            }
-          u->is_vis = 1; u->has_bbox = 1;
-        }
-      }
-    }
-    MOT_SUB(13);
-    if (lane == 0) update_bb(tp, u);
-    MOT_WAVE_SYNC();
-    MOT_SUB(14);
-    if (secondInit) {  // :882-921
-      if (lane == 0) {
-        if (nm == 0) u->track_num = 0;
-        else {
-          u->init_meas[0] = ws->xm[0]; u->init_meas[1] = ws->xm[1];
-          double targetX = s_cpx[last_prog], targetY = s_cpy[last_prog];
-          double dX = targetX - ws->xm[0], dY = targetY - ws->xm[1];
-          double targetYaw = wrap_pi(atan2(dY, dX));
-          for (int a = 0; a < 4; a++) { u->x[a][0] = targetX; u->x[a][1] = targetY; u->x[a][2] = 2; u->x[a][3] = targetYaw; }
-          u->track_num = track_num + 1;
-        }
-      }
-      MOT_WAVE_SYNC();
-      continue;
-    }
-    // track management :924-944
-    if (nm > 0) {
-      if (track_num < 3) track_num++;
-      else if (track_num == 3) track_num = 5;
-      else if (track_num >= 5) track_num = 5;
-    } else {
-      if (track_num < 5) track_num = 0;
-      else if (track_num >= 5 && track_num < 10) track_num++;
-      else track_num = 0;  // `else if(trackNumVec_[i] = 10)` assigns, is true, then sets 0
-    }
-    if (lane == 0) u->track_num = track_num;
-    if (track_num == 0) { MOT_WAVE_SYNC(); continue; }
-
-    MOT_SUB(15);
-    // filterPDA :259-394 — lanes over the gated measurements
-    {
-      const double numMeas = nm;
-      const double bpda = 2 * numMeas * (1 - tp.p_d * tp.p_g) / (tp.gamma_g * tp.p_d);
-      double Si[3][4];
-      for (int m = 0; m < 3; m++) inv2(ws->S[m], Si[m]);
-      // lanes over the boxes (one 64-box tile at a time); e and the residuals of a lane's box are kept for the three sums
-      double eSum[3] = {0, 0, 0};
-      double ce[3] = {0, 0, 0};   // exp() of this lane's box in the first 64-box tile, reused by the two passes below (all tiles but the
-                                  // first recompute it: more than 64 boxes in a frame is rare)
-      for (int w = 0; w * 64 < M; w++) {
-        int k = w * 64 + lane;
-        bool g = (gt[w] >> lane) & 1ull;
-#pragma unroll
-        for (int m = 0; m < 3; m++) {
-          double e = 0;
-          if (g) {
-            double d0 = s_cpx[k] - ws->z[m][0], d1 = s_cpy[k] - ws->z[m][1];
-            double h0 = -0.5 * d0, h1 = -0.5 * d1;
-            double t0 = h0 * Si[m][0] + h1 * Si[m][2], t1 = h0 * Si[m][1] + h1 * Si[m][3];
-            e = exp(t0 * d0 + t1 * d1);
-          }
-          if (w == 0) ce[m] = e;
-          eSum[m] += wave_sum_d(e);
-        }
-      }
-      double sx[3][2] = {{0, 0}, {0, 0}, {0, 0}};
-      double sp[3][4] = {{0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}};
-      for (int pass = 0; pass < 2; pass++) {  // pass 0: sigmaX, pass 1: sigmaP (needs the complete sigmaX)
-        for (int w = 0; w * 64 < M; w++) {
-          int k = w * 64 + lane;
-          bool g = (gt[w] >> lane) & 1ull;
-#pragma unroll
-          for (int m = 0; m < 3; m++) {
-            double d[2] = {0, 0}, beta = 0;
-            if (g) {
-              d[0] = s_cpx[k] - ws->z[m][0]; d[1] = s_cpy[k] - ws->z[m][1];
-              double e = ce[m];
-              if (w > 0) {
-                double h0 = -0.5 * d[0], h1 = -0.5 * d[1];
-                double t0 = h0 * Si[m][0] + h1 * Si[m][2], t1 = h0 * Si[m][1] + h1 * Si[m][3];
-                e = exp(t0 * d[0] + t1 * d[1]);
-              }
-              beta = e / (bpda + eSum[m]);
-            }
-            if (pass == 0) { sx[m][0] += wave_sum_d(beta * d[0]); sx[m][1] += wave_sum_d(beta * d[1]); }
-            else
-              for (int r = 0; r < 2; r++) for (int c = 0; c < 2; c++)
-                sp[m][r * 2 + c] += wave_sum_d(g ? (beta * d[r]) * d[c] - sx[m][r] * sx[m][c] : 0.0);
-          }
-        }
-      }
-      // x += K*sigmaX ; P update (:341-367) — one lane per matrix entry
-      MOT_WAVE_SYNC();
-      if (lane < 15) {
-        int m = lane / 5, r = lane % 5;
-        double v = ws->x[m][r] + (ws->K[m][r * 2] * sx[m][0] + ws->K[m][r * 2 + 1] * sx[m][1]);
-        ws->xo[m][r] = r == 3 ? wrap_pi(v) : v;
-      }
-      for (int e = lane; e < 75; e += 64) {
-        int m = e / 25, r = (e % 25) / 5, c = e % 5;
-        const double* K = ws->K[m];
-        double ks0 = K[r * 2] * ws->S[m][0] + K[r * 2 + 1] * ws->S[m][2], ks1 = K[r * 2] * ws->S[m][1] + K[r * 2 + 1] * ws->S[m][3];
-        double kp0 = K[r * 2] * sp[m][0] + K[r * 2 + 1] * sp[m][2], kp1 = K[r * 2] * sp[m][1] + K[r * 2 + 1] * sp[m][3];
-        double kskt = ks0 * K[c * 2] + ks1 * K[c * 2 + 1];
-        double kpk = kp0 * K[c * 2] + kp1 * K[c * 2 + 1];
-        double P = ws->P[m][r * 5 + c];
-        double betaZero = bpda / (bpda + eSum[m]);
-        ws->Po[m][r * 5 + c] = nm != 0 ? betaZero * P + (1 - betaZero) * (P - kskt) + kpk : P - kskt;
-      }
-      MOT_WAVE_SYNC();
-        // likelihoods :369-393, UpdateModeProb ukf.cpp:384-397, merge :419-437
-      int mx = find_max_model(ws->S);
-      double Vk = PI_D * sqrt(tp.gamma_g * det2(ws->S[mx]));
-      double lambda[3];
-      const double pw = pow(Vk, numMeas), pw1 = nm != 0 ? pow(Vk, 1 - numMeas) : 0.0;   // the same two powers in all three models
-#pragma unroll
-      for (int m = 0; m < 3; m++) {
-        if (nm != 0) lambda[m] = (1 - tp.p_g * tp.p_d) / pw + tp.p_d * pw1 * eSum[m] / (numMeas * sqrt(2 * PI_D * det2(ws->S[m])));
-        else lambda[m] = (1 - tp.p_g * tp.p_d) / pw;
-      }
-        double mode[3];
-      double sum = lambda[0] * ws->mode[0] + lambda[1] * ws->mode[1] + lambda[2] * ws->mode[2];
-      for (int m = 0; m < 3; m++) { mode[m] = (lambda[m] * ws->mode[m]) / sum; if (fabs(mode[m]) < 0.0001) mode[m] = 0.0001; }
-      double xmv[5];
-      for (int r = 0; r < 5; r++) xmv[r] = mode[0] * ws->xo[0][r] + mode[1] * ws->xo[1][r] + mode[2] * ws->xo[2][r];
-      xmv[3] = wrap_pi(xmv[3]);
-      double yaw;  // UpdateYawWithHighProb :399-417
-      if (mode[0] > mode[1]) yaw = (mode[0] > mode[2]) ? ws->xo[0][3] : ws->xo[2][3];
-      else yaw = (mode[1] > mode[2]) ? ws->xo[1][3] : ws->xo[2][3];
-      xmv[3] = yaw;
-      if (lane < 25) {
-        int r = lane / 5, c = lane % 5;
-        double acc = 0;
-        for (int m = 0; m < 3; m++) acc = acc + mode[m] * (ws->Po[m][r * 5 + c] + (ws->xo[m][r] - xmv[r]) * (ws->xo[m][c] - xmv[c]));
-        u->P[0][r * 5 + c] = acc;
-      }
-      if (lane < 5) u->x[0][lane] = xmv[lane];
-      if (lane < 3) u->mode[lane] = mode[lane];
-      for (int e = lane; e < 15; e += 64) u->x[1 + e / 5][e % 5] = ws->xo[e / 5][e % 5];
-      for (int e = lane; e < 75; e += 64) u->P[1 + e / 25][e % 25] = ws->Po[e / 25][e % 25];
-    }
-    MOT_WAVE_SYNC();
-  }
-  __syncthreads();
-  MOT_PHASE(4);
 
   // ---- PD: mergeOverSegmentation :666-700. The reference runs `for i { for j { if inside(j, box_i) {trackNum[i]=5; trackNum[j]=0;} } }`
-  // over ALL tracks; the value a track ends with is decided by the last (i,j) pair that writes it.
+  // over ALL tracks; the value a track ends with is decided by the last (i,j) pair that writes it. Only tracks that were live
+  // at the start of the step can carry a visible box (i); j runs over every track ever created (their merged positions).
   for (int t = tid; t < nt0; t += kTrackBlock) { gate[(long)t * kGateWords] = 0ull; prog[(long)t * kGateWords] = 0ull; }  // reuse: [t] -> has_a / max_b+1
   __syncthreads();
-  for (int i = wave; i < nt0; i += kTrackWaves) {
+  for (int li = wave; li < nlive; li += kTrackWaves) {
+    const int i = live[li];
     const DevTrack* a = &tracks[i];
     if (!a->is_vis) continue;
     const double v1x = a->bbox[0], v1y = a->bbox[1], v2x = a->bbox[3], v2y = a->bbox[4], v3x = a->bbox[6], v3y = a->bbox[7], v4x = a->bbox[9], v4y = a->bbox[10];
@@ -749,7 +843,8 @@ track_step_kernel(TrackBuffers tb) {
     bool any = false;
     for (int j = lane; j < nt0; j += 64) {
       if (j == i) continue;
-      double px = tracks[j].x[0][0], py = tracks[j].x[0][1];
+      const Vec2d q = pos[j];
+      const double px = q.x, py = q.y;
       double c1 = ICOEF(v1x, v1y, v2x, v2y, px, py, cp1x, cp1y), c2 = ICOEF(v1x, v1y, v3x, v3y, px, py, cp1x, cp1y),
              c3 = ICOEF(v3x, v3y, v2x, v2y, px, py, cp1x, cp1y), c4 = ICOEF(v1x, v1y, v4x, v4y, px, py, cp2x, cp2y),
              c5 = ICOEF(v1x, v1y, v3x, v3y, px, py, cp2x, cp2y), c6 = ICOEF(v3x, v3y, v4x, v4y, px, py, cp2x, cp2y);
@@ -768,8 +863,8 @@ track_step_kernel(TrackBuffers tb) {
     if (bmax >= 0 && (!has_a || bmax > t)) tracks[t].track_num = 0;
     else if (has_a) tracks[t].track_num = 5;
   }
+  if (tid == 0) s_born = 0;
   __syncthreads();
-  MOT_PHASE(5);
 
   // ---- PE: birth :972-989 — one new track per unclaimed box, in box order
   if (wave == 0) {
@@ -780,7 +875,7 @@ track_step_kernel(TrackBuffers tb) {
       unsigned long long um = __ballot(un);
       if (un) {
         int idx = nt0 + born + __popcll(um & ((1ull << lane) - 1ull));
-        if (idx < tb.T) track_init(&tracks[idx], s_cpx[k], s_cpy[k]);
+        if (idx < tb.T) { const Vec2d c = cp[k]; track_init(&tracks[idx], c.x, c.y); pos[idx] = c; }
       }
       born += __popcll(um);
     }
@@ -790,48 +885,41 @@ track_step_kernel(TrackBuffers tb) {
       tb.nt[b] = n; s_born = n;
     }
   }
+  if (tid == 0) s_nlive = 0;
   __syncthreads();
   const int nt1 = s_born;
-  MOT_PHASE(6);
 
-  // ---- PF: outputs + static classification :995-1081
-  for (int t = tid; t < nt1; t += kTrackBlock) {
-    DevTrack* u = &tracks[t];
-    double tx = u->x[0][0], ty = u->x[0][1], mx = u->init_meas[0], my = u->init_meas[1];
-    u->dist_from_init = sqrt((tx - mx) * (tx - mx) + (ty - my) * (ty - my));
-    if (!u->is_static && u->track_num == 5 && u->lifetime > 8) {
-      if (u->dist_from_init < 3.0 && (u->mode[2] > u->mode[0] || u->mode[2] > u->mode[1])) u->is_static = 1;
+  // ---- PF: outputs + static classification :995-1081; the tracks that are alive now, in index order, are the next step's work
+  for (int base = 0; base < nt1; base += kTrackBlock) {
+    const int t = base + tid;
+    bool alive = false;
+    if (t < nt1) {
+      DevTrack* u = &tracks[t];
+      double tx = u->x[0][0], ty = u->x[0][1], mx = u->init_meas[0], my = u->init_meas[1];
+      u->dist_from_init = sqrt((tx - mx) * (tx - mx) + (ty - my) * (ty - my));
+      if (!u->is_static && u->track_num == 5 && u->lifetime > 8) {
+        if (u->dist_from_init < 3.0 && (u->mode[2] > u->mode[0] || u->mode[2] > u->mode[1])) u->is_static = 1;
+      }
+      mot_track o;
+      o.id = t; o.track_manage = u->track_num; o.is_static = u->is_static; o.is_vis = u->is_vis;
+      o.px = (float)tx; o.py = (float)ty; o.pz = (float)(-1.73 / 2); o.lifetime = u->lifetime;
+      o.v = u->x[0][2];
+      o.yaw = wrap_pi(u->x[0][3] + args.ego_yaw);
+      for (int i = 0; i < 24; i++) o.vis_box[i] = u->is_vis ? u->bbox[i] : 0.f;
+      out[t] = o;
+      alive = u->track_num != 0;
     }
-    mot_track o;
-    o.id = t; o.track_manage = u->track_num; o.is_static = u->is_static; o.is_vis = u->is_vis;
-    o.px = (float)tx; o.py = (float)ty; o.pz = (float)(-1.73 / 2); o.lifetime = u->lifetime;
-    o.v = u->x[0][2];
-    o.yaw = wrap_pi(u->x[0][3] + args.ego_yaw);
-    for (int i = 0; i < 24; i++) o.vis_box[i] = u->is_vis ? u->bbox[i] : 0.f;
-    out[t] = o;
+    unsigned long long bm = __ballot(alive);
+    if (lane == 0) s_wcount[wave] = __popcll(bm);
+    __syncthreads();
+    int off = s_nlive;
+    for (int w = 0; w < wave; w++) off += s_wcount[w];
+    if (alive) live[off + __popcll(bm & ((1ull << lane) - 1ull))] = t;
+    __syncthreads();
+    if (tid == 0) { int s = 0; for (int w = 0; w < kTrackWaves; w++) s += s_wcount[w]; s_nlive += s; }
+    __syncthreads();
   }
-  __syncthreads();
-  MOT_PHASE(7);
-  if (tid == 0 && tb.phase_clock) { tb.phase_clock[b * 16 + 8] = nlive; tb.phase_clock[b * 16 + 9] = nt1; tb.phase_clock[b * 16 + 10] = M; }
-#undef MOT_PHASE
-}
-
-// the tf step of the tracking node (OT/tracking/main.cpp:143-158): boxes arrive in the sensor frame, the tracker
-// works in the global frame. tf is not part of the reference tree; a plain fp64 rigid transform rounded to fp32.
-__global__ void boxes_to_global_kernel(const float* src, const int* counts, const EgoPose* ego, float* dst) {
-  const int b = blockIdx.y;
-  const int nb = min(counts[b * kCountsStride + kCntBoxes], kMaxBoxesPerFrame);
-  const EgoPose e = ego[b];
-  const double c = cos(-e.yaw), s = sin(-e.yaw);
-  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < nb * 8; i += gridDim.x * blockDim.x) {
-    const float* p = src + ((long)b * kMaxBoxesPerFrame * 8 + i) * 3;
-    float* q = dst + ((long)b * kMaxBoxesPerFrame * 8 + i) * 3;
-    double dx = (double)p[0] - e.x, dy = (double)p[1] - e.y;
-    q[0] = (float)(c * dx - s * dy); q[1] = (float)(s * dx + c * dy); q[2] = p[2];
-  }
-}
-void mot_launch_boxes_to_global(const float* boxes_sensor, const int* counts, const EgoPose* ego, float* boxes_global, int batch, hipStream_t stream) {
-  hipLaunchKernelGGL(boxes_to_global_kernel, dim3(4, batch), dim3(256), 0, stream, boxes_sensor, counts, ego, boxes_global);
+  if (tid == 0) tb.nlive[b] = s_nlive;
 }
 
 // live tracks of a stream, in id order, into the caller's fixed-size record block
@@ -864,5 +952,14 @@ void mot_launch_export_tracks(const TrackBuffers& t, int batch, mot_track* dst, 
 }
 
 void mot_launch_track(const TrackBuffers& t, int batch, hipStream_t stream) {
-  hipLaunchKernelGGL(track_step_kernel, dim3(batch), dim3(kTrackBlock), 0, stream, t);
+#ifdef MOT_HIPEMU
+  const int item_groups = 2;   // the per-track kernels loop over the work list: any grid size gives the same result
+#else
+  int item_groups = batch * 16;   // 4 waves each: a round covers 64 live tracks per stream; the chip holds ~512 such workgroups
+  item_groups = item_groups < 16 ? 16 : (item_groups > 1024 ? 1024 : item_groups);
+#endif
+  hipLaunchKernelGGL(track_prep_kernel, dim3(batch), dim3(256), 0, stream, t);
+  hipLaunchKernelGGL(track_predict_kernel, dim3(item_groups), dim3(kItemWaves * 64), 0, stream, t);
+  hipLaunchKernelGGL(track_update_kernel, dim3(item_groups), dim3(kItemWaves * 64), 0, stream, t);
+  hipLaunchKernelGGL(track_finish_kernel, dim3(batch), dim3(kTrackBlock), 0, stream, t);
 }

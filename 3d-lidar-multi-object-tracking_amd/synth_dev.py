@@ -44,7 +44,7 @@ def load_ego(n_frames: int | None = None):
 def ego_path(v, yaw, dt: float = 0.1):
     """world pose (x, y, heading) of the sensor per frame: the tracker's dead reckoning, integrated"""
     th = yaw - yaw[0]
-    step = dt * v * np.stack([np.cos(th), np.sin(th)], axis=1)
+    step = (dt * v)[:, None] * np.stack([np.cos(th), np.sin(th)], axis=1)
     step[0] = 0.0
     pos = np.cumsum(step, axis=0)
     return np.concatenate([pos, th[:, None], np.zeros((len(v), 1))], axis=1).astype(np.float32)

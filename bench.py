@@ -141,7 +141,7 @@ def cpu_baseline(frames: np.ndarray, ego_v, ego_yaw, n_points: int, budget_s: fl
             ncpu = os.cpu_count() or 1
             path = f"/dev/shm/mot_bench_frames_{os.getpid()}.npy" if os.path.isdir("/dev/shm") else f"/tmp/mot_bench_frames_{os.getpid()}.npy"
             np.save(path, frames)
-            per = 6
+            per = 24
             idx = [[(w * per + j) % nF for j in range(per)] for w in range(ncpu)]
             with mp.get_context("spawn").Pool(ncpu, initializer=_cpu_worker_init, initargs=(path, frames.shape)) as pool:   # spawn: the parent holds a HIP runtime
                 pool.map(_cpu_worker, [[w % nF] for w in range(ncpu)])   # warm-up: library loaded, pages touched

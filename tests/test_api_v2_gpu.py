@@ -14,7 +14,7 @@ def test_fast_cells_agree_with_exact_on_device(mot, hip_lib):
     """getCellIndexFromPoints (ground_removal.cpp:67-76) and mapCartesianGrid's index
     (component_clustering.cpp:42-48). The streaming kernels answer from estimates built on the hardware's 1-ulp v_sqrt_f32 /
     v_rcp_f32; whenever they answer (not -2) the answer must be the exact evaluation's. > 4e9 points: uniform random, a
-    2^16 x 2^16 lattice, and every channel spoke / bin ring / grid line moved by -3..+3 ulp in x and y, both presets."""
+    2^16 x 2^16 lattice, and every channel spoke / bin ring / grid line moved by -3..+3 steps of 1..64 ulp in x and y, both presets."""
     total = 0
     for preset in (0, 1):
         with mot.Context(mot.params(preset), max_points=1024) as c:
@@ -28,7 +28,7 @@ def test_fast_cells_agree_with_exact_on_device(mot, hip_lib):
                 x = np.array([st[3] & 0xffffffff], np.uint32).view(np.float32)[0]; y = np.array([st[3] >> 32], np.uint32).view(np.float32)[0]
                 assert st[2] == 0, f"what={what} mode={mode} preset={preset}: {st[2]} mismatches, first at ({x!r}, {y!r}) fast/exact {st[4] & 0xffffffff:#x}/{st[4] >> 32:#x}"
                 und = st[1] / count
-                assert und < (0.5 if mode == 2 else 3e-3), (what, mode, und)   # the exact path stays rare away from boundaries
+                assert und < (0.999 if mode == 2 else 3e-3), (what, mode, und)   # the exact path stays rare away from boundaries (mode 2 sits ON them)
                 total += count
     assert total > 4e9
 
