@@ -40,6 +40,7 @@ class MotParams(C.Structure):
         ("gamma_g", C.c_double), ("p_g", C.c_double), ("p_d", C.c_double), ("distance_thres", C.c_double),
         ("life_time_thres", C.c_int32), ("seed_box_index", C.c_int32), ("bb_yaw_change_thres", C.c_double),
         ("first_ego_yaw_offset", C.c_double), ("seed_px", C.c_double), ("seed_py", C.c_double),
+        ("rng_mapping", C.c_int32), ("reserved_", C.c_int32),
     ]
 
 

@@ -513,17 +513,27 @@ cluster_gather_kernel(MotDevParams p, ClusterBuffers c) {
       cand.branch = 0;
       const int nsamp = p.ram_points < 128 ? p.ram_points : 128;
       {
-        // mt19937_64 mt(0); uniform_int_distribution<>(0, numPoints-1): libstdc++ >= 11 maps the 64-bit draw with
-        // Lemire's multiply-shift + rejection (bits/uniform_int_dist.h _S_nd), SURVEY.md H17. A rejection (probability
-        // numPoints / 2^64 per draw) shifts every later draw, so the draws are mapped in parallel and the rare
-        // rejection is replayed sequentially.
+        // mt19937_64 mt(0); uniform_int_distribution<>(0, numPoints-1): the mapping of a 64-bit draw to an index is libstdc++'s
+        //  and changed with GCC 11 — p.rng_mapping selects it:
+        //   libstdc++ >= 11  Lemire's multiply-shift + rejection (bits/uniform_int_dist.h, _S_nd): index = high64(draw * n),
+        //                    rejected when low64(draw * n) < (2^64 - n) % n
+        //   libstdc++ <= 10  scaling = (2^64 - 1) / n; rejected when draw >= n * scaling; index = draw / scaling
+        // A rejection (probability ~ n / 2^64 per draw) shifts every later draw, so the draws are mapped in parallel and the
+        // rare rejection is replayed sequentially.
         const unsigned long long range = (unsigned long long)numPoints;
+        const bool lemire = p.rng_mapping != MOT_RNG_LIBSTDCXX10;
+        const unsigned long long scaling = 0xffffffffffffffffull / range, past = range * scaling;
         bool reject = false;
         for (int i = tid; i < nsamp; i += kBoxBlock) {
           unsigned long long g = c.rng[i < kRngTable ? i : kRngTable - 1];
-          unsigned long long low = g * range, high = __umul64hi(g, range);
-          if (low < range && low < (0ull - range) % range) reject = true;
-          s_rank[i] = (int)high;
+          if (lemire) {
+            unsigned long long low = g * range, high = __umul64hi(g, range);
+            if (low < range && low < (0ull - range) % range) reject = true;
+            s_rank[i] = (int)high;
+          } else {
+            if (g >= past) reject = true;
+            s_rank[i] = (int)(g / scaling);
+          }
           s_pidx[i] = -1;
         }
         if (tid == 0) s_flag = 0;
@@ -535,15 +545,20 @@ cluster_gather_kernel(MotDevParams p, ClusterBuffers c) {
           bool exhausted = false;
           for (int i = 0; i < nsamp; i++) {
             unsigned long long g = c.rng[t < kRngTable ? t : kRngTable - 1]; exhausted |= t >= kRngTable; t++;
-            unsigned long long low = g * range, high = __umul64hi(g, range);
-            if (low < range) {
-              unsigned long long threshold = (0ull - range) % range;
-              while (low < threshold && !exhausted) {
-                g = c.rng[t < kRngTable ? t : kRngTable - 1]; exhausted |= t >= kRngTable; t++;
-                low = g * range; high = __umul64hi(g, range);
+            if (lemire) {
+              unsigned long long low = g * range, high = __umul64hi(g, range);
+              if (low < range) {
+                unsigned long long threshold = (0ull - range) % range;
+                while (low < threshold && !exhausted) {
+                  g = c.rng[t < kRngTable ? t : kRngTable - 1]; exhausted |= t >= kRngTable; t++;
+                  low = g * range; high = __umul64hi(g, range);
+                }
               }
+              s_rank[i] = (int)high;
+            } else {
+              while (g >= past && !exhausted) { g = c.rng[t < kRngTable ? t : kRngTable - 1]; exhausted |= t >= kRngTable; t++; }
+              s_rank[i] = (int)(g / scaling);
             }
-            s_rank[i] = (int)high;
           }
           if (exhausted) atomicOr(&c.counts[b * kCountsStride + kCntFlags], (int)kFlagRngExhausted);
         }

@@ -72,7 +72,7 @@ struct mot_ctx {
   int* d_live = nullptr;
   mot_track* d_tout = nullptr;
   int* d_tflags = nullptr;
-  EgoPose* d_ego = nullptr;
+  EgoTf* d_ego = nullptr;
   int* d_nlive = nullptr;
   Vec2d* d_pos = nullptr;
   Vec2d* d_cp = nullptr;
@@ -87,7 +87,7 @@ struct mot_ctx {
   };
   std::vector<SlotEgo> ego;
   std::vector<TrackFrameArgs> h_targs;
-  std::vector<EgoPose> h_ego;
+  std::vector<EgoTf> h_ego;
   // host mirrors
   std::vector<int> h_n;
   int* h_counts = nullptr;  // pinned [batch][4]
@@ -179,6 +179,7 @@ extern "C" int mot_params_preset(int preset, mot_params* o) {
   o->bb_yaw_change_thres = 0.2;
   o->first_ego_yaw_offset = (kitti ? 1.22191 : -0.63035) - M_PI / 2;
   o->seed_px = -1.5125; o->seed_py = -8.975;
+  o->rng_mapping = MOT_RNG_LIBSTDCXX11;
   return MOT_OK;
 }
 
@@ -186,6 +187,7 @@ static int make_dev_params(const mot_params& p, MotDevParams* d, std::string* er
   if (p.gauss_samples != 3) { *err = "gauss_samples must be 3"; return MOT_E_ARG; }
   if (p.num_grid < 8 || p.num_grid > MOT_MAX_GRID) { *err = "num_grid out of range"; return MOT_E_ARG; }
   if (p.ram_points < 1 || p.ram_points > 128) { *err = "ram_points must be in 1..128"; return MOT_E_ARG; }
+  if (p.rng_mapping != MOT_RNG_LIBSTDCXX10 && p.rng_mapping != MOT_RNG_LIBSTDCXX11) { *err = "rng_mapping must be MOT_RNG_LIBSTDCXX10 or MOT_RNG_LIBSTDCXX11"; return MOT_E_ARG; }
   if (!(p.pic_scale * p.roi_m <= 1000.f)) { *err = "pic_scale * roi_m must be <= 1000 pixels"; return MOT_E_ARG; }
   memset(d, 0, sizeof *d);
   d->r_min = p.r_min; d->r_max = p.r_max; d->r_span = p.r_max - p.r_min;
@@ -210,6 +212,7 @@ static int make_dev_params(const mot_params& p, MotDevParams* d, std::string* er
   d->roi_m = p.roi_m; d->roi_half = p.roi_m / 2;
   d->k_grid = (float)p.num_grid / p.roi_m;
   d->pic_scale = p.pic_scale; d->pic_full = p.pic_scale * p.roi_m; d->pic_half = p.roi_m * p.pic_scale / 2;
+  d->rng_mapping = p.rng_mapping;
   d->ram_points = p.ram_points; d->l_slope_dist = p.l_slope_dist; d->l_num_points = p.l_num_points;
   d->lshape_side_cond = p.lshape_side_cond; d->min_points = p.min_points; d->sensor_height = p.sensor_height;
   d->t_height_min = p.t_height_min; d->t_height_max = p.t_height_max; d->t_width_min = p.t_width_min;
@@ -327,7 +330,7 @@ static int create_impl(mot_ctx* c) {
   MOT_HIP(c, hipMalloc(&c->d_live, B * 2 * T * sizeof(int)));
   MOT_HIP(c, hipMalloc(&c->d_tout, B * T * sizeof(mot_track)));
   MOT_HIP(c, hipMalloc(&c->d_tflags, B * sizeof(int)));
-  MOT_HIP(c, hipMalloc(&c->d_ego, B * sizeof(EgoPose)));
+  MOT_HIP(c, hipMalloc(&c->d_ego, B * sizeof(EgoTf)));
   MOT_HIP(c, hipMalloc(&c->d_nlive, B * sizeof(int)));
   MOT_HIP(c, hipMalloc(&c->d_pos, B * T * sizeof(Vec2d)));
   MOT_HIP(c, hipMalloc(&c->d_cp, B * kMaxBoxesPerFrame * sizeof(Vec2d)));
@@ -339,7 +342,7 @@ static int create_impl(mot_ctx* c) {
   MOT_HIP(c, hipMemsetAsync(c->d_tflags, 0, B * sizeof(int), c->stream));
   c->ego.assign(B, mot_ctx::SlotEgo());
   c->h_targs.assign(B, TrackFrameArgs());
-  c->h_ego.assign(B, EgoPose());
+  c->h_ego.assign(B, EgoTf());
   MOT_HIP(c, hipMemsetAsync(c->d_pair_count, 0, B * c->max_chunks * sizeof(int), c->stream));
   MOT_HIP(c, hipMemsetAsync(c->d_counts, 0, B * kCountsStride * sizeof(int), c->stream));
   MOT_HIP(c, hipMemsetAsync(c->d_n, 0, B * sizeof(int), c->stream));
@@ -444,6 +447,80 @@ struct ProfScope {
   ~ProfScope() { if (on) { (void)hipEventRecord(c->prof_ev[c->prof_n][1], c->stream); c->prof_n++; } }
 };
 
+// The sensor -> global change of frame the tracking node asks tf for (OT/tracking/main.cpp:76-83 broadcast, :143-158
+// pcl_ros::transformPointCloud("/global", box, newBox, *tran)), walked down to the float matrix pcl::transformPointCloud
+// applies, every step in the arithmetic of the library that performs it in the reference's process:
+//   1. tf::Quaternion::setRPY(0, 0, yaw); tf::Transform::setRotation -> Matrix3x3::setRotation            (double, tf LinearMath)
+//   2. TransformBroadcaster::sendTransform stores (Transform::getRotation() = Matrix3x3::getRotation, origin)   (double, tf2)
+//   3. lookupTransform(global <- velodyne) inverts the stored edge: Transform(q^-1, quatRotate(q^-1, -v))  (double, tf2 BufferCore)
+//   4. pcl_ros: Eigen::Quaternionf(q), Eigen::Vector3f(v); Translation * Quaternion -> Affine3f:
+//      Eigen's QuaternionBase::toRotationMatrix in FLOAT                                                    (float, Eigen 3.2)
+// tf, tf2 and pcl_ros are not part of the reference tree: restated from their published sources, the same restatement the
+// node-level oracle runs on (oracle/ref_shim/tf, pcl_ros); tests/test_tf_exact.py compares the fused path's boxes with the
+// reference node's own call sequence executed on that shim, bit for bit.
+static void tf_set_rotation(const double q[4], double b[3][3]) {   // tf::Matrix3x3::setRotation
+  const double d = q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3];
+  const double s = 2.0 / d;
+  const double xs = q[0] * s, ys = q[1] * s, zs = q[2] * s;
+  const double wx = q[3] * xs, wy = q[3] * ys, wz = q[3] * zs;
+  const double xx = q[0] * xs, xy = q[0] * ys, xz = q[0] * zs;
+  const double yy = q[1] * ys, yz = q[1] * zs, zz = q[2] * zs;
+  b[0][0] = 1.0 - (yy + zz); b[0][1] = xy - wz; b[0][2] = xz + wy;
+  b[1][0] = xy + wz; b[1][1] = 1.0 - (xx + zz); b[1][2] = yz - wx;
+  b[2][0] = xz - wy; b[2][1] = yz + wx; b[2][2] = 1.0 - (xx + yy);
+}
+static void tf_get_rotation(const double b[3][3], double e[4]) {   // tf::Matrix3x3::getRotation
+  const double trace = b[0][0] + b[1][1] + b[2][2];
+  if (trace > 0.0) {
+    double s = sqrt(trace + 1.0);
+    e[3] = s * 0.5;
+    s = 0.5 / s;
+    e[0] = (b[2][1] - b[1][2]) * s; e[1] = (b[0][2] - b[2][0]) * s; e[2] = (b[1][0] - b[0][1]) * s;
+  } else {
+    const int i = b[0][0] < b[1][1] ? (b[1][1] < b[2][2] ? 2 : 1) : (b[0][0] < b[2][2] ? 2 : 0);
+    const int j = (i + 1) % 3, k = (i + 2) % 3;
+    double s = sqrt(b[i][i] - b[j][j] - b[k][k] + 1.0);
+    e[i] = s * 0.5;
+    s = 0.5 / s;
+    e[3] = (b[k][j] - b[j][k]) * s; e[j] = (b[j][i] + b[i][j]) * s; e[k] = (b[k][i] + b[i][k]) * s;
+  }
+}
+static void tf_velodyne_to_global(double x, double y, double yaw, float m[12]) {
+  // 1. setRPY(0, 0, yaw): the roll / pitch factors are cos(0) = 1, sin(0) = 0 exactly; Transform::setRotation
+  const double halfYaw = yaw * 0.5;
+  const double cosYaw = cos(halfYaw), sinYaw = sin(halfYaw);
+  const double cosPitch = 1.0, sinPitch = 0.0, cosRoll = 1.0, sinRoll = 0.0;
+  const double q[4] = {sinRoll * cosPitch * cosYaw - cosRoll * sinPitch * sinYaw, cosRoll * sinPitch * cosYaw + sinRoll * cosPitch * sinYaw,
+                       cosRoll * cosPitch * sinYaw - sinRoll * sinPitch * cosYaw, cosRoll * cosPitch * cosYaw + sinRoll * sinPitch * sinYaw};
+  double b[3][3];
+  tf_set_rotation(q, b);
+  // 2. the broadcaster stores Transform::getRotation()
+  double e[4];
+  tf_get_rotation(b, e);
+  // 3. inverse edge: qi = (-x, -y, -z, w); v' = quatRotate(qi, -v) = ((qi * (-v)) * qi^-1).xyz; the looked-up StampedTransform
+  //    is a Transform(qi, v'), i.e. qi becomes a matrix once more
+  const double qi[4] = {-e[0], -e[1], -e[2], e[3]};
+  const double w[3] = {-x, -y, -0.0};
+  const double t[4] = {qi[3] * w[0] + qi[1] * w[2] - qi[2] * w[1], qi[3] * w[1] + qi[2] * w[0] - qi[0] * w[2],
+                       qi[3] * w[2] + qi[0] * w[1] - qi[1] * w[0], -qi[0] * w[0] - qi[1] * w[1] - qi[2] * w[2]};   // Quaternion * Vector3
+  const double r[4] = {-qi[0], -qi[1], -qi[2], qi[3]};                                                               // qi.inverse()
+  const double v[3] = {t[3] * r[0] + t[0] * r[3] + t[1] * r[2] - t[2] * r[1], t[3] * r[1] + t[1] * r[3] + t[2] * r[0] - t[0] * r[2],
+                       t[3] * r[2] + t[2] * r[3] + t[0] * r[1] - t[1] * r[0]};                                      // Quaternion * Quaternion, xyz
+  double b2[3][3], q2[4];
+  tf_set_rotation(qi, b2);
+  // 4. pcl_ros::transformPointCloud(cloud, cloud, tf::Transform): transform.getRotation() -> Eigen::Quaternionf, origin ->
+  //    Eigen::Vector3f; Translation3f * Quaternionf: QuaternionBase::toRotationMatrix in FLOAT
+  tf_get_rotation(b2, q2);
+  const float fx = (float)q2[0], fy = (float)q2[1], fz = (float)q2[2], fw = (float)q2[3];
+  const float tx = 2.0f * fx, ty = 2.0f * fy, tz = 2.0f * fz;
+  const float twx = tx * fw, twy = ty * fw, twz = tz * fw;
+  const float txx = tx * fx, txy = ty * fx, txz = tz * fx;
+  const float tyy = ty * fy, tyz = tz * fy, tzz = tz * fz;
+  m[0] = 1.0f - (tyy + tzz); m[1] = txy - twz; m[2] = txz + twy; m[3] = (float)v[0];
+  m[4] = txy + twz; m[5] = 1.0f - (txx + tzz); m[6] = tyz - twx; m[7] = (float)v[1];
+  m[8] = txz - twy; m[9] = tyz + twx; m[10] = 1.0f - (txx + tyy); m[11] = (float)v[2];
+}
+
 // the fused launch sequence of one batch on the context stream; every argument has been validated
 static int launch_frames(mot_ctx* c, int batch, int run_tracker, const double* timestamps, const double* ego_v, const double* ego_yaw) {
   int rc;
@@ -465,10 +542,10 @@ static int launch_frames(mot_ctx* c, int batch, int run_tracker, const double* t
     for (int b = 0; b < batch; b++) {
       // the tracking node's per-frame sequence (OT/tracking/main.cpp:72-166): ego pose, boxes -> global frame, tracker
       if ((rc = mot_ego_update(c, b, timestamps[b], ego_v[b], ego_yaw[b], nullptr))) return rc;
-      c->h_ego[b].x = c->ego[b].egoPoint[0]; c->h_ego[b].y = c->ego[b].egoPoint[1]; c->h_ego[b].yaw = c->ego[b].egoPoint[2];
+      tf_velodyne_to_global(c->ego[b].egoPoint[0], c->ego[b].egoPoint[1], c->ego[b].egoPoint[2], c->h_ego[b].m);
       prepare_track_args(c, b, 0, timestamps[b], true);
     }
-    MOT_HIP(c, hipMemcpyAsync(c->d_ego, c->h_ego.data(), batch * sizeof(EgoPose), hipMemcpyHostToDevice, c->stream));
+    MOT_HIP(c, hipMemcpyAsync(c->d_ego, c->h_ego.data(), batch * sizeof(EgoTf), hipMemcpyHostToDevice, c->stream));
     MOT_HIP(c, hipMemcpyAsync(c->d_targs, c->h_targs.data(), c->batch * sizeof(TrackFrameArgs), hipMemcpyHostToDevice, c->stream));
     { ProfScope ps(c, kT1); mot_launch_track(track_buffers(c, true), batch, c->stream); }
   }
@@ -1145,6 +1222,7 @@ extern "C" int mot_debug_copy(mot_ctx* c, int which, int slot, void* dst, size_t
   else if (which == 8) src = c->d_pix + (size_t)slot * c->cap;
   else if (which == 9) src = c->d_groups + (size_t)slot * (c->cap / 2);
   else if (which == 10) src = c->d_hg + (size_t)slot * MOT_POLAR_CELLS;
+  else if (which == 11) src = c->d_tboxes + (size_t)slot * kMaxBoxesPerFrame * 24;
   else return MOT_E_ARG;
   MOT_HIP(c, hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, c->stream));
   MOT_HIP(c, hipStreamSynchronize(c->stream));
@@ -1165,5 +1243,12 @@ extern "C" int mot_debug_sweep(mot_ctx* c, int what, int mode, unsigned long lon
   MOT_HIP(c, hipMemcpyAsync(stats8, d, 8 * sizeof(unsigned long long), hipMemcpyDeviceToHost, c->stream));
   MOT_HIP(c, hipStreamSynchronize(c->stream));
   MOT_HIP(c, hipFree(d));
+  return MOT_OK;
+}
+
+// test hook (mot_debug_api.h): the float matrix of the fused path's sensor -> global change of frame for an ego pose
+extern "C" int mot_debug_tf_matrix(double x, double y, double yaw, float* m12) {
+  if (!m12) return MOT_E_ARG;
+  tf_velodyne_to_global(x, y, yaw, m12);
   return MOT_OK;
 }

@@ -59,6 +59,7 @@ struct MotDevParams {
   float k_grid;                                // numGrid / roiM, for the guarded fast path of the Cartesian cell only
   float pic_scale, pic_full, pic_half;         // picScale*roiM and roiM*picScale/2 (fp32 products)
   int ram_points, l_slope_dist, l_num_points, lshape_side_cond, min_points;
+  int rng_mapping;                             // MOT_RNG_LIBSTDCXX10 / 11: how a 64-bit draw becomes a sample index
   float sensor_height;
   float t_height_min, t_height_max, t_width_min, t_width_max, t_len_min, t_len_max, t_area_max, t_ratio_min,
       t_ratio_max, min_len_ratio, t_pt_per_m3;
@@ -211,7 +212,9 @@ struct MotTrackParams {
 
 struct Vec2d { double x, y; };
 struct TrackItem { int b, li; };  // one unit of per-track work: live track `li` (index into the stream's live list) of stream `b`
-struct EgoPose { double x, y, yaw; };
+// sensor -> global change of frame of the fused path: the float 3 x 4 matrix the tracking node's tf chain ends in
+// (mot_api.hip: tf_velodyne_to_global), row major
+struct EgoTf { float m[12]; };
 
 struct TrackBuffers {
   DevTrack* tracks;             // [B][T]
@@ -219,7 +222,7 @@ struct TrackBuffers {
   const float* boxes;           // [B][box_stride] floats, 24 per box, global frame: what the tracker reads
   long box_stride;              // floats per slot (kMaxBoxesPerFrame * 24 for the library's own buffer)
   const float* boxes_sensor;    // fused path: [B][kMaxBoxesPerFrame][24] boxes of the box stage in the sensor frame, or null
-  const EgoPose* ego;           //   ... the dead-reckoned ego pose per slot: the prep kernel writes their global-frame image
+  const EgoTf* ego;             //   ... the sensor -> global transform per slot: the prep kernel writes their global-frame image
   float* boxes_out;             //   ... into this buffer (= boxes)
   const TrackFrameArgs* args;   // [B]
   unsigned long long* gate;     // [B][T][kGateWords]

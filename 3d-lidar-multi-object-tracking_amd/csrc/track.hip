@@ -422,17 +422,20 @@ track_prep_kernel(TrackBuffers tb) {
   const int M = tb.m_dev ? min(tb.m_dev[b * kCountsStride + kCntBoxes], kMaxBoxesPerFrame) : args.m;
   const float* __restrict__ boxes = tb.boxes + (long)b * tb.box_stride;
   if (tb.boxes_sensor) {
-    // the tf step of the tracking node (OT/tracking/main.cpp:143-158): boxes arrive in the sensor frame, the tracker works in
-    // the global frame. tf is not part of the reference tree; a plain fp64 rigid transform rounded to fp32.
-    const EgoPose e = tb.ego[b];
-    const double c = cos(-e.yaw), s = sin(-e.yaw);
+    // the tf step of the tracking node (OT/tracking/main.cpp:143-158: pcl_ros::transformPointCloud("/global", box, ...)): the host
+    // walked the tf chain down to the float matrix pcl::transformPointCloud applies (mot_api.hip: tf_velodyne_to_global); each
+    // point is m(r,0)*x + m(r,1)*y + m(r,2)*z + m(r,3) in fp32, left to right, as PCL evaluates it (no contraction: the build
+    // has -ffp-contract=off)
+    const EgoTf e = tb.ego[b];
     const float* __restrict__ src = tb.boxes_sensor + (long)b * kMaxBoxesPerFrame * 24;
     float* __restrict__ dst = tb.boxes_out + (long)b * tb.box_stride;
     for (int i = tid; i < M * 8; i += 256) {
       const float* p = src + (long)i * 3;
       float* q = dst + (long)i * 3;
-      const double dx = (double)p[0] - e.x, dy = (double)p[1] - e.y;
-      q[0] = (float)(c * dx - s * dy); q[1] = (float)(s * dx + c * dy); q[2] = p[2];
+      const float x = p[0], y = p[1], z = p[2];
+      q[0] = e.m[0] * x + e.m[1] * y + e.m[2] * z + e.m[3];
+      q[1] = e.m[4] * x + e.m[5] * y + e.m[6] * z + e.m[7];
+      q[2] = e.m[8] * x + e.m[9] * y + e.m[10] * z + e.m[11];
     }
     __syncthreads();
   }

@@ -58,6 +58,8 @@ enum {
   MOT_E_STATE = 4     /* call sequence error */
 };
 
+enum { MOT_RNG_LIBSTDCXX10 = 0, MOT_RNG_LIBSTDCXX11 = 1 };
+
 enum {
   MOT_PRESET_OBJECT_TRACKING = 0, /* OT/  constants (the package north_star names) */
   MOT_PRESET_OBJECT_TRACKING0 = 1 /* OT0/ constants (KITTI-tuned), SURVEY.md §2.1 */
@@ -114,6 +116,17 @@ typedef struct mot_params {
   double bb_yaw_change_thres; /* 0.2 */
   double first_ego_yaw_offset; /* -0.63035 - pi/2 (OT0 1.22191 - pi/2) */
   double seed_px, seed_py;     /* hard-coded seed position (-1.5125, -8.975), :755-756 */
+  /* ---- toolchain dependence of the reference ----
+   * box_fitting.cpp:303-315 draws its 80 sample indices with std::uniform_int_distribution<> over std::mt19937_64(0); how a
+   * 64-bit draw becomes an index is libstdc++'s choice and changed in GCC 11:
+   *   MOT_RNG_LIBSTDCXX11 (1, default)  libstdc++ >= 11: Lemire's multiply-shift with rejection (bits/uniform_int_dist.h, _S_nd)
+   *   MOT_RNG_LIBSTDCXX10 (0)           libstdc++ <= 10 (GCC 5 .. 10, i.e. every ROS1 distribution's compiler): scale = (2^64-1) / n,
+   *                                     reject draws >= n * scale, index = draw / scale
+   * Both scale the draw proportionally and disagree only when draw * n / 2^64 lies within ~n^2 / 2^64 of an integer (5e-14 per
+   * draw for a 1000-point cluster): pick the one the reference build you replace was compiled with and the boxes are
+   * identical; pick the other and they still are, except with that probability (tests/test_oracle_vs_ref.py). */
+  int32_t rng_mapping;
+  int32_t reserved_;
 } mot_params;
 
 /* one record per track EVER created on a stream (the reference's output vectors are sized that

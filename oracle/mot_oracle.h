@@ -62,7 +62,8 @@ int orc_box_fit(const mot_params* p, const float* elevated_xyzw, int n, const in
 void orc_min_area_rect_points(const int32_t* xy, int n, float out_xy[8]);
 /* pieces exposed for unit tests */
 int orc_convex_hull(const int32_t* xy, int n, int32_t* hull_xy /* cap n */);
-void orc_lshape_indices(int num_points, int count, int32_t* out); /* mt19937_64(0) + uniform_int_distribution */
+void orc_lshape_indices(int num_points, int count, int32_t* out); /* mt19937_64(0) + uniform_int_distribution, libstdc++ >= 11 */
+void orc_lshape_indices_mapping(int num_points, int count, int mapping, int32_t* out); /* mapping: MOT_RNG_LIBSTDCXX10 / 11 */
 
 /* ---- tracker (OT/tracking/imm_ukf_jpda.cpp, ukf.cpp) ---- */
 typedef struct orc_tracker orc_tracker;

@@ -51,13 +51,24 @@ static uint64_t lemire(mt64* g, uint64_t range) {
   }
   return (uint64_t)(product >> 64);
 }
+/* the same distribution as libstdc++ <= 10 implements it (GCC 5 .. 10: bits/uniform_int_dist.h, operator() "downscaling" branch,
+ * urng range 2^64 - 1): scaling = urngrange / uerange; do ret = urng(); while (ret >= uerange * scaling); ret /= scaling.
+ * No build of that library exists in this image: restated from its published source, parity unpinned (include/mot.h,
+ * mot_params.rng_mapping). */
+static uint64_t scale_and_reject(mt64* g, uint64_t uerange) {
+  const uint64_t scaling = 0xFFFFFFFFFFFFFFFFULL / uerange, past = uerange * scaling;
+  uint64_t ret;
+  do ret = mt64_next(g); while (ret >= past);
+  return ret / scaling;
+}
 /* box_fitting.cpp:303-304,315: mt19937_64 mt(0); uniform_int_distribution<> randPoints(0, numPoints-1) */
-void orc_lshape_indices(int num_points, int count, int32_t* out) {
+void orc_lshape_indices_mapping(int num_points, int count, int mapping, int32_t* out) {
   mt64 g;
   mt64_seed(&g, 0);
   uint64_t urange = (uint64_t)(uint32_t)(num_points - 1); /* b - a as unsigned */
-  for (int i = 0; i < count; i++) out[i] = (int32_t)lemire(&g, urange + 1);
+  for (int i = 0; i < count; i++) out[i] = (int32_t)(mapping == MOT_RNG_LIBSTDCXX10 ? scale_and_reject(&g, urange + 1) : lemire(&g, urange + 1));
 }
+void orc_lshape_indices(int num_points, int count, int32_t* out) { orc_lshape_indices_mapping(num_points, count, MOT_RNG_LIBSTDCXX11, out); }
 
 static int cart_cell(const mot_params* p, float x, float y, int* xI, int* yI) { /* box_fitting.cpp:52-58 */
   float roiM = p->roi_m;
@@ -180,7 +191,7 @@ int orc_box_fit(const mot_params* p, const float* pts, int n, const int32_t* gri
     if (lshape) {
       float maxDist = 0, maxDx = 0, maxDy = 0;
       int dSet = 0;
-      orc_lshape_indices(numPoints, p->ram_points, rnd);
+      orc_lshape_indices_mapping(numPoints, p->ram_points, p->rng_mapping, rnd);
       for (int i = 0; i < p->ram_points; i++) {
         int pInd = rnd[i];
         float xI = pts[4 * idx[pInd]], yI = pts[4 * idx[pInd] + 1];

@@ -39,6 +39,7 @@ int orc_params_preset(int preset, mot_params* o) {
   o->seed_box_index = k ? 10 : 1; o->bb_yaw_change_thres = 0.2;
   o->first_ego_yaw_offset = (k ? 1.22191 : -0.63035) - M_PI / 2;
   o->seed_px = -1.5125; o->seed_py = -8.975;
+  o->rng_mapping = MOT_RNG_LIBSTDCXX11; /* this image builds oracle/_ref with GCC 11 */
   return MOT_OK;
 }
 

@@ -108,6 +108,18 @@ if __name__ == "__main__":
     import tempfile
     with tempfile.TemporaryDirectory() as d:
         np.savez_compressed(os.path.join(HERE, "tracker_ot0_us.npz"), **tracker_fixture(3, 30, 40000, 1e5, ot0_workdir=d))
+    # the tracking node's sensor -> global change of frame (OT/tracking/main.cpp:76-83,143-158) on the tf / pcl_ros code of the
+    # node-level oracle (oracle/ref_tf_capi.cpp): poses, boxes and their images, for tests/test_tf_exact.py
+    import ctypes as C
+    rng = np.random.default_rng(77)
+    poses, boxes, glob = [], [], []
+    for k in range(200):
+        yaw = rng.uniform(-7, 7) if k % 5 else [0.0, np.pi, -np.pi, np.pi / 2, -np.pi / 2][(k // 5) % 5]
+        pose = np.array([rng.uniform(-300, 300), rng.uniform(-300, 300), yaw])
+        b = rng.uniform(-60, 60, size=(3, 8, 3)).astype(np.float32); out = np.zeros_like(b)
+        assert O.ref().ref_boxes_to_global(b.ctypes.data_as(C.c_void_p), len(b), C.c_double(pose[0]), C.c_double(pose[1]), C.c_double(pose[2]), out.ctypes.data_as(C.c_void_p)) == 0
+        poses.append(pose); boxes.append(b); glob.append(out)
+    np.savez_compressed(os.path.join(HERE, "tf_boxes.npz"), pose=np.array(poses), boxes=np.array(boxes), **{"global": np.array(glob)})
     # the reference's only data fixture: the ego motion of KITTI drive_0005 its second package reads frame by frame
     # (OT0/src/imm_ukf_jpda.cpp:65-72). bench.py drives its synthetic 154-frame sequences with it.
     np.savez_compressed(os.path.join(HERE, "ego_drive0005.npz"),

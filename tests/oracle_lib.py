@@ -43,6 +43,7 @@ class MotParams(C.Structure):
         ("gamma_g", C.c_double), ("p_g", C.c_double), ("p_d", C.c_double), ("distance_thres", C.c_double),
         ("life_time_thres", C.c_int32), ("seed_box_index", C.c_int32), ("bb_yaw_change_thres", C.c_double),
         ("first_ego_yaw_offset", C.c_double), ("seed_px", C.c_double), ("seed_py", C.c_double),
+        ("rng_mapping", C.c_int32), ("reserved_", C.c_int32),
     ]
 
 
@@ -213,6 +214,12 @@ def convex_hull(xy) -> np.ndarray:
     orc().orc_convex_hull.restype = C.c_int
     k = orc().orc_convex_hull(xy.ctypes.data_as(C.c_void_p), len(xy), out.ctypes.data_as(C.c_void_p))
     return out[:k].copy()
+
+
+def lshape_indices_mapping(num_points: int, count: int, mapping: int) -> np.ndarray:
+    out = np.zeros(count, np.int32)
+    orc().orc_lshape_indices_mapping(num_points, count, mapping, out.ctypes.data_as(C.c_void_p))
+    return out
 
 
 def lshape_indices(num_points: int, count: int = 80) -> np.ndarray:

@@ -71,17 +71,6 @@ def test_emu_ground_remove_pointcloud2_and_resident_box_fit(mot, oracle, synth):
             assert np.array_equal(c.get_ground(0)["elevated"][:, :3], g["elevated"][:, :3])
 
 
-def test_bench_host_boundary_helper(mot, synth):
-    """bench.py's PCIe-inclusive side measurement, run here on the emulator library (small frames) so that the code path is
-    exercised before it meets a GPU"""
-    import importlib.util
-    import build_emu
-    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "bench.py"))
-    b = importlib.util.module_from_spec(spec); spec.loader.exec_module(b)
-    r = b.host_boundary(mot, synth, 6000, frames=3, lib_path=build_emu.build())
-    assert r["value"] > 0 and r["unit"] == "frames/s"
-
-
 @pytest.mark.parametrize("cap", [1, 63, 64, 65, 4095, 4096, 4097, 8191])
 def test_emu_frames_that_fill_the_capacity_exactly(mot, oracle, synth, cap):
     """n == max_points for capacities around the 64-point and 4096-point granularities of the kernels (under

@@ -137,6 +137,43 @@ int main(){ int ns[]={1,2,6,7,30,31,100,1000,4097,65536,1000003};
         assert np.array_equal(oracle.lshape_indices(n, 80), np.array(line.split(), np.int32)), n
 
 
+def test_lshape_sampling_of_older_libstdcxx(oracle):
+    """mot_params.rng_mapping = MOT_RNG_LIBSTDCXX10: uniform_int_distribution as GCC 5..10 ship it (every ROS1 toolchain), restated
+    from bits/uniform_int_dist.h of libstdc++ 9 (no such library in this image: parity unpinned upstream). The test carries that
+    operator()'s downscaling branch as a C++ program of its own over the real std::mt19937_64."""
+    import os, subprocess, tempfile
+    src = r'''
+#include <random>
+#include <cstdio>
+#include <cstdint>
+// libstdc++ <= 10, uniform_int_distribution<int>::operator()(urng, param), branch __urngrange > __urange
+static int old_dist(std::mt19937_64& urng, int a, int b) {
+  typedef uint64_t uctype;
+  const uctype urngmin = urng.min(), urngmax = urng.max(), urngrange = urngmax - urngmin, urange = uctype(b) - uctype(a);
+  uctype ret;
+  const uctype uerange = urange + 1, scaling = urngrange / uerange, past = uerange * scaling;
+  do ret = uctype(urng()) - urngmin; while (ret >= past);
+  ret /= scaling;
+  return int(ret + a);
+}
+int main(){ int ns[]={1,2,6,7,30,31,100,1000,4097,65536,1000003};
+ for(int n: ns){ std::mt19937_64 mt(0); for(int i=0;i<80;i++) printf("%d ", old_dist(mt, 0, n-1)); printf("\n"); } }
+'''
+    with tempfile.TemporaryDirectory() as d:
+        open(os.path.join(d, "r.cpp"), "w").write(src)
+        subprocess.run(["g++", "-O1", os.path.join(d, "r.cpp"), "-o", os.path.join(d, "r")], check=True)
+        lines = subprocess.run([os.path.join(d, "r")], capture_output=True, text=True).stdout.strip().split("\n")
+    differ = 0
+    for n, line in zip([1, 2, 6, 7, 30, 31, 100, 1000, 4097, 65536, 1000003], lines):
+        want = np.array(line.split(), np.int32)
+        assert np.array_equal(oracle.lshape_indices_mapping(n, 80, 0), want), n
+        differ += int(not np.array_equal(oracle.lshape_indices_mapping(n, 80, 1), want))
+    # Both generations scale the draw proportionally — floor(g * n / 2^64) vs floor(g / floor((2^64 - 1) / n)) — and disagree only when
+    # g * n / 2^64 lies within ~n^2 / 2^64 of an integer (5e-8 per draw at n = 1e6, 5e-14 at n = 1e3): on these sequences they coincide,
+    # i.e. the L-shape boxes of a GCC <= 10 build of the reference equal those of this image's GCC 11 build except with that probability
+    assert differ == 0
+
+
 @pytest.mark.parametrize("unit", [1e5, 0.1])
 def test_restatement_vs_ref_tracker(oracle, synth, unit):
     _need_ref(oracle)
