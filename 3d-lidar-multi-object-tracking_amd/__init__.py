@@ -74,7 +74,7 @@ EXPORTS = (
     "mot_get_boxes", "mot_get_tracks", "mot_export_tracks_dev", "mot_side_params_default", "mot_cluster_products", "mot_cluster_products_host", "mot_decode_pointcloud2_dev", "mot_time_stage",
     "mot_ground_remove_pointcloud2", "mot_box_fit_resident", "mot_frame_pointcloud2",
     "mot_reset_slot", "mot_frames_host", "mot_wait_uploads", "mot_host_alloc", "mot_host_free", "mot_fetch_tracks_async",
-    "mot_track_steps_dev", "mot_profile_kernel", "mot_profile_read",
+    "mot_track_steps_dev", "mot_profile_kernel", "mot_profile_read", "mot_get_params",
 )
 ABI_VERSION = 2
 

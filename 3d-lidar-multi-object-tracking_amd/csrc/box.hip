@@ -26,6 +26,7 @@
 //    angle come from the device math library; they are rounded to fp32 immediately.
 #include "mot_internal.h"
 #include "mot_wave.h"
+#include "mot_debug.h"
 
 #ifndef MOT_HIPEMU
 #define MOT_LAUNCH_BOUNDS(n) __launch_bounds__(n)
@@ -107,13 +108,7 @@ label_stats_kernel(MotDevParams p, ClusterBuffers c) {
     s_tab_rz[threadIdx.x] = mot_float_key(-99.f); s_tab_rmin[threadIdx.x] = kArgminInit; s_tab_rmax[threadIdx.x] = kArgmaxInit;
   }
   for (int i = threadIdx.x; i < kWgClusters * (kLabelChunk / 64 + 1); i += kLabelBlock) (&s_tilecnt[0][0])[i] = 0;
-#ifdef MOT_DBG_B1_TIMING
-  const long long t_start = clock64();
-  int* dbg = c.poly + (long)b * c.cap + blockIdx.x * 8;
-#define B1_T(slot) if (threadIdx.x == 0) dbg[slot] = (int)(clock64() - t_start)
-#else
-#define B1_T(slot)
-#endif
+  B1_T_BEGIN(c, b);
   const int num_cluster = c.counts[b * kCountsStride + kCntClusters];
   const float4* __restrict__ pts = c.elevated + (long)b * c.cap;
   const int* __restrict__ grid = c.grid + (long)b * (MOT_MAX_GRID * MOT_MAX_GRID);
@@ -264,9 +259,7 @@ label_stats_kernel(MotDevParams p, ClusterBuffers c) {
     if (gb + t < c.group_cap) out[gb + t] = g;
   }
   B1_T(5);
-#ifdef MOT_DBG_B1_TIMING
-  if (threadIdx.x == 0) dbg[6] = ng;
-#endif
+  B1_T_VALUE(6, ng);
 }
 
 // ------------------------------------------------------------------------------------------ B1b
@@ -303,13 +296,7 @@ cluster_index_kernel(ClusterBuffers c) {
   const bool fast = c.counts[b * kCountsStride + kCntIrregular] == 0 && nwg <= kIndexWgLds && nwg <= c.max_wg;
   const PointGroup* __restrict__ groups = c.groups + (long)b * c.group_cap;
   const ClusterStats* __restrict__ stats = c.stats + (long)b * kMaxClusters;
-#ifdef MOT_DBG_B1B_TIMING
-  const long long t_start = clock64();
-  int* dbg = c.poly + (long)b * c.cap;
-#define B1B_T(slot) if (tid == 0) dbg[slot] = (int)(clock64() - t_start)
-#else
-#define B1B_T(slot)
-#endif
+  B1B_T_BEGIN(c, b);
   // exclusive scan of the cluster sizes (kMaxClusters / kIndexBlock per thread)
   {
     constexpr int kPer = kMaxClusters / kIndexBlock;
@@ -407,9 +394,7 @@ cluster_index_kernel(ClusterBuffers c) {
     }
   }
   B1B_T(3);
-#ifdef MOT_DBG_B1B_TIMING
-  if (tid == 0) { dbg[4] = E; dbg[5] = nwg; dbg[6] = fast; }
-#endif
+  B1B_T_VALUE(4, E); B1B_T_VALUE(5, nwg); B1B_T_VALUE(6, fast);
   if (tid == 0) { c.counts[b * kCountsStride + kCntGroups] = 0; c.counts[b * kCountsStride + kCntIrregular] = 0; }  // re-arm
 }
 
@@ -470,13 +455,7 @@ cluster_gather_kernel(MotDevParams p, ClusterBuffers c) {
   (void)n;
 
   for (int ci = blockIdx.x; ci < num_cluster; ci += gridDim.x) {
-#ifdef MOT_DBG_TIMING
-    const long long t_start = clock64();
-#define MOT_T(slot) if (tid == 0) dbg_t[slot] = (int)(clock64() - t_start)
-    int dbg_t[6] = {0, 0, 0, 0, 0, 0};
-#else
-#define MOT_T(slot)
-#endif
+    GATHER_T_BEGIN();
     const ClusterStats st = c.stats[(long)b * kMaxClusters + ci];
     BoxCandidate cand;
     for (int k = 0; k < 8; k++) cand.pc[k] = 0.f;
@@ -507,7 +486,7 @@ cluster_gather_kernel(MotDevParams p, ClusterBuffers c) {
     const float slope = (maxMy - minMy) / (maxMx - minMx);
     bool lshape = slopeDist > (float)p.l_slope_dist && numPoints > p.l_num_points;  // :308
     if (p.lshape_side_cond) lshape = lshape && (maxMy > 8.f || maxMy < -5.f);
-    MOT_T(0);
+    GATHER_T(0);
 
     if (lshape) {  // ---------------------------------------------------------------- L-shape :310-356
       cand.branch = 0;
@@ -564,12 +543,12 @@ cluster_gather_kernel(MotDevParams p, ClusterBuffers c) {
         }
         __syncthreads();
       }
-      MOT_T(1);
+      GATHER_T(1);
       // the k-th point of the cluster in input order is one lookup in the cluster-sorted index
       const int first_slot = cstart[ci];
       for (int j = tid; j < nsamp; j += kBoxBlock) s_pidx[j] = sorted[first_slot + s_rank[j]];
       __syncthreads();
-      MOT_T(2);
+      GATHER_T(2);
       // farthest sampled point from the line through the two slope-extreme points; first maximum wins
       float pc[8];
       bool promising = false;
@@ -599,13 +578,11 @@ cluster_gather_kernel(MotDevParams p, ClusterBuffers c) {
         pc[4] = maxMx; pc[5] = maxMy; pc[6] = lastX; pc[7] = lastY;
         promising = rule_based_filter(p, pc, maxZ, numPoints);
       }
-      MOT_T(3);
+      GATHER_T(3);
       if (tid == 0) {
         if (!cand.undefined) for (int k = 0; k < 8; k++) cand.pc[k] = pc[k];
         cand.accepted = promising ? 1 : 0;
-#ifdef MOT_DBG_TIMING
-        cand.poly_off = dbg_t[0]; cand.poly_n = dbg_t[1]; cand.off_x = dbg_t[2]; cand.off_y = dbg_t[3];
-#endif
+        GATHER_T_STORE_LSHAPE(cand);
         c.cand[(long)b * kMaxClusters + ci] = cand;
       }
       __syncthreads();
@@ -638,7 +615,7 @@ cluster_gather_kernel(MotDevParams p, ClusterBuffers c) {
         }
       }
       __syncthreads();
-      MOT_T(1);
+      GATHER_T(1);
       if (wave == 0) {
         // compact the column extents into (x,y)-sorted points: 16 columns per lane, prefix over lanes
         int cnt = 0;
@@ -666,12 +643,10 @@ cluster_gather_kernel(MotDevParams p, ClusterBuffers c) {
         off = __shfl(off, 0, 64);
         int* pool = c.poly + (long)b * c.cap;
         for (int j = lane; j < total; j += 64) if (off + j < c.cap) pool[off + j] = ((int)(unsigned short)s_px[j]) | ((int)s_py[j] << 16);
-        MOT_T(2);
+        GATHER_T(2);
         if (lane == 0) {
           cand.poly_off = off; cand.poly_n = total; cand.off_x = offsetInitX; cand.off_y = offsetInitY;
-#ifdef MOT_DBG_TIMING
-          cand.pad = dbg_t[0]; cand.poly_off = dbg_t[1]; cand.poly_n = dbg_t[2];
-#endif
+          GATHER_T_STORE_RECT(cand);
           c.cand[(long)b * kMaxClusters + ci] = cand;
         }
       }

@@ -18,6 +18,7 @@
 //    is its first cell in the reference's scan order (for x { for y }), and the reference's cluster id is
 //    1 + (number of roots before it) — a popcount prefix. No recursion, no iteration-until-convergence.
 #include "mot_internal.h"
+#include "mot_debug.h"
 
 #ifndef MOT_HIPEMU
 #define MOT_LAUNCH_BOUNDS(n) __launch_bounds__(n)
@@ -125,13 +126,7 @@ ccl_kernel(MotDevParams p, ClusterBuffers c) {
   const int b = blockIdx.x;
   const int G = p.num_grid;
   const int tid = threadIdx.x;
-#ifdef MOT_DBG_CCL_TIMING   // phase clocks into the (idle at this point) polygon pool: tools/time_ccl.py
-  const long long t_start = clock64();
-  int* dbg = c.poly + (long)b * c.cap;
-#define CCL_T(slot) if (tid == 0) dbg[slot] = (int)(clock64() - t_start)
-#else
-#define CCL_T(slot)
-#endif
+  CCL_T_BEGIN(c, b);
   unsigned* __restrict__ ga = c.plane_a + (long)b * kPlaneWords;
   unsigned* __restrict__ gb = c.plane_b + (long)b * kPlaneWords;
 

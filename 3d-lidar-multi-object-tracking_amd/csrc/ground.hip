@@ -61,11 +61,7 @@ __device__ __forceinline__ void polar_cells(const MotDevParams& p, const float4 
   }
 #pragma unroll
   for (int k = 0; k < ITEMS; k++) {
-#ifdef MOT_DBG_CHEAPCELL   // timing ablation only (tools/ablate_k3.py): a trivial cell function, wrong results
-    int c = ((int)(pt[k].x * 0.5f) & 63) * MOT_NUM_BIN + ((int)(pt[k].y * 0.5f) & 63);
-#else
     int c = mot_polar_cell_try(p, pt[k].x, pt[k].y);
-#endif
     if (!((keep >> k) & 1u)) c = -1;
     cell[k] = c;
     if (c == -2) undecided |= 1u << k;
@@ -411,12 +407,7 @@ classify_compact_kernel(MotDevParams p, GroundBuffers g) {
     const unsigned long long ep = (unsigned long long)(g.epoch & kDescEpochMask) << kDescEpochShift;
     unsigned long long mine = ep | ((unsigned long long)(unsigned)tot_e << kDescCountBits) | (unsigned long long)(unsigned)tot_g;
     int excl_e = 0, excl_g = 0;
-#ifdef MOT_DBG_K3_NOLOOKBACK
-    excl_e = chunk * 1200; excl_g = chunk * 2896;
-    if (false) {
-#else
     if (chunk > 0) {
-#endif
       if (lane == 0) __hip_atomic_store(&desc[chunk], kDescAggregate | mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       int win_end = chunk;  // exclusive
       while (true) {        // wave-uniform

@@ -376,6 +376,11 @@ extern "C" int mot_create(const mot_params* params, int device, int max_points, 
   return MOT_OK;
 }
 
+extern "C" int mot_get_params(const mot_ctx* c, mot_params* out) {
+  if (!c || !out) return MOT_E_ARG;
+  *out = c->params;
+  return MOT_OK;
+}
 extern "C" const char* mot_last_error(const mot_ctx* c) { return c ? c->err.c_str() : "null context"; }
 extern "C" void* mot_stream(mot_ctx* c) { return c ? (void*)c->stream : nullptr; }
 extern "C" int mot_synchronize(mot_ctx* c) {

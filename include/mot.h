@@ -169,6 +169,8 @@ void mot_destroy(mot_ctx* ctx);
 int mot_reset(mot_ctx* ctx);
 /* the same for one stream */
 int mot_reset_slot(mot_ctx* ctx, int slot);
+/* the parameters the context was created with */
+int mot_get_params(const mot_ctx* ctx, mot_params* out);
 const char* mot_last_error(const mot_ctx* ctx);
 int mot_synchronize(mot_ctx* ctx);
 /* the HIP stream (hipStream_t) the context launches on, for callers that enqueue their own work */

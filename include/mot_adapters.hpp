@@ -77,6 +77,15 @@ inline mot_ctx* context() {
 inline void check(int rc) {
   if (rc != MOT_OK) throw std::runtime_error(std::string("mot: ") + mot_last_error(context()));
 }
+// the grid adapters are templates on the caller's array size: it must be the grid the context was created for (250 in OT/,
+// 200 in OT0/) — the library copies num_grid^2 cells in and out of the caller's array
+inline void require_grid(size_t G) {
+  mot_params p;
+  check(mot_get_params(context(), &p));
+  if ((size_t)p.num_grid != G)
+    throw std::runtime_error("mot_adapters: cartesianData is " + std::to_string(G) + " x " + std::to_string(G) + " but the context's preset has num_grid " +
+                             std::to_string(p.num_grid) + " — set mot_adapters::config().preset (MOT_PRESET_OBJECT_TRACKING0 for the 200-cell grid) before the first call");
+}
 inline std::vector<float> pack(const pcl::PointCloud<pcl::PointXYZ>& c) {
   std::vector<float> v(c.size() * 4 + 4);
   for (size_t i = 0; i < c.size(); i++) { v[4 * i] = c[i].x; v[4 * i + 1] = c[i].y; v[4 * i + 2] = c[i].z; v[4 * i + 3] = 0.f; }
@@ -140,6 +149,7 @@ template <size_t G>
 inline void componentClustering(pcl::PointCloud<pcl::PointXYZ>::Ptr elevatedCloud, std::array<std::array<int, G>, G>& cartesianData,
                                 int& numCluster) {
   using namespace mot_adapters;
+  require_grid(G);
   std::vector<float> in = pack(*elevatedCloud);
   std::vector<int32_t> grid(G * G);
   int nc = 0;
@@ -153,6 +163,7 @@ template <size_t G>
 inline void makeClusteredCloud(pcl::PointCloud<pcl::PointXYZ>::Ptr& elevatedCloud, std::array<std::array<int, G>, G> cartesianData,
                                pcl::PointCloud<pcl::PointXYZ>::Ptr& clusterCloud) {
   using namespace mot_adapters;
+  require_grid(G);
   std::vector<float> in = pack(*elevatedCloud);
   std::vector<int32_t> grid(G * G);
   for (size_t x = 0; x < G; x++) for (size_t y = 0; y < G; y++) grid[x * G + y] = cartesianData[x][y];
@@ -169,6 +180,7 @@ inline void makeClusteredCloud(pcl::PointCloud<pcl::PointXYZ>::Ptr& elevatedClou
 template <size_t G, typename ObstacleListT>
 inline void setObsMsg(pcl::PointCloud<pcl::PointXYZ>::Ptr& elevatedCloud, std::array<std::array<int, G>, G> cartesianData, ObstacleListT& clu_obs) {
   using namespace mot_adapters;
+  require_grid(G);
   std::vector<float> in = pack(*elevatedCloud);
   std::vector<int32_t> grid(G * G);
   for (size_t x = 0; x < G; x++) for (size_t y = 0; y < G; y++) grid[x * G + y] = cartesianData[x][y];
@@ -217,6 +229,7 @@ inline std::vector<pcl::PointCloud<pcl::PointXYZ>> boxFitting(pcl::PointCloud<pc
                                                               std::array<std::array<int, G>, G> cartesianData, int numCluster,
                                                               MarkerArrayT& ma) {
   using namespace mot_adapters;
+  require_grid(G);
   std::vector<float> in = pack(*elevatedCloud);
   std::vector<int32_t> grid(G * G);
   for (size_t x = 0; x < G; x++) for (size_t y = 0; y < G; y++) grid[x * G + y] = cartesianData[x][y];

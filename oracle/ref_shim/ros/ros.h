@@ -23,6 +23,11 @@
 #include <ros/time.h>
 #include <ros/wire.h>
 
+// rosconsole's printf-style macros, to stderr
+#define ROS_WARN(...) do { std::fprintf(stderr, "[ WARN] "); std::fprintf(stderr, __VA_ARGS__); std::fprintf(stderr, "\n"); } while (0)
+#define ROS_ERROR(...) do { std::fprintf(stderr, "[ERROR] "); std::fprintf(stderr, __VA_ARGS__); std::fprintf(stderr, "\n"); } while (0)
+#define ROS_INFO(...) do { std::fprintf(stderr, "[ INFO] "); std::fprintf(stderr, __VA_ARGS__); std::fprintf(stderr, "\n"); } while (0)
+
 namespace ros {
 namespace shim {
 struct State {

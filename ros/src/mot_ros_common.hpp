@@ -19,6 +19,21 @@ inline void check(mot_ctx* ctx, int rc, const char* what) {
   if (rc != MOT_OK) throw std::runtime_error(std::string(what) + ": " + mot_last_error(ctx));
 }
 
+// mot_track_step for a long-running node. The reference never frees a track (targets_ only grows, imm_ukf_jpda.cpp:972-989) and
+// only gets slower; the library holds at most ~max_tracks_total of them per stream and then reports MOT_E_CAPACITY on every step
+// (the records are still delivered). A node must not die of that (the launch file marks it required="true"): warn, publish what
+// came back, and start the stream's tracker over — the tracks re-form within lifeTimeThres_ frames.
+inline void track_step_or_restart(mot_ctx* ctx, int slot, const float* boxes_global, int n_boxes, double timestamp, mot_track* tracks,
+                                  int max_tracks, int* n_tracks) {
+  const int rc = mot_track_step(ctx, slot, boxes_global, n_boxes, timestamp, tracks, max_tracks, n_tracks);
+  if (rc == MOT_E_CAPACITY && *n_tracks <= max_tracks) {
+    ROS_WARN("tracker: %s — restarting the tracker of this stream (raise ~max_tracks_total to postpone this)", mot_last_error(ctx));
+    check(ctx, mot_reset_slot(ctx, slot), "mot_reset_slot");
+    return;
+  }
+  check(ctx, rc, "mot_track_step");
+}
+
 // private parameters common to the nodes (read from a NodeHandle("~")): ~device (HIP ordinal), ~max_points, ~preset
 // (0 = object_tracking, 1 = object_tracking0), ~max_tracks_total
 struct Settings { int device = 0, max_points = 262144, preset = MOT_PRESET_OBJECT_TRACKING, max_tracks_total = 16384; };

@@ -104,7 +104,7 @@ class PipelineNode {
       for (size_t i = 0; i < corners_global.size(); i++) { boxes_[3 * i] = corners_global[i].x; boxes_[3 * i + 1] = corners_global[i].y; boxes_[3 * i + 2] = corners_global[i].z; }
     }
     int n_tracks = 0;
-    mot_ros::check(ctx_, mot_track_step(ctx_, 0, boxes_.data(), n_boxes, timestamp, tracks_.data(), (int)tracks_.size(), &n_tracks), "mot_track_step");
+    mot_ros::track_step_or_restart(ctx_, 0, boxes_.data(), n_boxes, timestamp, tracks_.data(), (int)tracks_.size(), &n_tracks);
 
     // track positions and the boxes of the shown tracks, back in the sensor frame for drawing
     pcl::PointCloud<pcl::PointXYZ> targets, targets_local, shown, shown_local;

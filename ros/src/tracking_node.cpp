@@ -74,7 +74,7 @@ class TrackingNode {
     for (size_t i = 0; i < corners_global.size(); i++) { boxes_global_[3 * i] = corners_global[i].x; boxes_global_[3 * i + 1] = corners_global[i].y; boxes_global_[3 * i + 2] = corners_global[i].z; }
 
     int n_tracks = 0;
-    mot_ros::check(ctx_, mot_track_step(ctx_, 0, boxes_global_.data(), n_boxes, timestamp, tracks_.data(), (int)tracks_.size(), &n_tracks), "mot_track_step");
+    mot_ros::track_step_or_restart(ctx_, 0, boxes_global_.data(), n_boxes, timestamp, tracks_.data(), (int)tracks_.size(), &n_tracks);
 
     // track positions back into the sensor frame for drawing
     pcl::PointCloud<pcl::PointXYZ> targets, targets_local;
