@@ -108,6 +108,41 @@ __device__ __forceinline__ double wave_sum_f64(double v) {
 #endif
 }
 
+// ---- reductions over ONE DPP row (16 lanes): every lane of the row receives its row's result. The tracker packs one track
+// per row, four tracks per wave.
+__device__ __forceinline__ double row_sum_f64(double v) {
+#ifndef MOT_HIPEMU
+#define MOT_DPP_F64R(x, ctrl)                                                                        \
+  __hiloint2double(__builtin_amdgcn_update_dpp(0, __double2hiint(x), (ctrl), 0xf, 0xf, true),          \
+                   __builtin_amdgcn_update_dpp(0, __double2loint(x), (ctrl), 0xf, 0xf, true))
+  v += MOT_DPP_F64R(v, 0xB1);    // quad_perm [1,0,3,2]
+  v += MOT_DPP_F64R(v, 0x4E);    // quad_perm [2,3,0,1]
+  v += MOT_DPP_F64R(v, 0x141);   // row_half_mirror
+  v += MOT_DPP_F64R(v, 0x140);   // row_mirror
+#undef MOT_DPP_F64R
+  return v;
+#else
+  for (int m = 1; m <= 8; m <<= 1) v += __shfl_xor(v, m, 64);
+  return v;
+#endif
+}
+__device__ __forceinline__ unsigned long long row_or_u64(unsigned long long v) {
+#ifndef MOT_HIPEMU
+#define MOT_DPP_U64R(x, ctrl)                                                                                                      \
+  (((unsigned long long)(unsigned)__builtin_amdgcn_update_dpp(0, (int)((x) >> 32), (ctrl), 0xf, 0xf, true) << 32) |               \
+   (unsigned)__builtin_amdgcn_update_dpp(0, (int)(x), (ctrl), 0xf, 0xf, true))
+  v |= MOT_DPP_U64R(v, 0xB1);
+  v |= MOT_DPP_U64R(v, 0x4E);
+  v |= MOT_DPP_U64R(v, 0x141);
+  v |= MOT_DPP_U64R(v, 0x140);
+#undef MOT_DPP_U64R
+  return v;
+#else
+  for (int m = 1; m <= 8; m <<= 1) v |= __shfl_xor(v, m, 64);
+  return v;
+#endif
+}
+
 struct OpMinI { __device__ __forceinline__ int operator()(int a, int b) const { return a < b ? a : b; } };
 struct OpMaxI { __device__ __forceinline__ int operator()(int a, int b) const { return a > b ? a : b; } };
 struct OpMinU64 { __device__ __forceinline__ unsigned long long operator()(unsigned long long a, unsigned long long b) const { return a < b ? a : b; } };

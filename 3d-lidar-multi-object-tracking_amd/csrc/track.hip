@@ -39,17 +39,6 @@
 
 #define PI_D 3.14159265358979323846
 
-struct WaveScratch {
-  double x[3][5], P[3][25];      // per-model state being advanced
-  double xo[3][5], Po[3][25];    // copies (mixing inputs)
-  double xm[5], Pm[25];          // merged
-  double mode[3], mm[3][3];
-  double L[3][49];               // Cholesky factors of the augmented covariances
-  double Xs[3][75];              // predicted sigma points, 5 x 15 per model
-  double z[3][2], S[3][4], K[3][10], Tc[3][10];
-  double red[64];                // scratch for reductions
-};
-
 __device__ __forceinline__ int tlane() { return (int)(threadIdx.x & 63); }
 // `while (a > M_PI) a -= 2. * M_PI; while (a < -M_PI) a += 2. * M_PI;` — the reference's angle normalisation (ukf.cpp, imm_ukf_jpda.cpp
 // passim). Its cost is |a| / 2 pi iterations: a diverging track (a failed Cholesky leaves un-rooted covariance entries in the
@@ -66,7 +55,6 @@ __device__ __forceinline__ double wrap_pi(double a) {
 }
 __device__ __forceinline__ double det2(const double* m) { return m[0] * m[3] - m[1] * m[2]; }
 __device__ __forceinline__ void inv2(const double* m, double* o) { double d = det2(m); o[0] = m[3] / d; o[1] = -m[1] / d; o[2] = -m[2] / d; o[3] = m[0] / d; }
-__device__ __forceinline__ double wave_sum_d(double v) { return wave_sum_f64(v); }
 
 // determinant of a 5x5 (partial-pivot elimination, what Eigen's PartialPivLU::determinant amounts to). Every index below
 // is a compile-time constant: the pivot row is brought up by conditional swaps against each candidate row, never by
@@ -120,67 +108,118 @@ __device__ void track_init(DevTrack* t, double zx, double zy) {
   for (int i = 0; i < 24; i++) { t->bbox[i] = 0.f; t->best_bbox[i] = 0.f; }
 }
 
+// ---------------------------------------------------------------------------------------------- lanes and tracks
+// A track is worked on by a GROUP of 16 lanes — one DPP row — and a wave carries FOUR tracks. The filter's matrices are
+// tiny (5 x 5, 15 sigma points, 3 models): with a whole wave per track most instructions ran with 3, 15 or 1 of 64 lanes
+// doing anything, and the kernels were bound by exactly that — instruction issue (an fp64 instruction holds a SIMD for 8
+// cycles whatever the number of active lanes; profiles/r02_tracker_load_*.txt). Sixteen lanes fit every stage: 15 sigma
+// points of one model per pass, 15 state entries, 25 / 75 matrix entries in 2 / 5 passes, boxes 16 at a time — the same
+// instruction stream now advances four tracks. All four groups execute the same code with their own predicate (`act`, `ok`):
+// loops run to the wave's maximum trip count, wave-level operations (ballots, shuffles, row reductions) are never inside
+// divergent control flow.
+constexpr int kGroupLanes = 16;
+constexpr int kGroupsPerWave = 4;
+__device__ __forceinline__ int glane() { return (int)(threadIdx.x & 15); }
+__device__ __forceinline__ int ggroup() { return (int)((threadIdx.x >> 4) & 3); }
+
+struct GroupScratch {            // per track in flight, in LDS
+  double x[3][5], P[3][25];      // per-model state being advanced
+  double xo[3][5], Po[3][25];    // copies (mixing inputs) / updated state
+  double xm[5], Pm[25];          // merged
+  double mode[3], mm[3][3];
+  double L[3][25], Ld[3][2];     // Cholesky factors of the augmented covariances: the 5 x 5 block and the two trailing diagonal entries
+  double Xs[3][75];              // predicted sigma points, 5 x 15 per model (prediction); exp() of the gated boxes (update)
+  double z[3][2], S[3][4], K[3][10], Tc[3][10];
+};
+
 // sigma-point weights, ukf.cpp:268-274: lambda_aug = 3 - 7
 __device__ __forceinline__ double ukf_w(int i) { return i == 0 ? (-4.0 / (-4.0 + 7.0)) : (0.5 / (7.0 + -4.0)); }
 
-// ProcessIMMUKF(dt), ukf.cpp:507-527 — whole wave, state in ws
-__device__ void process_imm_ukf(WaveScratch* ws, double dt) {
-  const int lane = tlane();
-  // MixingProbability :439-456 (p1_,p2_,p3_ = rows of the transition matrix :139-154)
-  if (lane < 3) {
-    const int j = lane;
-    const double pj[3] = {j == 0 ? 0.9 : 0.05, j == 1 ? 0.9 : 0.05, j == 2 ? 0.9 : 0.05};  // p[i][j]
-    double sum = ws->mode[0] * pj[0] + ws->mode[1] * pj[1] + ws->mode[2] * pj[2];
-#pragma unroll
-    for (int i = 0; i < 3; i++) ws->mm[i][j] = ws->mode[i] * pj[i] / sum;
+__device__ void load_track(GroupScratch* G, const DevTrack* t, bool act) {
+  const int s = glane();
+  if (act) {
+    if (s < 15) G->x[s / 5][s % 5] = t->x[1 + s / 5][s % 5];
+    for (int e = s; e < 75; e += kGroupLanes) G->P[e / 25][e % 25] = t->P[1 + e / 25][e % 25];
+    if (s < 5) G->xm[s] = t->x[0][s];
+    for (int e = s; e < 25; e += kGroupLanes) G->Pm[e] = t->P[0][e];
+    if (s < 3) G->mode[s] = t->mode[s];
+    if (s < 6) G->z[s / 2][s % 2] = t->zpred[s / 2][s % 2];
+    if (s < 12) G->S[s / 4][s % 4] = t->S[s / 4][s % 4];
+    for (int e = s; e < 30; e += kGroupLanes) G->K[e / 10][e % 10] = t->K[e / 10][e % 10];
   }
-  for (int e = lane; e < 15; e += 64) ws->xo[e / 5][e % 5] = ws->x[e / 5][e % 5];
-  for (int e = lane; e < 75; e += 64) ws->Po[e / 25][e % 25] = ws->P[e / 25][e % 25];
+  MOT_WAVE_SYNC();
+}
+__device__ void store_models(const GroupScratch* G, DevTrack* t, bool act) {
+  const int s = glane();
+  if (!act) return;
+  if (s < 15) t->x[1 + s / 5][s % 5] = G->x[s / 5][s % 5];
+  for (int e = s; e < 75; e += kGroupLanes) t->P[1 + e / 25][e % 25] = G->P[e / 25][e % 25];
+  if (s < 6) t->zpred[s / 2][s % 2] = G->z[s / 2][s % 2];
+  if (s < 12) t->S[s / 4][s % 4] = G->S[s / 4][s % 4];
+  for (int e = s; e < 30; e += kGroupLanes) t->K[e / 10][e % 10] = G->K[e / 10][e % 10];
+}
+
+// ProcessIMMUKF(dt), ukf.cpp:507-527 — the group's track, state in G; `ok` is the group's predicate
+__device__ void process_imm_ukf(GroupScratch* G, double dt, bool ok) {
+  const int s = glane();
+  // MixingProbability :439-456 (p1_,p2_,p3_ = rows of the transition matrix :139-154)
+  if (ok && s < 3) {
+    const int j = s;
+    const double pj[3] = {j == 0 ? 0.9 : 0.05, j == 1 ? 0.9 : 0.05, j == 2 ? 0.9 : 0.05};  // p[i][j]
+    double sum = G->mode[0] * pj[0] + G->mode[1] * pj[1] + G->mode[2] * pj[2];
+#pragma unroll
+    for (int i = 0; i < 3; i++) G->mm[i][j] = G->mode[i] * pj[i] / sum;
+  }
+  if (ok) {
+    if (s < 15) G->xo[s / 5][s % 5] = G->x[s / 5][s % 5];
+    for (int e = s; e < 75; e += kGroupLanes) G->Po[e / 25][e % 25] = G->P[e / 25][e % 25];
+  }
   MOT_WAVE_SYNC();
   // Interaction :458-500
-  if (lane < 15) {
-    int j = lane / 5, r = lane % 5;
-    double v = ws->mm[0][j] * ws->xo[0][r] + ws->mm[1][j] * ws->xo[1][r] + ws->mm[2][j] * ws->xo[2][r];
-    if (r == 3) v = wrap_pi(ws->xo[j][3]);  // yaw is not mixed
-    ws->x[j][r] = v;
+  if (ok && s < 15) {
+    int j = s / 5, r = s % 5;
+    double v = G->mm[0][j] * G->xo[0][r] + G->mm[1][j] * G->xo[1][r] + G->mm[2][j] * G->xo[2][r];
+    if (r == 3) v = wrap_pi(G->xo[j][3]);  // yaw is not mixed
+    G->x[j][r] = v;
   }
   MOT_WAVE_SYNC();
-  for (int e = lane; e < 75; e += 64) {
-    int j = e / 25, r = (e % 25) / 5, c = e % 5;
-    double acc = 0;
+  if (ok)
+    for (int e = s; e < 75; e += kGroupLanes) {
+      int j = e / 25, r = (e % 25) / 5, c = e % 5;
+      double acc = 0;
 #pragma unroll
-    for (int i = 0; i < 3; i++) acc = acc + ws->mm[i][j] * (ws->Po[i][r * 5 + c] + (ws->xo[i][r] - ws->x[j][r]) * (ws->xo[i][c] - ws->x[j][c]));
-    ws->P[j][r * 5 + c] = acc;
-  }
+      for (int i = 0; i < 3; i++) acc = acc + G->mm[i][j] * (G->Po[i][r * 5 + c] + (G->xo[i][r] - G->x[j][r]) * (G->xo[i][c] - G->x[j][c]));
+      G->P[j][r * 5 + c] = acc;
+    }
   MOT_WAVE_SYNC();
   // Prediction(dt, m) :630-772. Augmented covariance, Eigen 3.2.10 LLT::unblocked semantics: a non-positive pivot
   // stops the factorisation and matrixL() returns the partially overwritten lower triangle.
-  if (lane < 3) {
+  if (ok && s < 3) {
     // P_aug = blockdiag(P, std_a^2, std_yawdd^2): rows 5 and 6 have no off-diagonal entries, so the 7x7 factorisation is
     // the 5x5 one of P (kept in registers) plus two square roots — unless an earlier pivot already failed, in which case
     // Eigen's loop has stopped and those diagonal entries are still the un-rooted inputs.
-    const int m = lane;
+    const int m = s;
     const double std_a = m == 2 ? 3. : 2., std_yawdd = m == 2 ? 3. : 2.;  // ukf.cpp:68-73
     double a[25];
 #pragma unroll
-    for (int i = 0; i < 25; i++) a[i] = ws->P[m][i];
-    bool ok = true;
+    for (int i = 0; i < 25; i++) a[i] = G->P[m][i];
+    bool good = true;
 #pragma unroll
     for (int k = 0; k < 5; k++) {
-      if (ok) {
+      if (good) {
         double xk = a[k * 5 + k];
 #pragma unroll
         for (int j = 0; j < 5; j++) if (j < k) xk -= a[k * 5 + j] * a[k * 5 + j];
-        if (xk <= 0) ok = false;
+        if (xk <= 0) good = false;
         else {
           a[k * 5 + k] = xk = sqrt(xk);
 #pragma unroll
           for (int r = 0; r < 5; r++)
             if (r > k) {
-              double s = 0;
+              double sm = 0;
 #pragma unroll
-              for (int j = 0; j < 5; j++) if (j < k) s += a[r * 5 + j] * a[k * 5 + j];
-              a[r * 5 + k] -= s;
+              for (int j = 0; j < 5; j++) if (j < k) sm += a[r * 5 + j] * a[k * 5 + j];
+              a[r * 5 + k] -= sm;
             }
           double inv = 1.0 / xk;  // Eigen 3.2: `A21 /= x` multiplies by the reciprocal
 #pragma unroll
@@ -188,109 +227,117 @@ __device__ void process_imm_ukf(WaveScratch* ws, double dt) {
         }
       }
     }
-    double* L = ws->L[m];
 #pragma unroll
-    for (int r = 0; r < 7; r++)
+    for (int r = 0; r < 5; r++)
 #pragma unroll
-      for (int c = 0; c < 7; c++) {
-        double v = 0;
-        if (r < 5 && c <= r) v = a[r * 5 + c];
-        else if (r == 5 && c == 5) v = ok ? std_a : std_a * std_a;
-        else if (r == 6 && c == 6) v = ok ? std_yawdd : std_yawdd * std_yawdd;
-        L[r * 7 + c] = v;
+      for (int c = 0; c < 5; c++) G->L[m][r * 5 + c] = c <= r ? a[r * 5 + c] : 0.0;
+    G->Ld[m][0] = good ? std_a : std_a * std_a;
+    G->Ld[m][1] = good ? std_yawdd : std_yawdd * std_yawdd;
+  }
+  MOT_WAVE_SYNC();
+  // 15 sigma points of ONE model per pass, a lane each: Cv :573, Ctrv :539, randomMotion :602 (the model is uniform over the
+  // wave, so only that model's code runs in a pass)
+#pragma unroll 1
+  for (int m = 0; m < 3; m++) {
+    if (ok && s < 15) {
+      const int i = s;
+      const double sc = sqrt(-4.0 + 7.0);
+      const int col = i <= 7 ? i - 1 : i - 8;   // column of the augmented factor this sigma point moves along
+      double xa[7];
+#pragma unroll
+      for (int r = 0; r < 7; r++) {
+        const double base = r < 5 ? G->x[m][r] : 0.0;
+        double l = 0.0;
+        if (r < 5) l = (col >= 0 && col < 5) ? G->L[m][r * 5 + col] : 0.0;   // (the stored upper triangle is zero)
+        else if (r == 5) l = col == 5 ? G->Ld[m][0] : 0.0;
+        else l = col == 6 ? G->Ld[m][1] : 0.0;
+        if (i == 0) xa[r] = base;
+        else if (i <= 7) xa[r] = base + sc * l;
+        else xa[r] = base - sc * l;
       }
+      const double p_x = xa[0], p_y = xa[1], v = xa[2], yaw = xa[3], yawd = xa[4], nu_a = xa[5], nu_yawdd = xa[6];
+      double sp[5];
+      if (m == 2) { sp[0] = p_x; sp[1] = p_y; sp[2] = v; sp[3] = yaw; sp[4] = yawd; }
+      else {
+        double px_p, py_p;
+        double sy, cy;   // every sin(yaw) / cos(yaw) of the reference's expressions: evaluated once
+        sincos(yaw, &sy, &cy);
+        if (m == 0) { px_p = p_x + v * cy * dt; py_p = p_y + v * sy * dt; }
+        else if (fabs(yawd) > 0.001) {
+          double s2, c2;
+          sincos(yaw + yawd * dt, &s2, &c2);
+          px_p = p_x + v / yawd * (s2 - sy);
+          py_p = p_y + v / yawd * (cy - c2);
+        } else { px_p = p_x + v * dt * cy; py_p = p_y + v * dt * sy; }
+        double v_p = v;
+        double yaw_p = m == 0 ? yaw : yaw + yawd * dt;
+        double yawd_p = yawd;
+        px_p = px_p + 0.5 * nu_a * dt * dt * cy;
+        py_p = py_p + 0.5 * nu_a * dt * dt * sy;
+        v_p = v_p + nu_a * dt;
+        yaw_p = yaw_p + 0.5 * nu_yawdd * dt * dt;
+        yawd_p = yawd_p + nu_yawdd * dt;
+        sp[0] = px_p; sp[1] = py_p; sp[2] = v_p; sp[3] = yaw_p; sp[4] = yawd_p;
+      }
+#pragma unroll
+      for (int r = 0; r < 5; r++) G->Xs[m][r * 15 + i] = sp[r];
+    }
   }
   MOT_WAVE_SYNC();
-  if (lane < 45) {  // one lane per (model, sigma point): Cv :573, Ctrv :539, randomMotion :602
-    const int m = lane / 15, i = lane % 15;
-    const double sc = sqrt(-4.0 + 7.0);
-    double xa[7];
-#pragma unroll
-    for (int r = 0; r < 7; r++) {
-      double base = r < 5 ? ws->x[m][r] : 0.0;
-      if (i == 0) xa[r] = base;
-      else if (i <= 7) xa[r] = base + sc * ws->L[m][r * 7 + (i - 1)];
-      else xa[r] = base - sc * ws->L[m][r * 7 + (i - 8)];
-    }
-    const double p_x = xa[0], p_y = xa[1], v = xa[2], yaw = xa[3], yawd = xa[4], nu_a = xa[5], nu_yawdd = xa[6];
-    double s[5];
-    if (m == 2) { s[0] = p_x; s[1] = p_y; s[2] = v; s[3] = yaw; s[4] = yawd; }
-    else {
-      double px_p, py_p;
-      double sy, cy;   // every sin(yaw) / cos(yaw) of the reference's expressions: evaluated once
-      sincos(yaw, &sy, &cy);
-      if (m == 0) { px_p = p_x + v * cy * dt; py_p = p_y + v * sy * dt; }
-      else if (fabs(yawd) > 0.001) {
-        double s2, c2;
-        sincos(yaw + yawd * dt, &s2, &c2);
-        px_p = p_x + v / yawd * (s2 - sy);
-        py_p = p_y + v / yawd * (cy - c2);
-      } else { px_p = p_x + v * dt * cy; py_p = p_y + v * dt * sy; }
-      double v_p = v;
-      double yaw_p = m == 0 ? yaw : yaw + yawd * dt;
-      double yawd_p = yawd;
-      px_p = px_p + 0.5 * nu_a * dt * dt * cy;
-      py_p = py_p + 0.5 * nu_a * dt * dt * sy;
-      v_p = v_p + nu_a * dt;
-      yaw_p = yaw_p + 0.5 * nu_yawdd * dt * dt;
-      yawd_p = yawd_p + nu_yawdd * dt;
-      s[0] = px_p; s[1] = py_p; s[2] = v_p; s[3] = yaw_p; s[4] = yawd_p;
-    }
-#pragma unroll
-    for (int r = 0; r < 5; r++) ws->Xs[m][r * 15 + i] = s[r];
-  }
-  MOT_WAVE_SYNC();
-  if (lane < 15) {  // predicted mean :736-742
-    int m = lane / 5, r = lane % 5;
+  if (ok && s < 15) {  // predicted mean :736-742
+    int m = s / 5, r = s % 5;
     double acc = 0;
 #pragma unroll
-    for (int i = 0; i < 15; i++) acc = acc + ukf_w(i) * ws->Xs[m][r * 15 + i];
+    for (int i = 0; i < 15; i++) acc = acc + ukf_w(i) * G->Xs[m][r * 15 + i];
     if (r == 3) acc = wrap_pi(acc);
-    ws->x[m][r] = acc;
+    G->x[m][r] = acc;
   }
   MOT_WAVE_SYNC();
-  for (int e = lane; e < 75; e += 64) {  // predicted covariance :743-749
-    int m = e / 25, r = (e % 25) / 5, c = e % 5;
-    double acc = 0;
+  if (ok)
+    for (int e = s; e < 75; e += kGroupLanes) {  // predicted covariance :743-749
+      int m = e / 25, r = (e % 25) / 5, c = e % 5;
+      double acc = 0;
 #pragma unroll
-    for (int i = 0; i < 15; i++) {
-      double dr = ws->Xs[m][r * 15 + i] - ws->x[m][r], dc = ws->Xs[m][c * 15 + i] - ws->x[m][c];
-      if (r == 3) dr = wrap_pi(dr);
-      if (c == 3) dc = wrap_pi(dc);
-      acc = acc + (ukf_w(i) * dr) * dc;
+      for (int i = 0; i < 15; i++) {
+        double dr = G->Xs[m][r * 15 + i] - G->x[m][r], dc = G->Xs[m][c * 15 + i] - G->x[m][c];
+        if (r == 3) dr = wrap_pi(dr);
+        if (c == 3) dc = wrap_pi(dc);
+        acc = acc + (ukf_w(i) * dr) * dc;
+      }
+      G->P[m][r * 5 + c] = acc;
     }
-    ws->P[m][r * 5 + c] = acc;
-  }
   // UpdateLidar(m) :778-902
-  if (lane < 6) {
-    int m = lane / 2, c = lane % 2;
+  if (ok && s < 6) {
+    int m = s / 2, c = s % 2;
     double acc = 0;
 #pragma unroll
-    for (int i = 0; i < 15; i++) acc = acc + ukf_w(i) * ws->Xs[m][c * 15 + i];
-    ws->z[m][c] = acc;
+    for (int i = 0; i < 15; i++) acc = acc + ukf_w(i) * G->Xs[m][c * 15 + i];
+    G->z[m][c] = acc;
   }
   MOT_WAVE_SYNC();
-  if (lane < 12) {
-    int m = lane / 4, r = (lane % 4) / 2, c = lane % 2;
+  if (ok && s < 12) {
+    int m = s / 4, r = (s % 4) / 2, c = s % 2;
     double acc = 0;
 #pragma unroll
-    for (int i = 0; i < 15; i++) acc = acc + (ukf_w(i) * (ws->Xs[m][r * 15 + i] - ws->z[m][r])) * (ws->Xs[m][c * 15 + i] - ws->z[m][c]);
+    for (int i = 0; i < 15; i++) acc = acc + (ukf_w(i) * (G->Xs[m][r * 15 + i] - G->z[m][r])) * (G->Xs[m][c * 15 + i] - G->z[m][c]);
     if (r == c) acc = acc + 0.15 * 0.15;  // R, ukf.cpp:91-94
-    ws->S[m][r * 2 + c] = acc;
+    G->S[m][r * 2 + c] = acc;
   }
-  if (lane >= 16 && lane < 46) {
-    int e = lane - 16, m = e / 10, r = (e % 10) / 2, c = e % 2;
-    double acc = 0;
+  if (ok)
+    for (int e = s; e < 30; e += kGroupLanes) {
+      int m = e / 10, r = (e % 10) / 2, c = e % 2;
+      double acc = 0;
 #pragma unroll
-    for (int i = 0; i < 15; i++) acc = acc + (ukf_w(i) * (ws->Xs[m][r * 15 + i] - ws->x[m][r])) * (ws->Xs[m][c * 15 + i] - ws->z[m][c]);
-    ws->Tc[m][r * 2 + c] = acc;
-  }
+      for (int i = 0; i < 15; i++) acc = acc + (ukf_w(i) * (G->Xs[m][r * 15 + i] - G->x[m][r])) * (G->Xs[m][c * 15 + i] - G->z[m][c]);
+      G->Tc[m][r * 2 + c] = acc;
+    }
   MOT_WAVE_SYNC();
-  if (lane < 30) {
-    int m = lane / 10, r = (lane % 10) / 2, c = lane % 2;
-    double Si[4]; inv2(ws->S[m], Si);
-    ws->K[m][r * 2 + c] = ws->Tc[m][r * 2 + 0] * Si[0 * 2 + c] + ws->Tc[m][r * 2 + 1] * Si[1 * 2 + c];
-  }
+  if (ok)
+    for (int e = s; e < 30; e += kGroupLanes) {
+      int m = e / 10, r = (e % 10) / 2, c = e % 2;
+      double Si[4]; inv2(G->S[m], Si);
+      G->K[m][r * 2 + c] = G->Tc[m][r * 2 + 0] * Si[0 * 2 + c] + G->Tc[m][r * 2 + 1] * Si[1 * 2 + c];
+    }
   MOT_WAVE_SYNC();
 }
 
@@ -381,27 +428,6 @@ __device__ void update_bb(const MotTrackParams& tp, DevTrack* u) {
   for (int i = 0; i < 24; i++) { u->bbox[i] = bb[i]; u->best_bbox[i] = best[i]; }
 }
 
-__device__ void load_track(WaveScratch* ws, const DevTrack* t) {
-  const int lane = tlane();
-  for (int e = lane; e < 15; e += 64) ws->x[e / 5][e % 5] = t->x[1 + e / 5][e % 5];
-  for (int e = lane; e < 75; e += 64) ws->P[e / 25][e % 25] = t->P[1 + e / 25][e % 25];
-  if (lane < 5) ws->xm[lane] = t->x[0][lane];
-  if (lane < 25) ws->Pm[lane] = t->P[0][lane];
-  if (lane < 3) ws->mode[lane] = t->mode[lane];
-  if (lane < 6) ws->z[lane / 2][lane % 2] = t->zpred[lane / 2][lane % 2];
-  if (lane < 12) ws->S[lane / 4][lane % 4] = t->S[lane / 4][lane % 4];
-  if (lane < 30) ws->K[lane / 10][lane % 10] = t->K[lane / 10][lane % 10];
-  MOT_WAVE_SYNC();
-}
-__device__ void store_models(const WaveScratch* ws, DevTrack* t) {
-  const int lane = tlane();
-  for (int e = lane; e < 15; e += 64) t->x[1 + e / 5][e % 5] = ws->x[e / 5][e % 5];
-  for (int e = lane; e < 75; e += 64) t->P[1 + e / 25][e % 25] = ws->P[e / 25][e % 25];
-  if (lane < 6) t->zpred[lane / 2][lane % 2] = ws->z[lane / 2][lane % 2];
-  if (lane < 12) t->S[lane / 4][lane % 4] = ws->S[lane / 4][lane % 4];
-  if (lane < 30) t->K[lane / 10][lane % 10] = ws->K[lane / 10][lane % 10];
-}
-
 // =============================================================================================== the frame step
 // Four launches per step and context, all stream-ordered:
 //   T0 track_prep_kernel     (B workgroups)  boxes -> global frame, box centres, first-frame seed, work list of (stream, live track)
@@ -410,7 +436,8 @@ __device__ void store_models(const WaveScratch* ws, DevTrack* t) {
 //   T3 track_finish_kernel   (B workgroups)  phases PD, PE, PF, the live list of the next step
 // The first version ran all phases in ONE workgroup per stream (8 waves): 128 streams kept half the chip idle and a stream
 // with 64 live tracks walked them 8 at a time (745 k cycles per step). The per-track phases now draw (stream, track) items
-// from one list across all streams of the context, so every CU works whatever the split of tracks over streams.
+// from one list across all streams of the context, four per wave (see "lanes and tracks"), so every CU works whatever the
+// split of tracks over streams.
 
 // ---- T0
 __global__ void MOT_LAUNCH_BOUNDS(256)
@@ -470,67 +497,81 @@ track_prep_kernel(TrackBuffers tb) {
   for (int i = tid; i < nlive; i += 256) { TrackItem it; it.b = b; it.li = i; items[i] = it; }
 }
 
-// ---- T1: PA — prediction + gating of one live track by one wave
-__device__ void predict_item(const TrackBuffers& tb, WaveScratch* ws, int b, int li) {
-  const int lane = tlane();
-  const TrackFrameArgs args = tb.args[b];
+// ---- T1: PA — prediction + gating; the wave's four groups each take one (stream, live track) item
+__device__ void predict_group(const TrackBuffers& tb, GroupScratch* G, int b, int li, bool act) {
+  const int s = glane(), grp = ggroup();
   const MotTrackParams& tp = tb.tp;
-  const int M = tb.m_dev ? min(tb.m_dev[b * kCountsStride + kCntBoxes], kMaxBoxesPerFrame) : args.m;
-  const int nW = (M + 63) >> 6;   // 64-box words of the gate bit-masks in use this frame (the rest is neither written nor read)
+  TrackFrameArgs args; args.dt = 0; args.m = 0;
+  int M = 0, t = 0;
   int* __restrict__ live = tb.live + (long)b * 2 * tb.T;
   int* __restrict__ liveok = live + tb.T;
-  const int t = live[li];
+  if (act) {
+    args = tb.args[b];
+    M = tb.m_dev ? min(tb.m_dev[b * kCountsStride + kCntBoxes], kMaxBoxesPerFrame) : args.m;
+    t = live[li];
+  }
   DevTrack* u = tb.tracks + (long)b * tb.T + t;
   unsigned long long* __restrict__ gate = tb.gate + ((long)b * tb.T + t) * kGateWords;
   unsigned long long* __restrict__ prog = tb.prog + ((long)b * tb.T + t) * kGateWords;
   const Vec2d* __restrict__ cp = tb.cp + (long)b * kMaxBoxesPerFrame;
-  const bool secondInit = u->track_num == 1;
-  if (lane == 0) u->is_vis = 0;   // isVisBB_ = false (:813); tracks that are dead already are cleared by the finish kernel
-  load_track(ws, u);
-  bool ok = true;
-  if (det5(ws->Pm) > 10 || ws->Pm[24] > 1000) ok = false;  // divergence guard :828-831
+  const bool secondInit = act && u->track_num == 1;
+  if (act && s == 0) u->is_vis = 0;   // isVisBB_ = false (:813); tracks that are dead already are cleared by the finish kernel
+  load_track(G, u, act);
+  bool ok = act;
+  if (ok && (det5(G->Pm) > 10 || G->Pm[24] > 1000)) ok = false;  // divergence guard :828-831
+  process_imm_ukf(G, args.dt, ok);  // :840
+  store_models(G, u, ok);
+  double Si[4] = {0, 0, 0, 0}, zx = 0, zy = 0;
   if (ok) {
-    process_imm_ukf(ws, args.dt);  // :840
-    store_models(ws, u);
-    int mx = find_max_model(ws->S);
+    int mx = find_max_model(G->S);
     double maxS[4];
-    for (int k = 0; k < 4; k++) maxS[k] = ws->S[mx][k] * 4;  // :844
+    for (int k = 0; k < 4; k++) maxS[k] = G->S[mx][k] * 4;  // :844
     double detS = det2(maxS);
     if (detS != detS || detS > 10) ok = false;  // :848-851
-    if (ok) {
-      // measurementValidation :205-257 as a bit-mask over the boxes; second-init keeps the running minimum
-      double Si[4]; inv2(maxS, Si);
-      const double zx = ws->z[mx][0], zy = ws->z[mx][1];
-      double run_min = 999;  // smallestNIS
-      for (int w = 0; w < nW; w++) {
-        int k = w * 64 + lane;
-        bool g = false; double nis = 1e300;
-        if (k < M) {
-          const Vec2d c = cp[k];
-          double d0 = c.x - zx, d1 = c.y - zy;
-          double t0 = d0 * Si[0] + d1 * Si[2], t1 = d0 * Si[1] + d1 * Si[3];
-          nis = t0 * d0 + t1 * d1;
-          g = nis < tp.gamma_g;
-        }
-        unsigned long long gm = __ballot(g);
-        unsigned long long pm = 0ull;
-        if (secondInit && gm) {
-          // `nis < smallestNIS` evaluated box by box: a box is kept iff it beats every earlier gated box
-          double v = g ? nis : 1e300, pre = v;
+    else { inv2(maxS, Si); zx = G->z[mx][0]; zy = G->z[mx][1]; }
+  }
+  // measurementValidation :205-257 as a bit-mask over the boxes, 16 boxes of the group's stream at a time; a track in its
+  // second initialisation keeps the running minimum ("progressive minima": `nis < smallestNIS` evaluated box by box)
+  const int Mg = ok ? M : 0;
+  const int Mmax = wave_reduce_i32(Mg, OpMaxI());
+  double run_min = 999;  // smallestNIS
+  unsigned long long acc_g = 0ull, acc_p = 0ull;
+  for (int k0 = 0; k0 < Mmax; k0 += kGroupLanes) {
+    const int k = k0 + s;
+    bool g = false; double nis = 1e300;
+    if (k < Mg) {
+      const Vec2d c = cp[k];
+      double d0 = c.x - zx, d1 = c.y - zy;
+      double t0 = d0 * Si[0] + d1 * Si[2], t1 = d0 * Si[1] + d1 * Si[3];
+      nis = t0 * d0 + t1 * d1;
+      g = nis < tp.gamma_g;
+    }
+    const unsigned long long bal = __ballot(g);
+    unsigned pbits = 0u;
+    if (__ballot(g && secondInit)) {   // uniform: some group of the wave needs the ordered minimum
+      double v = g ? nis : 1e300, pre = v;
 #pragma unroll
-          for (int d = 1; d < 64; d <<= 1) { double o = __shfl_up(pre, d, 64); if (lane >= d) pre = o < pre ? o : pre; }
-          double excl = __shfl_up(pre, 1, 64);
-          if (lane == 0) excl = 1e300;
-          excl = excl < run_min ? excl : run_min;
-          pm = __ballot(g && nis < excl);
-          double tile_min = __shfl(pre, 63, 64);
-          run_min = tile_min < run_min ? tile_min : run_min;
-        }
-        if (lane == 0) { gate[w] = gm; prog[w] = pm; }
+      for (int d = 1; d < kGroupLanes; d <<= 1) { double o = __shfl_up(pre, d, 64); if (s >= d) pre = o < pre ? o : pre; }
+      double excl = __shfl_up(pre, 1, 64);
+      if (s == 0) excl = 1e300;
+      excl = excl < run_min ? excl : run_min;
+      const unsigned long long pbal = __ballot(g && nis < excl);
+      const double tile_min = __shfl(pre, (int)(threadIdx.x & 48) | 15, 64);
+      if (secondInit) {
+        pbits = (unsigned)(pbal >> (grp * kGroupLanes)) & 0xffffu;
+        run_min = tile_min < run_min ? tile_min : run_min;
+      }
+    }
+    if (k0 < Mg) {
+      acc_g |= (unsigned long long)((unsigned)(bal >> (grp * kGroupLanes)) & 0xffffu) << (k0 & 63);
+      acc_p |= (unsigned long long)pbits << (k0 & 63);
+      if ((k0 & 63) == 48 || k0 + kGroupLanes >= Mg) {
+        if (s == 0) { gate[k0 >> 6] = acc_g; prog[k0 >> 6] = acc_p; }
+        acc_g = 0ull; acc_p = 0ull;
       }
     }
   }
-  if (lane == 0) {
+  if (act && s == 0) {
     liveok[li] = ok ? (secondInit ? 2 : 1) : 0;   // 2: the track is in its second initialisation (trackNum 1 at the start of the step)
     if (!ok) u->track_num = 0;
   }
@@ -538,32 +579,37 @@ __device__ void predict_item(const TrackBuffers& tb, WaveScratch* ws, int b, int
 }
 
 #ifndef MOT_TRACK_ITEM_WAVES
-#define MOT_TRACK_ITEM_WAVES 4
+#define MOT_TRACK_ITEM_WAVES 2
 #endif
-constexpr int kItemWaves = MOT_TRACK_ITEM_WAVES;     // waves (work items in flight) per workgroup of the two per-track kernels
+constexpr int kItemWaves = MOT_TRACK_ITEM_WAVES;     // waves per workgroup of the two per-track kernels (four tracks in flight per wave)
 __global__ void MOT_LAUNCH_BOUNDS2(kItemWaves * 64, MOT_PREDICT_WAVES)
 track_predict_kernel(TrackBuffers tb) {
-  __shared__ WaveScratch s_ws[kItemWaves];
-  const int wave = threadIdx.x >> 6;
+  __shared__ GroupScratch s_g[kItemWaves * kGroupsPerWave];
+  const int wave = threadIdx.x >> 6, grp = ggroup();
   const int n = *tb.n_items;
-  for (int i = blockIdx.x * kItemWaves + wave; i < n; i += gridDim.x * kItemWaves) {
-    const TrackItem it = tb.items[i];
-    predict_item(tb, &s_ws[wave], it.b, it.li);
+  for (int i0 = (blockIdx.x * kItemWaves + wave) * kGroupsPerWave; i0 < n; i0 += gridDim.x * kItemWaves * kGroupsPerWave) {
+    const bool act = i0 + grp < n;
+    TrackItem it; it.b = 0; it.li = 0;
+    if (act) it = tb.items[i0 + grp];
+    predict_group(tb, &s_g[wave * kGroupsPerWave + grp], it.b, it.li, act);
   }
 }
 
-// ---- T2: PB (this track's share) + PC — association, state machine, PDA update of one live track by one wave
-__device__ void update_item(const TrackBuffers& tb, WaveScratch* ws, int b, int li) {
-  const int lane = tlane();
-  const TrackFrameArgs args = tb.args[b];
+// ---- T2: PB (this track's share) + PC — association, state machine, PDA update; four tracks per wave
+__device__ void update_group(const TrackBuffers& tb, GroupScratch* G, int b, int li, bool act_in) {
+  const int s = glane();
   const MotTrackParams& tp = tb.tp;
-  const int M = tb.m_dev ? min(tb.m_dev[b * kCountsStride + kCntBoxes], kMaxBoxesPerFrame) : args.m;
-  const int nW = (M + 63) >> 6;
   const int* __restrict__ live = tb.live + (long)b * 2 * tb.T;
   const int* __restrict__ liveok = live + tb.T;
-  const int okflag = liveok[li];
-  if (!okflag) return;
-  const int t = live[li];
+  int M = 0, t = 0, okflag = 0;
+  if (act_in) {
+    const TrackFrameArgs args = tb.args[b];
+    M = tb.m_dev ? min(tb.m_dev[b * kCountsStride + kCntBoxes], kMaxBoxesPerFrame) : args.m;
+    okflag = liveok[li];
+    t = live[li];
+  }
+  const bool act = act_in && okflag != 0;
+  const int nW = act ? (M + 63) >> 6 : 0;
   DevTrack* u = tb.tracks + (long)b * tb.T + t;
   const unsigned long long* __restrict__ gate_b = tb.gate + (long)b * tb.T * kGateWords;
   const unsigned long long* __restrict__ prog_b = tb.prog + (long)b * tb.T * kGateWords;
@@ -575,26 +621,27 @@ __device__ void update_item(const TrackBuffers& tb, WaveScratch* ws, int b, int 
   // the gated boxes nobody claimed before. What the EARLIER live tracks of the stream claimed is the OR of
   // their gate masks (second-initialisation tracks claim only their progressive minima): lanes over the earlier tracks.
   {
+    const int nWmax = wave_reduce_i32(nW, OpMaxI()), limax = wave_reduce_i32(act ? li : 0, OpMaxI());
     int fresh = 0;
-    for (int w = 0; w < nW; w++) {
+    for (int w = 0; w < nWmax; w++) {
       unsigned long long before = 0ull;
-      for (int j0 = 0; j0 < li; j0 += 64) {
-        const int lj = j0 + lane;
+      for (int j0 = 0; j0 < limax; j0 += kGroupLanes) {
+        const int lj = j0 + s;
         unsigned long long m = 0ull;
-        if (lj < li) {
+        if (w < nW && lj < li) {
           const int f = liveok[lj];
           if (f) { const int tj = live[lj]; m = f == 2 ? prog_b[(long)tj * kGateWords + w] : gate_b[(long)tj * kGateWords + w]; }
         }
-        before |= wave_reduce_u64(m, OpOrU64());
+        before |= row_or_u64(m);
       }
-      fresh += __popcll(gt[w] & ~before);
+      if (w < nW) fresh += __popcll(gt[w] & ~before);
     }
-    if (lane == 0 && fresh) u->lifetime += fresh;
+    if (act && s == 0 && fresh) u->lifetime += fresh;
   }
   MOT_WAVE_SYNC();
-  load_track(ws, u);
-  int track_num = u->track_num;
-  const bool secondInit = okflag == 2;
+  load_track(G, u, act);
+  int track_num = act ? u->track_num : 0;
+  const bool secondInit = act && okflag == 2;
   int ngate = 0;
   for (int w = 0; w < nW; w++) ngate += __popcll(gt[w]);
   int nm = ngate;
@@ -604,11 +651,11 @@ __device__ void update_item(const TrackBuffers& tb, WaveScratch* ws, int b, int 
     nm = last_prog >= 0 ? 1 : 0;
   }
   // associateBB :416-463 + getNearestEuclidBBox :396-413 (int minDist, truncated on assignment)
-  if (!secondInit && ngate > 0 && track_num == 5 && u->lifetime > tp.life_time_thres) {
+  if (act && !secondInit && ngate > 0 && track_num == 5 && u->lifetime > tp.life_time_thres) {
     // sequential semantics: scan gated boxes in order, keep (minDist:int, minInd); reproduced by one lane
-    if (lane == 0) {
+    if (s == 0) {
       int minDist = 999, minBox = -1, first = -1;
-      double px = ws->xm[0], py = ws->xm[1];
+      double px = G->xm[0], py = G->xm[1];
       for (int w = 0; w < nW; w++) {
         unsigned long long g = gt[w];
         while (g) {
@@ -633,159 +680,162 @@ __device__ void update_item(const TrackBuffers& tb, WaveScratch* ws, int b, int 
       }
     }
   }
-  if (lane == 0) update_bb(tp, u);
+  if (act && s == 0) update_bb(tp, u);
   MOT_WAVE_SYNC();
   Vec2d* pos = tb.pos + (long)b * tb.T + t;
-  if (secondInit) {  // :882-921
-    if (lane == 0) {
-      if (nm == 0) u->track_num = 0;
-      else {
-        u->init_meas[0] = ws->xm[0]; u->init_meas[1] = ws->xm[1];
-        const Vec2d c = cp[last_prog];
-        double targetX = c.x, targetY = c.y;
-        double dX = targetX - ws->xm[0], dY = targetY - ws->xm[1];
-        double targetYaw = wrap_pi(atan2(dY, dX));
-        for (int a = 0; a < 4; a++) { u->x[a][0] = targetX; u->x[a][1] = targetY; u->x[a][2] = 2; u->x[a][3] = targetYaw; }
-        pos->x = targetX; pos->y = targetY;
-        u->track_num = track_num + 1;
-      }
+  if (secondInit && s == 0) {  // :882-921
+    if (nm == 0) u->track_num = 0;
+    else {
+      u->init_meas[0] = G->xm[0]; u->init_meas[1] = G->xm[1];
+      const Vec2d c = cp[last_prog];
+      double targetX = c.x, targetY = c.y;
+      double dX = targetX - G->xm[0], dY = targetY - G->xm[1];
+      double targetYaw = wrap_pi(atan2(dY, dX));
+      for (int a = 0; a < 4; a++) { u->x[a][0] = targetX; u->x[a][1] = targetY; u->x[a][2] = 2; u->x[a][3] = targetYaw; }
+      pos->x = targetX; pos->y = targetY;
+      u->track_num = track_num + 1;
     }
-    MOT_WAVE_SYNC();
-    return;
   }
+  bool upd = act && !secondInit;   // the group goes on to the filter update
   // track management :924-944
-  if (nm > 0) {
-    if (track_num < 3) track_num++;
-    else if (track_num == 3) track_num = 5;
-    else if (track_num >= 5) track_num = 5;
-  } else {
-    if (track_num < 5) track_num = 0;
-    else if (track_num >= 5 && track_num < 10) track_num++;
-    else track_num = 0;  // `else if(trackNumVec_[i] = 10)` assigns, is true, then sets 0
+  if (upd) {
+    if (nm > 0) {
+      if (track_num < 3) track_num++;
+      else if (track_num == 3) track_num = 5;
+      else if (track_num >= 5) track_num = 5;
+    } else {
+      if (track_num < 5) track_num = 0;
+      else if (track_num >= 5 && track_num < 10) track_num++;
+      else track_num = 0;  // `else if(trackNumVec_[i] = 10)` assigns, is true, then sets 0
+    }
+    if (s == 0) u->track_num = track_num;
+    if (track_num == 0) upd = false;
   }
-  if (lane == 0) u->track_num = track_num;
-  if (track_num == 0) { MOT_WAVE_SYNC(); return; }
 
-  // filterPDA :259-394 — lanes over the gated measurements
-  {
-    const double numMeas = nm;
-    const double bpda = 2 * numMeas * (1 - tp.p_d * tp.p_g) / (tp.gamma_g * tp.p_d);
-    double Si[3][4];
-    for (int m = 0; m < 3; m++) inv2(ws->S[m], Si[m]);
-    // lanes over the boxes (one 64-box tile at a time); e and the residuals of a lane's box are kept for the three sums
-    double eSum[3] = {0, 0, 0};
-    double ce[3] = {0, 0, 0};   // exp() of this lane's box in the first 64-box tile, reused by the two passes below (all tiles but the
-                                // first recompute it: more than 64 boxes in a frame is rare)
-    Vec2d c0; c0.x = 0; c0.y = 0;   // this lane's box centre in the first tile
-    if (lane < M) c0 = cp[lane];
-    for (int w = 0; w * 64 < M; w++) {
-      int k = w * 64 + lane;
-      bool g = (gt[w] >> lane) & 1ull;
-      Vec2d c = c0;
-      if (w > 0 && g) c = cp[k];
+  // filterPDA :259-394 — lanes over the measurements, 16 boxes at a time
+  const int Mg = upd ? M : 0;
+  const int Mmax = wave_reduce_i32(Mg, OpMaxI());
+  const double numMeas = nm;
+  const double bpda = 2 * numMeas * (1 - tp.p_d * tp.p_g) / (tp.gamma_g * tp.p_d);
+  double Si[3][4] = {{0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}};
+  if (upd) for (int m = 0; m < 3; m++) inv2(G->S[m], Si[m]);
+  double* ecache = &G->Xs[0][0];   // exp() of the gated boxes 0..63 per model ([3][64]; the sigma points are not needed here)
+  double eSum[3] = {0, 0, 0};
+  for (int k0 = 0; k0 < Mmax; k0 += kGroupLanes) {
+    const int k = k0 + s;
+    const bool g = k < Mg && ((gt[k0 >> 6] >> (k & 63)) & 1ull);
+    Vec2d c; c.x = 0; c.y = 0;
+    if (g) c = cp[k];
+#pragma unroll
+    for (int m = 0; m < 3; m++) {
+      double e = 0;
+      if (g) {
+        double d0 = c.x - G->z[m][0], d1 = c.y - G->z[m][1];
+        double h0 = -0.5 * d0, h1 = -0.5 * d1;
+        double t0 = h0 * Si[m][0] + h1 * Si[m][2], t1 = h0 * Si[m][1] + h1 * Si[m][3];
+        e = exp(t0 * d0 + t1 * d1);
+        if (k < 64) ecache[m * 64 + k] = e;
+      }
+      eSum[m] += row_sum_f64(e);
+    }
+  }
+  double sx[3][2] = {{0, 0}, {0, 0}, {0, 0}};
+  double sp[3][4] = {{0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}};
+#pragma unroll 1
+  for (int pass = 0; pass < 2; pass++) {  // pass 0: sigmaX, pass 1: sigmaP (needs the complete sigmaX)
+    for (int k0 = 0; k0 < Mmax; k0 += kGroupLanes) {
+      const int k = k0 + s;
+      const bool g = k < Mg && ((gt[k0 >> 6] >> (k & 63)) & 1ull);
+      Vec2d c; c.x = 0; c.y = 0;
+      if (g) c = cp[k];
 #pragma unroll
       for (int m = 0; m < 3; m++) {
-        double e = 0;
+        double d[2] = {0, 0}, beta = 0;
         if (g) {
-          double d0 = c.x - ws->z[m][0], d1 = c.y - ws->z[m][1];
-          double h0 = -0.5 * d0, h1 = -0.5 * d1;
-          double t0 = h0 * Si[m][0] + h1 * Si[m][2], t1 = h0 * Si[m][1] + h1 * Si[m][3];
-          e = exp(t0 * d0 + t1 * d1);
-        }
-        if (w == 0) ce[m] = e;
-        eSum[m] += wave_sum_d(e);
-      }
-    }
-    double sx[3][2] = {{0, 0}, {0, 0}, {0, 0}};
-    double sp[3][4] = {{0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}};
-    for (int pass = 0; pass < 2; pass++) {  // pass 0: sigmaX, pass 1: sigmaP (needs the complete sigmaX)
-      for (int w = 0; w * 64 < M; w++) {
-        int k = w * 64 + lane;
-        bool g = (gt[w] >> lane) & 1ull;
-        Vec2d c = c0;
-        if (w > 0 && g) c = cp[k];
-#pragma unroll
-        for (int m = 0; m < 3; m++) {
-          double d[2] = {0, 0}, beta = 0;
-          if (g) {
-            d[0] = c.x - ws->z[m][0]; d[1] = c.y - ws->z[m][1];
-            double e = ce[m];
-            if (w > 0) {
-              double h0 = -0.5 * d[0], h1 = -0.5 * d[1];
-              double t0 = h0 * Si[m][0] + h1 * Si[m][2], t1 = h0 * Si[m][1] + h1 * Si[m][3];
-              e = exp(t0 * d[0] + t1 * d[1]);
-            }
-            beta = e / (bpda + eSum[m]);
+          d[0] = c.x - G->z[m][0]; d[1] = c.y - G->z[m][1];
+          double e;
+          if (k < 64) e = ecache[m * 64 + k];
+          else {
+            double h0 = -0.5 * d[0], h1 = -0.5 * d[1];
+            double t0 = h0 * Si[m][0] + h1 * Si[m][2], t1 = h0 * Si[m][1] + h1 * Si[m][3];
+            e = exp(t0 * d[0] + t1 * d[1]);
           }
-          if (pass == 0) { sx[m][0] += wave_sum_d(beta * d[0]); sx[m][1] += wave_sum_d(beta * d[1]); }
-          else
-            for (int r = 0; r < 2; r++) for (int c2 = 0; c2 < 2; c2++)
-              sp[m][r * 2 + c2] += wave_sum_d(g ? (beta * d[r]) * d[c2] - sx[m][r] * sx[m][c2] : 0.0);
+          beta = e / (bpda + eSum[m]);
         }
+        if (pass == 0) { sx[m][0] += row_sum_f64(beta * d[0]); sx[m][1] += row_sum_f64(beta * d[1]); }
+        else
+          for (int r = 0; r < 2; r++) for (int c2 = 0; c2 < 2; c2++)
+            sp[m][r * 2 + c2] += row_sum_f64(g ? (beta * d[r]) * d[c2] - sx[m][r] * sx[m][c2] : 0.0);
       }
     }
-    // x += K*sigmaX ; P update (:341-367) — one lane per matrix entry
-    MOT_WAVE_SYNC();
-    if (lane < 15) {
-      int m = lane / 5, r = lane % 5;
-      double v = ws->x[m][r] + (ws->K[m][r * 2] * sx[m][0] + ws->K[m][r * 2 + 1] * sx[m][1]);
-      ws->xo[m][r] = r == 3 ? wrap_pi(v) : v;
+  }
+  // x += K*sigmaX ; P update (:341-367) — one lane per matrix entry
+  MOT_WAVE_SYNC();
+  if (upd) {
+    if (s < 15) {
+      int m = s / 5, r = s % 5;
+      double v = G->x[m][r] + (G->K[m][r * 2] * sx[m][0] + G->K[m][r * 2 + 1] * sx[m][1]);
+      G->xo[m][r] = r == 3 ? wrap_pi(v) : v;
     }
-    for (int e = lane; e < 75; e += 64) {
+    for (int e = s; e < 75; e += kGroupLanes) {
       int m = e / 25, r = (e % 25) / 5, c = e % 5;
-      const double* K = ws->K[m];
-      double ks0 = K[r * 2] * ws->S[m][0] + K[r * 2 + 1] * ws->S[m][2], ks1 = K[r * 2] * ws->S[m][1] + K[r * 2 + 1] * ws->S[m][3];
+      const double* K = G->K[m];
+      double ks0 = K[r * 2] * G->S[m][0] + K[r * 2 + 1] * G->S[m][2], ks1 = K[r * 2] * G->S[m][1] + K[r * 2 + 1] * G->S[m][3];
       double kp0 = K[r * 2] * sp[m][0] + K[r * 2 + 1] * sp[m][2], kp1 = K[r * 2] * sp[m][1] + K[r * 2 + 1] * sp[m][3];
       double kskt = ks0 * K[c * 2] + ks1 * K[c * 2 + 1];
       double kpk = kp0 * K[c * 2] + kp1 * K[c * 2 + 1];
-      double P = ws->P[m][r * 5 + c];
+      double P = G->P[m][r * 5 + c];
       double betaZero = bpda / (bpda + eSum[m]);
-      ws->Po[m][r * 5 + c] = nm != 0 ? betaZero * P + (1 - betaZero) * (P - kskt) + kpk : P - kskt;
+      G->Po[m][r * 5 + c] = nm != 0 ? betaZero * P + (1 - betaZero) * (P - kskt) + kpk : P - kskt;
     }
-    MOT_WAVE_SYNC();
+  }
+  MOT_WAVE_SYNC();
+  if (upd) {
     // likelihoods :369-393, UpdateModeProb ukf.cpp:384-397, merge :419-437
-    int mx = find_max_model(ws->S);
-    double Vk = PI_D * sqrt(tp.gamma_g * det2(ws->S[mx]));
+    int mx = find_max_model(G->S);
+    double Vk = PI_D * sqrt(tp.gamma_g * det2(G->S[mx]));
     double lambda[3];
     const double pw = pow(Vk, numMeas), pw1 = nm != 0 ? pow(Vk, 1 - numMeas) : 0.0;   // the same two powers in all three models
 #pragma unroll
     for (int m = 0; m < 3; m++) {
-      if (nm != 0) lambda[m] = (1 - tp.p_g * tp.p_d) / pw + tp.p_d * pw1 * eSum[m] / (numMeas * sqrt(2 * PI_D * det2(ws->S[m])));
+      if (nm != 0) lambda[m] = (1 - tp.p_g * tp.p_d) / pw + tp.p_d * pw1 * eSum[m] / (numMeas * sqrt(2 * PI_D * det2(G->S[m])));
       else lambda[m] = (1 - tp.p_g * tp.p_d) / pw;
     }
     double mode[3];
-    double sum = lambda[0] * ws->mode[0] + lambda[1] * ws->mode[1] + lambda[2] * ws->mode[2];
-    for (int m = 0; m < 3; m++) { mode[m] = (lambda[m] * ws->mode[m]) / sum; if (fabs(mode[m]) < 0.0001) mode[m] = 0.0001; }
+    double sum = lambda[0] * G->mode[0] + lambda[1] * G->mode[1] + lambda[2] * G->mode[2];
+    for (int m = 0; m < 3; m++) { mode[m] = (lambda[m] * G->mode[m]) / sum; if (fabs(mode[m]) < 0.0001) mode[m] = 0.0001; }
     double xmv[5];
-    for (int r = 0; r < 5; r++) xmv[r] = mode[0] * ws->xo[0][r] + mode[1] * ws->xo[1][r] + mode[2] * ws->xo[2][r];
+    for (int r = 0; r < 5; r++) xmv[r] = mode[0] * G->xo[0][r] + mode[1] * G->xo[1][r] + mode[2] * G->xo[2][r];
     xmv[3] = wrap_pi(xmv[3]);
     double yaw;  // UpdateYawWithHighProb :399-417
-    if (mode[0] > mode[1]) yaw = (mode[0] > mode[2]) ? ws->xo[0][3] : ws->xo[2][3];
-    else yaw = (mode[1] > mode[2]) ? ws->xo[1][3] : ws->xo[2][3];
+    if (mode[0] > mode[1]) yaw = (mode[0] > mode[2]) ? G->xo[0][3] : G->xo[2][3];
+    else yaw = (mode[1] > mode[2]) ? G->xo[1][3] : G->xo[2][3];
     xmv[3] = yaw;
-    if (lane < 25) {
-      int r = lane / 5, c = lane % 5;
+    for (int e = s; e < 25; e += kGroupLanes) {
+      int r = e / 5, c = e % 5;
       double acc = 0;
-      for (int m = 0; m < 3; m++) acc = acc + mode[m] * (ws->Po[m][r * 5 + c] + (ws->xo[m][r] - xmv[r]) * (ws->xo[m][c] - xmv[c]));
+      for (int m = 0; m < 3; m++) acc = acc + mode[m] * (G->Po[m][r * 5 + c] + (G->xo[m][r] - xmv[r]) * (G->xo[m][c] - xmv[c]));
       u->P[0][r * 5 + c] = acc;
     }
-    if (lane < 5) u->x[0][lane] = xmv[lane];
-    if (lane == 0) { pos->x = xmv[0]; pos->y = xmv[1]; }
-    if (lane < 3) u->mode[lane] = mode[lane];
-    for (int e = lane; e < 15; e += 64) u->x[1 + e / 5][e % 5] = ws->xo[e / 5][e % 5];
-    for (int e = lane; e < 75; e += 64) u->P[1 + e / 25][e % 25] = ws->Po[e / 25][e % 25];
+    if (s < 5) u->x[0][s] = xmv[s];
+    if (s == 0) { pos->x = xmv[0]; pos->y = xmv[1]; }
+    if (s < 3) u->mode[s] = mode[s];
+    if (s < 15) u->x[1 + s / 5][s % 5] = G->xo[s / 5][s % 5];
+    for (int e = s; e < 75; e += kGroupLanes) u->P[1 + e / 25][e % 25] = G->Po[e / 25][e % 25];
   }
   MOT_WAVE_SYNC();
 }
 
 __global__ void MOT_LAUNCH_BOUNDS2(kItemWaves * 64, MOT_UPDATE_WAVES)
 track_update_kernel(TrackBuffers tb) {
-  __shared__ WaveScratch s_ws[kItemWaves];
-  const int wave = threadIdx.x >> 6;
+  __shared__ GroupScratch s_g[kItemWaves * kGroupsPerWave];
+  const int wave = threadIdx.x >> 6, grp = ggroup();
   const int n = *tb.n_items;
-  for (int i = blockIdx.x * kItemWaves + wave; i < n; i += gridDim.x * kItemWaves) {
-    const TrackItem it = tb.items[i];
-    update_item(tb, &s_ws[wave], it.b, it.li);
+  for (int i0 = (blockIdx.x * kItemWaves + wave) * kGroupsPerWave; i0 < n; i0 += gridDim.x * kItemWaves * kGroupsPerWave) {
+    const bool act = i0 + grp < n;
+    TrackItem it; it.b = 0; it.li = 0;
+    if (act) it = tb.items[i0 + grp];
+    update_group(tb, &s_g[wave * kGroupsPerWave + grp], it.b, it.li, act);
   }
 }
 
@@ -958,7 +1008,7 @@ void mot_launch_track(const TrackBuffers& t, int batch, hipStream_t stream) {
 #ifdef MOT_HIPEMU
   const int item_groups = 2;   // the per-track kernels loop over the work list: any grid size gives the same result
 #else
-  int item_groups = batch * 16;   // 4 waves each: a round covers 64 live tracks per stream; the chip holds ~512 such workgroups
+  int item_groups = batch * 8;   // 2 waves x 4 tracks each: one round covers 64 live tracks per stream; the chip holds ~1024 such workgroups
   item_groups = item_groups < 16 ? 16 : (item_groups > 1024 ? 1024 : item_groups);
 #endif
   hipLaunchKernelGGL(track_prep_kernel, dim3(batch), dim3(256), 0, stream, t);

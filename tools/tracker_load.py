@@ -13,7 +13,8 @@ PKG = os.path.join(ROOT, "3d-lidar-multi-object-tracking_amd")
 mot = _load("mot_amd", os.path.join(PKG, "__init__.py")); sdev = _load("mot_amd.synth_dev", os.path.join(PKG, "synth_dev.py"))
 build = _load("mot_amd.build", os.path.join(PKG, "build.py"))
 S = int(sys.argv[1]) if len(sys.argv) > 1 else 128
-flags = sys.argv[2:]
+flags = [a for a in sys.argv[2:] if a.startswith("-D")]
+STRESS_ONLY = "stress-only" in sys.argv
 lib = None
 if flags:
     os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
@@ -42,6 +43,8 @@ for T in (8, 32, 64):
         print(f"stress T={T}: {r['mean_ms']*1e3:.1f} us mean, {r['min_ms']*1e3:.1f} min, {r['max_ms']*1e3:.1f} max over {r['samples']} steps of {S} streams; "
               f"live {int((tr['track_manage'] > 0).sum())}, ever {tr['n']}")
 
+if STRESS_ONLY:
+    sys.exit(0)
 B, N, F = 128 if S >= 128 else S, 120000, 154
 stride = ((N + 2047) // 2048) * 2048
 v, yaw = sdev.load_ego(F)
