@@ -40,12 +40,13 @@ def needs_build() -> bool:
     return any(os.path.getmtime(d) > t for d in deps)
 
 
-def build(force: bool = False, verbose: bool = False, extra_flags=(), out: str | None = None) -> str:
-    """extra_flags / out: experiment builds (e.g. -DMOT_DBG_* ablations written next to gpurun_out/), never the product"""
+def build(force: bool = False, verbose: bool = False, extra_flags=(), out: str | None = None, csrc: str | None = None) -> str:
+    """extra_flags / out / csrc: experiment builds (geometry knobs, timing stamps, patched scratch copies of the sources for
+    ablations — tools/ablate.py), written next to gpurun_out/, never the product"""
     if out is None and not force and not needs_build():
         return LIB
     out = out or LIB
-    cmd = [hipcc()] + HIPCC_FLAGS + list(extra_flags) + [os.path.join(CSRC, s) for s in SOURCES] + ["-o", out + ".tmp"]
+    cmd = [hipcc()] + HIPCC_FLAGS + list(extra_flags) + [os.path.join(csrc or CSRC, s) for s in SOURCES] + ["-o", out + ".tmp"]
     if verbose:
         print(" ".join(cmd), file=sys.stderr)
     r = subprocess.run(cmd, capture_output=True, text=True)

@@ -19,6 +19,7 @@
 //    1 + (number of roots before it) — a popcount prefix. No recursion, no iteration-until-convergence.
 #include "mot_internal.h"
 #include "mot_debug.h"
+#include <type_traits>
 
 #ifndef MOT_HIPEMU
 #define MOT_LAUNCH_BOUNDS(n) __launch_bounds__(n)
@@ -80,6 +81,11 @@ cart_occupancy_kernel(MotDevParams p, ClusterBuffers c) {
 
 // ------------------------------------------------------------------------------------------ C2
 constexpr int kCclBlock = 1024;
+// Runs whose union-find array lives in LDS. A frame can have up to kMaxRuns = 32768 runs (alternating cells in every row); a
+// street scene has a few hundred to a few thousand. Sizing LDS for the worst case made this one-workgroup-per-frame kernel own
+// a CU's whole LDS (159 KB), locking 128 CUs against the streaming kernels of the other contexts for its 30-40 us; with 6144 it
+// is 51 KB and three other workgroups fit next to it. Frames beyond that run the same code on an array in HBM.
+constexpr int kLdsRuns = 6144;
 
 // helpers on a 256-bit row stored as 8 words in LDS (bits >= num_grid are always 0)
 __device__ __forceinline__ int row_next_set(const unsigned* row, int p) {   // smallest q >= p with bit set, or 256
@@ -118,7 +124,7 @@ __global__ void MOT_LAUNCH_BOUNDS(kCclBlock)
 ccl_kernel(MotDevParams p, ClusterBuffers c) {
   __shared__ unsigned s_occ[kPlaneWords];        // occupancy after dilation
   __shared__ unsigned s_aux[kPlaneWords];        // horizontal dilation, then run-start bits
-  __shared__ unsigned s_parent[kMaxRuns];        // union-find over runs
+  __shared__ unsigned s_parent[kLdsRuns];        // union-find over runs (frames with more runs take a global-memory array)
   __shared__ int s_rowbase[MOT_MAX_GRID + 1];    // exclusive prefix of runs per row
   __shared__ unsigned s_isroot[kMaxRuns / 32];
   __shared__ int s_rootpre[kMaxRuns / 32 + 1];
@@ -187,7 +193,14 @@ ccl_kernel(MotDevParams p, ClusterBuffers c) {
   CCL_T(3);
   // after the scan s_rowbase[x+1] = number of runs in rows 0..x, i.e. base of row x is s_rowbase[x]
   const int R = s_rowbase[MOT_MAX_GRID];
-  for (int r = tid; r < R; r += kCclBlock) s_parent[r] = (unsigned)r;
+  // `in_lds`: the array is this workgroup's LDS (plain accesses are coherent); otherwise it sits in HBM, where another thread's
+  // atomicCAS happens in L2 and a plain load could be served a stale line from this CU's L1: those reads bypass L1
+  auto components = [&](unsigned* parent, auto in_lds) {
+  auto PL = [&](unsigned i) -> unsigned {
+    if constexpr (decltype(in_lds)::value) return parent[i];
+    else return __hip_atomic_load(&parent[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  };
+  for (int r = tid; r < R; r += kCclBlock) parent[r] = (unsigned)r;
   // per (row, word): run starts of the row before the word. With the row bases this gives the ordinal of the run that
   // contains ANY set cell y by popcounts alone: rowbase[x] + wpre[x][y / 32] + popc(starts[x][y / 32] & bits <= y) - 1
   for (int i = tid; i < kPlaneWords; i += kCclBlock) {
@@ -220,15 +233,15 @@ ccl_kernel(MotDevParams p, ClusterBuffers c) {
         const unsigned bb = (unsigned)(upbase + (int)s_wpre[upw + (q >> 5)] + __popc(s_aux[upw + (q >> 5)] & ((2u << (q & 31)) - 1u)));
         // lock-free union, hook the larger root under the smaller one
         unsigned ra = a, rb = bb;
-        while (s_parent[ra] != ra) ra = s_parent[ra];
-        while (s_parent[rb] != rb) rb = s_parent[rb];
+        for (unsigned q2 = PL(ra); q2 != ra; q2 = PL(ra)) ra = q2;
+        for (unsigned q2 = PL(rb); q2 != rb; q2 = PL(rb)) rb = q2;
         while (ra != rb) {
           if (ra < rb) { unsigned t = ra; ra = rb; rb = t; }
-          unsigned old = atomicCAS(&s_parent[ra], ra, rb);
+          unsigned old = atomicCAS(&parent[ra], ra, rb);
           if (old == ra) break;
           ra = old;
-          while (s_parent[ra] != ra) ra = s_parent[ra];
-          while (s_parent[rb] != rb) rb = s_parent[rb];
+          for (unsigned q2 = PL(ra); q2 != ra; q2 = PL(ra)) ra = q2;
+          for (unsigned q2 = PL(rb); q2 != rb; q2 = PL(rb)) rb = q2;
         }
         q = row_next_set(up, row_next_clear(up, q));
       }
@@ -238,8 +251,8 @@ ccl_kernel(MotDevParams p, ClusterBuffers c) {
   CCL_T(5);
   for (int r = tid; r < R; r += kCclBlock) {  // flatten (only roots are ever written)
     unsigned v = (unsigned)r;
-    while (s_parent[v] != v) v = s_parent[v];
-    s_parent[r] = v;
+    for (unsigned q2 = PL(v); q2 != v; q2 = PL(v)) v = q2;
+    parent[r] = v;
   }
   __syncthreads();
   CCL_T(6);
@@ -248,7 +261,7 @@ ccl_kernel(MotDevParams p, ClusterBuffers c) {
     int r0 = j << 5;
     if (r0 < R)
       for (int k = 0; k < 32 && r0 + k < R; k++)
-        if (s_parent[r0 + k] == (unsigned)(r0 + k)) bits |= 1u << k;
+        if (PL((unsigned)(r0 + k)) == (unsigned)(r0 + k)) bits |= 1u << k;
     s_isroot[j] = bits;
     s_rootpre[j + 1] = __popc(bits);
   }
@@ -272,8 +285,8 @@ ccl_kernel(MotDevParams p, ClusterBuffers c) {
   int* __restrict__ grid = c.grid + (long)b * (MOT_MAX_GRID * MOT_MAX_GRID);
   // every run's root becomes its cluster id (each thread reads only the entries it rewrites)
   for (int r = tid; r < R; r += kCclBlock) {
-    const unsigned root = s_parent[r];
-    s_parent[r] = 1u + (unsigned)s_rootpre[root >> 5] + (unsigned)__popc(s_isroot[root >> 5] & ((1u << (root & 31)) - 1u));
+    const unsigned root = PL((unsigned)r);
+    parent[r] = 1u + (unsigned)s_rootpre[root >> 5] + (unsigned)__popc(s_isroot[root >> 5] & ((1u << (root & 31)) - 1u));
   }
   __syncthreads();
   // A wave per row, four consecutive cells per lane. The run of a set cell y is the (number of run starts at or before y)-th
@@ -293,7 +306,7 @@ ccl_kernel(MotDevParams p, ClusterBuffers c) {
         const int before = s_rowbase[x] + (int)s_wpre[wi] - 1;
 #pragma unroll
         for (int j = 0; j < 4; j++)
-          if ((bits >> j) & 1u) lab[j] = (int)s_parent[before + __popc(st & ((2u << (sh + j)) - 1u))];
+          if ((bits >> j) & 1u) lab[j] = (int)PL((unsigned)(before + __popc(st & ((2u << (sh + j)) - 1u))));
       }
       int* dst = grid + x * G + y0;
       if (pairs && y0 + 4 <= G) {
@@ -305,6 +318,9 @@ ccl_kernel(MotDevParams p, ClusterBuffers c) {
       }
     }
   }
+  };
+  if (R <= kLdsRuns) components(s_parent, std::true_type());
+  else components(c.ccl_parent + (long)b * kMaxRuns, std::false_type());
   CCL_T(9);
 }
 

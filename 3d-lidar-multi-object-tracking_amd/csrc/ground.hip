@@ -10,7 +10,8 @@
 //
 // HBM traffic per point: K1 reads 16 B, K3 reads 16 B and writes 16 B (+1 B mask) = 48(+1) B — the
 // algorithmic minimum of SURVEY.md §8d: the classification needs the complete grid, so the cloud has to
-// be read twice. The polar grid (38 KB per frame) lives in L2.
+// be read twice — plus 2 + 2 B for the polar cell K1 hands to K3 (the cell computation was half of K3's instructions and
+// K3 was bound by them, not by HBM: profiles/r02_ablate_k3.txt). The polar grid (38 KB per frame) lives in L2.
 //
 // Design notes (MI355X-first, not a translation of the CPU loops):
 //  * K1 has no grid at all and issues NO atomics: beam-major clouds put a cell's points next to each other, so every
@@ -119,6 +120,19 @@ polar_minz_kernel(MotDevParams p, GroundBuffers g) {
   }
   int cells[kGroundItems];
   polar_cells<kGroundItems, kGroundBlock>(p, pt, in, base, n, cells);
+  {  // the compaction kernel classifies by the same cell: 2 bytes per point here instead of the whole cell computation there
+    unsigned short* __restrict__ cell16 = g.cell + (long)b * g.cap;
+    if (base + kGroundChunk <= n) {
+#pragma unroll
+      for (int k = 0; k < kGroundItems; k++) cell16[base + k * kGroundBlock + threadIdx.x] = (unsigned short)cells[k];   // -1 -> 0xffff
+    } else {
+#pragma unroll
+      for (int k = 0; k < kGroundItems; k++) {
+        long i = base + k * kGroundBlock + threadIdx.x;
+        if (i < n) cell16[i] = (unsigned short)cells[k];
+      }
+    }
+  }
 #pragma unroll
   for (int k = 0; k < kGroundItems; k++) {
     const float z = pt[k].z;
@@ -162,16 +176,15 @@ polar_minz_kernel(MotDevParams p, GroundBuffers g) {
 }
 
 // ------------------------------------------------------------------------------------------ K2
-// one workgroup per frame; the 80 x 120 grid sits in LDS (4 x 38 KB arrays would not be needed: the
-// passes are fused so only height / ground flag / smoothed are kept).
+// one workgroup per frame; the 80 x 120 grid sits in LDS: ONE float per cell (min z, then the height, updated in place) and
+// one flag byte — 48 KB, so that the workgroups of other kernels can share the CU (the first version kept five arrays, 135 KB:
+// with one workgroup per frame it locked 128 CUs' LDS against every other context's kernels for the length of the launch).
 constexpr int kFilterBlock = 960;  // 9600 cells = 10 per thread
 __global__ void MOT_LAUNCH_BOUNDS(kFilterBlock)
 polar_filter_kernel(MotDevParams p, GroundBuffers g) {
-  __shared__ float s_h[MOT_POLAR_CELLS];       // height
-  __shared__ float s_h2[MOT_POLAR_CELLS];      // height after the median pass
-  __shared__ unsigned char s_g[MOT_POLAR_CELLS];   // ground flag after decision
-  __shared__ unsigned char s_g2[MOT_POLAR_CELLS];  // ground flag after median
-  __shared__ int s_minz[MOT_POLAR_CELLS];        // createAndMapPolarGrid's per-cell min z (ordered keys)
+  __shared__ int s_minz[MOT_POLAR_CELLS];        // createAndMapPolarGrid's per-cell min z (ordered keys), then the cell's height
+  float* const s_h = reinterpret_cast<float*>(s_minz);   // same storage: every pass below that rewrites it reads only its own cell first
+  __shared__ unsigned char s_g[MOT_POLAR_CELLS];   // ground flag
   __shared__ int s_pcnt[256];
   const int b = blockIdx.x;
   float* __restrict__ hg = g.hg + (long)b * MOT_POLAR_CELLS;
@@ -218,7 +231,7 @@ polar_filter_kernel(MotDevParams p, GroundBuffers g) {
   }
   __syncthreads();
 
-  // height clamp, ground_removal.cpp:191-197
+  // height clamp, ground_removal.cpp:191-197 (in place: cell i's height depends on cell i's min z only)
   for (int i = threadIdx.x; i < MOT_POLAR_CELLS; i += kFilterBlock) {
     float zi = mot_key_float(s_minz[i]);
     float h;
@@ -248,8 +261,9 @@ polar_filter_kernel(MotDevParams p, GroundBuffers g) {
     s_g[i] = ground;
   }
   __syncthreads();
-  // applyMedianFilter (:120-146). Order independent: a cell flips only when its four
-  // neighbours are ground, so no flipped cell is an input of another flip.
+  // applyMedianFilter (:120-146). Order independent: a cell flips only when its four neighbours are ground,
+  // so no flipped cell is an input of another flip — two adjacent non-ground cells each wait for the other and neither ever
+  // flips, and the heights read are those of ground cells, which this pass does not touch. Hence in place, concurrently.
   for (int i = threadIdx.x; i < MOT_POLAR_CELLS; i += kFilterBlock) {
     int ch = i / MOT_NUM_BIN, bin = i % MOT_NUM_BIN;
     float h = s_h[i];
@@ -263,27 +277,25 @@ polar_filter_kernel(MotDevParams p, GroundBuffers g) {
       float m1 = lo1 > lo2 ? lo1 : lo2;   // larger of the two minima
       float m2 = hi1 < hi2 ? hi1 : hi2;   // smaller of the two maxima
       float s1 = m1 < m2 ? m1 : m2, s2 = m1 < m2 ? m2 : m1;
-      h = (s1 + s2) / 2;
-      ground = true;
+      s_h[i] = (s1 + s2) / 2;
+      s_g[i] = 1;
     }
-    s_h2[i] = h;
-    s_g2[i] = ground;
   }
   __syncthreads();
   // outlierFilter (:149-174). In-place left-to-right in the reference => a one-step dependency inside a
   // run of exactly two tHmin cells; evaluated here in closed form on the pre-pass values.
   for (int i = threadIdx.x; i < MOT_POLAR_CELLS; i += kFilterBlock) {
     int ch = i / MOT_NUM_BIN, bin = i % MOT_NUM_BIN;
-    float h = s_h2[i];
-    bool ground = s_g2[i];
+    float h = s_h[i];
+    bool ground = s_g[i];
     const float T = p.t_hmin;
     if (ch >= 1 && ch < MOT_NUM_CHANNEL - 1 && bin >= 1 && bin < MOT_NUM_BIN - 2 && h == T &&
-        ground && s_g2[i + 1] && s_g2[i - 1] && s_g2[i + 2]) {
-      float hm1 = s_h2[i - 1], h3 = s_h2[i + 1], h4 = s_h2[i + 2];
+        ground && s_g[i + 1] && s_g[i - 1] && s_g[i + 2]) {
+      float hm1 = s_h[i - 1], h3 = s_h[i + 1], h4 = s_h[i + 2];
       float h1 = hm1;  // value of cell bin-1 at the time the reference reaches this cell
-      if (hm1 == T && bin - 1 >= 1 && s_g2[i - 2]) {
+      if (hm1 == T && bin - 1 >= 1 && s_g[i - 2]) {
         // cell bin-1 may have been rewritten by its own step (flags of bin-2..bin+1 are all set here)
-        float hm2 = s_h2[i - 2];
+        float hm2 = s_h[i - 2];
         if (hm2 != T) {
           if (h != T) h1 = (hm2 + h) / 2;                  // case 1 at bin-1 (cannot happen: h == T)
           else if (h3 != T) h1 = (hm2 + h3) / 2;           // case 2 at bin-1: h3'==T (this cell), h4' = h3
@@ -341,11 +353,25 @@ classify_compact_kernel(MotDevParams p, GroundBuffers g) {
       pt[k] = i < n ? load_stream(&in[i]) : make_float4(0.f, 0.f, 0.f, 0.f);
     }
   }
-  polar_cells<kCompactItems, kCompactBlock>(p, pt, in, base, n, cls);
+  {  // polar cell of every point, as the min-z kernel found it (filterCloud + getCellIndexFromPoints + the node's crop)
+    const unsigned short* __restrict__ cell16 = g.cell + (long)b * g.cap;
+    if (full) {
+#pragma unroll
+      for (int k = 0; k < kCompactItems; k++) { const unsigned c = cell16[base + k * kCompactBlock + threadIdx.x]; cls[k] = c == 0xffffu ? -1 : (int)c; }
+    } else {
+#pragma unroll
+      for (int k = 0; k < kCompactItems; k++) {
+        long i = base + k * kCompactBlock + threadIdx.x;
+        const unsigned c = i < n ? cell16[i] : 0xffffu;
+        cls[k] = c == 0xffffu ? -1 : (int)c;
+      }
+    }
+  }
   float hgv[kCompactItems];
 #pragma unroll
   for (int k = 0; k < kCompactItems; k++) hgv[k] = hg[cls[k] > 0 ? cls[k] : 0];   // unpredicated independent gathers (L2), all in flight: -inf when the cell is not ground
   const unsigned long long below = (1ull << lane) - 1ull;
+  unsigned wave_has_elevated = 0;   // items whose 64 points include an elevated one (wave-uniform)
 #pragma unroll
   for (int k = 0; k < kCompactItems; k++) {
     int c = MOT_MASK_DROPPED;
@@ -353,41 +379,69 @@ classify_compact_kernel(MotDevParams p, GroundBuffers g) {
     cls[k] = c;
     const unsigned long long be = __ballot(c == MOT_MASK_ELEVATED);
     const unsigned long long bg = __ballot(c == MOT_MASK_GROUND);
+    if (be) wave_has_elevated |= 1u << k;
     rank[k] = __popcll((c == MOT_MASK_ELEVATED ? be : bg) & below);
     if (lane == 0) s_cnt[k * (kCompactBlock / 64) + wave] = (__popcll(be) << 16) | __popcll(bg);   // tile order inside the chunk: k-major, then wave
   }
-  if (occupancy) {
-    // mapCartesianGrid's histogram (component_clustering.cpp:36-50) for the elevated points, from registers: this is what
-    // cart_occupancy_kernel did with a second pass over the elevated cloud (16 N_e bytes and a launch per batch).
-    // Guarded fast cell first; the few undecided points go through ONE copy of the exact evaluation.
-    int bits[kCompactItems];
-    unsigned undecided = 0;
+  uint8_t* __restrict__ mask = g.mask ? g.mask + (long)b * g.cap : nullptr;
+  // Work that does not need the output positions — the occupancy of the cluster stage's grid and the per-point mask — is done
+  // by waves 1..7 WHILE wave 0 runs the look-back (the other waves used to idle at the barrier for its 2-4 us of agent-scope
+  // round trips: profiles/r02_ablate_k3.txt), and by wave 0 after the stores have been issued.
+  auto side_work = [&]() {
+    if (occupancy && wave_has_elevated) {
+      // mapCartesianGrid's histogram (component_clustering.cpp:36-50) for the elevated points, from registers: this is what
+      // cart_occupancy_kernel did with a second pass over the elevated cloud (16 N_e bytes and a launch per batch).
+      // Guarded fast cell first; the few undecided points go through ONE copy of the exact evaluation. Items without an
+      // elevated point in this wave (half of them: ground dominates) are skipped as a whole.
+      int bits[kCompactItems];
+      unsigned undecided = 0;
 #pragma unroll
-    for (int k = 0; k < kCompactItems; k++) {
-      int bit = cls[k] == MOT_MASK_ELEVATED ? mot_cart_bit_try(p, pt[k].x, pt[k].y) : -1;
-      if (bit == -2) undecided |= 1u << k;
-      bits[k] = bit;
-    }
-    while (undecided) {
-      const int k = __ffs(undecided) - 1;
-      undecided &= undecided - 1;
-      float qx = pt[0].x, qy = pt[0].y;
+      for (int k = 0; k < kCompactItems; k++) {
+        int bit = -1;
+        if ((wave_has_elevated >> k) & 1u) bit = cls[k] == MOT_MASK_ELEVATED ? mot_cart_bit_try(p, pt[k].x, pt[k].y) : -1;
+        if (bit == -2) undecided |= 1u << k;
+        bits[k] = bit;
+      }
+      while (undecided) {
+        const int k = __ffs(undecided) - 1;
+        undecided &= undecided - 1;
+        float qx = pt[0].x, qy = pt[0].y;
 #pragma unroll
-      for (int kk = 1; kk < kCompactItems; kk++) { qx = kk == k ? pt[kk].x : qx; qy = kk == k ? pt[kk].y : qy; }
-      int xI, yI;
-      const int r = mot_cart_cell(p, qx, qy, &xI, &yI) ? xI * MOT_MAX_GRID + yI : -1;
+        for (int kk = 1; kk < kCompactItems; kk++) { qx = kk == k ? pt[kk].x : qx; qy = kk == k ? pt[kk].y : qy; }
+        int xI, yI;
+        const int r = mot_cart_cell(p, qx, qy, &xI, &yI) ? xI * MOT_MAX_GRID + yI : -1;
 #pragma unroll
-      for (int kk = 0; kk < kCompactItems; kk++) bits[kk] = kk == k ? r : bits[kk];
-    }
+        for (int kk = 0; kk < kCompactItems; kk++) bits[kk] = kk == k ? r : bits[kk];
+      }
+      // Neighbouring lanes are neighbouring returns of one beam: a car side or a wall puts runs of lanes into the SAME cell, and
+      // LDS atomics on one address serialise lane by lane (the straightforward per-point atomicOr cost 14 us of the kernel's
+      // 104: profiles/r02_ablate_k3.txt). Only the first lane of a run of equal cells touches LDS; a run of two or more is
+      // "seen >= 2" by itself.
 #pragma unroll
-    for (int k = 0; k < kCompactItems; k++) {
-      if (bits[k] >= 0) {
-        const unsigned m = 1u << (bits[k] & 31);
-        const unsigned old = atomicOr(&s_occ_a[bits[k] >> 5], m);
-        if (old & m) atomicOr(&s_occ_b[bits[k] >> 5], m);
+      for (int k = 0; k < kCompactItems; k++) {
+        if ((wave_has_elevated >> k) & 1u) {   // uniform
+          const int prev = row_prev_i32(bits[k], -3), next = row_next_i32(bits[k], -3);
+          if (bits[k] >= 0 && prev != bits[k]) {
+            const unsigned m = 1u << (bits[k] & 31);
+            const unsigned old = atomicOr(&s_occ_a[bits[k] >> 5], m);
+            if ((old & m) || next == bits[k]) atomicOr(&s_occ_b[bits[k] >> 5], m);
+          }
+        }
       }
     }
-  }
+    if (mask) {
+      if (full) {
+#pragma unroll
+        for (int k = 0; k < kCompactItems; k++) mask[base + k * kCompactBlock + threadIdx.x] = (uint8_t)cls[k];
+      } else {
+#pragma unroll
+        for (int k = 0; k < kCompactItems; k++) {
+          long i = base + k * kCompactBlock + threadIdx.x;
+          if (i < n) mask[i] = (uint8_t)cls[k];
+        }
+      }
+    }
+  };
   __syncthreads();
   if (wave == 0) {
     // exclusive scan of the 64 tile counts (elevated in the high half-word, ground in the low one; a chunk holds at most
@@ -439,10 +493,10 @@ classify_compact_kernel(MotDevParams p, GroundBuffers g) {
       }
     }
   }
+  else side_work();
   __syncthreads();
   float4* __restrict__ out_e = g.elevated + (long)b * g.cap;
   float4* __restrict__ out_g = g.ground + (long)b * g.cap;
-  uint8_t* __restrict__ mask = g.mask ? g.mask + (long)b * g.cap : nullptr;
   const int be0 = s_base_e, bg0 = s_base_g;
 #pragma unroll
   for (int k = 0; k < kCompactItems; k++) {
@@ -452,22 +506,11 @@ classify_compact_kernel(MotDevParams p, GroundBuffers g) {
     const int at = (is_e ? be0 + (ex >> 16) : bg0 + (ex & 0xffff)) + rank[k];
     if (cls[k] != MOT_MASK_DROPPED) dst[at] = pt[k];
   }
-  if (mask) {
-    if (full) {
-#pragma unroll
-      for (int k = 0; k < kCompactItems; k++) mask[base + k * kCompactBlock + threadIdx.x] = (uint8_t)cls[k];
-    } else {
-#pragma unroll
-      for (int k = 0; k < kCompactItems; k++) {
-        long i = base + k * kCompactBlock + threadIdx.x;
-        if (i < n) mask[i] = (uint8_t)cls[k];
-      }
-    }
-  }
+  if (wave == 0) side_work();
   if (occupancy) {
     // merge into the frame's planes (L2) with one returning atomicOr per non-zero word; a bit that two workgroups both
-    // saw once is promoted to the ">= 2" plane by whoever merges second (the barrier after the look-back ordered every
-    // LDS atomic of this workgroup before these reads)
+    // saw once is promoted to the ">= 2" plane by whoever merges second
+    __syncthreads();   // wave 0's LDS atomics above, everybody else's before the previous barrier
     unsigned* __restrict__ ga = g.plane_a + (long)b * kPlaneWords;
     unsigned* __restrict__ gb = g.plane_b + (long)b * kPlaneWords;
     for (int i = threadIdx.x; i < kPlaneWords; i += kCompactBlock) {

@@ -28,6 +28,7 @@ struct mot_ctx {
   uint2* d_pairs = nullptr;
   int* d_pair_count = nullptr;
   float* d_hg = nullptr;
+  unsigned short* d_cell = nullptr;
   unsigned long long* d_desc = nullptr;
   int* d_ticket = nullptr;
   float4* d_elev = nullptr;
@@ -39,6 +40,7 @@ struct mot_ctx {
   // cluster + box stages
   unsigned* d_plane_a = nullptr;
   unsigned* d_plane_b = nullptr;
+  unsigned* d_ccl_parent = nullptr;
   int* d_grid = nullptr;
   int* d_label = nullptr;
   ClusterStats* d_stats = nullptr;
@@ -236,8 +238,8 @@ extern "C" void mot_destroy(mot_ctx* c) {
   if (c->d_fetch_counts) (void)hipFree(c->d_fetch_counts);
   if (c->prof_created)
     for (int i = 0; i < mot_ctx::kProfRing; i++) { (void)hipEventDestroy(c->prof_ev[i][0]); (void)hipEventDestroy(c->prof_ev[i][1]); }
-  void* bufs[] = {c->d_in, c->d_n, c->d_pairs, c->d_pair_count, c->d_hg, c->d_desc, c->d_ticket, c->d_elev, c->d_ground, c->d_mask, c->d_counts,
-                  c->d_plane_a, c->d_plane_b, c->d_grid, c->d_label, c->d_stats, c->d_cand, c->d_boxes, c->d_box_cluster, c->d_rng, c->d_poly, c->d_groups, c->d_cluster_start, c->d_sorted, c->d_pix, c->d_wgtab, c->d_side_cell, c->d_side_cloud, c->d_side_obs, c->d_side_cost, c->d_side_counts, c->d_raw,
+  void* bufs[] = {c->d_in, c->d_n, c->d_pairs, c->d_pair_count, c->d_hg, c->d_cell, c->d_desc, c->d_ticket, c->d_elev, c->d_ground, c->d_mask, c->d_counts,
+                  c->d_plane_a, c->d_plane_b, c->d_ccl_parent, c->d_grid, c->d_label, c->d_stats, c->d_cand, c->d_boxes, c->d_box_cluster, c->d_rng, c->d_poly, c->d_groups, c->d_cluster_start, c->d_sorted, c->d_pix, c->d_wgtab, c->d_side_cell, c->d_side_cloud, c->d_side_obs, c->d_side_cost, c->d_side_counts, c->d_raw,
                   c->d_tracks, c->d_nt, c->d_tboxes, c->d_targs, c->d_gate, c->d_prog, c->d_live, c->d_tout, c->d_tflags, c->d_ego, c->d_nlive, c->d_pos, c->d_cp, c->d_items, c->d_nitems};
   for (void* b : bufs) if (b) (void)hipFree(b);
   if (c->h_counts) (void)hipHostFree(c->h_counts);
@@ -252,7 +254,7 @@ static void prepare_track_args(mot_ctx* c, int slot, int m, double timestamp, bo
 
 static ClusterBuffers cluster_buffers(mot_ctx* c) {
   ClusterBuffers b;
-  b.elevated = c->d_elev; b.cap = c->cap; b.counts = c->d_counts; b.plane_a = c->d_plane_a; b.plane_b = c->d_plane_b;
+  b.elevated = c->d_elev; b.cap = c->cap; b.counts = c->d_counts; b.plane_a = c->d_plane_a; b.plane_b = c->d_plane_b; b.ccl_parent = c->d_ccl_parent;
   b.grid = c->d_grid; b.label = c->d_label; b.stats = c->d_stats; b.cand = c->d_cand; b.boxes = c->d_boxes;
   b.box_cluster = c->d_box_cluster; b.rng = c->d_rng; b.poly = c->d_poly; b.groups = c->d_groups; b.group_cap = c->cap / 2; b.cluster_start = c->d_cluster_start; b.sorted = c->d_sorted;
   b.pix = c->d_pix; b.wgtab = c->d_wgtab; b.max_wg = c->max_wg;
@@ -282,6 +284,7 @@ static int create_impl(mot_ctx* c) {
   MOT_HIP(c, hipMalloc(&c->d_pairs, B * c->max_chunks * kGroundChunk * sizeof(uint2)));
   MOT_HIP(c, hipMalloc(&c->d_pair_count, B * c->max_chunks * sizeof(int)));
   MOT_HIP(c, hipMalloc(&c->d_hg, B * MOT_POLAR_CELLS * sizeof(float)));
+  MOT_HIP(c, hipMalloc(&c->d_cell, B * N * sizeof(unsigned short)));
   MOT_HIP(c, hipMalloc(&c->d_desc, B * c->max_chunks * sizeof(unsigned long long)));
   MOT_HIP(c, hipMalloc(&c->d_ticket, B * sizeof(int)));
   MOT_HIP(c, hipMalloc(&c->d_elev, B * N * sizeof(float4)));
@@ -291,6 +294,7 @@ static int create_impl(mot_ctx* c) {
   MOT_HIP(c, hipHostMalloc(&c->h_counts, B * kCountsStride * sizeof(int), hipHostMallocDefault));
   MOT_HIP(c, hipMalloc(&c->d_plane_a, B * kPlaneWords * sizeof(unsigned)));
   MOT_HIP(c, hipMalloc(&c->d_plane_b, B * kPlaneWords * sizeof(unsigned)));
+  MOT_HIP(c, hipMalloc(&c->d_ccl_parent, B * kMaxRuns * sizeof(unsigned)));
   MOT_HIP(c, hipMalloc(&c->d_grid, B * MOT_MAX_GRID * MOT_MAX_GRID * sizeof(int)));
   MOT_HIP(c, hipMalloc(&c->d_label, B * N * sizeof(int)));
   MOT_HIP(c, hipMalloc(&c->d_stats, B * kMaxClusters * sizeof(ClusterStats)));
@@ -415,7 +419,7 @@ static int next_epoch(mot_ctx* c) {
 static GroundBuffers ground_buffers(mot_ctx* c, const float4* in, long stride, bool want_mask, bool planes = false) {
   GroundBuffers g;
   g.epoch = c->epoch;
-  g.in = in; g.in_stride = stride; g.n = c->d_n; g.pairs = c->d_pairs; g.pair_count = c->d_pair_count; g.hg = c->d_hg; g.desc = c->d_desc;
+  g.in = in; g.in_stride = stride; g.n = c->d_n; g.pairs = c->d_pairs; g.pair_count = c->d_pair_count; g.hg = c->d_hg; g.cell = c->d_cell; g.desc = c->d_desc;
   g.ticket = c->d_ticket; g.elevated = c->d_elev; g.ground = c->d_ground; g.mask = want_mask ? c->d_mask : nullptr;
   g.counts = c->d_counts; g.cap = c->cap; g.max_chunks = c->max_chunks;
   g.plane_a = planes ? c->d_plane_a : nullptr; g.plane_b = planes ? c->d_plane_b : nullptr;

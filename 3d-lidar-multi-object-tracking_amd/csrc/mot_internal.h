@@ -72,6 +72,7 @@ struct GroundBuffers {
   const int* n;            // [B] points per frame (device)
   uint2* pairs;            // [B][max_chunks][kGroundChunk] {polar cell, ordered-int key of a partial min z}
   int* pair_count;         // [B][max_chunks] entries each workgroup of the min-z kernel produced
+  unsigned short* cell;    // [B][cap] polar cell of every point (0xffff: takes no part), written by the min-z kernel, read by the compaction kernel
   float* hg;               // [B][9600] hGround of ground cells, -inf for non-ground cells
   unsigned long long* desc;  // [B][max_chunks]
   int* ticket;             // [B], zero between launches (the workgroup drawing the last ticket re-arms it)
@@ -133,6 +134,7 @@ struct ClusterBuffers {
   int* counts;                 // [B][kCountsStride]
   unsigned* plane_a;           // [B][2048] cell seen >= 1
   unsigned* plane_b;           // [B][2048] cell seen >= 2
+  unsigned* ccl_parent;        // [B][kMaxRuns] union-find array of the labelling kernel for frames with more runs than its LDS holds
   int* grid;                   // [B][65536] labels, x-major with stride num_grid
   int* label;                  // [B][cap] label of each elevated point
   ClusterStats* stats;         // [B][kMaxClusters]

@@ -143,6 +143,24 @@ __device__ __forceinline__ unsigned long long row_or_u64(unsigned long long v) {
 #endif
 }
 
+// value of the previous / next lane of the same 16-lane row; `fill` for the row's first / last lane
+__device__ __forceinline__ int row_prev_i32(int v, int fill) {
+#ifndef MOT_HIPEMU
+  return __builtin_amdgcn_update_dpp(fill, v, 0x111 /* row_shr:1 */, 0xf, 0xf, false);
+#else
+  const int o = __shfl_up(v, 1, 64);
+  return (threadIdx.x & 15) == 0 ? fill : o;
+#endif
+}
+__device__ __forceinline__ int row_next_i32(int v, int fill) {
+#ifndef MOT_HIPEMU
+  return __builtin_amdgcn_update_dpp(fill, v, 0x101 /* row_shl:1 */, 0xf, 0xf, false);
+#else
+  const int o = __shfl_down(v, 1, 64);
+  return (threadIdx.x & 15) == 15 ? fill : o;
+#endif
+}
+
 struct OpMinI { __device__ __forceinline__ int operator()(int a, int b) const { return a < b ? a : b; } };
 struct OpMaxI { __device__ __forceinline__ int operator()(int a, int b) const { return a > b ? a : b; } };
 struct OpMinU64 { __device__ __forceinline__ unsigned long long operator()(unsigned long long a, unsigned long long b) const { return a < b ? a : b; } };

@@ -15,16 +15,22 @@ def scene_of(rank: int, slot: int, scenes_per_rank: int = 8) -> int:
 
 
 class TrackGather:
-    """all-gather of the live-track blocks. `device` = "cuda" (RCCL) or "cpu" (gloo, emulated kernels)."""
+    """all-gather of the live-track blocks. `device` = "cuda" (RCCL) or "cpu" (gloo, emulated kernels).
 
-    def __init__(self, batch: int, max_tracks: int, world: int, device: str):
+    One flat int32 buffer per rank — the B x max_tracks records followed by the B counts — so that a step is ONE collective."""
+
+    def __init__(self, batch: int, max_tracks: int, world: int, device: str, group=None):
         import torch
         self.torch = torch
         self.batch, self.max_tracks, self.world = batch, max_tracks, world
-        self.src = torch.zeros(batch, max_tracks, TRACK_RECORD_WORDS, dtype=torch.int32, device=device)
-        self.cnt = torch.zeros(batch, dtype=torch.int32, device=device)
-        self.dst = [torch.zeros_like(self.src) for _ in range(world)] if world > 1 else [self.src]
-        self.dst_cnt = [torch.zeros_like(self.cnt) for _ in range(world)] if world > 1 else [self.cnt]
+        self.group = group   # process group of the collective (None = the default group)
+        nrec = batch * max_tracks * TRACK_RECORD_WORDS
+        self.flat = torch.zeros(nrec + batch, dtype=torch.int32, device=device)
+        self.src = self.flat[:nrec].view(batch, max_tracks, TRACK_RECORD_WORDS)
+        self.cnt = self.flat[nrec:]
+        self.dst_flat = [torch.zeros_like(self.flat) for _ in range(world)] if world > 1 else [self.flat]
+        self.dst = [d[:nrec].view(batch, max_tracks, TRACK_RECORD_WORDS) for d in self.dst_flat]
+        self.dst_cnt = [d[nrec:] for d in self.dst_flat]
         self._ext = {}   # context -> torch view of its HIP stream
 
     def step(self, ctx, force_collective: bool = False):
@@ -34,23 +40,27 @@ class TrackGather:
         waits for the previous step's collective (which still reads the block), the collective waits for the export —
         stream ordering only, so the next step's kernels are already queued behind it. On the CPU (gloo test) the
         emulated library is synchronous anyway."""
+        self.export(ctx)
+        return self.exchange(force_collective)
+
+    def export(self, ctx):
         torch = self.torch
-        gpu = self.src.is_cuda
-        if gpu:
+        if self.src.is_cuda:
             ext = self._ext.get(id(ctx))
             if ext is None:
                 ext = self._ext[id(ctx)] = torch.cuda.ExternalStream(ctx.lib.mot_stream(ctx._h))
             cur = torch.cuda.current_stream()
             ext.wait_stream(cur)      # the previous collective has consumed self.src / self.cnt
         ctx.export_tracks_dev(self.batch, self.src.data_ptr(), self.max_tracks, self.cnt.data_ptr())
-        if gpu:
+        if self.src.is_cuda:
             cur.wait_stream(ext)      # the block is complete before the collective reads it
         else:
             ctx.synchronize()
+
+    def exchange(self, force_collective: bool = False):
         if self.world > 1 or force_collective:
             import torch.distributed as dist
-            dist.all_gather(self.dst, self.src)
-            dist.all_gather(self.dst_cnt, self.cnt)
+            dist.all_gather(self.dst_flat, self.flat, group=self.group)
         return self.dst, self.dst_cnt
 
     def blocks_as_numpy(self):

@@ -30,6 +30,7 @@ import os
 import socket
 import subprocess
 import sys
+import threading
 import time
 
 import numpy as np
@@ -266,34 +267,62 @@ def selftest_cpu(args, rank, world):
     if world > 1:
         dist.init_process_group("gloo")
         assert dist.get_world_size() == args.gpus, (dist.get_world_size(), args.gpus)
-    B, N, stride, F = 2, 3000, 3072, 3
-    ctx = mot.Context(lib_path=lib, max_points=stride, max_batch=B, max_tracks_total=128)
-    tg = multi.TrackGather(B, 8, world, "cpu") if world > 1 else None
+    B, N, stride, F, NC = 2, 3000, 3072, 3, 2
+    Bc = B // NC
+    ctxs = [mot.Context(lib_path=lib, max_points=stride, max_batch=Bc, max_tracks_total=128) for _ in range(NC)]
+    groups = [dist.new_group(backend="gloo") for _ in range(NC)] if world > 1 else [None] * NC
+    tgs = [multi.TrackGather(Bc, 8, world, "cpu", group=groups[ci]) for ci in range(NC)] if world > 1 else None
     clouds = np.zeros((F, B, stride, 4), np.float32)
     for f in range(F):
         for b in range(B):
             clouds[f, b, :N] = synth.make_cloud(N, multi.scene_of(rank, b), f)
+
+    emu_lock = threading.Lock()   # the emulator keeps its "LDS" and fibers in process-wide state: one emulated kernel at a time
+
+    def run_context(ci, n_steps):   # the same issuing model as the GPU run: a host thread and a process group per context
+        cx = ctxs[ci]
+        for _ in range(n_steps):
+            with emu_lock:
+                cx.reset()
+            for f in range(F):
+                with emu_lock:
+                    cx.frames_dev(clouds[f, ci * Bc:(ci + 1) * Bc].ctypes.data, stride * 4, [N] * Bc, run_tracker=True, timestamps=[1.0e9 + f * 1e5] * Bc,
+                                  ego_v=[0.0] * Bc, ego_yaw=[0.0] * Bc)
+                if tgs:
+                    with emu_lock:
+                        tgs[ci].export(cx)
+                    tgs[ci].exchange()
+
+    def run_steps(n):
+        th = [threading.Thread(target=run_context, args=(ci, n)) for ci in range(NC)]
+        for t in th:
+            t.start()
+        for t in th:
+            t.join()
+
+    if args.warmup:
+        run_steps(args.warmup)
+    if world > 1:
+        dist.barrier()
     t0 = time.perf_counter()
-    for k in range(args.warmup + args.steps):
-        if k == args.warmup:
-            if world > 1:
-                dist.barrier()
-            t0 = time.perf_counter()
-        ctx.reset()
-        for f in range(F):
-            ctx.frames_dev(clouds[f].ctypes.data, stride * 4, [N] * B, run_tracker=True, timestamps=[1.0e9 + f * 1e5] * B, ego_v=[0.0] * B, ego_yaw=[0.0] * B)
-            if tg:
-                tg.step(ctx)
-    ctx.synchronize()
+    run_steps(args.steps)
+    for cx in ctxs:
+        cx.synchronize()
     if world > 1:
         dist.barrier()
     dt = time.perf_counter() - t0
+    if tgs:   # every rank holds every rank's block of every context
+        for tg in tgs:
+            blocks = tg.blocks_as_numpy()
+            assert len(blocks) == world and all(int(c.max()) >= 0 for c, _ in blocks)
     if rank == 0:
         frames = B * F * args.steps * world
-        print(json.dumps({"metric": "LiDAR frames/sec (120k-pt 64-beam cloud) end-to-end ground->cluster->track", "value": round(frames / dt, 2),
+        _JSON_OUT.write(json.dumps({"metric": "LiDAR frames/sec (120k-pt 64-beam cloud) end-to-end ground->cluster->track", "value": round(frames / dt, 2),
                           "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / max(args.steps, 1) * 1e3, 3),
                           "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32/f64", "data": "SELFTEST: emulated kernels on CPU, gloo — not a measurement",
-                          "config": {"workload": "launch-logic self-test", "streams": B * world, "frames_per_stream_per_step": F, "points_per_frame": N}}))
+                          "issue_threads": (NC if args.issue_threads and NC > 1 else 1),
+            "config": {"workload": "launch-logic self-test", "streams": B * world, "frames_per_stream_per_step": F, "points_per_frame": N}}) + "\n")
+        _JSON_OUT.flush()
     if world > 1:
         dist.barrier(); dist.destroy_process_group()
 
@@ -309,6 +338,8 @@ def main():
     ap.add_argument("--contexts", type=int, default=4, help="contexts (HIP streams) per GPU the streams are split over: the latency-bound "
                     "kernels of one (CCL, polygon, tracker: one workgroup per stream) overlap the streaming kernels of the others")
     ap.add_argument("--density", type=float, default=1.0, help="scene density (cars / pedestrians) of the synthetic street")
+    ap.add_argument("--issue-threads", type=int, default=1, help="1: one host thread per context issues its launches (default); 0: a single issuing thread")
+    ap.add_argument("--force-gather", action="store_true", help="run the per-frame RCCL all-gather of the track blocks even with one rank (exercises the N > 1 path on one GPU)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-aux", action="store_true", help="skip tracker_stress / host_boundary / per-kernel isolated timings")
     ap.add_argument("--selftest-cpu", action="store_true", help="launch-logic self-test on CPU (gloo + emulated kernels); not a measurement")
@@ -316,6 +347,14 @@ def main():
 
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
         sys.exit(self_spawn(args))
+    # stdout carries the ONE JSON line and nothing else: libraries that print there (RCCL's version banner at communicator
+    # creation) are sent to stderr for the whole run
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
+    json_out = os.fdopen(json_fd, "w")
+    global _JSON_OUT
+    _JSON_OUT = json_out
     rank = int(os.environ.get("RANK", "0")); world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
@@ -332,8 +371,11 @@ def main():
     if not torch.cuda.is_available():
         print("bench.py needs a GPU (the library has no CPU fallback)", file=sys.stderr); sys.exit(2)
     torch.cuda.set_device(local)
-    if world > 1:
+    gather_on = world > 1 or args.force_gather
+    if gather_on:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        if world == 1:   # --force-gather without a launcher: a one-rank group on the loopback
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29577"); os.environ.setdefault("RANK", "0"); os.environ.setdefault("WORLD_SIZE", "1")
         dist.init_process_group("nccl", device_id=torch.device("cuda", local))
         assert dist.get_world_size() == args.gpus, (dist.get_world_size(), args.gpus)
 
@@ -360,31 +402,60 @@ def main():
     n_seq = np.ascontiguousarray(n_seq, np.int32)
     ctxs = [mot.Context(device=local, max_points=stride, max_batch=Bc, max_tracks_total=4096) for _ in range(NC)]
     ctx = ctxs[0]
-    gathers = [multi.TrackGather(Bc, GATHER_TRACKS, world, "cuda") for _ in range(NC)] if world > 1 else None
+    # one process group (RCCL communicator) per context: each context's issuing thread orders its own collectives
+    groups = [dist.new_group(backend="nccl") for _ in range(NC)] if gather_on else None
+    gathers = [multi.TrackGather(Bc, GATHER_TRACKS, world, "cuda", group=groups[ci]) for ci in range(NC)] if gather_on else None
     torch.cuda.synchronize()
     frame_ptr = [seq_dev[f].data_ptr() for f in range(F)]
     ts_f = [np.full(Bc, 1.0e9 + f * 1.0e5, np.float64) for f in range(F)]   # microsecond stamps => dt = 0.1 s
     ev_f = [np.full(Bc, ego_v[f], np.float64) for f in range(F)]
     ey_f = [np.full(Bc, ego_yaw[f], np.float64) for f in range(F)]
-    host_issue = [0.0]   # seconds the host spent inside the asynchronous launch calls (if this approaches the step time, the host bounds the pipeline)
+    host_issue = [0.0]   # seconds the busiest issuing thread spent inside the asynchronous launch calls (if this approaches the timed region, the host bounds the pipeline)
+    busy = [0.0] * NC
+    side_streams = [torch.cuda.Stream() for _ in range(NC)]
 
-    def step():
+    def run_context(ci, n_steps):
+        """one host thread per context issues that context's launches: the C calls release the GIL, and a single issuing thread
+        (~0.2 ms per 128-frame launch sequence: 128 ego updates and tf matrices, 3 small H2D copies, 13 launches) starved the four
+        streams — each was idle a third of the time (profiles/r02_kernel_trace_B512_4ctx_tracker_v3.txt vs the step time)"""
+        torch.cuda.set_device(local)
+        cx = ctxs[ci]
         t_h = time.perf_counter()
-        for cx in ctxs:
-            cx.reset()   # every stream starts its sequence over (stream-ordered, no host synchronisation)
-        for f in range(F):
-            for ci, cx in enumerate(ctxs):  # asynchronous launches on NC HIP streams
-                cx.frames_dev(frame_ptr[f], stride * 4, n_seq[f], run_tracker=True, timestamps=ts_f[f], ego_v=ev_f[f], ego_yaw=ey_f[f])
-                if world > 1:  # the per-frame result blocks cross GPUs over RCCL / xGMI
-                    gathers[ci].step(cx)
-        host_issue[0] += time.perf_counter() - t_h
+        with torch.cuda.stream(side_streams[ci]):
+            for _ in range(n_steps):
+                cx.reset()   # every stream starts its sequence over (stream-ordered, no host synchronisation)
+                for f in range(F):
+                    cx.frames_dev(frame_ptr[f], stride * 4, n_seq[f], run_tracker=True, timestamps=ts_f[f], ego_v=ev_f[f], ego_yaw=ey_f[f])
+                    if gathers:  # the per-frame result blocks cross GPUs over RCCL / xGMI (one process group per context)
+                        gathers[ci].step(cx, force_collective=True)
+        busy[ci] = time.perf_counter() - t_h
+
+    def run_steps(n_steps):
+        if args.issue_threads and NC > 1:
+            th = [threading.Thread(target=run_context, args=(ci, n_steps)) for ci in range(NC)]
+            for t in th:
+                t.start()
+            for t in th:
+                t.join()
+        else:   # one issuing thread, contexts interleaved frame by frame
+            t_h = time.perf_counter()
+            for _ in range(n_steps):
+                for cx in ctxs:
+                    cx.reset()
+                for f in range(F):
+                    for ci, cx in enumerate(ctxs):
+                        cx.frames_dev(frame_ptr[f], stride * 4, n_seq[f], run_tracker=True, timestamps=ts_f[f], ego_v=ev_f[f], ego_yaw=ey_f[f])
+                        if gathers:
+                            gathers[ci].step(cx, force_collective=True)
+            busy[0] = time.perf_counter() - t_h
+        host_issue[0] = max(busy)
 
     def sync_all():
         for cx in ctxs:
             cx.synchronize()
 
-    for _ in range(args.warmup):
-        step()
+    if args.warmup:
+        run_steps(args.warmup)
     sync_all()
     # in-run timing of the dominant kernel: <= 64 event pairs per context, spread over the timed region
     dom = "classify_compact_kernel"
@@ -394,10 +465,8 @@ def main():
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
-    host_issue[0] = 0.0
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
+    run_steps(args.steps)
     sync_all()
     torch.cuda.synchronize()
     if world > 1:
@@ -450,6 +519,7 @@ def main():
             "dtype": "f32/f64 (fp32 grid indices with fp64 intermediates, int32 grids/labels, fp64 tracker — the reference's types)",
             "data": "synthetic", "inputs": "hbm-resident (rendered into HBM before the timed region; see host_boundary_pipelined for the PCIe-inclusive rate)",
             "timed_region_s": round(dt, 3), "host_issue_ms_per_step": round(host_issue[0] / args.steps * 1e3, 3),
+            "issue_threads": (NC if args.issue_threads and NC > 1 else 1),
             "config": {"workload": f"configs[3]: ground removal -> CCL -> box fit -> batched IMM-UKF-PDA tracker on one MI355X per rank; one step = {F}-frame "
                                    f"sequence (ego motion of KITTI drive_0005) of every stream, {N}-pt synthetic HDL-64E clouds, no frame repeated within a sequence",
                        "points_per_frame": N, "frames_per_stream_per_step": F, "streams_per_gpu": B, "streams": B * world, "distinct_scenes_per_gpu": Bc,
@@ -493,8 +563,8 @@ def main():
         del seq_dev
         if frames_host is not None:
             out["cpu_baseline"] = cpu_baseline(frames_host, ego_v, ego_yaw, N)
-        print(json.dumps(out))
-    if world > 1:
+        _JSON_OUT.write(json.dumps(out) + "\n"); _JSON_OUT.flush()
+    if gather_on:
         dist.barrier()
         dist.destroy_process_group()
 
