@@ -129,8 +129,8 @@ label_stats_kernel(MotDevParams p, ClusterBuffers c) {
   }
 #pragma unroll
   for (int k = 0; k < kLabelItems; k++) {
-    int xI, yI;
-    labs[k] = mot_cart_cell(p, qs[k].x, qs[k].y, &xI, &yI) ? xI * p.num_grid + yI : -1;
+    const int bit = mot_cart_bit(p, qs[k].x, qs[k].y);   // guarded fast cell (two IEEE divides per point otherwise), exact fallback
+    labs[k] = bit >= 0 ? (bit >> 8) * p.num_grid + (bit & 255) : -1;
   }
 #pragma unroll
   for (int k = 0; k < kLabelItems; k++) labs[k] = labs[k] >= 0 ? grid[labs[k]] : 0;
@@ -313,6 +313,21 @@ cluster_index_kernel(ClusterBuffers c) {
     if (tid == kIndexBlock - 1) s_start[kMaxClusters] = run;
   }
   B1B_T(0);
+  {  // processing order of the per-cluster kernels: largest first (a frame's kernel time is its slowest workgroup, and the big
+     // clusters — walls — take several times the average: profiles/r02_gather_phases.txt). Exact ranking up to 256 clusters.
+    __syncthreads();
+    int* __restrict__ order = c.order + (long)b * kMaxClusters;
+    if (num_cluster <= 256) {
+      for (int ci = tid; ci < num_cluster; ci += kIndexBlock) {
+        const int cnt = s_start[ci + 1] - s_start[ci];
+        int rank = 0;
+        for (int j = 0; j < num_cluster; j++) { const int cj = s_start[j + 1] - s_start[j]; rank += (cj > cnt || (cj == cnt && j < ci)) ? 1 : 0; }
+        order[rank] = ci;
+      }
+    } else {
+      for (int ci = tid; ci < num_cluster; ci += kIndexBlock) order[ci] = ci;
+    }
+  }
   int* __restrict__ cstart = c.cluster_start + (long)b * (kMaxClusters + 1);
   int* __restrict__ sorted = c.sorted + (long)b * c.cap;
   if (fast) {
@@ -445,6 +460,7 @@ cluster_gather_kernel(MotDevParams p, ClusterBuffers c) {
   __shared__ short s_px[kMaxHullIn + 2], s_py[kMaxHullIn + 2];
   __shared__ int s_rank[128], s_pidx[128];
   __shared__ int s_flag;
+  __shared__ int s_wsum[kBoxBlock / 64];
   const int b = blockIdx.y;
   const int n = c.counts[b * kCountsStride + kCntElev];
   const int num_cluster = min(c.counts[b * kCountsStride + kCntClusters], kMaxClusters);
@@ -454,6 +470,8 @@ cluster_gather_kernel(MotDevParams p, ClusterBuffers c) {
   const int lane = lane_id(), wave = (int)(threadIdx.x >> 6), tid = (int)threadIdx.x;
   (void)n;
 
+  // (clusters in label order. Dealing them by falling size — c.order, as the rectangle kernel does — measured SLOWER here:
+  // 42 -> 53 us even when dealt forwards and backwards in turn, 66 us forwards only; profiles/r02_cluster_order.txt)
   for (int ci = blockIdx.x; ci < num_cluster; ci += gridDim.x) {
     GATHER_T_BEGIN();
     const ClusterStats st = c.stats[(long)b * kMaxClusters + ci];
@@ -616,35 +634,38 @@ cluster_gather_kernel(MotDevParams p, ClusterBuffers c) {
       }
       __syncthreads();
       GATHER_T(1);
-      if (wave == 0) {
-        // compact the column extents into (x,y)-sorted points: 16 columns per lane, prefix over lanes
+      {
+        // compact the column extents into (x,y)-sorted points: 4 consecutive columns per thread, prefix over the workgroup
+        constexpr int kPerThread = kPicCols / kBoxBlock;
         int cnt = 0;
-        for (int k = 0; k < kPicCols / 64; k++) {
-          int col = lane * (kPicCols / 64) + k;
-          int lo = s_colmin[col], hi = s_colmax[col];
+#pragma unroll
+        for (int k = 0; k < kPerThread; k++) {
+          const int col = tid * kPerThread + k;
+          const int lo = s_colmin[col], hi = s_colmax[col];
           if (lo != 0x7fffffff) cnt += (hi != lo) ? 2 : 1;
         }
-        int incl = cnt;
+        const int incl = wave_scan_incl_i32(cnt);
+        if (lane == 63) s_wsum[wave] = incl;
+        __syncthreads();
+        int pos = incl - cnt, total = 0;
 #pragma unroll
-        for (int d = 1; d < 64; d <<= 1) { int o = __shfl_up(incl, d, 64); if (lane >= d) incl += o; }
-        int pos = incl - cnt;
-        for (int k = 0; k < kPicCols / 64; k++) {
-          int col = lane * (kPicCols / 64) + k;
-          int lo = s_colmin[col], hi = s_colmax[col];
+        for (int w2 = 0; w2 < kBoxBlock / 64; w2++) { const int ws = s_wsum[w2]; if (w2 < wave) pos += ws; total += ws; }
+#pragma unroll
+        for (int k = 0; k < kPerThread; k++) {
+          const int col = tid * kPerThread + k;
+          const int lo = s_colmin[col], hi = s_colmax[col];
           if (lo != 0x7fffffff) {
             s_px[pos] = (short)(col + offsetInitX); s_py[pos] = (short)lo; pos++;
             if (hi != lo) { s_px[pos] = (short)(col + offsetInitX); s_py[pos] = (short)hi; pos++; }
           }
         }
-        int total = __shfl(incl, 63, 64);
-        MOT_WAVE_SYNC();
-        int off = 0;
-        if (lane == 0) off = atomicAdd(&c.counts[b * kCountsStride + kCntPoly], total);
-        off = __shfl(off, 0, 64);
+        if (tid == 0) s_flag = atomicAdd(&c.counts[b * kCountsStride + kCntPoly], total);
+        __syncthreads();
+        const int off = s_flag;
         int* pool = c.poly + (long)b * c.cap;
-        for (int j = lane; j < total; j += 64) if (off + j < c.cap) pool[off + j] = ((int)(unsigned short)s_px[j]) | ((int)s_py[j] << 16);
+        for (int j = tid; j < total; j += kBoxBlock) if (off + j < c.cap) pool[off + j] = ((int)(unsigned short)s_px[j]) | ((int)s_py[j] << 16);
         GATHER_T(2);
-        if (lane == 0) {
+        if (tid == 0) {
           cand.poly_off = off; cand.poly_n = total; cand.off_x = offsetInitX; cand.off_y = offsetInitY;
           GATHER_T_STORE_RECT(cand);
           c.cand[(long)b * kMaxClusters + ci] = cand;
@@ -716,7 +737,13 @@ cluster_rect_kernel(MotDevParams p, ClusterBuffers c) {
 #else
 #define RLF(v, idx) __shfl((v), (idx), 64)
 #endif
-  for (int ci = blockIdx.x; ci < num_cluster; ci += gridDim.x) {
+  const int* __restrict__ order = c.order + (long)b * kMaxClusters;
+  // clusters by falling size, dealt to the frame's workgroups forwards, then backwards, ...: whoever got a large one in a round
+  // gets a small one in the next (45 -> 41 us)
+  for (int round = 0; round * (int)gridDim.x < num_cluster; round++) {
+    const int oi = round * (int)gridDim.x + ((round & 1) ? (int)gridDim.x - 1 - (int)blockIdx.x : (int)blockIdx.x);
+    if (oi >= num_cluster) continue;
+    const int ci = wave_uniform_i32(order[oi]);   // (a loaded value: keep the per-cluster addressing and branches scalar)
     BoxCandidate cand = c.cand[(long)b * kMaxClusters + ci];
     if (cand.branch != 1 || cand.undefined) continue;  // L-shape clusters are complete already
     const int offsetInitX = cand.off_x, offsetInitY = cand.off_y, numPoints = cand.num_points;

@@ -51,6 +51,7 @@ struct mot_ctx {
   int* d_poly = nullptr;
   PointGroup* d_groups = nullptr;
   int* d_cluster_start = nullptr;
+  int* d_order = nullptr;
   int* d_sorted = nullptr;
   int* d_pix = nullptr;
   // cluster-node side products (allocated on first use)
@@ -239,7 +240,7 @@ extern "C" void mot_destroy(mot_ctx* c) {
   if (c->prof_created)
     for (int i = 0; i < mot_ctx::kProfRing; i++) { (void)hipEventDestroy(c->prof_ev[i][0]); (void)hipEventDestroy(c->prof_ev[i][1]); }
   void* bufs[] = {c->d_in, c->d_n, c->d_pairs, c->d_pair_count, c->d_hg, c->d_cell, c->d_desc, c->d_ticket, c->d_elev, c->d_ground, c->d_mask, c->d_counts,
-                  c->d_plane_a, c->d_plane_b, c->d_ccl_parent, c->d_grid, c->d_label, c->d_stats, c->d_cand, c->d_boxes, c->d_box_cluster, c->d_rng, c->d_poly, c->d_groups, c->d_cluster_start, c->d_sorted, c->d_pix, c->d_wgtab, c->d_side_cell, c->d_side_cloud, c->d_side_obs, c->d_side_cost, c->d_side_counts, c->d_raw,
+                  c->d_plane_a, c->d_plane_b, c->d_ccl_parent, c->d_grid, c->d_label, c->d_stats, c->d_cand, c->d_boxes, c->d_box_cluster, c->d_rng, c->d_poly, c->d_groups, c->d_cluster_start, c->d_order, c->d_sorted, c->d_pix, c->d_wgtab, c->d_side_cell, c->d_side_cloud, c->d_side_obs, c->d_side_cost, c->d_side_counts, c->d_raw,
                   c->d_tracks, c->d_nt, c->d_tboxes, c->d_targs, c->d_gate, c->d_prog, c->d_live, c->d_tout, c->d_tflags, c->d_ego, c->d_nlive, c->d_pos, c->d_cp, c->d_items, c->d_nitems};
   for (void* b : bufs) if (b) (void)hipFree(b);
   if (c->h_counts) (void)hipHostFree(c->h_counts);
@@ -256,7 +257,7 @@ static ClusterBuffers cluster_buffers(mot_ctx* c) {
   ClusterBuffers b;
   b.elevated = c->d_elev; b.cap = c->cap; b.counts = c->d_counts; b.plane_a = c->d_plane_a; b.plane_b = c->d_plane_b; b.ccl_parent = c->d_ccl_parent;
   b.grid = c->d_grid; b.label = c->d_label; b.stats = c->d_stats; b.cand = c->d_cand; b.boxes = c->d_boxes;
-  b.box_cluster = c->d_box_cluster; b.rng = c->d_rng; b.poly = c->d_poly; b.groups = c->d_groups; b.group_cap = c->cap / 2; b.cluster_start = c->d_cluster_start; b.sorted = c->d_sorted;
+  b.box_cluster = c->d_box_cluster; b.rng = c->d_rng; b.poly = c->d_poly; b.groups = c->d_groups; b.group_cap = c->cap / 2; b.cluster_start = c->d_cluster_start; b.order = c->d_order; b.sorted = c->d_sorted;
   b.pix = c->d_pix; b.wgtab = c->d_wgtab; b.max_wg = c->max_wg;
   return b;
 }
@@ -305,6 +306,7 @@ static int create_impl(mot_ctx* c) {
   MOT_HIP(c, hipMalloc(&c->d_poly, B * N * sizeof(int)));
   MOT_HIP(c, hipMalloc(&c->d_groups, B * (N / 2) * sizeof(PointGroup)));
   MOT_HIP(c, hipMalloc(&c->d_cluster_start, B * (kMaxClusters + 1) * sizeof(int)));
+  MOT_HIP(c, hipMalloc(&c->d_order, B * kMaxClusters * sizeof(int)));
   MOT_HIP(c, hipMalloc(&c->d_sorted, B * N * sizeof(int)));
   MOT_HIP(c, hipMalloc(&c->d_pix, B * N * sizeof(int)));
   c->max_wg = (int)((N + 2047) / 2048);

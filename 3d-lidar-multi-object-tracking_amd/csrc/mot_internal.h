@@ -145,6 +145,7 @@ struct ClusterBuffers {
   int* poly;                   // [B][cap] candidate hull points (x | y << 16) of the min-area-rectangle clusters
   PointGroup* groups;          // [B][cap / 2] (tile, cluster) groups of the frame, any order
   int group_cap;               // cap / 2
+  int* order;                  // [B][kMaxClusters] clusters by falling size: the per-cluster kernels start on the largest ones
   int* cluster_start;          // [B][kMaxClusters + 1] first slot of every cluster in `sorted`
   int* sorted;                 // [B][cap] point indices grouped by cluster, input order inside a cluster
   int* pix;                    // [B][cap] picture pixel of every elevated point (x | y << 16, x = 0xffff outside), box_fitting.cpp:244-254

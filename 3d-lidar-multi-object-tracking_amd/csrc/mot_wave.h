@@ -108,6 +108,15 @@ __device__ __forceinline__ double wave_sum_f64(double v) {
 #endif
 }
 
+// a value every lane of the wave holds alike, moved to a scalar register: addresses and branches that depend on it stay scalar
+__device__ __forceinline__ int wave_uniform_i32(int v) {
+#ifndef MOT_HIPEMU
+  return __builtin_amdgcn_readfirstlane(v);
+#else
+  return v;
+#endif
+}
+
 // ---- reductions over ONE DPP row (16 lanes): every lane of the row receives its row's result. The tracker packs one track
 // per row, four tracks per wave.
 __device__ __forceinline__ double row_sum_f64(double v) {

@@ -8,27 +8,34 @@ def _load(name, path):
 import torch
 torch.cuda.init()
 PKG = os.path.join(ROOT, "3d-lidar-multi-object-tracking_amd")
-mot = _load("mot_amd", os.path.join(PKG, "__init__.py")); synth = _load("mot_amd.synth", os.path.join(PKG, "synth.py")); build = _load("mot_amd.build", os.path.join(PKG, "build.py"))
-B, N = 64, 120000
+mot = _load("mot_amd", os.path.join(PKG, "__init__.py")); sdev = _load("mot_amd.synth_dev", os.path.join(PKG, "synth_dev.py")); build = _load("mot_amd.build", os.path.join(PKG, "build.py"))
+B, N = 128, 120000
 stride = ((N + 2047) // 2048) * 2048
-host = np.zeros((B, stride, 4), np.float32)
-base = [synth.make_cloud(N, s, 0) for s in range(8)]
-for b in range(B): host[b, :N] = base[b % 8]
-dev = torch.from_numpy(host).cuda(); torch.cuda.synchronize()
+v, yaw = sdev.load_ego(2)
+seq, n_seq, _, _ = sdev.SequenceRenderer("cuda").render(list(range(B)), 2, N, stride, v, yaw)   # frames of the bench workload
 lib = build.build(extra_flags=["-DMOT_DBG_TIMING"], out=os.path.join(ROOT, "gpurun_out", "libmot_timing.so"))
 ctx = mot.Context(max_points=stride, max_batch=B, lib_path=lib)
-ctx.frames_dev(dev.data_ptr(), stride * 4, [N] * B); ctx.synchronize()
+ctx.frames_dev(seq[1].data_ptr(), stride * 4, n_seq[1]); ctx.synchronize()
 # run label+gather only, then read candidates
 import ctypes
 l = ctx.lib
 ms = ctx.time_stage(31, B, 3)   # leaves cand from gather overwritten by finalize? sequence: pre B1, timed B2, post B3 (B3 does not clear cand)
 cand_dt = np.dtype([("pc", "f4", 8), ("max_z", "f4"), ("accepted", "i4"), ("undefined", "i4"), ("branch", "i4"), ("poly_off", "i4"), ("poly_n", "i4"), ("off_x", "i4"), ("off_y", "i4"), ("num_points", "i4"), ("pad", "i4")])
-for slot in (0, 7):
-    buf = np.zeros(32, cand_dt)
+rows = []
+for slot in range(0, B, 4):
+    buf = np.zeros(64, cand_dt)
     rc = l.mot_debug_copy(ctx._h, 0, slot, buf.ctypes.data_as(ctypes.c_void_p), ctypes.c_size_t(buf.nbytes))
-    ncl = ctx.get_clusters(slot)["num_cluster"]
+    ncl = min(ctx.get_clusters(slot)["num_cluster"], 64)
     for i in range(ncl):
         c = buf[i]
-        if c["branch"] == 0: print(slot, i, "L  n=%d  t_prologue=%d t_rng=%d t_tiles=%d t_end=%d" % (c["num_points"], c["poly_off"], c["poly_n"], c["off_x"], c["off_y"]))
-        else: print(slot, i, "MAR n=%d  t_prologue=%d t_tiles=%d t_compact=%d  wait=%d process=%d" % (c["num_points"], c["pad"], c["poly_off"], c["poly_n"], c["off_x"], c["off_y"]))
-print("gather ms", ms)
+        if c["branch"] == 0: rows.append(("L", int(c["num_points"]), int(c["poly_off"]), int(c["poly_n"]), int(c["off_x"]), int(c["off_y"])))
+        elif c["branch"] == 1: rows.append(("MAR", int(c["num_points"]), int(c["pad"]), int(c["poly_off"]), int(c["poly_n"]), 0))
+for kind in ("L", "MAR"):
+    r = np.array([x[1:] for x in rows if x[0] == kind], np.float64)
+    if len(r) == 0: continue
+    print(kind, "clusters", len(r), "points mean %.0f max %.0f" % (r[:, 0].mean(), r[:, 0].max()))
+    names = ["prologue", "rng", "sample lookups", "end"] if kind == "L" else ["prologue", "point walk", "compaction", "-"]
+    print("   cycle stamps (mean / max):", {n: (int(r[:, 1 + k].mean()), int(r[:, 1 + k].max())) for k, n in enumerate(names)})
+    big = r[np.argsort(-r[:, 0])[:5]]
+    print("   five largest:", [tuple(int(v) for v in row) for row in big])
+print("gather ms", ms, "clusters per frame", len(rows) / (B / 4))
