@@ -723,10 +723,16 @@ __device__ int peel_chain(const int* src, int m, int* b0, int* b1, int sign, con
   return m;
 }
 
-__global__ void MOT_LAUNCH_BOUNDS(kRectBlock)
-cluster_rect_kernel(MotDevParams p, ClusterBuffers c) {
-  __shared__ int s_in[kMaxHullIn + 2];                        // candidate points (x | y << 16), sorted by (x,y)
-  __shared__ int s_b0[kMaxHullIn + 2], s_b1[kMaxHullIn + 2];  // peeling ping-pong
+// Two instantiations share the work by the number of candidate points of a cluster: up to kSmallHullIn (every cluster of a street
+// scene) / more (objects wider than ~14 m of picture columns). The small one keeps 14 KB of LDS per wave instead of 29 KB: with
+// one wave per workgroup that is the difference between sharing a CU with the streaming kernels of the other contexts and
+// locking them out of its LDS (bench 452 k -> 469 k frames/s, profiles/r02_ablate_bench_lds.txt). The large one finds no
+// work in most launches and returns after reading its clusters' candidate records.
+constexpr int kSmallHullIn = 510;
+template <int kIn, bool kLarge>
+__device__ __forceinline__ void cluster_rect_body(const MotDevParams& p, const ClusterBuffers& c) {
+  __shared__ int s_in[kIn + 2];                   // candidate points (x | y << 16), sorted by (x,y)
+  __shared__ int s_b0[kIn + 2], s_b1[kIn + 2];    // peeling ping-pong
   __shared__ float s_hx[kMaxHull], s_hy[kMaxHull], s_vx[kMaxHull], s_vy[kMaxHull], s_inv[kMaxHull];
   const int b = blockIdx.y;
   const int num_cluster = min(c.counts[b * kCountsStride + kCntClusters], kMaxClusters);
@@ -746,10 +752,11 @@ cluster_rect_kernel(MotDevParams p, ClusterBuffers c) {
     const int ci = wave_uniform_i32(order[oi]);   // (a loaded value: keep the per-cluster addressing and branches scalar)
     BoxCandidate cand = c.cand[(long)b * kMaxClusters + ci];
     if (cand.branch != 1 || cand.undefined) continue;  // L-shape clusters are complete already
+    if ((cand.poly_n > kSmallHullIn) != kLarge) continue;   // the other instantiation's cluster
     const int offsetInitX = cand.off_x, offsetInitY = cand.off_y, numPoints = cand.num_points;
     const float maxZ = cand.max_z;
     int total = cand.poly_n;
-    if (cand.poly_off + total > c.cap || total > kMaxHullIn) total = 0;
+    if (cand.poly_off + total > c.cap || total > kIn) total = 0;
     for (int j = lane; j < total; j += 64) s_in[j] = pool[cand.poly_off + j];
     MOT_WAVE_SYNC();
     // ---- cv::convexHull
@@ -939,6 +946,10 @@ cluster_rect_kernel(MotDevParams p, ClusterBuffers c) {
   }
 #undef RLF
 }
+__global__ void MOT_LAUNCH_BOUNDS(kRectBlock)
+cluster_rect_kernel(MotDevParams p, ClusterBuffers c) { cluster_rect_body<kSmallHullIn, false>(p, c); }
+__global__ void MOT_LAUNCH_BOUNDS(kRectBlock)
+cluster_rect_large_kernel(MotDevParams p, ClusterBuffers c) { cluster_rect_body<kMaxHullIn, true>(p, c); }
 
 // ------------------------------------------------------------------------------------------ B3
 constexpr int kFinalBlock = 256;
@@ -1007,7 +1018,10 @@ void mot_launch_box_kernel(int which, const MotDevParams& p, const ClusterBuffer
   if (chunks < 1) chunks = 1;
   if (which == 0) hipLaunchKernelGGL(label_stats_kernel, dim3(chunks, batch), dim3(kLabelBlock), 0, stream, p, c);
   else if (which == 1) hipLaunchKernelGGL(cluster_gather_kernel, dim3(32, batch), dim3(kBoxBlock), 0, stream, p, c);  // clusters beyond 32 per frame loop
-  else if (which == 3) hipLaunchKernelGGL(cluster_rect_kernel, dim3(24, batch), dim3(kRectBlock), 0, stream, p, c);
+  else if (which == 3) {
+    hipLaunchKernelGGL(cluster_rect_kernel, dim3(24, batch), dim3(kRectBlock), 0, stream, p, c);
+    hipLaunchKernelGGL(cluster_rect_large_kernel, dim3(8, batch), dim3(kRectBlock), 0, stream, p, c);
+  }
   else if (which == 4) hipLaunchKernelGGL(cluster_index_kernel, dim3(batch), dim3(kIndexBlock), 0, stream, c);
   else if (which == 2) hipLaunchKernelGGL(box_finalize_kernel, dim3(batch), dim3(kFinalBlock), 0, stream, p, c);
 }

@@ -400,7 +400,8 @@ def main():
     seq_dev, n_seq, _objs, _path = renderer.render([1000 * rank + s for s in range(Bc)], F, N, stride, ego_v, ego_yaw, density=args.density)
     render_s = time.perf_counter() - t_r
     n_seq = np.ascontiguousarray(n_seq, np.int32)
-    ctxs = [mot.Context(device=local, max_points=stride, max_batch=Bc, max_tracks_total=4096) for _ in range(NC)]
+    variant = os.environ.get("MOT_BENCH_LIB")   # experiments only (tools/ablate.py bench ...): a variant build of the library; the line then says so
+    ctxs = [mot.Context(device=local, max_points=stride, max_batch=Bc, max_tracks_total=4096, **({"lib_path": variant} if variant else {})) for _ in range(NC)]
     ctx = ctxs[0]
     # one process group (RCCL communicator) per context: each context's issuing thread orders its own collectives
     groups = [dist.new_group(backend="nccl") for _ in range(NC)] if gather_on else None
@@ -517,7 +518,7 @@ def main():
             "value": round(frames / dt, 1), "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(dt / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32/f64 (fp32 grid indices with fp64 intermediates, int32 grids/labels, fp64 tracker — the reference's types)",
-            "data": "synthetic", "inputs": "hbm-resident (rendered into HBM before the timed region; see host_boundary_pipelined for the PCIe-inclusive rate)",
+            "data": "synthetic" if not variant else f"synthetic; EXPERIMENT BUILD {variant} — not the product library", "inputs": "hbm-resident (rendered into HBM before the timed region; see host_boundary_pipelined for the PCIe-inclusive rate)",
             "timed_region_s": round(dt, 3), "host_issue_ms_per_step": round(host_issue[0] / args.steps * 1e3, 3),
             "issue_threads": (NC if args.issue_threads and NC > 1 else 1),
             "config": {"workload": f"configs[3]: ground removal -> CCL -> box fit -> batched IMM-UKF-PDA tracker on one MI355X per rank; one step = {F}-frame "
