@@ -136,12 +136,34 @@ ccl_kernel(MotDevParams p, ClusterBuffers c) {
   unsigned* __restrict__ ga = c.plane_a + (long)b * kPlaneWords;
   unsigned* __restrict__ gb = c.plane_b + (long)b * kPlaneWords;
 
-  // occupied cells: count > 1 (OT) or any point (OT0); consume and clear the frame's planes
-  for (int i = tid; i < kPlaneWords; i += kCclBlock) {
-    unsigned a = ga[i], bb = gb[i];
-    if (a) ga[i] = 0u;
-    if (bb) gb[i] = 0u;
-    s_occ[i] = p.occ_min_count >= 2 ? bb : a;
+  if (c.occ_list) {
+    // fused path: fold the per-chunk lists the compaction kernel left (ground.hip) — s_occ collects "seen >= 1", s_aux
+    // "seen >= 2"; a cell that two chunks saw once each is promoted by whichever entry arrives second
+    for (int i = tid; i < kPlaneWords; i += kCclBlock) { s_occ[i] = 0u; s_aux[i] = 0u; }
+    __syncthreads();
+    const int nchunks = (c.n_in[b] + kCompactChunk - 1) / kCompactChunk;
+    const OccWord* __restrict__ lists = c.occ_list + (long)b * c.occ_chunks * kPlaneWords;
+    const int* __restrict__ cnt = c.occ_count + (long)b * c.occ_chunks;
+    for (int ch = tid >> 6; ch < nchunks && ch < c.occ_chunks; ch += kCclBlock / 64) {   // a wave per list: the lists are read side by side
+      const int ne = cnt[ch];
+      for (int e = tid & 63; e < ne; e += 64) {
+        const OccWord w = lists[(long)ch * kPlaneWords + e];
+        const unsigned old = atomicOr(&s_occ[w.word], w.a);
+        const unsigned twice = w.b | (old & w.a);
+        if (twice) atomicOr(&s_aux[w.word], twice);
+      }
+    }
+    __syncthreads();
+    if (p.occ_min_count >= 2)
+      for (int i = tid; i < kPlaneWords; i += kCclBlock) s_occ[i] = s_aux[i];
+  } else {
+    // occupied cells: count > 1 (OT) or any point (OT0); consume and clear the frame's planes
+    for (int i = tid; i < kPlaneWords; i += kCclBlock) {
+      unsigned a = ga[i], bb = gb[i];
+      if (a) ga[i] = 0u;
+      if (bb) gb[i] = 0u;
+      s_occ[i] = p.occ_min_count >= 2 ? bb : a;
+    }
   }
   for (int i = tid; i <= MOT_MAX_GRID; i += kCclBlock) s_rowbase[i] = 0;
   __syncthreads();

@@ -317,6 +317,7 @@ classify_compact_kernel(MotDevParams p, GroundBuffers g) {
   __shared__ int s_base_e, s_base_g;
   // occupancy of the cluster stage's Cartesian grid by this chunk's elevated points: "cell seen >= 1" / "seen >= 2"
   __shared__ unsigned s_occ_a[kPlaneWords], s_occ_b[kPlaneWords];
+  __shared__ int s_occ_n;
   const int b = blockIdx.y;
   const int n = g.n[b];
   const int nchunks = (n + kCompactChunk - 1) / kCompactChunk;
@@ -324,14 +325,16 @@ classify_compact_kernel(MotDevParams p, GroundBuffers g) {
     if (nchunks == 0 && blockIdx.x == 0 && threadIdx.x == 0) { g.counts[b * kCountsStride + kCntElev] = 0; g.counts[b * kCountsStride + kCntGround] = 0; g.counts[b * kCountsStride + kCntDropped] = 0; }
     return;
   }
-  const bool occupancy = g.plane_a != nullptr;   // uniform
+  const bool occupancy = g.occ_list != nullptr;   // uniform
   if (threadIdx.x == 0) {
     int t = atomicAdd(&g.ticket[b], 1);      // chunk id in arrival order: every predecessor is already running
     if (t == nchunks - 1) g.ticket[b] = 0;   // last ticket of this frame: re-arm for the next launch
     s_chunk = t;
   }
-  if (occupancy)
+  if (occupancy) {
     for (int i = threadIdx.x; i < kPlaneWords; i += kCompactBlock) { s_occ_a[i] = 0u; s_occ_b[i] = 0u; }
+    if (threadIdx.x == 0) s_occ_n = 0;
+  }
   __syncthreads();
   const int chunk = s_chunk;
   const long base = (long)chunk * kCompactChunk;
@@ -508,19 +511,21 @@ classify_compact_kernel(MotDevParams p, GroundBuffers g) {
   }
   if (wave == 0) side_work();
   if (occupancy) {
-    // merge into the frame's planes (L2) with one returning atomicOr per non-zero word; a bit that two workgroups both
-    // saw once is promoted to the ">= 2" plane by whoever merges second
+    // The chunk's non-zero plane words leave as a list (plain stores); the labelling kernel — one workgroup per frame — folds
+    // the frame's lists in LDS, where a cell two chunks saw once each is promoted to "seen >= 2". (Merging into per-frame
+    // planes in HBM with returning atomics, as the stand-alone occupancy kernel does, cost ~10 us of this kernel: the 30
+    // workgroups of a frame sit on different XCDs, so those atomics are executed on the memory side.)
     __syncthreads();   // wave 0's LDS atomics above, everybody else's before the previous barrier
-    unsigned* __restrict__ ga = g.plane_a + (long)b * kPlaneWords;
-    unsigned* __restrict__ gb = g.plane_b + (long)b * kPlaneWords;
+    OccWord* __restrict__ list = g.occ_list + ((long)b * g.occ_chunks + chunk) * kPlaneWords;
     for (int i = threadIdx.x; i < kPlaneWords; i += kCompactBlock) {
       const unsigned a = s_occ_a[i];
       if (a) {
-        const unsigned old = atomicOr(&ga[i], a);
-        const unsigned twice = s_occ_b[i] | (old & a);
-        if (twice) atomicOr(&gb[i], twice);
+        OccWord w; w.word = (unsigned)i; w.a = a; w.b = s_occ_b[i]; w.pad = 0u;
+        list[atomicAdd(&s_occ_n, 1)] = w;   // at most kPlaneWords entries: cannot overflow
       }
     }
+    __syncthreads();
+    if (threadIdx.x == 0) g.occ_count[(long)b * g.occ_chunks + chunk] = s_occ_n;
   }
 }
 

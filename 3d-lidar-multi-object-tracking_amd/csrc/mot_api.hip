@@ -41,6 +41,9 @@ struct mot_ctx {
   unsigned* d_plane_a = nullptr;
   unsigned* d_plane_b = nullptr;
   unsigned* d_ccl_parent = nullptr;
+  OccWord* d_occ_list = nullptr;
+  int* d_occ_count = nullptr;
+  int occ_chunks = 0;
   int* d_grid = nullptr;
   int* d_label = nullptr;
   ClusterStats* d_stats = nullptr;
@@ -240,7 +243,7 @@ extern "C" void mot_destroy(mot_ctx* c) {
   if (c->prof_created)
     for (int i = 0; i < mot_ctx::kProfRing; i++) { (void)hipEventDestroy(c->prof_ev[i][0]); (void)hipEventDestroy(c->prof_ev[i][1]); }
   void* bufs[] = {c->d_in, c->d_n, c->d_pairs, c->d_pair_count, c->d_hg, c->d_cell, c->d_desc, c->d_ticket, c->d_elev, c->d_ground, c->d_mask, c->d_counts,
-                  c->d_plane_a, c->d_plane_b, c->d_ccl_parent, c->d_grid, c->d_label, c->d_stats, c->d_cand, c->d_boxes, c->d_box_cluster, c->d_rng, c->d_poly, c->d_groups, c->d_cluster_start, c->d_order, c->d_sorted, c->d_pix, c->d_wgtab, c->d_side_cell, c->d_side_cloud, c->d_side_obs, c->d_side_cost, c->d_side_counts, c->d_raw,
+                  c->d_plane_a, c->d_plane_b, c->d_ccl_parent, c->d_occ_list, c->d_occ_count, c->d_grid, c->d_label, c->d_stats, c->d_cand, c->d_boxes, c->d_box_cluster, c->d_rng, c->d_poly, c->d_groups, c->d_cluster_start, c->d_order, c->d_sorted, c->d_pix, c->d_wgtab, c->d_side_cell, c->d_side_cloud, c->d_side_obs, c->d_side_cost, c->d_side_counts, c->d_raw,
                   c->d_tracks, c->d_nt, c->d_tboxes, c->d_targs, c->d_gate, c->d_prog, c->d_live, c->d_tout, c->d_tflags, c->d_ego, c->d_nlive, c->d_pos, c->d_cp, c->d_items, c->d_nitems};
   for (void* b : bufs) if (b) (void)hipFree(b);
   if (c->h_counts) (void)hipHostFree(c->h_counts);
@@ -256,6 +259,7 @@ static void prepare_track_args(mot_ctx* c, int slot, int m, double timestamp, bo
 static ClusterBuffers cluster_buffers(mot_ctx* c) {
   ClusterBuffers b;
   b.elevated = c->d_elev; b.cap = c->cap; b.counts = c->d_counts; b.plane_a = c->d_plane_a; b.plane_b = c->d_plane_b; b.ccl_parent = c->d_ccl_parent;
+  b.occ_list = nullptr; b.occ_count = nullptr; b.n_in = c->d_n; b.occ_chunks = c->occ_chunks;   // the fused path points these at the compaction kernel's lists
   b.grid = c->d_grid; b.label = c->d_label; b.stats = c->d_stats; b.cand = c->d_cand; b.boxes = c->d_boxes;
   b.box_cluster = c->d_box_cluster; b.rng = c->d_rng; b.poly = c->d_poly; b.groups = c->d_groups; b.group_cap = c->cap / 2; b.cluster_start = c->d_cluster_start; b.order = c->d_order; b.sorted = c->d_sorted;
   b.pix = c->d_pix; b.wgtab = c->d_wgtab; b.max_wg = c->max_wg;
@@ -296,6 +300,10 @@ static int create_impl(mot_ctx* c) {
   MOT_HIP(c, hipMalloc(&c->d_plane_a, B * kPlaneWords * sizeof(unsigned)));
   MOT_HIP(c, hipMalloc(&c->d_plane_b, B * kPlaneWords * sizeof(unsigned)));
   MOT_HIP(c, hipMalloc(&c->d_ccl_parent, B * kMaxRuns * sizeof(unsigned)));
+  c->occ_chunks = (int)((N + kCompactChunk - 1) / kCompactChunk);
+  MOT_HIP(c, hipMalloc(&c->d_occ_list, B * c->occ_chunks * kPlaneWords * sizeof(OccWord)));
+  MOT_HIP(c, hipMalloc(&c->d_occ_count, B * c->occ_chunks * sizeof(int)));
+  MOT_HIP(c, hipMemsetAsync(c->d_occ_count, 0, B * c->occ_chunks * sizeof(int), c->stream));
   MOT_HIP(c, hipMalloc(&c->d_grid, B * MOT_MAX_GRID * MOT_MAX_GRID * sizeof(int)));
   MOT_HIP(c, hipMalloc(&c->d_label, B * N * sizeof(int)));
   MOT_HIP(c, hipMalloc(&c->d_stats, B * kMaxClusters * sizeof(ClusterStats)));
@@ -424,7 +432,7 @@ static GroundBuffers ground_buffers(mot_ctx* c, const float4* in, long stride, b
   g.in = in; g.in_stride = stride; g.n = c->d_n; g.pairs = c->d_pairs; g.pair_count = c->d_pair_count; g.hg = c->d_hg; g.cell = c->d_cell; g.desc = c->d_desc;
   g.ticket = c->d_ticket; g.elevated = c->d_elev; g.ground = c->d_ground; g.mask = want_mask ? c->d_mask : nullptr;
   g.counts = c->d_counts; g.cap = c->cap; g.max_chunks = c->max_chunks;
-  g.plane_a = planes ? c->d_plane_a : nullptr; g.plane_b = planes ? c->d_plane_b : nullptr;
+  g.occ_list = planes ? c->d_occ_list : nullptr; g.occ_count = planes ? c->d_occ_count : nullptr; g.occ_chunks = c->occ_chunks;
   return g;
 }
 
@@ -542,7 +550,8 @@ static int launch_frames(mot_ctx* c, int batch, int run_tracker, const double* t
   { ProfScope ps(c, kK2); mot_launch_ground_kernel(1, c->dp, g, batch, max_n, c->stream); }
   { ProfScope ps(c, kK3); mot_launch_ground_kernel(2, c->dp, g, batch, max_n, c->stream); }
   ClusterBuffers cb = cluster_buffers(c);
-  { ProfScope ps(c, kC2); mot_launch_cluster(c->dp, cb, batch, max_n, c->stream, true); }   // occupancy planes filled by the compaction kernel
+  cb.occ_list = c->d_occ_list; cb.occ_count = c->d_occ_count;   // the occupancy comes as the compaction kernel's per-chunk lists
+  { ProfScope ps(c, kC2); mot_launch_cluster(c->dp, cb, batch, max_n, c->stream, true); }
   { ProfScope ps(c, kB1); mot_launch_box_kernel(0, c->dp, cb, batch, max_n, c->stream); }
   { ProfScope ps(c, kB1b); mot_launch_box_kernel(4, c->dp, cb, batch, max_n, c->stream); }
   { ProfScope ps(c, kB2); mot_launch_box_kernel(1, c->dp, cb, batch, max_n, c->stream); }
@@ -983,13 +992,13 @@ static int launch_one(mot_ctx* c, int id, int batch) {
   int rc;
   const int max_n = c->last_max_n;
   if (id == kK3 && (rc = next_epoch(c))) return rc;
-  GroundBuffers g = ground_buffers(c, c->last_in, c->last_in_stride, true, true);   // as in the fused path: the compaction kernel fills the occupancy planes
+  GroundBuffers g = ground_buffers(c, c->last_in, c->last_in_stride, true, true);   // as in the fused path: the compaction kernel leaves the occupancy lists
   ClusterBuffers cb = cluster_buffers(c);
+  cb.occ_list = c->d_occ_list; cb.occ_count = c->d_occ_count;
   switch (id) {
     case kK1: mot_launch_ground_kernel(0, c->dp, g, batch, max_n, c->stream); break;
     case kK2: mot_launch_ground_kernel(1, c->dp, g, batch, max_n, c->stream); break;
     case kK3: mot_launch_ground_kernel(2, c->dp, g, batch, max_n, c->stream); break;
-    case kC1: mot_launch_cluster_kernel(0, c->dp, cb, batch, max_n, c->stream); break;
     case kC2: mot_launch_cluster_kernel(1, c->dp, cb, batch, max_n, c->stream); break;
     case kB1: mot_launch_box_kernel(0, c->dp, cb, batch, max_n, c->stream); break;
     case kB2: mot_launch_box_kernel(1, c->dp, cb, batch, max_n, c->stream); break;
@@ -1015,8 +1024,8 @@ extern "C" int mot_time_stage(mot_ctx* c, int stage, int batch, int iters, float
   struct Seq { int pre[4], timed[12], post[3]; };
   Seq s = {{0, 0, 0, 0}, {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, {0, 0, 0}};
   switch (stage) {
-    // (the compaction kernel K3 fills the occupancy planes, the labelling kernel C2 consumes and clears them: the two
-    // always run as a pair; C1, the stand-alone occupancy kernel of the stage-wise mot_cluster, is timed the same way)
+    // (the compaction kernel K3 leaves the occupancy lists the labelling kernel C2 folds; the stand-alone occupancy kernel
+    // of the stage-wise mot_cluster is not timed here)
     case 0: s = {{0}, {kK1, kK2, kK3}, {kC2}}; break;
     case 1: s = {{kK3}, {kC2}, {0}}; break;
     case 2: s = {{0}, {kB1, kB1b, kB2, kB2b, kB3}, {0}}; break;
@@ -1024,7 +1033,6 @@ extern "C" int mot_time_stage(mot_ctx* c, int stage, int batch, int iters, float
     case kK1: s = {{0}, {kK1}, {0}}; break;
     case kK2: s = {{0}, {kK2}, {0}}; break;
     case kK3: s = {{0}, {kK3}, {kC2}}; break;
-    case kC1: s = {{0}, {kC1}, {kC2}}; break;
     case kC2: s = {{kK3}, {kC2}, {0}}; break;
     case kB1: s = {{0}, {kB1}, {kB1b, kB3}}; break;
     case kB1b: s = {{kB1}, {kB1b}, {kB3}}; break;

@@ -65,6 +65,8 @@ struct MotDevParams {
       t_ratio_max, min_len_ratio, t_pt_per_m3;
 };
 
+struct OccWord { unsigned word, a, b, pad; };   // word index in the bit-plane, its "seen >= 1" and "seen >= 2" bits
+
 // device buffers of the ground stage for a batch of frames (frame b = slot b)
 struct GroundBuffers {
   const float4* in;        // [B][in_stride] points
@@ -83,11 +85,13 @@ struct GroundBuffers {
   int* counts;             // [B][kCountsStride]: n_elevated, n_ground, n_dropped, ...
   long cap;                // capacity (points) per frame of the outputs
   int max_chunks;
-  // occupancy bit-planes of the cluster stage ([B][kPlaneWords] each, see ClusterBuffers), or null: when set, the
-  // compaction kernel also files every elevated point under its Cartesian cell (mapCartesianGrid's histogram,
-  // component_clustering.cpp:36-50) while the point is still in registers, and the fused path skips cart_occupancy_kernel
-  unsigned* plane_a;
-  unsigned* plane_b;
+  // Occupancy of the cluster stage's grid, or null: when set, the compaction kernel also files every elevated point under its
+  // Cartesian cell (mapCartesianGrid's histogram, component_clustering.cpp:36-50) while the point is still in registers, and
+  // the fused path skips cart_occupancy_kernel. Every workgroup (chunk) leaves the non-zero words of its two bit-planes
+  // ("cell seen >= 1" / ">= 2" within the chunk) as a list; the labelling kernel folds the lists of a frame.
+  OccWord* occ_list;       // [B][occ_chunks][kPlaneWords]
+  int* occ_count;          // [B][occ_chunks] entries of each list
+  int occ_chunks;
 };
 
 // ---- cluster + box stages ------------------------------------------------------------------
@@ -132,8 +136,12 @@ struct ClusterBuffers {
   const float4* elevated;      // [B][cap]
   long cap;
   int* counts;                 // [B][kCountsStride]
-  unsigned* plane_a;           // [B][2048] cell seen >= 1
+  unsigned* plane_a;           // [B][2048] cell seen >= 1   (filled by cart_occupancy_kernel: the stage-wise mot_cluster)
   unsigned* plane_b;           // [B][2048] cell seen >= 2
+  const OccWord* occ_list;     // fused path: the compaction kernel's per-chunk lists instead (see GroundBuffers), else null
+  const int* occ_count;
+  const int* n_in;             //   ... points of the frame's input cloud (chunks in use)
+  int occ_chunks;
   unsigned* ccl_parent;        // [B][kMaxRuns] union-find array of the labelling kernel for frames with more runs than its LDS holds
   int* grid;                   // [B][65536] labels, x-major with stride num_grid
   int* label;                  // [B][cap] label of each elevated point

@@ -322,7 +322,7 @@ int mot_decode_pointcloud2_dev(mot_ctx* ctx, const void* d_data, int n_points, i
 /* ---------------------------------------------------------------- measurement helpers (bench.py) */
 /* Re-runs only the named stage `iters` times on the data resident from the last mot_frames_dev call,
  * bracketed by hipEvents ON THE CONTEXT STREAM; returns average milliseconds per iteration.
- * stage: 0 ground, 1 cluster, 2 box, 100 the three stateless stages; single kernels: 10-12 ground, 20-21 cluster,
+ * stage: 0 ground, 1 cluster, 2 box, 100 the three stateless stages; single kernels: 10-12 ground, 21 cluster,
  * 30-34 box; 40 re-runs the tracker kernel with the last frame's arguments (that ADVANCES tracker state: bench only). */
 int mot_time_stage(mot_ctx* ctx, int stage, int batch, int iters, float* ms_per_iter);
 /* In-run timing: from now on every `every`-th mot_frames_dev / mot_frames_host call brackets its launch of kernel `kernel_id`

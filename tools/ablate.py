@@ -19,7 +19,7 @@ EXPERIMENTS = {
     "k3_256x16": [("FLAGS", "-DMOT_COMPACT_BLOCK=256", "-DMOT_COMPACT_CHUNK=4096")],
     "k3_1024x8": [("FLAGS", "-DMOT_COMPACT_BLOCK=1024", "-DMOT_COMPACT_CHUNK=8192")],
     # ---- classify_compact_kernel (12)
-    "k3_no_occupancy": [("ground.hip", "const bool occupancy = g.plane_a != nullptr;", "const bool occupancy = false;")],
+    "k3_no_occupancy": [("ground.hip", "const bool occupancy = g.occ_list != nullptr;", "const bool occupancy = false;")],
     "k3_no_lookback": [("ground.hip", "    if (chunk > 0) {\n      if (lane == 0) __hip_atomic_store(&desc[chunk], kDescAggregate | mine",
                         "    excl_e = chunk * 1200; excl_g = chunk * 2896;\n    if (false) {\n      if (lane == 0) __hip_atomic_store(&desc[chunk], kDescAggregate | mine")],
     "k3_no_mask": [("ground.hip", "    if (mask) {\n      if (full) {", "    if (false) {\n      if (full) {")],
