@@ -332,7 +332,8 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=12, help="timed steps; one step = every stream's whole --frames sequence")
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--batch", type=int, default=512, help="sensor streams per GPU")
+    ap.add_argument("--batch", type=int, default=2048, help="sensor streams per GPU (512 per context and launch: the per-frame and per-cluster kernels fill the chip, the streaming "
+                    "kernels run at the device copy rate — profiles/r02_streams_per_launch_sweep.txt; 154 frames x 512 scenes x 1.93 MB = 152 GB of the 288 GB HBM)")
     ap.add_argument("--points", type=int, default=120000)
     ap.add_argument("--frames", type=int, default=154, help="frames per stream per step (BASELINE.json configs[3]: the 154 frames of drive_0005)")
     ap.add_argument("--contexts", type=int, default=4, help="contexts (HIP streams) per GPU the streams are split over: the latency-bound "
@@ -397,7 +398,16 @@ def main():
     t_r = time.perf_counter()
     ego_v, ego_yaw = sdev.load_ego(F)
     renderer = sdev.SequenceRenderer(f"cuda:{local}")
-    seq_dev, n_seq, _objs, _path = renderer.render([1000 * rank + s for s in range(Bc)], F, N, stride, ego_v, ego_yaw, density=args.density)
+    while True:
+        try:
+            seq_dev, n_seq, _objs, _path = renderer.render([1000 * rank + s for s in range(Bc)], F, N, stride, ego_v, ego_yaw, density=args.density)
+            break
+        except RuntimeError as e:   # the sequences do not fit this device's free HBM: halve the streams and say so
+            if "out of memory" not in str(e).lower() or Bc < 2:
+                raise
+            print(f"bench.py: {B} streams do not fit ({e}); retrying with {B // 2}", file=sys.stderr)
+            torch.cuda.empty_cache()
+            B //= 2; Bc = B // NC
     render_s = time.perf_counter() - t_r
     n_seq = np.ascontiguousarray(n_seq, np.int32)
     variant = os.environ.get("MOT_BENCH_LIB")   # experiments only (tools/ablate.py bench ...): a variant build of the library; the line then says so
@@ -481,9 +491,19 @@ def main():
     if rank == 0:
         prof = [cx.profile_read() for cx in ctxs]
         nsamp = sum(p["samples"] for p in prof)
-        dom_ms = sum(p["mean_ms"] * p["samples"] for p in prof) / max(nsamp, 1)
+        shared_ms = sum(p["mean_ms"] * p["samples"] for p in prof) / max(nsamp, 1)
+        # ---- the dominant kernel with the GPU to itself: the same pipeline, same data, ONE context (in the timed region the NC
+        # contexts' kernels run concurrently and share HBM and CUs, so a launch's duration there measures its share of the machine,
+        # not the kernel: ~3x longer). 60 consecutive frames of the sequence on context 0, every kernel of the pipeline in its
+        # place, HIP event pairs around this one.
+        ctx.reset(); ctx.profile_kernel(K_IDS[dom], 1)
+        for f in range(min(F, 60)):
+            ctx.frames_dev(frame_ptr[f], stride * 4, n_seq[f], run_tracker=True, timestamps=ts_f[f], ego_v=ev_f[f], ego_yaw=ey_f[f])
+        solo = ctx.profile_read()
+        dom_ms = solo["mean_ms"]
+        ctx.profile_kernel(0, 1)
         # ---- bytes: the state after the last frame of the sequence is resident in every context
-        f_last = F - 1
+        f_last = min(F, 60) - 1
         counts = [ctx.get_ground(b, want_clouds=False) for b in range(Bc)]
         ne_tot = sum(c["n_elevated"] for c in counts); ng_tot = sum(c["n_ground"] for c in counts)
         n_tot = int(n_seq[f_last].sum())
@@ -508,11 +528,12 @@ def main():
         # HBM bytes per launch from the committed PMC passes of this command (FETCH_SIZE x2 on gfx950 + WRITE_SIZE, KB), same launch size only
         traffic, traffic_src = None, None
         pmc_path = os.path.join(ROOT, "profiles", "r02_pmc_B128.json")
-        if BL == 128 and N == 120000 and os.path.exists(pmc_path):
+        if N == 120000 and os.path.exists(pmc_path):
             pmc = json.load(open(pmc_path)).get(dom)
             if pmc and "FETCH_SIZE" in pmc and "WRITE_SIZE" in pmc:
-                traffic = int((2.0 * pmc["FETCH_SIZE"] + pmc["WRITE_SIZE"]) * 1024)
-                traffic_src = "profiles/r02_pmc_B128.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command at 128 frames per launch)"
+                traffic = int((2.0 * pmc["FETCH_SIZE"] + pmc["WRITE_SIZE"]) * 1024 / 128 * BL)
+                traffic_src = (f"profiles/r02_pmc_B128.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this pipeline at 128 frames per launch (FETCH_SIZE x 2: the gfx950 "
+                               f"correction for wide coalesced reads), scaled to the {BL} frames of a launch here")
         out = {
             "metric": "LiDAR frames/sec (120k-pt 64-beam cloud) end-to-end ground->cluster->track",
             "value": round(frames / dt, 1), "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -531,8 +552,13 @@ def main():
                        "parallelism": f"stream-sharded x{world}" + (", all_gather of live-track records per frame (RCCL)" if world > 1 else "")},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_src,
-                         "kernel_ms_in_run": {"mean": round(dom_ms, 5), "min": round(min(p["min_ms"] for p in prof), 5), "max": round(max(p["max_ms"] for p in prof), 5), "samples": nsamp,
-                                              "how": f"HIP event pairs around the kernel's launch on its own stream inside the timed region, {NC} contexts running (mot_profile_kernel)"},
+                         "kernel_ms": {"mean": round(dom_ms, 5), "min": round(solo["min_ms"], 5), "max": round(solo["max_ms"], 5), "samples": solo["samples"],
+                                       "how": "HIP event pairs around the kernel's launch on its own stream (mot_profile_kernel), the whole pipeline running on ONE context, "
+                                              "nothing else on the GPU; rocprofv3 summary of the same schedule: profiles/r02_kernel_trace_B512_1ctx.txt"},
+                         "kernel_ms_in_timed_region": {"mean": round(shared_ms, 5), "min": round(min(p["min_ms"] for p in prof), 5), "max": round(max(p["max_ms"] for p in prof), 5), "samples": nsamp,
+                                       "frac_if_taken_alone": round(alg_bytes[dom] / (shared_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if shared_ms > 0 else None,
+                                       "how": f"the same event pairs inside the timed region, where {NC} contexts' kernels run concurrently and share HBM and CUs: a launch's duration there is its "
+                                              "share of the machine (see pipeline_frac for the whole); rocprofv3 summary: profiles/r02_kernel_trace_B2048_4ctx.txt"},
                          "algorithmic_bytes_per_launch": {k: int(v) for k, v in alg_bytes.items()},
                          "pipeline_bytes_per_frame": int(frame_bytes),
                          "pipeline_frac": round(frame_bytes * B * F / (dt / args.steps) / 1e9 / HBM_PEAK_GBS, 4)},
