@@ -339,7 +339,8 @@ def main():
     ap.add_argument("--contexts", type=int, default=4, help="contexts (HIP streams) per GPU the streams are split over: the latency-bound "
                     "kernels of one (CCL, polygon, tracker: one workgroup per stream) overlap the streaming kernels of the others")
     ap.add_argument("--density", type=float, default=1.0, help="scene density (cars / pedestrians) of the synthetic street")
-    ap.add_argument("--issue-threads", type=int, default=1, help="1: one host thread per context issues its launches (default); 0: a single issuing thread")
+    ap.add_argument("--issue-threads", type=int, default=0, help="0 (default): one host thread issues every context's launches, frame by frame, in a fixed order (also the order of the "
+                    "collectives on every rank); 1: a host thread per context (measured equal: the launch queues, not the host, hold the pace — profiles/r02_issue_threads_contexts_sweep.txt)")
     ap.add_argument("--force-gather", action="store_true", help="run the per-frame RCCL all-gather of the track blocks even with one rank (exercises the N > 1 path on one GPU)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-aux", action="store_true", help="skip tracker_stress / host_boundary / per-kernel isolated timings")
@@ -456,8 +457,9 @@ def main():
                 for f in range(F):
                     for ci, cx in enumerate(ctxs):
                         cx.frames_dev(frame_ptr[f], stride * 4, n_seq[f], run_tracker=True, timestamps=ts_f[f], ego_v=ev_f[f], ego_yaw=ey_f[f])
-                        if gathers:
-                            gathers[ci].step(cx, force_collective=True)
+                        if gathers:   # each context's collective on its own side stream and process group: contexts stay decoupled
+                            with torch.cuda.stream(side_streams[ci]):
+                                gathers[ci].step(cx, force_collective=True)
             busy[0] = time.perf_counter() - t_h
         host_issue[0] = max(busy)
 
