@@ -844,7 +844,10 @@ __global__ void MOT_LAUNCH_BOUNDS(kTrackBlock)
 track_finish_kernel(TrackBuffers tb) {
   __shared__ unsigned long long s_matched[kGateWords];
   __shared__ int s_wcount[kTrackWaves];
-  __shared__ int s_nlive, s_born;
+  __shared__ int s_nlive, s_born, s_nvis;
+  constexpr int kVisCap = 256;               // visible boxes of a stream held in LDS for the merge phase (more: the per-wave path)
+  __shared__ double s_vb[kVisCap][12];       // corners 1..4 (x, y) and the two triangle centroids
+  __shared__ int s_vi[kVisCap];
   const int b = blockIdx.x;
   const int tid = threadIdx.x, lane = tlane(), wave = tid >> 6;
   if (b == 0 && tid == 0) *tb.n_items = 0;   // every per-track wave of this step has finished: re-arm the work list
@@ -885,30 +888,70 @@ track_finish_kernel(TrackBuffers tb) {
   // over ALL tracks; the value a track ends with is decided by the last (i,j) pair that writes it. Only tracks that were live
   // at the start of the step can carry a visible box (i); j runs over every track ever created (their merged positions).
   for (int t = tid; t < nt0; t += kTrackBlock) { gate[(long)t * kGateWords] = 0ull; prog[(long)t * kGateWords] = 0ull; }  // reuse: [t] -> has_a / max_b+1
+  if (tid == 0) s_nvis = 0;
   __syncthreads();
-  for (int li = wave; li < nlive; li += kTrackWaves) {
-    const int i = live[li];
-    const DevTrack* a = &tracks[i];
-    if (!a->is_vis) continue;
-    const double v1x = a->bbox[0], v1y = a->bbox[1], v2x = a->bbox[3], v2y = a->bbox[4], v3x = a->bbox[6], v3y = a->bbox[7], v4x = a->bbox[9], v4y = a->bbox[10];
-    const double cp1x = (v1x + v2x + v3x) / 3, cp1y = (v1y + v2y + v3y) / 3, cp2x = (v1x + v4x + v3x) / 3, cp2y = (v1y + v4y + v3y) / 3;
 #define ICOEF(ax, ay, bx, by, px, py, cx, cy) ((((ax) - (bx)) * ((py) - (ay)) + ((ay) - (by)) * ((ax) - (px))) * (((ax) - (bx)) * ((cy) - (ay)) + ((ay) - (by)) * ((ax) - (cx))))
-    bool any = false;
-    for (int j = lane; j < nt0; j += 64) {
+  // the visible boxes first (one round trip for all of them), then every (box, track) pair on its own thread; the result does
+  // not depend on the order of the pairs (a maximum and a flag)
+  for (int base = 0; base < nlive; base += kTrackBlock) {
+    const int li = base + tid;
+    if (li < nlive) {
+      const int i = live[li];
+      const DevTrack* a = &tracks[i];
+      if (a->is_vis) {
+        const int v = atomicAdd(&s_nvis, 1);
+        if (v < kVisCap) {
+          const double v1x = a->bbox[0], v1y = a->bbox[1], v2x = a->bbox[3], v2y = a->bbox[4], v3x = a->bbox[6], v3y = a->bbox[7], v4x = a->bbox[9], v4y = a->bbox[10];
+          double* q = s_vb[v];
+          q[0] = v1x; q[1] = v1y; q[2] = v2x; q[3] = v2y; q[4] = v3x; q[5] = v3y; q[6] = v4x; q[7] = v4y;
+          q[8] = (v1x + v2x + v3x) / 3; q[9] = (v1y + v2y + v3y) / 3; q[10] = (v1x + v4x + v3x) / 3; q[11] = (v1y + v4y + v3y) / 3;
+          s_vi[v] = i;
+        }
+      }
+    }
+  }
+  __syncthreads();
+  const int nvis = s_nvis;
+  if (nvis <= kVisCap) {
+    for (int pr = tid; pr < nvis * nt0; pr += kTrackBlock) {
+      const int v = pr / nt0, j = pr - v * nt0, i = s_vi[v];
       if (j == i) continue;
-      const Vec2d q = pos[j];
-      const double px = q.x, py = q.y;
+      const double* q = s_vb[v];
+      const double v1x = q[0], v1y = q[1], v2x = q[2], v2y = q[3], v3x = q[4], v3y = q[5], v4x = q[6], v4y = q[7], cp1x = q[8], cp1y = q[9], cp2x = q[10], cp2y = q[11];
+      const Vec2d w = pos[j];
+      const double px = w.x, py = w.y;
       double c1 = ICOEF(v1x, v1y, v2x, v2y, px, py, cp1x, cp1y), c2 = ICOEF(v1x, v1y, v3x, v3y, px, py, cp1x, cp1y),
              c3 = ICOEF(v3x, v3y, v2x, v2y, px, py, cp1x, cp1y), c4 = ICOEF(v1x, v1y, v4x, v4y, px, py, cp2x, cp2y),
              c5 = ICOEF(v1x, v1y, v3x, v3y, px, py, cp2x, cp2y), c6 = ICOEF(v3x, v3y, v4x, v4y, px, py, cp2x, cp2y);
       if ((c1 > 0 && c2 > 0 && c3 > 0) || (c4 > 0 && c5 > 0 && c6 > 0)) {
-        any = true;
         atomicMax(&prog[(long)j * kGateWords], (unsigned long long)(i + 1));  // j is zeroed by (i, j)
+        gate[(long)i * kGateWords] = 1ull;                                     // i is set to 5 by some (i, j)
       }
     }
-#undef ICOEF
-    if (__any(any) && lane == 0) gate[(long)i * kGateWords] = 1ull;  // i is set to 5 by some (i, j)
+  } else {   // more visible boxes than the LDS list holds: a wave per box
+    for (int li = wave; li < nlive; li += kTrackWaves) {
+      const int i = live[li];
+      const DevTrack* a = &tracks[i];
+      if (!a->is_vis) continue;
+      const double v1x = a->bbox[0], v1y = a->bbox[1], v2x = a->bbox[3], v2y = a->bbox[4], v3x = a->bbox[6], v3y = a->bbox[7], v4x = a->bbox[9], v4y = a->bbox[10];
+      const double cp1x = (v1x + v2x + v3x) / 3, cp1y = (v1y + v2y + v3y) / 3, cp2x = (v1x + v4x + v3x) / 3, cp2y = (v1y + v4y + v3y) / 3;
+      bool any = false;
+      for (int j = lane; j < nt0; j += 64) {
+        if (j == i) continue;
+        const Vec2d q = pos[j];
+        const double px = q.x, py = q.y;
+        double c1 = ICOEF(v1x, v1y, v2x, v2y, px, py, cp1x, cp1y), c2 = ICOEF(v1x, v1y, v3x, v3y, px, py, cp1x, cp1y),
+               c3 = ICOEF(v3x, v3y, v2x, v2y, px, py, cp1x, cp1y), c4 = ICOEF(v1x, v1y, v4x, v4y, px, py, cp2x, cp2y),
+               c5 = ICOEF(v1x, v1y, v3x, v3y, px, py, cp2x, cp2y), c6 = ICOEF(v3x, v3y, v4x, v4y, px, py, cp2x, cp2y);
+        if ((c1 > 0 && c2 > 0 && c3 > 0) || (c4 > 0 && c5 > 0 && c6 > 0)) {
+          any = true;
+          atomicMax(&prog[(long)j * kGateWords], (unsigned long long)(i + 1));
+        }
+      }
+      if (__any(any) && lane == 0) gate[(long)i * kGateWords] = 1ull;
+    }
   }
+#undef ICOEF
   __syncthreads();
   for (int t = tid; t < nt0; t += kTrackBlock) {
     bool has_a = gate[(long)t * kGateWords] != 0ull;
