@@ -663,7 +663,7 @@ cluster_gather_kernel(MotDevParams p, ClusterBuffers c) {
         __syncthreads();
         const int off = s_flag;
         int* pool = c.poly + (long)b * c.cap;
-        for (int j = tid; j < total; j += kBoxBlock) if (off + j < c.cap) pool[off + j] = ((int)(unsigned short)s_px[j]) | ((int)s_py[j] << 16);
+        for (int j = tid; j < total; j += kBoxBlock) if (off + j < c.cap) pool[off + j] = ((int)(unsigned short)s_px[j]) | (int)((unsigned)(int)s_py[j] << 16);
         GATHER_T(2);
         if (tid == 0) {
           cand.poly_off = off; cand.poly_n = total; cand.off_x = offsetInitX; cand.off_y = offsetInitY;
@@ -796,8 +796,9 @@ __device__ __forceinline__ void cluster_rect_body(const MotDevParams& p, const C
           s_inv[i] = (float)(1. / sqrt(dx * dx + dy * dy));
           // `if (pt0.x < left_x) left = i` etc.: strict compares => the FIRST vertex holding the extreme value
           long long ix = (long long)(int)p0x, iy = (long long)(int)p0y;  // vertices are integers
-          long long a_ = (ix << 32) | (unsigned)i, b_ = (ix << 32) | (unsigned)(0xffff - i);
-          long long c_ = (iy << 32) | (unsigned)(0xffff - i), d_ = (iy << 32) | (unsigned)i;
+          ix *= 4294967296ll; iy *= 4294967296ll;   // (the coordinate in the high word; a multiplication: pixel rows can be negative)
+          long long a_ = ix | (unsigned)i, b_ = ix | (unsigned)(0xffff - i);
+          long long c_ = iy | (unsigned)(0xffff - i), d_ = iy | (unsigned)i;
           kl = a_ < kl ? a_ : kl; kr = b_ > kr ? b_ : kr; kt = c_ > kt ? c_ : kt; kb = d_ < kb ? d_ : kb;
         }
         kl = wave_min_t<long long>(kl); kr = wave_max_t<long long>(kr); kt = wave_max_t<long long>(kt); kb = wave_min_t<long long>(kb);

@@ -53,7 +53,7 @@ sweep_kernel(MotDevParams p, int what, int mode, unsigned long long seed, unsign
       x = ((float)(i % side) + 0.5f) * (2.f * R / (float)side) - R; y = ((float)((i / side) % side) + 0.5f) * (2.f * R / (float)side) - R;
     } else {
       // -3..+3 steps of 1, 2, 4, ... 64 ulp: from exactly on the boundary to just outside the guard band on either side
-      const int dx = ((int)(h2 % 7) - 3) << (int)((h2 >> 3) % 7), dy = ((int)((h2 >> 8) % 7) - 3) << (int)((h2 >> 11) % 7);
+      const int dx = ((int)(h2 % 7) - 3) * (1 << (int)((h2 >> 3) % 7)), dy = ((int)((h2 >> 8) % 7) - 3) * (1 << (int)((h2 >> 11) % 7));
       if (what == 0) {
         if (h2 & (1ull << 40)) {   // a channel spoke
           const int k = (int)((h2 >> 16) % (MOT_NUM_CHANNEL + 1));

@@ -305,7 +305,7 @@ MOT_HD int mot_cart_bit_try(const MotDevParams& p, float x, float y) {
   const float fx = floorf(tx), fy = floorf(ty);
   const float rx = tx - fx, ry = ty - fy;
   const bool safe = rx > kCartGuard && rx < 1.f - kCartGuard && ry > kCartGuard && ry < 1.f - kCartGuard;   // false on NaN
-  const int bit = (int)fx * MOT_MAX_GRID + (int)fy;
+  const int bit = (int)((unsigned)(int)fx * (unsigned)MOT_MAX_GRID + (unsigned)(int)fy);   // (unsigned: a point far outside wraps, and is discarded)
   return outside ? -1 : (safe ? bit : -2);
 }
 MOT_HD int mot_cart_bit(const MotDevParams& p, float x, float y) {
