@@ -80,7 +80,10 @@ cart_occupancy_kernel(MotDevParams p, ClusterBuffers c) {
 }
 
 // ------------------------------------------------------------------------------------------ C2
-constexpr int kCclBlock = 1024;
+#ifndef MOT_CCL_BLOCK
+#define MOT_CCL_BLOCK 1024
+#endif
+constexpr int kCclBlock = MOT_CCL_BLOCK;   // a multiple of 64, >= 64
 // Runs whose union-find array lives in LDS. A frame can have up to kMaxRuns = 32768 runs (alternating cells in every row); a
 // street scene has a few hundred to a few thousand. Sizing LDS for the worst case made this one-workgroup-per-frame kernel own
 // a CU's whole LDS (159 KB), locking 128 CUs against the streaming kernels of the other contexts for its 30-40 us; with 6144 it

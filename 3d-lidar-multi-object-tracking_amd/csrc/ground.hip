@@ -179,7 +179,10 @@ polar_minz_kernel(MotDevParams p, GroundBuffers g) {
 // one workgroup per frame; the 80 x 120 grid sits in LDS: ONE float per cell (min z, then the height, updated in place) and
 // one flag byte — 48 KB, so that the workgroups of other kernels can share the CU (the first version kept five arrays, 135 KB:
 // with one workgroup per frame it locked 128 CUs' LDS against every other context's kernels for the length of the launch).
-constexpr int kFilterBlock = 960;  // 9600 cells = 10 per thread
+#ifndef MOT_FILTER_BLOCK
+#define MOT_FILTER_BLOCK 960
+#endif
+constexpr int kFilterBlock = MOT_FILTER_BLOCK;  // 9600 cells = 10 per thread; a multiple of 64, >= 256
 __global__ void MOT_LAUNCH_BOUNDS(kFilterBlock)
 polar_filter_kernel(MotDevParams p, GroundBuffers g) {
   __shared__ int s_minz[MOT_POLAR_CELLS];        // createAndMapPolarGrid's per-cell min z (ordered keys), then the cell's height

@@ -43,7 +43,7 @@ __device__ __forceinline__ int tlane() { return (int)(threadIdx.x & 63); }
 // `while (a > M_PI) a -= 2. * M_PI; while (a < -M_PI) a += 2. * M_PI;` — the reference's angle normalisation (ukf.cpp, imm_ukf_jpda.cpp
 // passim). Its cost is |a| / 2 pi iterations: a diverging track (a failed Cholesky leaves un-rooted covariance entries in the
 // sigma-point spread, ukf.cpp:651-662) drives |a| to 1e5..1e8 and ONE such track held a whole launch for 10-160 ms on the
-// MI355X (profiles/r02_tracker_outliers.md). Up to 32 turns the loop runs as written (bit-identical to the reference);
+// MI355X (profiles/r02_kernel_trace_B512_4ctx_before_tracker_fix.txt). Up to 32 turns the loop runs as written (bit-identical to the reference);
 // beyond that the whole turns come off in one step first — the result differs from the loop's by the roundings the loop
 // would have accumulated (< 1e-9 for |a| < 1e4), on tracks whose state is garbage already and which the reference's own
 // guards (:828-851) are about to kill. Inf, which hangs the reference, becomes NaN here.
