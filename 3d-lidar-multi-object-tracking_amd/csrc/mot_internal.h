@@ -92,6 +92,9 @@ struct GroundBuffers {
   OccWord* occ_list;       // [B][occ_chunks][kPlaneWords]
   int* occ_count;          // [B][occ_chunks] entries of each list
   int occ_chunks;
+  // the frame-per-workgroup compaction kernel (large batches) leaves the frame's two bit-planes themselves, or null
+  unsigned* plane_a;       // [B][kPlaneWords] cell seen >= 1
+  unsigned* plane_b;       // [B][kPlaneWords] cell seen >= 2
 };
 
 // ---- cluster + box stages ------------------------------------------------------------------
@@ -103,7 +106,8 @@ constexpr int kMaxBoxesPerFrame = 1024;
 constexpr int kRngTable = 128;                     // raw mt19937_64(0) outputs kept on the device
 constexpr int kCountsStride = 12;                  // ints per frame in `counts`
 enum { kCntElev = 0, kCntGround = 1, kCntDropped = 2, kCntClusters = 3, kCntBoxes = 4, kCntUndef = 5, kCntFlags = 6, kCntPoly = 7, kCntGroups = 8,
-       kCntIrregular = 9 };   // kCntGroups, kCntIrregular: label kernel -> index kernel, zero between launches
+       kCntIrregular = 9,     // kCntGroups, kCntIrregular: label kernel -> index kernel, zero between launches
+       kCntLabelled = 10 };   // 1: label_index_frame_kernel labelled and indexed this frame (the chunk kernels skip it); zero between launches
 enum { kFlagClusterOverflow = 1, kFlagBoxOverflow = 2, kFlagRngExhausted = 4, kFlagHullOverflow = 8, kFlagGroupOverflow = 16 };
 
 struct ClusterStats {          // per cluster, accumulated by the label kernel, reset by the finalize kernel
