@@ -102,7 +102,7 @@ label_stats_kernel(MotDevParams p, ClusterBuffers c) {
   const int b = blockIdx.y;
   const int n = c.counts[b * kCountsStride + kCntElev];
   const long base = (long)blockIdx.x * kLabelChunk;
-  if (base >= n || c.counts[b * kCountsStride + kCntLabelled]) return;   // (labelled: label_index_frame_kernel did this frame)
+  if (base >= n) return;
   if (threadIdx.x < kWgClusters) {
     s_tab_label[threadIdx.x] = 0; s_tab_count[threadIdx.x] = 0; s_tab_first[threadIdx.x] = 0x7fffffff;
     s_tab_rz[threadIdx.x] = mot_float_key(-99.f); s_tab_rmin[threadIdx.x] = kArgminInit; s_tab_rmax[threadIdx.x] = kArgmaxInit;
@@ -288,7 +288,6 @@ cluster_index_kernel(ClusterBuffers c) {
   __shared__ uint2 s_raw[kGroupsLds];   // fast path: {cluster, points} tables [wg][64] then their prefixes; general path: group keys
   static_assert(kGroupsLds * sizeof(uint2) >= kIndexWgLds * kWgClusters * (sizeof(int2) + sizeof(int)), "LDS union too small");
   const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  if (c.counts[b * kCountsStride + kCntLabelled]) return;   // label_index_frame_kernel did this frame
   const int num_cluster = min(c.counts[b * kCountsStride + kCntClusters], kMaxClusters);
   const int n = c.counts[b * kCountsStride + kCntElev];
   int E = c.counts[b * kCountsStride + kCntGroups];
@@ -412,210 +411,6 @@ cluster_index_kernel(ClusterBuffers c) {
   B1B_T(3);
   B1B_T_VALUE(4, E); B1B_T_VALUE(5, nwg); B1B_T_VALUE(6, fast);
   if (tid == 0) { c.counts[b * kCountsStride + kCntGroups] = 0; c.counts[b * kCountsStride + kCntIrregular] = 0; }  // re-arm
-}
-
-// ------------------------------------------------------------------------------------------ B1 + B1b, one workgroup per frame
-// Labelling, per-cluster statistics and the cluster-sorted index of a whole frame in ONE workgroup, for LARGE BATCHES (the
-// frames of the launch fill the chip by themselves). label_stats_kernel is bound by instruction issue, not by HBM (3.4 TB/s:
-// ~220 wave instructions per 64 points, two thirds of them the per-cluster wave reductions of a workgroup that sees a
-// cluster for 2048 points and then forgets it), and cluster_index_kernel exists only to stitch its chunks together. Here
-//  * every wave walks its own contiguous part of the frame, 64 points (one tile) per step, the next tiles' points in flight;
-//  * the per-cluster statistics live in LDS for the WHOLE frame, so a tile first LOOKS: the slope / height reductions run only
-//    when one of its points can move an extreme (after a cluster's first few tiles almost never);
-//  * a point's label stays in LDS as one byte; once the frame has been read the cluster sizes are known, and a second sweep
-//    over those bytes — no HBM reads — hands every point its slot in the cluster-sorted index (a running count per wave and
-//    cluster, tiles in input order), which is what cluster_index_kernel derives from (tile, cluster) groups through HBM.
-// Frames with more than 255 clusters or 65536 elevated points are left to the two chunk kernels (launched behind this one;
-// they return at once for the frames marked done here).
-#ifndef MOT_LFRAME_BLOCK
-#define MOT_LFRAME_BLOCK 512
-#endif
-#ifndef MOT_LFRAME_DEPTH
-#define MOT_LFRAME_DEPTH 4
-#endif
-constexpr int kLfBlock = MOT_LFRAME_BLOCK, kLfWaves = kLfBlock / 64, kLfDepth = MOT_LFRAME_DEPTH;
-constexpr int kLfMaxPts = 65536, kLfMaxClusters = 255;
-__global__ void MOT_LAUNCH_BOUNDS(kLfBlock)
-label_index_frame_kernel(MotDevParams p, ClusterBuffers c) {
-  __shared__ unsigned char s_lab[kLfMaxPts];
-  __shared__ int s_first[kLfMaxClusters + 1], s_rz[kLfMaxClusters + 1], s_fz[kLfMaxClusters + 1], s_count[kLfMaxClusters + 1];
-  __shared__ unsigned long long s_rmin[kLfMaxClusters + 1], s_rmax[kLfMaxClusters + 1];
-  __shared__ unsigned short s_run[kLfWaves][kLfMaxClusters + 1];   // points of (wave, cluster), then the wave's next slot of the cluster
-  __shared__ int s_start[kLfMaxClusters + 2];
-  const int b = blockIdx.x;
-  const int n = c.counts[b * kCountsStride + kCntElev];
-  const int num_cluster = c.counts[b * kCountsStride + kCntClusters];
-  const int tid = threadIdx.x, lane = lane_id(), wave = tid >> 6;
-  if (n > kLfMaxPts || num_cluster > kLfMaxClusters) {   // uniform: the chunk kernels take this frame
-    if (tid == 0) c.counts[b * kCountsStride + kCntLabelled] = 0;
-    return;
-  }
-  for (int l = tid; l <= kLfMaxClusters; l += kLfBlock) {
-    s_first[l] = 0x7fffffff; s_rz[l] = mot_float_key(-99.f); s_fz[l] = 0x7fffffff; s_rmin[l] = kArgminInit; s_rmax[l] = kArgmaxInit;
-#pragma unroll
-    for (int w = 0; w < kLfWaves; w++) s_run[w][l] = 0;
-  }
-  __syncthreads();
-  const float4* __restrict__ pts = c.elevated + (long)b * c.cap;
-  const int* __restrict__ grid = c.grid + (long)b * (MOT_MAX_GRID * MOT_MAX_GRID);
-  int* __restrict__ label = c.label + (long)b * c.cap;
-  int* __restrict__ pix = c.pix + (long)b * c.cap;
-  constexpr int kNoMin = 0x7fffffff, kNoMax = (int)0x80000000;
-  const unsigned long long below = (1ull << lane) - 1ull;
-  const unsigned* const rmin_hi = reinterpret_cast<const unsigned*>(s_rmin) + 1;   // high words (ordered slope keys) of the 64-bit extremes
-  const unsigned* const rmax_hi = reinterpret_cast<const unsigned*>(s_rmax) + 1;
-  // this wave's tiles
-  const int tiles = (n + 63) >> 6, per_wave = (tiles + kLfWaves - 1) / kLfWaves;
-  const int t_begin = wave * per_wave, t_end = min(tiles, t_begin + per_wave);
-  const float4 far = make_float4(1.0e9f, 1.0e9f, 0.f, 0.f);   // outside every ROI
-  // two steps of points and one step of labels in flight: a step never waits for memory it asked for itself
-  auto load_pts = [&](float4 (&dst)[kLfDepth], int t0) {
-#pragma unroll
-    for (int u = 0; u < kLfDepth; u++) { const int t = t0 + u; const int i = t * 64 + lane; dst[u] = (t < t_end && i < n) ? pts[i] : far; }
-  };
-  auto gather_labels = [&](int (&dst)[kLfDepth], const float4 (&src)[kLfDepth]) {
-    int cell[kLfDepth];
-#pragma unroll
-    for (int u = 0; u < kLfDepth; u++) {
-      const int bit = mot_cart_bit(p, src[u].x, src[u].y);   // guarded fast cell, exact fallback (as label_stats_kernel)
-      cell[u] = bit >= 0 ? (bit >> 8) * p.num_grid + (bit & 255) : -1;
-    }
-#pragma unroll
-    for (int u = 0; u < kLfDepth; u++) dst[u] = cell[u] >= 0 ? grid[cell[u]] : 0;
-  };
-  float4 cur[kLfDepth], nx[kLfDepth];
-  int cur_lab[kLfDepth];
-  load_pts(cur, t_begin);
-  load_pts(nx, t_begin + kLfDepth);
-  gather_labels(cur_lab, cur);
-#pragma unroll 1
-  for (int t0 = t_begin; t0 < t_end; t0 += kLfDepth) {
-    float4 qs[kLfDepth];
-    int labs[kLfDepth];
-#pragma unroll
-    for (int u = 0; u < kLfDepth; u++) { qs[u] = cur[u]; labs[u] = cur_lab[u]; cur[u] = nx[u]; }
-    gather_labels(cur_lab, cur);            // the next step's labels
-    load_pts(nx, t0 + 2 * kLfDepth);        // the points of the step after that
-#pragma unroll
-    for (int u = 0; u < kLfDepth; u++) {
-      const int tile = t0 + u;
-      if (tile >= t_end) break;   // uniform
-      const int i = tile * 64 + lane;
-      int lab = labs[u];
-      const float4 q = qs[u];
-      if (lab < 0 || lab > num_cluster) lab = 0;
-      if (i < n) {
-        label[i] = lab;
-        const float roiX = q.x + p.roi_half, roiY = q.y + p.roi_half;   // box_fitting.cpp:244-254 (see label_stats_kernel)
-        const int picX = (int)floorf(roiX * p.pic_scale), y = (int)floorf(roiY * p.pic_scale);
-        const int picY = (int)(p.pic_full - (float)y);
-        pix[i] = (int)((unsigned)((picX >= 0 && picX < 1024) ? picX : 0xffff) | ((unsigned)picY << 16));
-        s_lab[i] = (unsigned char)lab;
-      } else lab = 0;
-      if (lab > 0 && q.z == 0.0f) atomicMin(&s_fz[lab], i);
-      const float m = q.y / q.x + 0.0f;  // slope, :264
-      const int skey = mot_float_key(m);
-      const int kmin = (m < 999.f) ? skey : kNoMin;
-      const int kmax = (m > -999.f) ? skey : kNoMax;
-      const int zkey = (q.z > -99.f) ? mot_float_key(q.z + 0.0f) : mot_float_key(-99.f);
-      const unsigned ukmin = (unsigned)kmin ^ 0x80000000u, ukmax = (unsigned)kmax ^ 0x80000000u;
-      unsigned long long active = __ballot(lab > 0);
-      while (active) {  // one trip per distinct cluster among the 64 points of the tile
-        const int leader = __ffsll(active) - 1;
-        const int l = wave_bcast_i32(lab, leader);
-        const bool mine = (lab == l);
-        const unsigned long long mm = __ballot(mine);
-        if (lane == leader) {   // this wave's row of the table: nobody else writes it
-          s_run[wave][l] = (unsigned short)(s_run[wave][l] + __popcll(mm));
-          atomicMin(&s_first[l], i);   // the leader is the lowest lane = the smallest index of the group
-        }
-        // look before reducing: the table knows the cluster's extremes so far; only a point at or beyond them can change them
-        // (equal slope keys are decided by the index inside the 64-bit key, so "equal" takes the full path)
-        const unsigned cur_min = rmin_hi[2 * l], cur_max = rmax_hi[2 * l];
-        const int cur_z = s_rz[l];
-        if (__ballot(mine && kmin != kNoMin && ukmin <= cur_min)) {
-          const int rmin_k = wave_reduce_i32_id(mine ? kmin : kNoMin, OpMinI(), kNoMin);
-          const unsigned long long at_min = __ballot(mine && kmin == rmin_k);
-          if (lane == leader && rmin_k != kNoMin)
-            atomicMin(&s_rmin[l], ((unsigned long long)((unsigned)rmin_k ^ 0x80000000u) << 32) | (unsigned)(tile * 64 + __ffsll(at_min) - 1));
-        }
-        if (__ballot(mine && kmax != kNoMax && ukmax >= cur_max)) {
-          const int rmax_k = wave_reduce_i32_id(mine ? kmax : kNoMax, OpMaxI(), kNoMax);
-          const unsigned long long at_max = __ballot(mine && kmax == rmax_k);
-          if (lane == leader && rmax_k != kNoMax)
-            atomicMax(&s_rmax[l], ((unsigned long long)((unsigned)rmax_k ^ 0x80000000u) << 32) | (unsigned)~(unsigned)(tile * 64 + __ffsll(at_max) - 1));
-        }
-        if (__ballot(mine && zkey > cur_z)) {
-          const int rz = wave_reduce_i32_id(mine ? zkey : kNoMax, OpMaxI(), kNoMax);
-          if (lane == leader) atomicMax(&s_rz[l], rz);
-        }
-        active &= ~mm;
-      }
-    }
-  }
-  __syncthreads();
-  // cluster sizes -> first slots (exclusive scan over at most 255 clusters by wave 0), statistics, processing order
-  for (int l = tid; l <= kLfMaxClusters; l += kLfBlock) {
-    int tot = 0;
-    if (l >= 1 && l <= num_cluster) {
-#pragma unroll
-      for (int w = 0; w < kLfWaves; w++) tot += s_run[w][l];
-    }
-    s_count[l] = tot;
-  }
-  __syncthreads();
-  if (wave == 0) {
-    int v[4], sum = 0;
-#pragma unroll
-    for (int k = 0; k < 4; k++) { const int l = 1 + lane * 4 + k; v[k] = l <= kLfMaxClusters ? s_count[l] : 0; sum += v[k]; }
-    const int incl = wave_scan_incl_i32(sum);
-    int run = incl - sum;
-#pragma unroll
-    for (int k = 0; k < 4; k++) { const int ci = lane * 4 + k; if (ci <= kLfMaxClusters) s_start[ci] = run; run += v[k]; }   // s_start[ci], ci = label - 1; s_start[num_cluster] = labelled points
-  }
-  __syncthreads();
-  {
-    ClusterStats* __restrict__ stats = c.stats + (long)b * kMaxClusters;
-    int* __restrict__ cstart = c.cluster_start + (long)b * (kMaxClusters + 1);
-    int* __restrict__ order = c.order + (long)b * kMaxClusters;
-    for (int ci = tid; ci <= num_cluster; ci += kLfBlock) cstart[ci] = s_start[ci];
-    for (int ci = tid; ci < num_cluster; ci += kLfBlock) {
-      const int l = ci + 1;
-      ClusterStats st;
-      st.count = s_count[l]; st.first = s_first[l]; st.maxz_key = s_rz[l]; st.first_zero = s_fz[l]; st.argmin = s_rmin[l]; st.argmax = s_rmax[l];
-      stats[ci] = st;
-      const int cnt = s_count[l];
-      int rank = 0;   // largest first, ties by label (cluster_index_kernel's order)
-      for (int j = 0; j < num_cluster; j++) { const int cj = s_count[j + 1]; rank += (cj > cnt || (cj == cnt && j < ci)) ? 1 : 0; }
-      order[rank] = ci;
-      int run = s_start[ci];   // wave w's first slot of this cluster: the cluster's start + its points in the earlier waves' parts
-#pragma unroll
-      for (int w = 0; w < kLfWaves; w++) { const int t = s_run[w][l]; s_run[w][l] = (unsigned short)run; run += t; }
-    }
-  }
-  __syncthreads();
-  // second sweep, over the label bytes: sorted[slot] = point, tiles in input order inside every wave's part
-  {
-    int* __restrict__ sorted = c.sorted + (long)b * c.cap;
-#pragma unroll 1
-    for (int tile = t_begin; tile < t_end; tile++) {
-      const int i = tile * 64 + lane;
-      const int lab = i < n ? (int)s_lab[i] : 0;
-      unsigned long long active = __ballot(lab > 0);
-      while (active) {
-        const int leader = __ffsll(active) - 1;
-        const int l = wave_bcast_i32(lab, leader);
-        const bool mine = (lab == l);
-        const unsigned long long mm = __ballot(mine);
-        int slot = 0;
-        if (lane == leader) { slot = s_run[wave][l]; s_run[wave][l] = (unsigned short)(slot + __popcll(mm)); }
-        slot = wave_bcast_i32(slot, leader);
-        if (mine) sorted[slot + __popcll(mm & below)] = i;
-        active &= ~mm;
-      }
-    }
-  }
-  if (tid == 0) c.counts[b * kCountsStride + kCntLabelled] = 1;
 }
 
 // ------------------------------------------------------------------------------------------ B2
@@ -1211,7 +1006,6 @@ box_finalize_kernel(MotDevParams p, ClusterBuffers c) {
     c.counts[b * kCountsStride + kCntBoxes] = nb;
     c.counts[b * kCountsStride + kCntUndef] = s_undef;
     c.counts[b * kCountsStride + kCntPoly] = 0;  // re-arm the polygon pool
-    c.counts[b * kCountsStride + kCntLabelled] = 0;
   }
 }
 
@@ -1230,7 +1024,6 @@ void mot_launch_box_kernel(int which, const MotDevParams& p, const ClusterBuffer
     hipLaunchKernelGGL(cluster_rect_large_kernel, dim3(8, batch), dim3(kRectBlock), 0, stream, p, c);
   }
   else if (which == 4) hipLaunchKernelGGL(cluster_index_kernel, dim3(batch), dim3(kIndexBlock), 0, stream, c);
-  else if (which == 5) hipLaunchKernelGGL(label_index_frame_kernel, dim3(batch), dim3(kLfBlock), 0, stream, p, c);
   else if (which == 2) hipLaunchKernelGGL(box_finalize_kernel, dim3(batch), dim3(kFinalBlock), 0, stream, p, c);
 }
 

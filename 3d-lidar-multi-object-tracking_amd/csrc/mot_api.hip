@@ -108,7 +108,7 @@ struct mot_ctx {
   hipEvent_t ev_consumed[2] = {nullptr, nullptr};  // last kernel reading stage[i] launched and done (compute stream)
   bool stage_used[2] = {false, false};
   int stage_next = 0;
-  int frame_kernel_mode = -1;   // frame-per-workgroup kernels of the fused path: -1 by batch size, else bit 0 the compaction kernel, bit 1 labelling + index (mot_debug_option)
+  int frame_kernel_mode = -1;   // compaction kernel of the fused path: -1 by batch size, 0 a workgroup per chunk, 1 a workgroup per frame (mot_debug_option)
   // device block of mot_fetch_tracks_async
   mot_track* d_fetch = nullptr;
   int* d_fetch_counts = nullptr;
@@ -257,7 +257,7 @@ extern "C" void mot_destroy(mot_ctx* c) {
 // The fused path's compaction kernel: a workgroup per CHUNK stitched by a look-back (any batch), or a workgroup per FRAME
 // (ground.hip) once the frames of a launch fill the chip by themselves (two 512-thread workgroups per CU on 256 CUs).
 constexpr int kFrameKernelMinBatch = 384;
-static bool use_frame_kernel(const mot_ctx* c, int batch, int which = 1) { return c->frame_kernel_mode < 0 ? batch >= kFrameKernelMinBatch : (c->frame_kernel_mode & which) != 0; }   // which: 1 compaction, 2 labelling
+static bool use_frame_kernel(const mot_ctx* c, int batch) { return c->frame_kernel_mode < 0 ? batch >= kFrameKernelMinBatch : c->frame_kernel_mode != 0; }
 
 static TrackBuffers track_buffers(mot_ctx* c, bool fused);
 static void prepare_track_args(mot_ctx* c, int slot, int m, double timestamp, bool run);
@@ -270,12 +270,6 @@ static ClusterBuffers cluster_buffers(mot_ctx* c) {
   b.box_cluster = c->d_box_cluster; b.rng = c->d_rng; b.poly = c->d_poly; b.groups = c->d_groups; b.group_cap = c->cap / 2; b.cluster_start = c->d_cluster_start; b.order = c->d_order; b.sorted = c->d_sorted;
   b.pix = c->d_pix; b.wgtab = c->d_wgtab; b.max_wg = c->max_wg;
   return b;
-}
-// labelling + statistics (+ the cluster-sorted index): one workgroup per frame for large batches (box.hip), the frames it
-// declines — more than 255 clusters or 65536 elevated points — and every frame of a small batch by the chunk kernels
-static void launch_label_kernels(mot_ctx* c, const ClusterBuffers& cb, int batch, int max_n) {
-  if (use_frame_kernel(c, batch, 2)) mot_launch_box_kernel(5, c->dp, cb, batch, max_n, c->stream);
-  mot_launch_box_kernel(0, c->dp, cb, batch, max_n, c->stream);
 }
 static ClusterBuffers fused_cluster_buffers(mot_ctx* c, int batch) {
   ClusterBuffers b = cluster_buffers(c);
@@ -577,7 +571,7 @@ static int launch_frames(mot_ctx* c, int batch, int run_tracker, const double* t
   { ProfScope ps(c, kK3); mot_launch_ground_kernel(g.plane_a ? 3 : 2, c->dp, g, batch, max_n, c->stream); }
   ClusterBuffers cb = fused_cluster_buffers(c, batch);   // the occupancy comes from the compaction kernel: per-chunk lists or the frame's planes
   { ProfScope ps(c, kC2); mot_launch_cluster(c->dp, cb, batch, max_n, c->stream, true); }
-  { ProfScope ps(c, kB1); launch_label_kernels(c, cb, batch, max_n); }
+  { ProfScope ps(c, kB1); mot_launch_box_kernel(0, c->dp, cb, batch, max_n, c->stream); }
   { ProfScope ps(c, kB1b); mot_launch_box_kernel(4, c->dp, cb, batch, max_n, c->stream); }
   { ProfScope ps(c, kB2); mot_launch_box_kernel(1, c->dp, cb, batch, max_n, c->stream); }
   { ProfScope ps(c, kB2b); mot_launch_box_kernel(3, c->dp, cb, batch, max_n, c->stream); }
@@ -1024,7 +1018,7 @@ static int launch_one(mot_ctx* c, int id, int batch) {
     case kK2: mot_launch_ground_kernel(1, c->dp, g, batch, max_n, c->stream); break;
     case kK3: mot_launch_ground_kernel(g.plane_a ? 3 : 2, c->dp, g, batch, max_n, c->stream); break;
     case kC2: mot_launch_cluster_kernel(1, c->dp, cb, batch, max_n, c->stream); break;
-    case kB1: launch_label_kernels(c, cb, batch, max_n); break;
+    case kB1: mot_launch_box_kernel(0, c->dp, cb, batch, max_n, c->stream); break;
     case kB2: mot_launch_box_kernel(1, c->dp, cb, batch, max_n, c->stream); break;
     case kB3: mot_launch_box_kernel(2, c->dp, cb, batch, max_n, c->stream); break;
     case kB2b: mot_launch_box_kernel(3, c->dp, cb, batch, max_n, c->stream); break;

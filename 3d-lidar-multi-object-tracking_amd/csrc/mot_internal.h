@@ -106,8 +106,7 @@ constexpr int kMaxBoxesPerFrame = 1024;
 constexpr int kRngTable = 128;                     // raw mt19937_64(0) outputs kept on the device
 constexpr int kCountsStride = 12;                  // ints per frame in `counts`
 enum { kCntElev = 0, kCntGround = 1, kCntDropped = 2, kCntClusters = 3, kCntBoxes = 4, kCntUndef = 5, kCntFlags = 6, kCntPoly = 7, kCntGroups = 8,
-       kCntIrregular = 9,     // kCntGroups, kCntIrregular: label kernel -> index kernel, zero between launches
-       kCntLabelled = 10 };   // 1: label_index_frame_kernel labelled and indexed this frame (the chunk kernels skip it); zero between launches
+       kCntIrregular = 9 };   // kCntGroups, kCntIrregular: label kernel -> index kernel, zero between launches
 enum { kFlagClusterOverflow = 1, kFlagBoxOverflow = 2, kFlagRngExhausted = 4, kFlagHullOverflow = 8, kFlagGroupOverflow = 16 };
 
 struct ClusterStats {          // per cluster, accumulated by the label kernel, reset by the finalize kernel

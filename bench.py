@@ -372,7 +372,7 @@ def main():
     ap.add_argument("--density", type=float, default=1.0, help="scene density (cars / pedestrians) of the synthetic street")
     ap.add_argument("--issue-threads", type=int, default=0, help="0 (default): one host thread issues every context's launches, frame by frame, in a fixed order (also the order of the "
                     "collectives on every rank); 1: a host thread per context (measured equal: the launch queues, not the host, hold the pace — profiles/r02_issue_threads_contexts_sweep.txt)")
-    ap.add_argument("--compaction", choices=("auto", "chunk", "frame", "k3frame", "labframe"), default="auto", help="experiments: pin the fused path's compaction kernel (workgroup per chunk / per frame) "
+    ap.add_argument("--compaction", choices=("auto", "chunk", "frame"), default="auto", help="experiments: pin the fused path's compaction kernel (workgroup per chunk / per frame) "
                     "instead of the library's choice by batch size")
     ap.add_argument("--force-gather", action="store_true", help="run the per-frame RCCL all-gather of the track blocks even with one rank (exercises the N > 1 path on one GPU)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -449,7 +449,7 @@ def main():
     ctx = ctxs[0]
     if args.compaction != "auto":
         for cx in ctxs:
-            assert cx.lib.mot_debug_option(cx._h, 0, {"chunk": 0, "k3frame": 1, "labframe": 2, "frame": 3}[args.compaction]) == 0
+            assert cx.lib.mot_debug_option(cx._h, 0, 1 if args.compaction == "frame" else 0) == 0
     # one process group (RCCL communicator) per context: each context's issuing thread orders its own collectives
     groups = [dist.new_group(backend="nccl") for _ in range(NC)] if gather_on else None
     gathers = [multi.TrackGather(Bc, GATHER_TRACKS, world, "cuda", group=groups[ci]) for ci in range(NC)] if gather_on else None

@@ -44,7 +44,7 @@ def run(mot, oracle, synth, lib_path, sizes, stride, preset=0, frames=2, crop=Fa
     over = dict(crop_enable=1, crop_x_min=-20.0, crop_x_max=30.0, crop_y_min=-15.0, crop_y_max=25.0, crop_z_min=-2.5, crop_z_max=1.0) if crop else {}
     with mot.Context(mot.params(preset, **over), max_points=stride, max_batch=B, max_tracks_total=128, **kw) as a, \
          mot.Context(mot.params(preset, **over), max_points=stride, max_batch=B, max_tracks_total=128, **kw) as b:
-        assert a.lib.mot_debug_option(a._h, 0, 3) == 0     # a: one workgroup per frame (compaction and labelling)
+        assert a.lib.mot_debug_option(a._h, 0, 1) == 0     # a: one workgroup per frame
         assert b.lib.mot_debug_option(b._h, 0, 0) == 0     # b: one workgroup per chunk
         for f in range(frames):
             host = np.zeros((B, stride, 4), np.float32)

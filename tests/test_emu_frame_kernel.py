@@ -25,9 +25,9 @@ def test_frame_kernel_equals_chunk_kernel_and_oracle(mot, oracle, synth, emu_lib
     frame_kernel_case.run(mot, oracle, synth, emu_lib, sizes, stride, preset=preset, frames=2, crop=crop)
 
 
-def test_frames_the_frame_kernels_decline(mot, oracle, synth, emu_lib):
-    """more than 255 clusters, and more than 65536 elevated points: label_index_frame_kernel leaves these frames to the chunk
-    kernels launched behind it (the compaction kernel has no such limit); a normal frame rides along in the same batch"""
+def test_frame_kernel_on_irregular_frames(mot, oracle, synth, emu_lib):
+    """several hundred tiny clusters (the occupancy planes it leaves are speckled), and a frame with more than 65536 elevated
+    points (many chunks, long running positions), next to normal frames in the same batch"""
     p = oracle.params(0)
     many = frame_kernel_case.many_clusters_cloud(); lifted = frame_kernel_case.crowded_cloud(oracle, synth, 60000, 9); normal = synth.make_cloud(9000, 4, 0)
     g = oracle.ground_remove(p, many)

@@ -19,9 +19,9 @@ def test_frame_kernel_equals_chunk_kernel_and_oracle(mot, hip_lib, oracle, synth
     frame_kernel_case.run(mot, oracle, synth, None, sizes, stride, preset=preset, frames=2, crop=crop)
 
 
-def test_frames_the_frame_kernels_decline(mot, hip_lib, oracle, synth):
-    """more than 255 clusters / more than 65536 elevated points: label_index_frame_kernel leaves these frames to the chunk kernels
-    launched behind it; normal frames ride along in the same batch"""
+def test_frame_kernel_on_irregular_frames(mot, hip_lib, oracle, synth):
+    """several hundred tiny clusters (the occupancy planes it leaves are speckled), and a frame with more than 65536 elevated
+    points (many chunks, long running positions), next to normal frames in the same batch"""
     p = oracle.params(0)
     many = frame_kernel_case.many_clusters_cloud(); lifted = frame_kernel_case.crowded_cloud(oracle, synth, 120000, 4); normal = synth.make_cloud(120000, 4, 0)
     assert oracle.cluster(p, oracle.ground_remove(p, many)["elevated"])["num_cluster"] > 255

@@ -17,7 +17,7 @@ v, yaw = sdev.load_ego(F)
 seq, n_seq, _, _ = sdev.SequenceRenderer("cuda").render(list(range(B)), F, N, stride, v, yaw)
 for lib in [l or None for l in libs]:
     with mot.Context(max_points=stride, max_batch=B, **({"lib_path": lib} if lib else {})) as c:
-        for mode, name in ((0, "chunk"), (3, "frame")):
+        for mode, name in ((0, "chunk"), (1, "frame")):
             assert c.lib.mot_debug_option(c._h, 0, mode) == 0
             c.frames_dev(seq[1].data_ptr(), stride * 4, n_seq[1]); c.synchronize()
             t = {k: c.time_stage(k, B, 10) * 1e3 for k in (12, 21, 30, 34, 31, 0, 2, 100)}
