@@ -122,20 +122,38 @@ constexpr int kGroupsPerWave = 4;
 __device__ __forceinline__ int glane() { return (int)(threadIdx.x & 15); }
 __device__ __forceinline__ int ggroup() { return (int)((threadIdx.x >> 4) & 3); }
 
-struct GroupScratch {            // per track in flight, in LDS
+// Per track in flight, in LDS. The two per-track kernels are latency chains whose throughput is the number of tracks resident
+// on the chip, and that number is set by this footprint (8 tracks per workgroup): 606 doubles (4.7 KB) let four workgroups
+// share a CU; 465 / 428 let five, i.e. 10240 instead of 8192 tracks in one round — 512 streams with 17-20 live tracks each
+// fit (they needed a second round before: profiles/r02_frame_kernels.txt, tracker section).
+struct PredictScratch {
   double x[3][5], P[3][25];      // per-model state being advanced
-  double xo[3][5], Po[3][25];    // copies (mixing inputs) / updated state
+  union {                        // three tenants, one after the other (a wave synchronisation between them):
+    struct { double xo[3][5], Po[3][25]; };         // the mixing inputs, until the interaction step is done
+    struct { double L[3][25], Ld[3][2]; };          // the Cholesky factors of the augmented covariances (5 x 5 block + two trailing
+                                                    // diagonal entries), until the sigma points exist
+    struct { double K[3][10], Tc[3][10]; };         // the cross-correlations and gains
+  };
   double xm[5], Pm[25];          // merged
   double mode[3], mm[3][3];
-  double L[3][25], Ld[3][2];     // Cholesky factors of the augmented covariances: the 5 x 5 block and the two trailing diagonal entries
-  double Xs[3][75];              // predicted sigma points, 5 x 15 per model (prediction); exp() of the gated boxes (update)
-  double z[3][2], S[3][4], K[3][10], Tc[3][10];
+  double Xs[3][75];              // predicted sigma points, 5 x 15 per model
+  double z[3][2], S[3][4];
+};
+struct UpdateScratch {
+  double x[3][5], P[3][25];      // predicted per-model state
+  double xo[3][5], Po[3][25];    // updated state
+  double xm[5];                  // merged state of the previous step
+  double mode[3];
+  double Xs[3][64];              // exp() of the gated boxes 0..63 per model
+  double z[3][2], S[3][4], K[3][10];
 };
 
 // sigma-point weights, ukf.cpp:268-274: lambda_aug = 3 - 7
 __device__ __forceinline__ double ukf_w(int i) { return i == 0 ? (-4.0 / (-4.0 + 7.0)) : (0.5 / (7.0 + -4.0)); }
 
-__device__ void load_track(GroupScratch* G, const DevTrack* t, bool act) {
+// the prediction needs the models, the merged state and the mode probabilities; the update also the predicted measurement,
+// its covariance and the gains the prediction left in the track record
+__device__ void load_track(PredictScratch* G, const DevTrack* t, bool act) {
   const int s = glane();
   if (act) {
     if (s < 15) G->x[s / 5][s % 5] = t->x[1 + s / 5][s % 5];
@@ -143,13 +161,23 @@ __device__ void load_track(GroupScratch* G, const DevTrack* t, bool act) {
     if (s < 5) G->xm[s] = t->x[0][s];
     for (int e = s; e < 25; e += kGroupLanes) G->Pm[e] = t->P[0][e];
     if (s < 3) G->mode[s] = t->mode[s];
+  }
+  MOT_WAVE_SYNC();
+}
+__device__ void load_track(UpdateScratch* G, const DevTrack* t, bool act) {
+  const int s = glane();
+  if (act) {
+    if (s < 15) G->x[s / 5][s % 5] = t->x[1 + s / 5][s % 5];
+    for (int e = s; e < 75; e += kGroupLanes) G->P[e / 25][e % 25] = t->P[1 + e / 25][e % 25];
+    if (s < 5) G->xm[s] = t->x[0][s];
+    if (s < 3) G->mode[s] = t->mode[s];
     if (s < 6) G->z[s / 2][s % 2] = t->zpred[s / 2][s % 2];
     if (s < 12) G->S[s / 4][s % 4] = t->S[s / 4][s % 4];
     for (int e = s; e < 30; e += kGroupLanes) G->K[e / 10][e % 10] = t->K[e / 10][e % 10];
   }
   MOT_WAVE_SYNC();
 }
-__device__ void store_models(const GroupScratch* G, DevTrack* t, bool act) {
+__device__ void store_models(const PredictScratch* G, DevTrack* t, bool act) {
   const int s = glane();
   if (!act) return;
   if (s < 15) t->x[1 + s / 5][s % 5] = G->x[s / 5][s % 5];
@@ -160,7 +188,7 @@ __device__ void store_models(const GroupScratch* G, DevTrack* t, bool act) {
 }
 
 // ProcessIMMUKF(dt), ukf.cpp:507-527 — the group's track, state in G; `ok` is the group's predicate
-__device__ void process_imm_ukf(GroupScratch* G, double dt, bool ok) {
+__device__ void process_imm_ukf(PredictScratch* G, double dt, bool ok) {
   const int s = glane();
   // MixingProbability :439-456 (p1_,p2_,p3_ = rows of the transition matrix :139-154)
   if (ok && s < 3) {
@@ -498,7 +526,7 @@ track_prep_kernel(TrackBuffers tb) {
 }
 
 // ---- T1: PA — prediction + gating; the wave's four groups each take one (stream, live track) item
-__device__ void predict_group(const TrackBuffers& tb, GroupScratch* G, int b, int li, bool act) {
+__device__ void predict_group(const TrackBuffers& tb, PredictScratch* G, int b, int li, bool act) {
   const int s = glane(), grp = ggroup();
   const MotTrackParams& tp = tb.tp;
   TrackFrameArgs args; args.dt = 0; args.m = 0;
@@ -584,7 +612,7 @@ __device__ void predict_group(const TrackBuffers& tb, GroupScratch* G, int b, in
 constexpr int kItemWaves = MOT_TRACK_ITEM_WAVES;     // waves per workgroup of the two per-track kernels (four tracks in flight per wave)
 __global__ void MOT_LAUNCH_BOUNDS2(kItemWaves * 64, MOT_PREDICT_WAVES)
 track_predict_kernel(TrackBuffers tb) {
-  __shared__ GroupScratch s_g[kItemWaves * kGroupsPerWave];
+  __shared__ PredictScratch s_g[kItemWaves * kGroupsPerWave];
   const int wave = threadIdx.x >> 6, grp = ggroup();
   const int n = *tb.n_items;
   for (int i0 = (blockIdx.x * kItemWaves + wave) * kGroupsPerWave; i0 < n; i0 += gridDim.x * kItemWaves * kGroupsPerWave) {
@@ -596,7 +624,7 @@ track_predict_kernel(TrackBuffers tb) {
 }
 
 // ---- T2: PB (this track's share) + PC — association, state machine, PDA update; four tracks per wave
-__device__ void update_group(const TrackBuffers& tb, GroupScratch* G, int b, int li, bool act_in) {
+__device__ void update_group(const TrackBuffers& tb, UpdateScratch* G, int b, int li, bool act_in) {
   const int s = glane();
   const MotTrackParams& tp = tb.tp;
   const int* __restrict__ live = tb.live + (long)b * 2 * tb.T;
@@ -828,7 +856,7 @@ __device__ void update_group(const TrackBuffers& tb, GroupScratch* G, int b, int
 
 __global__ void MOT_LAUNCH_BOUNDS2(kItemWaves * 64, MOT_UPDATE_WAVES)
 track_update_kernel(TrackBuffers tb) {
-  __shared__ GroupScratch s_g[kItemWaves * kGroupsPerWave];
+  __shared__ UpdateScratch s_g[kItemWaves * kGroupsPerWave];
   const int wave = threadIdx.x >> 6, grp = ggroup();
   const int n = *tb.n_items;
   for (int i0 = (blockIdx.x * kItemWaves + wave) * kGroupsPerWave; i0 < n; i0 += gridDim.x * kItemWaves * kGroupsPerWave) {
@@ -1051,8 +1079,8 @@ void mot_launch_track(const TrackBuffers& t, int batch, hipStream_t stream) {
 #ifdef MOT_HIPEMU
   const int item_groups = 2;   // the per-track kernels loop over the work list: any grid size gives the same result
 #else
-  int item_groups = batch * 8;   // 2 waves x 4 tracks each: one round covers 64 live tracks per stream; the chip holds ~1024 such workgroups
-  item_groups = item_groups < 16 ? 16 : (item_groups > 1024 ? 1024 : item_groups);
+  int item_groups = batch * 8;   // 2 waves x 4 tracks each: one round covers 64 live tracks per stream; the chip holds 1280 such workgroups (5 per CU: the scratch above)
+  item_groups = item_groups < 16 ? 16 : (item_groups > 1280 ? 1280 : item_groups);
 #endif
   hipLaunchKernelGGL(track_prep_kernel, dim3(batch), dim3(256), 0, stream, t);
   hipLaunchKernelGGL(track_predict_kernel, dim3(item_groups), dim3(kItemWaves * 64), 0, stream, t);
