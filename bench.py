@@ -507,7 +507,9 @@ def main():
         run_steps(args.warmup)
     sync_all()
     # in-run timing of the dominant kernel: <= 64 event pairs per context, spread over the timed region
-    dom = "classify_compact_kernel"
+    dom = "classify_compact_kernel"   # K_IDS key of the compaction step; which of its two kernels runs depends on the launch size
+    frame_kernel = args.compaction == "frame" or (args.compaction == "auto" and Bc >= 384)   # mot_api.hip: kFrameKernelMinBatch
+    dom_kernel = "classify_compact_frame_kernel" if frame_kernel else "classify_compact_kernel"
     every = max(1, -(-args.steps * F // 60))
     for cx in ctxs:
         cx.profile_kernel(K_IDS[dom], every)
@@ -565,13 +567,13 @@ def main():
         frames = B * F * args.steps * world
         # HBM bytes per launch from the committed PMC passes of this command (FETCH_SIZE x2 on gfx950 + WRITE_SIZE, KB), same launch size only
         traffic, traffic_src = None, None
-        pmc_path = os.path.join(ROOT, "profiles", "r02_pmc_B128.json")
+        pmc_path = os.path.join(ROOT, "profiles", "r02_pmc_B512.json")
         if N == 120000 and os.path.exists(pmc_path):
-            pmc = json.load(open(pmc_path)).get(dom)
+            pmc = json.load(open(pmc_path)).get(dom_kernel)
             if pmc and "FETCH_SIZE" in pmc and "WRITE_SIZE" in pmc:
-                traffic = int((2.0 * pmc["FETCH_SIZE"] + pmc["WRITE_SIZE"]) * 1024 / 128 * BL)
-                traffic_src = (f"profiles/r02_pmc_B128.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this pipeline at 128 frames per launch (FETCH_SIZE x 2: the gfx950 "
-                               f"correction for wide coalesced reads), scaled to the {BL} frames of a launch here")
+                traffic = int((2.0 * pmc["FETCH_SIZE"] + pmc["WRITE_SIZE"]) * 1024 / 512 * BL)
+                traffic_src = (f"profiles/r02_pmc_B512.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this pipeline at 512 frames per launch (FETCH_SIZE x 2: the gfx950 "
+                               f"correction for wide coalesced reads)" + ("" if BL == 512 else f", scaled to the {BL} frames of a launch here"))
         out = {
             "metric": "LiDAR frames/sec (120k-pt 64-beam cloud) end-to-end ground->cluster->track",
             "value": round(frames / dt, 1), "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -588,7 +590,7 @@ def main():
                        "tracks_ever_stream0": int(tr0["n"]), "live_tracks_per_stream": {"mean": round(float(np.mean(live)), 1), "max": int(np.max(live)), "streams_sampled": len(live)},
                        "render_s": round(render_s, 1), "scene_density": args.density,
                        "parallelism": f"stream-sharded x{world}" + (", all_gather of live-track records per frame (RCCL)" if world > 1 else "")},
-            "roofline": {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "roofline": {"bound": "hbm", "kernel": dom_kernel, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_src,
                          "kernel_ms": {"mean": round(dom_ms, 5), "min": round(solo["min_ms"], 5), "max": round(solo["max_ms"], 5), "samples": solo["samples"],
                                        "how": "HIP event pairs around the kernel's launch on its own stream (mot_profile_kernel), the whole pipeline running on ONE context, "
