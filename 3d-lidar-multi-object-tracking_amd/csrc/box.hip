@@ -733,7 +733,11 @@ template <int kIn, bool kLarge>
 __device__ __forceinline__ void cluster_rect_body(const MotDevParams& p, const ClusterBuffers& c) {
   __shared__ int s_in[kIn + 2];                   // candidate points (x | y << 16), sorted by (x,y)
   __shared__ int s_b0[kIn + 2], s_b1[kIn + 2];    // peeling ping-pong
-  __shared__ float s_hx[kMaxHull], s_hy[kMaxHull], s_vx[kMaxHull], s_vy[kMaxHull], s_inv[kMaxHull];
+  __shared__ float s_hx[kMaxHull], s_hy[kMaxHull];
+  // edge vectors and inverse lengths of the hull: computed once the hull is complete, i.e. when the candidate list and the peeling
+  // buffers are dead — they take over that storage (13.8 -> 9.2 KB per wave: 17 instead of 11 clusters in flight per CU)
+  static_assert(kIn + 2 >= kMaxHull, "the peeling buffers must hold the hull's edge arrays");
+  float* const s_vx = reinterpret_cast<float*>(s_b0); float* const s_vy = reinterpret_cast<float*>(s_b1); float* const s_inv = reinterpret_cast<float*>(s_in);
   const int b = blockIdx.y;
   const int num_cluster = min(c.counts[b * kCountsStride + kCntClusters], kMaxClusters);
   const int lane = lane_id();

@@ -424,7 +424,7 @@ def main():
     sdev = _load("mot_amd.synth_dev", os.path.join(PKG_DIR, "synth_dev.py"))
 
     B, N, F = args.batch, args.points, args.frames
-    stride = ((N + 2047) // 2048) * 2048
+    stride = ((N + 2047) // 2048) * 2048 + int(os.environ.get("MOT_BENCH_STRIDE_PAD", "0"))   # points between the frames of a batch (pad: address-interleave experiments)
     NC = max(1, min(args.contexts, B))
     assert B % NC == 0, "--batch must be divisible by --contexts"
     Bc = B // NC

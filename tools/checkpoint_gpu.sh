@@ -9,7 +9,7 @@ rm -rf gpurun_out/pmc_FETCH_SIZE gpurun_out/pmc_WRITE_SIZE
 cp $O/pmc_B512.json profiles/r02_pmc_B512.json   # the bench line below quotes its traffic figure from here
 timeout 900 python bench.py > $O/bench_default.json 2> $O/bench_default.err; tail -c 300 $O/bench_default.err; head -c 600 $O/bench_default.json; echo
 timeout -k 5 600 rocprofv3 --kernel-trace --stats -d $O/prof_4ctx -o kt -- python bench.py --no-aux --no-cpu-baseline > $O/prof_4ctx.log 2>&1
-python profiles/summarize_rocpd.py $O/prof_4ctx/kt_results.db > $O/kernel_trace_B2048_4ctx.txt 2>&1; grep -v "at::native\|rocprim" $O/kernel_trace_B2048_4ctx.txt | head -24
+python profiles/summarize_rocpd.py $O/prof_4ctx/kt_results.db --tail=60 > $O/kernel_trace_B2048_4ctx.txt 2>&1; grep -v "at::native\|rocprim" $O/kernel_trace_B2048_4ctx.txt | head -24
 timeout -k 5 600 rocprofv3 --kernel-trace --stats -d $O/prof_1ctx -o kt -- python bench.py --steps 3 --warmup 1 --batch 512 --contexts 1 --no-aux --no-cpu-baseline > $O/prof_1ctx.log 2>&1
 python profiles/summarize_rocpd.py $O/prof_1ctx/kt_results.db > $O/kernel_trace_B512_1ctx.txt 2>&1; grep -v "at::native\|rocprim" $O/kernel_trace_B512_1ctx.txt | head -24
 rm -rf $O/prof_4ctx $O/prof_1ctx
