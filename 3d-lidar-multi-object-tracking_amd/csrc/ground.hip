@@ -183,13 +183,12 @@ polar_minz_kernel(MotDevParams p, GroundBuffers g) {
 #define MOT_FILTER_BLOCK 960
 #endif
 constexpr int kFilterBlock = MOT_FILTER_BLOCK;  // 9600 cells = 10 per thread; a multiple of 64, >= 256
-__global__ void MOT_LAUNCH_BOUNDS(kFilterBlock)
-polar_filter_kernel(MotDevParams p, GroundBuffers g) {
-  __shared__ int s_minz[MOT_POLAR_CELLS];        // createAndMapPolarGrid's per-cell min z (ordered keys), then the cell's height
+// the frame's filter on LDS the caller provides: s_minz [9600] ints (per-cell min z as ordered keys, then the cell's height), s_g
+// [9600] ground flags, s_pcnt [256]; kBlock threads (a multiple of 64, >= 256). Leaves hGround in g.hg (global).
+template <int kBlock>
+__device__ __forceinline__ void polar_filter_body(const MotDevParams& p, const GroundBuffers& g, int b, int* s_minz, unsigned char* s_g, int* s_pcnt) {
+  constexpr int kFilterBlock = kBlock;   // (the name the body was written with)
   float* const s_h = reinterpret_cast<float*>(s_minz);   // same storage: every pass below that rewrites it reads only its own cell first
-  __shared__ unsigned char s_g[MOT_POLAR_CELLS];   // ground flag
-  __shared__ int s_pcnt[256];
-  const int b = blockIdx.x;
   float* __restrict__ hg = g.hg + (long)b * MOT_POLAR_CELLS;
   // fold the partial minima of every min-z workgroup of this frame (Cell::Cell: minZ = 1000, ground_removal.cpp:35-38):
   // a wave per workgroup list, eight independent loads in flight per lane
@@ -309,6 +308,14 @@ polar_filter_kernel(MotDevParams p, GroundBuffers g) {
     }
     hg[i] = ground ? h : -INFINITY;
   }
+}
+
+__global__ void MOT_LAUNCH_BOUNDS(kFilterBlock)
+polar_filter_kernel(MotDevParams p, GroundBuffers g) {
+  __shared__ int s_minz[MOT_POLAR_CELLS];
+  __shared__ unsigned char s_g[MOT_POLAR_CELLS];
+  __shared__ int s_pcnt[256];
+  polar_filter_body<kFilterBlock>(p, g, (int)blockIdx.x, s_minz, s_g, s_pcnt);
 }
 
 // ------------------------------------------------------------------------------------------ K3
@@ -552,6 +559,8 @@ static_assert(kFrameTiles <= 64 && kFrameChunk <= 4096, "a wave scans the chunk'
 __global__ void MOT_LAUNCH_BOUNDS(kFrameBlock)
 classify_compact_frame_kernel(MotDevParams p, GroundBuffers g) {
   __shared__ float s_hg[MOT_POLAR_CELLS];
+  __shared__ unsigned char s_flag[MOT_POLAR_CELLS];   // the filter's ground flags
+  __shared__ int s_pcnt[256];
   __shared__ int s_cnt[2][kFrameTiles];
   __shared__ unsigned s_occ_a[kPlaneWords], s_occ_b[kPlaneWords];
   const int b = blockIdx.x;
@@ -583,6 +592,11 @@ classify_compact_frame_kernel(MotDevParams p, GroundBuffers g) {
       }
     }
   };
+  // K2 in here: with a workgroup per frame the frame's filter (gaus_blur + the cell decisions, polar_filter_body) is this
+  // workgroup's own prologue — no separate launch of 512 large workgroups between the two streaming kernels. It works on the
+  // storage of s_hg and leaves hGround in g.hg, from where the thresholds are read back (a barrier: same workgroup).
+  polar_filter_body<kFrameBlock>(p, g, b, reinterpret_cast<int*>(s_hg), s_flag, s_pcnt);
+  __syncthreads();
   if (nchunks > 0) fetch(0);
   for (int i = threadIdx.x; i < MOT_POLAR_CELLS; i += kFrameBlock) s_hg[i] = hg[i];
   if (occupancy) for (int i = threadIdx.x; i < kPlaneWords; i += kFrameBlock) { s_occ_a[i] = 0u; s_occ_b[i] = 0u; }

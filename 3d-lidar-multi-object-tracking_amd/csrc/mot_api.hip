@@ -567,7 +567,7 @@ static int launch_frames(mot_ctx* c, int batch, int run_tracker, const double* t
   const int max_n = c->last_max_n;
   GroundBuffers g = fused_ground_buffers(c, batch);
   { ProfScope ps(c, kK1); mot_launch_ground_kernel(0, c->dp, g, batch, max_n, c->stream); }
-  { ProfScope ps(c, kK2); mot_launch_ground_kernel(1, c->dp, g, batch, max_n, c->stream); }
+  if (!g.plane_a) { ProfScope ps(c, kK2); mot_launch_ground_kernel(1, c->dp, g, batch, max_n, c->stream); }   // (the frame kernel runs the filter itself)
   { ProfScope ps(c, kK3); mot_launch_ground_kernel(g.plane_a ? 3 : 2, c->dp, g, batch, max_n, c->stream); }
   ClusterBuffers cb = fused_cluster_buffers(c, batch);   // the occupancy comes from the compaction kernel: per-chunk lists or the frame's planes
   { ProfScope ps(c, kC2); mot_launch_cluster(c->dp, cb, batch, max_n, c->stream, true); }
@@ -1015,7 +1015,7 @@ static int launch_one(mot_ctx* c, int id, int batch) {
   ClusterBuffers cb = fused_cluster_buffers(c, batch);
   switch (id) {
     case kK1: mot_launch_ground_kernel(0, c->dp, g, batch, max_n, c->stream); break;
-    case kK2: mot_launch_ground_kernel(1, c->dp, g, batch, max_n, c->stream); break;
+    case kK2: if (!g.plane_a) mot_launch_ground_kernel(1, c->dp, g, batch, max_n, c->stream); break;   // part of the frame kernel otherwise
     case kK3: mot_launch_ground_kernel(g.plane_a ? 3 : 2, c->dp, g, batch, max_n, c->stream); break;
     case kC2: mot_launch_cluster_kernel(1, c->dp, cb, batch, max_n, c->stream); break;
     case kB1: mot_launch_box_kernel(0, c->dp, cb, batch, max_n, c->stream); break;
