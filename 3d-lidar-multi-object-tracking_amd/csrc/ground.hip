@@ -183,12 +183,13 @@ polar_minz_kernel(MotDevParams p, GroundBuffers g) {
 #define MOT_FILTER_BLOCK 960
 #endif
 constexpr int kFilterBlock = MOT_FILTER_BLOCK;  // 9600 cells = 10 per thread; a multiple of 64, >= 256
-// the frame's filter on LDS the caller provides: s_minz [9600] ints (per-cell min z as ordered keys, then the cell's height), s_g
-// [9600] ground flags, s_pcnt [256]; kBlock threads (a multiple of 64, >= 256). Leaves hGround in g.hg (global).
-template <int kBlock>
-__device__ __forceinline__ void polar_filter_body(const MotDevParams& p, const GroundBuffers& g, int b, int* s_minz, unsigned char* s_g, int* s_pcnt) {
-  constexpr int kFilterBlock = kBlock;   // (the name the body was written with)
+__global__ void MOT_LAUNCH_BOUNDS(kFilterBlock)
+polar_filter_kernel(MotDevParams p, GroundBuffers g) {
+  __shared__ int s_minz[MOT_POLAR_CELLS];        // createAndMapPolarGrid's per-cell min z (ordered keys), then the cell's height
   float* const s_h = reinterpret_cast<float*>(s_minz);   // same storage: every pass below that rewrites it reads only its own cell first
+  __shared__ unsigned char s_g[MOT_POLAR_CELLS];   // ground flag
+  __shared__ int s_pcnt[256];
+  const int b = blockIdx.x;
   float* __restrict__ hg = g.hg + (long)b * MOT_POLAR_CELLS;
   // fold the partial minima of every min-z workgroup of this frame (Cell::Cell: minZ = 1000, ground_removal.cpp:35-38):
   // a wave per workgroup list, eight independent loads in flight per lane
@@ -308,14 +309,6 @@ __device__ __forceinline__ void polar_filter_body(const MotDevParams& p, const G
     }
     hg[i] = ground ? h : -INFINITY;
   }
-}
-
-__global__ void MOT_LAUNCH_BOUNDS(kFilterBlock)
-polar_filter_kernel(MotDevParams p, GroundBuffers g) {
-  __shared__ int s_minz[MOT_POLAR_CELLS];
-  __shared__ unsigned char s_g[MOT_POLAR_CELLS];
-  __shared__ int s_pcnt[256];
-  polar_filter_body<kFilterBlock>(p, g, (int)blockIdx.x, s_minz, s_g, s_pcnt);
 }
 
 // ------------------------------------------------------------------------------------------ K3
@@ -539,164 +532,6 @@ classify_compact_kernel(MotDevParams p, GroundBuffers g) {
   }
 }
 
-// ------------------------------------------------------------------------------------------ K3, one workgroup per frame
-// The same classification + order-preserving compaction (+ occupancy of the cluster grid) for LARGE BATCHES: with several
-// hundred frames per launch the frames themselves fill the chip, so a workgroup walks ONE frame chunk by chunk and simply
-// carries the running output positions in registers. What the chunk-per-workgroup kernel above needs to stitch a frame
-// together disappears: no tickets, no descriptors, no look-back (waves parked on agent-scope round trips), no per-chunk
-// occupancy lists (the frame's two bit-planes grow in LDS and leave once, as the planes the labelling kernel reads), no
-// L2 gathers of the ground thresholds (the frame's 9600 sit in LDS). The next chunk's points and cells are in flight while
-// the current chunk is classified and stored; one barrier per chunk (the tile counts are double-buffered, every wave scans
-// them for itself).
-#ifndef MOT_FRAME_BLOCK
-#define MOT_FRAME_BLOCK 256
-#endif
-#ifndef MOT_FRAME_ITEMS
-#define MOT_FRAME_ITEMS 8
-#endif
-constexpr int kFrameBlock = MOT_FRAME_BLOCK, kFrameItems = MOT_FRAME_ITEMS, kFrameChunk = kFrameBlock * kFrameItems, kFrameTiles = kFrameChunk / 64;
-static_assert(kFrameTiles <= 64 && kFrameChunk <= 4096, "a wave scans the chunk's tile counts; packed counts hold at most 4096 of a class");
-__global__ void MOT_LAUNCH_BOUNDS(kFrameBlock)
-classify_compact_frame_kernel(MotDevParams p, GroundBuffers g) {
-  __shared__ float s_hg[MOT_POLAR_CELLS];
-  __shared__ unsigned char s_flag[MOT_POLAR_CELLS];   // the filter's ground flags
-  __shared__ int s_pcnt[256];
-  __shared__ int s_cnt[2][kFrameTiles];
-  __shared__ unsigned s_occ_a[kPlaneWords], s_occ_b[kPlaneWords];
-  const int b = blockIdx.x;
-  const int n = g.n[b];
-  const int nchunks = (n + kFrameChunk - 1) / kFrameChunk;
-  const bool occupancy = g.plane_a != nullptr;   // uniform
-  const float4* __restrict__ in = g.in + (long)b * g.in_stride;
-  const unsigned short* __restrict__ cell16 = g.cell + (long)b * g.cap;
-  const float* __restrict__ hg = g.hg + (long)b * MOT_POLAR_CELLS;
-  float4* __restrict__ out_e = g.elevated + (long)b * g.cap;
-  float4* __restrict__ out_g = g.ground + (long)b * g.cap;
-  uint8_t* __restrict__ mask = g.mask ? g.mask + (long)b * g.cap : nullptr;
-  const int lane = wave_lane(), wave = threadIdx.x >> 6;
-  const unsigned long long below = (1ull << lane) - 1ull;
-
-  float4 nx[kFrameItems];      // the chunk in flight
-  unsigned nc[kFrameItems];
-  auto fetch = [&](int ch) {
-    const long base = (long)ch * kFrameChunk;
-    if (base + kFrameChunk <= n) {
-#pragma unroll
-      for (int k = 0; k < kFrameItems; k++) { const long i = base + k * kFrameBlock + threadIdx.x; nx[k] = load_stream(&in[i]); nc[k] = cell16[i]; }
-    } else {
-#pragma unroll
-      for (int k = 0; k < kFrameItems; k++) {
-        const long i = base + k * kFrameBlock + threadIdx.x;
-        nx[k] = i < n ? load_stream(&in[i]) : make_float4(0.f, 0.f, 0.f, 0.f);
-        nc[k] = i < n ? (unsigned)cell16[i] : 0xffffu;
-      }
-    }
-  };
-  // K2 in here: with a workgroup per frame the frame's filter (gaus_blur + the cell decisions, polar_filter_body) is this
-  // workgroup's own prologue — no separate launch of 512 large workgroups between the two streaming kernels. It works on the
-  // storage of s_hg and leaves hGround in g.hg, from where the thresholds are read back (a barrier: same workgroup).
-  polar_filter_body<kFrameBlock>(p, g, b, reinterpret_cast<int*>(s_hg), s_flag, s_pcnt);
-  __syncthreads();
-  if (nchunks > 0) fetch(0);
-  for (int i = threadIdx.x; i < MOT_POLAR_CELLS; i += kFrameBlock) s_hg[i] = hg[i];
-  if (occupancy) for (int i = threadIdx.x; i < kPlaneWords; i += kFrameBlock) { s_occ_a[i] = 0u; s_occ_b[i] = 0u; }
-  __syncthreads();
-
-  int base_e = 0, base_g = 0;   // output positions of this chunk's first elevated / ground point (uniform)
-#pragma unroll 1
-  for (int ch = 0; ch < nchunks; ch++) {
-    const long base = (long)ch * kFrameChunk;
-    const bool full = base + kFrameChunk <= n;
-    float4 pt[kFrameItems];
-    int cls[kFrameItems], rank[kFrameItems];
-#pragma unroll
-    for (int k = 0; k < kFrameItems; k++) { pt[k] = nx[k]; cls[k] = nc[k] == 0xffffu ? -1 : (int)nc[k]; }
-    if (ch + 1 < nchunks) fetch(ch + 1);
-    int* const cnt = s_cnt[ch & 1];
-    unsigned wave_has_elevated = 0;
-#pragma unroll
-    for (int k = 0; k < kFrameItems; k++) {
-      int c = MOT_MASK_DROPPED;
-      if (cls[k] >= 0) c = ((double)pt[k].z < (double)s_hg[cls[k]] + p.ground_margin) ? MOT_MASK_GROUND : MOT_MASK_ELEVATED;
-      cls[k] = c;
-      const unsigned long long be = __ballot(c == MOT_MASK_ELEVATED);
-      const unsigned long long bg = __ballot(c == MOT_MASK_GROUND);
-      if (be) wave_has_elevated |= 1u << k;
-      rank[k] = __popcll((c == MOT_MASK_ELEVATED ? be : bg) & below);
-      if (lane == 0) cnt[k * (kFrameBlock / 64) + wave] = (__popcll(be) << 16) | __popcll(bg);   // tile order inside the chunk: k-major, then wave
-    }
-    __syncthreads();
-    // every wave scans the chunk's tile counts for itself (elevated in the high half-word, ground in the low one)
-    const int cv = lane < kFrameTiles ? cnt[lane] : 0;
-    const int incl = wave_scan_incl_i32(cv);
-    const int tot = wave_bcast_i32(incl, 63);
-    const int excl = incl - cv;
-#pragma unroll
-    for (int k = 0; k < kFrameItems; k++) {
-      const int ex = wave_bcast_i32(excl, k * (kFrameBlock / 64) + wave);
-      const bool is_e = cls[k] == MOT_MASK_ELEVATED;
-      float4* __restrict__ dst = is_e ? out_e : out_g;
-      const int at = (is_e ? base_e + (ex >> 16) : base_g + (ex & 0xffff)) + rank[k];
-      if (cls[k] != MOT_MASK_DROPPED) dst[at] = pt[k];
-    }
-    base_e += tot >> 16; base_g += tot & 0xffff;
-    if (occupancy && wave_has_elevated) {   // mapCartesianGrid's histogram (component_clustering.cpp:36-50), as in the kernel above
-      int bits[kFrameItems];
-      unsigned undecided = 0;
-#pragma unroll
-      for (int k = 0; k < kFrameItems; k++) {
-        int bit = -1;
-        if ((wave_has_elevated >> k) & 1u) bit = cls[k] == MOT_MASK_ELEVATED ? mot_cart_bit_try(p, pt[k].x, pt[k].y) : -1;
-        if (bit == -2) undecided |= 1u << k;
-        bits[k] = bit;
-      }
-      while (undecided) {
-        const int k = __ffs(undecided) - 1;
-        undecided &= undecided - 1;
-        float qx = pt[0].x, qy = pt[0].y;
-#pragma unroll
-        for (int kk = 1; kk < kFrameItems; kk++) { qx = kk == k ? pt[kk].x : qx; qy = kk == k ? pt[kk].y : qy; }
-        int xI, yI;
-        const int r = mot_cart_cell(p, qx, qy, &xI, &yI) ? xI * MOT_MAX_GRID + yI : -1;
-#pragma unroll
-        for (int kk = 0; kk < kFrameItems; kk++) bits[kk] = kk == k ? r : bits[kk];
-      }
-#pragma unroll
-      for (int k = 0; k < kFrameItems; k++) {
-        if ((wave_has_elevated >> k) & 1u) {   // uniform
-          const int prev = row_prev_i32(bits[k], -3), next = row_next_i32(bits[k], -3);
-          if (bits[k] >= 0 && prev != bits[k]) {   // first lane of a run of equal cells; a run of two or more is "seen >= 2" by itself
-            const unsigned m = 1u << (bits[k] & 31);
-            const unsigned old = atomicOr(&s_occ_a[bits[k] >> 5], m);
-            if ((old & m) || next == bits[k]) atomicOr(&s_occ_b[bits[k] >> 5], m);
-          }
-        }
-      }
-    }
-    if (mask) {
-      if (full) {
-#pragma unroll
-        for (int k = 0; k < kFrameItems; k++) mask[base + k * kFrameBlock + threadIdx.x] = (uint8_t)cls[k];
-      } else {
-#pragma unroll
-        for (int k = 0; k < kFrameItems; k++) {
-          const long i = base + k * kFrameBlock + threadIdx.x;
-          if (i < n) mask[i] = (uint8_t)cls[k];
-        }
-      }
-    }
-  }
-  if (threadIdx.x == 0) {
-    g.counts[b * kCountsStride + kCntElev] = base_e; g.counts[b * kCountsStride + kCntGround] = base_g; g.counts[b * kCountsStride + kCntDropped] = n - base_e - base_g;
-  }
-  if (occupancy) {   // the frame's planes, every word (the labelling kernel consumes them: cluster.hip)
-    __syncthreads();
-    unsigned* __restrict__ ga = g.plane_a + (long)b * kPlaneWords;
-    unsigned* __restrict__ gb = g.plane_b + (long)b * kPlaneWords;
-    for (int i = threadIdx.x; i < kPlaneWords; i += kFrameBlock) { ga[i] = s_occ_a[i]; gb[i] = s_occ_b[i]; }
-  }
-}
-
 // ------------------------------------------------------------------------------------------ input decode
 // PointCloud2 records -> float4 (include/mot.h, mot_decode_pointcloud2_dev). HBM-bound gather: point_step bytes read,
 // 16 written per point. Records whose fields are 4-byte aligned take dword loads; anything else is assembled from bytes.
@@ -730,7 +565,6 @@ void mot_launch_ground_kernel(int which, const MotDevParams& p, const GroundBuff
   if (which == 0) hipLaunchKernelGGL(polar_minz_kernel, dim3(chunks, batch), dim3(kGroundBlock), 0, stream, p, g);
   else if (which == 1) hipLaunchKernelGGL(polar_filter_kernel, dim3(batch), dim3(kFilterBlock), 0, stream, p, g);
   else if (which == 2) hipLaunchKernelGGL(classify_compact_kernel, dim3(cchunks, batch), dim3(kCompactBlock), 0, stream, p, g);
-  else if (which == 3) hipLaunchKernelGGL(classify_compact_frame_kernel, dim3(batch), dim3(kFrameBlock), 0, stream, p, g);
 }
 
 void mot_launch_ground(const MotDevParams& p, const GroundBuffers& g, int batch, int max_n, hipStream_t stream) {

@@ -108,7 +108,6 @@ struct mot_ctx {
   hipEvent_t ev_consumed[2] = {nullptr, nullptr};  // last kernel reading stage[i] launched and done (compute stream)
   bool stage_used[2] = {false, false};
   int stage_next = 0;
-  int frame_kernel_mode = -1;   // compaction kernel of the fused path: -1 by batch size, 0 a workgroup per chunk, 1 a workgroup per frame (mot_debug_option)
   // device block of mot_fetch_tracks_async
   mot_track* d_fetch = nullptr;
   int* d_fetch_counts = nullptr;
@@ -254,11 +253,6 @@ extern "C" void mot_destroy(mot_ctx* c) {
   delete c;
 }
 
-// The fused path's compaction kernel: a workgroup per CHUNK stitched by a look-back (any batch), or a workgroup per FRAME
-// (ground.hip) once the frames of a launch fill the chip by themselves (two 512-thread workgroups per CU on 256 CUs).
-constexpr int kFrameKernelMinBatch = 384;
-static bool use_frame_kernel(const mot_ctx* c, int batch) { return c->frame_kernel_mode < 0 ? batch >= kFrameKernelMinBatch : c->frame_kernel_mode != 0; }
-
 static TrackBuffers track_buffers(mot_ctx* c, bool fused);
 static void prepare_track_args(mot_ctx* c, int slot, int m, double timestamp, bool run);
 
@@ -269,11 +263,6 @@ static ClusterBuffers cluster_buffers(mot_ctx* c) {
   b.grid = c->d_grid; b.label = c->d_label; b.stats = c->d_stats; b.cand = c->d_cand; b.boxes = c->d_boxes;
   b.box_cluster = c->d_box_cluster; b.rng = c->d_rng; b.poly = c->d_poly; b.groups = c->d_groups; b.group_cap = c->cap / 2; b.cluster_start = c->d_cluster_start; b.order = c->d_order; b.sorted = c->d_sorted;
   b.pix = c->d_pix; b.wgtab = c->d_wgtab; b.max_wg = c->max_wg;
-  return b;
-}
-static ClusterBuffers fused_cluster_buffers(mot_ctx* c, int batch) {
-  ClusterBuffers b = cluster_buffers(c);
-  if (!use_frame_kernel(c, batch)) { b.occ_list = c->d_occ_list; b.occ_count = c->d_occ_count; }
   return b;
 }
 
@@ -444,17 +433,8 @@ static GroundBuffers ground_buffers(mot_ctx* c, const float4* in, long stride, b
   g.ticket = c->d_ticket; g.elevated = c->d_elev; g.ground = c->d_ground; g.mask = want_mask ? c->d_mask : nullptr;
   g.counts = c->d_counts; g.cap = c->cap; g.max_chunks = c->max_chunks;
   g.occ_list = planes ? c->d_occ_list : nullptr; g.occ_count = planes ? c->d_occ_count : nullptr; g.occ_chunks = c->occ_chunks;
-  g.plane_a = nullptr; g.plane_b = nullptr;
   return g;
 }
-
-static GroundBuffers fused_ground_buffers(mot_ctx* c, int batch) {
-  const bool pf = use_frame_kernel(c, batch);
-  GroundBuffers g = ground_buffers(c, c->last_in, c->last_in_stride, true, !pf);
-  if (pf) { g.plane_a = c->d_plane_a; g.plane_b = c->d_plane_b; }   // the frame's occupancy planes, as the labelling kernel reads them
-  return g;
-}
-
 
 // uploads n[] and remembers the launch geometry
 static int set_batch(mot_ctx* c, const int* n_points, int batch, const float4* in, long stride) {
@@ -565,11 +545,12 @@ static int launch_frames(mot_ctx* c, int batch, int run_tracker, const double* t
   int rc;
   if ((rc = next_epoch(c))) return rc;
   const int max_n = c->last_max_n;
-  GroundBuffers g = fused_ground_buffers(c, batch);
+  GroundBuffers g = ground_buffers(c, c->last_in, c->last_in_stride, true, true);
   { ProfScope ps(c, kK1); mot_launch_ground_kernel(0, c->dp, g, batch, max_n, c->stream); }
-  if (!g.plane_a) { ProfScope ps(c, kK2); mot_launch_ground_kernel(1, c->dp, g, batch, max_n, c->stream); }   // (the frame kernel runs the filter itself)
-  { ProfScope ps(c, kK3); mot_launch_ground_kernel(g.plane_a ? 3 : 2, c->dp, g, batch, max_n, c->stream); }
-  ClusterBuffers cb = fused_cluster_buffers(c, batch);   // the occupancy comes from the compaction kernel: per-chunk lists or the frame's planes
+  { ProfScope ps(c, kK2); mot_launch_ground_kernel(1, c->dp, g, batch, max_n, c->stream); }
+  { ProfScope ps(c, kK3); mot_launch_ground_kernel(2, c->dp, g, batch, max_n, c->stream); }
+  ClusterBuffers cb = cluster_buffers(c);
+  cb.occ_list = c->d_occ_list; cb.occ_count = c->d_occ_count;   // the occupancy comes as the compaction kernel's per-chunk lists
   { ProfScope ps(c, kC2); mot_launch_cluster(c->dp, cb, batch, max_n, c->stream, true); }
   { ProfScope ps(c, kB1); mot_launch_box_kernel(0, c->dp, cb, batch, max_n, c->stream); }
   { ProfScope ps(c, kB1b); mot_launch_box_kernel(4, c->dp, cb, batch, max_n, c->stream); }
@@ -1011,12 +992,13 @@ static int launch_one(mot_ctx* c, int id, int batch) {
   int rc;
   const int max_n = c->last_max_n;
   if (id == kK3 && (rc = next_epoch(c))) return rc;
-  GroundBuffers g = fused_ground_buffers(c, batch);   // as in the fused path: the compaction kernel leaves the occupancy (lists or planes)
-  ClusterBuffers cb = fused_cluster_buffers(c, batch);
+  GroundBuffers g = ground_buffers(c, c->last_in, c->last_in_stride, true, true);   // as in the fused path: the compaction kernel leaves the occupancy lists
+  ClusterBuffers cb = cluster_buffers(c);
+  cb.occ_list = c->d_occ_list; cb.occ_count = c->d_occ_count;
   switch (id) {
     case kK1: mot_launch_ground_kernel(0, c->dp, g, batch, max_n, c->stream); break;
-    case kK2: if (!g.plane_a) mot_launch_ground_kernel(1, c->dp, g, batch, max_n, c->stream); break;   // part of the frame kernel otherwise
-    case kK3: mot_launch_ground_kernel(g.plane_a ? 3 : 2, c->dp, g, batch, max_n, c->stream); break;
+    case kK2: mot_launch_ground_kernel(1, c->dp, g, batch, max_n, c->stream); break;
+    case kK3: mot_launch_ground_kernel(2, c->dp, g, batch, max_n, c->stream); break;
     case kC2: mot_launch_cluster_kernel(1, c->dp, cb, batch, max_n, c->stream); break;
     case kB1: mot_launch_box_kernel(0, c->dp, cb, batch, max_n, c->stream); break;
     case kB2: mot_launch_box_kernel(1, c->dp, cb, batch, max_n, c->stream); break;
@@ -1284,12 +1266,6 @@ extern "C" int mot_debug_sweep(mot_ctx* c, int what, int mode, unsigned long lon
 }
 
 // test hook (mot_debug_api.h): the float matrix of the fused path's sensor -> global change of frame for an ego pose
-extern "C" int mot_debug_option(mot_ctx* c, int option, int value) {
-  if (!c) return MOT_E_ARG;
-  if (option == 0) { c->frame_kernel_mode = value; return MOT_OK; }
-  return fail(c, MOT_E_ARG, "mot_debug_option: unknown option");
-}
-
 extern "C" int mot_debug_tf_matrix(double x, double y, double yaw, float* m12) {
   if (!m12) return MOT_E_ARG;
   tf_velodyne_to_global(x, y, yaw, m12);

@@ -16,8 +16,6 @@ int mot_debug_copy(mot_ctx* ctx, int which, int slot, void* dst, size_t bytes);
  * what 0 polar cell, 1 Cartesian cell; mode 0 random, 1 lattice, 2 cell boundaries +-3 ulp. stats[0..4] = points, undecided,
  * mismatches, first mismatch (x bits | y bits << 32), its (fast | exact << 32). Synchronous. */
 int mot_debug_sweep(mot_ctx* ctx, int what, int mode, unsigned long long seed, unsigned long long count, unsigned long long* stats8);
-/* option 0: compaction kernel of the fused path — -1 chosen by batch size (default), 0 a workgroup per chunk, 1 a workgroup per frame */
-int mot_debug_option(mot_ctx* ctx, int option, int value);
 /* the float 3 x 4 matrix (row major) the fused path applies to take boxes from the sensor frame to the tracker's global frame */
 int mot_debug_tf_matrix(double x, double y, double yaw, float* m12);
 #ifdef __cplusplus

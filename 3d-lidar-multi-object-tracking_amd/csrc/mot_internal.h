@@ -92,9 +92,6 @@ struct GroundBuffers {
   OccWord* occ_list;       // [B][occ_chunks][kPlaneWords]
   int* occ_count;          // [B][occ_chunks] entries of each list
   int occ_chunks;
-  // the frame-per-workgroup compaction kernel (large batches) leaves the frame's two bit-planes themselves, or null
-  unsigned* plane_a;       // [B][kPlaneWords] cell seen >= 1
-  unsigned* plane_b;       // [B][kPlaneWords] cell seen >= 2
 };
 
 // ---- cluster + box stages ------------------------------------------------------------------

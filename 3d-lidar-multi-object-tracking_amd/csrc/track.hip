@@ -125,7 +125,7 @@ __device__ __forceinline__ int ggroup() { return (int)((threadIdx.x >> 4) & 3); 
 // Per track in flight, in LDS. The two per-track kernels are latency chains whose throughput is the number of tracks resident
 // on the chip, and that number is set by this footprint (8 tracks per workgroup): 606 doubles (4.7 KB) let four workgroups
 // share a CU; 465 / 428 let five, i.e. 10240 instead of 8192 tracks in one round — 512 streams with 17-20 live tracks each
-// fit (they needed a second round before: profiles/r02_frame_kernels.txt, tracker section).
+// fit (they needed a second round before: profiles/r02_tracker_scratch.txt).
 struct PredictScratch {
   double x[3][5], P[3][25];      // per-model state being advanced
   union {                        // three tenants, one after the other (a wave synchronisation between them):

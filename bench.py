@@ -372,8 +372,6 @@ def main():
     ap.add_argument("--density", type=float, default=1.0, help="scene density (cars / pedestrians) of the synthetic street")
     ap.add_argument("--issue-threads", type=int, default=0, help="0 (default): one host thread issues every context's launches, frame by frame, in a fixed order (also the order of the "
                     "collectives on every rank); 1: a host thread per context (measured equal: the launch queues, not the host, hold the pace — profiles/r02_issue_threads_contexts_sweep.txt)")
-    ap.add_argument("--compaction", choices=("auto", "chunk", "frame"), default="auto", help="experiments: pin the fused path's compaction kernel (workgroup per chunk / per frame) "
-                    "instead of the library's choice by batch size")
     ap.add_argument("--force-gather", action="store_true", help="run the per-frame RCCL all-gather of the track blocks even with one rank (exercises the N > 1 path on one GPU)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-aux", action="store_true", help="skip tracker_stress / host_boundary / per-kernel isolated timings")
@@ -447,9 +445,6 @@ def main():
     variant = os.environ.get("MOT_BENCH_LIB")   # experiments only (tools/ablate.py bench ...): a variant build of the library; the line then says so
     ctxs = [mot.Context(device=local, max_points=stride, max_batch=Bc, max_tracks_total=4096, **({"lib_path": variant} if variant else {})) for _ in range(NC)]
     ctx = ctxs[0]
-    if args.compaction != "auto":
-        for cx in ctxs:
-            assert cx.lib.mot_debug_option(cx._h, 0, 1 if args.compaction == "frame" else 0) == 0
     # one process group (RCCL communicator) per context: each context's issuing thread orders its own collectives
     groups = [dist.new_group(backend="nccl") for _ in range(NC)] if gather_on else None
     gathers = [multi.TrackGather(Bc, GATHER_TRACKS, world, "cuda", group=groups[ci]) for ci in range(NC)] if gather_on else None
@@ -507,9 +502,8 @@ def main():
         run_steps(args.warmup)
     sync_all()
     # in-run timing of the dominant kernel: <= 64 event pairs per context, spread over the timed region
-    dom = "classify_compact_kernel"   # K_IDS key of the compaction step; which of its two kernels runs depends on the launch size
-    frame_kernel = args.compaction == "frame" or (args.compaction == "auto" and Bc >= 384)   # mot_api.hip: kFrameKernelMinBatch
-    dom_kernel = "classify_compact_frame_kernel" if frame_kernel else "classify_compact_kernel"
+    dom = "classify_compact_kernel"
+    dom_kernel = dom
     every = max(1, -(-args.steps * F // 60))
     for cx in ctxs:
         cx.profile_kernel(K_IDS[dom], every)
@@ -585,7 +579,7 @@ def main():
             "config": {"workload": f"configs[3]: ground removal -> CCL -> box fit -> batched IMM-UKF-PDA tracker on one MI355X per rank; one step = {F}-frame "
                                    f"sequence (ego motion of KITTI drive_0005) of every stream, {N}-pt synthetic HDL-64E clouds, no frame repeated within a sequence",
                        "points_per_frame": N, "frames_per_stream_per_step": F, "streams_per_gpu": B, "streams": B * world, "distinct_scenes_per_gpu": Bc,
-                       "frames_per_step_per_gpu": B * F, "contexts_per_gpu": NC, "frames_per_launch": BL, "compaction_kernel": args.compaction,
+                       "frames_per_step_per_gpu": B * F, "contexts_per_gpu": NC, "frames_per_launch": BL,
                        "elevated_pts_per_frame": ne_tot // BL, "clusters_last_frame_stream0": cl0["num_cluster"], "boxes_last_frame_stream0": len(bx0["boxes"]),
                        "tracks_ever_stream0": int(tr0["n"]), "live_tracks_per_stream": {"mean": round(float(np.mean(live)), 1), "max": int(np.max(live)), "streams_sampled": len(live)},
                        "render_s": round(render_s, 1), "scene_density": args.density,

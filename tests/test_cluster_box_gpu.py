@@ -204,6 +204,27 @@ def test_fused_frames_dev(ctx, oracle, synth):
     dev.free()
 
 
+def test_fused_irregular_frames(mot, hip_lib, oracle, synth):
+    """several hundred tiny clusters (speckled occupancy lists), and a frame with more than 65536 elevated points (many compaction
+    and label chunks, long running positions), next to normal frames in the same batch"""
+    import hiprt
+    import irregular_clouds as ic
+    p = oracle.params(0)
+    many = ic.many_clusters_cloud(); crowded = ic.crowded_cloud(oracle, synth, 120000, 4); normal = synth.make_cloud(120000, 4, 0)
+    assert oracle.cluster(p, oracle.ground_remove(p, many)["elevated"])["num_cluster"] > 255
+    assert len(oracle.ground_remove(p, crowded)["elevated"]) > 65536
+    clouds = [normal, many, crowded, normal[::-1].copy()]
+    stride = ((max(len(x) for x in clouds) + 2047) // 2048) * 2048
+    bufs = []
+    def upload(host):
+        d = hiprt.DeviceBuffer(host); bufs.append(d); return d.ptr, d
+    with mot.Context(max_points=stride, max_batch=4) as c:
+        seen = ic.check_fused_against_oracle(c, oracle, clouds, stride, upload)
+    for d in bufs:
+        d.free()
+    assert seen["clusters"] > 255 and seen["boxes"] > 0
+
+
 def test_full_size_properties(ctx, synth):
     """200k-point frame: labels only on occupied cells, ids contiguous, boxes in cluster order, idempotent"""
     cloud = synth.make_cloud(200000, 11, 0)

@@ -88,3 +88,19 @@ def test_emu_ragged_batch_of_irregular_clouds(mot, oracle):
                 gb[..., 0] = co * dx - si * dy; gb[..., 1] = si * dx + co * dy
                 o = Ts[b].step(gb.astype(np.float32), ts[b]); a = c.get_tracks(b)
                 assert a["n"] == o["n"] and np.array_equal(a["track_manage"], o["track_manage"]), (f, b)
+
+
+def test_emu_fused_irregular_frames(mot, oracle, synth):
+    """several hundred tiny clusters, and more than 65536 elevated points in one frame, next to a normal frame in the same batch"""
+    import build_emu
+    import irregular_clouds as ic
+    lib = build_emu.build()
+    p = oracle.params(0)
+    many = ic.many_clusters_cloud(); crowded = ic.crowded_cloud(oracle, synth, 60000, 9); normal = synth.make_cloud(9000, 4, 0)
+    assert oracle.cluster(p, oracle.ground_remove(p, many)["elevated"])["num_cluster"] > 255
+    assert len(oracle.ground_remove(p, crowded)["elevated"]) > 65536
+    clouds = [many, crowded, normal]
+    stride = max(len(x) for x in clouds) + 64
+    with mot.Context(lib_path=lib, max_points=stride, max_batch=3) as c:
+        seen = ic.check_fused_against_oracle(c, oracle, clouds, stride, lambda host: (host.ctypes.data, host))
+    assert seen["clusters"] > 255
