@@ -321,19 +321,6 @@ __device__ void process_imm_ukf(PredictScratch* G, double dt, bool ok) {
     G->x[m][r] = acc;
   }
   MOT_WAVE_SYNC();
-  if (ok)
-    for (int e = s; e < 75; e += kGroupLanes) {  // predicted covariance :743-749
-      int m = e / 25, r = (e % 25) / 5, c = e % 5;
-      double acc = 0;
-#pragma unroll
-      for (int i = 0; i < 15; i++) {
-        double dr = G->Xs[m][r * 15 + i] - G->x[m][r], dc = G->Xs[m][c * 15 + i] - G->x[m][c];
-        if (r == 3) dr = wrap_pi(dr);
-        if (c == 3) dc = wrap_pi(dc);
-        acc = acc + (ukf_w(i) * dr) * dc;
-      }
-      G->P[m][r * 5 + c] = acc;
-    }
   // UpdateLidar(m) :778-902
   if (ok && s < 6) {
     int m = s / 2, c = s % 2;
@@ -365,6 +352,28 @@ __device__ void process_imm_ukf(PredictScratch* G, double dt, bool ok) {
       int m = e / 10, r = (e % 10) / 2, c = e % 2;
       double Si[4]; inv2(G->S[m], Si);
       G->K[m][r * 2 + c] = G->Tc[m][r * 2 + 0] * Si[0 * 2 + c] + G->Tc[m][r * 2 + 1] * Si[1 * 2 + c];
+    }
+  MOT_WAVE_SYNC();
+  // Predicted covariance :743-749, LAST: its yaw differences are normalised (`while (x_diff(3) > M_PI) ...`), and inside the 75-entry
+  // loop that meant two wrap_pi evaluations per sigma point and entry for the whole wave (any lane with r == 3 or c == 3 drags
+  // the others along): ~150 of them per step, a quarter of this kernel's instructions. Nothing after the covariance reads the
+  // sigma points, so their yaw row is replaced by the normalised difference once (15 lanes x 3 models) and the loop only selects.
+  if (ok && s < 15) {
+#pragma unroll
+    for (int m = 0; m < 3; m++) G->Xs[m][3 * 15 + s] = wrap_pi(G->Xs[m][3 * 15 + s] - G->x[m][3]);
+  }
+  MOT_WAVE_SYNC();
+  if (ok)
+    for (int e = s; e < 75; e += kGroupLanes) {
+      int m = e / 25, r = (e % 25) / 5, c = e % 5;
+      double acc = 0;
+#pragma unroll
+      for (int i = 0; i < 15; i++) {
+        const double dr = r == 3 ? G->Xs[m][3 * 15 + i] : G->Xs[m][r * 15 + i] - G->x[m][r];
+        const double dc = c == 3 ? G->Xs[m][3 * 15 + i] : G->Xs[m][c * 15 + i] - G->x[m][c];
+        acc = acc + (ukf_w(i) * dr) * dc;
+      }
+      G->P[m][r * 5 + c] = acc;
     }
   MOT_WAVE_SYNC();
 }
