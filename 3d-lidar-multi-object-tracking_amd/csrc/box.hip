@@ -101,6 +101,8 @@ label_stats_kernel(MotDevParams p, ClusterBuffers c) {
   __shared__ int s_tilecnt[kWgClusters][kTilesPerChunk + 1];   // +1: the 64 scanning threads walk different banks
   const int b = blockIdx.y;
   const int n = c.counts[b * kCountsStride + kCntElev];
+  // (one workgroup per chunk of the largest possible frame; two thirds find nothing to do and leave. Fewer workgroups that loop
+  // over the chunks are SLOWER — 190 us with 24 per frame, 197 with 8, against 176: profiles/r02_block_size_variants.txt)
   const long base = (long)blockIdx.x * kLabelChunk;
   if (base >= n) return;
   if (threadIdx.x < kWgClusters) {
@@ -1014,6 +1016,16 @@ box_finalize_kernel(MotDevParams p, ClusterBuffers c) {
 }
 
 // ------------------------------------------------------------------------------------------ host
+// workgroups per frame of the per-cluster kernels (each loops over its share of the frame's clusters)
+#ifndef MOT_GATHER_GRID
+#define MOT_GATHER_GRID 16   // 138 -> 124 us per 512 frames against 32 (8: 127, 4: 132); the rectangle kernels want all of theirs (24 / 8: 77 us; 12 / 4: 90)
+#endif
+#ifndef MOT_RECT_GRID
+#define MOT_RECT_GRID 24
+#endif
+#ifndef MOT_RECT_LARGE_GRID
+#define MOT_RECT_LARGE_GRID 8
+#endif
 void mot_launch_stats_init(const ClusterBuffers& c, int batch, hipStream_t stream) {
   hipLaunchKernelGGL(stats_init_kernel, dim3((kMaxClusters + 255) / 256, batch), dim3(256), 0, stream, c);
 }
@@ -1022,10 +1034,10 @@ void mot_launch_box_kernel(int which, const MotDevParams& p, const ClusterBuffer
   int chunks = (max_n + kLabelChunk - 1) / kLabelChunk;
   if (chunks < 1) chunks = 1;
   if (which == 0) hipLaunchKernelGGL(label_stats_kernel, dim3(chunks, batch), dim3(kLabelBlock), 0, stream, p, c);
-  else if (which == 1) hipLaunchKernelGGL(cluster_gather_kernel, dim3(32, batch), dim3(kBoxBlock), 0, stream, p, c);  // clusters beyond 32 per frame loop
+  else if (which == 1) hipLaunchKernelGGL(cluster_gather_kernel, dim3(MOT_GATHER_GRID, batch), dim3(kBoxBlock), 0, stream, p, c);  // a frame's clusters are dealt round-robin to its workgroups
   else if (which == 3) {
-    hipLaunchKernelGGL(cluster_rect_kernel, dim3(24, batch), dim3(kRectBlock), 0, stream, p, c);
-    hipLaunchKernelGGL(cluster_rect_large_kernel, dim3(8, batch), dim3(kRectBlock), 0, stream, p, c);
+    hipLaunchKernelGGL(cluster_rect_kernel, dim3(MOT_RECT_GRID, batch), dim3(kRectBlock), 0, stream, p, c);
+    hipLaunchKernelGGL(cluster_rect_large_kernel, dim3(MOT_RECT_LARGE_GRID, batch), dim3(kRectBlock), 0, stream, p, c);
   }
   else if (which == 4) hipLaunchKernelGGL(cluster_index_kernel, dim3(batch), dim3(kIndexBlock), 0, stream, c);
   else if (which == 2) hipLaunchKernelGGL(box_finalize_kernel, dim3(batch), dim3(kFinalBlock), 0, stream, p, c);

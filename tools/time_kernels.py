@@ -1,0 +1,24 @@
+"""single-kernel timings (mot_time_stage: HIP events, one context, nothing else on the GPU) of the product library and of every
+prebuilt variant in variants/ (tools/prebuild.py), at B frames per launch of the bench workload:
+    python tools/time_kernels.py [B] [kernel ids, comma separated: 10-12 ground, 21 cluster, 30/34/31/33/32 box, 0/1/2/100 stages]"""
+import glob, importlib.util, os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+def _load(name, path):
+    spec = importlib.util.spec_from_file_location(name, path, submodule_search_locations=[os.path.dirname(path)])
+    m = importlib.util.module_from_spec(spec); sys.modules[name] = m; spec.loader.exec_module(m); return m
+import torch
+torch.cuda.init()
+PKG = os.path.join(ROOT, "3d-lidar-multi-object-tracking_amd")
+mot = _load("mot_amd", os.path.join(PKG, "__init__.py")); sdev = _load("mot_amd.synth_dev", os.path.join(PKG, "synth_dev.py"))
+B = int(sys.argv[1]) if len(sys.argv) > 1 else 512
+ids = [int(x) for x in sys.argv[2].split(",")] if len(sys.argv) > 2 else [30, 34, 31, 33, 2, 100]
+N, F = 120000, 2
+stride = ((N + 2047) // 2048) * 2048
+v, yaw = sdev.load_ego(F)
+seq, n_seq, _, _ = sdev.SequenceRenderer("cuda").render(list(range(B)), F, N, stride, v, yaw)
+libs = [None] + sorted(glob.glob(os.path.join(ROOT, "variants", "libmot_*.so"))) + [None]
+for lib in libs:
+    with mot.Context(max_points=stride, max_batch=B, **({"lib_path": lib} if lib else {})) as c:
+        c.frames_dev(seq[1].data_ptr(), stride * 4, n_seq[1]); c.synchronize()
+        t = {k: c.time_stage(k, B, 10) * 1e3 for k in ids}
+        print(f"{os.path.basename(lib)[7:-3] if lib else 'product':26s} " + "  ".join(f"{k}: {t[k]:7.1f}" for k in ids) + f"  us  (B={B})", flush=True)
