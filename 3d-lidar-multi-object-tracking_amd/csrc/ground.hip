@@ -120,30 +120,33 @@ polar_minz_kernel(MotDevParams p, GroundBuffers g) {
   }
   int cells[kGroundItems];
   polar_cells<kGroundItems, kGroundBlock>(p, pt, in, base, n, cells);
-  {  // the compaction kernel classifies by the same cell: 2 bytes per point here instead of the whole cell computation there
-    unsigned short* __restrict__ cell16 = g.cell + (long)b * g.cap;
-    if (base + kGroundChunk <= n) {
-#pragma unroll
-      for (int k = 0; k < kGroundItems; k++) cell16[base + k * kGroundBlock + threadIdx.x] = (unsigned short)cells[k];   // -1 -> 0xffff
-    } else {
-#pragma unroll
-      for (int k = 0; k < kGroundItems; k++) {
-        long i = base + k * kGroundBlock + threadIdx.x;
-        if (i < n) cell16[i] = (unsigned short)cells[k];
-      }
-    }
-  }
 #pragma unroll
   for (int k = 0; k < kGroundItems; k++) {
     const float z = pt[k].z;
-    int cell = cells[k];
-    if (!(z == z)) cell = -1;                 // `z < minZ` is false for NaN: never updates
-    s_stage[kStagePad(k * kGroundBlock + (int)threadIdx.x)] = make_uint2((unsigned)cell, (unsigned)mot_float_key(z + 0.0f));  // canonical +0
+    // `z < minZ` is false for NaN: such a point never updates its cell — it travels with the largest key, which no minimum takes
+    const int zkey = (z == z) ? mot_float_key(z + 0.0f) : 0x7fffffff;   // canonical +0
+    s_stage[kStagePad(k * kGroundBlock + (int)threadIdx.x)] = make_uint2((unsigned)cells[k], (unsigned)zkey);
   }
   __syncthreads();
   uint2 e[kGroundItems];
 #pragma unroll
   for (int j = 0; j < kGroundItems; j++) e[j] = s_stage[(int)threadIdx.x * (kGroundItems + 1) + j];   // = kStagePad(8 * tid + j)
+  {  // The compaction kernel classifies by the same cell: 2 bytes per point here instead of the whole cell computation there.
+     // Written from THIS side of the transposition: a thread holds the cells of 8 consecutive points = one 16-byte store (from the
+     // loading side it was 8 two-byte stores per thread, 128 bytes per wave instruction).
+    static_assert(kGroundItems == 8, "one 16-byte store of 8 cells per thread");
+    unsigned short* __restrict__ cell16 = g.cell + (long)b * g.cap;
+    const long i0 = base + (long)threadIdx.x * kGroundItems;
+    if (i0 + kGroundItems <= n) {
+      uint4 v;
+      v.x = (e[0].x & 0xffffu) | (e[1].x << 16); v.y = (e[2].x & 0xffffu) | (e[3].x << 16);   // -1 -> 0xffff
+      v.z = (e[4].x & 0xffffu) | (e[5].x << 16); v.w = (e[6].x & 0xffffu) | (e[7].x << 16);
+      *reinterpret_cast<uint4*>(cell16 + i0) = v;
+    } else {
+#pragma unroll
+      for (int j = 0; j < kGroundItems; j++) if (i0 + j < n) cell16[i0 + j] = (unsigned short)e[j].x;
+    }
+  }
   int cnt = 0;   // runs of a real cell among my 8 points
 #pragma unroll
   for (int j = 0; j < kGroundItems; j++) cnt += ((int)e[j].x >= 0 && (j == 0 || e[j].x != e[j - 1].x)) ? 1 : 0;
@@ -361,7 +364,8 @@ classify_compact_kernel(MotDevParams p, GroundBuffers g) {
   }
   {  // polar cell of every point, as the min-z kernel found it (filterCloud + getCellIndexFromPoints + the node's crop)
     const unsigned short* __restrict__ cell16 = g.cell + (long)b * g.cap;
-    if (full) {
+    if (full) {   // (one 16-byte load per lane + a wave-private LDS transposition instead of these 8 two-byte loads, and the same for
+                  // the mask bytes on the way out, measured no faster: 366-369 against 371 us — this kernel waits for HBM, not for its TA)
 #pragma unroll
       for (int k = 0; k < kCompactItems; k++) { const unsigned c = cell16[base + k * kCompactBlock + threadIdx.x]; cls[k] = c == 0xffffu ? -1 : (int)c; }
     } else {
