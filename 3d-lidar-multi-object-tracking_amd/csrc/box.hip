@@ -477,6 +477,7 @@ cluster_gather_kernel(MotDevParams p, ClusterBuffers c) {
   for (int ci = blockIdx.x; ci < num_cluster; ci += gridDim.x) {
     GATHER_T_BEGIN();
     const ClusterStats st = c.stats[(long)b * kMaxClusters + ci];
+    const int first_slot = cstart[ci];   // (asked for together with the statistics: one round trip, not two)
     BoxCandidate cand;
     for (int k = 0; k < 8; k++) cand.pc[k] = 0.f;
     cand.max_z = 0.f; cand.accepted = 0; cand.undefined = 0; cand.branch = -1;
@@ -488,6 +489,11 @@ cluster_gather_kernel(MotDevParams p, ClusterBuffers c) {
       if (tid == 0) c.cand[(long)b * kMaxClusters + ci] = cand;
       continue;
     }
+    // The first trip of the rectangle branch's point walk is requested HERE, next to the three points the branch decision needs,
+    // so that its round trip overlaps theirs (an L-shape cluster throws these 8 indices per thread away).
+    int nxt[kGatherDepth];
+#pragma unroll
+    for (int u = 0; u < kGatherDepth; u++) { int j = u * kBoxBlock + tid; nxt[u] = j < numPoints ? sorted[first_slot + j] : -1; }
     const float4 first = pts[st.first];
     const float initPX = first.x + p.roi_half, initPY = first.y + p.roi_half;  // :218-225
     const int initX = (int)floorf(initPX * p.pic_scale), initY = (int)floorf(initPY * p.pic_scale);
@@ -565,7 +571,6 @@ cluster_gather_kernel(MotDevParams p, ClusterBuffers c) {
       }
       GATHER_T(1);
       // the k-th point of the cluster in input order is one lookup in the cluster-sorted index
-      const int first_slot = cstart[ci];
       for (int j = tid; j < nsamp; j += kBoxBlock) s_pidx[j] = sorted[first_slot + s_rank[j]];
       __syncthreads();
       GATHER_T(2);
@@ -610,14 +615,10 @@ cluster_gather_kernel(MotDevParams p, ClusterBuffers c) {
       cand.branch = 1;
       for (int i = tid; i < kPicCols; i += kBoxBlock) { s_colmin[i] = 0x7fffffff; s_colmax[i] = -0x7fffffff - 1; }
       __syncthreads();
-      const int first_slot = cstart[ci];
       // the cluster's points through the sorted index; what is fetched per point is its 4-byte picture pixel (label kernel)
       const int* __restrict__ pix = c.pix + (long)b * c.cap;
       // two dependent loads per point (sorted index -> pixel): the indices of the NEXT trip are requested right behind the
       // pixel loads of this one (loads return in order), so a trip costs one memory round trip instead of two
-      int nxt[kGatherDepth];
-#pragma unroll
-      for (int u = 0; u < kGatherDepth; u++) { int j = u * kBoxBlock + tid; nxt[u] = j < numPoints ? sorted[first_slot + j] : -1; }
       for (int j0 = 0; j0 < numPoints; j0 += kBoxBlock * kGatherDepth) {
         int v[kGatherDepth];
 #pragma unroll
