@@ -447,6 +447,10 @@ def main():
     ctx = ctxs[0]
     # one process group (RCCL communicator) per context: each context's issuing thread orders its own collectives
     groups = [dist.new_group(backend="nccl") for _ in range(NC)] if gather_on else None
+    if gather_on:   # RCCL builds a communicator at a group's first collective (~1 s): here, not inside the timed region, whatever --warmup is
+        for g_ in groups:
+            dist.all_reduce(torch.zeros(1, device="cuda"), group=g_)
+        torch.cuda.synchronize()
     gathers = [multi.TrackGather(Bc, GATHER_TRACKS, world, "cuda", group=groups[ci]) for ci in range(NC)] if gather_on else None
     torch.cuda.synchronize()
     frame_ptr = [seq_dev[f].data_ptr() for f in range(F)]
