@@ -581,7 +581,9 @@ def main():
             "timed_region_s": round(dt, 3), "host_issue_ms_per_step": round(host_issue[0] / args.steps * 1e3, 3),
             "issue_threads": (NC if args.issue_threads and NC > 1 else 1),
             "config": {"workload": f"configs[3]: ground removal -> CCL -> box fit -> batched IMM-UKF-PDA tracker on one MI355X per rank; one step = {F}-frame "
-                                   f"sequence (ego motion of KITTI drive_0005) of every stream, {N}-pt synthetic HDL-64E clouds, no frame repeated within a sequence",
+                                   f"sequence (ego motion of KITTI drive_0005) of every stream, {N}-pt synthetic HDL-64E clouds, no frame repeated within a sequence"
+                                   + ("" if world == 1 else f"; sharded as configs[4] (every stream pinned to one GPU, RCCL all-gather of the live-track blocks per frame) "
+                                      f"with the SAME per-GPU work as the 1-GPU line (weak scaling); configs[4]'s 200 k-point frames: --points 200000"),
                        "points_per_frame": N, "frames_per_stream_per_step": F, "streams_per_gpu": B, "streams": B * world, "distinct_scenes_per_gpu": Bc,
                        "frames_per_step_per_gpu": B * F, "contexts_per_gpu": NC, "frames_per_launch": BL,
                        "elevated_pts_per_frame": ne_tot // BL, "clusters_last_frame_stream0": cl0["num_cluster"], "boxes_last_frame_stream0": len(bx0["boxes"]),
