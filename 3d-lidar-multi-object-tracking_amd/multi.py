@@ -28,10 +28,18 @@ class TrackGather:
         self.flat = torch.zeros(nrec + batch, dtype=torch.int32, device=device)
         self.src = self.flat[:nrec].view(batch, max_tracks, TRACK_RECORD_WORDS)
         self.cnt = self.flat[nrec:]
-        self.dst_flat = [torch.zeros_like(self.flat) for _ in range(world)] if world > 1 else [self.flat]
-        self.dst = [d[:nrec].view(batch, max_tracks, TRACK_RECORD_WORDS) for d in self.dst_flat]
-        self.dst_cnt = [d[nrec:] for d in self.dst_flat]
+        self._nrec = nrec
+        self.recv = None          # [world x (records + counts)]: ONE receive buffer, filled by all_gather_into_tensor
+        self._point_views(torch.zeros(world * self.flat.numel(), dtype=torch.int32, device=device) if world > 1 else None)
         self._ext = {}   # context -> torch view of its HIP stream
+
+    def _point_views(self, recv):
+        """dst / dst_cnt: per-rank views of the receive buffer (with one rank and no collective: of the send buffer itself)"""
+        L = self.flat.numel()
+        self.recv = recv
+        self.dst_flat = [recv[r * L:(r + 1) * L] for r in range(self.world)] if recv is not None else [self.flat]
+        self.dst = [d[:self._nrec].view(self.batch, self.max_tracks, TRACK_RECORD_WORDS) for d in self.dst_flat]
+        self.dst_cnt = [d[self._nrec:] for d in self.dst_flat]
 
     def step(self, ctx, force_collective: bool = False):
         """export this rank's block (async on the context stream), then exchange.
@@ -60,7 +68,10 @@ class TrackGather:
     def exchange(self, force_collective: bool = False):
         if self.world > 1 or force_collective:
             import torch.distributed as dist
-            dist.all_gather(self.dst_flat, self.flat, group=self.group)
+            if self.recv is None:   # one rank, collective forced (bench.py --force-gather, tools/check_gather_gpu.py): its own receive buffer
+                self._point_views(self.torch.zeros_like(self.flat))
+            # one contiguous receive buffer: no list of per-rank tensors for c10d to flatten and copy back, one enqueue per step
+            dist.all_gather_into_tensor(self.recv, self.flat, group=self.group)
         return self.dst, self.dst_cnt
 
     def blocks_as_numpy(self):

@@ -21,10 +21,6 @@ for f in range(6):
     frames.append(torch.from_numpy(host).cuda())
 ctxs = [mot.Context(max_points=stride, max_batch=B, max_tracks_total=512) for _ in range(NC)]
 tgs = [multi.TrackGather(B, K, 1, "cuda") for _ in range(NC)]
-for tg in tgs:   # a receive buffer of its own, as with more than one rank (with one rank TrackGather gathers in place)
-    tg.dst_flat = [torch.zeros_like(tg.flat)]
-    nrec = tg.batch * tg.max_tracks * multi.TRACK_RECORD_WORDS
-    tg.dst = [tg.dst_flat[0][:nrec].view(tg.batch, tg.max_tracks, multi.TRACK_RECORD_WORDS)]; tg.dst_cnt = [tg.dst_flat[0][nrec:]]
 snaps = []
 for f in range(6):
     ts = np.full(B, 1.0e9 + f * 1e5)
