@@ -86,27 +86,68 @@ def _cpu_worker(idx):
     return k, time.perf_counter() - t0
 
 
-def cpu_baseline(frames: np.ndarray, ego_v, ego_yaw, n_points: int, budget_s: float = 10.0):
+def usable_cores() -> int:
+    """host cores this process may actually run on: the scheduler affinity mask, capped by the cgroup CPU quota when there is one
+    (os.cpu_count() reports the machine, not the container)"""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if q != "max":
+            n = max(1, min(n, int(float(q) / float(per))))
+    except Exception:
+        pass
+    return max(1, n)
+
+
+def gpu_sequence_results(mot, device, seq_dev, n_seq, stride, ego_v, ego_yaw, stream=0, lib_path=None):
+    """the GPU's results for ONE stream of the bench workload, frame by frame through the fused path (mot_frames_dev, tracker on), kept
+    on the host for `parity_check`: digests of mask / clouds / label grid, boxes (sensor and global frame), track outputs and the
+    filter state of every live track."""
+    import ctypes as C
+    import hashlib
+    F = seq_dev.shape[0]
+    dig = lambda a: hashlib.blake2b(np.ascontiguousarray(a[..., :3] if a.ndim == 2 and a.shape[-1] == 4 else a).tobytes(), digest_size=16).hexdigest()   # clouds: x, y, z (PointXYZ has no 4th value)
+    out = []
+    with mot.Context(device=device, max_points=stride, max_batch=1, max_tracks_total=1024, **({"lib_path": lib_path} if lib_path else {})) as c:
+        for f in range(F):
+            n = int(n_seq[f, stream])
+            c.frames_dev(seq_dev[f, stream].data_ptr(), stride * 4, [n], run_tracker=True, timestamps=[1.0e9 + f * 1e5], ego_v=[float(ego_v[f])], ego_yaw=[float(ego_yaw[f])])
+            g = c.get_ground(0, n_hint=n); cl = c.get_clusters(0); bx = c.get_boxes(0); tr = c.get_tracks(0)
+            gb = np.zeros((1024, 8, 3), np.float32)
+            assert c.lib.mot_debug_copy(c._h, 11, 0, gb.ctypes.data_as(C.c_void_p), C.c_size_t(gb.nbytes)) == 0
+            live = np.nonzero(tr["track_manage"] > 0)[0]
+            out.append(dict(mask=g["mask"], elevated=dig(g["elevated"]), ground=dig(g["ground"]), n_elevated=len(g["elevated"]), n_ground=len(g["ground"]),
+                            grid=dig(cl["grid"]), num_cluster=cl["num_cluster"], boxes=bx["boxes"], boxes_global=gb[: len(bx["boxes"])].copy(),
+                            tracks=tr, states={int(i): c.track_state(int(i)) for i in live}))
+    return out
+
+
+def cpu_baseline(frames: np.ndarray, ego_v, ego_yaw, n_points: int, budget_s: float = 10.0, gpu_results=None, n_per_frame=None, lib=None, quick=False):
     """the reference CPU path (its own sources, oracle/_ref) on consecutive frames of one stream of the bench workload.
     BASELINE.md §2 protocol: single thread with per-stage median / p95, frame-parallel over the host cores for the stateless
-    stages, and the -O0 build (the reference's CMakeLists sets no build type)."""
+    stages, and the -O0 build (the reference's CMakeLists sets no build type).
+    With `gpu_results` (gpu_sequence_results of the SAME stream) what the reference computes is not thrown away: every frame's
+    clouds, label grid, boxes, tracker outputs and filter states are compared with the GPU's -> second return value
+    (`parity_check` of the bench line: the benched frames themselves, BASELINE.json configs[3] as written)."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import hashlib
     import oracle_lib as O
-    seq = _load("mot_amd.sequence", os.path.join(PKG_DIR, "sequence.py"))
+    import seq_parity as SP
     try:
         use_ref = O.ref() is not None
     except Exception:
         use_ref = False
     p = O.params(0)
     nF = len(frames)
+    dig = lambda a: hashlib.blake2b(np.ascontiguousarray(a[..., :3] if a.ndim == 2 and a.shape[-1] == 4 else a).tobytes(), digest_size=16).hexdigest()   # clouds: x, y, z (PointXYZ has no 4th value)
 
-    def run_single(max_frames, budget):
+    def run_single(max_frames, budget, keep=None):
         trk = O.RefTracker() if use_ref else O.Tracker(p)
         trk.reset()
         st = {"ground": [], "cluster": [], "box": [], "tracker": []}
-        t_all = time.perf_counter(); k = 0
+        t_all = time.perf_counter(); k = 0; busy = 0.0
         for f in range(min(max_frames, nF)):
-            c = frames[f]
+            c = frames[f] if n_per_frame is None else np.ascontiguousarray(frames[f][: int(n_per_frame[f])])
             t0 = time.perf_counter()
             g = O.ref_ground_remove(c) if use_ref else O.ground_remove(p, c)
             t1 = time.perf_counter()
@@ -116,43 +157,84 @@ def cpu_baseline(frames: np.ndarray, ego_v, ego_yaw, n_points: int, budget_s: fl
             t3 = time.perf_counter()
             ts = 1.0e9 + f * 1e5
             ego = trk.ego_update(ts, float(ego_v[f]), float(ego_yaw[f]))
-            trk.step(seq.boxes_to_global(bx, ego), ts, max_tracks=65536)
+            gb = SP.boxes_to_global(O, lib, bx, ego[:3])   # the tracking node's tf step (oracle/ref_tf_capi.cpp), as tests/test_tf_exact.py
+            tr = trk.step(gb, ts, max_tracks=65536)
             t4 = time.perf_counter()
             for name, d in zip(("ground", "cluster", "box", "tracker"), (t1 - t0, t2 - t1, t3 - t2, t4 - t3)):
                 st[name].append(d * 1e3)
+            busy += t4 - t0
             k += 1
+            if keep is not None:   # (outside the timed intervals)
+                live = np.nonzero(tr["track_manage"] > 0)[0]
+                keep.append(dict(elevated=dig(g["elevated"]), ground=dig(g["ground"]), n_elevated=len(g["elevated"]), n_ground=len(g["ground"]), grid=dig(cl["grid"]),
+                                 num_cluster=cl["num_cluster"], boxes=bx, boxes_global=gb, tracks=tr, states={int(i): trk.state(int(i)) for i in live},
+                                 mask=O.ground_remove(p, c)["mask"]))
             if time.perf_counter() - t_all > budget:
                 break
-        wall = time.perf_counter() - t_all
         if hasattr(trk, "close"):
             trk.close()
-        return k, wall, st
+        return k, busy, st
 
     run_single(2, 5.0)  # warm-up
-    k, wall, st = run_single(nF, budget_s * 0.5)
+    kept = [] if gpu_results is not None else None
+    k, wall, st = run_single(nF, max(budget_s * 0.5, 30.0 if kept is not None else 0.0), kept)
+    parity = None
+    if kept is not None:
+        parity = {"frames": len(kept), "stream": 0, "oracle": "the reference's own sources (oracle/_ref/libmot_ref.so), tracker fed through the node's tf sequence" if use_ref
+                  else "C restatement (oracle/_ref not present)", "workload": "the benched frames: stream 0 of this run, every frame"}
+        first_bad = {}
+        flags = {"clouds_bit_exact": True, "masks_equal_restatement": True, "label_grids_bit_exact": True, "boxes_bit_exact": True, "global_boxes_bit_exact": True, "track_sets_equal": True}
+        stats = {}
+        for f, (r, gres) in enumerate(zip(kept, gpu_results)):
+            def bad(key):
+                flags[key] = False; first_bad.setdefault(key, f)
+            if r["elevated"] != gres["elevated"] or r["ground"] != gres["ground"]:
+                bad("clouds_bit_exact")
+            if not np.array_equal(r["mask"], gres["mask"]):
+                bad("masks_equal_restatement")
+            if r["grid"] != gres["grid"] or r["num_cluster"] != gres["num_cluster"]:
+                bad("label_grids_bit_exact")
+            if not SP.bits_equal(r["boxes"], gres["boxes"]):
+                bad("boxes_bit_exact")
+            if not SP.bits_equal(r["boxes_global"], gres["boxes_global"]):
+                bad("global_boxes_bit_exact")
+            try:
+                SP.compare_tracks(gres["tracks"], r["tracks"], lambda i: gres["states"][i], lambda i: r["states"][i], f, stats=stats)
+            except (AssertionError, KeyError) as e:
+                bad("track_sets_equal"); first_bad.setdefault("track_detail", str(e)[:200])
+        parity.update(flags)
+        parity["masks_boxes_bit_exact"] = all(flags[k_] for k_ in ("clouds_bit_exact", "masks_equal_restatement", "label_grids_bit_exact", "boxes_bit_exact", "global_boxes_bit_exact"))
+        parity.update({"max_rel_state_err": stats.get("max_rel_state_err"), "state_compares": stats.get("state_compares", 0), "live_tracks_max": stats.get("live_max", 0),
+                       "tracks_ever": stats.get("tracks_ever", 0), "boxes_total": int(sum(len(r["boxes"]) for r in kept)), "first_mismatch_frame": first_bad or None,
+                       "bar": "clouds / label grids / boxes bit-exact; track set, trackManage, lifetime, static / vis flags exact; every state key <= 1e-4 relative"})
+        del kept
     out = {"value": round(k / wall, 2), "unit": "frames/s", "cores": 1, "kind": "reference" if use_ref else "port",
            "sample": f"{k} consecutive frames x {n_points} pts of one bench stream: ground + cluster + box + tracker, one thread "
-                     f"({os.cpu_count()} host cores present; the reference is single-threaded)",
+                     f"({usable_cores()} host cores usable; the reference is single-threaded)",
            "single": {"frames": k, "frames_per_s": round(k / wall, 2),
                       "stage_ms": {n: {"median": round(_pct(v, 50), 4), "p95": round(_pct(v, 95), 4)} for n, v in st.items()}}}
     # ---- frame-parallel: N processes, the stateless stages (the tracker is sequential per stream)
-    if use_ref:
+    if use_ref and not quick:
         try:
             import multiprocessing as mp
-            ncpu = os.cpu_count() or 1
+            ncpu = usable_cores()
             path = f"/dev/shm/mot_bench_frames_{os.getpid()}.npy" if os.path.isdir("/dev/shm") else f"/tmp/mot_bench_frames_{os.getpid()}.npy"
             np.save(path, frames)
             per = 24
             idx = [[(w * per + j) % nF for j in range(per)] for w in range(ncpu)]
             with mp.get_context("spawn").Pool(ncpu, initializer=_cpu_worker_init, initargs=(path, frames.shape)) as pool:   # spawn: the parent holds a HIP runtime
-                pool.map(_cpu_worker, [[w % nF] for w in range(ncpu)])   # warm-up: library loaded, pages touched
+                pool.map(_cpu_worker, [[w % nF] for w in range(ncpu)], chunksize=1)   # warm-up: library loaded, pages touched
                 t0 = time.perf_counter()
                 res = pool.map(_cpu_worker, idx, chunksize=1)
-                wall = time.perf_counter() - t0
+                wall_p = time.perf_counter() - t0
             os.unlink(path)
             done = sum(r[0] for r in res)
-            out["parallel"] = {"frames_per_s": round(done / wall, 1), "cores": ncpu, "frames": done,
-                               "what": "ground + cluster + box, one process per host core, each on its own frames (the tracker is sequential per stream)"}
+            busy = [r[1] for r in res]
+            out["parallel"] = {"frames_per_s": round(done / wall_p, 1), "cores": ncpu, "frames": done,
+                               "frames_per_s_per_core": round(done / wall_p / ncpu, 2), "worker_busy_s": {"min": round(min(busy), 2), "max": round(max(busy), 2)},
+                               "wall_s": round(wall_p, 2), "os_cpu_count": os.cpu_count(),
+                               "what": "ground + cluster + box, one process per USABLE host core (affinity mask / cgroup quota), each on its own frames (the tracker is "
+                                       "sequential per stream); per-core rate below the single-thread figure = memory bandwidth and cache shared by the workers"}
         except Exception as e:   # an auxiliary figure must never cost the bench line
             out["parallel"] = {"error": str(e)[:200]}
         # ---- the -O0 build
@@ -167,7 +249,7 @@ def cpu_baseline(frames: np.ndarray, ego_v, ego_yaw, n_points: int, budget_s: fl
                              "what": "the same sources at -O0 (OT/CMakeLists.txt sets no build type)"}
             finally:
                 O.set_ref_library(None)
-    return out
+    return out, parity
 
 
 # ------------------------------------------------------------------------------------------------ auxiliary GPU lines
@@ -176,7 +258,15 @@ def tracker_stress(mot, torch, device, streams=128, loads=(8, 32, 64), frames=40
     after 12 frames every box carries a confirmed track. Mean kernel duration over the remaining frames (HIP events)."""
     out = {}
     rng = np.random.default_rng(11)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    try:   # the checker (test infrastructure): stream 0 of every load is also stepped by the oracle and compared at the end
+        import oracle_lib as O
+        import seq_parity as SP
+        op = O.params(0)
+    except Exception:
+        O = None
     for T in loads:
+        orc_t = O.Tracker(op) if O is not None else None
         with mot.Context(device=device, max_points=1024, max_batch=streams, max_tracks_total=1024) as c:
             side = int(np.ceil(np.sqrt(T)))
             centres = np.stack(np.meshgrid(np.arange(side), np.arange(side)), -1).reshape(-1, 2)[:T] * 9.0 - side * 4.5
@@ -196,12 +286,23 @@ def tracker_stress(mot, torch, device, streams=128, loads=(8, 32, 64), frames=40
                     c.synchronize(); c.profile_kernel(40, 1)
                 c.track_steps_dev(d.data_ptr(), stride, [T] * streams, [ts] * streams)
                 c.synchronize()
+                if orc_t is not None:
+                    orc_t.ego_update(ts, 0.0, 0.0); o_tr = orc_t.step(bx[0], ts, max_tracks=1024)
             r = c.profile_read()
             tr = c.get_tracks(0)
             live = int((tr["track_manage"] > 0).sum())
+            checked = None
+            if orc_t is not None:
+                try:
+                    st_ = {}
+                    SP.compare_tracks(tr, o_tr, lambda i: c.track_state(i, slot=0), orc_t.state, ("tracker_stress", T), stats=st_)
+                    checked = {"equal": True, "max_rel_state_err": st_.get("max_rel_state_err"), "live": st_.get("live_max")}
+                except AssertionError as e:
+                    checked = {"equal": False, "detail": str(e)[:200]}
+                orc_t.close()
             out[str(T)] = {"us_per_launch": round(r["mean_ms"] * 1e3, 2), "min_us": round(r["min_ms"] * 1e3, 2), "max_us": round(r["max_ms"] * 1e3, 2),
                            "samples": r["samples"], "streams": streams, "boxes_per_stream": T, "live_tracks_stream0": live,
-                           "tracks_ever_stream0": int(tr["n"])}
+                           "tracks_ever_stream0": int(tr["n"]), "stream0_vs_oracle_after_all_frames": checked}
     return out
 
 
@@ -616,6 +717,12 @@ def main():
         frames_host = seq_dev[:, 0, :N].cpu().numpy() if (not args.no_cpu_baseline and world == 1) else None
         for cx in ctxs:
             cx.close()
+        gpu_res = None
+        if frames_host is not None:   # the GPU's results for bench stream 0, every frame, for the parity check against the reference below
+            try:
+                gpu_res = gpu_sequence_results(mot, local, seq_dev, n_seq, stride, ego_v, ego_yaw, 0)
+            except Exception as e:
+                print(f"gpu_sequence_results failed: {e}", file=sys.stderr)
         if not args.no_aux and world == 1:
             try:
                 out["tracker_stress"] = tracker_stress(mot, torch, local)
@@ -634,7 +741,7 @@ def main():
                 print(f"host_boundary_pipelined failed: {e}", file=sys.stderr)
         del seq_dev
         if frames_host is not None:
-            out["cpu_baseline"] = cpu_baseline(frames_host, ego_v, ego_yaw, N)
+            out["cpu_baseline"], out["parity_check"] = cpu_baseline(frames_host, ego_v, ego_yaw, N, gpu_results=gpu_res, n_per_frame=n_seq[:, 0], lib=mot.load_library(variant) if variant else mot.load_library())
         _JSON_OUT.write(json.dumps(out) + "\n"); _JSON_OUT.flush()
     if gather_on:
         dist.barrier()

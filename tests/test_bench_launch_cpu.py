@@ -36,3 +36,35 @@ def test_bench_refuses_a_world_size_mismatch():
     env = dict(os.environ, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0")
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--selftest-cpu"], capture_output=True, text=True, timeout=300, env=env, cwd=ROOT)
     assert r.returncode == 2 and "WORLD_SIZE" in r.stderr
+
+
+def test_bench_parity_check_logic_on_the_emulator():
+    """bench.py's `parity_check` (the GPU's per-frame results of bench stream 0 against what the reference computes in the
+    cpu_baseline leg) with the emulator build standing in for the GPU and tiny frames: the plumbing, and that a corrupted result is
+    reported — the real comparison runs inside `python bench.py` on the MI355X."""
+    torch = pytest.importorskip("torch")
+    import importlib.util
+    import numpy as np
+    sys.path.insert(0, os.path.join(ROOT, "tests", "emu"))
+    import build_emu
+    from conftest import load_pkg, load_sub
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(ROOT, "bench.py"))
+    bench = importlib.util.module_from_spec(spec); spec.loader.exec_module(bench)
+    mot = load_pkg(); synth = load_sub("synth")
+    lib = build_emu.build()
+    F, N, stride = 6, 6000, 6144
+    host = np.zeros((F, 1, stride, 4), np.float32)
+    n_seq = np.zeros((F, 1), np.int32)
+    for f in range(F):
+        n = N - 11 * f
+        host[f, 0, :n] = synth.make_cloud(N, 4, f)[:n]; n_seq[f, 0] = n
+    seq = torch.from_numpy(host)
+    ego_v = np.full(F, 2.0); ego_yaw = 0.01 * np.arange(F)
+    res = bench.gpu_sequence_results(mot, 0, seq, n_seq, stride, ego_v, ego_yaw, 0, lib_path=lib)
+    base, par = bench.cpu_baseline(host[:, 0, :N], ego_v, ego_yaw, N, budget_s=2.0, gpu_results=res, n_per_frame=n_seq[:, 0], lib=mot.load_library(lib), quick=True)
+    assert base["value"] > 0 and par["frames"] == F
+    assert par["masks_boxes_bit_exact"] and par["track_sets_equal"] and par["boxes_total"] > 0 and par["first_mismatch_frame"] is None, par
+    assert par["max_rel_state_err"] is not None and par["max_rel_state_err"] <= 1e-4
+    res[3]["boxes"] = res[3]["boxes"] + np.float32(1e-3)   # a corrupted GPU result must show up, with its frame
+    _, par2 = bench.cpu_baseline(host[:, 0, :N], ego_v, ego_yaw, N, budget_s=2.0, gpu_results=res, n_per_frame=n_seq[:, 0], lib=mot.load_library(lib), quick=True)
+    assert not par2["boxes_bit_exact"] and not par2["masks_boxes_bit_exact"] and par2["first_mismatch_frame"]["boxes_bit_exact"] == 3

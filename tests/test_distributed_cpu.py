@@ -19,6 +19,7 @@ def _worker(rank, world, port, lib, q):
         dist.init_process_group("gloo", rank=rank, world_size=world)
         from conftest import load_pkg, load_sub
         import oracle_lib as O
+        import seq_parity as SP
         mot = load_pkg(); synth = load_sub("synth"); multi = load_sub("multi")
         B, N, stride, K = 2, 6000, 6144, 16
         p = O.params(0)
@@ -31,7 +32,7 @@ def _worker(rank, world, port, lib, q):
             for b in range(B):
                 host[b, :N] = synth.make_cloud(N, multi.scene_of(rank, b), f)
             ts = [1.0e9 + f * 1e5] * B
-            ctx.frames_dev(host.ctypes.data, stride * 4, [N] * B, run_tracker=True, timestamps=ts, ego_v=[0.0] * B, ego_yaw=[0.0] * B)
+            ctx.frames_dev(host.ctypes.data, stride * 4, [N] * B, run_tracker=True, timestamps=ts, ego_v=[1.5] * B, ego_yaw=[0.004 * f] * B)
             tg.step(ctx)
             # oracle for EVERY rank's streams (each rank checks the whole gathered result)
             for r in range(world):
@@ -40,12 +41,8 @@ def _worker(rank, world, port, lib, q):
                     g = O.ground_remove(p, c); cl = O.cluster(p, g["elevated"])
                     bx = O.box_fit(p, g["elevated"], cl["grid"], cl["num_cluster"])["boxes"]
                     T = trackers[(r, b)]
-                    ego = T.ego_update(ts[b], 0.0, 0.0)
-                    co, si = np.cos(-ego[2]), np.sin(-ego[2])
-                    gb = bx.astype(np.float64).copy()
-                    dx, dy = gb[..., 0] - ego[0], gb[..., 1] - ego[1]
-                    gb[..., 0] = co * dx - si * dy; gb[..., 1] = si * dx + co * dy
-                    expect[(r, b)] = T.step(gb.astype(np.float32), ts[b])
+                    ego = T.ego_update(ts[b], 1.5, 0.004 * f)
+                    expect[(r, b)] = T.step(SP.boxes_to_global(O, ctx.lib, bx, ego[:3]), ts[b])   # the tracking node's tf step
         blocks = tg.blocks_as_numpy()
         assert len(blocks) == world
         for r, (cnt, rec) in enumerate(blocks):
@@ -55,7 +52,10 @@ def _worker(rank, world, port, lib, q):
                 assert cnt[b] == len(live), (rank, r, b, cnt[b], len(live))
                 assert np.array_equal(rec[b]["id"][: cnt[b]], live)
                 assert np.array_equal(rec[b]["track_manage"][: cnt[b]], o["track_manage"][live])
-                assert np.allclose(rec[b]["p"][: cnt[b]], o["p"][live], rtol=1e-3, atol=1e-4)
+                assert np.allclose(rec[b]["p"][: cnt[b]], o["p"][live], rtol=1e-4, atol=1e-6)     # BASELINE.json's bar
+                assert np.allclose(rec[b]["v_yaw"][: cnt[b]], o["v_yaw"][live], rtol=1e-4, atol=1e-7)
+                assert np.array_equal(rec[b]["is_vis"][: cnt[b]], o["is_vis"][live]) and np.array_equal(rec[b]["lifetime"][: cnt[b]], o["lifetime"][live])
+                assert np.allclose(rec[b]["vis_box"][: cnt[b]], o["vis_box"][live], rtol=1e-4, atol=1e-5)
         dist.barrier()
         dist.destroy_process_group()
         q.put((rank, "ok"))

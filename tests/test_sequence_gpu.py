@@ -1,0 +1,37 @@
+"""BASELINE.json configs[3] as written, on the MI355X: 154-frame sequences (ego motion of KITTI drive_0005) of the generator the
+bench times (csrc/synth.hip through synth_dev.py), 120 k-point frames — and one stream of configs[4]'s 200 k-point frames —
+through the fused device path, EVERY frame against the oracle (tests/seq_parity.py). Both timestamp units.
+Reference loop matched: OT/tracking/imm_ukf_jpda.cpp:812-961 (births :972-989), ego fixture OT0/src/imm_ukf_jpda.cpp:65-72."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def _run(*argv, timeout=900):
+    r = subprocess.run([sys.executable, os.path.join(HERE, "seq_parity_gpu_run.py"), *map(str, argv)], capture_output=True, text=True, timeout=timeout)
+    ok = [l for l in r.stdout.splitlines() if l.startswith("sequence parity ok ")]
+    assert r.returncode == 0 and ok, (r.stdout[-1500:], r.stderr[-3000:])
+    return json.loads(ok[-1][len("sequence parity ok "):])
+
+
+def test_154_frame_sequences_120k_points_every_frame_vs_oracle(hip_lib):
+    st = _run("--points", 120000, "--frames", 154, "--scenes", 0, 1001, "--units", 1e5, 0.1)
+    assert st["frames"] == 154 and st["streams"] == 2 and st["points_per_frame"] > 100000
+    assert st["max_rel_state_err"] <= 1e-4
+
+
+def test_154_frame_sequence_200k_points_every_frame_vs_oracle(hip_lib):
+    st = _run("--points", 200000, "--frames", 154, "--scenes", 7, "--units", 1e5)
+    assert st["frames"] == 154 and st["points_per_frame"] > 150000 and st["max_rel_state_err"] <= 1e-4
+
+
+def test_sequence_kitti_preset(hip_lib):
+    """preset 1 (object_tracking0's KITTI constants: 200-cell grid, no dilation, L-shape rule without the side test), 40 frames"""
+    st = _run("--points", 120000, "--frames", 40, "--scenes", 3, "--units", 1e5, "--preset", 1)
+    assert st["frames"] == 40

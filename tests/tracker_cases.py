@@ -1,0 +1,91 @@
+"""Tracker load cases shared by the emulator test (tests/test_emu_tracker_load.py, CPU) and the MI355X test
+(tests/test_tracker_gpu.py): bodies only; the callers supply the library and how a numpy array becomes a device buffer.
+TEST INFRASTRUCTURE (compares with the oracle)."""
+import numpy as np
+
+import seq_parity as SP
+
+
+def grid_boxes(streams, T, f, vel, rng, spacing):
+    """`T` boxes per stream on a sqrt(T) x sqrt(T) lattice `spacing` metres apart, drifting with `vel` (bench.py tracker_stress's
+    generator): spacing 9 m keeps every gate to itself; 2 m makes neighbouring tracks share gated boxes — the cross-track
+    matchingVec bookkeeping of imm_ukf_jpda.cpp:232 at the size BASELINE.json configs[3] names (<= 64 tracks)"""
+    side = int(np.ceil(np.sqrt(T)))
+    centres = np.stack(np.meshgrid(np.arange(side), np.arange(side)), -1).reshape(-1, 2)[:T] * spacing - side * spacing / 2
+    ctr = centres[None] + vel * (0.1 * f) + rng.normal(0, 0.02, size=(streams, T, 2))
+    bx = np.zeros((streams, T, 8, 3), np.float32)
+    w, l = (3.8, 1.7) if spacing >= 6 else (1.2, 0.8)
+    bx[..., :2] = ctr[:, :, None, :] + np.array([[0, 0], [w, 0], [w, l], [0, l]] * 2)[None, None]
+    bx[:, :, :4, 2] = -2.0; bx[:, :, 4:, 2] = -0.4
+    return bx
+
+
+def many_live_tracks(mot, oracle, to_dev, lib_path=None, streams=3, T=64, frames=30, spacing=9.0, seed=11, min_live=64):
+    """mot_track_steps_dev (every stream at once, boxes on the device) against the oracle with `T` simultaneously live tracks
+    per stream: every frame, every stream, discrete outputs exact and every state key <= 1e-4"""
+    rng = np.random.default_rng(seed)
+    vel = rng.uniform(-1.0, 1.0, size=(streams, T, 2))
+    p = oracle.params(0)
+    kw = dict(lib_path=lib_path) if lib_path else {}
+    stats = {}
+    with mot.Context(max_points=1024, max_batch=streams, max_tracks_total=1024, **kw) as c:
+        Ts = [oracle.Tracker(p) for _ in range(streams)]
+        stride = T * 24
+        live = [0] * streams
+        for f in range(frames):
+            ts = 1.0e9 + f * 1e5
+            bx = grid_boxes(streams, T, f, vel, rng, spacing)
+            ptr, free = to_dev(bx.reshape(streams, stride))
+            for s in range(streams):
+                a_ego = c.ego_update(ts, 0.0, 0.0, s); o_ego = Ts[s].ego_update(ts, 0.0, 0.0)
+                assert np.array_equal(a_ego, o_ego)
+            c.track_steps_dev(ptr, stride, [T] * streams, [ts] * streams)
+            for s in range(streams):
+                a = c.get_tracks(s); o = Ts[s].step(bx[s], ts, max_tracks=1024)
+                SP.compare_tracks(a, o, lambda i: c.track_state(i, slot=s), Ts[s].state, (f, s), stats=stats, skip_ill_conditioned=spacing < 6)
+                live[s] = int((o["track_manage"] > 0).sum())
+            free()
+        for T_ in Ts:
+            T_.close()
+    assert min(live) >= min_live, live
+    stats["live_last"] = live
+    return stats
+
+
+def angle_far_beyond_32_turns(mot, oracle, lib_path=None):
+    """The one documented deviation from the reference (csrc/track.hip wrap_pi): up to 32 turns the normalisation loop runs as
+    written, beyond it whole turns come off in one step. Two ways past 32 turns: (a) an ego yaw of hundreds of radians — the
+    output yaw is wrap(x_merge(3) + egoYaw), OT/tracking/imm_ukf_jpda.cpp:1010 — and (b) a time step of thousands of seconds,
+    which carries every CTRV sigma point yaw + yawd * dt round and round (ukf.cpp:539-571). The oracle keeps the reference's
+    loops (oracle/mot_oracle_track.c). Discrete outputs must stay equal on every frame; the yaw outputs agree to 1e-9."""
+    import test_emu_tracker_random as TR
+    p = oracle.params(0)
+    kw = dict(lib_path=lib_path) if lib_path else {}
+    rng = np.random.default_rng(5)
+    n_obj = 6
+    pos = rng.uniform(-20, 20, (n_obj, 2)); vel = rng.uniform(-1.5, 1.5, (n_obj, 2)); yaw = rng.uniform(-3, 3, n_obj)
+    hit_ego = hit_dt = False
+    with mot.Context(max_points=1024, max_tracks_total=512, **kw) as c:
+        T = oracle.Tracker(p)
+        ts = 1.0e9
+        for f in range(34):
+            jump = f in (16, 25)
+            ts += 6.0e9 if jump else 1.0e5                      # (b): dt = 6000 s on two frames
+            ego_yaw = 0.01 * f + (900.0 if f >= 8 else 0.0)     # (a): 143 turns from frame 8 on
+            boxes = np.array([TR.box(*(pos[o] + vel[o] * 0.1 * f), 1.8, 4.2, yaw[o] + 0.02 * f, -0.3) for o in range(n_obj)], np.float32)
+            a_ego = c.ego_update(ts, 3.0, ego_yaw); o_ego = T.ego_update(ts, 3.0, ego_yaw)
+            assert np.allclose(a_ego, o_ego, rtol=1e-12, atol=1e-9)
+            pre = [T.state(i) for i in range(c.get_tracks(0)["n"])] if jump else []   # states the 6000 s prediction starts from
+            a = c.track_step(boxes, ts); o = T.step(boxes, ts)
+            assert a["n"] == o["n"], f
+            for k in ("track_manage", "is_static", "is_vis", "lifetime"):
+                assert np.array_equal(a[k], o[k]), (f, k)
+            livei = np.nonzero(o["track_manage"] > 0)[0]
+            fin = np.isfinite(o["v_yaw"][livei, 1])
+            assert np.allclose(a["v_yaw"][livei, 1][fin], o["v_yaw"][livei, 1][fin], rtol=0, atol=1e-9), f
+            if f >= 8 and len(livei):
+                hit_ego = True
+            if jump:
+                hit_dt |= any(s["track_manage"] > 0 and abs(s["x_ctrv"][4]) * 6000.0 > 64 * np.pi for s in pre)
+        T.close()
+    assert hit_ego and hit_dt
