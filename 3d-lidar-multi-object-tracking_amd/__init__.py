@@ -74,9 +74,10 @@ EXPORTS = (
     "mot_get_boxes", "mot_get_tracks", "mot_export_tracks_dev", "mot_side_params_default", "mot_cluster_products", "mot_cluster_products_host", "mot_decode_pointcloud2_dev", "mot_time_stage",
     "mot_ground_remove_pointcloud2", "mot_box_fit_resident", "mot_frame_pointcloud2",
     "mot_reset_slot", "mot_frames_host", "mot_wait_uploads", "mot_host_alloc", "mot_host_free", "mot_fetch_tracks_async",
-    "mot_track_steps_dev", "mot_profile_kernel", "mot_profile_read", "mot_get_params",
+    "mot_track_steps_dev", "mot_profile_kernel", "mot_profile_read", "mot_get_params", "mot_set_fused_outputs", "mot_reset_tracks_slot",
 )
-ABI_VERSION = 2
+ABI_VERSION = 3
+OUT_GROUND, OUT_MASK = 1, 2
 
 _libs: dict[str, C.CDLL] = {}
 
@@ -176,6 +177,22 @@ class Context:
     def reset_slot(self, slot: int):
         self._ck(self.lib.mot_reset_slot(self._h, slot))
 
+    def reset_tracks_slot(self, slot: int):
+        """forget the tracks of one stream, keep its ego pose (the origin of its global frame)"""
+        self._ck(self.lib.mot_reset_tracks_slot(self._h, slot))
+
+    def set_fused_outputs(self, flags: int):
+        """which by-products of the ground stage the fused entry points write (OUT_GROUND | OUT_MASK; default 0: on demand)"""
+        self._ck(self.lib.mot_set_fused_outputs(self._h, flags))
+
+    def _ck_tracks(self, rc, n, cap):
+        """mot_get_tracks / mot_track_step deliver the records AND report MOT_E_CAPACITY once a stream has used up max_tracks_total
+        (sticky until reset): a soft condition here — the records are returned, `capacity_exceeded` says so"""
+        if rc == MOT_E_CAPACITY and n <= cap:
+            return True
+        self._ck(rc)
+        return False
+
     # ------------------------------------------------------------------ stage calls, host buffers
     def ground_remove(self, xyzw, want_mask: bool = True):
         """groundRemove(cloud, elevatedCloud, groundCloud) — OT/include/ground_removal.h:62-64"""
@@ -241,8 +258,9 @@ class Context:
         b = np.ascontiguousarray(boxes_global, np.float32).reshape(-1, 8, 3)
         max_tracks = max_tracks or self.max_tracks_total
         arr = (MotTrack * max_tracks)(); nt = C.c_int(0)
-        self._ck(self.lib.mot_track_step(self._h, slot, _vp(b), len(b), C.c_double(timestamp), arr, max_tracks, C.byref(nt)))
-        return tracks_to_dict(arr, nt.value)
+        full = self._ck_tracks(self.lib.mot_track_step(self._h, slot, _vp(b), len(b), C.c_double(timestamp), arr, max_tracks, C.byref(nt)), nt.value, max_tracks)
+        out = tracks_to_dict(arr, nt.value); out["capacity_exceeded"] = full
+        return out
 
     def track_state(self, track_id: int, slot: int = 0):
         s = MotTrackState()
@@ -317,8 +335,9 @@ class Context:
     def get_tracks(self, slot: int = 0, max_tracks: int | None = None):
         max_tracks = max_tracks or self.max_tracks_total
         arr = (MotTrack * max_tracks)(); nt = C.c_int(0)
-        self._ck(self.lib.mot_get_tracks(self._h, slot, arr, max_tracks, C.byref(nt)))
-        return tracks_to_dict(arr, nt.value)
+        full = self._ck_tracks(self.lib.mot_get_tracks(self._h, slot, arr, max_tracks, C.byref(nt)), nt.value, max_tracks)
+        out = tracks_to_dict(arr, nt.value); out["capacity_exceeded"] = full
+        return out
 
     def frames_host(self, h_ptr: int, frame_stride_floats: int, n_points, run_tracker: bool = False,
                     timestamps=None, ego_v=None, ego_yaw=None):

@@ -129,10 +129,20 @@ label_stats_kernel(MotDevParams p, ClusterBuffers c) {
     long i = base + k * kLabelBlock + threadIdx.x;
     qs[k] = i < n ? pts[i] : make_float4(1.0e9f, 1.0e9f, 0.f, 0.f);   // outside every ROI
   }
+  if (c.ecell) {   // fused path: the compaction kernel filed every elevated point under this cell already and left it behind, 2 bytes per point
+    const unsigned short* __restrict__ ecell = c.ecell + (long)b * c.cap;
 #pragma unroll
-  for (int k = 0; k < kLabelItems; k++) {
-    const int bit = mot_cart_bit(p, qs[k].x, qs[k].y);   // guarded fast cell (two IEEE divides per point otherwise), exact fallback
-    labs[k] = bit >= 0 ? (bit >> 8) * p.num_grid + (bit & 255) : -1;
+    for (int k = 0; k < kLabelItems; k++) {
+      long i = base + k * kLabelBlock + threadIdx.x;
+      const unsigned e = i < n ? (unsigned)ecell[i] : 0xffffu;
+      labs[k] = e != 0xffffu ? (int)((e >> 8) * (unsigned)p.num_grid + (e & 255u)) : -1;
+    }
+  } else {
+#pragma unroll
+    for (int k = 0; k < kLabelItems; k++) {
+      const int bit = mot_cart_bit(p, qs[k].x, qs[k].y);   // guarded fast cell (two IEEE divides per point otherwise), exact fallback
+      labs[k] = bit >= 0 ? (bit >> 8) * p.num_grid + (bit & 255) : -1;
+    }
   }
 #pragma unroll
   for (int k = 0; k < kLabelItems; k++) labs[k] = labs[k] >= 0 ? grid[labs[k]] : 0;

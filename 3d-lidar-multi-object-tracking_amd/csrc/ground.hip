@@ -316,8 +316,11 @@ polar_filter_kernel(MotDevParams p, GroundBuffers g) {
 
 // ------------------------------------------------------------------------------------------ K3
 // per-point classification (ground_removal.cpp:221-247) + order-preserving compaction
-__global__ void MOT_LAUNCH_BOUNDS(kCompactBlock)
-classify_compact_kernel(MotDevParams p, GroundBuffers g) {
+// kGround = false: the fused path's default — the ground cloud is not materialised (nothing downstream of groundRemove reads it:
+// OT0/src/main.cpp:63-79 drops groundCloud after the call; mot_get_ground re-runs this kernel with kGround = true when a caller
+// asks for it): 16 N_g fewer bytes written per frame, a quarter of this kernel's traffic on a street scene.
+template <bool kGround>
+__device__ __forceinline__ void classify_compact_body(const MotDevParams& p, const GroundBuffers& g) {
   __shared__ int s_chunk;
   __shared__ int s_cnt[kSubTiles];  // per 64-point tile counts (elevated << 16 | ground) -> exclusive prefixes
   __shared__ int s_base_e, s_base_g;
@@ -390,20 +393,22 @@ classify_compact_kernel(MotDevParams p, GroundBuffers g) {
     const unsigned long long be = __ballot(c == MOT_MASK_ELEVATED);
     const unsigned long long bg = __ballot(c == MOT_MASK_GROUND);
     if (be) wave_has_elevated |= 1u << k;
-    rank[k] = __popcll((c == MOT_MASK_ELEVATED ? be : bg) & below);
+    rank[k] = __popcll((kGround ? (c == MOT_MASK_ELEVATED ? be : bg) : be) & below);
     if (lane == 0) s_cnt[k * (kCompactBlock / 64) + wave] = (__popcll(be) << 16) | __popcll(bg);   // tile order inside the chunk: k-major, then wave
   }
   uint8_t* __restrict__ mask = g.mask ? g.mask + (long)b * g.cap : nullptr;
+  int bits[kCompactItems];   // Cartesian cell (xI * 256 + yI) of my elevated points, -1 otherwise / outside the ROI
   // Work that does not need the output positions — the occupancy of the cluster stage's grid and the per-point mask — is done
   // by waves 1..7 WHILE wave 0 runs the look-back (the other waves used to idle at the barrier for its 2-4 us of agent-scope
   // round trips: profiles/r02_ablate_k3.txt), and by wave 0 after the stores have been issued.
-  auto side_work = [&]() {
+  auto cart_cells = [&]() {
+#pragma unroll
+    for (int k = 0; k < kCompactItems; k++) bits[k] = -1;
     if (occupancy && wave_has_elevated) {
       // mapCartesianGrid's histogram (component_clustering.cpp:36-50) for the elevated points, from registers: this is what
       // cart_occupancy_kernel did with a second pass over the elevated cloud (16 N_e bytes and a launch per batch).
       // Guarded fast cell first; the few undecided points go through ONE copy of the exact evaluation. Items without an
       // elevated point in this wave (half of them: ground dominates) are skipped as a whole.
-      int bits[kCompactItems];
       unsigned undecided = 0;
 #pragma unroll
       for (int k = 0; k < kCompactItems; k++) {
@@ -423,6 +428,10 @@ classify_compact_kernel(MotDevParams p, GroundBuffers g) {
 #pragma unroll
         for (int kk = 0; kk < kCompactItems; kk++) bits[kk] = kk == k ? r : bits[kk];
       }
+    }
+  };
+  auto side_work = [&]() {
+    if (occupancy && wave_has_elevated) {
       // Neighbouring lanes are neighbouring returns of one beam: a car side or a wall puts runs of lanes into the SAME cell, and
       // LDS atomics on one address serialise lane by lane (the straightforward per-point atomicOr cost 14 us of the kernel's
       // 104: profiles/r02_ablate_k3.txt). Only the first lane of a run of equal cells touches LDS; a run of two or more is
@@ -503,18 +512,26 @@ classify_compact_kernel(MotDevParams p, GroundBuffers g) {
       }
     }
   }
-  else side_work();
+  else { cart_cells(); side_work(); }
   __syncthreads();
+  if (wave == 0) cart_cells();
   float4* __restrict__ out_e = g.elevated + (long)b * g.cap;
-  float4* __restrict__ out_g = g.ground + (long)b * g.cap;
+  float4* __restrict__ out_g = kGround ? g.ground + (long)b * g.cap : nullptr;
+  unsigned short* __restrict__ ecell = (g.ecell && occupancy) ? g.ecell + (long)b * g.cap : nullptr;   // (the cells exist only with the occupancy)
   const int be0 = s_base_e, bg0 = s_base_g;
 #pragma unroll
   for (int k = 0; k < kCompactItems; k++) {
     const int ex = s_cnt[k * (kCompactBlock / 64) + wave];   // the tile's exclusive prefixes (wave-uniform)
     const bool is_e = cls[k] == MOT_MASK_ELEVATED;
-    float4* __restrict__ dst = is_e ? out_e : out_g;
-    const int at = (is_e ? be0 + (ex >> 16) : bg0 + (ex & 0xffff)) + rank[k];
-    if (cls[k] != MOT_MASK_DROPPED) dst[at] = pt[k];
+    if (kGround) {
+      float4* __restrict__ dst = is_e ? out_e : out_g;
+      const int at = (is_e ? be0 + (ex >> 16) : bg0 + (ex & 0xffff)) + rank[k];
+      if (cls[k] != MOT_MASK_DROPPED) dst[at] = pt[k];
+      if (ecell && is_e) ecell[at] = (unsigned short)bits[k];
+    } else {
+      const int at = be0 + (ex >> 16) + rank[k];
+      if (is_e) { out_e[at] = pt[k]; if (ecell) ecell[at] = (unsigned short)bits[k]; }
+    }
   }
   if (wave == 0) side_work();
   if (occupancy) {
@@ -535,6 +552,10 @@ classify_compact_kernel(MotDevParams p, GroundBuffers g) {
     if (threadIdx.x == 0) g.occ_count[(long)b * g.occ_chunks + chunk] = s_occ_n;
   }
 }
+__global__ void MOT_LAUNCH_BOUNDS(kCompactBlock)
+classify_compact_kernel(MotDevParams p, GroundBuffers g) { classify_compact_body<true>(p, g); }
+__global__ void MOT_LAUNCH_BOUNDS(kCompactBlock)
+classify_compact_elevated_kernel(MotDevParams p, GroundBuffers g) { classify_compact_body<false>(p, g); }
 
 // ------------------------------------------------------------------------------------------ input decode
 // PointCloud2 records -> float4 (include/mot.h, mot_decode_pointcloud2_dev). HBM-bound gather: point_step bytes read,
@@ -568,7 +589,10 @@ void mot_launch_ground_kernel(int which, const MotDevParams& p, const GroundBuff
   if (cchunks < 1) cchunks = 1;
   if (which == 0) hipLaunchKernelGGL(polar_minz_kernel, dim3(chunks, batch), dim3(kGroundBlock), 0, stream, p, g);
   else if (which == 1) hipLaunchKernelGGL(polar_filter_kernel, dim3(batch), dim3(kFilterBlock), 0, stream, p, g);
-  else if (which == 2) hipLaunchKernelGGL(classify_compact_kernel, dim3(cchunks, batch), dim3(kCompactBlock), 0, stream, p, g);
+  else if (which == 2) {
+    if (g.ground) hipLaunchKernelGGL(classify_compact_kernel, dim3(cchunks, batch), dim3(kCompactBlock), 0, stream, p, g);
+    else hipLaunchKernelGGL(classify_compact_elevated_kernel, dim3(cchunks, batch), dim3(kCompactBlock), 0, stream, p, g);   // ground cloud on demand
+  }
 }
 
 void mot_launch_ground(const MotDevParams& p, const GroundBuffers& g, int batch, int max_n, hipStream_t stream) {

@@ -86,16 +86,30 @@ struct mot_ctx {
   int* d_nitems = nullptr;
   struct SlotEgo {  // file-scope globals of OT/tracking/imm_ukf_jpda.cpp:19-24,56-70, one set per stream
     bool init = false, ego_called = false;
+    bool tracks_restart = false;   // mot_reset_tracks_slot: the next tracker step seeds anew, the ego history stays
     double timestamp = 0, egoVelo = 0, egoYaw = 0, egoPreYaw = 0;
     double rx = 0, ry = 0, ryaw = -M_PI / 2;   // running result of the ego-history replay (:137-151)
     double egoPoint[3] = {0, 0, 0};
     int nt = 0;
   };
   std::vector<SlotEgo> ego;
-  std::vector<TrackFrameArgs> h_targs;
-  std::vector<EgoTf> h_ego;
+  // Per-batch launch arguments — points per frame, tracker arguments, sensor -> global matrices — live in ONE device block
+  // (d_n, d_targs and d_ego point into it) and travel in ONE stream-ordered H2D copy at the head of a launch sequence, from a ring
+  // of page-locked staging blocks: no pageable copy (the runtime stages those through its own buffer and may hold the calling
+  // thread), and nothing between the box stage's last kernel and the tracker's first.
+  static constexpr int kArgRing = 16;
+  char* d_argblk = nullptr;
+  char* h_argring = nullptr;           // pinned, kArgRing blocks of arg_bytes
+  size_t arg_bytes = 0, arg_off_targs = 0, arg_off_ego = 0;
+  hipEvent_t arg_ev[kArgRing] = {};
+  bool arg_used[kArgRing] = {};
+  int arg_next = 0;
   // host mirrors
   std::vector<int> h_n;
+  unsigned short* d_ecell = nullptr;   // Cartesian cell of every elevated point (fused path: compaction kernel -> label kernel)
+  int fused_outputs = 0;               // MOT_OUT_* the fused entry points materialise besides what the next stage needs
+  bool ground_resident = false;        // d_ground / d_mask hold the last batch's ground cloud and mask
+  bool last_fused = false;             // the last ground launch was a fused one (input, cells and thresholds of the batch still resident)
   int* h_counts = nullptr;  // pinned [batch][4]
   int last_batch = 0, last_max_n = 0;
   const float4* last_in = nullptr;
@@ -103,6 +117,7 @@ struct mot_ctx {
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   // pipelined host ingest (mot_frames_host): a copy stream and two staging copies of the input batch
   hipStream_t copy_stream = nullptr;
+  bool copy_ready = false;             // copy stream, staging buffers and events all exist
   float4* d_stage[2] = {nullptr, nullptr};
   hipEvent_t ev_copied[2] = {nullptr, nullptr};    // H2D of stage[i] complete (copy stream)
   hipEvent_t ev_consumed[2] = {nullptr, nullptr};  // last kernel reading stage[i] launched and done (compute stream)
@@ -242,9 +257,11 @@ extern "C" void mot_destroy(mot_ctx* c) {
   if (c->d_fetch_counts) (void)hipFree(c->d_fetch_counts);
   if (c->prof_created)
     for (int i = 0; i < mot_ctx::kProfRing; i++) { (void)hipEventDestroy(c->prof_ev[i][0]); (void)hipEventDestroy(c->prof_ev[i][1]); }
-  void* bufs[] = {c->d_in, c->d_n, c->d_pairs, c->d_pair_count, c->d_hg, c->d_cell, c->d_desc, c->d_ticket, c->d_elev, c->d_ground, c->d_mask, c->d_counts,
+  for (int i = 0; i < mot_ctx::kArgRing; i++) if (c->arg_ev[i]) (void)hipEventDestroy(c->arg_ev[i]);
+  if (c->h_argring) (void)hipHostFree(c->h_argring);
+  void* bufs[] = {c->d_in, c->d_argblk, c->d_ecell, c->d_pairs, c->d_pair_count, c->d_hg, c->d_cell, c->d_desc, c->d_ticket, c->d_elev, c->d_ground, c->d_mask, c->d_counts,
                   c->d_plane_a, c->d_plane_b, c->d_ccl_parent, c->d_occ_list, c->d_occ_count, c->d_grid, c->d_label, c->d_stats, c->d_cand, c->d_boxes, c->d_box_cluster, c->d_rng, c->d_poly, c->d_groups, c->d_cluster_start, c->d_order, c->d_sorted, c->d_pix, c->d_wgtab, c->d_side_cell, c->d_side_cloud, c->d_side_obs, c->d_side_cost, c->d_side_counts, c->d_raw,
-                  c->d_tracks, c->d_nt, c->d_tboxes, c->d_targs, c->d_gate, c->d_prog, c->d_live, c->d_tout, c->d_tflags, c->d_ego, c->d_nlive, c->d_pos, c->d_cp, c->d_items, c->d_nitems};
+                  c->d_tracks, c->d_nt, c->d_tboxes, c->d_gate, c->d_prog, c->d_live, c->d_tout, c->d_tflags, c->d_nlive, c->d_pos, c->d_cp, c->d_items, c->d_nitems};
   for (void* b : bufs) if (b) (void)hipFree(b);
   if (c->h_counts) (void)hipHostFree(c->h_counts);
   if (c->ev0) (void)hipEventDestroy(c->ev0);
@@ -254,7 +271,27 @@ extern "C" void mot_destroy(mot_ctx* c) {
 }
 
 static TrackBuffers track_buffers(mot_ctx* c, bool fused);
-static void prepare_track_args(mot_ctx* c, int slot, int m, double timestamp, bool run);
+static void prepare_track_args(mot_ctx* c, TrackFrameArgs* targs, int slot, int m, double timestamp, bool run);
+
+// The next staging block of the argument ring. The host waits here only when the copy queued from this block kArgRing launch
+// sequences ago has not executed yet, i.e. when it is that far ahead of the GPU.
+static int arg_block_acquire(mot_ctx* c, char** blk) {
+  const int i = c->arg_next;
+  if (c->arg_used[i]) MOT_HIP(c, hipEventSynchronize(c->arg_ev[i]));
+  *blk = c->h_argring + (size_t)i * c->arg_bytes;
+  return MOT_OK;
+}
+// queues the copy of bytes [off, off + bytes) of the acquired block into the device block (stream-ordered: behind every kernel of
+// the previous launch sequence that still reads the old values) and moves the ring on
+static int arg_block_commit(mot_ctx* c, size_t off, size_t bytes) {
+  const int i = c->arg_next;
+  const char* blk = c->h_argring + (size_t)i * c->arg_bytes;
+  MOT_HIP(c, hipMemcpyAsync(c->d_argblk + off, blk + off, bytes, hipMemcpyHostToDevice, c->stream));
+  MOT_HIP(c, hipEventRecord(c->arg_ev[i], c->stream));
+  c->arg_used[i] = true;
+  c->arg_next = (i + 1) % mot_ctx::kArgRing;
+  return MOT_OK;
+}
 
 static ClusterBuffers cluster_buffers(mot_ctx* c) {
   ClusterBuffers b;
@@ -263,6 +300,7 @@ static ClusterBuffers cluster_buffers(mot_ctx* c) {
   b.grid = c->d_grid; b.label = c->d_label; b.stats = c->d_stats; b.cand = c->d_cand; b.boxes = c->d_boxes;
   b.box_cluster = c->d_box_cluster; b.rng = c->d_rng; b.poly = c->d_poly; b.groups = c->d_groups; b.group_cap = c->cap / 2; b.cluster_start = c->d_cluster_start; b.order = c->d_order; b.sorted = c->d_sorted;
   b.pix = c->d_pix; b.wgtab = c->d_wgtab; b.max_wg = c->max_wg;
+  b.ecell = nullptr;   // stage-wise: the label kernel computes the cells itself
   return b;
 }
 
@@ -285,7 +323,21 @@ static int create_impl(mot_ctx* c) {
   const size_t B = c->batch, N = c->cap;
   c->max_chunks = (int)((N + kGroundChunk - 1) / kGroundChunk) + 1;
   MOT_HIP(c, hipMalloc(&c->d_in, B * N * sizeof(float4)));
-  MOT_HIP(c, hipMalloc(&c->d_n, B * sizeof(int)));
+  {  // the argument block and its staging ring
+    auto up = [](size_t v) { return (v + 255) & ~(size_t)255; };
+    c->arg_off_targs = up(B * sizeof(int));
+    c->arg_off_ego = up(c->arg_off_targs + B * sizeof(TrackFrameArgs));
+    c->arg_bytes = up(c->arg_off_ego + B * sizeof(EgoTf));
+    MOT_HIP(c, hipMalloc(&c->d_argblk, c->arg_bytes));
+    MOT_HIP(c, hipMemsetAsync(c->d_argblk, 0, c->arg_bytes, c->stream));
+    MOT_HIP(c, hipHostMalloc(&c->h_argring, c->arg_bytes * mot_ctx::kArgRing, hipHostMallocDefault));
+    memset(c->h_argring, 0, c->arg_bytes * mot_ctx::kArgRing);
+    for (int i = 0; i < mot_ctx::kArgRing; i++) MOT_HIP(c, hipEventCreateWithFlags(&c->arg_ev[i], hipEventDisableTiming));
+    c->d_n = reinterpret_cast<int*>(c->d_argblk);
+    c->d_targs = reinterpret_cast<TrackFrameArgs*>(c->d_argblk + c->arg_off_targs);
+    c->d_ego = reinterpret_cast<EgoTf*>(c->d_argblk + c->arg_off_ego);
+  }
+  MOT_HIP(c, hipMalloc(&c->d_ecell, B * N * sizeof(unsigned short)));
   MOT_HIP(c, hipMalloc(&c->d_pairs, B * c->max_chunks * kGroundChunk * sizeof(uint2)));
   MOT_HIP(c, hipMalloc(&c->d_pair_count, B * c->max_chunks * sizeof(int)));
   MOT_HIP(c, hipMalloc(&c->d_hg, B * MOT_POLAR_CELLS * sizeof(float)));
@@ -338,13 +390,11 @@ static int create_impl(mot_ctx* c) {
   MOT_HIP(c, hipMalloc(&c->d_tracks, B * T * sizeof(DevTrack)));
   MOT_HIP(c, hipMalloc(&c->d_nt, B * sizeof(int)));
   MOT_HIP(c, hipMalloc(&c->d_tboxes, B * kMaxBoxesPerFrame * 24 * sizeof(float)));
-  MOT_HIP(c, hipMalloc(&c->d_targs, B * sizeof(TrackFrameArgs)));
   MOT_HIP(c, hipMalloc(&c->d_gate, B * T * kGateWords * sizeof(unsigned long long)));
   MOT_HIP(c, hipMalloc(&c->d_prog, B * T * kGateWords * sizeof(unsigned long long)));
   MOT_HIP(c, hipMalloc(&c->d_live, B * 2 * T * sizeof(int)));
   MOT_HIP(c, hipMalloc(&c->d_tout, B * T * sizeof(mot_track)));
   MOT_HIP(c, hipMalloc(&c->d_tflags, B * sizeof(int)));
-  MOT_HIP(c, hipMalloc(&c->d_ego, B * sizeof(EgoTf)));
   MOT_HIP(c, hipMalloc(&c->d_nlive, B * sizeof(int)));
   MOT_HIP(c, hipMalloc(&c->d_pos, B * T * sizeof(Vec2d)));
   MOT_HIP(c, hipMalloc(&c->d_cp, B * kMaxBoxesPerFrame * sizeof(Vec2d)));
@@ -355,11 +405,8 @@ static int create_impl(mot_ctx* c) {
   MOT_HIP(c, hipMemsetAsync(c->d_nt, 0, B * sizeof(int), c->stream));
   MOT_HIP(c, hipMemsetAsync(c->d_tflags, 0, B * sizeof(int), c->stream));
   c->ego.assign(B, mot_ctx::SlotEgo());
-  c->h_targs.assign(B, TrackFrameArgs());
-  c->h_ego.assign(B, EgoTf());
   MOT_HIP(c, hipMemsetAsync(c->d_pair_count, 0, B * c->max_chunks * sizeof(int), c->stream));
   MOT_HIP(c, hipMemsetAsync(c->d_counts, 0, B * kCountsStride * sizeof(int), c->stream));
-  MOT_HIP(c, hipMemsetAsync(c->d_n, 0, B * sizeof(int), c->stream));
   MOT_HIP(c, hipMemsetAsync(c->d_ticket, 0, B * sizeof(int), c->stream));
   MOT_HIP(c, hipMemsetAsync(c->d_desc, 0, B * c->max_chunks * sizeof(unsigned long long), c->stream));
   MOT_HIP(c, hipStreamSynchronize(c->stream));
@@ -433,11 +480,13 @@ static GroundBuffers ground_buffers(mot_ctx* c, const float4* in, long stride, b
   g.ticket = c->d_ticket; g.elevated = c->d_elev; g.ground = c->d_ground; g.mask = want_mask ? c->d_mask : nullptr;
   g.counts = c->d_counts; g.cap = c->cap; g.max_chunks = c->max_chunks;
   g.occ_list = planes ? c->d_occ_list : nullptr; g.occ_count = planes ? c->d_occ_count : nullptr; g.occ_chunks = c->occ_chunks;
+  g.ecell = (planes && c->params.num_grid < MOT_MAX_GRID) ? c->d_ecell : nullptr;   // (a 256-cell grid uses all 65536 codes: no "outside" left)
   return g;
 }
 
-// uploads n[] and remembers the launch geometry
-static int set_batch(mot_ctx* c, const int* n_points, int batch, const float4* in, long stride) {
+// validates n[], remembers the launch geometry and (stage-wise entry points: upload = true) sends n[] to the device; the fused
+// path sends it with the rest of its arguments (launch_frames)
+static int set_batch(mot_ctx* c, const int* n_points, int batch, const float4* in, long stride, bool upload = true) {
   if (batch < 1 || batch > c->batch) return fail(c, MOT_E_ARG, "batch out of range");
   int max_n = 0;
   for (int b = 0; b < batch; b++) {
@@ -447,7 +496,12 @@ static int set_batch(mot_ctx* c, const int* n_points, int batch, const float4* i
   }
   if (stride < max_n && batch > 1) return fail(c, MOT_E_ARG, "frame_stride is smaller than a frame");
   for (int b = 0; b < batch; b++) c->h_n[b] = n_points[b];
-  MOT_HIP(c, hipMemcpyAsync(c->d_n, c->h_n.data(), batch * sizeof(int), hipMemcpyHostToDevice, c->stream));
+  if (upload) {
+    char* blk; int rc;
+    if ((rc = arg_block_acquire(c, &blk))) return rc;
+    memcpy(blk, c->h_n.data(), batch * sizeof(int));
+    if ((rc = arg_block_commit(c, 0, batch * sizeof(int)))) return rc;
+  }
   c->last_batch = batch; c->last_max_n = max_n; c->last_in = in; c->last_in_stride = stride;
   return MOT_OK;
 }
@@ -545,30 +599,39 @@ static int launch_frames(mot_ctx* c, int batch, int run_tracker, const double* t
   int rc;
   if ((rc = next_epoch(c))) return rc;
   const int max_n = c->last_max_n;
-  GroundBuffers g = ground_buffers(c, c->last_in, c->last_in_stride, true, true);
+  {  // every per-batch argument in ONE copy at the head of the sequence: n[], and for the tracker the tracking node's per-frame
+     // host work (OT/tracking/main.cpp:72-166): ego pose, the tf chain's matrix, dt / first-frame flags
+    char* blk;
+    if ((rc = arg_block_acquire(c, &blk))) return rc;
+    memcpy(blk, c->h_n.data(), batch * sizeof(int));
+    TrackFrameArgs* targs = reinterpret_cast<TrackFrameArgs*>(blk + c->arg_off_targs);
+    EgoTf* ego = reinterpret_cast<EgoTf*>(blk + c->arg_off_ego);
+    for (int b = 0; b < c->batch; b++) targs[b].run = 0;
+    if (run_tracker)
+      for (int b = 0; b < batch; b++) {
+        if ((rc = mot_ego_update(c, b, timestamps[b], ego_v[b], ego_yaw[b], nullptr))) return rc;
+        tf_velodyne_to_global(c->ego[b].egoPoint[0], c->ego[b].egoPoint[1], c->ego[b].egoPoint[2], ego[b].m);
+        prepare_track_args(c, targs, b, 0, timestamps[b], true);
+      }
+    if ((rc = arg_block_commit(c, 0, run_tracker ? c->arg_bytes : batch * sizeof(int)))) return rc;
+  }
+  const bool want_ground = (c->fused_outputs & MOT_OUT_GROUND) != 0, want_mask = (c->fused_outputs & MOT_OUT_MASK) != 0;
+  GroundBuffers g = ground_buffers(c, c->last_in, c->last_in_stride, want_mask, true);
+  if (!want_ground) g.ground = nullptr;   // the ground cloud on demand (mot_get_ground re-runs the compaction)
+  c->ground_resident = want_ground && want_mask; c->last_fused = true;
   { ProfScope ps(c, kK1); mot_launch_ground_kernel(0, c->dp, g, batch, max_n, c->stream); }
   { ProfScope ps(c, kK2); mot_launch_ground_kernel(1, c->dp, g, batch, max_n, c->stream); }
   { ProfScope ps(c, kK3); mot_launch_ground_kernel(2, c->dp, g, batch, max_n, c->stream); }
   ClusterBuffers cb = cluster_buffers(c);
   cb.occ_list = c->d_occ_list; cb.occ_count = c->d_occ_count;   // the occupancy comes as the compaction kernel's per-chunk lists
+  cb.ecell = g.ecell;                                            // ... and every elevated point's cell with it
   { ProfScope ps(c, kC2); mot_launch_cluster(c->dp, cb, batch, max_n, c->stream, true); }
   { ProfScope ps(c, kB1); mot_launch_box_kernel(0, c->dp, cb, batch, max_n, c->stream); }
   { ProfScope ps(c, kB1b); mot_launch_box_kernel(4, c->dp, cb, batch, max_n, c->stream); }
   { ProfScope ps(c, kB2); mot_launch_box_kernel(1, c->dp, cb, batch, max_n, c->stream); }
   { ProfScope ps(c, kB2b); mot_launch_box_kernel(3, c->dp, cb, batch, max_n, c->stream); }
   { ProfScope ps(c, kB3); mot_launch_box_kernel(2, c->dp, cb, batch, max_n, c->stream); }
-  if (run_tracker) {
-    for (int b = 0; b < c->batch; b++) c->h_targs[b].run = 0;
-    for (int b = 0; b < batch; b++) {
-      // the tracking node's per-frame sequence (OT/tracking/main.cpp:72-166): ego pose, boxes -> global frame, tracker
-      if ((rc = mot_ego_update(c, b, timestamps[b], ego_v[b], ego_yaw[b], nullptr))) return rc;
-      tf_velodyne_to_global(c->ego[b].egoPoint[0], c->ego[b].egoPoint[1], c->ego[b].egoPoint[2], c->h_ego[b].m);
-      prepare_track_args(c, b, 0, timestamps[b], true);
-    }
-    MOT_HIP(c, hipMemcpyAsync(c->d_ego, c->h_ego.data(), batch * sizeof(EgoTf), hipMemcpyHostToDevice, c->stream));
-    MOT_HIP(c, hipMemcpyAsync(c->d_targs, c->h_targs.data(), c->batch * sizeof(TrackFrameArgs), hipMemcpyHostToDevice, c->stream));
-    { ProfScope ps(c, kT1); mot_launch_track(track_buffers(c, true), batch, c->stream); }
-  }
+  if (run_tracker) { ProfScope ps(c, kT1); mot_launch_track(track_buffers(c, true), batch, c->stream); }
   MOT_HIP(c, hipGetLastError());
   return MOT_OK;
 }
@@ -589,19 +652,22 @@ extern "C" int mot_frames_dev(mot_ctx* c, const float* d_xyzw, long frame_stride
   // every argument is checked before the first launch or state change
   int rc = check_frames_args(c, d_xyzw, frame_stride, n_points, batch, run_tracker, timestamps, ego_v, ego_yaw);
   if (rc) return rc;
-  if ((rc = set_batch(c, n_points, batch, (const float4*)d_xyzw, frame_stride / 4))) return rc;
+  if ((rc = set_batch(c, n_points, batch, (const float4*)d_xyzw, frame_stride / 4, false))) return rc;
   return launch_frames(c, batch, run_tracker, timestamps, ego_v, ego_yaw);
 }
 
 // ---------------------------------------------------------------------------------------- pipelined host ingest
 static int ensure_copy_path(mot_ctx* c) {
-  if (c->copy_stream) return MOT_OK;
-  MOT_HIP(c, hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking));
+  if (c->copy_ready) return MOT_OK;
+  // a failure half-way (two batch x cap x 16-byte staging buffers: out of memory is plausible) leaves what exists for mot_destroy
+  // and the path not ready: the next call tries again from where this one stopped
+  if (!c->copy_stream) MOT_HIP(c, hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking));
   for (int i = 0; i < 2; i++) {
-    MOT_HIP(c, hipMalloc(&c->d_stage[i], (size_t)c->batch * c->cap * sizeof(float4)));
-    MOT_HIP(c, hipEventCreateWithFlags(&c->ev_copied[i], hipEventDisableTiming));
-    MOT_HIP(c, hipEventCreateWithFlags(&c->ev_consumed[i], hipEventDisableTiming));
+    if (!c->d_stage[i]) MOT_HIP(c, hipMalloc(&c->d_stage[i], (size_t)c->batch * c->cap * sizeof(float4)));
+    if (!c->ev_copied[i]) MOT_HIP(c, hipEventCreateWithFlags(&c->ev_copied[i], hipEventDisableTiming));
+    if (!c->ev_consumed[i]) MOT_HIP(c, hipEventCreateWithFlags(&c->ev_consumed[i], hipEventDisableTiming));
   }
+  c->copy_ready = true;
   return MOT_OK;
 }
 
@@ -637,7 +703,7 @@ extern "C" int mot_frames_host(mot_ctx* c, const float* h_xyzw, long frame_strid
   }
   MOT_HIP(c, hipEventRecord(c->ev_copied[s], c->copy_stream));
   MOT_HIP(c, hipStreamWaitEvent(c->stream, c->ev_copied[s], 0));
-  if ((rc = set_batch(c, n_points, batch, c->d_stage[s], c->cap))) return rc;
+  if ((rc = set_batch(c, n_points, batch, c->d_stage[s], c->cap, false))) return rc;
   rc = launch_frames(c, batch, run_tracker, timestamps, ego_v, ego_yaw);
   // (recorded after the whole sequence: the input is last read by the compaction kernel, but mot_time_stage may re-read it)
   MOT_HIP(c, hipEventRecord(c->ev_consumed[s], c->stream));
@@ -742,9 +808,9 @@ extern "C" int mot_get_clusters(mot_ctx* c, int slot, int32_t* grid, int* num_cl
   if (rc) return rc;
   const int G = c->params.num_grid;
   if (num_cluster) *num_cluster = c->h_counts[slot * kCountsStride + kCntClusters];
-  if (grid) MOT_HIP(c, hipMemcpyAsync(grid, c->d_grid + (size_t)slot * MOT_MAX_GRID * MOT_MAX_GRID, (size_t)G * G * sizeof(int), hipMemcpyDeviceToHost, c->stream));
   int ne = c->h_counts[slot * kCountsStride + kCntElev];
-  if (point_label && ne > label_capacity) return fail(c, MOT_E_CAPACITY, "more elevated points than the caller's label buffer holds");
+  if (point_label && ne > label_capacity) return fail(c, MOT_E_CAPACITY, "more elevated points than the caller's label buffer holds");   // before any copy is queued: "nothing copied"
+  if (grid) MOT_HIP(c, hipMemcpyAsync(grid, c->d_grid + (size_t)slot * MOT_MAX_GRID * MOT_MAX_GRID, (size_t)G * G * sizeof(int), hipMemcpyDeviceToHost, c->stream));
   if (point_label && ne > 0) MOT_HIP(c, hipMemcpyAsync(point_label, c->d_label + (size_t)slot * c->cap, (size_t)ne * sizeof(int), hipMemcpyDeviceToHost, c->stream));
   MOT_HIP(c, hipStreamSynchronize(c->stream));
   return MOT_OK;
@@ -918,6 +984,18 @@ extern "C" int mot_get_ground(mot_ctx* c, int slot, float* elev, int* n_elev, fl
   if (n_ground) *n_ground = ng;
   if ((elev && ne > capacity_points) || (ground && ng > capacity_points) || (mask && c->h_n[slot] > capacity_points))
     return fail(c, MOT_E_CAPACITY, "more points resident than the caller's buffers hold (capacity_points)");
+  if ((ground || mask) && !c->ground_resident) {
+    // The fused path left the ground cloud / mask out (mot_set_fused_outputs): materialise them for the whole last batch by
+    // re-running the compaction with every output, from the batch's input, polar cells and thresholds — all still resident.
+    // (No occupancy this time: the cluster stage has consumed it. The elevated cloud and the counts are rewritten with the
+    // same values.)
+    if (!c->last_fused || !c->last_in || c->last_batch < 1) return fail(c, MOT_E_STATE, "mot_get_ground: no ground result resident");
+    if ((rc = next_epoch(c))) return rc;
+    GroundBuffers g = ground_buffers(c, c->last_in, c->last_in_stride, true, false);
+    mot_launch_ground_kernel(2, c->dp, g, c->last_batch, c->last_max_n, c->stream);
+    MOT_HIP(c, hipGetLastError());
+    c->ground_resident = true;
+  }
   if (elev && ne > 0) MOT_HIP(c, hipMemcpyAsync(elev, c->d_elev + (size_t)slot * c->cap, (size_t)ne * 16, hipMemcpyDeviceToHost, c->stream));
   if (ground && ng > 0) MOT_HIP(c, hipMemcpyAsync(ground, c->d_ground + (size_t)slot * c->cap, (size_t)ng * 16, hipMemcpyDeviceToHost, c->stream));
   if (mask && c->h_n[slot] > 0) MOT_HIP(c, hipMemcpyAsync(mask, c->d_mask + (size_t)slot * c->cap, (size_t)c->h_n[slot], hipMemcpyDeviceToHost, c->stream));
@@ -938,6 +1016,7 @@ extern "C" int mot_ground_remove(mot_ctx* c, const float* xyzw, int n, float* el
   GroundBuffers g = ground_buffers(c, c->d_in, c->cap, true);
   mot_launch_ground(c->dp, g, 1, n, c->stream);
   MOT_HIP(c, hipGetLastError());
+  c->ground_resident = true; c->last_fused = false;
   return mot_get_ground(c, 0, elev, n_elev, ground, n_ground, mask, n);
 }
 
@@ -975,6 +1054,7 @@ extern "C" int mot_ground_remove_pointcloud2(mot_ctx* c, const void* data, int n
   GroundBuffers g = ground_buffers(c, c->d_in, c->cap, true);
   mot_launch_ground(c->dp, g, 1, n, c->stream);
   MOT_HIP(c, hipGetLastError());
+  c->ground_resident = true; c->last_fused = false;
   return mot_get_ground(c, 0, elev, n_elev, ground, n_ground, mask, n);
 }
 
@@ -992,9 +1072,11 @@ static int launch_one(mot_ctx* c, int id, int batch) {
   int rc;
   const int max_n = c->last_max_n;
   if (id == kK3 && (rc = next_epoch(c))) return rc;
-  GroundBuffers g = ground_buffers(c, c->last_in, c->last_in_stride, true, true);   // as in the fused path: the compaction kernel leaves the occupancy lists
+  GroundBuffers g = ground_buffers(c, c->last_in, c->last_in_stride, (c->fused_outputs & MOT_OUT_MASK) != 0, true);   // as in the fused path: the compaction kernel leaves the occupancy lists
+  if (!(c->fused_outputs & MOT_OUT_GROUND)) g.ground = nullptr;
+  if (id == kK3) c->ground_resident = (c->fused_outputs & (MOT_OUT_GROUND | MOT_OUT_MASK)) == (MOT_OUT_GROUND | MOT_OUT_MASK);
   ClusterBuffers cb = cluster_buffers(c);
-  cb.occ_list = c->d_occ_list; cb.occ_count = c->d_occ_count;
+  cb.occ_list = c->d_occ_list; cb.occ_count = c->d_occ_count; cb.ecell = g.ecell;
   switch (id) {
     case kK1: mot_launch_ground_kernel(0, c->dp, g, batch, max_n, c->stream); break;
     case kK2: mot_launch_ground_kernel(1, c->dp, g, batch, max_n, c->stream); break;
@@ -1112,11 +1194,12 @@ extern "C" int mot_ego_update(mot_ctx* c, int slot, double timestamp, double v_g
 }
 
 // fills the per-slot launch arguments and advances the host-side copies of timestamp_ / egoPreYaw_ / init_
-static void prepare_track_args(mot_ctx* c, int slot, int m, double timestamp, bool run) {
+static void prepare_track_args(mot_ctx* c, TrackFrameArgs* targs, int slot, int m, double timestamp, bool run) {
   mot_ctx::SlotEgo& e = c->ego[slot];
-  TrackFrameArgs& a = c->h_targs[slot];
+  TrackFrameArgs& a = targs[slot];
   a.m = m; a.run = run ? 1 : 0; a.pad = 0;
-  a.first_frame = e.init ? 0 : 1;
+  a.first_frame = (e.init && !e.tracks_restart) ? 0 : 1;
+  if (run) e.tracks_restart = false;
   a.dt = (timestamp - e.timestamp) / 1000000.0;
   a.ego_yaw = e.egoPoint[2];
   if (run) { e.timestamp = timestamp; e.egoPreYaw = e.egoYaw; e.init = true; }
@@ -1146,6 +1229,26 @@ extern "C" int mot_get_tracks(mot_ctx* c, int slot, mot_track* tracks, int max_t
   return MOT_OK;
 }
 
+extern "C" int mot_set_fused_outputs(mot_ctx* c, int flags) {
+  if (!c) return MOT_E_ARG;
+  if (flags & ~(MOT_OUT_GROUND | MOT_OUT_MASK)) return fail(c, MOT_E_ARG, "mot_set_fused_outputs: unknown flag");
+  c->fused_outputs = flags;
+  return MOT_OK;
+}
+
+// forget the TRACKS of one stream, keep its ego dead reckoning (the origin of its global frame)
+extern "C" int mot_reset_tracks_slot(mot_ctx* c, int slot) {
+  if (!c) return MOT_E_ARG;
+  MOT_GUARD(c);
+  if (slot < 0 || slot >= c->batch) return fail(c, MOT_E_ARG, "slot out of range");
+  MOT_HIP(c, hipMemsetAsync(c->d_nt + slot, 0, sizeof(int), c->stream));
+  MOT_HIP(c, hipMemsetAsync(c->d_nlive + slot, 0, sizeof(int), c->stream));
+  MOT_HIP(c, hipMemsetAsync(c->d_tflags + slot, 0, sizeof(int), c->stream));
+  c->ego[slot].tracks_restart = true;   // the next step is a "first frame" for the tracker only: prepare_track_args
+  c->ego[slot].nt = 0;
+  return MOT_OK;
+}
+
 // forget the tracker state of ONE stream (mot_reset does it for all of them)
 extern "C" int mot_reset_slot(mot_ctx* c, int slot) {
   if (!c) return MOT_E_ARG;
@@ -1166,10 +1269,15 @@ extern "C" int mot_track_step(mot_ctx* c, int slot, const float* boxes_global, i
   if (slot < 0 || slot >= c->batch || m < 0 || (!boxes_global && m > 0) || !n_tracks) return fail(c, MOT_E_ARG, "mot_track_step: slot out of range, negative m, null boxes or null n_tracks");
   if (m > kMaxBoxesPerFrame) return fail(c, MOT_E_CAPACITY, "more boxes in a frame than the library supports (1024)");
   if (!c->ego[slot].ego_called) return fail(c, MOT_E_STATE, "mot_ego_update must precede mot_track_step (getOriginPoints precedes immUkfJpdaf, OT/tracking/main.cpp:74,166)");
-  for (int b = 0; b < c->batch; b++) c->h_targs[b].run = 0;
-  prepare_track_args(c, slot, m, timestamp, true);
+  {
+    char* blk; int rc;
+    if ((rc = arg_block_acquire(c, &blk))) return rc;
+    TrackFrameArgs* targs = reinterpret_cast<TrackFrameArgs*>(blk + c->arg_off_targs);
+    for (int b = 0; b < c->batch; b++) targs[b].run = 0;
+    prepare_track_args(c, targs, slot, m, timestamp, true);
+    if ((rc = arg_block_commit(c, c->arg_off_targs, c->batch * sizeof(TrackFrameArgs)))) return rc;
+  }
   if (m > 0) MOT_HIP(c, hipMemcpyAsync(c->d_tboxes + (size_t)slot * kMaxBoxesPerFrame * 24, boxes_global, (size_t)m * 24 * sizeof(float), hipMemcpyHostToDevice, c->stream));
-  MOT_HIP(c, hipMemcpyAsync(c->d_targs, c->h_targs.data(), c->batch * sizeof(TrackFrameArgs), hipMemcpyHostToDevice, c->stream));
   mot_launch_track(track_buffers(c, false), c->batch, c->stream);
   MOT_HIP(c, hipGetLastError());
   return mot_get_tracks(c, slot, tracks, max_tracks, n_tracks);
@@ -1187,9 +1295,14 @@ extern "C" int mot_track_steps_dev(mot_ctx* c, const float* d_boxes_global, long
     if (m[b] > kMaxBoxesPerFrame) return fail(c, MOT_E_CAPACITY, "more boxes in a frame than the library supports (1024)");
     if (!c->ego[b].ego_called) return fail(c, MOT_E_STATE, "mot_ego_update must precede the tracker step of a slot");
   }
-  for (int b = 0; b < c->batch; b++) c->h_targs[b].run = 0;
-  for (int b = 0; b < batch; b++) prepare_track_args(c, b, m[b], timestamps[b], true);
-  MOT_HIP(c, hipMemcpyAsync(c->d_targs, c->h_targs.data(), c->batch * sizeof(TrackFrameArgs), hipMemcpyHostToDevice, c->stream));
+  {
+    char* blk; int rc;
+    if ((rc = arg_block_acquire(c, &blk))) return rc;
+    TrackFrameArgs* targs = reinterpret_cast<TrackFrameArgs*>(blk + c->arg_off_targs);
+    for (int b = 0; b < c->batch; b++) targs[b].run = 0;
+    for (int b = 0; b < batch; b++) prepare_track_args(c, targs, b, m[b], timestamps[b], true);
+    if ((rc = arg_block_commit(c, c->arg_off_targs, c->batch * sizeof(TrackFrameArgs)))) return rc;
+  }
   TrackBuffers t = track_buffers(c, false);
   t.boxes = d_boxes_global; t.box_stride = box_stride_floats;
   { ProfScope ps(c, kT1); mot_launch_track(t, batch, c->stream); }

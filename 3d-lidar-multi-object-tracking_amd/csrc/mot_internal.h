@@ -92,6 +92,10 @@ struct GroundBuffers {
   OccWord* occ_list;       // [B][occ_chunks][kPlaneWords]
   int* occ_count;          // [B][occ_chunks] entries of each list
   int occ_chunks;
+  // Cartesian cell (xI * 256 + yI; 0xffff = outside the ROI) of every ELEVATED point, at its position in the elevated cloud, or null:
+  // written next to the occupancy (same value, still in registers) so that the box stage's label kernel reads 2 bytes per point
+  // instead of recomputing the cell (only with occ_list, and only for grids of fewer than 256 cells per side: 0xffff must be free)
+  unsigned short* ecell;   // [B][cap]
 };
 
 // ---- cluster + box stages ------------------------------------------------------------------
@@ -142,6 +146,7 @@ struct ClusterBuffers {
   const int* occ_count;
   const int* n_in;             //   ... points of the frame's input cloud (chunks in use)
   int occ_chunks;
+  const unsigned short* ecell; // fused path: Cartesian cell of every elevated point from the compaction kernel (see GroundBuffers), else null
   unsigned* ccl_parent;        // [B][kMaxRuns] union-find array of the labelling kernel for frames with more runs than its LDS holds
   int* grid;                   // [B][65536] labels, x-major with stride num_grid
   int* label;                  // [B][cap] label of each elevated point

@@ -484,7 +484,7 @@ track_prep_kernel(TrackBuffers tb) {
   if (!args.run) return;
   const MotTrackParams tp = tb.tp;
   const int M = tb.m_dev ? min(tb.m_dev[b * kCountsStride + kCntBoxes], kMaxBoxesPerFrame) : args.m;
-  const float* __restrict__ boxes = tb.boxes + (long)b * tb.box_stride;
+  const float* boxes = tb.boxes + (long)b * tb.box_stride;   // (fused path: the same memory as `dst` below — no __restrict__ on either)
   if (tb.boxes_sensor) {
     // the tf step of the tracking node (OT/tracking/main.cpp:143-158: pcl_ros::transformPointCloud("/global", box, ...)): the host
     // walked the tf chain down to the float matrix pcl::transformPointCloud applies (mot_api.hip: tf_velodyne_to_global); each
@@ -492,7 +492,7 @@ track_prep_kernel(TrackBuffers tb) {
     // has -ffp-contract=off)
     const EgoTf e = tb.ego[b];
     const float* __restrict__ src = tb.boxes_sensor + (long)b * kMaxBoxesPerFrame * 24;
-    float* __restrict__ dst = tb.boxes_out + (long)b * tb.box_stride;
+    float* dst = tb.boxes_out + (long)b * tb.box_stride;
     for (int i = tid; i < M * 8; i += 256) {
       const float* p = src + (long)i * 3;
       float* q = dst + (long)i * 3;

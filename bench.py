@@ -473,6 +473,8 @@ def main():
     ap.add_argument("--density", type=float, default=1.0, help="scene density (cars / pedestrians) of the synthetic street")
     ap.add_argument("--issue-threads", type=int, default=0, help="0 (default): one host thread issues every context's launches, frame by frame, in a fixed order (also the order of the "
                     "collectives on every rank); 1: a host thread per context (measured equal: the launch queues, not the host, hold the pace — profiles/r02_issue_threads_contexts_sweep.txt)")
+    ap.add_argument("--phase", type=int, default=38, help="frames by which context c runs ahead of context c-1 within the (shared) sequences: at any instant the contexts' launches "
+                    "read DISJOINT frames, so no context finds another's input in the 256 MiB Infinity Cache (0 = lock-step: every context on the same frame, round 2's layout)")
     ap.add_argument("--force-gather", action="store_true", help="run the per-frame RCCL all-gather of the track blocks even with one rank (exercises the N > 1 path on one GPU)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-aux", action="store_true", help="skip tracker_stress / host_boundary / per-kernel isolated timings")
@@ -562,53 +564,79 @@ def main():
     busy = [0.0] * NC
     side_streams = [torch.cuda.Stream() for _ in range(NC)]
 
-    def run_context(ci, n_steps):
-        """one host thread per context issues that context's launches: the C calls release the GIL, and a single issuing thread
-        (~0.2 ms per 128-frame launch sequence: 128 ego updates and tf matrices, 3 small H2D copies, 13 launches) starved the four
-        streams — each was idle a third of the time (profiles/r02_kernel_trace_B512_4ctx_tracker_v3.txt vs the step time)"""
-        torch.cuda.set_device(local)
+    # Every context walks the SAME Bc sequences (the rendered set fills HBM once) but `--phase` frames ahead of its neighbour: context c
+    # has issued 38 c frames more than context 0 at any time, so concurrent launches of different contexts never read the same frame
+    # (round 2 ran them in lock-step: up to four streaming kernels on the same 0.98 GB, which the 256 MiB Infinity Cache can serve
+    # on-die). A context's position carries over from the warm-up into the timed region; in the timed region every context
+    # processes exactly steps x F frames, in order, restarting its trackers (mot_reset) whenever it wraps to frame 0.
+    pos = [0] * NC   # frames issued so far per context
+
+    def issue_frame(ci):
         cx = ctxs[ci]
+        f = pos[ci] % F
+        if f == 0:
+            cx.reset()   # every stream starts its sequence over (stream-ordered, no host synchronisation)
+        cx.frames_dev(frame_ptr[f], stride * 4, n_seq[f], run_tracker=True, timestamps=ts_f[f], ego_v=ev_f[f], ego_yaw=ey_f[f])
+        pos[ci] += 1
+        if gathers:  # the per-frame result blocks cross GPUs over RCCL / xGMI (one process group per context)
+            with torch.cuda.stream(side_streams[ci]):
+                gathers[ci].step(cx, force_collective=True)
+
+    def run_context(ci, n_frames):
+        """--issue-threads 1: one host thread per context (the C calls release the GIL)"""
+        torch.cuda.set_device(local)
         t_h = time.perf_counter()
-        with torch.cuda.stream(side_streams[ci]):
-            for _ in range(n_steps):
-                cx.reset()   # every stream starts its sequence over (stream-ordered, no host synchronisation)
-                for f in range(F):
-                    cx.frames_dev(frame_ptr[f], stride * 4, n_seq[f], run_tracker=True, timestamps=ts_f[f], ego_v=ev_f[f], ego_yaw=ey_f[f])
-                    if gathers:  # the per-frame result blocks cross GPUs over RCCL / xGMI (one process group per context)
-                        gathers[ci].step(cx, force_collective=True)
+        for _ in range(n_frames):
+            issue_frame(ci)
         busy[ci] = time.perf_counter() - t_h
 
-    def run_steps(n_steps):
+    def run_frames(n_frames, extra=None):
+        """n_frames per context (+ extra[ci]: the phase offsets, issued first); one issuing thread interleaves the contexts frame by frame"""
+        extra = extra or [0] * NC
+        t_c = time.thread_time()
         if args.issue_threads and NC > 1:
-            th = [threading.Thread(target=run_context, args=(ci, n_steps)) for ci in range(NC)]
+            th = [threading.Thread(target=run_context, args=(ci, n_frames + extra[ci])) for ci in range(NC)]
             for t in th:
                 t.start()
             for t in th:
                 t.join()
-        else:   # one issuing thread, contexts interleaved frame by frame
+        else:
             t_h = time.perf_counter()
-            for _ in range(n_steps):
-                for cx in ctxs:
-                    cx.reset()
-                for f in range(F):
-                    for ci, cx in enumerate(ctxs):
-                        cx.frames_dev(frame_ptr[f], stride * 4, n_seq[f], run_tracker=True, timestamps=ts_f[f], ego_v=ev_f[f], ego_yaw=ey_f[f])
-                        if gathers:   # each context's collective on its own side stream and process group: contexts stay decoupled
-                            with torch.cuda.stream(side_streams[ci]):
-                                gathers[ci].step(cx, force_collective=True)
+            for ci in range(NC):
+                for _ in range(extra[ci]):
+                    issue_frame(ci)
+            for _ in range(n_frames):
+                for ci in range(NC):
+                    issue_frame(ci)
             busy[0] = time.perf_counter() - t_h
         host_issue[0] = max(busy)
+        host_cpu[0] = time.thread_time() - t_c
+
+    def run_steps(n_steps):
+        run_frames(n_steps * F)
+
+    host_cpu = [0.0]
 
     def sync_all():
         for cx in ctxs:
             cx.synchronize()
 
-    if args.warmup:
-        run_steps(args.warmup)
+    phase = [(args.phase * ci) % F for ci in range(NC)]
+    run_frames(args.warmup * F, extra=phase)   # (with --warmup 0 only the phase offsets are issued)
+    sync_all()
+    # the host's own cost of one launch sequence: the first call after a synchronise finds empty queues, so nothing in it waits for
+    # the GPU (inside the timed region the calls also absorb the back-pressure of full queues: host_issue_ms_per_step)
+    t_u = time.perf_counter()
+    for ci in range(NC):
+        issue_frame(ci)
+    host_unblocked_us = (time.perf_counter() - t_u) / NC * 1e6
+    for ci in range(NC):   # keep every context on a whole number of steps + its phase: F - 1 more frames, untimed
+        for _ in range(F - 1):
+            issue_frame(ci)
     sync_all()
     # in-run timing of the dominant kernel: <= 64 event pairs per context, spread over the timed region
     dom = "classify_compact_kernel"
-    dom_kernel = dom
+    dom_kernel = "classify_compact_elevated_kernel"   # the instantiation the fused path launches by default (ground cloud / mask on demand)
     every = max(1, -(-args.steps * F // 60))
     for cx in ctxs:
         cx.profile_kernel(K_IDS[dom], every)
@@ -653,7 +681,7 @@ def main():
         # algorithmic HBM bytes per launch (what a kernel must read and write once), at the last frame's counts
         alg_bytes = {"polar_minz_kernel": 16.0 * n_tot,
                      "polar_filter_kernel": 8.0 * 9600 * BL,
-                     "classify_compact_kernel": 16.0 * n_tot + 16.0 * (ne_tot + ng_tot) + 1.0 * n_tot,
+                     "classify_compact_kernel": 16.0 * n_tot + 16.0 * ne_tot,   # the fused path's default: ground cloud and mask on demand (round 2: + 16 N_g + N)
                      "ccl_kernel": (2 * 2048 * 4 + 4.0 * G * G) * BL,
                      "label_stats_kernel": (16.0 + 4.0 + 4.0) * ne_tot,
                      "cluster_index_kernel": 4.0 * ne_tot,
@@ -666,12 +694,12 @@ def main():
         frames = B * F * args.steps * world
         # HBM bytes per launch from the committed PMC passes of this command (FETCH_SIZE x2 on gfx950 + WRITE_SIZE, KB), same launch size only
         traffic, traffic_src = None, None
-        pmc_path = os.path.join(ROOT, "profiles", "r02_pmc_B512.json")
+        pmc_path = os.path.join(ROOT, "profiles", "r03_pmc_B512.json")
         if N == 120000 and os.path.exists(pmc_path):
             pmc = json.load(open(pmc_path)).get(dom_kernel)
             if pmc and "FETCH_SIZE" in pmc and "WRITE_SIZE" in pmc:
                 traffic = int((2.0 * pmc["FETCH_SIZE"] + pmc["WRITE_SIZE"]) * 1024 / 512 * BL)
-                traffic_src = (f"profiles/r02_pmc_B512.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this pipeline at 512 frames per launch (FETCH_SIZE x 2: the gfx950 "
+                traffic_src = (f"profiles/r03_pmc_B512.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this pipeline at 512 frames per launch (FETCH_SIZE x 2: the gfx950 "
                                f"correction for wide coalesced reads)" + ("" if BL == 512 else f", scaled to the {BL} frames of a launch here"))
         out = {
             "metric": "LiDAR frames/sec (120k-pt 64-beam cloud) end-to-end ground->cluster->track",
@@ -680,13 +708,17 @@ def main():
             "dtype": "f32/f64 (fp32 grid indices with fp64 intermediates, int32 grids/labels, fp64 tracker — the reference's types)",
             "data": "synthetic" if not variant else f"synthetic; EXPERIMENT BUILD {variant} — not the product library", "inputs": "hbm-resident (rendered into HBM before the timed region; see host_boundary_pipelined for the PCIe-inclusive rate)",
             "timed_region_s": round(dt, 3), "host_issue_ms_per_step": round(host_issue[0] / args.steps * 1e3, 3),
+            "host_cpu_ms_per_step": round(host_cpu[0] / args.steps * 1e3, 3) if not (args.issue_threads and NC > 1) else None,
+            "host_unblocked_us_per_launch_sequence": round(host_unblocked_us, 1),
+            "host_note": "host_issue = wall time the issuing thread spent inside the asynchronous launch calls (includes waiting for room in the hardware queues); host_cpu = CPU time of "
+                         "that thread (time.thread_time) over the timed region; host_unblocked = one launch sequence issued right after a synchronise (nothing to wait for): the host's own cost",
             "issue_threads": (NC if args.issue_threads and NC > 1 else 1),
             "config": {"workload": f"configs[3]: ground removal -> CCL -> box fit -> batched IMM-UKF-PDA tracker on one MI355X per rank; one step = {F}-frame "
                                    f"sequence (ego motion of KITTI drive_0005) of every stream, {N}-pt synthetic HDL-64E clouds, no frame repeated within a sequence"
                                    + ("" if world == 1 else f"; sharded as configs[4] (every stream pinned to one GPU, RCCL all-gather of the live-track blocks per frame) "
                                       f"with the SAME per-GPU work as the 1-GPU line (weak scaling); configs[4]'s 200 k-point frames: --points 200000"),
                        "points_per_frame": N, "frames_per_stream_per_step": F, "streams_per_gpu": B, "streams": B * world, "distinct_scenes_per_gpu": Bc,
-                       "frames_per_step_per_gpu": B * F, "contexts_per_gpu": NC, "frames_per_launch": BL,
+                       "frames_per_step_per_gpu": B * F, "contexts_per_gpu": NC, "frames_per_launch": BL, "context_phase_frames": args.phase,
                        "elevated_pts_per_frame": ne_tot // BL, "clusters_last_frame_stream0": cl0["num_cluster"], "boxes_last_frame_stream0": len(bx0["boxes"]),
                        "tracks_ever_stream0": int(tr0["n"]), "live_tracks_per_stream": {"mean": round(float(np.mean(live)), 1), "max": int(np.max(live)), "streams_sampled": len(live)},
                        "render_s": round(render_s, 1), "scene_density": args.density,
@@ -695,11 +727,11 @@ def main():
                          "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_src,
                          "kernel_ms": {"mean": round(dom_ms, 5), "min": round(solo["min_ms"], 5), "max": round(solo["max_ms"], 5), "samples": solo["samples"],
                                        "how": "HIP event pairs around the kernel's launch on its own stream (mot_profile_kernel), the whole pipeline running on ONE context, "
-                                              "nothing else on the GPU; rocprofv3 summary of the same schedule: profiles/r02_kernel_trace_B512_1ctx.txt"},
+                                              "nothing else on the GPU; rocprofv3 summary of the same schedule: profiles/r03_kernel_trace_B512_1ctx.txt"},
                          "kernel_ms_in_timed_region": {"mean": round(shared_ms, 5), "min": round(min(p["min_ms"] for p in prof), 5), "max": round(max(p["max_ms"] for p in prof), 5), "samples": nsamp,
                                        "frac_if_taken_alone": round(alg_bytes[dom] / (shared_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if shared_ms > 0 else None,
                                        "how": f"the same event pairs inside the timed region, where {NC} contexts' kernels run concurrently and share HBM and CUs: a launch's duration there is its "
-                                              "share of the machine (see pipeline_frac for the whole); rocprofv3 summary: profiles/r02_kernel_trace_B2048_4ctx.txt"},
+                                              "share of the machine (see pipeline_frac for the whole); rocprofv3 summary: profiles/r03_kernel_trace_B2048_4ctx.txt"},
                          "algorithmic_bytes_per_launch": {k: int(v) for k, v in alg_bytes.items()},
                          "pipeline_bytes_per_frame": int(frame_bytes),
                          "pipeline_frac": round(frame_bytes * B * F / (dt / args.steps) / 1e9 / HBM_PEAK_GBS, 4)},

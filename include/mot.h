@@ -38,7 +38,7 @@
 extern "C" {
 #endif
 
-#define MOT_ABI_VERSION 2
+#define MOT_ABI_VERSION 3
 
 /* polar grid of the ground stage: compile-time in the reference too
  * (OT/include/ground_removal.h:16-17) */
@@ -67,6 +67,9 @@ enum {
 
 /* per-point classification written by the ground stage */
 enum { MOT_MASK_DROPPED = 0, MOT_MASK_GROUND = 1, MOT_MASK_ELEVATED = 2 };
+
+/* by-products of groundRemove that nothing downstream of it reads (mot_set_fused_outputs) */
+enum { MOT_OUT_GROUND = 1, /* groundCloud */ MOT_OUT_MASK = 2 /* the per-point classification */ };
 
 /* All tunables of the path. The reference keeps them as file-scope globals; file:line in the
  * comments. mot_params_preset() fills either preset. */
@@ -169,6 +172,11 @@ void mot_destroy(mot_ctx* ctx);
 int mot_reset(mot_ctx* ctx);
 /* the same for one stream */
 int mot_reset_slot(mot_ctx* ctx, int slot);
+/* forget the TRACKS of one stream but keep its dead-reckoned ego pose, i.e. the origin of its global frame: what a long-running
+ * node wants when a stream has used up max_tracks_total (mot_reset_slot would re-origin /global at the current pose and make
+ * every published position jump). The next tracker step of the slot behaves like the reference's first frame (one seeded
+ * track, OT/tracking/imm_ukf_jpda.cpp:741-795). */
+int mot_reset_tracks_slot(mot_ctx* ctx, int slot);
 /* the parameters the context was created with */
 int mot_get_params(const mot_ctx* ctx, mot_params* out);
 const char* mot_last_error(const mot_ctx* ctx);
@@ -239,6 +247,15 @@ int mot_track_get_state(mot_ctx* ctx, int slot, int id, mot_track_state* out);
  * Asynchronous: results are read back with the mot_get_* calls below (which synchronise). */
 int mot_frames_dev(mot_ctx* ctx, const float* d_xyzw, long frame_stride, const int* n_points, int batch,
                    int run_tracker, const double* timestamps, const double* ego_v, const double* ego_yaw);
+
+/* Which by-products of the ground stage the FUSED entry points (mot_frames_dev, mot_frames_host, mot_frame_pointcloud2) write
+ * besides what the next stage needs: flags = OR of MOT_OUT_GROUND / MOT_OUT_MASK, default 0. The reference's own fused
+ * precedent never touches groundCloud after groundRemove (OT0/src/main.cpp:63-79), and the ground cloud is a quarter of the
+ * compaction kernel's HBM traffic. Nothing is lost with the default: mot_get_ground materialises the ground cloud / mask of
+ * the LAST batch on demand (it re-runs the compaction from the batch's input, polar cells and thresholds, all still resident —
+ * so with mot_frames_dev the caller's input buffer must be unchanged until then). Sticky per context. The stage-wise
+ * mot_ground_remove always delivers both outputs (OT/src/groundremove/ground_removal.cpp:226-247). */
+int mot_set_fused_outputs(mot_ctx* ctx, int flags);
 
 /* The same for frames in HOST memory — what the reference's nodes receive, one message per frame
  * (OT/src/groundremove/main.cpp:91-136, OT0/src/main.cpp:51-95) — pipelined: the H2D copy of this batch runs on the

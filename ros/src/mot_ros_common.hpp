@@ -22,31 +22,37 @@ inline void check(mot_ctx* ctx, int rc, const char* what) {
 // mot_track_step for a long-running node. The reference never frees a track (targets_ only grows, imm_ukf_jpda.cpp:972-989) and
 // only gets slower; the library holds at most ~max_tracks_total of them per stream and then reports MOT_E_CAPACITY on every step
 // (the records are still delivered). A node must not die of that (the launch file marks it required="true"): warn, publish what
-// came back, and start the stream's tracker over — the tracks re-form within lifeTimeThres_ frames.
+// came back, and start the stream's TRACKS over — mot_reset_tracks_slot keeps the stream's dead-reckoned ego pose, so the /global
+// frame and every published position stay continuous; the tracks re-form within lifeTimeThres_ frames.
 inline void track_step_or_restart(mot_ctx* ctx, int slot, const float* boxes_global, int n_boxes, double timestamp, mot_track* tracks,
                                   int max_tracks, int* n_tracks) {
   const int rc = mot_track_step(ctx, slot, boxes_global, n_boxes, timestamp, tracks, max_tracks, n_tracks);
   if (rc == MOT_E_CAPACITY && *n_tracks <= max_tracks) {
     ROS_WARN("tracker: %s — restarting the tracker of this stream (raise ~max_tracks_total to postpone this)", mot_last_error(ctx));
-    check(ctx, mot_reset_slot(ctx, slot), "mot_reset_slot");
+    check(ctx, mot_reset_tracks_slot(ctx, slot), "mot_reset_tracks_slot");
     return;
   }
   check(ctx, rc, "mot_track_step");
 }
 
 // private parameters common to the nodes (read from a NodeHandle("~")): ~device (HIP ordinal), ~max_points, ~preset
-// (0 = object_tracking, 1 = object_tracking0), ~max_tracks_total
-struct Settings { int device = 0, max_points = 262144, preset = MOT_PRESET_OBJECT_TRACKING, max_tracks_total = 16384; };
+// (0 = object_tracking, 1 = object_tracking0), ~max_tracks_total, ~rng_mapping (how the reference build being replaced maps its
+// mt19937_64 draws to sample indices, include/mot.h: 0 = libstdc++ <= 10 — the compiler of every ROS1 distribution, hence the
+// default here — 1 = libstdc++ >= 11; the two agree except with probability ~5e-14 per draw)
+struct Settings { int device = 0, max_points = 262144, preset = MOT_PRESET_OBJECT_TRACKING, max_tracks_total = 16384, rng_mapping = MOT_RNG_LIBSTDCXX10; };
 inline Settings settings(const ros::NodeHandle& nh) {
   Settings s;
   nh.param<int>("device", s.device, s.device);
   nh.param<int>("max_points", s.max_points, s.max_points);
   nh.param<int>("preset", s.preset, s.preset);
   nh.param<int>("max_tracks_total", s.max_tracks_total, s.max_tracks_total);
+  nh.param<int>("rng_mapping", s.rng_mapping, s.rng_mapping);
   return s;
 }
-inline mot_ctx* create(const mot_params& p, const Settings& s) {
+inline mot_ctx* create(const mot_params& p_in, const Settings& s) {
   mot_ctx* ctx = nullptr;
+  mot_params p = p_in;
+  p.rng_mapping = s.rng_mapping;
   if (mot_create(&p, s.device, s.max_points, 1, s.max_tracks_total, &ctx) != MOT_OK)
     throw std::runtime_error("mot_create failed: no MI355X / HIP device? (this library has no CPU path)");
   return ctx;

@@ -100,18 +100,17 @@ def test_reset_slot_and_sticky_capacity(mot, emu):
             ts = 1.0e9 + f * 1e5
             for s in range(2):
                 c.ego_update(ts, 0.0, 0.0, s)
-                try:
-                    c.track_step(_moving_boxes(f, 12), ts, s)
-                except mot.MotError as e:
-                    assert e.code == mot.MOT_E_CAPACITY
-                    hit += 1
+                out = c.track_step(_moving_boxes(f, 12), ts, s)   # the records are delivered; the binding reports the condition softly
+                hit += int(out["capacity_exceeded"])
+                assert out["n"] <= 4
         assert hit >= 6                      # told again on every call once births are being dropped (both streams)
-        with pytest.raises(mot.MotError):
-            c.get_tracks(0)                  # ... also by the getter, until the stream is started over
+        tr = (mot.MotTrack * 4)(); nt = C.c_int(0)
+        assert L.mot_get_tracks(c._h, 0, tr, 4, C.byref(nt)) == mot.MOT_E_CAPACITY and nt.value == 4   # the C call: MOT_E_CAPACITY, records delivered
+        assert c.get_tracks(0)["capacity_exceeded"]   # ... also by the getter, until the stream is started over
         c.reset_slot(0)
-        assert c.get_tracks(0)["n"] == 0     # slot 0 forgot everything
-        with pytest.raises(mot.MotError):
-            c.get_tracks(1)                  # slot 1 did not
+        t0 = c.get_tracks(0)
+        assert t0["n"] == 0 and not t0["capacity_exceeded"]     # slot 0 forgot everything
+        assert c.get_tracks(1)["capacity_exceeded"]             # slot 1 did not
         with pytest.raises(mot.MotError) as e:
             c.reset_slot(5)
         assert e.value.code == mot.MOT_E_ARG and "slot" in str(e.value)
@@ -164,3 +163,60 @@ def test_fast_path_sweeps_on_the_emulator(mot, emu):
             for mode in (0, 1, 2):
                 assert L.mot_debug_sweep(c._h, what, mode, C.c_ulonglong(7), C.c_ulonglong(200000), st) == 0
                 assert st[0] == 200000 and st[2] == 0, (what, mode, list(st))
+
+
+def test_fused_outputs_on_demand_and_materialised(mot, emu, synth, oracle):
+    """mot_set_fused_outputs: by default the fused path writes neither the ground cloud nor the mask (nothing downstream reads them);
+    mot_get_ground re-runs the compaction of the last batch when they are asked for. With the flags set they are written in the
+    first place. Either way: equal to the oracle, for every slot of a ragged batch, and the cluster stage's results are untouched."""
+    lib, L = emu
+    B, N, stride = 3, 5000, 5120
+    p = oracle.params(0)
+    n = [N, N - 1234, 300]
+    host = np.zeros((B, stride, 4), np.float32)
+    for s in range(B):
+        host[s, : n[s]] = synth.make_cloud(N, 50 + s, 1)[: n[s]]
+    res = {}
+    for flags in (0, mot.OUT_GROUND, mot.OUT_GROUND | mot.OUT_MASK):
+        with mot.Context(lib_path=lib, max_points=stride, max_batch=B, max_tracks_total=64) as c:
+            c.set_fused_outputs(flags)
+            c.frames_dev(host.ctypes.data, stride * 4, n)
+            bx = [c.get_boxes(s)["boxes"] for s in range(B)]          # before any materialisation
+            cl = [c.get_clusters(s, n_elevated=n[s]) for s in range(B)]
+            g = [c.get_ground(s, n_hint=n[s]) for s in (2, 0, 1)]      # any order; one re-run serves the whole batch
+            g = [g[1], g[2], g[0]]
+            assert all(np.array_equal(c.get_boxes(s)["boxes"], bx[s]) for s in range(B))   # ... and leaves the later stages' results alone
+            res[flags] = (g, bx, cl)
+    for s in range(B):
+        o = oracle.ground_remove(p, host[s, : n[s]])
+        for flags, (g, bx, cl) in res.items():
+            assert np.array_equal(g[s]["mask"], o["mask"]) and np.array_equal(g[s]["elevated"], o["elevated"]) and np.array_equal(g[s]["ground"], o["ground"]), (flags, s)
+            assert np.array_equal(bx[s], res[0][1][s]) and np.array_equal(cl[s]["grid"], res[0][2][s]["grid"])
+            assert np.array_equal(cl[s]["point_label"][: len(o["elevated"])], oracle.cluster(p, o["elevated"])["point_label"])
+    with mot.Context(lib_path=lib, max_points=stride, max_batch=1) as c:
+        with pytest.raises(mot.MotError) as e:
+            c.set_fused_outputs(8)
+        assert e.value.code == mot.MOT_E_ARG
+
+
+def test_reset_tracks_slot_keeps_the_global_frame(mot, emu, oracle):
+    """mot_reset_tracks_slot forgets a stream's tracks but not its ego dead reckoning: the origin of the global frame stays where it
+    was (mot_reset_slot would re-origin it at the current pose), and the next tracker step seeds anew like the reference's first frame"""
+    lib, L = emu
+    with mot.Context(lib_path=lib, max_points=1024, max_batch=2, max_tracks_total=64) as c, mot.Context(lib_path=lib, max_points=1024, max_batch=1, max_tracks_total=64) as ref:
+        for f in range(6):
+            ts = 1.0e9 + f * 1e5
+            e0 = c.ego_update(ts, 3.0, 0.02 * f, 0); r0 = ref.ego_update(ts, 3.0, 0.02 * f)
+            assert np.array_equal(e0, r0)
+            c.track_step(_moving_boxes(f), ts, 0); ref.track_step(_moving_boxes(f), ts)
+        assert c.get_tracks(0)["n"] > 1
+        c.reset_tracks_slot(0)
+        assert c.get_tracks(0)["n"] == 0
+        for f in range(6, 10):
+            ts = 1.0e9 + f * 1e5
+            e0 = c.ego_update(ts, 3.0, 0.02 * f, 0); r0 = ref.ego_update(ts, 3.0, 0.02 * f)
+            assert np.array_equal(e0, r0) and abs(e0[0]) + abs(e0[1]) > 0.5     # same pose as the uninterrupted stream: no re-origin
+            t = c.track_step(_moving_boxes(f), ts, 0); ref.track_step(_moving_boxes(f), ts)
+            if f == 6:
+                assert t["n"] == 1 and t["track_manage"][0] == 1             # the reference's first frame: one seeded track
+        assert c.get_tracks(0)["n"] > 1

@@ -58,11 +58,11 @@ def test_calls_report_capacity_and_argument_errors(mot, emu, synth):
         for k in range(12):
             boxes[k, :, :2] = np.array([[0, 0], [2, 0], [2, 1], [0, 1]] * 2) + [6.0 * k - 30, 5.0]
             boxes[k, 4:, 2] = 1.0; boxes[k, :4, 2] = -2.0
-        with pytest.raises(mot.MotError) as e:
-            for f in range(6):
-                ts = 1.0e9 + f * 1e5
-                c.ego_update(ts, 0.0, 0.0); c.track_step(boxes, ts)
-        assert e.value.code == mot.MOT_E_CAPACITY
+        full = False   # (MOT_E_CAPACITY from the C call with the records delivered; the binding turns it into `capacity_exceeded`)
+        for f in range(6):
+            ts = 1.0e9 + f * 1e5
+            c.ego_update(ts, 0.0, 0.0); full |= c.track_step(boxes, ts)["capacity_exceeded"]
+        assert full
         # the context stays usable after an error
         c.reset()
         small = synth.make_cloud(1500, 1, 0)

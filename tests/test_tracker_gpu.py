@@ -115,16 +115,18 @@ def test_tracker_edge_cases(mot, hip_lib, oracle):
         a = c.track_step(box, 1e6); o = T.step(box, 1e6)
         assert a["n"] == o["n"] == 0
         rng = np.random.default_rng(0)
-        with pytest.raises(mot.MotError) as e:   # the reference never frees tracks: capacity is an error, not a drop
-            for f in range(1, 6):
-                ts = 1e6 + f * 1e5
-                c.ego_update(ts, 0, 0)
-                b = np.zeros((4, 8, 3), np.float32)
-                for k in range(4):
-                    cx, cy = rng.uniform(-20, 20, 2)
-                    b[k, :, :2] = (np.array([[0, 0], [2, 0], [2, 1], [0, 1]] * 2) + [cx, cy])
-                c.track_step(b, ts)
-        assert e.value.code == mot.MOT_E_CAPACITY
+        full = False   # the reference never frees tracks: capacity is reported (MOT_E_CAPACITY in C, `capacity_exceeded` here), the records still delivered
+        for f in range(1, 6):
+            ts = 1e6 + f * 1e5
+            c.ego_update(ts, 0, 0)
+            b = np.zeros((4, 8, 3), np.float32)
+            for k in range(4):
+                cx, cy = rng.uniform(-20, 20, 2)
+                b[k, :, :2] = (np.array([[0, 0], [2, 0], [2, 1], [0, 1]] * 2) + [cx, cy])
+            out = c.track_step(b, ts)
+            full |= out["capacity_exceeded"]
+            assert out["n"] <= 8
+        assert full
 
 
 def test_fused_frames_with_tracker(mot, hip_lib, oracle, synth):
