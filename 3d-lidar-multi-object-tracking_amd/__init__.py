@@ -74,7 +74,7 @@ EXPORTS = (
     "mot_get_boxes", "mot_get_tracks", "mot_export_tracks_dev", "mot_side_params_default", "mot_cluster_products", "mot_cluster_products_host", "mot_decode_pointcloud2_dev", "mot_time_stage",
     "mot_ground_remove_pointcloud2", "mot_box_fit_resident", "mot_frame_pointcloud2",
     "mot_reset_slot", "mot_frames_host", "mot_wait_uploads", "mot_host_alloc", "mot_host_free", "mot_fetch_tracks_async",
-    "mot_track_steps_dev", "mot_profile_kernel", "mot_profile_read", "mot_get_params", "mot_set_fused_outputs", "mot_reset_tracks_slot",
+    "mot_track_steps_dev", "mot_profile_kernel", "mot_profile_read", "mot_get_params", "mot_set_fused_outputs", "mot_reset_tracks_slot", "mot_export_tracks_packed_dev",
 )
 ABI_VERSION = 3
 OUT_GROUND, OUT_MASK = 1, 2
@@ -372,6 +372,10 @@ class Context:
     def export_tracks_dev(self, batch: int, d_tracks_ptr: int, max_per_slot: int, d_counts_ptr: int):
         """live tracks of every slot -> caller's device buffer (the block that is all-gathered across GPUs)"""
         self._ck(self.lib.mot_export_tracks_dev(self._h, batch, C.c_void_p(d_tracks_ptr), max_per_slot, C.c_void_p(d_counts_ptr)))
+
+    def export_tracks_packed_dev(self, batch: int, d_block_ptr: int, block_bytes: int):
+        """live tracks of every slot, packed (counts header + records back to back) -> caller's device block"""
+        self._ck(self.lib.mot_export_tracks_packed_dev(self._h, batch, C.c_void_p(d_block_ptr), C.c_long(block_bytes)))
 
     def time_stage(self, stage: int, batch: int, iters: int) -> float:
         """average ms per iteration of one stage re-run on resident data, HIP events on the context stream"""

@@ -30,8 +30,16 @@
 
 #ifndef MOT_HIPEMU
 #define MOT_LAUNCH_BOUNDS(n) __launch_bounds__(n)
+#define MOT_LAUNCH_BOUNDS2(n, waves_per_simd) __launch_bounds__(n, waves_per_simd)
 #else
 #define MOT_LAUNCH_BOUNDS(n)
+#define MOT_LAUNCH_BOUNDS2(n, waves_per_simd)
+#endif
+#ifndef MOT_GATHER_WAVES
+#define MOT_GATHER_WAVES 6
+#endif
+#ifndef MOT_RECT_WAVES
+#define MOT_RECT_WAVES 4
 #endif
 
 #ifndef MOT_LABEL_BLOCK
@@ -466,10 +474,9 @@ __device__ bool rule_based_filter(const MotDevParams& p, const float* pc, float 
 // one workgroup per cluster, threads over the cluster's OWN points through the cluster-sorted index (no walk over the
 // frame). L-shape branch completes here; the rectangle branch leaves the cluster's candidate hull points (lowest /
 // highest pixel of every pixel column) in the polygon pool.
-__global__ void MOT_LAUNCH_BOUNDS(kBoxBlock)
+__global__ void MOT_LAUNCH_BOUNDS2(kBoxBlock, MOT_GATHER_WAVES)
 cluster_gather_kernel(MotDevParams p, ClusterBuffers c) {
   __shared__ int s_colmin[kPicCols], s_colmax[kPicCols];
-  __shared__ short s_px[kMaxHullIn + 2], s_py[kMaxHullIn + 2];
   __shared__ int s_rank[128], s_pidx[128];
   __shared__ int s_flag;
   __shared__ int s_wsum[kBoxBlock / 64];
@@ -648,14 +655,18 @@ cluster_gather_kernel(MotDevParams p, ClusterBuffers c) {
       __syncthreads();
       GATHER_T(1);
       {
-        // compact the column extents into (x,y)-sorted points: 4 consecutive columns per thread, prefix over the workgroup
+        // compact the column extents into (x,y)-sorted points: 4 consecutive columns per thread, prefix over the workgroup. A
+        // cluster's candidates go to the cluster's OWN slots of the polygon pool — the slots its points have in the cluster-sorted
+        // index: every candidate is a distinct point of the cluster, so there are never more of them — straight from the
+        // registers. (They used to be staged in LDS and placed behind a returning device-scope atomicAdd on a per-frame counter:
+        // that round trip to the memory side and its two barriers were half of this branch, profiles/r02_gather_phases.txt.)
         constexpr int kPerThread = kPicCols / kBoxBlock;
-        int cnt = 0;
+        int cnt = 0, lo[kPerThread], hi[kPerThread];
 #pragma unroll
         for (int k = 0; k < kPerThread; k++) {
           const int col = tid * kPerThread + k;
-          const int lo = s_colmin[col], hi = s_colmax[col];
-          if (lo != 0x7fffffff) cnt += (hi != lo) ? 2 : 1;
+          lo[k] = s_colmin[col]; hi[k] = s_colmax[col];
+          if (lo[k] != 0x7fffffff) cnt += (hi[k] != lo[k]) ? 2 : 1;
         }
         const int incl = wave_scan_incl_i32(cnt);
         if (lane == 63) s_wsum[wave] = incl;
@@ -663,23 +674,18 @@ cluster_gather_kernel(MotDevParams p, ClusterBuffers c) {
         int pos = incl - cnt, total = 0;
 #pragma unroll
         for (int w2 = 0; w2 < kBoxBlock / 64; w2++) { const int ws = s_wsum[w2]; if (w2 < wave) pos += ws; total += ws; }
+        int* __restrict__ pool = c.poly + (long)b * c.cap + first_slot;
 #pragma unroll
         for (int k = 0; k < kPerThread; k++) {
-          const int col = tid * kPerThread + k;
-          const int lo = s_colmin[col], hi = s_colmax[col];
-          if (lo != 0x7fffffff) {
-            s_px[pos] = (short)(col + offsetInitX); s_py[pos] = (short)lo; pos++;
-            if (hi != lo) { s_px[pos] = (short)(col + offsetInitX); s_py[pos] = (short)hi; pos++; }
+          const int px = (int)(unsigned short)(short)(tid * kPerThread + k + offsetInitX);
+          if (lo[k] != 0x7fffffff) {
+            pool[pos++] = px | (int)((unsigned)lo[k] << 16);
+            if (hi[k] != lo[k]) pool[pos++] = px | (int)((unsigned)hi[k] << 16);
           }
         }
-        if (tid == 0) s_flag = atomicAdd(&c.counts[b * kCountsStride + kCntPoly], total);
-        __syncthreads();
-        const int off = s_flag;
-        int* pool = c.poly + (long)b * c.cap;
-        for (int j = tid; j < total; j += kBoxBlock) if (off + j < c.cap) pool[off + j] = ((int)(unsigned short)s_px[j]) | (int)((unsigned)(int)s_py[j] << 16);
         GATHER_T(2);
         if (tid == 0) {
-          cand.poly_off = off; cand.poly_n = total; cand.off_x = offsetInitX; cand.off_y = offsetInitY;
+          cand.poly_off = first_slot; cand.poly_n = total; cand.off_x = offsetInitX; cand.off_y = offsetInitY;
           GATHER_T_STORE_RECT(cand);
           c.cand[(long)b * kMaxClusters + ci] = cand;
         }
@@ -761,15 +767,27 @@ __device__ __forceinline__ void cluster_rect_body(const MotDevParams& p, const C
 #define RLF(v, idx) __shfl((v), (idx), 64)
 #endif
   const int* __restrict__ order = c.order + (long)b * kMaxClusters;
-  // clusters by falling size, dealt to the frame's workgroups forwards, then backwards, ...: whoever got a large one in a round
-  // gets a small one in the next (45 -> 41 us)
-  for (int round = 0; round * (int)gridDim.x < num_cluster; round++) {
-    const int oi = round * (int)gridDim.x + ((round & 1) ? (int)gridDim.x - 1 - (int)blockIdx.x : (int)blockIdx.x);
-    if (oi >= num_cluster) continue;
-    const int ci = wave_uniform_i32(order[oi]);   // (a loaded value: keep the per-cluster addressing and branches scalar)
+  // Which clusters are this instantiation's: 64 candidates at a time, a lane each (ONE round trip for all of them; walking the
+  // clusters one by one cost two dependent loads per cluster just to find that most need nothing here — every L-shape cluster,
+  // and for the large-hull instantiation practically all of them). The clusters that do need a rectangle are dealt by falling
+  // size to the frame's workgroups forwards, then backwards, ...: whoever got a large one in a round gets a small one in the next.
+  int dealt = 0;   // rectangle clusters of this instantiation met so far (uniform)
+  for (int base = 0; base < num_cluster; base += 64) {
+    int my_ci = -1;
+    bool need = false;
+    if (base + lane < num_cluster) {
+      my_ci = order[base + lane];
+      const BoxCandidate* q = &c.cand[(long)b * kMaxClusters + my_ci];
+      need = q->branch == 1 && ((q->poly_n > kSmallHullIn) == kLarge);   // (fields the gather kernel wrote and this kernel rewrites unchanged: every workgroup counts the same set)
+    }
+    unsigned long long todo = __ballot(need);
+  while (todo) {
+    const int src = __ffsll(todo) - 1;
+    todo &= todo - 1ull;
+    const int k = dealt++, round = k / (int)gridDim.x, at = k - round * (int)gridDim.x;
+    if (((round & 1) ? (int)gridDim.x - 1 - at : at) != (int)blockIdx.x) continue;
+    const int ci = wave_bcast_i32(my_ci, src);
     BoxCandidate cand = c.cand[(long)b * kMaxClusters + ci];
-    if (cand.branch != 1 || cand.undefined) continue;  // L-shape clusters are complete already
-    if ((cand.poly_n > kSmallHullIn) != kLarge) continue;   // the other instantiation's cluster
     const int offsetInitX = cand.off_x, offsetInitY = cand.off_y, numPoints = cand.num_points;
     const float maxZ = cand.max_z;
     int total = cand.poly_n;
@@ -962,9 +980,10 @@ __device__ __forceinline__ void cluster_rect_body(const MotDevParams& p, const C
     }
     MOT_WAVE_SYNC();
   }
+  }
 #undef RLF
 }
-__global__ void MOT_LAUNCH_BOUNDS(kRectBlock)
+__global__ void MOT_LAUNCH_BOUNDS2(kRectBlock, MOT_RECT_WAVES)
 cluster_rect_kernel(MotDevParams p, ClusterBuffers c) { cluster_rect_body<kSmallHullIn, false>(p, c); }
 __global__ void MOT_LAUNCH_BOUNDS(kRectBlock)
 cluster_rect_large_kernel(MotDevParams p, ClusterBuffers c) { cluster_rect_body<kMaxHullIn, true>(p, c); }

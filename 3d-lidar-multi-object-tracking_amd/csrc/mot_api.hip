@@ -1319,6 +1319,17 @@ extern "C" int mot_export_tracks_dev(mot_ctx* c, int batch, void* d_tracks, int 
   return MOT_OK;
 }
 
+extern "C" int mot_export_tracks_packed_dev(mot_ctx* c, int batch, void* d_block, long block_bytes) {
+  if (!c) return MOT_E_ARG;
+  MOT_GUARD(c);
+  const long head = ((long)batch * 4 + 15) & ~15l;
+  if (!d_block || batch < 1 || batch > c->batch || ((size_t)d_block & 15) || block_bytes < head) return fail(c, MOT_E_ARG, "mot_export_tracks_packed_dev: bad argument");
+  const long cap = (block_bytes - head) / (long)sizeof(mot_track);
+  mot_launch_export_tracks_packed(track_buffers(c, false), batch, (int*)d_block, (mot_track*)((char*)d_block + head), (int)(cap > 0x7fffffff ? 0x7fffffff : cap), c->stream);
+  MOT_HIP(c, hipGetLastError());
+  return MOT_OK;
+}
+
 extern "C" int mot_track_get_state(mot_ctx* c, int slot, int id, mot_track_state* o) {
   if (!c) return MOT_E_ARG;
   MOT_GUARD(c);

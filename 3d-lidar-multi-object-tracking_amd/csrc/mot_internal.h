@@ -260,6 +260,7 @@ enum { kTrackFlagCapacity = 1 };
 
 void mot_launch_track(const TrackBuffers& t, int batch, hipStream_t stream);
 void mot_launch_export_tracks(const TrackBuffers& t, int batch, mot_track* dst, int max_per_slot, int* dst_counts, hipStream_t stream);
+void mot_launch_export_tracks_packed(const TrackBuffers& t, int batch, int* header, mot_track* dst, int capacity, hipStream_t stream);
 
 #ifdef MOT_HIPEMU
 #define MOT_WAVE_SYNC() ((void)__ballot(1))

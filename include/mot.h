@@ -294,6 +294,14 @@ int mot_track_steps_dev(mot_ctx* ctx, const float* d_boxes_global, long box_stri
  * per-stream record block that the multi-GPU harness all-gathers over RCCL. Asynchronous on the context stream. */
 int mot_export_tracks_dev(mot_ctx* ctx, int batch, void* d_tracks, int max_per_slot, int32_t* d_counts);
 
+/* The same records PACKED into one caller-owned DEVICE block of block_bytes bytes (16-byte aligned):
+ *   int32 counts[batch]                       live tracks per slot (always the true number)
+ *   (padding to a multiple of 16 bytes)
+ *   mot_track records[]                       slot 0's live tracks in id order, then slot 1's, ... back to back
+ * as many records as fit; sum(counts) > (block_bytes - header) / sizeof(mot_track) means the tail was dropped. This is the block
+ * the multi-GPU harness all-gathers: at ~17 live tracks per stream it is a quarter of the fixed 64-slot block. Asynchronous. */
+int mot_export_tracks_packed_dev(mot_ctx* ctx, int batch, void* d_block, long block_bytes);
+
 /* ---------------------------------------------------------------- cluster-node side products
  * What OT/src/cluster/main.cpp publishes besides the boxes, computed from the elevated cloud and the label grid resident in
  * `slot` (after mot_cluster / mot_box_fit on slot 0, or mot_frames_dev on any slot). SURVEY.md 8(f) rank 3.

@@ -109,6 +109,22 @@ def ref():
     return _ref
 
 
+_ref_tf = None
+
+
+def ref_tf():
+    """the library that holds the tracking node's tf call sequence (oracle/ref_tf_capi.cpp -> ref_boxes_to_global): always the
+    default reference build, whatever set_ref_library() routes the stage functions to (the -O0 build does not carry it); None
+    when oracle/_ref is absent"""
+    global _ref_tf
+    if _ref_tf is None:
+        if not os.path.exists(REF_SO):
+            if ref() is None:
+                return None
+        _ref_tf = C.CDLL(REF_SO)
+    return _ref_tf
+
+
 def params(preset: int = 0, **overrides) -> MotParams:
     p = MotParams()
     rc = orc().orc_params_preset(preset, C.byref(p))

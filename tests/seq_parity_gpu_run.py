@@ -44,9 +44,9 @@ def main():
     p = O.params(args.preset)
     t0 = time.time()
     with mot.Context(mot.params(args.preset), max_points=stride, max_batch=S, max_tracks_total=1024) as c:
-        st = SP.check_sequence(c, O, p, lambda f: seq[f].data_ptr(), lambda f, b: seq[f, b].cpu().numpy(), n_seq, stride, ego_v, ego_yaw, units)
+        st = SP.check_sequence(c, O, p, lambda f: seq[f].data_ptr(), lambda f, b: seq[f, b].cpu().numpy(), n_seq, stride, ego_v, ego_yaw, units, skip_ill_conditioned=True)
     st.update(render_s=round(t_render, 1), check_s=round(time.time() - t0, 1), points_per_frame=int(n_seq.mean()), scenes=args.scenes, units=units,
-              reference_tf=O.ref() is not None)
+              reference_tf=O.ref_tf() is not None)
     if args.preset == 0:
         assert st["boxes"] > F and st["tracks_ever"] >= 20 and st["live_max"] >= 5, st   # the sequence really exercises the tracker
     print("sequence parity ok " + json.dumps(st))

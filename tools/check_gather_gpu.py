@@ -40,5 +40,24 @@ for ci, cx in enumerate(ctxs):
         assert cnt[b] == len(live), (ci, b, cnt[b], len(live))
         assert np.array_equal(rec[b]["id"][: cnt[b]], live) and np.allclose(rec[b]["p"][: cnt[b]], t["p"][live])
 assert all(int(s[0][1].sum()) >= 0 for s in snaps) and int(snaps[-1][0][1].sum()) > 0
+# ---- the packed form: ONE collective per frame for both contexts (multi.TrackGatherAll), forced on the one-rank group
+for cx in ctxs: cx.reset()
+tga = multi.TrackGatherAll(ctxs, B, B * 64, 1, "cuda")
+for f in range(6):
+    ts = np.full(B, 1.0e9 + f * 1e5)
+    for ci, cx in enumerate(ctxs):
+        cx.frames_dev(frames[f].data_ptr() + ci * B * stride * 16, stride * 4, [N] * B, run_tracker=True, timestamps=ts, ego_v=np.zeros(B), ego_yaw=np.zeros(B))
+    tga.step(force_collective=True)   # no host synchronisation inside the loop
+packed = tga.blocks_as_numpy()[0]
+for ci, cx in enumerate(ctxs):
+    counts, recs, trunc = packed[ci]
+    assert not trunc
+    for b in range(B):
+        t = cx.get_tracks(b)
+        live = np.nonzero(t["track_manage"] > 0)[0]
+        assert counts[b] == len(live) == len(recs[b]), (ci, b, counts[b], len(live))
+        assert np.array_equal(recs[b]["id"], live) and np.array_equal(recs[b]["p"], t["p"][live]) and np.array_equal(recs[b]["v_yaw"], t["v_yaw"][live])
+        assert np.array_equal(recs[b]["vis_box"], t["vis_box"][live])
+assert sum(int(c.sum()) for c, _, _ in packed) > 0
 print("gather check ok: live tracks per slot", [int(x) for x in tgs[0].dst_cnt[0].cpu()])
 dist.destroy_process_group()
