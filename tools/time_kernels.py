@@ -16,6 +16,14 @@ N, F = 120000, 2
 stride = ((N + 2047) // 2048) * 2048
 v, yaw = sdev.load_ego(F)
 seq, n_seq, _, _ = sdev.SequenceRenderer("cuda").render(list(range(B)), F, N, stride, v, yaw)
+import numpy as np
+with mot.Context(max_points=stride, max_batch=B) as c:   # what the box stage sees: how many elevated points lie in a labelled cell (the rest never matter after groundRemove)
+    c.frames_dev(seq[1].data_ptr(), stride * 4, n_seq[1]); c.synchronize()
+    for s_ in range(min(B, 4)):
+        g = c.get_ground(s_, want_clouds=False); cl = c.get_clusters(s_, n_elevated=g["n_elevated"]); e = c.get_ground(s_, n_hint=int(n_seq[1][s_]))["elevated"]
+        lab = cl["point_label"]; roi = (np.abs(e[:, 0]) < 25) & (np.abs(e[:, 1]) < 25)
+        print(f"stream {s_}: {g['n_elevated']} elevated, {int((lab > 0).sum())} in a labelled cell ({(lab > 0).mean():.2f}), {int(roi.sum())} inside the ROI ({roi.mean():.2f}), "
+              f"{cl['num_cluster']} clusters, {len(c.get_boxes(s_)['boxes'])} boxes", flush=True)
 libs = [None] + sorted(glob.glob(os.path.join(ROOT, "variants", "libmot_*.so"))) + [None]
 for lib in libs:
     with mot.Context(max_points=stride, max_batch=B, **({"lib_path": lib} if lib else {})) as c:
