@@ -327,7 +327,8 @@ __device__ __forceinline__ void classify_compact_body(const MotDevParams& p, con
   // occupancy of the cluster stage's Cartesian grid by this chunk's elevated points: "cell seen >= 1" / "seen >= 2"
   __shared__ unsigned s_occ_a[kPlaneWords], s_occ_b[kPlaneWords];
   __shared__ int s_occ_n;
-  const int b = blockIdx.y;
+  const int b = blockIdx.y;   // (frames in the REVERSE order of the min-z kernel, so that its last-read frames might still sit in the Infinity Cache: +1.5 % with one
+                              // context, -3 % with four; a second pass over <= 256 MiB reads at 6.0-6.7 TB/s against 5.2-6.3 cold — profiles/r03_infinity_cache_probe.txt)
   const int n = g.n[b];
   const int nchunks = (n + kCompactChunk - 1) / kCompactChunk;
   if ((int)blockIdx.x >= nchunks) {
