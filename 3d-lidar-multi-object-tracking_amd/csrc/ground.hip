@@ -582,6 +582,10 @@ void mot_launch_decode_pointcloud2(const void* data, int n, int step, int ox, in
 }
 
 // ------------------------------------------------------------------------------------------ host
+// (Capping the streaming kernels' workgroups per CU with a dynamic-LDS pad — so that they leave wave slots to the other contexts'
+// latency-bound kernels — changes nothing: 4 instead of 8 min-z workgroups per CU, 2 instead of 3 compaction workgroups, alone or
+// together, all land inside the +-3 % spread of the 4-context bench line; 1 compaction workgroup per CU loses 10 %.
+// profiles/r03_streaming_occupancy_sweep.txt)
 void mot_launch_ground_kernel(int which, const MotDevParams& p, const GroundBuffers& g, int batch, int max_n,
                               hipStream_t stream) {
   int chunks = (max_n + kGroundChunk - 1) / kGroundChunk;

@@ -15,7 +15,8 @@ host = np.zeros((B, stride, 4), np.float32)
 base = [synth.make_cloud(N, s, 0) for s in range(8)]
 for b in range(B): host[b, :N] = base[b % 8]
 dev = torch.from_numpy(host).cuda(); torch.cuda.synchronize()
-lib = build.build(extra_flags=["-DMOT_DBG_CCL_TIMING"], out=os.path.join(ROOT, "gpurun_out", "libmot_cclt.so"))
+_pre = os.path.join(ROOT, "variants", "dbg_libmot_cclt.so")   # prebuilt on the CPU box (tools/prebuild_dbg.py): no hipcc minutes on the GPU box
+lib = _pre if os.path.exists(_pre) else build.build(extra_flags=["-DMOT_DBG_CCL_TIMING"], out=os.path.join(ROOT, "gpurun_out", "libmot_cclt.so"))
 ctx = mot.Context(max_points=stride, max_batch=B, lib_path=lib)
 ctx.frames_dev(dev.data_ptr(), stride * 4, [N] * B); ctx.synchronize()
 print("ccl ms", ctx.time_stage(21, B, 3))
