@@ -350,6 +350,8 @@ cluster_index_kernel(ClusterBuffers c) {
   }
   int* __restrict__ cstart = c.cluster_start + (long)b * (kMaxClusters + 1);
   int* __restrict__ sorted = c.sorted + (long)b * c.cap;
+  const int* __restrict__ pix = c.pix + (long)b * c.cap;
+  int* __restrict__ spix = c.poly + (long)b * c.cap;   // the polygon pool doubles as the cluster-sorted pixel list until the gather kernel replaces a cluster's run by its candidates
   if (fast) {
     int2* s_tab = reinterpret_cast<int2*>(s_raw);                       // [nwg][64] {cluster, points}
     int* s_pref = reinterpret_cast<int*>(s_tab + kIndexWgLds * kWgClusters);   // [nwg][64] points of the cluster in earlier chunks
@@ -401,11 +403,34 @@ cluster_index_kernel(ClusterBuffers c) {
         mypos = s_start[mine.label - 1] + pref + within;
       }
       const int cnt = E - g0 < 64 ? E - g0 : 64;
-      for (int j = 0; j < cnt; j++) {
-        const unsigned mlo = (unsigned)wave_bcast_i32((int)(unsigned)mine.mask, j), mhi = (unsigned)wave_bcast_i32((int)(unsigned)(mine.mask >> 32), j);
-        const unsigned long long m = ((unsigned long long)mhi << 32) | mlo;
-        const int tile = wave_bcast_i32(mine.tile, j) & kGroupTileMask, pos = wave_bcast_i32(mypos, j);
-        if ((m >> lane) & 1ull) sorted[pos + __popcll(m & ((1ull << lane) - 1ull))] = tile * 64 + lane;
+      // Besides its index every point's picture PIXEL goes to the point's slot (into the polygon pool): the rectangle branch of the
+      // gather kernel then reads a cluster's pixels as ONE contiguous run instead of chasing index -> pixel (two dependent round
+      // trips per trip of its walk; a 15 k-point wall needed eight such trips: profiles/r03_gather_phases.txt). The pixel loads of
+      // eight groups are issued together; a tile's lanes read consecutive words.
+      for (int j0 = 0; j0 < cnt; j0 += 8) {
+        int pv[8];
+#pragma unroll
+        for (int u = 0; u < 8; u++) {
+          const int j = j0 + u < cnt ? j0 + u : cnt - 1;   // (uniform; the tail repeats the last group: harmless loads)
+          const unsigned mlo = (unsigned)wave_bcast_i32((int)(unsigned)mine.mask, j), mhi = (unsigned)wave_bcast_i32((int)(unsigned)(mine.mask >> 32), j);
+          const unsigned long long m = ((unsigned long long)mhi << 32) | mlo;
+          const int tile = wave_bcast_i32(mine.tile, j) & kGroupTileMask;
+          pv[u] = ((m >> lane) & 1ull) ? pix[tile * 64 + lane] : 0;
+        }
+#pragma unroll
+        for (int u = 0; u < 8; u++) {
+          const int j = j0 + u;
+          if (j < cnt) {
+            const unsigned mlo = (unsigned)wave_bcast_i32((int)(unsigned)mine.mask, j), mhi = (unsigned)wave_bcast_i32((int)(unsigned)(mine.mask >> 32), j);
+            const unsigned long long m = ((unsigned long long)mhi << 32) | mlo;
+            const int tile = wave_bcast_i32(mine.tile, j) & kGroupTileMask, pos = wave_bcast_i32(mypos, j);
+            if ((m >> lane) & 1ull) {
+              const int at = pos + __popcll(m & ((1ull << lane) - 1ull));
+              sorted[at] = tile * 64 + lane;
+              spix[at] = pv[u];
+            }
+          }
+        }
       }
     }
   } else {
@@ -425,7 +450,7 @@ cluster_index_kernel(ClusterBuffers c) {
       }
       int pos = s_start[g.label - 1] + before;
       unsigned long long m = g.mask;
-      while (m) { sorted[pos++] = gtile * 64 + __ffsll(m) - 1; m &= m - 1ull; }
+      while (m) { const int idx = gtile * 64 + __ffsll(m) - 1; sorted[pos] = idx; spix[pos] = pix[idx]; pos++; m &= m - 1ull; }
     }
   }
   B1B_T(3);
@@ -495,22 +520,29 @@ cluster_gather_kernel(MotDevParams p, ClusterBuffers c) {
     GATHER_T_BEGIN();
     const ClusterStats st = c.stats[(long)b * kMaxClusters + ci];
     const int first_slot = cstart[ci];   // (asked for together with the statistics: one round trip, not two)
-    BoxCandidate cand;
-    for (int k = 0; k < 8; k++) cand.pc[k] = 0.f;
-    cand.max_z = 0.f; cand.accepted = 0; cand.undefined = 0; cand.branch = -1;
-    cand.poly_off = 0; cand.poly_n = 0; cand.off_x = 0; cand.off_y = 0; cand.num_points = st.count; cand.pad = 0;
+    // the cluster's candidate record is assembled where it is stored (thread 0), not carried in registers across the branches
+    BoxCandidate* const cand_out = &c.cand[(long)b * kMaxClusters + ci];
+    auto store_cand = [&](const float* pc8, float max_z, int accepted, int undefined, int branch, int poly_off, int poly_n, int off_x, int off_y) {
+      BoxCandidate q;
+#pragma unroll
+      for (int k = 0; k < 8; k++) q.pc[k] = pc8 ? pc8[k] : 0.f;
+      q.max_z = max_z; q.accepted = accepted; q.undefined = undefined; q.branch = branch;
+      q.poly_off = poly_off; q.poly_n = poly_n; q.off_x = off_x; q.off_y = off_y; q.num_points = st.count; q.pad = 0;
+      return q;
+    };
     const int numPoints = st.count;
     bool have = numPoints > 0 && st.argmin != kArgminInit && st.argmax != kArgmaxInit;  // SURVEY.md H7 otherwise
     if (!have) {
-      cand.undefined = 1;
-      if (tid == 0) c.cand[(long)b * kMaxClusters + ci] = cand;
+      if (tid == 0) *cand_out = store_cand(nullptr, 0.f, 0, 1, -1, 0, 0, 0, 0);
       continue;
     }
-    // The first trip of the rectangle branch's point walk is requested HERE, next to the three points the branch decision needs,
-    // so that its round trip overlaps theirs (an L-shape cluster throws these 8 indices per thread away).
+    // The first trip of the rectangle branch's pixel walk is requested HERE, next to the three points the branch decision needs,
+    // so that its round trip overlaps theirs (an L-shape cluster throws these 8 words per thread away). The cluster's pixels lie
+    // in its run of the polygon pool, in input order (cluster_index_kernel).
+    const int* spx = c.poly + (long)b * c.cap + first_slot;   // (no __restrict__: the candidates written below replace this very run)
     int nxt[kGatherDepth];
 #pragma unroll
-    for (int u = 0; u < kGatherDepth; u++) { int j = u * kBoxBlock + tid; nxt[u] = j < numPoints ? sorted[first_slot + j] : -1; }
+    for (int u = 0; u < kGatherDepth; u++) { int j = u * kBoxBlock + tid; nxt[u] = j < numPoints ? spx[j] : 0xffff; }
     const float4 first = pts[st.first];
     const float initPX = first.x + p.roi_half, initPY = first.y + p.roi_half;  // :218-225
     const int initX = (int)floorf(initPX * p.pic_scale), initY = (int)floorf(initPY * p.pic_scale);
@@ -523,7 +555,6 @@ cluster_gather_kernel(MotDevParams p, ClusterBuffers c) {
     const float minMx = pmin.x, minMy = pmin.y, maxMx = pmax.x, maxMy = pmax.y;
     float maxZ = mot_key_float(st.maxz_key);
     if (maxZ == 0.0f && st.first_zero != 0x7fffffff) maxZ = pts[st.first_zero].z;   // -0 or +0, whichever came first
-    cand.max_z = maxZ;
     const float xDist = maxMx - minMx, yDist = maxMy - minMy;  // :296-300
     const float slopeDist = sqrtf(xDist * xDist + yDist * yDist);
     const float slope = (maxMy - minMy) / (maxMx - minMx);
@@ -532,7 +563,6 @@ cluster_gather_kernel(MotDevParams p, ClusterBuffers c) {
     GATHER_T(0);
 
     if (lshape) {  // ---------------------------------------------------------------- L-shape :310-356
-      cand.branch = 0;
       const int nsamp = p.ram_points < 128 ? p.ram_points : 128;
       {
         // mt19937_64 mt(0); uniform_int_distribution<>(0, numPoints-1): the mapping of a 64-bit draw to an index is libstdc++'s
@@ -607,9 +637,8 @@ cluster_gather_kernel(MotDevParams p, ClusterBuffers c) {
         }
       }
       best = wave_max_t<unsigned long long>(best);
-      if (best == 0ull) {
-        cand.undefined = 1;  // maxDx/maxDy would be read uninitialised (H7)
-      } else {
+      const bool undef = best == 0ull;   // maxDx/maxDy would be read uninitialised (H7)
+      if (!undef) {
         int j = 0xffff - (int)(best & 0xffffull);
         const float maxDx = pts[s_pidx[j]].x, maxDy = pts[s_pidx[j]].y;
         float maxMvecX = maxMx - maxDx, maxMvecY = maxMy - maxDy;
@@ -622,26 +651,22 @@ cluster_gather_kernel(MotDevParams p, ClusterBuffers c) {
       }
       GATHER_T(3);
       if (tid == 0) {
-        if (!cand.undefined) for (int k = 0; k < 8; k++) cand.pc[k] = pc[k];
-        cand.accepted = promising ? 1 : 0;
+        BoxCandidate cand = store_cand(undef ? nullptr : pc, maxZ, promising ? 1 : 0, undef ? 1 : 0, 0, 0, 0, 0, 0);
         GATHER_T_STORE_LSHAPE(cand);
-        c.cand[(long)b * kMaxClusters + ci] = cand;
+        *cand_out = cand;
       }
       __syncthreads();
     } else {  // ------------------------------------------------------- minAreaRect :358-366, part 1
-      cand.branch = 1;
       for (int i = tid; i < kPicCols; i += kBoxBlock) { s_colmin[i] = 0x7fffffff; s_colmax[i] = -0x7fffffff - 1; }
       __syncthreads();
-      // the cluster's points through the sorted index; what is fetched per point is its 4-byte picture pixel (label kernel)
-      const int* __restrict__ pix = c.pix + (long)b * c.cap;
-      // two dependent loads per point (sorted index -> pixel): the indices of the NEXT trip are requested right behind the
-      // pixel loads of this one (loads return in order), so a trip costs one memory round trip instead of two
+      // the cluster's pixels (x | y << 16, label kernel; x = 0xffff outside the picture), one contiguous coalesced run; the next
+      // trip is requested before this one is filed
       for (int j0 = 0; j0 < numPoints; j0 += kBoxBlock * kGatherDepth) {
         int v[kGatherDepth];
 #pragma unroll
-        for (int u = 0; u < kGatherDepth; u++) v[u] = nxt[u] >= 0 ? pix[nxt[u]] : 0xffff;
+        for (int u = 0; u < kGatherDepth; u++) v[u] = nxt[u];
 #pragma unroll
-        for (int u = 0; u < kGatherDepth; u++) { int j = j0 + kBoxBlock * kGatherDepth + u * kBoxBlock + tid; nxt[u] = j < numPoints ? sorted[first_slot + j] : -1; }
+        for (int u = 0; u < kGatherDepth; u++) { int j = j0 + kBoxBlock * kGatherDepth + u * kBoxBlock + tid; nxt[u] = j < numPoints ? spx[j] : 0xffff; }
 #pragma unroll
         for (int u = 0; u < kGatherDepth; u++) {
           const int picX = v[u] & 0xffff;
@@ -674,7 +699,7 @@ cluster_gather_kernel(MotDevParams p, ClusterBuffers c) {
         int pos = incl - cnt, total = 0;
 #pragma unroll
         for (int w2 = 0; w2 < kBoxBlock / 64; w2++) { const int ws = s_wsum[w2]; if (w2 < wave) pos += ws; total += ws; }
-        int* __restrict__ pool = c.poly + (long)b * c.cap + first_slot;
+        int* pool = c.poly + (long)b * c.cap + first_slot;   // = spx: the walk above has consumed it (barrier)
 #pragma unroll
         for (int k = 0; k < kPerThread; k++) {
           const int px = (int)(unsigned short)(short)(tid * kPerThread + k + offsetInitX);
@@ -685,9 +710,9 @@ cluster_gather_kernel(MotDevParams p, ClusterBuffers c) {
         }
         GATHER_T(2);
         if (tid == 0) {
-          cand.poly_off = first_slot; cand.poly_n = total; cand.off_x = offsetInitX; cand.off_y = offsetInitY;
+          BoxCandidate cand = store_cand(nullptr, maxZ, 0, 0, 1, first_slot, total, offsetInitX, offsetInitY);
           GATHER_T_STORE_RECT(cand);
-          c.cand[(long)b * kMaxClusters + ci] = cand;
+          *cand_out = cand;
         }
       }
       __syncthreads();
