@@ -350,8 +350,6 @@ cluster_index_kernel(ClusterBuffers c) {
   }
   int* __restrict__ cstart = c.cluster_start + (long)b * (kMaxClusters + 1);
   int* __restrict__ sorted = c.sorted + (long)b * c.cap;
-  const int* __restrict__ pix = c.pix + (long)b * c.cap;
-  int* __restrict__ spix = c.poly + (long)b * c.cap;   // the polygon pool doubles as the cluster-sorted pixel list until the gather kernel replaces a cluster's run by its candidates
   if (fast) {
     int2* s_tab = reinterpret_cast<int2*>(s_raw);                       // [nwg][64] {cluster, points}
     int* s_pref = reinterpret_cast<int*>(s_tab + kIndexWgLds * kWgClusters);   // [nwg][64] points of the cluster in earlier chunks
@@ -403,34 +401,14 @@ cluster_index_kernel(ClusterBuffers c) {
         mypos = s_start[mine.label - 1] + pref + within;
       }
       const int cnt = E - g0 < 64 ? E - g0 : 64;
-      // Besides its index every point's picture PIXEL goes to the point's slot (into the polygon pool): the rectangle branch of the
-      // gather kernel then reads a cluster's pixels as ONE contiguous run instead of chasing index -> pixel (two dependent round
-      // trips per trip of its walk; a 15 k-point wall needed eight such trips: profiles/r03_gather_phases.txt). The pixel loads of
-      // eight groups are issued together; a tile's lanes read consecutive words.
-      for (int j0 = 0; j0 < cnt; j0 += 8) {
-        int pv[8];
-#pragma unroll
-        for (int u = 0; u < 8; u++) {
-          const int j = j0 + u < cnt ? j0 + u : cnt - 1;   // (uniform; the tail repeats the last group: harmless loads)
-          const unsigned mlo = (unsigned)wave_bcast_i32((int)(unsigned)mine.mask, j), mhi = (unsigned)wave_bcast_i32((int)(unsigned)(mine.mask >> 32), j);
-          const unsigned long long m = ((unsigned long long)mhi << 32) | mlo;
-          const int tile = wave_bcast_i32(mine.tile, j) & kGroupTileMask;
-          pv[u] = ((m >> lane) & 1ull) ? pix[tile * 64 + lane] : 0;
-        }
-#pragma unroll
-        for (int u = 0; u < 8; u++) {
-          const int j = j0 + u;
-          if (j < cnt) {
-            const unsigned mlo = (unsigned)wave_bcast_i32((int)(unsigned)mine.mask, j), mhi = (unsigned)wave_bcast_i32((int)(unsigned)(mine.mask >> 32), j);
-            const unsigned long long m = ((unsigned long long)mhi << 32) | mlo;
-            const int tile = wave_bcast_i32(mine.tile, j) & kGroupTileMask, pos = wave_bcast_i32(mypos, j);
-            if ((m >> lane) & 1ull) {
-              const int at = pos + __popcll(m & ((1ull << lane) - 1ull));
-              sorted[at] = tile * 64 + lane;
-              spix[at] = pv[u];
-            }
-          }
-        }
+      // (writing every point's picture pixel to its slot as well — so that the gather kernel reads a cluster's pixels as one contiguous run
+      // instead of chasing index -> pixel — took the gather kernel from 102 to 75 us per 512 frames and THIS kernel from 52 to 127:
+      // one workgroup per frame cannot hide the extra loads. profiles/r03_box_stage_experiments.txt)
+      for (int j = 0; j < cnt; j++) {
+        const unsigned mlo = (unsigned)wave_bcast_i32((int)(unsigned)mine.mask, j), mhi = (unsigned)wave_bcast_i32((int)(unsigned)(mine.mask >> 32), j);
+        const unsigned long long m = ((unsigned long long)mhi << 32) | mlo;
+        const int tile = wave_bcast_i32(mine.tile, j) & kGroupTileMask, pos = wave_bcast_i32(mypos, j);
+        if ((m >> lane) & 1ull) sorted[pos + __popcll(m & ((1ull << lane) - 1ull))] = tile * 64 + lane;
       }
     }
   } else {
@@ -450,7 +428,7 @@ cluster_index_kernel(ClusterBuffers c) {
       }
       int pos = s_start[g.label - 1] + before;
       unsigned long long m = g.mask;
-      while (m) { const int idx = gtile * 64 + __ffsll(m) - 1; sorted[pos] = idx; spix[pos] = pix[idx]; pos++; m &= m - 1ull; }
+      while (m) { sorted[pos++] = gtile * 64 + __ffsll(m) - 1; m &= m - 1ull; }
     }
   }
   B1B_T(3);
@@ -469,6 +447,7 @@ constexpr int kBoxBlock = MOT_BOX_BLOCK;       // one workgroup per cluster
 constexpr int kGatherDepth = MOT_GATHER_DEPTH;
 constexpr int kPicCols = 1024;       // pixel columns 0..900
 constexpr int kMaxHullIn = 2 * 901;  // two extreme pixels per column
+constexpr int kSmallHullIn = 510;   // candidate points up to which a cluster goes to cluster_rect_kernel (more: cluster_rect_large_kernel)
 constexpr int kMaxHull = 384;        // vertices of a convex lattice polygon in a 900^2 box: < 3.5 * 900^(2/3) ~ 330
 
 // ruleBasedFilter :97-158 (fall-through = false)
@@ -536,13 +515,11 @@ cluster_gather_kernel(MotDevParams p, ClusterBuffers c) {
       if (tid == 0) *cand_out = store_cand(nullptr, 0.f, 0, 1, -1, 0, 0, 0, 0);
       continue;
     }
-    // The first trip of the rectangle branch's pixel walk is requested HERE, next to the three points the branch decision needs,
-    // so that its round trip overlaps theirs (an L-shape cluster throws these 8 words per thread away). The cluster's pixels lie
-    // in its run of the polygon pool, in input order (cluster_index_kernel).
-    const int* spx = c.poly + (long)b * c.cap + first_slot;   // (no __restrict__: the candidates written below replace this very run)
+    // The first trip of the rectangle branch's point walk is requested HERE, next to the three points the branch decision needs,
+    // so that its round trip overlaps theirs (an L-shape cluster throws these 8 indices per thread away).
     int nxt[kGatherDepth];
 #pragma unroll
-    for (int u = 0; u < kGatherDepth; u++) { int j = u * kBoxBlock + tid; nxt[u] = j < numPoints ? spx[j] : 0xffff; }
+    for (int u = 0; u < kGatherDepth; u++) { int j = u * kBoxBlock + tid; nxt[u] = j < numPoints ? sorted[first_slot + j] : -1; }
     const float4 first = pts[st.first];
     const float initPX = first.x + p.roi_half, initPY = first.y + p.roi_half;  // :218-225
     const int initX = (int)floorf(initPX * p.pic_scale), initY = (int)floorf(initPY * p.pic_scale);
@@ -659,14 +636,16 @@ cluster_gather_kernel(MotDevParams p, ClusterBuffers c) {
     } else {  // ------------------------------------------------------- minAreaRect :358-366, part 1
       for (int i = tid; i < kPicCols; i += kBoxBlock) { s_colmin[i] = 0x7fffffff; s_colmax[i] = -0x7fffffff - 1; }
       __syncthreads();
-      // the cluster's pixels (x | y << 16, label kernel; x = 0xffff outside the picture), one contiguous coalesced run; the next
-      // trip is requested before this one is filed
+      // the cluster's points through the sorted index; what is fetched per point is its 4-byte picture pixel (label kernel)
+      const int* __restrict__ pix = c.pix + (long)b * c.cap;
+      // two dependent loads per point (sorted index -> pixel): the indices of the NEXT trip are requested right behind the
+      // pixel loads of this one (loads return in order), so a trip costs one memory round trip instead of two
       for (int j0 = 0; j0 < numPoints; j0 += kBoxBlock * kGatherDepth) {
         int v[kGatherDepth];
 #pragma unroll
-        for (int u = 0; u < kGatherDepth; u++) v[u] = nxt[u];
+        for (int u = 0; u < kGatherDepth; u++) v[u] = nxt[u] >= 0 ? pix[nxt[u]] : 0xffff;
 #pragma unroll
-        for (int u = 0; u < kGatherDepth; u++) { int j = j0 + kBoxBlock * kGatherDepth + u * kBoxBlock + tid; nxt[u] = j < numPoints ? spx[j] : 0xffff; }
+        for (int u = 0; u < kGatherDepth; u++) { int j = j0 + kBoxBlock * kGatherDepth + u * kBoxBlock + tid; nxt[u] = j < numPoints ? sorted[first_slot + j] : -1; }
 #pragma unroll
         for (int u = 0; u < kGatherDepth; u++) {
           const int picX = v[u] & 0xffff;
@@ -699,7 +678,7 @@ cluster_gather_kernel(MotDevParams p, ClusterBuffers c) {
         int pos = incl - cnt, total = 0;
 #pragma unroll
         for (int w2 = 0; w2 < kBoxBlock / 64; w2++) { const int ws = s_wsum[w2]; if (w2 < wave) pos += ws; total += ws; }
-        int* pool = c.poly + (long)b * c.cap + first_slot;   // = spx: the walk above has consumed it (barrier)
+        int* __restrict__ pool = c.poly + (long)b * c.cap + first_slot;
 #pragma unroll
         for (int k = 0; k < kPerThread; k++) {
           const int px = (int)(unsigned short)(short)(tid * kPerThread + k + offsetInitX);
@@ -710,6 +689,7 @@ cluster_gather_kernel(MotDevParams p, ClusterBuffers c) {
         }
         GATHER_T(2);
         if (tid == 0) {
+          if (total > kSmallHullIn) c.counts[b * kCountsStride + kCntPoly] = 1;   // work for cluster_rect_large_kernel in this frame (re-armed by box_finalize_kernel)
           BoxCandidate cand = store_cand(nullptr, maxZ, 0, 0, 1, first_slot, total, offsetInitX, offsetInitY);
           GATHER_T_STORE_RECT(cand);
           *cand_out = cand;
@@ -772,7 +752,6 @@ __device__ int peel_chain(const int* src, int m, int* b0, int* b1, int sign, con
 // one wave per workgroup that is the difference between sharing a CU with the streaming kernels of the other contexts and
 // locking them out of its LDS (bench 452 k -> 469 k frames/s, profiles/r02_ablate_bench_lds.txt). The large one finds no
 // work in most launches and returns after reading its clusters' candidate records.
-constexpr int kSmallHullIn = 510;
 template <int kIn, bool kLarge>
 __device__ __forceinline__ void cluster_rect_body(const MotDevParams& p, const ClusterBuffers& c) {
   __shared__ int s_in[kIn + 2];                   // candidate points (x | y << 16), sorted by (x,y)
@@ -792,27 +771,18 @@ __device__ __forceinline__ void cluster_rect_body(const MotDevParams& p, const C
 #define RLF(v, idx) __shfl((v), (idx), 64)
 #endif
   const int* __restrict__ order = c.order + (long)b * kMaxClusters;
-  // Which clusters are this instantiation's: 64 candidates at a time, a lane each (ONE round trip for all of them; walking the
-  // clusters one by one cost two dependent loads per cluster just to find that most need nothing here — every L-shape cluster,
-  // and for the large-hull instantiation practically all of them). The clusters that do need a rectangle are dealt by falling
-  // size to the frame's workgroups forwards, then backwards, ...: whoever got a large one in a round gets a small one in the next.
-  int dealt = 0;   // rectangle clusters of this instantiation met so far (uniform)
-  for (int base = 0; base < num_cluster; base += 64) {
-    int my_ci = -1;
-    bool need = false;
-    if (base + lane < num_cluster) {
-      my_ci = order[base + lane];
-      const BoxCandidate* q = &c.cand[(long)b * kMaxClusters + my_ci];
-      need = q->branch == 1 && ((q->poly_n > kSmallHullIn) == kLarge);   // (fields the gather kernel wrote and this kernel rewrites unchanged: every workgroup counts the same set)
-    }
-    unsigned long long todo = __ballot(need);
-  while (todo) {
-    const int src = __ffsll(todo) - 1;
-    todo &= todo - 1ull;
-    const int k = dealt++, round = k / (int)gridDim.x, at = k - round * (int)gridDim.x;
-    if (((round & 1) ? (int)gridDim.x - 1 - at : at) != (int)blockIdx.x) continue;
-    const int ci = wave_bcast_i32(my_ci, src);
+  // the large-hull instantiation finds no work in almost every frame: the gather kernel leaves a per-frame flag, and without it
+  // this kernel is one load (walking the frame's clusters to discover that cost 24 us per 512 frames)
+  if (kLarge && c.counts[b * kCountsStride + kCntPoly] == 0) return;
+  // clusters by falling size, dealt to the frame's workgroups forwards, then backwards, ...: whoever got a large one in a round
+  // gets a small one in the next (45 -> 41 us)
+  for (int round = 0; round * (int)gridDim.x < num_cluster; round++) {
+    const int oi = round * (int)gridDim.x + ((round & 1) ? (int)gridDim.x - 1 - (int)blockIdx.x : (int)blockIdx.x);
+    if (oi >= num_cluster) continue;
+    const int ci = wave_uniform_i32(order[oi]);   // (a loaded value: keep the per-cluster addressing and branches scalar)
     BoxCandidate cand = c.cand[(long)b * kMaxClusters + ci];
+    if (cand.branch != 1 || cand.undefined) continue;  // L-shape clusters are complete already
+    if ((cand.poly_n > kSmallHullIn) != kLarge) continue;   // the other instantiation's cluster
     const int offsetInitX = cand.off_x, offsetInitY = cand.off_y, numPoints = cand.num_points;
     const float maxZ = cand.max_z;
     int total = cand.poly_n;
@@ -1004,7 +974,6 @@ __device__ __forceinline__ void cluster_rect_body(const MotDevParams& p, const C
       c.cand[(long)b * kMaxClusters + ci] = cand;
     }
     MOT_WAVE_SYNC();
-  }
   }
 #undef RLF
 }

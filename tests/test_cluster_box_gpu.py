@@ -296,3 +296,18 @@ def test_large_irregular_clouds(mot, hip_lib, oracle, preset):
             sd = c.cluster_products(0); osd = oracle.cluster_products(p, og["elevated"], ocl["grid"])
             for k in ("clustered", "obstacles", "cost_map"):
                 assert sd[k].shape == osd[k].shape and np.array_equal(sd[k], osd[k]), (seed, k)
+
+
+def test_wide_clusters_take_the_large_hull_kernel(mot, hip_lib, oracle):
+    """see tests/test_emu_cluster_box.py: the per-frame flag for cluster_rect_large_kernel, on the MI355X (stage-wise calls and a fused batch
+    that mixes frames with and without wide clusters)"""
+    import hiprt
+    import wide_clusters as W
+    kw = dict(t_len_max=100.0, t_area_max=200.0, t_width_max=10.0, t_ratio_max=500.0, t_pt_per_m3=0.1)
+    p = oracle.params(0, **kw)
+    with mot.Context(mot.params(0, **kw), max_points=32768, max_batch=4) as c:
+        wide = 0
+        for seed, walls in ((0, 2), (1, 0), (2, 1), (3, 0), (4, 2)):
+            bx = W.check(c, oracle, p, W.wide_wall_cloud(seed, walls))
+            wide += sum(1 for d in bx["debug"] if d["branch"] == 1 and d["num_points"] > 5000)
+        assert wide >= 4

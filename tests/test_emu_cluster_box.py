@@ -110,3 +110,17 @@ def test_emu_box_height_sign_of_zero(mot, emu_lib, oracle):
             o = oracle.cluster(p, e)
             b = c.box_fit(e, o["grid"], o["num_cluster"]); ob = oracle.box_fit(p, e, o["grid"], o["num_cluster"])
             assert len(ob["boxes"]) == 1 and np.array_equal(b["boxes"].view(np.uint32), ob["boxes"].view(np.uint32)), zs
+
+
+def test_emu_wide_clusters_take_the_large_hull_kernel(mot, emu_lib, oracle):
+    """frames with and without clusters of more than 510 candidate hull points, alternating on one context: the per-frame flag the
+    gather kernel leaves for cluster_rect_large_kernel must be raised, honoured and re-armed"""
+    import wide_clusters as W
+    p = oracle.params(0, t_len_max=100.0, t_area_max=200.0, t_width_max=10.0, t_ratio_max=500.0, t_pt_per_m3=0.1)   # let the long boxes through the rule filter
+    mp = mot.params(0, lib=mot.load_library(emu_lib), t_len_max=100.0, t_area_max=200.0, t_width_max=10.0, t_ratio_max=500.0, t_pt_per_m3=0.1)
+    with mot.Context(mp, lib_path=emu_lib, max_points=32768) as c:
+        wide = 0
+        for seed, walls in ((0, 2), (1, 0), (2, 1), (3, 0), (4, 2)):
+            bx = W.check(c, oracle, p, W.wide_wall_cloud(seed, walls))
+            wide += sum(1 for d in bx["debug"] if d["branch"] == 1 and d["num_points"] > 5000)
+        assert wide >= 4
