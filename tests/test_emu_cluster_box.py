@@ -121,6 +121,6 @@ def test_emu_wide_clusters_take_the_large_hull_kernel(mot, emu_lib, oracle):
     with mot.Context(mp, lib_path=emu_lib, max_points=32768) as c:
         wide = 0
         for seed, walls in ((0, 2), (1, 0), (2, 1), (3, 0), (4, 2)):
-            bx = W.check(c, oracle, p, W.wide_wall_cloud(seed, walls))
-            wide += sum(1 for d in bx["debug"] if d["branch"] == 1 and d["num_points"] > 5000)
+            bx, got = W.check(c, oracle, p, W.wide_wall_cloud(seed, walls))
+            wide += sum(1 for d in bx["debug"] if d["branch"] == 1 and d["num_points"] > 5000 and d["accepted"])   # a box that only the large-hull kernel can have produced
         assert wide >= 4

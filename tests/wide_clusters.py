@@ -13,7 +13,7 @@ def wide_wall_cloud(seed=0, walls=2, n_small=3):
         n = 9000
         x = rng.uniform(-22.0, 22.0, n)                       # 44 m along x: ~790 picture columns
         y = (9.0 + 4.0 * w) + rng.uniform(-0.45, 0.45, n)      # thick enough for distinct lowest / highest pixel rows per column
-        z = rng.uniform(-1.2, 0.9, n)
+        z = rng.uniform(-1.2, 0.4, n)                           # height 2.4 m: inside the rule filter
         pts.append(np.stack([x, y, z, np.ones(n)], 1))
     for k in range(n_small):
         n = 600
@@ -28,4 +28,4 @@ def check(ctx, oracle, p, cloud):
     a = ctx.cluster(cloud); b = ctx.box_fit(cloud, a["grid"], a["num_cluster"])
     assert a["num_cluster"] == cl["num_cluster"] and np.array_equal(a["grid"], cl["grid"])
     assert np.array_equal(b["boxes"].view(np.uint32), bx["boxes"].view(np.uint32)) and np.array_equal(b["box_cluster"], bx["box_cluster"]) and b["n_undefined"] == bx["n_undefined"]
-    return bx
+    return bx, b
