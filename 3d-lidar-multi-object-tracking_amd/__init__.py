@@ -40,7 +40,7 @@ class MotParams(C.Structure):
         ("gamma_g", C.c_double), ("p_g", C.c_double), ("p_d", C.c_double), ("distance_thres", C.c_double),
         ("life_time_thres", C.c_int32), ("seed_box_index", C.c_int32), ("bb_yaw_change_thres", C.c_double),
         ("first_ego_yaw_offset", C.c_double), ("seed_px", C.c_double), ("seed_py", C.c_double),
-        ("rng_mapping", C.c_int32), ("reserved_", C.c_int32),
+        ("rng_mapping", C.c_int32), ("max_tracks_ever", C.c_int32),
     ]
 
 
@@ -185,6 +185,15 @@ class Context:
         """which by-products of the ground stage the fused entry points write (OUT_GROUND | OUT_MASK; default 0: on demand)"""
         self._ck(self.lib.mot_set_fused_outputs(self._h, flags))
 
+    def _track_buffer(self, slot, max_tracks):
+        """records a call can deliver: one per track EVER created on the stream, which outgrows the number of slots on a long run"""
+        if max_tracks:
+            return max_tracks
+        hint = getattr(self, "_nt_hint", None)
+        if hint is None:
+            hint = self._nt_hint = {}
+        return max(self.max_tracks_total, hint.get(slot, 0) + 256)
+
     def _ck_tracks(self, rc, n, cap):
         """mot_get_tracks / mot_track_step deliver the records AND report MOT_E_CAPACITY once a stream has used up max_tracks_total
         (sticky until reset): a soft condition here — the records are returned, `capacity_exceeded` says so"""
@@ -256,9 +265,13 @@ class Context:
     def track_step(self, boxes_global, timestamp: float, slot: int = 0, max_tracks: int | None = None):
         """immUkfJpdaf(bBoxes, timestamp, ...) — OT/include/imm_ukf_jpda.h:19-22"""
         b = np.ascontiguousarray(boxes_global, np.float32).reshape(-1, 8, 3)
-        max_tracks = max_tracks or self.max_tracks_total
-        arr = (MotTrack * max_tracks)(); nt = C.c_int(0)
-        full = self._ck_tracks(self.lib.mot_track_step(self._h, slot, _vp(b), len(b), C.c_double(timestamp), arr, max_tracks, C.byref(nt)), nt.value, max_tracks)
+        cap = self._track_buffer(slot, max_tracks)
+        arr = (MotTrack * cap)(); nt = C.c_int(0)
+        rc = self.lib.mot_track_step(self._h, slot, _vp(b), len(b), C.c_double(timestamp), arr, cap, C.byref(nt))
+        self._nt_hint[slot] = nt.value
+        if rc == MOT_E_CAPACITY and nt.value > cap and not max_tracks:   # the step has run; only the buffer was too small: fetch again
+            return self.get_tracks(slot)
+        full = self._ck_tracks(rc, nt.value, cap)
         out = tracks_to_dict(arr, nt.value); out["capacity_exceeded"] = full
         return out
 
@@ -333,9 +346,15 @@ class Context:
         return dict(boxes=boxes[: nb.value].copy(), box_cluster=bc[: nb.value].copy(), n_undefined=nu.value)
 
     def get_tracks(self, slot: int = 0, max_tracks: int | None = None):
-        max_tracks = max_tracks or self.max_tracks_total
-        arr = (MotTrack * max_tracks)(); nt = C.c_int(0)
-        full = self._ck_tracks(self.lib.mot_get_tracks(self._h, slot, arr, max_tracks, C.byref(nt)), nt.value, max_tracks)
+        cap = self._track_buffer(slot, max_tracks)
+        arr = (MotTrack * cap)(); nt = C.c_int(0)
+        rc = self.lib.mot_get_tracks(self._h, slot, arr, cap, C.byref(nt))
+        self._nt_hint[slot] = nt.value
+        if rc == MOT_E_CAPACITY and nt.value > cap and not max_tracks:
+            cap = nt.value + 256
+            arr = (MotTrack * cap)()
+            rc = self.lib.mot_get_tracks(self._h, slot, arr, cap, C.byref(nt))
+        full = self._ck_tracks(rc, nt.value, cap)
         out = tracks_to_dict(arr, nt.value); out["capacity_exceeded"] = full
         return out
 

@@ -81,6 +81,13 @@ struct mot_ctx {
   EgoTf* d_ego = nullptr;
   int* d_nlive = nullptr;
   Vec2d* d_pos = nullptr;
+  int* d_slot_of = nullptr;
+  TrackTomb* d_tomb = nullptr;
+  unsigned long long* d_used = nullptr;
+  int* d_zomb = nullptr;
+  int* d_nzomb = nullptr;
+  int max_tracks_ever = 0;             // E: capacity of the per-ever-track arrays (positions, slot map, tombstones)
+  std::vector<char> h_trk;             // mot_get_tracks: host scratch for the slot records and the per-ever-track arrays
   Vec2d* d_cp = nullptr;
   TrackItem* d_items = nullptr;
   int* d_nitems = nullptr;
@@ -261,7 +268,7 @@ extern "C" void mot_destroy(mot_ctx* c) {
   if (c->h_argring) (void)hipHostFree(c->h_argring);
   void* bufs[] = {c->d_in, c->d_argblk, c->d_ecell, c->d_pairs, c->d_pair_count, c->d_hg, c->d_cell, c->d_desc, c->d_ticket, c->d_elev, c->d_ground, c->d_mask, c->d_counts,
                   c->d_plane_a, c->d_plane_b, c->d_ccl_parent, c->d_occ_list, c->d_occ_count, c->d_grid, c->d_label, c->d_stats, c->d_cand, c->d_boxes, c->d_box_cluster, c->d_rng, c->d_poly, c->d_groups, c->d_cluster_start, c->d_order, c->d_sorted, c->d_pix, c->d_wgtab, c->d_side_cell, c->d_side_cloud, c->d_side_obs, c->d_side_cost, c->d_side_counts, c->d_raw,
-                  c->d_tracks, c->d_nt, c->d_tboxes, c->d_gate, c->d_prog, c->d_live, c->d_tout, c->d_tflags, c->d_nlive, c->d_pos, c->d_cp, c->d_items, c->d_nitems};
+                  c->d_tracks, c->d_nt, c->d_tboxes, c->d_gate, c->d_prog, c->d_live, c->d_tout, c->d_tflags, c->d_nlive, c->d_pos, c->d_slot_of, c->d_tomb, c->d_used, c->d_zomb, c->d_nzomb, c->d_cp, c->d_items, c->d_nitems};
   for (void* b : bufs) if (b) (void)hipFree(b);
   if (c->h_counts) (void)hipHostFree(c->h_counts);
   if (c->ev0) (void)hipEventDestroy(c->ev0);
@@ -396,7 +403,15 @@ static int create_impl(mot_ctx* c) {
   MOT_HIP(c, hipMalloc(&c->d_tout, B * T * sizeof(mot_track)));
   MOT_HIP(c, hipMalloc(&c->d_tflags, B * sizeof(int)));
   MOT_HIP(c, hipMalloc(&c->d_nlive, B * sizeof(int)));
-  MOT_HIP(c, hipMalloc(&c->d_pos, B * T * sizeof(Vec2d)));
+  const size_t E = c->max_tracks_ever;
+  MOT_HIP(c, hipMalloc(&c->d_pos, B * E * sizeof(Vec2d)));
+  MOT_HIP(c, hipMalloc(&c->d_slot_of, B * E * sizeof(int)));
+  MOT_HIP(c, hipMalloc(&c->d_tomb, B * E * sizeof(TrackTomb)));
+  MOT_HIP(c, hipMalloc(&c->d_used, B * ((T + 63) / 64) * sizeof(unsigned long long)));
+  MOT_HIP(c, hipMalloc(&c->d_zomb, B * T * sizeof(int)));
+  MOT_HIP(c, hipMalloc(&c->d_nzomb, B * sizeof(int)));
+  MOT_HIP(c, hipMemsetAsync(c->d_used, 0, B * ((T + 63) / 64) * sizeof(unsigned long long), c->stream));
+  MOT_HIP(c, hipMemsetAsync(c->d_nzomb, 0, B * sizeof(int), c->stream));
   MOT_HIP(c, hipMalloc(&c->d_cp, B * kMaxBoxesPerFrame * sizeof(Vec2d)));
   MOT_HIP(c, hipMalloc(&c->d_items, B * T * sizeof(TrackItem)));
   MOT_HIP(c, hipMalloc(&c->d_nitems, sizeof(int)));
@@ -426,6 +441,12 @@ extern "C" int mot_create(const mot_params* params, int device, int max_points, 
   c->max_points = max_points;
   c->cap = (max_points + 63) / 64 * 64;  // per-slot stride of every per-point buffer: keeps 16-byte vector loads aligned
   c->max_tracks_total = max_tracks_total;
+  {  // tracks EVER created per stream that the light arrays hold (28 bytes each); mot_params.max_tracks_ever, 0 = kEverFactor x the slots
+    long e = params->max_tracks_ever > 0 ? (long)params->max_tracks_ever : (long)max_tracks_total * kEverFactor;
+    if (e < max_tracks_total) e = max_tracks_total;
+    if (e > (1l << 26)) e = 1l << 26;
+    c->max_tracks_ever = (int)e;
+  }
   int rc = make_dev_params(c->params, &c->dp, &c->err);
   if (rc == MOT_OK) rc = create_impl(c);
   if (rc != MOT_OK) {
@@ -1150,6 +1171,7 @@ static TrackBuffers track_buffers(mot_ctx* c, bool fused) {
   t.live = c->d_live; t.out = c->d_tout; t.flags = c->d_tflags; t.m_dev = fused ? c->d_counts : nullptr; t.T = c->max_tracks_total;
   t.box_stride = (long)kMaxBoxesPerFrame * 24;
   t.nlive = c->d_nlive; t.pos = c->d_pos; t.cp = c->d_cp; t.items = c->d_items; t.n_items = c->d_nitems;
+  t.slot_of = c->d_slot_of; t.tomb = c->d_tomb; t.used = c->d_used; t.zomb = c->d_zomb; t.nzomb = c->d_nzomb; t.E = c->max_tracks_ever;
   // fused path: the box stage's boxes (sensor frame) become the tracker's input through the dead-reckoned ego pose
   t.boxes_sensor = fused ? c->d_boxes : nullptr; t.ego = fused ? c->d_ego : nullptr; t.boxes_out = fused ? c->d_tboxes : nullptr;
   t.tp.gamma_g = c->params.gamma_g; t.tp.p_g = c->params.p_g; t.tp.p_d = c->params.p_d; t.tp.distance_thres = c->params.distance_thres;
@@ -1213,19 +1235,45 @@ extern "C" int mot_get_tracks(mot_ctx* c, int slot, mot_track* tracks, int max_t
   MOT_HIP(c, hipMemcpyAsync(&meta[0], c->d_nt + slot, sizeof(int), hipMemcpyDeviceToHost, c->stream));
   MOT_HIP(c, hipMemcpyAsync(&meta[1], c->d_tflags + slot, sizeof(int), hipMemcpyDeviceToHost, c->stream));
   MOT_HIP(c, hipStreamSynchronize(c->stream));
-  c->ego[slot].nt = meta[0];
-  *n_tracks = meta[0];
-  if (meta[0] > max_tracks) return fail(c, MOT_E_CAPACITY, "more tracks than the caller's buffer holds");
-  if (tracks && meta[0] > 0) {
-    MOT_HIP(c, hipMemcpyAsync(tracks, c->d_tout + (size_t)slot * c->max_tracks_total, (size_t)meta[0] * sizeof(mot_track), hipMemcpyDeviceToHost, c->stream));
+  const int n = meta[0];
+  c->ego[slot].nt = n;
+  *n_tracks = n;
+  if (n > max_tracks) return fail(c, MOT_E_CAPACITY, "more tracks than the caller's buffer holds");
+  if (tracks && n > 0) {
+    // One record per track EVER created, in the reference's index order (its output vectors are sized that way,
+    // OT/tracking/imm_ukf_jpda.cpp:995-1041). A track that still owns a slot — alive, or dead since the last step only — has its
+    // record there; of an evicted one (dead for longer) the position, lifetime_ and the static flag are kept: trackManage 0, not
+    // shown, v and yaw 0 (the reference reports the frozen state with the current ego yaw added; every consumer skips dead tracks).
+    const size_t T = c->max_tracks_total, E = c->max_tracks_ever;
+    const size_t o_out = 0, o_slot = o_out + T * sizeof(mot_track), o_tomb = o_slot + (size_t)n * sizeof(int), o_pos = (o_tomb + (size_t)n * sizeof(TrackTomb) + 15) & ~(size_t)15;
+    c->h_trk.resize(o_pos + (size_t)n * sizeof(Vec2d));
+    char* h = c->h_trk.data();
+    MOT_HIP(c, hipMemcpyAsync(h + o_out, c->d_tout + (size_t)slot * T, T * sizeof(mot_track), hipMemcpyDeviceToHost, c->stream));
+    MOT_HIP(c, hipMemcpyAsync(h + o_slot, c->d_slot_of + (size_t)slot * E, (size_t)n * sizeof(int), hipMemcpyDeviceToHost, c->stream));
+    MOT_HIP(c, hipMemcpyAsync(h + o_tomb, c->d_tomb + (size_t)slot * E, (size_t)n * sizeof(TrackTomb), hipMemcpyDeviceToHost, c->stream));
+    MOT_HIP(c, hipMemcpyAsync(h + o_pos, c->d_pos + (size_t)slot * E, (size_t)n * sizeof(Vec2d), hipMemcpyDeviceToHost, c->stream));
     MOT_HIP(c, hipStreamSynchronize(c->stream));
+    const mot_track* rec = reinterpret_cast<const mot_track*>(h + o_out);
+    const int* slot_of = reinterpret_cast<const int*>(h + o_slot);
+    const TrackTomb* tomb = reinterpret_cast<const TrackTomb*>(h + o_tomb);
+    const Vec2d* pos = reinterpret_cast<const Vec2d*>(h + o_pos);
+    for (int i = 0; i < n; i++) {
+      if (slot_of[i] >= 0 && (size_t)slot_of[i] < T) tracks[i] = rec[slot_of[i]];
+      else {
+        mot_track o;
+        memset(&o, 0, sizeof o);
+        o.id = i; o.px = (float)pos[i].x; o.py = (float)pos[i].y; o.pz = (float)(-1.73 / 2);
+        o.lifetime = tomb[i].lifetime; o.is_static = tomb[i].is_static;
+        tracks[i] = o;
+      }
+    }
   }
   // The capacity flag is STICKY: once a birth has been dropped the stream keeps answering MOT_E_CAPACITY (the records above
-  // are still delivered) until the caller starts it over with mot_reset / mot_reset_slot — a caller that ignores one error
-  // is told again on every call, not only at the next dropped birth.
+  // are still delivered) until the caller starts it over with mot_reset / mot_reset_slot / mot_reset_tracks_slot — a caller that
+  // ignores one error is told again on every call, not only at the next dropped birth.
   if (meta[1])
-    return fail(c, MOT_E_CAPACITY, "more tracks were created on this stream than max_tracks_total (the reference never frees a track): "
-                                   "births are being dropped; mot_reset_slot() starts the stream over");
+    return fail(c, MOT_E_CAPACITY, "a stream ran out of track slots (more than max_tracks_total tracks alive or just dead) or of its lifetime track budget "
+                                   "(mot_params.max_tracks_ever): births are being dropped; mot_reset_tracks_slot() starts its tracks over");
   return MOT_OK;
 }
 
@@ -1338,8 +1386,12 @@ extern "C" int mot_track_get_state(mot_ctx* c, int slot, int id, mot_track_state
   MOT_HIP(c, hipMemcpyAsync(&nt, c->d_nt + slot, sizeof(int), hipMemcpyDeviceToHost, c->stream));
   MOT_HIP(c, hipStreamSynchronize(c->stream));
   if (id >= nt) return fail(c, MOT_E_ARG, "no such track");
+  int sl = -1;
+  MOT_HIP(c, hipMemcpyAsync(&sl, c->d_slot_of + (size_t)slot * c->max_tracks_ever + id, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+  MOT_HIP(c, hipStreamSynchronize(c->stream));
+  if (sl < 0 || sl >= c->max_tracks_total) return fail(c, MOT_E_STATE, "mot_track_get_state: the track died more than a step ago; its filter state has been evicted");
   DevTrack t;
-  MOT_HIP(c, hipMemcpyAsync(&t, c->d_tracks + (size_t)slot * c->max_tracks_total + id, sizeof t, hipMemcpyDeviceToHost, c->stream));
+  MOT_HIP(c, hipMemcpyAsync(&t, c->d_tracks + (size_t)slot * c->max_tracks_total + sl, sizeof t, hipMemcpyDeviceToHost, c->stream));
   MOT_HIP(c, hipStreamSynchronize(c->stream));
   memset(o, 0, sizeof *o);
   memcpy(o->x_merge, t.x[0], 40); memcpy(o->x_cv, t.x[1], 40); memcpy(o->x_ctrv, t.x[2], 40); memcpy(o->x_rm, t.x[3], 40);

@@ -202,13 +202,21 @@ constexpr int kTrackBlock = MOT_TRACK_BLOCK;      // one workgroup (a wave per l
 constexpr int kTrackWaves = kTrackBlock / 64;
 constexpr int kGateWords = kMaxBoxesPerFrame / 64;  // gate bit-mask of one track over the frame's boxes
 
+// Track storage. The reference keeps every track it ever created (targets_ only grows, OT/tracking/imm_ukf_jpda.cpp:972-989) and
+// addresses a track by its index in that vector. Here a track's filter state lives in one of T = max_tracks_total SLOTS; a track
+// keeps its slot while it is alive and for one more step after it died (that step's outputs still show the dead track as the
+// reference would), then the slot is free again. What outlives the slot, per track EVER created, addressed by the reference's
+// index: the merged position (the over-segmentation merge tests EVERY track's last position against the visible boxes, dead
+// tracks included, :666-700), lifetime_ and the static flag (outputs), and the slot map — 28 bytes instead of ~2 KB.
+constexpr int kEverFactor = 64;   // default capacity of the per-ever-track arrays, as a multiple of max_tracks_total
+struct TrackTomb { int lifetime, is_static; };
 struct DevTrack {               // filter state of one track (the reference's class UKF, OT/include/ukf.h:15-263)
   double x[4][5];               // x_merge_, x_cv_, x_ctrv_, x_rm_
   double P[4][25];              // P_merge_, P_cv_, P_ctrv_, P_rm_ (row-major)
   double mode[3];               // modeProbCV_, modeProbCTRV_, modeProbRM_
   double zpred[3][2], S[3][4], K[3][10];
   double init_meas[2], dist_from_init, best_yaw;
-  int lifetime, track_num, is_static, is_vis, has_bbox, has_best, pad0, pad1;
+  int lifetime, track_num, is_static, is_vis, has_bbox, has_best, ref_id, pad1;   // ref_id: index the reference gives this track (its position in targets_)
   float bbox[24], best_bbox[24];
 };
 
@@ -233,8 +241,8 @@ struct TrackItem { int b, li; };  // one unit of per-track work: live track `li`
 struct EgoTf { float m[12]; };
 
 struct TrackBuffers {
-  DevTrack* tracks;             // [B][T]
-  int* nt;                      // [B] tracks ever created
+  DevTrack* tracks;             // [B][T] by SLOT
+  int* nt;                      // [B] tracks ever created = the next reference index
   const float* boxes;           // [B][box_stride] floats, 24 per box, global frame: what the tracker reads
   long box_stride;              // floats per slot (kMaxBoxesPerFrame * 24 for the library's own buffer)
   const float* boxes_sensor;    // fused path: [B][kMaxBoxesPerFrame][24] boxes of the box stage in the sensor frame, or null
@@ -243,20 +251,26 @@ struct TrackBuffers {
   const TrackFrameArgs* args;   // [B]
   unsigned long long* gate;     // [B][T][kGateWords]
   unsigned long long* prog;     // [B][T][kGateWords]
-  int* live;                    // [B][2*T]: compact list of the tracks alive at the start of the step, then their flags (0 killed by a
-                                // guard, 1 reached gating, 2 reached gating in second initialisation)
+  int* live;                    // [B][2*T]: compact list of the SLOTS of the tracks alive at the start of the step, in the order of their reference
+                                // indices; then their flags (0 killed by a guard, 1 reached gating, 2 reached gating in second initialisation)
   int* nlive;                   // [B] length of that list (written by the previous step's finish kernel)
-  Vec2d* pos;                   // [B][T] merged position (x_merge_(0..1)) of every track ever created, mirrored for the merge phase
+  Vec2d* pos;                   // [B][E] merged position (x_merge_(0..1)) of every track EVER created, by reference index, for the merge phase
+  int* slot_of;                 // [B][E] slot of the track with reference index i; -1 once it has been evicted
+  TrackTomb* tomb;              // [B][E] lifetime_ / static flag of evicted tracks
+  unsigned long long* used;     // [B][(T + 63) / 64] slots in use
+  int* zomb;                    // [B][T] slots of the tracks that died in the last step (evicted at the start of the next one)
+  int* nzomb;                   // [B]
+  int E;                        // capacity of the per-ever-track arrays
   Vec2d* cp;                    // [B][kMaxBoxesPerFrame] box centres of the frame (trackPoints)
   TrackItem* items;             // [B*T] work list of the two per-track kernels, any order
   int* n_items;                 // its length; zero between steps
-  mot_track* out;               // [B][T]
+  mot_track* out;               // [B][T] by slot
   int* flags;                   // [B] capacity flags
   const int* m_dev;             // optional: boxes per frame read from counts[b*kCountsStride + kCntBoxes] (fused path)
   int T;
   MotTrackParams tp;
 };
-enum { kTrackFlagCapacity = 1 };
+enum { kTrackFlagCapacity = 1 };   // a birth was dropped: no free slot (more than T tracks alive or just dead) or E tracks ever created
 
 void mot_launch_track(const TrackBuffers& t, int batch, hipStream_t stream);
 void mot_launch_export_tracks(const TrackBuffers& t, int batch, mot_track* dst, int max_per_slot, int* dst_counts, hipStream_t stream);

@@ -92,7 +92,7 @@ __device__ double det5(const double* a) {
 }
 
 // UKF::UKF + UKF::Initialize, ukf.cpp:20-249, 257-322
-__device__ void track_init(DevTrack* t, double zx, double zy) {
+__device__ void track_init(DevTrack* t, double zx, double zy, int ref_id) {
   for (int a = 0; a < 4; a++) {
     t->x[a][0] = zx; t->x[a][1] = zy; t->x[a][2] = 0; t->x[a][3] = 0; t->x[a][4] = 0.1;
     for (int i = 0; i < 25; i++) t->P[a][i] = 0;
@@ -104,7 +104,7 @@ __device__ void track_init(DevTrack* t, double zx, double zy) {
     for (int i = 0; i < 10; i++) t->K[m][i] = 0;
   }
   t->init_meas[0] = 0; t->init_meas[1] = 0; t->dist_from_init = 0; t->best_yaw = 0;
-  t->lifetime = 0; t->track_num = 1; t->is_static = 0; t->is_vis = 0; t->has_bbox = 0; t->has_best = 0; t->pad0 = 0; t->pad1 = 0;
+  t->lifetime = 0; t->track_num = 1; t->is_static = 0; t->is_vis = 0; t->has_bbox = 0; t->has_best = 0; t->ref_id = ref_id; t->pad1 = 0;
   for (int i = 0; i < 24; i++) { t->bbox[i] = 0.f; t->best_bbox[i] = 0.f; }
 }
 
@@ -507,12 +507,18 @@ track_prep_kernel(TrackBuffers tb) {
   Vec2d* __restrict__ cp = tb.cp + (long)b * kMaxBoxesPerFrame;
   for (int k = tid; k < M; k += 256) { double x, y; cp_from_bbox(boxes + (long)k * 24, &x, &y); cp[k].x = x; cp[k].y = y; }
   if (args.first_frame) {  // :741-795 — seed exactly one track at a hard-coded position; nothing else happens in this frame
+    // (also the start of a stream after mot_reset / mot_reset_slot / mot_reset_tracks_slot: every slot is free again)
+    unsigned long long* __restrict__ used = tb.used + (long)b * ((tb.T + 63) / 64);
+    for (int w = tid; w < (tb.T + 63) / 64; w += 256) used[w] = 0ull;
+    __syncthreads();
     if (tid == 0) {
       int n = 0;
-      if (M > tp.seed_box_index && tb.T >= 1) {
+      if (M > tp.seed_box_index && tb.T >= 1 && tb.E >= 1) {
         DevTrack* tracks = tb.tracks + (long)b * tb.T;
-        track_init(&tracks[0], tp.seed_px, tp.seed_py);
-        tb.pos[(long)b * tb.T].x = tp.seed_px; tb.pos[(long)b * tb.T].y = tp.seed_py;
+        track_init(&tracks[0], tp.seed_px, tp.seed_py, 0);   // reference index 0 in slot 0
+        tb.pos[(long)b * tb.E].x = tp.seed_px; tb.pos[(long)b * tb.E].y = tp.seed_py;
+        tb.slot_of[(long)b * tb.E] = 0;
+        used[0] = 1ull;
         mot_track o;
         o.id = 0; o.track_manage = 1; o.is_static = 0; o.is_vis = 0;
         o.px = (float)tp.seed_px; o.py = (float)tp.seed_py; o.pz = (float)(-1.73 / 2); o.lifetime = 0; o.v = 0; o.yaw = 0;
@@ -521,7 +527,7 @@ track_prep_kernel(TrackBuffers tb) {
         tb.live[(long)b * 2 * tb.T] = 0;
         n = 1;
       }
-      tb.nt[b] = n; tb.nlive[b] = n;
+      tb.nt[b] = n; tb.nlive[b] = n; tb.nzomb[b] = 0;
     }
     return;
   }
@@ -719,7 +725,7 @@ __device__ void update_group(const TrackBuffers& tb, UpdateScratch* G, int b, in
   }
   if (act && s == 0) update_bb(tp, u);
   MOT_WAVE_SYNC();
-  Vec2d* pos = tb.pos + (long)b * tb.T + t;
+  Vec2d* pos = tb.pos + (long)b * tb.E + (act ? u->ref_id : 0);   // the merged position is kept by REFERENCE index (it outlives the slot)
   if (secondInit && s == 0) {  // :882-921
     if (nm == 0) u->track_num = 0;
     else {
@@ -876,15 +882,19 @@ track_update_kernel(TrackBuffers tb) {
   }
 }
 
-// ---- T3: PD merge, PE birth, PF outputs, the live list of the next step — one workgroup per stream
+// ---- T3: eviction, PD merge, PE birth, PF outputs, the live list of the next step — one workgroup per stream
+// All loops run over the tracks that are RESIDENT (alive at the start of the step, born in it) except the merge's inner loop,
+// which the reference runs over every track ever created: that one reads 16-byte positions by reference index.
+constexpr int kMaxBornLds = kMaxBoxesPerFrame;   // a frame gives birth to at most one track per box
 __global__ void MOT_LAUNCH_BOUNDS(kTrackBlock)
 track_finish_kernel(TrackBuffers tb) {
   __shared__ unsigned long long s_matched[kGateWords];
   __shared__ int s_wcount[kTrackWaves];
-  __shared__ int s_nlive, s_born, s_nvis;
+  __shared__ int s_nlive, s_born, s_nvis, s_nz;
+  __shared__ int s_free[kMaxBornLds];        // free slots in ascending order (as many as this frame can need); the first s_born become the newborns' slots
   constexpr int kVisCap = 256;               // visible boxes of a stream held in LDS for the merge phase (more: the per-wave path)
   __shared__ double s_vb[kVisCap][12];       // corners 1..4 (x, y) and the two triangle centroids
-  __shared__ int s_vi[kVisCap];
+  __shared__ int s_vi[kVisCap], s_vr[kVisCap];   // slot and reference index of the box's track
   const int b = blockIdx.x;
   const int tid = threadIdx.x, lane = tlane(), wave = tid >> 6;
   if (b == 0 && tid == 0) *tb.n_items = 0;   // every per-track wave of this step has finished: re-arm the work list
@@ -892,21 +902,36 @@ track_finish_kernel(TrackBuffers tb) {
   if (!args.run || args.first_frame) return;
   const int M = tb.m_dev ? min(tb.m_dev[b * kCountsStride + kCntBoxes], kMaxBoxesPerFrame) : args.m;
   const int nW = (M + 63) >> 6;
-  DevTrack* __restrict__ tracks = tb.tracks + (long)b * tb.T;
-  Vec2d* __restrict__ pos = tb.pos + (long)b * tb.T;
-  unsigned long long* __restrict__ gate = tb.gate + (long)b * tb.T * kGateWords;
-  unsigned long long* __restrict__ prog = tb.prog + (long)b * tb.T * kGateWords;
-  int* __restrict__ live = tb.live + (long)b * 2 * tb.T;
-  int* __restrict__ liveok = live + tb.T;
-  mot_track* __restrict__ out = tb.out + (long)b * tb.T;
+  const int T = tb.T, E = tb.E, usedW = (T + 63) / 64;
+  DevTrack* __restrict__ tracks = tb.tracks + (long)b * T;
+  Vec2d* __restrict__ pos = tb.pos + (long)b * E;
+  int* __restrict__ slot_of = tb.slot_of + (long)b * E;
+  TrackTomb* __restrict__ tomb = tb.tomb + (long)b * E;
+  unsigned long long* __restrict__ used = tb.used + (long)b * usedW;
+  int* __restrict__ zomb = tb.zomb + (long)b * T;
+  unsigned long long* __restrict__ gate = tb.gate + (long)b * T * kGateWords;
+  unsigned long long* __restrict__ prog = tb.prog + (long)b * T * kGateWords;
+  int* __restrict__ live = tb.live + (long)b * 2 * T;
+  int* __restrict__ liveok = live + T;
+  mot_track* __restrict__ out = tb.out + (long)b * T;
   const Vec2d* __restrict__ cp = tb.cp + (long)b * kMaxBoxesPerFrame;
   const int nt0 = tb.nt[b];
   const int nlive = tb.nlive[b];
+  const int nz0 = tb.nzomb[b];
 
-  // isVisBB_ = false for every track (:813): the live ones were cleared by their prediction wave; a track that is dead has
-  // either been cleared there too, or died in an earlier step with the flag of that step still set
-  for (int t = tid; t < nt0; t += kTrackBlock) if (tracks[t].track_num == 0) tracks[t].is_vis = 0;
-  // matchingVec after the whole track loop: everything a live track claimed (see update_item)
+  // ---- eviction. The tracks that died in the LAST step were still shown by that step's outputs as the reference shows them; from
+  // this step on the reference only resets their isVisBB_ (:813) and never touches their filter again: what the outputs and the
+  // merge still need of them moves to the per-ever-track arrays, the slot is free.
+  for (int z = tid; z < nz0; z += kTrackBlock) {
+    const int sl = zomb[z];
+    const DevTrack* u = &tracks[sl];
+    const int ref = u->ref_id;
+    TrackTomb tm; tm.lifetime = u->lifetime; tm.is_static = u->is_static;
+    tomb[ref] = tm;
+    slot_of[ref] = -1;
+    atomicAnd(&used[sl >> 6], ~(1ull << (sl & 63)));
+  }
+  // matchingVec after the whole track loop: everything a live track claimed (see update_group)
   if (wave == 0) {
     for (int w = 0; w < kGateWords; w++) {
       unsigned long long m = 0ull;
@@ -923,9 +948,10 @@ track_finish_kernel(TrackBuffers tb) {
 
   // ---- PD: mergeOverSegmentation :666-700. The reference runs `for i { for j { if inside(j, box_i) {trackNum[i]=5; trackNum[j]=0;} } }`
   // over ALL tracks; the value a track ends with is decided by the last (i,j) pair that writes it. Only tracks that were live
-  // at the start of the step can carry a visible box (i); j runs over every track ever created (their merged positions).
-  for (int t = tid; t < nt0; t += kTrackBlock) { gate[(long)t * kGateWords] = 0ull; prog[(long)t * kGateWords] = 0ull; }  // reuse: [t] -> has_a / max_b+1
-  if (tid == 0) s_nvis = 0;
+  // at the start of the step can carry a visible box (i); j runs over every track ever created (their merged positions) — a dead
+  // j changes nothing about itself but still counts for i ("has_a" below), which is why the positions are kept for ever.
+  for (int li = tid; li < nlive; li += kTrackBlock) { const int sl = live[li]; gate[(long)sl * kGateWords] = 0ull; prog[(long)sl * kGateWords] = 0ull; }  // reuse: [slot] -> has_a / max_b+1
+  if (tid == 0) { s_nvis = 0; s_nz = 0; }
   __syncthreads();
 #define ICOEF(ax, ay, bx, by, px, py, cx, cy) ((((ax) - (bx)) * ((py) - (ay)) + ((ay) - (by)) * ((ax) - (px))) * (((ax) - (bx)) * ((cy) - (ay)) + ((ay) - (by)) * ((ax) - (cx))))
   // the visible boxes first (one round trip for all of them), then every (box, track) pair on its own thread; the result does
@@ -942,7 +968,7 @@ track_finish_kernel(TrackBuffers tb) {
           double* q = s_vb[v];
           q[0] = v1x; q[1] = v1y; q[2] = v2x; q[3] = v2y; q[4] = v3x; q[5] = v3y; q[6] = v4x; q[7] = v4y;
           q[8] = (v1x + v2x + v3x) / 3; q[9] = (v1y + v2y + v3y) / 3; q[10] = (v1x + v4x + v3x) / 3; q[11] = (v1y + v4y + v3y) / 3;
-          s_vi[v] = i;
+          s_vi[v] = i; s_vr[v] = a->ref_id;
         }
       }
     }
@@ -951,8 +977,8 @@ track_finish_kernel(TrackBuffers tb) {
   const int nvis = s_nvis;
   if (nvis <= kVisCap) {
     for (int pr = tid; pr < nvis * nt0; pr += kTrackBlock) {
-      const int v = pr / nt0, j = pr - v * nt0, i = s_vi[v];
-      if (j == i) continue;
+      const int v = pr / nt0, j = pr - v * nt0, i = s_vi[v], ri = s_vr[v];
+      if (j == ri) continue;
       const double* q = s_vb[v];
       const double v1x = q[0], v1y = q[1], v2x = q[2], v2y = q[3], v3x = q[4], v3y = q[5], v4x = q[6], v4y = q[7], cp1x = q[8], cp1y = q[9], cp2x = q[10], cp2y = q[11];
       const Vec2d w = pos[j];
@@ -961,8 +987,9 @@ track_finish_kernel(TrackBuffers tb) {
              c3 = ICOEF(v3x, v3y, v2x, v2y, px, py, cp1x, cp1y), c4 = ICOEF(v1x, v1y, v4x, v4y, px, py, cp2x, cp2y),
              c5 = ICOEF(v1x, v1y, v3x, v3y, px, py, cp2x, cp2y), c6 = ICOEF(v3x, v3y, v4x, v4y, px, py, cp2x, cp2y);
       if ((c1 > 0 && c2 > 0 && c3 > 0) || (c4 > 0 && c5 > 0 && c6 > 0)) {
-        atomicMax(&prog[(long)j * kGateWords], (unsigned long long)(i + 1));  // j is zeroed by (i, j)
-        gate[(long)i * kGateWords] = 1ull;                                     // i is set to 5 by some (i, j)
+        const int sj = slot_of[j];
+        if (sj >= 0) atomicMax(&prog[(long)sj * kGateWords], (unsigned long long)(ri + 1));  // j is zeroed by (i, j); an evicted j is dead already
+        gate[(long)i * kGateWords] = 1ull;                                                    // i is set to 5 by some (i, j)
       }
     }
   } else {   // more visible boxes than the LDS list holds: a wave per box
@@ -970,11 +997,12 @@ track_finish_kernel(TrackBuffers tb) {
       const int i = live[li];
       const DevTrack* a = &tracks[i];
       if (!a->is_vis) continue;
+      const int ri = a->ref_id;
       const double v1x = a->bbox[0], v1y = a->bbox[1], v2x = a->bbox[3], v2y = a->bbox[4], v3x = a->bbox[6], v3y = a->bbox[7], v4x = a->bbox[9], v4y = a->bbox[10];
       const double cp1x = (v1x + v2x + v3x) / 3, cp1y = (v1y + v2y + v3y) / 3, cp2x = (v1x + v4x + v3x) / 3, cp2y = (v1y + v4y + v3y) / 3;
       bool any = false;
       for (int j = lane; j < nt0; j += 64) {
-        if (j == i) continue;
+        if (j == ri) continue;
         const Vec2d q = pos[j];
         const double px = q.x, py = q.y;
         double c1 = ICOEF(v1x, v1y, v2x, v2y, px, py, cp1x, cp1y), c2 = ICOEF(v1x, v1y, v3x, v3y, px, py, cp1x, cp1y),
@@ -982,7 +1010,8 @@ track_finish_kernel(TrackBuffers tb) {
                c5 = ICOEF(v1x, v1y, v3x, v3y, px, py, cp2x, cp2y), c6 = ICOEF(v3x, v3y, v4x, v4y, px, py, cp2x, cp2y);
         if ((c1 > 0 && c2 > 0 && c3 > 0) || (c4 > 0 && c5 > 0 && c6 > 0)) {
           any = true;
-          atomicMax(&prog[(long)j * kGateWords], (unsigned long long)(i + 1));
+          const int sj = slot_of[j];
+          if (sj >= 0) atomicMax(&prog[(long)sj * kGateWords], (unsigned long long)(ri + 1));
         }
       }
       if (__any(any) && lane == 0) gate[(long)i * kGateWords] = 1ull;
@@ -990,95 +1019,117 @@ track_finish_kernel(TrackBuffers tb) {
   }
 #undef ICOEF
   __syncthreads();
-  for (int t = tid; t < nt0; t += kTrackBlock) {
-    bool has_a = gate[(long)t * kGateWords] != 0ull;
-    int bmax = (int)prog[(long)t * kGateWords] - 1;  // largest i whose box contains t, or -1
-    if (bmax >= 0 && (!has_a || bmax > t)) tracks[t].track_num = 0;
-    else if (has_a) tracks[t].track_num = 5;
+  for (int li = tid; li < nlive; li += kTrackBlock) {   // (a track that was dead before the step keeps trackNum 0 whatever the pairs say)
+    const int sl = live[li];
+    const int ref = tracks[sl].ref_id;
+    bool has_a = gate[(long)sl * kGateWords] != 0ull;
+    int bmax = (int)prog[(long)sl * kGateWords] - 1;  // largest reference index whose box contains this track, or -1
+    if (bmax >= 0 && (!has_a || bmax > ref)) tracks[sl].track_num = 0;
+    else if (has_a) tracks[sl].track_num = 5;
   }
   if (tid == 0) s_born = 0;
   __syncthreads();
 
-  // ---- PE: birth :972-989 — one new track per unclaimed box, in box order
+  // ---- PE: birth :972-989 — one new track per unclaimed box, in box order. Free slots first (ascending, at most one per box).
   if (wave == 0) {
+    int nfree = 0;
+    for (int w0 = 0; w0 < usedW && nfree < kMaxBornLds; w0 += 64) {
+      const int w = w0 + lane;
+      unsigned long long fr = 0ull;
+      if (w < usedW) {
+        fr = ~used[w];
+        const int hi = T - w * 64;                     // slots of this word that exist
+        if (hi < 64) fr &= hi <= 0 ? 0ull : ((1ull << hi) - 1ull);
+      }
+      const int cnt = __popcll(fr);
+      const int incl = wave_scan_incl_i32(cnt);
+      int at = nfree + incl - cnt;
+      while (fr && at < kMaxBornLds) { s_free[at++] = w * 64 + __ffsll(fr) - 1; fr &= fr - 1ull; }
+      nfree += wave_bcast_i32(incl, 63);
+    }
+    if (nfree > kMaxBornLds) nfree = kMaxBornLds;
     int born = 0;
+    bool dropped = false;
     for (int w = 0; w * 64 < M; w++) {
       int k = w * 64 + lane;
       bool un = k < M && !((s_matched[w] >> lane) & 1ull);
       unsigned long long um = __ballot(un);
       if (un) {
-        int idx = nt0 + born + __popcll(um & ((1ull << lane) - 1ull));
-        if (idx < tb.T) { const Vec2d c = cp[k]; track_init(&tracks[idx], c.x, c.y); pos[idx] = c; }
+        const int r = born + __popcll(um & ((1ull << lane) - 1ull));   // rank among this frame's births
+        const int ref = nt0 + r;
+        if (r < nfree && ref < E) {
+          const int sl = s_free[r];
+          const Vec2d c = cp[k];
+          track_init(&tracks[sl], c.x, c.y, ref);
+          pos[ref] = c; slot_of[ref] = sl;
+          atomicOr(&used[sl >> 6], 1ull << (sl & 63));
+        }
       }
       born += __popcll(um);
     }
+    int ok_born = born < nfree ? born : nfree;
+    if (nt0 + ok_born > E) ok_born = E - nt0 > 0 ? E - nt0 : 0;
+    dropped = ok_born < born;
     if (lane == 0) {
-      int n = nt0 + born;
-      if (n > tb.T) { n = tb.T; atomicOr(&tb.flags[b], (int)kTrackFlagCapacity); }
-      tb.nt[b] = n; s_born = n;
+      if (dropped) atomicOr(&tb.flags[b], (int)kTrackFlagCapacity);
+      tb.nt[b] = nt0 + ok_born; s_born = ok_born;
     }
   }
   if (tid == 0) s_nlive = 0;
   __syncthreads();
-  const int nt1 = s_born;
+  const int nb = s_born;
 
-  // ---- PF: outputs + static classification :995-1081; the tracks that are alive now, in index order, are the next step's work
-  for (int base = 0; base < nt1; base += kTrackBlock) {
-    const int t = base + tid;
+  // ---- PF: outputs + static classification :995-1081 of the tracks that were alive at the start of the step and of the newborn (the
+  // reference recomputes every track it ever created; for one that was dead before the step nothing changes but its yaw output,
+  // which follows the ego yaw — nobody reads a dead track's yaw, mot_get_tracks reports 0). The tracks alive now, in the order
+  // of their reference indices (survivors keep their order, the newborn follow), are the next step's work; the ones that died
+  // in this step keep their slot and outputs for one more step.
+  for (int base = 0; base < nlive + nb; base += kTrackBlock) {
+    const int e = base + tid;
     bool alive = false;
-    if (t < nt1) {
-      DevTrack* u = &tracks[t];
+    int sl = -1;
+    if (e < nlive + nb) {
+      sl = e < nlive ? live[e] : s_free[e - nlive];
+      DevTrack* u = &tracks[sl];
       double tx = u->x[0][0], ty = u->x[0][1], mx = u->init_meas[0], my = u->init_meas[1];
       u->dist_from_init = sqrt((tx - mx) * (tx - mx) + (ty - my) * (ty - my));
       if (!u->is_static && u->track_num == 5 && u->lifetime > 8) {
         if (u->dist_from_init < 3.0 && (u->mode[2] > u->mode[0] || u->mode[2] > u->mode[1])) u->is_static = 1;
       }
       mot_track o;
-      o.id = t; o.track_manage = u->track_num; o.is_static = u->is_static; o.is_vis = u->is_vis;
+      o.id = u->ref_id; o.track_manage = u->track_num; o.is_static = u->is_static; o.is_vis = u->is_vis;
       o.px = (float)tx; o.py = (float)ty; o.pz = (float)(-1.73 / 2); o.lifetime = u->lifetime;
       o.v = u->x[0][2];
       o.yaw = wrap_pi(u->x[0][3] + args.ego_yaw);
       for (int i = 0; i < 24; i++) o.vis_box[i] = u->is_vis ? u->bbox[i] : 0.f;
-      out[t] = o;
+      out[sl] = o;
       alive = u->track_num != 0;
+      if (!alive) zomb[atomicAdd(&s_nz, 1)] = sl;   // died in this step (any order)
     }
     unsigned long long bm = __ballot(alive);
     if (lane == 0) s_wcount[wave] = __popcll(bm);
     __syncthreads();
     int off = s_nlive;
     for (int w = 0; w < wave; w++) off += s_wcount[w];
-    if (alive) live[off + __popcll(bm & ((1ull << lane) - 1ull))] = t;
+    if (alive) live[off + __popcll(bm & ((1ull << lane) - 1ull))] = sl;   // (off + rank <= e: never ahead of an entry still to be read)
     __syncthreads();
     if (tid == 0) { int s = 0; for (int w = 0; w < kTrackWaves; w++) s += s_wcount[w]; s_nlive += s; }
     __syncthreads();
   }
-  if (tid == 0) tb.nlive[b] = s_nlive;
+  if (tid == 0) { tb.nlive[b] = s_nlive; tb.nzomb[b] = s_nz; }
 }
 
-// live tracks of a stream, in id order, into the caller's fixed-size record block
-__global__ void export_tracks_kernel(const mot_track* out, const int* nt, int T, mot_track* dst, int max_per_slot, int* dst_counts) {
-  __shared__ int s_w[kTrackWaves];
-  __shared__ int s_off;
-  const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const mot_track* src = out + (long)b * T;
-  const int n = nt[b];
-  if (tid == 0) s_off = 0;
-  __syncthreads();
-  for (int base = 0; base < n; base += kTrackBlock) {
-    int t = base + tid;
-    bool alive = t < n && src[t].track_manage != 0;
-    unsigned long long bm = __ballot(alive);
-    if (lane == 0) s_w[wave] = __popcll(bm);
-    __syncthreads();
-    int off = s_off;
-    for (int w = 0; w < wave; w++) off += s_w[w];
-    int pos = off + __popcll(bm & ((1ull << lane) - 1ull));
-    if (alive && pos < max_per_slot) dst[(long)b * max_per_slot + pos] = src[t];
-    __syncthreads();
-    if (tid == 0) { int s2 = 0; for (int w = 0; w < kTrackWaves; w++) s2 += s_w[w]; s_off += s2; }
-    __syncthreads();
-  }
-  if (tid == 0) dst_counts[b] = s_off < max_per_slot ? s_off : max_per_slot;
+// live tracks of a stream, in id order, into the caller's fixed-size record block. The live list the finish kernel left for the next
+// step IS the set of tracks with track_manage != 0, in the order of their reference indices.
+__global__ void export_tracks_kernel(const mot_track* out, const int* nlive, const int* live, int T, mot_track* dst, int max_per_slot, int* dst_counts) {
+  const int b = blockIdx.x, tid = threadIdx.x;
+  const int n = nlive[b] < max_per_slot ? nlive[b] : max_per_slot;
+  const int* __restrict__ ids = live + (long)b * 2 * T;
+  const int* __restrict__ s32 = reinterpret_cast<const int*>(out + (long)b * T);
+  int* __restrict__ d32 = reinterpret_cast<int*>(dst + (long)b * max_per_slot);
+  constexpr int kW = (int)(sizeof(mot_track) / 4);
+  for (int e = tid; e < n * kW; e += kTrackBlock) { const int i = e / kW, w = e - i * kW; d32[(long)i * kW + w] = s32[(long)ids[i] * kW + w]; }
+  if (tid == 0) dst_counts[b] = n;
 }
 // The same records PACKED: header counts[batch], then the live tracks of stream 0, stream 1, ... back to back (stream-major, id order
 // inside a stream) — what crosses GPUs each frame (multi.TrackGatherAll): 3-4x fewer bytes than the fixed 64 slots per stream.
@@ -1113,7 +1164,7 @@ void mot_launch_export_tracks_packed(const TrackBuffers& t, int batch, int* head
 }
 
 void mot_launch_export_tracks(const TrackBuffers& t, int batch, mot_track* dst, int max_per_slot, int* dst_counts, hipStream_t stream) {
-  hipLaunchKernelGGL(export_tracks_kernel, dim3(batch), dim3(kTrackBlock), 0, stream, t.out, t.nt, t.T, dst, max_per_slot, dst_counts);
+  hipLaunchKernelGGL(export_tracks_kernel, dim3(batch), dim3(kTrackBlock), 0, stream, t.out, t.nlive, t.live, t.T, dst, max_per_slot, dst_counts);
 }
 
 void mot_launch_track(const TrackBuffers& t, int batch, hipStream_t stream) {

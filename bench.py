@@ -109,7 +109,7 @@ def gpu_sequence_results(mot, device, seq_dev, n_seq, stride, ego_v, ego_yaw, st
     F = seq_dev.shape[0]
     dig = lambda a: hashlib.blake2b(np.ascontiguousarray(a[..., :3] if a.ndim == 2 and a.shape[-1] == 4 else a).tobytes(), digest_size=16).hexdigest()   # clouds: x, y, z (PointXYZ has no 4th value)
     out = []
-    with mot.Context(device=device, max_points=stride, max_batch=1, max_tracks_total=1024, **({"lib_path": lib_path} if lib_path else {})) as c:
+    with mot.Context(device=device, max_points=stride, max_batch=1, max_tracks_total=256, **({"lib_path": lib_path} if lib_path else {})) as c:
         for f in range(F):
             n = int(n_seq[f, stream])
             c.frames_dev(seq_dev[f, stream].data_ptr(), stride * 4, [n], run_tracker=True, timestamps=[1.0e9 + f * 1e5], ego_v=[float(ego_v[f])], ego_yaw=[float(ego_yaw[f])])
@@ -335,10 +335,20 @@ def single_stream(mot, torch, device, seq_dev, n_seq, stride, ego_v, ego_yaw, fr
             frame(f)
         c.synchronize()
         thr = F / (time.perf_counter() - t0)
+        # where a single frame's 0.2 ms goes: every kernel of the sequence timed alone on this one frame (HIP events around the kernel,
+        # mot_time_stage) — their sum is what the GPU needs for the dependent chain even if launching cost nothing (what a hipGraph
+        # could remove is the rest)
+        try:
+            k_us = {k: c.time_stage(v, 1, 20 if v != 40 else 3) * 1e3 for k, v in K_IDS.items()}
+        except Exception:
+            k_us = None
     lat_ms = np.array(lat) * 1e3
     return {"frames": F, "latency_ms": {"median": round(float(np.median(lat_ms)), 4), "p95": round(_pct(lat_ms, 95), 4), "max": round(float(lat_ms.max()), 4)},
             "frames_per_s_latency_bound": round(1e3 / float(np.mean(lat_ms)), 1), "frames_per_s_back_to_back": round(thr, 1),
             "hbm_frac_back_to_back": round(frame_bytes * thr / 1e9 / HBM_PEAK_GBS, 5), "tracks_ever": n_tracks,
+            "kernel_chain_us": ({"sum": round(sum(k_us.values()), 1), "per_kernel": {k: round(v, 1) for k, v in k_us.items()},
+                                 "what": "each kernel of the frame's sequence alone on ONE frame (event to event, includes that one launch): the dependent chain the GPU executes per frame; "
+                                         "median latency minus this sum bounds what capturing the sequence in a hipGraph could save"} if k_us else None),
             "what": "one stream, one 120k-pt frame per launch sequence (the reference's operating point), inputs resident in HBM; latency = launches + "
                     "synchronise per frame, back_to_back = no wait between frames; the batched headline amortises the same launches over 512 frames"}
 
@@ -359,7 +369,7 @@ def host_boundary_pipelined(mot, torch, device, seq_dev, n_seq, stride, n_points
     tp = C.c_void_p(); cp = C.c_void_p()
     assert lib.mot_host_alloc(C.c_size_t(contexts * slots * K * TRACK_RECORD_BYTES), C.byref(tp)) == 0
     assert lib.mot_host_alloc(C.c_size_t(contexts * slots * 4), C.byref(cp)) == 0
-    ctxs = [mot.Context(device=device, max_points=stride, max_batch=slots, max_tracks_total=2048) for _ in range(contexts)]
+    ctxs = [mot.Context(device=device, max_points=stride, max_batch=slots, max_tracks_total=256) for _ in range(contexts)]
     frame_bytes = slots * stride * 16
 
     def run(nb):
@@ -545,7 +555,7 @@ def main():
     render_s = time.perf_counter() - t_r
     n_seq = np.ascontiguousarray(n_seq, np.int32)
     variant = os.environ.get("MOT_BENCH_LIB")   # experiments only (tools/ablate.py bench ...): a variant build of the library; the line then says so
-    ctxs = [mot.Context(device=local, max_points=stride, max_batch=Bc, max_tracks_total=4096, **({"lib_path": variant} if variant else {})) for _ in range(NC)]
+    ctxs = [mot.Context(device=local, max_points=stride, max_batch=Bc, max_tracks_total=256, **({"lib_path": variant} if variant else {})) for _ in range(NC)]
     ctx = ctxs[0]
     # ONE collective per frame tick for all contexts of the rank, of packed blocks (multi.TrackGatherAll): counts header + the live
     # records back to back, capacity GATHER_RECORDS_PER_STREAM per stream on average (the header carries the true counts; a block that

@@ -129,12 +129,15 @@ typedef struct mot_params {
    * draw for a 1000-point cluster): pick the one the reference build you replace was compiled with and the boxes are
    * identical; pick the other and they still are, except with that probability (tests/test_oracle_vs_ref.py). */
   int32_t rng_mapping;
-  int32_t reserved_;
+  /* ---- track storage: how many tracks a stream may CREATE over its lifetime (the per-ever-track arrays: 28 bytes each);
+   * 0 (preset) = 64 x max_tracks_total. See mot_create. */
+  int32_t max_tracks_ever;
 } mot_params;
 
 /* one record per track EVER created on a stream (the reference's output vectors are sized that
  * way: targetPoints / targetVandYaw / trackManage / isStaticVec / isVisVec,
- * OT/tracking/imm_ukf_jpda.cpp:995-1041). 144 bytes. */
+ * OT/tracking/imm_ukf_jpda.cpp:995-1041). 144 bytes. A track that died more than one step ago is reported with
+ * track_manage 0, is_vis 0, its last position, lifetime and static flag, v = yaw = 0. */
 typedef struct mot_track {
   int32_t id;           /* index into targets_ */
   int32_t track_manage; /* trackNumVec_[id] : 0 dead, 1..3 tentative, 5 confirmed, 6..9 coasting */
@@ -163,7 +166,13 @@ typedef struct mot_ctx mot_ctx;
 int mot_abi_version(void);
 int mot_params_preset(int preset, mot_params* out);
 /* device: HIP device ordinal. max_points: capacity per frame. max_batch: number of stream slots (>=1).
- * max_tracks_total: capacity of "tracks ever created" per stream (the reference never frees them). */
+ * max_tracks_total: track SLOTS per stream = how many tracks may be alive (or dead since the last step) at the same time.
+ * The reference never frees a track (targets_ only grows, OT/tracking/imm_ukf_jpda.cpp:972-989) and addresses tracks by their
+ * index in that vector; here the filter state (~2 KB) of a track is evicted one step after the track died, while the index
+ * keeps counting: ids, output order and every result stay those of the reference with unbounded memory. Per track EVER
+ * created 28 bytes remain (its last position — the reference's merge step tests dead tracks' positions too — lifetime and
+ * static flag): mot_params.max_tracks_ever of them, 64 x max_tracks_total by default. A birth that finds no slot or exceeds
+ * that budget is dropped and reported (MOT_E_CAPACITY, sticky). */
 int mot_create(const mot_params* params, int device, int max_points, int max_batch,
                int max_tracks_total, mot_ctx** out);
 void mot_destroy(mot_ctx* ctx);
@@ -235,7 +244,7 @@ int mot_ego_update(mot_ctx* ctx, int slot, double timestamp, double v_gps, doubl
  * boxes_global: m x 8 x 3 floats in the global frame. tracks: capacity max_tracks records. */
 int mot_track_step(mot_ctx* ctx, int slot, const float* boxes_global, int m, double timestamp,
                    mot_track* tracks, int max_tracks, int* n_tracks);
-/* filter state of track `id` on `slot` (parity/debug) */
+/* filter state of track `id` (reference index) on `slot` (parity/debug); MOT_E_STATE once the track has been dead for more than a step */
 int mot_track_get_state(mot_ctx* ctx, int slot, int id, mot_track_state* out);
 
 /* ---------------------------------------------------------------- fused frame, DEVICE buffers
@@ -279,8 +288,9 @@ int mot_get_ground(mot_ctx* ctx, int slot, float* elevated_xyzw, int* n_elevated
 int mot_get_clusters(mot_ctx* ctx, int slot, int32_t* grid, int* num_cluster, int32_t* point_label, int label_capacity);
 int mot_get_boxes(mot_ctx* ctx, int slot, float* boxes, int max_boxes, int* n_boxes, int32_t* box_cluster,
                   int* n_undefined);
-/* MOT_E_CAPACITY with the records still delivered when births were dropped on this stream (more tracks ever created than
- * max_tracks_total; the reference never frees a track): the condition is STICKY until mot_reset / mot_reset_slot. */
+/* MOT_E_CAPACITY with the records still delivered when births were dropped on this stream (no free track slot, or
+ * max_tracks_ever tracks created): the condition is STICKY until mot_reset / mot_reset_slot / mot_reset_tracks_slot.
+ * n_tracks = tracks ever created (the reference's vector length); MOT_E_CAPACITY without records when that exceeds max_tracks. */
 int mot_get_tracks(mot_ctx* ctx, int slot, mot_track* tracks, int max_tracks, int* n_tracks);
 
 /* immUkfJpdaf for one frame of every slot 0..batch-1 with the boxes already on the DEVICE (global frame):

@@ -43,7 +43,7 @@ class MotParams(C.Structure):
         ("gamma_g", C.c_double), ("p_g", C.c_double), ("p_d", C.c_double), ("distance_thres", C.c_double),
         ("life_time_thres", C.c_int32), ("seed_box_index", C.c_int32), ("bb_yaw_change_thres", C.c_double),
         ("first_ego_yaw_offset", C.c_double), ("seed_px", C.c_double), ("seed_py", C.c_double),
-        ("rng_mapping", C.c_int32), ("reserved_", C.c_int32),
+        ("rng_mapping", C.c_int32), ("max_tracks_ever", C.c_int32),
     ]
 
 
@@ -276,16 +276,16 @@ class Tracker:
         return state_to_dict(s)
 
 
+_TRACK_DT = np.dtype([("id", "i4"), ("track_manage", "i4"), ("is_static", "i4"), ("is_vis", "i4"), ("p", "f4", 3), ("lifetime", "i4"), ("v_yaw", "f8", 2), ("vis_box", "f4", 24)])
+
+
 def tracks_to_dict(arr, n):
-    return dict(
-        n=n,
-        track_manage=np.array([arr[i].track_manage for i in range(n)], np.int32),
-        is_static=np.array([arr[i].is_static for i in range(n)], np.int32),
-        is_vis=np.array([arr[i].is_vis for i in range(n)], np.int32),
-        lifetime=np.array([arr[i].lifetime for i in range(n)], np.int32),
-        p=np.array([[arr[i].px, arr[i].py, arr[i].pz] for i in range(n)], np.float32).reshape(n, 3),
-        v_yaw=np.array([[arr[i].v, arr[i].yaw] for i in range(n)], np.float64).reshape(n, 2),
-        vis_box=np.array([arr[i].vis_box[:] for i in range(n)], np.float32).reshape(n, 24))
+    if n == 0:
+        return dict(n=0, track_manage=np.zeros(0, np.int32), is_static=np.zeros(0, np.int32), is_vis=np.zeros(0, np.int32), lifetime=np.zeros(0, np.int32),
+                    p=np.zeros((0, 3), np.float32), v_yaw=np.zeros((0, 2)), vis_box=np.zeros((0, 24), np.float32))
+    buf = np.frombuffer(arr, dtype=_TRACK_DT, count=n)
+    return dict(n=n, track_manage=buf["track_manage"].copy(), is_static=buf["is_static"].copy(), is_vis=buf["is_vis"].copy(), lifetime=buf["lifetime"].copy(),
+                p=buf["p"].copy(), v_yaw=buf["v_yaw"].copy(), vis_box=buf["vis_box"].copy())
 
 
 def state_to_dict(s: MotTrackState):

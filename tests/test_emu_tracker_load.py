@@ -27,3 +27,12 @@ def test_angles_beyond_32_turns_emulated(mot, oracle):
     import build_emu
     import tracker_cases as TC
     TC.angle_far_beyond_32_turns(mot, oracle, lib_path=build_emu.build())
+
+
+def test_long_run_on_bounded_track_slots_emulated(mot, oracle):
+    """far more tracks created than there are slots: every frame equal to the oracle with unbounded memory (eviction one step after death,
+    positions of dead tracks kept for the merge step)"""
+    import build_emu
+    import tracker_cases as TC
+    st = TC.long_run_bounded_slots(mot, oracle, lib_path=build_emu.build(), frames=700, slots=16, spots=9)
+    assert st["tracks_ever"] >= 64

@@ -125,7 +125,7 @@ def test_tracker_edge_cases(mot, hip_lib, oracle):
                 b[k, :, :2] = (np.array([[0, 0], [2, 0], [2, 1], [0, 1]] * 2) + [cx, cy])
             out = c.track_step(b, ts)
             full |= out["capacity_exceeded"]
-            assert out["n"] <= 8
+            assert int((out["track_manage"] > 0).sum()) <= 8   # 8 slots
         assert full
 
 
@@ -216,3 +216,19 @@ def test_tracker_random_and_degenerate_sequences(mot, hip_lib, oracle, preset):
                         scale = max(np.abs(so[k]).max(), 1e-300)
                         assert np.abs(np.asarray(sa[k]) - so[k]).max() <= RTOL * scale + 1e-9, (seed, f, int(i), k)
             T.close()
+
+
+def test_long_run_on_256_track_slots(mot, hip_lib, oracle):
+    """10 000 frames on max_tracks_total = 256 slots, thousands of tracks created: every frame the discrete outputs of every track ever
+    created equal the oracle's with unbounded memory (the reference never frees a track, imm_ukf_jpda.cpp:972-989); filter states of the
+    live tracks every 50 frames. The world replays the situation in which a dead track's last position decides a live track's fate."""
+    import tracker_cases as TC
+    st = TC.long_run_bounded_slots(mot, oracle, frames=10000, slots=256, spots=40, state_every=50, min_ever_factor=8)
+    assert st["tracks_ever"] >= 2048 and st["max_rel_state_err"] <= RTOL
+
+
+def test_long_run_on_few_slots(mot, hip_lib, oracle):
+    """the same with 24 slots for up to ~20 live tracks: slots are recycled constantly"""
+    import tracker_cases as TC
+    st = TC.long_run_bounded_slots(mot, oracle, frames=2500, slots=24, spots=14, state_every=25, min_ever_factor=8)
+    assert st["tracks_ever"] >= 192

@@ -89,3 +89,79 @@ def angle_far_beyond_32_turns(mot, oracle, lib_path=None):
                 hit_dt |= any(s["track_manage"] > 0 and abs(s["x_ctrv"][4]) * 6000.0 > 64 * np.pi for s in pre)
         T.close()
     assert hit_ego and hit_dt
+
+
+def blinking_world(seed, spots, frames):
+    """objects that appear at fixed spots of a lattice, drift a little, vanish, and come back: the tracks of a spot die and new ones
+    are born where dead ones lie — over a long run far more tracks are created than are ever alive, and a new track's visible box
+    regularly contains the last position of a dead one (the reference's merge step looks at those too, imm_ukf_jpda.cpp:666-700)"""
+    import test_emu_tracker_random as TR
+    rng = np.random.default_rng(seed)
+    side = int(np.ceil(np.sqrt(spots)))
+    centre = (np.stack(np.meshgrid(np.arange(side), np.arange(side)), -1).reshape(-1, 2)[:spots] - side / 2) * 7.0 + rng.uniform(-1, 1, (spots, 2))
+    state = np.zeros(spots, np.int64)           # > 0: frames the object stays; < 0: frames until it is back
+    state[:] = rng.integers(1, 40, spots) * np.where(rng.random(spots) < 0.7, 1, -1)
+    drift = rng.uniform(-0.6, 0.6, (spots, 2)); size = rng.uniform(0.8, 4.5, (spots, 2)); yaw = rng.uniform(-3, 3, spots)
+    age = np.zeros(spots)
+    for f in range(frames):
+        boxes = []
+        for k in range(spots):
+            if k % 3 == 0:
+                # Every third spot replays, with a period of 200 frames, the one situation in which a DEAD track changes a live one's fate in
+                # the reference (mergeOverSegmentation runs over every track ever created, imm_ukf_jpda.cpp:666-700): a small object D lives
+                # and dies at (2, 0.9); later a large static object A stands over the spot and a long object B drives into A's box from the
+                # right. B's centre inside A's visible box would merge B away (A is older) — unless B's own box holds some track's position:
+                # D's last position does that job for a while. An implementation that forgets dead tracks kills B the moment it enters.
+                t = (f + 37 * k) % 200
+                c0 = centre[k] + rng.normal(0, 0.01, 2)
+                if t < 25:
+                    boxes.append(TR.box(c0[0] + 2.0, c0[1] + 0.9, 1.0, 1.0, 0.0, -0.3))
+                if 40 <= t < 190:
+                    boxes.append(TR.box(c0[0], c0[1], 3.0, 6.0, 0.0, -0.3))                                # A: x in [-3, 3], y in [-1.5, 1.5]
+                if 42 <= t < 190:
+                    boxes.append(TR.box(c0[0] + 8.0 - 0.06 * (t - 42), c0[1] + 0.9, 1.0, 3.0, 0.0, -0.3))   # B: 3 m long, 1 m wide, moving left
+                continue
+            if state[k] > 0:
+                p = centre[k] + drift[k] * 0.1 * age[k] + rng.normal(0, 0.03, 2)
+                boxes.append(TR.box(p[0], p[1], size[k, 0], size[k, 1], yaw[k] + rng.normal(0, 0.02), -0.3))
+                age[k] += 1; state[k] -= 1
+                if state[k] == 0:
+                    state[k] = -int(rng.integers(4, 30)); age[k] = 0; drift[k] = rng.uniform(-0.6, 0.6, 2)
+            else:
+                state[k] += 1
+                if state[k] == 0:
+                    state[k] = int(rng.integers(12, 70))
+        if rng.random() < 0.2:
+            boxes.append(TR.box(*rng.uniform(-30, 30, 2), *rng.uniform(0.5, 2.5, 2), rng.uniform(-3, 3), -0.2))   # clutter
+        yield np.array(boxes, np.float32).reshape(-1, 8, 3), 1.0e9 + f * 1.0e5, 1.0 + 0.5 * np.sin(0.01 * f), 0.0005 * f
+
+
+def long_run_bounded_slots(mot, oracle, lib_path=None, frames=1500, slots=16, spots=10, seed=3, state_every=25, min_ever_factor=4):
+    """SURVEY.md H14 / the reference never frees a track: a long run on `slots` track slots must give what the oracle gives with
+    unbounded memory — every frame the discrete outputs of EVERY track ever created (reference index order), every `state_every`
+    frames the filter states of the live ones — while far more tracks are created than there are slots."""
+    p = oracle.params(0)
+    kw = dict(lib_path=lib_path) if lib_path else {}
+    stats = {}
+    with mot.Context(max_points=1024, max_tracks_total=slots, **kw) as c:
+        T = oracle.Tracker(p)
+        for f, (boxes, ts, v, yaw) in enumerate(blinking_world(seed, spots, frames)):
+            assert np.allclose(c.ego_update(ts, v, yaw), T.ego_update(ts, v, yaw), rtol=1e-12, atol=1e-12)
+            a = c.track_step(boxes, ts); o = T.step(boxes, ts, max_tracks=1 << 16)
+            assert not a["capacity_exceeded"], f
+            assert a["n"] == o["n"], (f, a["n"], o["n"])
+            for k in ("track_manage", "is_static", "is_vis", "lifetime"):
+                assert np.array_equal(a[k], o[k]), (f, k, np.nonzero(a[k] != o[k])[0][:5])
+            live = o["track_manage"] > 0
+            assert np.allclose(a["p"][live], o["p"][live], rtol=1e-4, atol=1e-6, equal_nan=True), f
+            dead = ~live
+            assert np.allclose(a["p"][dead][:, :2], o["p"][dead][:, :2], rtol=1e-4, atol=1e-6, equal_nan=True), f   # an evicted track keeps its last position
+            assert np.array_equal(a["vis_box"][dead & (o["is_vis"] == 0)], o["vis_box"][dead & (o["is_vis"] == 0)])
+            if f % state_every == 0 or f == frames - 1:
+                SP.compare_tracks(a, o, c.track_state, T.state, f, stats=stats, skip_ill_conditioned=True)
+            stats["live_peak"] = max(stats.get("live_peak", 0), int(live.sum()))
+        n_ever = o["n"]
+        T.close()
+    assert n_ever >= min_ever_factor * slots and stats["live_peak"] <= slots, (n_ever, stats)
+    stats["tracks_ever"] = n_ever
+    return stats
