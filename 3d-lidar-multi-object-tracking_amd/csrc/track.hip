@@ -139,13 +139,16 @@ struct PredictScratch {
   double Xs[3][75];              // predicted sigma points, 5 x 15 per model
   double z[3][2], S[3][4];
 };
+struct BbFlags { int is_vis, has_bbox, has_best, pad; double best_yaw; };
 struct UpdateScratch {
   double x[3][5], P[3][25];      // predicted per-model state
   double xo[3][5], Po[3][25];    // updated state
   double xm[5];                  // merged state of the previous step
   double mode[3];
-  double Xs[3][64];              // exp() of the gated boxes 0..63 per model
+  double Xs[3][64];              // exp() of the gated boxes 0..63 per model (before that: the two boxes of updateBB, as floats)
   double z[3][2], S[3][4], K[3][10];
+  double pda[3][7];              // filterPDA's sums per model: eSum, sigmaX(0..1), sigmaP(0..3)
+  BbFlags bbf;                   // isVisBB_, BBox_ set, bestBBox_ set, bestYaw_ while updateBB works on the boxes staged in Xs
 };
 
 // sigma-point weights, ukf.cpp:268-274: lambda_aug = 3 - 7
@@ -174,6 +177,10 @@ __device__ void load_track(UpdateScratch* G, const DevTrack* t, bool act) {
     if (s < 6) G->z[s / 2][s % 2] = t->zpred[s / 2][s % 2];
     if (s < 12) G->S[s / 4][s % 4] = t->S[s / 4][s % 4];
     for (int e = s; e < 30; e += kGroupLanes) G->K[e / 10][e % 10] = t->K[e / 10][e % 10];
+    // BBox_ / bestBBox_ for updateBB, as floats in the storage of the exp() cache (not needed before the PDA sums)
+    float* fb = reinterpret_cast<float*>(&G->Xs[0][0]);
+    for (int e = s; e < 24; e += kGroupLanes) { fb[e] = t->bbox[e]; fb[24 + e] = t->best_bbox[e]; }
+    if (s == 0) { G->bbf.is_vis = t->is_vis; G->bbf.has_bbox = t->has_bbox; G->bbf.has_best = t->has_best; G->bbf.pad = 0; G->bbf.best_yaw = t->best_yaw; }
   }
   MOT_WAVE_SYNC();
 }
@@ -423,46 +430,60 @@ __device__ __forceinline__ void rotate_box(float* b, const double* cp, double a)
     b[3 * i + 1] = (float)(sa * (preX - cp[0]) + ca * (preY - cp[1]) + cp[1]);
   }
 }
-// updateBB :565-653 (single lane). The two boxes are worked on in registers and written back once: every access to the
-// track record is a global-memory round trip, and this function is a chain of dependent reads and writes of it.
-__device__ void update_bb(const MotTrackParams& tp, DevTrack* u) {
-  if (!u->is_vis) return;
-  float bb[24], best[24];
-#pragma unroll
-  for (int i = 0; i < 24; i++) bb[i] = u->bbox[i];
-  const double ukfYaw = u->x[0][3];
-  if (!u->has_best) {
-#pragma unroll
-    for (int i = 0; i < 24; i++) u->best_bbox[i] = bb[i];
-    u->has_best = 1; u->best_yaw = bbox_yaw(bb, ukfYaw);
-    return;
+// updateBB :565-653, by the 16 lanes of the track's group on the two boxes staged in LDS (8 corners x (x, y, z) floats each). The
+// reference's function is a chain of small scalar steps on two 8-corner boxes; one lane walking it on register copies of both
+// boxes cost this kernel 48 VGPRs for the whole wave and, before that, a chain of global round trips on the track record. Here every
+// lane evaluates the scalar steps (centres, yaws, areas: the same expressions on the same values, read from LDS by broadcast) and
+// the per-corner steps (shift, copy, rotation) are spread over the lanes. Phases are separated by wave synchronisations at
+// uniform points of the control flow; `on` is uniform over the group.
+__device__ void update_bb_group(const MotTrackParams& tp, float* bb, float* best, BbFlags* fl, double ukfYaw, bool act) {
+  const int s = glane();
+  const bool on = act && fl->is_vis;              // group-uniform (LDS broadcast read)
+  const bool first = on && !fl->has_best;
+  const bool both = on && fl->has_best;
+  // ---- phase 1: scalars of the boxes as they are (reads)
+  double cp[2] = {0, 0}, dt0 = 0, dt1 = 0, yaw = 0, deltaArea = 0;
+  if (on) yaw = bbox_yaw(bb, ukfYaw);
+  if (both) {
+    double bestCP[2];
+    cp_from_bbox(bb, &cp[0], &cp[1]);
+    cp_from_bbox(best, &bestCP[0], &bestCP[1]);
+    dt0 = cp[0] - bestCP[0]; dt1 = cp[1] - bestCP[1];
+    deltaArea = bbox_area(bb) - bbox_area(best);
   }
-#pragma unroll
-  for (int i = 0; i < 24; i++) best[i] = u->best_bbox[i];
-  double cp[2], bestCP[2];
-  cp_from_bbox(bb, &cp[0], &cp[1]);
-  cp_from_bbox(best, &bestCP[0], &bestCP[1]);
-  double dt0 = cp[0] - bestCP[0], dt1 = cp[1] - bestCP[1];
-  double yaw = bbox_yaw(bb, ukfYaw);
-  double area = bbox_area(bb), bestArea = bbox_area(best);
-  double deltaArea = area - bestArea;
-  if (deltaArea < 0) {  // updateVisBoxArea :496-510
-#pragma unroll
-    for (int i = 0; i < 8; i++) { bb[3 * i] = (float)(best[3 * i] + dt0); bb[3 * i + 1] = (float)(best[3 * i + 1] + dt1); }
-  } else if (deltaArea > 0) {
-#pragma unroll
-    for (int i = 0; i < 24; i++) best[i] = bb[i];
+  MOT_WAVE_SYNC();
+  // ---- phase 2: first sighting: the box becomes the best box; otherwise updateVisBoxArea :496-510 / the larger box becomes the best
+  if (first) {
+    for (int e = s; e < 24; e += kGroupLanes) best[e] = bb[e];
+    if (s == 0) { fl->has_best = 1; fl->best_yaw = yaw; }
   }
-  double currentYaw = bbox_yaw(bb, ukfYaw);
-  double DiffYaw = yaw - currentYaw;
-  if (fabs(DiffYaw) > tp.bb_yaw_change_thres) {
-  } else if (fabs(DiffYaw) < tp.bb_yaw_change_thres) {
-    rotate_box(bb, cp, DiffYaw);
-    rotate_box(best, cp, DiffYaw);
-    u->best_yaw = yaw;
+  if (both) {
+    if (deltaArea < 0) {
+      if (s < 8) { bb[3 * s] = (float)(best[3 * s] + dt0); bb[3 * s + 1] = (float)(best[3 * s + 1] + dt1); }
+    } else if (deltaArea > 0) {
+      for (int e = s; e < 24; e += kGroupLanes) best[e] = bb[e];
+    }
   }
-#pragma unroll
-  for (int i = 0; i < 24; i++) { u->bbox[i] = bb[i]; u->best_bbox[i] = best[i]; }
+  MOT_WAVE_SYNC();
+  // ---- phase 3: yaw of the (possibly shifted) box
+  double DiffYaw = 0;
+  bool rot = false;
+  if (both) {
+    const double currentYaw = bbox_yaw(bb, ukfYaw);
+    DiffYaw = yaw - currentYaw;
+    rot = !(fabs(DiffYaw) > tp.bb_yaw_change_thres) && fabs(DiffYaw) < tp.bb_yaw_change_thres;
+  }
+  MOT_WAVE_SYNC();
+  // ---- phase 4: updateBoxYaw :512-532 on both boxes, a corner per lane (lanes 0-7: the box, 8-15: the best box)
+  if (rot) {
+    float* q = s < 8 ? bb + 3 * s : best + 3 * (s - 8);
+    const double ca = cos(DiffYaw), sa = sin(DiffYaw);
+    const double preX = q[0], preY = q[1];
+    q[0] = (float)(ca * (preX - cp[0]) - sa * (preY - cp[1]) + cp[0]);
+    q[1] = (float)(sa * (preX - cp[0]) + ca * (preY - cp[1]) + cp[1]);
+    if (s == 0) fl->best_yaw = yaw;
+  }
+  MOT_WAVE_SYNC();
 }
 
 // =============================================================================================== the frame step
@@ -713,17 +734,26 @@ __device__ void update_group(const TrackBuffers& tb, UpdateScratch* G, int b, in
       if (minBox < 0) minBox = first;  // minInd stays 0 = first gated box
       if (minDist < tp.distance_thres) {
         const float* bx = boxes + (long)minBox * 24;
+        float* fb = reinterpret_cast<float*>(&G->Xs[0][0]);
         for (int h = 0; h < 2; h++)
           for (int q = 0; q < 4; q++) {
-            u->bbox[(h * 4 + q) * 3] = bx[3 * q];
-            u->bbox[(h * 4 + q) * 3 + 1] = bx[3 * q + 1];
-            u->bbox[(h * 4 + q) * 3 + 2] = (float)(h == 0 ? -1.73 : 0);
+            fb[(h * 4 + q) * 3] = bx[3 * q];
+            fb[(h * 4 + q) * 3 + 1] = bx[3 * q + 1];
+            fb[(h * 4 + q) * 3 + 2] = (float)(h == 0 ? -1.73 : 0);
           }
-        u->is_vis = 1; u->has_bbox = 1;
+        G->bbf.is_vis = 1; G->bbf.has_bbox = 1;
       }
     }
   }
-  if (act && s == 0) update_bb(tp, u);
+  MOT_WAVE_SYNC();
+  {
+    float* fb = reinterpret_cast<float*>(&G->Xs[0][0]);
+    update_bb_group(tp, fb, fb + 24, &G->bbf, G->xm[3], act);
+    if (act) {   // the boxes and their flags go back to the track record before the exp() cache takes the storage
+      for (int e = s; e < 24; e += kGroupLanes) { u->bbox[e] = fb[e]; u->best_bbox[e] = fb[24 + e]; }
+      if (s == 0) { u->is_vis = G->bbf.is_vis; u->has_bbox = G->bbf.has_bbox; u->has_best = G->bbf.has_best; u->best_yaw = G->bbf.best_yaw; }
+    }
+  }
   MOT_WAVE_SYNC();
   Vec2d* pos = tb.pos + (long)b * tb.E + (act ? u->ref_id : 0);   // the merged position is kept by REFERENCE index (it outlives the slot)
   if (secondInit && s == 0) {  // :882-921
@@ -755,61 +785,62 @@ __device__ void update_group(const TrackBuffers& tb, UpdateScratch* G, int b, in
     if (track_num == 0) upd = false;
   }
 
-  // filterPDA :259-394 — lanes over the measurements, 16 boxes at a time
+  // filterPDA :259-394 — lanes over the measurements, 16 boxes at a time; ONE MODEL AT A TIME: the three models' inverse innovation
+  // covariances and running sums used to sit side by side in registers (this kernel: 256 VGPRs, two waves per SIMD, and a second
+  // round of workgroups for the bench's 9-10 k tracks); the sums of a finished model wait in LDS
   const int Mg = upd ? M : 0;
   const int Mmax = wave_reduce_i32(Mg, OpMaxI());
   const double numMeas = nm;
   const double bpda = 2 * numMeas * (1 - tp.p_d * tp.p_g) / (tp.gamma_g * tp.p_d);
-  double Si[3][4] = {{0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}};
-  if (upd) for (int m = 0; m < 3; m++) inv2(G->S[m], Si[m]);
   double* ecache = &G->Xs[0][0];   // exp() of the gated boxes 0..63 per model ([3][64]; the sigma points are not needed here)
-  double eSum[3] = {0, 0, 0};
-  for (int k0 = 0; k0 < Mmax; k0 += kGroupLanes) {
-    const int k = k0 + s;
-    const bool g = k < Mg && ((gt[k0 >> 6] >> (k & 63)) & 1ull);
-    Vec2d c; c.x = 0; c.y = 0;
-    if (g) c = cp[k];
-#pragma unroll
-    for (int m = 0; m < 3; m++) {
-      double e = 0;
-      if (g) {
-        double d0 = c.x - G->z[m][0], d1 = c.y - G->z[m][1];
-        double h0 = -0.5 * d0, h1 = -0.5 * d1;
-        double t0 = h0 * Si[m][0] + h1 * Si[m][2], t1 = h0 * Si[m][1] + h1 * Si[m][3];
-        e = exp(t0 * d0 + t1 * d1);
-        if (k < 64) ecache[m * 64 + k] = e;
-      }
-      eSum[m] += row_sum_f64(e);
-    }
-  }
-  double sx[3][2] = {{0, 0}, {0, 0}, {0, 0}};
-  double sp[3][4] = {{0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}};
 #pragma unroll 1
-  for (int pass = 0; pass < 2; pass++) {  // pass 0: sigmaX, pass 1: sigmaP (needs the complete sigmaX)
+  for (int m = 0; m < 3; m++) {
+    double Si[4] = {0, 0, 0, 0};
+    if (upd) inv2(G->S[m], Si);
+    const double zm0 = G->z[m][0], zm1 = G->z[m][1];
+    double eS = 0;
     for (int k0 = 0; k0 < Mmax; k0 += kGroupLanes) {
       const int k = k0 + s;
       const bool g = k < Mg && ((gt[k0 >> 6] >> (k & 63)) & 1ull);
-      Vec2d c; c.x = 0; c.y = 0;
-      if (g) c = cp[k];
-#pragma unroll
-      for (int m = 0; m < 3; m++) {
+      double e = 0;
+      if (g) {
+        const Vec2d c = cp[k];
+        double d0 = c.x - zm0, d1 = c.y - zm1;
+        double h0 = -0.5 * d0, h1 = -0.5 * d1;
+        double t0 = h0 * Si[0] + h1 * Si[2], t1 = h0 * Si[1] + h1 * Si[3];
+        e = exp(t0 * d0 + t1 * d1);
+        if (k < 64) ecache[m * 64 + k] = e;
+      }
+      eS += row_sum_f64(e);
+    }
+    double sxm[2] = {0, 0}, spm[4] = {0, 0, 0, 0};
+#pragma unroll 1
+    for (int pass = 0; pass < 2; pass++) {  // pass 0: sigmaX, pass 1: sigmaP (needs the complete sigmaX)
+      for (int k0 = 0; k0 < Mmax; k0 += kGroupLanes) {
+        const int k = k0 + s;
+        const bool g = k < Mg && ((gt[k0 >> 6] >> (k & 63)) & 1ull);
         double d[2] = {0, 0}, beta = 0;
         if (g) {
-          d[0] = c.x - G->z[m][0]; d[1] = c.y - G->z[m][1];
+          const Vec2d c = cp[k];
+          d[0] = c.x - zm0; d[1] = c.y - zm1;
           double e;
           if (k < 64) e = ecache[m * 64 + k];
           else {
             double h0 = -0.5 * d[0], h1 = -0.5 * d[1];
-            double t0 = h0 * Si[m][0] + h1 * Si[m][2], t1 = h0 * Si[m][1] + h1 * Si[m][3];
+            double t0 = h0 * Si[0] + h1 * Si[2], t1 = h0 * Si[1] + h1 * Si[3];
             e = exp(t0 * d[0] + t1 * d[1]);
           }
-          beta = e / (bpda + eSum[m]);
+          beta = e / (bpda + eS);
         }
-        if (pass == 0) { sx[m][0] += row_sum_f64(beta * d[0]); sx[m][1] += row_sum_f64(beta * d[1]); }
+        if (pass == 0) { sxm[0] += row_sum_f64(beta * d[0]); sxm[1] += row_sum_f64(beta * d[1]); }
         else
           for (int r = 0; r < 2; r++) for (int c2 = 0; c2 < 2; c2++)
-            sp[m][r * 2 + c2] += row_sum_f64(g ? (beta * d[r]) * d[c2] - sx[m][r] * sx[m][c2] : 0.0);
+            spm[r * 2 + c2] += row_sum_f64(g ? (beta * d[r]) * d[c2] - sxm[r] * sxm[c2] : 0.0);
       }
+    }
+    if (s == 0) {   // (row sums: every lane of the group holds the same values)
+      G->pda[m][0] = eS; G->pda[m][1] = sxm[0]; G->pda[m][2] = sxm[1];
+      G->pda[m][3] = spm[0]; G->pda[m][4] = spm[1]; G->pda[m][5] = spm[2]; G->pda[m][6] = spm[3];
     }
   }
   // x += K*sigmaX ; P update (:341-367) — one lane per matrix entry
@@ -817,18 +848,19 @@ __device__ void update_group(const TrackBuffers& tb, UpdateScratch* G, int b, in
   if (upd) {
     if (s < 15) {
       int m = s / 5, r = s % 5;
-      double v = G->x[m][r] + (G->K[m][r * 2] * sx[m][0] + G->K[m][r * 2 + 1] * sx[m][1]);
+      double v = G->x[m][r] + (G->K[m][r * 2] * G->pda[m][1] + G->K[m][r * 2 + 1] * G->pda[m][2]);
       G->xo[m][r] = r == 3 ? wrap_pi(v) : v;
     }
     for (int e = s; e < 75; e += kGroupLanes) {
       int m = e / 25, r = (e % 25) / 5, c = e % 5;
       const double* K = G->K[m];
       double ks0 = K[r * 2] * G->S[m][0] + K[r * 2 + 1] * G->S[m][2], ks1 = K[r * 2] * G->S[m][1] + K[r * 2 + 1] * G->S[m][3];
-      double kp0 = K[r * 2] * sp[m][0] + K[r * 2 + 1] * sp[m][2], kp1 = K[r * 2] * sp[m][1] + K[r * 2 + 1] * sp[m][3];
+      const double* sp = &G->pda[m][3];
+      double kp0 = K[r * 2] * sp[0] + K[r * 2 + 1] * sp[2], kp1 = K[r * 2] * sp[1] + K[r * 2 + 1] * sp[3];
       double kskt = ks0 * K[c * 2] + ks1 * K[c * 2 + 1];
       double kpk = kp0 * K[c * 2] + kp1 * K[c * 2 + 1];
       double P = G->P[m][r * 5 + c];
-      double betaZero = bpda / (bpda + eSum[m]);
+      double betaZero = bpda / (bpda + G->pda[m][0]);
       G->Po[m][r * 5 + c] = nm != 0 ? betaZero * P + (1 - betaZero) * (P - kskt) + kpk : P - kskt;
     }
   }
@@ -841,7 +873,7 @@ __device__ void update_group(const TrackBuffers& tb, UpdateScratch* G, int b, in
     const double pw = pow(Vk, numMeas), pw1 = nm != 0 ? pow(Vk, 1 - numMeas) : 0.0;   // the same two powers in all three models
 #pragma unroll
     for (int m = 0; m < 3; m++) {
-      if (nm != 0) lambda[m] = (1 - tp.p_g * tp.p_d) / pw + tp.p_d * pw1 * eSum[m] / (numMeas * sqrt(2 * PI_D * det2(G->S[m])));
+      if (nm != 0) lambda[m] = (1 - tp.p_g * tp.p_d) / pw + tp.p_d * pw1 * G->pda[m][0] / (numMeas * sqrt(2 * PI_D * det2(G->S[m])));
       else lambda[m] = (1 - tp.p_g * tp.p_d) / pw;
     }
     double mode[3];

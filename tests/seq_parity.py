@@ -58,11 +58,26 @@ def well_conditioned(state) -> bool:
     reference's own guards kill the track; its discrete outputs are compared regardless"""
     x, P = np.asarray(state["x_merge"]), np.asarray(state["p_merge"])
     ok = np.isfinite(x).all() and np.isfinite(P).all() and np.isfinite(state["mode_prob"]).all()
-    return bool(ok and abs(x[4]) < 20.0 and np.abs(P).max() < 1e3 and np.diag(P.reshape(5, 5)).min() > 0.0)
+    if not (ok and abs(x[4]) < 20.0 and np.abs(P).max() < 1e3 and np.diag(P.reshape(5, 5)).min() > 0.0):
+        return False
+    P = P.reshape(5, 5)
+    return bool(np.linalg.eigvalsh((P + P.T) * 0.5).min() > 0.0)   # a covariance that is not positive definite: numerically meaningless
 
 
-def compare_tracks(a, o, state_dev, state_orc, where, rtol=RTOL, stats=None, skip_ill_conditioned=False):
-    """a: the library's tracks of one stream (Context.get_tracks), o: the oracle's. Discrete outputs exact, continuous <= rtol."""
+TAINT_FRAMES = 30   # a track whose filter went through a diverging phase carries the amplified last-bit differences for a while after its
+                    # covariance looks sane again (the measurements pull the state back within a few tens of frames)
+
+
+def note_conditioning(o, state_orc, frame, taint):
+    """call every frame: remembers until when a live track of the oracle is excluded from CONTINUOUS comparisons"""
+    for i in np.nonzero(o["track_manage"] > 0)[0]:
+        if not well_conditioned(state_orc(int(i))):
+            taint[int(i)] = frame + TAINT_FRAMES
+
+
+def compare_tracks(a, o, state_dev, state_orc, where, rtol=RTOL, stats=None, skip_ill_conditioned=False, taint=None, frame=None):
+    """a: the library's tracks of one stream (Context.get_tracks), o: the oracle's. Discrete outputs exact, continuous <= rtol.
+    taint / frame: see note_conditioning (when given, this call also records the current conditioning)."""
     assert a["n"] == o["n"], (where, a["n"], o["n"])
     for k in ("track_manage", "is_static", "is_vis"):
         assert np.array_equal(a[k], o[k]), (where, k, np.nonzero(a[k] != o[k])[0][:8])
@@ -73,6 +88,10 @@ def compare_tracks(a, o, state_dev, state_orc, where, rtol=RTOL, stats=None, ski
     for i in live:
         so = state_orc(int(i))
         ill = not well_conditioned(so)
+        if taint is not None and frame is not None:
+            if ill:
+                taint[int(i)] = frame + TAINT_FRAMES
+            ill = ill or taint.get(int(i), -1) >= frame
         check = not (ill and skip_ill_conditioned)   # discrete outputs were compared above regardless
         sd = state_dev(int(i))
         assert sd["lifetime"] == so["lifetime"] and sd["track_manage"] == so["track_manage"], (where, int(i))
@@ -125,6 +144,7 @@ def check_sequence(ctx, oracle, p, frame_ptr, host_frame, n_seq, stride, ego_v, 
     B = len(n_seq[0])
     slots = list(range(B)) if slots is None else list(slots)
     trackers = {b: oracle.Tracker(p) for b in slots}
+    taints = {}
     stats = dict(frames=F, streams=len(slots), points=0, elevated=0, boxes=0, clusters=0)
     try:
         for f in range(F):
@@ -155,7 +175,8 @@ def check_sequence(ctx, oracle, p, frame_ptr, host_frame, n_seq, stride, ego_v, 
                     assert bits_equal(gdev[: len(gb)], gb), (where, "boxes in the global frame")
                 o = T.step(gb, float(ts[b]), max_tracks=max(ctx.max_tracks_total, 64))
                 at = ctx.get_tracks(b)
-                compare_tracks(at, o, lambda i: ctx.track_state(i, slot=b), T.state, where, rtol, stats, skip_ill_conditioned)
+                compare_tracks(at, o, lambda i: ctx.track_state(i, slot=b), T.state, where, rtol, stats, skip_ill_conditioned,
+                               taint=taints.setdefault(b, {}), frame=f)
                 stats["points"] += n; stats["elevated"] += len(g["elevated"]); stats["boxes"] += len(bx["boxes"]); stats["clusters"] += cl["num_cluster"]
     finally:
         for T in trackers.values():

@@ -104,7 +104,7 @@ def test_tracker_slots_are_independent_and_reset_works(ctx, oracle, synth):
 
 def test_tracker_edge_cases(mot, hip_lib, oracle):
     p = oracle.params(0)
-    with mot.Context(max_points=1024, max_tracks_total=8) as c:
+    with mot.Context(max_points=1024, max_tracks_total=3) as c:
         with pytest.raises(mot.MotError) as e:   # ego update must come first (getOriginPoints precedes immUkfJpdaf)
             c.track_step(np.zeros((0, 8, 3), np.float32), 0.0)
         assert e.value.code == mot.MOT_E_STATE
@@ -115,7 +115,7 @@ def test_tracker_edge_cases(mot, hip_lib, oracle):
         a = c.track_step(box, 1e6); o = T.step(box, 1e6)
         assert a["n"] == o["n"] == 0
         rng = np.random.default_rng(0)
-        full = False   # the reference never frees tracks: capacity is reported (MOT_E_CAPACITY in C, `capacity_exceeded` here), the records still delivered
+        full = False   # more births in a frame than free slots: reported (MOT_E_CAPACITY in C, `capacity_exceeded` here), the records still delivered
         for f in range(1, 6):
             ts = 1e6 + f * 1e5
             c.ego_update(ts, 0, 0)
@@ -125,7 +125,7 @@ def test_tracker_edge_cases(mot, hip_lib, oracle):
                 b[k, :, :2] = (np.array([[0, 0], [2, 0], [2, 1], [0, 1]] * 2) + [cx, cy])
             out = c.track_step(b, ts)
             full |= out["capacity_exceeded"]
-            assert int((out["track_manage"] > 0).sum()) <= 8   # 8 slots
+            assert int((out["track_manage"] > 0).sum()) <= 3   # 3 slots, 4 births per frame
         assert full
 
 
@@ -223,12 +223,12 @@ def test_long_run_on_256_track_slots(mot, hip_lib, oracle):
     created equal the oracle's with unbounded memory (the reference never frees a track, imm_ukf_jpda.cpp:972-989); filter states of the
     live tracks every 50 frames. The world replays the situation in which a dead track's last position decides a live track's fate."""
     import tracker_cases as TC
-    st = TC.long_run_bounded_slots(mot, oracle, frames=10000, slots=256, spots=40, state_every=50, min_ever_factor=8)
-    assert st["tracks_ever"] >= 2048 and st["max_rel_state_err"] <= RTOL
+    st = TC.long_run_bounded_slots(mot, oracle, frames=10000, slots=256, spots=40, state_every=50, min_ever_factor=8, max_chaos_restarts=12)
+    assert st["tracks_ever"] >= 2048 and st["max_rel_state_err"] <= RTOL and st["frames_compared"] >= 9900
 
 
 def test_long_run_on_few_slots(mot, hip_lib, oracle):
     """the same with 24 slots for up to ~20 live tracks: slots are recycled constantly"""
     import tracker_cases as TC
-    st = TC.long_run_bounded_slots(mot, oracle, frames=2500, slots=24, spots=14, state_every=25, min_ever_factor=8)
-    assert st["tracks_ever"] >= 192
+    st = TC.long_run_bounded_slots(mot, oracle, frames=2500, slots=24, spots=14, state_every=25, min_ever_factor=8, max_chaos_restarts=6)
+    assert st["tracks_ever"] >= 192 and st["frames_compared"] >= 2450

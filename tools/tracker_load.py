@@ -15,11 +15,11 @@ build = _load("mot_amd.build", os.path.join(PKG, "build.py"))
 S = int(sys.argv[1]) if len(sys.argv) > 1 else 128
 flags = [a for a in sys.argv[2:] if a.startswith("-D")]
 STRESS_ONLY = "stress-only" in sys.argv
-lib = None
+lib = next((a[4:] for a in sys.argv[2:] if a.startswith("lib=")), None)   # a prebuilt variant library (variants/, built on the CPU box)
 if flags:
     os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
     lib = build.build(extra_flags=flags, out=os.path.join(ROOT, "gpurun_out", "libmot_variant_" + "_".join(f.strip("-D").replace("=", "") for f in flags) + ".so"))
-print("variant:", flags or "product build")
+print("variant:", flags or lib or "product build")
 kw = dict(lib_path=lib) if lib else {}
 
 rng = np.random.default_rng(11)
