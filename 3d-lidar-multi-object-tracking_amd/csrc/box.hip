@@ -35,15 +35,6 @@
 #define MOT_LAUNCH_BOUNDS(n)
 #define MOT_LAUNCH_BOUNDS2(n, waves_per_simd)
 #endif
-#ifndef MOT_LABEL_WAVES
-#define MOT_LABEL_WAVES 8
-#endif
-#ifndef MOT_LABEL_PREFETCH_POINTS
-#define MOT_LABEL_PREFETCH_POINTS 0
-#endif
-#ifndef MOT_LABEL_GRID
-#define MOT_LABEL_GRID 8   // workgroups per frame of the persistent label kernel when a launch holds hundreds of frames
-#endif
 #ifndef MOT_GATHER_WAVES
 #define MOT_GATHER_WAVES 6
 #endif
@@ -102,7 +93,7 @@ __device__ __forceinline__ void stats_commit(ClusterStats* s, int count, int fir
   if (rmax != kArgmaxInit) atomicMax(&s->argmax, rmax);
 }
 
-__global__ void MOT_LAUNCH_BOUNDS2(kLabelBlock, MOT_LABEL_WAVES)
+__global__ void MOT_LAUNCH_BOUNDS(kLabelBlock)
 label_stats_kernel(MotDevParams p, ClusterBuffers c) {
   constexpr int kWaves = kLabelBlock / 64, kPerWave = kGroupsPerWg / kWaves;
   // (tile, cluster) groups with their partial statistics, one region per wave (no atomics while they are produced)
@@ -118,84 +109,54 @@ label_stats_kernel(MotDevParams p, ClusterBuffers c) {
   __shared__ int s_tilecnt[kWgClusters][kTilesPerChunk + 1];   // +1: the 64 scanning threads walk different banks
   const int b = blockIdx.y;
   const int n = c.counts[b * kCountsStride + kCntElev];
-  // PERSISTENT since round 3: a few workgroups per frame, each walking the frame's 2048-point chunks blockIdx.x, + gridDim.x, ... with the
-  // NEXT chunk's points and cells requested before the current one is worked on and its labels gathered half-way through. A
-  // workgroup per chunk spent the first third of its life waiting for count -> cell -> label (three dependent round trips:
-  // profiles/r03_label_kernel_phases.txt), and the grid had to cover the largest possible frame: two thirds of the workgroups only
-  // read the frame's count and left. (Round 2's looping variants had no prefetch and were slower.)
-  const int nchunks = (n + kLabelChunk - 1) / kLabelChunk;
-  if ((int)blockIdx.x >= nchunks) return;
+  // (one workgroup per chunk of the largest possible frame; two thirds find nothing to do and leave. Fewer workgroups that loop
+  // over the chunks are SLOWER — 190 us with 24 per frame, 197 with 8, against 176: profiles/r02_block_size_variants.txt — and
+  // still are when the next chunk's cells / labels / points are requested ahead: 178-208 us against 160 for 6-16 persistent
+  // workgroups per frame, profiles/r03_box_stage_experiments.txt: many independent workgroups hide the three dependent round
+  // trips at a chunk's start better than any one workgroup's prefetch)
+  const long base = (long)blockIdx.x * kLabelChunk;
+  if (base >= n) return;
+  if (threadIdx.x < kWgClusters) {
+    s_tab_label[threadIdx.x] = 0; s_tab_count[threadIdx.x] = 0; s_tab_first[threadIdx.x] = 0x7fffffff;
+    s_tab_rz[threadIdx.x] = mot_float_key(-99.f); s_tab_rmin[threadIdx.x] = kArgminInit; s_tab_rmax[threadIdx.x] = kArgmaxInit;
+  }
+  for (int i = threadIdx.x; i < kWgClusters * (kLabelChunk / 64 + 1); i += kLabelBlock) (&s_tilecnt[0][0])[i] = 0;
   B1_T_BEGIN(c, b);
   const int num_cluster = c.counts[b * kCountsStride + kCntClusters];
   const float4* __restrict__ pts = c.elevated + (long)b * c.cap;
   const int* __restrict__ grid = c.grid + (long)b * (MOT_MAX_GRID * MOT_MAX_GRID);
-  const unsigned short* __restrict__ ecell = c.ecell ? c.ecell + (long)b * c.cap : nullptr;   // fused path: the compaction kernel left every elevated point's cell, 2 bytes per point
   int* __restrict__ label = c.label + (long)b * c.cap;
   int* __restrict__ pix = c.pix + (long)b * c.cap;
   ClusterStats* __restrict__ stats = c.stats + (long)b * kMaxClusters;
   PointGroup* __restrict__ out = c.groups + (long)b * c.group_cap;
   const int lane = lane_id(), wave = threadIdx.x >> 6;
   constexpr int kNoMin = 0x7fffffff, kNoMax = (int)0x80000000;
-  // a chunk's loads: points; (handed-over) cells -> cell index -> label
-  auto request_points = [&](int chunk, float4 (&q)[kLabelItems]) {
-    const long cb = (long)chunk * kLabelChunk;
-#pragma unroll
-    for (int k = 0; k < kLabelItems; k++) {
-      long i = cb + k * kLabelBlock + threadIdx.x;
-      q[k] = i < n ? pts[i] : make_float4(1.0e9f, 1.0e9f, 0.f, 0.f);   // outside every ROI
-    }
-  };
-  auto request_cells = [&](int chunk, int (&l)[kLabelItems]) {   // fused path only
-    const long cb = (long)chunk * kLabelChunk;
-#pragma unroll
-    for (int k = 0; k < kLabelItems; k++) {
-      long i = cb + k * kLabelBlock + threadIdx.x;
-      l[k] = i < n ? (int)ecell[i] : 0xffff;
-    }
-  };
-  auto request_labels = [&](const float4 (&q)[kLabelItems], int (&l)[kLabelItems]) {
-#pragma unroll
-    for (int k = 0; k < kLabelItems; k++) {
-      int cell;
-      if (ecell) { const unsigned e = (unsigned)l[k]; cell = e != 0xffffu ? (int)((e >> 8) * (unsigned)p.num_grid + (e & 255u)) : -1; }
-      else { const int bit = mot_cart_bit(p, q[k].x, q[k].y); cell = bit >= 0 ? (bit >> 8) * p.num_grid + (bit & 255) : -1; }   // guarded fast cell (two IEEE divides per point otherwise), exact fallback
-      l[k] = cell;
-    }
-#pragma unroll
-    for (int k = 0; k < kLabelItems; k++) l[k] = l[k] >= 0 ? grid[l[k]] : 0;   // all gathers in flight together
-  };
-  // What is requested ahead: with MOT_LABEL_PREFETCH_POINTS the whole next chunk (16 more VGPRs: 78, three workgroups per CU instead of
-  // four); without, only its cells and labels — the dependent part — and the points at the top of their own iteration (one round trip
-  // of waiting instead of three). The stage-wise path (no handed-over cells) computes the cells from the points and prefetches nothing
-  // in that form.
+  int wn = 0;   // groups this wave has produced (wave-uniform)
+  // all loads first, then all label gathers: 8 + 8 independent requests in flight instead of 16 dependent round trips
   float4 qs[kLabelItems];
   int labs[kLabelItems];
-#if MOT_LABEL_PREFETCH_POINTS
-  const bool ahead = true;
-#else
-  const bool ahead = ecell != nullptr;
-#endif
-  request_points(blockIdx.x, qs);
-  if (ecell) request_cells(blockIdx.x, labs);
-  if (ahead) request_labels(qs, labs);
-  for (int chunk = blockIdx.x; chunk < nchunks; chunk += gridDim.x) {
-  const long base = (long)chunk * kLabelChunk;
-  const bool more = chunk + (int)gridDim.x < nchunks;   // uniform
-#if MOT_LABEL_PREFETCH_POINTS
-  float4 qn[kLabelItems];
-  if (more) request_points(chunk + gridDim.x, qn);
-#else
-  if (chunk != (int)blockIdx.x) request_points(chunk, qs);
-  if (!ahead) request_labels(qs, labs);
-#endif
-  int ln[kLabelItems];
-  if (more && ecell) request_cells(chunk + gridDim.x, ln);
-  if (threadIdx.x < kWgClusters) {
-    s_tab_label[threadIdx.x] = 0; s_tab_count[threadIdx.x] = 0; s_tab_first[threadIdx.x] = 0x7fffffff;
-    s_tab_rz[threadIdx.x] = mot_float_key(-99.f); s_tab_rmin[threadIdx.x] = kArgminInit; s_tab_rmax[threadIdx.x] = kArgmaxInit;
+#pragma unroll
+  for (int k = 0; k < kLabelItems; k++) {
+    long i = base + k * kLabelBlock + threadIdx.x;
+    qs[k] = i < n ? pts[i] : make_float4(1.0e9f, 1.0e9f, 0.f, 0.f);   // outside every ROI
   }
-  for (int i = threadIdx.x; i < kWgClusters * (kLabelChunk / 64 + 1); i += kLabelBlock) (&s_tilecnt[0][0])[i] = 0;
-  int wn = 0;   // groups this wave has produced (wave-uniform)
+  if (c.ecell) {   // fused path: the compaction kernel filed every elevated point under this cell already and left it behind, 2 bytes per point
+    const unsigned short* __restrict__ ecell = c.ecell + (long)b * c.cap;
+#pragma unroll
+    for (int k = 0; k < kLabelItems; k++) {
+      long i = base + k * kLabelBlock + threadIdx.x;
+      const unsigned e = i < n ? (unsigned)ecell[i] : 0xffffu;
+      labs[k] = e != 0xffffu ? (int)((e >> 8) * (unsigned)p.num_grid + (e & 255u)) : -1;
+    }
+  } else {
+#pragma unroll
+    for (int k = 0; k < kLabelItems; k++) {
+      const int bit = mot_cart_bit(p, qs[k].x, qs[k].y);   // guarded fast cell (two IEEE divides per point otherwise), exact fallback
+      labs[k] = bit >= 0 ? (bit >> 8) * p.num_grid + (bit & 255) : -1;
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < kLabelItems; k++) labs[k] = labs[k] >= 0 ? grid[labs[k]] : 0;
 #pragma unroll
   for (int k = 0; k < kLabelItems; k++) {
     long i = base + k * kLabelBlock + threadIdx.x;
@@ -257,11 +218,6 @@ label_stats_kernel(MotDevParams p, ClusterBuffers c) {
       active &= ~mm;
     }
   }
-#if MOT_LABEL_PREFETCH_POINTS
-  if (more) request_labels(qn, ln);   // the next chunk's cells have arrived by now; its labels travel during the merge below
-#else
-  if (more && ahead) request_labels(qs, ln);   // (fused path: the points are not needed for the cells)
-#endif
   if (lane == 0) s_wcount[wave] = wn < kPerWave ? wn : kPerWave;
   B1_T(1);
   __syncthreads();
@@ -312,8 +268,8 @@ label_stats_kernel(MotDevParams p, ClusterBuffers c) {
                  s_tab_rmin[threadIdx.x], s_tab_rmax[threadIdx.x]);
   __syncthreads();
   // the workgroup's table, for the index kernel's cross-chunk prefix
-  if (threadIdx.x < kWgClusters && chunk < c.max_wg)
-    c.wgtab[((long)b * c.max_wg + chunk) * kWgClusters + threadIdx.x] = make_int2(s_tab_label[threadIdx.x], s_tab_count[threadIdx.x]);
+  if (threadIdx.x < kWgClusters && (int)blockIdx.x < c.max_wg)
+    c.wgtab[((long)b * c.max_wg + blockIdx.x) * kWgClusters + threadIdx.x] = make_int2(s_tab_label[threadIdx.x], s_tab_count[threadIdx.x]);
   // the (tile, cluster) groups leave with ONE returning global atomic (a slot reservation)
   const int gb = s_gbase;
   for (int t = threadIdx.x; t < ng; t += kLabelBlock) {
@@ -327,15 +283,6 @@ label_stats_kernel(MotDevParams p, ClusterBuffers c) {
   }
   B1_T(5);
   B1_T_VALUE(6, ng);
-  __syncthreads();   // the tables and the staged groups have been consumed: the next chunk may reset them
-#pragma unroll
-  for (int k = 0; k < kLabelItems; k++) {
-#if MOT_LABEL_PREFETCH_POINTS
-    qs[k] = qn[k];
-#endif
-    labs[k] = ln[k];
-  }
-  }
 }
 
 // ------------------------------------------------------------------------------------------ B1b
@@ -1113,16 +1060,7 @@ void mot_launch_stats_init(const ClusterBuffers& c, int batch, hipStream_t strea
 void mot_launch_box_kernel(int which, const MotDevParams& p, const ClusterBuffers& c, int batch, int max_n, hipStream_t stream) {
   int chunks = (max_n + kLabelChunk - 1) / kLabelChunk;
   if (chunks < 1) chunks = 1;
-  if (which == 0) {   // persistent: ~4096 workgroups per launch, at least MOT_LABEL_GRID per frame, never more than the largest frame has chunks
-#ifdef MOT_HIPEMU
-    int gx = 2;   // the emulator tests run small batches: make every workgroup walk several chunks there too (any grid gives the same result)
-#else
-    int gx = 4096 / (batch > 0 ? batch : 1);
-    gx = gx < MOT_LABEL_GRID ? MOT_LABEL_GRID : gx;
-#endif
-    gx = gx > chunks ? chunks : gx;
-    hipLaunchKernelGGL(label_stats_kernel, dim3(gx, batch), dim3(kLabelBlock), 0, stream, p, c);
-  }
+  if (which == 0) hipLaunchKernelGGL(label_stats_kernel, dim3(chunks, batch), dim3(kLabelBlock), 0, stream, p, c);
   else if (which == 1) hipLaunchKernelGGL(cluster_gather_kernel, dim3(MOT_GATHER_GRID, batch), dim3(kBoxBlock), 0, stream, p, c);  // a frame's clusters are dealt round-robin to its workgroups
   else if (which == 3) {
     hipLaunchKernelGGL(cluster_rect_kernel, dim3(MOT_RECT_GRID, batch), dim3(kRectBlock), 0, stream, p, c);

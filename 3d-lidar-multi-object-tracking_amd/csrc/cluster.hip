@@ -132,6 +132,7 @@ ccl_kernel(MotDevParams p, ClusterBuffers c) {
   __shared__ unsigned s_isroot[kMaxRuns / 32];
   __shared__ int s_rootpre[kMaxRuns / 32 + 1];
   __shared__ unsigned char s_wpre[kPlaneWords];  // per (row, word): run starts of the row before the word
+  __shared__ unsigned short s_run[kLdsRuns];     // (row << 8) | first column of every run, by run ordinal (frames whose runs fit in LDS)
   const int b = blockIdx.x;
   const int G = p.num_grid;
   const int tid = threadIdx.x;
@@ -238,37 +239,55 @@ ccl_kernel(MotDevParams p, ClusterBuffers c) {
   CCL_T(4);
 
   // union every run with the runs of the previous row it touches (8-connectivity: columns s-1 .. e+1)
-  for (int i = tid; i < kPlaneWords; i += kCclBlock) {
-    int x = i >> 3, w = i & 7;
-    unsigned st = s_aux[i];
-    if (x == 0 || x >= G) st = 0u;
+  auto unite = [&](unsigned a, int x, int s) {   // run `a` = columns s.. of row x (x >= 1)
     const unsigned* row = &s_occ[x * kRowWords];
-    const unsigned* up = &s_occ[(x > 0 ? x - 1 : 0) * kRowWords];
-    int ord = s_rowbase[x] + (int)s_wpre[i];
-    const int upbase = s_rowbase[x > 0 ? x - 1 : 0] - 1, upw = (x > 0 ? x - 1 : 0) * kRowWords;
-    while (st) {
-      int bit = __ffs(st) - 1;
-      st &= st - 1u;
-      int s = (w << 5) + bit;
-      int e = row_next_clear(row, s) - 1;
-      int lo = s > 0 ? s - 1 : 0, hi = e + 1 < G ? e + 1 : G - 1;
-      unsigned a = (unsigned)ord++;
-      int q = row_next_set(up, lo);
-      while (q <= hi) {
-        const unsigned bb = (unsigned)(upbase + (int)s_wpre[upw + (q >> 5)] + __popc(s_aux[upw + (q >> 5)] & ((2u << (q & 31)) - 1u)));
-        // lock-free union, hook the larger root under the smaller one
-        unsigned ra = a, rb = bb;
+    const unsigned* up = &s_occ[(x - 1) * kRowWords];
+    const int upbase = s_rowbase[x - 1] - 1, upw = (x - 1) * kRowWords;
+    const int e = row_next_clear(row, s) - 1;
+    const int lo = s > 0 ? s - 1 : 0, hi = e + 1 < G ? e + 1 : G - 1;
+    int q = row_next_set(up, lo);
+    while (q <= hi) {
+      const unsigned bb = (unsigned)(upbase + (int)s_wpre[upw + (q >> 5)] + __popc(s_aux[upw + (q >> 5)] & ((2u << (q & 31)) - 1u)));
+      // lock-free union, hook the larger root under the smaller one
+      unsigned ra = a, rb = bb;
+      for (unsigned q2 = PL(ra); q2 != ra; q2 = PL(ra)) ra = q2;
+      for (unsigned q2 = PL(rb); q2 != rb; q2 = PL(rb)) rb = q2;
+      while (ra != rb) {
+        if (ra < rb) { unsigned t = ra; ra = rb; rb = t; }
+        unsigned old = atomicCAS(&parent[ra], ra, rb);
+        if (old == ra) break;
+        ra = old;
         for (unsigned q2 = PL(ra); q2 != ra; q2 = PL(ra)) ra = q2;
         for (unsigned q2 = PL(rb); q2 != rb; q2 = PL(rb)) rb = q2;
-        while (ra != rb) {
-          if (ra < rb) { unsigned t = ra; ra = rb; rb = t; }
-          unsigned old = atomicCAS(&parent[ra], ra, rb);
-          if (old == ra) break;
-          ra = old;
-          for (unsigned q2 = PL(ra); q2 != ra; q2 = PL(ra)) ra = q2;
-          for (unsigned q2 = PL(rb); q2 != rb; q2 = PL(rb)) rb = q2;
-        }
-        q = row_next_set(up, row_next_clear(up, q));
+      }
+      q = row_next_set(up, row_next_clear(up, q));
+    }
+  };
+  if constexpr (decltype(in_lds)::value) {
+    // ONE RUN PER THREAD. The runs sit where the objects are: a thread per (row, word) left most threads without a run and a few with ten
+    // (the pass was a third of this kernel: profiles/r03_ccl_phases.txt). Every (row, word) first files its runs' positions by run
+    // ordinal — cheap stores — then the unions are dealt out evenly.
+    for (int i = tid; i < kPlaneWords; i += kCclBlock) {
+      const int x = i >> 3, w = i & 7;
+      unsigned st = x < G ? s_aux[i] : 0u;
+      int ord = s_rowbase[x] + (int)s_wpre[i];
+      while (st) { const int bit = __ffs(st) - 1; st &= st - 1u; s_run[ord++] = (unsigned short)((x << 8) | ((w << 5) + bit)); }
+    }
+    __syncthreads();
+    for (int r = tid; r < R; r += kCclBlock) {
+      const int x = s_run[r] >> 8, s0 = s_run[r] & 255;
+      if (x >= 1) unite((unsigned)r, x, s0);
+    }
+  } else {
+    for (int i = tid; i < kPlaneWords; i += kCclBlock) {
+      int x = i >> 3, w = i & 7;
+      unsigned st = s_aux[i];
+      if (x == 0 || x >= G) st = 0u;
+      int ord = s_rowbase[x] + (int)s_wpre[i];
+      while (st) {
+        int bit = __ffs(st) - 1;
+        st &= st - 1u;
+        unite((unsigned)ord++, x, (w << 5) + bit);
       }
     }
   }
@@ -320,19 +339,22 @@ ccl_kernel(MotDevParams p, ClusterBuffers c) {
   {
     const int lane = tid & 63, wave = tid >> 6;
     const bool pairs = (G & 1) == 0;   // rows start 8-byte aligned
-    for (int x = wave; x < G; x += kCclBlock / 64) {
-      const int y0 = lane * 4;
-      if (y0 >= G) continue;
+    const int y0 = lane * 4;
+    // the labels of a row's quad: branch-free, so that the LDS chains of the two rows a wave handles per trip overlap (the pass was a
+    // quarter of this kernel, one dependent chain of five LDS reads per row and lane)
+    auto quad = [&](int x, int (&lab)[4]) {
       const int wi = x * kRowWords + (y0 >> 5), sh = y0 & 31;   // y0 is a multiple of 4: the quad never straddles a word
       const unsigned bits = (s_occ[wi] >> sh) & 0xfu;
-      int lab[4] = {0, 0, 0, 0};
-      if (bits) {
-        const unsigned st = s_aux[wi];
-        const int before = s_rowbase[x] + (int)s_wpre[wi] - 1;
+      const unsigned st = s_aux[wi];
+      const int before = s_rowbase[x] + (int)s_wpre[wi] - 1;
 #pragma unroll
-        for (int j = 0; j < 4; j++)
-          if ((bits >> j) & 1u) lab[j] = (int)PL((unsigned)(before + __popc(st & ((2u << (sh + j)) - 1u))));
+      for (int j = 0; j < 4; j++) {
+        const int r = before + __popc(st & ((2u << (sh + j)) - 1u));
+        const unsigned v = PL((unsigned)(r > 0 ? r : 0));        // (a clear cell may compute -1: clamped, discarded)
+        lab[j] = ((bits >> j) & 1u) ? (int)v : 0;
       }
+    };
+    auto put = [&](int x, const int (&lab)[4]) {
       int* dst = grid + x * G + y0;
       if (pairs && y0 + 4 <= G) {
         reinterpret_cast<int2*>(dst)[0] = make_int2(lab[0], lab[1]);
@@ -341,6 +363,20 @@ ccl_kernel(MotDevParams p, ClusterBuffers c) {
 #pragma unroll
         for (int j = 0; j < 4; j++) if (y0 + j < G) dst[j] = lab[j];
       }
+    };
+    constexpr int kRowStep = kCclBlock / 64;
+    if (y0 < G && R > 0) {
+      for (int x = wave; x < G; x += 2 * kRowStep) {
+        int la[4], lb[4] = {0, 0, 0, 0};
+        const int x2 = x + kRowStep;
+        quad(x, la);
+        if (x2 < G) quad(x2, lb);
+        put(x, la);
+        if (x2 < G) put(x2, lb);
+      }
+    } else if (y0 < G) {   // a frame without a single occupied cell: the grid is all zeros
+      const int zero[4] = {0, 0, 0, 0};
+      for (int x = wave; x < G; x += kRowStep) put(x, zero);
     }
   }
   };
