@@ -384,11 +384,15 @@ cluster_index_kernel(ClusterBuffers c) {
     B1B_T(2);
     // 64 groups per wave at a time: every lane works out the first slot of ITS group from the tables, then the wave walks
     // the 64 groups with one lane per point of the tile (four readlanes and a store per group)
-    for (int g0 = wave * 64; g0 < E; g0 += kIndexBlock) {
+    // (a frame of the bench has ~600 groups: dealt 64 per wave, ten of the sixteen waves walked 64 groups each and six had none; dealt
+    // evenly, every wave walks ~40)
+    const int per = E <= kIndexWaves * 64 ? (E + kIndexWaves - 1) / kIndexWaves : 64;
+    for (int g0 = wave * per; g0 < E; g0 += kIndexWaves * per) {
+      const int mine_n = E - g0 < per ? E - g0 : per;
       PointGroup mine;
       mine.mask = 0ull; mine.label = 0; mine.tile = 0;
       int mypos = 0;
-      if (g0 + lane < E) {
+      if (lane < mine_n) {
         mine = groups[g0 + lane];
         const int tile = mine.tile & kGroupTileMask, within = (int)((unsigned)mine.tile >> kGroupTileBits);
         const int wg = tile / (kLabelChunk / 64);
@@ -403,7 +407,7 @@ cluster_index_kernel(ClusterBuffers c) {
         }
         mypos = s_start[mine.label - 1] + pref + within;
       }
-      const int cnt = E - g0 < 64 ? E - g0 : 64;
+      const int cnt = mine_n;
       // (writing every point's picture pixel to its slot as well — so that the gather kernel reads a cluster's pixels as one contiguous run
       // instead of chasing index -> pixel — took the gather kernel from 102 to 75 us per 512 frames and THIS kernel from 52 to 127:
       // one workgroup per frame cannot hide the extra loads. profiles/r03_box_stage_experiments.txt)

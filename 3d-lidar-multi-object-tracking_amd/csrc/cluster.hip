@@ -148,14 +148,26 @@ ccl_kernel(MotDevParams p, ClusterBuffers c) {
     const int nchunks = (c.n_in[b] + kCompactChunk - 1) / kCompactChunk;
     const OccWord* __restrict__ lists = c.occ_list + (long)b * c.occ_chunks * kPlaneWords;
     const int* __restrict__ cnt = c.occ_count + (long)b * c.occ_chunks;
-    for (int ch = tid >> 6; ch < nchunks && ch < c.occ_chunks; ch += kCclBlock / 64) {   // a wave per list: the lists are read side by side
-      const int ne = cnt[ch];
-      for (int e = tid & 63; e < ne; e += 64) {
-        const OccWord w = lists[(long)ch * kPlaneWords + e];
-        const unsigned old = atomicOr(&s_occ[w.word], w.a);
-        const unsigned twice = w.b | (old & w.a);
-        if (twice) atomicOr(&s_aux[w.word], twice);
-      }
+    // a wave per list, two lists per trip: both counts, then the first 64 entries of both, are requested together (the kernel spent an
+    // eighth of its time in the two dependent round trips of this fold, once per list)
+    const int nlists = nchunks < c.occ_chunks ? nchunks : c.occ_chunks;
+    constexpr int kW = kCclBlock / 64;
+    auto file = [&](const OccWord& w) {
+      const unsigned old = atomicOr(&s_occ[w.word], w.a);
+      const unsigned twice = w.b | (old & w.a);
+      if (twice) atomicOr(&s_aux[w.word], twice);
+    };
+    for (int ch0 = tid >> 6; ch0 < nlists; ch0 += 2 * kW) {
+      const int ch1 = ch0 + kW, lane = tid & 63;
+      const int n0 = cnt[ch0], n1 = ch1 < nlists ? cnt[ch1] : 0;
+      OccWord w0, w1;
+      w0.word = 0; w0.a = 0; w0.b = 0; w0.pad = 0; w1 = w0;
+      if (lane < n0) w0 = lists[(long)ch0 * kPlaneWords + lane];
+      if (lane < n1) w1 = lists[(long)ch1 * kPlaneWords + lane];
+      if (lane < n0) file(w0);
+      if (lane < n1) file(w1);
+      for (int e = 64 + lane; e < n0; e += 64) file(lists[(long)ch0 * kPlaneWords + e]);
+      for (int e = 64 + lane; e < n1; e += 64) file(lists[(long)ch1 * kPlaneWords + e]);
     }
     __syncthreads();
     if (p.occ_min_count >= 2)
@@ -300,14 +312,18 @@ ccl_kernel(MotDevParams p, ClusterBuffers c) {
   }
   __syncthreads();
   CCL_T(6);
-  for (int j = tid; j < kMaxRuns / 32; j += kCclBlock) {
-    unsigned bits = 0u;
-    int r0 = j << 5;
-    if (r0 < R)
-      for (int k = 0; k < 32 && r0 + k < R; k++)
-        if (PL((unsigned)(r0 + k)) == (unsigned)(r0 + k)) bits |= 1u << k;
-    s_isroot[j] = bits;
-    s_rootpre[j + 1] = __popc(bits);
+  // which runs are roots: a lane per run and a ballot (a thread per 32 runs read them one after the other: 4 k cycles)
+  for (int j = tid; j < kMaxRuns / 32; j += kCclBlock) { s_isroot[j] = 0u; s_rootpre[j + 1] = 0; }
+  __syncthreads();
+  for (int r0 = (tid & ~63); r0 < R; r0 += kCclBlock) {   // wave-uniform trip count
+    const int r = r0 + (tid & 63);
+    const bool root = r < R && PL((unsigned)r) == (unsigned)r;
+    const unsigned long long m = __ballot(root);
+    if ((tid & 63) == 0) {
+      const unsigned lo = (unsigned)m, hi = (unsigned)(m >> 32);
+      s_isroot[r0 >> 5] = lo; s_rootpre[(r0 >> 5) + 1] = __popc(lo);
+      s_isroot[(r0 >> 5) + 1] = hi; s_rootpre[(r0 >> 5) + 2] = __popc(hi);
+    }
   }
   if (tid == 0) s_rootpre[0] = 0;
   __syncthreads();
