@@ -362,23 +362,19 @@ cluster_index_kernel(ClusterBuffers c) {
     __syncthreads();
     B1B_T(1);
     for (int ci = tid; ci <= num_cluster; ci += kIndexBlock) cstart[ci] = s_start[ci];
-    for (int i = tid; i < entries; i += kIndexBlock) {
-      const int2 t = s_tab[i];
-      int pref = 0;
-      if (t.x) {
-        const int wg = i / kWgClusters;
-        for (int w2 = 0; w2 < wg; w2++) {   // the cluster's entry in every earlier chunk's table (same hash, linear probing)
-          unsigned h = mot_label_hash(t.x);
-#pragma unroll 1
-          for (int probe = 0; probe < kWgClusters; probe++) {
-            const int2 o = s_tab[w2 * kWgClusters + (int)h];
-            if (o.x == t.x) { pref += o.y; break; }
-            if (o.x == 0) break;
-            h = (h + 1) & (kWgClusters - 1);
-          }
-        }
+    __syncthreads();   // the cluster starts have left for global memory: s_start becomes the running position of every cluster
+    // First slot of every (chunk, cluster) table entry = the cluster's start + its points in earlier chunks: ONE wave walks the chunks in
+    // order, a lane per table slot, advancing the cluster's running position in s_start (a chunk's table holds a cluster once, so the
+    // lanes never meet). The first version let every entry probe every earlier chunk's hash table: 18 x 64 entries x up to 17
+    // tables of dependent LDS probes, a quarter of this kernel (profiles/r03_label_kernel_phases.txt).
+    if (wave == 0) {
+      for (int wg = 0; wg < nwg; wg++) {
+        const int2 t = s_tab[wg * kWgClusters + lane];
+        int at = 0;
+        if (t.x) { at = s_start[t.x - 1]; s_start[t.x - 1] = at + t.y; }
+        s_pref[wg * kWgClusters + lane] = at;
+        MOT_WAVE_SYNC();
       }
-      s_pref[i] = pref;
     }
     __syncthreads();
     B1B_T(2);
@@ -405,7 +401,7 @@ cluster_index_kernel(ClusterBuffers c) {
           if (o.x == 0) break;
           h = (h + 1) & (kWgClusters - 1);
         }
-        mypos = s_start[mine.label - 1] + pref + within;
+        mypos = pref + within;   // (pref: the absolute first slot of the cluster's points of this chunk)
       }
       const int cnt = mine_n;
       // (writing every point's picture pixel to its slot as well — so that the gather kernel reads a cluster's pixels as one contiguous run

@@ -32,10 +32,8 @@
 
 #ifndef MOT_HIPEMU
 #define MOT_LAUNCH_BOUNDS(n) __launch_bounds__(n)
-#define MOT_LAUNCH_BOUNDS2(n, waves_per_simd) __launch_bounds__(n, waves_per_simd)
 #else
 #define MOT_LAUNCH_BOUNDS(n)
-#define MOT_LAUNCH_BOUNDS2(n, waves_per_simd)
 #endif
 
 // streaming (non-temporal) 16-byte load for data that is not read again: it does not displace the grids, lists and
@@ -188,10 +186,7 @@ polar_minz_kernel(MotDevParams p, GroundBuffers g) {
 #define MOT_FILTER_BLOCK 960
 #endif
 constexpr int kFilterBlock = MOT_FILTER_BLOCK;  // 9600 cells = 10 per thread; a multiple of 64, >= 256
-#ifndef MOT_FILTER_AHEAD
-#define MOT_FILTER_AHEAD 2
-#endif
-__global__ void MOT_LAUNCH_BOUNDS2(kFilterBlock, 8)
+__global__ void MOT_LAUNCH_BOUNDS(kFilterBlock)
 polar_filter_kernel(MotDevParams p, GroundBuffers g) {
   __shared__ int s_minz[MOT_POLAR_CELLS];        // createAndMapPolarGrid's per-cell min z (ordered keys), then the cell's height
   float* const s_h = reinterpret_cast<float*>(s_minz);   // same storage: every pass below that rewrites it reads only its own cell first
@@ -209,55 +204,36 @@ polar_filter_kernel(MotDevParams p, GroundBuffers g) {
     __syncthreads();
     const int wv = threadIdx.x >> 6, ln = threadIdx.x & 63, nwv = kFilterBlock / 64;
     const int lim = nchunks - c0 < 256 ? nchunks - c0 : 256;
+    // (Requesting the first 512 entries of TWO lists per wave and trip, to halve the number of dependent round trips, measured 36.6 us
+    // against 34.8: it needs 64 VGPRs + scratch to keep two workgroups on a CU. Not kept.)
     // A lane takes 8 CONSECUTIVE entries (64 bytes: the wave still reads one contiguous 4 KB block) and merges equal
     // neighbours in registers first: a cell's run that the min-z kernel split across threads comes back together, and the
     // lanes of one LDS atomic instruction no longer hit the same cell.
-    // The first 512 entries (a whole list, normally) of the TWO lists a wave folds in a trip are requested together: one memory round
-    // trip per two lists instead of one per list (a frame has ~60 lists for the kernel's 15 waves; four at a time would need 105
-    // VGPRs: one workgroup per CU instead of two).
-    auto fold8 = [&](const uint2 (&q)[8]) {
-      unsigned cur = q[0].x;
-      int mn = (int)q[0].y;
+    for (int ch = wv; ch < lim; ch += nwv) {
+      const int cnt = s_pcnt[ch];
+      const uint2* __restrict__ src = g.pairs + ((long)b * g.max_chunks + c0 + ch) * kGroundChunk;
+      for (int e0 = 0; e0 < cnt; e0 += 512) {
+        const int eb = e0 + ln * 8;
+        uint2 q[8];
+        if (eb + 8 <= cnt) {
+          const uint4* __restrict__ s4 = reinterpret_cast<const uint4*>(src + eb);
 #pragma unroll
-      for (int u = 1; u < 8; u++) {
-        if (q[u].x == cur) mn = (int)q[u].y < mn ? (int)q[u].y : mn;
-        else {
-          if (cur != 0xffffffffu) atomicMin(&s_minz[cur], mn);
-          cur = q[u].x; mn = (int)q[u].y;
+          for (int u = 0; u < 4; u++) { const uint4 v = s4[u]; q[2 * u] = make_uint2(v.x, v.y); q[2 * u + 1] = make_uint2(v.z, v.w); }
+        } else {
+#pragma unroll
+          for (int u = 0; u < 8; u++) q[u] = eb + u < cnt ? src[eb + u] : make_uint2(0xffffffffu, 0u);
         }
-      }
-      if (cur != 0xffffffffu) atomicMin(&s_minz[cur], mn);
-    };
-    auto load8 = [&](const uint2* __restrict__ src, int cnt, int eb, uint2 (&q)[8]) {
-      if (eb + 8 <= cnt) {
-        const uint4* __restrict__ s4 = reinterpret_cast<const uint4*>(src + eb);
+        unsigned cur = q[0].x;
+        int mn = (int)q[0].y;
 #pragma unroll
-        for (int u = 0; u < 4; u++) { const uint4 v = s4[u]; q[2 * u] = make_uint2(v.x, v.y); q[2 * u + 1] = make_uint2(v.z, v.w); }
-      } else {
-#pragma unroll
-        for (int u = 0; u < 8; u++) q[u] = eb + u < cnt ? src[eb + u] : make_uint2(0xffffffffu, 0u);
-      }
-    };
-    constexpr int kAhead = MOT_FILTER_AHEAD;
-    for (int ch0 = wv; ch0 < lim; ch0 += nwv * kAhead) {
-      uint2 q[kAhead][8];
-      int cnts[kAhead];
-#pragma unroll
-      for (int a = 0; a < kAhead; a++) {
-        const int ch = ch0 + a * nwv;
-        cnts[a] = ch < lim ? s_pcnt[ch] : 0;
-        load8(g.pairs + ((long)b * g.max_chunks + c0 + (ch < lim ? ch : 0)) * kGroundChunk, cnts[a], ln * 8, q[a]);
-      }
-#pragma unroll
-      for (int a = 0; a < kAhead; a++) {
-        fold8(q[a]);
-        const int ch = ch0 + a * nwv;
-        const uint2* __restrict__ src = g.pairs + ((long)b * g.max_chunks + c0 + (ch < lim ? ch : 0)) * kGroundChunk;
-        for (int e0 = 512; e0 < cnts[a]; e0 += 512) {   // lists longer than 512 entries (a chunk of many tiny runs)
-          uint2 r[8];
-          load8(src, cnts[a], e0 + ln * 8, r);
-          fold8(r);
+        for (int u = 1; u < 8; u++) {
+          if (q[u].x == cur) mn = (int)q[u].y < mn ? (int)q[u].y : mn;
+          else {
+            if (cur != 0xffffffffu) atomicMin(&s_minz[cur], mn);
+            cur = q[u].x; mn = (int)q[u].y;
+          }
         }
+        if (cur != 0xffffffffu) atomicMin(&s_minz[cur], mn);
       }
     }
   }
