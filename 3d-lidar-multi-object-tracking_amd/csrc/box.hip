@@ -157,7 +157,6 @@ label_stats_kernel(MotDevParams p, ClusterBuffers c) {
   }
 #pragma unroll
   for (int k = 0; k < kLabelItems; k++) labs[k] = labs[k] >= 0 ? grid[labs[k]] : 0;
-  int kmin[kLabelItems], kmax[kLabelItems], zkey[kLabelItems];
 #pragma unroll
   for (int k = 0; k < kLabelItems; k++) {
     long i = base + k * kLabelBlock + threadIdx.x;
@@ -181,54 +180,44 @@ label_stats_kernel(MotDevParams p, ClusterBuffers c) {
     // `m < minM` with minM = 999 / `m > maxM` with maxM = -999 (NaN never compares); "first occurrence wins" (strict
     // compares, :268-280) = the lowest lane among those holding the extreme key
     const int skey = mot_float_key(m);
-    kmin[k] = (m < 999.f) ? skey : kNoMin;
-    kmax[k] = (m > -999.f) ? skey : kNoMax;
-    zkey[k] = (q.z > -99.f) ? mot_float_key(q.z + 0.0f) : mot_float_key(-99.f);  // `pZ > maxZ`, maxZ = -99
-    labs[k] = lab;
+    const int kmin = (m < 999.f) ? skey : kNoMin;
+    const int kmax = (m > -999.f) ? skey : kNoMax;
+    const int zkey = (q.z > -99.f) ? mot_float_key(q.z + 0.0f) : mot_float_key(-99.f);  // `pZ > maxZ`, maxZ = -99
+    // (walking TWO tiles of the wave per trip of the loop below, so that their reduction chains overlap, measured 172-175 us against 165:
+    // a tile that has run out of clusters rides along on an empty match, and tiles rarely hold equally many. profiles/r03_box_stage_experiments.txt)
+    unsigned long long active = __ballot(lab > 0);
     if (k == 0) { B1_T(0); }
-  }
-  // (tile, cluster) groups: one trip per distinct cluster among the 64 points of a tile. TWO tiles of the wave advance in the same
-  // trip: their reductions are independent chains of DPP steps, and one chain at a time left the SIMD waiting for its own results
-  // a quarter of this kernel's time (profiles/r03_label_kernel_phases.txt). A tile that has run out of clusters runs along on an
-  // empty match.
-  auto emit = [&](int k, int l, unsigned long long mm, int rmin_k, int rmax_k, int rz, unsigned long long at_min, unsigned long long at_max, int leader) {
     const int tile = (int)((base + k * kLabelBlock + (threadIdx.x & ~63)) / 64);
-    if (lane == leader) {  // the leader is the lowest lane = the smallest index of the group
-      const unsigned i0 = (unsigned)tile * 64u;
-      // keys as this file's consumers decode them: high word = unsigned ordered slope, low word = index (min) / ~index (max)
-      const unsigned long long rmin = rmin_k == kNoMin ? kArgminInit
-          : (((unsigned long long)((unsigned)rmin_k ^ 0x80000000u) << 32) | (i0 + (unsigned)(__ffsll(at_min) - 1)));
-      const unsigned long long rmax = rmax_k == kNoMax ? kArgmaxInit
-          : (((unsigned long long)((unsigned)rmax_k ^ 0x80000000u) << 32) | (unsigned)~(i0 + (unsigned)(__ffsll(at_max) - 1)));
-      PointGroup g; g.mask = mm; g.label = l; g.tile = tile;
-      if (wn < kPerWave) {
-        const int e = wave * kPerWave + wn;
-        s_groups[e] = g; s_rmin[e] = rmin; s_rmax[e] = rmax; s_rz[e] = rz;
-      } else {  // more groups than the LDS stage holds (a badly fragmented chunk): this one goes out on its own,
-        // and the index kernel falls back to its general path for this frame
-        stats_commit(&stats[l - 1], __popcll(mm), (int)(i0 + (unsigned)leader), rz, rmin, rmax);
-        const int gs = atomicAdd(&c.counts[b * kCountsStride + kCntGroups], 1);
-        if (gs < c.group_cap) out[gs] = g;
-        c.counts[b * kCountsStride + kCntIrregular] = 1;
+    while (active) {  // one trip per distinct cluster among the 64 points of this wave
+      const int leader = __ffsll(active) - 1;
+      const int l = wave_bcast_i32(lab, leader);
+      const bool mine = (lab == l);
+      const unsigned long long mm = __ballot(mine);
+      const int rmin_k = wave_reduce_i32_id(mine ? kmin : kNoMin, OpMinI(), kNoMin);
+      const int rmax_k = wave_reduce_i32_id(mine ? kmax : kNoMax, OpMaxI(), kNoMax);
+      const int rz = wave_reduce_i32_id(mine ? zkey : kNoMax, OpMaxI(), kNoMax);   // every real key exceeds kNoMax
+      const unsigned long long at_min = __ballot(mine && kmin == rmin_k), at_max = __ballot(mine && kmax == rmax_k);
+      if (lane == leader) {  // the leader is the lowest lane = the smallest index of the group
+        const unsigned i0 = (unsigned)tile * 64u;
+        // keys as this file's consumers decode them: high word = unsigned ordered slope, low word = index (min) / ~index (max)
+        const unsigned long long rmin = rmin_k == kNoMin ? kArgminInit
+            : (((unsigned long long)((unsigned)rmin_k ^ 0x80000000u) << 32) | (i0 + (unsigned)(__ffsll(at_min) - 1)));
+        const unsigned long long rmax = rmax_k == kNoMax ? kArgmaxInit
+            : (((unsigned long long)((unsigned)rmax_k ^ 0x80000000u) << 32) | (unsigned)~(i0 + (unsigned)(__ffsll(at_max) - 1)));
+        PointGroup g; g.mask = mm; g.label = l; g.tile = tile;
+        if (wn < kPerWave) {
+          const int e = wave * kPerWave + wn;
+          s_groups[e] = g; s_rmin[e] = rmin; s_rmax[e] = rmax; s_rz[e] = rz;
+        } else {  // more groups than the LDS stage holds (a badly fragmented chunk): this one goes out on its own,
+          // and the index kernel falls back to its general path for this frame
+          stats_commit(&stats[l - 1], __popcll(mm), (int)i, rz, rmin, rmax);
+          const int gs = atomicAdd(&c.counts[b * kCountsStride + kCntGroups], 1);
+          if (gs < c.group_cap) out[gs] = g;
+          c.counts[b * kCountsStride + kCntIrregular] = 1;
+        }
       }
-    }
-  };
-  static_assert(kLabelItems % 2 == 0, "tiles are walked in pairs");
-#pragma unroll
-  for (int k0 = 0; k0 < kLabelItems; k0 += 2) {
-    unsigned long long act0 = __ballot(labs[k0] > 0), act1 = __ballot(labs[k0 + 1] > 0);
-    while (act0 | act1) {
-      const int lead0 = act0 ? __ffsll(act0) - 1 : 0, lead1 = act1 ? __ffsll(act1) - 1 : 0;
-      const int l0 = act0 ? wave_bcast_i32(labs[k0], lead0) : -1, l1 = act1 ? wave_bcast_i32(labs[k0 + 1], lead1) : -1;   // (-1 matches no point)
-      const bool mine0 = labs[k0] == l0, mine1 = labs[k0 + 1] == l1;
-      const unsigned long long mm0 = __ballot(mine0), mm1 = __ballot(mine1);
-      const int rmin0 = wave_reduce_i32_id(mine0 ? kmin[k0] : kNoMin, OpMinI(), kNoMin), rmin1 = wave_reduce_i32_id(mine1 ? kmin[k0 + 1] : kNoMin, OpMinI(), kNoMin);
-      const int rmax0 = wave_reduce_i32_id(mine0 ? kmax[k0] : kNoMax, OpMaxI(), kNoMax), rmax1 = wave_reduce_i32_id(mine1 ? kmax[k0 + 1] : kNoMax, OpMaxI(), kNoMax);
-      const int rz0 = wave_reduce_i32_id(mine0 ? zkey[k0] : kNoMax, OpMaxI(), kNoMax), rz1 = wave_reduce_i32_id(mine1 ? zkey[k0 + 1] : kNoMax, OpMaxI(), kNoMax);   // every real key exceeds kNoMax
-      const unsigned long long amin0 = __ballot(mine0 && kmin[k0] == rmin0), amax0 = __ballot(mine0 && kmax[k0] == rmax0);
-      const unsigned long long amin1 = __ballot(mine1 && kmin[k0 + 1] == rmin1), amax1 = __ballot(mine1 && kmax[k0 + 1] == rmax1);
-      if (act0) { emit(k0, l0, mm0, rmin0, rmax0, rz0, amin0, amax0, lead0); wn++; act0 &= ~mm0; }
-      if (act1) { emit(k0 + 1, l1, mm1, rmin1, rmax1, rz1, amin1, amax1, lead1); wn++; act1 &= ~mm1; }
+      wn++;
+      active &= ~mm;
     }
   }
   if (lane == 0) s_wcount[wave] = wn < kPerWave ? wn : kPerWave;
