@@ -804,6 +804,7 @@ __device__ __forceinline__ void cluster_rect_body(const MotDevParams& p, const C
   for (int round = 0; round * (int)gridDim.x < num_cluster; round++) {
     const int oi = round * (int)gridDim.x + ((round & 1) ? (int)gridDim.x - 1 - (int)blockIdx.x : (int)blockIdx.x);
     if (oi >= num_cluster) continue;
+    RECT_T_BEGIN();
     const int ci = wave_uniform_i32(order[oi]);   // (a loaded value: keep the per-cluster addressing and branches scalar)
     BoxCandidate cand = c.cand[(long)b * kMaxClusters + ci];
     if (cand.branch != 1 || cand.undefined) continue;  // L-shape clusters are complete already
@@ -814,6 +815,7 @@ __device__ __forceinline__ void cluster_rect_body(const MotDevParams& p, const C
     if (cand.poly_off + total > c.cap || total > kIn) total = 0;
     for (int j = lane; j < total; j += 64) s_in[j] = pool[cand.poly_off + j];
     MOT_WAVE_SYNC();
+    RECT_T(0);
     // ---- cv::convexHull
     int hn = 0;
     bool hull_overflow = false;
@@ -832,6 +834,7 @@ __device__ __forceinline__ void cluster_rect_body(const MotDevParams& p, const C
       else for (int i = lane; i < ml - 2; i += 64) { int v = ch[ml - 2 - i]; s_hx[mu + i] = (float)(short)(v & 0xffff); s_hy[mu + i] = (float)(v >> 16); }  // decreasing order
     }
     MOT_WAVE_SYNC();
+    RECT_T(1);
     float pc[8];
     bool promising = false;
     float rect[8] = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -842,7 +845,10 @@ __device__ __forceinline__ void cluster_rect_body(const MotDevParams& p, const C
     } else {
       if (hn > 2) {
         // ---- rotatingCalipers(points, n, CALIPERS_MINAREARECT, out), OpenCV 3.2 rotcalipers.cpp
-        long long kl = 0x7fffffffffffffffll, kr = -0x7fffffffffffffffll - 1, kt = -0x7fffffffffffffffll - 1, kb = 0x7fffffffffffffffll;
+        // the four extreme vertices: 32-bit keys {coordinate + 32768, vertex} reduced with DPP steps (pixel coordinates are far inside
+        // +-32768, a hull has at most 384 vertices). As 64-bit keys through __shfl_xor butterflies these four reductions were 48
+        // dependent LDS-crossbar shuffles: most of the 3.9 k cycles of the caliper set-up (profiles/r03_rect_phases.txt).
+        unsigned kl = 0xffffffffu, kr = 0u, kt = 0u, kb = 0xffffffffu;
         for (int i = lane; i < hn; i += 64) {
           int nx = (i + 1 < hn) ? i + 1 : 0;
           float p0x = s_hx[i], p0y = s_hy[i], ptx = s_hx[nx], pty = s_hy[nx];
@@ -850,13 +856,14 @@ __device__ __forceinline__ void cluster_rect_body(const MotDevParams& p, const C
           s_vx[i] = (float)dx; s_vy[i] = (float)dy;
           s_inv[i] = (float)(1. / sqrt(dx * dx + dy * dy));
           // `if (pt0.x < left_x) left = i` etc.: strict compares => the FIRST vertex holding the extreme value
-          long long ix = (long long)(int)p0x, iy = (long long)(int)p0y;  // vertices are integers
-          ix *= 4294967296ll; iy *= 4294967296ll;   // (the coordinate in the high word; a multiplication: pixel rows can be negative)
-          long long a_ = ix | (unsigned)i, b_ = ix | (unsigned)(0xffff - i);
-          long long c_ = iy | (unsigned)(0xffff - i), d_ = iy | (unsigned)i;
+          const unsigned ix = (unsigned)((int)p0x + 32768) << 16, iy = (unsigned)((int)p0y + 32768) << 16;  // vertices are integers
+          const unsigned a_ = ix | (unsigned)i, b_ = ix | (unsigned)(0xffff - i);
+          const unsigned c_ = iy | (unsigned)(0xffff - i), d_ = iy | (unsigned)i;
           kl = a_ < kl ? a_ : kl; kr = b_ > kr ? b_ : kr; kt = c_ > kt ? c_ : kt; kb = d_ < kb ? d_ : kb;
         }
-        kl = wave_min_t<long long>(kl); kr = wave_max_t<long long>(kr); kt = wave_max_t<long long>(kt); kb = wave_min_t<long long>(kb);
+        // unsigned order through the signed DPP reductions: flip the top bit
+        kl = (unsigned)wave_reduce_i32((int)(kl ^ 0x80000000u), OpMinI()) ^ 0x80000000u; kr = (unsigned)wave_reduce_i32((int)(kr ^ 0x80000000u), OpMaxI()) ^ 0x80000000u;
+        kt = (unsigned)wave_reduce_i32((int)(kt ^ 0x80000000u), OpMaxI()) ^ 0x80000000u; kb = (unsigned)wave_reduce_i32((int)(kb ^ 0x80000000u), OpMinI()) ^ 0x80000000u;
         const int left = (int)(kl & 0xffff), right = 0xffff - (int)(kr & 0xffff), top = 0xffff - (int)(kt & 0xffff), bottom = (int)(kb & 0xffff);
         MOT_WAVE_SYNC();
         float orientation = 0;  // sign of the first non-zero cross product of consecutive edges
@@ -870,11 +877,12 @@ __device__ __forceinline__ void cluster_rect_body(const MotDevParams& p, const C
           unsigned long long nz = __ballot(convexity != 0);
           if (nz) { int f = __ffsll(nz) - 1; double cv = __shfl(convexity, f, 64); orientation = cv > 0 ? 1.f : -1.f; }
         }
+        RECT_T(2);
         if (orientation != 0) {  // OpenCV asserts otherwise
           float minarea = 3.402823466e+38f;
           int bi0 = 0, bi5 = 0; float b1 = 0, b2 = 0, b3 = 0, b4 = 0;
           float base_a = orientation, base_b = 0;
-          int seq0 = bottom, seq1 = right, seq2 = top, seq3 = left;
+          int seq0 = wave_uniform_i32(bottom), seq1 = wave_uniform_i32(right), seq2 = wave_uniform_i32(top), seq3 = wave_uniform_i32(left);
           if (hn <= 64) {
             const float rhx = lane < hn ? s_hx[lane] : 0.f, rhy = lane < hn ? s_hy[lane] : 0.f;
             const float rvx = lane < hn ? s_vx[lane] : 0.f, rvy = lane < hn ? s_vy[lane] : 0.f, rinv = lane < hn ? s_inv[lane] : 0.f;
@@ -891,7 +899,7 @@ __device__ __forceinline__ void cluster_rect_body(const MotDevParams& p, const C
               if (cosalpha > maxcos) { main_element = 2; maxcos = cosalpha; }
               cosalpha = dp3 * RLF(rinv, seq3);
               if (cosalpha > maxcos) { main_element = 3; maxcos = cosalpha; }
-              int pindex = main_element == 0 ? seq0 : main_element == 1 ? seq1 : main_element == 2 ? seq2 : seq3;
+              const int pindex = wave_uniform_i32(main_element == 0 ? seq0 : main_element == 1 ? seq1 : main_element == 2 ? seq2 : seq3);
               float lead_x = RLF(rvx, pindex) * RLF(rinv, pindex);
               float lead_y = RLF(rvy, pindex) * RLF(rinv, pindex);
               switch (main_element) {
@@ -900,6 +908,9 @@ __device__ __forceinline__ void cluster_rect_body(const MotDevParams& p, const C
                 case 2: base_a = -lead_x; base_b = -lead_y; seq2 = seq2 + 1 == hn ? 0 : seq2 + 1; break;
                 default: base_a = -lead_y; base_b = lead_x; seq3 = seq3 + 1 == hn ? 0 : seq3 + 1; break;
               }
+              // the four caliper positions are the same in every lane: kept in scalar registers, so that the ~20 readlanes of a step take
+              // their lane index from an SGPR instead of each fetching it out of a VGPR first
+              seq0 = wave_uniform_i32(seq0); seq1 = wave_uniform_i32(seq1); seq2 = wave_uniform_i32(seq2); seq3 = wave_uniform_i32(seq3);
               float dx = RLF(rhx, seq1) - RLF(rhx, seq3);
               float dy = RLF(rhy, seq1) - RLF(rhy, seq3);
               float width = dx * base_a + dy * base_b;
@@ -942,6 +953,7 @@ __device__ __forceinline__ void cluster_rect_body(const MotDevParams& p, const C
               if (area <= minarea) { minarea = area; bi0 = seq3; b1 = base_a; b2 = width; b3 = base_b; b4 = height; bi5 = seq0; }
             }
           }
+          RECT_T(3);
           float A1 = b1, B1 = b3, A2 = -b3, B2 = b1;
           float C1 = A1 * s_hx[bi0] + s_hy[bi0] * B1;
           float C2 = A2 * s_hx[bi5] + s_hy[bi5] * B2;
@@ -993,6 +1005,8 @@ __device__ __forceinline__ void cluster_rect_body(const MotDevParams& p, const C
       pc[2 * i + 1] = rmY - p.roi_half;
     }
     promising = !cand.undefined && rule_based_filter(p, pc, maxZ, numPoints);
+    RECT_T(4);
+    RECT_T_STORE(c.poly + (long)b * c.cap, cand, hn);
     if (lane == 0) {
       if (!cand.undefined) for (int k = 0; k < 8; k++) cand.pc[k] = pc[k];
       cand.accepted = promising ? 1 : 0;

@@ -439,27 +439,17 @@ __device__ __forceinline__ void classify_compact_body(const MotDevParams& p, con
       // LDS atomics on one address serialise lane by lane (the straightforward per-point atomicOr cost 14 us of the kernel's
       // 104: profiles/r02_ablate_k3.txt). Only the first lane of a run of equal cells touches LDS; a run of two or more is
       // "seen >= 2" by itself.
-      // (all the returning atomics of the eight items first, then the ones that depend on their answers: item by item it was a chain of
-      // eight LDS round trips)
-      unsigned twice = 0;   // items whose cell must also be set in the "seen >= 2" plane
-      unsigned olds[kCompactItems];
+      // (all the returning atomics of the eight items first, then the ones that depend on their answers, instead of item by item: 311-313 us
+      // against 306 — the waves doing this are hidden under wave 0's look-back anyway. Not kept.)
 #pragma unroll
       for (int k = 0; k < kCompactItems; k++) {
-        olds[k] = 0u;
         if ((wave_has_elevated >> k) & 1u) {   // uniform
           const int prev = row_prev_i32(bits[k], -3), next = row_next_i32(bits[k], -3);
           if (bits[k] >= 0 && prev != bits[k]) {
-            olds[k] = atomicOr(&s_occ_a[bits[k] >> 5], 1u << (bits[k] & 31));
-            twice |= 1u << (k + 8);                        // a run leader
-            if (next == bits[k]) twice |= 1u << k;         // ... of a run of two or more
+            const unsigned m = 1u << (bits[k] & 31);
+            const unsigned old = atomicOr(&s_occ_a[bits[k] >> 5], m);
+            if ((old & m) || next == bits[k]) atomicOr(&s_occ_b[bits[k] >> 5], m);
           }
-        }
-      }
-#pragma unroll
-      for (int k = 0; k < kCompactItems; k++) {
-        if ((twice >> (k + 8)) & 1u) {
-          const unsigned m = 1u << (bits[k] & 31);
-          if ((olds[k] & m) || ((twice >> k) & 1u)) atomicOr(&s_occ_b[bits[k] >> 5], m);
         }
       }
     }

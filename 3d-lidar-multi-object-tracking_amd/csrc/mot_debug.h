@@ -42,6 +42,17 @@
 #define GATHER_T_STORE_RECT(cand)
 #endif
 
+// ---- cluster_rect_kernel (box.hip), stamps into the cluster's own run of the polygon pool (consumed by then: >= 8 candidates needed)
+#ifdef MOT_DBG_RECT_TIMING
+#define RECT_T_BEGIN() const long long dbg_t0 = clock64(); int dbg_t[6] = {0, 0, 0, 0, 0, 0}
+#define RECT_T(slot) dbg_t[slot] = (int)(clock64() - dbg_t0)
+#define RECT_T_STORE(pool, cand, hn) if (lane == 0 && (cand).poly_n >= 8) { int* d_ = (pool) + (cand).poly_off; d_[0] = 0x7ec7; for (int q_ = 0; q_ < 5; q_++) d_[1 + q_] = dbg_t[q_]; d_[6] = (hn); d_[7] = (cand).poly_n; }
+#else
+#define RECT_T_BEGIN()
+#define RECT_T(slot)
+#define RECT_T_STORE(pool, cand, hn)
+#endif
+
 // ---- ccl_kernel (cluster.hip), stamps into the polygon pool
 #ifdef MOT_DBG_CCL_TIMING
 #define CCL_T_BEGIN(c, b) const long long dbg_t0 = clock64(); int* dbg = (c).poly + (long)(b) * (c).cap
