@@ -13,7 +13,7 @@ B, N = 128, 120000
 stride = ((N + 2047) // 2048) * 2048
 v, yaw = sdev.load_ego(2)
 seq, n_seq, _, _ = sdev.SequenceRenderer("cuda").render(list(range(B)), 2, N, stride, v, yaw)
-_pre = os.path.join(ROOT, "variants", "dbg_libmot_rect.so")
+_pre = sys.argv[1] if len(sys.argv) > 1 else os.path.join(ROOT, "variants", "dbg_libmot_rect.so")
 lib = _pre if os.path.exists(_pre) else build.build(extra_flags=["-DMOT_DBG_RECT_TIMING"], out=os.path.join(ROOT, "gpurun_out", "libmot_rect.so"))
 ctx = mot.Context(max_points=stride, max_batch=B, lib_path=lib)
 ctx.frames_dev(seq[1].data_ptr(), stride * 4, n_seq[1]); ctx.synchronize()
