@@ -104,7 +104,7 @@ polar_minz_kernel(MotDevParams p, GroundBuffers g) {
   const int n = g.n[b];
   const long base = (long)blockIdx.x * kGroundChunk;
   if (base >= n) return;  // whole workgroup leaves together
-  const float4* __restrict__ in = g.in + (long)b * g.in_stride;
+  const float4* __restrict__ in = g.launch ? g.launch->in + (long)b * g.launch->in_stride : g.in + (long)b * g.in_stride;
   const int lane = wave_lane(), wave = threadIdx.x >> 6;
 
   float4 pt[kGroundItems];
@@ -350,7 +350,8 @@ __device__ __forceinline__ void classify_compact_body(const MotDevParams& p, con
   __syncthreads();
   const int chunk = s_chunk;
   const long base = (long)chunk * kCompactChunk;
-  const float4* __restrict__ in = g.in + (long)b * g.in_stride;
+  const float4* __restrict__ in = g.launch ? g.launch->in + (long)b * g.launch->in_stride : g.in + (long)b * g.in_stride;
+  const unsigned epoch = g.launch ? g.launch->epoch : g.epoch;
   const float* __restrict__ hg = g.hg + (long)b * MOT_POLAR_CELLS;
   const int lane = wave_lane(), wave = threadIdx.x >> 6;
 
@@ -482,7 +483,7 @@ __device__ __forceinline__ void classify_compact_body(const MotDevParams& p, con
     for (int j = 0; j < kPerLane; j++) { s_cnt[lane * kPerLane + j] = run; run += c[j]; }
     // decoupled look-back over the chunks of THIS frame
     unsigned long long* desc = g.desc + (long)b * g.max_chunks;
-    const unsigned long long ep = (unsigned long long)(g.epoch & kDescEpochMask) << kDescEpochShift;
+    const unsigned long long ep = (unsigned long long)(epoch & kDescEpochMask) << kDescEpochShift;
     unsigned long long mine = ep | ((unsigned long long)(unsigned)tot_e << kDescCountBits) | (unsigned long long)(unsigned)tot_g;
     int excl_e = 0, excl_g = 0;
     if (chunk > 0) {
@@ -494,7 +495,7 @@ __device__ __forceinline__ void classify_compact_body(const MotDevParams& p, con
         if (idx >= 0) {
           while (true) {
             d = __hip_atomic_load(&desc[idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if (((d >> kDescEpochShift) & kDescEpochMask) == (g.epoch & kDescEpochMask) && (d >> 62) != 0) break;
+            if (((d >> kDescEpochShift) & kDescEpochMask) == (epoch & kDescEpochMask) && (d >> 62) != 0) break;
             __builtin_amdgcn_s_sleep(1);
           }
         }

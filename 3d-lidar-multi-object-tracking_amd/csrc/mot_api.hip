@@ -107,7 +107,12 @@ struct mot_ctx {
   static constexpr int kArgRing = 16;
   char* d_argblk = nullptr;
   char* h_argring = nullptr;           // pinned, kArgRing blocks of arg_bytes
-  size_t arg_bytes = 0, arg_off_targs = 0, arg_off_ego = 0;
+  size_t arg_bytes = 0, arg_off_targs = 0, arg_off_ego = 0, arg_off_launch = 0;
+  // launch sequences captured as hipGraphs (contexts of few streams: the per-frame latency path), keyed by launch geometry
+  struct GraphKey { int batch, chunks, tracker, outputs; };
+  struct GraphEntry { GraphKey key; void* exec; };
+  std::vector<GraphEntry> graphs;
+  int graph_mode = 0;                  // 0 off, 1 on; turned off for good when a capture fails
   hipEvent_t arg_ev[kArgRing] = {};
   bool arg_used[kArgRing] = {};
   int arg_next = 0;
@@ -264,6 +269,9 @@ extern "C" void mot_destroy(mot_ctx* c) {
   if (c->d_fetch_counts) (void)hipFree(c->d_fetch_counts);
   if (c->prof_created)
     for (int i = 0; i < mot_ctx::kProfRing; i++) { (void)hipEventDestroy(c->prof_ev[i][0]); (void)hipEventDestroy(c->prof_ev[i][1]); }
+#ifndef MOT_HIPEMU
+  for (auto& ge : c->graphs) if (ge.exec) (void)hipGraphExecDestroy((hipGraphExec_t)ge.exec);
+#endif
   for (int i = 0; i < mot_ctx::kArgRing; i++) if (c->arg_ev[i]) (void)hipEventDestroy(c->arg_ev[i]);
   if (c->h_argring) (void)hipHostFree(c->h_argring);
   void* bufs[] = {c->d_in, c->d_argblk, c->d_ecell, c->d_pairs, c->d_pair_count, c->d_hg, c->d_cell, c->d_desc, c->d_ticket, c->d_elev, c->d_ground, c->d_mask, c->d_counts,
@@ -334,7 +342,8 @@ static int create_impl(mot_ctx* c) {
     auto up = [](size_t v) { return (v + 255) & ~(size_t)255; };
     c->arg_off_targs = up(B * sizeof(int));
     c->arg_off_ego = up(c->arg_off_targs + B * sizeof(TrackFrameArgs));
-    c->arg_bytes = up(c->arg_off_ego + B * sizeof(EgoTf));
+    c->arg_off_launch = up(c->arg_off_ego + B * sizeof(EgoTf));
+    c->arg_bytes = up(c->arg_off_launch + sizeof(FrameLaunch));
     MOT_HIP(c, hipMalloc(&c->d_argblk, c->arg_bytes));
     MOT_HIP(c, hipMemsetAsync(c->d_argblk, 0, c->arg_bytes, c->stream));
     MOT_HIP(c, hipHostMalloc(&c->h_argring, c->arg_bytes * mot_ctx::kArgRing, hipHostMallocDefault));
@@ -496,6 +505,7 @@ static int next_epoch(mot_ctx* c) {
 
 static GroundBuffers ground_buffers(mot_ctx* c, const float4* in, long stride, bool want_mask, bool planes = false) {
   GroundBuffers g;
+  g.launch = nullptr;
   g.epoch = c->epoch;
   g.in = in; g.in_stride = stride; g.n = c->d_n; g.pairs = c->d_pairs; g.pair_count = c->d_pair_count; g.hg = c->d_hg; g.cell = c->d_cell; g.desc = c->d_desc;
   g.ticket = c->d_ticket; g.elevated = c->d_elev; g.ground = c->d_ground; g.mask = want_mask ? c->d_mask : nullptr;
@@ -615,6 +625,26 @@ static void tf_velodyne_to_global(double x, double y, double yaw, float m[12]) {
   m[8] = txz - twy; m[9] = tyz + twx; m[10] = 1.0f - (txx + tyy); m[11] = (float)v[2];
 }
 
+// the kernels of one fused launch sequence, in order, on the context stream (plain launches, or under stream capture)
+static void issue_frame_kernels(mot_ctx* c, int batch, int max_n, int run_tracker, bool want_ground, bool want_mask, bool from_block) {
+  GroundBuffers g = ground_buffers(c, c->last_in, c->last_in_stride, want_mask, true);
+  if (!want_ground) g.ground = nullptr;   // the ground cloud on demand (mot_get_ground re-runs the compaction)
+  if (from_block) g.launch = reinterpret_cast<const FrameLaunch*>(c->d_argblk + c->arg_off_launch);
+  { ProfScope ps(c, kK1); mot_launch_ground_kernel(0, c->dp, g, batch, max_n, c->stream); }
+  { ProfScope ps(c, kK2); mot_launch_ground_kernel(1, c->dp, g, batch, max_n, c->stream); }
+  { ProfScope ps(c, kK3); mot_launch_ground_kernel(2, c->dp, g, batch, max_n, c->stream); }
+  ClusterBuffers cb = cluster_buffers(c);
+  cb.occ_list = c->d_occ_list; cb.occ_count = c->d_occ_count;   // the occupancy comes as the compaction kernel's per-chunk lists
+  cb.ecell = g.ecell;                                            // ... and every elevated point's cell with it
+  { ProfScope ps(c, kC2); mot_launch_cluster(c->dp, cb, batch, max_n, c->stream, true); }
+  { ProfScope ps(c, kB1); mot_launch_box_kernel(0, c->dp, cb, batch, max_n, c->stream); }
+  { ProfScope ps(c, kB1b); mot_launch_box_kernel(4, c->dp, cb, batch, max_n, c->stream); }
+  { ProfScope ps(c, kB2); mot_launch_box_kernel(1, c->dp, cb, batch, max_n, c->stream); }
+  { ProfScope ps(c, kB2b); mot_launch_box_kernel(3, c->dp, cb, batch, max_n, c->stream); }
+  { ProfScope ps(c, kB3); mot_launch_box_kernel(2, c->dp, cb, batch, max_n, c->stream); }
+  if (run_tracker) { ProfScope ps(c, kT1); mot_launch_track(track_buffers(c, true), batch, c->stream); }
+}
+
 // the fused launch sequence of one batch on the context stream; every argument has been validated
 static int launch_frames(mot_ctx* c, int batch, int run_tracker, const double* timestamps, const double* ego_v, const double* ego_yaw) {
   int rc;
@@ -634,25 +664,42 @@ static int launch_frames(mot_ctx* c, int batch, int run_tracker, const double* t
         tf_velodyne_to_global(c->ego[b].egoPoint[0], c->ego[b].egoPoint[1], c->ego[b].egoPoint[2], ego[b].m);
         prepare_track_args(c, targs, b, 0, timestamps[b], true);
       }
-    if ((rc = arg_block_commit(c, 0, run_tracker ? c->arg_bytes : batch * sizeof(int)))) return rc;
+    FrameLaunch* fl = reinterpret_cast<FrameLaunch*>(blk + c->arg_off_launch);
+    fl->in = c->last_in; fl->in_stride = c->last_in_stride; fl->epoch = c->epoch; fl->pad = 0;
+    if ((rc = arg_block_commit(c, 0, (run_tracker || c->graph_mode) ? c->arg_bytes : batch * sizeof(int)))) return rc;
   }
   const bool want_ground = (c->fused_outputs & MOT_OUT_GROUND) != 0, want_mask = (c->fused_outputs & MOT_OUT_MASK) != 0;
-  GroundBuffers g = ground_buffers(c, c->last_in, c->last_in_stride, want_mask, true);
-  if (!want_ground) g.ground = nullptr;   // the ground cloud on demand (mot_get_ground re-runs the compaction)
   c->ground_resident = want_ground && want_mask; c->last_fused = true;
-  { ProfScope ps(c, kK1); mot_launch_ground_kernel(0, c->dp, g, batch, max_n, c->stream); }
-  { ProfScope ps(c, kK2); mot_launch_ground_kernel(1, c->dp, g, batch, max_n, c->stream); }
-  { ProfScope ps(c, kK3); mot_launch_ground_kernel(2, c->dp, g, batch, max_n, c->stream); }
-  ClusterBuffers cb = cluster_buffers(c);
-  cb.occ_list = c->d_occ_list; cb.occ_count = c->d_occ_count;   // the occupancy comes as the compaction kernel's per-chunk lists
-  cb.ecell = g.ecell;                                            // ... and every elevated point's cell with it
-  { ProfScope ps(c, kC2); mot_launch_cluster(c->dp, cb, batch, max_n, c->stream, true); }
-  { ProfScope ps(c, kB1); mot_launch_box_kernel(0, c->dp, cb, batch, max_n, c->stream); }
-  { ProfScope ps(c, kB1b); mot_launch_box_kernel(4, c->dp, cb, batch, max_n, c->stream); }
-  { ProfScope ps(c, kB2); mot_launch_box_kernel(1, c->dp, cb, batch, max_n, c->stream); }
-  { ProfScope ps(c, kB2b); mot_launch_box_kernel(3, c->dp, cb, batch, max_n, c->stream); }
-  { ProfScope ps(c, kB3); mot_launch_box_kernel(2, c->dp, cb, batch, max_n, c->stream); }
-  if (run_tracker) { ProfScope ps(c, kT1); mot_launch_track(track_buffers(c, true), batch, c->stream); }
+#ifndef MOT_HIPEMU
+  // Few streams per launch = somebody waits for every frame: the sequence's 14-18 launches go out as ONE hipGraph launch, captured
+  // once per launch geometry. What differs from call to call without changing the geometry (the cloud's address, the look-back
+  // epoch) travels in the argument block (FrameLaunch). Not while a kernel is being timed (the event pairs are host calls).
+  if (c->graph_mode && c->prof_kernel == 0) {
+    const mot_ctx::GraphKey key = {batch, (max_n + kGroundChunk - 1) / kGroundChunk, run_tracker ? 1 : 0, c->fused_outputs};
+    void* exec = nullptr;
+    for (const auto& ge : c->graphs)
+      if (ge.key.batch == key.batch && ge.key.chunks == key.chunks && ge.key.tracker == key.tracker && ge.key.outputs == key.outputs) { exec = ge.exec; break; }
+    if (!exec) {
+      hipGraph_t graph = nullptr;
+      hipGraphExec_t ge = nullptr;
+      bool ok = hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal) == hipSuccess;
+      if (ok) {
+        issue_frame_kernels(c, batch, key.chunks * kGroundChunk, run_tracker, want_ground, want_mask, true);   // (grids from the chunk count: any frame of this geometry)
+        ok = hipStreamEndCapture(c->stream, &graph) == hipSuccess && graph != nullptr;
+      }
+      if (ok) ok = hipGraphInstantiate(&ge, graph, nullptr, nullptr, 0) == hipSuccess;
+      if (graph) (void)hipGraphDestroy(graph);
+      if (!ok) { (void)hipGetLastError(); c->graph_mode = 0; }   // this runtime cannot capture the sequence: plain launches from now on
+      else { if (c->graphs.size() >= 16) { (void)hipGraphExecDestroy((hipGraphExec_t)c->graphs.front().exec); c->graphs.erase(c->graphs.begin()); }
+             c->graphs.push_back({key, (void*)ge}); exec = (void*)ge; }
+    }
+    if (exec) {
+      MOT_HIP(c, hipGraphLaunch((hipGraphExec_t)exec, c->stream));
+      return MOT_OK;
+    }
+  }
+#endif
+  issue_frame_kernels(c, batch, max_n, run_tracker, want_ground, want_mask, false);
   MOT_HIP(c, hipGetLastError());
   return MOT_OK;
 }
@@ -1274,6 +1321,12 @@ extern "C" int mot_get_tracks(mot_ctx* c, int slot, mot_track* tracks, int max_t
   if (meta[1])
     return fail(c, MOT_E_CAPACITY, "a stream ran out of track slots (more than max_tracks_total tracks alive or just dead) or of its lifetime track budget "
                                    "(mot_params.max_tracks_ever): births are being dropped; mot_reset_tracks_slot() starts its tracks over");
+  return MOT_OK;
+}
+
+extern "C" int mot_set_launch_graphs(mot_ctx* c, int on) {
+  if (!c) return MOT_E_ARG;
+  c->graph_mode = on ? 1 : 0;
   return MOT_OK;
 }
 

@@ -67,8 +67,19 @@ struct MotDevParams {
 
 struct OccWord { unsigned word, a, b, pad; };   // word index in the bit-plane, its "seen >= 1" and "seen >= 2" bits
 
+// What changes from one launch sequence to the next without changing the launch geometry — the input cloud's address and the
+// look-back epoch — as a DEVICE-resident record (part of the argument block): a launch sequence captured once in a hipGraph
+// (mot_api.hip, small batches: the per-frame latency path) reads them from here instead of from its baked-in kernel arguments.
+struct FrameLaunch {
+  const float4* in;
+  long in_stride;
+  unsigned epoch;
+  int pad;
+};
+
 // device buffers of the ground stage for a batch of frames (frame b = slot b)
 struct GroundBuffers {
+  const FrameLaunch* launch;  // non-null (graph-captured sequences): in / in_stride / epoch are read from this record, not from the fields below
   const float4* in;        // [B][in_stride] points
   long in_stride;          // in points
   const int* n;            // [B] points per frame (device)

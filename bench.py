@@ -319,6 +319,29 @@ def single_stream(mot, torch, device, seq_dev, n_seq, stride, ego_v, ego_yaw, fr
     `throughput` = the same launches issued back to back without waiting (launch-bound: 13 kernels of a few microseconds each)."""
     F = seq_dev.shape[0]
     one = [np.ascontiguousarray(n_seq[f, :1]) for f in range(F)]
+    graphs = None
+    try:   # the same with the launch sequence sent as ONE hipGraph launch per frame (mot_set_launch_graphs)
+        with mot.Context(device=device, max_points=stride, max_batch=1, max_tracks_total=256) as c:
+            c.set_launch_graphs(True)
+            def gframe(f):
+                c.frames_dev(seq_dev[f].data_ptr(), stride * 4, one[f], run_tracker=True, timestamps=[1.0e9 + f * 1e5], ego_v=[float(ego_v[f])], ego_yaw=[float(ego_yaw[f])])
+            for f in range(min(F, 8)):
+                gframe(f)
+            c.synchronize(); c.reset()
+            glat = []
+            for f in range(F):
+                t0 = time.perf_counter(); gframe(f); c.synchronize(); glat.append(time.perf_counter() - t0)
+            g_tracks = int(c.get_tracks(0)["n"])
+            c.reset(); c.synchronize()
+            t0 = time.perf_counter()
+            for f in range(F):
+                gframe(f)
+            c.synchronize()
+            gthr = F / (time.perf_counter() - t0)
+        gl = np.array(glat) * 1e3
+        graphs = {"latency_ms": {"median": round(float(np.median(gl)), 4), "p95": round(_pct(gl, 95), 4)}, "frames_per_s_back_to_back": round(gthr, 1), "tracks_ever": g_tracks}
+    except Exception as e:
+        graphs = {"error": str(e)[:200]}
     with mot.Context(device=device, max_points=stride, max_batch=1, max_tracks_total=256) as c:
         def frame(f):
             c.frames_dev(seq_dev[f].data_ptr(), stride * 4, one[f], run_tracker=True, timestamps=[1.0e9 + f * 1e5], ego_v=[float(ego_v[f])], ego_yaw=[float(ego_yaw[f])])
@@ -346,6 +369,7 @@ def single_stream(mot, torch, device, seq_dev, n_seq, stride, ego_v, ego_yaw, fr
     return {"frames": F, "latency_ms": {"median": round(float(np.median(lat_ms)), 4), "p95": round(_pct(lat_ms, 95), 4), "max": round(float(lat_ms.max()), 4)},
             "frames_per_s_latency_bound": round(1e3 / float(np.mean(lat_ms)), 1), "frames_per_s_back_to_back": round(thr, 1),
             "hbm_frac_back_to_back": round(frame_bytes * thr / 1e9 / HBM_PEAK_GBS, 5), "tracks_ever": n_tracks,
+            "with_launch_graphs": graphs,
             "kernel_chain_us": ({"sum": round(sum(k_us.values()), 1), "per_kernel": {k: round(v, 1) for k, v in k_us.items()},
                                  "what": "each kernel of the frame's sequence alone on ONE frame (event to event, includes that one launch): the dependent chain the GPU executes per frame; "
                                          "median latency minus this sum bounds what capturing the sequence in a hipGraph could save"} if k_us else None),

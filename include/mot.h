@@ -266,6 +266,13 @@ int mot_frames_dev(mot_ctx* ctx, const float* d_xyzw, long frame_stride, const i
  * mot_ground_remove always delivers both outputs (OT/src/groundremove/ground_removal.cpp:226-247). */
 int mot_set_fused_outputs(mot_ctx* ctx, int flags);
 
+/* on != 0: the fused entry points send their launch sequence (14-18 kernels) as ONE hipGraph launch, captured once per launch geometry
+ * (batch, chunks of the largest frame, tracker on / off, outputs); what changes per call without changing the geometry travels in the
+ * device-resident argument block. For contexts somebody waits on frame by frame (one or a few streams): the host's part of a frame
+ * drops to one copy and one launch. Default off; a runtime that cannot capture the sequence falls back to plain launches silently.
+ * Kernel timing (mot_profile_kernel) uses plain launches while it is armed. */
+int mot_set_launch_graphs(mot_ctx* ctx, int on);
+
 /* The same for frames in HOST memory — what the reference's nodes receive, one message per frame
  * (OT/src/groundremove/main.cpp:91-136, OT0/src/main.cpp:51-95) — pipelined: the H2D copy of this batch runs on the
  * context's copy stream into one of two staging buffers while the kernels of the previous batch run. Returns when

@@ -110,3 +110,34 @@ def test_track_steps_dev_equals_track_step(mot, hip_lib):
                 assert ta["n"] == tb["n"] and np.array_equal(ta["track_manage"], tb["track_manage"]) and np.array_equal(ta["lifetime"], tb["lifetime"])
                 assert np.array_equal(ta["p"], tb["p"]) and np.array_equal(ta["v_yaw"], tb["v_yaw"])
         assert (a.get_tracks(0)["track_manage"] > 0).sum() >= 30    # the tracker really runs with tens of live tracks
+
+
+def test_launch_graphs_equal_plain_launches(mot, hip_lib, oracle, synth):
+    """mot_set_launch_graphs: the fused sequence as one hipGraph launch per frame (captured once per launch geometry) must give what the
+    plain launches give — frames at changing addresses, changing point counts (inside one geometry and across two), tracker on, the ground
+    cloud materialised on demand afterwards — and what the oracle gives."""
+    p = oracle.params(0)
+    stride = 32768
+    with mot.Context(max_points=stride, max_batch=2, max_tracks_total=128) as a, mot.Context(max_points=stride, max_batch=2, max_tracks_total=128) as g:
+        g.set_launch_graphs(True)
+        bufs = []
+        for f in range(10):
+            n = [30000 - 37 * f, 17000 + 501 * f] if f % 4 != 3 else [9000 + f, 30000]     # a second geometry every fourth frame
+            host = np.zeros((2, stride, 4), np.float32)
+            for s in range(2):
+                host[s, : n[s]] = synth.make_cloud(30000, 60 + s, f)[: n[s]]
+            dev = hiprt.DeviceBuffer(host); bufs.append(dev)     # a new address every frame
+            kw = dict(run_tracker=True, timestamps=[1.0e9 + f * 1e5] * 2, ego_v=[2.0, 1.0], ego_yaw=[0.01 * f, 0.0])
+            a.frames_dev(dev.ptr, stride * 4, n, **kw); g.frames_dev(dev.ptr, stride * 4, n, **kw)
+            for s in range(2):
+                assert np.array_equal(a.get_boxes(s)["boxes"], g.get_boxes(s)["boxes"]), (f, s)
+                ta, tg = a.get_tracks(s), g.get_tracks(s)
+                assert ta["n"] == tg["n"] and np.array_equal(ta["track_manage"], tg["track_manage"]) and np.array_equal(ta["p"], tg["p"]) and np.array_equal(ta["v_yaw"], tg["v_yaw"]), (f, s)
+                ga, gg = a.get_ground(s, n_hint=n[s]), g.get_ground(s, n_hint=n[s])
+                assert np.array_equal(ga["mask"], gg["mask"]) and np.array_equal(ga["ground"], gg["ground"]) and np.array_equal(ga["elevated"], gg["elevated"])
+            o = oracle.ground_remove(p, host[0, : n[0]])
+            assert np.array_equal(g.get_ground(0, n_hint=n[0])["elevated"], o["elevated"])
+            cl = oracle.cluster(p, o["elevated"])
+            assert np.array_equal(g.get_boxes(0)["boxes"], oracle.box_fit(p, o["elevated"], cl["grid"], cl["num_cluster"])["boxes"])
+        for d in bufs:
+            d.free()
