@@ -1279,8 +1279,11 @@ extern "C" int mot_get_tracks(mot_ctx* c, int slot, mot_track* tracks, int max_t
   MOT_GUARD(c);
   if (slot < 0 || slot >= c->batch || !n_tracks || max_tracks < 0) return fail(c, MOT_E_ARG, "mot_get_tracks: slot out of range, null n_tracks or negative max_tracks");
   int meta[2] = {0, 0};
+  const size_t T = c->max_tracks_total, E = c->max_tracks_ever, usedW = (T + 63) / 64;
+  std::vector<unsigned long long> used(usedW, 0ull);
   MOT_HIP(c, hipMemcpyAsync(&meta[0], c->d_nt + slot, sizeof(int), hipMemcpyDeviceToHost, c->stream));
   MOT_HIP(c, hipMemcpyAsync(&meta[1], c->d_tflags + slot, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+  MOT_HIP(c, hipMemcpyAsync(used.data(), c->d_used + (size_t)slot * usedW, usedW * sizeof(unsigned long long), hipMemcpyDeviceToHost, c->stream));
   MOT_HIP(c, hipStreamSynchronize(c->stream));
   const int n = meta[0];
   c->ego[slot].nt = n;
@@ -1291,11 +1294,14 @@ extern "C" int mot_get_tracks(mot_ctx* c, int slot, mot_track* tracks, int max_t
     // OT/tracking/imm_ukf_jpda.cpp:995-1041). A track that still owns a slot — alive, or dead since the last step only — has its
     // record there; of an evicted one (dead for longer) the position, lifetime_ and the static flag are kept: trackManage 0, not
     // shown, v and yaw 0 (the reference reports the frozen state with the current ego yaw added; every consumer skips dead tracks).
-    const size_t T = c->max_tracks_total, E = c->max_tracks_ever;
-    const size_t o_out = 0, o_slot = o_out + T * sizeof(mot_track), o_tomb = o_slot + (size_t)n * sizeof(int), o_pos = (o_tomb + (size_t)n * sizeof(TrackTomb) + 15) & ~(size_t)15;
+    // Only the slots up to the highest one in use are read back (slots are handed out lowest first).
+    size_t hi = 0;
+    for (size_t w = 0; w < usedW; w++) if (used[w]) hi = w * 64 + (63 - (size_t)__builtin_clzll(used[w])) + 1;
+    if (hi > T) hi = T;
+    const size_t o_out = 0, o_slot = o_out + hi * sizeof(mot_track), o_tomb = o_slot + (size_t)n * sizeof(int), o_pos = (o_tomb + (size_t)n * sizeof(TrackTomb) + 15) & ~(size_t)15;
     c->h_trk.resize(o_pos + (size_t)n * sizeof(Vec2d));
     char* h = c->h_trk.data();
-    MOT_HIP(c, hipMemcpyAsync(h + o_out, c->d_tout + (size_t)slot * T, T * sizeof(mot_track), hipMemcpyDeviceToHost, c->stream));
+    if (hi) MOT_HIP(c, hipMemcpyAsync(h + o_out, c->d_tout + (size_t)slot * T, hi * sizeof(mot_track), hipMemcpyDeviceToHost, c->stream));
     MOT_HIP(c, hipMemcpyAsync(h + o_slot, c->d_slot_of + (size_t)slot * E, (size_t)n * sizeof(int), hipMemcpyDeviceToHost, c->stream));
     MOT_HIP(c, hipMemcpyAsync(h + o_tomb, c->d_tomb + (size_t)slot * E, (size_t)n * sizeof(TrackTomb), hipMemcpyDeviceToHost, c->stream));
     MOT_HIP(c, hipMemcpyAsync(h + o_pos, c->d_pos + (size_t)slot * E, (size_t)n * sizeof(Vec2d), hipMemcpyDeviceToHost, c->stream));
@@ -1305,7 +1311,7 @@ extern "C" int mot_get_tracks(mot_ctx* c, int slot, mot_track* tracks, int max_t
     const TrackTomb* tomb = reinterpret_cast<const TrackTomb*>(h + o_tomb);
     const Vec2d* pos = reinterpret_cast<const Vec2d*>(h + o_pos);
     for (int i = 0; i < n; i++) {
-      if (slot_of[i] >= 0 && (size_t)slot_of[i] < T) tracks[i] = rec[slot_of[i]];
+      if (slot_of[i] >= 0 && (size_t)slot_of[i] < hi) tracks[i] = rec[slot_of[i]];
       else {
         mot_track o;
         memset(&o, 0, sizeof o);
