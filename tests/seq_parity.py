@@ -102,7 +102,7 @@ def compare_tracks(a, o, state_dev, state_orc, where, rtol=RTOL, stats=None, ski
                 av, ov = np.asarray(a[key][i], np.float64), np.asarray(o[key][i], np.float64)
                 nan = np.isnan(ov)
                 assert np.array_equal(nan, np.isnan(av)), (where, int(i), key, "NaN pattern")
-                if not nan.all():
+                if not nan.all() and np.isfinite(rtol):   # (rtol = inf: the caller only collects the state errors)
                     assert np.abs(av[~nan] - ov[~nan]).max() <= rtol * np.abs(ov[~nan]).max() + atol, (where, int(i), key, av, ov)
         w_i = 0.0
         for k in STATE_KEYS:
@@ -114,7 +114,7 @@ def compare_tracks(a, o, state_dev, state_orc, where, rtol=RTOL, stats=None, ski
                 continue
             scale = max(float(np.abs(so_k[~nan]).max()), 1e-300)
             err = float(np.abs(sd_k[~nan] - so_k[~nan]).max())
-            if check:
+            if check and np.isfinite(rtol):
                 assert err <= rtol * scale + 1e-9, (where, int(i), k, err, scale, "ILL-CONDITIONED" if ill else "well conditioned",
                                                      "x_merge", list(np.asarray(so["x_merge"])), "diag P", list(np.diag(np.asarray(so["p_merge"]).reshape(5, 5))),
                                                      "lifetime", so["lifetime"], "track_manage", so["track_manage"])
