@@ -208,7 +208,7 @@ def cpu_baseline(frames: np.ndarray, ego_v, ego_yaw, n_points: int, budget_s: fl
         parity["states_within_1e-4"] = stats.get("max_rel_state_err") is not None and stats["max_rel_state_err"] <= 1e-4
         parity.update({"max_rel_state_err": stats.get("max_rel_state_err"), "ill_conditioned_track_frames": stats.get("ill_conditioned", 0),
                        "max_rel_state_err_ill_conditioned": stats.get("max_rel_state_err_ill_conditioned"),
-                       "ill_conditioned_means": "a track whose filter is diverging (|yaw rate| >= 20 rad/s, a covariance entry >= 1e3, a non-positive variance or NaN: tests/seq_parity.py) "
+                       "ill_conditioned_means": "a track whose filter is diverging (|yaw rate| >= 20 rad/s, a covariance entry >= 1e3, a yaw / yaw-rate variance > 9, a covariance that is not positive definite, NaN — or was so within the last 30 frames: tests/seq_parity.py) "
                                                 "amplifies last-bit differences of equivalent operation orders by decades per frame until the reference's own guards kill it; its discrete outputs are compared like everybody's",
                        "state_compares": stats.get("state_compares", 0), "live_tracks_max": stats.get("live_max", 0),
                        "tracks_ever": stats.get("tracks_ever", 0), "boxes_total": int(sum(len(r["boxes"]) for r in kept)), "first_mismatch_frame": first_bad or None,

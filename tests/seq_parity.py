@@ -61,6 +61,8 @@ def well_conditioned(state) -> bool:
     if not (ok and abs(x[4]) < 20.0 and np.abs(P).max() < 1e3 and np.diag(P.reshape(5, 5)).min() > 0.0):
         return False
     P = P.reshape(5, 5)
+    if P[3, 3] > 9.0 or P[4, 4] > 9.0:   # the yaw (rate) is unknown to within a turn (sigma > 3 rad): the sigma points wrap around, the filter is a random walk
+        return False
     return bool(np.linalg.eigvalsh((P + P.T) * 0.5).min() > 0.0)   # a covariance that is not positive definite: numerically meaningless
 
 
