@@ -223,7 +223,7 @@ def test_long_run_on_256_track_slots(mot, hip_lib, oracle):
     created equal the oracle's with unbounded memory (the reference never frees a track, imm_ukf_jpda.cpp:972-989); filter states of the
     live tracks every 50 frames. The world replays the situation in which a dead track's last position decides a live track's fate."""
     import tracker_cases as TC
-    st = TC.long_run_bounded_slots(mot, oracle, frames=10000, slots=256, spots=40, state_every=50, min_ever_factor=8, max_chaos_restarts=12)
+    st = TC.long_run_bounded_slots(mot, oracle, frames=10000, slots=256, spots=40, state_every=50, min_ever_factor=8, max_chaos_restarts=40)
     assert st["tracks_ever"] >= 2048 and st["max_rel_state_err"] <= 1e-2 and st["frames_compared"] >= 9900
 
 
