@@ -509,6 +509,8 @@ def main():
     ap.add_argument("--phase", type=int, default=38, help="frames by which context c runs ahead of context c-1 within the (shared) sequences: at any instant the contexts' launches "
                     "read DISJOINT frames, so no context finds another's input in the 256 MiB Infinity Cache (0 = lock-step: every context on the same frame, round 2's layout)")
     ap.add_argument("--force-gather", action="store_true", help="run the per-frame RCCL all-gather of the track blocks even with one rank (exercises the N > 1 path on one GPU)")
+    ap.add_argument("--shared-gpu-dryrun", action="store_true", help="every rank on device 0, collectives over gloo: drives the N > 1 code path of this script (spawn, stream "
+                    "sharding, packed gather, max over ranks, the JSON line) on a 1-GPU box. Not a measurement; the line says so")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-aux", action="store_true", help="skip tracker_stress / host_boundary / per-kernel isolated timings")
     ap.add_argument("--selftest-cpu", action="store_true", help="launch-logic self-test on CPU (gloo + emulated kernels); not a measurement")
@@ -539,13 +541,18 @@ def main():
 
     if not torch.cuda.is_available():
         print("bench.py needs a GPU (the library has no CPU fallback)", file=sys.stderr); sys.exit(2)
+    if args.shared_gpu_dryrun:
+        local = 0
     torch.cuda.set_device(local)
     gather_on = world > 1 or args.force_gather
     if gather_on:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         if world == 1:   # --force-gather without a launcher: a one-rank group on the loopback
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29577"); os.environ.setdefault("RANK", "0"); os.environ.setdefault("WORLD_SIZE", "1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        if args.shared_gpu_dryrun:
+            dist.init_process_group("gloo")   # RCCL refuses two ranks on one device
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
         assert dist.get_world_size() == args.gpus, (dist.get_world_size(), args.gpus)
 
     build = _load("mot_amd.build", os.path.join(PKG_DIR, "build.py"))
@@ -739,7 +746,7 @@ def main():
             "value": round(frames / dt, 1), "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(dt / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32/f64 (fp32 grid indices with fp64 intermediates, int32 grids/labels, fp64 tracker — the reference's types)",
-            "data": "synthetic" if not variant else f"synthetic; EXPERIMENT BUILD {variant} — not the product library", "inputs": "hbm-resident (rendered into HBM before the timed region; see host_boundary_pipelined for the PCIe-inclusive rate)",
+            "data": "synthetic; DRY RUN: every rank on ONE device, gloo collectives — not a measurement" if args.shared_gpu_dryrun else "synthetic" if not variant else f"synthetic; EXPERIMENT BUILD {variant} — not the product library", "inputs": "hbm-resident (rendered into HBM before the timed region; see host_boundary_pipelined for the PCIe-inclusive rate)",
             "timed_region_s": round(dt, 3), "host_issue_ms_per_step": round(host_issue[0] / args.steps * 1e3, 3),
             "host_cpu_ms_per_step": round(host_cpu[0] / args.steps * 1e3, 3) if not (args.issue_threads and NC > 1) else None,
             "host_unblocked_us_per_launch_sequence": round(host_unblocked_us, 1),

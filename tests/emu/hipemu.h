@@ -313,6 +313,8 @@ static inline hipError_t hipMemsetAsync(void* d, int v, size_t n, hipStream_t) {
 static inline hipError_t hipMemsetD32Async(void* d, int v, size_t count, hipStream_t) { int* q = (int*)d; for (size_t i = 0; i < count; i++) q[i] = v; return hipSuccess; }
 static inline hipError_t hipStreamCreate(hipStream_t* s) { *s = (void*)1; return hipSuccess; }
 static inline hipError_t hipStreamCreateWithFlags(hipStream_t* s, unsigned) { *s = (void*)1; return hipSuccess; }
+static inline hipError_t hipStreamCreateWithPriority(hipStream_t* s, unsigned, int) { *s = (void*)1; return hipSuccess; }
+static inline hipError_t hipDeviceGetStreamPriorityRange(int* least, int* greatest) { *least = 1; *greatest = -1; return hipSuccess; }
 #define hipStreamNonBlocking 1
 #define hipHostMallocDefault 0
 static inline hipError_t hipStreamDestroy(hipStream_t) { return hipSuccess; }
