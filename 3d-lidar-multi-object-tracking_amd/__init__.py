@@ -77,7 +77,7 @@ EXPORTS = (
     "mot_track_steps_dev", "mot_profile_kernel", "mot_profile_read", "mot_get_params", "mot_set_fused_outputs", "mot_reset_tracks_slot", "mot_export_tracks_packed_dev", "mot_set_launch_graphs",
 )
 ABI_VERSION = 3
-OUT_GROUND, OUT_MASK = 1, 2
+OUT_GROUND, OUT_MASK, OUT_LABELS = 1, 2, 4
 
 _libs: dict[str, C.CDLL] = {}
 
@@ -186,7 +186,7 @@ class Context:
         self._ck(self.lib.mot_set_launch_graphs(self._h, int(on)))
 
     def set_fused_outputs(self, flags: int):
-        """which by-products of the ground stage the fused entry points write (OUT_GROUND | OUT_MASK; default 0: on demand)"""
+        """which by-products of the ground stage the fused entry points write (OUT_GROUND | OUT_MASK | OUT_LABELS; default 0: on demand)"""
         self._ck(self.lib.mot_set_fused_outputs(self._h, flags))
 
     def _track_buffer(self, slot, max_tracks):

@@ -125,7 +125,7 @@ label_stats_kernel(MotDevParams p, ClusterBuffers c) {
   const int num_cluster = c.counts[b * kCountsStride + kCntClusters];
   const float4* __restrict__ pts = c.elevated + (long)b * c.cap;
   const int* __restrict__ grid = c.grid + (long)b * (MOT_MAX_GRID * MOT_MAX_GRID);
-  int* __restrict__ label = c.label + (long)b * c.cap;
+  int* __restrict__ label = c.label ? c.label + (long)b * c.cap : nullptr;   // null: the fused path without MOT_OUT_LABELS (point_labels_kernel on demand)
   int* __restrict__ pix = c.pix + (long)b * c.cap;
   ClusterStats* __restrict__ stats = c.stats + (long)b * kMaxClusters;
   PointGroup* __restrict__ out = c.groups + (long)b * c.group_cap;
@@ -164,7 +164,7 @@ label_stats_kernel(MotDevParams p, ClusterBuffers c) {
     const float4 q = qs[k];
     if (lab < 0 || lab > num_cluster) lab = 0;
     if (i < n) {
-      label[i] = lab;
+      if (label) label[i] = lab;
       // picture pixel of the point (box_fitting.cpp:244-254, before the per-cluster re-centring): the rectangle branch of
       // the gather kernel works on these, read in cluster-sorted order, instead of fetching every point again
       const float roiX = q.x + p.roi_half, roiY = q.y + p.roi_half;
@@ -1076,6 +1076,36 @@ box_finalize_kernel(MotDevParams p, ClusterBuffers c) {
     c.counts[b * kCountsStride + kCntUndef] = s_undef;
     c.counts[b * kCountsStride + kCntPoly] = 0;  // re-arm the polygon pool
   }
+}
+
+// ------------------------------------------------------------------------------------------ per-point labels on demand
+// getClusteredPoints' label of every elevated point of ONE frame (box_fitting.cpp:46-72), for mot_get_clusters after a fused launch
+// that did not ask for them (MOT_OUT_LABELS): the label kernel's first lines again, from the cells / grid still resident.
+__global__ void MOT_LAUNCH_BOUNDS(256)
+point_labels_kernel(MotDevParams p, ClusterBuffers c, int b) {
+  const int n = c.counts[b * kCountsStride + kCntElev];
+  const int num_cluster = c.counts[b * kCountsStride + kCntClusters];
+  const int* __restrict__ grid = c.grid + (long)b * (MOT_MAX_GRID * MOT_MAX_GRID);
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    int cell;
+    if (c.ecell) {
+      const unsigned e = c.ecell[(long)b * c.cap + i];
+      cell = e != 0xffffu ? (int)((e >> 8) * (unsigned)p.num_grid + (e & 255u)) : -1;
+    } else {
+      const float4 q = c.elevated[(long)b * c.cap + i];
+      const int bit = mot_cart_bit(p, q.x, q.y);
+      cell = bit >= 0 ? (bit >> 8) * p.num_grid + (bit & 255) : -1;
+    }
+    int lab = cell >= 0 ? grid[cell] : 0;
+    if (lab < 0 || lab > num_cluster) lab = 0;
+    c.label[(long)b * c.cap + i] = lab;
+  }
+}
+void mot_launch_point_labels(const MotDevParams& p, const ClusterBuffers& c, int slot, int max_n, hipStream_t stream) {
+  int blocks = (max_n + 255) / 256;
+  if (blocks < 1) blocks = 1;
+  if (blocks > 1024) blocks = 1024;
+  hipLaunchKernelGGL(point_labels_kernel, dim3(blocks), dim3(256), 0, stream, p, c, slot);
 }
 
 // ------------------------------------------------------------------------------------------ host

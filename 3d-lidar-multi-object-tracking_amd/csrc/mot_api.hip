@@ -120,6 +120,9 @@ struct mot_ctx {
   std::vector<int> h_n;
   unsigned short* d_ecell = nullptr;   // Cartesian cell of every elevated point (fused path: compaction kernel -> label kernel)
   int fused_outputs = 0;               // MOT_OUT_* the fused entry points materialise besides what the next stage needs
+  // per-point cluster labels of a slot: 1 = in d_label; 0 = not computed, the slot's cloud and cells come from the fused compaction kernel;
+  // 2 = not computed, the slot's cloud was uploaded by a stage-wise call (no cells). mot_get_clusters computes them on demand.
+  std::vector<char> label_state;
   bool ground_resident = false;        // d_ground / d_mask hold the last batch's ground cloud and mask
   bool last_fused = false;             // the last ground launch was a fused one (input, cells and thresholds of the batch still resident)
   int* h_counts = nullptr;  // pinned [batch][4]
@@ -435,6 +438,7 @@ static int create_impl(mot_ctx* c) {
   MOT_HIP(c, hipMemsetAsync(c->d_desc, 0, B * c->max_chunks * sizeof(unsigned long long), c->stream));
   MOT_HIP(c, hipStreamSynchronize(c->stream));
   c->h_n.assign(B, 0);
+  c->label_state.assign(B, 2);
   return MOT_OK;
 }
 
@@ -636,6 +640,7 @@ static void issue_frame_kernels(mot_ctx* c, int batch, int max_n, int run_tracke
   ClusterBuffers cb = cluster_buffers(c);
   cb.occ_list = c->d_occ_list; cb.occ_count = c->d_occ_count;   // the occupancy comes as the compaction kernel's per-chunk lists
   cb.ecell = g.ecell;                                            // ... and every elevated point's cell with it
+  if (!(c->fused_outputs & MOT_OUT_LABELS)) cb.label = nullptr;  // per-point labels on demand (mot_get_clusters)
   { ProfScope ps(c, kC2); mot_launch_cluster(c->dp, cb, batch, max_n, c->stream, true); }
   { ProfScope ps(c, kB1); mot_launch_box_kernel(0, c->dp, cb, batch, max_n, c->stream); }
   { ProfScope ps(c, kB1b); mot_launch_box_kernel(4, c->dp, cb, batch, max_n, c->stream); }
@@ -670,6 +675,7 @@ static int launch_frames(mot_ctx* c, int batch, int run_tracker, const double* t
   }
   const bool want_ground = (c->fused_outputs & MOT_OUT_GROUND) != 0, want_mask = (c->fused_outputs & MOT_OUT_MASK) != 0;
   c->ground_resident = want_ground && want_mask; c->last_fused = true;
+  c->label_state.assign(c->batch, (c->fused_outputs & MOT_OUT_LABELS) ? 1 : 0);
 #ifndef MOT_HIPEMU
   // Few streams per launch = somebody waits for every frame: the sequence's 14-18 launches go out as ONE hipGraph launch, captured
   // once per launch geometry. What differs from call to call without changing the geometry (the cloud's address, the look-back
@@ -879,6 +885,14 @@ extern "C" int mot_get_clusters(mot_ctx* c, int slot, int32_t* grid, int* num_cl
   int ne = c->h_counts[slot * kCountsStride + kCntElev];
   if (point_label && ne > label_capacity) return fail(c, MOT_E_CAPACITY, "more elevated points than the caller's label buffer holds");   // before any copy is queued: "nothing copied"
   if (grid) MOT_HIP(c, hipMemcpyAsync(grid, c->d_grid + (size_t)slot * MOT_MAX_GRID * MOT_MAX_GRID, (size_t)G * G * sizeof(int), hipMemcpyDeviceToHost, c->stream));
+  if (point_label && ne > 0 && c->label_state[slot] != 1) {
+    // the fused path left the per-point labels out (mot_set_fused_outputs): this slot's, from its cells and label grid
+    ClusterBuffers cb = cluster_buffers(c);
+    cb.ecell = (c->label_state[slot] == 0 && c->params.num_grid < MOT_MAX_GRID) ? c->d_ecell : nullptr;
+    mot_launch_point_labels(c->dp, cb, slot, ne, c->stream);
+    MOT_HIP(c, hipGetLastError());
+    c->label_state[slot] = 1;
+  }
   if (point_label && ne > 0) MOT_HIP(c, hipMemcpyAsync(point_label, c->d_label + (size_t)slot * c->cap, (size_t)ne * sizeof(int), hipMemcpyDeviceToHost, c->stream));
   MOT_HIP(c, hipStreamSynchronize(c->stream));
   return MOT_OK;
@@ -915,6 +929,7 @@ extern "C" int mot_cluster(mot_ctx* c, const float* elev, int n, int32_t* grid, 
     mot_launch_stats_init(cb, 1, c->stream);
     MOT_HIP(c, hipMemsetAsync(c->d_counts + kCntGroups, 0, 2 * sizeof(int), c->stream));   // kCntGroups, kCntIrregular
   }
+  c->label_state[0] = point_label ? 1 : 2;
   MOT_HIP(c, hipGetLastError());
   return mot_get_clusters(c, 0, grid, num_cluster, point_label, n);
 }
@@ -934,6 +949,7 @@ extern "C" int mot_box_fit(mot_ctx* c, const float* elev, int n, const int32_t* 
   if ((rc = set_count(c, 0, kCntClusters, num_cluster))) return rc;
   ClusterBuffers cb = cluster_buffers(c);
   mot_launch_box(c->dp, cb, 1, n, c->stream);
+  c->label_state[0] = 1;
   MOT_HIP(c, hipGetLastError());
   return mot_get_boxes(c, 0, boxes, max_boxes, n_boxes, box_cluster, n_undefined);
 }
@@ -950,6 +966,7 @@ extern "C" int mot_box_fit_resident(mot_ctx* c, float* boxes, int max_boxes, int
   if (n < 0 || n > c->cap) return fail(c, MOT_E_STATE, "mot_box_fit_resident: no cloud resident in slot 0");
   if (c->h_counts[kCntClusters] > kMaxClusters) return fail(c, MOT_E_CAPACITY, "more clusters than the library supports (4096)");
   mot_launch_box(c->dp, cluster_buffers(c), 1, n, c->stream);
+  c->label_state[0] = 1;
   MOT_HIP(c, hipGetLastError());
   return mot_get_boxes(c, 0, boxes, max_boxes, n_boxes, box_cluster, n_undefined);
 }
@@ -1084,7 +1101,7 @@ extern "C" int mot_ground_remove(mot_ctx* c, const float* xyzw, int n, float* el
   GroundBuffers g = ground_buffers(c, c->d_in, c->cap, true);
   mot_launch_ground(c->dp, g, 1, n, c->stream);
   MOT_HIP(c, hipGetLastError());
-  c->ground_resident = true; c->last_fused = false;
+  c->ground_resident = true; c->last_fused = false; c->label_state[0] = 2;
   return mot_get_ground(c, 0, elev, n_elev, ground, n_ground, mask, n);
 }
 
@@ -1122,7 +1139,7 @@ extern "C" int mot_ground_remove_pointcloud2(mot_ctx* c, const void* data, int n
   GroundBuffers g = ground_buffers(c, c->d_in, c->cap, true);
   mot_launch_ground(c->dp, g, 1, n, c->stream);
   MOT_HIP(c, hipGetLastError());
-  c->ground_resident = true; c->last_fused = false;
+  c->ground_resident = true; c->last_fused = false; c->label_state[0] = 2;
   return mot_get_ground(c, 0, elev, n_elev, ground, n_ground, mask, n);
 }
 
@@ -1145,12 +1162,13 @@ static int launch_one(mot_ctx* c, int id, int batch) {
   if (id == kK3) c->ground_resident = (c->fused_outputs & (MOT_OUT_GROUND | MOT_OUT_MASK)) == (MOT_OUT_GROUND | MOT_OUT_MASK);
   ClusterBuffers cb = cluster_buffers(c);
   cb.occ_list = c->d_occ_list; cb.occ_count = c->d_occ_count; cb.ecell = g.ecell;
+  if (!(c->fused_outputs & MOT_OUT_LABELS)) cb.label = nullptr;   // as in the fused path
   switch (id) {
     case kK1: mot_launch_ground_kernel(0, c->dp, g, batch, max_n, c->stream); break;
     case kK2: mot_launch_ground_kernel(1, c->dp, g, batch, max_n, c->stream); break;
     case kK3: mot_launch_ground_kernel(2, c->dp, g, batch, max_n, c->stream); break;
     case kC2: mot_launch_cluster_kernel(1, c->dp, cb, batch, max_n, c->stream); break;
-    case kB1: mot_launch_box_kernel(0, c->dp, cb, batch, max_n, c->stream); break;
+    case kB1: mot_launch_box_kernel(0, c->dp, cb, batch, max_n, c->stream); c->label_state.assign(c->batch, cb.label ? 1 : 0); break;
     case kB2: mot_launch_box_kernel(1, c->dp, cb, batch, max_n, c->stream); break;
     case kB3: mot_launch_box_kernel(2, c->dp, cb, batch, max_n, c->stream); break;
     case kB2b: mot_launch_box_kernel(3, c->dp, cb, batch, max_n, c->stream); break;
@@ -1338,7 +1356,7 @@ extern "C" int mot_set_launch_graphs(mot_ctx* c, int on) {
 
 extern "C" int mot_set_fused_outputs(mot_ctx* c, int flags) {
   if (!c) return MOT_E_ARG;
-  if (flags & ~(MOT_OUT_GROUND | MOT_OUT_MASK)) return fail(c, MOT_E_ARG, "mot_set_fused_outputs: unknown flag");
+  if (flags & ~(MOT_OUT_GROUND | MOT_OUT_MASK | MOT_OUT_LABELS)) return fail(c, MOT_E_ARG, "mot_set_fused_outputs: unknown flag");
   c->fused_outputs = flags;
   return MOT_OK;
 }

@@ -183,6 +183,7 @@ void mot_launch_box(const MotDevParams& p, const ClusterBuffers& c, int batch, i
 // pieces, for the stage-wise host entry points and per-kernel timing
 void mot_launch_cluster_kernel(int which, const MotDevParams& p, const ClusterBuffers& c, int batch, int max_n, hipStream_t stream);
 void mot_launch_stats_init(const ClusterBuffers& c, int batch, hipStream_t stream);
+void mot_launch_point_labels(const MotDevParams& p, const ClusterBuffers& c, int slot, int max_n, hipStream_t stream);
 void mot_launch_box_kernel(int which, const MotDevParams& p, const ClusterBuffers& c, int batch, int max_n, hipStream_t stream);
 
 // ---- cluster-node side products (side.hip) ------------------------------------------------------

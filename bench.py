@@ -723,7 +723,7 @@ def main():
                      "polar_filter_kernel": 8.0 * 9600 * BL,
                      "classify_compact_kernel": 16.0 * n_tot + 16.0 * ne_tot,   # the fused path's default: ground cloud and mask on demand (round 2: + 16 N_g + N)
                      "ccl_kernel": (2 * 2048 * 4 + 4.0 * G * G) * BL,
-                     "label_stats_kernel": (16.0 + 4.0 + 4.0) * ne_tot,
+                     "label_stats_kernel": (16.0 + 4.0) * ne_tot,   # points read, pixels written; the per-point labels are written on demand only (MOT_OUT_LABELS)
                      "cluster_index_kernel": 4.0 * ne_tot,
                      "cluster_gather_kernel": (4.0 + 4.0) * ne_tot,
                      "cluster_rect_kernel": 4.0 * ne_tot / 8,

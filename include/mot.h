@@ -69,7 +69,7 @@ enum {
 enum { MOT_MASK_DROPPED = 0, MOT_MASK_GROUND = 1, MOT_MASK_ELEVATED = 2 };
 
 /* by-products of groundRemove that nothing downstream of it reads (mot_set_fused_outputs) */
-enum { MOT_OUT_GROUND = 1, /* groundCloud */ MOT_OUT_MASK = 2 /* the per-point classification */ };
+enum { MOT_OUT_GROUND = 1, /* groundCloud */ MOT_OUT_MASK = 2, /* the per-point classification */ MOT_OUT_LABELS = 4 /* the cluster label of every elevated point */ };
 
 /* All tunables of the path. The reference keeps them as file-scope globals; file:line in the
  * comments. mot_params_preset() fills either preset. */
@@ -258,12 +258,15 @@ int mot_frames_dev(mot_ctx* ctx, const float* d_xyzw, long frame_stride, const i
                    int run_tracker, const double* timestamps, const double* ego_v, const double* ego_yaw);
 
 /* Which by-products of the ground stage the FUSED entry points (mot_frames_dev, mot_frames_host, mot_frame_pointcloud2) write
- * besides what the next stage needs: flags = OR of MOT_OUT_GROUND / MOT_OUT_MASK, default 0. The reference's own fused
+ * besides what the next stage needs: flags = OR of MOT_OUT_GROUND / MOT_OUT_MASK / MOT_OUT_LABELS, default 0. The reference's own fused
  * precedent never touches groundCloud after groundRemove (OT0/src/main.cpp:63-79), and the ground cloud is a quarter of the
  * compaction kernel's HBM traffic. Nothing is lost with the default: mot_get_ground materialises the ground cloud / mask of
  * the LAST batch on demand (it re-runs the compaction from the batch's input, polar cells and thresholds, all still resident —
- * so with mot_frames_dev the caller's input buffer must be unchanged until then). Sticky per context. The stage-wise
- * mot_ground_remove always delivers both outputs (OT/src/groundremove/ground_removal.cpp:226-247). */
+ * so with mot_frames_dev the caller's input buffer must be unchanged until then). Likewise the per-point cluster labels
+ * (getClusteredPoints, OT/src/cluster/box_fitting.cpp:46-72: the box stage itself works on a cluster-sorted index and never reads
+ * them back): mot_get_clusters(point_label) computes them for the slot it is asked about, from the cells and the label grid still
+ * resident. Sticky per context. The stage-wise mot_ground_remove / mot_cluster always deliver all their outputs
+ * (OT/src/groundremove/ground_removal.cpp:226-247). */
 int mot_set_fused_outputs(mot_ctx* ctx, int flags);
 
 /* on != 0: the fused entry points send their launch sequence (14-18 kernels) as ONE hipGraph launch, captured once per launch geometry

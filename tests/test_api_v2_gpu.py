@@ -141,3 +141,42 @@ def test_launch_graphs_equal_plain_launches(mot, hip_lib, oracle, synth):
             assert np.array_equal(g.get_boxes(0)["boxes"], oracle.box_fit(p, o["elevated"], cl["grid"], cl["num_cluster"])["boxes"])
         for d in bufs:
             d.free()
+
+
+def test_by_products_on_demand_equal_materialised(mot, hip_lib, oracle, synth):
+    """mot_set_fused_outputs on the device: ground cloud, mask and per-point cluster labels written by the fused path or computed
+    when asked for (compaction re-run; labels from the handed-over cells, or from the points on a 256-cell grid and after a
+    stage-wise mot_cluster) — every way equal to the oracle, ragged batch"""
+    B, N, stride = 3, 60000, 61440
+    n = [N, N - 4321, 900]
+    host = np.zeros((B, stride, 4), np.float32)
+    for s in range(B):
+        host[s, : n[s]] = synth.make_cloud(N, 90 + s, 3)[: n[s]]
+    dev = hiprt.DeviceBuffer(host)
+    for num_grid in (250, 256):
+        po = oracle.params(0, num_grid=num_grid)
+        want = []
+        for s in range(B):
+            g = oracle.ground_remove(po, host[s, : n[s]]); want.append((g, oracle.cluster(po, g["elevated"])))
+        for flags in (0, mot.OUT_LABELS, mot.OUT_GROUND | mot.OUT_MASK | mot.OUT_LABELS):
+            with mot.Context(mot.params(0, num_grid=num_grid), max_points=stride, max_batch=B) as c:
+                c.set_fused_outputs(flags)
+                c.frames_dev(dev.ptr, stride * 4, n)
+                for s in (2, 0, 1):
+                    g, cl = want[s]
+                    got = c.get_clusters(s, n_elevated=len(g["elevated"]))
+                    assert np.array_equal(got["grid"], cl["grid"]) and np.array_equal(got["point_label"], cl["point_label"]), (num_grid, flags, s)
+                    gg = c.get_ground(s, n_hint=n[s])
+                    assert np.array_equal(gg["mask"], g["mask"]) and np.array_equal(gg["ground"].view(np.uint32), g["ground"].view(np.uint32))
+                    assert np.array_equal(c.get_clusters(s, n_elevated=len(g["elevated"]))["point_label"], cl["point_label"])   # still there after the compaction re-run
+    po = oracle.params(0)
+    g = oracle.ground_remove(po, host[0, :N])
+    a = np.ascontiguousarray(g["elevated"][::-1])
+    ref = oracle.cluster(po, a)
+    with mot.Context(max_points=stride, max_batch=B) as c:
+        c.frames_dev(dev.ptr, stride * 4, n)
+        G = c.params.num_grid
+        grid = np.zeros((G, G), np.int32); nc = C.c_int(0)
+        assert hip_lib.mot_cluster(c._h, a.ctypes.data_as(C.c_void_p), len(a), grid.ctypes.data_as(C.c_void_p), C.byref(nc), None) == 0
+        got = c.get_clusters(0, n_elevated=len(a))
+        assert np.array_equal(got["grid"], ref["grid"]) and np.array_equal(got["point_label"], ref["point_label"])

@@ -167,9 +167,9 @@ def test_fast_path_sweeps_on_the_emulator(mot, emu):
 
 
 def test_fused_outputs_on_demand_and_materialised(mot, emu, synth, oracle):
-    """mot_set_fused_outputs: by default the fused path writes neither the ground cloud nor the mask (nothing downstream reads them);
-    mot_get_ground re-runs the compaction of the last batch when they are asked for. With the flags set they are written in the
-    first place. Either way: equal to the oracle, for every slot of a ragged batch, and the cluster stage's results are untouched."""
+    """mot_set_fused_outputs: by default the fused path writes neither the ground cloud nor the mask nor the per-point cluster labels
+    (nothing downstream reads them); mot_get_ground re-runs the compaction of the last batch when they are asked for, mot_get_clusters
+    computes a slot's labels from its cells and label grid. With the flags set they are written in the first place. Either way: equal to the oracle, for every slot of a ragged batch, and the cluster stage's results are untouched."""
     lib, L = emu
     B, N, stride = 3, 5000, 5120
     p = oracle.params(0)
@@ -178,7 +178,7 @@ def test_fused_outputs_on_demand_and_materialised(mot, emu, synth, oracle):
     for s in range(B):
         host[s, : n[s]] = synth.make_cloud(N, 50 + s, 1)[: n[s]]
     res = {}
-    for flags in (0, mot.OUT_GROUND, mot.OUT_GROUND | mot.OUT_MASK):
+    for flags in (0, mot.OUT_GROUND, mot.OUT_GROUND | mot.OUT_MASK, mot.OUT_LABELS, mot.OUT_GROUND | mot.OUT_MASK | mot.OUT_LABELS):
         with mot.Context(lib_path=lib, max_points=stride, max_batch=B, max_tracks_total=64) as c:
             c.set_fused_outputs(flags)
             c.frames_dev(host.ctypes.data, stride * 4, n)
@@ -198,6 +198,35 @@ def test_fused_outputs_on_demand_and_materialised(mot, emu, synth, oracle):
         with pytest.raises(mot.MotError) as e:
             c.set_fused_outputs(8)
         assert e.value.code == mot.MOT_E_ARG
+
+
+def test_point_labels_on_demand_without_cells(mot, emu, synth, oracle):
+    """the other two ways into the on-demand labels: a 256-cell grid (all 65536 cell codes in use, so the compaction kernel hands no
+    cells over: the label comes from the point itself) and a stage-wise mot_cluster that was not asked for labels"""
+    lib, L = emu
+    N, stride = 6000, 6144
+    cloud = synth.make_cloud(N, 77, 2)
+    host = np.zeros((1, stride, 4), np.float32); host[0, :N] = cloud
+    po = oracle.params(0, num_grid=256)
+    o = oracle.ground_remove(po, cloud)
+    want = oracle.cluster(po, o["elevated"])
+    assert want["num_cluster"] > 3
+    with mot.Context(mot.params(0, lib=mot.load_library(lib), num_grid=256), lib_path=lib, max_points=stride, max_batch=1) as c:
+        c.frames_dev(host.ctypes.data, stride * 4, [N])
+        got = c.get_clusters(0, n_elevated=len(o["elevated"]))
+        assert np.array_equal(got["grid"], want["grid"]) and np.array_equal(got["point_label"], want["point_label"])
+    po = oracle.params(0)
+    want = oracle.cluster(po, o["elevated"])
+    with mot.Context(lib_path=lib, max_points=stride, max_batch=1) as c:
+        c.frames_dev(host.ctypes.data, stride * 4, [N])                    # slot 0 holds a fused result (cells resident) ...
+        a = np.ascontiguousarray(o["elevated"][::-1])                       # ... then a stage-wise cloud in another order takes its place
+        G = c.params.num_grid
+        grid = np.zeros((G, G), np.int32); nc = mot.C.c_int(0)
+        assert L.mot_cluster(c._h, a.ctypes.data_as(mot.C.c_void_p), len(a), grid.ctypes.data_as(mot.C.c_void_p), mot.C.byref(nc), None) == 0
+        got = c.get_clusters(0, n_elevated=len(a))
+        ref = oracle.cluster(po, a)
+        assert np.array_equal(got["grid"], ref["grid"]) and np.array_equal(got["point_label"], ref["point_label"])
+        assert ref["num_cluster"] == want["num_cluster"]
 
 
 def test_reset_tracks_slot_keeps_the_global_frame(mot, emu, oracle):
