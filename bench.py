@@ -207,6 +207,7 @@ def cpu_baseline(frames: np.ndarray, ego_v, ego_yaw, n_points: int, budget_s: fl
         parity["masks_boxes_bit_exact"] = all(flags[k_] for k_ in ("clouds_bit_exact", "masks_equal_restatement", "label_grids_bit_exact", "boxes_bit_exact", "global_boxes_bit_exact"))
         parity["states_within_1e-4"] = stats.get("max_rel_state_err") is not None and stats["max_rel_state_err"] <= 1e-4
         parity.update({"max_rel_state_err": stats.get("max_rel_state_err"), "ill_conditioned_track_frames": stats.get("ill_conditioned", 0),
+                       "track_frames_above_1e-4": stats.get("above_bar", 0), "track_frames_above_1e-4_well_conditioned": stats.get("above_bar_well_conditioned", 0),
                        "max_rel_state_err_ill_conditioned": stats.get("max_rel_state_err_ill_conditioned"),
                        "ill_conditioned_means": "a track whose filter is diverging (|yaw rate| >= 20 rad/s, a covariance entry >= 1e3, a yaw / yaw-rate variance > 9, a covariance that is not positive definite, NaN — or was so within the last 30 frames: tests/seq_parity.py) "
                                                 "amplifies last-bit differences of equivalent operation orders by decades per frame until the reference's own guards kill it; its discrete outputs are compared like everybody's",

@@ -127,6 +127,10 @@ def compare_tracks(a, o, state_dev, state_orc, where, rtol=RTOL, stats=None, ski
             stats[key] = max(stats.get(key, 0.0), w_i)
             if ill:
                 stats["ill_conditioned"] = stats.get("ill_conditioned", 0) + 1
+            if w_i > RTOL:   # whatever the conditioning: how many live track-frames differ by more than the bar at all
+                stats["above_bar"] = stats.get("above_bar", 0) + 1
+                if not ill:
+                    stats["above_bar_well_conditioned"] = stats.get("above_bar_well_conditioned", 0) + 1
         if not ill:
             worst = max(worst, w_i)
     if stats is not None:
