@@ -15,7 +15,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libmot_hip.so")
 SOURCES = ["ground.hip", "cluster.hip", "box.hip", "side.hip", "track.hip", "debug.hip", "mot_api.hip"]
-HEADERS = ["mot_internal.h", "mot_math.h", "mot_wave.h", "mot_debug.h", "mot_debug_api.h", os.path.join("..", "..", "include", "mot.h")]
+HEADERS = ["mot_internal.h", "mot_math.h", "mot_wave.h", "mot_debug.h", "mot_debug_api.h", "mot_track_prep.h", os.path.join("..", "..", "include", "mot.h")]
 
 HIPCC_FLAGS = [
     "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",

@@ -27,6 +27,7 @@
 #include "mot_internal.h"
 #include "mot_wave.h"
 #include "mot_debug.h"
+#include "mot_track_prep.h"
 
 #ifndef MOT_HIPEMU
 #define MOT_LAUNCH_BOUNDS(n) __launch_bounds__(n)
@@ -1023,8 +1024,7 @@ cluster_rect_large_kernel(MotDevParams p, ClusterBuffers c) { cluster_rect_body<
 
 // ------------------------------------------------------------------------------------------ B3
 constexpr int kFinalBlock = 256;
-__global__ void MOT_LAUNCH_BOUNDS(kFinalBlock)
-box_finalize_kernel(MotDevParams p, ClusterBuffers c) {
+static __device__ void box_finalize_body(const MotDevParams& p, const ClusterBuffers& c) {
   __shared__ int s_wave[kFinalBlock / 64];
   __shared__ int s_base, s_undef;
   const int b = blockIdx.x;
@@ -1076,6 +1076,19 @@ box_finalize_kernel(MotDevParams p, ClusterBuffers c) {
     c.counts[b * kCountsStride + kCntUndef] = s_undef;
     c.counts[b * kCountsStride + kCntPoly] = 0;  // re-arm the polygon pool
   }
+}
+__global__ void MOT_LAUNCH_BOUNDS(kFinalBlock)
+box_finalize_kernel(MotDevParams p, ClusterBuffers c) {
+  box_finalize_body(p, c);
+}
+// the fused path with the tracker on: the tracker's per-frame prologue (mot_track_prep.h — same geometry, one 256-thread workgroup per
+// frame) runs right behind, on the boxes and the box count this workgroup has just written (workgroup-scope visibility: the barrier)
+static_assert(kFinalBlock == 256, "track_prep_body assumes 256 threads");
+__global__ void MOT_LAUNCH_BOUNDS(kFinalBlock)
+box_finalize_prep_kernel(MotDevParams p, ClusterBuffers c, TrackBuffers tb) {
+  box_finalize_body(p, c);
+  __syncthreads();
+  track_prep_body(tb, (int)blockIdx.x);
 }
 
 // ------------------------------------------------------------------------------------------ per-point labels on demand
@@ -1134,6 +1147,10 @@ void mot_launch_box_kernel(int which, const MotDevParams& p, const ClusterBuffer
   }
   else if (which == 4) hipLaunchKernelGGL(cluster_index_kernel, dim3(batch), dim3(kIndexBlock), 0, stream, c);
   else if (which == 2) hipLaunchKernelGGL(box_finalize_kernel, dim3(batch), dim3(kFinalBlock), 0, stream, p, c);
+}
+
+void mot_launch_box_finalize_prep(const MotDevParams& p, const ClusterBuffers& c, const TrackBuffers& tb, int batch, hipStream_t stream) {
+  hipLaunchKernelGGL(box_finalize_prep_kernel, dim3(batch), dim3(kFinalBlock), 0, stream, p, c, tb);
 }
 
 void mot_launch_box(const MotDevParams& p, const ClusterBuffers& c, int batch, int max_n, hipStream_t stream) {

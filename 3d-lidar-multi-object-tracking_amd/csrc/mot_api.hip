@@ -646,8 +646,13 @@ static void issue_frame_kernels(mot_ctx* c, int batch, int max_n, int run_tracke
   { ProfScope ps(c, kB1b); mot_launch_box_kernel(4, c->dp, cb, batch, max_n, c->stream); }
   { ProfScope ps(c, kB2); mot_launch_box_kernel(1, c->dp, cb, batch, max_n, c->stream); }
   { ProfScope ps(c, kB2b); mot_launch_box_kernel(3, c->dp, cb, batch, max_n, c->stream); }
-  { ProfScope ps(c, kB3); mot_launch_box_kernel(2, c->dp, cb, batch, max_n, c->stream); }
-  if (run_tracker) { ProfScope ps(c, kT1); mot_launch_track(track_buffers(c, true), batch, c->stream); }
+  if (run_tracker) {   // the tracker's per-frame prologue rides at the tail of the box stage's last kernel (same geometry)
+    const TrackBuffers tb = track_buffers(c, true);
+    { ProfScope ps(c, kB3); mot_launch_box_finalize_prep(c->dp, cb, tb, batch, c->stream); }
+    { ProfScope ps(c, kT1); mot_launch_track(tb, batch, c->stream, true); }
+  } else {
+    ProfScope ps(c, kB3); mot_launch_box_kernel(2, c->dp, cb, batch, max_n, c->stream);
+  }
 }
 
 // the fused launch sequence of one batch on the context stream; every argument has been validated

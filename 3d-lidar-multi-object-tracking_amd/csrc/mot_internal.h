@@ -284,7 +284,8 @@ struct TrackBuffers {
 };
 enum { kTrackFlagCapacity = 1 };   // a birth was dropped: no free slot (more than T tracks alive or just dead) or E tracks ever created
 
-void mot_launch_track(const TrackBuffers& t, int batch, hipStream_t stream);
+void mot_launch_track(const TrackBuffers& t, int batch, hipStream_t stream, bool prep_done = false);
+void mot_launch_box_finalize_prep(const MotDevParams& p, const ClusterBuffers& c, const TrackBuffers& tb, int batch, hipStream_t stream);
 void mot_launch_export_tracks(const TrackBuffers& t, int batch, mot_track* dst, int max_per_slot, int* dst_counts, hipStream_t stream);
 void mot_launch_export_tracks_packed(const TrackBuffers& t, int batch, int* header, mot_track* dst, int capacity, hipStream_t stream);
 

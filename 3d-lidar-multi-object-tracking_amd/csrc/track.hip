@@ -22,6 +22,7 @@
 // Parity bar: track sets and integer state exact, continuous state <= 1e-4 relative (BASELINE.json).
 #include "mot_internal.h"
 #include "mot_wave.h"
+#include "mot_track_prep.h"
 
 #ifndef MOT_HIPEMU
 #define MOT_LAUNCH_BOUNDS(n) __launch_bounds__(n)
@@ -91,22 +92,7 @@ __device__ double det5(const double* a) {
   return det;
 }
 
-// UKF::UKF + UKF::Initialize, ukf.cpp:20-249, 257-322
-__device__ void track_init(DevTrack* t, double zx, double zy, int ref_id) {
-  for (int a = 0; a < 4; a++) {
-    t->x[a][0] = zx; t->x[a][1] = zy; t->x[a][2] = 0; t->x[a][3] = 0; t->x[a][4] = 0.1;
-    for (int i = 0; i < 25; i++) t->P[a][i] = 0;
-    t->P[a][0] = 0.5; t->P[a][6] = 0.5; t->P[a][12] = 3; t->P[a][18] = 10; t->P[a][24] = 1;
-  }
-  for (int m = 0; m < 3; m++) {
-    t->mode[m] = 0.33; t->zpred[m][0] = zx; t->zpred[m][1] = zy;
-    t->S[m][0] = 1; t->S[m][1] = 0; t->S[m][2] = 0; t->S[m][3] = 1;
-    for (int i = 0; i < 10; i++) t->K[m][i] = 0;
-  }
-  t->init_meas[0] = 0; t->init_meas[1] = 0; t->dist_from_init = 0; t->best_yaw = 0;
-  t->lifetime = 0; t->track_num = 1; t->is_static = 0; t->is_vis = 0; t->has_bbox = 0; t->has_best = 0; t->ref_id = ref_id; t->pad1 = 0;
-  for (int i = 0; i < 24; i++) { t->bbox[i] = 0.f; t->best_bbox[i] = 0.f; }
-}
+// (track_init — UKF::UKF + UKF::Initialize — and cp_from_bbox live in mot_track_prep.h)
 
 // ---------------------------------------------------------------------------------------------- lanes and tracks
 // A track is worked on by a GROUP of 16 lanes — one DPP row — and a wave carries FOUR tracks. The filter's matrices are
@@ -392,14 +378,6 @@ __device__ __forceinline__ int find_max_model(const double S[3][4]) {
   return (ctrv > rm) ? 1 : 2;
 }
 
-// getCpFromBbox :465-479 — fp32 products, then fp64
-__device__ __forceinline__ void cp_from_bbox(const float* b, double* cx, double* cy) {
-  float p1x = b[0], p1y = b[1], p2x = b[3], p2y = b[4], p3x = b[6], p3y = b[7], p4x = b[9], p4y = b[10];
-  double S1 = ((p4x - p2x) * (p1y - p2y) - (p4y - p2y) * (p1x - p2x)) / 2;
-  double S2 = ((p4x - p2x) * (p2y - p3y) - (p4y - p2y) * (p2x - p3x)) / 2;
-  *cx = p1x + (p3x - p1x) * S1 / (S1 + S2);
-  *cy = p1y + (p3y - p1y) * S1 / (S1 + S2);
-}
 // getBboxArea :482-494
 __device__ __forceinline__ double bbox_area(const float* b) {
   float p1x = b[0], p1y = b[1], p2x = b[3], p2y = b[4], p3x = b[6], p3y = b[7], p4x = b[9], p4y = b[10];
@@ -497,68 +475,10 @@ __device__ void update_bb_group(const MotTrackParams& tp, float* bb, float* best
 // from one list across all streams of the context, four per wave (see "lanes and tracks"), so every CU works whatever the
 // split of tracks over streams.
 
-// ---- T0
+// ---- T0 (body: mot_track_prep.h; the fused path runs it inside box_finalize_prep_kernel instead)
 __global__ void MOT_LAUNCH_BOUNDS(256)
 track_prep_kernel(TrackBuffers tb) {
-  const int b = blockIdx.x, tid = threadIdx.x;
-  const TrackFrameArgs args = tb.args[b];
-  if (!args.run) return;
-  const MotTrackParams tp = tb.tp;
-  const int M = tb.m_dev ? min(tb.m_dev[b * kCountsStride + kCntBoxes], kMaxBoxesPerFrame) : args.m;
-  const float* boxes = tb.boxes + (long)b * tb.box_stride;   // (fused path: the same memory as `dst` below — no __restrict__ on either)
-  if (tb.boxes_sensor) {
-    // the tf step of the tracking node (OT/tracking/main.cpp:143-158: pcl_ros::transformPointCloud("/global", box, ...)): the host
-    // walked the tf chain down to the float matrix pcl::transformPointCloud applies (mot_api.hip: tf_velodyne_to_global); each
-    // point is m(r,0)*x + m(r,1)*y + m(r,2)*z + m(r,3) in fp32, left to right, as PCL evaluates it (no contraction: the build
-    // has -ffp-contract=off)
-    const EgoTf e = tb.ego[b];
-    const float* __restrict__ src = tb.boxes_sensor + (long)b * kMaxBoxesPerFrame * 24;
-    float* dst = tb.boxes_out + (long)b * tb.box_stride;
-    for (int i = tid; i < M * 8; i += 256) {
-      const float* p = src + (long)i * 3;
-      float* q = dst + (long)i * 3;
-      const float x = p[0], y = p[1], z = p[2];
-      q[0] = e.m[0] * x + e.m[1] * y + e.m[2] * z + e.m[3];
-      q[1] = e.m[4] * x + e.m[5] * y + e.m[6] * z + e.m[7];
-      q[2] = e.m[8] * x + e.m[9] * y + e.m[10] * z + e.m[11];
-    }
-    __syncthreads();
-  }
-  // trackPoints :713-736 — centre of every box
-  Vec2d* __restrict__ cp = tb.cp + (long)b * kMaxBoxesPerFrame;
-  for (int k = tid; k < M; k += 256) { double x, y; cp_from_bbox(boxes + (long)k * 24, &x, &y); cp[k].x = x; cp[k].y = y; }
-  if (args.first_frame) {  // :741-795 — seed exactly one track at a hard-coded position; nothing else happens in this frame
-    // (also the start of a stream after mot_reset / mot_reset_slot / mot_reset_tracks_slot: every slot is free again)
-    unsigned long long* __restrict__ used = tb.used + (long)b * ((tb.T + 63) / 64);
-    for (int w = tid; w < (tb.T + 63) / 64; w += 256) used[w] = 0ull;
-    __syncthreads();
-    if (tid == 0) {
-      int n = 0;
-      if (M > tp.seed_box_index && tb.T >= 1 && tb.E >= 1) {
-        DevTrack* tracks = tb.tracks + (long)b * tb.T;
-        track_init(&tracks[0], tp.seed_px, tp.seed_py, 0);   // reference index 0 in slot 0
-        tb.pos[(long)b * tb.E].x = tp.seed_px; tb.pos[(long)b * tb.E].y = tp.seed_py;
-        tb.slot_of[(long)b * tb.E] = 0;
-        used[0] = 1ull;
-        mot_track o;
-        o.id = 0; o.track_manage = 1; o.is_static = 0; o.is_vis = 0;
-        o.px = (float)tp.seed_px; o.py = (float)tp.seed_py; o.pz = (float)(-1.73 / 2); o.lifetime = 0; o.v = 0; o.yaw = 0;
-        for (int i = 0; i < 24; i++) o.vis_box[i] = 0.f;
-        tb.out[(long)b * tb.T] = o;
-        tb.live[(long)b * 2 * tb.T] = 0;
-        n = 1;
-      }
-      tb.nt[b] = n; tb.nlive[b] = n; tb.nzomb[b] = 0;
-    }
-    return;
-  }
-  // work items of this stream: its live tracks (list left by the previous step's finish kernel), in any order
-  __shared__ int s_base;
-  const int nlive = tb.nlive[b];
-  if (tid == 0) s_base = nlive ? atomicAdd(tb.n_items, nlive) : 0;
-  __syncthreads();
-  TrackItem* __restrict__ items = tb.items + s_base;
-  for (int i = tid; i < nlive; i += 256) { TrackItem it; it.b = b; it.li = i; items[i] = it; }
+  track_prep_body(tb, (int)blockIdx.x);
 }
 
 // ---- T1: PA — prediction + gating; the wave's four groups each take one (stream, live track) item
@@ -1199,14 +1119,14 @@ void mot_launch_export_tracks(const TrackBuffers& t, int batch, mot_track* dst, 
   hipLaunchKernelGGL(export_tracks_kernel, dim3(batch), dim3(kTrackBlock), 0, stream, t.out, t.nlive, t.live, t.T, dst, max_per_slot, dst_counts);
 }
 
-void mot_launch_track(const TrackBuffers& t, int batch, hipStream_t stream) {
+void mot_launch_track(const TrackBuffers& t, int batch, hipStream_t stream, bool prep_done) {
 #ifdef MOT_HIPEMU
   const int item_groups = 2;   // the per-track kernels loop over the work list: any grid size gives the same result
 #else
   int item_groups = batch * 8;   // 2 waves x 4 tracks each: one round covers 64 live tracks per stream; the chip holds 1280 such workgroups (5 per CU: the scratch above)
   item_groups = item_groups < 16 ? 16 : (item_groups > 1280 ? 1280 : item_groups);
 #endif
-  hipLaunchKernelGGL(track_prep_kernel, dim3(batch), dim3(256), 0, stream, t);
+  if (!prep_done) hipLaunchKernelGGL(track_prep_kernel, dim3(batch), dim3(256), 0, stream, t);   // (fused path: done at the tail of the box stage)
   hipLaunchKernelGGL(track_predict_kernel, dim3(item_groups), dim3(kItemWaves * 64), 0, stream, t);
   hipLaunchKernelGGL(track_update_kernel, dim3(item_groups), dim3(kItemWaves * 64), 0, stream, t);
   hipLaunchKernelGGL(track_finish_kernel, dim3(batch), dim3(kTrackBlock), 0, stream, t);
