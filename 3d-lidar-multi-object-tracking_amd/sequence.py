@@ -2,7 +2,8 @@
 ego motion through the same per-frame sequence the three reference nodes run (OT/src/groundremove/main.cpp:120,
 OT/src/cluster/main.cpp:74,119, OT/tracking/main.cpp:74-166) on a `Context` of this package.
 
-Host-buffer entry points on purpose — this mirrors the nodes one to one; the throughput path is `Context.frames_dev`."""
+`play` uses the host-buffer stage calls on purpose — it mirrors the nodes one to one; `play_fused` runs the same sequence on the
+throughput path (`Context.frames_host`: pipelined uploads, one launch sequence per frame, several streams per call)."""
 from __future__ import annotations
 
 import glob
@@ -59,3 +60,36 @@ def play(ctx, frames, dt_us: float = 1.0e5, t0: float = 1.0e9):
     """frames: iterable of (cloud, v, yaw); timestamps advance by dt_us microseconds (the tracking node's unit)"""
     for k, (cloud, v, yaw) in enumerate(frames):
         yield play_frame(ctx, cloud, t0 + k * dt_us, v, yaw)
+
+
+def play_fused(ctx, frames, dt_us: float = 1.0e5, t0: float = 1.0e9, slot_count: int = 1):
+    """The same sequence on the THROUGHPUT path: one `frames_host` call per frame (pipelined upload from a page-locked staging
+    block, ground -> cluster -> box -> tf -> tracker in one launch sequence, nothing but the results comes back). The change of
+    frame is the tracking node's own tf chain (mot_api.hip: tf_velodyne_to_global), not the numpy transform of `play`.
+
+    frames: iterable of (cloud, v, yaw) — or of lists of `slot_count` such triples, one per stream. Yields per frame a list of
+    per-stream dicts (boxes in the sensor frame, tracks)."""
+    import ctypes as C
+    stride = ctx.max_points                       # points between the streams of a batch
+    hp = C.c_void_p()
+    ctx._ck(ctx.lib.mot_host_alloc(C.c_size_t(slot_count * stride * 16), C.byref(hp)))
+    try:
+        pinned = np.ctypeslib.as_array(C.cast(hp, C.POINTER(C.c_float)), shape=(slot_count, stride, 4))
+        for k, fr in enumerate(frames):
+            per = fr if isinstance(fr, list) else [fr]
+            if len(per) != slot_count:
+                raise ValueError(f"frame {k}: {len(per)} streams, expected {slot_count}")
+            ctx.wait_uploads()                    # the previous upload has left the staging block
+            n = []
+            for s, (cloud, _v, _yaw) in enumerate(per):
+                a = np.asarray(cloud, np.float32).reshape(-1, 4)
+                if len(a) > stride:
+                    raise ValueError(f"frame {k}, stream {s}: {len(a)} points, the context holds {stride}")
+                pinned[s, : len(a)] = a
+                n.append(len(a))
+            ts = [t0 + k * dt_us] * slot_count
+            ctx.frames_host(hp.value, stride * 4, n, run_tracker=True, timestamps=ts, ego_v=[p[1] for p in per], ego_yaw=[p[2] for p in per])
+            yield [dict(boxes=ctx.get_boxes(s)["boxes"], tracks=ctx.get_tracks(s)) for s in range(slot_count)]
+    finally:
+        ctx.synchronize()
+        ctx.lib.mot_host_free(hp)

@@ -55,3 +55,32 @@ def test_sequence_player_kitti_layout(mot, oracle, synth, tmp_path):
             n += 1
         assert n == 4
     T.close()
+
+
+def test_fused_sequence_player_equals_the_stagewise_one(mot, oracle, synth):
+    """sequence.play_fused (one frames_host call per frame, two streams) against sequence.play (the nodes' stage-wise calls) and the
+    oracle fed through the tracking node's tf chain: boxes bit-exact, track sets / trackManage equal, positions within 1e-4"""
+    import build_emu
+    import conftest
+    import seq_parity as SP
+    seq = conftest.load_sub("sequence")
+    lib = build_emu.build()
+    F, N = 6, 12000
+    frames = [[(synth.make_cloud(N, 3 + s, f), 1.5 + 0.1 * f, 0.002 * f * (1 + s)) for s in range(2)] for f in range(F)]
+    p = oracle.params(0)
+    with mot.Context(lib_path=lib, max_points=12288, max_batch=2, max_tracks_total=256) as c:
+        fused = list(seq.play_fused(c, frames, slot_count=2))
+    assert len(fused) == F
+    for s in range(2):
+        T = oracle.Tracker(p)
+        with mot.Context(lib_path=lib, max_points=12288, max_tracks_total=256) as c1:
+            for f, r in enumerate(seq.play(c1, [fr[s] for fr in frames])):
+                got = fused[f][s]
+                assert np.array_equal(got["boxes"], r["boxes"]), (f, s)
+                ts = 1.0e9 + f * 1.0e5
+                ego = T.ego_update(ts, frames[f][s][1], frames[f][s][2])
+                o = T.step(SP.boxes_to_global(oracle, c1.lib, r["boxes"], ego), ts)
+                assert got["tracks"]["n"] == o["n"] and np.array_equal(got["tracks"]["track_manage"], o["track_manage"]), (f, s)
+                live = o["track_manage"] > 0
+                assert np.allclose(got["tracks"]["p"][live], o["p"][live], rtol=1e-4, atol=1e-5), (f, s)
+        T.close()
