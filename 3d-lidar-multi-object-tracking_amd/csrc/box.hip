@@ -77,8 +77,8 @@ __global__ void stats_init_kernel(ClusterBuffers c) {
   int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i < kMaxClusters) {
     ClusterStats s;
-    s.count = 0; s.first = 0x7fffffff; s.maxz_key = mot_float_key(-99.f); s.first_zero = 0x7fffffff;
-    s.argmin = kArgminInit; s.argmax = kArgmaxInit;
+    s.count_groups = 0ull; s.first = 0x7fffffff; s.maxz_key = mot_float_key(-99.f); s.first_zero = 0x7fffffff;
+    s.argmin = kArgminInit; s.argmax = kArgmaxInit; s.pad = 0;
     c.stats[(long)b * kMaxClusters + i] = s;
   }
 }
@@ -86,8 +86,8 @@ __global__ void stats_init_kernel(ClusterBuffers c) {
 // ------------------------------------------------------------------------------------------ B1
 // getClusteredPoints :46-72 (label of every point) + the per-point loop of getBoundingBox :239-293
 constexpr int kGroupsPerWg = 512;   // (tile, cluster) groups a workgroup stages in LDS; any beyond go straight to global memory
-__device__ __forceinline__ void stats_commit(ClusterStats* s, int count, int first, int rz, unsigned long long rmin, unsigned long long rmax) {
-  atomicAdd(&s->count, count);
+__device__ __forceinline__ void stats_commit(ClusterStats* s, int count, int first, int rz, unsigned long long rmin, unsigned long long rmax, int groups) {
+  atomicAdd(&s->count_groups, (unsigned long long)(unsigned)count | ((unsigned long long)(unsigned)groups << 32));
   atomicMin(&s->first, first);
   atomicMax(&s->maxz_key, rz);
   if (rmin != kArgminInit) atomicMin(&s->argmin, rmin);
@@ -211,7 +211,7 @@ label_stats_kernel(MotDevParams p, ClusterBuffers c) {
           s_groups[e] = g; s_rmin[e] = rmin; s_rmax[e] = rmax; s_rz[e] = rz;
         } else {  // more groups than the LDS stage holds (a badly fragmented chunk): this one goes out on its own,
           // and the index kernel falls back to its general path for this frame
-          stats_commit(&stats[l - 1], __popcll(mm), (int)i, rz, rmin, rmax);
+          stats_commit(&stats[l - 1], __popcll(mm), (int)i, rz, rmin, rmax, 1);
           const int gs = atomicAdd(&c.counts[b * kCountsStride + kCntGroups], 1);
           if (gs < c.group_cap) out[gs] = g;
           c.counts[b * kCountsStride + kCntIrregular] = 1;
@@ -251,7 +251,7 @@ label_stats_kernel(MotDevParams p, ClusterBuffers c) {
       atomicAdd(&s_tab_count[slot], cnt); atomicMin(&s_tab_first[slot], first); atomicMax(&s_tab_rz[slot], s_rz[e]);
       atomicMin(&s_tab_rmin[slot], s_rmin[e]); atomicMax(&s_tab_rmax[slot], s_rmax[e]);
     } else {
-      stats_commit(&stats[g.label - 1], cnt, first, s_rz[e], s_rmin[e], s_rmax[e]);   // more than 64 clusters in this chunk
+      stats_commit(&stats[g.label - 1], cnt, first, s_rz[e], s_rmin[e], s_rmax[e], 1);   // more than 64 clusters in this chunk
       c.counts[b * kCountsStride + kCntIrregular] = 1;
     }
     // this group's points, filed under (table slot, tile of the chunk): the prefix over tiles below gives the number of the
@@ -261,18 +261,23 @@ label_stats_kernel(MotDevParams p, ClusterBuffers c) {
   }
   __syncthreads();
   B1_T(3);
-  if (threadIdx.x < kWgClusters && s_tab_label[threadIdx.x]) {   // exclusive prefix over the 32 tiles of the chunk, one table slot per thread
-    int run = 0;
+  int my_groups = 0;   // groups (= tiles) of my table slot's cluster in this chunk
+  if (threadIdx.x < kWgClusters && s_tab_label[threadIdx.x]) {   // exclusive prefixes over the 32 tiles of the chunk, one table slot per thread:
+    int run = 0;                                                 // points (low half) and groups (high half) of the cluster in earlier tiles
 #pragma unroll
-    for (int t2 = 0; t2 < kTilesPerChunk; t2++) { const int v = s_tilecnt[threadIdx.x][t2]; s_tilecnt[threadIdx.x][t2] = run; run += v; }
+    for (int t2 = 0; t2 < kTilesPerChunk; t2++) {
+      const int v = s_tilecnt[threadIdx.x][t2];
+      s_tilecnt[threadIdx.x][t2] = run | (my_groups << 16);
+      run += v; my_groups += v > 0 ? 1 : 0;
+    }
   }
   if (threadIdx.x < kWgClusters && s_tab_label[threadIdx.x])
     stats_commit(&stats[s_tab_label[threadIdx.x] - 1], s_tab_count[threadIdx.x], s_tab_first[threadIdx.x], s_tab_rz[threadIdx.x],
-                 s_tab_rmin[threadIdx.x], s_tab_rmax[threadIdx.x]);
+                 s_tab_rmin[threadIdx.x], s_tab_rmax[threadIdx.x], my_groups);
   __syncthreads();
-  // the workgroup's table, for the index kernel's cross-chunk prefix
+  // the workgroup's table, for the index kernel's cross-chunk prefixes
   if (threadIdx.x < kWgClusters && (int)blockIdx.x < c.max_wg)
-    c.wgtab[((long)b * c.max_wg + blockIdx.x) * kWgClusters + threadIdx.x] = make_int2(s_tab_label[threadIdx.x], s_tab_count[threadIdx.x]);
+    c.wgtab[((long)b * c.max_wg + blockIdx.x) * kWgClusters + threadIdx.x] = make_int2(s_tab_label[threadIdx.x], s_tab_count[threadIdx.x] | (my_groups << 16));
   // the (tile, cluster) groups leave with ONE returning global atomic (a slot reservation)
   const int gb = s_gbase;
   for (int t = threadIdx.x; t < ng; t += kLabelBlock) {
@@ -281,7 +286,11 @@ label_stats_kernel(MotDevParams p, ClusterBuffers c) {
     for (int x = 1; x < kWaves; x++) if (t >= wbase[x]) w = x;
     const int e = w * kPerWave + (t - wbase[w]);
     PointGroup g = s_groups[e];
-    if (s_slot[e] >= 0) g.tile |= s_tilecnt[s_slot[e]][g.tile & (kTilesPerChunk - 1)] << kGroupTileBits;   // < 2048 points per chunk
+    if (s_slot[e] >= 0) {
+      const int pre = s_tilecnt[s_slot[e]][g.tile & (kTilesPerChunk - 1)];
+      g.tile |= (pre & 0xffff) << kGroupTileBits;   // < 2048 points per chunk
+      g.label |= (pre >> 16) << 16;                 // < 32 groups per chunk and cluster
+    }
     if (gb + t < c.group_cap) out[gb + t] = g;
   }
   B1_T(5);
@@ -289,14 +298,17 @@ label_stats_kernel(MotDevParams p, ClusterBuffers c) {
 }
 
 // ------------------------------------------------------------------------------------------ B1b
-// one workgroup per frame: turns the (tile, cluster) groups into the cluster-sorted point index
-//   sorted[cluster_start[c] + r] = index of the r-th point of cluster c in input order
-// (the reference's getClusteredPoints, box_fitting.cpp:46-72, without copying a point). The first slot of a group is
-//   cluster_start[c] + (points of c in earlier 2048-point chunks) + (points of c in earlier tiles of its own chunk);
+// one workgroup per frame: puts the (tile, cluster) groups into CLUSTER ORDER
+//   gsorted[cluster_gstart[c] + k] = the k-th group of cluster c in input (tile) order: {tile, lanes, points of c before it}
+// — the reference's getClusteredPoints (box_fitting.cpp:46-72) without copying a point, and without a per-point index either:
+// the per-cluster kernels walk a cluster's groups (a tile's points are 64 consecutive pixels / points), and "the r-th point of
+// cluster c" is a search over its groups' running counts. (Until round 3 this kernel scattered one index per POINT —
+// sorted[cluster_start[c] + r] — which was half of its time and 94 MB written + read per 512 frames.) The slot of a group is
+//   cluster_gstart[c] + (groups of c in earlier 2048-point chunks) + (groups of c in earlier tiles of its own chunk);
 // the last term comes with the group from the label kernel, the middle one is a prefix over the label kernel's
-// per-workgroup tables — O(groups) work here. A frame the label kernel flagged irregular (a chunk with more than 64
-// clusters or more than 64 groups in the four tiles of one wave) or with more than 64 chunks of elevated points takes the general path: the
-// sum over all the other groups of the cluster.
+// per-workgroup tables — O(groups) work here; the point counts go the same way. A frame the label kernel flagged irregular (a
+// chunk with more than 64 clusters or more than 64 groups in the four tiles of one wave), with more than 64 chunks of elevated
+// points or of more than 2^19 points takes the general path: the sums over all the other groups of the cluster.
 #ifndef MOT_INDEX_BLOCK
 #define MOT_INDEX_BLOCK 1024
 #endif
@@ -310,8 +322,8 @@ constexpr int kIndexWgLds = 64;               // fast path: label-kernel workgro
 __global__ void MOT_LAUNCH_BOUNDS(kIndexBlock)
 cluster_index_kernel(ClusterBuffers c) {
   __shared__ int s_start[kMaxClusters + 1];
-  __shared__ int s_part[kIndexWaves];
-  __shared__ uint2 s_raw[kGroupsLds];   // fast path: {cluster, points} tables [wg][64] then their prefixes; general path: group keys
+  __shared__ int s_part[kIndexWaves], s_gpart[kIndexWaves];
+  __shared__ uint2 s_raw[kGroupsLds];   // fast path: {cluster, points | groups << 16} tables [wg][64] then their prefixes; general path: group keys
   static_assert(kGroupsLds * sizeof(uint2) >= kIndexWgLds * kWgClusters * (sizeof(int2) + sizeof(int)), "LDS union too small");
   const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int num_cluster = min(c.counts[b * kCountsStride + kCntClusters], kMaxClusters);
@@ -319,24 +331,37 @@ cluster_index_kernel(ClusterBuffers c) {
   int E = c.counts[b * kCountsStride + kCntGroups];
   if (E > c.group_cap) { E = c.group_cap; if (tid == 0) atomicOr(&c.counts[b * kCountsStride + kCntFlags], (int)kFlagGroupOverflow); }
   const int nwg = (n + kLabelChunk - 1) / kLabelChunk;
-  const bool fast = c.counts[b * kCountsStride + kCntIrregular] == 0 && nwg <= kIndexWgLds && nwg <= c.max_wg;
+  const bool fast = c.counts[b * kCountsStride + kCntIrregular] == 0 && nwg <= kIndexWgLds && nwg <= c.max_wg && n < (1 << kIndexPointBits);
   const PointGroup* __restrict__ groups = c.groups + (long)b * c.group_cap;
   const ClusterStats* __restrict__ stats = c.stats + (long)b * kMaxClusters;
+  int* cstart = c.cluster_start + (long)b * (kMaxClusters + 1);
+  int* cgstart = c.cluster_gstart + (long)b * (kMaxClusters + 1);   // (read back below by other threads of this workgroup: no __restrict__)
+  SortedGroup* __restrict__ gsorted = c.gsorted + (long)b * c.group_cap;
   B1B_T_BEGIN(c, b);
-  // exclusive scan of the cluster sizes (kMaxClusters / kIndexBlock per thread)
+  // exclusive scans of the cluster sizes in points and in groups (kMaxClusters / kIndexBlock clusters per thread)
   {
     constexpr int kPer = kMaxClusters / kIndexBlock;
-    int v[kPer], sum = 0;
+    int v[kPer], gv[kPer], sum = 0, gsum = 0;
 #pragma unroll
-    for (int k = 0; k < kPer; k++) { int ci = tid * kPer + k; v[k] = ci < num_cluster ? stats[ci].count : 0; sum += v[k]; }
-    const int incl = wave_scan_incl_i32(sum);
-    if (lane == 63) s_part[wave] = incl;
+    for (int k = 0; k < kPer; k++) {
+      const int ci = tid * kPer + k;
+      const unsigned long long cg = ci < num_cluster ? stats[ci].count_groups : 0ull;
+      v[k] = (int)(unsigned)cg; gv[k] = (int)(cg >> 32);
+      sum += v[k]; gsum += gv[k];
+    }
+    const int incl = wave_scan_incl_i32(sum), gincl = wave_scan_incl_i32(gsum);
+    if (lane == 63) { s_part[wave] = incl; s_gpart[wave] = gincl; }
     __syncthreads();
-    int run = incl - sum;
-    for (int w2 = 0; w2 < wave; w2++) run += s_part[w2];
+    int run = incl - sum, grun = gincl - gsum;
+    for (int w2 = 0; w2 < wave; w2++) { run += s_part[w2]; grun += s_gpart[w2]; }
 #pragma unroll
-    for (int k = 0; k < kPer; k++) { s_start[tid * kPer + k] = run; run += v[k]; }
-    if (tid == kIndexBlock - 1) s_start[kMaxClusters] = run;
+    for (int k = 0; k < kPer; k++) {
+      const int ci = tid * kPer + k;
+      s_start[ci] = run;
+      if (ci <= num_cluster) { cstart[ci] = run; cgstart[ci] = grun < c.group_cap ? grun : c.group_cap; }
+      run += v[k]; grun += gv[k];
+    }
+    if (tid == kIndexBlock - 1) { s_start[kMaxClusters] = run; if (num_cluster == kMaxClusters) { cstart[kMaxClusters] = run; cgstart[kMaxClusters] = grun < c.group_cap ? grun : c.group_cap; } }
   }
   B1B_T(0);
   {  // processing order of the per-cluster kernels: largest first (a frame's kernel time is its slowest workgroup, and the big
@@ -354,87 +379,68 @@ cluster_index_kernel(ClusterBuffers c) {
       for (int ci = tid; ci < num_cluster; ci += kIndexBlock) order[ci] = ci;
     }
   }
-  int* __restrict__ cstart = c.cluster_start + (long)b * (kMaxClusters + 1);
-  int* __restrict__ sorted = c.sorted + (long)b * c.cap;
+  __syncthreads();   // the ranking has read the starts; the group starts are in global memory for every thread of this workgroup
   if (fast) {
-    int2* s_tab = reinterpret_cast<int2*>(s_raw);                       // [nwg][64] {cluster, points}
-    int* s_pref = reinterpret_cast<int*>(s_tab + kIndexWgLds * kWgClusters);   // [nwg][64] points of the cluster in earlier chunks
+    int2* s_tab = reinterpret_cast<int2*>(s_raw);                       // [nwg][64] {cluster, points | groups << 16}
+    int* s_pref = reinterpret_cast<int*>(s_tab + kIndexWgLds * kWgClusters);   // [nwg][64] (groups << 19 | points) of the cluster in earlier chunks
     const int2* __restrict__ gtab = c.wgtab + (long)b * c.max_wg * kWgClusters;
     const int entries = nwg * kWgClusters;
     for (int i = tid; i < entries; i += kIndexBlock) s_tab[i] = gtab[i];
+    // s_start becomes the RUNNING count of every cluster — its groups and points so far, packed (groups << 19 | points)
+    for (int ci = tid; ci < num_cluster; ci += kIndexBlock) s_start[ci] = 0;
     __syncthreads();
     B1B_T(1);
-    for (int ci = tid; ci <= num_cluster; ci += kIndexBlock) cstart[ci] = s_start[ci];
-    __syncthreads();   // the cluster starts have left for global memory: s_start becomes the running position of every cluster
-    // First slot of every (chunk, cluster) table entry = the cluster's start + its points in earlier chunks: ONE wave walks the chunks in
-    // order, a lane per table slot, advancing the cluster's running position in s_start (a chunk's table holds a cluster once, so the
-    // lanes never meet). The first version let every entry probe every earlier chunk's hash table: 18 x 64 entries x up to 17
-    // tables of dependent LDS probes, a quarter of this kernel (profiles/r03_label_kernel_phases.txt).
+    // What a (chunk, cluster) table entry has before it = the cluster's groups and points in earlier chunks: ONE wave walks the chunks
+    // in order, a lane per table slot, advancing the cluster's running count (a chunk's table holds a cluster once, so the lanes never
+    // meet). The first version let every entry probe every earlier chunk's hash table: 18 x 64 entries x up to 17 tables of dependent
+    // LDS probes, a quarter of this kernel (profiles/r03_label_kernel_phases.txt).
     if (wave == 0) {
       for (int wg = 0; wg < nwg; wg++) {
         const int2 t = s_tab[wg * kWgClusters + lane];
         int at = 0;
-        if (t.x) { at = s_start[t.x - 1]; s_start[t.x - 1] = at + t.y; }
+        if (t.x) { at = s_start[t.x - 1]; s_start[t.x - 1] = at + (t.y & 0xffff) + ((int)((unsigned)t.y >> 16) << kIndexPointBits); }
         s_pref[wg * kWgClusters + lane] = at;
         MOT_WAVE_SYNC();
       }
     }
     __syncthreads();
     B1B_T(2);
-    // 64 groups per wave at a time: every lane works out the first slot of ITS group from the tables, then the wave walks
-    // the 64 groups with one lane per point of the tile (four readlanes and a store per group)
-    // (a frame of the bench has ~600 groups: dealt 64 per wave, ten of the sixteen waves walked 64 groups each and six had none; dealt
-    // evenly, every wave walks ~40)
-    const int per = E <= kIndexWaves * 64 ? (E + kIndexWaves - 1) / kIndexWaves : 64;
-    for (int g0 = wave * per; g0 < E; g0 += kIndexWaves * per) {
-      const int mine_n = E - g0 < per ? E - g0 : per;
-      PointGroup mine;
-      mine.mask = 0ull; mine.label = 0; mine.tile = 0;
-      int mypos = 0;
-      if (lane < mine_n) {
-        mine = groups[g0 + lane];
-        const int tile = mine.tile & kGroupTileMask, within = (int)((unsigned)mine.tile >> kGroupTileBits);
-        const int wg = tile / (kLabelChunk / 64);
-        unsigned h = mot_label_hash(mine.label);
-        int pref = 0;
+    // one group per thread: its slot and the points before it from the tables, one 16-byte record out
+    for (int e = tid; e < E; e += kIndexBlock) {
+      const PointGroup g = groups[e];
+      const int lab = g.label & kGroupLabelMask, grank = (int)((unsigned)g.label >> 16);
+      const int tile = g.tile & kGroupTileMask, within = (int)((unsigned)g.tile >> kGroupTileBits);
+      const int wg = tile / (kLabelChunk / 64);
+      unsigned h = mot_label_hash(lab);
+      int pref = 0;
 #pragma unroll 1
-        for (int probe = 0; probe < kWgClusters; probe++) {
-          const int2 o = s_tab[wg * kWgClusters + (int)h];
-          if (o.x == mine.label) { pref = s_pref[wg * kWgClusters + (int)h]; break; }
-          if (o.x == 0) break;
-          h = (h + 1) & (kWgClusters - 1);
-        }
-        mypos = pref + within;   // (pref: the absolute first slot of the cluster's points of this chunk)
+      for (int probe = 0; probe < kWgClusters; probe++) {
+        const int2 o = s_tab[wg * kWgClusters + (int)h];
+        if (o.x == lab) { pref = s_pref[wg * kWgClusters + (int)h]; break; }
+        if (o.x == 0) break;
+        h = (h + 1) & (kWgClusters - 1);
       }
-      const int cnt = mine_n;
-      // (writing every point's picture pixel to its slot as well — so that the gather kernel reads a cluster's pixels as one contiguous run
-      // instead of chasing index -> pixel — took the gather kernel from 102 to 75 us per 512 frames and THIS kernel from 52 to 127:
-      // one workgroup per frame cannot hide the extra loads. profiles/r03_box_stage_experiments.txt)
-      for (int j = 0; j < cnt; j++) {
-        const unsigned mlo = (unsigned)wave_bcast_i32((int)(unsigned)mine.mask, j), mhi = (unsigned)wave_bcast_i32((int)(unsigned)(mine.mask >> 32), j);
-        const unsigned long long m = ((unsigned long long)mhi << 32) | mlo;
-        const int tile = wave_bcast_i32(mine.tile, j) & kGroupTileMask, pos = wave_bcast_i32(mypos, j);
-        if ((m >> lane) & 1ull) sorted[pos + __popcll(m & ((1ull << lane) - 1ull))] = tile * 64 + lane;
-      }
+      const int slot = cgstart[lab - 1] + (int)((unsigned)pref >> kIndexPointBits) + grank;
+      SortedGroup r; r.mask = g.mask; r.tile = tile; r.before = (pref & ((1 << kIndexPointBits) - 1)) + within;
+      if (slot < c.group_cap) gsorted[slot] = r;
     }
   } else {
     uint2* s_key = s_raw;   // {cluster, tile << 8 | points}
     const bool in_lds = E <= kGroupsLds;
-    if (in_lds) for (int e = tid; e < E; e += kIndexBlock) { PointGroup g = groups[e]; s_key[e] = make_uint2((unsigned)g.label, ((unsigned)(g.tile & kGroupTileMask) << 8) | (unsigned)__popcll(g.mask)); }
+    if (in_lds) for (int e = tid; e < E; e += kIndexBlock) { PointGroup g = groups[e]; s_key[e] = make_uint2((unsigned)(g.label & kGroupLabelMask), ((unsigned)(g.tile & kGroupTileMask) << 8) | (unsigned)__popcll(g.mask)); }
     __syncthreads();
-    for (int ci = tid; ci <= num_cluster; ci += kIndexBlock) cstart[ci] = s_start[ci];
     for (int e = tid; e < E; e += kIndexBlock) {
       const PointGroup g = groups[e];
-      const int gtile = g.tile & kGroupTileMask;
-      int before = 0;  // points of the same cluster in earlier tiles
+      const int gtile = g.tile & kGroupTileMask, lab = g.label & kGroupLabelMask;
+      int before = 0, rank = 0;  // points / groups of the same cluster in earlier tiles
       if (in_lds) {
-        for (int f = 0; f < E; f++) { uint2 q = s_key[f]; if ((int)q.x == g.label && (int)(q.y >> 8) < gtile) before += (int)(q.y & 0xffu); }
-      } else {  // more groups than fit in LDS (heavily interleaved clusters): same sum straight from L2
-        for (int f = 0; f < E; f++) { PointGroup h = groups[f]; if (h.label == g.label && (h.tile & kGroupTileMask) < gtile) before += __popcll(h.mask); }
+        for (int f = 0; f < E; f++) { uint2 q = s_key[f]; if ((int)q.x == lab && (int)(q.y >> 8) < gtile) { before += (int)(q.y & 0xffu); rank++; } }
+      } else {  // more groups than fit in LDS (heavily interleaved clusters): same sums straight from L2
+        for (int f = 0; f < E; f++) { PointGroup h = groups[f]; if ((h.label & kGroupLabelMask) == lab && (h.tile & kGroupTileMask) < gtile) { before += __popcll(h.mask); rank++; } }
       }
-      int pos = s_start[g.label - 1] + before;
-      unsigned long long m = g.mask;
-      while (m) { sorted[pos++] = gtile * 64 + __ffsll(m) - 1; m &= m - 1ull; }
+      const int slot = cgstart[lab - 1] + rank;
+      SortedGroup r; r.mask = g.mask; r.tile = gtile; r.before = before;
+      if (slot < c.group_cap) gsorted[slot] = r;
     }
   }
   B1B_T(3);
@@ -481,12 +487,13 @@ __device__ bool rule_based_filter(const MotDevParams& p, const float* pc, float 
 }
 
 // ------------------------------------------------------------------------------------------ B2
-// one workgroup per cluster, threads over the cluster's OWN points through the cluster-sorted index (no walk over the
+// one workgroup per cluster, waves over the cluster's OWN groups of points (cluster-sorted by the index kernel: no walk over the
 // frame). L-shape branch completes here; the rectangle branch leaves the cluster's candidate hull points (lowest /
 // highest pixel of every pixel column) in the polygon pool.
 __global__ void MOT_LAUNCH_BOUNDS2(kBoxBlock, MOT_GATHER_WAVES)
 cluster_gather_kernel(MotDevParams p, ClusterBuffers c) {
-  __shared__ int s_colmin[kPicCols], s_colmax[kPicCols];
+  __shared__ int s_col[2 * kPicCols];   // rectangle branch: per pixel column lowest / highest row; L-shape branch: the groups' running point counts
+  int* const s_colmin = s_col; int* const s_colmax = s_col + kPicCols;
   __shared__ int s_rank[128], s_pidx[128];
   __shared__ int s_flag;
   __shared__ int s_wsum[kBoxBlock / 64];
@@ -494,9 +501,10 @@ cluster_gather_kernel(MotDevParams p, ClusterBuffers c) {
   const int n = c.counts[b * kCountsStride + kCntElev];
   const int num_cluster = min(c.counts[b * kCountsStride + kCntClusters], kMaxClusters);
   const float4* __restrict__ pts = c.elevated + (long)b * c.cap;
-  const int* __restrict__ sorted = c.sorted + (long)b * c.cap;
+  const SortedGroup* __restrict__ gsorted = c.gsorted + (long)b * c.group_cap;
   const int* __restrict__ cstart = c.cluster_start + (long)b * (kMaxClusters + 1);
-  const int lane = lane_id(), wave = (int)(threadIdx.x >> 6), tid = (int)threadIdx.x;
+  const int* __restrict__ cgstart = c.cluster_gstart + (long)b * (kMaxClusters + 1);
+  const int lane = lane_id(), wave = wave_uniform_i32((int)(threadIdx.x >> 6)), tid = (int)threadIdx.x;   // (wave: in a scalar register, so that the walk's trip counts and branches are)
   (void)n;
 
   // (clusters in label order. Dealing them by falling size — c.order, as the rectangle kernel does — measured SLOWER here:
@@ -505,6 +513,8 @@ cluster_gather_kernel(MotDevParams p, ClusterBuffers c) {
     GATHER_T_BEGIN();
     const ClusterStats st = c.stats[(long)b * kMaxClusters + ci];
     const int first_slot = cstart[ci];   // (asked for together with the statistics: one round trip, not two)
+    const int gs = cgstart[ci];          // the cluster's groups: gsorted[gs .. gs + ng)
+    const int ng = min(st.groups(), c.group_cap - gs);
     // the cluster's candidate record is assembled where it is stored (thread 0), not carried in registers across the branches
     BoxCandidate* const cand_out = &c.cand[(long)b * kMaxClusters + ci];
     auto store_cand = [&](const float* pc8, float max_z, int accepted, int undefined, int branch, int poly_off, int poly_n, int off_x, int off_y) {
@@ -512,20 +522,28 @@ cluster_gather_kernel(MotDevParams p, ClusterBuffers c) {
 #pragma unroll
       for (int k = 0; k < 8; k++) q.pc[k] = pc8 ? pc8[k] : 0.f;
       q.max_z = max_z; q.accepted = accepted; q.undefined = undefined; q.branch = branch;
-      q.poly_off = poly_off; q.poly_n = poly_n; q.off_x = off_x; q.off_y = off_y; q.num_points = st.count; q.pad = 0;
+      q.poly_off = poly_off; q.poly_n = poly_n; q.off_x = off_x; q.off_y = off_y; q.num_points = st.count(); q.pad = 0;
       return q;
     };
-    const int numPoints = st.count;
+    const int numPoints = st.count();
     bool have = numPoints > 0 && st.argmin != kArgminInit && st.argmax != kArgmaxInit;  // SURVEY.md H7 otherwise
     if (!have) {
       if (tid == 0) *cand_out = store_cand(nullptr, 0.f, 0, 1, -1, 0, 0, 0, 0);
       continue;
     }
-    // The first trip of the rectangle branch's point walk is requested HERE, next to the three points the branch decision needs,
-    // so that its round trip overlaps theirs (an L-shape cluster throws these 8 indices per thread away).
-    int nxt[kGatherDepth];
-#pragma unroll
-    for (int u = 0; u < kGatherDepth; u++) { int j = u * kBoxBlock + tid; nxt[u] = j < numPoints ? sorted[first_slot + j] : -1; }
+    // A wave walks a quarter of the cluster's groups, and it fetches their records 64 at a time, a lane each — the first 64 HERE,
+    // next to the three points the branch decision needs, so that the round trips overlap (an L-shape cluster throws them away).
+    constexpr int kWaves = kBoxBlock / 64;
+#ifdef MOT_HIPEMU
+    constexpr int kRecBatch = 8, kStageMax = 48;   // (the emulator's tests reach the refill and the unstaged search with small clusters)
+#else
+    constexpr int kRecBatch = 64, kStageMax = kPicCols / 2;
+#endif
+    const int per = (ng + kWaves - 1) / kWaves;
+    const int g_first = wave * per;
+    const int g_mine = ng - g_first < per ? (ng - g_first > 0 ? ng - g_first : 0) : per;
+    SortedGroup rec; rec.mask = 0ull; rec.tile = 0; rec.before = 0;
+    if (lane < g_mine && lane < kRecBatch) rec = gsorted[gs + g_first + lane];
     const float4 first = pts[st.first];
     const float initPX = first.x + p.roi_half, initPY = first.y + p.roi_half;  // :218-225
     const int initX = (int)floorf(initPX * p.pic_scale), initY = (int)floorf(initPY * p.pic_scale);
@@ -600,8 +618,51 @@ cluster_gather_kernel(MotDevParams p, ClusterBuffers c) {
         __syncthreads();
       }
       GATHER_T(1);
-      // the k-th point of the cluster in input order is one lookup in the cluster-sorted index
-      for (int j = tid; j < nsamp; j += kBoxBlock) s_pidx[j] = sorted[first_slot + s_rank[j]];
+      // the r-th point of the cluster in input order: the group whose running count brackets r (a binary search per sample), then the
+      // (r - before)-th set lane of that group's tile. The records the waves fetched in the prologue go to LDS from their registers —
+      // no further memory round trip for clusters of up to 4 x 64 groups (~14 k points); the records beyond those are fetched now.
+      constexpr int kS = kStageMax;   // staged groups: running count, tile, lanes (low / high)
+      static_assert(4 * kStageMax <= 2 * kPicCols, "the staged records live in the column arrays");
+      const bool staged = ng <= kS;
+      if (staged) {
+        if (lane < g_mine && lane < kRecBatch) {
+          const int g = g_first + lane;
+          s_col[g] = rec.before; s_col[kS + g] = rec.tile; s_col[2 * kS + g] = (int)(unsigned)rec.mask; s_col[3 * kS + g] = (int)(unsigned)(rec.mask >> 32);
+        }
+        for (int k = kRecBatch + lane; k < g_mine; k += 64) {   // (a wave's share beyond its first batch)
+          const int g = g_first + k;
+          const SortedGroup q = gsorted[gs + g];
+          s_col[g] = q.before; s_col[kS + g] = q.tile; s_col[2 * kS + g] = (int)(unsigned)q.mask; s_col[3 * kS + g] = (int)(unsigned)(q.mask >> 32);
+        }
+      }
+      __syncthreads();
+      for (int j = tid; j < nsamp; j += kBoxBlock) {
+        const int r = s_rank[j];
+        int lo_g = 0;   // the last group with before <= r
+        if (staged) {   // groups hold about the same number of points: start where r would sit if they all did, then step (a few LDS reads, not ten)
+          lo_g = (int)(((long)r * ng) / numPoints);
+          lo_g = lo_g < ng ? lo_g : ng - 1;
+          while (lo_g > 0 && s_col[lo_g] > r) lo_g--;
+          while (lo_g + 1 < ng && s_col[lo_g + 1] <= r) lo_g++;
+        } else {
+          int hi_g = ng;
+          while (hi_g - lo_g > 1) { const int mid = (lo_g + hi_g) >> 1; if (gsorted[gs + mid].before <= r) lo_g = mid; else hi_g = mid; }
+        }
+        int pi = -1;
+        if (ng > 0) {
+          SortedGroup q;
+          if (staged) { q.before = s_col[lo_g]; q.tile = s_col[kS + lo_g]; q.mask = (unsigned long long)(unsigned)s_col[2 * kS + lo_g] | ((unsigned long long)(unsigned)s_col[3 * kS + lo_g] << 32); }
+          else q = gsorted[gs + lo_g];
+          int k = r - q.before, pos = 0;
+#pragma unroll
+          for (int w = 32; w >= 1; w >>= 1) {   // the k-th set bit of the mask
+            const int cnt = __popcll(q.mask & (((1ull << w) - 1ull) << pos));
+            if (k >= cnt) { k -= cnt; pos += w; }
+          }
+          pi = q.tile * 64 + pos;
+        }
+        s_pidx[j] = pi;
+      }
       __syncthreads();
       GATHER_T(2);
       // farthest sampled point from the line through the two slope-extreme points; first maximum wins
@@ -640,29 +701,28 @@ cluster_gather_kernel(MotDevParams p, ClusterBuffers c) {
       }
       __syncthreads();
     } else {  // ------------------------------------------------------- minAreaRect :358-366, part 1
-      for (int i = tid; i < kPicCols; i += kBoxBlock) { s_colmin[i] = 0x7fffffff; s_colmax[i] = -0x7fffffff - 1; }
-      __syncthreads();
-      // the cluster's points through the sorted index; what is fetched per point is its 4-byte picture pixel (label kernel).
-      // Two dependent loads per point (sorted index -> pixel), software-pipelined TWO trips deep: while trip t is filed into the column
-      // extents, the pixels of trip t+1 and the indices of trip t+2 are in flight (a 15 k-point wall walks 8-15 trips; with the pixel
-      // loads issued at the top of their own trip every trip waited a memory round trip: profiles/r03_gather_phases.txt)
+      // The cluster's points, group by group: a group = the lanes of one 64-point tile, so its pixels (4 bytes per point, label kernel)
+      // are ONE coalesced load at an address that comes out of the wave's pre-fetched records — no per-point index in between (until
+      // round 3: sorted index -> pixel, two dependent loads per point). Software-pipelined two trips deep: while the pixels of trip t
+      // are filed into the column extents, those of trips t+1 and t+2 are in flight.
       const int* __restrict__ pix = c.pix + (long)b * c.cap;
-      constexpr int kTrip = kBoxBlock * kGatherDepth;
-      int pv[kGatherDepth];
+      auto load_trip = [&](const SortedGroup& rc, int j0, int cntb, int* out) {
 #pragma unroll
-      for (int u = 0; u < kGatherDepth; u++) pv[u] = nxt[u] >= 0 ? pix[nxt[u]] : 0xffff;                                    // pixels of trip 0
-#pragma unroll
-      for (int u = 0; u < kGatherDepth; u++) { int j = kTrip + u * kBoxBlock + tid; nxt[u] = j < numPoints ? sorted[first_slot + j] : -1; }   // indices of trip 1
-      for (int j0 = 0; j0 < numPoints; j0 += kTrip) {
-        int v[kGatherDepth];
-#pragma unroll
-        for (int u = 0; u < kGatherDepth; u++) v[u] = pv[u];
-        if (j0 + kTrip < numPoints) {   // uniform
-#pragma unroll
-          for (int u = 0; u < kGatherDepth; u++) pv[u] = nxt[u] >= 0 ? pix[nxt[u]] : 0xffff;                                // pixels of trip t+1
-#pragma unroll
-          for (int u = 0; u < kGatherDepth; u++) { int j = j0 + 2 * kTrip + u * kBoxBlock + tid; nxt[u] = j < numPoints ? sorted[first_slot + j] : -1; }   // indices of trip t+2
+        for (int u = 0; u < kGatherDepth; u++) {
+          const int j = j0 + u;
+          int val = 0xffff;
+          if (j < cntb) {   // wave-uniform
+            const unsigned mlo = (unsigned)wave_bcast_i32((int)(unsigned)rc.mask, j), mhi = (unsigned)wave_bcast_i32((int)(unsigned)(rc.mask >> 32), j);
+            const int tile = wave_bcast_i32(rc.tile, j);
+            const unsigned long long m = ((unsigned long long)mhi << 32) | mlo;
+            if ((m >> lane) & 1ull) val = pix[(long)tile * 64 + lane];
+          }
+          out[u] = val;
         }
+      };
+      // Two register sets, A and B, alternate (no copies between them: a copy of a load's destination waits for the load, and with it
+      // for every load issued before the wait — the first version rotated one set into the other and waited out its own prefetches).
+      auto file_trip = [&](const int* v) {
         // look before the atomic: most points do not move an extreme (unconditional atomics: 60 -> 74 us). All the looks of a trip first,
         // unpredicated and independent, then the few atomics: looking inside each point's own branch made a chain of 2 x 8 LDS round
         // trips per trip — a wall's walk spent 500 cycles per point and thread on it (profiles/r03_gather_phases.txt). A stale look only
@@ -680,6 +740,34 @@ cluster_gather_kernel(MotDevParams p, ClusterBuffers c) {
           const int offsetY = (v[u] >> 16) + offsetInitY;
           if (picX != 0xffff && offsetY < lo[u]) atomicMin(&s_colmin[picX], offsetY);
           if (picX != 0xffff && offsetY > hi[u]) atomicMax(&s_colmax[picX], offsetY);
+        }
+        // (letting only the lanes no neighbour of their 16-lane row covers — same column, lower row — issue the atomic, against the
+        // same-address serialisation of a wall's 64 consecutive points: 85 -> 99 us, the walk is bound by its instructions, not by
+        // LDS conflicts. profiles/r03_box_stage_experiments.txt)
+      };
+      int pa[kGatherDepth], pb[kGatherDepth];
+      {
+        const int cnt0 = g_mine < kRecBatch ? g_mine : kRecBatch;
+        load_trip(rec, 0, cnt0, pa);   // the first pixels are on their way while the column extents are reset
+        load_trip(rec, kGatherDepth, cnt0, pb);
+      }
+      for (int i = tid; i < kPicCols; i += kBoxBlock) { s_colmin[i] = 0x7fffffff; s_colmax[i] = -0x7fffffff - 1; }
+      __syncthreads();
+      for (int base = 0; base < g_mine; base += kRecBatch) {
+        const int cntb = g_mine - base < kRecBatch ? g_mine - base : kRecBatch;
+        if (base > 0) {
+          rec.mask = 0ull; rec.tile = 0;
+          if (base + lane < g_mine && lane < kRecBatch) rec = gsorted[gs + g_first + base + lane];
+          load_trip(rec, 0, cntb, pa);
+          load_trip(rec, kGatherDepth, cntb, pb);
+        }
+        for (int j0 = 0; j0 < cntb; j0 += 2 * kGatherDepth) {
+          file_trip(pa);
+          if (j0 + 2 * kGatherDepth < cntb) load_trip(rec, j0 + 2 * kGatherDepth, cntb, pa);
+          if (j0 + kGatherDepth < cntb) {
+            file_trip(pb);
+            if (j0 + 3 * kGatherDepth < cntb) load_trip(rec, j0 + 3 * kGatherDepth, cntb, pb);
+          }
         }
       }
       __syncthreads();
@@ -1063,8 +1151,8 @@ static __device__ void box_finalize_body(const MotDevParams& p, const ClusterBuf
     // re-arm the statistics of the clusters just consumed
     if (ci < num_cluster) {
       ClusterStats s;
-      s.count = 0; s.first = 0x7fffffff; s.maxz_key = mot_float_key(-99.f); s.first_zero = 0x7fffffff;
-      s.argmin = kArgminInit; s.argmax = kArgmaxInit;
+      s.count_groups = 0ull; s.first = 0x7fffffff; s.maxz_key = mot_float_key(-99.f); s.first_zero = 0x7fffffff;
+      s.argmin = kArgminInit; s.argmax = kArgmaxInit; s.pad = 0;
       c.stats[(long)b * kMaxClusters + ci] = s;
     }
     __syncthreads();

@@ -55,7 +55,8 @@ struct mot_ctx {
   PointGroup* d_groups = nullptr;
   int* d_cluster_start = nullptr;
   int* d_order = nullptr;
-  int* d_sorted = nullptr;
+  SortedGroup* d_gsorted = nullptr;
+  int* d_cluster_gstart = nullptr;
   int* d_pix = nullptr;
   // cluster-node side products (allocated on first use)
   int* d_side_cell = nullptr;
@@ -278,7 +279,7 @@ extern "C" void mot_destroy(mot_ctx* c) {
   for (int i = 0; i < mot_ctx::kArgRing; i++) if (c->arg_ev[i]) (void)hipEventDestroy(c->arg_ev[i]);
   if (c->h_argring) (void)hipHostFree(c->h_argring);
   void* bufs[] = {c->d_in, c->d_argblk, c->d_ecell, c->d_pairs, c->d_pair_count, c->d_hg, c->d_cell, c->d_desc, c->d_ticket, c->d_elev, c->d_ground, c->d_mask, c->d_counts,
-                  c->d_plane_a, c->d_plane_b, c->d_ccl_parent, c->d_occ_list, c->d_occ_count, c->d_grid, c->d_label, c->d_stats, c->d_cand, c->d_boxes, c->d_box_cluster, c->d_rng, c->d_poly, c->d_groups, c->d_cluster_start, c->d_order, c->d_sorted, c->d_pix, c->d_wgtab, c->d_side_cell, c->d_side_cloud, c->d_side_obs, c->d_side_cost, c->d_side_counts, c->d_raw,
+                  c->d_plane_a, c->d_plane_b, c->d_ccl_parent, c->d_occ_list, c->d_occ_count, c->d_grid, c->d_label, c->d_stats, c->d_cand, c->d_boxes, c->d_box_cluster, c->d_rng, c->d_poly, c->d_groups, c->d_cluster_start, c->d_cluster_gstart, c->d_order, c->d_gsorted, c->d_pix, c->d_wgtab, c->d_side_cell, c->d_side_cloud, c->d_side_obs, c->d_side_cost, c->d_side_counts, c->d_raw,
                   c->d_tracks, c->d_nt, c->d_tboxes, c->d_gate, c->d_prog, c->d_live, c->d_tout, c->d_tflags, c->d_nlive, c->d_pos, c->d_slot_of, c->d_tomb, c->d_used, c->d_zomb, c->d_nzomb, c->d_cp, c->d_items, c->d_nitems};
   for (void* b : bufs) if (b) (void)hipFree(b);
   if (c->h_counts) (void)hipHostFree(c->h_counts);
@@ -316,7 +317,7 @@ static ClusterBuffers cluster_buffers(mot_ctx* c) {
   b.elevated = c->d_elev; b.cap = c->cap; b.counts = c->d_counts; b.plane_a = c->d_plane_a; b.plane_b = c->d_plane_b; b.ccl_parent = c->d_ccl_parent;
   b.occ_list = nullptr; b.occ_count = nullptr; b.n_in = c->d_n; b.occ_chunks = c->occ_chunks;   // the fused path points these at the compaction kernel's lists
   b.grid = c->d_grid; b.label = c->d_label; b.stats = c->d_stats; b.cand = c->d_cand; b.boxes = c->d_boxes;
-  b.box_cluster = c->d_box_cluster; b.rng = c->d_rng; b.poly = c->d_poly; b.groups = c->d_groups; b.group_cap = c->cap / 2; b.cluster_start = c->d_cluster_start; b.order = c->d_order; b.sorted = c->d_sorted;
+  b.box_cluster = c->d_box_cluster; b.rng = c->d_rng; b.poly = c->d_poly; b.groups = c->d_groups; b.group_cap = c->cap / 2; b.cluster_start = c->d_cluster_start; b.cluster_gstart = c->d_cluster_gstart; b.order = c->d_order; b.gsorted = c->d_gsorted;
   b.pix = c->d_pix; b.wgtab = c->d_wgtab; b.max_wg = c->max_wg;
   b.ecell = nullptr;   // stage-wise: the label kernel computes the cells itself
   return b;
@@ -386,7 +387,8 @@ static int create_impl(mot_ctx* c) {
   MOT_HIP(c, hipMalloc(&c->d_groups, B * (N / 2) * sizeof(PointGroup)));
   MOT_HIP(c, hipMalloc(&c->d_cluster_start, B * (kMaxClusters + 1) * sizeof(int)));
   MOT_HIP(c, hipMalloc(&c->d_order, B * kMaxClusters * sizeof(int)));
-  MOT_HIP(c, hipMalloc(&c->d_sorted, B * N * sizeof(int)));
+  MOT_HIP(c, hipMalloc(&c->d_gsorted, B * (N / 2) * sizeof(SortedGroup)));
+  MOT_HIP(c, hipMalloc(&c->d_cluster_gstart, B * (kMaxClusters + 1) * sizeof(int)));
   MOT_HIP(c, hipMalloc(&c->d_pix, B * N * sizeof(int)));
   c->max_wg = (int)((N + 2047) / 2048);
   MOT_HIP(c, hipMalloc(&c->d_wgtab, B * c->max_wg * kWgClusters * sizeof(int2)));
@@ -1494,7 +1496,7 @@ extern "C" int mot_debug_copy(mot_ctx* c, int which, int slot, void* dst, size_t
   if (which == 0) src = c->d_cand + (size_t)slot * kMaxClusters;
   else if (which == 1) src = c->d_stats + (size_t)slot * kMaxClusters;
   else if (which == 3) src = c->d_poly + (size_t)slot * c->cap;
-  else if (which == 5) src = c->d_sorted + (size_t)slot * c->cap;
+  else if (which == 5) src = c->d_gsorted + (size_t)slot * (c->cap / 2);
   else if (which == 7) src = c->d_cluster_start + (size_t)slot * (kMaxClusters + 1);
   else if (which == 8) src = c->d_pix + (size_t)slot * c->cap;
   else if (which == 9) src = c->d_groups + (size_t)slot * (c->cap / 2);

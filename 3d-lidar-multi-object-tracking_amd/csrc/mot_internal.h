@@ -121,22 +121,34 @@ enum { kCntElev = 0, kCntGround = 1, kCntDropped = 2, kCntClusters = 3, kCntBoxe
        kCntIrregular = 9 };   // kCntGroups, kCntIrregular: label kernel -> index kernel, zero between launches
 enum { kFlagClusterOverflow = 1, kFlagBoxOverflow = 2, kFlagRngExhausted = 4, kFlagHullOverflow = 8, kFlagGroupOverflow = 16 };
 
-struct ClusterStats {          // per cluster, accumulated by the label kernel, reset by the finalize kernel
-  int count;                   // numPoints
+struct ClusterStats {          // per cluster, accumulated by the label kernel, reset by the finalize kernel (40 bytes)
+  unsigned long long count_groups;   // low word: numPoints; high word: (tile, cluster) groups of the cluster = 64-point tiles that hold a point
+                               // of it (ONE 64-bit atomic for both: a wall's statistics are hit by every chunk it spans)
+  unsigned long long argmin;   // (key(m) << 32) | idx        -> minimum = smallest slope, first occurrence
+  unsigned long long argmax;   // (key(m) << 32) | ~idx       -> maximum = largest slope, first occurrence
   int first;                   // smallest point index (clusteredPoints[i][0])
   int maxz_key;                // ordered key of max z (init key(-99)); -0 and +0 share the key of +0
   int first_zero;              // smallest index of a point with z == +-0 (0x7fffffff if none): the sign of a zero maximum
-  unsigned long long argmin;   // (key(m) << 32) | idx        -> minimum = smallest slope, first occurrence
-  unsigned long long argmax;   // (key(m) << 32) | ~idx       -> maximum = largest slope, first occurrence
+  int pad;
+  __host__ __device__ int count() const { return (int)(unsigned)count_groups; }
+  __host__ __device__ int groups() const { return (int)(count_groups >> 32); }
 };
+static_assert(sizeof(ClusterStats) == 40, "ClusterStats layout");
 struct PointGroup {            // the points of one 64-point tile that belong to one cluster (label kernel)
   unsigned long long mask;     // lanes of the tile
-  int label;                   // 1-based cluster id
-  int tile;                    // bits 0-19: points 64*tile .. 64*tile + 63; bits 20-31: points of the cluster in EARLIER tiles of the
+  int label;                   // bits 0-15: 1-based cluster id; bits 16-31: GROUPS of the cluster in earlier tiles of the same chunk
+  int tile;                    // bits 0-19: points 64*tile .. 64*tile + 63; bits 20-31: POINTS of the cluster in EARLIER tiles of the
                                // same label-kernel workgroup (2048-point chunk)
 };
 constexpr int kGroupTileBits = 20;
 constexpr int kGroupTileMask = (1 << kGroupTileBits) - 1;
+constexpr int kGroupLabelMask = 0xffff;
+struct SortedGroup {           // the same groups in cluster order (index kernel): what the per-cluster kernels walk
+  unsigned long long mask;     // lanes of the tile
+  int tile;                    // points 64*tile .. 64*tile + 63
+  int before;                  // points of the cluster in its earlier groups (= rank of the group's first point within the cluster)
+};
+constexpr int kIndexPointBits = 19;   // the index kernel's fast path packs (groups << 19 | points) per cluster: frames of up to 2^19 points
 constexpr int kWgClusters = 64;     // distinct clusters a label-kernel workgroup merges in LDS (its open-addressed table)
 struct BoxCandidate {          // per cluster, written by the box kernels
   float pc[8];                 // 4 corners (x,y)
@@ -170,10 +182,11 @@ struct ClusterBuffers {
   PointGroup* groups;          // [B][cap / 2] (tile, cluster) groups of the frame, any order
   int group_cap;               // cap / 2
   int* order;                  // [B][kMaxClusters] clusters by falling size: the per-cluster kernels start on the largest ones
-  int* cluster_start;          // [B][kMaxClusters + 1] first slot of every cluster in `sorted`
-  int* sorted;                 // [B][cap] point indices grouped by cluster, input order inside a cluster
+  int* cluster_start;          // [B][kMaxClusters + 1] points of all earlier clusters (a cluster's own slots of the polygon pool start here)
+  int* cluster_gstart;         // [B][kMaxClusters + 1] first entry of every cluster in `gsorted`
+  SortedGroup* gsorted;        // [B][cap / 2] the frame's groups by cluster, in input (tile) order inside a cluster
   int* pix;                    // [B][cap] picture pixel of every elevated point (x | y << 16, x = 0xffff outside), box_fitting.cpp:244-254
-  int2* wgtab;                 // [B][max_wg][kWgClusters] {cluster, points} per label-kernel workgroup (its LDS table, empty = {0,0})
+  int2* wgtab;                 // [B][max_wg][kWgClusters] {cluster, points | groups << 16} per label-kernel workgroup (its LDS table, empty = {0,0})
   int max_wg;                  // cap / 2048 rounded up
 };
 

@@ -725,8 +725,8 @@ def main():
                      "classify_compact_kernel": 16.0 * n_tot + 16.0 * ne_tot,   # the fused path's default: ground cloud and mask on demand (round 2: + 16 N_g + N)
                      "ccl_kernel": (2 * 2048 * 4 + 4.0 * G * G) * BL,
                      "label_stats_kernel": (16.0 + 4.0) * ne_tot,   # points read, pixels written; the per-point labels are written on demand only (MOT_OUT_LABELS)
-                     "cluster_index_kernel": 4.0 * ne_tot,
-                     "cluster_gather_kernel": (4.0 + 4.0) * ne_tot,
+                     "cluster_index_kernel": 32.0 * ne_tot / 64,   # a 16-byte record per (tile, cluster) group read and written; at least one group per 64 points
+                     "cluster_gather_kernel": (4.0 + 16.0 / 64) * ne_tot,   # the pixels, and the cluster-sorted group records
                      "cluster_rect_kernel": 4.0 * ne_tot / 8,
                      "box_finalize_kernel": 96.0 * BL,
                      "track_step_kernel": (2 * 1624.0 + 144.0) * max(int(np.mean(live)), 1) * BL}
