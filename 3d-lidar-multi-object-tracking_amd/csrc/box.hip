@@ -3,8 +3,8 @@
 // Replaces boxFitting() = getClusteredPoints() + getBoundingBox() (+ ruleBasedFilter, getPointsInPcFrame and
 // OpenCV's minAreaRect / RotatedRect::points) — OT/src/cluster/box_fitting.cpp:46-435 — for a batch of frames:
 //
-//   B1 label_stats_kernel   N_e pts  -> per-point label + per-cluster {count, first point, max z, slope extrema}
-//   B1b cluster_index_kernel groups  -> cluster-sorted stable point index
+//   B1 label_stats_kernel   N_e pts  -> (tile, cluster) groups + per-cluster {count, first point, max z, slope extrema} (+ per-point labels on request)
+//   B1b cluster_index_kernel groups  -> the groups in cluster order, input order inside a cluster (no per-point index)
 //   B2 cluster_gather_kernel  clusters -> L-shape fit, or the candidate hull points of the cluster (4 waves per cluster)
 //   B2b cluster_rect_kernel  clusters -> min-area rectangle + rule filter (one wave per cluster)
 //   B3 box_finalize_kernel  clusters -> boxes compacted in cluster order (the order the reference push_backs them)
@@ -16,7 +16,8 @@
 //    label, merged per workgroup in LDS, and one 64-bit atomic min/max per (workgroup, cluster) on keys that carry the
 //    point index as tie-break; (b) the FIRST point of the cluster (pixel re-centring, :218-225) = atomic min of the
 //    index; (c) for the L-shape branch the k-th point of the cluster in input order for 80 seeded k (mt19937_64(0) +
-//    libstdc++'s uniform_int_distribution): a lookup in the cluster-sorted index.
+//    libstdc++'s uniform_int_distribution): a search over the cluster's groups' running point counts, then the k'-th set
+//    lane of that group's tile.
 //  * min-area rectangle: pixel coordinates are integers in [0,900], so only the lowest and highest pixel of
 //    every pixel column can be hull vertices; column extents are gathered with LDS atomics and handed — already
 //    sorted by (x,y) — to a parallel peeling of the upper / lower chains that yields exactly the vertex list and order
