@@ -515,7 +515,7 @@ cluster_gather_kernel(MotDevParams p, ClusterBuffers c) {
     const ClusterStats st = c.stats[(long)b * kMaxClusters + ci];
     const int first_slot = cstart[ci];   // (asked for together with the statistics: one round trip, not two)
     const int gs = cgstart[ci];          // the cluster's groups: gsorted[gs .. gs + ng)
-    const int ng = min(st.groups(), c.group_cap - gs);
+    const int ng = min(mot_stats_groups(st), c.group_cap - gs);
     // the cluster's candidate record is assembled where it is stored (thread 0), not carried in registers across the branches
     BoxCandidate* const cand_out = &c.cand[(long)b * kMaxClusters + ci];
     auto store_cand = [&](const float* pc8, float max_z, int accepted, int undefined, int branch, int poly_off, int poly_n, int off_x, int off_y) {
@@ -523,10 +523,10 @@ cluster_gather_kernel(MotDevParams p, ClusterBuffers c) {
 #pragma unroll
       for (int k = 0; k < 8; k++) q.pc[k] = pc8 ? pc8[k] : 0.f;
       q.max_z = max_z; q.accepted = accepted; q.undefined = undefined; q.branch = branch;
-      q.poly_off = poly_off; q.poly_n = poly_n; q.off_x = off_x; q.off_y = off_y; q.num_points = st.count(); q.pad = 0;
+      q.poly_off = poly_off; q.poly_n = poly_n; q.off_x = off_x; q.off_y = off_y; q.num_points = mot_stats_count(st); q.pad = 0;
       return q;
     };
-    const int numPoints = st.count();
+    const int numPoints = mot_stats_count(st);
     bool have = numPoints > 0 && st.argmin != kArgminInit && st.argmax != kArgmaxInit;  // SURVEY.md H7 otherwise
     if (!have) {
       if (tid == 0) *cand_out = store_cand(nullptr, 0.f, 0, 1, -1, 0, 0, 0, 0);

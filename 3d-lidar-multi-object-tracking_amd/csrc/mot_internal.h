@@ -130,8 +130,6 @@ struct ClusterStats {          // per cluster, accumulated by the label kernel, 
   int maxz_key;                // ordered key of max z (init key(-99)); -0 and +0 share the key of +0
   int first_zero;              // smallest index of a point with z == +-0 (0x7fffffff if none): the sign of a zero maximum
   int pad;
-  __host__ __device__ int count() const { return (int)(unsigned)count_groups; }
-  __host__ __device__ int groups() const { return (int)(count_groups >> 32); }
 };
 static_assert(sizeof(ClusterStats) == 40, "ClusterStats layout");
 struct PointGroup {            // the points of one 64-point tile that belong to one cluster (label kernel)
@@ -321,6 +319,8 @@ void mot_launch_ground_kernel(int which, const MotDevParams& p, const GroundBuff
 
 // ordered-int key of a float: signed integer compare == float compare
 // slot of a cluster in a label-kernel workgroup's 64-entry table (linear probing from here)
+MOT_HD int mot_stats_count(const ClusterStats& s) { return (int)(unsigned)s.count_groups; }
+MOT_HD int mot_stats_groups(const ClusterStats& s) { return (int)(s.count_groups >> 32); }
 MOT_HD unsigned mot_label_hash(int label) { return ((unsigned)label * 0x9E3779B1u) >> 26; }
 MOT_HD int mot_float_key(float f) { int k = mot_f2i(f); return k >= 0 ? k : k ^ 0x7fffffff; }
 MOT_HD float mot_key_float(int k) { return mot_i2f(k >= 0 ? k : k ^ 0x7fffffff); }
