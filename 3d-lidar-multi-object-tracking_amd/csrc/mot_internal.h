@@ -121,7 +121,9 @@ enum { kCntElev = 0, kCntGround = 1, kCntDropped = 2, kCntClusters = 3, kCntBoxe
        kCntIrregular = 9 };   // kCntGroups, kCntIrregular: label kernel -> index kernel, zero between launches
 enum { kFlagClusterOverflow = 1, kFlagBoxOverflow = 2, kFlagRngExhausted = 4, kFlagHullOverflow = 8, kFlagGroupOverflow = 16 };
 
-struct ClusterStats {          // per cluster, accumulated by the label kernel, reset by the finalize kernel (40 bytes)
+struct alignas(64) ClusterStats {   // per cluster, accumulated by the label kernel, reset by the finalize kernel. A cache line each: the five
+                               // atomics of a commit go to ONE line and no two clusters share one (40-byte records: the label kernel alone
+                               // 4 us faster, the four-context line 2 % slower, profiles/r03_box_stage_experiments.txt)
   unsigned long long count_groups;   // low word: numPoints; high word: (tile, cluster) groups of the cluster = 64-point tiles that hold a point
                                // of it (ONE 64-bit atomic for both: a wall's statistics are hit by every chunk it spans)
   unsigned long long argmin;   // (key(m) << 32) | idx        -> minimum = smallest slope, first occurrence
@@ -131,7 +133,7 @@ struct ClusterStats {          // per cluster, accumulated by the label kernel, 
   int first_zero;              // smallest index of a point with z == +-0 (0x7fffffff if none): the sign of a zero maximum
   int pad;
 };
-static_assert(sizeof(ClusterStats) == 40, "ClusterStats layout");
+static_assert(sizeof(ClusterStats) == 64, "ClusterStats layout");
 struct PointGroup {            // the points of one 64-point tile that belong to one cluster (label kernel)
   unsigned long long mask;     // lanes of the tile
   int label;                   // bits 0-15: 1-based cluster id; bits 16-31: GROUPS of the cluster in earlier tiles of the same chunk
