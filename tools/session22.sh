@@ -10,4 +10,4 @@ pass cycles SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_ANY SQ_WAIT_AN
 python profiles/summarize_pmc.py $(find $O/pmc_insts $O/pmc_cycles -name '*.db') --json=$O/pmc_sq.json > $O/pmc_sq_raw.txt 2>&1; tail -20 $O/pmc_sq_raw.txt
 rm -rf $O/pmc_insts $O/pmc_cycles
 # randomised tracker sequences and irregular clouds on the real kernels
-timeout 600 python tests/explore_gpu.py 60 10 2>&1 | tail -8 | tee $O/explore_gpu.txt
+timeout 600 python tests/explore_gpu.py 300 40 2>&1 | tail -8 | tee $O/explore_gpu.txt
