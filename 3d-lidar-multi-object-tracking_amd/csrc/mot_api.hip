@@ -684,7 +684,7 @@ static int launch_frames(mot_ctx* c, int batch, int run_tracker, const double* t
   c->ground_resident = want_ground && want_mask; c->last_fused = true;
   c->label_state.assign(c->batch, (c->fused_outputs & MOT_OUT_LABELS) ? 1 : 0);
 #ifndef MOT_HIPEMU
-  // Few streams per launch = somebody waits for every frame: the sequence's 14-18 launches go out as ONE hipGraph launch, captured
+  // Few streams per launch = somebody waits for every frame: the sequence's 10-13 launches go out as ONE hipGraph launch, captured
   // once per launch geometry. What differs from call to call without changing the geometry (the cloud's address, the look-back
   // epoch) travels in the argument block (FrameLaunch). Not while a kernel is being timed (the event pairs are host calls).
   if (c->graph_mode && c->prof_kernel == 0) {

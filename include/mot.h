@@ -269,7 +269,7 @@ int mot_frames_dev(mot_ctx* ctx, const float* d_xyzw, long frame_stride, const i
  * (OT/src/groundremove/ground_removal.cpp:226-247). */
 int mot_set_fused_outputs(mot_ctx* ctx, int flags);
 
-/* on != 0: the fused entry points send their launch sequence (14-18 kernels) as ONE hipGraph launch, captured once per launch geometry
+/* on != 0: the fused entry points send their launch sequence (13 kernels with the tracker) as ONE hipGraph launch, captured once per launch geometry
  * (batch, chunks of the largest frame, tracker on / off, outputs); what changes per call without changing the geometry travels in the
  * device-resident argument block. For contexts somebody waits on frame by frame (one or a few streams): the host's part of a frame
  * drops to one copy and one launch. Default off; a runtime that cannot capture the sequence falls back to plain launches silently.
