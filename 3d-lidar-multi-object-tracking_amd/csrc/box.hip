@@ -332,7 +332,7 @@ cluster_index_kernel(ClusterBuffers c) {
   int E = c.counts[b * kCountsStride + kCntGroups];
   if (E > c.group_cap) { E = c.group_cap; if (tid == 0) atomicOr(&c.counts[b * kCountsStride + kCntFlags], (int)kFlagGroupOverflow); }
   const int nwg = (n + kLabelChunk - 1) / kLabelChunk;
-  const bool fast = c.counts[b * kCountsStride + kCntIrregular] == 0 && nwg <= kIndexWgLds && nwg <= c.max_wg && n < (1 << kIndexPointBits);
+  const bool fast = c.counts[b * kCountsStride + kCntIrregular] == 0 && nwg <= kIndexWgLds && nwg <= c.max_wg && n <= (1 << kIndexPointBits) - 64;   // (fewer than 2^13 tiles: a cluster's groups fit the 13 bits above its 19 bits of points)
   const PointGroup* __restrict__ groups = c.groups + (long)b * c.group_cap;
   const ClusterStats* __restrict__ stats = c.stats + (long)b * kMaxClusters;
   int* cstart = c.cluster_start + (long)b * (kMaxClusters + 1);
@@ -399,7 +399,7 @@ cluster_index_kernel(ClusterBuffers c) {
       for (int wg = 0; wg < nwg; wg++) {
         const int2 t = s_tab[wg * kWgClusters + lane];
         int at = 0;
-        if (t.x) { at = s_start[t.x - 1]; s_start[t.x - 1] = at + (t.y & 0xffff) + ((int)((unsigned)t.y >> 16) << kIndexPointBits); }
+        if (t.x) { at = s_start[t.x - 1]; s_start[t.x - 1] = (int)((unsigned)at + ((unsigned)t.y & 0xffffu) + (((unsigned)t.y >> 16) << kIndexPointBits)); }
         s_pref[wg * kWgClusters + lane] = at;
         MOT_WAVE_SYNC();
       }
