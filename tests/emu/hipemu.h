@@ -300,7 +300,9 @@ static inline hipError_t hipSetDevice(int) { return hipSuccess; }
 static inline hipError_t hipGetDevice(int* d) { *d = 0; return hipSuccess; }
 static inline hipError_t hipGetDeviceProperties(hipDeviceProp_t* p, int) { memset(p, 0, sizeof *p); strcpy(p->name, "hipemu"); strcpy(p->gcnArchName, "gfx950:emulated"); p->multiProcessorCount = 256; return hipSuccess; }
 // device memory arrives poisoned (0xFF: NaN floats, -1 ints) so that reads of never-written memory show up in the tests
-static inline hipError_t hipMalloc(void** p, size_t n) { *p = malloc(n ? n : 1); if (*p) memset(*p, 0xFF, n ? n : 1); return *p ? hipSuccess : 2; }
+static inline hipError_t hipMalloc(void** p, size_t n) {   // 256-byte aligned like the device allocator (types with alignas(64) live in these buffers)
+  const size_t m = ((n ? n : 1) + 255) & ~(size_t)255;
+  *p = aligned_alloc(256, m); if (*p) memset(*p, 0xFF, m); return *p ? hipSuccess : 2; }
 template <typename T> static inline hipError_t hipMalloc(T** p, size_t n) { return hipMalloc((void**)p, n); }
 static inline hipError_t hipHostMalloc(void** p, size_t n, unsigned = 0) { return hipMalloc(p, n); }
 template <typename T> static inline hipError_t hipHostMalloc(T** p, size_t n, unsigned f = 0) { return hipHostMalloc((void**)p, n, f); }
