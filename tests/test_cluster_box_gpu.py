@@ -311,3 +311,16 @@ def test_wide_clusters_take_the_large_hull_kernel(mot, hip_lib, oracle):
             bx, got = W.check(c, oracle, p, W.wide_wall_cloud(seed, walls))
             wide += sum(1 for d in bx["debug"] if d["branch"] == 1 and d["num_points"] > 5000 and d["accepted"])   # a box that only the large-hull kernel can have produced
         assert wide >= 4
+
+
+def test_l_shape_cluster_with_more_groups_than_the_staging_holds(mot, hip_lib, oracle):
+    """the L-shape branch finds "the r-th point of the cluster" by a search over the cluster's (tile, cluster) groups; up to 512 of them
+    are staged in LDS, a cluster with more searches global memory: a 40 000-point L in random order (~640 groups), both RNG mappings"""
+    import wide_clusters as W
+    for mapping in (1, 0):   # MOT_RNG_LIBSTDCXX11 (default), MOT_RNG_LIBSTDCXX10
+        kw = dict(rng_mapping=mapping)
+        p = oracle.params(0, **kw)
+        with mot.Context(mot.params(0, **kw), max_points=65536) as c:
+            for seed in (1, 2):
+                bx, got = W.check(c, oracle, p, W.big_l_cloud(seed))
+                assert any(d["branch"] == 0 and d["num_points"] >= 33000 and d["accepted"] for d in bx["debug"]), [(d["num_points"], d["branch"], d["accepted"]) for d in bx["debug"]]

@@ -124,3 +124,15 @@ def test_emu_wide_clusters_take_the_large_hull_kernel(mot, emu_lib, oracle):
             bx, got = W.check(c, oracle, p, W.wide_wall_cloud(seed, walls))
             wide += sum(1 for d in bx["debug"] if d["branch"] == 1 and d["num_points"] > 5000 and d["accepted"])   # a box that only the large-hull kernel can have produced
         assert wide >= 4
+
+
+def test_emu_l_shape_cluster_with_more_groups_than_the_staging_holds(mot, emu_lib, oracle):
+    """the L-shape branch's "r-th point of the cluster" search over the cluster's groups, with more groups than are staged in LDS (the
+    emulator build stages 48) and more than one batch of records per wave (8 there): a dense car-sized L in random order, both RNG mappings"""
+    import wide_clusters as W
+    for mapping in (1, 0):
+        kw = dict(rng_mapping=mapping)
+        p = oracle.params(0, **kw)
+        with mot.Context(mot.params(0, lib=mot.load_library(emu_lib), **kw), lib_path=emu_lib, max_points=16384) as c:
+            bx, got = W.check(c, oracle, p, W.big_l_cloud(1, n_per_wall=5000))
+            assert any(d["branch"] == 0 and d["num_points"] >= 8000 and d["accepted"] for d in bx["debug"])

@@ -29,3 +29,20 @@ def check(ctx, oracle, p, cloud):
     assert a["num_cluster"] == cl["num_cluster"] and np.array_equal(a["grid"], cl["grid"])
     assert np.array_equal(b["boxes"].view(np.uint32), bx["boxes"].view(np.uint32)) and np.array_equal(b["box_cluster"], bx["box_cluster"]) and b["n_undefined"] == bx["n_undefined"]
     return bx, b
+
+
+def big_l_cloud(seed=1, n_per_wall=20000, n_small=2):
+    """one L-shaped cluster of 2 x n_per_wall points (the two visible sides of a car, very densely sampled) in RANDOM order, so that almost every
+    64-point tile holds points of it: more (tile, cluster) groups than the gather kernel stages in LDS for the L-shape branch's
+    "r-th point of the cluster" search (512) — plus a few compact blobs"""
+    rng = np.random.default_rng(seed)
+    n = n_per_wall
+    a = np.stack([rng.uniform(5.0, 9.0, n), 10.0 + rng.uniform(-0.1, 0.1, n), rng.uniform(-1.2, 0.0, n), np.ones(n)], 1)      # a car's long side ...
+    b = np.stack([9.0 + rng.uniform(-0.1, 0.1, n), rng.uniform(10.0, 11.8, n), rng.uniform(-1.2, 0.0, n), np.ones(n)], 1)     # ... and its short side
+    pts = [a, b]
+    for k in range(n_small):
+        m = 700
+        c = np.array([-10.0 - 6 * k, -12.0])
+        pts.append(np.concatenate([c + rng.normal(0, 0.5, (m, 2)), rng.uniform(-1.2, 0.6, (m, 1)), np.ones((m, 1))], 1))
+    out = np.concatenate(pts).astype(np.float32)
+    return out[rng.permutation(len(out))]
