@@ -701,6 +701,14 @@ cluster_gather_kernel(MotDevParams p, ClusterBuffers c) {
         *cand_out = cand;
       }
       __syncthreads();
+    } else if (numPoints < p.min_points || !(maxZ + p.sensor_height > p.t_height_min && maxZ + p.sensor_height < p.t_height_max)) {
+      // ruleBasedFilter (:97-158) turns this cluster down whatever its rectangle: too few points (:100), or a height — it depends on max z
+      // alone (:127, :137) — outside the window; every other test is nested inside that one. The reference fits the rectangle first and
+      // asks afterwards; nothing of the fit is kept for a rejected cluster, so it is not computed: no walk over the points, no hull, no
+      // calipers. On a street scene that is every second rectangle cluster and two fifths of their points — the walls above 2.6 m, i.e. the
+      // clusters this kernel's slowest workgroups and cluster_rect_large_kernel used to spend their time on. (The L-shape branch above is
+      // left alone: a degenerate sample set makes a cluster "undefined", SURVEY.md H7, and those are counted whether accepted or not.)
+      if (tid == 0) *cand_out = store_cand(nullptr, maxZ, 0, 0, 1, first_slot, 0, offsetInitX, offsetInitY);
     } else {  // ------------------------------------------------------- minAreaRect :358-366, part 1
       // The cluster's points, group by group: a group = the lanes of one 64-point tile, so its pixels (4 bytes per point, label kernel)
       // are ONE coalesced load at an address that comes out of the wave's pre-fetched records — no per-point index in between (until
@@ -899,6 +907,7 @@ __device__ __forceinline__ void cluster_rect_body(const MotDevParams& p, const C
     BoxCandidate cand = c.cand[(long)b * kMaxClusters + ci];
     if (cand.branch != 1 || cand.undefined) continue;  // L-shape clusters are complete already
     if ((cand.poly_n > kSmallHullIn) != kLarge) continue;   // the other instantiation's cluster
+    if (cand.poly_n == 0) continue;   // turned down before the fit (gather kernel), or not a point inside the picture: accepted = 0 stands
     const int offsetInitX = cand.off_x, offsetInitY = cand.off_y, numPoints = cand.num_points;
     const float maxZ = cand.max_z;
     int total = cand.poly_n;
