@@ -928,6 +928,7 @@ extern "C" int mot_cluster(mot_ctx* c, const float* elev, int n, int32_t* grid, 
   if (n > c->max_points) return fail(c, MOT_E_CAPACITY, "cloud has more points than max_points");
   int rc;
   if (n > 0) MOT_HIP(c, hipMemcpyAsync(c->d_elev, elev, (size_t)n * 16, hipMemcpyHostToDevice, c->stream));
+  c->last_fused = false;   // slot 0 now holds this call's cloud: mot_get_ground must not re-run a fused batch's compaction over it
   if ((rc = set_count(c, 0, kCntElev, n))) return rc;
   ClusterBuffers cb = cluster_buffers(c);
   mot_launch_cluster(c->dp, cb, 1, n, c->stream);
@@ -952,6 +953,7 @@ extern "C" int mot_box_fit(mot_ctx* c, const float* elev, int n, const int32_t* 
   const int G = c->params.num_grid;
   if (n > 0) MOT_HIP(c, hipMemcpyAsync(c->d_elev, elev, (size_t)n * 16, hipMemcpyHostToDevice, c->stream));
   MOT_HIP(c, hipMemcpyAsync(c->d_grid, grid, (size_t)G * G * sizeof(int), hipMemcpyHostToDevice, c->stream));
+  c->last_fused = false;   // slot 0 now holds this call's cloud: mot_get_ground must not re-run a fused batch's compaction over it
   if ((rc = set_count(c, 0, kCntElev, n))) return rc;
   if ((rc = set_count(c, 0, kCntClusters, num_cluster))) return rc;
   ClusterBuffers cb = cluster_buffers(c);
@@ -1059,6 +1061,7 @@ extern "C" int mot_cluster_products_host(mot_ctx* c, const float* elev, int n, c
   const int G = c->params.num_grid;
   if (n > 0) MOT_HIP(c, hipMemcpyAsync(c->d_elev, elev, (size_t)n * 16, hipMemcpyHostToDevice, c->stream));
   MOT_HIP(c, hipMemcpyAsync(c->d_grid, grid, (size_t)G * G * sizeof(int), hipMemcpyHostToDevice, c->stream));
+  c->last_fused = false;   // slot 0 now holds this call's cloud: mot_get_ground must not re-run a fused batch's compaction over it
   int rc = set_count(c, 0, kCntElev, n);
   if (rc) return rc;
   return mot_cluster_products(c, 0, sp, clustered_xyzw, max_clustered, n_clustered, obstacles_xyzc, max_obstacles, n_obstacles, cost_map);

@@ -928,8 +928,8 @@ track_finish_kernel(TrackBuffers tb) {
   __syncthreads();
   const int nvis = s_nvis;
   if (nvis <= kVisCap) {
-    for (int pr = tid; pr < nvis * nt0; pr += kTrackBlock) {
-      const int v = pr / nt0, j = pr - v * nt0, i = s_vi[v], ri = s_vr[v];
+    for (long pr = tid, npr = (long)nvis * nt0; pr < npr; pr += kTrackBlock) {   // (64-bit: 256 boxes x 2^26 tracks ever created)
+      const int v = (int)(pr / nt0), j = (int)(pr - (long)v * nt0), i = s_vi[v], ri = s_vr[v];
       if (j == ri) continue;
       const double* q = s_vb[v];
       const double v1x = q[0], v1y = q[1], v2x = q[2], v2y = q[3], v3x = q[4], v3y = q[5], v4x = q[6], v4y = q[7], cp1x = q[8], cp1y = q[9], cp2x = q[10], cp2y = q[11];

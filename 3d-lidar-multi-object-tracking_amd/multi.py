@@ -142,10 +142,12 @@ class TrackGatherAll:
                     ev = torch.cuda.Event(); ev.record(self.side); self.done[i] = ev
             else:
                 dist.all_gather_into_tensor(self.recv[i], send, group=self.group)
+        elif self.cuda:   # one rank, no collective: the block itself — on the side stream, which waits for the exports (like the collective)
+            with torch.cuda.stream(self.side):
+                self.recv[i][: send.numel()].copy_(send, non_blocking=True)
+                ev = torch.cuda.Event(); ev.record(self.side); self.done[i] = ev
         else:
-            self.recv[i][: send.numel()] = send if not self.cuda else send   # one rank, no collective: the block itself
-            if self.cuda:
-                ev = torch.cuda.Event(); ev.record(torch.cuda.current_stream()); self.done[i] = ev
+            self.recv[i][: send.numel()] = send
         self.last = i
         return self.recv[i]
 

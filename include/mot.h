@@ -241,7 +241,8 @@ int mot_frame_pointcloud2(mot_ctx* ctx, const void* data, int n_points, int poin
 int mot_ego_update(mot_ctx* ctx, int slot, double timestamp, double v_gps, double yaw_gps, double* origin6);
 
 /* replaces immUkfJpdaf(bBoxes, timestamp, ...), OT/include/imm_ukf_jpda.h:19-22.
- * boxes_global: m x 8 x 3 floats in the global frame. tracks: capacity max_tracks records. */
+ * boxes_global: m x 8 x 3 floats in the global frame. tracks: capacity max_tracks records — one per track EVER created on the
+ * stream (see mot_get_tracks for sizing and the two meanings of MOT_E_CAPACITY). */
 int mot_track_step(mot_ctx* ctx, int slot, const float* boxes_global, int m, double timestamp,
                    mot_track* tracks, int max_tracks, int* n_tracks);
 /* filter state of track `id` (reference index) on `slot` (parity/debug); MOT_E_STATE once the track has been dead for more than a step */
@@ -262,7 +263,8 @@ int mot_frames_dev(mot_ctx* ctx, const float* d_xyzw, long frame_stride, const i
  * precedent never touches groundCloud after groundRemove (OT0/src/main.cpp:63-79), and the ground cloud is a quarter of the
  * compaction kernel's HBM traffic. Nothing is lost with the default: mot_get_ground materialises the ground cloud / mask of
  * the LAST batch on demand (it re-runs the compaction from the batch's input, polar cells and thresholds, all still resident —
- * so with mot_frames_dev the caller's input buffer must be unchanged until then). Likewise the per-point cluster labels
+ * so with mot_frames_dev the caller's input buffer must be unchanged until then; a stage-wise mot_cluster / mot_box_fit /
+ * mot_cluster_products_host in between takes slot 0 for itself and ends that possibility: MOT_E_STATE). Likewise the per-point cluster labels
  * (getClusteredPoints, OT/src/cluster/box_fitting.cpp:46-72: the box stage itself works on a cluster-sorted index and never reads
  * them back): mot_get_clusters(point_label) computes them for the slot it is asked about, from the cells and the label grid still
  * resident. Sticky per context. The stage-wise mot_ground_remove / mot_cluster always deliver all their outputs
@@ -298,9 +300,15 @@ int mot_get_ground(mot_ctx* ctx, int slot, float* elevated_xyzw, int* n_elevated
 int mot_get_clusters(mot_ctx* ctx, int slot, int32_t* grid, int* num_cluster, int32_t* point_label, int label_capacity);
 int mot_get_boxes(mot_ctx* ctx, int slot, float* boxes, int max_boxes, int* n_boxes, int32_t* box_cluster,
                   int* n_undefined);
-/* MOT_E_CAPACITY with the records still delivered when births were dropped on this stream (no free track slot, or
- * max_tracks_ever tracks created): the condition is STICKY until mot_reset / mot_reset_slot / mot_reset_tracks_slot.
- * n_tracks = tracks ever created (the reference's vector length); MOT_E_CAPACITY without records when that exceeds max_tracks. */
+/* One record per track EVER created on the stream, in the reference's index order (its output vectors are sized that way,
+ * OT/tracking/imm_ukf_jpda.cpp:995-1041): n_tracks grows with the stream's age, up to mot_params.max_tracks_ever (default
+ * 64 x max_tracks_total). SIZE THE BUFFER FOR THAT: max_tracks >= max_tracks_ever never overflows; a long-running consumer either
+ * creates the context with max_tracks_ever = its buffer size (ros/src/mot_ros_common.hpp does) or re-fetches with a larger buffer when
+ * n_tracks > max_tracks (MOT_E_CAPACITY, nothing copied, n_tracks delivered — the step itself has run). The call costs a D2H copy
+ * of 28 B x n_tracks + the live slots: consumers that only need the LIVE tracks every frame read mot_fetch_tracks_async /
+ * mot_export_tracks[_packed]_dev instead, whose cost does not grow with the stream's age.
+ * MOT_E_CAPACITY WITH the records delivered (n_tracks <= max_tracks) when births were dropped on this stream (no free track slot, or
+ * max_tracks_ever tracks created): STICKY until mot_reset / mot_reset_slot / mot_reset_tracks_slot. */
 int mot_get_tracks(mot_ctx* ctx, int slot, mot_track* tracks, int max_tracks, int* n_tracks);
 
 /* immUkfJpdaf for one frame of every slot 0..batch-1 with the boxes already on the DEVICE (global frame):

@@ -20,15 +20,20 @@ inline void check(mot_ctx* ctx, int rc, const char* what) {
 }
 
 // mot_track_step for a long-running node. The reference never frees a track (targets_ only grows, imm_ukf_jpda.cpp:972-989) and
-// only gets slower; the library holds at most ~max_tracks_total of them per stream and then reports MOT_E_CAPACITY on every step
-// (the records are still delivered). A node must not die of that (the launch file marks it required="true"): warn, publish what
-// came back, and start the stream's TRACKS over — mot_reset_tracks_slot keeps the stream's dead-reckoned ego pose, so the /global
-// frame and every published position stay continuous; the tracks re-form within lifeTimeThres_ frames.
+// only gets slower; the library reports one record per track EVER created on the stream (n_tracks keeps growing like the
+// reference's vectors) and holds at most max_tracks_ever of them — create() below sets that budget to the size of the node's
+// record buffer (~max_tracks_total), so n_tracks can never outgrow the buffer: when the budget is used up births are dropped and
+// every step answers MOT_E_CAPACITY (the records are still delivered). A node must not die of that (the launch file marks it
+// required="true"): warn, publish what came back, and start the stream's TRACKS over — mot_reset_tracks_slot keeps the stream's
+// dead-reckoned ego pose, so the /global frame and every published position stay continuous; the tracks re-form within
+// lifeTimeThres_ frames. Should n_tracks exceed the buffer all the same (a context created with another budget), nothing was
+// delivered: publish no track for this frame (*n_tracks = 0) and restart likewise — never throw after the step has run.
 inline void track_step_or_restart(mot_ctx* ctx, int slot, const float* boxes_global, int n_boxes, double timestamp, mot_track* tracks,
                                   int max_tracks, int* n_tracks) {
   const int rc = mot_track_step(ctx, slot, boxes_global, n_boxes, timestamp, tracks, max_tracks, n_tracks);
-  if (rc == MOT_E_CAPACITY && *n_tracks <= max_tracks) {
+  if (rc == MOT_E_CAPACITY) {
     ROS_WARN("tracker: %s — restarting the tracker of this stream (raise ~max_tracks_total to postpone this)", mot_last_error(ctx));
+    if (*n_tracks > max_tracks) *n_tracks = 0;
     check(ctx, mot_reset_tracks_slot(ctx, slot), "mot_reset_tracks_slot");
     return;
   }
@@ -53,6 +58,7 @@ inline mot_ctx* create(const mot_params& p_in, const Settings& s) {
   mot_ctx* ctx = nullptr;
   mot_params p = p_in;
   p.rng_mapping = s.rng_mapping;
+  p.max_tracks_ever = s.max_tracks_total;   // = the nodes' record buffers (tracks_): see track_step_or_restart
   if (mot_create(&p, s.device, s.max_points, 1, s.max_tracks_total, &ctx) != MOT_OK)
     throw std::runtime_error("mot_create failed: no MI355X / HIP device? (this library has no CPU path)");
   return ctx;

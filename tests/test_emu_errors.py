@@ -67,3 +67,30 @@ def test_calls_report_capacity_and_argument_errors(mot, emu, synth):
         c.reset()
         small = synth.make_cloud(1500, 1, 0)
         assert len(c.ground_remove(small)["mask"]) == 1500
+
+
+def test_track_records_never_outgrow_a_buffer_of_max_tracks_ever(mot, emu):
+    """the contract a long-running consumer (ros/src/mot_ros_common.hpp) relies on: with mot_params.max_tracks_ever = the size of its
+    record buffer, n_tracks never exceeds the buffer however many tracks the world would create — births beyond the budget are dropped,
+    MOT_E_CAPACITY (sticky) comes WITH the records, and mot_reset_tracks_slot clears it"""
+    import tracker_cases as TC
+    lib, L = emu
+    cap = 10
+    with mot.Context(mot.params(0, lib=L, max_tracks_ever=cap), lib_path=lib, max_points=1024, max_tracks_total=cap) as c:
+        arr = (mot.MotTrack * cap)(); nt = C.c_int(0)
+        rcs, restarted = [], 0
+        for f, (boxes, ts, v, yaw) in enumerate(TC.blinking_world(5, 9, 200)):
+            c.ego_update(ts, v, yaw)
+            b = np.ascontiguousarray(boxes, np.float32)
+            rc = L.mot_track_step(c._h, 0, b.ctypes.data_as(C.c_void_p), len(b), C.c_double(ts), arr, cap, C.byref(nt))
+            assert rc in (mot.MOT_OK, mot.MOT_E_CAPACITY), (f, rc, L.mot_last_error(c._h))
+            assert 0 <= nt.value <= cap, (f, nt.value)                       # the records were delivered
+            if nt.value:
+                assert [arr[i].id for i in range(nt.value)] == list(range(nt.value))
+            rcs.append(rc)
+            if rc == mot.MOT_E_CAPACITY:
+                if restarted == 0:   # sticky until the tracks are started over
+                    assert L.mot_get_tracks(c._h, 0, arr, cap, C.byref(nt)) == mot.MOT_E_CAPACITY and nt.value <= cap
+                assert L.mot_reset_tracks_slot(c._h, 0) == mot.MOT_OK
+                restarted += 1
+        assert restarted >= 2 and rcs[0] == mot.MOT_OK

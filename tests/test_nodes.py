@@ -152,3 +152,27 @@ def test_tracking_node_on_random_sequences(emu_lib, ref_nodes, tmp_path):
         a = U.run(ref_nodes["tracking"], recs, tmp_path, f"ref{seed}"); b = U.run(own["tracking"], recs, tmp_path, f"own{seed}")
         assert len(a) >= 4 * 14
         U.markers_close(a, b)
+
+
+def test_tracking_node_outlives_its_track_budget(emu_lib, tmp_path):
+    """a long run on a tiny ~max_tracks_total (the advisor's round-3 finding: once a stream had CREATED more tracks than the node's
+    record buffer holds, mot_track_step answered MOT_E_CAPACITY without records and the required="true" node threw): far more tracks are
+    created than the buffer holds — the node must warn, restart the stream's tracks and keep publishing its four markers per frame"""
+    import roslog as R
+    import tracker_cases as TC
+    own = NB.own_nodes(emu_lib)
+    recs, frames = [], 260
+    for f, (boxes, ts, v, yaw) in enumerate(TC.blinking_world(5, 9, frames)):
+        t = U.T0 + 0.1 * f
+        m = dict(header=dict(seq=f, stamp=R.stamp(t), frame_id="velodyne"), box_num=len(boxes) & 255)
+        for k, name in enumerate(("x1", "x2", "x3", "x4", "y1", "y2", "y3", "y4")):
+            m[name] = boxes[:, k, :].reshape(-1).astype(np.float32)
+        odom = dict(header=dict(seq=f, stamp=R.stamp(t), frame_id="gps"), child_frame_id="base_link",
+                    pose=dict(pose=dict(orientation=dict(x=0.0, y=0.0, z=float(yaw), w=1.0))), twist=dict(twist=dict(linear=dict(x=float(v), y=0.0, z=0.0))))
+        recs += [("__now__", t + 0.01), ("/gps/odom", "nav_msgs/Odometry", odom), ("track_box", "object_tracking/trackbox", m)]
+    i, o = str(tmp_path / "in.log"), str(tmp_path / "out.log")
+    R.write_log(i, recs)
+    r = NB.run_node(own["tracking"], i, o, {"max_tracks_total": 12})      # raises when the node exits non-zero
+    out = R.read_log(o)
+    assert "restarting the tracker of this stream" in (r.stderr + r.stdout)   # the budget WAS used up
+    assert len([1 for t, _, _ in out if t == "visualization_marker"]) >= 4 * frames

@@ -59,5 +59,20 @@ for ci, cx in enumerate(ctxs):
         assert np.array_equal(recs[b]["id"], live) and np.array_equal(recs[b]["p"], t["p"][live]) and np.array_equal(recs[b]["v_yaw"], t["v_yaw"][live])
         assert np.array_equal(recs[b]["vis_box"], t["vis_box"][live])
 assert sum(int(c.sum()) for c, _, _ in packed) > 0
+# ---- the same WITHOUT the forced collective (world 1: the block is copied on the side stream, ordered after the exports by events
+# only — the advisor's round-3 finding: that copy ran on torch's current stream, unordered with the contexts' streams)
+for cx in ctxs: cx.reset()
+tgb = multi.TrackGatherAll(ctxs, B, B * 64, 1, "cuda")
+for f in range(6):
+    ts = np.full(B, 1.0e9 + f * 1e5)
+    for ci, cx in enumerate(ctxs):
+        cx.frames_dev(frames[f].data_ptr() + ci * B * stride * 16, stride * 4, [N] * B, run_tracker=True, timestamps=ts, ego_v=np.zeros(B), ego_yaw=np.zeros(B))
+    tgb.step()                        # no host synchronisation inside the loop
+plain = tgb.blocks_as_numpy()[0]
+for ci, cx in enumerate(ctxs):
+    counts, recs, trunc = plain[ci]
+    assert not trunc and np.array_equal(counts, packed[ci][0])
+    for b in range(B):
+        assert np.array_equal(recs[b], packed[ci][1][b]), (ci, b, "one-rank copy path differs from the collective's block")
 print("gather check ok: live tracks per slot", [int(x) for x in tgs[0].dst_cnt[0].cpu()])
 dist.destroy_process_group()
