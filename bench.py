@@ -134,6 +134,7 @@ def cpu_baseline(frames: np.ndarray, ego_v, ego_yaw, n_points: int, budget_s: fl
     import hashlib
     import oracle_lib as O
     import seq_parity as SP
+    import mar_check as MC
     try:
         use_ref = O.ref() is not None
     except Exception:
@@ -145,6 +146,7 @@ def cpu_baseline(frames: np.ndarray, ego_v, ego_yaw, n_points: int, budget_s: fl
     def run_single(max_frames, budget, keep=None):
         trk = O.RefTracker() if use_ref else O.Tracker(p)
         trk.reset()
+        nf = SP.NoiseFloor(O, p, primary_is_ref=use_ref) if keep is not None else None   # the reference's own arithmetic noise, per track-frame (outside the timed intervals)
         st = {"ground": [], "cluster": [], "box": [], "tracker": []}
         t_all = time.perf_counter(); k = 0; busy = 0.0
         for f in range(min(max_frames, nF)):
@@ -167,13 +169,31 @@ def cpu_baseline(frames: np.ndarray, ego_v, ego_yaw, n_points: int, budget_s: fl
             k += 1
             if keep is not None:   # (outside the timed intervals)
                 live = np.nonzero(tr["track_manage"] > 0)[0]
+                states = {int(i): trk.state(int(i)) for i in live}
+                nf.step(gb, ts, float(ego_v[f]), float(ego_yaw[f]), tr, f)
+                rg = O.ground_remove(p, c)   # the restatement: the mask (the reference's API has none), and the rectangle-branch clusters for the cross-check below
+                mar = {"n": 0, "worst": 0.0, "failed": 0}
+                try:
+                    rcl = O.cluster(p, rg["elevated"])
+                    with O.observe_mar() as seen:
+                        O.box_fit(p, rg["elevated"], rcl["grid"], rcl["num_cluster"])
+                    for pix, _rect in seen:
+                        try:
+                            mar["worst"] = max(mar["worst"], MC.check(O, pix, where=f)[0])
+                        except AssertionError:
+                            mar["failed"] += 1
+                    mar["n"] = len(seen)
+                except Exception:
+                    mar["failed"] += 1
                 keep.append(dict(elevated=dig(g["elevated"]), ground=dig(g["ground"]), n_elevated=len(g["elevated"]), n_ground=len(g["ground"]), grid=dig(cl["grid"]),
-                                 num_cluster=cl["num_cluster"], boxes=bx, boxes_global=gb, tracks=tr, states={int(i): trk.state(int(i)) for i in live},
-                                 mask=O.ground_remove(p, c)["mask"]))
+                                 num_cluster=cl["num_cluster"], boxes=bx, boxes_global=gb, tracks=tr, states=states,
+                                 floors={i: nf.floor(i, so) for i, so in states.items()}, replicas=nf.names(), mar=mar, mask=rg["mask"]))
             if time.perf_counter() - t_all > budget:
                 break
         if hasattr(trk, "close"):
             trk.close()
+        if nf is not None:
+            run_single.replicas_retired = dict(nf.retired); nf.close()
         return k, busy, st
 
     run_single(2, 5.0)  # warm-up
@@ -199,18 +219,35 @@ def cpu_baseline(frames: np.ndarray, ego_v, ego_yaw, n_points: int, budget_s: fl
                 bad("boxes_bit_exact")
             if not SP.bits_equal(r["boxes_global"], gres["boxes_global"]):
                 bad("global_boxes_bit_exact")
-            try:
-                SP.compare_tracks(gres["tracks"], r["tracks"], lambda i: gres["states"][i], lambda i: r["states"][i], f, rtol=float("inf"), stats=stats)   # discrete outputs asserted; the state errors are collected
+            try:   # discrete outputs asserted; the state errors are collected and held against the reference's own noise floor on the same track-frame
+                SP.compare_tracks(gres["tracks"], r["tracks"], lambda i: gres["states"][i], lambda i: r["states"][i], f, rtol=float("inf"), stats=stats,
+                                  criterion="narrow", floor=(lambda i, so, fl=r["floors"]: fl.get(i)) if r["replicas"] else None)
             except (AssertionError, KeyError) as e:
                 bad("track_sets_equal"); first_bad.setdefault("track_detail", str(e)[:200])
         parity.update(flags)
         parity["masks_boxes_bit_exact"] = all(flags[k_] for k_ in ("clouds_bit_exact", "masks_equal_restatement", "label_grids_bit_exact", "boxes_bit_exact", "global_boxes_bit_exact"))
-        parity["states_within_1e-4"] = stats.get("max_rel_state_err") is not None and stats["max_rel_state_err"] <= 1e-4
-        parity.update({"max_rel_state_err": stats.get("max_rel_state_err"), "ill_conditioned_track_frames": stats.get("ill_conditioned", 0),
-                       "track_frames_above_1e-4": stats.get("above_bar", 0), "track_frames_above_1e-4_well_conditioned": stats.get("above_bar_well_conditioned", 0),
-                       "max_rel_state_err_ill_conditioned": stats.get("max_rel_state_err_ill_conditioned"),
-                       "ill_conditioned_means": "a track whose filter is diverging (|yaw rate| >= 20 rad/s, a covariance entry >= 1e3, a yaw / yaw-rate variance > 9, a covariance that is not positive definite, NaN — or was so within the last 30 frames: tests/seq_parity.py) "
-                                                "amplifies last-bit differences of equivalent operation orders by decades per frame until the reference's own guards kill it; its discrete outputs are compared like everybody's",
+        fsum = SP.floor_summary(stats)
+        n_live = max(stats.get("state_compares", 0), 1)
+        # true only if EVERY live track-frame is within 1e-4 — or is set aside by the narrow criterion AND within 10 x the reference's own noise there
+        parity["states_within_1e-4"] = (stats.get("max_rel_state_err") is not None and stats["max_rel_state_err"] <= 1e-4 and stats.get("above_bar_well_conditioned", 0) == 0
+                                        and (stats.get("above_bar", 0) == 0 or (fsum["track_frames_with_floor"] > 0 and fsum["above_1e-4_unexplained"] == 0)))
+        parity.update({"max_rel_state_err": stats.get("max_rel_state_err"), "track_frames_above_1e-4": stats.get("above_bar", 0),
+                       "track_frames_above_1e-4_unexplained": fsum["above_1e-4_unexplained"] if fsum["track_frames_with_floor"] or not stats.get("above_bar", 0) else None,
+                       "track_frames_above_1e-4_not_set_aside": stats.get("above_bar_well_conditioned", 0),
+                       "set_aside_track_frames": stats.get("ill_conditioned", 0), "set_aside_fraction": round(stats.get("ill_conditioned", 0) / n_live, 4),
+                       "set_aside_by": stats.get("set_aside_by", {}), "max_rel_state_err_set_aside": stats.get("max_rel_state_err_ill_conditioned"),
+                       "noise_floor_ill_conditioned": fsum["noise_floor"], "device_err_over_noise_floor_set_aside": fsum["device_err_over_floor"],
+                       "set_aside_above_10x_floor": fsum["set_aside_above_10x_floor"], "unexplained_detail": fsum["unexplained_detail"] or None,
+                       "noise_floor_replicas": {"in_use_last_frame": kept[-1]["replicas"] if kept else [], "retired_at_frame": getattr(run_single, "replicas_retired", {})},
+                       "set_aside_means": "NARROW criterion (tests/seq_parity.py conditioning): NaN / Inf, |yaw rate| >= 20 rad/s, a covariance entry >= 1e3, a non-positive variance — a filter the reference's own guards "
+                                          "(P(4,4) > 1000, det P > 10: imm_ukf_jpda.cpp:826-851) are about to kill. No conditioning memory, no yaw-variance rule (round 3's wider criterion). A set-aside track-frame is not "
+                                          "exempt: its error is held against noise_floor = the largest difference, on that very track-frame, between the reference build and replicas of the reference that differ in the "
+                                          "order of fp64 additions only (the C restatement; the reference's sources rebuilt with -DEIGEN_DONT_VECTORIZE); 'unexplained' = above 1e-4 AND above 10 x that floor. "
+                                          "Discrete outputs are compared on every track-frame",
+                       "min_area_rect_cross_check": {"clusters": int(sum(r["mar"]["n"] for r in kept)), "failed": int(sum(r["mar"]["failed"] for r in kept)),
+                                                     "worst_area_err_in_float32_units": round(max([r["mar"]["worst"] for r in kept] + [0.0]), 3),
+                                                     "what": "every cluster of these frames that takes the cv::minAreaRect branch: the restated rectangle against the exhaustive integer oracle "
+                                                             "(oracle/mot_oracle_mar_brute.c; tests/mar_check.py: area, hull-edge alignment, containment, OpenCV 3.2 angle / corner conventions)"},
                        "state_compares": stats.get("state_compares", 0), "live_tracks_max": stats.get("live_max", 0),
                        "tracks_ever": stats.get("tracks_ever", 0), "boxes_total": int(sum(len(r["boxes"]) for r in kept)), "first_mismatch_frame": first_bad or None,
                        "bar": "clouds / label grids / boxes bit-exact; track set, trackManage, lifetime, static / vis flags exact; every state key <= 1e-4 relative"})
@@ -512,6 +549,12 @@ def main():
     ap.add_argument("--force-gather", action="store_true", help="run the per-frame RCCL all-gather of the track blocks even with one rank (exercises the N > 1 path on one GPU)")
     ap.add_argument("--shared-gpu-dryrun", action="store_true", help="every rank on device 0, collectives over gloo: drives the N > 1 code path of this script (spawn, stream "
                     "sharding, packed gather, max over ranks, the JSON line) on a 1-GPU box. Not a measurement; the line says so")
+    ap.add_argument("--outputs", choices=["headline", "all"], default="headline", help="all: the HEADLINE itself runs with every by-product of the reference written "
+                    "(mot_set_fused_outputs GROUND | MASK | LABELS); default: the headline writes what the next stage reads, and the all-outputs rate is measured in a second, "
+                    "shorter timed region of the same run and reported beside it as `all_outputs`")
+    ap.add_argument("--kitti-dir", default=os.environ.get("MOT_KITTI_DIR"), help="a KITTI raw drive directory (…/2011_09_26_drive_0005_sync: velodyne_points/data/*.bin, oxts/data/*.txt): "
+                    "the benched streams are that drive's own scans and ego motion (`data: kitti`), every stream of the GPU replaying the drive — the only real sequence the reference names "
+                    "(README.md:154; its ego fixtures OT0/src/imm_ukf_jpda.cpp:65-72). Default (no such data in this image): synthetic streams. Also read from $MOT_KITTI_DIR")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-aux", action="store_true", help="skip tracker_stress / host_boundary / per-kernel isolated timings")
     ap.add_argument("--selftest-cpu", action="store_true", help="launch-logic self-test on CPU (gloo + emulated kernels); not a measurement")
@@ -572,23 +615,48 @@ def main():
     Bc = B // NC
     # ---- the workload, rendered into HBM: Bc distinct streams (scenes) x F frames; every context replays these Bc streams
     t_r = time.perf_counter()
-    ego_v, ego_yaw = sdev.load_ego(F)
-    renderer = sdev.SequenceRenderer(f"cuda:{local}")
-    while True:
-        try:
-            seq_dev, n_seq, _objs, _path = renderer.render([1000 * rank + s for s in range(Bc)], F, N, stride, ego_v, ego_yaw, density=args.density)
-            break
-        except RuntimeError as e:   # the sequences do not fit this device's free HBM: halve the streams and say so
-            if "out of memory" not in str(e).lower() or Bc < 2:
-                raise
-            print(f"bench.py: {B} streams do not fit ({e}); retrying with {B // 2}", file=sys.stderr)
-            torch.cuda.empty_cache()
+    kitti = None
+    if args.kitti_dir:
+        # ---- real data: the drive's own scans (float32 x, y, z, reflectance = this library's layout) and oxts ego motion; every one of the Bc
+        # streams per context replays the drive (its own copy in HBM: Bc x F frames, as the synthetic layout, so the traffic is the same kind)
+        seqmod = _load("mot_amd.sequence", os.path.join(PKG_DIR, "sequence.py"))
+        scans = list(seqmod.kitti_frames(args.kitti_dir))
+        if not scans:
+            print(f"bench.py: no velodyne_points/data/*.bin under {args.kitti_dir}", file=sys.stderr); sys.exit(2)
+        F = min(F, len(scans)); scans = scans[:F]
+        N = int(np.mean([len(c) for c, _, _ in scans]))
+        stride = ((max(len(c) for c, _, _ in scans) + 2047) // 2048) * 2048
+        ego_v = np.array([v for _, v, _ in scans], np.float64); ego_yaw = np.array([y for _, _, y in scans], np.float64)
+        while Bc > 1 and Bc * F * stride * 16 > 0.8 * torch.cuda.mem_get_info(local)[0]:
             B //= 2; Bc = B // NC
+        seq_dev = torch.zeros((F, Bc, stride, 4), dtype=torch.float32, device=f"cuda:{local}")
+        for f, (c, _, _) in enumerate(scans):
+            seq_dev[f, :, : len(c)] = torch.from_numpy(np.ascontiguousarray(c, np.float32)).to(seq_dev.device)[None]
+        n_seq = np.repeat(np.array([len(c) for c, _, _ in scans], np.int32)[:, None], Bc, axis=1)
+        kitti = {"dir": os.path.basename(os.path.normpath(args.kitti_dir)), "frames": F, "points_mean": N, "points_max": int(n_seq.max())}
+        del scans
+    else:
+        ego_v, ego_yaw = sdev.load_ego(F)
+        renderer = sdev.SequenceRenderer(f"cuda:{local}")
+        while True:
+            try:
+                seq_dev, n_seq, _objs, _path = renderer.render([1000 * rank + s for s in range(Bc)], F, N, stride, ego_v, ego_yaw, density=args.density)
+                break
+            except RuntimeError as e:   # the sequences do not fit this device's free HBM: halve the streams and say so
+                if "out of memory" not in str(e).lower() or Bc < 2:
+                    raise
+                print(f"bench.py: {B} streams do not fit ({e}); retrying with {B // 2}", file=sys.stderr)
+                torch.cuda.empty_cache()
+                B //= 2; Bc = B // NC
     render_s = time.perf_counter() - t_r
     n_seq = np.ascontiguousarray(n_seq, np.int32)
     variant = os.environ.get("MOT_BENCH_LIB")   # experiments only (tools/ablate.py bench ...): a variant build of the library; the line then says so
     ctxs = [mot.Context(device=local, max_points=stride, max_batch=Bc, max_tracks_total=256, **({"lib_path": variant} if variant else {})) for _ in range(NC)]
     ctx = ctxs[0]
+    ALL_OUT = 7   # MOT_OUT_GROUND | MOT_OUT_MASK | MOT_OUT_LABELS (include/mot.h)
+    if args.outputs == "all":
+        for cx in ctxs:
+            cx.set_fused_outputs(ALL_OUT)
     # ONE collective per frame tick for all contexts of the rank, of packed blocks (multi.TrackGatherAll): counts header + the live
     # records back to back, capacity GATHER_RECORDS_PER_STREAM per stream on average (the header carries the true counts; a block that
     # overflows is flagged by the receiver's decode, never silently short)
@@ -696,8 +764,32 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
 
+    # ---- the same workload with EVERY output the reference produces written in the fused path: groundRemove's ground cloud
+    # (ground_removal.cpp:226-247; the `ground` node publishes it, groundremove/main.cpp:125-132), the per-point mask and the per-point
+    # cluster labels (getClusteredPoints, box_fitting.cpp:46-72). A second timed region of the same process, same streams, same phases.
+    all_out = None
+    prof = [cx.profile_read() for cx in ctxs] if rank == 0 else None   # the dominant kernel's event pairs of the timed region (read before anything else is launched)
+    host_timed = (host_issue[0], host_cpu[0])   # (run_frames overwrites them)
+    if rank == 0 and world == 1 and args.outputs == "headline" and not variant:
+        try:
+            k_all = max(2, min(4, args.steps))
+            for cx in ctxs:
+                cx.profile_kernel(0, 1); cx.set_fused_outputs(ALL_OUT)
+            run_frames(F)             # one untimed step with the new outputs (positions stay on whole steps + phase)
+            sync_all(); torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            run_steps(k_all)
+            sync_all(); torch.cuda.synchronize()
+            dt_all = time.perf_counter() - t1
+            all_out = {"steps": k_all, "dt": dt_all}
+            for cx in ctxs:
+                cx.set_fused_outputs(0)
+            run_frames(F); sync_all()   # back to the headline's state for the single-context passes below
+        except Exception as e:
+            print(f"all-outputs leg failed: {e}", file=sys.stderr)
+            all_out = None
+    host_issue[0], host_cpu[0] = host_timed
     if rank == 0:
-        prof = [cx.profile_read() for cx in ctxs]
         nsamp = sum(p["samples"] for p in prof)
         shared_ms = sum(p["mean_ms"] * p["samples"] for p in prof) / max(nsamp, 1)
         # ---- the dominant kernel with the GPU to itself: the same pipeline, same data, ONE context (in the timed region the NC
@@ -747,7 +839,7 @@ def main():
             "value": round(frames / dt, 1), "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(dt / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32/f64 (fp32 grid indices with fp64 intermediates, int32 grids/labels, fp64 tracker — the reference's types)",
-            "data": "synthetic; DRY RUN: every rank on ONE device, gloo collectives — not a measurement" if args.shared_gpu_dryrun else "synthetic" if not variant else f"synthetic; EXPERIMENT BUILD {variant} — not the product library", "inputs": "hbm-resident (rendered into HBM before the timed region; see host_boundary_pipelined for the PCIe-inclusive rate)",
+            "data": (("kitti" if kitti else "synthetic") + ("; DRY RUN: every rank on ONE device, gloo collectives — not a measurement" if args.shared_gpu_dryrun else "" if not variant else f"; EXPERIMENT BUILD {variant} — not the product library")), "inputs": "hbm-resident (rendered into HBM before the timed region; see host_boundary_pipelined for the PCIe-inclusive rate)",
             "timed_region_s": round(dt, 3), "host_issue_ms_per_step": round(host_issue[0] / args.steps * 1e3, 3),
             "host_cpu_ms_per_step": round(host_cpu[0] / args.steps * 1e3, 3) if not (args.issue_threads and NC > 1) else None,
             "host_unblocked_us_per_launch_sequence": round(host_unblocked_us, 1),
@@ -755,14 +847,15 @@ def main():
                          "that thread (time.thread_time) over the timed region; host_unblocked = one launch sequence issued right after a synchronise (nothing to wait for): the host's own cost",
             "issue_threads": (NC if args.issue_threads and NC > 1 else 1),
             "config": {"workload": f"configs[3]: ground removal -> CCL -> box fit -> batched IMM-UKF-PDA tracker on one MI355X per rank; one step = {F}-frame "
-                                   f"sequence (ego motion of KITTI drive_0005) of every stream, {N}-pt synthetic HDL-64E clouds, no frame repeated within a sequence"
+                                   (f"sequence (ego motion of KITTI drive_0005) of every stream, {N}-pt synthetic HDL-64E clouds, no frame repeated within a sequence" if not kitti else
+                                    f"drive {kitti['dir']} (its own velodyne scans, ~{N} pts, and oxts ego motion), every stream replaying the drive from its own copy in HBM")
                                    + ("" if world == 1 else f"; sharded as configs[4] (every stream pinned to one GPU, RCCL all-gather of the live-track blocks per frame) "
                                       f"with the SAME per-GPU work as the 1-GPU line (weak scaling); configs[4]'s 200 k-point frames: --points 200000"),
-                       "points_per_frame": N, "frames_per_stream_per_step": F, "streams_per_gpu": B, "streams": B * world, "distinct_scenes_per_gpu": Bc,
+                       "points_per_frame": N, "frames_per_stream_per_step": F, "streams_per_gpu": B, "streams": B * world, "distinct_scenes_per_gpu": 1 if kitti else Bc,
                        "frames_per_step_per_gpu": B * F, "contexts_per_gpu": NC, "frames_per_launch": BL, "context_phase_frames": args.phase,
                        "elevated_pts_per_frame": ne_tot // BL, "clusters_last_frame_stream0": cl0["num_cluster"], "boxes_last_frame_stream0": len(bx0["boxes"]),
                        "tracks_ever_stream0": int(tr0["n"]), "live_tracks_per_stream": {"mean": round(float(np.mean(live)), 1), "max": int(np.max(live)), "streams_sampled": len(live)},
-                       "render_s": round(render_s, 1), "scene_density": args.density,
+                       "render_s": round(render_s, 1), "scene_density": args.density, "kitti": kitti,
                        "parallelism": f"stream-sharded x{world}" + (", all_gather of live-track records per frame (RCCL)" if world > 1 else "")},
             "roofline": {"bound": "hbm", "kernel": dom_kernel, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_src,
@@ -777,6 +870,23 @@ def main():
                          "pipeline_bytes_per_frame": int(frame_bytes),
                          "pipeline_frac": round(frame_bytes * B * F / (dt / args.steps) / 1e9 / HBM_PEAK_GBS, 4)},
         }
+        if args.outputs == "all":
+            out["config"]["outputs"] = "all (ground cloud, mask, per-point labels written in the fused path)"
+        if all_out is not None:
+            # algorithmic bytes with every output written: SURVEY.md 8(d)'s own accounting — ground 16 N + 16 N + 16 (N_e + N_g), cluster 16 N_e + 16 N_e
+            # + 4 N_e + 0.5 MB of grid, box (16 + 4) N_e, 0.1 MB of polar grid = 48 N + 56 N_e + 0.6 MB — at this run's measured N, N_e
+            n_f, ne_f = n_tot / BL, ne_tot / BL
+            survey_bytes = 48.0 * n_f + 56.0 * ne_f + 0.6e6
+            own_bytes = frame_bytes + (16.0 * ng_tot + n_tot + 4.0 * ne_tot) / BL   # this implementation's own accounting + ground cloud, mask, labels
+            v_all = B * F * all_out["steps"] / all_out["dt"]
+            out["all_outputs"] = {"value": round(v_all, 1), "unit": "frames/s", "steps": all_out["steps"], "ms_per_step": round(all_out["dt"] / all_out["steps"] * 1e3, 4),
+                                  "vs_headline": round(v_all / (frames / dt), 4),
+                                  "pipeline_bytes_per_frame": int(survey_bytes), "pipeline_frac": round(survey_bytes * v_all / 1e9 / HBM_PEAK_GBS, 4),
+                                  "pipeline_bytes_per_frame_own_accounting": int(own_bytes), "pipeline_frac_own_accounting": round(own_bytes * v_all / 1e9 / HBM_PEAK_GBS, 4),
+                                  "what": "the same streams, contexts and phases in a second timed region of this run with mot_set_fused_outputs(GROUND | MASK | LABELS): every output the "
+                                          "reference's groundRemove / getClusteredPoints produce is written by the fused path (the headline writes what the next stage reads and "
+                                          "materialises the rest on demand). pipeline_bytes_per_frame = SURVEY.md 8(d): 48 N + 56 N_e + 0.6 MB at the measured N, N_e; "
+                                          "own accounting = the headline's algorithmic bytes (which charge one read of the elevated cloud where the survey charges three) + 16 N_g + N + 4 N_e"}
         if not args.no_aux and world == 1:
             try:   # per-kernel timing ISOLATED (one context, nothing else running) on the resident last frame
                 it = 10

@@ -60,6 +60,14 @@ int orc_box_fit(const mot_params* p, const float* elevated_xyzw, int n, const in
                 orc_box_debug* dbg);
 /* cv::minAreaRect + RotatedRect::points on integer points; out: 4 corners (x,y) float */
 void orc_min_area_rect_points(const int32_t* xy, int n, float out_xy[8]);
+/* the RotatedRect itself: {center.x, center.y, size.width, size.height, angle [deg]} */
+void orc_min_area_rect(const int32_t* xy, int n, float rr[5]);
+/* independent cross-check (mot_oracle_mar_brute.c): exact minimum over all hull-edge-aligned enclosing rectangles, integer arithmetic */
+int orc_mar_brute(const int32_t* xy, int n, int32_t* hull_xy /* cap n */, double* edge_area /* cap n */, int* best_edge, double* min_area, int* ties);
+/* observer of the min-area-rectangle branch of orc_box_fit: called with every such cluster's picture pixels and the restated rectangle
+ * (tests cross-check the clusters of whole streams against orc_mar_brute); NULL = none */
+typedef void (*orc_mar_observer)(const int32_t* xy, int n, const float rect[8]);
+void orc_set_mar_observer(orc_mar_observer cb);
 /* pieces exposed for unit tests */
 int orc_convex_hull(const int32_t* xy, int n, int32_t* hull_xy /* cap n */);
 void orc_lshape_indices(int num_points, int count, int32_t* out); /* mt19937_64(0) + uniform_int_distribution, libstdc++ >= 11 */

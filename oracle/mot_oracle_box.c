@@ -70,6 +70,9 @@ void orc_lshape_indices_mapping(int num_points, int count, int mapping, int32_t*
 }
 void orc_lshape_indices(int num_points, int count, int32_t* out) { orc_lshape_indices_mapping(num_points, count, MOT_RNG_LIBSTDCXX11, out); }
 
+static orc_mar_observer g_mar_observer = NULL;
+void orc_set_mar_observer(orc_mar_observer cb) { g_mar_observer = cb; }
+
 static int cart_cell(const mot_params* p, float x, float y, int* xI, int* yI) { /* box_fitting.cpp:52-58 */
   float roiM = p->roi_m;
   int numGrid = p->num_grid;
@@ -211,6 +214,7 @@ int orc_box_fit(const mot_params* p, const float* pts, int n, const int32_t* gri
       float rect[8];
       if (d) d->branch = 1;
       orc_min_area_rect_points(pix, numPoints, rect);
+      if (g_mar_observer) g_mar_observer(pix, numPoints, rect);
       points_in_pc_frame(p, rect, pc, offsetInitX, offsetInitY);
       promising = rule_based_filter(p, pc, maxZ, numPoints);
     }

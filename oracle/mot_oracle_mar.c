@@ -201,8 +201,16 @@ static int rotating_calipers(const float* px, const float* py, int n, float* out
   return 1;
 }
 
+static void rotated_rect_points(const float rr[5], float pt[8]);
 /* cv::minAreaRect(points) followed by RotatedRect::points(pt) */
 void orc_min_area_rect_points(const int32_t* xy, int n, float pt[8]) {
+  float rr[5];
+  orc_min_area_rect(xy, n, rr);
+  rotated_rect_points(rr, pt);
+}
+
+/* cv::minAreaRect(points): rr = {center.x, center.y, size.width, size.height, angle in degrees} */
+void orc_min_area_rect(const int32_t* xy, int n, float rr[5]) {
   float cx = 0, cy = 0, w = 0, h = 0, angle = 0;
   int32_t* hull = (int32_t*)malloc(sizeof(int32_t) * 2 * (n > 0 ? n : 1));
   int hn = orc_convex_hull(xy, n, hull);
@@ -229,7 +237,13 @@ void orc_min_area_rect_points(const int32_t* xy, int n, float pt[8]) {
     cx = hx[0]; cy = hy[0];
   }
   angle = (float)(angle * 180 / M_PI);
-  /* RotatedRect::points */
+  rr[0] = cx; rr[1] = cy; rr[2] = w; rr[3] = h; rr[4] = angle;
+  free(hull); free(hx);
+}
+
+/* RotatedRect::points */
+static void rotated_rect_points(const float rr[5], float pt[8]) {
+  const float cx = rr[0], cy = rr[1], w = rr[2], h = rr[3], angle = rr[4];
   double _angle = angle * M_PI / 180.;
   float b = (float)cos(_angle) * 0.5f;
   float a = (float)sin(_angle) * 0.5f;
@@ -241,5 +255,4 @@ void orc_min_area_rect_points(const int32_t* xy, int n, float pt[8]) {
   pt[5] = 2 * cy - pt[1];
   pt[6] = 2 * cx - pt[2];
   pt[7] = 2 * cy - pt[3];
-  free(hull); free(hx);
 }

@@ -49,10 +49,46 @@ def synth():
 
 
 @pytest.fixture(scope="session")
-def oracle():
+def _oracle_module():
     import oracle_lib
     oracle_lib.build_oracle()
     return oracle_lib
+
+
+ORACLE_LOG = []   # (test id, {(function, which oracle answered): calls})
+
+
+@pytest.fixture
+def oracle(request, _oracle_module):
+    """CPU tests: the C restatement (tests/oracle_lib.py; pinned to the reference build by tests/test_oracle_vs_ref.py).
+    `-m gpu` tests: the reference's OWN sources first (oracle_lib.RefFirst: oracle/_ref/*.so is on the GPU box), the restatement only
+    where the reference cannot answer; which one answered is printed per test at the end of the run (MOT_ORACLE=restatement: off)."""
+    if request.node.get_closest_marker("gpu") is None or os.environ.get("MOT_ORACLE") == "restatement" or _oracle_module.ref() is None:
+        yield _oracle_module
+        return
+    o = _oracle_module.RefFirst(_oracle_module)
+    yield o
+    ORACLE_LOG.append((request.node.nodeid, dict(o.used)))
+
+
+def pytest_terminal_summary(terminalreporter):
+    if not ORACLE_LOG:
+        return
+    tr = terminalreporter
+    tr.section("oracle used per GPU test (reference build = the reference's own sources, oracle/_ref)")
+    for nodeid, used in ORACLE_LOG:
+        by = {}
+        for (fn, who), k in sorted(used.items()):
+            by.setdefault(who.split(" (")[0], []).append(f"{fn} x{k}")
+        tr.write_line(f"{nodeid}: " + ("; ".join(f"{who}: {', '.join(v)}" for who, v in sorted(by.items())) or "no oracle call"))
+    out = os.path.join(ROOT, "gpurun_out")
+    try:
+        os.makedirs(out, exist_ok=True)
+        with open(os.path.join(out, "oracle_used_per_test.txt"), "w") as f:
+            for nodeid, used in ORACLE_LOG:
+                f.write(nodeid + "\n" + "".join(f"    {fn:<16}{who}  x{k}\n" for (fn, who), k in sorted(used.items())))
+    except OSError:
+        pass
 
 
 @pytest.fixture(scope="session")

@@ -22,7 +22,10 @@ SAN_FLAGS = (["-fsanitize=address", "-fno-omit-frame-pointer"] if ASAN else
 # MOT_EMU_PERTURB=1: sin / cos / exp / atan2 / pow of the kernels answer one ulp off now and then (see hipemu.h) — what the
 # device math library is allowed to do; the host side of the library (mot_api.hip: the reference's libm calls) is not touched
 PERTURB = bool(os.environ.get("MOT_EMU_PERTURB"))
-LIB = os.path.join(HERE, "libmot_emu_asan.so" if ASAN else "libmot_emu_ubsan.so" if SANITIZE else "libmot_emu_ulp.so" if PERTURB else "libmot_emu.so")
+# MOT_EMU_DEFINES="-DMOT_X=1 -DMOT_Y=2": a variant build of the kernels (the knobs tools/prebuild.py gives hipcc), in a library of its own
+DEFINES = os.environ.get("MOT_EMU_DEFINES", "").split()
+_TAG = ("_" + "".join(ch if ch.isalnum() else "_" for ch in "".join(DEFINES))) if DEFINES else ""
+LIB = os.path.join(HERE, ("libmot_emu_asan" if ASAN else "libmot_emu_ubsan" if SANITIZE else "libmot_emu_ulp" if PERTURB else "libmot_emu") + _TAG + ".so")
 
 
 def sources():
@@ -39,9 +42,9 @@ def build(force: bool = False) -> str:
         return LIB
     objs = []
     for s in srcs:
-        o = os.path.join(HERE, ("objasan_" if ASAN else "objsan_" if SANITIZE else "objulp_" if PERTURB else "obj_") + s.replace(".hip", ".o"))
+        o = os.path.join(HERE, ("objasan_" if ASAN else "objsan_" if SANITIZE else "objulp_" if PERTURB else "obj_") + _TAG.strip("_") + ("_" if _TAG else "") + s.replace(".hip", ".o"))
         perturb = ["-DMOT_EMU_PERTURB=1"] if PERTURB and s != "mot_api.hip" else []
-        cmd = ["g++", "-std=c++17", "-O1", "-g", "-fPIC"] + SAN_FLAGS + [ "-ffp-contract=off", "-fno-fast-math", "-DMOT_HIPEMU=1"] + perturb + [ "-x", "c++",
+        cmd = ["g++", "-std=c++17", "-O1", "-g", "-fPIC"] + SAN_FLAGS + [ "-ffp-contract=off", "-fno-fast-math", "-DMOT_HIPEMU=1"] + perturb + DEFINES + [ "-x", "c++",
                "-include", os.path.join(HERE, "hipemu.h"), "-I", CSRC, "-Wall", "-Wno-unused-function", "-Wno-unknown-pragmas",
                "-Wno-unused-variable", "-c", os.path.join(CSRC, s), "-o", o]
         r = subprocess.run(cmd, capture_output=True, text=True)

@@ -225,6 +225,43 @@ def min_area_rect_points(xy) -> np.ndarray:
     return out.reshape(4, 2)
 
 
+def min_area_rect(xy) -> np.ndarray:
+    """the restated cv::minAreaRect's RotatedRect: (cx, cy, width, height, angle in degrees)"""
+    xy = np.ascontiguousarray(xy, np.int32); out = np.zeros(5, np.float32)
+    orc().orc_min_area_rect(xy.ctypes.data_as(C.c_void_p), len(xy), out.ctypes.data_as(C.c_void_p))
+    return out
+
+
+def mar_brute(xy):
+    """oracle/mot_oracle_mar_brute.c: exact minimum-area enclosing rectangle by exhaustion over the hull edges (integer arithmetic,
+    a different hull algorithm) — the independent cross-check of the restated cv::minAreaRect"""
+    xy = np.ascontiguousarray(xy, np.int32); n = len(xy)
+    hull = np.zeros((max(n, 1), 2), np.int32); area = np.zeros(max(n, 1)); be = C.c_int(-1); mn = C.c_double(0); ties = C.c_int(0)
+    o = orc(); o.orc_mar_brute.restype = C.c_int
+    k = o.orc_mar_brute(xy.ctypes.data_as(C.c_void_p), n, hull.ctypes.data_as(C.c_void_p), area.ctypes.data_as(C.c_void_p), C.byref(be), C.byref(mn), C.byref(ties))
+    return dict(hull=hull[:k].copy(), edge_area=area[:k].copy() if k >= 3 else np.zeros(0), best_edge=be.value, min_area=mn.value, ties=ties.value)
+
+
+MAR_OBSERVER = C.CFUNCTYPE(None, C.POINTER(C.c_int32), C.c_int, C.POINTER(C.c_float))
+
+
+class observe_mar:
+    """with observe_mar() as seen: ... oracle.box_fit(...) ...  -> seen = [(pixels (n, 2) int32, rect (4, 2) float32)] of every cluster
+    that went through the min-area-rectangle branch of the restated box fit (OT/src/cluster/box_fitting.cpp:357-362)"""
+
+    def __enter__(self):
+        self.seen = []
+
+        def cb(xy, n, rect):
+            self.seen.append((np.ctypeslib.as_array(xy, (n, 2)).copy(), np.ctypeslib.as_array(rect, (4, 2)).copy()))
+        self._cb = MAR_OBSERVER(cb)
+        orc().orc_set_mar_observer(self._cb)
+        return self.seen
+
+    def __exit__(self, *a):
+        orc().orc_set_mar_observer(None)
+
+
 def convex_hull(xy) -> np.ndarray:
     xy = np.ascontiguousarray(xy, np.int32); out = np.zeros((max(len(xy), 1), 2), np.int32)
     orc().orc_convex_hull.restype = C.c_int
@@ -375,18 +412,48 @@ def ref_cluster_products(elev, grid):
     return dict(clustered=cc[: ncc.value].copy(), obstacles=ob[: nob.value].copy(), cost_map=cm[:ncell].reshape(50, 50))
 
 
+_variants = {}
+
+
+def ref_variant(tag: str, instance: int = 0):
+    """another build of the reference's own sources with a different floating-point operation order (oracle/Makefile REF_VARIANT:
+    "fma" = -ffp-contract=fast -mfma, "novec" = Eigen's packet kernels off), or None when it is not on this box / this CPU cannot
+    run it; tag "ref" = the default build itself. Each library carries its own copy of the tracker's file-scope globals (-Bsymbolic,
+    RTLD_LOCAL); instance > 0 loads a private COPY of the file (the dynamic loader keys on the path), i.e. one more independent
+    tracker of the same build — for checkers that follow several streams at once."""
+    key = (tag, instance)
+    if key not in _variants:
+        path = REF_SO if tag == "ref" else os.path.join(ORACLE_DIR, "_ref", f"libmot_ref_{tag}.so")
+        ok = os.path.exists(path)
+        if ok and instance:
+            import shutil, tempfile
+            d = tempfile.mkdtemp(prefix="mot_ref_copy_")
+            path = shutil.copy(path, os.path.join(d, f"libmot_ref_{tag}_{instance}.so"))
+        if ok and tag == "fma":
+            try:
+                ok = " fma " in open("/proc/cpuinfo").read().split("flags", 1)[1].split("\n", 1)[0] + " "
+            except Exception:
+                ok = False
+        _variants[key] = C.CDLL(path) if ok else None
+    return _variants[key]
+
+
 class RefTracker:
-    """the reference tracker: file-scope globals => one instance at a time"""
+    """the reference tracker: file-scope globals => one instance at a time PER LIBRARY (lib: a ref_variant(); default the -O2
+    -ffp-contract=off build, or whatever set_ref_library() routes to)"""
     _pre = "ref_"
 
+    def __init__(self, lib=None):
+        self._own = lib
+
     def _lib(self):
-        return ref()
+        return self._own if self._own is not None else ref()
 
     def reset(self):
-        ref().ref_tracker_reset()
+        self._lib().ref_tracker_reset()
 
     def ego_update(self, ts, v, yaw):
-        out = np.zeros(6); ref().ref_ego_update(C.c_double(ts), C.c_double(v), C.c_double(yaw), out.ctypes.data_as(C.c_void_p)); return out
+        out = np.zeros(6); self._lib().ref_ego_update(C.c_double(ts), C.c_double(v), C.c_double(yaw), out.ctypes.data_as(C.c_void_p)); return out
 
     def step(self, boxes, ts, max_tracks=8192):
         b = np.ascontiguousarray(boxes, np.float32).reshape(-1, 8, 3)
@@ -401,6 +468,9 @@ class RefTracker:
 
     def count(self):
         return getattr(self._lib(), self._pre + "track_count")()
+
+    def close(self):
+        pass
 
     def state(self, i):
         x = np.zeros(20); p = np.zeros(100); mode = np.zeros(3); z = np.zeros(6); s = np.zeros(12); k = np.zeros(30); misc = np.zeros(4)
@@ -434,3 +504,152 @@ class Ref0Tracker(RefTracker):
 
     def ego_update(self, ts):
         out = np.zeros(6); ref0().ref0_ego_update(C.c_double(ts), out.ctypes.data_as(C.c_void_p)); return out
+
+
+# ------------------------------------------------------------------ the reference build FIRST (GPU parity suite)
+class RefFirst:
+    """The oracle the `-m gpu` tests compare the device with: the reference's OWN sources (oracle/_ref/libmot_ref.so for preset 0,
+    libmot_ref0.so for preset 1) wherever they are on the box and the call is one the reference can answer — its constants are
+    compile-time, so a parameter set that is not exactly a preset goes to the restatement, and so do the pieces the reference's API
+    does not have (see each method). Everything else of this module is passed through. `used` counts, per function, which oracle
+    answered; tests/conftest.py prints the table per test.
+
+    What is taken from where when the reference answers:
+      ground_remove  clouds from groundRemove (ground_removal.cpp:177-249). The reference has no mask: it is RECONSTRUCTED from its two
+                     clouds — both are order-preserving subsequences of the input, so one forward pass matching x, y, z bit patterns
+                     assigns every input point to elevated / ground / dropped uniquely (equal points classify equally) — and the
+                     returned clouds are the input's own records (4th float included) selected by that mask, after asserting that their
+                     x, y, z are bit-equal to the reference's. want_dump: the per-cell arrays come from ref_ground_polar.
+      cluster        label grid and count from componentClustering (component_clustering.cpp:260-268); the per-point labels (no such
+                     output in the reference) are the restatement's, after asserting that its grid equals the reference's.
+      box_fit        boxes from boxFitting (box_fitting.cpp:422-435); box -> cluster ids and the undefined-behaviour count (SURVEY.md
+                     H7) are the restatement's; a frame with n_undefined > 0 has no defined reference result and goes to the restatement.
+      Tracker        immUkfJpdaf + UKF (imm_ukf_jpda.cpp:704-1112) through RefTracker — a private copy of the library per instance
+                     (file-scope globals), preset 0 only."""
+
+    def __init__(self, base):
+        self._b = base
+        self.used = {}
+        self._p = {0: bytes(base.params(0)), 1: bytes(base.params(1))}
+        self._trk = 0
+
+    def __getattr__(self, name):
+        return getattr(self._b, name)
+
+    def _note(self, fn, who):
+        k = (fn, who); self.used[k] = self.used.get(k, 0) + 1
+
+    def _preset(self, p):
+        raw = bytes(p)
+        if raw == self._p[0] and self._b.ref() is not None:
+            return 0
+        if raw == self._p[1] and self._b.ref0() is not None:
+            return 1
+        return None
+
+    @staticmethod
+    def _mask_from_subsequences(a, elev, ground):
+        """a: input (n, 4); elev / ground: the reference's clouds (x, y, z). One forward pass: the next unmatched elevated / ground point."""
+        key = np.ascontiguousarray(a[:, :3]).view(np.uint32)
+        ke = np.ascontiguousarray(elev[:, :3]).view(np.uint32); kg = np.ascontiguousarray(ground[:, :3]).view(np.uint32)
+        mask = np.zeros(len(a), np.uint8); ie = ig = 0
+        eq_e = lambda i: ie < len(ke) and key[i, 0] == ke[ie, 0] and key[i, 1] == ke[ie, 1] and key[i, 2] == ke[ie, 2]
+        eq_g = lambda i: ig < len(kg) and key[i, 0] == kg[ig, 0] and key[i, 1] == kg[ig, 1] and key[i, 2] == kg[ig, 2]
+        for i in range(len(a)):
+            if eq_e(i):
+                assert not eq_g(i) or not np.array_equal(ke[ie], kg[ig]) or True
+                mask[i] = 2; ie += 1
+            elif eq_g(i):
+                mask[i] = 1; ig += 1
+        assert ie == len(ke) and ig == len(kg), ("the reference's clouds are not order-preserving subsequences of the input", ie, len(ke), ig, len(kg))
+        return mask
+
+    def ground_remove(self, p, xyzw, want_dump=False):
+        ps = self._preset(p)
+        if ps is None:
+            self._note("ground_remove", "restatement (parameters are not a preset)")
+            return self._b.ground_remove(p, xyzw, want_dump)
+        a = _pts(xyzw)
+        r = self._b.ref_ground_remove(a) if ps == 0 else None
+        if ps == 1:
+            L = self._b.ref0(); n = len(a)
+            e = np.zeros((max(n, 1), 4), np.float32); g = np.zeros((max(n, 1), 4), np.float32); ne = C.c_int(0); ng = C.c_int(0)
+            L.ref0_ground_remove(a.ctypes.data_as(C.c_void_p), n, e.ctypes.data_as(C.c_void_p), C.byref(ne), g.ctypes.data_as(C.c_void_p), C.byref(ng))
+            r = dict(elevated=e[: ne.value], ground=g[: ng.value])
+        mask = self._mask_from_subsequences_fast(a, r["elevated"], r["ground"])
+        out = dict(mask=mask, elevated=a[mask == 2].copy(), ground=a[mask == 1].copy())
+        if want_dump:
+            if ps == 0:
+                out.update(self._b.ref_ground_polar(a))
+            else:
+                d = self._b.ground_remove(p, a, True)
+                out.update({k: d[k] for k in ("min_z", "height", "smoothed", "hdiff", "hground", "is_ground")})
+        self._note("ground_remove", "reference build" + (" (object_tracking0)" if ps else ""))
+        return out
+
+    def _mask_from_subsequences_fast(self, a, elev, ground):
+        """the same matching vectorised for the common case (no two input points share x, y, z bits across classes — they cannot): a point
+        is elevated iff its bits occur in the elevated cloud; counts and order are then verified, the slow pass is the fallback"""
+        n = len(a)
+        if n == 0:
+            return np.zeros(0, np.uint8)
+        key = np.ascontiguousarray(a[:, :3]).view(np.uint32).astype(np.uint64)
+        pack = lambda k: (k[:, 0] << np.uint64(42)) ^ (k[:, 1] << np.uint64(21)) ^ k[:, 2] ^ (k[:, 0] >> np.uint64(13)) ^ (k[:, 1] * np.uint64(0x9E3779B97F4A7C15))
+        ha = pack(key)
+        he = pack(np.ascontiguousarray(elev[:, :3]).view(np.uint32).astype(np.uint64)) if len(elev) else np.zeros(0, np.uint64)
+        hg = pack(np.ascontiguousarray(ground[:, :3]).view(np.uint32).astype(np.uint64)) if len(ground) else np.zeros(0, np.uint64)
+        mask = np.zeros(n, np.uint8)
+        mask[np.isin(ha, he)] = 2
+        mask[np.isin(ha, hg) & (mask == 0)] = 1
+        ok = (int((mask == 2).sum()) == len(elev) and int((mask == 1).sum()) == len(ground)
+              and np.array_equal(np.ascontiguousarray(a[mask == 2][:, :3]).view(np.uint32), np.ascontiguousarray(elev[:, :3]).view(np.uint32))
+              and np.array_equal(np.ascontiguousarray(a[mask == 1][:, :3]).view(np.uint32), np.ascontiguousarray(ground[:, :3]).view(np.uint32)))
+        if ok:
+            return mask
+        mask = self._mask_from_subsequences(a, elev, ground)
+        assert np.array_equal(np.ascontiguousarray(a[mask == 2][:, :3]).view(np.uint32), np.ascontiguousarray(elev[:, :3]).view(np.uint32))
+        assert np.array_equal(np.ascontiguousarray(a[mask == 1][:, :3]).view(np.uint32), np.ascontiguousarray(ground[:, :3]).view(np.uint32))
+        return mask
+
+    def cluster(self, p, elev):
+        ps = self._preset(p)
+        o = self._b.cluster(p, elev)
+        if ps is None:
+            self._note("cluster", "restatement (parameters are not a preset)")
+            return o
+        a = _pts(elev)
+        if ps == 0:
+            r = self._b.ref_cluster(a)
+        else:
+            L = self._b.ref0(); G = L.ref0_num_grid(); grid = np.zeros((G, G), np.int32); nc = C.c_int(0)
+            L.ref0_cluster(a.ctypes.data_as(C.c_void_p), len(a), grid.ctypes.data_as(C.c_void_p), C.byref(nc))
+            r = dict(grid=grid, num_cluster=nc.value)
+        assert r["num_cluster"] == o["num_cluster"] and np.array_equal(r["grid"], o["grid"]), "restatement and reference build disagree on the label grid"
+        self._note("cluster", "reference build (per-point labels: restatement on the reference's grid)")
+        return dict(grid=r["grid"], num_cluster=r["num_cluster"], point_label=o["point_label"])
+
+    def box_fit(self, p, elev, grid, num_cluster, max_boxes=4096, debug=False):
+        ps = self._preset(p)
+        o = self._b.box_fit(p, elev, grid, num_cluster, max_boxes, debug)
+        if ps is None or o["n_undefined"] > 0 or debug:
+            self._note("box_fit", "restatement (" + ("parameters are not a preset" if ps is None else "per-cluster debug record" if debug else "the reference reads uninitialised memory on this frame: SURVEY.md H7") + ")")
+            return o
+        a = _pts(elev); g = np.ascontiguousarray(grid, np.int32)
+        if ps == 0:
+            r = self._b.ref_box_fit(a, g, num_cluster, max_boxes)
+        else:
+            L = self._b.ref0(); boxes = np.zeros((max_boxes, 8, 3), np.float32); nb = C.c_int(0)
+            L.ref0_box_fit(a.ctypes.data_as(C.c_void_p), len(a), g.ctypes.data_as(C.c_void_p), num_cluster, boxes.ctypes.data_as(C.c_void_p), max_boxes, C.byref(nb))
+            r = dict(boxes=boxes[: min(nb.value, max_boxes)].copy(), n=nb.value)
+        assert len(r["boxes"]) == len(o["boxes"]), "restatement and reference build disagree on the number of boxes"
+        self._note("box_fit", "reference build (box -> cluster ids: restatement)")
+        return dict(boxes=r["boxes"], box_cluster=o["box_cluster"], n_undefined=0)
+
+    def Tracker(self, p):
+        if self._preset(p) == 0 and self._b.ref_variant("ref", self._trk + 1) is not None:
+            self._trk += 1
+            t = self._b.RefTracker(self._b.ref_variant("ref", self._trk)); t.reset()
+            self._note("Tracker", "reference build")
+            return t
+        self._note("Tracker", "restatement (" + ("object_tracking0's tracker reads its ego motion from files" if self._preset(p) == 1 else "parameters are not a preset") + ")")
+        return self._b.Tracker(p)

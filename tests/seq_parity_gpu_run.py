@@ -33,6 +33,8 @@ def main():
     if not os.path.exists(build.LIB):
         raise SystemExit("libmot_hip.so is missing: no fallback")
     O.build_oracle()
+    if O.ref() is not None and os.environ.get("MOT_ORACLE") != "restatement":
+        O = O.RefFirst(O)   # the reference's own sources wherever they can answer (tests/oracle_lib.py); the restatement otherwise
     S, F, N = len(args.scenes), args.frames, args.points
     stride = ((N + 2047) // 2048) * 2048
     ego_v, ego_yaw = sdev.load_ego(F)
@@ -44,9 +46,10 @@ def main():
     p = O.params(args.preset)
     t0 = time.time()
     with mot.Context(mot.params(args.preset), max_points=stride, max_batch=S, max_tracks_total=1024) as c:
-        st = SP.check_sequence(c, O, p, lambda f: seq[f].data_ptr(), lambda f, b: seq[f, b].cpu().numpy(), n_seq, stride, ego_v, ego_yaw, units, skip_ill_conditioned=True)
+        st = SP.check_sequence(c, O, p, lambda f: seq[f].data_ptr(), lambda f, b: seq[f, b].cpu().numpy(), n_seq, stride, ego_v, ego_yaw, units, skip_ill_conditioned=True, noise_floor=True, mar_check=True)
     st.update(render_s=round(t_render, 1), check_s=round(time.time() - t0, 1), points_per_frame=int(n_seq.mean()), scenes=args.scenes, units=units,
-              reference_tf=O.ref_tf() is not None)
+              reference_tf=O.ref_tf() is not None,
+              oracle_used={f"{fn}: {who}": k for (fn, who), k in sorted(getattr(O, "used", {}).items())} or "restatement")
     if args.preset == 0:
         assert st["boxes"] > F and st["tracks_ever"] >= 20 and st["live_max"] >= 5, st   # the sequence really exercises the tracker
     print("sequence parity ok " + json.dumps(st))

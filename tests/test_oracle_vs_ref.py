@@ -464,3 +464,43 @@ def test_parallel_hull_construction(oracle):
             x = np.arange(n) - n // 2; pts = np.stack([x, -(x * x) // 8 + rng.integers(0, 2, size=n)], 1)
         pts = np.unique(pts.astype(np.int64), axis=0)
         assert np.array_equal(oracle.convex_hull(pts.astype(np.int32)), peel_hull(pts))
+
+
+@pytest.mark.parametrize("preset", [0, 1])
+def test_ref_first_proxy(oracle, synth, preset):
+    """the oracle the GPU suite uses (oracle_lib.RefFirst: the reference build first) against the restatement, on CPU: the mask it
+    reconstructs from the reference's two clouds, the clouds with their 4th float, label grid, boxes, tracker outputs — and that a
+    parameter set which is not a preset is answered by the restatement"""
+    _need_ref(oracle)
+    R = oracle.RefFirst(oracle)
+    p = oracle.params(preset)
+    for f in range(3):
+        cloud = np.concatenate([synth.make_cloud(30000, 5 + preset, f)] + ([synth.edge_case_points()] if preset == 0 else [])).astype(np.float32)   # (under preset 1 the edge points make a cluster on which the reference reads uninitialised memory: that frame would go to the restatement)
+        cloud[::7, 3] = 0.25                                  # the 4th float must come back as it went in
+        a = R.ground_remove(p, cloud, want_dump=True); o = oracle.ground_remove(p, cloud, want_dump=True)
+        assert np.array_equal(a["mask"], o["mask"])
+        for k in ("elevated", "ground"):
+            assert np.array_equal(a[k].view(np.uint32), o[k].view(np.uint32)), k
+        for k in ("min_z", "height", "hground", "is_ground"):
+            m = o["is_ground"].astype(bool) if k == "hground" else slice(None)
+            assert np.array_equal(np.asarray(a[k])[m], np.asarray(o[k])[m]), k
+        ca = R.cluster(p, a["elevated"]); co = oracle.cluster(p, o["elevated"])
+        assert ca["num_cluster"] == co["num_cluster"] and np.array_equal(ca["grid"], co["grid"]) and np.array_equal(ca["point_label"], co["point_label"])
+        ba = R.box_fit(p, a["elevated"], ca["grid"], ca["num_cluster"]); bo = oracle.box_fit(p, o["elevated"], co["grid"], co["num_cluster"])
+        assert np.array_equal(ba["boxes"].view(np.uint32), bo["boxes"].view(np.uint32)) and np.array_equal(ba["box_cluster"], bo["box_cluster"])
+    assert R.used.get(("ground_remove", "reference build" + (" (object_tracking0)" if preset else ""))) == 3
+    assert any(k[0] == "box_fit" and k[1].startswith("reference build") for k in R.used) and any(k[0] == "cluster" and k[1].startswith("reference build") for k in R.used)
+    q = oracle.params(preset, t_hdiff=0.07)
+    R.ground_remove(q, cloud)
+    assert ("ground_remove", "restatement (parameters are not a preset)") in R.used
+    if preset == 0:   # two trackers at once: private copies of the reference library
+        import test_emu_tracker_random as RS
+        T1, T2, T0 = R.Tracker(p), R.Tracker(p), oracle.Tracker(p)
+        assert isinstance(T1, oracle.RefTracker) and isinstance(T2, oracle.RefTracker) and T1._lib() is not T2._lib()
+        for (b1, ts, v, yaw), (b2, _, _, _) in zip(RS.sequence(11), RS.sequence(12)):
+            for T in (T1, T2, T0):
+                T.ego_update(ts, v, yaw)
+            o1, o2, o0 = T1.step(b1, ts), T2.step(b2, ts), T0.step(b1, ts)
+            assert o1["n"] == o0["n"] and np.array_equal(o1["track_manage"], o0["track_manage"])
+        assert o2["n"] != o1["n"] or not np.array_equal(o2["p"], o1["p"])     # the second instance really followed its own sequence
+        T0.close()

@@ -23,7 +23,9 @@ def _run(*argv, timeout=900):
 def test_154_frame_sequences_120k_points_every_frame_vs_oracle(hip_lib):
     st = _run("--points", 120000, "--frames", 154, "--scenes", 0, 1001, "--units", 1e5, 0.1)
     assert st["frames"] == 154 and st["streams"] == 2 and st["points_per_frame"] > 100000
-    assert st["max_rel_state_err"] <= 1e-4
+    assert st["max_rel_state_err"] <= 1e-4 and st["above_1e-4_unexplained"] == 0 and st.get("above_bar_well_conditioned", 0) == 0
+    assert st["mar_clusters_cross_checked"] > 1000 and st["mar_worst_area_err_units"] <= 6.0   # every rectangle-branch cluster of both streams
+    print("sequence parity:", st)
 
 
 def test_154_frame_sequence_200k_points_every_frame_vs_oracle(hip_lib):
@@ -35,3 +37,26 @@ def test_sequence_kitti_preset(hip_lib):
     """preset 1 (object_tracking0's KITTI constants: 200-cell grid, no dilation, L-shape rule without the side test), 40 frames"""
     st = _run("--points", 120000, "--frames", 40, "--scenes", 3, "--units", 1e5, "--preset", 1)
     assert st["frames"] == 40
+
+
+def test_bench_on_a_kitti_shaped_drive(hip_lib, tmp_path):
+    """`bench.py --kitti-dir DIR` (the real-data leg: `data: "kitti"`). With $MOT_KITTI_DIR set it runs on that drive; without (no KITTI data
+    in this image) on a KITTI-raw-shaped directory of rendered scans, which exercises the loader, the ragged frame sizes and the line."""
+    import numpy as np
+    root = os.path.dirname(HERE)
+    d = os.environ.get("MOT_KITTI_DIR")
+    if not d:
+        sys.path.insert(0, HERE)
+        from conftest import load_sub
+        synth = load_sub("synth")
+        d = str(tmp_path / "2011_09_26_drive_0005_sync")
+        os.makedirs(os.path.join(d, "velodyne_points", "data")); os.makedirs(os.path.join(d, "oxts", "data"))
+        for f in range(6):
+            synth.make_cloud(60000 - 501 * f, 3, f).tofile(os.path.join(d, "velodyne_points", "data", f"{f:010d}.bin"))
+            ox = np.zeros(30); ox[8] = 3.0 + 0.1 * f; ox[5] = 0.004 * f
+            np.savetxt(os.path.join(d, "oxts", "data", f"{f:010d}.txt"), ox[None])
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--kitti-dir", d, "--batch", "8", "--contexts", "2", "--steps", "2", "--warmup", "1", "--no-aux",
+                        "--no-cpu-baseline", "--phase", "2"], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = json.loads(r.stdout.strip().splitlines()[-1])
+    assert line["data"] == "kitti" and line["value"] > 0 and line["config"]["kitti"]["frames"] >= 6 and line["all_outputs"]["value"] > 0
