@@ -108,97 +108,118 @@ int orc_convex_hull(const int32_t* xy, int total, int32_t* hull_xy) {
 }
 
 /* rotatingCalipers(points, n, CALIPERS_MINAREARECT, out), rotcalipers.cpp. returns 0 if the
- * orientation assertion would fire. */
-static int rotating_calipers(const float* px, const float* py, int n, float* out) {
-  float minarea = FLT_MAX;
-  int bi0 = 0, bi5 = 0; float b1 = 0, b2 = 0, b3 = 0, b4 = 0; /* buf[0..5] */
-  float* inv_vect_length = (float*)malloc(sizeof(float) * n * 3);
-  float* vx = inv_vect_length + n;
-  float* vy = vx + n;
-  int left = 0, bottom = 0, right = 0, top = 0;
-  int seq[4] = {-1, -1, -1, -1};
-  float orientation = 0, base_a, base_b = 0;
-  float left_x, right_x, top_y, bottom_y;
-  float pt0x = px[0], pt0y = py[0];
-  left_x = right_x = pt0x; top_y = bottom_y = pt0y;
-  for (int i = 0; i < n; i++) {
-    double dx, dy;
-    if (pt0x < left_x) left_x = pt0x, left = i;
-    if (pt0x > right_x) right_x = pt0x, right = i;
-    if (pt0y > top_y) top_y = pt0y, top = i;
-    if (pt0y < bottom_y) bottom_y = pt0y, bottom = i;
-    int nx = (i + 1 < n) ? i + 1 : 0;
-    float ptx = px[nx], pty = py[nx];
-    dx = ptx - pt0x; dy = pty - pt0y; /* float subtraction widened to double */
-    vx[i] = (float)dx; vy[i] = (float)dy;
-    inv_vect_length[i] = (float)(1. / sqrt(dx * dx + dy * dy));
-    pt0x = ptx; pt0y = pty;
+ * orientation assertion would fire.
+ * Instantiated twice: in float — OpenCV's arithmetic, the restatement proper — and in double (rotating_calipers_f64), the SAME walk
+ * with no float32 rounding inside it, for tests/mar_check.py: where the two part, the cause is float32's resolution of the cosines the
+ * walk compares (consecutive edges of a thin hull differ by less than acos(1 - 2^-24) = 0.02 degrees), not the transcription. */
+#define ORC_DEFINE_CALIPERS(NAME, REAL) \
+static int NAME(const REAL* px, const REAL* py, int n, REAL* out) { \
+  REAL minarea = (REAL)FLT_MAX; \
+  int bi0 = 0, bi5 = 0; REAL b1 = 0, b2 = 0, b3 = 0, b4 = 0; /* buf[0..5] */ \
+  REAL* inv_vect_length = (REAL*)malloc(sizeof(REAL) * n * 3); \
+  REAL* vx = inv_vect_length + n; \
+  REAL* vy = vx + n; \
+  int left = 0, bottom = 0, right = 0, top = 0; \
+  int seq[4] = {-1, -1, -1, -1}; \
+  REAL orientation = 0, base_a, base_b = 0; \
+  REAL left_x, right_x, top_y, bottom_y; \
+  REAL pt0x = px[0], pt0y = py[0]; \
+  left_x = right_x = pt0x; top_y = bottom_y = pt0y; \
+  for (int i = 0; i < n; i++) { \
+    double dx, dy; \
+    if (pt0x < left_x) left_x = pt0x, left = i; \
+    if (pt0x > right_x) right_x = pt0x, right = i; \
+    if (pt0y > top_y) top_y = pt0y, top = i; \
+    if (pt0y < bottom_y) bottom_y = pt0y, bottom = i; \
+    int nx = (i + 1 < n) ? i + 1 : 0; \
+    REAL ptx = px[nx], pty = py[nx]; \
+    dx = ptx - pt0x; dy = pty - pt0y; /* REAL subtraction widened to double */ \
+    vx[i] = (REAL)dx; vy[i] = (REAL)dy; \
+    inv_vect_length[i] = (REAL)(1. / sqrt(dx * dx + dy * dy)); \
+    pt0x = ptx; pt0y = pty; \
+  } \
+  { \
+    double ax = vx[n - 1], ay = vy[n - 1]; \
+    for (int i = 0; i < n; i++) { \
+      double bx = vx[i], by = vy[i]; \
+      double convexity = ax * by - ay * bx; \
+      if (convexity != 0) { orientation = (convexity > 0) ? (REAL)1 : (-(REAL)1); break; } \
+      ax = bx; ay = by; \
+    } \
+    if (orientation == 0) { free(inv_vect_length); return 0; } /* CV_Assert( orientation != 0 ) */ \
+  } \
+  base_a = orientation; \
+  seq[0] = bottom; seq[1] = right; seq[2] = top; seq[3] = left; \
+  for (int k = 0; k < n; k++) { \
+    REAL dp[4] = { \
+        +base_a * vx[seq[0]] + base_b * vy[seq[0]], \
+        -base_b * vx[seq[1]] + base_a * vy[seq[1]], \
+        -base_a * vx[seq[2]] - base_b * vy[seq[2]], \
+        +base_b * vx[seq[3]] - base_a * vy[seq[3]], \
+    }; \
+    REAL maxcos = dp[0] * inv_vect_length[seq[0]]; \
+    int main_element = 0; \
+    for (int i = 1; i < 4; ++i) { \
+      REAL cosalpha = dp[i] * inv_vect_length[seq[i]]; \
+      if (cosalpha > maxcos) { main_element = i; maxcos = cosalpha; } \
+    } \
+    { \
+      int pindex = seq[main_element]; \
+      REAL lead_x = vx[pindex] * inv_vect_length[pindex]; \
+      REAL lead_y = vy[pindex] * inv_vect_length[pindex]; \
+      switch (main_element) { \
+        case 0: base_a = lead_x; base_b = lead_y; break; \
+        case 1: base_a = lead_y; base_b = -lead_x; break; \
+        case 2: base_a = -lead_x; base_b = -lead_y; break; \
+        default: base_a = -lead_y; base_b = lead_x; break; \
+      } \
+    } \
+    seq[main_element] += 1; \
+    seq[main_element] = (seq[main_element] == n) ? 0 : seq[main_element]; \
+    { \
+      REAL dx = px[seq[1]] - px[seq[3]]; \
+      REAL dy = py[seq[1]] - py[seq[3]]; \
+      REAL width = dx * base_a + dy * base_b; \
+      dx = px[seq[2]] - px[seq[0]]; \
+      dy = py[seq[2]] - py[seq[0]]; \
+      REAL height = -dx * base_b + dy * base_a; \
+      REAL area = width * height; \
+      if (area <= minarea) { \
+        minarea = area; \
+        bi0 = seq[3]; b1 = base_a; b2 = width; b3 = base_b; b4 = height; bi5 = seq[0]; \
+      } \
+    } \
+  } \
+  { \
+    REAL A1 = b1, B1 = b3, A2 = -b3, B2 = b1; \
+    REAL C1 = A1 * px[bi0] + py[bi0] * B1; \
+    REAL C2 = A2 * px[bi5] + py[bi5] * B2; \
+    REAL idet = (REAL)1 / (A1 * B2 - A2 * B1); \
+    REAL qx = (C1 * B2 - C2 * B1) * idet; \
+    REAL qy = (A1 * C2 - A2 * C1) * idet; \
+    out[0] = qx; out[1] = qy; \
+    out[2] = A1 * b2; out[3] = B1 * b2; \
+    out[4] = A2 * b4; out[5] = B2 * b4; \
+  } \
+  free(inv_vect_length); \
+  return 1; \
+}
+ORC_DEFINE_CALIPERS(rotating_calipers, float)
+ORC_DEFINE_CALIPERS(rotating_calipers_f64, double)
+
+/* width x height of the rectangle the SAME caliper walk finds when it is carried out in double precision (0 for degenerate hulls) */
+double orc_min_area_rect_f64_area(const int32_t* xy, int n) {
+  int32_t* hull = (int32_t*)malloc(sizeof(int32_t) * 2 * (n > 0 ? n : 1));
+  int hn = orc_convex_hull(xy, n, hull);
+  double area = 0;
+  if (hn > 2) {
+    double* hx = (double*)malloc(sizeof(double) * 2 * hn); double* hy = hx + hn; double out[6] = {0, 0, 0, 0, 0, 0};
+    for (int i = 0; i < hn; i++) { hx[i] = hull[2 * i]; hy[i] = hull[2 * i + 1]; }
+    if (rotating_calipers_f64(hx, hy, hn, out)) area = sqrt(out[2] * out[2] + out[3] * out[3]) * sqrt(out[4] * out[4] + out[5] * out[5]);
+    free(hx);
   }
-  {
-    double ax = vx[n - 1], ay = vy[n - 1];
-    for (int i = 0; i < n; i++) {
-      double bx = vx[i], by = vy[i];
-      double convexity = ax * by - ay * bx;
-      if (convexity != 0) { orientation = (convexity > 0) ? 1.f : (-1.f); break; }
-      ax = bx; ay = by;
-    }
-    if (orientation == 0) { free(inv_vect_length); return 0; } /* CV_Assert( orientation != 0 ) */
-  }
-  base_a = orientation;
-  seq[0] = bottom; seq[1] = right; seq[2] = top; seq[3] = left;
-  for (int k = 0; k < n; k++) {
-    float dp[4] = {
-        +base_a * vx[seq[0]] + base_b * vy[seq[0]],
-        -base_b * vx[seq[1]] + base_a * vy[seq[1]],
-        -base_a * vx[seq[2]] - base_b * vy[seq[2]],
-        +base_b * vx[seq[3]] - base_a * vy[seq[3]],
-    };
-    float maxcos = dp[0] * inv_vect_length[seq[0]];
-    int main_element = 0;
-    for (int i = 1; i < 4; ++i) {
-      float cosalpha = dp[i] * inv_vect_length[seq[i]];
-      if (cosalpha > maxcos) { main_element = i; maxcos = cosalpha; }
-    }
-    {
-      int pindex = seq[main_element];
-      float lead_x = vx[pindex] * inv_vect_length[pindex];
-      float lead_y = vy[pindex] * inv_vect_length[pindex];
-      switch (main_element) {
-        case 0: base_a = lead_x; base_b = lead_y; break;
-        case 1: base_a = lead_y; base_b = -lead_x; break;
-        case 2: base_a = -lead_x; base_b = -lead_y; break;
-        default: base_a = -lead_y; base_b = lead_x; break;
-      }
-    }
-    seq[main_element] += 1;
-    seq[main_element] = (seq[main_element] == n) ? 0 : seq[main_element];
-    {
-      float dx = px[seq[1]] - px[seq[3]];
-      float dy = py[seq[1]] - py[seq[3]];
-      float width = dx * base_a + dy * base_b;
-      dx = px[seq[2]] - px[seq[0]];
-      dy = py[seq[2]] - py[seq[0]];
-      float height = -dx * base_b + dy * base_a;
-      float area = width * height;
-      if (area <= minarea) {
-        minarea = area;
-        bi0 = seq[3]; b1 = base_a; b2 = width; b3 = base_b; b4 = height; bi5 = seq[0];
-      }
-    }
-  }
-  {
-    float A1 = b1, B1 = b3, A2 = -b3, B2 = b1;
-    float C1 = A1 * px[bi0] + py[bi0] * B1;
-    float C2 = A2 * px[bi5] + py[bi5] * B2;
-    float idet = 1.f / (A1 * B2 - A2 * B1);
-    float qx = (C1 * B2 - C2 * B1) * idet;
-    float qy = (A1 * C2 - A2 * C1) * idet;
-    out[0] = qx; out[1] = qy;
-    out[2] = A1 * b2; out[3] = B1 * b2;
-    out[4] = A2 * b4; out[5] = B2 * b4;
-  }
-  free(inv_vect_length);
-  return 1;
+  free(hull);
+  return area;
 }
 
 static void rotated_rect_points(const float rr[5], float pt[8]);

@@ -133,6 +133,7 @@ int ref0_track_step(const float* boxes, int m, double timestamp, int max_tracks,
   return trk_step(boxes, m, timestamp, max_tracks, target_xyz, v_yaw, track_manage, is_static, is_vis, vis_bb, n_tracks);
 }
 int ref0_track_count() { return (int)targets_.size(); }
+int ref0_track_lifetimes(int* out, int max_tracks) { return trk_lifetimes(out, max_tracks); }
 int ref0_track_get_state(int id, double* x4x5, double* p4x25, double* mode3, double* zpred6, double* s12, double* k30,
                          double* misc4, int* ints5, float* bbox24, float* best24) {
   return trk_get_state(id, x4x5, p4x25, mode3, zpred6, s12, k30, misc4, ints5, bbox24, best24);

@@ -184,6 +184,7 @@ int ref_track_step(const float* boxes, int m, double timestamp, int max_tracks, 
   return trk_step(boxes, m, timestamp, max_tracks, target_xyz, v_yaw, track_manage, is_static, is_vis, vis_bb, n_tracks);
 }
 int ref_track_count() { return (int)targets_.size(); }
+int ref_track_lifetimes(int* out, int max_tracks) { return trk_lifetimes(out, max_tracks); }
 // filter state of targets_[id], laid out as mot_track_state (include/mot.h)
 int ref_track_get_state(int id, double* x4x5, double* p4x25, double* mode3, double* zpred6, double* s12, double* k30,
                         double* misc4 /*initMeas x,y, distFromInit, bestYaw*/, int* ints5 /*lifetime, trackNum, isStatic, isVis, hasBest*/,

@@ -27,6 +27,12 @@ inline int trk_step(const float* boxes, int m, double timestamp, int max_tracks,
   }
   return 0;
 }
+// UKF::lifetime_ of every track (the reference's outputs carry none; the tests compare it)
+inline int trk_lifetimes(int* out, int max_tracks) {
+  int n = (int)targets_.size();
+  for (int i = 0; i < n && i < max_tracks; i++) out[i] = targets_[i].lifetime_;
+  return n;
+}
 // filter state of targets_[id], laid out as mot_track_state (include/mot.h)
 inline int trk_get_state(int id, double* x4x5, double* p4x25, double* mode3, double* zpred6, double* s12, double* k30,
                         double* misc4 /*initMeas x,y, distFromInit, bestYaw*/, int* ints5 /*lifetime, trackNum, isStatic, isVis, hasBest*/,

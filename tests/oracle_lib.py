@@ -463,8 +463,12 @@ class RefTracker:
                              vy.ctypes.data_as(C.c_void_p), tm.ctypes.data_as(C.c_void_p), st.ctypes.data_as(C.c_void_p),
                              vis.ctypes.data_as(C.c_void_p), vbb.ctypes.data_as(C.c_void_p), C.byref(nt))
         n = nt.value
-        return dict(n=n, track_manage=tm[:n].copy(), is_static=st[:n].copy(), is_vis=vis[:n].copy(), p=xyz[:n].copy(),
-                    v_yaw=vy[:n].copy(), vis_box=vbb[:n].copy())
+        out = dict(n=n, track_manage=tm[:n].copy(), is_static=st[:n].copy(), is_vis=vis[:n].copy(), p=xyz[:n].copy(),
+                   v_yaw=vy[:n].copy(), vis_box=vbb[:n].copy())
+        lt = getattr(self._lib(), self._pre + "track_lifetimes", None)   # (a prebuilt library from before this entry point existed has none)
+        if lt is not None:
+            life = np.zeros(max(n, 1), np.int32); lt(life.ctypes.data_as(C.c_void_p), n); out["lifetime"] = life[:n].copy()
+        return out
 
     def count(self):
         return getattr(self._lib(), self._pre + "track_count")()
@@ -564,6 +568,11 @@ class RefFirst:
         assert ie == len(ke) and ig == len(kg), ("the reference's clouds are not order-preserving subsequences of the input", ie, len(ke), ig, len(kg))
         return mask
 
+    def restatement(self, fn: str, why: str):
+        """the C restatement, on purpose (logged like every other routing decision)"""
+        self._note(fn, "restatement (" + why + ")")
+        return self._b
+
     def ground_remove(self, p, xyzw, want_dump=False):
         ps = self._preset(p)
         if ps is None:
@@ -618,6 +627,9 @@ class RefFirst:
             self._note("cluster", "restatement (parameters are not a preset)")
             return o
         a = _pts(elev)
+        if not np.isfinite(a[:, :3]).all():   # (a cloud no ground stage can emit; the reference's unchecked casts index out of bounds on it and crash)
+            self._note("cluster", "restatement (non-finite points: the reference indexes out of bounds)")
+            return o
         if ps == 0:
             r = self._b.ref_cluster(a)
         else:
@@ -631,10 +643,14 @@ class RefFirst:
     def box_fit(self, p, elev, grid, num_cluster, max_boxes=4096, debug=False):
         ps = self._preset(p)
         o = self._b.box_fit(p, elev, grid, num_cluster, max_boxes, debug)
-        if ps is None or o["n_undefined"] > 0 or debug:
-            self._note("box_fit", "restatement (" + ("parameters are not a preset" if ps is None else "per-cluster debug record" if debug else "the reference reads uninitialised memory on this frame: SURVEY.md H7") + ")")
-            return o
         a = _pts(elev); g = np.ascontiguousarray(grid, np.int32)
+        finite = bool(np.isfinite(a[:, :3]).all())
+        sane_grid = bool(((g >= 0) & (g <= max(num_cluster, 0))).all())   # (a hostile caller-made grid: the reference indexes its cluster vector with it)
+        if ps is None or o["n_undefined"] > 0 or debug or not finite or not sane_grid:
+            self._note("box_fit", "restatement (" + ("parameters are not a preset" if ps is None else "per-cluster debug record" if debug else
+                                                       "non-finite points: the reference indexes out of bounds" if not finite else "labels outside 0..num_cluster in the grid" if not sane_grid else
+                                                       "the reference reads uninitialised memory on this frame: SURVEY.md H7") + ")")
+            return o
         if ps == 0:
             r = self._b.ref_box_fit(a, g, num_cluster, max_boxes)
         else:

@@ -37,7 +37,8 @@ def test_restated_min_area_rect_against_the_exhaustive_oracle(oracle):
     rng = np.random.default_rng(20260926)
     worst, tied, proper = 0.0, 0, 0
     for t, p in enumerate(point_sets(rng, 14000 * SCALE)):
-        rel, ties = MC.check(oracle, p, where=t)
+        rel, ties, clause = MC.check(oracle, p, where=t)
+        assert clause == "rounding"          # none of these sets is thin enough for the cosine-resolution clause
         worst = max(worst, rel); tied += ties > 1; proper += ties > 0
     assert proper >= 10000 * SCALE and tied > 100    # real rectangles, and sets on which several hull edges attain the minimum exactly
     print("min-area rectangle cross-check: %d proper sets, %d with exact ties, worst area error %.2f x eps32 x diameter x (w + h)" % (proper, tied, worst))
@@ -57,3 +58,19 @@ def test_brute_oracle_on_known_shapes(oracle):
     b = oracle.mar_brute(seg); assert len(b["hull"]) == 2 and b["min_area"] == 0.0
     big = np.array([[-30000, -30000], [30000, -29999], [30000, 30000], [-29999, 30000]], np.int32)   # 2^68-sized numerators
     b = oracle.mar_brute(big); assert np.isfinite(b["min_area"]) and abs(b["min_area"] - 3.6e9) < 2e5
+
+
+def test_thin_walls_from_the_rendered_streams(oracle):
+    """tests/golden/mar_thin_walls.npz: the 69 rectangle clusters of the rendered 154-frame streams (scenes 0, 1001 at 120 k points,
+    scene 7 at 200 k; collected on the MI355X run of tests/test_sequence_gpu.py) on which the float32 caliper walk does NOT end on the
+    exact minimum — 12 m walls 1.3 pixels thin. The double-precision walk does (asserted inside check), the float32 result stays within
+    the cosine-resolution clause, and none of them can become a box (thin side < 2 pixels = 0.11 m against the rule filter's 0.2 m)."""
+    import os
+    d = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "mar_thin_walls.npz"))
+    n = 0
+    for k in d.files:
+        rel, _, clause = MC.check(oracle, d[k], where=k)
+        rr = oracle.min_area_rect(d[k])
+        assert clause == "cosine resolution" and rel > MC.AREA_UNITS and min(rr[2], rr[3]) < 2.0
+        n += 1
+    assert n == 69

@@ -24,13 +24,14 @@ def test_154_frame_sequences_120k_points_every_frame_vs_oracle(hip_lib):
     st = _run("--points", 120000, "--frames", 154, "--scenes", 0, 1001, "--units", 1e5, 0.1)
     assert st["frames"] == 154 and st["streams"] == 2 and st["points_per_frame"] > 100000
     assert st["max_rel_state_err"] <= 1e-4 and st["above_1e-4_unexplained"] == 0 and st.get("above_bar_well_conditioned", 0) == 0
-    assert st["mar_clusters_cross_checked"] > 1000 and st["mar_worst_area_err_units"] <= 6.0   # every rectangle-branch cluster of both streams
+    assert st["mar_clusters_cross_checked"] > 1000 and st["mar_worst_area_err_units"] <= 6.0 and not st.get("mar_failures")   # every rectangle-branch cluster of both streams
     print("sequence parity:", st)
 
 
 def test_154_frame_sequence_200k_points_every_frame_vs_oracle(hip_lib):
     st = _run("--points", 200000, "--frames", 154, "--scenes", 7, "--units", 1e5)
     assert st["frames"] == 154 and st["points_per_frame"] > 150000 and st["max_rel_state_err"] <= 1e-4
+    assert st["above_1e-4_unexplained"] == 0 and st.get("above_bar_well_conditioned", 0) == 0 and not st.get("mar_failures")
 
 
 def test_sequence_kitti_preset(hip_lib):

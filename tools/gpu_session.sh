@@ -26,7 +26,7 @@ for step in "$@"; do
   IFS=: read -r what a1 a2 <<< "$step"
   echo "=== $step"
   case $what in
-    tests) timeout 1700 python -m pytest ${a1:-tests} -q -m gpu -p no:cacheprovider 2>&1 | tail -12 | tee $O/pytest_gpu.txt ;;
+    tests) timeout 1700 python -X faulthandler -m pytest ${a1:-tests} -q -m gpu -p no:cacheprovider > $O/pytest_gpu_full.txt 2>&1; grep -n "Fatal Python error\|Segmentation" -A12 $O/pytest_gpu_full.txt | head -40; tail -40 $O/pytest_gpu_full.txt | tee $O/pytest_gpu.txt ;;
     smoke) timeout 180 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -1 | tee $O/smoke.txt ;;
     bench) timeout 900 python bench.py $a2 > $O/bench_${a1:-default}.json 2> $O/bench_${a1:-default}.err; tail -c 300 $O/bench_${a1:-default}.err; head -c 700 $O/bench_${a1:-default}.json; echo ;;
     quick) for r in 1 2; do timeout 300 python bench.py --steps 8 --warmup 1 --no-aux --no-cpu-baseline $a2 2>/dev/null | tee -a $O/quick_${a1:-default}.jsonl | head -c 260; echo; done ;;
