@@ -70,13 +70,13 @@ class MotError(RuntimeError):
 EXPORTS = (
     "mot_abi_version", "mot_params_preset", "mot_create", "mot_destroy", "mot_reset", "mot_last_error",
     "mot_synchronize", "mot_stream", "mot_ground_remove", "mot_cluster", "mot_box_fit", "mot_ego_update",
-    "mot_track_step", "mot_track_get_state", "mot_frames_dev", "mot_get_ground", "mot_get_clusters",
+    "mot_track_step", "mot_track_get_state", "mot_frames_dev", "mot_sequence_dev", "mot_get_ground", "mot_get_clusters",
     "mot_get_boxes", "mot_get_tracks", "mot_export_tracks_dev", "mot_side_params_default", "mot_cluster_products", "mot_cluster_products_host", "mot_decode_pointcloud2_dev", "mot_time_stage",
     "mot_ground_remove_pointcloud2", "mot_box_fit_resident", "mot_frame_pointcloud2",
     "mot_reset_slot", "mot_frames_host", "mot_wait_uploads", "mot_host_alloc", "mot_host_free", "mot_fetch_tracks_async",
     "mot_track_steps_dev", "mot_profile_kernel", "mot_profile_read", "mot_get_params", "mot_set_fused_outputs", "mot_reset_tracks_slot", "mot_export_tracks_packed_dev", "mot_set_launch_graphs",
 )
-ABI_VERSION = 3
+ABI_VERSION = 4
 OUT_GROUND, OUT_MASK, OUT_LABELS = 1, 2, 4
 
 _libs: dict[str, C.CDLL] = {}
@@ -294,6 +294,16 @@ class Context:
         ey = np.ascontiguousarray(ego_yaw if ego_yaw is not None else np.zeros(B), np.float64)
         self._ck(self.lib.mot_frames_dev(self._h, C.c_void_p(d_ptr), C.c_long(frame_stride_floats), _vp(n), B,
                                          int(run_tracker), _vp(ts), _vp(ev), _vp(ey)))
+
+    def sequence_dev(self, d_ptr: int, frame_stride_floats: int, n_points, timestamps, ego_v, ego_yaw, d_tracks_ptr: int = 0,
+                     max_per_frame: int = 0, d_counts_ptr: int = 0):
+        """SEQUENCE MODE (mot_sequence_dev): len(n_points) consecutive frames of ONE stream — stateless stages as one batch (slot k = frame
+        k), the tracker chained on the device on stream 0's tracks. Optional device buffers receive the live tracks after every frame."""
+        n = np.ascontiguousarray(n_points, np.int32); K = len(n)
+        ts = np.ascontiguousarray(timestamps, np.float64); ev = np.ascontiguousarray(ego_v, np.float64); ey = np.ascontiguousarray(ego_yaw, np.float64)
+        assert len(ts) == len(ev) == len(ey) == K
+        self._ck(self.lib.mot_sequence_dev(self._h, C.c_void_p(d_ptr), C.c_long(frame_stride_floats), _vp(n), K, _vp(ts), _vp(ev), _vp(ey),
+                                           C.c_void_p(d_tracks_ptr or None), int(max_per_frame), C.c_void_p(d_counts_ptr or None)))
 
     def get_ground(self, slot: int = 0, n_hint: int | None = None, want_clouds: bool = True):
         """n_hint: number of input points of the frame (length of the returned mask); the buffers are sized by max_points"""

@@ -738,6 +738,57 @@ extern "C" int mot_frames_dev(mot_ctx* c, const float* d_xyzw, long frame_stride
 }
 
 // ---------------------------------------------------------------------------------------- pipelined host ingest
+// K consecutive frames of ONE stream (BASELINE.json configs[3] as written: one 154-frame drive; the single-process precedent is
+// OT0/src/main.cpp:51-375 — one callback per frame): the stateless stages are independent per frame, so all K frames go through
+// ground -> cluster -> box as ONE batch (slot k = frame k: the launches a batch of K streams would get), and only the tracker — sequential
+// by nature, imm_ukf_jpda.cpp:704-1112 carries targets_ from frame to frame — runs K steps, chained on the device, each reading frame
+// k's boxes where the box stage left them (slot k) and stream 0's track state. No host synchronisation anywhere.
+extern "C" int mot_sequence_dev(mot_ctx* c, const float* d_xyzw, long frame_stride, const int* n_points, int frames,
+                                const double* timestamps, const double* ego_v, const double* ego_yaw,
+                                void* d_tracks, int max_per_frame, int32_t* d_counts) {
+  if (!c) return MOT_E_ARG;
+  MOT_GUARD(c);
+  int rc = check_frames_args(c, d_xyzw, frame_stride, n_points, frames, 1, timestamps, ego_v, ego_yaw);
+  if (rc) return rc;
+  if ((d_tracks != nullptr) != (d_counts != nullptr) || (d_tracks && max_per_frame < 1)) return fail(c, MOT_E_ARG, "mot_sequence_dev: d_tracks and d_counts go together, max_per_frame >= 1");
+  if ((rc = set_batch(c, n_points, frames, (const float4*)d_xyzw, frame_stride / 4, false))) return rc;
+  if ((rc = next_epoch(c))) return rc;
+  const int K = frames, max_n = c->last_max_n;
+  {  // one argument block for the whole sequence: n[k], and per FRAME what the tracking node computes per callback (main.cpp:72-166) —
+     // the ego pose advanced frame by frame on the host (slot 0's dead reckoning), its tf matrix, dt / first-frame flag
+    char* blk;
+    if ((rc = arg_block_acquire(c, &blk))) return rc;
+    memcpy(blk, c->h_n.data(), K * sizeof(int));
+    TrackFrameArgs* targs = reinterpret_cast<TrackFrameArgs*>(blk + c->arg_off_targs);
+    EgoTf* ego = reinterpret_cast<EgoTf*>(blk + c->arg_off_ego);
+    for (int b = 0; b < c->batch; b++) targs[b].run = 0;
+    TrackFrameArgs one[1];
+    for (int k = 0; k < K; k++) {
+      if ((rc = mot_ego_update(c, 0, timestamps[k], ego_v[k], ego_yaw[k], nullptr))) return rc;
+      tf_velodyne_to_global(c->ego[0].egoPoint[0], c->ego[0].egoPoint[1], c->ego[0].egoPoint[2], ego[k].m);
+      prepare_track_args(c, one, 0, 0, timestamps[k], true);
+      targs[k] = one[0];
+    }
+    FrameLaunch* fl = reinterpret_cast<FrameLaunch*>(blk + c->arg_off_launch);
+    fl->in = c->last_in; fl->in_stride = c->last_in_stride; fl->epoch = c->epoch; fl->pad = 0;
+    if ((rc = arg_block_commit(c, 0, c->arg_bytes))) return rc;
+  }
+  const bool want_ground = (c->fused_outputs & MOT_OUT_GROUND) != 0, want_mask = (c->fused_outputs & MOT_OUT_MASK) != 0;
+  c->ground_resident = want_ground && want_mask; c->last_fused = true;
+  c->label_state.assign(c->batch, (c->fused_outputs & MOT_OUT_LABELS) ? 1 : 0);
+  issue_frame_kernels(c, K, max_n, 0, want_ground, want_mask, false);   // slots = frames; ends with the plain box_finalize_kernel
+  const TrackBuffers base = track_buffers(c, true);
+  for (int k = 0; k < K; k++) {   // the per-frame inputs of step k live in slot k, the track state in slot 0
+    TrackBuffers tb = base;
+    tb.args += k; tb.ego += k; tb.m_dev += (long)k * kCountsStride; tb.cp += (long)k * kMaxBoxesPerFrame;
+    tb.boxes_sensor += (long)k * kMaxBoxesPerFrame * 24; tb.boxes += (long)k * tb.box_stride; tb.boxes_out += (long)k * tb.box_stride;
+    mot_launch_track(tb, 1, c->stream, false);
+    if (d_tracks) mot_launch_export_tracks(tb, 1, reinterpret_cast<mot_track*>(d_tracks) + (long)k * max_per_frame, max_per_frame, reinterpret_cast<int*>(d_counts) + k, c->stream);
+  }
+  MOT_HIP(c, hipGetLastError());
+  return MOT_OK;
+}
+
 static int ensure_copy_path(mot_ctx* c) {
   if (c->copy_ready) return MOT_OK;
   // a failure half-way (two batch x cap x 16-byte staging buffers: out of memory is plausible) leaves what exists for mot_destroy

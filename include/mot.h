@@ -38,7 +38,7 @@
 extern "C" {
 #endif
 
-#define MOT_ABI_VERSION 3
+#define MOT_ABI_VERSION 4
 
 /* polar grid of the ground stage: compile-time in the reference too
  * (OT/include/ground_removal.h:16-17) */
@@ -257,6 +257,20 @@ int mot_track_get_state(mot_ctx* ctx, int slot, int id, mot_track_state* out);
  * Asynchronous: results are read back with the mot_get_* calls below (which synchronise). */
 int mot_frames_dev(mot_ctx* ctx, const float* d_xyzw, long frame_stride, const int* n_points, int batch,
                    int run_tracker, const double* timestamps, const double* ego_v, const double* ego_yaw);
+
+/* SEQUENCE MODE: `frames` CONSECUTIVE frames of ONE sensor stream in one call (BASELINE.json configs[3] as written — a recorded drive
+ * replayed; the reference's single-process precedent runs one callback per frame, OT0/src/main.cpp:51-375). Frame k of the sequence is
+ * at d_xyzw + k*frame_stride floats; n_points / timestamps / ego_v / ego_yaw are host arrays of length `frames` (frames <= max_batch).
+ * The stateless stages (groundRemove, componentClustering, boxFitting) of all frames run as ONE batch — slot k of the context holds
+ * frame k afterwards: mot_get_ground / mot_get_clusters / mot_get_boxes(slot k) read its results — and the tracker
+ * (immUkfJpdaf, OT/tracking/imm_ukf_jpda.cpp:704-1112: sequential by nature) runs `frames` steps chained on the device on the track state
+ * of stream (slot) 0, step k taking frame k's boxes through the ego pose of frame k. Results are those of `frames` calls of
+ * mot_frames_dev(batch 1) in a row, bit for bit. Optional per-frame track records: the LIVE tracks after step k (mot_export_tracks_dev's
+ * records) go to d_tracks[k][max_per_frame] / d_counts[k] (device pointers; both NULL: none). After the call mot_get_tracks(slot 0) /
+ * mot_track_get_state(slot 0) see the state after the last frame. Asynchronous. */
+int mot_sequence_dev(mot_ctx* ctx, const float* d_xyzw, long frame_stride, const int* n_points, int frames,
+                     const double* timestamps, const double* ego_v, const double* ego_yaw,
+                     void* d_tracks, int max_per_frame, int32_t* d_counts);
 
 /* Which by-products of the ground stage the FUSED entry points (mot_frames_dev, mot_frames_host, mot_frame_pointcloud2) write
  * besides what the next stage needs: flags = OR of MOT_OUT_GROUND / MOT_OUT_MASK / MOT_OUT_LABELS, default 0. The reference's own fused

@@ -40,3 +40,52 @@ def test_sequence_checker_on_the_emulator(mot, synth, oracle, which):
     assert st["tracker_oracle"].startswith("restatement" if which == "restatement" else "reference build")
     if which != "restatement":
         assert ("box_fit", "reference build (box -> cluster ids: restatement)") in oracle.used and ("Tracker", "reference build") in oracle.used
+
+
+def test_sequence_mode_equals_frame_by_frame(mot, synth):
+    """mot_sequence_dev (K consecutive frames of ONE stream in one call: stateless stages as one batch, the tracker chained on the device)
+    against K calls of mot_frames_dev with one frame each — every stage's results of every frame and the tracker's outputs and full
+    filter states after every frame, bit for bit (the same kernels on the same inputs in the same order). Emulator build."""
+    import ctypes as C
+    import build_emu
+    import seq_parity as SP
+    lib = build_emu.build()
+    K, N, stride = 9, 7000, 7168
+    clouds = np.zeros((K, stride, 4), np.float32); n = np.zeros(K, np.int32)
+    for f in range(K):
+        n[f] = N - 13 * f; clouds[f, : n[f]] = synth.make_cloud(N, 31, f)[: n[f]]
+    ts = 1.0e9 + 1.0e5 * np.arange(K); ev = 2.0 + 0.1 * np.arange(K); ey = 0.004 * np.arange(K)
+    per_frame = []
+    with mot.Context(lib_path=lib, max_points=stride, max_batch=1, max_tracks_total=128) as c:
+        for f in range(K):
+            c.frames_dev(clouds[f].ctypes.data, stride * 4, [n[f]], run_tracker=True, timestamps=[ts[f]], ego_v=[ev[f]], ego_yaw=[ey[f]])
+            tr = c.get_tracks(0)
+            gb = np.zeros((1024, 8, 3), np.float32); assert c.lib.mot_debug_copy(c._h, 11, 0, gb.ctypes.data_as(C.c_void_p), C.c_size_t(gb.nbytes)) == 0
+            per_frame.append(dict(boxes=c.get_boxes(0)["boxes"], grid=c.get_clusters(0)["grid"], ne=c.get_ground(0, want_clouds=False)["n_elevated"], tracks=tr,
+                                  gb=gb[: len(c.get_boxes(0)["boxes"])].copy(),
+                                  states={int(i): c.track_state(int(i)) for i in np.nonzero(tr["track_manage"] > 0)[0]}))
+    rec = np.dtype([("id", "i4"), ("track_manage", "i4"), ("is_static", "i4"), ("is_vis", "i4"), ("p", "f4", 3), ("lifetime", "i4"), ("v_yaw", "f8", 2), ("vis_box", "f4", 24)])
+    with mot.Context(lib_path=lib, max_points=stride, max_batch=K, max_tracks_total=128) as c:
+        out = np.zeros((K, 64), rec); cnt = np.full(K, -1, np.int32)
+        c.sequence_dev(clouds.ctypes.data, stride * 4, n, ts, ev, ey, out.ctypes.data, 64, cnt.ctypes.data)
+        c.synchronize()
+        for f in range(K):
+            r = per_frame[f]
+            assert SP.bits_equal(c.get_boxes(f)["boxes"], r["boxes"]) and np.array_equal(c.get_clusters(f)["grid"], r["grid"]) and c.get_ground(f, want_clouds=False)["n_elevated"] == r["ne"], f
+            gb = np.zeros((1024, 8, 3), np.float32); assert c.lib.mot_debug_copy(c._h, 11, f, gb.ctypes.data_as(C.c_void_p), C.c_size_t(gb.nbytes)) == 0
+            assert SP.bits_equal(gb[: len(r["gb"])], r["gb"]), (f, "boxes in the global frame")
+            live = np.nonzero(r["tracks"]["track_manage"] > 0)[0]   # the per-frame record block: the live tracks after frame f, in id order
+            assert cnt[f] == len(live) and np.array_equal(out[f]["id"][: cnt[f]], live), (f, cnt[f], live)
+            for key in ("track_manage", "is_static", "is_vis", "lifetime"):
+                assert np.array_equal(out[f][key][: cnt[f]], r["tracks"][key][live]), (f, key)
+            assert np.array_equal(out[f]["p"][: cnt[f]], r["tracks"]["p"][live]) and np.array_equal(out[f]["v_yaw"][: cnt[f]], r["tracks"]["v_yaw"][live])
+        last = per_frame[-1]; tr = c.get_tracks(0)
+        assert tr["n"] == last["tracks"]["n"] and all(np.array_equal(tr[k], last["tracks"][k]) for k in ("track_manage", "lifetime", "is_static", "is_vis", "p", "v_yaw", "vis_box"))
+        for i, so in last["states"].items():
+            sd = c.track_state(i)
+            for k in SP.STATE_KEYS:
+                assert np.array_equal(np.asarray(sd[k]), np.asarray(so[k])), (i, k)
+        assert tr["n"] > 3 and len(last["states"]) > 1
+        # a second sequence continues the first (the stream's state carries over): frames K.. of the same drive
+        with pytest.raises(mot.MotError):
+            c.sequence_dev(clouds.ctypes.data, stride * 4, np.r_[n, n[:1]], np.r_[ts, ts[:1]], np.r_[ev, ev[:1]], np.r_[ey, ey[:1]])   # more frames than slots
