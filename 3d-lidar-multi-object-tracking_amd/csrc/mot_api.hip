@@ -114,6 +114,7 @@ struct mot_ctx {
   struct GraphEntry { GraphKey key; void* exec; };
   std::vector<GraphEntry> graphs;
   int graph_mode = 0;                  // 0 off, 1 on; turned off for good when a capture fails
+  int tracker_mode = MOT_TRACKER_AUTO; // mot_set_tracker_mode
   hipEvent_t arg_ev[kArgRing] = {};
   bool arg_used[kArgRing] = {};
   int arg_next = 0;
@@ -1295,7 +1296,7 @@ static TrackBuffers track_buffers(mot_ctx* c, bool fused) {
   TrackBuffers t;
   t.tracks = c->d_tracks; t.nt = c->d_nt; t.boxes = c->d_tboxes; t.args = c->d_targs; t.gate = c->d_gate; t.prog = c->d_prog;
   t.live = c->d_live; t.out = c->d_tout; t.flags = c->d_tflags; t.m_dev = fused ? c->d_counts : nullptr; t.T = c->max_tracks_total;
-  t.box_stride = (long)kMaxBoxesPerFrame * 24;
+  t.box_stride = (long)kMaxBoxesPerFrame * 24; t.step_mode = c->tracker_mode;
   t.nlive = c->d_nlive; t.pos = c->d_pos; t.cp = c->d_cp; t.items = c->d_items; t.n_items = c->d_nitems;
   t.slot_of = c->d_slot_of; t.tomb = c->d_tomb; t.used = c->d_used; t.zomb = c->d_zomb; t.nzomb = c->d_nzomb; t.E = c->max_tracks_ever;
   // fused path: the box stage's boxes (sensor frame) become the tracker's input through the dead-reckoned ego pose
@@ -1412,6 +1413,17 @@ extern "C" int mot_get_tracks(mot_ctx* c, int slot, mot_track* tracks, int max_t
 extern "C" int mot_set_launch_graphs(mot_ctx* c, int on) {
   if (!c) return MOT_E_ARG;
   c->graph_mode = on ? 1 : 0;
+  return MOT_OK;
+}
+
+extern "C" int mot_set_tracker_mode(mot_ctx* c, int mode) {
+  if (!c) return MOT_E_ARG;
+  if (mode != MOT_TRACKER_AUTO && mode != MOT_TRACKER_SPLIT && mode != MOT_TRACKER_STREAM) return fail(c, MOT_E_ARG, "mot_set_tracker_mode: unknown mode");
+  c->tracker_mode = mode;
+#ifndef MOT_HIPEMU
+  for (auto& ge : c->graphs) (void)hipGraphExecDestroy((hipGraphExec_t)ge.exec);   // captured launch sequences hold the old choice
+#endif
+  c->graphs.clear();
   return MOT_OK;
 }
 

@@ -293,6 +293,7 @@ struct TrackBuffers {
   int* flags;                   // [B] capacity flags
   const int* m_dev;             // optional: boxes per frame read from counts[b*kCountsStride + kCntBoxes] (fused path)
   int T;
+  int step_mode;                // host only: MOT_TRACKER_AUTO / _SPLIT / _STREAM (mot_set_tracker_mode) — how mot_launch_track launches the step
   MotTrackParams tp;
 };
 enum { kTrackFlagCapacity = 1 };   // a birth was dropped: no free slot (more than T tracks alive or just dead) or E tracks ever created

@@ -31,8 +31,11 @@ static __device__ __forceinline__ void cp_from_bbox(const float* b, double* cx, 
   *cy = p1y + (p3y - p1y) * S1 / (S1 + S2);
 }
 
-// b = the stream (slot) of this workgroup. Every exit is uniform over the workgroup.
-static __device__ void track_prep_body(const TrackBuffers& tb, const int b) {
+// b = the stream (slot) of this workgroup. Every exit is uniform over the workgroup. kThreads: threads of the workgroup;
+// kItems: append the stream's live tracks to the context's work list (the two per-track kernels; the one-launch stream kernel walks
+// the stream's live list itself).
+template <int kThreads, bool kItems>
+static __device__ void track_prep_body_t(const TrackBuffers& tb, const int b) {
   const int tid = threadIdx.x;
   const TrackFrameArgs args = tb.args[b];
   if (!args.run) return;
@@ -47,7 +50,7 @@ static __device__ void track_prep_body(const TrackBuffers& tb, const int b) {
     const EgoTf e = tb.ego[b];
     const float* __restrict__ src = tb.boxes_sensor + (long)b * kMaxBoxesPerFrame * 24;
     float* dst = tb.boxes_out + (long)b * tb.box_stride;
-    for (int i = tid; i < M * 8; i += 256) {
+    for (int i = tid; i < M * 8; i += kThreads) {
       const float* p = src + (long)i * 3;
       float* q = dst + (long)i * 3;
       const float x = p[0], y = p[1], z = p[2];
@@ -59,11 +62,11 @@ static __device__ void track_prep_body(const TrackBuffers& tb, const int b) {
   }
   // trackPoints :713-736 — centre of every box
   Vec2d* __restrict__ cp = tb.cp + (long)b * kMaxBoxesPerFrame;
-  for (int k = tid; k < M; k += 256) { double x, y; cp_from_bbox(boxes + (long)k * 24, &x, &y); cp[k].x = x; cp[k].y = y; }
+  for (int k = tid; k < M; k += kThreads) { double x, y; cp_from_bbox(boxes + (long)k * 24, &x, &y); cp[k].x = x; cp[k].y = y; }
   if (args.first_frame) {  // :741-795 — seed exactly one track at a hard-coded position; nothing else happens in this frame
     // (also the start of a stream after mot_reset / mot_reset_slot / mot_reset_tracks_slot: every slot is free again)
     unsigned long long* __restrict__ used = tb.used + (long)b * ((tb.T + 63) / 64);
-    for (int w = tid; w < (tb.T + 63) / 64; w += 256) used[w] = 0ull;
+    for (int w = tid; w < (tb.T + 63) / 64; w += kThreads) used[w] = 0ull;
     __syncthreads();
     if (tid == 0) {
       int n = 0;
@@ -85,11 +88,13 @@ static __device__ void track_prep_body(const TrackBuffers& tb, const int b) {
     }
     return;
   }
-  // work items of this stream: its live tracks (list left by the previous step's finish kernel), in any order
-  __shared__ int s_base;
-  const int nlive = tb.nlive[b];
-  if (tid == 0) s_base = nlive ? atomicAdd(tb.n_items, nlive) : 0;
-  __syncthreads();
-  TrackItem* __restrict__ items = tb.items + s_base;
-  for (int i = tid; i < nlive; i += 256) { TrackItem it; it.b = b; it.li = i; items[i] = it; }
+  if (kItems) {   // work items of this stream: its live tracks (list left by the previous step's finish kernel), in any order
+    __shared__ int s_base;
+    const int nlive = tb.nlive[b];
+    if (tid == 0) s_base = nlive ? atomicAdd(tb.n_items, nlive) : 0;
+    __syncthreads();
+    TrackItem* __restrict__ items = tb.items + s_base;
+    for (int i = tid; i < nlive; i += kThreads) { TrackItem it; it.b = b; it.li = i; items[i] = it; }
+  }
 }
+static __device__ void track_prep_body(const TrackBuffers& tb, const int b) { track_prep_body_t<256, true>(tb, b); }

@@ -838,8 +838,7 @@ track_update_kernel(TrackBuffers tb) {
 // All loops run over the tracks that are RESIDENT (alive at the start of the step, born in it) except the merge's inner loop,
 // which the reference runs over every track ever created: that one reads 16-byte positions by reference index.
 constexpr int kMaxBornLds = kMaxBoxesPerFrame;   // a frame gives birth to at most one track per box
-__global__ void MOT_LAUNCH_BOUNDS(kTrackBlock)
-track_finish_kernel(TrackBuffers tb) {
+static __device__ void track_finish_body(const TrackBuffers& tb, const int b) {
   __shared__ unsigned long long s_matched[kGateWords];
   __shared__ int s_wcount[kTrackWaves];
   __shared__ int s_nlive, s_born, s_nvis, s_nz;
@@ -847,7 +846,6 @@ track_finish_kernel(TrackBuffers tb) {
   constexpr int kVisCap = 256;               // visible boxes of a stream held in LDS for the merge phase (more: the per-wave path)
   __shared__ double s_vb[kVisCap][12];       // corners 1..4 (x, y) and the two triangle centroids
   __shared__ int s_vi[kVisCap], s_vr[kVisCap];   // slot and reference index of the box's track
-  const int b = blockIdx.x;
   const int tid = threadIdx.x, lane = tlane(), wave = tid >> 6;
   if (b == 0 && tid == 0) *tb.n_items = 0;   // every per-track wave of this step has finished: re-arm the work list
   const TrackFrameArgs args = tb.args[b];
@@ -1070,6 +1068,39 @@ track_finish_kernel(TrackBuffers tb) {
   }
   if (tid == 0) { tb.nlive[b] = s_nlive; tb.nzomb[b] = s_nz; }
 }
+__global__ void MOT_LAUNCH_BOUNDS(kTrackBlock)
+track_finish_kernel(TrackBuffers tb) {
+  track_finish_body(tb, (int)blockIdx.x);
+}
+
+// ---- the whole frame step of a stream in ONE launch, one workgroup per stream: prologue (when the box stage has not run it), PA over
+// the stream's live tracks 32 at a time (8 waves x 4 groups), PB + PC likewise, then eviction / merge / birth / outputs — the phases
+// of the four kernels above separated by workgroup barriers instead of kernel boundaries (what one phase leaves in global memory for
+// the next — gate masks, flags, DevTrack — is written and read inside ONE workgroup: a barrier orders it). For contexts of few
+// streams — one sensor per process (the ROS nodes), sequence mode (mot_sequence_dev: 154 dependent steps of one stream), latency runs —
+// where a step is a chain of four launches whose every link waits for the previous one's tail; with hundreds of streams per launch
+// the four kernels above spread the tracks of all streams over the chip and this one would leave it to one CU per stream.
+constexpr int kStreamGroups = (kTrackBlock / 64) * kGroupsPerWave;
+__global__ void MOT_LAUNCH_BOUNDS(kTrackBlock)
+track_step_stream_kernel(TrackBuffers tb, int do_prep) {
+  __shared__ union StreamScratch { PredictScratch p[kStreamGroups]; UpdateScratch u[kStreamGroups]; } s_g;
+  const int b = blockIdx.x;
+  if (do_prep) { track_prep_body_t<kTrackBlock, false>(tb, b); __syncthreads(); }
+  const TrackFrameArgs args = tb.args[b];
+  if (args.run && !args.first_frame) {
+    const int nlive = tb.nlive[b];
+    const int g = (int)(threadIdx.x >> 6) * kGroupsPerWave + ggroup();
+    for (int i0 = 0; i0 < nlive; i0 += kStreamGroups) {
+      if (i0 + (int)(threadIdx.x >> 6) * kGroupsPerWave < nlive) predict_group(tb, &s_g.p[g], b, i0 + g, i0 + g < nlive);   // (wave-uniform: a wave with no track sits the round out)
+    }
+    __syncthreads();
+    for (int i0 = 0; i0 < nlive; i0 += kStreamGroups) {
+      if (i0 + (int)(threadIdx.x >> 6) * kGroupsPerWave < nlive) update_group(tb, &s_g.u[g], b, i0 + g, i0 + g < nlive);
+    }
+    __syncthreads();
+  }
+  track_finish_body(tb, b);
+}
 
 // live tracks of a stream, in id order, into the caller's fixed-size record block. The live list the finish kernel left for the next
 // step IS the set of tracks with track_manage != 0, in the order of their reference indices.
@@ -1126,6 +1157,13 @@ void mot_launch_track(const TrackBuffers& t, int batch, hipStream_t stream, bool
   int item_groups = batch * 8;   // 2 waves x 4 tracks each: one round covers 64 live tracks per stream; the chip holds 1280 such workgroups (5 per CU: the scratch above)
   item_groups = item_groups < 16 ? 16 : (item_groups > 1280 ? 1280 : item_groups);
 #endif
+#ifndef MOT_STREAM_KERNEL_MAX_BATCH
+#define MOT_STREAM_KERNEL_MAX_BATCH 32
+#endif
+  if (t.step_mode == MOT_TRACKER_STREAM || (t.step_mode == MOT_TRACKER_AUTO && batch <= MOT_STREAM_KERNEL_MAX_BATCH)) {   // few streams: the step as ONE launch, a workgroup per stream (see track_step_stream_kernel)
+    hipLaunchKernelGGL(track_step_stream_kernel, dim3(batch), dim3(kTrackBlock), 0, stream, t, prep_done ? 0 : 1);
+    return;
+  }
   if (!prep_done) hipLaunchKernelGGL(track_prep_kernel, dim3(batch), dim3(256), 0, stream, t);   // (fused path: done at the tail of the box stage)
   hipLaunchKernelGGL(track_predict_kernel, dim3(item_groups), dim3(kItemWaves * 64), 0, stream, t);
   hipLaunchKernelGGL(track_update_kernel, dim3(item_groups), dim3(kItemWaves * 64), 0, stream, t);

@@ -401,6 +401,7 @@ def single_stream(mot, torch, device, seq_dev, n_seq, stride, ego_v, ego_yaw, fr
             frame(f)
         c.synchronize()
         thr = F / (time.perf_counter() - t0)
+        final_tracks = c.get_tracks(0)
         # where a single frame's 0.2 ms goes: every kernel of the sequence timed alone on this one frame (HIP events around the kernel,
         # mot_time_stage) — their sum is what the GPU needs for the dependent chain even if launching cost nothing (what a hipGraph
         # could remove is the rest)
@@ -408,10 +409,43 @@ def single_stream(mot, torch, device, seq_dev, n_seq, stride, ego_v, ego_yaw, fr
             k_us = {k: c.time_stage(v, 1, 20 if v != 40 else 3) * 1e3 for k, v in K_IDS.items()}
         except Exception:
             k_us = None
+        # the same loop with the tracker step as FOUR launches (what contexts of many streams run; round 3's only form) instead of the one-launch
+        # stream kernel that contexts of few streams get by default (mot_set_tracker_mode)
+        split = None
+        try:
+            c.set_tracker_mode(1); c.reset(); c.synchronize()
+            t0 = time.perf_counter()
+            for f in range(F):
+                frame(f)
+            c.synchronize()
+            split = {"frames_per_s_back_to_back": round(F / (time.perf_counter() - t0), 1), "track_step_us": round(c.time_stage(40, 1, 3) * 1e3, 1)}
+            c.set_tracker_mode(0)
+        except Exception as e:
+            split = {"error": str(e)[:120]}
+    # ---- SEQUENCE MODE (mot_sequence_dev): the same 154 frames of the same ONE stream in one call — the stateless stages of all frames as one
+    # batch (slot = frame), the tracker's 154 steps chained on the device. BASELINE.json configs[3] as written (a recorded drive replayed).
+    seq_mode = None
+    try:
+        with mot.Context(device=device, max_points=stride, max_batch=F, max_tracks_total=256) as c:
+            fstride = int(seq_dev.stride(0))   # floats between consecutive frames of stream 0
+            n0 = np.ascontiguousarray(n_seq[:F, 0]); ts = 1.0e9 + 1e5 * np.arange(F)
+            def run():
+                c.sequence_dev(seq_dev[0, 0].data_ptr(), fstride, n0, ts, ego_v[:F], ego_yaw[:F])
+            run(); c.synchronize(); c.reset(); c.synchronize()
+            reps = []
+            for _ in range(3):
+                t0 = time.perf_counter(); run(); c.synchronize(); reps.append(time.perf_counter() - t0)
+                tr = c.get_tracks(0); c.reset(); c.synchronize()
+            same = bool(tr["n"] == final_tracks["n"] and all(np.array_equal(tr[k], final_tracks[k]) for k in ("track_manage", "lifetime", "is_static", "is_vis", "p", "v_yaw")))
+            seq_mode = {"frames": F, "ms_per_sequence": round(min(reps) * 1e3, 3), "frames_per_s": round(F / min(reps), 1), "frames_per_s_runs": [round(F / r, 1) for r in reps],
+                        "tracks_after_last_frame_equal_frame_by_frame_run": same, "tracks_ever": int(tr["n"]),
+                        "what": "mot_sequence_dev: one call for the whole 154-frame drive of ONE stream, wall clock call -> synchronise; results are those of the frame-by-frame loop above, bit for bit"}
+    except Exception as e:
+        seq_mode = {"error": str(e)[:200]}
     lat_ms = np.array(lat) * 1e3
-    return {"frames": F, "latency_ms": {"median": round(float(np.median(lat_ms)), 4), "p95": round(_pct(lat_ms, 95), 4), "max": round(float(lat_ms.max()), 4)},
+    return {"frames": F, "sequence_mode": seq_mode, "latency_ms": {"median": round(float(np.median(lat_ms)), 4), "p95": round(_pct(lat_ms, 95), 4), "max": round(float(lat_ms.max()), 4)},
             "frames_per_s_latency_bound": round(1e3 / float(np.mean(lat_ms)), 1), "frames_per_s_back_to_back": round(thr, 1),
-            "hbm_frac_back_to_back": round(frame_bytes * thr / 1e9 / HBM_PEAK_GBS, 5), "tracks_ever": n_tracks,
+            "hbm_frac_back_to_back": round(frame_bytes * thr / 1e9 / HBM_PEAK_GBS, 5), "tracks_ever": n_tracks, "with_four_launch_tracker_step": split,
             "with_launch_graphs": graphs,
             "kernel_chain_us": ({"sum": round(sum(k_us.values()), 1), "per_kernel": {k: round(v, 1) for k, v in k_us.items()},
                                  "what": "each kernel of the frame's sequence alone on ONE frame (event to event, includes that one launch): the dependent chain the GPU executes per frame; "

@@ -292,6 +292,15 @@ int mot_set_fused_outputs(mot_ctx* ctx, int flags);
  * Kernel timing (mot_profile_kernel) uses plain launches while it is armed. */
 int mot_set_launch_graphs(mot_ctx* ctx, int on);
 
+/* How a tracker step (immUkfJpdaf for one frame of every stream of the call) is launched. Results are identical in every mode.
+ *   MOT_TRACKER_AUTO (default)  by the number of streams in the call: STREAM up to 32, SPLIT beyond
+ *   MOT_TRACKER_SPLIT           four launches (prologue, prediction + gating, association + update, merge / birth / outputs), the tracks of
+ *                               ALL streams dealt over the whole chip: the throughput form (hundreds of streams per call)
+ *   MOT_TRACKER_STREAM          ONE launch, one workgroup per stream doing the four phases behind workgroup barriers: the latency form (one
+ *                               sensor per process, mot_sequence_dev's chained steps) — three launch boundaries fewer per frame */
+enum { MOT_TRACKER_AUTO = 0, MOT_TRACKER_SPLIT = 1, MOT_TRACKER_STREAM = 2 };
+int mot_set_tracker_mode(mot_ctx* ctx, int mode);
+
 /* The same for frames in HOST memory — what the reference's nodes receive, one message per frame
  * (OT/src/groundremove/main.cpp:91-136, OT0/src/main.cpp:51-95) — pipelined: the H2D copy of this batch runs on the
  * context's copy stream into one of two staging buffers while the kernels of the previous batch run. Returns when

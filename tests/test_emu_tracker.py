@@ -84,3 +84,52 @@ def test_fused_sequence_player_equals_the_stagewise_one(mot, oracle, synth):
                 live = o["track_manage"] > 0
                 assert np.allclose(got["tracks"]["p"][live], o["p"][live], rtol=1e-4, atol=1e-5), (f, s)
         T.close()
+
+
+def test_tracker_launch_modes_give_identical_results(mot, oracle):
+    """mot_set_tracker_mode: the step as four launches (tracks of all streams dealt over the chip — what the bench's 512-stream contexts run)
+    and as ONE launch with a workgroup per stream (what contexts of few streams run) must give the same bits: same phases, same order per
+    track, kernel boundaries replaced by workgroup barriers. Random and degenerate sequences on three streams at once, 40 live tracks."""
+    import build_emu
+    import seq_parity as SP
+    import test_emu_tracker_random as TR
+    import tracker_cases as TC
+    lib = build_emu.build()
+    results = {}
+    for mode in (1, 2):
+        res = []
+        with mot.Context(lib_path=lib, max_points=1024, max_batch=3, max_tracks_total=256) as c:
+            c.set_tracker_mode(mode)
+            seqs = [TR.sequence(70 + k, frames=20) if k < 2 else TR.hostile_sequence(5, frames=20) for k in range(3)]
+            for f in range(20):
+                for s in range(3):
+                    boxes, ts, v, yaw = seqs[s][f]
+                    c.ego_update(ts, v, yaw, s)
+                    tr = c.track_step(boxes, ts, s)
+                    res.append((tr, {int(i): c.track_state(int(i), slot=s) for i in np.nonzero(tr["track_manage"] > 0)[0]}))
+            # and the batched device entry point with many live tracks per stream (more than one round of 32 groups in the stream kernel)
+            st = None
+        results[mode] = res
+        st = TC.many_live_tracks(_ModeCtx(mot, mode), oracle, lambda a: (a.ctypes.data, lambda: None), lib_path=lib, streams=2, T=40, frames=14, spacing=9.0, min_live=40)
+        results[(mode, "many")] = st["max_rel_state_err"]
+    for (ta, sa), (tb_, sb) in zip(results[1], results[2]):
+        bits = lambda a: np.ascontiguousarray(a).view(np.uint8)   # (NaN outputs of a diverged track must be the same NaNs)
+        assert ta["n"] == tb_["n"] and all(np.array_equal(bits(ta[k]), bits(tb_[k])) for k in ("track_manage", "lifetime", "is_static", "is_vis", "p", "v_yaw", "vis_box"))
+        assert sa.keys() == sb.keys()
+        for i in sa:
+            for k in SP.STATE_KEYS:
+                assert np.array_equal(bits(np.asarray(sa[i][k])), bits(np.asarray(sb[i][k]))), (i, k)
+    assert results[(1, "many")] == results[(2, "many")]
+
+
+class _ModeCtx:
+    """the package with every new Context put into one tracker launch mode (for helpers that create their own contexts)"""
+
+    def __init__(self, mot, mode):
+        self._mot, self._mode = mot, mode
+
+    def __getattr__(self, k):
+        return getattr(self._mot, k)
+
+    def Context(self, *a, **kw):
+        c = self._mot.Context(*a, **kw); c.set_tracker_mode(self._mode); return c

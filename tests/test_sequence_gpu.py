@@ -61,3 +61,10 @@ def test_bench_on_a_kitti_shaped_drive(hip_lib, tmp_path):
     assert r.returncode == 0, r.stderr[-2000:]
     line = json.loads(r.stdout.strip().splitlines()[-1])
     assert line["data"] == "kitti" and line["value"] > 0 and line["config"]["kitti"]["frames"] >= 6 and line["all_outputs"]["value"] > 0
+
+
+def test_sequence_mode_on_the_device(hip_lib):
+    """mot_sequence_dev on the MI355X: a rendered 154-frame stream in ONE call against 154 calls of mot_frames_dev — boxes of every frame,
+    the per-frame live-track records and the final filter states bit for bit (tests/test_emu_sequence.py is the same check on the emulator)"""
+    r = subprocess.run([sys.executable, os.path.join(HERE, "seq_mode_gpu_run.py")], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "sequence mode ok" in r.stdout, (r.stdout[-1500:], r.stderr[-3000:])
