@@ -29,10 +29,11 @@ with mot.Context(max_points=stride, max_batch=F, max_tracks_total=256) as c:
         assert SP.bits_equal(c.get_boxes(f)["boxes"], bx), (f, "boxes")
         live = np.nonzero(tr["track_manage"] > 0)[0]
         assert k[f] == len(live) and np.array_equal(o[f]["id"][: k[f]], live), (f, k[f], len(live))
+        bits = lambda a: np.ascontiguousarray(a).view(np.uint8)   # (a diverging track's NaN outputs must be the same NaNs)
         for key in ("track_manage", "is_static", "is_vis", "lifetime", "p", "v_yaw", "vis_box"):
-            assert np.array_equal(o[f][key][: k[f]], tr[key][live]), (f, key)
+            assert np.array_equal(bits(o[f][key][: k[f]]), bits(tr[key][live])), (f, key)
     for i, so in states.items():
         sd = c.track_state(i)
         for key in SP.STATE_KEYS:
-            assert np.array_equal(np.asarray(sd[key]), np.asarray(so[key])), (i, key)
+            assert np.array_equal(bits(np.asarray(sd[key])), bits(np.asarray(so[key]))), (i, key)
 print("sequence mode ok:", F, "frames,", int(tr["n"]), "tracks ever,", len(states), "live at the end")

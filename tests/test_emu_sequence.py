@@ -78,7 +78,8 @@ def test_sequence_mode_equals_frame_by_frame(mot, synth):
             assert cnt[f] == len(live) and np.array_equal(out[f]["id"][: cnt[f]], live), (f, cnt[f], live)
             for key in ("track_manage", "is_static", "is_vis", "lifetime"):
                 assert np.array_equal(out[f][key][: cnt[f]], r["tracks"][key][live]), (f, key)
-            assert np.array_equal(out[f]["p"][: cnt[f]], r["tracks"]["p"][live]) and np.array_equal(out[f]["v_yaw"][: cnt[f]], r["tracks"]["v_yaw"][live])
+            bits = lambda a: np.ascontiguousarray(a).view(np.uint8)
+            assert np.array_equal(bits(out[f]["p"][: cnt[f]]), bits(r["tracks"]["p"][live])) and np.array_equal(bits(out[f]["v_yaw"][: cnt[f]]), bits(r["tracks"]["v_yaw"][live]))
         last = per_frame[-1]; tr = c.get_tracks(0)
         assert tr["n"] == last["tracks"]["n"] and all(np.array_equal(tr[k], last["tracks"][k]) for k in ("track_manage", "lifetime", "is_static", "is_vis", "p", "v_yaw", "vis_box"))
         for i, so in last["states"].items():
