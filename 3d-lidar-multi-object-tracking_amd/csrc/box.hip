@@ -60,6 +60,9 @@ constexpr int kLabelGridPct = MOT_LABEL_GRID_PCT;
 #ifndef MOT_LABEL_SPEC
 #define MOT_LABEL_SPEC 0
 #endif
+#ifndef MOT_XCD_LABEL
+#define MOT_XCD_LABEL 0
+#endif
 #ifndef MOT_LABEL_SPEC_PCT
 #define MOT_LABEL_SPEC_PCT 25
 #endif
@@ -107,7 +110,7 @@ __device__ __forceinline__ void stats_commit(ClusterStats* s, int count, int fir
 }
 
 __global__ void MOT_LAUNCH_BOUNDS(kLabelBlock)
-label_stats_kernel(MotDevParams p, ClusterBuffers c, int spec_n) {
+label_stats_kernel(MotDevParams p, ClusterBuffers c, int spec_n, int nframes) {
   constexpr int kWaves = kLabelBlock / 64, kPerWave = kGroupsPerWg / kWaves;
   // (tile, cluster) groups with their partial statistics, one region per wave (no atomics while they are produced)
   __shared__ PointGroup s_groups[kGroupsPerWg];
@@ -120,7 +123,12 @@ label_stats_kernel(MotDevParams p, ClusterBuffers c, int spec_n) {
   constexpr int kTilesPerChunk = kLabelChunk / 64;
   __shared__ int s_slot[kGroupsPerWg];
   __shared__ int s_tilecnt[kWgClusters][kTilesPerChunk + 1];   // +1: the 64 scanning threads walk different banks
-  const int b = blockIdx.y;
+#if MOT_XCD_LABEL
+  int b, blk_x;
+  if (!mot_xcd_frame(nframes, b, blk_x)) return;
+#else
+  const int b = blockIdx.y, blk_x = blockIdx.x;
+#endif
 #if !MOT_LABEL_SPEC
   const int n = c.counts[b * kCountsStride + kCntElev];
 #endif
@@ -138,17 +146,17 @@ label_stats_kernel(MotDevParams p, ClusterBuffers c, int spec_n) {
   // spec_n (a quarter of the batch's largest input cloud: hardly any frame has fewer elevated points, and every per-point buffer holds
   // `cap` records, so the reads are in bounds whatever n turns out to be; lanes at or beyond n are blanked afterwards). One of the
   // three dependent round trips at a workgroup's start (count -> points / cells -> labels) runs under another.
-  const bool spec = c.ecell != nullptr && (long)(blockIdx.x + 1) * kLabelChunk <= (long)spec_n;
+  const bool spec = c.ecell != nullptr && (long)(blk_x + 1) * kLabelChunk <= (long)spec_n;
   float4 qs0[kLabelItems]; unsigned ec0[kLabelItems];
   if (spec) {
-    const float4* __restrict__ pts0 = c.elevated + (long)b * c.cap + (long)blockIdx.x * kLabelChunk;
-    const unsigned short* __restrict__ ecell0 = c.ecell + (long)b * c.cap + (long)blockIdx.x * kLabelChunk;
+    const float4* __restrict__ pts0 = c.elevated + (long)b * c.cap + (long)blk_x * kLabelChunk;
+    const unsigned short* __restrict__ ecell0 = c.ecell + (long)b * c.cap + (long)blk_x * kLabelChunk;
 #pragma unroll
     for (int k = 0; k < kLabelItems; k++) { qs0[k] = pts0[k * kLabelBlock + threadIdx.x]; ec0[k] = ecell0[k * kLabelBlock + threadIdx.x]; }
   }
   const int n = c.counts[b * kCountsStride + kCntElev];
 #endif
-  for (int chunk = blockIdx.x; (long)chunk * kLabelChunk < n; chunk += gridDim.x) {
+  for (int chunk = blk_x; (long)chunk * kLabelChunk < n; chunk += gridDim.x) {
   const long base = (long)chunk * kLabelChunk;
   if (threadIdx.x < kWgClusters) {
     s_tab_label[threadIdx.x] = 0; s_tab_count[threadIdx.x] = 0; s_tab_first[threadIdx.x] = 0x7fffffff;
@@ -170,7 +178,7 @@ label_stats_kernel(MotDevParams p, ClusterBuffers c, int spec_n) {
   float4 qs[kLabelItems];
   int labs[kLabelItems];
 #if MOT_LABEL_SPEC
-  if (spec && chunk == (int)blockIdx.x) {
+  if (spec && chunk == blk_x) {
 #pragma unroll
     for (int k = 0; k < kLabelItems; k++) {
       const bool in = base + k * kLabelBlock + threadIdx.x < n;
@@ -1289,7 +1297,8 @@ void mot_launch_box_kernel(int which, const MotDevParams& p, const ClusterBuffer
     // lands on from frame to frame; with a multiple of 8 chunk x of EVERY frame sits on XCD x mod 8, and as only the first third of
     // the chunks hold points, some XCDs would get 3 of them per frame and others 2
     const int gx = kLabelGridPct >= 100 ? chunks : (((chunks * kLabelGridPct + 99) / 100) | 1);
-    hipLaunchKernelGGL(label_stats_kernel, dim3(gx, batch), dim3(kLabelBlock), 0, stream, p, c, (int)(((long)max_n * kLabelSpecPct / 100) < c.cap ? ((long)max_n * kLabelSpecPct / 100) : c.cap));
+    hipLaunchKernelGGL(label_stats_kernel, dim3(gx, MOT_XCD_LABEL ? (batch + 7) / 8 * 8 : batch), dim3(kLabelBlock), 0, stream, p, c,
+                       (int)(((long)max_n * kLabelSpecPct / 100) < c.cap ? ((long)max_n * kLabelSpecPct / 100) : c.cap), batch);
   }
   else if (which == 1) hipLaunchKernelGGL(cluster_gather_kernel, dim3(MOT_GATHER_GRID, batch), dim3(kBoxBlock), 0, stream, p, c);  // a frame's clusters are dealt round-robin to its workgroups
   else if (which == 3) {

@@ -1085,7 +1085,15 @@ __global__ void MOT_LAUNCH_BOUNDS(kTrackBlock)
 track_step_stream_kernel(TrackBuffers tb, int do_prep) {
   __shared__ union StreamScratch { PredictScratch p[kStreamGroups]; UpdateScratch u[kStreamGroups]; } s_g;
   const int b = blockIdx.x;
+#ifdef MOT_DBG_STREAM_TIMING   // phase clocks (100 MHz wall clock) of stream b into the work list's storage, which this kernel does not use: tools/time_stream_kernel.py
+  long long* dbg = reinterpret_cast<long long*>(tb.items) + (long)b * 8;
+  const long long dbg_t0 = wall_clock64();
+#define STREAM_T(slot) do { if (threadIdx.x == 0) dbg[slot] = wall_clock64() - dbg_t0; } while (0)
+#else
+#define STREAM_T(slot)
+#endif
   if (do_prep) { track_prep_body_t<kTrackBlock, false>(tb, b); __syncthreads(); }
+  STREAM_T(0);
   const TrackFrameArgs args = tb.args[b];
   if (args.run && !args.first_frame) {
     const int nlive = tb.nlive[b];
@@ -1093,13 +1101,21 @@ track_step_stream_kernel(TrackBuffers tb, int do_prep) {
     for (int i0 = 0; i0 < nlive; i0 += kStreamGroups) {
       if (i0 + (int)(threadIdx.x >> 6) * kGroupsPerWave < nlive) predict_group(tb, &s_g.p[g], b, i0 + g, i0 + g < nlive);   // (wave-uniform: a wave with no track sits the round out)
     }
+    STREAM_T(1);
     __syncthreads();
+    STREAM_T(2);
     for (int i0 = 0; i0 < nlive; i0 += kStreamGroups) {
       if (i0 + (int)(threadIdx.x >> 6) * kGroupsPerWave < nlive) update_group(tb, &s_g.u[g], b, i0 + g, i0 + g < nlive);
     }
+    STREAM_T(3);
     __syncthreads();
+    STREAM_T(4);
   }
   track_finish_body(tb, b);
+  STREAM_T(5);
+#ifdef MOT_DBG_STREAM_TIMING
+  if (threadIdx.x == 0) dbg[6] = tb.nlive[b];
+#endif
 }
 
 // live tracks of a stream, in id order, into the caller's fixed-size record block. The live list the finish kernel left for the next
