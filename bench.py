@@ -867,12 +867,15 @@ def main():
         frames = B * F * args.steps * world
         # HBM bytes per launch from the committed PMC passes of this command (FETCH_SIZE x2 on gfx950 + WRITE_SIZE, KB), same launch size only
         traffic, traffic_src = None, None
-        pmc_path = os.path.join(ROOT, "profiles", "r03_pmc_B512.json")
+        import glob
+        PROF = sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]_pmc_B512.json")))   # the latest round's committed counter passes
+        pmc_path = PROF[-1] if PROF else ""
+        RND = os.path.basename(pmc_path)[:3] if PROF else "r04"
         if N == 120000 and os.path.exists(pmc_path):
             pmc = json.load(open(pmc_path)).get(dom_kernel)
             if pmc and "FETCH_SIZE" in pmc and "WRITE_SIZE" in pmc:
                 traffic = int((2.0 * pmc["FETCH_SIZE"] + pmc["WRITE_SIZE"]) * 1024 / 512 * BL)
-                traffic_src = (f"profiles/r03_pmc_B512.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this pipeline at 512 frames per launch (FETCH_SIZE x 2: the gfx950 "
+                traffic_src = (f"profiles/{RND}_pmc_B512.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this pipeline at 512 frames per launch (FETCH_SIZE x 2: the gfx950 "
                                f"correction for wide coalesced reads)" + ("" if BL == 512 else f", scaled to the {BL} frames of a launch here"))
         out = {
             "metric": "LiDAR frames/sec (120k-pt 64-beam cloud) end-to-end ground->cluster->track",
@@ -901,11 +904,11 @@ def main():
                          "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_src,
                          "kernel_ms": {"mean": round(dom_ms, 5), "min": round(solo["min_ms"], 5), "max": round(solo["max_ms"], 5), "samples": solo["samples"],
                                        "how": "HIP event pairs around the kernel's launch on its own stream (mot_profile_kernel), the whole pipeline running on ONE context, "
-                                              "nothing else on the GPU; rocprofv3 summary of the same schedule: profiles/r03_kernel_trace_B512_1ctx.txt"},
+                                              f"nothing else on the GPU; rocprofv3 summary of the same schedule: profiles/{RND}_kernel_trace_B512_1ctx.txt"},
                          "kernel_ms_in_timed_region": {"mean": round(shared_ms, 5), "min": round(min(p["min_ms"] for p in prof), 5), "max": round(max(p["max_ms"] for p in prof), 5), "samples": nsamp,
                                        "frac_if_taken_alone": round(alg_bytes[dom] / (shared_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if shared_ms > 0 else None,
                                        "how": f"the same event pairs inside the timed region, where {NC} contexts' kernels run concurrently and share HBM and CUs: a launch's duration there is its "
-                                              "share of the machine (see pipeline_frac for the whole); rocprofv3 summary: profiles/r03_kernel_trace_B2048_4ctx.txt"},
+                                              f"share of the machine (see pipeline_frac for the whole); rocprofv3 summary: profiles/{RND}_kernel_trace_B2048_4ctx.txt"},
                          "algorithmic_bytes_per_launch": {k: int(v) for k, v in alg_bytes.items()},
                          "pipeline_bytes_per_frame": int(frame_bytes),
                          "pipeline_frac": round(frame_bytes * B * F / (dt / args.steps) / 1e9 / HBM_PEAK_GBS, 4)},
