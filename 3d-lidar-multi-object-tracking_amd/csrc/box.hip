@@ -53,20 +53,6 @@ constexpr int kLabelBlock = MOT_LABEL_BLOCK;
 #endif
 constexpr int kLabelItems = MOT_LABEL_ITEMS;
 constexpr int kLabelChunk = kLabelBlock * kLabelItems;
-#ifndef MOT_LABEL_GRID_PCT
-#define MOT_LABEL_GRID_PCT 100
-#endif
-constexpr int kLabelGridPct = MOT_LABEL_GRID_PCT;
-#ifndef MOT_LABEL_SPEC
-#define MOT_LABEL_SPEC 0
-#endif
-#ifndef MOT_XCD_LABEL
-#define MOT_XCD_LABEL 0
-#endif
-#ifndef MOT_LABEL_SPEC_PCT
-#define MOT_LABEL_SPEC_PCT 25
-#endif
-constexpr int kLabelSpecPct = MOT_LABEL_SPEC_PCT;
 constexpr unsigned long long kArgminInit = ~0ull;   // nothing compared below 999 yet
 constexpr unsigned long long kArgmaxInit = 0ull;    // nothing compared above -999 yet
 
@@ -110,7 +96,7 @@ __device__ __forceinline__ void stats_commit(ClusterStats* s, int count, int fir
 }
 
 __global__ void MOT_LAUNCH_BOUNDS(kLabelBlock)
-label_stats_kernel(MotDevParams p, ClusterBuffers c, int spec_n, int nframes) {
+label_stats_kernel(MotDevParams p, ClusterBuffers c) {
   constexpr int kWaves = kLabelBlock / 64, kPerWave = kGroupsPerWg / kWaves;
   // (tile, cluster) groups with their partial statistics, one region per wave (no atomics while they are produced)
   __shared__ PointGroup s_groups[kGroupsPerWg];
@@ -123,41 +109,15 @@ label_stats_kernel(MotDevParams p, ClusterBuffers c, int spec_n, int nframes) {
   constexpr int kTilesPerChunk = kLabelChunk / 64;
   __shared__ int s_slot[kGroupsPerWg];
   __shared__ int s_tilecnt[kWgClusters][kTilesPerChunk + 1];   // +1: the 64 scanning threads walk different banks
-#if MOT_XCD_LABEL
-  int b, blk_x;
-  if (!mot_xcd_frame(nframes, b, blk_x)) return;
-#else
-  const int b = blockIdx.y, blk_x = blockIdx.x;
-#endif
-#if !MOT_LABEL_SPEC
+  const int b = blockIdx.y;
   const int n = c.counts[b * kCountsStride + kCntElev];
-#endif
   // (one workgroup per chunk of the largest possible frame; two thirds find nothing to do and leave. Fewer workgroups that loop
   // over the chunks are SLOWER — 190 us with 24 per frame, 197 with 8, against 176: profiles/r02_block_size_variants.txt — and
   // still are when the next chunk's cells / labels / points are requested ahead: 178-208 us against 160 for 6-16 persistent
   // workgroups per frame, profiles/r03_box_stage_experiments.txt: many independent workgroups hide the three dependent round
   // trips at a chunk's start better than any one workgroup's prefetch)
-  // The grid covers kLabelGridPct % of the chunks the largest frame of the batch COULD have (its elevated points are counted on the
-  // device: every input point might be one); a frame with more elevated points than that has its workgroups take a second chunk,
-  // gridDim.x further on. A third of the input is elevated in a street scene, so a grid sized for all of it is two thirds empty
-  // workgroups — each of which still occupies eight wave slots for the round trip of the count it exits on.
-#if MOT_LABEL_SPEC
-  // The chunk's points and cells are requested BEFORE the frame's count of elevated points has arrived, when the chunk lies below
-  // spec_n (a quarter of the batch's largest input cloud: hardly any frame has fewer elevated points, and every per-point buffer holds
-  // `cap` records, so the reads are in bounds whatever n turns out to be; lanes at or beyond n are blanked afterwards). One of the
-  // three dependent round trips at a workgroup's start (count -> points / cells -> labels) runs under another.
-  const bool spec = c.ecell != nullptr && (long)(blk_x + 1) * kLabelChunk <= (long)spec_n;
-  float4 qs0[kLabelItems]; unsigned ec0[kLabelItems];
-  if (spec) {
-    const float4* __restrict__ pts0 = c.elevated + (long)b * c.cap + (long)blk_x * kLabelChunk;
-    const unsigned short* __restrict__ ecell0 = c.ecell + (long)b * c.cap + (long)blk_x * kLabelChunk;
-#pragma unroll
-    for (int k = 0; k < kLabelItems; k++) { qs0[k] = pts0[k * kLabelBlock + threadIdx.x]; ec0[k] = ecell0[k * kLabelBlock + threadIdx.x]; }
-  }
-  const int n = c.counts[b * kCountsStride + kCntElev];
-#endif
-  for (int chunk = blk_x; (long)chunk * kLabelChunk < n; chunk += gridDim.x) {
-  const long base = (long)chunk * kLabelChunk;
+  const long base = (long)blockIdx.x * kLabelChunk;
+  if (base >= n) return;
   if (threadIdx.x < kWgClusters) {
     s_tab_label[threadIdx.x] = 0; s_tab_count[threadIdx.x] = 0; s_tab_first[threadIdx.x] = 0x7fffffff;
     s_tab_rz[threadIdx.x] = mot_float_key(-99.f); s_tab_rmin[threadIdx.x] = kArgminInit; s_tab_rmax[threadIdx.x] = kArgmaxInit;
@@ -177,18 +137,6 @@ label_stats_kernel(MotDevParams p, ClusterBuffers c, int spec_n, int nframes) {
   // all loads first, then all label gathers: 8 + 8 independent requests in flight instead of 16 dependent round trips
   float4 qs[kLabelItems];
   int labs[kLabelItems];
-#if MOT_LABEL_SPEC
-  if (spec && chunk == blk_x) {
-#pragma unroll
-    for (int k = 0; k < kLabelItems; k++) {
-      const bool in = base + k * kLabelBlock + threadIdx.x < n;
-      qs[k] = in ? qs0[k] : make_float4(1.0e9f, 1.0e9f, 0.f, 0.f);
-      const unsigned e = in ? ec0[k] : 0xffffu;
-      labs[k] = e != 0xffffu ? (int)((e >> 8) * (unsigned)p.num_grid + (e & 255u)) : -1;
-    }
-  } else
-#endif
-  {
 #pragma unroll
   for (int k = 0; k < kLabelItems; k++) {
     long i = base + k * kLabelBlock + threadIdx.x;
@@ -208,7 +156,6 @@ label_stats_kernel(MotDevParams p, ClusterBuffers c, int spec_n, int nframes) {
       const int bit = mot_cart_bit(p, qs[k].x, qs[k].y);   // guarded fast cell (two IEEE divides per point otherwise), exact fallback
       labs[k] = bit >= 0 ? (bit >> 8) * p.num_grid + (bit & 255) : -1;
     }
-  }
   }
 #pragma unroll
   for (int k = 0; k < kLabelItems; k++) labs[k] = labs[k] >= 0 ? grid[labs[k]] : 0;
@@ -330,8 +277,8 @@ label_stats_kernel(MotDevParams p, ClusterBuffers c, int spec_n, int nframes) {
                  s_tab_rmin[threadIdx.x], s_tab_rmax[threadIdx.x], my_groups);
   __syncthreads();
   // the workgroup's table, for the index kernel's cross-chunk prefixes
-  if (threadIdx.x < kWgClusters && chunk < c.max_wg)
-    c.wgtab[((long)b * c.max_wg + chunk) * kWgClusters + threadIdx.x] = make_int2(s_tab_label[threadIdx.x], s_tab_count[threadIdx.x] | (my_groups << 16));
+  if (threadIdx.x < kWgClusters && (int)blockIdx.x < c.max_wg)
+    c.wgtab[((long)b * c.max_wg + blockIdx.x) * kWgClusters + threadIdx.x] = make_int2(s_tab_label[threadIdx.x], s_tab_count[threadIdx.x] | (my_groups << 16));
   // the (tile, cluster) groups leave with ONE returning global atomic (a slot reservation)
   const int gb = s_gbase;
   for (int t = threadIdx.x; t < ng; t += kLabelBlock) {
@@ -349,8 +296,6 @@ label_stats_kernel(MotDevParams p, ClusterBuffers c, int spec_n, int nframes) {
   }
   B1_T(5);
   B1_T_VALUE(6, ng);
-  __syncthreads();   // (a second chunk re-arms the tables)
-  }
 }
 
 // ------------------------------------------------------------------------------------------ B1b
@@ -1292,14 +1237,7 @@ void mot_launch_stats_init(const ClusterBuffers& c, int batch, hipStream_t strea
 void mot_launch_box_kernel(int which, const MotDevParams& p, const ClusterBuffers& c, int batch, int max_n, hipStream_t stream) {
   int chunks = (max_n + kLabelChunk - 1) / kLabelChunk;
   if (chunks < 1) chunks = 1;
-  if (which == 0) {
-    // workgroups go to the 8 XCDs round-robin by their linear id (x + gridDim.x * frame): an ODD gridDim.x rotates the XCD a given chunk
-    // lands on from frame to frame; with a multiple of 8 chunk x of EVERY frame sits on XCD x mod 8, and as only the first third of
-    // the chunks hold points, some XCDs would get 3 of them per frame and others 2
-    const int gx = kLabelGridPct >= 100 ? chunks : (((chunks * kLabelGridPct + 99) / 100) | 1);
-    hipLaunchKernelGGL(label_stats_kernel, dim3(gx, MOT_XCD_LABEL ? (batch + 7) / 8 * 8 : batch), dim3(kLabelBlock), 0, stream, p, c,
-                       (int)(((long)max_n * kLabelSpecPct / 100) < c.cap ? ((long)max_n * kLabelSpecPct / 100) : c.cap), batch);
-  }
+  if (which == 0) hipLaunchKernelGGL(label_stats_kernel, dim3(chunks, batch), dim3(kLabelBlock), 0, stream, p, c);
   else if (which == 1) hipLaunchKernelGGL(cluster_gather_kernel, dim3(MOT_GATHER_GRID, batch), dim3(kBoxBlock), 0, stream, p, c);  // a frame's clusters are dealt round-robin to its workgroups
   else if (which == 3) {
     hipLaunchKernelGGL(cluster_rect_kernel, dim3(MOT_RECT_GRID, batch), dim3(kRectBlock), 0, stream, p, c);

@@ -322,30 +322,19 @@ polar_filter_kernel(MotDevParams p, GroundBuffers g) {
 // OT0/src/main.cpp:63-79 drops groundCloud after the call; mot_get_ground re-runs this kernel with kGround = true when a caller
 // asks for it): 16 N_g fewer bytes written per frame, a quarter of this kernel's traffic on a street scene.
 template <bool kGround>
-#ifndef MOT_XCD_COMPACT
-#define MOT_XCD_COMPACT 0
-#endif
-__device__ __forceinline__ void classify_compact_body(const MotDevParams& p, const GroundBuffers& g, const int nframes) {
+__device__ __forceinline__ void classify_compact_body(const MotDevParams& p, const GroundBuffers& g) {
   __shared__ int s_chunk;
   __shared__ int s_cnt[kSubTiles];  // per 64-point tile counts (elevated << 16 | ground) -> exclusive prefixes
   __shared__ int s_base_e, s_base_g;
   // occupancy of the cluster stage's Cartesian grid by this chunk's elevated points: "cell seen >= 1" / "seen >= 2"
   __shared__ unsigned s_occ_a[kPlaneWords], s_occ_b[kPlaneWords];
   __shared__ int s_occ_n;
-#if MOT_XCD_COMPACT
-  int b, blk_x;   // a frame's chunks on one XCD: its thresholds in one L2, its look-back descriptors polled inside one XCD (mot_wave.h)
-  if (!mot_xcd_frame(nframes, b, blk_x)) return;
-#else
-  const int blk_x = blockIdx.x;
-#endif
-#if !MOT_XCD_COMPACT
   const int b = blockIdx.y;   // (frames in the REVERSE order of the min-z kernel, so that its last-read frames might still sit in the Infinity Cache: +1.5 % with one
                               // context, -3 % with four; a second pass over <= 256 MiB reads at 6.0-6.7 TB/s against 5.2-6.3 cold — profiles/r03_infinity_cache_probe.txt)
-#endif
   const int n = g.n[b];
   const int nchunks = (n + kCompactChunk - 1) / kCompactChunk;
-  if (blk_x >= nchunks) {
-    if (nchunks == 0 && blk_x == 0 && threadIdx.x == 0) { g.counts[b * kCountsStride + kCntElev] = 0; g.counts[b * kCountsStride + kCntGround] = 0; g.counts[b * kCountsStride + kCntDropped] = 0; }
+  if ((int)blockIdx.x >= nchunks) {
+    if (nchunks == 0 && blockIdx.x == 0 && threadIdx.x == 0) { g.counts[b * kCountsStride + kCntElev] = 0; g.counts[b * kCountsStride + kCntGround] = 0; g.counts[b * kCountsStride + kCntDropped] = 0; }
     return;
   }
   const bool occupancy = g.occ_list != nullptr;   // uniform
@@ -570,9 +559,9 @@ __device__ __forceinline__ void classify_compact_body(const MotDevParams& p, con
   }
 }
 __global__ void MOT_LAUNCH_BOUNDS(kCompactBlock)
-classify_compact_kernel(MotDevParams p, GroundBuffers g, int nframes) { classify_compact_body<true>(p, g, nframes); }
+classify_compact_kernel(MotDevParams p, GroundBuffers g) { classify_compact_body<true>(p, g); }
 __global__ void MOT_LAUNCH_BOUNDS(kCompactBlock)
-classify_compact_elevated_kernel(MotDevParams p, GroundBuffers g, int nframes) { classify_compact_body<false>(p, g, nframes); }
+classify_compact_elevated_kernel(MotDevParams p, GroundBuffers g) { classify_compact_body<false>(p, g); }
 
 // ------------------------------------------------------------------------------------------ input decode
 // PointCloud2 records -> float4 (include/mot.h, mot_decode_pointcloud2_dev). HBM-bound gather: point_step bytes read,
@@ -611,9 +600,8 @@ void mot_launch_ground_kernel(int which, const MotDevParams& p, const GroundBuff
   if (which == 0) hipLaunchKernelGGL(polar_minz_kernel, dim3(chunks, batch), dim3(kGroundBlock), 0, stream, p, g);
   else if (which == 1) hipLaunchKernelGGL(polar_filter_kernel, dim3(batch), dim3(kFilterBlock), 0, stream, p, g);
   else if (which == 2) {
-    const int gy = MOT_XCD_COMPACT ? (batch + 7) / 8 * 8 : batch;
-    if (g.ground) hipLaunchKernelGGL(classify_compact_kernel, dim3(cchunks, gy), dim3(kCompactBlock), 0, stream, p, g, batch);
-    else hipLaunchKernelGGL(classify_compact_elevated_kernel, dim3(cchunks, gy), dim3(kCompactBlock), 0, stream, p, g, batch);   // ground cloud on demand
+    if (g.ground) hipLaunchKernelGGL(classify_compact_kernel, dim3(cchunks, batch), dim3(kCompactBlock), 0, stream, p, g);
+    else hipLaunchKernelGGL(classify_compact_elevated_kernel, dim3(cchunks, batch), dim3(kCompactBlock), 0, stream, p, g);   // ground cloud on demand
   }
 }
 

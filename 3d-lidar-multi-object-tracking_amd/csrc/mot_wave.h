@@ -177,18 +177,3 @@ struct OpOrU64 { __device__ __forceinline__ unsigned long long operator()(unsign
 struct OpMaxU64 { __device__ __forceinline__ unsigned long long operator()(unsigned long long a, unsigned long long b) const { return a > b ? a : b; } };
 
 #endif  // MOT_WAVE_H_
-
-// ---- XCD-aware placement of a frame's workgroups ---------------------------------------------------------------------------------
-// Workgroups of a launch are dealt to the chip's 8 XCDs round-robin by their linear id (MI355X_MICROARCH.md: "block b runs on XCD
-// b % 8" — observed, usable for speed only, never for correctness), and every XCD has an L2 of its own. With the plain (chunk, frame)
-// grid the chunks of ONE frame land on all eight XCDs, so whatever they share — the frame's label grid (250 KB, gathered per point),
-// its ground thresholds, the look-back descriptors they poll — is fetched into eight L2s and polled across the fabric. Here the linear
-// id is re-read as (xcd = id % 8, j = id / 8) and frame = (j / X) * 8 + xcd, chunk = j % X: every chunk of a frame runs on the frame's
-// own XCD, eight frames advance side by side. The grid is (X, 8 * ceil(frames / 8)); returns false for a padding workgroup.
-__device__ __forceinline__ bool mot_xcd_frame(int nframes, int& b, int& x) {
-  const unsigned X = gridDim.x, lin = blockIdx.x + X * blockIdx.y;
-  const unsigned r = lin & 7u, j = lin >> 3;
-  b = (int)((j / X) * 8u + r); x = (int)(j % X);
-  return b < nframes;
-}
-
