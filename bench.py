@@ -592,6 +592,7 @@ def main():
     ap.add_argument("--outputs", choices=["headline", "all"], default="headline", help="all: the HEADLINE itself runs with every by-product of the reference written "
                     "(mot_set_fused_outputs GROUND | MASK | LABELS); default: the headline writes what the next stage reads, and the all-outputs rate is measured in a second, "
                     "shorter timed region of the same run and reported beside it as `all_outputs`")
+    ap.add_argument("--no-all-outputs", action="store_true", help="skip the second timed region (every output written): profiling runs, whose per-kernel averages it would mix into")
     ap.add_argument("--kitti-dir", default=os.environ.get("MOT_KITTI_DIR"), help="a KITTI raw drive directory (…/2011_09_26_drive_0005_sync: velodyne_points/data/*.bin, oxts/data/*.txt): "
                     "the benched streams are that drive's own scans and ego motion (`data: kitti`), every stream of the GPU replaying the drive — the only real sequence the reference names "
                     "(README.md:154; its ego fixtures OT0/src/imm_ukf_jpda.cpp:65-72). Default (no such data in this image): synthetic streams. Also read from $MOT_KITTI_DIR")
@@ -810,7 +811,7 @@ def main():
     all_out = None
     prof = [cx.profile_read() for cx in ctxs] if rank == 0 else None   # the dominant kernel's event pairs of the timed region (read before anything else is launched)
     host_timed = (host_issue[0], host_cpu[0])   # (run_frames overwrites them)
-    if rank == 0 and world == 1 and args.outputs == "headline" and not variant:
+    if rank == 0 and world == 1 and args.outputs == "headline" and not variant and not args.no_all_outputs:
         try:
             k_all = max(2, min(4, args.steps))
             for cx in ctxs:

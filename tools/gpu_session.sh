@@ -18,7 +18,7 @@ cd "${GRAFT_REPO_ROOT:-$(dirname "$0")/..}"; export TMPDIR=/tmp
 NAME=$1; shift; O=gpurun_out/$NAME; mkdir -p $O
 trace() {   # $1 tag, rest: bench args
   local tag=$1; shift
-  timeout -k 5 600 rocprofv3 --kernel-trace --stats -d $O/prof_$tag -o kt -- python bench.py --no-aux --no-cpu-baseline "$@" > $O/bench_under_rocprof_$tag.json 2> $O/prof_$tag.log
+  timeout -k 5 600 rocprofv3 --kernel-trace --stats -d $O/prof_$tag -o kt -- python bench.py --no-aux --no-cpu-baseline --no-all-outputs "$@" > $O/bench_under_rocprof_$tag.json 2> $O/prof_$tag.log
   python profiles/summarize_rocpd.py $O/prof_$tag/kt_results.db --tail=60 > $O/kernel_trace_$tag.txt 2>&1; grep -v "at::native\|rocprim" $O/kernel_trace_$tag.txt | head -24
   rm -rf $O/prof_$tag
 }
@@ -33,7 +33,7 @@ for step in "$@"; do
     trace1) trace B512_1ctx --steps 3 --warmup 1 --batch 512 --contexts 1 ;;
     trace4) trace B2048_4ctx ;;
     pmc) for ctr in $(echo ${a1:-FETCH_SIZE,WRITE_SIZE} | tr , ' '); do
-           timeout -k 5 170 rocprofv3 --kernel-trace --pmc $ctr -d $O/pmc_$ctr -o p -- python bench.py --steps 1 --warmup 0 --frames 12 --no-aux --no-cpu-baseline --batch 512 --contexts 1 > $O/pmc_$ctr.log 2>&1; echo "$ctr rc=$?"
+           timeout -k 5 170 rocprofv3 --kernel-trace --pmc $ctr -d $O/pmc_$ctr -o p -- python bench.py --steps 1 --warmup 0 --frames 12 --no-aux --no-cpu-baseline --no-all-outputs --batch 512 --contexts 1 > $O/pmc_$ctr.log 2>&1; echo "$ctr rc=$?"
          done
          python profiles/summarize_pmc.py $(for ctr in $(echo ${a1:-FETCH_SIZE,WRITE_SIZE} | tr , ' '); do echo $O/pmc_$ctr/p_results.db; done) --json=$O/pmc_B512.json > $O/pmc_B512.txt 2>&1
          grep -v "at::native\|rocprim" $O/pmc_B512.txt | head -20; rm -rf $O/pmc_*/ ;;
