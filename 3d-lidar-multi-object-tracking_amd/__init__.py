@@ -74,7 +74,7 @@ EXPORTS = (
     "mot_get_boxes", "mot_get_tracks", "mot_export_tracks_dev", "mot_side_params_default", "mot_cluster_products", "mot_cluster_products_host", "mot_decode_pointcloud2_dev", "mot_time_stage",
     "mot_ground_remove_pointcloud2", "mot_box_fit_resident", "mot_frame_pointcloud2",
     "mot_reset_slot", "mot_frames_host", "mot_wait_uploads", "mot_host_alloc", "mot_host_free", "mot_fetch_tracks_async",
-    "mot_track_steps_dev", "mot_profile_kernel", "mot_profile_read", "mot_get_params", "mot_set_fused_outputs", "mot_set_tracker_mode", "mot_reset_tracks_slot", "mot_export_tracks_packed_dev", "mot_set_launch_graphs",
+    "mot_track_steps_dev", "mot_profile_kernel", "mot_profile_read", "mot_get_params", "mot_set_fused_outputs", "mot_set_tracker_mode", "mot_set_trace_ranges", "mot_reset_tracks_slot", "mot_export_tracks_packed_dev", "mot_set_launch_graphs",
 )
 ABI_VERSION = 4
 OUT_GROUND, OUT_MASK, OUT_LABELS = 1, 2, 4
@@ -184,6 +184,10 @@ class Context:
     def set_launch_graphs(self, on: bool = True):
         """send the fused entry points' launch sequence as one hipGraph launch (per-frame latency path; default off)"""
         self._ck(self.lib.mot_set_launch_graphs(self._h, int(on)))
+
+    def set_trace_ranges(self, on: bool = True):
+        """roctx ranges "mot:ground / cluster / box / tracker" around the stages of the fused entry points (rocprofv3 --marker-trace)"""
+        self._ck(self.lib.mot_set_trace_ranges(self._h, int(on)))
 
     def set_tracker_mode(self, mode: int):
         """0 auto (by the number of streams per call), 1 split (four launches, tracks of all streams over the whole chip), 2 stream (one launch, a workgroup per stream)"""

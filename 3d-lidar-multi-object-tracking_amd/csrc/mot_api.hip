@@ -2,6 +2,9 @@
 // Owns the device buffers, the HIP stream and the launch sequences. There is no CPU fallback:
 // mot_create() fails with MOT_E_HIP when no HIP device is present.
 #include "mot_internal.h"
+#ifndef MOT_HIPEMU
+#include <dlfcn.h>
+#endif
 #include "mot_debug_api.h"
 
 #include <math.h>
@@ -115,6 +118,7 @@ struct mot_ctx {
   std::vector<GraphEntry> graphs;
   int graph_mode = 0;                  // 0 off, 1 on; turned off for good when a capture fails
   int tracker_mode = MOT_TRACKER_AUTO; // mot_set_tracker_mode
+  int trace_ranges = 0;                // mot_set_trace_ranges
   hipEvent_t arg_ev[kArgRing] = {};
   bool arg_used[kArgRing] = {};
   int arg_next = 0;
@@ -548,6 +552,36 @@ static int set_batch(mot_ctx* c, const int* n_points, int batch, const float4* i
 enum { kK1 = 10, kK2 = 11, kK3 = 12, kC1 = 20, kC2 = 21, kB1 = 30, kB2 = 31, kB3 = 32, kB2b = 33, kB1b = 34, kT1 = 40 };
 
 // in-run timing of one kernel: an event pair around its launch, on the context stream, while the ring has room
+// roctx ranges around the stages of a launch sequence (the reference has none; a tracing aid of this library):
+// "mot:ground", "mot:cluster", "mot:box", "mot:tracker" on the issuing thread, visible in rocprofv3 --marker-trace / rocprof-sys
+// timelines next to the kernels they launched. libroctx64 is looked up at run time on first use (no link-time dependency; silently
+// off when it is not there). mot_set_trace_ranges(ctx, 1) turns them on.
+struct Roctx {
+  int (*push)(const char*) = nullptr;
+  int (*pop)() = nullptr;
+  bool tried = false;
+  void load() {
+    if (tried) return;
+    tried = true;
+#ifndef MOT_HIPEMU
+    for (const char* name : {"libroctx64.so", "libroctx64.so.4", "librocprofiler-sdk-roctx.so"}) {
+      if (void* h = dlopen(name, RTLD_LAZY | RTLD_LOCAL)) {
+        push = reinterpret_cast<int (*)(const char*)>(dlsym(h, "roctxRangePushA"));
+        pop = reinterpret_cast<int (*)()>(dlsym(h, "roctxRangePop"));
+        if (push && pop) return;
+        push = nullptr; pop = nullptr;
+      }
+    }
+#endif
+  }
+};
+static Roctx g_roctx;
+struct RangeScope {
+  bool on;
+  RangeScope(const mot_ctx* c, const char* name);
+  ~RangeScope() { if (on) (void)g_roctx.pop(); }
+};
+
 struct ProfScope {
   mot_ctx* c; bool on;
   ProfScope(mot_ctx* ctx, int id) : c(ctx), on(false) {
@@ -633,18 +667,28 @@ static void tf_velodyne_to_global(double x, double y, double yaw, float m[12]) {
 }
 
 // the kernels of one fused launch sequence, in order, on the context stream (plain launches, or under stream capture)
+RangeScope::RangeScope(const mot_ctx* c, const char* name) : on(false) {
+  if (!c->trace_ranges) return;
+  g_roctx.load();
+  if (g_roctx.push) { (void)g_roctx.push(name); on = true; }
+}
+
 static void issue_frame_kernels(mot_ctx* c, int batch, int max_n, int run_tracker, bool want_ground, bool want_mask, bool from_block) {
   GroundBuffers g = ground_buffers(c, c->last_in, c->last_in_stride, want_mask, true);
   if (!want_ground) g.ground = nullptr;   // the ground cloud on demand (mot_get_ground re-runs the compaction)
   if (from_block) g.launch = reinterpret_cast<const FrameLaunch*>(c->d_argblk + c->arg_off_launch);
-  { ProfScope ps(c, kK1); mot_launch_ground_kernel(0, c->dp, g, batch, max_n, c->stream); }
-  { ProfScope ps(c, kK2); mot_launch_ground_kernel(1, c->dp, g, batch, max_n, c->stream); }
-  { ProfScope ps(c, kK3); mot_launch_ground_kernel(2, c->dp, g, batch, max_n, c->stream); }
+  {
+    RangeScope rs(c, "mot:ground");
+    { ProfScope ps(c, kK1); mot_launch_ground_kernel(0, c->dp, g, batch, max_n, c->stream); }
+    { ProfScope ps(c, kK2); mot_launch_ground_kernel(1, c->dp, g, batch, max_n, c->stream); }
+    { ProfScope ps(c, kK3); mot_launch_ground_kernel(2, c->dp, g, batch, max_n, c->stream); }
+  }
   ClusterBuffers cb = cluster_buffers(c);
   cb.occ_list = c->d_occ_list; cb.occ_count = c->d_occ_count;   // the occupancy comes as the compaction kernel's per-chunk lists
   cb.ecell = g.ecell;                                            // ... and every elevated point's cell with it
   if (!(c->fused_outputs & MOT_OUT_LABELS)) cb.label = nullptr;  // per-point labels on demand (mot_get_clusters)
-  { ProfScope ps(c, kC2); mot_launch_cluster(c->dp, cb, batch, max_n, c->stream, true); }
+  { RangeScope rs(c, "mot:cluster"); ProfScope ps(c, kC2); mot_launch_cluster(c->dp, cb, batch, max_n, c->stream, true); }
+  RangeScope rb(c, "mot:box");
   { ProfScope ps(c, kB1); mot_launch_box_kernel(0, c->dp, cb, batch, max_n, c->stream); }
   { ProfScope ps(c, kB1b); mot_launch_box_kernel(4, c->dp, cb, batch, max_n, c->stream); }
   { ProfScope ps(c, kB2); mot_launch_box_kernel(1, c->dp, cb, batch, max_n, c->stream); }
@@ -652,7 +696,8 @@ static void issue_frame_kernels(mot_ctx* c, int batch, int max_n, int run_tracke
   if (run_tracker) {   // the tracker's per-frame prologue rides at the tail of the box stage's last kernel (same geometry)
     const TrackBuffers tb = track_buffers(c, true);
     { ProfScope ps(c, kB3); mot_launch_box_finalize_prep(c->dp, cb, tb, batch, c->stream); }
-    { ProfScope ps(c, kT1); mot_launch_track(tb, batch, c->stream, true); }
+    if (rb.on) { (void)g_roctx.pop(); rb.on = false; }
+    { RangeScope rt(c, "mot:tracker"); ProfScope ps(c, kT1); mot_launch_track(tb, batch, c->stream, true); }
   } else {
     ProfScope ps(c, kB3); mot_launch_box_kernel(2, c->dp, cb, batch, max_n, c->stream);
   }
@@ -779,6 +824,7 @@ extern "C" int mot_sequence_dev(mot_ctx* c, const float* d_xyzw, long frame_stri
   c->label_state.assign(c->batch, (c->fused_outputs & MOT_OUT_LABELS) ? 1 : 0);
   issue_frame_kernels(c, K, max_n, 0, want_ground, want_mask, false);   // slots = frames; ends with the plain box_finalize_kernel
   const TrackBuffers base = track_buffers(c, true);
+  RangeScope rt(c, "mot:tracker (sequence)");
   for (int k = 0; k < K; k++) {   // the per-frame inputs of step k live in slot k, the track state in slot 0
     TrackBuffers tb = base;
     tb.args += k; tb.ego += k; tb.m_dev += (long)k * kCountsStride; tb.cp += (long)k * kMaxBoxesPerFrame;
@@ -1413,6 +1459,13 @@ extern "C" int mot_get_tracks(mot_ctx* c, int slot, mot_track* tracks, int max_t
 extern "C" int mot_set_launch_graphs(mot_ctx* c, int on) {
   if (!c) return MOT_E_ARG;
   c->graph_mode = on ? 1 : 0;
+  return MOT_OK;
+}
+
+extern "C" int mot_set_trace_ranges(mot_ctx* c, int on) {
+  if (!c) return MOT_E_ARG;
+  c->trace_ranges = on ? 1 : 0;
+  if (on) { g_roctx.load(); if (!g_roctx.push) return fail(c, MOT_E_STATE, "mot_set_trace_ranges: libroctx64 was not found (ranges stay off)"); }
   return MOT_OK;
 }
 

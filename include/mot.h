@@ -292,6 +292,11 @@ int mot_set_fused_outputs(mot_ctx* ctx, int flags);
  * Kernel timing (mot_profile_kernel) uses plain launches while it is armed. */
 int mot_set_launch_graphs(mot_ctx* ctx, int on);
 
+/* on != 0: the fused entry points wrap their stages in roctx ranges — "mot:ground", "mot:cluster", "mot:box", "mot:tracker" on the issuing thread
+ * (rocprofv3 --marker-trace shows them next to the kernels). libroctx64 is loaded at run time on first use; MOT_E_STATE when it is not installed
+ * (the ranges then stay off, nothing else changes). A tracing aid of this library: the reference has none. */
+int mot_set_trace_ranges(mot_ctx* ctx, int on);
+
 /* How a tracker step (immUkfJpdaf for one frame of every stream of the call) is launched. Results are identical in every mode.
  *   MOT_TRACKER_AUTO (default)  by the number of streams in the call: STREAM up to 32, SPLIT beyond
  *   MOT_TRACKER_SPLIT           four launches (prologue, prediction + gating, association + update, merge / birth / outputs), the tracks of

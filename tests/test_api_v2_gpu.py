@@ -180,3 +180,19 @@ def test_by_products_on_demand_equal_materialised(mot, hip_lib, oracle, synth):
         assert hip_lib.mot_cluster(c._h, a.ctypes.data_as(C.c_void_p), len(a), grid.ctypes.data_as(C.c_void_p), C.byref(nc), None) == 0
         got = c.get_clusters(0, n_elevated=len(a))
         assert np.array_equal(got["grid"], ref["grid"]) and np.array_equal(got["point_label"], ref["point_label"])
+
+
+def test_trace_ranges_on_the_device(mot, hip_lib, synth):
+    """roctx stage ranges (mot_set_trace_ranges) change nothing but the markers: a frame with them on equals a frame with them off"""
+    cloud = synth.make_cloud(30000, 2, 0)
+    out = []
+    for on in (False, True):
+        with mot.Context(max_points=32768, max_tracks_total=64) as c:
+            if on:
+                rc = c.lib.mot_set_trace_ranges(c._h, 1)
+                assert rc in (mot.MOT_OK, mot.MOT_E_STATE)   # E_STATE: no libroctx64 on this box (ranges stay off)
+            dev = hiprt.DeviceBuffer(np.pad(cloud, ((0, 32768 - len(cloud)), (0, 0))))
+            c.frames_dev(dev.ptr, 32768 * 4, [len(cloud)], run_tracker=True, timestamps=[1e9], ego_v=[0.0], ego_yaw=[0.0])
+            out.append((c.get_boxes(0)["boxes"], c.get_clusters(0)["grid"]))
+            dev.free()
+    assert np.array_equal(out[0][0], out[1][0]) and np.array_equal(out[0][1], out[1][1])

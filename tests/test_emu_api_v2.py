@@ -250,3 +250,14 @@ def test_reset_tracks_slot_keeps_the_global_frame(mot, emu, oracle):
             if f == 6:
                 assert t["n"] == 1 and t["track_manage"][0] == 1             # the reference's first frame: one seeded track
         assert c.get_tracks(0)["n"] > 1
+
+
+def test_trace_ranges_are_optional(mot, emu_lib=None):
+    """mot_set_trace_ranges: roctx ranges around the stages. The emulator build has no roctx: the call must answer MOT_E_STATE and leave
+    everything working (the real library loads libroctx64 lazily; tests/test_api_v2_gpu.py turns the ranges on around a frame)."""
+    import os, sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "emu"))
+    import build_emu
+    with mot.Context(lib_path=build_emu.build(), max_points=2048) as c:
+        assert c.lib.mot_set_trace_ranges(c._h, 1) == mot.MOT_E_STATE and b"roctx" in c.lib.mot_last_error(c._h)
+        assert c.lib.mot_set_trace_ranges(c._h, 0) == mot.MOT_OK
