@@ -838,11 +838,20 @@ track_update_kernel(TrackBuffers tb) {
 // All loops run over the tracks that are RESIDENT (alive at the start of the step, born in it) except the merge's inner loop,
 // which the reference runs over every track ever created: that one reads 16-byte positions by reference index.
 constexpr int kMaxBornLds = kMaxBoxesPerFrame;   // a frame gives birth to at most one track per box
+#ifdef MOT_DBG_STREAM_TIMING
+#define FIN_T(slot) do { if (threadIdx.x == 0) (reinterpret_cast<long long*>(tb.items) + (long)b * 16)[8 + (slot)] = wall_clock64() - fin_t0; } while (0)
+#else
+#define FIN_T(slot)
+#endif
 static __device__ void track_finish_body(const TrackBuffers& tb, const int b) {
+#ifdef MOT_DBG_STREAM_TIMING
+  const long long fin_t0 = wall_clock64();
+#endif
   __shared__ unsigned long long s_matched[kGateWords];
   __shared__ int s_wcount[kTrackWaves];
   __shared__ int s_nlive, s_born, s_nvis, s_nz;
   __shared__ int s_free[kMaxBornLds];        // free slots in ascending order (as many as this frame can need); the first s_born become the newborns' slots
+  __shared__ unsigned short s_bbox[kMaxBornLds];   // the box each newborn comes from (the workgroup writes their records together, below)
   constexpr int kVisCap = 256;               // visible boxes of a stream held in LDS for the merge phase (more: the per-wave path)
   __shared__ double s_vb[kVisCap][12];       // corners 1..4 (x, y) and the two triangle centroids
   __shared__ int s_vi[kVisCap], s_vr[kVisCap];   // slot and reference index of the box's track
@@ -881,8 +890,9 @@ static __device__ void track_finish_body(const TrackBuffers& tb, const int b) {
     slot_of[ref] = -1;
     atomicAnd(&used[sl >> 6], ~(1ull << (sl & 63)));
   }
-  // matchingVec after the whole track loop: everything a live track claimed (see update_group)
-  if (wave == 0) {
+  // matchingVec after the whole track loop: everything a live track claimed (see update_group). (The LAST wave: the eviction above keeps
+  // the first lanes of wave 0 busy with a chain of dependent loads of its own — the two run side by side.)
+  if (wave == kTrackWaves - 1) {
     for (int w = 0; w < kGateWords; w++) {
       unsigned long long m = 0ull;
       if (w < nW)
@@ -895,6 +905,7 @@ static __device__ void track_finish_body(const TrackBuffers& tb, const int b) {
     }
   }
   __syncthreads();
+  FIN_T(0);
 
   // ---- PD: mergeOverSegmentation :666-700. The reference runs `for i { for j { if inside(j, box_i) {trackNum[i]=5; trackNum[j]=0;} } }`
   // over ALL tracks; the value a track ends with is decided by the last (i,j) pair that writes it. Only tracks that were live
@@ -924,6 +935,7 @@ static __device__ void track_finish_body(const TrackBuffers& tb, const int b) {
     }
   }
   __syncthreads();
+  FIN_T(1);
   const int nvis = s_nvis;
   if (nvis <= kVisCap) {
     for (long pr = tid, npr = (long)nvis * nt0; pr < npr; pr += kTrackBlock) {   // (64-bit: 256 boxes x 2^26 tracks ever created)
@@ -969,6 +981,7 @@ static __device__ void track_finish_body(const TrackBuffers& tb, const int b) {
   }
 #undef ICOEF
   __syncthreads();
+  FIN_T(2);
   for (int li = tid; li < nlive; li += kTrackBlock) {   // (a track that was dead before the step keeps trackNum 0 whatever the pairs say)
     const int sl = live[li];
     const int ref = tracks[sl].ref_id;
@@ -979,11 +992,17 @@ static __device__ void track_finish_body(const TrackBuffers& tb, const int b) {
   }
   if (tid == 0) s_born = 0;
   __syncthreads();
+  FIN_T(3);
 
   // ---- PE: birth :972-989 — one new track per unclaimed box, in box order. Free slots first (ascending, at most one per box).
   if (wave == 0) {
+    // how many slots this frame can need: its unclaimed boxes. Only that many free slots are listed — a lane used to write out every free
+    // slot of its bitmap word (hundreds of LDS stores in a row on a stream with few tracks: a third of this phase's time)
+    int need = 0;
+    for (int w = 0; w * 64 < M; w++) need += __popcll(__ballot(w * 64 + lane < M && !((s_matched[w] >> lane) & 1ull)));
+    if (need > kMaxBornLds) need = kMaxBornLds;
     int nfree = 0;
-    for (int w0 = 0; w0 < usedW && nfree < kMaxBornLds; w0 += 64) {
+    for (int w0 = 0; w0 < usedW && nfree < need; w0 += 64) {
       const int w = w0 + lane;
       unsigned long long fr = 0ull;
       if (w < usedW) {
@@ -994,10 +1013,10 @@ static __device__ void track_finish_body(const TrackBuffers& tb, const int b) {
       const int cnt = __popcll(fr);
       const int incl = wave_scan_incl_i32(cnt);
       int at = nfree + incl - cnt;
-      while (fr && at < kMaxBornLds) { s_free[at++] = w * 64 + __ffsll(fr) - 1; fr &= fr - 1ull; }
+      while (fr && at < need) { s_free[at++] = w * 64 + __ffsll(fr) - 1; fr &= fr - 1ull; }
       nfree += wave_bcast_i32(incl, 63);
     }
-    if (nfree > kMaxBornLds) nfree = kMaxBornLds;
+    if (nfree > need) nfree = need;   // (free slots beyond the frame's births are not listed: nfree = min(free, births) — all the code below asks is r < nfree)
     int born = 0;
     bool dropped = false;
     for (int w = 0; w * 64 < M; w++) {
@@ -1010,7 +1029,7 @@ static __device__ void track_finish_body(const TrackBuffers& tb, const int b) {
         if (r < nfree && ref < E) {
           const int sl = s_free[r];
           const Vec2d c = cp[k];
-          track_init(&tracks[sl], c.x, c.y, ref);
+          s_bbox[r] = (unsigned short)k;   // UKF::UKF + Initialize (track_init): written by the whole workgroup after the barrier
           pos[ref] = c; slot_of[ref] = sl;
           atomicOr(&used[sl >> 6], 1ull << (sl & 63));
         }
@@ -1028,6 +1047,14 @@ static __device__ void track_finish_body(const TrackBuffers& tb, const int b) {
   if (tid == 0) s_nlive = 0;
   __syncthreads();
   const int nb = s_born;
+  // the newborns' records, 8 bytes per thread and trip: word w of track r is a function of (w, box centre, reference index)
+  for (int idx = tid; idx < nb * kTrackWords; idx += kTrackBlock) {
+    const int r = idx / kTrackWords, w = idx - r * kTrackWords;
+    const Vec2d c = cp[s_bbox[r]];
+    reinterpret_cast<unsigned long long*>(&tracks[s_free[r]])[w] = track_init_word(w, c.x, c.y, nt0 + r);
+  }
+  __syncthreads();
+  FIN_T(4);
 
   // ---- PF: outputs + static classification :995-1081 of the tracks that were alive at the start of the step and of the newborn (the
   // reference recomputes every track it ever created; for one that was dead before the step nothing changes but its yaw output,
@@ -1067,6 +1094,7 @@ static __device__ void track_finish_body(const TrackBuffers& tb, const int b) {
     __syncthreads();
   }
   if (tid == 0) { tb.nlive[b] = s_nlive; tb.nzomb[b] = s_nz; }
+  FIN_T(5);
 }
 __global__ void MOT_LAUNCH_BOUNDS(kTrackBlock)
 track_finish_kernel(TrackBuffers tb) {
@@ -1086,7 +1114,7 @@ track_step_stream_kernel(TrackBuffers tb, int do_prep) {
   __shared__ union StreamScratch { PredictScratch p[kStreamGroups]; UpdateScratch u[kStreamGroups]; } s_g;
   const int b = blockIdx.x;
 #ifdef MOT_DBG_STREAM_TIMING   // phase clocks (100 MHz wall clock) of stream b into the work list's storage, which this kernel does not use: tools/time_stream_kernel.py
-  long long* dbg = reinterpret_cast<long long*>(tb.items) + (long)b * 8;
+  long long* dbg = reinterpret_cast<long long*>(tb.items) + (long)b * 16;
   const long long dbg_t0 = wall_clock64();
 #define STREAM_T(slot) do { if (threadIdx.x == 0) dbg[slot] = wall_clock64() - dbg_t0; } while (0)
 #else

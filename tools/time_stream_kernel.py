@@ -19,11 +19,12 @@ rows = []
 with mot.Context(max_points=stride, max_batch=1, max_tracks_total=256, lib_path=lib) as c:
     for f in range(F):
         c.frames_dev(seq[f].data_ptr(), stride * 4, n_seq[f], run_tracker=True, timestamps=[1e9 + f * 1e5], ego_v=[v[f]], ego_yaw=[yaw[f]])
-        d = np.zeros(8, np.int64)
-        assert c.lib.mot_debug_copy(c._h, 12, 0, d.ctypes.data_as(C.c_void_p), C.c_size_t(64)) == 0
+        d = np.zeros(16, np.int64)
+        assert c.lib.mot_debug_copy(c._h, 12, 0, d.ctypes.data_as(C.c_void_p), C.c_size_t(128)) == 0
         rows.append(d.copy())
 r = np.array(rows[10:], np.float64)
 print("us since kernel start (100 MHz clock), mean over frames 10..153: prologue %.1f | predict done %.1f | barrier %.1f | update done %.1f | barrier %.1f | finish done %.1f | live %.1f"
       % tuple(list(r[:, :6].mean(0) / 100.0) + [r[:, 6].mean()]))
+print("finish phase from its start: claimed boxes %.1f | visible boxes %.1f | merge pairs %.1f | apply %.1f | birth %.1f | outputs + live list %.1f" % tuple(r[:, 8:14].mean(0) / 100.0))
 for f in (20, 60, 100, 150):
     print("frame", f, (rows[f][:6] / 100.0).round(1), "live", rows[f][6])
