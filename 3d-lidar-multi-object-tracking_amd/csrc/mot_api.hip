@@ -1621,7 +1621,7 @@ extern "C" int mot_debug_copy(mot_ctx* c, int which, int slot, void* dst, size_t
   else if (which == 9) src = c->d_groups + (size_t)slot * (c->cap / 2);
   else if (which == 10) src = c->d_hg + (size_t)slot * MOT_POLAR_CELLS;
   else if (which == 11) src = c->d_tboxes + (size_t)slot * kMaxBoxesPerFrame * 24;
-  else if (which == 12) src = reinterpret_cast<const long long*>(c->d_items) + (size_t)slot * 16;   // -DMOT_DBG_STREAM_TIMING builds: phase clocks of track_step_stream_kernel
+  else if (which == 12) src = reinterpret_cast<const long long*>(c->d_items) + (size_t)slot * 32;   // -DMOT_DBG_STREAM_TIMING builds: phase clocks of track_step_stream_kernel
   else return MOT_E_ARG;
   MOT_HIP(c, hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, c->stream));
   MOT_HIP(c, hipStreamSynchronize(c->stream));

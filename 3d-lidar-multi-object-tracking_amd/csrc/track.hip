@@ -39,6 +39,12 @@
 #endif
 
 #define PI_D 3.14159265358979323846
+#ifdef MOT_DBG_STREAM_TIMING   // absolute 100 MHz clocks of thread 0 inside the per-track bodies (tools/time_stream_kernel.py: one stream)
+__device__ long long* g_sdbg = nullptr;
+#define GRP_T(slot) do { if (threadIdx.x == 0 && g_sdbg) g_sdbg[slot] = wall_clock64(); } while (0)
+#else
+#define GRP_T(slot)
+#endif
 
 __device__ __forceinline__ int tlane() { return (int)(threadIdx.x & 63); }
 // `while (a > M_PI) a -= 2. * M_PI; while (a < -M_PI) a += 2. * M_PI;` — the reference's angle normalisation (ukf.cpp, imm_ukf_jpda.cpp
@@ -213,6 +219,7 @@ __device__ void process_imm_ukf(PredictScratch* G, double dt, bool ok) {
       G->P[j][r * 5 + c] = acc;
     }
   MOT_WAVE_SYNC();
+  GRP_T(17);
   // Prediction(dt, m) :630-772. Augmented covariance, Eigen 3.2.10 LLT::unblocked semantics: a non-positive pivot
   // stops the factorisation and matrixL() returns the partially overwritten lower triangle.
   if (ok && s < 3) {
@@ -256,6 +263,7 @@ __device__ void process_imm_ukf(PredictScratch* G, double dt, bool ok) {
     G->Ld[m][1] = good ? std_yawdd : std_yawdd * std_yawdd;
   }
   MOT_WAVE_SYNC();
+  GRP_T(18);
   // 15 sigma points of ONE model per pass, a lane each: Cv :573, Ctrv :539, randomMotion :602 (the model is uniform over the
   // wave, so only that model's code runs in a pass)
 #pragma unroll 1
@@ -305,68 +313,63 @@ __device__ void process_imm_ukf(PredictScratch* G, double dt, bool ok) {
     }
   }
   MOT_WAVE_SYNC();
-  if (ok && s < 15) {  // predicted mean :736-742
-    int m = s / 5, r = s % 5;
-    double acc = 0;
+  GRP_T(19);
+  // From here on a LANE IS A SIGMA POINT (15 of the group's 16 lanes; the 16th adds zeros): every weighted sum over the sigma points — the
+  // predicted mean :736-742, z / S / Tc of UpdateLidar :778-902, the predicted covariance :743-749 — is one reduction over the group's DPP row
+  // (row_sum_f64: every lane receives it). Until round 4 a lane was a MATRIX ENTRY that read its 15 (30) terms from LDS: 132 sums of 15 terms,
+  // ~2000 LDS reads per lane and step with the selects of the yaw row — the covariance alone took 9 of the prediction's 22 us, bound by LDS
+  // traffic and bank conflicts (profiles/r04_stream_kernel_phases.txt). The terms are the reference's, (w_i * d_r) * d_c; the ORDER of the
+  // additions is the row tree's — as Eigen's own vectorised reductions, not defined by the source.
+  {
+    const double wi = s < 15 ? ukf_w(s) : 0.0;
+    const bool on = ok && s < 15;
+#pragma unroll 1
+    for (int m = 0; m < 3; m++) {
+      double X[5];
 #pragma unroll
-    for (int i = 0; i < 15; i++) acc = acc + ukf_w(i) * G->Xs[m][r * 15 + i];
-    if (r == 3) acc = wrap_pi(acc);
-    G->x[m][r] = acc;
-  }
-  MOT_WAVE_SYNC();
-  // UpdateLidar(m) :778-902
-  if (ok && s < 6) {
-    int m = s / 2, c = s % 2;
-    double acc = 0;
+      for (int r = 0; r < 5; r++) X[r] = on ? G->Xs[m][r * 15 + s] : 0.0;
+      double mean[5];
 #pragma unroll
-    for (int i = 0; i < 15; i++) acc = acc + ukf_w(i) * G->Xs[m][c * 15 + i];
-    G->z[m][c] = acc;
-  }
-  MOT_WAVE_SYNC();
-  if (ok && s < 12) {
-    int m = s / 4, r = (s % 4) / 2, c = s % 2;
-    double acc = 0;
+      for (int r = 0; r < 5; r++) mean[r] = row_sum_f64(wi * X[r]);
+      const double z0 = mean[0], z1 = mean[1];          // zPred :790-797 is the same weighted sum of rows 0 and 1
+      mean[3] = wrap_pi(mean[3]);                        // :740
+      double dT[5], dP[5];
 #pragma unroll
-    for (int i = 0; i < 15; i++) acc = acc + (ukf_w(i) * (G->Xs[m][r * 15 + i] - G->z[m][r])) * (G->Xs[m][c * 15 + i] - G->z[m][c]);
-    if (r == c) acc = acc + 0.15 * 0.15;  // R, ukf.cpp:91-94
-    G->S[m][r * 2 + c] = acc;
-  }
-  if (ok)
-    for (int e = s; e < 30; e += kGroupLanes) {
-      int m = e / 10, r = (e % 10) / 2, c = e % 2;
-      double acc = 0;
+      for (int r = 0; r < 5; r++) { dT[r] = on ? X[r] - mean[r] : 0.0; dP[r] = dT[r]; }
+      dP[3] = on ? wrap_pi(X[3] - mean[3]) : 0.0;       // the covariance normalises its yaw differences (`while (x_diff(3) > M_PI) ...`), Tc does not
+      const double e0 = on ? X[0] - z0 : 0.0, e1 = on ? X[1] - z1 : 0.0;
+      // every sum is stored by ONE lane as soon as it exists (no arrays of results kept in registers: the kernel runs at 3 waves per SIMD)
+      // S = sum w (z_i - z)(z_i - z)^T + R :812-833, R = 0.15^2 I (ukf.cpp:91-94)
+      {
+        const double s00 = row_sum_f64((wi * e0) * e0) + 0.15 * 0.15, s01 = row_sum_f64((wi * e0) * e1);
+        const double s10 = row_sum_f64((wi * e1) * e0), s11 = row_sum_f64((wi * e1) * e1) + 0.15 * 0.15;
+        if (ok && s == 6) { G->S[m][0] = s00; G->S[m][1] = s01; G->S[m][2] = s10; G->S[m][3] = s11; }
+      }
 #pragma unroll
-      for (int i = 0; i < 15; i++) acc = acc + (ukf_w(i) * (G->Xs[m][r * 15 + i] - G->x[m][r])) * (G->Xs[m][c * 15 + i] - G->z[m][c]);
-      G->Tc[m][r * 2 + c] = acc;
+      for (int r = 0; r < 5; r++) {   // Tc :835-848
+        const double t0 = row_sum_f64((wi * dT[r]) * e0), t1 = row_sum_f64((wi * dT[r]) * e1);
+        if (ok && s == 7 + r) { G->Tc[m][r * 2] = t0; G->Tc[m][r * 2 + 1] = t1; }
+      }
+#pragma unroll
+      for (int r = 0; r < 5; r++)
+#pragma unroll
+        for (int c = 0; c < 5; c++) {
+          const double v = row_sum_f64((wi * dP[r]) * dP[c]);
+          if (ok && s == ((r * 5 + c) & 15)) G->P[m][r * 5 + c] = v;
+        }
+      if (ok) {
+        if (s < 5) G->x[m][s] = s == 0 ? mean[0] : s == 1 ? mean[1] : s == 2 ? mean[2] : s == 3 ? mean[3] : mean[4];
+        if (s == 5) { G->z[m][0] = z0; G->z[m][1] = z1; }
+      }
     }
+  }
   MOT_WAVE_SYNC();
+  GRP_T(20);
   if (ok)
     for (int e = s; e < 30; e += kGroupLanes) {
       int m = e / 10, r = (e % 10) / 2, c = e % 2;
       double Si[4]; inv2(G->S[m], Si);
       G->K[m][r * 2 + c] = G->Tc[m][r * 2 + 0] * Si[0 * 2 + c] + G->Tc[m][r * 2 + 1] * Si[1 * 2 + c];
-    }
-  MOT_WAVE_SYNC();
-  // Predicted covariance :743-749, LAST: its yaw differences are normalised (`while (x_diff(3) > M_PI) ...`), and inside the 75-entry
-  // loop that meant two wrap_pi evaluations per sigma point and entry for the whole wave (any lane with r == 3 or c == 3 drags
-  // the others along): ~150 of them per step, a quarter of this kernel's instructions. Nothing after the covariance reads the
-  // sigma points, so their yaw row is replaced by the normalised difference once (15 lanes x 3 models) and the loop only selects.
-  if (ok && s < 15) {
-#pragma unroll
-    for (int m = 0; m < 3; m++) G->Xs[m][3 * 15 + s] = wrap_pi(G->Xs[m][3 * 15 + s] - G->x[m][3]);
-  }
-  MOT_WAVE_SYNC();
-  if (ok)
-    for (int e = s; e < 75; e += kGroupLanes) {
-      int m = e / 25, r = (e % 25) / 5, c = e % 5;
-      double acc = 0;
-#pragma unroll
-      for (int i = 0; i < 15; i++) {
-        const double dr = r == 3 ? G->Xs[m][3 * 15 + i] : G->Xs[m][r * 15 + i] - G->x[m][r];
-        const double dc = c == 3 ? G->Xs[m][3 * 15 + i] : G->Xs[m][c * 15 + i] - G->x[m][c];
-        acc = acc + (ukf_w(i) * dr) * dc;
-      }
-      G->P[m][r * 5 + c] = acc;
     }
   MOT_WAVE_SYNC();
 }
@@ -500,11 +503,16 @@ __device__ void predict_group(const TrackBuffers& tb, PredictScratch* G, int b, 
   const Vec2d* __restrict__ cp = tb.cp + (long)b * kMaxBoxesPerFrame;
   const bool secondInit = act && u->track_num == 1;
   if (act && s == 0) u->is_vis = 0;   // isVisBB_ = false (:813); tracks that are dead already are cleared by the finish kernel
+  GRP_T(14);
   load_track(G, u, act);
+  GRP_T(15);
   bool ok = act;
   if (ok && (det5(G->Pm) > 10 || G->Pm[24] > 1000)) ok = false;  // divergence guard :828-831
+  GRP_T(16);
   process_imm_ukf(G, args.dt, ok);  // :840
+  GRP_T(21);
   store_models(G, u, ok);
+  GRP_T(22);
   double Si[4] = {0, 0, 0, 0}, zx = 0, zy = 0;
   if (ok) {
     int mx = find_max_model(G->S);
@@ -555,6 +563,7 @@ __device__ void predict_group(const TrackBuffers& tb, PredictScratch* G, int b, 
       }
     }
   }
+  GRP_T(23);
   if (act && s == 0) {
     liveok[li] = ok ? (secondInit ? 2 : 1) : 0;   // 2: the track is in its second initialisation (trackNum 1 at the start of the step)
     if (!ok) u->track_num = 0;
@@ -623,7 +632,9 @@ __device__ void update_group(const TrackBuffers& tb, UpdateScratch* G, int b, in
     if (act && s == 0 && fresh) u->lifetime += fresh;
   }
   MOT_WAVE_SYNC();
+  GRP_T(25);
   load_track(G, u, act);
+  GRP_T(26);
   int track_num = act ? u->track_num : 0;
   const bool secondInit = act && okflag == 2;
   int ngate = 0;
@@ -675,6 +686,7 @@ __device__ void update_group(const TrackBuffers& tb, UpdateScratch* G, int b, in
     }
   }
   MOT_WAVE_SYNC();
+  GRP_T(27);
   Vec2d* pos = tb.pos + (long)b * tb.E + (act ? u->ref_id : 0);   // the merged position is kept by REFERENCE index (it outlives the slot)
   if (secondInit && s == 0) {  // :882-921
     if (nm == 0) u->track_num = 0;
@@ -839,7 +851,7 @@ track_update_kernel(TrackBuffers tb) {
 // which the reference runs over every track ever created: that one reads 16-byte positions by reference index.
 constexpr int kMaxBornLds = kMaxBoxesPerFrame;   // a frame gives birth to at most one track per box
 #ifdef MOT_DBG_STREAM_TIMING
-#define FIN_T(slot) do { if (threadIdx.x == 0) (reinterpret_cast<long long*>(tb.items) + (long)b * 16)[8 + (slot)] = wall_clock64() - fin_t0; } while (0)
+#define FIN_T(slot) do { if (threadIdx.x == 0) (reinterpret_cast<long long*>(tb.items) + (long)b * 32)[8 + (slot)] = wall_clock64() - fin_t0; } while (0)
 #else
 #define FIN_T(slot)
 #endif
@@ -1114,8 +1126,9 @@ track_step_stream_kernel(TrackBuffers tb, int do_prep) {
   __shared__ union StreamScratch { PredictScratch p[kStreamGroups]; UpdateScratch u[kStreamGroups]; } s_g;
   const int b = blockIdx.x;
 #ifdef MOT_DBG_STREAM_TIMING   // phase clocks (100 MHz wall clock) of stream b into the work list's storage, which this kernel does not use: tools/time_stream_kernel.py
-  long long* dbg = reinterpret_cast<long long*>(tb.items) + (long)b * 16;
+  long long* dbg = reinterpret_cast<long long*>(tb.items) + (long)b * 32;
   const long long dbg_t0 = wall_clock64();
+  if (threadIdx.x == 0) { g_sdbg = dbg; dbg[13] = dbg_t0; }
 #define STREAM_T(slot) do { if (threadIdx.x == 0) dbg[slot] = wall_clock64() - dbg_t0; } while (0)
 #else
 #define STREAM_T(slot)
@@ -1132,9 +1145,11 @@ track_step_stream_kernel(TrackBuffers tb, int do_prep) {
     STREAM_T(1);
     __syncthreads();
     STREAM_T(2);
+    GRP_T(24);
     for (int i0 = 0; i0 < nlive; i0 += kStreamGroups) {
       if (i0 + (int)(threadIdx.x >> 6) * kGroupsPerWave < nlive) update_group(tb, &s_g.u[g], b, i0 + g, i0 + g < nlive);
     }
+    GRP_T(28);
     STREAM_T(3);
     __syncthreads();
     STREAM_T(4);
