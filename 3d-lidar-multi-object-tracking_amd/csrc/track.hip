@@ -645,6 +645,14 @@ __device__ void update_group(const TrackBuffers& tb, UpdateScratch* G, int b, in
     for (int w = 0; w < nW; w++) if (pt[w]) last_prog = w * 64 + 63 - __clzll((long long)pt[w]);
     nm = last_prog >= 0 ? 1 : 0;
   }
+  // the first 16 boxes' centres once, in registers and (for lane 0's ordered scan below) in LDS: a street scene has 10-20 boxes per frame, and
+  // every pass over the gated boxes — the association scan, then nine passes of the PDA sums — used to fetch the same centres from global
+  // memory again, a dependent round trip each
+  Vec2d c_first; c_first.x = 0; c_first.y = 0;
+  if (act && s < M) c_first = cp[s];
+  double* cstage = &G->Xs[1][0];   // (Xs[0] holds updateBB's two boxes until the exp() cache takes the storage)
+  cstage[2 * s] = c_first.x; cstage[2 * s + 1] = c_first.y;
+  MOT_WAVE_SYNC();
   // associateBB :416-463 + getNearestEuclidBBox :396-413 (int minDist, truncated on assignment)
   if (act && !secondInit && ngate > 0 && track_num == 5 && u->lifetime > tp.life_time_thres) {
     // sequential semantics: scan gated boxes in order, keep (minDist:int, minInd); reproduced by one lane
@@ -657,7 +665,8 @@ __device__ void update_group(const TrackBuffers& tb, UpdateScratch* G, int b, in
           int k = w * 64 + __ffsll(g) - 1;
           g &= g - 1ull;
           if (first < 0) first = k;
-          const Vec2d c = cp[k];
+          Vec2d c;
+          if (k < kGroupLanes) { c.x = cstage[2 * k]; c.y = cstage[2 * k + 1]; } else c = cp[k];
           double dist = sqrt((px - c.x) * (px - c.x) + (py - c.y) * (py - c.y));
           if (dist < minDist) { minDist = (int)dist; minBox = k; }
         }
@@ -725,6 +734,8 @@ __device__ void update_group(const TrackBuffers& tb, UpdateScratch* G, int b, in
   const double numMeas = nm;
   const double bpda = 2 * numMeas * (1 - tp.p_d * tp.p_g) / (tp.gamma_g * tp.p_d);
   double* ecache = &G->Xs[0][0];   // exp() of the gated boxes 0..63 per model ([3][64]; the sigma points are not needed here)
+  // (the first 16 boxes' centres are in registers, c_first; their gate word too)
+  const unsigned long long gt0 = Mg > 0 ? gt[0] : 0ull;
 #pragma unroll 1
   for (int m = 0; m < 3; m++) {
     double Si[4] = {0, 0, 0, 0};
@@ -733,10 +744,10 @@ __device__ void update_group(const TrackBuffers& tb, UpdateScratch* G, int b, in
     double eS = 0;
     for (int k0 = 0; k0 < Mmax; k0 += kGroupLanes) {
       const int k = k0 + s;
-      const bool g = k < Mg && ((gt[k0 >> 6] >> (k & 63)) & 1ull);
+      const bool g = k < Mg && (((k0 < 64 ? gt0 : gt[k0 >> 6]) >> (k & 63)) & 1ull);
       double e = 0;
       if (g) {
-        const Vec2d c = cp[k];
+        const Vec2d c = k0 == 0 ? c_first : cp[k];
         double d0 = c.x - zm0, d1 = c.y - zm1;
         double h0 = -0.5 * d0, h1 = -0.5 * d1;
         double t0 = h0 * Si[0] + h1 * Si[2], t1 = h0 * Si[1] + h1 * Si[3];
@@ -750,10 +761,10 @@ __device__ void update_group(const TrackBuffers& tb, UpdateScratch* G, int b, in
     for (int pass = 0; pass < 2; pass++) {  // pass 0: sigmaX, pass 1: sigmaP (needs the complete sigmaX)
       for (int k0 = 0; k0 < Mmax; k0 += kGroupLanes) {
         const int k = k0 + s;
-        const bool g = k < Mg && ((gt[k0 >> 6] >> (k & 63)) & 1ull);
+        const bool g = k < Mg && (((k0 < 64 ? gt0 : gt[k0 >> 6]) >> (k & 63)) & 1ull);
         double d[2] = {0, 0}, beta = 0;
         if (g) {
-          const Vec2d c = cp[k];
+          const Vec2d c = k0 == 0 ? c_first : cp[k];
           d[0] = c.x - zm0; d[1] = c.y - zm1;
           double e;
           if (k < 64) e = ecache[m * 64 + k];
