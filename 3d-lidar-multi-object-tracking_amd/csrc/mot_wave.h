@@ -135,6 +135,42 @@ __device__ __forceinline__ double row_sum_f64(double v) {
   return v;
 #endif
 }
+// EIGHT sums over one DPP row at once, transposed: lane L of the row hands in v[0..7] and receives the complete sum of v[idx(L)] over the
+// row's 16 lanes, idx(L) = row_sum8_index(L). A butterfly that halves what a lane carries at every stage (keep one half, give the partner the
+// other): 4 + 2 + 1 + 1 exchange-and-add steps for eight sums where eight row_sum_f64 take 32 — and the SAME addition tree per sum
+// (partial = own partial + partner's partial at distances 1, 2, 4, 8), so the results are bit-identical to row_sum_f64's.
+__device__ __forceinline__ int row_sum8_index(int lane_in_row) { return ((lane_in_row & 1) << 2) | (lane_in_row & 2) | ((lane_in_row >> 2) & 1); }
+__device__ __forceinline__ double row_sum8_f64(const double (&v)[8]) {
+  const int L = (int)(threadIdx.x & 15);
+  const bool b0 = L & 1, b1 = L & 2, b2 = L & 4;
+#ifndef MOT_HIPEMU
+#define MOT_DPP_F64X(x, ctrl)                                                                        \
+  __hiloint2double(__builtin_amdgcn_update_dpp(0, __double2hiint(x), (ctrl), 0xf, 0xf, true),          \
+                   __builtin_amdgcn_update_dpp(0, __double2loint(x), (ctrl), 0xf, 0xf, true))
+#define MOT_XOR1(x) MOT_DPP_F64X(x, 0xB1)                                    /* quad_perm [1,0,3,2] */
+#define MOT_XOR2(x) MOT_DPP_F64X(x, 0x4E)                                    /* quad_perm [2,3,0,1] */
+  auto xor4 = [](double x) { double t = MOT_DPP_F64X(x, 0x141); return MOT_DPP_F64X(t, 0x1B); };    // row_half_mirror (i -> 7 - i), then quad_perm [3,2,1,0]
+  auto xor8 = [](double x) { double t = MOT_DPP_F64X(x, 0x140); return MOT_DPP_F64X(t, 0x141); };   // row_mirror (i -> 15 - i), then row_half_mirror
+#else
+#define MOT_XOR1(x) __shfl_xor((x), 1, 64)
+#define MOT_XOR2(x) __shfl_xor((x), 2, 64)
+  auto xor4 = [](double x) { return __shfl_xor(x, 4, 64); };
+  auto xor8 = [](double x) { return __shfl_xor(x, 8, 64); };
+#endif
+  double w[4], x2[2];
+#pragma unroll
+  for (int j = 0; j < 4; j++) { const double mine = b0 ? v[j + 4] : v[j], give = b0 ? v[j] : v[j + 4]; w[j] = mine + MOT_XOR1(give); }
+#pragma unroll
+  for (int j = 0; j < 2; j++) { const double mine = b1 ? w[j + 2] : w[j], give = b1 ? w[j] : w[j + 2]; x2[j] = mine + MOT_XOR2(give); }
+  const double mine = b2 ? x2[1] : x2[0], give = b2 ? x2[0] : x2[1];
+  const double y = mine + xor4(give);
+  return y + xor8(y);
+#undef MOT_XOR1
+#undef MOT_XOR2
+#ifndef MOT_HIPEMU
+#undef MOT_DPP_F64X
+#endif
+}
 __device__ __forceinline__ unsigned long long row_or_u64(unsigned long long v) {
 #ifndef MOT_HIPEMU
 #define MOT_DPP_U64R(x, ctrl)                                                                                                      \

@@ -338,25 +338,30 @@ __device__ void process_imm_ukf(PredictScratch* G, double dt, bool ok) {
       for (int r = 0; r < 5; r++) { dT[r] = on ? X[r] - mean[r] : 0.0; dP[r] = dT[r]; }
       dP[3] = on ? wrap_pi(X[3] - mean[3]) : 0.0;       // the covariance normalises its yaw differences (`while (x_diff(3) > M_PI) ...`), Tc does not
       const double e0 = on ? X[0] - z0 : 0.0, e1 = on ? X[1] - z1 : 0.0;
-      // every sum is stored by ONE lane as soon as it exists (no arrays of results kept in registers: the kernel runs at 3 waves per SIMD)
-      // S = sum w (z_i - z)(z_i - z)^T + R :812-833, R = 0.15^2 I (ukf.cpp:91-94)
-      {
-        const double s00 = row_sum_f64((wi * e0) * e0) + 0.15 * 0.15, s01 = row_sum_f64((wi * e0) * e1);
-        const double s10 = row_sum_f64((wi * e1) * e0), s11 = row_sum_f64((wi * e1) * e1) + 0.15 * 0.15;
-        if (ok && s == 6) { G->S[m][0] = s00; G->S[m][1] = s01; G->S[m][2] = s10; G->S[m][3] = s11; }
-      }
+      // The 39 sums of a model — P (25), Tc (10), S (4), in that order — go through the row EIGHT AT A TIME (row_sum8_f64: a transposed
+      // butterfly, same addition tree and bits as 39 row_sum_f64 at a quarter of their exchange-and-add steps); lane L of the lower half-row
+      // ends up with sum number batch * 8 + row_sum8_index(L) and stores it.
+      //   P  :743-749   (w_i * dP_r) * dP_c          Tc :835-848   (w_i * dT_r) * e_c          S :812-833   (w_i * e_r) * e_c  (+ R = 0.15^2 on the diagonal, ukf.cpp:91-94)
+      auto term = [&](int n) -> double {
+        if (n < 25) return (wi * dP[n / 5]) * dP[n % 5];
+        if (n < 35) return (wi * dT[(n - 25) / 2]) * ((n - 25) % 2 ? e1 : e0);
+        if (n < 39) return (wi * ((n - 35) / 2 ? e1 : e0)) * ((n - 35) % 2 ? e1 : e0);
+        return 0.0;
+      };
+      const int mine = row_sum8_index(s);
 #pragma unroll
-      for (int r = 0; r < 5; r++) {   // Tc :835-848
-        const double t0 = row_sum_f64((wi * dT[r]) * e0), t1 = row_sum_f64((wi * dT[r]) * e1);
-        if (ok && s == 7 + r) { G->Tc[m][r * 2] = t0; G->Tc[m][r * 2 + 1] = t1; }
-      }
+      for (int batch = 0; batch < 5; batch++) {
+        double v[8];
 #pragma unroll
-      for (int r = 0; r < 5; r++)
-#pragma unroll
-        for (int c = 0; c < 5; c++) {
-          const double v = row_sum_f64((wi * dP[r]) * dP[c]);
-          if (ok && s == ((r * 5 + c) & 15)) G->P[m][r * 5 + c] = v;
+        for (int j = 0; j < 8; j++) v[j] = term(batch * 8 + j);
+        double sum = row_sum8_f64(v);
+        const int n = batch * 8 + mine;
+        if (n == 35 || n == 38) sum = sum + 0.15 * 0.15;
+        if (ok && s < 8 && n < 39) {
+          double* dst = n < 25 ? &G->P[m][n] : n < 35 ? &G->Tc[m][n - 25] : &G->S[m][n - 35];
+          *dst = sum;
         }
+      }
       if (ok) {
         if (s < 5) G->x[m][s] = s == 0 ? mean[0] : s == 1 ? mean[1] : s == 2 ? mean[2] : s == 3 ? mean[3] : mean[4];
         if (s == 5) { G->z[m][0] = z0; G->z[m][1] = z1; }
