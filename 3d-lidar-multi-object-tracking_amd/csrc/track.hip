@@ -793,6 +793,7 @@ __device__ void update_group(const TrackBuffers& tb, UpdateScratch* G, int b, in
   }
   // x += K*sigmaX ; P update (:341-367) — one lane per matrix entry
   MOT_WAVE_SYNC();
+  GRP_T(29);
   if (upd) {
     if (s < 15) {
       int m = s / 5, r = s % 5;
@@ -813,6 +814,7 @@ __device__ void update_group(const TrackBuffers& tb, UpdateScratch* G, int b, in
     }
   }
   MOT_WAVE_SYNC();
+  GRP_T(30);
   if (upd) {
     // likelihoods :369-393, UpdateModeProb ukf.cpp:384-397, merge :419-437
     int mx = find_max_model(G->S);

@@ -26,10 +26,10 @@ r = np.array(rows[10:], np.float64)
 print("us since kernel start (100 MHz clock), mean over frames 10..153: prologue %.1f | predict done %.1f | barrier %.1f | update done %.1f | barrier %.1f | finish done %.1f | live %.1f"
       % tuple(list(r[:, :6].mean(0) / 100.0) + [r[:, 6].mean()]))
 print("finish phase from its start: claimed boxes %.1f | visible boxes %.1f | merge pairs %.1f | apply %.1f | birth %.1f | outputs + live list %.1f" % tuple(r[:, 8:14].mean(0) / 100.0))
-a = (r[:, 14:29] - r[:, 13:14]) / 100.0   # absolute clocks of thread 0 (wave 0, group 0) relative to the kernel's start
+a = (r[:, 14:31] - r[:, 14:15]) / 100.0   # absolute clocks of thread 0 (wave 0, group 0) relative to the kernel's start
 m = a.mean(0)
-print("prediction (thread 0's group; us since kernel start): enter %.1f | track loaded %.1f | det5 guard %.1f | mixing + interaction %.1f | Cholesky %.1f | sigma points %.1f | mean, S, Tc, K %.1f | covariance %.1f | models stored %.1f | gating done %.1f"
+print("prediction (thread 0's group; us since it entered the prediction): enter %.1f | track loaded %.1f | det5 guard %.1f | mixing + interaction %.1f | Cholesky %.1f | sigma points %.1f | mean, S, Tc, K %.1f | covariance %.1f | models stored %.1f | gating done %.1f"
       % (m[0], m[1], m[2], m[3], m[4], m[5], m[6], m[7], m[8], m[9]))
-print("update: enter %.1f | claimed-before bookkeeping %.1f | track loaded %.1f | association + updateBB %.1f | PDA update + merge done %.1f" % (m[10], m[11], m[12], m[13], m[14]))
+print("update: enter %.1f | claimed-before bookkeeping %.1f | track loaded %.1f | association + updateBB %.1f | PDA sums %.1f | state / covariance update %.1f | mode probabilities + merge + stores %.1f" % (m[10], m[11], m[12], m[13], m[15], m[16], m[14]))
 for f in (20, 60, 100, 150):
     print("frame", f, (rows[f][:6] / 100.0).round(1), "live", rows[f][6])
