@@ -509,6 +509,8 @@ __device__ void predict_group(const TrackBuffers& tb, PredictScratch* G, int b, 
   const bool secondInit = act && u->track_num == 1;
   if (act && s == 0) u->is_vis = 0;   // isVisBB_ = false (:813); tracks that are dead already are cleared by the finish kernel
   GRP_T(14);
+  Vec2d c_first; c_first.x = 0; c_first.y = 0;
+  if (act && s < M) c_first = cp[s];   // the first 16 box centres for the gating below: requested now, under the prediction, not after it
   load_track(G, u, act);
   GRP_T(15);
   bool ok = act;
@@ -537,7 +539,7 @@ __device__ void predict_group(const TrackBuffers& tb, PredictScratch* G, int b, 
     const int k = k0 + s;
     bool g = false; double nis = 1e300;
     if (k < Mg) {
-      const Vec2d c = cp[k];
+      const Vec2d c = k0 == 0 ? c_first : cp[k];
       double d0 = c.x - zx, d1 = c.y - zy;
       double t0 = d0 * Si[0] + d1 * Si[2], t1 = d0 * Si[1] + d1 * Si[3];
       nis = t0 * d0 + t1 * d1;
@@ -618,6 +620,10 @@ __device__ void update_group(const TrackBuffers& tb, UpdateScratch* G, int b, in
   // ---- PB: matchingVec / lifetime_ bookkeeping (:232). The reference walks the tracks in index order and counts, per track,
   // the gated boxes nobody claimed before. What the EARLIER live tracks of the stream claimed is the OR of
   // their gate masks (second-initialisation tracks claim only their progressive minima): lanes over the earlier tracks.
+  // (the track's own words — management state, lifetime — are requested here, ahead of the chain of dependent loads below; the lifetime the
+  // association test needs is then old + fresh in a register instead of a read-back of what lane 0 just wrote)
+  int track_num = act ? u->track_num : 0;
+  int life = act ? u->lifetime : 0;
   {
     const int nWmax = wave_reduce_i32(nW, OpMaxI()), limax = wave_reduce_i32(act ? li : 0, OpMaxI());
     int fresh = 0;
@@ -627,20 +633,20 @@ __device__ void update_group(const TrackBuffers& tb, UpdateScratch* G, int b, in
         const int lj = j0 + s;
         unsigned long long m = 0ull;
         if (w < nW && lj < li) {
-          const int f = liveok[lj];
-          if (f) { const int tj = live[lj]; m = f == 2 ? prog_b[(long)tj * kGateWords + w] : gate_b[(long)tj * kGateWords + w]; }
+          const int f = liveok[lj], tj = live[lj];   // (independent: one round trip for both, then the mask)
+          if (f) m = f == 2 ? prog_b[(long)tj * kGateWords + w] : gate_b[(long)tj * kGateWords + w];
         }
         before |= row_or_u64(m);
       }
       if (w < nW) fresh += __popcll(gt[w] & ~before);
     }
-    if (act && s == 0 && fresh) u->lifetime += fresh;
+    life += fresh;
+    if (act && s == 0 && fresh) u->lifetime = life;
   }
   MOT_WAVE_SYNC();
   GRP_T(25);
   load_track(G, u, act);
   GRP_T(26);
-  int track_num = act ? u->track_num : 0;
   const bool secondInit = act && okflag == 2;
   int ngate = 0;
   for (int w = 0; w < nW; w++) ngate += __popcll(gt[w]);
@@ -659,7 +665,7 @@ __device__ void update_group(const TrackBuffers& tb, UpdateScratch* G, int b, in
   cstage[2 * s] = c_first.x; cstage[2 * s + 1] = c_first.y;
   MOT_WAVE_SYNC();
   // associateBB :416-463 + getNearestEuclidBBox :396-413 (int minDist, truncated on assignment)
-  if (act && !secondInit && ngate > 0 && track_num == 5 && u->lifetime > tp.life_time_thres) {
+  if (act && !secondInit && ngate > 0 && track_num == 5 && life > tp.life_time_thres) {
     // sequential semantics: scan gated boxes in order, keep (minDist:int, minInd); reproduced by one lane
     if (s == 0) {
       int minDist = 999, minBox = -1, first = -1;
@@ -927,8 +933,8 @@ static __device__ void track_finish_body(const TrackBuffers& tb, const int b) {
       unsigned long long m = 0ull;
       if (w < nW)
         for (int lj = lane; lj < nlive; lj += 64) {
-          const int f = liveok[lj];
-          if (f) { const int tj = live[lj]; m |= f == 2 ? prog[(long)tj * kGateWords + w] : gate[(long)tj * kGateWords + w]; }
+          const int f = liveok[lj], tj = live[lj];
+          if (f) m |= f == 2 ? prog[(long)tj * kGateWords + w] : gate[(long)tj * kGateWords + w];
         }
       m = wave_reduce_u64(m, OpOrU64());
       if (lane == 0) s_matched[w] = m;
