@@ -22,6 +22,28 @@
 #endif
 
 #include <ucontext.h>
+// Fiber switch. glibc's swapcontext saves and restores the signal mask with two system calls per switch — a rendezvous of a 512-thread
+// workgroup is a thousand switches, and a third of the CPU suite's time was spent in rt_sigprocmask. On x86-64, outside the AddressSanitizer
+// build (whose runtime must see fiber switches: it intercepts swapcontext), the switch is the six callee-saved registers, the two
+// floating-point control words and the stack pointer.
+#if defined(__x86_64__) && !defined(__SANITIZE_ADDRESS__) && !defined(HIPEMU_UCONTEXT)
+#define HIPEMU_FAST_SWITCH 1
+extern "C" void hipemu_switch(void** save_sp, void* const* load_sp);
+__asm__(
+    ".text\n"
+    ".p2align 4\n"
+    ".weak hipemu_switch\n"
+    ".type hipemu_switch,@function\n"
+    "hipemu_switch:\n"
+    "  pushq %rbp\n  pushq %rbx\n  pushq %r12\n  pushq %r13\n  pushq %r14\n  pushq %r15\n"
+    "  subq $8, %rsp\n  stmxcsr (%rsp)\n  fnstcw 4(%rsp)\n"
+    "  movq %rsp, (%rdi)\n"
+    "  movq (%rsi), %rsp\n"
+    "  ldmxcsr (%rsp)\n  fldcw 4(%rsp)\n  addq $8, %rsp\n"
+    "  popq %r15\n  popq %r14\n  popq %r13\n  popq %r12\n  popq %rbx\n  popq %rbp\n"
+    "  ret\n"
+    ".size hipemu_switch,.-hipemu_switch\n");
+#endif
 #include <cmath>
 #include <cstdint>
 #include <cstdio>
@@ -72,7 +94,11 @@ constexpr int kWave = 64;
 constexpr size_t kStack = 128 * 1024;
 
 struct Thread {
+#ifdef HIPEMU_FAST_SWITCH
+  void* ctx = nullptr;   // saved stack pointer
+#else
   ucontext_t ctx;
+#endif
   dim3 tid;
   int lin = 0;     // linear thread id in block
   bool done = false;
@@ -88,13 +114,22 @@ struct State {
   std::vector<Thread> threads;
   std::vector<Wave> waves;
   std::vector<char> stacks;
+#ifdef HIPEMU_FAST_SWITCH
+  void* sched = nullptr;
+#else
   ucontext_t sched;
+#endif
   Thread* cur = nullptr;
   std::function<void()> body;
 };
 inline State& S() { static State s; return s; }
 
-inline void yield() { State& s = S(); swapcontext(&s.cur->ctx, &s.sched); }
+#ifdef HIPEMU_FAST_SWITCH
+#define HIPEMU_SWAP(from, to) hipemu_switch(&(from), &(to))
+#else
+#define HIPEMU_SWAP(from, to) swapcontext(&(from), &(to))
+#endif
+inline void yield() { State& s = S(); HIPEMU_SWAP(s.cur->ctx, s.sched); }
 
 inline void release_barrier_if_complete(State& s) {
   if (s.bar_count > 0 && s.bar_count >= s.alive) { s.bar_count = 0; s.bar_gen++; }
@@ -111,7 +146,7 @@ inline void trampoline() {
   w.alive--;
   release_barrier_if_complete(s);
   release_wave_if_complete(w);
-  swapcontext(&s.cur->ctx, &s.sched);
+  HIPEMU_SWAP(s.cur->ctx, s.sched);
 }
 
 inline void syncthreads() {
@@ -201,11 +236,24 @@ inline void launch(dim3 grid, dim3 block, F&& f) {
           Thread& th = s.threads[t];
           th.lin = t; th.done = false;
           th.tid = dim3(t % block.x, (t / block.x) % block.y, t / (block.x * block.y));
+#ifdef HIPEMU_FAST_SWITCH
+          {   // a fresh fiber: the frame hipemu_switch pops — control words, six registers, then `ret` into the trampoline with the stack as after a call
+            uintptr_t top = (uintptr_t)(s.stacks.data() + (size_t)(t + 1) * kStack) & ~(uintptr_t)15;
+            void** sp = (void**)(top - 72);
+            const uint32_t cw[2] = {0x1F80u, 0x037Fu};   // MXCSR and x87 control word at their defaults
+            memcpy(&sp[0], cw, 8);
+            for (int r = 1; r <= 6; r++) sp[r] = nullptr;
+            sp[7] = (void*)(void (*)())trampoline;          // at top - 16; the trampoline then runs with rsp = top - 8 (it never returns)
+            sp[8] = nullptr;
+            th.ctx = (void*)sp;
+          }
+#else
           getcontext(&th.ctx);
           th.ctx.uc_stack.ss_sp = s.stacks.data() + (size_t)t * kStack;
           th.ctx.uc_stack.ss_size = kStack;
           th.ctx.uc_link = &s.sched;
           makecontext(&th.ctx, (void (*)())trampoline, 0);
+#endif
         }
         int live = s.nthreads;
         long spins = 0;
@@ -220,7 +268,7 @@ inline void launch(dim3 grid, dim3 block, F&& f) {
             Thread& th = s.threads[t];
             if (th.done) continue;
             s.cur = &th;
-            swapcontext(&s.sched, &th.ctx);
+            HIPEMU_SWAP(s.sched, th.ctx);
             if (!th.done) live++;
           }
           if (++spins > 50000000L) { fprintf(stderr, "hipemu: block (%u,%u,%u) appears deadlocked\n", bx, by, bz); abort(); }

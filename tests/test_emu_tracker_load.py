@@ -34,6 +34,5 @@ def test_long_run_on_bounded_track_slots_emulated(mot, oracle):
     positions of dead tracks kept for the merge step)"""
     import build_emu
     import tracker_cases as TC
-    st = TC.long_run_bounded_slots(mot, oracle, lib_path=build_emu.build(), frames=700 if int(os.environ.get("MOT_PROP_SCALE", "1")) > 1 else 320, slots=16, spots=9,
-                                   min_ever_factor=4 if int(os.environ.get("MOT_PROP_SCALE", "1")) > 1 else 2)   # (320 frames: ~2.5 x the slots in tracks ever created; the 10 000-frame run is tests/test_tracker_gpu.py's)
+    st = TC.long_run_bounded_slots(mot, oracle, lib_path=build_emu.build(), frames=700, slots=16, spots=9)
     assert st["tracks_ever"] >= 64

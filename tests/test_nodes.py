@@ -161,7 +161,7 @@ def test_tracking_node_outlives_its_track_budget(emu_lib, tmp_path):
     import roslog as R
     import tracker_cases as TC
     own = NB.own_nodes(emu_lib)
-    recs, frames = [], 150
+    recs, frames = [], 260
     for f, (boxes, ts, v, yaw) in enumerate(TC.blinking_world(5, 9, frames)):
         t = U.T0 + 0.1 * f
         m = dict(header=dict(seq=f, stamp=R.stamp(t), frame_id="velodyne"), box_num=len(boxes) & 255)

@@ -96,13 +96,7 @@ def test_emulated_device_within_noise_floor(mot, oracle, perturb):
         import build_emu as _b
         importlib.reload(_b)
     p = oracle.params(0)
-    full = int(os.environ.get("MOT_PROP_SCALE", "1")) > 1   # every stream in both modes; by default the bench stream + three others spread over the two
-    pick = ("scene0_",) if perturb else ("scene0_", "scene1_")   # (the two streams with a track-frame above 1e-4: frames 63 and 59)
-    for name, unit, preset, boxes, ego_v, ego_yaw in streams():
-        if not full and not name.startswith(pick):
-            continue
-        if not full and perturb:
-            boxes = boxes[:90]
+    for name, unit, preset, boxes, ego_v, ego_yaw in streams():   # all six streams, both modes
         R = oracle.RefTracker(); R.reset()
         NF = SP.NoiseFloor(oracle, p, primary_is_ref=True)
         stats = {}
