@@ -126,7 +126,7 @@ label_stats_kernel(MotDevParams p, ClusterBuffers c) {
   B1_T_BEGIN(c, b);
   const int num_cluster = c.counts[b * kCountsStride + kCntClusters];
   const float4* __restrict__ pts = c.elevated + (long)b * c.cap;
-  const int* __restrict__ grid = c.grid + (long)b * (MOT_MAX_GRID * MOT_MAX_GRID);
+  const GridLabel* __restrict__ grid = c.grid + (long)b * (MOT_MAX_GRID * MOT_MAX_GRID);
   int* __restrict__ label = c.label ? c.label + (long)b * c.cap : nullptr;   // null: the fused path without MOT_OUT_LABELS (point_labels_kernel on demand)
   int* __restrict__ pix = c.pix + (long)b * c.cap;
   ClusterStats* __restrict__ stats = c.stats + (long)b * kMaxClusters;
@@ -1196,7 +1196,7 @@ __global__ void MOT_LAUNCH_BOUNDS(256)
 point_labels_kernel(MotDevParams p, ClusterBuffers c, int b) {
   const int n = c.counts[b * kCountsStride + kCntElev];
   const int num_cluster = c.counts[b * kCountsStride + kCntClusters];
-  const int* __restrict__ grid = c.grid + (long)b * (MOT_MAX_GRID * MOT_MAX_GRID);
+  const GridLabel* __restrict__ grid = c.grid + (long)b * (MOT_MAX_GRID * MOT_MAX_GRID);
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
     int cell;
     if (c.ecell) {

@@ -5,7 +5,7 @@
 //
 //   C1 cart_occupancy_kernel   N_e pts -> two bit-planes per frame ("cell seen >= 1", "seen >= 2"); stage-wise entry
 //                              points only — in the fused path classify_compact_kernel (ground.hip) fills the planes
-//   C2 ccl_kernel              bit-plane -> 3x3 dilation -> connected components -> int32 label grid
+//   C2 ccl_kernel              bit-plane -> 3x3 dilation -> connected components -> label grid (16-bit on the device, int32 across the ABI)
 //
 // Design (not a translation of the recursive flood fill):
 //  * the reference only needs "count > 1" per cell, so the 250 x 250 counter histogram collapses to two
@@ -342,7 +342,7 @@ ccl_kernel(MotDevParams p, ClusterBuffers c) {
   const int num_cluster = s_rootpre[kMaxRuns / 32];
   if (tid == 0) c.counts[b * kCountsStride + kCntClusters] = num_cluster;
   // label grid, x-major with stride G (cartesianData[x][y]); ids in raster order of each component's first cell
-  int* __restrict__ grid = c.grid + (long)b * (MOT_MAX_GRID * MOT_MAX_GRID);
+  GridLabel* __restrict__ grid = c.grid + (long)b * (MOT_MAX_GRID * MOT_MAX_GRID);
   // every run's root becomes its cluster id (each thread reads only the entries it rewrites)
   for (int r = tid; r < R; r += kCclBlock) {
     const unsigned root = PL((unsigned)r);
@@ -354,7 +354,7 @@ ccl_kernel(MotDevParams p, ClusterBuffers c) {
   // start, a popcount loop, the parent and two prefix tables per cell (that version of the pass was 46 % of the kernel).
   {
     const int lane = tid & 63, wave = tid >> 6;
-    const bool pairs = (G & 1) == 0;   // rows start 8-byte aligned
+    const bool pairs = (G & 1) == 0;   // every quad starts 4-byte aligned (y0 is a multiple of 4, rows start at even offsets): two 32-bit stores of two labels each
     const int y0 = lane * 4;
     // the labels of a row's quad: branch-free, so that the LDS chains of the two rows a wave handles per trip overlap (the pass was a
     // quarter of this kernel, one dependent chain of five LDS reads per row and lane)
@@ -371,13 +371,13 @@ ccl_kernel(MotDevParams p, ClusterBuffers c) {
       }
     };
     auto put = [&](int x, const int (&lab)[4]) {
-      int* dst = grid + x * G + y0;
+      GridLabel* dst = grid + x * G + y0;
       if (pairs && y0 + 4 <= G) {
-        reinterpret_cast<int2*>(dst)[0] = make_int2(lab[0], lab[1]);
-        reinterpret_cast<int2*>(dst)[1] = make_int2(lab[2], lab[3]);
+        reinterpret_cast<unsigned*>(dst)[0] = (unsigned)lab[0] | ((unsigned)lab[1] << 16);
+        reinterpret_cast<unsigned*>(dst)[1] = (unsigned)lab[2] | ((unsigned)lab[3] << 16);
       } else {
 #pragma unroll
-        for (int j = 0; j < 4; j++) if (y0 + j < G) dst[j] = lab[j];
+        for (int j = 0; j < 4; j++) if (y0 + j < G) dst[j] = (GridLabel)lab[j];
       }
     };
     constexpr int kRowStep = kCclBlock / 64;

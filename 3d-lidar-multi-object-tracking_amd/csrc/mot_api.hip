@@ -47,7 +47,8 @@ struct mot_ctx {
   OccWord* d_occ_list = nullptr;
   int* d_occ_count = nullptr;
   int occ_chunks = 0;
-  int* d_grid = nullptr;
+  GridLabel* d_grid = nullptr;
+  std::vector<GridLabel> h_grid16;     // host side of the int32 <-> 16-bit conversion of the ABI's label grid
   int* d_label = nullptr;
   ClusterStats* d_stats = nullptr;
   BoxCandidate* d_cand = nullptr;
@@ -381,7 +382,7 @@ static int create_impl(mot_ctx* c) {
   MOT_HIP(c, hipMalloc(&c->d_occ_list, B * c->occ_chunks * kPlaneWords * sizeof(OccWord)));
   MOT_HIP(c, hipMalloc(&c->d_occ_count, B * c->occ_chunks * sizeof(int)));
   MOT_HIP(c, hipMemsetAsync(c->d_occ_count, 0, B * c->occ_chunks * sizeof(int), c->stream));
-  MOT_HIP(c, hipMalloc(&c->d_grid, B * MOT_MAX_GRID * MOT_MAX_GRID * sizeof(int)));
+  MOT_HIP(c, hipMalloc(&c->d_grid, B * MOT_MAX_GRID * MOT_MAX_GRID * sizeof(GridLabel)));
   MOT_HIP(c, hipMalloc(&c->d_label, B * N * sizeof(int)));
   MOT_HIP(c, hipMalloc(&c->d_stats, B * kMaxClusters * sizeof(ClusterStats)));
   MOT_HIP(c, hipMalloc(&c->d_cand, B * kMaxClusters * sizeof(BoxCandidate)));
@@ -406,7 +407,7 @@ static int create_impl(mot_ctx* c) {
   }
   MOT_HIP(c, hipMemsetAsync(c->d_plane_a, 0, B * kPlaneWords * sizeof(unsigned), c->stream));
   MOT_HIP(c, hipMemsetAsync(c->d_plane_b, 0, B * kPlaneWords * sizeof(unsigned), c->stream));
-  MOT_HIP(c, hipMemsetAsync(c->d_grid, 0, B * MOT_MAX_GRID * MOT_MAX_GRID * sizeof(int), c->stream));
+  MOT_HIP(c, hipMemsetAsync(c->d_grid, 0, B * MOT_MAX_GRID * MOT_MAX_GRID * sizeof(GridLabel), c->stream));
   {
     ClusterBuffers cb = cluster_buffers(c);
     mot_launch_stats_init(cb, (int)B, c->stream);
@@ -989,7 +990,7 @@ extern "C" int mot_get_clusters(mot_ctx* c, int slot, int32_t* grid, int* num_cl
   if (num_cluster) *num_cluster = c->h_counts[slot * kCountsStride + kCntClusters];
   int ne = c->h_counts[slot * kCountsStride + kCntElev];
   if (point_label && ne > label_capacity) return fail(c, MOT_E_CAPACITY, "more elevated points than the caller's label buffer holds");   // before any copy is queued: "nothing copied"
-  if (grid) MOT_HIP(c, hipMemcpyAsync(grid, c->d_grid + (size_t)slot * MOT_MAX_GRID * MOT_MAX_GRID, (size_t)G * G * sizeof(int), hipMemcpyDeviceToHost, c->stream));
+  if (grid) { c->h_grid16.resize((size_t)G * G); MOT_HIP(c, hipMemcpyAsync(c->h_grid16.data(), c->d_grid + (size_t)slot * MOT_MAX_GRID * MOT_MAX_GRID, (size_t)G * G * sizeof(GridLabel), hipMemcpyDeviceToHost, c->stream)); }
   if (point_label && ne > 0 && c->label_state[slot] != 1) {
     // the fused path left the per-point labels out (mot_set_fused_outputs): this slot's, from its cells and label grid
     ClusterBuffers cb = cluster_buffers(c);
@@ -1000,6 +1001,7 @@ extern "C" int mot_get_clusters(mot_ctx* c, int slot, int32_t* grid, int* num_cl
   }
   if (point_label && ne > 0) MOT_HIP(c, hipMemcpyAsync(point_label, c->d_label + (size_t)slot * c->cap, (size_t)ne * sizeof(int), hipMemcpyDeviceToHost, c->stream));
   MOT_HIP(c, hipStreamSynchronize(c->stream));
+  if (grid) for (size_t i = 0, n = (size_t)G * G; i < n; i++) grid[i] = (int32_t)c->h_grid16[i];   // the ABI's cartesianData is int32 (component_clustering.h:20-22)
   return MOT_OK;
 }
 
@@ -1050,7 +1052,12 @@ extern "C" int mot_box_fit(mot_ctx* c, const float* elev, int n, const int32_t* 
   int rc;
   const int G = c->params.num_grid;
   if (n > 0) MOT_HIP(c, hipMemcpyAsync(c->d_elev, elev, (size_t)n * 16, hipMemcpyHostToDevice, c->stream));
-  MOT_HIP(c, hipMemcpyAsync(c->d_grid, grid, (size_t)G * G * sizeof(int), hipMemcpyHostToDevice, c->stream));
+  // the caller's int32 grid onto the device's 16-bit one: a value outside 0 .. num_cluster names no cluster (getClusteredPoints indexes
+  // its per-cluster vectors with it, box_fitting.cpp:59-66; the kernels treat it as "no label") and becomes 0
+  c->h_grid16.resize((size_t)G * G);
+  for (size_t i = 0, ng = (size_t)G * G; i < ng; i++) { const int32_t v = grid[i]; c->h_grid16[i] = (v < 0 || v > num_cluster) ? (GridLabel)0 : (GridLabel)v; }
+  MOT_HIP(c, hipMemcpyAsync(c->d_grid, c->h_grid16.data(), (size_t)G * G * sizeof(GridLabel), hipMemcpyHostToDevice, c->stream));
+  MOT_HIP(c, hipStreamSynchronize(c->stream));   // (h_grid16 is reused by the next call)
   c->last_fused = false;   // slot 0 now holds this call's cloud: mot_get_ground must not re-run a fused batch's compaction over it
   if ((rc = set_count(c, 0, kCntElev, n))) return rc;
   if ((rc = set_count(c, 0, kCntClusters, num_cluster))) return rc;
@@ -1158,7 +1165,15 @@ extern "C" int mot_cluster_products_host(mot_ctx* c, const float* elev, int n, c
   if (n > c->max_points) return fail(c, MOT_E_CAPACITY, "cloud has more points than max_points");
   const int G = c->params.num_grid;
   if (n > 0) MOT_HIP(c, hipMemcpyAsync(c->d_elev, elev, (size_t)n * 16, hipMemcpyHostToDevice, c->stream));
-  MOT_HIP(c, hipMemcpyAsync(c->d_grid, grid, (size_t)G * G * sizeof(int), hipMemcpyHostToDevice, c->stream));
+  // the caller's int32 grid onto the device's 16-bit one. componentClustering's labels are 0 .. numCluster <= 32 768; the three functions replaced
+  // here use a label only as "!= 0" and as the obstacle's cluster id, so anything outside 0 .. 65 535 is not a label grid
+  c->h_grid16.resize((size_t)G * G);
+  for (size_t i = 0, ng = (size_t)G * G; i < ng; i++) {
+    if (grid[i] < 0 || grid[i] > 65535) return fail(c, MOT_E_ARG, "mot_cluster_products_host: grid labels must lie in 0 .. 65535");
+    c->h_grid16[i] = (GridLabel)grid[i];
+  }
+  MOT_HIP(c, hipMemcpyAsync(c->d_grid, c->h_grid16.data(), (size_t)G * G * sizeof(GridLabel), hipMemcpyHostToDevice, c->stream));
+  MOT_HIP(c, hipStreamSynchronize(c->stream));
   c->last_fused = false;   // slot 0 now holds this call's cloud: mot_get_ground must not re-run a fused batch's compaction over it
   int rc = set_count(c, 0, kCntElev, n);
   if (rc) return rc;

@@ -159,6 +159,10 @@ struct BoxCandidate {          // per cluster, written by the box kernels
   int num_points, pad;
 };
 
+// A cell's cluster label on the device: 16 bits. A grid of at most 256 x 256 cells has at most 32 768 runs, hence clusters; the ABI's int32
+// cartesianData (component_clustering.h:20-22) is widened / narrowed on the host by the entry points that cross it. Half the bytes of the labelling
+// kernel's grid write and half the footprint of the label kernel's per-point gathers (each XCD's L2 fetches a frame's occupied lines for itself).
+typedef unsigned short GridLabel;
 struct ClusterBuffers {
   const float4* elevated;      // [B][cap]
   long cap;
@@ -171,7 +175,7 @@ struct ClusterBuffers {
   int occ_chunks;
   const unsigned short* ecell; // fused path: Cartesian cell of every elevated point from the compaction kernel (see GroundBuffers), else null
   unsigned* ccl_parent;        // [B][kMaxRuns] union-find array of the labelling kernel for frames with more runs than its LDS holds
-  int* grid;                   // [B][65536] labels, x-major with stride num_grid
+  GridLabel* grid;             // [B][65536] labels (16 bits each), x-major with stride num_grid
   int* label;                  // [B][cap] label of each elevated point
   ClusterStats* stats;         // [B][kMaxClusters]
   BoxCandidate* cand;          // [B][kMaxClusters]
@@ -208,7 +212,7 @@ struct SideDevParams {
 };
 struct SideBuffers {
   const float4* elevated;   // the slot's elevated cloud
-  const int* grid;          // the slot's label grid, x-major with stride num_grid
+  const GridLabel* grid;    // the slot's label grid, x-major with stride num_grid
   const int* counts;        // the slot's counters (kCntElev)
   int* cell_first;          // [MOT_MAX_GRID^2] scratch: first point of every labelled cell
   float4* clustered;        // [max_clustered]
