@@ -7,6 +7,7 @@
 #   quick[:tag[:bench args]]   bench.py --steps 8 --warmup 1 --no-aux --no-cpu-baseline <args>, twice
 #   trace1 / trace4            rocprofv3 --kernel-trace --stats of one context alone (B 512) / of the default 4-context line
 #   pmc[:CTR,CTR…]             one rocprofv3 --pmc pass per counter (default FETCH_SIZE,WRITE_SIZE), summarised
+#   pmcsq                      two multi-counter SQ passes (instruction mix; wave / wait / stall cycles), raw means + the per-wave table
 #   kernels:ids[:B]            tools/time_kernels.py B ids  (isolated kernel timings, product and variants/)
 #   tracker[:streams]          tools/tracker_load.py
 #   ab[:steps[:rounds]]        tools/bench_variants_ab.sh (product vs prebuilt variants/, interleaved)
@@ -37,6 +38,12 @@ for step in "$@"; do
          done
          python profiles/summarize_pmc.py $(for ctr in $(echo ${a1:-FETCH_SIZE,WRITE_SIZE} | tr , ' '); do echo $O/pmc_$ctr/p_results.db; done) --json=$O/pmc_B512.json > $O/pmc_B512.txt 2>&1
          grep -v "at::native\|rocprim" $O/pmc_B512.txt | head -20; rm -rf $O/pmc_*/ ;;
+    pmcsq) sqpass() { local tag=$1; shift
+             timeout -k 5 200 rocprofv3 --kernel-trace --pmc "$@" -d $O/pmc_$tag -o p -- python bench.py --steps 1 --warmup 0 --frames 12 --no-aux --no-cpu-baseline --no-all-outputs --batch 512 --contexts 1 > $O/pmc_$tag.log 2>&1; echo "$tag rc=$?"; }
+           sqpass insts SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_SMEM SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR
+           sqpass cycles SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_ANY SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU GRBM_GUI_ACTIVE
+           python profiles/summarize_pmc.py $(find $O/pmc_insts $O/pmc_cycles -name '*.db') --json=$O/pmc_sq_B512.json > $O/pmc_sq_B512.txt 2>&1
+           grep -v "at::native\|rocprim" $O/pmc_sq_B512.txt | tail -18; rm -rf $O/pmc_insts $O/pmc_cycles ;;
     kernels) timeout 500 python tools/time_kernels.py ${a2:-512} $a1 2>&1 | grep -v "amdgpu.ids\|^stream" | tee $O/time_kernels.txt ;;
     tracker) timeout 400 python tools/tracker_load.py ${a1:-128} 2>&1 | grep -v amdgpu.ids | tee $O/tracker_load.txt ;;
     ab) bash tools/bench_variants_ab.sh ${a1:-8} ${a2:-2} 2>&1 | tee $O/ab.txt ;;
