@@ -71,7 +71,7 @@ EXPORTS = (
     "mot_abi_version", "mot_params_preset", "mot_create", "mot_destroy", "mot_reset", "mot_last_error",
     "mot_synchronize", "mot_stream", "mot_ground_remove", "mot_cluster", "mot_box_fit", "mot_ego_update",
     "mot_track_step", "mot_track_get_state", "mot_frames_dev", "mot_sequence_dev", "mot_get_ground", "mot_get_clusters",
-    "mot_get_boxes", "mot_get_tracks", "mot_export_tracks_dev", "mot_side_params_default", "mot_cluster_products", "mot_cluster_products_host", "mot_decode_pointcloud2_dev", "mot_time_stage",
+    "mot_get_boxes", "mot_get_tracks", "mot_export_tracks_dev", "mot_side_params_default", "mot_cluster_products", "mot_cluster_products_host", "mot_box_markers", "mot_decode_pointcloud2_dev", "mot_time_stage",
     "mot_ground_remove_pointcloud2", "mot_box_fit_resident", "mot_frame_pointcloud2",
     "mot_reset_slot", "mot_frames_host", "mot_wait_uploads", "mot_host_alloc", "mot_host_free", "mot_fetch_tracks_async",
     "mot_track_steps_dev", "mot_profile_kernel", "mot_profile_read", "mot_get_params", "mot_set_fused_outputs", "mot_set_tracker_mode", "mot_set_trace_ranges", "mot_reset_tracks_slot", "mot_export_tracks_packed_dev", "mot_set_launch_graphs",
@@ -361,6 +361,12 @@ class Context:
         self._ck(self.lib.mot_cluster_products_host(self._h, _vp(a), n, _vp(grid), C.byref(sp), _vp(cc), max(n, 1), C.byref(ncc), _vp(ob), G * G,
                                                     C.byref(nob), _vp(cm)))
         return dict(clustered=cc[: ncc.value].copy(), obstacles=ob[: nob.value].copy(), cost_map=cm.reshape(sp.cost_height, sp.cost_width))
+
+    def box_markers(self, slot: int = 0, max_boxes: int = 1024):
+        """mark_cluster (box_fitting.cpp:161-209) of every box of ``slot``'s last box stage -> [n_boxes, 6]: centroid xyz, extent xyz"""
+        out = np.zeros((max_boxes, 6), np.float32); nb = C.c_int(0)
+        self._ck(self.lib.mot_box_markers(self._h, slot, _vp(out), max_boxes, C.byref(nb)))
+        return out[: nb.value].copy()
 
     def get_boxes(self, slot: int = 0, max_boxes: int = 4096):
         boxes = np.zeros((max_boxes, 8, 3), np.float32); nb = C.c_int(0); bc = np.zeros(max_boxes, np.int32); nu = C.c_int(0)

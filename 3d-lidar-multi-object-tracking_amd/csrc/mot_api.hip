@@ -68,6 +68,7 @@ struct mot_ctx {
   float4* d_side_obs = nullptr;
   int* d_side_cost = nullptr;
   int* d_side_counts = nullptr;
+  float* d_markers = nullptr;          // [kMaxBoxesPerFrame][6], mot_box_markers (allocated at its first call)
   int2* d_wgtab = nullptr;
   int max_wg = 0;
   // staging buffer of mot_ground_remove_pointcloud2 (grow-only, allocated on first use)
@@ -285,7 +286,7 @@ extern "C" void mot_destroy(mot_ctx* c) {
   for (int i = 0; i < mot_ctx::kArgRing; i++) if (c->arg_ev[i]) (void)hipEventDestroy(c->arg_ev[i]);
   if (c->h_argring) (void)hipHostFree(c->h_argring);
   void* bufs[] = {c->d_in, c->d_argblk, c->d_ecell, c->d_pairs, c->d_pair_count, c->d_hg, c->d_cell, c->d_desc, c->d_ticket, c->d_elev, c->d_ground, c->d_mask, c->d_counts,
-                  c->d_plane_a, c->d_plane_b, c->d_ccl_parent, c->d_occ_list, c->d_occ_count, c->d_grid, c->d_label, c->d_stats, c->d_cand, c->d_boxes, c->d_box_cluster, c->d_rng, c->d_poly, c->d_groups, c->d_cluster_start, c->d_cluster_gstart, c->d_order, c->d_gsorted, c->d_pix, c->d_wgtab, c->d_side_cell, c->d_side_cloud, c->d_side_obs, c->d_side_cost, c->d_side_counts, c->d_raw,
+                  c->d_plane_a, c->d_plane_b, c->d_ccl_parent, c->d_occ_list, c->d_occ_count, c->d_grid, c->d_label, c->d_stats, c->d_cand, c->d_boxes, c->d_box_cluster, c->d_rng, c->d_poly, c->d_groups, c->d_cluster_start, c->d_cluster_gstart, c->d_order, c->d_gsorted, c->d_pix, c->d_wgtab, c->d_side_cell, c->d_side_cloud, c->d_side_obs, c->d_side_cost, c->d_side_counts, c->d_markers, c->d_raw,
                   c->d_tracks, c->d_nt, c->d_tboxes, c->d_gate, c->d_prog, c->d_live, c->d_tout, c->d_tflags, c->d_nlive, c->d_pos, c->d_slot_of, c->d_tomb, c->d_used, c->d_zomb, c->d_nzomb, c->d_cp, c->d_items, c->d_nitems};
   for (void* b : bufs) if (b) (void)hipFree(b);
   if (c->h_counts) (void)hipHostFree(c->h_counts);
@@ -1164,20 +1165,41 @@ extern "C" int mot_cluster_products_host(mot_ctx* c, const float* elev, int n, c
   if ((!elev && n > 0) || n < 0 || !grid) return fail(c, MOT_E_ARG, "mot_cluster_products_host: null cloud / grid or negative n");
   if (n > c->max_points) return fail(c, MOT_E_CAPACITY, "cloud has more points than max_points");
   const int G = c->params.num_grid;
-  if (n > 0) MOT_HIP(c, hipMemcpyAsync(c->d_elev, elev, (size_t)n * 16, hipMemcpyHostToDevice, c->stream));
   // the caller's int32 grid onto the device's 16-bit one. componentClustering's labels are 0 .. numCluster <= 32 768; the three functions replaced
-  // here use a label only as "!= 0" and as the obstacle's cluster id, so anything outside 0 .. 65 535 is not a label grid
+  // here use a label only as "!= 0" and as the obstacle's cluster id, so anything outside 0 .. 65 535 is not a label grid (checked before anything
+  // of slot 0 is overwritten)
   c->h_grid16.resize((size_t)G * G);
   for (size_t i = 0, ng = (size_t)G * G; i < ng; i++) {
     if (grid[i] < 0 || grid[i] > 65535) return fail(c, MOT_E_ARG, "mot_cluster_products_host: grid labels must lie in 0 .. 65535");
     c->h_grid16[i] = (GridLabel)grid[i];
   }
+  if (n > 0) MOT_HIP(c, hipMemcpyAsync(c->d_elev, elev, (size_t)n * 16, hipMemcpyHostToDevice, c->stream));
   MOT_HIP(c, hipMemcpyAsync(c->d_grid, c->h_grid16.data(), (size_t)G * G * sizeof(GridLabel), hipMemcpyHostToDevice, c->stream));
   MOT_HIP(c, hipStreamSynchronize(c->stream));
   c->last_fused = false;   // slot 0 now holds this call's cloud: mot_get_ground must not re-run a fused batch's compaction over it
   int rc = set_count(c, 0, kCntElev, n);
   if (rc) return rc;
   return mot_cluster_products(c, 0, sp, clustered_xyzw, max_clustered, n_clustered, obstacles_xyzc, max_obstacles, n_obstacles, cost_map);
+}
+
+// mark_cluster() for every box of the slot's last box stage (OT/src/cluster/box_fitting.cpp:161-209, :410): what the cluster node's rviz CUBE
+// markers are made of, from the cloud and the cluster-ordered groups still resident in HBM
+extern "C" int mot_box_markers(mot_ctx* c, int slot, float* centroid_extent, int max_boxes, int* n_boxes) {
+  if (!c) return MOT_E_ARG;
+  MOT_GUARD(c);
+  if (slot < 0 || slot >= c->batch || max_boxes < 0 || !n_boxes) return fail(c, MOT_E_ARG, "mot_box_markers: slot or max_boxes out of range, or null n_boxes");
+  int rc = fetch_counts(c, slot);   // (also reports a frame whose groups overflowed: its cluster order is incomplete)
+  if (rc) return rc;
+  const int nb = c->h_counts[slot * kCountsStride + kCntBoxes];
+  *n_boxes = nb;
+  if (nb > max_boxes) return fail(c, MOT_E_CAPACITY, "more boxes than the caller's buffer holds");
+  if (nb == 0 || !centroid_extent) return MOT_OK;
+  if (!c->d_markers) MOT_HIP(c, hipMalloc(&c->d_markers, (size_t)kMaxBoxesPerFrame * 6 * sizeof(float)));
+  mot_launch_box_markers(cluster_buffers(c), slot, c->d_markers, c->stream);
+  MOT_HIP(c, hipGetLastError());
+  MOT_HIP(c, hipMemcpyAsync(centroid_extent, c->d_markers, (size_t)nb * 6 * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+  MOT_HIP(c, hipStreamSynchronize(c->stream));
+  return MOT_OK;
 }
 
 extern "C" int mot_get_ground(mot_ctx* c, int slot, float* elev, int* n_elev, float* ground, int* n_ground,

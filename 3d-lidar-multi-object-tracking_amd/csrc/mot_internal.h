@@ -222,6 +222,7 @@ struct SideBuffers {
   int max_clustered, max_obstacles;
 };
 void mot_launch_side_products(const MotDevParams& p, const SideDevParams& sp, const SideBuffers& s, hipStream_t stream);
+void mot_launch_box_markers(const ClusterBuffers& c, int slot, float* out /*[kMaxBoxesPerFrame][6]*/, hipStream_t stream);
 
 // ---- tracker stage ---------------------------------------------------------------------------
 #ifndef MOT_TRACK_BLOCK

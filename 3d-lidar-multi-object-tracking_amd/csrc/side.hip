@@ -78,6 +78,63 @@ side_products_kernel(MotDevParams p, SideDevParams sp, SideBuffers s) {
   if (tid == 0) { s.out_counts[0] = base_c; s.out_counts[1] = base_o; }
 }
 
+// ------------------------------------------------------------------------------------------ rviz cubes
+// mark_cluster(), OT/src/cluster/box_fitting.cpp:161-209, called at :410 for every cluster whose box survives the rule filter: the CUBE
+// marker's centre is pcl::compute3DCentroid of the cluster's points (float sums in input order, then divided by the count) and its scale
+// pcl::getMinMax3D's max - min. One wave per BOX walks the cluster's groups in input order (the index kernel's gsorted: a group = the points
+// of one 64-point tile that belong to the cluster): every lane loads its point of the tile, the extrema are per-lane and reduced at the end
+// (order-independent), and the three sums advance point by point — the additions of a float sum cannot be reordered — with every lane of the
+// wave carrying the same running sums (a broadcast of the next point's coordinates per step). out[box] = {centroid xyz, extent xyz}.
+constexpr int kMarkerWaves = 4;
+__global__ void MOT_LAUNCH_BOUNDS(kMarkerWaves * 64)
+box_markers_kernel(ClusterBuffers c, int slot, float* __restrict__ out) {
+  const int lane = threadIdx.x & 63, box = blockIdx.x * kMarkerWaves + (threadIdx.x >> 6);
+  const int* counts = c.counts + (long)slot * kCountsStride;
+  int nb = counts[kCntBoxes];
+  if (nb > kMaxBoxesPerFrame) nb = kMaxBoxesPerFrame;
+  if (box >= nb) return;   // (no workgroup barrier below)
+  const int ci = c.box_cluster[(long)slot * kMaxBoxesPerFrame + box] - 1;
+  const int* __restrict__ cgstart = c.cluster_gstart + (long)slot * (kMaxClusters + 1);
+  const SortedGroup* __restrict__ gs = c.gsorted + (long)slot * c.group_cap;
+  const float4* __restrict__ pts = c.elevated + (long)slot * c.cap;
+  const int g0 = cgstart[ci], g1 = cgstart[ci + 1];
+  float sx = 0.f, sy = 0.f, sz = 0.f;
+  int lo[3] = {0x7fffffff, 0x7fffffff, 0x7fffffff}, hi[3] = {(int)0x80000000, (int)0x80000000, (int)0x80000000};   // ordered keys (mot_float_key)
+  int count = 0;
+  SortedGroup g = g0 < g1 ? gs[g0] : SortedGroup{0ull, 0, 0};
+  float4 q = ((g.mask >> lane) & 1ull) ? pts[(long)g.tile * 64 + lane] : make_float4(0.f, 0.f, 0.f, 0.f);
+  for (int gi = g0; gi < g1; gi++) {
+    // the next group's points are on their way while this group's are added up
+    const SortedGroup gn = gi + 1 < g1 ? gs[gi + 1] : SortedGroup{0ull, 0, 0};
+    const float4 qn = ((gn.mask >> lane) & 1ull) ? pts[(long)gn.tile * 64 + lane] : make_float4(0.f, 0.f, 0.f, 0.f);
+    if ((g.mask >> lane) & 1ull) {
+      const int kx = mot_float_key(q.x), ky = mot_float_key(q.y), kz = mot_float_key(q.z);
+      lo[0] = kx < lo[0] ? kx : lo[0]; lo[1] = ky < lo[1] ? ky : lo[1]; lo[2] = kz < lo[2] ? kz : lo[2];
+      hi[0] = kx > hi[0] ? kx : hi[0]; hi[1] = ky > hi[1] ? ky : hi[1]; hi[2] = kz > hi[2] ? kz : hi[2];
+    }
+    unsigned long long m = g.mask;   // wave-uniform
+    while (m) {
+      const int bit = __ffsll((long long)m) - 1;
+      m &= m - 1ull;
+      sx += mot_i2f(wave_bcast_i32(mot_f2i(q.x), bit)); sy += mot_i2f(wave_bcast_i32(mot_f2i(q.y), bit)); sz += mot_i2f(wave_bcast_i32(mot_f2i(q.z), bit));
+    }
+    count += __popcll(g.mask);
+    g = gn; q = qn;
+  }
+#pragma unroll
+  for (int k = 0; k < 3; k++) { lo[k] = wave_reduce_i32_id(lo[k], OpMinI(), 0x7fffffff); hi[k] = wave_reduce_i32_id(hi[k], OpMaxI(), (int)0x80000000); }
+  if (lane == 0) {
+    const float n = (float)count;   // static_cast<Scalar>(cloud.size()), pcl/common/impl/centroid.hpp
+    float* o = out + (long)box * 6;
+    o[0] = sx / n; o[1] = sy / n; o[2] = sz / n;
+    o[3] = mot_key_float(hi[0]) - mot_key_float(lo[0]); o[4] = mot_key_float(hi[1]) - mot_key_float(lo[1]); o[5] = mot_key_float(hi[2]) - mot_key_float(lo[2]);
+  }
+}
+
+void mot_launch_box_markers(const ClusterBuffers& c, int slot, float* out, hipStream_t stream) {
+  hipLaunchKernelGGL(box_markers_kernel, dim3(kMaxBoxesPerFrame / kMarkerWaves), dim3(kMarkerWaves * 64), 0, stream, c, slot, out);
+}
+
 void mot_launch_side_products(const MotDevParams& p, const SideDevParams& sp, const SideBuffers& s, hipStream_t stream) {
   hipLaunchKernelGGL(side_products_kernel, dim3(1), dim3(kSideBlock), 0, stream, p, sp, s);
 }

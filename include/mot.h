@@ -387,6 +387,13 @@ int mot_cluster_products(mot_ctx* ctx, int slot, const mot_side_params* sp, floa
 int mot_cluster_products_host(mot_ctx* ctx, const float* elevated_xyzw, int n, const int32_t* grid, const mot_side_params* sp,
                               float* clustered_xyzw, int max_clustered, int* n_clustered, float* obstacles_xyzc,
                               int max_obstacles, int* n_obstacles, int32_t* cost_map);
+/* The rviz CUBE of every box: mark_cluster(), OT/src/cluster/box_fitting.cpp:161-209, which getBoundingBox calls (:410) for each
+ * cluster whose box it keeps. For box i of `slot`'s last box stage (mot_box_fit / mot_box_fit_resident on slot 0, mot_frames_dev /
+ * mot_sequence_dev on any slot), in the order mot_get_boxes returns them:
+ *   centroid_extent[6*i + 0..2] = pcl::compute3DCentroid of the cluster's points: float sums in input order, divided by the count
+ *   centroid_extent[6*i + 3..5] = pcl::getMinMax3D's max - min, as floats (marker.scale; the caller substitutes 0.1 for a 0, :192-199)
+ * centroid_extent may be NULL (only *n_boxes is written). MOT_E_CAPACITY when max_boxes < *n_boxes. */
+int mot_box_markers(mot_ctx* ctx, int slot, float* centroid_extent, int max_boxes, int* n_boxes);
 
 /* ---------------------------------------------------------------- input decode
  * sensor_msgs/PointCloud2 payload -> the float4 (x, y, z, w) layout of this library, on the device: what

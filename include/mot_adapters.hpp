@@ -11,15 +11,14 @@
 //     before the first call. The reference's tracker state is file-scope globals; here it lives in the context
 //     (mot_reset() forgets it — the reference cannot).
 //   * errors raise std::runtime_error with mot_last_error() instead of assert()/abort().
-//   * boxFitting() fills the rviz CUBE markers (`ma`, box_fitting.cpp:161-209,404-405) on the host from the per-point
-//     cluster labels the library returns: centroid and extent are sequential float sums in input order, as PCL computes them.
+//   * boxFitting() fills the rviz CUBE markers (`ma`, box_fitting.cpp:161-209,404-405) from mot_box_markers: centroid and extent
+//     of every boxed cluster, folded on the device (sequential float sums in input order, as PCL computes them).
 //   * the header defines `numGrid` (component_clustering.h:15) because OT/src/cluster/main.cpp:73 needs it once the
 //     reference header is gone; define MOT_ADAPTERS_NO_REFERENCE_CONSTANTS to keep it out, MOT_ADAPTERS_NUM_GRID=200 for OT0.
 #ifndef MOT_ADAPTERS_HPP_
 #define MOT_ADAPTERS_HPP_
 
 #include <array>
-#include <cfloat>
 #include <stdexcept>
 #include <string>
 #include <type_traits>
@@ -93,33 +92,21 @@ inline std::vector<float> pack(const pcl::PointCloud<pcl::PointXYZ>& c) {
 }
 
 // mark_cluster(), OT/src/cluster/box_fitting.cpp:161-209, for every emitted box (getBoundingBox pushes one marker per box,
-// :404-405). label[i] = cluster of elevated point i (0 = none), box_cluster[b] = 1-based cluster of box b. Centroid =
-// pcl::compute3DCentroid (float accumulation in point order, then a float division), extent = pcl::getMinMax3D.
+// :404-405), from mot_box_markers' six floats per box: pcl::compute3DCentroid (float accumulation in point order, then a
+// float division) and pcl::getMinMax3D's max - min, folded on the device.
 // Compiled only for MarkerArray types that have a `markers` member (any other type is left untouched).
 template <typename MarkerArrayT>
-inline auto fill_cube_markers(MarkerArrayT& ma, const pcl::PointCloud<pcl::PointXYZ>& cloud, const std::vector<int32_t>& label,
-                              const std::vector<int32_t>& box_cluster, int num_cluster, int) -> decltype(ma.markers, void()) {
+inline auto fill_cube_markers(MarkerArrayT& ma, const std::vector<float>& centroid_extent, int n_boxes, int) -> decltype(ma.markers, void()) {
   typedef typename std::decay<decltype(ma.markers)>::type::value_type Marker;
-  struct Acc { float sx = 0, sy = 0, sz = 0, lo[3] = {FLT_MAX, FLT_MAX, FLT_MAX}, hi[3] = {-FLT_MAX, -FLT_MAX, -FLT_MAX}; unsigned n = 0; };
-  std::vector<Acc> acc((size_t)num_cluster + 1);
-  for (size_t i = 0; i < cloud.size(); i++) {
-    int c = label[i];
-    if (c <= 0 || c > num_cluster) continue;
-    Acc& a = acc[c];
-    const float v[3] = {cloud[i].x, cloud[i].y, cloud[i].z};
-    a.sx += v[0]; a.sy += v[1]; a.sz += v[2]; a.n++;
-    for (int k = 0; k < 3; k++) { a.lo[k] = v[k] < a.lo[k] ? v[k] : a.lo[k]; a.hi[k] = v[k] > a.hi[k] ? v[k] : a.hi[k]; }
-  }
-  for (int32_t c : box_cluster) {
-    const Acc& a = acc[c];
+  for (int b = 0; b < n_boxes; b++) {
+    const float* a = &centroid_extent[6 * (size_t)b];
     Marker m;
     m.header.frame_id = "/velodyne";
     m.header.stamp = std::decay<decltype(m.header.stamp)>::type::now();
     m.ns = "cube"; m.id = 0; m.type = Marker::CUBE; m.action = Marker::ADD;
-    const float n = static_cast<float>(a.n);
-    m.pose.position.x = a.sx / n; m.pose.position.y = a.sy / n; m.pose.position.z = a.sz / n;
+    m.pose.position.x = a[0]; m.pose.position.y = a[1]; m.pose.position.z = a[2];
     m.pose.orientation.x = 0.0; m.pose.orientation.y = 0.0; m.pose.orientation.z = 0.0; m.pose.orientation.w = 1.0;
-    m.scale.x = a.hi[0] - a.lo[0]; m.scale.y = a.hi[1] - a.lo[1]; m.scale.z = a.hi[2] - a.lo[2];
+    m.scale.x = a[3]; m.scale.y = a[4]; m.scale.z = a[5];
     if (m.scale.x == 0) m.scale.x = 0.1;
     if (m.scale.y == 0) m.scale.y = 0.1;
     if (m.scale.z == 0) m.scale.z = 0.1;
@@ -129,7 +116,7 @@ inline auto fill_cube_markers(MarkerArrayT& ma, const pcl::PointCloud<pcl::Point
   }
 }
 template <typename MarkerArrayT>
-inline void fill_cube_markers(MarkerArrayT&, const pcl::PointCloud<pcl::PointXYZ>&, const std::vector<int32_t>&, const std::vector<int32_t>&, int, long) {}
+inline void fill_cube_markers(MarkerArrayT&, const std::vector<float>&, int, long) {}
 }  // namespace mot_adapters
 
 // OT/include/ground_removal.h:62-64 — appends to elevatedCloud / groundCloud in input order, like the reference
@@ -234,13 +221,13 @@ inline std::vector<pcl::PointCloud<pcl::PointXYZ>> boxFitting(pcl::PointCloud<pc
   std::vector<int32_t> grid(G * G);
   for (size_t x = 0; x < G; x++) for (size_t y = 0; y < G; y++) grid[x * G + y] = cartesianData[x][y];
   std::vector<float> boxes(1024 * 24);
-  std::vector<int32_t> box_cluster(1024), label(elevatedCloud->size() + 1);
   int nb = 0;
-  check(mot_box_fit(context(), in.data(), (int)elevatedCloud->size(), grid.data(), numCluster, boxes.data(), 1024, &nb, box_cluster.data(), nullptr));
-  box_cluster.resize(nb);
-  if (nb > 0) {   // the per-point labels the box stage left in slot 0 (getClusteredPoints' lookup, box_fitting.cpp:46-72)
-    check(mot_get_clusters(context(), 0, nullptr, nullptr, label.data(), (int)label.size()));
-    fill_cube_markers(ma, *elevatedCloud, label, box_cluster, numCluster, 0);
+  check(mot_box_fit(context(), in.data(), (int)elevatedCloud->size(), grid.data(), numCluster, boxes.data(), 1024, &nb, nullptr, nullptr));
+  if (nb > 0) {   // the cubes, from the cloud and the cluster order the box stage left in slot 0
+    std::vector<float> cubes(6 * (size_t)nb);
+    int n_marked = 0;
+    check(mot_box_markers(context(), 0, cubes.data(), nb, &n_marked));
+    fill_cube_markers(ma, cubes, nb, 0);
   }
   std::vector<pcl::PointCloud<pcl::PointXYZ>> out(nb);
   for (int b = 0; b < nb; b++)

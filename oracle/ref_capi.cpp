@@ -165,6 +165,23 @@ int ref_box_fit(const float* elev, int n, const int32_t* grid, int num_cluster, 
   return 0;
 }
 
+// the MarkerArray boxFitting() fills through mark_cluster(), OT/src/cluster/box_fitting.cpp:161-209, :410 — per kept box the CUBE's
+// pose.position and scale (doubles, the 0.1 substitution of :192-199 applied); pcl::compute3DCentroid / getMinMax3D are the shim's
+int ref_box_markers(const float* elev, int n, const int32_t* grid, int num_cluster, double* pos_scale6, int max_boxes, int* n_boxes) {
+  Quiet q;
+  auto cloud = to_cloud(elev, n);
+  for (int x = 0; x < numGrid; x++) memcpy(g_grid[x].data(), grid + x * numGrid, sizeof(int) * numGrid);
+  visualization_msgs::MarkerArray ma;
+  boxFitting(cloud, g_grid, num_cluster, ma);
+  *n_boxes = (int)ma.markers.size();
+  for (int i = 0; i < (int)ma.markers.size() && i < max_boxes; i++) {
+    const auto& m = ma.markers[i];
+    pos_scale6[6 * i] = m.pose.position.x; pos_scale6[6 * i + 1] = m.pose.position.y; pos_scale6[6 * i + 2] = m.pose.position.z;
+    pos_scale6[6 * i + 3] = m.scale.x; pos_scale6[6 * i + 4] = m.scale.y; pos_scale6[6 * i + 5] = m.scale.z;
+  }
+  return 0;
+}
+
 // ---- tracker (file-scope globals) ----
 void ref_tracker_reset() {
   init_ = false; timestamp_ = 0; egoVelo_ = 0; egoYaw_ = 0; egoPreYaw_ = 0; countIt = 0;

@@ -8,7 +8,6 @@
 // mot_box_fit_resident). The host only assembles messages. The rviz CUBE markers need each boxed cluster's centroid and
 // extent exactly as PCL accumulates them (float sums in point order), so they are folded on the host from the per-point
 // labels the library returns — a few tens of microseconds on data the node holds anyway.
-#include <cfloat>
 
 #include <nav_msgs/OccupancyGrid.h>
 #include <object_tracking/ObstacleList.h>
@@ -44,7 +43,7 @@ class ClusterNode {
     grid_msg_.info.origin.position.y = (-1) * (side_.cost_height / 2.0) * side_.cost_resolution + side_.cost_offset_y;
     grid_msg_.info.origin.position.z = side_.cost_offset_z;
     grid_msg_.info.origin.orientation.w = 1.0;
-    boxes_.resize((size_t)kMaxBoxes * 24); box_cluster_.resize(kMaxBoxes);
+    boxes_.resize((size_t)kMaxBoxes * 24);
     cost_.resize((size_t)side_.cost_width * side_.cost_height);
     obstacles_.resize((size_t)prm_.num_grid * prm_.num_grid * 4);
     sub_ = nh.subscribe("none_ground_topic", 160, &ClusterNode::on_cloud, this);
@@ -67,13 +66,13 @@ class ClusterNode {
   void on_cloud(const sensor_msgs::PointCloud2ConstPtr& input) {
     const size_t n = (size_t)input->width * input->height;
     const float* elevated = as_float4(*input, n);
-    if (clustered_.size() < 4 * n + 4) { clustered_.resize(4 * n + 4); label_.resize(n + 1); }
+    if (clustered_.size() < 4 * n + 4) { clustered_.resize(4 * n + 4); }
 
     int num_cluster = 0, n_clustered = 0, n_obstacles = 0, n_boxes = 0;
     mot_ros::check(ctx_, mot_cluster(ctx_, elevated, (int)n, nullptr, &num_cluster, nullptr), "mot_cluster");
     mot_ros::check(ctx_, mot_cluster_products(ctx_, 0, &side_, clustered_.data(), (int)n, &n_clustered, obstacles_.data(), prm_.num_grid * prm_.num_grid,
                                               &n_obstacles, cost_.data()), "mot_cluster_products");
-    mot_ros::check(ctx_, mot_box_fit_resident(ctx_, boxes_.data(), kMaxBoxes, &n_boxes, box_cluster_.data(), nullptr), "mot_box_fit_resident");
+    mot_ros::check(ctx_, mot_box_fit_resident(ctx_, boxes_.data(), kMaxBoxes, &n_boxes, nullptr, nullptr), "mot_box_fit_resident");
 
     // realtime_cost_map
     grid_msg_.header.frame_id = input->header.frame_id;
@@ -109,40 +108,28 @@ class ClusterNode {
     }
     boxes_pub_.publish(box_msg);
 
-    cubes_pub_.publish(cube_markers(elevated, n, num_cluster, n_boxes));
+    cubes_pub_.publish(cube_markers(n_boxes));
     lines_pub_.publish(mot_ros::box_edges("velodyne", boxes_.data(), n_boxes));
   }
 
-  // one CUBE per box: centroid and axis-aligned extent of the cluster's points (mark_cluster, box_fitting.cpp:161-209)
-  visualization_msgs::MarkerArray cube_markers(const float* elevated, size_t n, int num_cluster, int n_boxes) {
+  // one CUBE per box: centroid and axis-aligned extent of the cluster's points (mark_cluster, box_fitting.cpp:161-209), folded on the
+  // device from the cloud and the cluster-ordered groups the box stage left in HBM (mot_box_markers): 24 bytes per box come back
+  visualization_msgs::MarkerArray cube_markers(int n_boxes) {
     visualization_msgs::MarkerArray out;
     if (n_boxes == 0) return out;
-    mot_ros::check(ctx_, mot_get_clusters(ctx_, 0, nullptr, nullptr, label_.data(), (int)label_.size()), "mot_get_clusters");
-    struct Fold { float sum[3] = {0, 0, 0}, lo[3] = {FLT_MAX, FLT_MAX, FLT_MAX}, hi[3] = {-FLT_MAX, -FLT_MAX, -FLT_MAX}; unsigned count = 0; };
-    std::vector<Fold> fold((size_t)num_cluster + 1);
-    for (size_t i = 0; i < n; i++) {
-      const int c = label_[i];
-      if (c <= 0 || c > num_cluster) continue;
-      Fold& f = fold[c];
-      for (int k = 0; k < 3; k++) {
-        const float v = elevated[4 * i + k];
-        f.sum[k] += v;
-        if (v < f.lo[k]) f.lo[k] = v;
-        if (v > f.hi[k]) f.hi[k] = v;
-      }
-      f.count++;
-    }
+    cubes_.resize(6 * (size_t)n_boxes);
+    int nb = 0;
+    mot_ros::check(ctx_, mot_box_markers(ctx_, 0, cubes_.data(), n_boxes, &nb), "mot_box_markers");
     for (int b = 0; b < n_boxes; b++) {
-      const Fold& f = fold[box_cluster_[b]];
+      const float* f = &cubes_[6 * (size_t)b];
       visualization_msgs::Marker m;
       m.header.frame_id = "/velodyne";
       m.header.stamp = ros::Time::now();
       m.ns = "cube"; m.id = 0;
       m.type = visualization_msgs::Marker::CUBE; m.action = visualization_msgs::Marker::ADD;
-      const float count = static_cast<float>(f.count);
-      m.pose.position.x = f.sum[0] / count; m.pose.position.y = f.sum[1] / count; m.pose.position.z = f.sum[2] / count;
+      m.pose.position.x = f[0]; m.pose.position.y = f[1]; m.pose.position.z = f[2];
       m.pose.orientation.w = 1.0;
-      const float extent[3] = {f.hi[0] - f.lo[0], f.hi[1] - f.lo[1], f.hi[2] - f.lo[2]};
+      const float extent[3] = {f[3], f[4], f[5]};
       m.scale.x = extent[0] == 0 ? 0.1 : extent[0]; m.scale.y = extent[1] == 0 ? 0.1 : extent[1]; m.scale.z = extent[2] == 0 ? 0.1 : extent[2];
       m.color.g = 1.0f; m.color.a = 1.0;
       m.lifetime = ros::Duration(1.0);
@@ -157,8 +144,8 @@ class ClusterNode {
   ros::Publisher cloud_pub_, lines_pub_, cubes_pub_, costmap_pub_, obstacles_pub_, boxes_pub_;
   ros::Subscriber sub_;
   nav_msgs::OccupancyGrid grid_msg_;
-  std::vector<float> clustered_, obstacles_, boxes_, repacked_;
-  std::vector<int32_t> cost_, box_cluster_, label_;
+  std::vector<float> clustered_, obstacles_, boxes_, repacked_, cubes_;
+  std::vector<int32_t> cost_;
   std::vector<uint8_t> scratch_;
 };
 

@@ -402,6 +402,28 @@ def ref_box_fit(elev, grid, num_cluster, max_boxes=4096):
     return dict(boxes=boxes[: min(nb.value, max_boxes)].copy(), n=nb.value)
 
 
+def ref_box_markers(elev, grid, num_cluster, max_boxes=4096):
+    """the CUBE markers the reference's boxFitting fills (mark_cluster, box_fitting.cpp:161-209): [n_boxes, 6] float64
+    pose.position xyz, scale xyz (0.1 where the extent is 0)"""
+    a = _pts(elev); grid = np.ascontiguousarray(grid, np.int32)
+    out = np.zeros((max_boxes, 6), np.float64); nb = C.c_int(0)
+    ref().ref_box_markers(a.ctypes.data_as(C.c_void_p), len(a), grid.ctypes.data_as(C.c_void_p), num_cluster,
+                          out.ctypes.data_as(C.c_void_p), max_boxes, C.byref(nb))
+    return out[: min(nb.value, max_boxes)].copy()
+
+
+def box_markers_numpy(elev, point_label, box_cluster):
+    """mark_cluster restated: float32 sums in input order (np.add.accumulate is sequential), divided by the count; max - min.
+    -> [n_boxes, 6] float32 centroid xyz, extent xyz (no 0.1 substitution)"""
+    a = _pts(elev); lab = np.asarray(point_label)
+    out = np.zeros((len(box_cluster), 6), np.float32)
+    for i, c in enumerate(box_cluster):
+        pts = a[lab == c, :3]
+        out[i, :3] = np.add.accumulate(pts, axis=0, dtype=np.float32)[-1] / np.float32(len(pts))
+        out[i, 3:] = pts.max(axis=0) - pts.min(axis=0)
+    return out
+
+
 def ref_cluster_products(elev, grid):
     """the reference's own makeClusteredCloud / setObsMsg / createCostMap (OT preset; 50 x 50 cost map)"""
     a = _pts(elev); n = len(a); grid = np.ascontiguousarray(grid, np.int32)

@@ -254,6 +254,38 @@ def test_box_fit_resident(ctx, oracle, synth):
     assert len(o["boxes"]) > 0 and np.array_equal(a["boxes"], o["boxes"]) and np.array_equal(b["boxes"], o["boxes"])
     assert np.array_equal(a["box_cluster"], b["box_cluster"])
 
+@pytest.mark.parametrize("n,stream,frame", [(120000, 3, 1), (200000, 4, 1), (9000, 6, 2)])
+def test_box_markers(ctx, oracle, synth, n, stream, frame):
+    """the rviz cubes (mark_cluster, box_fitting.cpp:161-209) folded on the device: bit-equal to the float32 sums in input order, and to
+    the MarkerArray the reference's own boxFitting fills where that build is present; then every slot of a fused batch"""
+    import oracle_lib as O
+    p = oracle.params(0)
+    e = oracle.ground_remove(p, synth.make_cloud(n, stream, frame))["elevated"]
+    cl = ctx.cluster(e)
+    b = ctx.box_fit_resident()
+    m = ctx.box_markers(0)
+    assert len(m) == len(b["boxes"]) > 0
+    assert np.array_equal(m.view(np.uint32), O.box_markers_numpy(e, cl["point_label"], b["box_cluster"]).view(np.uint32))
+    if O.ref() is not None:
+        mine = m.astype(np.float64); mine[:, 3:][mine[:, 3:] == 0] = 0.1
+        assert np.array_equal(mine, O.ref_box_markers(e, cl["grid"], cl["num_cluster"]))
+    with pytest.raises(Exception):
+        ctx.box_markers(0, max_boxes=len(m) - 1)
+    if n == 120000:
+        import hiprt
+        clouds = [synth.make_cloud(120000, s, f) for s, f in ((0, 0), (1, 4), (2, 9))]
+        stride = 131072
+        host = np.zeros((3, stride, 4), np.float32)
+        for s, c in enumerate(clouds):
+            host[s, : len(c)] = c
+        dev = hiprt.DeviceBuffer(host)
+        ctx.frames_dev(dev.ptr, stride * 4, [len(c) for c in clouds])
+        for s, c in enumerate(clouds):
+            es = oracle.ground_remove(p, c)["elevated"]
+            k = ctx.get_clusters(s, len(es)); bb = ctx.get_boxes(s)
+            assert np.array_equal(ctx.box_markers(s).view(np.uint32), O.box_markers_numpy(es, k["point_label"], bb["box_cluster"]).view(np.uint32))
+
+
 ZERO_HEIGHT_CASES = ([np.nan, np.nan, np.nan, -0.0, np.nan, np.nan], [np.nan, 0.0, np.nan, -0.0, np.nan, np.nan], [-1.0, -0.0, 0.0, -0.5, np.nan, np.nan],
                      [-1.0, -2.0, -0.0, -0.0, 0.0, np.nan], [0.5, -0.0, 0.0, np.nan, np.nan, np.nan], [-0.0] * 6, [0.0] + [-0.0] * 5)
 

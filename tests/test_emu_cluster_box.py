@@ -57,6 +57,40 @@ def test_emu_side_products(mot, emu_lib, oracle, synth):
             assert np.array_equal(h[k], oh[k]), k
 
 
+def test_emu_box_markers(mot, emu_lib, oracle, synth):
+    """mot_box_markers (the rviz cubes: mark_cluster, box_fitting.cpp:161-209) under the emulator: equal to the float32 restatement in
+    numpy bit for bit, and to the markers the reference's own boxFitting fills; stage-wise and fused slots"""
+    import oracle_lib as O
+    p = oracle.params(0)
+    with mot.Context(lib_path=emu_lib, max_points=40000, max_batch=2) as c:
+        clouds = [synth.make_cloud(36000, 2, 1), synth.make_cloud(30000, 5, 0)]
+        elev = oracle.ground_remove(p, clouds[0])["elevated"]
+        r = c.cluster(elev)
+        b = c.box_fit_resident()
+        m = c.box_markers(0)
+        assert len(m) == len(b["boxes"]) > 5
+        want = O.box_markers_numpy(elev, r["point_label"], b["box_cluster"])
+        assert np.array_equal(m.view(np.uint32), want.view(np.uint32))
+        if O.ref() is not None:
+            rm = O.ref_box_markers(elev, r["grid"], r["num_cluster"])
+            mine = m.astype(np.float64); mine[:, 3:][mine[:, 3:] == 0] = 0.1
+            assert np.array_equal(mine, rm)
+        with pytest.raises(mot.MotError):
+            c.box_markers(0, max_boxes=len(m) - 1)
+        # every slot of a fused batch
+        host = np.zeros((2, 40000, 4), np.float32)
+        for s, cl in enumerate(clouds):
+            host[s, : len(cl)] = cl
+        c.frames_dev(host.ctypes.data, 40000 * 4, [len(cl) for cl in clouds])
+        for s, cl in enumerate(clouds):
+            e = oracle.ground_remove(p, cl)["elevated"]
+            k = c.get_clusters(s, len(e)); bb = c.get_boxes(s)
+            assert np.array_equal(c.box_markers(s).view(np.uint32), O.box_markers_numpy(e, k["point_label"], bb["box_cluster"]).view(np.uint32))
+        # no boxes: nothing to mark
+        c.cluster(np.zeros((0, 4), np.float32)); c.box_fit_resident()
+        assert c.box_markers(0).shape == (0, 6)
+
+
 @pytest.mark.parametrize("preset", [0, 1])
 def test_emu_ccl_patterns(mot, emu_lib, oracle, preset):
     rng = np.random.default_rng(1)
