@@ -11,6 +11,7 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <mutex>
 #include <random>
 #include <string>
 #include <vector>
@@ -561,10 +562,9 @@ enum { kK1 = 10, kK2 = 11, kK3 = 12, kC1 = 20, kC2 = 21, kB1 = 30, kB2 = 31, kB3
 struct Roctx {
   int (*push)(const char*) = nullptr;
   int (*pop)() = nullptr;
-  bool tried = false;
-  void load() {
-    if (tried) return;
-    tried = true;
+  std::once_flag once;
+  void load() { std::call_once(once, [this] { find(); }); }   // (contexts of several threads may switch their ranges on at the same time)
+  void find() {
 #ifndef MOT_HIPEMU
     for (const char* name : {"libroctx64.so", "libroctx64.so.4", "librocprofiler-sdk-roctx.so"}) {
       if (void* h = dlopen(name, RTLD_LAZY | RTLD_LOCAL)) {

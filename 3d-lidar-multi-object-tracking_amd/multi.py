@@ -120,7 +120,9 @@ class TrackGatherAll:
             self.done = [None, None]   # the collective that last used buffer pair i
 
     def step(self, force_collective: bool = False):
-        """export every context's packed block (async, each on its context's stream), then ONE collective for all of them"""
+        """export every context's packed block (async, each on its context's stream), then ONE collective for all of them.
+        Returns the receive buffer of this step: complete once the side stream has run (synchronize(), or a wait on `self.done[self.last]`
+        from the consumer's stream), and REWRITTEN by the step after next — a consumer that needs it longer copies it."""
         torch = self.torch
         i = self.tick & 1
         self.tick += 1
