@@ -123,6 +123,11 @@ def test_emu_shuffled_many_clusters(mot, emu_lib, oracle):
         assert r["num_cluster"] == o["num_cluster"] and np.array_equal(r["grid"], o["grid"])
         b = c.box_fit(cloud, o["grid"], o["num_cluster"]); ob = oracle.box_fit(p, cloud, o["grid"], o["num_cluster"])
         assert np.array_equal(b["boxes"], ob["boxes"]) and np.array_equal(b["box_cluster"], ob["box_cluster"])
+        # the cubes of a frame whose clusters are interleaved point by point (hundreds of one-point groups per cluster, the index
+        # kernel's general path): still the sums in input order
+        import oracle_lib as O
+        assert len(b["boxes"]) > 0
+        assert np.array_equal(c.box_markers(0).view(np.uint32), O.box_markers_numpy(cloud, o["point_label"], b["box_cluster"]).view(np.uint32))
 
 ZERO_HEIGHT_CASES = ([np.nan, np.nan, np.nan, -0.0, np.nan, np.nan], [np.nan, 0.0, np.nan, -0.0, np.nan, np.nan], [-1.0, -0.0, 0.0, -0.5, np.nan, np.nan],
                      [-1.0, -2.0, -0.0, -0.0, 0.0, np.nan], [0.5, -0.0, 0.0, np.nan, np.nan, np.nan], [-0.0] * 6, [0.0] + [-0.0] * 5)
