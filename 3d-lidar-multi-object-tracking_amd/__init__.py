@@ -73,7 +73,7 @@ EXPORTS = (
     "mot_track_step", "mot_track_get_state", "mot_frames_dev", "mot_sequence_dev", "mot_get_ground", "mot_get_clusters",
     "mot_get_boxes", "mot_get_tracks", "mot_export_tracks_dev", "mot_side_params_default", "mot_cluster_products", "mot_cluster_products_host", "mot_box_markers", "mot_decode_pointcloud2_dev", "mot_time_stage",
     "mot_ground_remove_pointcloud2", "mot_box_fit_resident", "mot_frame_pointcloud2",
-    "mot_reset_slot", "mot_frames_host", "mot_wait_uploads", "mot_host_alloc", "mot_host_free", "mot_fetch_tracks_async",
+    "mot_reset_slot", "mot_stream_snapshot_size", "mot_stream_save", "mot_stream_load", "mot_frames_host", "mot_wait_uploads", "mot_host_alloc", "mot_host_free", "mot_fetch_tracks_async",
     "mot_track_steps_dev", "mot_profile_kernel", "mot_profile_read", "mot_get_params", "mot_set_fused_outputs", "mot_set_tracker_mode", "mot_set_trace_ranges", "mot_reset_tracks_slot", "mot_export_tracks_packed_dev", "mot_set_launch_graphs",
 )
 ABI_VERSION = 4
@@ -180,6 +180,18 @@ class Context:
     def reset_tracks_slot(self, slot: int):
         """forget the tracks of one stream, keep its ego pose (the origin of its global frame)"""
         self._ck(self.lib.mot_reset_tracks_slot(self._h, slot))
+
+    def stream_save(self, slot: int = 0) -> bytes:
+        """the tracker state of one stream as a relocatable block (mot_stream_save): load it into any slot of a context with the
+        same max_tracks_total and the stream continues bit for bit"""
+        cap = C.c_size_t(0)
+        self._ck(self.lib.mot_stream_snapshot_size(self._h, C.byref(cap)))
+        buf = (C.c_char * cap.value)(); n = C.c_size_t(0)
+        self._ck(self.lib.mot_stream_save(self._h, slot, buf, cap, C.byref(n)))
+        return bytes(buf[: n.value])
+
+    def stream_load(self, slot: int, blob: bytes):
+        self._ck(self.lib.mot_stream_load(self._h, slot, blob, C.c_size_t(len(blob))))
 
     def set_launch_graphs(self, on: bool = True):
         """send the fused entry points' launch sequence as one hipGraph launch (per-frame latency path; default off)"""

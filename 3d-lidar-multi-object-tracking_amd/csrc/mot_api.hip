@@ -1549,6 +1549,122 @@ extern "C" int mot_reset_slot(mot_ctx* c, int slot) {
   return MOT_OK;
 }
 
+// ---------------------------------------------------------------------------------------- stream snapshots
+// The tracker state of ONE stream as a relocatable block of host memory: save it, load it into any slot of any context with the same
+// track-slot count (another GPU, another process, after a restart) and the stream continues bit for bit. The reference keeps this state
+// in file-scope globals (imm_ukf_jpda.cpp:19-24,56-70) and can neither save nor reset it (checkpoint / resume).
+// Layout: SnapshotHeader, then the arrays in the order written below; the per-ever-track arrays carry nt entries, not E.
+struct SnapshotHeader {
+  uint32_t magic, abi, header_bytes, track_bytes, record_bytes;   // 'MOTS', MOT_ABI_VERSION, sizeof(SnapshotHeader), sizeof(DevTrack), sizeof(mot_track)
+  int32_t T, nt, nlive, nzomb, flags;
+  uint8_t init, ego_called, tracks_restart, pad[5];
+  double timestamp, egoVelo, egoYaw, egoPreYaw, rx, ry, ryaw, egoPoint[3];
+  uint64_t total_bytes;
+};
+static size_t snapshot_bytes(size_t T, size_t nt) {
+  const size_t usedW = (T + 63) / 64;
+  return sizeof(SnapshotHeader) + T * sizeof(DevTrack) + T * sizeof(int) /*live*/ + T * sizeof(int) /*zomb*/ + usedW * sizeof(unsigned long long) +
+         T * sizeof(mot_track) + nt * (sizeof(Vec2d) + sizeof(int) + sizeof(TrackTomb));
+}
+
+extern "C" int mot_stream_snapshot_size(mot_ctx* c, size_t* bytes) {
+  if (!c) return MOT_E_ARG;
+  if (!bytes) return fail(c, MOT_E_ARG, "mot_stream_snapshot_size: null bytes");
+  *bytes = snapshot_bytes((size_t)c->max_tracks_total, (size_t)c->max_tracks_ever);
+  return MOT_OK;
+}
+
+extern "C" int mot_stream_save(mot_ctx* c, int slot, void* blob, size_t capacity, size_t* written) {
+  if (!c) return MOT_E_ARG;
+  MOT_GUARD(c);
+  if (slot < 0 || slot >= c->batch || !blob || !written) return fail(c, MOT_E_ARG, "mot_stream_save: slot out of range, null blob or null written");
+  const size_t T = c->max_tracks_total, E = c->max_tracks_ever, usedW = (T + 63) / 64;
+  int meta[4] = {0, 0, 0, 0};
+  MOT_HIP(c, hipMemcpyAsync(&meta[0], c->d_nt + slot, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+  MOT_HIP(c, hipMemcpyAsync(&meta[1], c->d_nlive + slot, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+  MOT_HIP(c, hipMemcpyAsync(&meta[2], c->d_nzomb + slot, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+  MOT_HIP(c, hipMemcpyAsync(&meta[3], c->d_tflags + slot, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+  MOT_HIP(c, hipStreamSynchronize(c->stream));
+  const mot_ctx::SlotEgo& e = c->ego[slot];
+  const bool seeded = e.init && !e.tracks_restart;   // before the first tracker step (or after a restart) the device arrays of the slot mean nothing
+  const size_t nt = seeded ? (size_t)meta[0] : 0;
+  if (nt > E) return fail(c, MOT_E_STATE, "mot_stream_save: the slot's track count exceeds the context's capacity");
+  const size_t total = snapshot_bytes(T, nt);
+  *written = total;
+  if (total > capacity) return fail(c, MOT_E_CAPACITY, "mot_stream_save: the blob is smaller than the snapshot (mot_stream_snapshot_size gives the upper bound)");
+  SnapshotHeader h;
+  memset(&h, 0, sizeof h);
+  h.magic = 0x53544f4du; h.abi = MOT_ABI_VERSION; h.header_bytes = sizeof(SnapshotHeader); h.track_bytes = sizeof(DevTrack); h.record_bytes = sizeof(mot_track);
+  h.T = (int32_t)T; h.nt = (int32_t)nt; h.nlive = seeded ? meta[1] : 0; h.nzomb = seeded ? meta[2] : 0; h.flags = seeded ? meta[3] : 0;
+  h.init = e.init; h.ego_called = e.ego_called; h.tracks_restart = e.tracks_restart;
+  h.timestamp = e.timestamp; h.egoVelo = e.egoVelo; h.egoYaw = e.egoYaw; h.egoPreYaw = e.egoPreYaw; h.rx = e.rx; h.ry = e.ry; h.ryaw = e.ryaw;
+  for (int k = 0; k < 3; k++) h.egoPoint[k] = e.egoPoint[k];
+  h.total_bytes = total;
+  char* o = static_cast<char*>(blob);
+  memcpy(o, &h, sizeof h); o += sizeof h;
+  auto take = [&](const void* d, size_t bytes) -> hipError_t {
+    hipError_t rc = bytes ? hipMemcpyAsync(o, d, bytes, hipMemcpyDeviceToHost, c->stream) : hipSuccess;
+    o += bytes;
+    return rc;
+  };
+  MOT_HIP(c, take(c->d_tracks + (size_t)slot * T, T * sizeof(DevTrack)));
+  MOT_HIP(c, take(c->d_live + (size_t)slot * 2 * T, T * sizeof(int)));
+  MOT_HIP(c, take(c->d_zomb + (size_t)slot * T, T * sizeof(int)));
+  MOT_HIP(c, take(c->d_used + (size_t)slot * usedW, usedW * sizeof(unsigned long long)));
+  MOT_HIP(c, take(c->d_tout + (size_t)slot * T, T * sizeof(mot_track)));
+  MOT_HIP(c, take(c->d_pos + (size_t)slot * E, nt * sizeof(Vec2d)));
+  MOT_HIP(c, take(c->d_slot_of + (size_t)slot * E, nt * sizeof(int)));
+  MOT_HIP(c, take(c->d_tomb + (size_t)slot * E, nt * sizeof(TrackTomb)));
+  MOT_HIP(c, hipStreamSynchronize(c->stream));
+  return MOT_OK;
+}
+
+extern "C" int mot_stream_load(mot_ctx* c, int slot, const void* blob, size_t bytes) {
+  if (!c) return MOT_E_ARG;
+  MOT_GUARD(c);
+  if (slot < 0 || slot >= c->batch || !blob) return fail(c, MOT_E_ARG, "mot_stream_load: slot out of range or null blob");
+  const size_t T = c->max_tracks_total, E = c->max_tracks_ever, usedW = (T + 63) / 64;
+  SnapshotHeader h;
+  if (bytes < sizeof h) return fail(c, MOT_E_ARG, "mot_stream_load: not a snapshot (shorter than its header)");
+  memcpy(&h, blob, sizeof h);
+  // everything is checked before the slot is touched
+  if (h.magic != 0x53544f4du || h.header_bytes != sizeof(SnapshotHeader)) return fail(c, MOT_E_ARG, "mot_stream_load: not a snapshot of this library");
+  if (h.abi != MOT_ABI_VERSION || h.track_bytes != sizeof(DevTrack) || h.record_bytes != sizeof(mot_track))
+    return fail(c, MOT_E_ARG, "mot_stream_load: the snapshot was written by another version of the library");
+  if ((size_t)h.T != T) return fail(c, MOT_E_ARG, "mot_stream_load: the snapshot's track-slot count differs from this context's max_tracks_total");
+  if (h.nt < 0 || h.nlive < 0 || h.nzomb < 0 || (size_t)h.nlive > T || (size_t)h.nzomb > T) return fail(c, MOT_E_ARG, "mot_stream_load: corrupt counters");
+  if ((size_t)h.nt > E) return fail(c, MOT_E_CAPACITY, "mot_stream_load: the stream has created more tracks than this context's max_tracks_ever");
+  const size_t nt = (size_t)h.nt;
+  if (h.total_bytes != snapshot_bytes(T, nt) || bytes < h.total_bytes) return fail(c, MOT_E_ARG, "mot_stream_load: truncated snapshot");
+  const char* in = static_cast<const char*>(blob) + sizeof h;
+  auto give = [&](void* d, size_t n) -> hipError_t {
+    hipError_t rc = n ? hipMemcpyAsync(d, in, n, hipMemcpyHostToDevice, c->stream) : hipSuccess;
+    in += n;
+    return rc;
+  };
+  MOT_HIP(c, give(c->d_tracks + (size_t)slot * T, T * sizeof(DevTrack)));
+  MOT_HIP(c, give(c->d_live + (size_t)slot * 2 * T, T * sizeof(int)));
+  MOT_HIP(c, give(c->d_zomb + (size_t)slot * T, T * sizeof(int)));
+  MOT_HIP(c, give(c->d_used + (size_t)slot * usedW, usedW * sizeof(unsigned long long)));
+  MOT_HIP(c, give(c->d_tout + (size_t)slot * T, T * sizeof(mot_track)));
+  MOT_HIP(c, give(c->d_pos + (size_t)slot * E, nt * sizeof(Vec2d)));
+  MOT_HIP(c, give(c->d_slot_of + (size_t)slot * E, nt * sizeof(int)));
+  MOT_HIP(c, give(c->d_tomb + (size_t)slot * E, nt * sizeof(TrackTomb)));
+  const int meta[4] = {h.nt, h.nlive, h.nzomb, h.flags};
+  MOT_HIP(c, hipMemcpyAsync(c->d_nt + slot, &meta[0], sizeof(int), hipMemcpyHostToDevice, c->stream));
+  MOT_HIP(c, hipMemcpyAsync(c->d_nlive + slot, &meta[1], sizeof(int), hipMemcpyHostToDevice, c->stream));
+  MOT_HIP(c, hipMemcpyAsync(c->d_nzomb + slot, &meta[2], sizeof(int), hipMemcpyHostToDevice, c->stream));
+  MOT_HIP(c, hipMemcpyAsync(c->d_tflags + slot, &meta[3], sizeof(int), hipMemcpyHostToDevice, c->stream));
+  MOT_HIP(c, hipStreamSynchronize(c->stream));   // the caller's blob and `meta` may go away
+  mot_ctx::SlotEgo e;
+  e.init = h.init != 0; e.ego_called = h.ego_called != 0; e.tracks_restart = h.tracks_restart != 0;
+  e.timestamp = h.timestamp; e.egoVelo = h.egoVelo; e.egoYaw = h.egoYaw; e.egoPreYaw = h.egoPreYaw; e.rx = h.rx; e.ry = h.ry; e.ryaw = h.ryaw;
+  for (int k = 0; k < 3; k++) e.egoPoint[k] = h.egoPoint[k];
+  e.nt = h.nt;
+  c->ego[slot] = e;
+  return MOT_OK;
+}
+
 // immUkfJpdaf(), OT/tracking/imm_ukf_jpda.cpp:704
 extern "C" int mot_track_step(mot_ctx* c, int slot, const float* boxes_global, int m, double timestamp, mot_track* tracks,
                               int max_tracks, int* n_tracks) {

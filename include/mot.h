@@ -186,6 +186,20 @@ int mot_reset_slot(mot_ctx* ctx, int slot);
  * every published position jump). The next tracker step of the slot behaves like the reference's first frame (one seeded
  * track, OT/tracking/imm_ukf_jpda.cpp:741-795). */
 int mot_reset_tracks_slot(mot_ctx* ctx, int slot);
+/* Checkpoint / resume of ONE stream's tracker (the reference keeps this state in file-scope globals,
+ * OT/tracking/imm_ukf_jpda.cpp:19-24,56-70, and can neither save nor reset it). mot_stream_save writes everything the next
+ * frame of the stream depends on — the filter state of every track slot, the per-track-ever arrays, the live / just-died lists,
+ * the last step's outputs, the dead-reckoned ego pose and timestamps — into a block of HOST memory that holds no pointers;
+ * mot_stream_load puts it into any slot of any context of the same library version with the same max_tracks_total (another GPU,
+ * another process, after a restart; max_tracks_ever at least the stream's track count), and the stream continues bit for bit:
+ * the next mot_get_tracks returns what it returned before the save, the next step what it would have computed. Both calls
+ * synchronise the context's stream. mot_stream_snapshot_size: the upper bound for this context (a snapshot is shorter when
+ * the stream has created fewer than max_tracks_ever tracks; *written says how long). Errors: MOT_E_CAPACITY (blob too small;
+ * more tracks than the loading context's max_tracks_ever), MOT_E_ARG (not a snapshot, another version, another slot count,
+ * truncated) — a failed load leaves the slot as it was. */
+int mot_stream_snapshot_size(mot_ctx* ctx, size_t* bytes);
+int mot_stream_save(mot_ctx* ctx, int slot, void* blob, size_t capacity, size_t* written);
+int mot_stream_load(mot_ctx* ctx, int slot, const void* blob, size_t bytes);
 /* the parameters the context was created with */
 int mot_get_params(const mot_ctx* ctx, mot_params* out);
 const char* mot_last_error(const mot_ctx* ctx);

@@ -1,0 +1,101 @@
+"""mot_stream_save / mot_stream_load (checkpoint / resume of one stream's tracker): the shared body of the emulator test
+(tests/test_emu_api_v2.py) and the -m gpu test (tests/test_api_v2_gpu.py). A stream saved on one context and loaded into another
+slot of another context must continue bit for bit — outputs and filter states of every frame after the load."""
+import numpy as np
+import pytest
+
+
+def boxes_of(f: int) -> np.ndarray:
+    """a small scene with births and deaths: six objects moving, two of them present only in some frames, one newcomer per few frames"""
+    keep = [k for k in range(8) if not (k == 3 and 5 <= f % 11 <= 8) and not (k == 6 and f % 7 < 3)]
+    if f % 5 == 4:
+        keep.append(8 + f // 5)
+    b = np.zeros((len(keep), 8, 3), np.float32)
+    for i, k in enumerate(keep):
+        b[i, :, :2] = np.array([[0, 0], [2.2, 0], [2.2, 1.1], [0, 1.1]] * 2) + [7.0 * (k % 9) - 28 + 0.35 * f * (1 if k % 2 else -1), 5.0 + 2.5 * (k // 9) + 0.12 * f * (k % 3)]
+        b[i, :4, 2] = -2.0; b[i, 4:, 2] = 0.4
+    return b
+
+
+def _same(a: dict, b: dict):
+    assert a["n"] == b["n"]
+    for k in a:
+        if isinstance(a[k], np.ndarray):
+            assert np.array_equal(a[k].view(np.uint8), b[k].view(np.uint8)), k
+        else:
+            assert a[k] == b[k], k
+
+
+def _meta(blob: bytes):
+    """(header, slot bitmap) of a snapshot — mot_api.hip's SnapshotHeader: five uint32 (magic, abi, header bytes, track bytes, record bytes),
+    then int32 T, nt, nlive, nzomb, flags; the bitmap follows the T track records and the two T-int lists"""
+    u = np.frombuffer(blob[:40], np.uint32)
+    hb, tb, T = int(u[2]), int(u[3]), int(u[5])
+    off = hb + T * tb + 8 * T
+    return blob[:hb], blob[off: off + 8 * ((T + 63) // 64)], dict(nt=int(u[6]), nlive=int(u[7]), nzomb=int(u[8]))
+
+
+def _step(ctx, slot, f):
+    ts = 1.0e9 + f * 1e5
+    ctx.ego_update(ts, 2.0 + 0.05 * f, 0.01 * f, slot)
+    return ctx.track_step(boxes_of(f), ts, slot)
+
+
+def check(mot, lib_path=None):
+    kw = dict(lib_path=lib_path) if lib_path else {}
+    with mot.Context(max_points=1024, max_batch=2, max_tracks_total=64, **kw) as a, \
+         mot.Context(max_points=1024, max_batch=3, max_tracks_total=64, **kw) as b, \
+         mot.Context(max_points=1024, max_batch=1, max_tracks_total=32, **kw) as small:
+        # a stream that has not run yet: an (almost) empty snapshot, and its first frame after the load is the reference's first frame
+        b.stream_load(1, a.stream_save(0))
+        assert b.get_tracks(1)["n"] == 0
+        _same(_step(a, 0, 0), _step(b, 1, 0))
+        a.reset_slot(0); b.reset_slot(1)
+
+        saves = (6, 15, 25)     # steps in which a track has just died: a non-empty just-died list travels
+        died = 0
+        for f in range(40):
+            out_a = _step(a, 1, f)
+            if f > saves[0]:
+                _same(out_a, _step(b, 2, f))
+                # counters, ego state and the slots in use stay equal too (a just-died list that did not travel would leak its slots)
+                ha, ua, ma = _meta(a.stream_save(1)); hb, ub, mb = _meta(b.stream_save(2))
+                assert ha == hb and ua == ub, (f, ma, mb)
+                died += ma["nzomb"]
+                if f % 6 == 0:
+                    for tid in np.nonzero(out_a["track_manage"] > 0)[0][:6]:
+                        sa, sb = a.track_state(int(tid), 1), b.track_state(int(tid), 2)
+                        for k in sa:
+                            assert np.atleast_1d(sa[k]).tobytes() == np.atleast_1d(sb[k]).tobytes(), (f, tid, k)
+            if f in saves:
+                blob = a.stream_save(1)
+                assert _meta(blob)[2]["nzomb"] > 0      # a track died in this very step: its slot is freed by the NEXT step, on either context
+                before = b.get_tracks(2)
+                # what must be refused, and leave the slot as it was
+                for bad, code in ((blob[:-8], mot.MOT_E_ARG), (blob[: 40], mot.MOT_E_ARG), (b"XXXX" + blob[4:], mot.MOT_E_ARG)):
+                    with pytest.raises(mot.MotError) as e:
+                        b.stream_load(2, bad)
+                    assert e.value.code == code
+                with pytest.raises(mot.MotError) as e:
+                    small.stream_load(0, blob)          # another track-slot count
+                assert e.value.code == mot.MOT_E_ARG
+                with pytest.raises(mot.MotError) as e:
+                    b.stream_load(3, blob)              # no such slot
+                assert e.value.code == mot.MOT_E_ARG
+                _same(before, b.get_tracks(2))
+                b.stream_load(2, blob)
+                _same(out_a, b.get_tracks(2))           # the outputs of the step before the save travel too
+                # a snapshot of the restored stream restores as well (a second hop)
+                b.stream_load(0, b.stream_save(2)); _same(out_a, b.get_tracks(0))
+        assert died >= 3 and out_a["n"] > 12 and int((out_a["track_manage"] > 0).sum()) >= 4 and int((out_a["track_manage"] == 0).sum()) >= 3
+
+        # a stream whose tracks were restarted (mot_reset_tracks_slot) keeps that through a snapshot: the next step seeds anew, the ego pose goes on
+        a.reset_tracks_slot(1)
+        b.stream_load(2, a.stream_save(1))
+        oa, ob = _step(a, 1, 40), _step(b, 2, 40)
+        _same(oa, ob)
+        assert oa["n"] == 1 and oa["track_manage"][0] == 1
+        # the C call's capacity check
+        import ctypes as C
+        buf = (C.c_char * 64)(); n = C.c_size_t(0)
+        assert a.lib.mot_stream_save(a._h, 1, buf, C.c_size_t(64), C.byref(n)) == mot.MOT_E_CAPACITY and n.value > 64

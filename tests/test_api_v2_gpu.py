@@ -196,3 +196,10 @@ def test_trace_ranges_on_the_device(mot, hip_lib, synth):
             out.append((c.get_boxes(0)["boxes"], c.get_clusters(0)["grid"]))
             dev.free()
     assert np.array_equal(out[0][0], out[1][0]) and np.array_equal(out[0][1], out[1][1])
+
+
+def test_stream_snapshot_round_trip(mot, hip_lib):
+    """mot_stream_save / mot_stream_load on the MI355X: a stream moved to another slot of another context continues bit for bit
+    (every output and filter state of every later frame; tests/snapshot_case.py)"""
+    import snapshot_case
+    snapshot_case.check(mot)

@@ -252,6 +252,12 @@ def test_reset_tracks_slot_keeps_the_global_frame(mot, emu, oracle):
         assert c.get_tracks(0)["n"] > 1
 
 
+def test_stream_snapshot_round_trip(mot, emu):
+    """mot_stream_save / mot_stream_load: a stream moved to another slot of another context continues bit for bit (tests/snapshot_case.py)"""
+    import snapshot_case
+    snapshot_case.check(mot, emu[0])
+
+
 def test_trace_ranges_are_optional(mot, emu_lib=None):
     """mot_set_trace_ranges: roctx ranges around the stages. The emulator build has no roctx: the call must answer MOT_E_STATE and leave
     everything working (the real library loads libroctx64 lazily; tests/test_api_v2_gpu.py turns the ranges on around a frame)."""
