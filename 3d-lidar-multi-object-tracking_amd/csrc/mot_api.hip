@@ -69,6 +69,7 @@ struct mot_ctx {
   float4* d_side_obs = nullptr;
   int* d_side_cost = nullptr;
   int* d_side_counts = nullptr;
+  int2* d_side_chunks = nullptr;
   float* d_markers = nullptr;          // [kMaxBoxesPerFrame][6], mot_box_markers (allocated at its first call)
   int2* d_wgtab = nullptr;
   int max_wg = 0;
@@ -287,7 +288,7 @@ extern "C" void mot_destroy(mot_ctx* c) {
   for (int i = 0; i < mot_ctx::kArgRing; i++) if (c->arg_ev[i]) (void)hipEventDestroy(c->arg_ev[i]);
   if (c->h_argring) (void)hipHostFree(c->h_argring);
   void* bufs[] = {c->d_in, c->d_argblk, c->d_ecell, c->d_pairs, c->d_pair_count, c->d_hg, c->d_cell, c->d_desc, c->d_ticket, c->d_elev, c->d_ground, c->d_mask, c->d_counts,
-                  c->d_plane_a, c->d_plane_b, c->d_ccl_parent, c->d_occ_list, c->d_occ_count, c->d_grid, c->d_label, c->d_stats, c->d_cand, c->d_boxes, c->d_box_cluster, c->d_rng, c->d_poly, c->d_groups, c->d_cluster_start, c->d_cluster_gstart, c->d_order, c->d_gsorted, c->d_pix, c->d_wgtab, c->d_side_cell, c->d_side_cloud, c->d_side_obs, c->d_side_cost, c->d_side_counts, c->d_markers, c->d_raw,
+                  c->d_plane_a, c->d_plane_b, c->d_ccl_parent, c->d_occ_list, c->d_occ_count, c->d_grid, c->d_label, c->d_stats, c->d_cand, c->d_boxes, c->d_box_cluster, c->d_rng, c->d_poly, c->d_groups, c->d_cluster_start, c->d_cluster_gstart, c->d_order, c->d_gsorted, c->d_pix, c->d_wgtab, c->d_side_cell, c->d_side_cloud, c->d_side_obs, c->d_side_cost, c->d_side_counts, c->d_side_chunks, c->d_markers, c->d_raw,
                   c->d_tracks, c->d_nt, c->d_tboxes, c->d_gate, c->d_prog, c->d_live, c->d_tout, c->d_tflags, c->d_nlive, c->d_pos, c->d_slot_of, c->d_tomb, c->d_used, c->d_zomb, c->d_nzomb, c->d_cp, c->d_items, c->d_nitems};
   for (void* b : bufs) if (b) (void)hipFree(b);
   if (c->h_counts) (void)hipHostFree(c->h_counts);
@@ -1124,13 +1125,13 @@ extern "C" int mot_cluster_products(mot_ctx* c, int slot, const mot_side_params*
   if ((clustered_xyzw && !n_clustered) || (obstacles_xyzc && !n_obstacles)) return fail(c, MOT_E_ARG, "mot_cluster_products: an output list needs its count pointer");
   if (sp->cost_width < 1 || sp->cost_height < 1 || (long)sp->cost_width * sp->cost_height > kMaxCostCells || !(sp->cost_resolution > 0))
     return fail(c, MOT_E_ARG, "cost map must have 1..65536 cells and a positive resolution");
-  if (!c->d_side_cell) {
-    MOT_HIP(c, hipMalloc(&c->d_side_cell, (size_t)MOT_MAX_GRID * MOT_MAX_GRID * sizeof(int)));
-    MOT_HIP(c, hipMalloc(&c->d_side_cloud, (size_t)c->cap * sizeof(float4)));
-    MOT_HIP(c, hipMalloc(&c->d_side_obs, (size_t)MOT_MAX_GRID * MOT_MAX_GRID * sizeof(float4)));
-    MOT_HIP(c, hipMalloc(&c->d_side_cost, (size_t)kMaxCostCells * sizeof(int)));
-    MOT_HIP(c, hipMalloc(&c->d_side_counts, 2 * sizeof(int)));
-  }
+  // (a failure half-way — out of memory is plausible — leaves what exists for mot_destroy; the next call tries again from there)
+  if (!c->d_side_cell) MOT_HIP(c, hipMalloc(&c->d_side_cell, (size_t)MOT_MAX_GRID * MOT_MAX_GRID * sizeof(int)));
+  if (!c->d_side_cloud) MOT_HIP(c, hipMalloc(&c->d_side_cloud, (size_t)c->cap * sizeof(float4)));
+  if (!c->d_side_obs) MOT_HIP(c, hipMalloc(&c->d_side_obs, (size_t)MOT_MAX_GRID * MOT_MAX_GRID * sizeof(float4)));
+  if (!c->d_side_cost) MOT_HIP(c, hipMalloc(&c->d_side_cost, (size_t)kMaxCostCells * sizeof(int)));
+  if (!c->d_side_counts) MOT_HIP(c, hipMalloc(&c->d_side_counts, 2 * sizeof(int)));
+  if (!c->d_side_chunks) MOT_HIP(c, hipMalloc(&c->d_side_chunks, ((size_t)c->cap / 1024 + 1) * sizeof(int2)));
   SideDevParams d;
   d.cell_size = sp->cell_size; d.cost_width = sp->cost_width; d.cost_height = sp->cost_height; d.cost_resolution = sp->cost_resolution;
   d.center_x = (sp->cost_width / 2.0) * sp->cost_resolution - sp->cost_offset_x;    // map_center_x, :428
@@ -1139,9 +1140,9 @@ extern "C" int mot_cluster_products(mot_ctx* c, int slot, const mot_side_params*
   SideBuffers s;
   s.elevated = c->d_elev + (size_t)slot * c->cap; s.grid = c->d_grid + (size_t)slot * MOT_MAX_GRID * MOT_MAX_GRID;
   s.counts = c->d_counts + (size_t)slot * kCountsStride; s.cell_first = c->d_side_cell; s.clustered = c->d_side_cloud;
-  s.obstacles = c->d_side_obs; s.cost = c->d_side_cost; s.out_counts = c->d_side_counts;
+  s.obstacles = c->d_side_obs; s.cost = c->d_side_cost; s.out_counts = c->d_side_counts; s.chunk_counts = c->d_side_chunks;
   s.max_clustered = c->cap; s.max_obstacles = MOT_MAX_GRID * MOT_MAX_GRID;
-  mot_launch_side_products(c->dp, d, s, c->stream);
+  mot_launch_side_products(c->dp, d, s, c->cap, c->stream);
   MOT_HIP(c, hipGetLastError());
   int h[2] = {0, 0};
   MOT_HIP(c, hipMemcpyAsync(h, c->d_side_counts, sizeof h, hipMemcpyDeviceToHost, c->stream));
@@ -1195,7 +1196,7 @@ extern "C" int mot_box_markers(mot_ctx* c, int slot, float* centroid_extent, int
   if (nb > max_boxes) return fail(c, MOT_E_CAPACITY, "more boxes than the caller's buffer holds");
   if (nb == 0 || !centroid_extent) return MOT_OK;
   if (!c->d_markers) MOT_HIP(c, hipMalloc(&c->d_markers, (size_t)kMaxBoxesPerFrame * 6 * sizeof(float)));
-  mot_launch_box_markers(cluster_buffers(c), slot, c->d_markers, c->stream);
+  mot_launch_box_markers(cluster_buffers(c), slot, nb < kMaxBoxesPerFrame ? nb : kMaxBoxesPerFrame, c->d_markers, c->stream);
   MOT_HIP(c, hipGetLastError());
   MOT_HIP(c, hipMemcpyAsync(centroid_extent, c->d_markers, (size_t)nb * 6 * sizeof(float), hipMemcpyDeviceToHost, c->stream));
   MOT_HIP(c, hipStreamSynchronize(c->stream));

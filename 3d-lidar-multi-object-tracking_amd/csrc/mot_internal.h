@@ -215,14 +215,15 @@ struct SideBuffers {
   const GridLabel* grid;    // the slot's label grid, x-major with stride num_grid
   const int* counts;        // the slot's counters (kCntElev)
   int* cell_first;          // [MOT_MAX_GRID^2] scratch: first point of every labelled cell
+  int2* chunk_counts;       // [ceil(cap / 1024)] scratch: clustered points / obstacles of every 1024-point chunk
   float4* clustered;        // [max_clustered]
   float4* obstacles;        // [max_obstacles] (x, y, z, cluster)
   int* cost;                // [cost_width * cost_height]
   int* out_counts;          // [2] clustered points, obstacles
   int max_clustered, max_obstacles;
 };
-void mot_launch_side_products(const MotDevParams& p, const SideDevParams& sp, const SideBuffers& s, hipStream_t stream);
-void mot_launch_box_markers(const ClusterBuffers& c, int slot, float* out /*[kMaxBoxesPerFrame][6]*/, hipStream_t stream);
+void mot_launch_side_products(const MotDevParams& p, const SideDevParams& sp, const SideBuffers& s, int max_points, hipStream_t stream);
+void mot_launch_box_markers(const ClusterBuffers& c, int slot, int n_boxes, float* out /*[n_boxes][6]*/, hipStream_t stream);
 
 // ---- tracker stage ---------------------------------------------------------------------------
 #ifndef MOT_TRACK_BLOCK

@@ -473,7 +473,7 @@ def stage_wise_host_buffers(mot, device, seq_dev, n_seq, stride, ego_v, ego_yaw,
         t_g, t_c, t_t, nb_last, nt_last = [], [], [], 0, 0
         for rep in range(2):   # the first pass warms allocations and code paths; the second is the one reported
             c.reset(); c.synchronize()
-            t_g, t_c, t_t = [], [], []
+            t_g, t_c, t_t, calls = [], [], [], []
             for f in range(F):
                 ts = 1.0e9 + f * 1e5
                 t0 = time.perf_counter()
@@ -482,10 +482,14 @@ def stage_wise_host_buffers(mot, device, seq_dev, n_seq, stride, ego_v, ego_yaw,
                 e = g["elevated"]; n = len(e)
                 nc, ncc, nob, nb, nm = C.c_int(0), C.c_int(0), C.c_int(0), C.c_int(0), C.c_int(0)
                 c._ck(L.mot_cluster(h, vp(e), n, None, C.byref(nc), None))            # `cluster` node: one upload, everything else on the resident copy
+                ta = time.perf_counter()
                 c._ck(L.mot_cluster_products(h, 0, C.byref(sp), vp(cc), stride, C.byref(ncc), vp(ob), G * G, C.byref(nob), vp(cm)))
+                tb = time.perf_counter()
                 c._ck(L.mot_box_fit_resident(h, vp(boxes), 1024, C.byref(nb), None, None))
+                tc = time.perf_counter()
                 c._ck(L.mot_box_markers(h, 0, vp(cubes), 1024, C.byref(nm)))
                 t2 = time.perf_counter()
+                calls.append((ta - t1, tb - ta, tc - tb, t2 - tc))
                 ego = c.ego_update(ts, float(ego_v[f]), float(ego_yaw[f]))            # `tracking` node: getOriginPoints, tf, immUkfJpdaf
                 tr = c.track_step(seqmod.boxes_to_global(boxes[: nb.value], ego), ts)
                 t3 = time.perf_counter()
@@ -494,7 +498,9 @@ def stage_wise_host_buffers(mot, device, seq_dev, n_seq, stride, ego_v, ego_yaw,
     ms = lambda a: {"median": round(float(np.median(a)) * 1e3, 4), "p95": round(_pct(np.array(a) * 1e3, 95), 4)}
     tot = np.array(t_g) + np.array(t_c) + np.array(t_t)
     return {"frames": F, "ms_per_frame": ms(tot), "frames_per_s": round(F / float(tot.sum()), 1),
-            "stage_ms": {"ground": ms(t_g), "cluster_box": ms(t_c), "tracker": ms(t_t)}, "boxes_last_frame": nb_last, "tracks_ever": nt_last,
+            "stage_ms": {"ground": ms(t_g), "cluster_box": ms(t_c), "tracker": ms(t_t)},
+            "cluster_box_calls_ms_median": dict(zip(("mot_cluster", "mot_cluster_products", "mot_box_fit_resident", "mot_box_markers"),
+                                                    [round(float(v) * 1e3, 4) for v in np.median(np.array(calls), axis=0)])), "boxes_last_frame": nb_last, "tracks_ever": nt_last,
             "what": "the reference's function boundary call by call on host buffers (mot_ground_remove; mot_cluster + mot_cluster_products + mot_box_fit_resident + "
                     "mot_box_markers; mot_ego_update + host change of frame + mot_track_step): every stage uploads its input, synchronises and downloads "
                     "its outputs, as the three ROS nodes do per scan; compare cpu_baseline.single.stage_ms (the reference's own sources on one host core)"}

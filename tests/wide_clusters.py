@@ -28,6 +28,11 @@ def check(ctx, oracle, p, cloud):
     a = ctx.cluster(cloud); b = ctx.box_fit(cloud, a["grid"], a["num_cluster"])
     assert a["num_cluster"] == cl["num_cluster"] and np.array_equal(a["grid"], cl["grid"])
     assert np.array_equal(b["boxes"].view(np.uint32), bx["boxes"].view(np.uint32)) and np.array_equal(b["box_cluster"], bx["box_cluster"]) and b["n_undefined"] == bx["n_undefined"]
+    # the rviz cubes of the same boxes (mot_box_markers): clusters of thousands of points fill the kernel's 2048-point LDS window several
+    # times over, in random order they are hundreds of sparse tiles
+    import oracle_lib as O
+    m = ctx.box_markers(0)
+    assert np.array_equal(m.view(np.uint32), O.box_markers_numpy(cloud, cl["point_label"], bx["box_cluster"]).view(np.uint32))
     return bx, b
 
 
