@@ -8,6 +8,7 @@
 #include "mot_debug_api.h"
 
 #include <math.h>
+#include <stddef.h>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
@@ -1637,6 +1638,20 @@ extern "C" int mot_stream_load(mot_ctx* c, int slot, const void* blob, size_t by
   if ((size_t)h.nt > E) return fail(c, MOT_E_CAPACITY, "mot_stream_load: the stream has created more tracks than this context's max_tracks_ever");
   const size_t nt = (size_t)h.nt;
   if (h.total_bytes != snapshot_bytes(T, nt) || bytes < h.total_bytes) return fail(c, MOT_E_ARG, "mot_stream_load: truncated snapshot");
+  {  // the index arrays the kernels follow without looking: a damaged file must not send them out of bounds
+    const char* b0 = static_cast<const char*>(blob) + sizeof h;
+    const char* p_tracks = b0;
+    const int* p_live = reinterpret_cast<const int*>(b0 + T * sizeof(DevTrack));
+    const int* p_zomb = p_live + T;
+    const char* p_after = reinterpret_cast<const char*>(p_zomb + T) + usedW * sizeof(unsigned long long) + T * sizeof(mot_track) + nt * sizeof(Vec2d);
+    const int* p_slot_of = reinterpret_cast<const int*>(p_after);
+    auto ref_of = [&](int sl) { int r; memcpy(&r, p_tracks + (size_t)sl * sizeof(DevTrack) + offsetof(DevTrack, ref_id), sizeof r); return r; };
+    bool ok = true;
+    for (int i = 0; i < h.nlive && ok; i++) { int sl; memcpy(&sl, p_live + i, sizeof sl); ok = sl >= 0 && (size_t)sl < T && ref_of(sl) >= 0 && ref_of(sl) < h.nt; }
+    for (int i = 0; i < h.nzomb && ok; i++) { int sl; memcpy(&sl, p_zomb + i, sizeof sl); ok = sl >= 0 && (size_t)sl < T && ref_of(sl) >= 0 && ref_of(sl) < h.nt; }
+    for (size_t i = 0; i < nt && ok; i++) { int sl; memcpy(&sl, p_slot_of + i, sizeof sl); ok = sl >= -1 && (sl < 0 || (size_t)sl < T); }
+    if (!ok) return fail(c, MOT_E_ARG, "mot_stream_load: corrupt snapshot (a track slot or reference index out of range)");
+  }
   const char* in = static_cast<const char*>(blob) + sizeof h;
   auto give = [&](void* d, size_t n) -> hipError_t {
     hipError_t rc = n ? hipMemcpyAsync(d, in, n, hipMemcpyHostToDevice, c->stream) : hipSuccess;

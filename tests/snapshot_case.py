@@ -76,6 +76,11 @@ def check(mot, lib_path=None):
                     with pytest.raises(mot.MotError) as e:
                         b.stream_load(2, bad)
                     assert e.value.code == code
+                hb, tb, T = (int(v) for v in np.frombuffer(blob[:24], np.uint32)[[2, 3, 5]])
+                bad = bytearray(blob); bad[hb + T * tb: hb + T * tb + 4] = (10 ** 6).to_bytes(4, "little")   # the first live slot: out of range
+                with pytest.raises(mot.MotError) as e:
+                    b.stream_load(2, bytes(bad))
+                assert e.value.code == mot.MOT_E_ARG and "corrupt" in str(e.value)
                 with pytest.raises(mot.MotError) as e:
                     small.stream_load(0, blob)          # another track-slot count
                 assert e.value.code == mot.MOT_E_ARG
