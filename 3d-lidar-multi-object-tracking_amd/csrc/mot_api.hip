@@ -96,7 +96,8 @@ struct mot_ctx {
   int* d_zomb = nullptr;
   int* d_nzomb = nullptr;
   int max_tracks_ever = 0;             // E: capacity of the per-ever-track arrays (positions, slot map, tombstones)
-  std::vector<char> h_trk;             // mot_get_tracks: host scratch for the slot records and the per-ever-track arrays
+  char* h_pin = nullptr;               // page-locked scratch of the getters' small read-backs (mot_get_tracks: counters, slot bitmap, slot records, per-ever-track
+  size_t h_pin_bytes = 0;              // arrays): a copy into pageable memory is staged by the runtime and costs ~10 us apiece whatever its size
   Vec2d* d_cp = nullptr;
   TrackItem* d_items = nullptr;
   int* d_nitems = nullptr;
@@ -293,6 +294,7 @@ extern "C" void mot_destroy(mot_ctx* c) {
                   c->d_tracks, c->d_nt, c->d_tboxes, c->d_gate, c->d_prog, c->d_live, c->d_tout, c->d_tflags, c->d_nlive, c->d_pos, c->d_slot_of, c->d_tomb, c->d_used, c->d_zomb, c->d_nzomb, c->d_cp, c->d_items, c->d_nitems};
   for (void* b : bufs) if (b) (void)hipFree(b);
   if (c->h_counts) (void)hipHostFree(c->h_counts);
+  if (c->h_pin) (void)hipHostFree(c->h_pin);
   if (c->ev0) (void)hipEventDestroy(c->ev0);
   if (c->ev1) (void)hipEventDestroy(c->ev1);
   if (c->stream) (void)hipStreamDestroy(c->stream);
@@ -300,6 +302,7 @@ extern "C" void mot_destroy(mot_ctx* c) {
 }
 
 static TrackBuffers track_buffers(mot_ctx* c, bool fused);
+static int pinned_scratch(mot_ctx* c, size_t bytes, char** out);
 static void prepare_track_args(mot_ctx* c, TrackFrameArgs* targs, int slot, int m, double timestamp, bool run);
 
 // The next staging block of the argument ring. The host waits here only when the copy queued from this block kArgRing launch
@@ -1145,8 +1148,11 @@ extern "C" int mot_cluster_products(mot_ctx* c, int slot, const mot_side_params*
   s.max_clustered = c->cap; s.max_obstacles = MOT_MAX_GRID * MOT_MAX_GRID;
   mot_launch_side_products(c->dp, d, s, c->cap, c->stream);
   MOT_HIP(c, hipGetLastError());
-  int h[2] = {0, 0};
-  MOT_HIP(c, hipMemcpyAsync(h, c->d_side_counts, sizeof h, hipMemcpyDeviceToHost, c->stream));
+  char* pin;
+  int rc = pinned_scratch(c, 64, &pin);
+  if (rc) return rc;
+  int* h = reinterpret_cast<int*>(pin);
+  MOT_HIP(c, hipMemcpyAsync(h, c->d_side_counts, 2 * sizeof(int), hipMemcpyDeviceToHost, c->stream));
   MOT_HIP(c, hipStreamSynchronize(c->stream));
   if (n_clustered) *n_clustered = h[0];
   if (n_obstacles) *n_obstacles = h[1];
@@ -1439,18 +1445,33 @@ static void prepare_track_args(mot_ctx* c, TrackFrameArgs* targs, int slot, int 
   if (run) { e.timestamp = timestamp; e.egoPreYaw = e.egoYaw; e.init = true; }
 }
 
+static int pinned_scratch(mot_ctx* c, size_t bytes, char** out) {
+  if (c->h_pin_bytes < bytes) {
+    if (c->h_pin) { (void)hipHostFree(c->h_pin); c->h_pin = nullptr; c->h_pin_bytes = 0; }
+    const size_t want = (bytes + 65535) & ~(size_t)65535;
+    MOT_HIP(c, hipHostMalloc(&c->h_pin, want, hipHostMallocDefault));
+    c->h_pin_bytes = want;
+  }
+  *out = c->h_pin;
+  return MOT_OK;
+}
+
 extern "C" int mot_get_tracks(mot_ctx* c, int slot, mot_track* tracks, int max_tracks, int* n_tracks) {
   if (!c) return MOT_E_ARG;
   MOT_GUARD(c);
   if (slot < 0 || slot >= c->batch || !n_tracks || max_tracks < 0) return fail(c, MOT_E_ARG, "mot_get_tracks: slot out of range, null n_tracks or negative max_tracks");
-  int meta[2] = {0, 0};
   const size_t T = c->max_tracks_total, E = c->max_tracks_ever, usedW = (T + 63) / 64;
-  std::vector<unsigned long long> used(usedW, 0ull);
+  const size_t o_used = 16, o_rec = (o_used + usedW * sizeof(unsigned long long) + 15) & ~(size_t)15;
+  char* pin;
+  int rc = pinned_scratch(c, o_rec, &pin);
+  if (rc) return rc;
+  int* meta = reinterpret_cast<int*>(pin);
+  const unsigned long long* used = reinterpret_cast<const unsigned long long*>(pin + o_used);
   MOT_HIP(c, hipMemcpyAsync(&meta[0], c->d_nt + slot, sizeof(int), hipMemcpyDeviceToHost, c->stream));
   MOT_HIP(c, hipMemcpyAsync(&meta[1], c->d_tflags + slot, sizeof(int), hipMemcpyDeviceToHost, c->stream));
-  MOT_HIP(c, hipMemcpyAsync(used.data(), c->d_used + (size_t)slot * usedW, usedW * sizeof(unsigned long long), hipMemcpyDeviceToHost, c->stream));
+  MOT_HIP(c, hipMemcpyAsync(pin + o_used, c->d_used + (size_t)slot * usedW, usedW * sizeof(unsigned long long), hipMemcpyDeviceToHost, c->stream));
   MOT_HIP(c, hipStreamSynchronize(c->stream));
-  const int n = meta[0];
+  const int n = meta[0], sticky = meta[1];
   c->ego[slot].nt = n;
   *n_tracks = n;
   if (n > max_tracks) return fail(c, MOT_E_CAPACITY, "more tracks than the caller's buffer holds");
@@ -1464,8 +1485,8 @@ extern "C" int mot_get_tracks(mot_ctx* c, int slot, mot_track* tracks, int max_t
     for (size_t w = 0; w < usedW; w++) if (used[w]) hi = w * 64 + (63 - (size_t)__builtin_clzll(used[w])) + 1;
     if (hi > T) hi = T;
     const size_t o_out = 0, o_slot = o_out + hi * sizeof(mot_track), o_tomb = o_slot + (size_t)n * sizeof(int), o_pos = (o_tomb + (size_t)n * sizeof(TrackTomb) + 15) & ~(size_t)15;
-    c->h_trk.resize(o_pos + (size_t)n * sizeof(Vec2d));
-    char* h = c->h_trk.data();
+    if ((rc = pinned_scratch(c, o_rec + o_pos + (size_t)n * sizeof(Vec2d), &pin))) return rc;   // (may move the scratch: `used` and `meta` are not read again)
+    char* h = pin + o_rec;
     if (hi) MOT_HIP(c, hipMemcpyAsync(h + o_out, c->d_tout + (size_t)slot * T, hi * sizeof(mot_track), hipMemcpyDeviceToHost, c->stream));
     MOT_HIP(c, hipMemcpyAsync(h + o_slot, c->d_slot_of + (size_t)slot * E, (size_t)n * sizeof(int), hipMemcpyDeviceToHost, c->stream));
     MOT_HIP(c, hipMemcpyAsync(h + o_tomb, c->d_tomb + (size_t)slot * E, (size_t)n * sizeof(TrackTomb), hipMemcpyDeviceToHost, c->stream));
@@ -1489,7 +1510,7 @@ extern "C" int mot_get_tracks(mot_ctx* c, int slot, mot_track* tracks, int max_t
   // The capacity flag is STICKY: once a birth has been dropped the stream keeps answering MOT_E_CAPACITY (the records above
   // are still delivered) until the caller starts it over with mot_reset / mot_reset_slot / mot_reset_tracks_slot — a caller that
   // ignores one error is told again on every call, not only at the next dropped birth.
-  if (meta[1])
+  if (sticky)
     return fail(c, MOT_E_CAPACITY, "a stream ran out of track slots (more than max_tracks_total tracks alive or just dead) or of its lifetime track budget "
                                    "(mot_params.max_tracks_ever): births are being dropped; mot_reset_tracks_slot() starts its tracks over");
   return MOT_OK;
