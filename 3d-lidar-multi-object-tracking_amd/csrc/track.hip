@@ -489,8 +489,16 @@ track_prep_kernel(TrackBuffers tb) {
   track_prep_body(tb, (int)blockIdx.x);
 }
 
+// One-launch step only (track_step_stream_kernel): what every live track of the stream CLAIMS of the frame's boxes — its gate mask, or its
+// progressive minima in second initialisation, nothing if a guard killed it — kept in LDS by live index while the frame has at most 64
+// boxes (one mask word) and the stream at most kStreamClaimCap live tracks. The update phase's "claimed by earlier tracks" and the finish
+// phase's "claimed by anybody" then cost an LDS read instead of two dependent round trips to the masks in global memory each
+// (1.8 + ~2 us of the step's 49, profiles/r04_stream_kernel_phases.txt). The four-launch form passes nullptr and reads the masks.
+constexpr int kStreamClaimCap = 256;
+struct StreamClaims { unsigned long long claim[kStreamClaimCap]; unsigned long long matched; int usable, pad; };
+
 // ---- T1: PA — prediction + gating; the wave's four groups each take one (stream, live track) item
-__device__ void predict_group(const TrackBuffers& tb, PredictScratch* G, int b, int li, bool act) {
+__device__ void predict_group(const TrackBuffers& tb, PredictScratch* G, int b, int li, bool act, StreamClaims* sc = nullptr) {
   const int s = glane(), grp = ggroup();
   const MotTrackParams& tp = tb.tp;
   TrackFrameArgs args; args.dt = 0; args.m = 0;
@@ -534,7 +542,7 @@ __device__ void predict_group(const TrackBuffers& tb, PredictScratch* G, int b, 
   const int Mg = ok ? M : 0;
   const int Mmax = wave_reduce_i32(Mg, OpMaxI());
   double run_min = 999;  // smallestNIS
-  unsigned long long acc_g = 0ull, acc_p = 0ull;
+  unsigned long long acc_g = 0ull, acc_p = 0ull, w0_g = 0ull, w0_p = 0ull;
   for (int k0 = 0; k0 < Mmax; k0 += kGroupLanes) {
     const int k = k0 + s;
     bool g = false; double nis = 1e300;
@@ -566,6 +574,7 @@ __device__ void predict_group(const TrackBuffers& tb, PredictScratch* G, int b, 
       acc_p |= (unsigned long long)pbits << (k0 & 63);
       if ((k0 & 63) == 48 || k0 + kGroupLanes >= Mg) {
         if (s == 0) { gate[k0 >> 6] = acc_g; prog[k0 >> 6] = acc_p; }
+        if ((k0 >> 6) == 0) { w0_g = acc_g; w0_p = acc_p; }
         acc_g = 0ull; acc_p = 0ull;
       }
     }
@@ -574,6 +583,11 @@ __device__ void predict_group(const TrackBuffers& tb, PredictScratch* G, int b, 
   if (act && s == 0) {
     liveok[li] = ok ? (secondInit ? 2 : 1) : 0;   // 2: the track is in its second initialisation (trackNum 1 at the start of the step)
     if (!ok) u->track_num = 0;
+    if (sc && sc->usable) {
+      const unsigned long long mine = ok ? (secondInit ? w0_p : w0_g) : 0ull;
+      sc->claim[li] = mine;
+      if (mine) atomicOr(&sc->matched, mine);
+    }
   }
   MOT_WAVE_SYNC();
 }
@@ -596,7 +610,7 @@ track_predict_kernel(TrackBuffers tb) {
 }
 
 // ---- T2: PB (this track's share) + PC — association, state machine, PDA update; four tracks per wave
-__device__ void update_group(const TrackBuffers& tb, UpdateScratch* G, int b, int li, bool act_in) {
+__device__ void update_group(const TrackBuffers& tb, UpdateScratch* G, int b, int li, bool act_in, const StreamClaims* sc = nullptr) {
   const int s = glane();
   const MotTrackParams& tp = tb.tp;
   const int* __restrict__ live = tb.live + (long)b * 2 * tb.T;
@@ -626,6 +640,7 @@ __device__ void update_group(const TrackBuffers& tb, UpdateScratch* G, int b, in
   int life = act ? u->lifetime : 0;
   {
     const int nWmax = wave_reduce_i32(nW, OpMaxI()), limax = wave_reduce_i32(act ? li : 0, OpMaxI());
+    const bool cached = sc && sc->usable;   // (uniform over the workgroup; then nW <= 1)
     int fresh = 0;
     for (int w = 0; w < nWmax; w++) {
       unsigned long long before = 0ull;
@@ -633,8 +648,11 @@ __device__ void update_group(const TrackBuffers& tb, UpdateScratch* G, int b, in
         const int lj = j0 + s;
         unsigned long long m = 0ull;
         if (w < nW && lj < li) {
-          const int f = liveok[lj], tj = live[lj];   // (independent: one round trip for both, then the mask)
-          if (f) m = f == 2 ? prog_b[(long)tj * kGateWords + w] : gate_b[(long)tj * kGateWords + w];
+          if (cached) m = sc->claim[lj];
+          else {
+            const int f = liveok[lj], tj = live[lj];   // (independent: one round trip for both, then the mask)
+            if (f) m = f == 2 ? prog_b[(long)tj * kGateWords + w] : gate_b[(long)tj * kGateWords + w];
+          }
         }
         before |= row_or_u64(m);
       }
@@ -879,7 +897,7 @@ constexpr int kMaxBornLds = kMaxBoxesPerFrame;   // a frame gives birth to at mo
 #else
 #define FIN_T(slot)
 #endif
-static __device__ void track_finish_body(const TrackBuffers& tb, const int b) {
+static __device__ void track_finish_body(const TrackBuffers& tb, const int b, const StreamClaims* sc = nullptr) {
 #ifdef MOT_DBG_STREAM_TIMING
   const long long fin_t0 = wall_clock64();
 #endif
@@ -928,7 +946,9 @@ static __device__ void track_finish_body(const TrackBuffers& tb, const int b) {
   }
   // matchingVec after the whole track loop: everything a live track claimed (see update_group). (The LAST wave: the eviction above keeps
   // the first lanes of wave 0 busy with a chain of dependent loads of its own — the two run side by side.)
-  if (wave == kTrackWaves - 1) {
+  if (sc && sc->usable) {   // the one-launch step collected the claims in LDS while it predicted (a frame of at most 64 boxes: one word)
+    if (tid < kGateWords) s_matched[tid] = tid == 0 ? sc->matched : 0ull;
+  } else if (wave == kTrackWaves - 1) {
     for (int w = 0; w < kGateWords; w++) {
       unsigned long long m = 0ull;
       if (w < nW)
@@ -1148,6 +1168,7 @@ constexpr int kStreamGroups = (kTrackBlock / 64) * kGroupsPerWave;
 __global__ void MOT_LAUNCH_BOUNDS(kTrackBlock)
 track_step_stream_kernel(TrackBuffers tb, int do_prep) {
   __shared__ union StreamScratch { PredictScratch p[kStreamGroups]; UpdateScratch u[kStreamGroups]; } s_g;
+  __shared__ StreamClaims s_claims;
   const int b = blockIdx.x;
 #ifdef MOT_DBG_STREAM_TIMING   // phase clocks (100 MHz wall clock) of stream b into the work list's storage, which this kernel does not use: tools/time_stream_kernel.py
   long long* dbg = reinterpret_cast<long long*>(tb.items) + (long)b * 32;
@@ -1162,23 +1183,28 @@ track_step_stream_kernel(TrackBuffers tb, int do_prep) {
   const TrackFrameArgs args = tb.args[b];
   if (args.run && !args.first_frame) {
     const int nlive = tb.nlive[b];
+    {
+      const int M = tb.m_dev ? min(tb.m_dev[b * kCountsStride + kCntBoxes], kMaxBoxesPerFrame) : args.m;
+      if (threadIdx.x == 0) { s_claims.usable = (M <= 64 && nlive <= kStreamClaimCap) ? 1 : 0; s_claims.matched = 0ull; s_claims.pad = 0; }
+      __syncthreads();
+    }
     const int g = (int)(threadIdx.x >> 6) * kGroupsPerWave + ggroup();
     for (int i0 = 0; i0 < nlive; i0 += kStreamGroups) {
-      if (i0 + (int)(threadIdx.x >> 6) * kGroupsPerWave < nlive) predict_group(tb, &s_g.p[g], b, i0 + g, i0 + g < nlive);   // (wave-uniform: a wave with no track sits the round out)
+      if (i0 + (int)(threadIdx.x >> 6) * kGroupsPerWave < nlive) predict_group(tb, &s_g.p[g], b, i0 + g, i0 + g < nlive, &s_claims);   // (wave-uniform: a wave with no track sits the round out)
     }
     STREAM_T(1);
     __syncthreads();
     STREAM_T(2);
     GRP_T(24);
     for (int i0 = 0; i0 < nlive; i0 += kStreamGroups) {
-      if (i0 + (int)(threadIdx.x >> 6) * kGroupsPerWave < nlive) update_group(tb, &s_g.u[g], b, i0 + g, i0 + g < nlive);
+      if (i0 + (int)(threadIdx.x >> 6) * kGroupsPerWave < nlive) update_group(tb, &s_g.u[g], b, i0 + g, i0 + g < nlive, &s_claims);
     }
     GRP_T(28);
     STREAM_T(3);
     __syncthreads();
     STREAM_T(4);
   }
-  track_finish_body(tb, b);
+  track_finish_body(tb, b, (args.run && !args.first_frame) ? &s_claims : nullptr);
   STREAM_T(5);
 #ifdef MOT_DBG_STREAM_TIMING
   if (threadIdx.x == 0) dbg[6] = tb.nlive[b];
