@@ -77,3 +77,28 @@ def test_bench_parity_check_logic_on_the_emulator():
     res[3]["boxes"] = res[3]["boxes"] + np.float32(1e-3)   # a corrupted GPU result must show up, with its frame
     _, par2 = bench.cpu_baseline(host[:, 0, :N], ego_v, ego_yaw, N, budget_s=2.0, gpu_results=res, n_per_frame=n_seq[:, 0], lib=mot.load_library(lib), quick=True)
     assert not par2["boxes_bit_exact"] and not par2["masks_boxes_bit_exact"] and par2["first_mismatch_frame"]["boxes_bit_exact"] == 3
+
+
+def test_stage_wise_leg_on_the_emulator(mot, synth):
+    """bench.py's single_stream.stage_wise_host_buffers — the three nodes' call sequence on host buffers — run on the emulator build with a
+    few small frames: the leg's code (C calls with NULL outputs, the change of frame, the per-call clocks) must work before a GPU sees it"""
+    import functools
+    import types
+    torch = pytest.importorskip("torch")
+    import numpy as np
+    sys.path.insert(0, os.path.join(ROOT, "tests", "emu"))
+    sys.path.insert(0, ROOT)
+    import build_emu
+    import bench
+    lib = build_emu.build()
+    seqmod = bench._load("mot_amd.sequence", os.path.join(bench.PKG_DIR, "sequence.py"))
+    F, N, stride = 4, 12000, 12288
+    seq = np.zeros((F, 1, stride, 4), np.float32)
+    for f in range(F):
+        seq[f, 0, :N] = synth.make_cloud(N, 3, f)
+    m = types.SimpleNamespace(**{k: getattr(mot, k) for k in dir(mot) if not k.startswith("__")})
+    m.Context = functools.partial(mot.Context, lib_path=lib)
+    r = bench.stage_wise_host_buffers(m, 0, torch.from_numpy(seq), np.full((F, 1), N, np.int32), stride, np.linspace(2, 3, F), np.linspace(0, 0.05, F), seqmod)
+    assert r["frames"] == F and r["ms_per_frame"]["median"] > 0 and set(r["stage_ms"]) == {"ground", "cluster_box", "tracker"}
+    assert set(r["cluster_box_calls_ms_median"]) == {"mot_cluster", "mot_cluster_products", "mot_box_fit_resident", "mot_box_markers"}
+    assert r["tracks_ever"] >= 1
