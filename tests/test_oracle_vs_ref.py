@@ -81,6 +81,20 @@ def test_side_products_vs_ref(oracle, synth, stream, frame, n):
         assert r[k].shape == o[k].shape and np.array_equal(r[k], o[k]), k
 
 
+@pytest.mark.parametrize("stream,frame,n", [(0, 0, 120000), (3, 1, 36000), (4, 1, 200000)])
+def test_box_markers_restatement_vs_ref(oracle, synth, stream, frame, n):
+    """the rviz cubes (mark_cluster, box_fitting.cpp:161-209): the float32 restatement the device is held against (sequential sums in
+    input order, max - min) equals the MarkerArray the reference's own boxFitting fills, after the 0 -> 0.1 substitution of :192-199"""
+    _need_ref(oracle)
+    p = oracle.params(0)
+    elev = oracle.ref_ground_remove(synth.make_cloud(n, stream, frame))["elevated"]
+    cl = oracle.cluster(p, elev); bx = oracle.box_fit(p, elev, cl["grid"], cl["num_cluster"])
+    rm = oracle.ref_box_markers(elev, cl["grid"], cl["num_cluster"])
+    mine = oracle.box_markers_numpy(elev, cl["point_label"], bx["box_cluster"]).astype(np.float64)
+    mine[:, 3:][mine[:, 3:] == 0] = 0.1
+    assert len(rm) == len(bx["boxes"]) > 3 and np.array_equal(mine, rm)
+
+
 @pytest.mark.parametrize("stream,frame,n", [(0, 0, 120000), (1, 3, 60000), (5, 2, 24000), (4, 0, 200000)])
 def test_preset_ot0_vs_ref0(oracle, synth, stream, frame, n):
     """preset 1 (the KITTI-tuned constants and rules of object_tracking0) against that package's own sources"""
