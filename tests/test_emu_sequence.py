@@ -87,6 +87,14 @@ def test_sequence_mode_equals_frame_by_frame(mot, synth):
             for k in SP.STATE_KEYS:
                 assert np.array_equal(np.asarray(sd[k]), np.asarray(so[k])), (i, k)
         assert tr["n"] > 3 and len(last["states"]) > 1
+        # the by-products of frame k, on demand (mot_get_ground re-runs the compaction of the batch = the sequence; labels from cells and grid):
+        # what the stage-wise calls return for the same frame
+        for f in (0, K // 2, K - 1):
+            with mot.Context(lib_path=lib, max_points=stride) as st:
+                g = st.ground_remove(clouds[f, : n[f]]); cl = st.cluster(g["elevated"])
+            got = c.get_ground(f, n_hint=int(n[f]))
+            assert np.array_equal(got["elevated"], g["elevated"]) and np.array_equal(got["ground"], g["ground"]) and np.array_equal(got["mask"][: n[f]], g["mask"]), f
+            assert np.array_equal(c.get_clusters(f, len(g["elevated"]))["point_label"], cl["point_label"]), f
         # a second sequence continues the first (the stream's state carries over): frames K.. of the same drive
         with pytest.raises(mot.MotError):
             c.sequence_dev(clouds.ctypes.data, stride * 4, np.r_[n, n[:1]], np.r_[ts, ts[:1]], np.r_[ev, ev[:1]], np.r_[ey, ey[:1]])   # more frames than slots
