@@ -17,6 +17,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libmot_hip.so")
 
 MOT_OK, MOT_E_ARG, MOT_E_CAPACITY, MOT_E_HIP, MOT_E_STATE = 0, 1, 2, 3, 4
+MOT_TRACKER_AUTO, MOT_TRACKER_SPLIT, MOT_TRACKER_STREAM = 0, 1, 2   # mot_set_tracker_mode (include/mot.h)
 PRESET_OBJECT_TRACKING, PRESET_OBJECT_TRACKING0 = 0, 1
 MASK_DROPPED, MASK_GROUND, MASK_ELEVATED = 0, 1, 2
 NUM_CHANNEL, NUM_BIN = 80, 120

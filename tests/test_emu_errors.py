@@ -94,3 +94,40 @@ def test_track_records_never_outgrow_a_buffer_of_max_tracks_ever(mot, emu):
                 assert L.mot_reset_tracks_slot(c._h, 0) == mot.MOT_OK
                 restarted += 1
         assert restarted >= 2 and rcs[0] == mot.MOT_OK
+
+
+def test_round_4_entry_points_check_their_arguments(mot, emu, synth):
+    """mot_box_markers, mot_stream_*, mot_sequence_dev, mot_set_tracker_mode: null pointers, slots out of range, undersized buffers — a status
+    and a message, the context stays usable"""
+    lib, L = emu
+    with mot.Context(lib_path=lib, max_points=8192, max_batch=2, max_tracks_total=32) as c:
+        h = c._h
+        n = C.c_int(0); six = (C.c_float * 60)()
+        assert L.mot_box_markers(h, 0, six, 10, None) == mot.MOT_E_ARG          # null n_boxes
+        assert L.mot_box_markers(h, 2, six, 10, C.byref(n)) == mot.MOT_E_ARG     # no such slot
+        assert L.mot_box_markers(h, 0, six, -1, C.byref(n)) == mot.MOT_E_ARG
+        assert L.mot_box_markers(h, 0, None, 0, C.byref(n)) == mot.MOT_OK and n.value == 0   # nothing fitted yet: no boxes
+        cloud = synth.make_cloud(8000, 2, 0)
+        g = c.ground_remove(cloud); c.cluster(g["elevated"]); b = c.box_fit_resident()
+        if len(b["boxes"]) > 1:
+            assert L.mot_box_markers(h, 0, six, 1, C.byref(n)) == mot.MOT_E_CAPACITY and n.value == len(b["boxes"])
+        assert L.mot_box_markers(h, 0, None, 1024, C.byref(n)) == mot.MOT_OK and n.value == len(b["boxes"])   # count only
+        sz = C.c_size_t(0); w = C.c_size_t(0); buf = (C.c_char * 16)()
+        assert L.mot_stream_snapshot_size(h, None) == mot.MOT_E_ARG
+        assert L.mot_stream_snapshot_size(h, C.byref(sz)) == mot.MOT_OK and sz.value > 32 * 1600
+        assert L.mot_stream_save(h, 0, None, C.c_size_t(0), C.byref(w)) == mot.MOT_E_ARG
+        assert L.mot_stream_save(h, 5, buf, C.c_size_t(16), C.byref(w)) == mot.MOT_E_ARG
+        assert L.mot_stream_save(h, 0, buf, C.c_size_t(16), C.byref(w)) == mot.MOT_E_CAPACITY and w.value > 16
+        assert L.mot_stream_load(h, 0, None, C.c_size_t(0)) == mot.MOT_E_ARG
+        assert L.mot_stream_load(h, 0, buf, C.c_size_t(16)) == mot.MOT_E_ARG          # shorter than a header
+        assert L.mot_set_tracker_mode(h, 7) == mot.MOT_E_ARG and b"mode" in L.mot_last_error(h)
+        assert L.mot_set_tracker_mode(h, mot.MOT_TRACKER_SPLIT) == mot.MOT_OK and L.mot_set_tracker_mode(h, mot.MOT_TRACKER_AUTO) == mot.MOT_OK
+        one = np.array([100], np.int32); ts = np.array([1.0e9]); z = np.zeros(1)
+        pts = np.zeros((8192, 4), np.float32)
+        seq = L.mot_sequence_dev
+        assert seq(h, None, 8192 * 4, one.ctypes.data_as(C.c_void_p), 1, ts.ctypes.data_as(C.c_void_p), z.ctypes.data_as(C.c_void_p), z.ctypes.data_as(C.c_void_p), None, 0, None) == mot.MOT_E_ARG
+        assert seq(h, pts.ctypes.data_as(C.c_void_p), 8192 * 4, one.ctypes.data_as(C.c_void_p), 1, None, z.ctypes.data_as(C.c_void_p), z.ctypes.data_as(C.c_void_p), None, 0, None) == mot.MOT_E_ARG
+        cnt = (C.c_int * 1)()
+        assert seq(h, pts.ctypes.data_as(C.c_void_p), 8192 * 4, one.ctypes.data_as(C.c_void_p), 1, ts.ctypes.data_as(C.c_void_p), z.ctypes.data_as(C.c_void_p), z.ctypes.data_as(C.c_void_p), None, 4, cnt) == mot.MOT_E_ARG   # counts without records
+        # ... and the context still works
+        assert len(c.ground_remove(cloud)["elevated"]) == len(g["elevated"])
