@@ -53,9 +53,14 @@ __device__ __forceinline__ int tlane() { return (int)(threadIdx.x & 63); }
 // MI355X (profiles/r02_kernel_trace_B512_4ctx_before_tracker_fix.txt). Up to 32 turns the loop runs as written (bit-identical to the reference);
 // beyond that the whole turns come off in one step first — the result differs from the loop's by the roundings the loop
 // would have accumulated (< 1e-9 for |a| < 1e4), on tracks whose state is garbage already and which the reference's own
-// guards (:828-851) are about to kill. Inf, which hangs the reference, becomes NaN here.
+// guards (:828-851) are about to kill. Inf, which hangs the reference, becomes NaN here; and an angle so large that the one-step
+// reduction cannot resolve it any more (|a| beyond ~1e17: a garbage timestamp makes dt astronomical) takes the exact remainder instead
+// of leaving the loops below an operand they cannot move — the reference spins for ever there, a GPU must not.
 __device__ __forceinline__ double wrap_pi(double a) {
-  if (fabs(a) > 64. * PI_D) a = a - trunc(a / (2. * PI_D)) * (2. * PI_D);
+  if (fabs(a) > 64. * PI_D) {
+    const double r = a - trunc(a / (2. * PI_D)) * (2. * PI_D);
+    a = fabs(r) <= 64. * PI_D ? r : fmod(a, 2. * PI_D);
+  }
   while (a > PI_D) a -= 2. * PI_D;
   while (a < -PI_D) a += 2. * PI_D;
   return a;

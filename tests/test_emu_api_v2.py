@@ -258,6 +258,43 @@ def test_stream_snapshot_round_trip(mot, emu):
     snapshot_case.check(mot, emu[0])
 
 
+def test_stream_load_survives_damaged_snapshots(mot, emu):
+    """a snapshot with random bytes flipped — in its header, its index arrays, its filter states — is either refused or loaded; in both cases the
+    context keeps stepping (whatever garbage the tracker then computes stays inside its buffers: run under MOT_EMU_SANITIZE=address this is a
+    memory-safety check of mot_stream_load's validation and of the kernels on corrupt state)"""
+    import snapshot_case as S
+    lib = emu[0]
+    rng = np.random.default_rng(2024)
+    with mot.Context(lib_path=lib, max_points=1024, max_batch=2, max_tracks_total=64) as a, mot.Context(lib_path=lib, max_points=1024, max_batch=2, max_tracks_total=64) as b:
+        for f in range(18):
+            S._step(a, 0, f)
+        blob = a.stream_save(0)
+        hb, tb, T = (int(v) for v in np.frombuffer(blob[:24], np.uint32)[[2, 3, 5]])
+        regions = [(0, hb), (hb, hb + 64 * 8), (hb + T * tb, hb + T * tb + 8 * T + 8), (len(blob) - 400, len(blob)), (0, len(blob))]
+        refused = loaded = 0
+        for k in range(120):
+            lo, hi = regions[k % len(regions)]
+            bad = bytearray(blob)
+            for _ in range(1 + k % 4):
+                i = int(rng.integers(lo, hi)); bad[i] = int(rng.integers(0, 256))
+            try:
+                b.stream_load(1, bytes(bad)); loaded += 1
+            except mot.MotError as e:
+                assert e.code in (mot.MOT_E_ARG, mot.MOT_E_CAPACITY); refused += 1
+            for f in (18, 19):
+                ts = 1.0e9 + f * 1e5
+                b.ego_update(ts, 2.0, 0.01 * f, 1)
+                try:
+                    b.track_step(S.boxes_of(f), ts, 1)
+                except mot.MotError:
+                    pass
+            b.reset_slot(1)
+        assert refused >= 10 and loaded >= 10, (refused, loaded)
+        # and an undamaged one still loads and continues like the original
+        b.stream_load(1, blob)
+        S._same(S._step(a, 0, 18), S._step(b, 1, 18))
+
+
 def test_trace_ranges_are_optional(mot, emu_lib=None):
     """mot_set_trace_ranges: roctx ranges around the stages. The emulator build has no roctx: the call must answer MOT_E_STATE and leave
     everything working (the real library loads libroctx64 lazily; tests/test_api_v2_gpu.py turns the ranges on around a frame)."""

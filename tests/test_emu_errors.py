@@ -131,3 +131,23 @@ def test_round_4_entry_points_check_their_arguments(mot, emu, synth):
         assert seq(h, pts.ctypes.data_as(C.c_void_p), 8192 * 4, one.ctypes.data_as(C.c_void_p), 1, ts.ctypes.data_as(C.c_void_p), z.ctypes.data_as(C.c_void_p), z.ctypes.data_as(C.c_void_p), None, 4, cnt) == mot.MOT_E_ARG   # counts without records
         # ... and the context still works
         assert len(c.ground_remove(cloud)["elevated"]) == len(g["elevated"])
+
+
+@pytest.mark.timeout(120)
+def test_an_astronomical_timestamp_jump_does_not_hang_the_tracker(mot, emu):
+    """dt = 1e34 s (a garbage timestamp) makes yaw + yaw_rate * dt an angle no subtraction of 2 pi can move: the reference's
+    `while (a > M_PI) a -= 2. * M_PI` spins for ever there. The device takes the exact remainder instead (track.hip: wrap_pi) and the step
+    returns — with tracks killed by the divergence guards or carrying NaN, but it returns, on the emulator as on a GPU that must never hang"""
+    import snapshot_case as S
+    lib, L = emu
+    with mot.Context(lib_path=lib, max_points=1024, max_batch=1, max_tracks_total=64) as c:
+        for f in range(12):
+            S._step(c, 0, f)
+        assert int((c.get_tracks(0)["track_manage"] > 0).sum()) >= 4
+        for jump in (1.0e40, 1.0e300, float("inf")):
+            ts = 1.0e9 + 12 * 1e5 + jump
+            c.ego_update(ts, 2.0, 0.1, 0)
+            out = c.track_step(S.boxes_of(12), ts, 0)
+            assert out["n"] >= 1
+        c.reset_slot(0)
+        assert S._step(c, 0, 0)["n"] == 1      # and the stream starts over cleanly
