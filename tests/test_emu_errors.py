@@ -151,3 +151,43 @@ def test_an_astronomical_timestamp_jump_does_not_hang_the_tracker(mot, emu):
             assert out["n"] >= 1
         c.reset_slot(0)
         assert S._step(c, 0, 0)["n"] == 1      # and the stream starts over cleanly
+
+
+@pytest.mark.timeout(300)
+def test_hostile_tracker_inputs_never_hang_or_crash(mot, emu):
+    """boxes with NaN / Inf / 1e30 corners, zero-size and repeated boxes, timestamps that stand still, run backwards, jump or are NaN, ego values
+    that are NaN or huge: the step must come back every time (no assertion on the numbers — the reference asserts or spins on most of these),
+    the track count stays inside the context's limits and a reset gives a clean stream again"""
+    import snapshot_case as S
+    lib, L = emu
+    rng = np.random.default_rng(77)
+    specials = np.array([np.nan, np.inf, -np.inf, 1e30, -1e30, 1e-30, 0.0, -0.0, 3.0e4, -3.0e4], np.float32)
+    with mot.Context(lib_path=lib, max_points=1024, max_batch=1, max_tracks_total=32) as c:
+        for trial in range(40):
+            c.reset_slot(0)
+            ts = 1.0e9
+            for f in range(10):
+                b = S.boxes_of(f + trial)
+                kind = int(rng.integers(0, 6))
+                if kind == 0:      # a few corners replaced by special values
+                    idx = rng.integers(0, b.size, size=int(rng.integers(1, 12)))
+                    b.reshape(-1)[idx] = rng.choice(specials, size=len(idx))
+                elif kind == 1:    # every box collapsed to a point / all boxes identical
+                    b[:] = b[:, :1, :] if rng.random() < 0.5 else b[:1]
+                elif kind == 2:    # far away and huge
+                    b *= np.float32(10.0 ** float(rng.integers(3, 30)))
+                elif kind == 3:    # no boxes at all
+                    b = b[:0]
+                step = [1e5, 0.0, -1e5, 1e12, np.nan, 1e5][int(rng.integers(0, 6))]
+                ts = ts + step if np.isfinite(step) else float("nan")
+                v = float(rng.choice([2.0, 0.0, np.nan, 1e20, -5.0])); yaw = float(rng.choice([0.01 * f, np.nan, 1e10, -400.0]))
+                c.ego_update(ts, v, yaw, 0)
+                try:
+                    out = c.track_step(b, ts, 0)
+                    assert 0 <= out["n"] <= 32 * 64
+                except mot.MotError as e:
+                    assert e.code in (mot.MOT_E_CAPACITY, mot.MOT_E_ARG, mot.MOT_E_STATE)
+                if not np.isfinite(ts):
+                    ts = 1.0e9 + 1e6 * (trial + 1)
+        c.reset_slot(0)
+        assert S._step(c, 0, 0)["n"] == 1
