@@ -191,3 +191,38 @@ def test_hostile_tracker_inputs_never_hang_or_crash(mot, emu):
                     ts = 1.0e9 + 1e6 * (trial + 1)
         c.reset_slot(0)
         assert S._step(c, 0, 0)["n"] == 1
+
+
+@pytest.mark.timeout(600)
+def test_hostile_clouds_never_hang_or_crash_the_stateless_stages(mot, emu, synth):
+    """clouds salted with NaN / Inf / 1e30 / FLT_MAX coordinates, collapsed onto one point, stretched by 1e19, with special heights only — through the
+    stage-wise calls (ground, cluster, box fit, cube markers, side products) and through a fused batch with the tracker: every call comes back
+    with a status (run under MOT_EMU_SANITIZE=address this is the memory-safety check of every float -> cell / pixel conversion)"""
+    lib, L = emu
+    rng = np.random.default_rng(5)
+    specials = np.array([np.nan, np.inf, -np.inf, 1e30, -1e30, 1e-38, 0.0, -0.0, 3.4e38, -3.4e38, 59.99, 60.0, -60.0, 1e9], np.float32)
+    with mot.Context(lib_path=lib, max_points=8192, max_batch=2, max_tracks_total=32) as c:
+        for trial in range(36):
+            n = int(rng.integers(0, 8000))
+            base = synth.make_cloud(8000, int(rng.integers(0, 9)), trial)[:n].copy()
+            kind = trial % 6
+            if n and kind == 0:
+                idx = rng.integers(0, base.size, size=int(rng.integers(1, 200))); base.reshape(-1)[idx] = rng.choice(specials, size=len(idx))
+            elif n and kind == 1:
+                base[:, :3] = base[0, :3]
+            elif n and kind == 2:
+                base[:, :2] *= np.float32(10.0 ** float(rng.integers(1, 20)))
+            elif n and kind == 3:
+                base[:, 2] = rng.choice(specials, size=n)
+            elif n and kind == 4:
+                base[:, :3] = rng.choice(specials, size=(n, 3))
+            try:
+                g = c.ground_remove(base); c.cluster(g["elevated"]); b = c.box_fit_resident()
+                assert len(c.box_markers(0)) == len(b["boxes"])
+                c.cluster_products(0)
+                host = np.zeros((2, 8192, 4), np.float32); host[0, :n] = base; host[1, : n // 2] = base[: n // 2]
+                c.frames_dev(host.ctypes.data, 8192 * 4, [n, n // 2], run_tracker=True, timestamps=[1e9 + trial * 1e5] * 2, ego_v=[1.0] * 2, ego_yaw=[0.0] * 2)
+                assert len(c.box_markers(1)) == len(c.get_boxes(1)["boxes"])
+                c.get_tracks(0)
+            except mot.MotError as e:
+                assert e.code in (mot.MOT_E_CAPACITY, mot.MOT_E_ARG, mot.MOT_E_STATE)
