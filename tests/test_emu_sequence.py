@@ -98,3 +98,27 @@ def test_sequence_mode_equals_frame_by_frame(mot, synth):
         # a second sequence continues the first (the stream's state carries over): frames K.. of the same drive
         with pytest.raises(mot.MotError):
             c.sequence_dev(clouds.ctypes.data, stride * 4, np.r_[n, n[:1]], np.r_[ts, ts[:1]], np.r_[ev, ev[:1]], np.r_[ey, ey[:1]])   # more frames than slots
+
+
+def test_sequence_mode_with_empty_single_point_and_full_frames(mot, synth):
+    """a drive whose frames are ragged to the extreme — 0 points, 1 point, a full slot, 64 points — in sequence mode against the frame-by-frame loop"""
+    import build_emu
+    lib = build_emu.build()
+    stride = 7168; ns = [7000, 0, 1, 6999, 64, 7168, 3000]; K = len(ns)
+    clouds = np.zeros((K, stride, 4), np.float32)
+    for f, n in enumerate(ns):
+        clouds[f, :n] = synth.make_cloud(7168, 31, f)[:n]
+    ts = 1e9 + 1e5 * np.arange(K); ev = 2.0 + 0.1 * np.arange(K); ey = 0.004 * np.arange(K)
+    ref = []
+    with mot.Context(lib_path=lib, max_points=stride, max_batch=1, max_tracks_total=64) as c:
+        for f in range(K):
+            c.frames_dev(clouds[f].ctypes.data, stride * 4, [ns[f]], run_tracker=True, timestamps=[ts[f]], ego_v=[ev[f]], ego_yaw=[ey[f]])
+            ref.append((c.get_boxes(0)["boxes"].copy(), c.get_tracks(0)))
+    with mot.Context(lib_path=lib, max_points=stride, max_batch=K, max_tracks_total=64) as c:
+        c.sequence_dev(clouds.ctypes.data, stride * 4, np.array(ns, np.int32), ts, ev, ey); c.synchronize()
+        for f in range(K):
+            assert np.array_equal(c.get_boxes(f)["boxes"].view(np.uint32), ref[f][0].view(np.uint32)), f
+        tr = c.get_tracks(0)
+        for k in ("track_manage", "lifetime", "p", "v_yaw"):
+            assert np.array_equal(tr[k].view(np.uint8), ref[-1][1][k].view(np.uint8)), k
+        assert tr["n"] >= 2 and sum(len(r[0]) for r in ref) >= 4
