@@ -226,3 +226,55 @@ def test_hostile_clouds_never_hang_or_crash_the_stateless_stages(mot, emu, synth
                 c.get_tracks(0)
             except mot.MotError as e:
                 assert e.code in (mot.MOT_E_CAPACITY, mot.MOT_E_ARG, mot.MOT_E_STATE)
+
+
+@pytest.mark.timeout(600)
+def test_random_call_orders_never_crash(mot, emu, synth):
+    """a few hundred valid calls in random order on one context — stage-wise stages, fused batches with and without the tracker, sequence mode,
+    getters of both slots, resets, snapshots saved and loaded, output flags and tracker modes switched in between: every call returns a status
+    (MOT_E_STATE where the header says so, e.g. mot_get_ground after a stage-wise call took slot 0), nothing crashes, the context stays usable"""
+    import snapshot_case as S
+    lib, L = emu
+    rng = np.random.default_rng(11)
+    N, stride = 6000, 6144
+    clouds = [synth.make_cloud(N, s, f) for s, f in ((1, 0), (2, 1), (3, 2))]
+    host = np.zeros((2, stride, 4), np.float32); host[0, :N] = clouds[0]; host[1, :N] = clouds[1]
+    errs = {}
+    with mot.Context(lib_path=lib, max_points=stride, max_batch=2, max_tracks_total=32) as c:
+        elev = cl = blob = None; t = 0
+        ops = ["ground", "cluster", "box_res", "box_fit", "markers", "products", "frames", "frames_trk", "get_ground", "get_clusters", "get_boxes", "get_tracks",
+               "track", "reset", "reset_slot", "save", "load", "outputs", "mode", "seq", "products_host"]
+        for _ in range(260):
+            op = ops[int(rng.integers(0, len(ops)))]; slot = int(rng.integers(0, 2))
+            try:
+                if op == "ground": elev = c.ground_remove(clouds[int(rng.integers(0, 3))])["elevated"]
+                elif op == "cluster" and elev is not None: cl = c.cluster(elev)
+                elif op == "box_res": c.box_fit_resident()
+                elif op == "box_fit" and cl is not None: c.box_fit(elev, cl["grid"], cl["num_cluster"])
+                elif op == "markers": c.box_markers(slot)
+                elif op == "products": c.cluster_products(slot)
+                elif op == "products_host" and cl is not None: c.cluster_products_host(elev[:3000], cl["grid"])
+                elif op == "frames": c.frames_dev(host.ctypes.data, stride * 4, [N, N - int(rng.integers(0, N))])
+                elif op == "frames_trk":
+                    t += 1; c.frames_dev(host.ctypes.data, stride * 4, [N, N], run_tracker=True, timestamps=[1e9 + t * 1e5] * 2, ego_v=[1.0] * 2, ego_yaw=[0.0] * 2)
+                elif op == "get_ground": c.get_ground(slot, n_hint=N)
+                elif op == "get_clusters": c.get_clusters(slot, int(rng.integers(0, N)))
+                elif op == "get_boxes": c.get_boxes(slot)
+                elif op == "get_tracks": c.get_tracks(slot)
+                elif op == "track":
+                    t += 1; c.ego_update(1e9 + t * 1e5, 1.0, 0.0, slot); c.track_step(S.boxes_of(t % 30), 1e9 + t * 1e5, slot)
+                elif op == "reset": c.reset()
+                elif op == "reset_slot": c.reset_slot(slot) if rng.random() < 0.5 else c.reset_tracks_slot(slot)
+                elif op == "save": blob = c.stream_save(slot)
+                elif op == "load" and blob is not None: c.stream_load(slot, blob)
+                elif op == "outputs": c.set_fused_outputs(int(rng.integers(0, 8)))
+                elif op == "mode": c.set_tracker_mode(int(rng.integers(0, 3)))
+                elif op == "seq":
+                    t += 2
+                    c.sequence_dev(host.ctypes.data, stride * 4, np.array([N, N], np.int32), np.array([1e9 + (t - 1) * 1e5, 1e9 + t * 1e5]), np.array([1.0, 1.0]), np.array([0.0, 0.0]))
+            except mot.MotError as e:
+                errs[(op, e.code)] = errs.get((op, e.code), 0) + 1
+        c.synchronize()
+        assert all(code in (mot.MOT_E_STATE, mot.MOT_E_CAPACITY) for _, code in errs), errs
+        c.reset(); c.set_fused_outputs(0); c.set_tracker_mode(0)
+        assert len(c.ground_remove(clouds[0])["elevated"]) > 100
