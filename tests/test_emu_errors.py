@@ -278,3 +278,37 @@ def test_random_call_orders_never_crash(mot, emu, synth):
         assert all(code in (mot.MOT_E_STATE, mot.MOT_E_CAPACITY) for _, code in errs), errs
         c.reset(); c.set_fused_outputs(0); c.set_tracker_mode(0)
         assert len(c.ground_remove(clouds[0])["elevated"]) > 100
+
+
+@pytest.mark.timeout(600)
+def test_extreme_parameters_are_refused_or_harmless(mot, emu, synth):
+    """mot_params with one to three fields set to 0, -1, NaN, Inf, 1e30, INT_MAX ...: mot_create either refuses them or the context runs a frame
+    and a few tracker steps to the end (a parameter must never size a buffer the kernels then overrun, nor a loop that does not end;
+    MOT_EMU_SANITIZE=address makes this the memory-safety check of the parameter validation)"""
+    import snapshot_case as S
+    lib, L = emu
+    rng = np.random.default_rng(3)
+    cloud = synth.make_cloud(6000, 2, 0)
+    fvals = [0.0, -1.0, 1e-30, 1e30, float("nan"), float("inf"), -float("inf"), 1.0, 0.5, 100.0, -100.0, 1e9]
+    ivals = [0, -1, 1, 2, 3, 7, 64, 255, 256, 257, 1000, 65536, 2 ** 31 - 1, -2 ** 31]
+    types = dict(mot.MotParams._fields_); fields = list(types)
+    created = refused = 0
+    for trial in range(90):
+        p = mot.params(trial % 2, lib=L)
+        for _ in range(int(rng.integers(1, 4))):
+            f = fields[int(rng.integers(0, len(fields)))]
+            setattr(p, f, ivals[int(rng.integers(0, len(ivals)))] if types[f] is C.c_int32 else fvals[int(rng.integers(0, len(fvals)))])
+        try:
+            c = mot.Context(p, lib_path=lib, max_points=6144, max_batch=1, max_tracks_total=16)
+        except mot.MotError as e:
+            assert e.code == mot.MOT_E_ARG; refused += 1
+            continue
+        created += 1
+        try:
+            g = c.ground_remove(cloud); c.cluster(g["elevated"]); c.box_fit_resident(); c.box_markers(0); c.cluster_products(0)
+            for f in range(4):
+                S._step(c, 0, f)
+        except mot.MotError as e:
+            assert e.code in (mot.MOT_E_CAPACITY, mot.MOT_E_ARG, mot.MOT_E_STATE)
+        c.close()
+    assert created >= 30 and refused >= 5, (created, refused)
