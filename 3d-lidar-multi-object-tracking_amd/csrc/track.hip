@@ -53,13 +53,14 @@ __device__ __forceinline__ int tlane() { return (int)(threadIdx.x & 63); }
 // MI355X (profiles/r02_kernel_trace_B512_4ctx_before_tracker_fix.txt). Up to 32 turns the loop runs as written (bit-identical to the reference);
 // beyond that the whole turns come off in one step first — the result differs from the loop's by the roundings the loop
 // would have accumulated (< 1e-9 for |a| < 1e4), on tracks whose state is garbage already and which the reference's own
-// guards (:828-851) are about to kill. Inf, which hangs the reference, becomes NaN here; and an angle so large that the one-step
-// reduction cannot resolve it any more (|a| beyond ~1e17: a garbage timestamp makes dt astronomical) takes the exact remainder instead
-// of leaving the loops below an operand they cannot move — the reference spins for ever there, a GPU must not.
+// guards (:828-851) are about to kill. Inf, which hangs the reference, becomes NaN here; and so does an angle so large that the one-step
+// reduction cannot resolve it any more (|a| beyond ~1e17: a garbage timestamp makes dt astronomical) — it used to leave the loops below an
+// operand they cannot move: the reference spins for ever there, a GPU must not. (NaN, not a remainder: no digit of such an angle means
+// anything, the NaN reaches the divergence guards of the next step, and a call to fmod cost the prediction kernel its spill-free registers.)
 __device__ __forceinline__ double wrap_pi(double a) {
   if (fabs(a) > 64. * PI_D) {
     const double r = a - trunc(a / (2. * PI_D)) * (2. * PI_D);
-    a = fabs(r) <= 64. * PI_D ? r : fmod(a, 2. * PI_D);
+    a = fabs(r) <= 64. * PI_D ? r : __builtin_nan("");
   }
   while (a > PI_D) a -= 2. * PI_D;
   while (a < -PI_D) a += 2. * PI_D;
@@ -192,7 +193,7 @@ __device__ void store_models(const PredictScratch* G, DevTrack* t, bool act) {
 }
 
 // ProcessIMMUKF(dt), ukf.cpp:507-527 — the group's track, state in G; `ok` is the group's predicate
-__device__ void process_imm_ukf(PredictScratch* G, double dt, bool ok) {
+__device__ __forceinline__ void process_imm_ukf(PredictScratch* G, double dt, bool ok) {   // (inlined into both forms of the step: as a call it costs a stack frame)
   const int s = glane();
   // MixingProbability :439-456 (p1_,p2_,p3_ = rows of the transition matrix :139-154)
   if (ok && s < 3) {
@@ -503,6 +504,7 @@ constexpr int kStreamClaimCap = 256;
 struct StreamClaims { unsigned long long claim[kStreamClaimCap]; unsigned long long matched; int usable, pad; };
 
 // ---- T1: PA — prediction + gating; the wave's four groups each take one (stream, live track) item
+template <bool kClaims>   // (the four-launch kernel instantiates the claim-free form: the extra live values cost it 12 bytes of scratch per lane otherwise)
 __device__ void predict_group(const TrackBuffers& tb, PredictScratch* G, int b, int li, bool act, StreamClaims* sc = nullptr) {
   const int s = glane(), grp = ggroup();
   const MotTrackParams& tp = tb.tp;
@@ -579,7 +581,7 @@ __device__ void predict_group(const TrackBuffers& tb, PredictScratch* G, int b, 
       acc_p |= (unsigned long long)pbits << (k0 & 63);
       if ((k0 & 63) == 48 || k0 + kGroupLanes >= Mg) {
         if (s == 0) { gate[k0 >> 6] = acc_g; prog[k0 >> 6] = acc_p; }
-        if ((k0 >> 6) == 0) { w0_g = acc_g; w0_p = acc_p; }
+        if (kClaims && (k0 >> 6) == 0) { w0_g = acc_g; w0_p = acc_p; }
         acc_g = 0ull; acc_p = 0ull;
       }
     }
@@ -588,7 +590,7 @@ __device__ void predict_group(const TrackBuffers& tb, PredictScratch* G, int b, 
   if (act && s == 0) {
     liveok[li] = ok ? (secondInit ? 2 : 1) : 0;   // 2: the track is in its second initialisation (trackNum 1 at the start of the step)
     if (!ok) u->track_num = 0;
-    if (sc && sc->usable) {
+    if (kClaims && sc && sc->usable) {
       const unsigned long long mine = ok ? (secondInit ? w0_p : w0_g) : 0ull;
       sc->claim[li] = mine;
       if (mine) atomicOr(&sc->matched, mine);
@@ -610,7 +612,7 @@ track_predict_kernel(TrackBuffers tb) {
     const bool act = i0 + grp < n;
     TrackItem it; it.b = 0; it.li = 0;
     if (act) it = tb.items[i0 + grp];
-    predict_group(tb, &s_g[wave * kGroupsPerWave + grp], it.b, it.li, act);
+    predict_group<false>(tb, &s_g[wave * kGroupsPerWave + grp], it.b, it.li, act);
   }
 }
 
@@ -1195,7 +1197,7 @@ track_step_stream_kernel(TrackBuffers tb, int do_prep) {
     }
     const int g = (int)(threadIdx.x >> 6) * kGroupsPerWave + ggroup();
     for (int i0 = 0; i0 < nlive; i0 += kStreamGroups) {
-      if (i0 + (int)(threadIdx.x >> 6) * kGroupsPerWave < nlive) predict_group(tb, &s_g.p[g], b, i0 + g, i0 + g < nlive, &s_claims);   // (wave-uniform: a wave with no track sits the round out)
+      if (i0 + (int)(threadIdx.x >> 6) * kGroupsPerWave < nlive) predict_group<true>(tb, &s_g.p[g], b, i0 + g, i0 + g < nlive, &s_claims);   // (wave-uniform: a wave with no track sits the round out)
     }
     STREAM_T(1);
     __syncthreads();
