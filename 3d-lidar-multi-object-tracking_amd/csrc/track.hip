@@ -56,7 +56,7 @@ __device__ __forceinline__ int tlane() { return (int)(threadIdx.x & 63); }
 // guards (:828-851) are about to kill. Inf, which hangs the reference, becomes NaN here; and so does an angle so large that the one-step
 // reduction cannot resolve it any more (|a| beyond ~1e17: a garbage timestamp makes dt astronomical) — it used to leave the loops below an
 // operand they cannot move: the reference spins for ever there, a GPU must not. (NaN, not a remainder: no digit of such an angle means
-// anything, the NaN reaches the divergence guards of the next step, and a call to fmod cost the prediction kernel its spill-free registers.)
+// anything, and the NaN reaches the divergence guards of the next step.)
 __device__ __forceinline__ double wrap_pi(double a) {
   if (fabs(a) > 64. * PI_D) {
     const double r = a - trunc(a / (2. * PI_D)) * (2. * PI_D);

@@ -136,7 +136,7 @@ def test_round_4_entry_points_check_their_arguments(mot, emu, synth):
 @pytest.mark.timeout(120)
 def test_an_astronomical_timestamp_jump_does_not_hang_the_tracker(mot, emu):
     """dt = 1e34 s (a garbage timestamp) makes yaw + yaw_rate * dt an angle no subtraction of 2 pi can move: the reference's
-    `while (a > M_PI) a -= 2. * M_PI` spins for ever there. The device takes the exact remainder instead (track.hip: wrap_pi) and the step
+    `while (a > M_PI) a -= 2. * M_PI` spins for ever there. The device answers NaN instead (track.hip: wrap_pi, as it does for Inf) and the step
     returns — with tracks killed by the divergence guards or carrying NaN, but it returns, on the emulator as on a GPU that must never hang"""
     import snapshot_case as S
     lib, L = emu
