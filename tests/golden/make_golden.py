@@ -54,6 +54,15 @@ def side_fixture(n, stream, frame):
     return dict(elevated=elev, grid=cl["grid"].astype(np.int16), clustered=r["clustered"], obstacles=r["obstacles"], cost_map=r["cost_map"])
 
 
+def markers_fixture(n, stream, frame):
+    """the rviz CUBE markers boxFitting fills (mark_cluster, box_fitting.cpp:161-209) for one frame: pose.position and scale per kept box"""
+    elev = O.ref_ground_remove(S.make_cloud(n, stream, frame))["elevated"]
+    cl = O.ref_cluster(elev)
+    bx = O.ref_box_fit(elev, cl["grid"], cl["num_cluster"])
+    return dict(elevated=elev, grid=cl["grid"].astype(np.int16), num_cluster=np.int32(cl["num_cluster"]), boxes=bx["boxes"],
+                markers=O.ref_box_markers(elev, cl["grid"], cl["num_cluster"]))
+
+
 def tracker_fixture(stream, nframes, npts, unit, ot0_workdir=None):
     """ot0_workdir: run object_tracking0's tracker instead (KITTI constants; it reads the ego motion from text files that
     Ref0Tracker writes under that directory); the boxes still come from the first package's chain (more of them)."""
@@ -101,6 +110,7 @@ if __name__ == "__main__":
     fx = frame_fixture(24000, 5, 2)
     np.savez_compressed(os.path.join(HERE, "frame_ot_24k.npz"), **fx)
     np.savez_compressed(os.path.join(HERE, "side_ot_9k.npz"), **side_fixture(9000, 3, 0))
+    np.savez_compressed(os.path.join(HERE, "markers_ot_24k.npz"), **markers_fixture(24000, 5, 2))
     assert O.ref0() is not None, "oracle/_ref/libmot_ref0.so is not built"
     np.savez_compressed(os.path.join(HERE, "frame_ot0_60k.npz"), **frame0_fixture(60000, 4, 1))
     for unit, name in ((1e5, "us"), (0.1, "sec")):

@@ -286,6 +286,17 @@ def test_box_markers(ctx, oracle, synth, n, stream, frame):
             assert np.array_equal(ctx.box_markers(s).view(np.uint32), O.box_markers_numpy(es, k["point_label"], bb["box_cluster"]).view(np.uint32))
 
 
+def test_box_markers_golden(ctx):
+    """the cube markers of the golden frame tests/golden/markers_ot_24k.npz (the reference's own boxFitting, make_golden.py) on the MI355X"""
+    fx = G.load("markers_ot_24k.npz")
+    cl = ctx.cluster(fx["elevated"])
+    assert cl["num_cluster"] == int(fx["num_cluster"]) and np.array_equal(cl["grid"], fx["grid"].astype(np.int32))
+    b = ctx.box_fit_resident()
+    assert np.array_equal(b["boxes"].view(np.uint32), fx["boxes"].view(np.uint32))
+    m = ctx.box_markers(0).astype(np.float64); m[:, 3:][m[:, 3:] == 0] = 0.1
+    assert np.array_equal(m, fx["markers"])
+
+
 ZERO_HEIGHT_CASES = ([np.nan, np.nan, np.nan, -0.0, np.nan, np.nan], [np.nan, 0.0, np.nan, -0.0, np.nan, np.nan], [-1.0, -0.0, 0.0, -0.5, np.nan, np.nan],
                      [-1.0, -2.0, -0.0, -0.0, 0.0, np.nan], [0.5, -0.0, 0.0, np.nan, np.nan, np.nan], [-0.0] * 6, [0.0] + [-0.0] * 5)
 
