@@ -19,6 +19,7 @@
 #define MOT_ADAPTERS_HPP_
 
 #include <array>
+#include <cstdio>
 #include <stdexcept>
 #include <string>
 #include <type_traits>
@@ -58,7 +59,8 @@ struct Config {
   int preset = MOT_PRESET_OBJECT_TRACKING;
   int device = 0;
   int max_points = 262144;
-  int max_tracks_total = 16384;
+  int max_tracks_total = 16384;   // track SLOTS: tracks alive at the same time
+  int max_tracks_ever = 0;        // tracks a stream may create before it is restarted (0 = 64 x max_tracks_total); see immUkfJpdaf below
 };
 inline Config& config() { static Config c; return c; }
 inline void configure(const Config& c) { config() = c; }
@@ -68,6 +70,7 @@ inline mot_ctx* context() {
   if (!ctx) {
     mot_params p;
     if (mot_params_preset(config().preset, &p) != MOT_OK) throw std::runtime_error("mot_params_preset failed");
+    if (config().max_tracks_ever > 0) p.max_tracks_ever = config().max_tracks_ever;   // 0: the library's default, 64 x max_tracks_total
     if (mot_create(&p, config().device, config().max_points, 1, config().max_tracks_total, &ctx) != MOT_OK)
       throw std::runtime_error("mot_create failed (no MI355X / HIP device?) — this library has no CPU fallback");
   }
@@ -251,9 +254,26 @@ inline void immUkfJpdaf(std::vector<pcl::PointCloud<pcl::PointXYZ>> bBoxes, doub
   std::vector<float> boxes(bBoxes.size() * 24 + 24);
   for (size_t b = 0; b < bBoxes.size(); b++)
     for (int k = 0; k < 8; k++) { boxes[(b * 8 + k) * 3] = bBoxes[b][k].x; boxes[(b * 8 + k) * 3 + 1] = bBoxes[b][k].y; boxes[(b * 8 + k) * 3 + 2] = bBoxes[b][k].z; }
-  std::vector<mot_track> tr(config().max_tracks_total);
+  // One record per track EVER created, like the reference's output vectors (imm_ukf_jpda.cpp:995-1041), so the read-back buffer
+  // grows with the stream's age: it starts at max_tracks_total records and doubles whenever the step reports more (the step itself
+  // has run by then; mot_get_tracks fetches the same records again). MOT_E_CAPACITY WITH the records delivered means births were
+  // dropped — every track slot alive at once, or the stream's max_tracks_ever budget (64 x max_tracks_total here) used up: the
+  // reference would have grown for ever; this adapter publishes what came back and starts the stream's TRACKS over
+  // (mot_reset_tracks_slot keeps the dead-reckoned ego pose, so the global frame stays continuous). It never throws for that.
+  static std::vector<mot_track> tr;
+  if (tr.size() < (size_t)config().max_tracks_total) tr.resize((size_t)config().max_tracks_total);
   int nt = 0;
-  check(mot_track_step(context(), 0, boxes.data(), (int)bBoxes.size(), timestamp, tr.data(), (int)tr.size(), &nt));
+  int rc = mot_track_step(context(), 0, boxes.data(), (int)bBoxes.size(), timestamp, tr.data(), (int)tr.size(), &nt);
+  if (rc == MOT_E_CAPACITY && (size_t)nt > tr.size()) {   // nothing was copied: fetch again with room for every record
+    tr.resize(2 * (size_t)nt);
+    rc = mot_get_tracks(context(), 0, tr.data(), (int)tr.size(), &nt);
+  }
+  if (rc == MOT_E_CAPACITY && (size_t)nt <= tr.size()) {
+    std::fprintf(stderr, "mot_adapters: %s -- restarting the tracks of this stream\n", mot_last_error(context()));
+    check(mot_reset_tracks_slot(context(), 0));
+    rc = MOT_OK;
+  }
+  check(rc);
   for (int i = 0; i < nt; i++) {
     targets.push_back(pcl::PointXYZ(tr[i].px, tr[i].py, tr[i].pz));
     targetVandYaw.push_back({tr[i].v, tr[i].yaw});

@@ -64,14 +64,14 @@ def reference_nodes() -> dict:
     return {n: os.path.join(REF_BIN, n) for n in list(NODES) + ["pipeline0"]}
 
 
-def recipe_nodes(lib: str) -> dict:
+def recipe_nodes(lib: str, out_dir: str = REF_BIN, link_extra=()) -> dict:
     """the reference's node sources with only their algorithm includes swapped for the adapter header"""
-    os.makedirs(REF_BIN, exist_ok=True)
+    os.makedirs(out_dir, exist_ok=True)
     out = {}
     pat = re.compile(r'^#include "(%s)"\s*$' % "|".join(re.escape(h) for h in ALGO_HEADERS), re.M)
     for n, rel in NODES.items():
         path = os.path.join(REF, rel)
-        exe = os.path.join(REF_BIN, "recipe_" + n)
+        exe = os.path.join(out_dir, "recipe_" + n)
         deps = [path, lib, os.path.join(ROOT, "include", "mot_adapters.hpp"), os.path.join(ROOT, "include", "mot.h"), os.path.abspath(__file__)] + _shim_files()
         if not _newer(exe, deps, lib):
             src = open(path, encoding="utf-8", errors="replace").read()
@@ -81,7 +81,7 @@ def recipe_nodes(lib: str) -> dict:
                 if first[0]:
                     first[0] = False; return '#include "mot_adapters.hpp"'
                 return ""
-            _cxx(["-I", SHIM, "-I", os.path.join(REF, "tracking"), "-I", os.path.join(ROOT, "include"), "-x", "c++", "-", "-o", exe] + _link_args(lib),
+            _cxx(["-I", SHIM, "-I", os.path.join(REF, "tracking"), "-I", os.path.join(ROOT, "include"), "-x", "c++", "-", "-o", exe] + _link_args(lib) + list(link_extra),
                  exe, stdin_source=pat.sub(swap, src))
             _stamp(exe, lib)
         out[n] = exe
@@ -105,12 +105,44 @@ def own_nodes(lib: str, out_dir: str = OWN_BIN, link_extra=()) -> dict:
     return out
 
 
+def adapter_driver(lib: str, out_dir: str = OWN_BIN, link_extra=()) -> str:
+    """tests/drivers/adapter_tracker_driver.cpp: the adapter header's tracker functions on a small track budget"""
+    os.makedirs(out_dir, exist_ok=True)
+    src = os.path.join(HERE, "drivers", "adapter_tracker_driver.cpp")
+    exe = os.path.join(out_dir, "adapter_tracker_driver")
+    deps = [src, lib, os.path.join(ROOT, "include", "mot_adapters.hpp"), os.path.join(ROOT, "include", "mot.h")] + _shim_files()
+    if not _newer(exe, deps, lib):
+        _cxx(["-I", SHIM, "-I", os.path.join(REF, "tracking"), "-I", os.path.join(ROOT, "include"), src, "-o", exe] + _link_args(lib) + list(link_extra), exe)
+        _stamp(exe, lib)
+    return exe
+
+
+def _hip_link_extra():
+    rel = os.path.relpath(os.path.dirname(HIP_LIB), HIP_BIN)
+    return ["-Wl,-rpath,$ORIGIN/" + rel, "-Wl,-rpath-link,/opt/rocm/lib", "-Wl,--allow-shlib-undefined"]
+
+
+def hip_recipe_nodes() -> dict:
+    """the reference's UNMODIFIED node sources + the adapter header (recipe_nodes) linked against the real library: ros/bin/recipe_*,
+    built where /root/reference exists, run on the GPU box (tests/test_nodes_gpu.py). Plus the adapter's tracker driver."""
+    os.makedirs(HIP_BIN, exist_ok=True)
+    out = recipe_nodes(HIP_LIB, HIP_BIN, _hip_link_extra())
+    out["adapter_tracker_driver"] = adapter_driver(HIP_LIB, HIP_BIN, _hip_link_extra())
+    return out
+
+
 def hip_nodes() -> dict:
     """the node shells linked against the real library (needs the reference's vendored Eigen for the tf / pcl_ros shim, so it
     is built in the container that has /root/reference — __graft_entry__.build() — and travels to the GPU box prebuilt).
     The run path is relative to the executable, the HIP runtime is found through the library's own run path."""
-    rel = os.path.relpath(os.path.dirname(HIP_LIB), HIP_BIN)
-    return own_nodes(HIP_LIB, HIP_BIN, ["-Wl,-rpath,$ORIGIN/" + rel, "-Wl,-rpath-link,/opt/rocm/lib", "-Wl,--allow-shlib-undefined"])
+    return own_nodes(HIP_LIB, HIP_BIN, _hip_link_extra())
+
+
+def prebuilt_recipe(dirname: str = HIP_BIN):
+    """{node: path} of the recipe executables (+ the adapter driver) when they all exist in dirname, else None"""
+    out = {n: os.path.join(dirname, "recipe_" + n) for n in NODES}
+    out["adapter_tracker_driver"] = os.path.join(dirname, "adapter_tracker_driver")
+    return out if all(os.path.isfile(p) and os.access(p, os.X_OK) for p in out.values()) else None
 
 
 def prebuilt(dirname: str):
