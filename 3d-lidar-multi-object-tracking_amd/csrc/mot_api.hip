@@ -135,6 +135,7 @@ struct mot_ctx {
   // per-point cluster labels of a slot: 1 = in d_label; 0 = not computed, the slot's cloud and cells come from the fused compaction kernel;
   // 2 = not computed, the slot's cloud was uploaded by a stage-wise call (no cells). mot_get_clusters computes them on demand.
   std::vector<char> label_state;
+  std::vector<char> box_valid;        // per slot: the box stage's products (boxes, cluster order, groups) belong to the cloud now resident in the slot
   bool ground_resident = false;        // d_ground / d_mask hold the last batch's ground cloud and mask
   bool last_fused = false;             // the last ground launch was a fused one (input, cells and thresholds of the batch still resident)
   int* h_counts = nullptr;  // pinned [batch][4]
@@ -454,6 +455,7 @@ static int create_impl(mot_ctx* c) {
   MOT_HIP(c, hipStreamSynchronize(c->stream));
   c->h_n.assign(B, 0);
   c->label_state.assign(B, 2);
+  c->box_valid.assign(B, 0);
   return MOT_OK;
 }
 
@@ -736,6 +738,7 @@ static int launch_frames(mot_ctx* c, int batch, int run_tracker, const double* t
   const bool want_ground = (c->fused_outputs & MOT_OUT_GROUND) != 0, want_mask = (c->fused_outputs & MOT_OUT_MASK) != 0;
   c->ground_resident = want_ground && want_mask; c->last_fused = true;
   c->label_state.assign(c->batch, (c->fused_outputs & MOT_OUT_LABELS) ? 1 : 0);
+  c->box_valid.assign(c->batch, 1);
 #ifndef MOT_HIPEMU
   // Few streams per launch = somebody waits for every frame: the sequence's 10-13 launches go out as ONE hipGraph launch, captured
   // once per launch geometry. What differs from call to call without changing the geometry (the cloud's address, the look-back
@@ -829,6 +832,7 @@ extern "C" int mot_sequence_dev(mot_ctx* c, const float* d_xyzw, long frame_stri
   const bool want_ground = (c->fused_outputs & MOT_OUT_GROUND) != 0, want_mask = (c->fused_outputs & MOT_OUT_MASK) != 0;
   c->ground_resident = want_ground && want_mask; c->last_fused = true;
   c->label_state.assign(c->batch, (c->fused_outputs & MOT_OUT_LABELS) ? 1 : 0);
+  c->box_valid.assign(c->batch, 1);
   issue_frame_kernels(c, K, max_n, 0, want_ground, want_mask, false);   // slots = frames; ends with the plain box_finalize_kernel
   const TrackBuffers base = track_buffers(c, true);
   RangeScope rt(c, "mot:tracker (sequence)");
@@ -1044,6 +1048,7 @@ extern "C" int mot_cluster(mot_ctx* c, const float* elev, int n, int32_t* grid, 
     MOT_HIP(c, hipMemsetAsync(c->d_counts + kCntGroups, 0, 2 * sizeof(int), c->stream));   // kCntGroups, kCntIrregular
   }
   c->label_state[0] = point_label ? 1 : 2;
+  c->box_valid[0] = 0;   // a new cloud in slot 0: what an earlier box stage left there is stale (mot_box_markers answers MOT_E_STATE)
   MOT_HIP(c, hipGetLastError());
   return mot_get_clusters(c, 0, grid, num_cluster, point_label, n);
 }
@@ -1069,7 +1074,7 @@ extern "C" int mot_box_fit(mot_ctx* c, const float* elev, int n, const int32_t* 
   if ((rc = set_count(c, 0, kCntClusters, num_cluster))) return rc;
   ClusterBuffers cb = cluster_buffers(c);
   mot_launch_box(c->dp, cb, 1, n, c->stream);
-  c->label_state[0] = 1;
+  c->label_state[0] = 1; c->box_valid[0] = 1;
   MOT_HIP(c, hipGetLastError());
   return mot_get_boxes(c, 0, boxes, max_boxes, n_boxes, box_cluster, n_undefined);
 }
@@ -1086,7 +1091,7 @@ extern "C" int mot_box_fit_resident(mot_ctx* c, float* boxes, int max_boxes, int
   if (n < 0 || n > c->cap) return fail(c, MOT_E_STATE, "mot_box_fit_resident: no cloud resident in slot 0");
   if (c->h_counts[kCntClusters] > kMaxClusters) return fail(c, MOT_E_CAPACITY, "more clusters than the library supports (4096)");
   mot_launch_box(c->dp, cluster_buffers(c), 1, n, c->stream);
-  c->label_state[0] = 1;
+  c->label_state[0] = 1; c->box_valid[0] = 1;
   MOT_HIP(c, hipGetLastError());
   return mot_get_boxes(c, 0, boxes, max_boxes, n_boxes, box_cluster, n_undefined);
 }
@@ -1185,6 +1190,7 @@ extern "C" int mot_cluster_products_host(mot_ctx* c, const float* elev, int n, c
   MOT_HIP(c, hipMemcpyAsync(c->d_grid, c->h_grid16.data(), (size_t)G * G * sizeof(GridLabel), hipMemcpyHostToDevice, c->stream));
   MOT_HIP(c, hipStreamSynchronize(c->stream));
   c->last_fused = false;   // slot 0 now holds this call's cloud: mot_get_ground must not re-run a fused batch's compaction over it
+  c->box_valid[0] = 0;
   int rc = set_count(c, 0, kCntElev, n);
   if (rc) return rc;
   return mot_cluster_products(c, 0, sp, clustered_xyzw, max_clustered, n_clustered, obstacles_xyzc, max_obstacles, n_obstacles, cost_map);
@@ -1196,6 +1202,7 @@ extern "C" int mot_box_markers(mot_ctx* c, int slot, float* centroid_extent, int
   if (!c) return MOT_E_ARG;
   MOT_GUARD(c);
   if (slot < 0 || slot >= c->batch || max_boxes < 0 || !n_boxes) return fail(c, MOT_E_ARG, "mot_box_markers: slot or max_boxes out of range, or null n_boxes");
+  if (!c->box_valid[slot]) return fail(c, MOT_E_STATE, "mot_box_markers: no box stage has run on the cloud now resident in this slot (a stage-wise call replaced it since)");
   int rc = fetch_counts(c, slot);   // (also reports a frame whose groups overflowed: its cluster order is incomplete)
   if (rc) return rc;
   const int nb = c->h_counts[slot * kCountsStride + kCntBoxes];
@@ -1254,7 +1261,7 @@ extern "C" int mot_ground_remove(mot_ctx* c, const float* xyzw, int n, float* el
   GroundBuffers g = ground_buffers(c, c->d_in, c->cap, true);
   mot_launch_ground(c->dp, g, 1, n, c->stream);
   MOT_HIP(c, hipGetLastError());
-  c->ground_resident = true; c->last_fused = false; c->label_state[0] = 2;
+  c->ground_resident = true; c->last_fused = false; c->label_state[0] = 2; c->box_valid[0] = 0;
   return mot_get_ground(c, 0, elev, n_elev, ground, n_ground, mask, n);
 }
 
@@ -1292,7 +1299,7 @@ extern "C" int mot_ground_remove_pointcloud2(mot_ctx* c, const void* data, int n
   GroundBuffers g = ground_buffers(c, c->d_in, c->cap, true);
   mot_launch_ground(c->dp, g, 1, n, c->stream);
   MOT_HIP(c, hipGetLastError());
-  c->ground_resident = true; c->last_fused = false; c->label_state[0] = 2;
+  c->ground_resident = true; c->last_fused = false; c->label_state[0] = 2; c->box_valid[0] = 0;
   return mot_get_ground(c, 0, elev, n_elev, ground, n_ground, mask, n);
 }
 
@@ -1672,6 +1679,34 @@ extern "C" int mot_stream_load(mot_ctx* c, int slot, const void* blob, size_t by
     for (int i = 0; i < h.nzomb && ok; i++) { int sl; memcpy(&sl, p_zomb + i, sizeof sl); ok = sl >= 0 && (size_t)sl < T && ref_of(sl) >= 0 && ref_of(sl) < h.nt; }
     for (size_t i = 0; i < nt && ok; i++) { int sl; memcpy(&sl, p_slot_of + i, sizeof sl); ok = sl >= -1 && (sl < 0 || (size_t)sl < T); }
     if (!ok) return fail(c, MOT_E_ARG, "mot_stream_load: corrupt snapshot (a track slot or reference index out of range)");
+    // ... and the slot bookkeeping must be CONSISTENT, not only in range: the finish kernel lists the free slots from the `used` bitmap
+    // and appends newborns to the live list, so a bitmap that misses a listed slot (or a slot listed twice) would let nlive + births
+    // exceed T and the next step write past the slot's live / zombie arrays — into another stream's state. Required: every listed
+    // slot is listed once and has its bit set, no other bit is set (none at or beyond T), nlive + nzomb <= T, and the per-track-ever
+    // table points back at each listed slot.
+    const char* p_used = reinterpret_cast<const char*>(p_zomb + T);
+    auto used_bit = [&](size_t sl) { unsigned long long w; memcpy(&w, p_used + (sl >> 6) * sizeof w, sizeof w); return (w >> (sl & 63)) & 1ull; };
+    std::vector<unsigned char> seen(T, 0);
+    size_t listed = 0;
+    auto visit = [&](const int* list, int n) {
+      for (int i = 0; i < n && ok; i++) {
+        int sl; memcpy(&sl, list + i, sizeof sl);
+        int back; memcpy(&back, p_slot_of + ref_of(sl), sizeof back);
+        ok = !seen[sl] && used_bit((size_t)sl) && back == sl;
+        seen[sl] = 1; listed++;
+      }
+    };
+    visit(p_live, h.nlive); visit(p_zomb, h.nzomb);
+    size_t bits = 0;
+    const bool seeded = h.init && !h.tracks_restart;   // otherwise the arrays mean nothing (mot_stream_save wrote the counters as zero): the next step seeds them anew
+    if (!seeded) { if (h.nt || h.nlive || h.nzomb) ok = false; bits = listed; }
+    for (size_t w = 0; seeded && w < usedW && ok; w++) {
+      unsigned long long v; memcpy(&v, p_used + w * sizeof v, sizeof v);
+      if (w == usedW - 1 && (T & 63)) ok = (v >> (T & 63)) == 0;
+      bits += (size_t)__builtin_popcountll(v);
+    }
+    if (!ok || listed > T || bits != listed)
+      return fail(c, MOT_E_ARG, "mot_stream_load: corrupt snapshot (the live / just-died lists, the slot bitmap and the per-track table disagree)");
   }
   const char* in = static_cast<const char*>(blob) + sizeof h;
   auto give = [&](void* d, size_t n) -> hipError_t {

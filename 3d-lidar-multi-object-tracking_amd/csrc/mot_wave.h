@@ -119,6 +119,29 @@ __device__ __forceinline__ int wave_uniform_i32(int v) {
 
 // ---- reductions over ONE DPP row (16 lanes): every lane of the row receives its row's result. The tracker packs one track
 // per row, four tracks per wave.
+//
+// ADDITION ORDER. The reference's sums over the sigma points are explicit loops, i = 0 .. 14 in order (ukf.cpp:736-749: x_ = x_ + w_i * col_i;
+// P_ = P_ + w_i * d * d^T; likewise S and Tc, :812-848); the row tree below adds the same terms pairwise at lane distances 1, 2, 4, 8. That is a
+// DEVIATION in the last bits of every sum (DESIGN.md "Parity"), inside the 1e-4 bar for every well-conditioned track and amplified to O(1) only on
+// the tracks whose covariance has stopped being positive definite (where two builds of the reference itself part as far:
+// tests/test_tracker_noise_floor.py). -DMOT_TRACK_SEQ_SUMS=1 restores the reference's order (a 15-step chain of shuffles per sum: slow) so that the
+// parity suites can separate reordering noise from a real regression: tests/test_emu_tracker.py::test_sum_order_knob.
+#ifdef MOT_TRACK_SEQ_SUMS
+__device__ __forceinline__ double row_sum_f64(double v) {
+  const int row0 = (int)(threadIdx.x & 63) & ~15;
+  double acc = 0.0;   // x_.fill(0.0) / P_.fill(0.0)
+  for (int i = 0; i < 16; i++) acc = acc + __shfl(v, row0 + i, 64);   // lane 15 holds a zero term wherever 15 sigma points are summed
+  return acc;
+}
+__device__ __forceinline__ int row_sum8_index(int lane_in_row) { return lane_in_row & 7; }
+__device__ __forceinline__ double row_sum8_f64(const double (&v)[8]) {
+  const int L = (int)(threadIdx.x & 7);
+  double mine = 0.0;
+#pragma unroll
+  for (int j = 0; j < 8; j++) { const double t = row_sum_f64(v[j]); mine = L == j ? t : mine; }
+  return mine;
+}
+#else
 __device__ __forceinline__ double row_sum_f64(double v) {
 #ifndef MOT_HIPEMU
 #define MOT_DPP_F64R(x, ctrl)                                                                        \
@@ -171,6 +194,7 @@ __device__ __forceinline__ double row_sum8_f64(const double (&v)[8]) {
 #undef MOT_DPP_F64X
 #endif
 }
+#endif  // MOT_TRACK_SEQ_SUMS
 __device__ __forceinline__ unsigned long long row_or_u64(unsigned long long v) {
 #ifndef MOT_HIPEMU
 #define MOT_DPP_U64R(x, ctrl)                                                                                                      \

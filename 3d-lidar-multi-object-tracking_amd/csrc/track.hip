@@ -1,24 +1,26 @@
 // track.hip — IMM-UKF-PDA multi-object tracker step on gfx950. Product code (HIP, wave64, fp64).
 //
 // Replaces immUkfJpdaf() (OT/tracking/imm_ukf_jpda.cpp:704-1112) and the class UKF it drives
-// (OT/tracking/ukf.cpp) for a batch of independent sensor streams. ONE wave owns one track at a time ("one warp per track"
-// of BASELINE.json's north_star). The reference walks its tracks one after the other and lets them interact through shared
-// vectors; here the frame step is cut into phases, spread over four launches (see "the frame step" below):
+// (OT/tracking/ukf.cpp) for a batch of independent sensor streams. ONE 16-LANE DPP ROW owns one track, four tracks per wave
+// (BASELINE.json's north_star says "one warp per track": 15 sigma points fill a quarter of a wave64, so a whole wave per track left
+// three quarters of every fp64 instruction idle — round 3). The reference walks its tracks one after the other and lets them interact
+// through shared vectors; here the frame step is cut into phases, spread over four launches — or ONE, a workgroup per stream, for calls
+// of few streams (see "the frame step" below):
 //
-//   PA  per live track (a wave): clear isVis, divergence guard, IMM mixing, 3 x sigma-point prediction, 3 x lidar
+//   PA  per live track (a row): clear isVis, divergence guard, IMM mixing, 3 x sigma-point prediction, 3 x lidar
 //       measurement prediction, pick the max-det(S) model, gate every box of the frame (NIS < 9.22)
 //       -> bit-mask per track; lanes = sigma points / matrix entries / boxes
 //   PB  lifetime += #gated boxes no EARLIER track of the stream claimed                            (SURVEY.md H12:
 //       matchingVec is shared across the reference's track loop — the only true cross-track order dependence); every
-//       track's wave ORs the masks of its predecessors itself, so no sequential pass over the tracks is left
-//   PC  per track (a wave): box association + best-box upkeep, second initialisation, track-management state
+//       track's row ORs the masks of its predecessors itself, so no sequential pass over the tracks is left
+//   PC  per track (a row): box association + best-box upkeep, second initialisation, track-management state
 //       machine, PDA update of the three models, mode probabilities, merge
 //   PD  over-segmentation merge in closed form (last write of the reference's (i,j) double loop wins)
 //   PE  birth of a track from every unclaimed box, in box order
 //   PF  per-track outputs, the sticky static classification, the compact list of the tracks alive for the next step
 //
-// fp64 like the reference; operation order follows the reference except inside reductions over sigma points /
-// measurements (Eigen's own reductions are vectorised, so that order is not defined by the source either).
+// fp64 like the reference; operation order follows the reference except inside the sums over sigma points / measurements, which are
+// reductions over the row (the reference's loops add in index order: a last-bit deviation, mot_wave.h "ADDITION ORDER").
 // Parity bar: track sets and integer state exact, continuous state <= 1e-4 relative (BASELINE.json).
 #include "mot_internal.h"
 #include "mot_wave.h"
@@ -325,7 +327,8 @@ __device__ __forceinline__ void process_imm_ukf(PredictScratch* G, double dt, bo
   // (row_sum_f64: every lane receives it). Until round 4 a lane was a MATRIX ENTRY that read its 15 (30) terms from LDS: 132 sums of 15 terms,
   // ~2000 LDS reads per lane and step with the selects of the yaw row — the covariance alone took 9 of the prediction's 22 us, bound by LDS
   // traffic and bank conflicts (profiles/r04_stream_kernel_phases.txt). The terms are the reference's, (w_i * d_r) * d_c; the ORDER of the
-  // additions is the row tree's — as Eigen's own vectorised reductions, not defined by the source.
+  // additions is the row tree's, NOT the reference's (its loops add i = 0 .. 14 in turn, ukf.cpp:736-749): a last-bit deviation, see mot_wave.h
+  // (-DMOT_TRACK_SEQ_SUMS=1 restores the reference's order for the parity suites).
   {
     const double wi = s < 15 ? ukf_w(s) : 0.0;
     const bool on = ok && s < 15;
@@ -936,8 +939,10 @@ static __device__ void track_finish_body(const TrackBuffers& tb, const int b, co
   mot_track* __restrict__ out = tb.out + (long)b * T;
   const Vec2d* __restrict__ cp = tb.cp + (long)b * kMaxBoxesPerFrame;
   const int nt0 = tb.nt[b];
-  const int nlive = tb.nlive[b];
-  const int nz0 = tb.nzomb[b];
+  // (both lists hold distinct slots of T, so they never exceed T: an invariant of this kernel, and mot_stream_load refuses a snapshot that
+  // breaks it; the clamps only keep a violated invariant from becoming an out-of-bounds store into another stream's arrays)
+  const int nlive = tb.nlive[b] < T ? tb.nlive[b] : T;
+  const int nz0 = tb.nzomb[b] < T ? tb.nzomb[b] : T;
 
   // ---- eviction. The tracks that died in the LAST step were still shown by that step's outputs as the reference shows them; from
   // this step on the reference only resets their isVisBB_ (:813) and never touches their filter again: what the outputs and the

@@ -228,7 +228,9 @@ int mot_cluster(mot_ctx* ctx, const float* elevated_xyzw, int n, int32_t* grid, 
  * boxes: capacity max_boxes x 8 x 3 floats (4 bottom corners z=-sensor_height, 4 top corners z=maxZ,
  * box_fitting.cpp:379-389). box_cluster (optional): 1-based cluster id of each emitted box.
  * n_undefined (optional): clusters whose result is undefined behaviour in the reference
- * (uninitialised reads); they are rejected here. */
+ * (uninitialised reads); they are rejected here.
+ * LABEL RANGE: the device's label grid is 16 bits wide (a frame has at most 4096 clusters). A grid value outside 0..num_cluster
+ * names no cluster — getClusteredPoints would index past its per-cluster vectors with it (box_fitting.cpp:59-66) — and is read as 0. */
 int mot_box_fit(mot_ctx* ctx, const float* elevated_xyzw, int n, const int32_t* grid, int num_cluster,
                 float* boxes, int max_boxes, int* n_boxes, int32_t* box_cluster, int* n_undefined);
 
@@ -397,7 +399,9 @@ int mot_side_params_default(mot_side_params* out);
 int mot_cluster_products(mot_ctx* ctx, int slot, const mot_side_params* sp, float* clustered_xyzw, int max_clustered,
                          int* n_clustered, float* obstacles_xyzc, int max_obstacles, int* n_obstacles, int32_t* cost_map);
 /* the same on a caller-supplied cloud and label grid (the argument lists of the three reference functions): uploads them
- * into slot 0 first. elevated_xyzw: n x 4 floats; grid: num_grid x num_grid int32, x-major. */
+ * into slot 0 first. elevated_xyzw: n x 4 floats; grid: num_grid x num_grid int32, x-major.
+ * LABEL RANGE: 0 .. 65535 (the device's grid is 16 bits wide; componentClustering's labels never exceed numGrid^2 / 2 = 31 250); any other
+ * value is MOT_E_ARG, checked before slot 0 is touched. The reference's int grid would take any int as an obstacle's cluster id. */
 int mot_cluster_products_host(mot_ctx* ctx, const float* elevated_xyzw, int n, const int32_t* grid, const mot_side_params* sp,
                               float* clustered_xyzw, int max_clustered, int* n_clustered, float* obstacles_xyzc,
                               int max_obstacles, int* n_obstacles, int32_t* cost_map);
@@ -406,7 +410,9 @@ int mot_cluster_products_host(mot_ctx* ctx, const float* elevated_xyzw, int n, c
  * mot_sequence_dev on any slot), in the order mot_get_boxes returns them:
  *   centroid_extent[6*i + 0..2] = pcl::compute3DCentroid of the cluster's points: float sums in input order, divided by the count
  *   centroid_extent[6*i + 3..5] = pcl::getMinMax3D's max - min, as floats (marker.scale; the caller substitutes 0.1 for a 0, :192-199)
- * centroid_extent may be NULL (only *n_boxes is written). MOT_E_CAPACITY when max_boxes < *n_boxes. */
+ * centroid_extent may be NULL (only *n_boxes is written). MOT_E_CAPACITY when max_boxes < *n_boxes. MOT_E_STATE when the slot's cloud has
+ * been replaced since its last box stage (mot_ground_remove*, mot_cluster, mot_cluster_products_host write into slot 0): the cluster
+ * order the cubes are folded from would belong to another cloud. */
 int mot_box_markers(mot_ctx* ctx, int slot, float* centroid_extent, int max_boxes, int* n_boxes);
 
 /* ---------------------------------------------------------------- input decode

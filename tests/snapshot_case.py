@@ -81,6 +81,27 @@ def check(mot, lib_path=None):
                 with pytest.raises(mot.MotError) as e:
                     b.stream_load(2, bytes(bad))
                 assert e.value.code == mot.MOT_E_ARG and "corrupt" in str(e.value)
+                # in range but INCONSISTENT (the round-4 advisor's finding: an empty slot bitmap under a full live list made the finish kernel
+                # list every slot as free, and nlive + births ran past the slot's arrays): bitmap cleared; a live slot listed twice; a bit
+                # nobody lists; the per-track table not pointing back
+                o_live, o_zomb = hb + T * tb, hb + T * tb + 4 * T
+                o_used = o_zomb + 4 * T
+                nlive = _meta(blob)[2]["nlive"]
+                assert nlive >= 2
+                cases = []
+                bad = bytearray(blob); bad[o_used: o_used + 8 * ((T + 63) // 64)] = bytes(8 * ((T + 63) // 64)); cases.append(bad)
+                bad = bytearray(blob); bad[o_live + 4: o_live + 8] = bad[o_live: o_live + 4]; cases.append(bad)
+                used = int.from_bytes(blob[o_used: o_used + 8], "little"); free = next(k for k in range(T) if not (used >> k) & 1)
+                bad = bytearray(blob); bad[o_used: o_used + 8] = (used | (1 << free)).to_bytes(8, "little"); cases.append(bad)
+                rec_bytes = int(np.frombuffer(blob[:24], np.uint32)[4]); nt = _meta(blob)[2]["nt"]
+                o_slot_of = o_used + 8 * ((T + 63) // 64) + T * rec_bytes + 16 * nt
+                sl0 = int.from_bytes(blob[o_live: o_live + 4], "little")
+                k = next(i for i in range(nt) if int.from_bytes(blob[o_slot_of + 4 * i: o_slot_of + 4 * i + 4], "little", signed=True) == sl0)
+                bad = bytearray(blob); bad[o_slot_of + 4 * k: o_slot_of + 4 * k + 4] = (-1).to_bytes(4, "little", signed=True); cases.append(bad)
+                for bad in cases:
+                    with pytest.raises(mot.MotError) as e:
+                        b.stream_load(2, bytes(bad))
+                    assert e.value.code == mot.MOT_E_ARG and "disagree" in str(e.value)
                 with pytest.raises(mot.MotError) as e:
                     small.stream_load(0, blob)          # another track-slot count
                 assert e.value.code == mot.MOT_E_ARG

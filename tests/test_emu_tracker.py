@@ -133,3 +133,23 @@ class _ModeCtx:
 
     def Context(self, *a, **kw):
         c = self._mot.Context(*a, **kw); c.set_tracker_mode(self._mode); return c
+
+
+def test_sum_order_knob():
+    """-DMOT_TRACK_SEQ_SUMS=1 (mot_wave.h) puts the sums over the sigma points back into the reference's order (ukf.cpp:736-749: explicit
+    loops, i = 0..14); the product adds the same terms as a tree over the DPP row. On the golden fixtures (the reference build's own values)
+    both stay far inside the bar — and the sequential build is the closer one, which is what makes the knob useful: a parity difference that
+    survives it is not reordering noise."""
+    import subprocess
+    probe = os.path.join(os.path.dirname(os.path.abspath(__file__)), "sum_order_probe.py")
+    res = {}
+    for tag, defs in (("tree", ""), ("seq", "-DMOT_TRACK_SEQ_SUMS=1")):
+        env = dict(os.environ, MOT_EMU_DEFINES=defs)
+        r = subprocess.run([sys.executable, probe], capture_output=True, text=True, env=env, timeout=1500)
+        assert r.returncode == 0, r.stderr[-2000:]
+        res[tag] = {ln.split()[0]: float(ln.split()[1]) for ln in r.stdout.splitlines() if ln.strip()}
+    print(res)
+    assert set(res["tree"]) == set(res["seq"]) and res["tree"]
+    for name in res["tree"]:
+        assert res["tree"][name] <= 1e-6 and res["seq"][name] <= 1e-6, res
+    assert sum(res["seq"].values()) <= sum(res["tree"].values()), res

@@ -1,0 +1,363 @@
+// frame_team_probe.hip — STAGE 1 of "stop reading the cloud twice" (VERDICT round 4, item 1). EXPERIMENT TOOL, not product code.
+//
+// Question: the ground stage reads every input cloud twice (polar_minz_kernel, then classify_compact_kernel: the classification
+// needs the frame's complete polar grid) — 0.98 of the 3.82 GB a 512-frame launch sequence moves. Can a PERSISTENT kernel whose
+// workgroup TEAMS hold a whole frame's {polar cell, z} in registers (6 bytes per point) between the two phases, and then re-load
+// only the points that turned out elevated, beat min-z + filter + compaction (546 us per 512 frames of 120 k points)?
+//
+// The probe is the real data flow, minus the filter's arithmetic:
+//   A  a team of W workgroups (1024 threads, P points per thread) loads a frame with coalesced 16-byte loads, computes every
+//      point's polar cell with the product's guarded fast path (mot_internal.h), keeps {cell:16, z:32} in registers, and folds the
+//      per-cell minimum of z: segmented min over the DPP row, one LDS atomicMin per run and row, one LDS grid per workgroup;
+//      the W grids leave with write-through stores
+//   B  team rendezvous (one returning device-scope atomic per workgroup); the LAST workgroup to arrive merges the W grids and
+//      stands in for polar_filter_kernel: it waits `filter_us` (the filter's dependent passes: 18 us alone on the chip) and
+//      publishes the frame's thresholds — precomputed by the product for this probe — to the team
+//   C  every workgroup classifies its points from registers against the thresholds (LDS), ballots / tile counts / workgroup scan,
+//      exchange of the W totals, then RE-LOADS the elevated points only (predicated per lane: the memory system fetches only the
+//      lines that hold one) and writes the elevated cloud in input order + each point's Cartesian cell (2 B), and files the
+//      occupancy bit-planes of the cluster stage — everything classify_compact_elevated_kernel produces
+// so its elevated clouds can be compared bit for bit with the product's (tools/probes/frame_team_probe.py does).
+//
+// Build:  hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared -ffp-contract=off -I 3d-lidar-multi-object-tracking_amd/csrc
+//             tools/probes/frame_team_probe.hip -o variants/libframe_team_probe.so        (tools/probes/build_probes.py)
+#include <string.h>
+
+#include "mot_internal.h"
+#include "mot_wave.h"
+
+namespace {
+
+#ifndef PROBE_BATCH
+#define PROBE_BATCH 8
+#endif
+constexpr int kBatch = PROBE_BATCH;   // loads in flight per thread
+constexpr long long kWatchdogTicks = 20 * 1000 * 100;   // 20 ms of the 100 MHz clock: a team that never completes gives up (sync[2] != 0) instead of hanging the box
+
+struct TeamArgs {
+  const float4* in; long in_stride; const int* n; int frames;
+  const float* hg_in;              // [frames][9600] the product's thresholds (stand-in for the filter's result)
+  float4* out_e; long cap; int* counts;   // [frames][2] elevated, ground
+  unsigned short* ecell;           // [frames][cap]
+  unsigned* occ;                   // [frames][W][2][kPlaneWords] the workgroups' occupancy planes (the product would write lists)
+  int* team_minz;                  // [teams][W][9600] per-workgroup min-z grids (ordered keys)
+  float* team_hg;                  // [teams][9600]
+  int* merged_minz;                // [frames][9600] the merged grid (what the filter would start from) — written for verification
+  unsigned* sync;                  // [teams][32]: [0] arrivals, [1] thresholds ready (frame round), [8 + w] total of workgroup w, tagged
+  int* ticket;                     // [1]
+  int W;                           // workgroups per team
+  int teams;
+  int filter_ticks;                // stand-in delay, 100 MHz ticks
+  int reload;                      // 1: re-load only elevated points (the design); 0: re-load every point (upper bound of the second read)
+};
+
+__device__ __forceinline__ int ld_sc(const int* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ unsigned ld_sc(const unsigned* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void st_sc(int* p, int v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void st_sc(unsigned* p, unsigned v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+
+typedef float v4f_t __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ float4 load_stream(const float4* p) {
+  v4f_t q = __builtin_nontemporal_load((const v4f_t*)p);
+  return make_float4(q.x, q.y, q.z, q.w);
+}
+
+// kTB threads per workgroup, P points held per thread: 1024 x 40 (128 VGPRs) or 512 x 80 (256 VGPRs) — either way ONE workgroup owns a
+// CU's whole register file and three of them hold a 120 k-point frame
+template <int kTB, int P>
+__global__ void __launch_bounds__(kTB) frame_team_kernel(MotDevParams p, TeamArgs a) {
+  static_assert(P % kBatch == 0, "points per thread in batches");
+  constexpr int kWaves = kTB / 64;
+  constexpr int kTiles = P * kWaves;           // 64-point tiles per workgroup
+  __shared__ int s_grid[MOT_POLAR_CELLS];      // min-z keys of my points, later the frame's thresholds (as float bits)
+  __shared__ int s_cnt[kTiles];                // elevated points per tile -> exclusive prefix
+  __shared__ unsigned long long s_be[kTiles];  // the tile's elevated lanes
+  __shared__ unsigned s_occ_a[kPlaneWords], s_occ_b[kPlaneWords];
+  __shared__ int s_misc[8];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  if (tid == 0) {
+    const int t = atomicAdd(a.ticket, 1);      // arrival order: the members of a team are consecutive tickets, so a team is complete
+    if (t == (int)gridDim.x - 1) *a.ticket = 0;  // as soon as its last member runs, whatever else occupies the chip
+    s_misc[0] = t;
+  }
+  __syncthreads();
+  const int team = s_misc[0] / a.W, rank = s_misc[0] % a.W;
+  if (team >= a.teams) return;
+  unsigned* sync = a.sync + team * 32;
+  int* my_minz = a.team_minz + ((long)team * a.W + rank) * MOT_POLAR_CELLS;
+  float* team_hg = a.team_hg + (long)team * MOT_POLAR_CELLS;
+  const unsigned long long below = (1ull << lane) - 1ull;
+
+  unsigned round = 0;
+  for (int f = team; f < a.frames; f += a.teams) {
+    round++;
+    const int n = a.n[f];
+    const float4* __restrict__ in = a.in + (long)f * a.in_stride;
+    const long wg_base = (long)rank * kTiles * 64;
+    const long rem = (long)n - wg_base;   // points of the frame from my first one on
+    // ---------------------------------------------------------------- A: load, cells, hold, fold
+    for (int i = tid; i < MOT_POLAR_CELLS; i += kTB) s_grid[i] = kMinzInit;
+    for (int i = tid; i < kPlaneWords; i += kTB) { s_occ_a[i] = 0u; s_occ_b[i] = 0u; }
+    if (tid == 0) s_misc[4] = 0;
+    __syncthreads();
+    float zz[P];
+    unsigned cc[P / 2];   // two 16-bit cells per register (0xffff: none)
+    unsigned undec[(P + 31) / 32];   // points the guarded fast path could not decide (4e-4 of them): resolved by ONE copy of the exact evaluation below
+#pragma unroll
+    for (int w = 0; w < (P + 31) / 32; w++) undec[w] = 0u;
+#pragma unroll
+    for (int kb = 0; kb < P; kb += kBatch) {
+      float4 pt[kBatch];
+#pragma unroll
+      for (int j = 0; j < kBatch; j++) {   // point (kb + j) * kTB + tid of my workgroup's run: a UNIFORM tile pointer + the thread's 32-bit offset
+        const float4* tp = in + wg_base + (long)(kb + j) * kTB;   // (a 64-bit address per load, hoisted out of the frame loop, would cost 2 P registers)
+        pt[j] = (long)tid < rem - (long)(kb + j) * kTB ? tp[(unsigned)tid] : make_float4(0.f, 0.f, 0.f, 0.f);
+      }
+#pragma unroll
+      for (int j = 0; j < kBatch; j++) {
+        const int k = kb + j;
+        const int c = mot_polar_cell_try(p, pt[j].x, pt[j].y);   // -2: undecided — a cell of its own for the fold below
+        if (c == -2) undec[k / 32] |= 1u << (k & 31);
+        const float z = pt[j].z;
+        zz[k] = z;
+        const unsigned c16 = (unsigned)c & 0xffffu;
+        if ((k & 1) == 0) cc[k / 2] = c16; else cc[k / 2] |= c16 << 16;
+        // per-cell minimum: segmented min-scan over the 16-lane row (a cell's points are consecutive returns of one beam), then the
+        // last lane of every run hands the run's minimum to the LDS grid
+        int zk = (z == z) ? mot_float_key(z + 0.0f) : 0x7fffffff;
+#define SEG_STEP(ctrl)                                                                                   \
+        {                                                                                                \
+          const int co = __builtin_amdgcn_update_dpp(-3, c, (ctrl), 0xf, 0xf, false);                     \
+          const int zo = __builtin_amdgcn_update_dpp(0x7fffffff, zk, (ctrl), 0xf, 0xf, false);            \
+          zk = (co == c && zo < zk) ? zo : zk;                                                           \
+        }
+        SEG_STEP(0x111) SEG_STEP(0x112) SEG_STEP(0x114) SEG_STEP(0x118)
+#undef SEG_STEP
+        const int nx = __builtin_amdgcn_update_dpp(-3, c, 0x101 /* row_shl:1 */, 0xf, 0xf, false);
+        if (c >= 0 && nx != c) atomicMin(&s_grid[c], zk);
+      }
+    }
+    {  // the undecided points, one at a time (a loop, NOT unrolled: one copy of the exact evaluation in the kernel)
+      unsigned any = 0;
+#pragma unroll
+      for (int w = 0; w < (P + 31) / 32; w++) any |= undec[w];
+      if (__ballot(any != 0)) {
+#pragma unroll 1
+        for (int w = 0; w < (P + 31) / 32; w++) {
+          unsigned m = 0;
+#pragma unroll
+          for (int ww = 0; ww < (P + 31) / 32; ww++) m = ww == w ? undec[ww] : m;
+#pragma unroll 1
+          while (m) {
+            const int k = w * 32 + __ffs(m) - 1;
+            m &= m - 1;
+            const float4 q = in[wg_base + (long)k * kTB + tid];
+            const int r = mot_polar_cell_exact(p, q.x, q.y);
+            const unsigned c16 = (unsigned)r & 0xffffu;
+#pragma unroll
+            for (int h = 0; h < P / 2; h++) {
+              if (h == k / 2) cc[h] = (k & 1) ? (cc[h] & 0xffffu) | (c16 << 16) : (cc[h] & 0xffff0000u) | c16;
+            }
+            if (r >= 0 && q.z == q.z) atomicMin(&s_grid[r], mot_float_key(q.z + 0.0f));
+          }
+        }
+      }
+    }
+    __syncthreads();
+    for (int i = tid; i < MOT_POLAR_CELLS; i += kTB) st_sc(&my_minz[i], s_grid[i]);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");   // my write-through stores have been acknowledged ...
+    __syncthreads();                                          // ... and everybody's
+    // ---------------------------------------------------------------- B: rendezvous; the last to arrive is the frame's filter
+    if (tid == 0) s_misc[1] = (int)__hip_atomic_fetch_add(&sync[0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __syncthreads();
+    const bool filter = (unsigned)s_misc[1] == round * (unsigned)a.W - 1u;
+    if (filter) {
+      const long long t0 = wall_clock64();
+      for (int i = tid; i < MOT_POLAR_CELLS; i += kTB) {
+        int m = kMinzInit;
+        for (int w = 0; w < a.W; w++) { const int v = ld_sc(&a.team_minz[((long)team * a.W + w) * MOT_POLAR_CELLS + i]); m = v < m ? v : m; }
+        a.merged_minz[(long)f * MOT_POLAR_CELLS + i] = m;
+      }
+      while (wall_clock64() - t0 < a.filter_ticks) __builtin_amdgcn_s_sleep(8);   // polar_filter_kernel's dependent passes
+      for (int i = tid; i < MOT_POLAR_CELLS; i += kTB) {
+        const int h = __float_as_int(a.hg_in[(long)f * MOT_POLAR_CELLS + i]);
+        s_grid[i] = h;
+        st_sc(reinterpret_cast<int*>(&team_hg[i]), h);
+      }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+      __syncthreads();
+      if (tid == 0) st_sc(&sync[1], round);
+    } else {
+      if (tid == 0) { const long long w0 = wall_clock64(); while (ld_sc(&sync[1]) < round) { __builtin_amdgcn_s_sleep(4); if (wall_clock64() - w0 > kWatchdogTicks) { st_sc(&sync[2], 1u); break; } } }
+      __syncthreads();
+      for (int i = tid; i < MOT_POLAR_CELLS; i += kTB) s_grid[i] = ld_sc(reinterpret_cast<const int*>(&team_hg[i]));
+      __syncthreads();
+    }
+    // ---------------------------------------------------------------- C: classify from registers, positions, re-load, write
+    unsigned ebits[(P + 31) / 32];   // bit k: my k-th point is elevated
+#pragma unroll
+    for (int w = 0; w < (P + 31) / 32; w++) ebits[w] = 0u;
+    int n_ground = 0;
+#pragma unroll
+    for (int k = 0; k < P; k++) {
+      const unsigned c16 = (k & 1) ? cc[k / 2] >> 16 : cc[k / 2] & 0xffffu;
+      const bool in_grid = c16 < (unsigned)MOT_POLAR_CELLS;   // (0xffff: none; 0xfffe cannot remain)
+      const float hgv = __int_as_float(s_grid[in_grid ? c16 : 0]);
+      const bool ground = in_grid && ((double)zz[k] < (double)hgv + p.ground_margin);
+      const bool e = in_grid && !ground;
+      if (e) ebits[k / 32] |= 1u << (k & 31);
+      const unsigned long long be = __ballot(e);
+      n_ground += __popcll(__ballot(ground));
+      if (lane == 0) { s_cnt[k * kWaves + wave] = __popcll(be); s_be[k * kWaves + wave] = be; }
+      if ((k & 3) == 3) __builtin_amdgcn_sched_barrier(0);   // four threshold gathers in flight, not P
+    }
+    __syncthreads();
+    if (wave == 0) {
+      constexpr int kPer = (kTiles + 63) / 64;
+      int c[kPer], cnt = 0;
+#pragma unroll
+      for (int j = 0; j < kPer; j++) { const int t = lane * kPer + j; c[j] = t < kTiles ? s_cnt[t] : 0; cnt += c[j]; }
+      const int incl = wave_scan_incl_i32(cnt);
+      int run = incl - cnt;
+#pragma unroll
+      for (int j = 0; j < kPer; j++) { const int t = lane * kPer + j; if (t < kTiles) s_cnt[t] = run; run += c[j]; }
+      const int tot = wave_bcast_i32(incl, 63);
+      if (lane == 0) {
+        st_sc(&sync[8 + rank], (round << 20) | (unsigned)tot);     // a workgroup holds < 2^20 points
+        int base = 0;
+        const long long w0 = wall_clock64();
+        for (int w = 0; w < rank; w++) {
+          unsigned v;
+          while (((v = ld_sc(&sync[8 + w])) >> 20) != (round & 0xfffu)) { __builtin_amdgcn_s_sleep(2); if (wall_clock64() - w0 > kWatchdogTicks) { st_sc(&sync[2], 2u); break; } }
+          base += (int)(v & 0xfffffu);
+        }
+        s_misc[2] = base;
+        if (rank == a.W - 1) a.counts[2 * f] = base + tot;
+      }
+    }
+    if (lane == 0 && n_ground) atomicAdd(&s_misc[4], n_ground);   // (n_ground is wave-uniform: sums of ballots)
+    __syncthreads();
+    if (tid == 0 && s_misc[4]) atomicAdd(&a.counts[2 * f + 1], s_misc[4]);   // one device atomic per workgroup and frame
+    const int base_e = s_misc[2];
+    float4* __restrict__ out_e = a.out_e + (long)f * a.cap;
+    unsigned short* __restrict__ ecell = a.ecell + (long)f * a.cap;
+#pragma unroll
+    for (int w = 0; w < (P + 31) / 32; w++) undec[w] = 0u;
+#pragma unroll
+    for (int kb = 0; kb < P; kb += kBatch) {
+      float4 pt[kBatch];
+#pragma unroll
+      for (int j = 0; j < kBatch; j++) {
+        const int k = kb + j;
+        const bool e = (ebits[k / 32] >> (k & 31)) & 1u;
+        const float4* tp = in + wg_base + (long)k * kTB;
+        pt[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (a.reload ? e : ((long)tid < rem - (long)k * kTB)) pt[j] = load_stream(&tp[(unsigned)tid]);
+      }
+#pragma unroll
+      for (int j = 0; j < kBatch; j++) {
+        const int k = kb + j;
+        const unsigned long long be = s_be[k * kWaves + wave];   // (wave-uniform LDS read instead of a second ballot)
+        if (be == 0ull) continue;   // no elevated point among these 64
+        const bool e = (ebits[k / 32] >> (k & 31)) & 1u;
+        const int at = base_e + s_cnt[k * kWaves + wave] + __popcll(be & below);
+        const int bit = e ? mot_cart_bit_try(p, pt[j].x, pt[j].y) : -1;   // -2: undecided, resolved below
+        if (bit == -2) undec[k / 32] |= 1u << (k & 31);
+        if (e) { out_e[at] = pt[j]; ecell[at] = (unsigned short)bit; }
+        const int prev = row_prev_i32(bit, -3), next = row_next_i32(bit, -3);
+        if (bit >= 0 && prev != bit) {
+          const unsigned m = 1u << (bit & 31);
+          const unsigned old = atomicOr(&s_occ_a[bit >> 5], m);
+          if ((old & m) || next == bit) atomicOr(&s_occ_b[bit >> 5], m);
+        }
+      }
+    }
+    {  // elevated points whose Cartesian cell the fast path left open: the exact evaluation, once in the kernel
+      unsigned any = 0;
+#pragma unroll
+      for (int w = 0; w < (P + 31) / 32; w++) any |= undec[w];
+      if (__ballot(any != 0)) {
+#pragma unroll 1
+        for (int w = 0; w < (P + 31) / 32; w++) {
+          unsigned m = 0;
+#pragma unroll
+          for (int ww = 0; ww < (P + 31) / 32; ww++) m = ww == w ? undec[ww] : m;
+#pragma unroll 1
+          while (m) {
+            const int k = w * 32 + __ffs(m) - 1;
+            m &= m - 1;
+            const float4 q = in[wg_base + (long)k * kTB + tid];
+            int xI, yI;
+            const int bit = mot_cart_cell(p, q.x, q.y, &xI, &yI) ? xI * MOT_MAX_GRID + yI : -1;
+            const int at = base_e + s_cnt[k * kWaves + wave] + __popcll(s_be[k * kWaves + wave] & below);
+            ecell[at] = (unsigned short)bit;
+            if (bit >= 0) {
+              const unsigned mm = 1u << (bit & 31);
+              const unsigned old = atomicOr(&s_occ_a[bit >> 5], mm);
+              if (old & mm) atomicOr(&s_occ_b[bit >> 5], mm);
+            }
+          }
+        }
+      }
+    }
+    __syncthreads();
+    unsigned* occ = a.occ + ((long)f * a.W + rank) * 2 * kPlaneWords;
+    for (int i = tid; i < kPlaneWords; i += kTB) { occ[i] = s_occ_a[i]; occ[kPlaneWords + i] = s_occ_b[i]; }
+  }
+}
+
+}  // namespace
+
+extern "C" int team_probe_params(MotDevParams* out) {
+  // object_tracking's preset, the fields the probe's device functions read (mot_api.hip make_dev_params)
+  MotDevParams d;
+  memset(&d, 0, sizeof d);
+  d.r_min = 3.4f; d.r_max = 120.f; d.r_span = d.r_max - d.r_min; d.k_bin = (float)MOT_NUM_BIN / d.r_span;
+  d.ground_margin = 0.25;
+  d.num_grid = 250; d.roi_m = 50.f; d.roi_half = d.roi_m / 2; d.k_grid = (float)d.num_grid / d.roi_m;
+  *out = d;
+  return 0;
+}
+
+// returns 0; ms = mean time of one launch over `iters` launches (after one untimed launch)
+extern "C" int team_probe_run(const void* d_in, long in_stride, const int* d_n, int frames, const float* d_hg, void* d_out_e, long cap, int* d_counts,
+                              void* d_ecell, unsigned* d_occ, int* d_team_minz, float* d_team_hg, int* d_merged_minz, unsigned* d_sync, int* d_ticket,
+                              int W, int grid_wgs, int tb, int pts, float filter_us, int reload, int iters, const MotDevParams* params, void* stream, float* ms, int* resident_out) {
+  MotDevParams p = *params;
+  TeamArgs a;
+  a.in = (const float4*)d_in; a.in_stride = in_stride; a.n = d_n; a.frames = frames; a.hg_in = d_hg; a.out_e = (float4*)d_out_e; a.cap = cap; a.counts = d_counts;
+  a.ecell = (unsigned short*)d_ecell; a.occ = d_occ; a.team_minz = d_team_minz; a.team_hg = d_team_hg; a.merged_minz = d_merged_minz; a.sync = d_sync; a.ticket = d_ticket;
+  a.W = W; a.filter_ticks = (int)(filter_us * 100.f); a.reload = reload;
+  {  // every workgroup of the grid must be RESIDENT at the same time (the members of a team wait for each other): clamp the grid to what fits
+    int per_cu = 0, cus = 0;
+    hipError_t e = hipErrorInvalidValue;
+#define PROBE_OCC(TB, PP) if (tb == TB && pts == PP) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, frame_team_kernel<TB, PP>, TB, 0);
+    PROBE_OCC(1024, 40) PROBE_OCC(1024, 32) PROBE_OCC(1024, 24) PROBE_OCC(1024, 16) PROBE_OCC(512, 80) PROBE_OCC(512, 64) PROBE_OCC(512, 48)
+#undef PROBE_OCC
+    if (e != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, 0) != hipSuccess || per_cu < 1) return 6;
+    if (grid_wgs > per_cu * cus) grid_wgs = per_cu * cus;
+    if (resident_out) *resident_out = per_cu * cus;
+  }
+  a.teams = grid_wgs / W;
+  hipStream_t s = (hipStream_t)stream;
+  hipEvent_t e0, e1;
+  if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) return 2;
+  auto launch = [&]() {
+    (void)hipMemsetAsync(d_sync, 0, (size_t)a.teams * 32 * sizeof(unsigned), s);
+#define PROBE_CASE(TB, PP) if (tb == TB && pts == PP) { hipLaunchKernelGGL((frame_team_kernel<TB, PP>), dim3(a.teams * W), dim3(TB), 0, s, p, a); return; }
+    PROBE_CASE(1024, 40) PROBE_CASE(1024, 32) PROBE_CASE(1024, 24) PROBE_CASE(1024, 16)
+    PROBE_CASE(512, 80) PROBE_CASE(512, 64) PROBE_CASE(512, 48)
+#undef PROBE_CASE
+  };
+  launch();
+  if (hipStreamSynchronize(s) != hipSuccess) return 3;
+  (void)hipEventRecord(e0, s);
+  for (int i = 0; i < iters; i++) launch();
+  (void)hipEventRecord(e1, s);
+  if (hipEventSynchronize(e1) != hipSuccess) return 4;
+  float t = 0;
+  (void)hipEventElapsedTime(&t, e0, e1);
+  *ms = t / (iters > 0 ? iters : 1);
+  (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+  return hipGetLastError() == hipSuccess ? 0 : 5;
+}
