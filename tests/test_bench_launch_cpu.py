@@ -65,7 +65,8 @@ def test_bench_parity_check_logic_on_the_emulator():
     assert base["value"] > 0 and par["frames"] == F
     assert par["masks_boxes_bit_exact"] and par["track_sets_equal"] and par["boxes_total"] > 0 and par["first_mismatch_frame"] is None, par
     assert par["max_rel_state_err"] is not None and par["max_rel_state_err"] <= 1e-4
-    assert par["states_within_1e-4"] and par["track_frames_above_1e-4"] == 0 and par["track_frames_above_1e-4_unexplained"] == 0
+    assert par["states_within_1e-4"] and par["states_within_bar"] and not par["states_explained_by_reference_noise"]
+    assert par["track_frames_above_1e-4"] == 0 and par["track_frames_above_1e-4_unexplained"] == 0
     assert {"restatement", "novec"} <= set(par["noise_floor_replicas"]["in_use_last_frame"]) and par["min_area_rect_cross_check"]["failed"] == 0
     # a state off by 1e-3 on a perfectly conditioned track: above the bar, NOT explained by the reference's own noise -> the flag must fall
     import copy
@@ -73,7 +74,7 @@ def test_bench_parity_check_logic_on_the_emulator():
     i = sorted(res_bad[5]["states"])[0]
     res_bad[5]["states"][i]["x_merge"] = res_bad[5]["states"][i]["x_merge"] * (1 + 1e-3)
     _, par3 = bench.cpu_baseline(host[:, 0, :N], ego_v, ego_yaw, N, budget_s=2.0, gpu_results=res_bad, n_per_frame=n_seq[:, 0], lib=mot.load_library(lib), quick=True)
-    assert not par3["states_within_1e-4"] and par3["track_frames_above_1e-4"] == 1 and par3["track_frames_above_1e-4_unexplained"] == 1, par3
+    assert not par3["states_within_1e-4"] and not par3["states_within_bar"] and par3["track_frames_above_1e-4"] == 1 and par3["track_frames_above_1e-4_unexplained"] == 1, par3
     res[3]["boxes"] = res[3]["boxes"] + np.float32(1e-3)   # a corrupted GPU result must show up, with its frame
     _, par2 = bench.cpu_baseline(host[:, 0, :N], ego_v, ego_yaw, N, budget_s=2.0, gpu_results=res, n_per_frame=n_seq[:, 0], lib=mot.load_library(lib), quick=True)
     assert not par2["boxes_bit_exact"] and not par2["masks_boxes_bit_exact"] and par2["first_mismatch_frame"]["boxes_bit_exact"] == 3

@@ -36,3 +36,6 @@ def test_long_run_on_bounded_track_slots_emulated(mot, oracle):
     import tracker_cases as TC
     st = TC.long_run_bounded_slots(mot, oracle, lib_path=build_emu.build(), frames=700, slots=16, spots=9)
     assert st["tracks_ever"] >= 64
+    if "reference_builds_stepped" in st:   # the head of the run also met the reference's own builds (narrow criterion + their noise floor)
+        print(st["reference_builds_stepped"], st.get("reference_frames"), st.get("reference_builds_retired_at"), st.get("head_vs_reference_builds"))
+        assert st.get("reference_frames", 0) >= 40 and st["head_vs_reference_builds"]["state_compares"] > 50

@@ -225,6 +225,7 @@ def test_long_run_on_256_track_slots(mot, hip_lib, oracle):
     import tracker_cases as TC
     st = TC.long_run_bounded_slots(mot, oracle, frames=10000, slots=256, spots=40, state_every=50, min_ever_factor=8, max_chaos_restarts=40)
     assert st["tracks_ever"] >= 2048 and st["max_rel_state_err"] <= 1e-2 and st["frames_compared"] >= 9900
+    _report_head(st)
 
 
 def test_long_run_on_few_slots(mot, hip_lib, oracle):
@@ -232,3 +233,14 @@ def test_long_run_on_few_slots(mot, hip_lib, oracle):
     import tracker_cases as TC
     st = TC.long_run_bounded_slots(mot, oracle, frames=2500, slots=24, spots=14, state_every=25, min_ever_factor=8, max_chaos_restarts=6)
     assert st["tracks_ever"] >= 192 and st["frames_compared"] >= 2450
+    _report_head(st)
+
+
+def _report_head(st):
+    """the head of a long run against the reference's OWN builds (tracker_cases.long_run_bounded_slots: ref_frames): stepped as long as their
+    discrete outputs equal the restatement's; the device's states on those frames under the narrow criterion + the builds' noise floor"""
+    if "reference_builds_stepped" not in st:
+        return
+    print("long run, head vs the reference builds:", st["reference_builds_stepped"], "frames", st.get("reference_frames"), "retired at",
+          st.get("reference_builds_retired_at"), st.get("head_vs_reference_builds"))
+    assert st.get("reference_frames", 0) >= 40 and st["head_vs_reference_builds"]["state_compares"] > 50

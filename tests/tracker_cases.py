@@ -136,7 +136,8 @@ def blinking_world(seed, spots, frames):
         yield np.array(boxes, np.float32).reshape(-1, 8, 3), 1.0e9 + f * 1.0e5, 1.0 + 0.5 * np.sin(0.01 * f), 0.0005 * f
 
 
-def long_run_bounded_slots(mot, oracle, lib_path=None, frames=1500, slots=16, spots=10, seed=3, state_every=25, min_ever_factor=4, max_chaos_restarts=0):
+def long_run_bounded_slots(mot, oracle, lib_path=None, frames=1500, slots=16, spots=10, seed=3, state_every=25, min_ever_factor=4, max_chaos_restarts=0,
+                           ref_frames=500):
     """SURVEY.md H14 / the reference never frees a track: a long run on `slots` track slots must give what the oracle gives with
     unbounded memory — every frame the discrete outputs of EVERY track ever created (reference index order), every `state_every`
     frames the filter states of the live ones — while far more tracks are created than there are slots.
@@ -163,6 +164,16 @@ def long_run_bounded_slots(mot, oracle, lib_path=None, frames=1500, slots=16, sp
     stats = {"chaos_restarts": 0, "frames_compared": 0}
     taint = {}
     ever_total = 0
+    # THE REFERENCE'S OWN BUILD for the head of the run (round-4 review: these runs never met the reference's code on the GPU box): for the
+    # first `ref_frames` frames — while the tracks ever created are few and its O(tracks ever) step is cheap — oracle/_ref/libmot_ref.so
+    # (and its -DEIGEN_DONT_VECTORIZE rebuild) are stepped beside the restatement. Their DISCRETE outputs must equal the restatement's (a
+    # replica that parts from it is chaos reaching a gate decision: it is retired and the frame recorded), and their state differences are
+    # the noise floor the device's states are held against under the NARROW criterion on those frames (assert: every live track-frame
+    # within 1e-4, or set aside and within 10 x the reference's own noise there). Beyond ref_frames: the wide criterion at 1e-2, see below.
+    floor = None
+    if ref_frames and getattr(oracle, "ref", lambda: None)() is not None:
+        floor = SP.NoiseFloor(oracle, p, primary_is_ref=False, instance=3, kinds=("ref", "novec"))
+        stats["reference_builds_stepped"] = floor.names()
     with mot.Context(max_points=1024, max_tracks_total=slots, **kw) as c:
         T = oracle.Tracker(p)
         o = None
@@ -170,6 +181,12 @@ def long_run_bounded_slots(mot, oracle, lib_path=None, frames=1500, slots=16, sp
             assert np.allclose(c.ego_update(ts, v, yaw), T.ego_update(ts, v, yaw), rtol=1e-12, atol=1e-12)
             a = c.track_step(boxes, ts); o_prev = o; o = T.step(boxes, ts, max_tracks=1 << 16)
             assert not a["capacity_exceeded"], f
+            if floor is not None:
+                if f < ref_frames and floor.reps:
+                    floor.step(boxes, ts, v, yaw, o, f)
+                    stats["reference_frames"] = f + 1
+                else:
+                    stats["reference_builds_retired_at"] = dict(floor.retired); floor.close(); floor = None
             equal = a["n"] == o["n"] and all(np.array_equal(a[k], o[k]) for k in ("track_manage", "is_static", "is_vis", "lifetime"))
             if not equal:
                 chaotic = any(until >= f - 1 for until in taint.values())
@@ -196,12 +213,21 @@ def long_run_bounded_slots(mot, oracle, lib_path=None, frames=1500, slots=16, sp
                 # of 11.3 / 10.4 (rad)^2 — a filter that is alive by every test of the reference and a random walk in yaw — by 1.7e-2 in
                 # p_merge. The counts per criterion are in stats["set_aside_by"].
                 SP.compare_tracks(a, o, c.track_state, T.state, f, rtol=1e-2, stats=stats, skip_ill_conditioned=True, taint=taint, frame=f, criterion="wide")
+            if floor is not None and floor.reps and (f % 5 == 0):   # the head of the run, against the reference's own builds: narrow criterion + noise floor
+                head = stats.setdefault("head", {})
+                SP.compare_tracks(a, o, c.track_state, T.state, f, rtol=float("inf"), stats=head, criterion="narrow", floor=floor.floor, assert_floor=True)
+                assert head.get("above_bar_well_conditioned", 0) == 0, (f, head)
                 for i in np.nonzero(dead)[0][-64:]:
                     if SP.well_conditioned(T.state(int(i)), "wide") and taint.get(int(i), -1) < 0:
                         assert np.allclose(a["p"][i][:2], o["p"][i][:2], rtol=1e-2, atol=1e-4), (f, int(i), "position of a dead track")
             stats["live_peak"] = max(stats.get("live_peak", 0), int(live.sum()))
         ever_total += o["n"] if o is not None else 0
         T.close()
+        if floor is not None:
+            stats["reference_builds_retired_at"] = dict(floor.retired); floor.close()
+    if "head" in stats:
+        h = stats.pop("head")
+        stats["head_vs_reference_builds"] = {k: h.get(k) for k in ("state_compares", "max_rel_state_err", "above_bar", "ill_conditioned", "unexplained") if k in h}
     assert ever_total >= min_ever_factor * slots and stats["live_peak"] <= slots, (ever_total, stats)
     stats["tracks_ever"] = ever_total
     return stats

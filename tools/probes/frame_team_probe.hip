@@ -49,6 +49,7 @@ struct TeamArgs {
   int teams;
   int filter_ticks;                // stand-in delay, 100 MHz ticks
   int reload;                      // 1: re-load only elevated points (the design); 0: re-load every point (upper bound of the second read)
+  long long* stamps;               // [grid][8] ticks (100 MHz) a workgroup spent: 0 load+cells+fold, 1 grid out, 2 rendezvous+filter/wait, 3 thresholds in, 4 classify+scan+totals, 5 re-load+write, 6 occupancy out, 7 frames
 };
 
 __device__ __forceinline__ int ld_sc(const int* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
@@ -89,6 +90,9 @@ __global__ void __launch_bounds__(kTB) frame_team_kernel(MotDevParams p, TeamArg
   const unsigned long long below = (1ull << lane) - 1ull;
 
   unsigned round = 0;
+  long long tph[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#define PH(k) { const long long t_ = wall_clock64(); tph[k] += t_ - tlast; tlast = t_; }
+  long long tlast = wall_clock64();
   for (int f = team; f < a.frames; f += a.teams) {
     round++;
     const int n = a.n[f];
@@ -164,9 +168,11 @@ __global__ void __launch_bounds__(kTB) frame_team_kernel(MotDevParams p, TeamArg
       }
     }
     __syncthreads();
+    PH(0)
     for (int i = tid; i < MOT_POLAR_CELLS; i += kTB) st_sc(&my_minz[i], s_grid[i]);
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");   // my write-through stores have been acknowledged ...
     __syncthreads();                                          // ... and everybody's
+    PH(1)
     // ---------------------------------------------------------------- B: rendezvous; the last to arrive is the frame's filter
     if (tid == 0) s_misc[1] = (int)__hip_atomic_fetch_add(&sync[0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     __syncthreads();
@@ -187,12 +193,15 @@ __global__ void __launch_bounds__(kTB) frame_team_kernel(MotDevParams p, TeamArg
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
       __syncthreads();
       if (tid == 0) st_sc(&sync[1], round);
+      PH(2)
     } else {
       if (tid == 0) { const long long w0 = wall_clock64(); while (ld_sc(&sync[1]) < round) { __builtin_amdgcn_s_sleep(4); if (wall_clock64() - w0 > kWatchdogTicks) { st_sc(&sync[2], 1u); break; } } }
       __syncthreads();
+      PH(2)
       for (int i = tid; i < MOT_POLAR_CELLS; i += kTB) s_grid[i] = ld_sc(reinterpret_cast<const int*>(&team_hg[i]));
       __syncthreads();
     }
+    PH(3)
     // ---------------------------------------------------------------- C: classify from registers, positions, re-load, write
     unsigned ebits[(P + 31) / 32];   // bit k: my k-th point is elevated
 #pragma unroll
@@ -239,6 +248,7 @@ __global__ void __launch_bounds__(kTB) frame_team_kernel(MotDevParams p, TeamArg
     __syncthreads();
     if (tid == 0 && s_misc[4]) atomicAdd(&a.counts[2 * f + 1], s_misc[4]);   // one device atomic per workgroup and frame
     const int base_e = s_misc[2];
+    PH(4)
     float4* __restrict__ out_e = a.out_e + (long)f * a.cap;
     unsigned short* __restrict__ ecell = a.ecell + (long)f * a.cap;
 #pragma unroll
@@ -301,9 +311,14 @@ __global__ void __launch_bounds__(kTB) frame_team_kernel(MotDevParams p, TeamArg
       }
     }
     __syncthreads();
+    PH(5)
     unsigned* occ = a.occ + ((long)f * a.W + rank) * 2 * kPlaneWords;
     for (int i = tid; i < kPlaneWords; i += kTB) { occ[i] = s_occ_a[i]; occ[kPlaneWords + i] = s_occ_b[i]; }
+    PH(6)
+    tph[7] += 1;
   }
+  if (tid == 0 && a.stamps) for (int k = 0; k < 8; k++) a.stamps[(long)(team * a.W + rank) * 8 + k] = tph[k];
+#undef PH
 }
 
 }  // namespace
@@ -322,12 +337,12 @@ extern "C" int team_probe_params(MotDevParams* out) {
 // returns 0; ms = mean time of one launch over `iters` launches (after one untimed launch)
 extern "C" int team_probe_run(const void* d_in, long in_stride, const int* d_n, int frames, const float* d_hg, void* d_out_e, long cap, int* d_counts,
                               void* d_ecell, unsigned* d_occ, int* d_team_minz, float* d_team_hg, int* d_merged_minz, unsigned* d_sync, int* d_ticket,
-                              int W, int grid_wgs, int tb, int pts, float filter_us, int reload, int iters, const MotDevParams* params, void* stream, float* ms, int* resident_out) {
+                              int W, int grid_wgs, int tb, int pts, float filter_us, int reload, int iters, const MotDevParams* params, void* stream, float* ms, int* resident_out, long long* d_stamps) {
   MotDevParams p = *params;
   TeamArgs a;
   a.in = (const float4*)d_in; a.in_stride = in_stride; a.n = d_n; a.frames = frames; a.hg_in = d_hg; a.out_e = (float4*)d_out_e; a.cap = cap; a.counts = d_counts;
   a.ecell = (unsigned short*)d_ecell; a.occ = d_occ; a.team_minz = d_team_minz; a.team_hg = d_team_hg; a.merged_minz = d_merged_minz; a.sync = d_sync; a.ticket = d_ticket;
-  a.W = W; a.filter_ticks = (int)(filter_us * 100.f); a.reload = reload;
+  a.W = W; a.filter_ticks = (int)(filter_us * 100.f); a.reload = reload; a.stamps = d_stamps;
   {  // every workgroup of the grid must be RESIDENT at the same time (the members of a team wait for each other): clamp the grid to what fits
     int per_cu = 0, cus = 0;
     hipError_t e = hipErrorInvalidValue;

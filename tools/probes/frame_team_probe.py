@@ -68,7 +68,7 @@ def main():
         if b < a.verify:
             elev_ref[b] = g["elevated"]
     # ---------------------------------------------------------------- stage 0
-    ELEV = 1   # MOT_MASK_ELEVATED (include/mot.h)
+    ELEV = 2   # MOT_MASK_ELEVATED (include/mot.h)
     assert int((masks[0] == ELEV).sum()) == ne_ref[0], "mask code"
     res = {"frames": B, "points": N, "elevated_fraction": float(ne_ref.sum() / n.sum())}
     for line_pts in (4, 8, 16, 64):
@@ -100,7 +100,7 @@ def main():
     assert P.team_probe_params(C.byref(dp)) == 0
     P.team_probe_run.argtypes = [C.c_void_p, C.c_long, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_long, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                  C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_int, C.c_int, C.c_void_p, C.c_void_p,
-                                 C.POINTER(C.c_float), C.POINTER(C.c_int)]
+                                 C.POINTER(C.c_float), C.POINTER(C.c_int), C.c_void_p]
     d_n = torch.from_numpy(n).to(dev)
     d_hg = torch.from_numpy(hg).to(dev)
     out_e = torch.zeros((B, stride, 4), dtype=torch.float32, device=dev)
@@ -113,6 +113,7 @@ def main():
     merged = torch.zeros((B, 9600), dtype=torch.int32, device=dev)
     sync = torch.zeros((256, 32), dtype=torch.int32, device=dev)
     ticket = torch.zeros(4, dtype=torch.int32, device=dev)
+    stamps = torch.zeros((1024, 8), dtype=torch.int64, device=dev)
     torch.cuda.synchronize()
     rows = []
     for tb, pts in ((512, 48), (1024, 24), (1024, 16)):
@@ -122,7 +123,7 @@ def main():
             ms = C.c_float(0); resident = C.c_int(0)
             rc = P.team_probe_run(frames.data_ptr(), stride, d_n.data_ptr(), B, d_hg.data_ptr(), out_e.data_ptr(), stride, counts.data_ptr(), ecell.data_ptr(),
                                   occ.data_ptr(), team_minz.data_ptr(), team_hg.data_ptr(), merged.data_ptr(), sync.data_ptr(), ticket.data_ptr(), W, 4096, tb, pts,
-                                  C.c_float(filter_us), reload, a.iters, C.byref(dp), None, C.byref(ms), C.byref(resident))
+                                  C.c_float(filter_us), reload, a.iters, C.byref(dp), None, C.byref(ms), C.byref(resident), stamps.data_ptr())
             torch.cuda.synchronize()
             stuck = int((sync[:, 2] != 0).sum())
             cnt = counts.cpu().numpy()
@@ -134,9 +135,12 @@ def main():
                 for b in range(a.verify):
                     if not np.array_equal(oe[b, : ne_ref[b]].view(np.uint32), elev_ref[b].view(np.uint32)):
                         ok_cloud = False
+            st = stamps[: (min(resident.value, 4096) // W) * W].cpu().numpy().astype(np.float64)
+            per_frame = (st[:, :7] / np.maximum(st[:, 7:8], 1)).mean(0) / 100.0   # us per frame and workgroup, mean over the workgroups
             row = dict(block=tb, points_per_thread=pts, team_wgs=W, resident_wgs=resident.value, teams=min(resident.value, 4096) // W, filter_us=filter_us, reload_only_elevated=bool(reload),
                        us_per_launch=round(ms.value * 1e3, 1), rc=rc, teams_gave_up=stuck, counts_equal_product=ok_counts, clouds_equal_product=ok_cloud,
-                       vs_ground_stage=round(ms.value * 1e3 / base["ground_stage"], 3))
+                       vs_ground_stage=round(ms.value * 1e3 / base["ground_stage"], 3),
+                       us_per_frame_in_phases=dict(zip(("load_cells_fold", "grid_out", "rendezvous_filter", "thresholds_in", "classify_scan", "reload_write", "occupancy_out"), [round(float(x), 1) for x in per_frame])))
             rows.append(row)
             print("STAGE 1", json.dumps(row), flush=True)
     best = min((r for r in rows if r["reload_only_elevated"] and r["filter_us"] == 18.0 and r["counts_equal_product"] and r["teams_gave_up"] == 0), key=lambda r: r["us_per_launch"], default=None)
