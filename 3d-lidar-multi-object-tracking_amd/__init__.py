@@ -76,8 +76,9 @@ EXPORTS = (
     "mot_ground_remove_pointcloud2", "mot_box_fit_resident", "mot_frame_pointcloud2",
     "mot_reset_slot", "mot_stream_snapshot_size", "mot_stream_save", "mot_stream_load", "mot_frames_host", "mot_wait_uploads", "mot_host_alloc", "mot_host_free", "mot_fetch_tracks_async",
     "mot_track_steps_dev", "mot_profile_kernel", "mot_profile_read", "mot_get_params", "mot_set_fused_outputs", "mot_set_tracker_mode", "mot_set_trace_ranges", "mot_reset_tracks_slot", "mot_export_tracks_packed_dev", "mot_set_launch_graphs",
+    "mot_cluster_node_frame", "mot_ground_node_frame",
 )
-ABI_VERSION = 4
+ABI_VERSION = 5
 OUT_GROUND, OUT_MASK, OUT_LABELS = 1, 2, 4
 
 _libs: dict[str, C.CDLL] = {}
@@ -120,6 +121,13 @@ class MotSideParams(C.Structure):
     _fields_ = [("cell_size", C.c_float), ("cost_width", C.c_int32), ("cost_height", C.c_int32), ("cost_resolution", C.c_double),
                 ("cost_offset_x", C.c_double), ("cost_offset_y", C.c_double), ("height_limit", C.c_double),
                 ("car_length", C.c_double), ("car_width", C.c_double), ("cost_offset_z", C.c_double)]
+
+
+class MotClusterFrame(C.Structure):
+    """mirror of struct mot_cluster_frame (include/mot.h): counts + views into the context's page-locked block"""
+    _fields_ = [("num_cluster", C.c_int32), ("n_clustered", C.c_int32), ("n_obstacles", C.c_int32), ("n_boxes", C.c_int32), ("n_undefined", C.c_int32),
+                ("cost_cells", C.c_int32), ("clustered_xyzw", C.POINTER(C.c_float)), ("obstacles_xyzc", C.POINTER(C.c_float)), ("cost_map", C.POINTER(C.c_int32)),
+                ("boxes", C.POINTER(C.c_float)), ("box_cluster", C.POINTER(C.c_int32)), ("centroid_extent", C.POINTER(C.c_float))]
 
 
 def _pts(a) -> np.ndarray:
@@ -374,6 +382,28 @@ class Context:
         self._ck(self.lib.mot_cluster_products_host(self._h, _vp(a), n, _vp(grid), C.byref(sp), _vp(cc), max(n, 1), C.byref(ncc), _vp(ob), G * G,
                                                     C.byref(nob), _vp(cm)))
         return dict(clustered=cc[: ncc.value].copy(), obstacles=ob[: nob.value].copy(), cost_map=cm.reshape(sp.cost_height, sp.cost_width))
+
+    def cluster_node_frame(self, elev, sp: "MotSideParams | None" = None, copy: bool = True):
+        """the cluster node's whole callback in one call (mot_cluster_node_frame): labelling, side products, box fit, cubes"""
+        if sp is None:
+            sp = MotSideParams(); self._ck(self.lib.mot_side_params_default(C.byref(sp)))
+        a = _pts(elev); fr = MotClusterFrame()
+        self._ck(self.lib.mot_cluster_node_frame(self._h, _vp(a), len(a), C.byref(sp), C.byref(fr)))
+        view = lambda ptr, shape, dt: (np.ctypeslib.as_array(ptr, shape=shape).view(dt) if shape[0] else np.zeros(shape, dt))
+        out = dict(num_cluster=fr.num_cluster, n_undefined=fr.n_undefined,
+                   clustered=view(fr.clustered_xyzw, (fr.n_clustered, 4), np.float32), obstacles=view(fr.obstacles_xyzc, (fr.n_obstacles, 4), np.float32),
+                   cost_map=view(fr.cost_map, (fr.cost_cells,), np.int32).reshape(sp.cost_height, sp.cost_width),
+                   boxes=view(fr.boxes, (fr.n_boxes, 24), np.float32).reshape(-1, 8, 3), box_cluster=view(fr.box_cluster, (fr.n_boxes,), np.int32),
+                   cubes=view(fr.centroid_extent, (fr.n_boxes, 6), np.float32))
+        return {k: (v.copy() if copy and isinstance(v, np.ndarray) else v) for k, v in out.items()}
+
+    def ground_node_frame(self, cloud, copy: bool = True):
+        """mot_ground_node_frame: groundRemove with the two clouds as views into the context's page-locked block"""
+        a = _pts(cloud); pe, pg = C.POINTER(C.c_float)(), C.POINTER(C.c_float)(); ne, ng = C.c_int(0), C.c_int(0)
+        self._ck(self.lib.mot_ground_node_frame(self._h, _vp(a), len(a), C.byref(pe), C.byref(ne), C.byref(pg), C.byref(ng)))
+        e = np.ctypeslib.as_array(pe, shape=(ne.value, 4)) if ne.value else np.zeros((0, 4), np.float32)
+        g = np.ctypeslib.as_array(pg, shape=(ng.value, 4)) if ng.value else np.zeros((0, 4), np.float32)
+        return dict(elevated=e.copy() if copy else e, ground=g.copy() if copy else g)
 
     def box_markers(self, slot: int = 0, max_boxes: int = 1024):
         """mark_cluster (box_fitting.cpp:161-209) of every box of ``slot``'s last box stage -> [n_boxes, 6]: centroid xyz, extent xyz"""

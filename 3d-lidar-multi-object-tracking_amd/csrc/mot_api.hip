@@ -1125,15 +1125,7 @@ extern "C" int mot_side_params_default(mot_side_params* o) {
 
 constexpr int kMaxCostCells = 65536;
 
-// makeClusteredCloud / setObsMsg / createCostMap, OT/src/cluster/component_clustering.cpp:311-379, 425-457
-extern "C" int mot_cluster_products(mot_ctx* c, int slot, const mot_side_params* sp, float* clustered_xyzw, int max_clustered,
-                                    int* n_clustered, float* obstacles_xyzc, int max_obstacles, int* n_obstacles, int32_t* cost_map) {
-  if (!c) return MOT_E_ARG;
-  MOT_GUARD(c);
-  if (!sp || slot < 0 || slot >= c->batch || max_clustered < 0 || max_obstacles < 0) return fail(c, MOT_E_ARG, "mot_cluster_products: null parameters, slot or a capacity out of range");
-  if ((clustered_xyzw && !n_clustered) || (obstacles_xyzc && !n_obstacles)) return fail(c, MOT_E_ARG, "mot_cluster_products: an output list needs its count pointer");
-  if (sp->cost_width < 1 || sp->cost_height < 1 || (long)sp->cost_width * sp->cost_height > kMaxCostCells || !(sp->cost_resolution > 0))
-    return fail(c, MOT_E_ARG, "cost map must have 1..65536 cells and a positive resolution");
+static int side_setup(mot_ctx* c, int slot, const mot_side_params* sp, SideDevParams* dout, SideBuffers* sout) {
   // (a failure half-way — out of memory is plausible — leaves what exists for mot_destroy; the next call tries again from there)
   if (!c->d_side_cell) MOT_HIP(c, hipMalloc(&c->d_side_cell, (size_t)MOT_MAX_GRID * MOT_MAX_GRID * sizeof(int)));
   if (!c->d_side_cloud) MOT_HIP(c, hipMalloc(&c->d_side_cloud, (size_t)c->cap * sizeof(float4)));
@@ -1151,6 +1143,24 @@ extern "C" int mot_cluster_products(mot_ctx* c, int slot, const mot_side_params*
   s.counts = c->d_counts + (size_t)slot * kCountsStride; s.cell_first = c->d_side_cell; s.clustered = c->d_side_cloud;
   s.obstacles = c->d_side_obs; s.cost = c->d_side_cost; s.out_counts = c->d_side_counts; s.chunk_counts = c->d_side_chunks;
   s.max_clustered = c->cap; s.max_obstacles = MOT_MAX_GRID * MOT_MAX_GRID;
+  *dout = d; *sout = s;
+  return MOT_OK;
+}
+
+// makeClusteredCloud / setObsMsg / createCostMap, OT/src/cluster/component_clustering.cpp:311-379, 425-457
+extern "C" int mot_cluster_products(mot_ctx* c, int slot, const mot_side_params* sp, float* clustered_xyzw, int max_clustered,
+                                    int* n_clustered, float* obstacles_xyzc, int max_obstacles, int* n_obstacles, int32_t* cost_map) {
+  if (!c) return MOT_E_ARG;
+  MOT_GUARD(c);
+  if (!sp || slot < 0 || slot >= c->batch || max_clustered < 0 || max_obstacles < 0) return fail(c, MOT_E_ARG, "mot_cluster_products: null parameters, slot or a capacity out of range");
+  if ((clustered_xyzw && !n_clustered) || (obstacles_xyzc && !n_obstacles)) return fail(c, MOT_E_ARG, "mot_cluster_products: an output list needs its count pointer");
+  if (sp->cost_width < 1 || sp->cost_height < 1 || (long)sp->cost_width * sp->cost_height > kMaxCostCells || !(sp->cost_resolution > 0))
+    return fail(c, MOT_E_ARG, "cost map must have 1..65536 cells and a positive resolution");
+  SideDevParams d; SideBuffers s;
+  {
+    const int rc0 = side_setup(c, slot, sp, &d, &s);
+    if (rc0) return rc0;
+  }
   mot_launch_side_products(c->dp, d, s, c->cap, c->stream);
   MOT_HIP(c, hipGetLastError());
   char* pin;
@@ -1217,6 +1227,72 @@ extern "C" int mot_box_markers(mot_ctx* c, int slot, float* centroid_extent, int
   return MOT_OK;
 }
 
+// The cluster node's whole callback in one call (include/mot.h): upload, labelling, side products, box fit and cubes queued back to back on
+// the resident cloud; the counts come back first (one small copy + synchronisation), then every result in one batch of copies into the
+// context's page-locked block (second synchronisation). Same kernels as the call-by-call entry points.
+extern "C" int mot_cluster_node_frame(mot_ctx* c, const float* elev, int n, const mot_side_params* sp, mot_cluster_frame* out) {
+  if (!c) return MOT_E_ARG;
+  MOT_GUARD(c);
+  if ((!elev && n > 0) || n < 0 || !sp || !out) return fail(c, MOT_E_ARG, "mot_cluster_node_frame: null cloud / parameters / result, or negative n");
+  if (n > c->max_points) return fail(c, MOT_E_CAPACITY, "cloud has more points than max_points");
+  if (sp->cost_width < 1 || sp->cost_height < 1 || (long)sp->cost_width * sp->cost_height > kMaxCostCells || !(sp->cost_resolution > 0))
+    return fail(c, MOT_E_ARG, "cost map must have 1..65536 cells and a positive resolution");
+  memset(out, 0, sizeof *out);
+  SideDevParams d; SideBuffers s;
+  int rc = side_setup(c, 0, sp, &d, &s);
+  if (rc) return rc;
+  if (!c->d_markers) MOT_HIP(c, hipMalloc(&c->d_markers, (size_t)kMaxBoxesPerFrame * 6 * sizeof(float)));
+  const size_t cost_cells = (size_t)sp->cost_width * sp->cost_height;
+  // the page-locked block: [counts 64 B][clustered n x 16][obstacles min(n, G^2) x 16][cost map][boxes][box clusters][cubes]
+  const size_t G2 = (size_t)c->params.num_grid * c->params.num_grid, max_obs = (size_t)n < G2 ? (size_t)n : G2;
+  const size_t o_cc = 64, o_ob = o_cc + (size_t)n * 16, o_cm = o_ob + max_obs * 16, o_bx = o_cm + cost_cells * sizeof(int),
+               o_bc = o_bx + (size_t)kMaxBoxesPerFrame * 24 * sizeof(float), o_mk = o_bc + (size_t)kMaxBoxesPerFrame * sizeof(int),
+               total = o_mk + (size_t)kMaxBoxesPerFrame * 6 * sizeof(float);
+  char* pin;
+  if ((rc = pinned_scratch(c, total, &pin))) return rc;
+  if (n > 0) MOT_HIP(c, hipMemcpyAsync(c->d_elev, elev, (size_t)n * 16, hipMemcpyHostToDevice, c->stream));
+  c->last_fused = false;   // slot 0 now holds this call's cloud
+  if ((rc = set_count(c, 0, kCntElev, n))) return rc;
+  ClusterBuffers cb = cluster_buffers(c);
+  mot_launch_cluster(c->dp, cb, 1, n, c->stream);
+  mot_launch_side_products(c->dp, d, s, n > 0 ? n : 1, c->stream);
+  mot_launch_box(c->dp, cb, 1, n, c->stream);
+  mot_launch_box_markers(cb, 0, kMaxBoxesPerFrame, c->d_markers, c->stream);   // (the box count is still on the device: workgroups beyond it leave at once)
+  c->label_state[0] = 1; c->box_valid[0] = 1;
+  MOT_HIP(c, hipGetLastError());
+  int* h = reinterpret_cast<int*>(pin);
+  MOT_HIP(c, hipMemcpyAsync(h, c->d_counts, kCountsStride * sizeof(int), hipMemcpyDeviceToHost, c->stream));
+  MOT_HIP(c, hipMemcpyAsync(h + kCountsStride, c->d_side_counts, 2 * sizeof(int), hipMemcpyDeviceToHost, c->stream));
+  MOT_HIP(c, hipStreamSynchronize(c->stream));
+  memcpy(c->h_counts, h, kCountsStride * sizeof(int));
+  if (h[kCntFlags]) {
+    const int f = h[kCntFlags];
+    MOT_HIP(c, hipMemsetAsync(c->d_counts + kCntFlags, 0, sizeof(int), c->stream));
+    if (f & kFlagClusterOverflow) return fail(c, MOT_E_CAPACITY, "more clusters in a frame than the library supports (4096)");
+    if (f & kFlagBoxOverflow) return fail(c, MOT_E_CAPACITY, "more boxes in a frame than the library supports (1024)");
+    if (f & kFlagHullOverflow) return fail(c, MOT_E_CAPACITY, "convex hull larger than 384 vertices");
+    if (f & kFlagGroupOverflow) return fail(c, MOT_E_CAPACITY, "cloud too fragmented: more than max_points/2 (tile, cluster) groups in a frame");
+    if (f & kFlagRngExhausted) return fail(c, MOT_E_CAPACITY, "L-shape sampling ran out of pre-generated random draws");
+  }
+  const int ncc = h[kCountsStride], nob = h[kCountsStride + 1], nb = h[kCntBoxes];
+  if (ncc < 0 || ncc > n || nob < 0 || (size_t)nob > max_obs || nb < 0 || nb > kMaxBoxesPerFrame) return fail(c, MOT_E_STATE, "mot_cluster_node_frame: inconsistent counts");
+  if (ncc > 0) MOT_HIP(c, hipMemcpyAsync(pin + o_cc, c->d_side_cloud, (size_t)ncc * 16, hipMemcpyDeviceToHost, c->stream));
+  if (nob > 0) MOT_HIP(c, hipMemcpyAsync(pin + o_ob, c->d_side_obs, (size_t)nob * 16, hipMemcpyDeviceToHost, c->stream));
+  MOT_HIP(c, hipMemcpyAsync(pin + o_cm, c->d_side_cost, cost_cells * sizeof(int), hipMemcpyDeviceToHost, c->stream));
+  if (nb > 0) {
+    MOT_HIP(c, hipMemcpyAsync(pin + o_bx, c->d_boxes, (size_t)nb * 24 * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+    MOT_HIP(c, hipMemcpyAsync(pin + o_bc, c->d_box_cluster, (size_t)nb * sizeof(int), hipMemcpyDeviceToHost, c->stream));
+    MOT_HIP(c, hipMemcpyAsync(pin + o_mk, c->d_markers, (size_t)nb * 6 * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+  }
+  MOT_HIP(c, hipStreamSynchronize(c->stream));
+  out->num_cluster = h[kCntClusters]; out->n_clustered = ncc; out->n_obstacles = nob; out->n_boxes = nb; out->n_undefined = h[kCntUndef];
+  out->cost_cells = (int32_t)cost_cells;
+  out->clustered_xyzw = reinterpret_cast<const float*>(pin + o_cc); out->obstacles_xyzc = reinterpret_cast<const float*>(pin + o_ob);
+  out->cost_map = reinterpret_cast<const int32_t*>(pin + o_cm); out->boxes = reinterpret_cast<const float*>(pin + o_bx);
+  out->box_cluster = reinterpret_cast<const int32_t*>(pin + o_bc); out->centroid_extent = reinterpret_cast<const float*>(pin + o_mk);
+  return MOT_OK;
+}
+
 extern "C" int mot_get_ground(mot_ctx* c, int slot, float* elev, int* n_elev, float* ground, int* n_ground,
                               uint8_t* mask, int capacity_points) {
   if (!c) return MOT_E_ARG;
@@ -1263,6 +1339,34 @@ extern "C" int mot_ground_remove(mot_ctx* c, const float* xyzw, int n, float* el
   MOT_HIP(c, hipGetLastError());
   c->ground_resident = true; c->last_fused = false; c->label_state[0] = 2; c->box_valid[0] = 0;
   return mot_get_ground(c, 0, elev, n_elev, ground, n_ground, mask, n);
+}
+
+// mot_ground_remove with the two clouds left in the context's page-locked block (include/mot.h)
+extern "C" int mot_ground_node_frame(mot_ctx* c, const float* xyzw, int n, const float** elev, int* n_elev, const float** ground, int* n_ground) {
+  if (!c) return MOT_E_ARG;
+  MOT_GUARD(c);
+  if ((!xyzw && n > 0) || n < 0 || !elev || !n_elev || !ground || !n_ground) return fail(c, MOT_E_ARG, "mot_ground_node_frame: null cloud / result pointers or negative n");
+  if (n > c->max_points) return fail(c, MOT_E_CAPACITY, "frame has more points than max_points");
+  char* pin;
+  int rc = pinned_scratch(c, 64 + 2 * (size_t)n * 16, &pin);
+  if (rc) return rc;
+  if (n > 0) MOT_HIP(c, hipMemcpyAsync(c->d_in, xyzw, (size_t)n * 16, hipMemcpyHostToDevice, c->stream));
+  if ((rc = set_batch(c, &n, 1, c->d_in, c->cap))) return rc;
+  if ((rc = next_epoch(c))) return rc;
+  GroundBuffers g = ground_buffers(c, c->d_in, c->cap, false);
+  mot_launch_ground(c->dp, g, 1, n, c->stream);
+  MOT_HIP(c, hipGetLastError());
+  c->ground_resident = false;   // (no mask: a later mot_get_ground that asks for one answers MOT_E_STATE)
+  c->last_fused = false; c->label_state[0] = 2; c->box_valid[0] = 0;
+  if ((rc = fetch_counts(c, 0))) return rc;
+  const int ne = c->h_counts[kCntElev], ng = c->h_counts[kCntGround];
+  if (ne < 0 || ng < 0 || ne + ng > n) return fail(c, MOT_E_STATE, "mot_ground_node_frame: inconsistent counts");
+  if (ne > 0) MOT_HIP(c, hipMemcpyAsync(pin + 64, c->d_elev, (size_t)ne * 16, hipMemcpyDeviceToHost, c->stream));
+  if (ng > 0) MOT_HIP(c, hipMemcpyAsync(pin + 64 + (size_t)ne * 16, c->d_ground, (size_t)ng * 16, hipMemcpyDeviceToHost, c->stream));
+  MOT_HIP(c, hipStreamSynchronize(c->stream));
+  *elev = reinterpret_cast<const float*>(pin + 64); *n_elev = ne;
+  *ground = reinterpret_cast<const float*>(pin + 64 + (size_t)ne * 16); *n_ground = ng;
+  return MOT_OK;
 }
 
 // one H2D of the raw PointCloud2 records of a frame into the staging buffer, unpacked on the device into the context's own

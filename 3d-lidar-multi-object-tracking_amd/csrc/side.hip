@@ -125,6 +125,7 @@ box_markers_kernel(ClusterBuffers c, int slot, float* __restrict__ out) {
   __shared__ float4 s_win[kMarkerWindow];
   __shared__ int s_lo[3], s_hi[3];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, box = blockIdx.x;
+  if (box >= c.counts[(long)slot * kCountsStride + kCntBoxes]) return;   // (launched for the library's limit when the host does not know the count yet)
   const int ci = c.box_cluster[(long)slot * kMaxBoxesPerFrame + box] - 1;
   const int* __restrict__ cgstart = c.cluster_gstart + (long)slot * (kMaxClusters + 1);
   const SortedGroup* __restrict__ gs = c.gsorted + (long)slot * c.group_cap;

@@ -461,54 +461,73 @@ def single_stream(mot, torch, device, seq_dev, n_seq, stride, ego_v, ego_yaw, fr
 
 
 def stage_wise_host_buffers(mot, device, seq_dev, n_seq, stride, ego_v, ego_yaw, seqmod):
-    """The reference's OWN function boundary, call by call, on HOST buffers: what its three nodes do per scan (groundRemove on the message's
-    cloud -> two clouds back; componentClustering + side products + boxFitting + cube markers on the elevated cloud; getOriginPoints, the
-    change of frame and immUkfJpdaf on the boxes) — the drop-in a maintainer gets by swapping the calls (ros/src/*_node.cpp),
-    every stage paying its own PCIe copies and a synchronisation. ONE stream, the 154 frames of bench stream 0. Wall clock per stage,
-    ctypes / numpy overhead of this harness included (a few tens of microseconds per call)."""
+    """The reference's OWN node boundary on HOST buffers: what its three nodes do per scan (groundRemove on the message's cloud -> two clouds
+    back; componentClustering + side products + boxFitting + cube markers on the elevated cloud; getOriginPoints, the change of frame and
+    immUkfJpdaf on the boxes) — the drop-in the node shells ros/src/*_node.cpp are, every stage paying its own PCIe copies and synchronisations.
+    ONE stream, the 154 frames of bench stream 0. Two forms of the same work: `per_node_call` — one library call per node callback
+    (mot_ground_node_frame, mot_cluster_node_frame: round 5) — and `call_by_call` — the reference's function boundary call by call
+    (mot_ground_remove; mot_cluster + mot_cluster_products + mot_box_fit_resident + mot_box_markers: what include/mot_adapters.hpp gives a
+    maintainer who keeps the reference's main.cpp). Wall clock per stage, ctypes / numpy overhead of this harness included."""
     import ctypes as C
     F = seq_dev.shape[0]
     clouds = [seq_dev[f, 0, : int(n_seq[f, 0])].cpu().numpy() for f in range(F)]
     vp = lambda a: a.ctypes.data_as(C.c_void_p)
+    ms = lambda a: {"median": round(float(np.median(a)) * 1e3, 4), "p95": round(_pct(np.array(a) * 1e3, 95), 4)}
+    res = {}
     with mot.Context(device=device, max_points=stride, max_batch=1, max_tracks_total=256) as c:
         L, h, G = c.lib, c._h, c.params.num_grid
         sp = mot.MotSideParams(); c._ck(L.mot_side_params_default(C.byref(sp)))
         cc = np.zeros((stride, 4), np.float32); ob = np.zeros((G * G, 4), np.float32); cm = np.zeros(sp.cost_width * sp.cost_height, np.int32)
         boxes = np.zeros((1024, 8, 3), np.float32); cubes = np.zeros((1024, 6), np.float32)
-        t_g, t_c, t_t, nb_last, nt_last = [], [], [], 0, 0
-        for rep in range(2):   # the first pass warms allocations and code paths; the second is the one reported
-            c.reset(); c.synchronize()
-            t_g, t_c, t_t, calls = [], [], [], []
-            for f in range(F):
-                ts = 1.0e9 + f * 1e5
-                t0 = time.perf_counter()
-                g = c.ground_remove(clouds[f], want_mask=False)                       # `ground` node: mot_ground_remove
-                t1 = time.perf_counter()
-                e = g["elevated"]; n = len(e)
-                nc, ncc, nob, nb, nm = C.c_int(0), C.c_int(0), C.c_int(0), C.c_int(0), C.c_int(0)
-                c._ck(L.mot_cluster(h, vp(e), n, None, C.byref(nc), None))            # `cluster` node: one upload, everything else on the resident copy
-                ta = time.perf_counter()
-                c._ck(L.mot_cluster_products(h, 0, C.byref(sp), vp(cc), stride, C.byref(ncc), vp(ob), G * G, C.byref(nob), vp(cm)))
-                tb = time.perf_counter()
-                c._ck(L.mot_box_fit_resident(h, vp(boxes), 1024, C.byref(nb), None, None))
-                tc = time.perf_counter()
-                c._ck(L.mot_box_markers(h, 0, vp(cubes), 1024, C.byref(nm)))
-                t2 = time.perf_counter()
-                calls.append((ta - t1, tb - ta, tc - tb, t2 - tc))
-                ego = c.ego_update(ts, float(ego_v[f]), float(ego_yaw[f]))            # `tracking` node: getOriginPoints, tf, immUkfJpdaf
-                tr = c.track_step(seqmod.boxes_to_global(boxes[: nb.value], ego), ts)
-                t3 = time.perf_counter()
-                t_g.append(t1 - t0); t_c.append(t2 - t1); t_t.append(t3 - t2)
-                nb_last, nt_last = nb.value, int(tr["n"])
-    ms = lambda a: {"median": round(float(np.median(a)) * 1e3, 4), "p95": round(_pct(np.array(a) * 1e3, 95), 4)}
-    tot = np.array(t_g) + np.array(t_c) + np.array(t_t)
-    return {"frames": F, "ms_per_frame": ms(tot), "frames_per_s": round(F / float(tot.sum()), 1),
-            "stage_ms": {"ground": ms(t_g), "cluster_box": ms(t_c), "tracker": ms(t_t)},
-            "cluster_box_calls_ms_median": dict(zip(("mot_cluster", "mot_cluster_products", "mot_box_fit_resident", "mot_box_markers"),
-                                                    [round(float(v) * 1e3, 4) for v in np.median(np.array(calls), axis=0)])), "boxes_last_frame": nb_last, "tracks_ever": nt_last,
-            "what": "the reference's function boundary call by call on host buffers (mot_ground_remove; mot_cluster + mot_cluster_products + mot_box_fit_resident + "
-                    "mot_box_markers; mot_ego_update + host change of frame + mot_track_step): every stage uploads its input, synchronises and downloads "
-                    "its outputs, as the three ROS nodes do per scan; compare cpu_baseline.single.stage_ms (the reference's own sources on one host core)"}
+        fr = mot.MotClusterFrame(); pe, pg = C.POINTER(C.c_float)(), C.POINTER(C.c_float)(); ne, ng = C.c_int(0), C.c_int(0)
+        for form in ("call_by_call", "per_node_call"):
+            for rep in range(2):   # the first pass warms allocations and code paths; the second is the one reported
+                c.reset(); c.synchronize()
+                t_g, t_c, t_t, calls = [], [], [], []
+                for f in range(F):
+                    ts = 1.0e9 + f * 1e5
+                    t0 = time.perf_counter()
+                    if form == "call_by_call":
+                        g = c.ground_remove(clouds[f], want_mask=False)                   # `ground` node: mot_ground_remove
+                        t1 = time.perf_counter()
+                        e = g["elevated"]; n = len(e)
+                        nc, ncc, nob, nb, nm = C.c_int(0), C.c_int(0), C.c_int(0), C.c_int(0), C.c_int(0)
+                        c._ck(L.mot_cluster(h, vp(e), n, None, C.byref(nc), None))        # `cluster` node: one upload, everything else on the resident copy
+                        ta = time.perf_counter()
+                        c._ck(L.mot_cluster_products(h, 0, C.byref(sp), vp(cc), stride, C.byref(ncc), vp(ob), G * G, C.byref(nob), vp(cm)))
+                        tb = time.perf_counter()
+                        c._ck(L.mot_box_fit_resident(h, vp(boxes), 1024, C.byref(nb), None, None))
+                        tc = time.perf_counter()
+                        c._ck(L.mot_box_markers(h, 0, vp(cubes), 1024, C.byref(nm)))
+                        t2 = time.perf_counter()
+                        calls.append((ta - t1, tb - ta, tc - tb, t2 - tc))
+                        bx = boxes[: nb.value]
+                    else:
+                        a = clouds[f]
+                        c._ck(L.mot_ground_node_frame(h, vp(a), len(a), C.byref(pe), C.byref(ne), C.byref(pg), C.byref(ng)))    # `ground` node
+                        t1 = time.perf_counter()
+                        c._ck(L.mot_cluster_node_frame(h, pe, ne.value, C.byref(sp), C.byref(fr)))                               # `cluster` node (the elevated cloud: the ground node's message payload)
+                        t2 = time.perf_counter()
+                        bx = np.ctypeslib.as_array(fr.boxes, shape=(fr.n_boxes, 8, 3)) if fr.n_boxes else np.zeros((0, 8, 3), np.float32)
+                        nb = C.c_int(fr.n_boxes)
+                    ego = c.ego_update(ts, float(ego_v[f]), float(ego_yaw[f]))            # `tracking` node: getOriginPoints, tf, immUkfJpdaf
+                    tr = c.track_step(seqmod.boxes_to_global(bx, ego), ts)
+                    t3 = time.perf_counter()
+                    t_g.append(t1 - t0); t_c.append(t2 - t1); t_t.append(t3 - t2)
+                    nb_last, nt_last = nb.value, int(tr["n"])
+            tot = np.array(t_g) + np.array(t_c) + np.array(t_t)
+            res[form] = {"ms_per_frame": ms(tot), "frames_per_s": round(F / float(tot.sum()), 1),
+                         "stage_ms": {"ground": ms(t_g), "cluster_box": ms(t_c), "tracker": ms(t_t)}, "boxes_last_frame": nb_last, "tracks_ever": nt_last}
+            if calls:
+                res[form]["cluster_box_calls_ms_median"] = dict(zip(("mot_cluster", "mot_cluster_products", "mot_box_fit_resident", "mot_box_markers"),
+                                                                     [round(float(v) * 1e3, 4) for v in np.median(np.array(calls), axis=0)]))
+    out = dict(res["per_node_call"])
+    out.update({"frames": F, "call_by_call": res["call_by_call"], "cluster_box_calls_ms_median": res["call_by_call"]["cluster_box_calls_ms_median"],
+                "what": "what the three ROS nodes do per scan on host buffers, every stage uploading its input, synchronising and downloading its outputs. Top level = one library "
+                        "call per node callback (mot_ground_node_frame; mot_cluster_node_frame; mot_ego_update + host change of frame + mot_track_step: ros/src/*_node.cpp); "
+                        "call_by_call = the reference's function boundary call by call (mot_ground_remove; mot_cluster + mot_cluster_products + mot_box_fit_resident + "
+                        "mot_box_markers: include/mot_adapters.hpp); compare cpu_baseline.single.stage_ms (the reference's own sources on one host core)"})
+    return out
 
 
 def host_boundary_pipelined(mot, torch, device, seq_dev, n_seq, stride, n_points, ego_v, ego_yaw, contexts=4, slots=16, batches=48, lib=None):

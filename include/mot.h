@@ -38,7 +38,7 @@
 extern "C" {
 #endif
 
-#define MOT_ABI_VERSION 4
+#define MOT_ABI_VERSION 5
 
 /* polar grid of the ground stage: compile-time in the reference too
  * (OT/include/ground_removal.h:16-17) */
@@ -414,6 +414,33 @@ int mot_cluster_products_host(mot_ctx* ctx, const float* elevated_xyzw, int n, c
  * been replaced since its last box stage (mot_ground_remove*, mot_cluster, mot_cluster_products_host write into slot 0): the cluster
  * order the cubes are folded from would belong to another cloud. */
 int mot_box_markers(mot_ctx* ctx, int slot, float* centroid_extent, int max_boxes, int* n_boxes);
+
+/* ---------------------------------------------------------------- one call per node callback (round 5)
+ * What the reference's `cluster` node does per scan (OT/src/cluster/main.cpp:63-234: componentClustering, makeClusteredCloud, createCostMap,
+ * setObsMsg, boxFitting with its cube markers) as ONE call on the elevated cloud in host memory: one upload, every kernel on the resident
+ * copy, TWO synchronisations (the counts, then every result in one batch of copies) instead of the nine of the call-by-call sequence
+ * mot_cluster + mot_cluster_products + mot_box_fit_resident + mot_box_markers — same kernels, same results. The results are VIEWS into a
+ * page-locked block owned by the context, valid until the next call on this context (a node copies them into its messages anyway). */
+typedef struct mot_cluster_frame {
+  int32_t num_cluster;             /* componentClustering's numCluster */
+  int32_t n_clustered;             /* makeClusteredCloud */
+  int32_t n_obstacles;             /* setObsMsg */
+  int32_t n_boxes, n_undefined;    /* boxFitting (n_undefined: see mot_box_fit) */
+  int32_t cost_cells;              /* cost_width * cost_height */
+  const float* clustered_xyzw;     /* n_clustered x 4 (x, y, z, 0) */
+  const float* obstacles_xyzc;     /* n_obstacles x 4 (x, y, z, cluster id) */
+  const int32_t* cost_map;         /* cost_cells */
+  const float* boxes;              /* n_boxes x 8 x 3 */
+  const int32_t* box_cluster;      /* n_boxes: 1-based cluster id of every box */
+  const float* centroid_extent;    /* n_boxes x 6: mot_box_markers */
+} mot_cluster_frame;
+int mot_cluster_node_frame(mot_ctx* ctx, const float* elevated_xyzw, int n, const mot_side_params* sp, mot_cluster_frame* out);
+
+/* The `ground` node's call (OT/src/groundremove/main.cpp:120: groundRemove) with the two clouds returned as VIEWS into the context's page-locked
+ * block (valid until the next call on this context) instead of copies into caller buffers: mot_ground_remove's results, one device-to-host
+ * transfer less staging. *elevated_xyzw / *ground_xyzw: n_elevated / n_ground x 4 floats. */
+int mot_ground_node_frame(mot_ctx* ctx, const float* xyzw, int n, const float** elevated_xyzw, int* n_elevated, const float** ground_xyzw,
+                          int* n_ground);
 
 /* ---------------------------------------------------------------- input decode
  * sensor_msgs/PointCloud2 payload -> the float4 (x, y, z, w) layout of this library, on the device: what

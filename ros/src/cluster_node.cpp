@@ -4,10 +4,9 @@
 //
 // Data path: the elevated cloud is uploaded ONCE (the payload of none_ground_topic already is the library's float4 layout
 // when it comes from the ground node); connected-component labelling, the three side products (cell-centre cloud,
-// obstacle list, cost map) and the box fit all run on that resident copy (mot_cluster -> mot_cluster_products ->
-// mot_box_fit_resident). The host only assembles messages. The rviz CUBE markers need each boxed cluster's centroid and
-// extent exactly as PCL accumulates them (float sums in point order), so they are folded on the host from the per-point
-// labels the library returns — a few tens of microseconds on data the node holds anyway.
+// obstacle list, cost map), the box fit and the rviz CUBE markers (each boxed cluster's centroid and extent exactly as PCL
+// accumulates them: float sums in point order, folded on the device) all run on that resident copy, queued by ONE library call
+// per callback (mot_cluster_node_frame: two synchronisations, every result in one page-locked block). The host only assembles messages.
 
 #include <nav_msgs/OccupancyGrid.h>
 #include <object_tracking/ObstacleList.h>
@@ -43,9 +42,6 @@ class ClusterNode {
     grid_msg_.info.origin.position.y = (-1) * (side_.cost_height / 2.0) * side_.cost_resolution + side_.cost_offset_y;
     grid_msg_.info.origin.position.z = side_.cost_offset_z;
     grid_msg_.info.origin.orientation.w = 1.0;
-    boxes_.resize((size_t)kMaxBoxes * 24);
-    cost_.resize((size_t)side_.cost_width * side_.cost_height);
-    obstacles_.resize((size_t)prm_.num_grid * prm_.num_grid * 4);
     sub_ = nh.subscribe("none_ground_topic", 160, &ClusterNode::on_cloud, this);
   }
   ~ClusterNode() { mot_destroy(ctx_); }
@@ -66,17 +62,13 @@ class ClusterNode {
   void on_cloud(const sensor_msgs::PointCloud2ConstPtr& input) {
     const size_t n = (size_t)input->width * input->height;
     const float* elevated = as_float4(*input, n);
-    if (clustered_.size() < 4 * n + 4) { clustered_.resize(4 * n + 4); }
-
-    int num_cluster = 0, n_clustered = 0, n_obstacles = 0, n_boxes = 0;
-    mot_ros::check(ctx_, mot_cluster(ctx_, elevated, (int)n, nullptr, &num_cluster, nullptr), "mot_cluster");
-    mot_ros::check(ctx_, mot_cluster_products(ctx_, 0, &side_, clustered_.data(), (int)n, &n_clustered, obstacles_.data(), prm_.num_grid * prm_.num_grid,
-                                              &n_obstacles, cost_.data()), "mot_cluster_products");
-    mot_ros::check(ctx_, mot_box_fit_resident(ctx_, boxes_.data(), kMaxBoxes, &n_boxes, nullptr, nullptr), "mot_box_fit_resident");
+    mot_cluster_frame fr;
+    mot_ros::check(ctx_, mot_cluster_node_frame(ctx_, elevated, (int)n, &side_, &fr), "mot_cluster_node_frame");
+    const int n_clustered = fr.n_clustered, n_obstacles = fr.n_obstacles, n_boxes = fr.n_boxes;
 
     // realtime_cost_map
     grid_msg_.header.frame_id = input->header.frame_id;
-    grid_msg_.data.assign(cost_.begin(), cost_.end());
+    grid_msg_.data.assign(fr.cost_map, fr.cost_map + fr.cost_cells);
     costmap_pub_.publish(grid_msg_);
     grid_msg_.data.clear();
 
@@ -86,14 +78,14 @@ class ClusterNode {
     obstacle_msg.obstacles.resize(n_obstacles);
     for (int i = 0; i < n_obstacles; i++) {
       object_tracking::Obstacle& o = obstacle_msg.obstacles[i];
-      o.x = obstacles_[4 * i]; o.y = obstacles_[4 * i + 1]; o.z = obstacles_[4 * i + 2]; o.cluster = (int32_t)obstacles_[4 * i + 3];
+      o.x = fr.obstacles_xyzc[4 * i]; o.y = fr.obstacles_xyzc[4 * i + 1]; o.z = fr.obstacles_xyzc[4 * i + 2]; o.cluster = (int32_t)fr.obstacles_xyzc[4 * i + 3];
     }
     obstacles_pub_.publish(obstacle_msg);
 
     // output: every clustered point moved to its cell centre (makeClusteredCloud)
-    for (int i = 0; i < n_clustered; i++) clustered_[4 * i + 3] = 1.0f;   // pcl::PointXYZ's padding
     sensor_msgs::PointCloud2 cloud_msg;
-    mot_ros::fill_xyz_cloud(cloud_msg, clustered_.data(), (size_t)n_clustered);
+    mot_ros::fill_xyz_cloud(cloud_msg, fr.clustered_xyzw, (size_t)n_clustered);
+    for (int i = 0; i < n_clustered; i++) { const float one = 1.0f; std::memcpy(&cloud_msg.data[16 * (size_t)i + 12], &one, 4); }   // pcl::PointXYZ's padding
     cloud_msg.header.frame_id = input->header.frame_id;
     cloud_pub_.publish(cloud_msg);
 
@@ -104,24 +96,20 @@ class ClusterNode {
     std::vector<float>* corner[8] = {&box_msg.x1, &box_msg.x2, &box_msg.x3, &box_msg.x4, &box_msg.y1, &box_msg.y2, &box_msg.y3, &box_msg.y4};
     for (int k = 0; k < 8; k++) {
       corner[k]->resize(3 * (size_t)n_boxes);
-      for (int b = 0; b < n_boxes; b++) std::memcpy(&(*corner[k])[3 * b], &boxes_[(size_t)b * 24 + 3 * k], 12);
+      for (int b = 0; b < n_boxes; b++) std::memcpy(&(*corner[k])[3 * b], &fr.boxes[(size_t)b * 24 + 3 * k], 12);
     }
     boxes_pub_.publish(box_msg);
 
-    cubes_pub_.publish(cube_markers(n_boxes));
-    lines_pub_.publish(mot_ros::box_edges("velodyne", boxes_.data(), n_boxes));
+    cubes_pub_.publish(cube_markers(fr.centroid_extent, n_boxes));
+    lines_pub_.publish(mot_ros::box_edges("velodyne", fr.boxes, n_boxes));
   }
 
   // one CUBE per box: centroid and axis-aligned extent of the cluster's points (mark_cluster, box_fitting.cpp:161-209), folded on the
-  // device from the cloud and the cluster-ordered groups the box stage left in HBM (mot_box_markers): 24 bytes per box come back
-  visualization_msgs::MarkerArray cube_markers(int n_boxes) {
+  // device from the cloud and the cluster-ordered groups the box stage left in HBM: 24 bytes per box came back with the frame
+  visualization_msgs::MarkerArray cube_markers(const float* cubes, int n_boxes) {
     visualization_msgs::MarkerArray out;
-    if (n_boxes == 0) return out;
-    cubes_.resize(6 * (size_t)n_boxes);
-    int nb = 0;
-    mot_ros::check(ctx_, mot_box_markers(ctx_, 0, cubes_.data(), n_boxes, &nb), "mot_box_markers");
     for (int b = 0; b < n_boxes; b++) {
-      const float* f = &cubes_[6 * (size_t)b];
+      const float* f = &cubes[6 * (size_t)b];
       visualization_msgs::Marker m;
       m.header.frame_id = "/velodyne";
       m.header.stamp = ros::Time::now();
@@ -144,8 +132,7 @@ class ClusterNode {
   ros::Publisher cloud_pub_, lines_pub_, cubes_pub_, costmap_pub_, obstacles_pub_, boxes_pub_;
   ros::Subscriber sub_;
   nav_msgs::OccupancyGrid grid_msg_;
-  std::vector<float> clustered_, obstacles_, boxes_, repacked_, cubes_;
-  std::vector<int32_t> cost_;
+  std::vector<float> repacked_;
   std::vector<uint8_t> scratch_;
 };
 

@@ -103,3 +103,5 @@ def test_stage_wise_leg_on_the_emulator(mot, synth):
     assert r["frames"] == F and r["ms_per_frame"]["median"] > 0 and set(r["stage_ms"]) == {"ground", "cluster_box", "tracker"}
     assert set(r["cluster_box_calls_ms_median"]) == {"mot_cluster", "mot_cluster_products", "mot_box_fit_resident", "mot_box_markers"}
     assert r["tracks_ever"] >= 1
+    cb = r["call_by_call"]   # both forms ran the same frames: same boxes, same tracks
+    assert cb["boxes_last_frame"] == r["boxes_last_frame"] and cb["tracks_ever"] == r["tracks_ever"] and cb["ms_per_frame"]["median"] > 0

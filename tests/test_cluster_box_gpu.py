@@ -367,3 +367,9 @@ def test_l_shape_cluster_with_more_groups_than_the_staging_holds(mot, hip_lib, o
             for seed in (1, 2):
                 bx, got = W.check(c, oracle, p, W.big_l_cloud(seed))
                 assert any(d["branch"] == 0 and d["num_points"] >= 33000 and d["accepted"] for d in bx["debug"]), [(d["num_points"], d["branch"], d["accepted"]) for d in bx["debug"]]
+
+
+def test_node_frame_calls(ctx, oracle, synth):
+    """mot_cluster_node_frame / mot_ground_node_frame on the MI355X = the call-by-call sequences they bundle (tests/node_frame_case.py)"""
+    import node_frame_case
+    node_frame_case.check(ctx, oracle, synth, sizes=((120000, 3, 1), (30000, 5, 0), (200000, 4, 1)))

@@ -106,12 +106,19 @@ def test_round_4_entry_points_check_their_arguments(mot, emu, synth):
         assert L.mot_box_markers(h, 0, six, 10, None) == mot.MOT_E_ARG          # null n_boxes
         assert L.mot_box_markers(h, 2, six, 10, C.byref(n)) == mot.MOT_E_ARG     # no such slot
         assert L.mot_box_markers(h, 0, six, -1, C.byref(n)) == mot.MOT_E_ARG
-        assert L.mot_box_markers(h, 0, None, 0, C.byref(n)) == mot.MOT_OK and n.value == 0   # nothing fitted yet: no boxes
+        assert L.mot_box_markers(h, 0, None, 0, C.byref(n)) == mot.MOT_E_STATE   # nothing fitted yet
         cloud = synth.make_cloud(8000, 2, 0)
         g = c.ground_remove(cloud); c.cluster(g["elevated"]); b = c.box_fit_resident()
         if len(b["boxes"]) > 1:
             assert L.mot_box_markers(h, 0, six, 1, C.byref(n)) == mot.MOT_E_CAPACITY and n.value == len(b["boxes"])
         assert L.mot_box_markers(h, 0, None, 1024, C.byref(n)) == mot.MOT_OK and n.value == len(b["boxes"])   # count only
+        # a stage-wise call that puts another cloud into slot 0 makes the box stage's products stale (round-4 advisor): MOT_E_STATE, not cubes of the wrong cloud
+        c.cluster(g["elevated"][: len(g["elevated"]) // 2])
+        assert L.mot_box_markers(h, 0, six, 10, C.byref(n)) == mot.MOT_E_STATE and b"box stage" in L.mot_last_error(h)
+        c.box_fit_resident()
+        assert L.mot_box_markers(h, 0, None, 1024, C.byref(n)) == mot.MOT_OK
+        c.ground_remove(cloud)
+        assert L.mot_box_markers(h, 0, None, 1024, C.byref(n)) == mot.MOT_E_STATE
         sz = C.c_size_t(0); w = C.c_size_t(0); buf = (C.c_char * 16)()
         assert L.mot_stream_snapshot_size(h, None) == mot.MOT_E_ARG
         assert L.mot_stream_snapshot_size(h, C.byref(sz)) == mot.MOT_OK and sz.value > 32 * 1600
