@@ -41,20 +41,40 @@ __device__ __forceinline__ SidePoint side_point(const MotDevParams& p, const Sid
   return r;
 }
 
+constexpr int kCostLds = 4096;   // cost maps up to this many cells are counted in LDS first (the reference's is 50 x 50)
 __global__ void MOT_LAUNCH_BOUNDS(kSideBlock)
 side_mark_kernel(MotDevParams p, SideDevParams sp, SideBuffers s) {
+  __shared__ int s_cost[kCostLds];
   const int n = s.counts[kCntElev], i = blockIdx.x * kSideBlock + threadIdx.x;
-  if (i >= n) return;
-  const float4 q = s.elevated[i];
-  int xI, yI;
-  if (mot_cart_cell(p, q.x, q.y, &xI, &yI) && s.grid[xI * p.num_grid + yI] != 0) atomicMin(&s.cell_first[xI * p.num_grid + yI], i);
-  // createCostMap :431-452 (doubles; `int grid_y = ...` truncates toward zero; NaN / out-of-int values fail the range test)
-  if (!((double)q.z > sp.height_limit) && !(fabs((double)q.x) < sp.car_length && fabs((double)q.y) < sp.car_width)) {
-    const double gy = ((double)q.x + sp.center_x) / sp.cost_resolution, gx = ((double)q.y + sp.center_y) / sp.cost_resolution;
-    if (gy > -2147483649.0 && gy < 2147483648.0 && gx > -2147483649.0 && gx < 2147483648.0) {
-      const int grid_y = (int)gy, grid_x = (int)gx;
-      if (grid_y >= 0 && grid_y < sp.cost_width && grid_x >= 0 && grid_x < sp.cost_height) atomicAdd(&s.cost[sp.cost_width * grid_x + grid_y], 1);
+  if ((int)blockIdx.x * kSideBlock >= n) return;   // (the whole workgroup)
+  const int cells = sp.cost_width * sp.cost_height;
+  const bool lds_cost = cells <= kCostLds;   // uniform
+  if (lds_cost) for (int k = threadIdx.x; k < cells; k += kSideBlock) s_cost[k] = 0;
+  __syncthreads();
+  // The first point of every labelled cell: atomicMin of the index — but neighbouring lanes are neighbouring returns of one beam and fall into
+  // the SAME cell in runs, the run's first lane holds its smallest index, and a device-scope atomic is executed on the memory side, one at a
+  // time per address: only the first lane of a run of equal cells (within its 16-lane row) issues one (30 k atomics per frame were 40 us of a
+  // 0.23 ms cluster-node callback: profiles/r05_node_frame_trace.txt)
+  int cell = -1, cost_at = -1;
+  if (i < n) {
+    const float4 q = s.elevated[i];
+    int xI, yI;
+    if (mot_cart_cell(p, q.x, q.y, &xI, &yI) && s.grid[xI * p.num_grid + yI] != 0) cell = xI * p.num_grid + yI;
+    // createCostMap :431-452 (doubles; `int grid_y = ...` truncates toward zero; NaN / out-of-int values fail the range test)
+    if (!((double)q.z > sp.height_limit) && !(fabs((double)q.x) < sp.car_length && fabs((double)q.y) < sp.car_width)) {
+      const double gy = ((double)q.x + sp.center_x) / sp.cost_resolution, gx = ((double)q.y + sp.center_y) / sp.cost_resolution;
+      if (gy > -2147483649.0 && gy < 2147483648.0 && gx > -2147483649.0 && gx < 2147483648.0) {
+        const int grid_y = (int)gy, grid_x = (int)gx;
+        if (grid_y >= 0 && grid_y < sp.cost_width && grid_x >= 0 && grid_x < sp.cost_height) cost_at = sp.cost_width * grid_x + grid_y;
+      }
     }
+  }
+  const int prev = row_prev_i32(cell, -2);
+  if (cell >= 0 && prev != cell) atomicMin(&s.cell_first[cell], i);
+  if (cost_at >= 0) { if (lds_cost) atomicAdd(&s_cost[cost_at], 1); else atomicAdd(&s.cost[cost_at], 1); }
+  if (lds_cost) {   // the workgroup's counts leave with one atomic per cell it touched
+    __syncthreads();
+    for (int k = threadIdx.x; k < cells; k += kSideBlock) { const int v = s_cost[k]; if (v) atomicAdd(&s.cost[k], v); }
   }
 }
 
@@ -116,7 +136,8 @@ side_scatter_kernel(MotDevParams p, SideDevParams sp, SideBuffers s) {
 //   stage   the cluster's points go into an LDS window COMPACTED and in input order (slot = rank - window base): 32 groups at a time, eight
 //           per wave, a tile per request, all of a wave's requests in flight together — a wall is hundreds of tiles with a handful of its
 //           points in each, and walking them one dependent round trip at a time was nine tenths of the first version's 0.7 ms;
-//   sum     when the next 32 groups might not fit, wave 0 adds the window up front to back (one broadcast LDS read and three adds per point);
+//   sum     when the next 32 groups might not fit, waves 0, 1, 2 add the window's x, y, z front to back: one serial chain per wave / SIMD, a SIMD each
+//           (round 5; until then wave 0 ran the three chains interleaved on one SIMD);
 // the extrema are per-lane and merged at the end (order-independent). out[box] = {centroid xyz, extent xyz}.
 constexpr int kMarkerWindow = 2048;                 // points per LDS window (32 KB)
 constexpr int kMarkerWaves = 4, kMarkerDepth = 8;   // 32 groups (at most 2048 points: an empty window always takes them) per round
@@ -132,19 +153,25 @@ box_markers_kernel(ClusterBuffers c, int slot, float* __restrict__ out) {
   const float4* __restrict__ pts = c.elevated + (long)slot * c.cap;
   const int g0 = cgstart[ci], g1 = cgstart[ci + 1];
   if (threadIdx.x < 3) { s_lo[threadIdx.x] = 0x7fffffff; s_hi[threadIdx.x] = (int)0x80000000; }   // ordered keys (mot_float_key)
-  float sx = 0.f, sy = 0.f, sz = 0.f;   // wave 0's running sums
+  __shared__ float s_sum[3];
+  float acc = 0.f;   // waves 0, 1, 2: the running sum of x, y, z — ONE serial chain per wave (a SIMD each), so the three chains run side by side
+                     // instead of interleaved on one SIMD (a wave64 add holds its SIMD for 4 cycles whatever the active lanes: 12 -> 4 cycles a point)
   int lo[3] = {0x7fffffff, 0x7fffffff, 0x7fffffff}, hi[3] = {(int)0x80000000, (int)0x80000000, (int)0x80000000};
   int base = 0, filled = 0;   // rank of the window's first point within the cluster; points in the window (uniform over the workgroup)
   const unsigned long long below = (1ull << lane) - 1ull;
   auto flush = [&]() {   // (called by every thread: the condition is uniform)
     __syncthreads();
-    if (wave == 0) {
+    if (wave < 3) {
+      const float* comp = reinterpret_cast<const float*>(s_win) + wave;   // my coordinate of point i: comp[4 * i] (a broadcast LDS read)
+      // (prefetching the next 16 operands under the adds of the current 16 — with a copy, or ping-pong between two register sets — measured
+      // 80 / 68 us against 61 for this plain form on a frame whose largest boxed cluster has ~8 k points: profiles/r05_node_frame.md)
       int i = 0;
-      for (; i + 4 <= filled; i += 4) {
-        const float4 a = s_win[i], b = s_win[i + 1], d = s_win[i + 2], e = s_win[i + 3];
-        sx += a.x; sy += a.y; sz += a.z; sx += b.x; sy += b.y; sz += b.z; sx += d.x; sy += d.y; sz += d.z; sx += e.x; sy += e.y; sz += e.z;
+      for (; i + 8 <= filled; i += 8) {
+        const float a0 = comp[4 * i], a1 = comp[4 * i + 4], a2 = comp[4 * i + 8], a3 = comp[4 * i + 12], a4 = comp[4 * i + 16], a5 = comp[4 * i + 20],
+                    a6 = comp[4 * i + 24], a7 = comp[4 * i + 28];
+        acc += a0; acc += a1; acc += a2; acc += a3; acc += a4; acc += a5; acc += a6; acc += a7;   // front to back: the order of pcl::compute3DCentroid
       }
-      for (; i < filled; i++) { const float4 a = s_win[i]; sx += a.x; sy += a.y; sz += a.z; }
+      for (; i < filled; i++) acc += comp[4 * i];
     }
     __syncthreads();
     base += filled; filled = 0;
@@ -189,11 +216,12 @@ box_markers_kernel(ClusterBuffers c, int slot, float* __restrict__ out) {
     const int l = wave_reduce_i32_id(lo[k], OpMinI(), 0x7fffffff), h = wave_reduce_i32_id(hi[k], OpMaxI(), (int)0x80000000);
     if (lane == 0) { atomicMin(&s_lo[k], l); atomicMax(&s_hi[k], h); }
   }
+  if (wave < 3 && lane == 0) s_sum[wave] = acc;
   __syncthreads();
   if (threadIdx.x == 0) {
     const float n = (float)base;   // static_cast<Scalar>(cloud.size()), pcl/common/impl/centroid.hpp
     float* o = out + (long)box * 6;
-    o[0] = sx / n; o[1] = sy / n; o[2] = sz / n;
+    o[0] = s_sum[0] / n; o[1] = s_sum[1] / n; o[2] = s_sum[2] / n;
     o[3] = mot_key_float(s_hi[0]) - mot_key_float(s_lo[0]); o[4] = mot_key_float(s_hi[1]) - mot_key_float(s_lo[1]); o[5] = mot_key_float(s_hi[2]) - mot_key_float(s_lo[2]);
   }
 }
