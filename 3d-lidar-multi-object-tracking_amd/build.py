@@ -14,7 +14,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libmot_hip.so")
-SOURCES = ["ground.hip", "cluster.hip", "box.hip", "side.hip", "track.hip", "debug.hip", "mot_api.hip"]
+SOURCES = ["ground.hip", "cluster.hip", "box.hip", "side.hip", "track.hip", "mot_api.hip"]
 HEADERS = ["mot_internal.h", "mot_math.h", "mot_wave.h", "mot_debug.h", "mot_debug_api.h", "mot_track_prep.h", os.path.join("..", "..", "include", "mot.h")]
 
 HIPCC_FLAGS = [
@@ -58,23 +58,5 @@ def build(force: bool = False, verbose: bool = False, extra_flags=(), out: str |
     return out
 
 
-SYNTH_LIB = os.path.join(HERE, "libmot_synth.so")
-
-
-def build_synth(force: bool = False) -> str:
-    """csrc/synth.hip -> libmot_synth.so: the bench / test data generator (synthetic lidar sequences rendered on the GPU).
-    A library of its own: libmot_hip.so and include/mot.h do not depend on it."""
-    src = os.path.join(CSRC, "synth.hip")
-    if not force and os.path.exists(SYNTH_LIB) and os.path.getmtime(SYNTH_LIB) >= max(os.path.getmtime(src), os.path.getmtime(os.path.abspath(__file__))):
-        return SYNTH_LIB
-    cmd = [hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-Wall", src, "-o", SYNTH_LIB + ".tmp"]
-    r = subprocess.run(cmd, capture_output=True, text=True)
-    if r.returncode != 0:
-        raise RuntimeError("hipcc failed:\n" + r.stdout + r.stderr)
-    os.replace(SYNTH_LIB + ".tmp", SYNTH_LIB)
-    return SYNTH_LIB
-
-
 if __name__ == "__main__":
     print(build(force="--force" in sys.argv, verbose=True))
-    print(build_synth(force="--force" in sys.argv))

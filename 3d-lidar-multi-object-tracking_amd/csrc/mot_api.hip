@@ -1957,20 +1957,10 @@ extern "C" int mot_debug_copy(mot_ctx* c, int which, int slot, void* dst, size_t
   return MOT_OK;
 }
 
-void mot_launch_sweep(const MotDevParams& p, int what, int mode, unsigned long long seed, unsigned long long count, void* d_stats, hipStream_t stream);
-
-// test hook (mot_debug_api.h): the guarded fast cells against their exact evaluation, on the device
-extern "C" int mot_debug_sweep(mot_ctx* c, int what, int mode, unsigned long long seed, unsigned long long count, unsigned long long* stats8) {
-  if (!c || !stats8 || what < 0 || what > 1 || mode < 0 || mode > 2) return MOT_E_ARG;
-  MOT_GUARD(c);
-  void* d = nullptr;
-  MOT_HIP(c, hipMalloc(&d, 8 * sizeof(unsigned long long)));
-  MOT_HIP(c, hipMemsetAsync(d, 0, 8 * sizeof(unsigned long long), c->stream));
-  mot_launch_sweep(c->dp, what, mode, seed, count, d, c->stream);
-  MOT_HIP(c, hipGetLastError());
-  MOT_HIP(c, hipMemcpyAsync(stats8, d, 8 * sizeof(unsigned long long), hipMemcpyDeviceToHost, c->stream));
-  MOT_HIP(c, hipStreamSynchronize(c->stream));
-  MOT_HIP(c, hipFree(d));
+// test hook (mot_debug_api.h): the context's device parameters, for the fast-path sweeps of tests/devcheck (a library of their own)
+extern "C" int mot_debug_dev_params(mot_ctx* c, void* dst, size_t bytes) {
+  if (!c || !dst || bytes < sizeof(MotDevParams)) return MOT_E_ARG;
+  memcpy(dst, &c->dp, sizeof(MotDevParams));
   return MOT_OK;
 }
 

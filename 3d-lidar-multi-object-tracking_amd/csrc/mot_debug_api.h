@@ -12,10 +12,9 @@ extern "C" {
  * 3 polygon pool, 5 cluster-sorted index, 7 cluster starts, 8 pixels, 9 (tile, cluster) groups, 10 polar thresholds hGround,
  * 11 the fused path's boxes in the global frame (the tracker's input)) */
 int mot_debug_copy(mot_ctx* ctx, int which, int slot, void* dst, size_t bytes);
-/* on-device sweep of a guarded fast path against its exact evaluation with the REAL hardware instructions (debug.hip):
- * what 0 polar cell, 1 Cartesian cell; mode 0 random, 1 lattice, 2 cell boundaries +-3 ulp. stats[0..4] = points, undecided,
- * mismatches, first mismatch (x bits | y bits << 32), its (fast | exact << 32). Synchronous. */
-int mot_debug_sweep(mot_ctx* ctx, int what, int mode, unsigned long long seed, unsigned long long count, unsigned long long* stats8);
+/* the context's device-side parameter block (MotDevParams, mot_internal.h; bytes >= 512 is enough): what the on-device sweeps of the guarded
+ * fast paths (tests/devcheck/sweep.hip -> libmot_sweep.so: test infrastructure, not in this library) are run with */
+int mot_debug_dev_params(mot_ctx* ctx, void* dst, size_t bytes);
 /* the float 3 x 4 matrix (row major) the fused path applies to take boxes from the sensor frame to the tracker's global frame */
 int mot_debug_tf_matrix(double x, double y, double yaw, float* m12);
 #ifdef __cplusplus

@@ -587,7 +587,7 @@ def selftest_cpu(args, rank, world):
     import build_emu
     lib = build_emu.build()
     mot = _load("mot_amd", os.path.join(PKG_DIR, "__init__.py"))
-    synth = _load("mot_amd.synth", os.path.join(PKG_DIR, "synth.py"))
+    synth = _load("mot_amd.synth", os.path.join(ROOT, "tools", "synth", "synth.py"))
     multi = _load("mot_amd.multi", os.path.join(PKG_DIR, "multi.py"))
     if world > 1:
         dist.init_process_group("gloo")
@@ -718,11 +718,10 @@ def main():
     build = _load("mot_amd.build", os.path.join(PKG_DIR, "build.py"))
     if not os.path.exists(build.LIB):
         build.build()
-    if not os.path.exists(build.SYNTH_LIB):
-        build.build_synth()
     mot = _load("mot_amd", os.path.join(PKG_DIR, "__init__.py"))
     multi = _load("mot_amd.multi", os.path.join(PKG_DIR, "multi.py"))
-    sdev = _load("mot_amd.synth_dev", os.path.join(PKG_DIR, "synth_dev.py"))
+    sdev = _load("mot_amd.synth_dev", os.path.join(ROOT, "tools", "synth", "synth_dev.py"))   # the workload generator: bench / test infrastructure
+    sdev.build_lib()
 
     B, N, F = args.batch, args.points, args.frames
     stride = ((N + 2047) // 2048) * 2048 + int(os.environ.get("MOT_BENCH_STRIDE_PAD", "0"))   # points between the frames of a batch (pad: address-interleave experiments)

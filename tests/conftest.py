@@ -27,7 +27,9 @@ def load_sub(name):
     if full in sys.modules:
         return sys.modules[full]
     load_pkg()
-    spec = importlib.util.spec_from_file_location(full, os.path.join(PKG_DIR, name + ".py"))
+    # the workload generators (synthetic clouds / rendered sequences) are bench + test infrastructure: tools/synth, not the product package
+    where = os.path.join(ROOT, "tools", "synth") if name in ("synth", "synth_dev") else PKG_DIR
+    spec = importlib.util.spec_from_file_location(full, os.path.join(where, name + ".py"))
     m = importlib.util.module_from_spec(spec)
     sys.modules[full] = m
     spec.loader.exec_module(m)

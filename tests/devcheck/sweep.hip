@@ -1,5 +1,6 @@
-// debug.hip — on-device self-checks of the guarded fast paths. Test support compiled into the library (entry point
-// mot_debug_sweep, declared in mot_debug_api.h, not part of include/mot.h); no product entry point launches these kernels.
+// sweep.hip — on-device self-checks of the guarded fast paths. TEST INFRASTRUCTURE: a library of its own (tests/devcheck/libmot_sweep.so,
+// built by tests/devcheck/build_sweep.py; until round 4 these kernels shipped inside libmot_hip.so). It includes the product's
+// mot_internal.h, so it runs the very device functions the streaming kernels inline; entry point mot_sweep_run below.
 //
 // The two streaming kernels decide a point's polar cell (ground stage) and its Cartesian cell (cluster stage) with cheap
 // estimates — the hardware's v_sqrt_f32 / v_rcp_f32, an atan polynomial, a multiply instead of a divide — and fall back to
@@ -8,12 +9,18 @@
 // require  try(x, y) in { -2 (undecided), exact(x, y) }  for every one of them.
 //   reference semantics: getCellIndexFromPoints + filterCloud, OT/src/groundremove/ground_removal.cpp:46-76;
 //                        mapCartesianGrid's index, OT/src/cluster/component_clustering.cpp:42-48
+#include <string.h>
+
 #include "mot_internal.h"
 
 #ifndef MOT_HIPEMU
 #define MOT_LAUNCH_BOUNDS(n) __launch_bounds__(n)
 #else
 #define MOT_LAUNCH_BOUNDS(n)
+#endif
+
+#ifdef MOT_HIPEMU
+__attribute__((used)) __shared__ int hipemu_lds_anchor;   // the emulator's launcher clears the "mot_lds" section: it has to exist in every library built against it
 #endif
 
 struct SweepStats {            // [0] points, [1] undecided, [2] mismatches, [3] first mismatch: x bits | y bits << 32, [4] its try / exact
@@ -97,9 +104,19 @@ sweep_kernel(MotDevParams p, int what, int mode, unsigned long long seed, unsign
   if (n_bad) atomicAdd(&out->v[2], n_bad);
 }
 
-void mot_launch_sweep(const MotDevParams& p, int what, int mode, unsigned long long seed, unsigned long long count, void* d_stats, hipStream_t stream) {
+// dev_params: the context's MotDevParams (mot_debug_dev_params, mot_debug_api.h). Synchronous, on the null stream.
+extern "C" int mot_sweep_run(const void* dev_params, int what, int mode, unsigned long long seed, unsigned long long count, unsigned long long* stats8) {
+  if (!dev_params || !stats8 || what < 0 || what > 1 || mode < 0 || mode > 2) return 1;
+  MotDevParams p;
+  memcpy(&p, dev_params, sizeof p);
+  SweepStats* d = nullptr;
+  if (hipMalloc(&d, sizeof(SweepStats)) != hipSuccess) return 3;
+  (void)hipMemset(d, 0, sizeof(SweepStats));
   const int per_thread = 256;
   const unsigned long long threads = (count + per_thread - 1) / per_thread;
   const unsigned blocks = (unsigned)((threads + 255) / 256);
-  if (blocks) hipLaunchKernelGGL(sweep_kernel, dim3(blocks), dim3(256), 0, stream, p, what, mode, seed, count, per_thread, (SweepStats*)d_stats);
+  if (blocks) hipLaunchKernelGGL(sweep_kernel, dim3(blocks), dim3(256), 0, 0, p, what, mode, seed, count, per_thread, d);
+  const bool ok = hipDeviceSynchronize() == hipSuccess && hipMemcpy(stats8, d, sizeof(SweepStats), hipMemcpyDeviceToHost) == hipSuccess;
+  (void)hipFree(d);
+  return ok ? 0 : 3;
 }

@@ -18,7 +18,7 @@ import importlib.util
 
 import oracle_lib as O
 
-spec = importlib.util.spec_from_file_location("synth", os.path.join(ROOT, "3d-lidar-multi-object-tracking_amd", "synth.py"))
+spec = importlib.util.spec_from_file_location("synth", os.path.join(ROOT, "tools", "synth", "synth.py"))
 S = importlib.util.module_from_spec(spec); spec.loader.exec_module(S)
 
 

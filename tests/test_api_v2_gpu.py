@@ -1,11 +1,15 @@
 """ABI-v2 entry points on the MI355X, through the C-ABI: the on-device proof of the guarded fast cells (real v_sqrt_f32 /
 v_rcp_f32), pipelined host ingest == resident path == oracle, batched device-box tracker step, polar-grid intermediates."""
 import ctypes as C
+import os
+import sys
 
 import numpy as np
 import pytest
 
 import hiprt
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "devcheck"))
 
 pytestmark = pytest.mark.gpu
 
@@ -15,14 +19,18 @@ def test_fast_cells_agree_with_exact_on_device(mot, hip_lib):
     (component_clustering.cpp:42-48). The streaming kernels answer from estimates built on the hardware's 1-ulp v_sqrt_f32 /
     v_rcp_f32; whenever they answer (not -2) the answer must be the exact evaluation's. > 4e9 points: uniform random, a
     2^16 x 2^16 lattice, and every channel spoke / bin ring / grid line moved by -3..+3 steps of 1..64 ulp in x and y, both presets."""
+    import build_sweep   # tests/devcheck: the sweep kernels are a test library of their own (until round 4 they shipped inside libmot_hip.so)
+    S = C.CDLL(build_sweep.build())
     total = 0
     for preset in (0, 1):
         with mot.Context(mot.params(preset), max_points=1024) as c:
+            dp = (C.c_char * 512)()
+            assert hip_lib.mot_debug_dev_params(c._h, dp, C.c_size_t(512)) == 0
             st = (C.c_ulonglong * 8)()
             for what, mode, count in ((0, 0, 1 << 30), (0, 1, 1 << 30), (0, 2, 1 << 29), (1, 0, 1 << 28), (1, 1, 1 << 28), (1, 2, 1 << 28)):
                 if preset == 1 and what == 0 and mode < 2:
                     continue   # the polar grid does not depend on the preset: boundaries only
-                rc = hip_lib.mot_debug_sweep(c._h, what, mode, C.c_ulonglong(1234567 + 17 * mode + preset), C.c_ulonglong(count), st)
+                rc = S.mot_sweep_run(dp, what, mode, C.c_ulonglong(1234567 + 17 * mode + preset), C.c_ulonglong(count), st)
                 assert rc == 0
                 assert st[0] == count
                 x = np.array([st[3] & 0xffffffff], np.uint32).view(np.float32)[0]; y = np.array([st[3] >> 32], np.uint32).view(np.float32)[0]

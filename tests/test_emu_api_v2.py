@@ -158,11 +158,16 @@ def test_profile_ring(mot, emu, synth):
 def test_fast_path_sweeps_on_the_emulator(mot, emu):
     """the sweep hook itself (the real check needs the hardware's v_sqrt / v_rcp: tests/test_ground_gpu.py)"""
     lib, L = emu
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "devcheck"))
+    import build_sweep
+    S = C.CDLL(build_sweep.build_emu())
     with mot.Context(lib_path=lib, max_points=1024) as c:
+        dp = (C.c_char * 512)()
+        assert L.mot_debug_dev_params(c._h, dp, C.c_size_t(512)) == 0
         st = (C.c_ulonglong * 8)()
         for what in (0, 1):
             for mode in (0, 1, 2):
-                assert L.mot_debug_sweep(c._h, what, mode, C.c_ulonglong(7), C.c_ulonglong(200000), st) == 0
+                assert S.mot_sweep_run(dp, what, mode, C.c_ulonglong(7), C.c_ulonglong(200000), st) == 0
                 assert st[0] == 200000 and st[2] == 0, (what, mode, list(st))
 
 

@@ -11,7 +11,7 @@ os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER
 torch.cuda.set_device(0)
 dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
 PKG = os.path.join(ROOT, "3d-lidar-multi-object-tracking_amd")
-mot = _load("mot_amd", os.path.join(PKG, "__init__.py")); synth = _load("mot_amd.synth", os.path.join(PKG, "synth.py")); multi = _load("mot_amd.multi", os.path.join(PKG, "multi.py"))
+mot = _load("mot_amd", os.path.join(PKG, "__init__.py")); synth = _load("mot_amd.synth", os.path.join(os.path.dirname(PKG), "tools", "synth", "synth.py")); multi = _load("mot_amd.multi", os.path.join(PKG, "multi.py"))
 B, N, K, NC = 4, 30000, 64, 2
 stride = 30720
 frames = []

@@ -38,7 +38,7 @@ def main():
     a = ap.parse_args()
     import torch
     mot = _load("mot_amd", os.path.join(PKG, "__init__.py"))
-    sdev = _load("mot_amd.synth_dev", os.path.join(PKG, "synth_dev.py"))
+    sdev = _load("mot_amd.synth_dev", os.path.join(os.path.dirname(PKG), "tools", "synth", "synth_dev.py"))
     dev = "cuda:0"
     B, N, S = a.frames, a.points, a.scenes
     F = B // S

@@ -1,5 +1,5 @@
 // synth.hip — synthetic 64-beam lidar sequences rendered on the GPU. BENCH / TEST DATA GENERATOR, built into its own
-// library (libmot_synth.so); nothing in libmot_hip.so or include/mot.h depends on it.
+// library (tools/synth/libmot_synth.so); nothing in libmot_hip.so or include/mot.h depends on it.
 //
 // No KITTI data ships with the reference or this image, and BASELINE.json's sequence configuration is 154
 // frames of ~120 k points per stream: 512 streams x 154 frames cannot be ray-cast on the host in any reasonable time, so

@@ -1,4 +1,5 @@
-"""Synthetic lidar SEQUENCES rendered on the GPU (bench / test data; csrc/synth.hip -> libmot_synth.so).
+"""Synthetic lidar SEQUENCES rendered on the GPU — BENCH / TEST DATA GENERATOR (tools/synth/synth.hip -> tools/synth/libmot_synth.so), not part of
+the product package: libmot_hip.so and include/mot.h do not depend on it.
 
 BASELINE.json's sequence configuration is the 154-frame KITTI drive_0005; no KITTI data exists here, so a
 street of oriented boxes — parked and moving cars, pedestrians, walls, poles — is laid out along the path the ego vehicle
@@ -18,8 +19,26 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(_HERE))
 SYNTH_LIB = os.path.join(_HERE, "libmot_synth.so")
-EGO_FIXTURE = os.path.join(os.path.dirname(_HERE), "tests", "golden", "ego_drive0005.npz")
+EGO_FIXTURE = os.path.join(ROOT, "tests", "golden", "ego_drive0005.npz")
+
+
+def build_lib(force: bool = False) -> str:
+    """synth.hip -> libmot_synth.so (hipcc, gfx950; cross-compiles without a GPU). Built in-tree so that it travels to the GPU box."""
+    import shutil
+    import subprocess
+    src = os.path.join(_HERE, "synth.hip")
+    if not force and os.path.exists(SYNTH_LIB) and os.path.getmtime(SYNTH_LIB) >= os.path.getmtime(src):
+        return SYNTH_LIB
+    hipcc = next((c for c in (os.environ.get("HIPCC"), shutil.which("hipcc"), "/opt/rocm/bin/hipcc") if c and os.path.exists(c)), None)
+    if hipcc is None:
+        raise RuntimeError("hipcc not found")
+    r = subprocess.run([hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-Wall", src, "-o", SYNTH_LIB + ".tmp"], capture_output=True, text=True)
+    if r.returncode != 0:
+        raise RuntimeError("hipcc failed:\n" + r.stdout + r.stderr)
+    os.replace(SYNTH_LIB + ".tmp", SYNTH_LIB)
+    return SYNTH_LIB
 MAX_OBJECTS = 256
 
 _KINDS = {  # half length, half width, height
@@ -116,7 +135,7 @@ class SequenceRenderer:
         self.device = torch.device(device)
         path = lib_path or SYNTH_LIB
         if not os.path.exists(path):
-            raise ImportError(f"{path} is missing — run `python __graft_entry__.py build`")
+            raise ImportError(f"{path} is missing — run `python __graft_entry__.py build` (or tools/synth/synth_dev.py build_lib())")
         self.lib = C.CDLL(path)
         self.lib.mot_synth_raycast.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float,
                                                C.c_ulonglong, C.c_void_p, C.c_void_p]

@@ -8,7 +8,7 @@ def _load(name, path):
 import torch
 torch.cuda.init()
 PKG = os.path.join(ROOT, "3d-lidar-multi-object-tracking_amd")
-mot = _load("mot_amd", os.path.join(PKG, "__init__.py")); synth = _load("mot_amd.synth", os.path.join(PKG, "synth.py")); build = _load("mot_amd.build", os.path.join(PKG, "build.py"))
+mot = _load("mot_amd", os.path.join(PKG, "__init__.py")); synth = _load("mot_amd.synth", os.path.join(os.path.dirname(PKG), "tools", "synth", "synth.py")); build = _load("mot_amd.build", os.path.join(PKG, "build.py"))
 B, N = 128, 120000
 stride = ((N + 2047) // 2048) * 2048
 host = np.zeros((B, stride, 4), np.float32)

@@ -9,7 +9,7 @@ def _load(name, path):
 import torch
 torch.cuda.init()
 PKG = os.path.join(ROOT, "3d-lidar-multi-object-tracking_amd")
-mot = _load("mot_amd", os.path.join(PKG, "__init__.py")); sdev = _load("mot_amd.synth_dev", os.path.join(PKG, "synth_dev.py"))
+mot = _load("mot_amd", os.path.join(PKG, "__init__.py")); sdev = _load("mot_amd.synth_dev", os.path.join(os.path.dirname(PKG), "tools", "synth", "synth_dev.py"))
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 512
 ids = [int(x) for x in sys.argv[2].split(",")] if len(sys.argv) > 2 else [30, 34, 31, 33, 2, 100]
 N, F = 120000, 2

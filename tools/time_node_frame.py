@@ -21,7 +21,7 @@ def _load(name, path):
 def main():
     reps = int(sys.argv[1]) if len(sys.argv) > 1 else 200
     mot = _load("mot_amd", os.path.join(PKG, "__init__.py"))
-    synth = _load("mot_amd.synth", os.path.join(PKG, "synth.py"))
+    synth = _load("mot_amd.synth", os.path.join(os.path.dirname(PKG), "tools", "synth", "synth.py"))
     with mot.Context(device=0, max_points=131072, max_batch=1, max_tracks_total=64) as c:
         clouds = [synth.make_cloud(120000, s, 0) for s in (0, 1)]
         L, h = c.lib, c._h

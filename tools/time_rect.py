@@ -8,7 +8,7 @@ def _load(name, path):
 import torch
 torch.cuda.init()
 PKG = os.path.join(ROOT, "3d-lidar-multi-object-tracking_amd")
-mot = _load("mot_amd", os.path.join(PKG, "__init__.py")); sdev = _load("mot_amd.synth_dev", os.path.join(PKG, "synth_dev.py")); build = _load("mot_amd.build", os.path.join(PKG, "build.py"))
+mot = _load("mot_amd", os.path.join(PKG, "__init__.py")); sdev = _load("mot_amd.synth_dev", os.path.join(os.path.dirname(PKG), "tools", "synth", "synth_dev.py")); build = _load("mot_amd.build", os.path.join(PKG, "build.py"))
 B, N = 128, 120000
 stride = ((N + 2047) // 2048) * 2048
 v, yaw = sdev.load_ego(2)

@@ -3,7 +3,7 @@ sys.path.insert(0, os.getcwd())
 import numpy as np, torch
 import bench
 mot = bench._load("mot_amd", os.path.join(bench.PKG_DIR, "__init__.py"))
-sdev = bench._load("mot_amd.synth_dev", os.path.join(bench.PKG_DIR, "synth_dev.py"))
+sdev = bench._load("mot_amd.synth_dev", os.path.join(bench.ROOT, "tools", "synth", "synth_dev.py"))
 seqmod = bench._load("mot_amd.sequence", os.path.join(bench.PKG_DIR, "sequence.py"))
 F, N = 154, 120000
 stride = ((N + 2047) // 2048) * 2048

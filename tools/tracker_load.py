@@ -10,7 +10,7 @@ def _load(name, path):
 import torch
 torch.cuda.init()
 PKG = os.path.join(ROOT, "3d-lidar-multi-object-tracking_amd")
-mot = _load("mot_amd", os.path.join(PKG, "__init__.py")); sdev = _load("mot_amd.synth_dev", os.path.join(PKG, "synth_dev.py"))
+mot = _load("mot_amd", os.path.join(PKG, "__init__.py")); sdev = _load("mot_amd.synth_dev", os.path.join(os.path.dirname(PKG), "tools", "synth", "synth_dev.py"))
 build = _load("mot_amd.build", os.path.join(PKG, "build.py"))
 S = int(sys.argv[1]) if len(sys.argv) > 1 else 128
 flags = [a for a in sys.argv[2:] if a.startswith("-D")]
