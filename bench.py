@@ -360,6 +360,82 @@ def tracker_stress(mot, torch, device, streams=128, loads=(8, 32, 64), frames=40
     return out
 
 
+def dense_scene(mot, sdev, torch, device, N, stride, streams=512, contexts=4, steps=2, phase=38, parity=True, lib=None):
+    """BASELINE.json configs[3] says "<= 64 tracks"; the street scene of the headline never shows the tracker more than ~25 at a time. This leg
+    is the SAME pipeline (ground removal -> clustering -> box fit -> tracker, inputs resident in HBM, `contexts` contexts, every stream a
+    154-frame sequence with the drive's ego motion) on the `plaza` scene of tools/synth/synth_dev.py: an open square of standing and strolling
+    people, 50-65 live tracks per stream throughout. Reported next to the headline, with its own parity check of stream 0 against the reference."""
+    F = 154
+    ego_v, ego_yaw = sdev.load_ego(F)
+    Bc = streams // contexts
+    seq, n_seq, _o, _p = sdev.SequenceRenderer(f"cuda:{device}").render([7000 + s for s in range(Bc)], F, N, stride, ego_v, ego_yaw, scene="plaza")
+    n_seq = np.ascontiguousarray(n_seq, np.int32)
+    ctxs = [mot.Context(device=device, max_points=stride, max_batch=Bc, max_tracks_total=256) for _ in range(contexts)]
+    ptr = [seq[f].data_ptr() for f in range(F)]
+    ts_f = [np.full(Bc, 1.0e9 + f * 1.0e5) for f in range(F)]; ev_f = [np.full(Bc, ego_v[f]) for f in range(F)]; ey_f = [np.full(Bc, ego_yaw[f]) for f in range(F)]
+    pos = [0] * contexts
+
+    def issue(ci):
+        f = pos[ci] % F
+        if f == 0:
+            ctxs[ci].reset()
+        ctxs[ci].frames_dev(ptr[f], stride * 4, n_seq[f], run_tracker=True, timestamps=ts_f[f], ego_v=ev_f[f], ego_yaw=ey_f[f])
+        pos[ci] += 1
+
+    def run(nf, extra=None):
+        for k in range(nf + (max(extra) if extra else 0)):
+            for ci in range(contexts):
+                if k < nf + (extra[ci] if extra else 0):
+                    issue(ci)
+
+    run(F, extra=[(phase * ci) % F for ci in range(contexts)])   # one untimed step + the contexts' phase offsets
+    for c in ctxs:
+        c.synchronize()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    run(steps * F)
+    for c in ctxs:
+        c.synchronize()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    # the tracker's launches with the GPU to themselves (one context, the whole pipeline in place): HIP event pairs around the step
+    c0 = ctxs[0]
+    c0.reset(); c0.profile_kernel(K_IDS["track_step_kernel"], 1)
+    live_hist = []
+    for f in range(60):
+        c0.frames_dev(ptr[f], stride * 4, n_seq[f], run_tracker=True, timestamps=ts_f[f], ego_v=ev_f[f], ego_yaw=ey_f[f])
+        if f in (20, 40, 59):
+            live_hist.append([int((c0.get_tracks(b)["track_manage"] > 0).sum()) for b in range(min(Bc, 16))])
+    trk = c0.profile_read(); c0.profile_kernel(0, 1)
+    nb = [len(c0.get_boxes(b)["boxes"]) for b in range(min(Bc, 16))]
+    ne = [c0.get_ground(b, want_clouds=False)["n_elevated"] for b in range(min(Bc, 16))]
+    for c in ctxs:
+        c.close()
+    live = np.array(live_hist)
+    out = {"value": round(streams * F * steps / dt, 1), "unit": "frames/s", "steps": steps, "ms_per_step": round(dt / steps * 1e3, 3), "streams": streams, "contexts": contexts,
+           "frames_per_stream_per_step": F, "points_per_frame": N, "scene": "plaza",
+           "live_tracks_per_stream": {"mean": round(float(live.mean()), 1), "min": int(live.min()), "max": int(live.max()), "sampled": "16 streams at frames 20, 40, 59"},
+           "boxes_per_frame_mean": round(float(np.mean(nb)), 1), "elevated_pts_per_frame": int(np.mean(ne)),
+           "tracker_step_us_alone": {"mean": round(trk["mean_ms"] * 1e3, 1), "min": round(trk["min_ms"] * 1e3, 1), "max": round(trk["max_ms"] * 1e3, 1), "samples": trk["samples"],
+                                     "what": f"the tracker's launches of one {Bc}-stream context with the GPU to itself (the whole pipeline in place), HIP event pairs"},
+           "what": "the headline's pipeline and harness on the tracker-load scene (an open square of standing and strolling people instead of the street): what BASELINE.json configs[3]'s "
+                   "'<= 64 tracks' asks of the tracker, in the rendered workload itself (tracker_stress drives the tracker alone with synthetic boxes)"}
+    if parity:
+        try:
+            gpu_res = gpu_sequence_results(mot, device, seq, n_seq, stride, ego_v, ego_yaw, 0)
+            frames_host = seq[:, 0, :N].cpu().numpy()
+            del seq
+            _base, par = cpu_baseline(frames_host, ego_v, ego_yaw, N, budget_s=4.0, gpu_results=gpu_res, n_per_frame=n_seq[:, 0], lib=lib, quick=True)
+            keys = ("frames", "masks_boxes_bit_exact", "track_sets_equal", "states_within_1e-4", "states_within_bar", "states_explained_by_reference_noise", "max_rel_state_err",
+                    "track_frames_above_1e-4", "track_frames_above_1e-4_unexplained", "set_aside_track_frames", "state_compares", "live_tracks_max", "tracks_ever", "boxes_total",
+                    "first_mismatch_frame")
+            out["parity_check"] = {k: par.get(k) for k in keys}
+        except Exception:
+            import traceback
+            out["parity_check"] = {"error": traceback.format_exc()[-600:]}
+    return out
+
+
 def single_stream(mot, torch, device, seq_dev, n_seq, stride, ego_v, ego_yaw, frame_bytes):
     """the PER-FRAME figures next to the batched headline ("show both per-frame and batched numbers"): ONE sensor
     stream, one frame per launch sequence — the reference's own operating point (a 10 Hz lidar through three nodes). Inputs are
@@ -657,6 +733,9 @@ def main():
     ap.add_argument("--contexts", type=int, default=4, help="contexts (HIP streams) per GPU the streams are split over: the latency-bound "
                     "kernels of one (CCL, polygon, tracker: one workgroup per stream) overlap the streaming kernels of the others")
     ap.add_argument("--density", type=float, default=1.0, help="scene density (cars / pedestrians) of the synthetic street")
+    ap.add_argument("--scene", choices=("street", "plaza"), default="street",
+                    help="street: the default workload (~17 live tracks per stream); plaza: the tracker-load scene, 50-65 live tracks per stream (the default run reports it as the dense_scene leg)")
+    ap.add_argument("--no-dense-scene", action="store_true", help="skip the dense_scene leg (plaza scene, 512 streams) of the default run")
     ap.add_argument("--issue-threads", type=int, default=0, help="0 (default): one host thread issues every context's launches, frame by frame, in a fixed order (also the order of the "
                     "collectives on every rank); 1: a host thread per context (measured equal: the launch queues, not the host, hold the pace — profiles/r02_issue_threads_contexts_sweep.txt)")
     ap.add_argument("--phase", type=int, default=38, help="frames by which context c runs ahead of context c-1 within the (shared) sequences: at any instant the contexts' launches "
@@ -755,7 +834,7 @@ def main():
         renderer = sdev.SequenceRenderer(f"cuda:{local}")
         while True:
             try:
-                seq_dev, n_seq, _objs, _path = renderer.render([1000 * rank + s for s in range(Bc)], F, N, stride, ego_v, ego_yaw, density=args.density)
+                seq_dev, n_seq, _objs, _path = renderer.render([1000 * rank + s for s in range(Bc)], F, N, stride, ego_v, ego_yaw, density=args.density, scene=args.scene)
                 break
             except RuntimeError as e:   # the sequences do not fit this device's free HBM: halve the streams and say so
                 if "out of memory" not in str(e).lower() or Bc < 2:
@@ -973,7 +1052,7 @@ def main():
                        "frames_per_step_per_gpu": B * F, "contexts_per_gpu": NC, "frames_per_launch": BL, "context_phase_frames": args.phase,
                        "elevated_pts_per_frame": ne_tot // BL, "clusters_last_frame_stream0": cl0["num_cluster"], "boxes_last_frame_stream0": len(bx0["boxes"]),
                        "tracks_ever_stream0": int(tr0["n"]), "live_tracks_per_stream": {"mean": round(float(np.mean(live)), 1), "max": int(np.max(live)), "streams_sampled": len(live)},
-                       "render_s": round(render_s, 1), "scene_density": args.density, "kitti": kitti,
+                       "render_s": round(render_s, 1), "scene": args.scene, "scene_density": args.density, "kitti": kitti,
                        "parallelism": f"stream-sharded x{world}" + (", all_gather of live-track records per frame (RCCL)" if world > 1 else "")},
             "roofline": {"bound": "hbm", "kernel": dom_kernel, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_src,
@@ -1046,6 +1125,14 @@ def main():
                 out["host_boundary_pipelined"] = None
                 print(f"host_boundary_pipelined failed: {e}", file=sys.stderr)
         del seq_dev
+        torch.cuda.empty_cache()
+        if not args.no_aux and not args.no_dense_scene and world == 1 and not kitti and args.scene == "street" and N == 120000:
+            try:
+                out["dense_scene"] = dense_scene(mot, sdev, torch, local, N, stride, parity=not args.no_cpu_baseline, lib=mot.load_library(variant) if variant else mot.load_library())
+                out["dense_scene"]["vs_headline"] = round(out["dense_scene"]["value"] / out["value"], 4)
+            except Exception as e:
+                out["dense_scene"] = None
+                print(f"dense_scene failed: {e}", file=sys.stderr)
         if frames_host is not None:
           try:
             out["cpu_baseline"], out["parity_check"] = cpu_baseline(frames_host, ego_v, ego_yaw, N, gpu_results=gpu_res, n_per_frame=n_seq[:, 0], lib=mot.load_library(variant) if variant else mot.load_library())
