@@ -240,6 +240,11 @@ def cpu_baseline(frames: np.ndarray, ego_v, ego_yaw, n_points: int, budget_s: fl
         parity["states_within_1e-4"] = bool(within_well and stats.get("above_bar", 0) == 0)
         parity["states_within_bar"] = bool(within_well and (stats.get("above_bar", 0) == 0 or explained))
         parity["states_explained_by_reference_noise"] = bool(within_well and stats.get("above_bar", 0) > 0 and explained)
+        # the weakest statement, and the one the -m gpu sequence tests assert (assert_floor): every live track-frame — set aside or not — is within 1e-4 OR within
+        # 10 x the difference between the reference's OWN builds on that very track-frame (a scene of 60 coasting pedestrian tracks has track-frames the narrow criterion
+        # does not flag — a model covariance with a negative variance under a sane merged one — on which libmot_ref.so and its rebuilds are 1e-3 .. 5e-1 apart)
+        parity["states_within_1e-4_or_reference_noise"] = bool(stats.get("max_rel_state_err") is not None and (stats.get("above_bar", 0) == 0 or explained))
+        parity["above_1e-4_worst_err_over_reference_noise"] = round(stats["above_bar_err_over_floor_max"], 3) if "above_bar_err_over_floor_max" in stats else None
         parity.update({"max_rel_state_err": stats.get("max_rel_state_err"), "track_frames_above_1e-4": stats.get("above_bar", 0),
                        "track_frames_above_1e-4_unexplained": fsum["above_1e-4_unexplained"] if fsum["track_frames_with_floor"] or not stats.get("above_bar", 0) else None,
                        "track_frames_above_1e-4_not_set_aside": stats.get("above_bar_well_conditioned", 0),
@@ -247,6 +252,7 @@ def cpu_baseline(frames: np.ndarray, ego_v, ego_yaw, n_points: int, budget_s: fl
                        "set_aside_by": stats.get("set_aside_by", {}), "max_rel_state_err_set_aside": stats.get("max_rel_state_err_ill_conditioned"),
                        "noise_floor_ill_conditioned": fsum["noise_floor"], "device_err_over_noise_floor_set_aside": fsum["device_err_over_floor"],
                        "set_aside_above_10x_floor": fsum["set_aside_above_10x_floor"], "unexplained_detail": fsum["unexplained_detail"] or None,
+                       "above_bar_detail": stats.get("above_bar_detail"),
                        "noise_floor_replicas": {"in_use_last_frame": kept[-1]["replicas"] if kept else [], "retired_at_frame": getattr(run_single, "replicas_retired", {})},
                        "set_aside_means": "NARROW criterion (tests/seq_parity.py conditioning): NaN / Inf, |yaw rate| >= 20 rad/s, a covariance entry >= 1e3, a non-positive variance — a filter the reference's own guards "
                                           "(P(4,4) > 1000, det P > 10: imm_ukf_jpda.cpp:826-851) are about to kill. No conditioning memory, no yaw-variance rule (round 3's wider criterion). A set-aside track-frame is not "
@@ -426,9 +432,10 @@ def dense_scene(mot, sdev, torch, device, N, stride, streams=512, contexts=4, st
             frames_host = seq[:, 0, :N].cpu().numpy()
             del seq
             _base, par = cpu_baseline(frames_host, ego_v, ego_yaw, N, budget_s=4.0, gpu_results=gpu_res, n_per_frame=n_seq[:, 0], lib=lib, quick=True)
-            keys = ("frames", "masks_boxes_bit_exact", "track_sets_equal", "states_within_1e-4", "states_within_bar", "states_explained_by_reference_noise", "max_rel_state_err",
+            keys = ("frames", "masks_boxes_bit_exact", "track_sets_equal", "states_within_1e-4", "states_within_bar", "states_explained_by_reference_noise",
+                    "states_within_1e-4_or_reference_noise", "above_1e-4_worst_err_over_reference_noise", "track_frames_above_1e-4_not_set_aside", "max_rel_state_err",
                     "track_frames_above_1e-4", "track_frames_above_1e-4_unexplained", "set_aside_track_frames", "state_compares", "live_tracks_max", "tracks_ever", "boxes_total",
-                    "first_mismatch_frame")
+                    "first_mismatch_frame", "above_bar_detail", "noise_floor_ill_conditioned")
             out["parity_check"] = {k: par.get(k) for k in keys}
         except Exception:
             import traceback

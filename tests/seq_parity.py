@@ -224,6 +224,7 @@ def compare_tracks(a, o, state_dev, state_orc, where, rtol=RTOL, stats=None, ski
                 if not nan.all() and np.isfinite(rtol):   # (rtol = inf: the caller only collects the state errors)
                     assert np.abs(av[~nan] - ov[~nan]).max() <= rtol * np.abs(ov[~nan]).max() + atol, (where, int(i), key, av, ov)
         w_i = 0.0
+        w_key = None
         for k in STATE_KEYS:
             so_k = np.asarray(so[k], np.float64); sd_k = np.asarray(sd[k], np.float64).reshape(so_k.shape)
             nan = np.isnan(so_k)
@@ -238,6 +239,8 @@ def compare_tracks(a, o, state_dev, state_orc, where, rtol=RTOL, stats=None, ski
                                                      "x_merge", list(np.asarray(so["x_merge"])), "diag P", list(np.diag(np.asarray(so["p_merge"]).reshape(5, 5))),
                                                      "lifetime", so["lifetime"], "track_manage", so["track_manage"])
             if scale > 1e-6:
+                if err / scale > w_i:
+                    w_key = (k, int(np.argmax(np.abs(np.where(nan, 0.0, sd_k - so_k)))))
                 w_i = max(w_i, err / scale)
         fl = None
         if floor is not None and (ill or w_i > RTOL):
@@ -255,6 +258,13 @@ def compare_tracks(a, o, state_dev, state_orc, where, rtol=RTOL, stats=None, ski
                     stats.setdefault("set_aside_by", {})[q] = stats.setdefault("set_aside_by", {}).get(q, 0) + 1
             if w_i > RTOL:   # whatever the conditioning: how many live track-frames differ by more than the bar at all
                 stats["above_bar"] = stats.get("above_bar", 0) + 1
+                if fl is not None and fl > 0:
+                    stats["above_bar_err_over_floor_max"] = max(stats.get("above_bar_err_over_floor_max", 0.0), w_i / fl)
+                if len(stats.setdefault("above_bar_detail", [])) < 6 and w_key is not None:   # which entry of which matrix, and what the filter looked like
+                    kk, at = w_key
+                    stats["above_bar_detail"].append(dict(where=str(where), track=int(i), err=float(w_i), floor=None if fl is None else float(fl), set_aside=list(why), key=kk, entry=at,
+                                                         device=float(np.asarray(sd[kk], np.float64).reshape(-1)[at]), oracle=float(np.asarray(so[kk], np.float64).reshape(-1)[at]),
+                                                         lifetime=int(so["lifetime"])))
                 if not ill:
                     stats["above_bar_well_conditioned"] = stats.get("above_bar_well_conditioned", 0) + 1
             if fl is not None:
