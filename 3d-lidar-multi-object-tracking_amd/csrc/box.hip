@@ -126,6 +126,7 @@ label_stats_kernel(MotDevParams p, ClusterBuffers c) {
   B1_T_BEGIN(c, b);
   const int num_cluster = c.counts[b * kCountsStride + kCntClusters];
   const float4* __restrict__ pts = c.elevated + (long)b * c.cap;
+  const int packed = c.elevated_packed;   // uniform: 12-byte points from the fused path's compaction kernel
   const GridLabel* __restrict__ grid = c.grid + (long)b * (MOT_MAX_GRID * MOT_MAX_GRID);
   int* __restrict__ label = c.label ? c.label + (long)b * c.cap : nullptr;   // null: the fused path without MOT_OUT_LABELS (point_labels_kernel on demand)
   int* __restrict__ pix = c.pix + (long)b * c.cap;
@@ -140,7 +141,7 @@ label_stats_kernel(MotDevParams p, ClusterBuffers c) {
 #pragma unroll
   for (int k = 0; k < kLabelItems; k++) {
     long i = base + k * kLabelBlock + threadIdx.x;
-    qs[k] = i < n ? pts[i] : make_float4(1.0e9f, 1.0e9f, 0.f, 0.f);   // outside every ROI
+    qs[k] = i < n ? mot_load_xyz(pts, i, packed) : make_float4(1.0e9f, 1.0e9f, 0.f, 0.f);   // outside every ROI
   }
   if (c.ecell) {   // fused path: the compaction kernel filed every elevated point under this cell already and left it behind, 2 bytes per point
     const unsigned short* __restrict__ ecell = c.ecell + (long)b * c.cap;
@@ -562,18 +563,19 @@ cluster_gather_kernel(MotDevParams p, ClusterBuffers c) {
     const int g_mine = ng - g_first < per ? (ng - g_first > 0 ? ng - g_first : 0) : per;
     SortedGroup rec; rec.mask = 0ull; rec.tile = 0; rec.before = 0;
     if (lane < g_mine && lane < kRecBatch) rec = gsorted[gs + g_first + lane];
-    const float4 first = pts[st.first];
+    const int packed = c.elevated_packed;
+    const float4 first = mot_load_xyz(pts, st.first, packed);
     const float initPX = first.x + p.roi_half, initPY = first.y + p.roi_half;  // :218-225
     const int initX = (int)floorf(initPX * p.pic_scale), initY = (int)floorf(initPY * p.pic_scale);
     const int initPicX = initX;
     const int initPicY = (int)(p.pic_full - (float)initY);
     const int offsetInitX = (int)(p.pic_half - (float)initPicX);
     const int offsetInitY = (int)(p.pic_half - (float)initPicY);
-    const float4 pmin = pts[(unsigned)(st.argmin & 0xffffffffull)];
-    const float4 pmax = pts[~(unsigned)(st.argmax & 0xffffffffull)];
+    const float4 pmin = mot_load_xyz(pts, (unsigned)(st.argmin & 0xffffffffull), packed);
+    const float4 pmax = mot_load_xyz(pts, ~(unsigned)(st.argmax & 0xffffffffull), packed);
     const float minMx = pmin.x, minMy = pmin.y, maxMx = pmax.x, maxMy = pmax.y;
     float maxZ = mot_key_float(st.maxz_key);
-    if (maxZ == 0.0f && st.first_zero != 0x7fffffff) maxZ = pts[st.first_zero].z;   // -0 or +0, whichever came first
+    if (maxZ == 0.0f && st.first_zero != 0x7fffffff) maxZ = mot_load_xyz(pts, st.first_zero, packed).z;   // -0 or +0, whichever came first
     const float xDist = maxMx - minMx, yDist = maxMy - minMy;  // :296-300
     const float slopeDist = sqrtf(xDist * xDist + yDist * yDist);
     const float slope = (maxMy - minMy) / (maxMx - minMx);
@@ -690,7 +692,8 @@ cluster_gather_kernel(MotDevParams p, ClusterBuffers c) {
       for (int j = lane; j < nsamp; j += 64) {
         int pi = s_pidx[j];
         if (pi >= 0) {
-          float xI = pts[pi].x, yI = pts[pi].y;
+          const float4 qI = mot_load_xyz(pts, pi, packed);
+          float xI = qI.x, yI = qI.y;
           float dist = fabsf(slope * xI - 1 * yI + maxMy - slope * maxMx) / sqrtf(slope * slope + 1);
           if (dist > 0.f) {  // `dist > maxDist`, maxDist = 0 (NaN never)
             unsigned long long key = ((unsigned long long)__float_as_uint(dist) << 32) | (unsigned)(0xffff - j);
@@ -702,7 +705,8 @@ cluster_gather_kernel(MotDevParams p, ClusterBuffers c) {
       const bool undef = best == 0ull;   // maxDx/maxDy would be read uninitialised (H7)
       if (!undef) {
         int j = 0xffff - (int)(best & 0xffffull);
-        const float maxDx = pts[s_pidx[j]].x, maxDy = pts[s_pidx[j]].y;
+        const float4 qD = mot_load_xyz(pts, s_pidx[j], packed);
+        const float maxDx = qD.x, maxDy = qD.y;
         float maxMvecX = maxMx - maxDx, maxMvecY = maxMy - maxDy;
         float minMvecX = minMx - maxDx, minMvecY = minMy - maxDy;
         float lastX = maxDx + maxMvecX + minMvecX;
@@ -1220,7 +1224,7 @@ point_labels_kernel(MotDevParams p, ClusterBuffers c, int b) {
       const unsigned e = c.ecell[(long)b * c.cap + i];
       cell = e != 0xffffu ? (int)((e >> 8) * (unsigned)p.num_grid + (e & 255u)) : -1;
     } else {
-      const float4 q = c.elevated[(long)b * c.cap + i];
+      const float4 q = mot_load_xyz(c.elevated + (long)b * c.cap, i, c.elevated_packed);
       const int bit = mot_cart_bit(p, q.x, q.y);
       cell = bit >= 0 ? (bit >> 8) * p.num_grid + (bit & 255) : -1;
     }

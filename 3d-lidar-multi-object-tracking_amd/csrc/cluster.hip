@@ -54,7 +54,7 @@ cart_occupancy_kernel(MotDevParams p, ClusterBuffers c) {
 #pragma unroll
   for (int k = 0; k < kOccItems; k++) {
     long i = base + k * kOccBlock + threadIdx.x;
-    q[k] = i < n ? pts[i] : make_float4(1.0e9f, 1.0e9f, 0.f, 0.f);   // outside every ROI
+    q[k] = i < n ? mot_load_xyz(pts, i, c.elevated_packed) : make_float4(1.0e9f, 1.0e9f, 0.f, 0.f);   // outside every ROI
   }
 #pragma unroll
   for (int k = 0; k < kOccItems; k++) {

@@ -274,7 +274,6 @@ polar_filter_kernel(MotDevParams p, GroundBuffers g) {
   // flips, and the heights read are those of ground cells, which this pass does not touch. Hence in place, concurrently.
   for (int i = threadIdx.x; i < MOT_POLAR_CELLS; i += kFilterBlock) {
     int ch = i / MOT_NUM_BIN, bin = i % MOT_NUM_BIN;
-    float h = s_h[i];
     bool ground = s_g[i];
     if (!ground && ch >= 1 && ch < MOT_NUM_CHANNEL - 1 && bin >= 1 && bin < MOT_NUM_BIN - 1 &&
         s_g[i + 1] && s_g[i - 1] && s_g[i + MOT_NUM_BIN] && s_g[i - MOT_NUM_BIN]) {
@@ -525,6 +524,7 @@ __device__ __forceinline__ void classify_compact_body(const MotDevParams& p, con
   float4* __restrict__ out_g = kGround ? g.ground + (long)b * g.cap : nullptr;
   unsigned short* __restrict__ ecell = (g.ecell && occupancy) ? g.ecell + (long)b * g.cap : nullptr;   // (the cells exist only with the occupancy)
   const int be0 = s_base_e, bg0 = s_base_g;
+  const bool packed = !kGround && g.elevated_packed;   // uniform
 #pragma unroll
   for (int k = 0; k < kCompactItems; k++) {
     const int ex = s_cnt[k * (kCompactBlock / 64) + wave];   // the tile's exclusive prefixes (wave-uniform)
@@ -536,7 +536,11 @@ __device__ __forceinline__ void classify_compact_body(const MotDevParams& p, con
       if (ecell && is_e) ecell[at] = (unsigned short)bits[k];
     } else {
       const int at = be0 + (ex >> 16) + rank[k];
-      if (is_e) { out_e[at] = pt[k]; if (ecell) ecell[at] = (unsigned short)bits[k]; }
+      if (is_e) {
+        if (packed) { PackedXyz q; q.x = pt[k].x; q.y = pt[k].y; q.z = pt[k].z; reinterpret_cast<PackedXyz*>(out_e)[at] = q; }   // 12 bytes a point (mot_internal.h)
+        else out_e[at] = pt[k];
+        if (ecell) ecell[at] = (unsigned short)bits[k];
+      }
     }
   }
   if (wave == 0) side_work();

@@ -135,6 +135,7 @@ struct mot_ctx {
   // per-point cluster labels of a slot: 1 = in d_label; 0 = not computed, the slot's cloud and cells come from the fused compaction kernel;
   // 2 = not computed, the slot's cloud was uploaded by a stage-wise call (no cells). mot_get_clusters computes them on demand.
   std::vector<char> label_state;
+  bool elev_packed = false;           // the elevated clouds now resident are 12-byte points (the fused path's elevated-only compaction: mot_internal.h PackedXyz)
   std::vector<char> box_valid;        // per slot: the box stage's products (boxes, cluster order, groups) belong to the cloud now resident in the slot
   bool ground_resident = false;        // d_ground / d_mask hold the last batch's ground cloud and mask
   bool last_fused = false;             // the last ground launch was a fused one (input, cells and thresholds of the batch still resident)
@@ -328,7 +329,7 @@ static int arg_block_commit(mot_ctx* c, size_t off, size_t bytes) {
 
 static ClusterBuffers cluster_buffers(mot_ctx* c) {
   ClusterBuffers b;
-  b.elevated = c->d_elev; b.cap = c->cap; b.counts = c->d_counts; b.plane_a = c->d_plane_a; b.plane_b = c->d_plane_b; b.ccl_parent = c->d_ccl_parent;
+  b.elevated = c->d_elev; b.elevated_packed = c->elev_packed ? 1 : 0; b.cap = c->cap; b.counts = c->d_counts; b.plane_a = c->d_plane_a; b.plane_b = c->d_plane_b; b.ccl_parent = c->d_ccl_parent;
   b.occ_list = nullptr; b.occ_count = nullptr; b.n_in = c->d_n; b.occ_chunks = c->occ_chunks;   // the fused path points these at the compaction kernel's lists
   b.grid = c->d_grid; b.label = c->d_label; b.stats = c->d_stats; b.cand = c->d_cand; b.boxes = c->d_boxes;
   b.box_cluster = c->d_box_cluster; b.rng = c->d_rng; b.poly = c->d_poly; b.groups = c->d_groups; b.group_cap = c->cap / 2; b.cluster_start = c->d_cluster_start; b.cluster_gstart = c->d_cluster_gstart; b.order = c->d_order; b.gsorted = c->d_gsorted;
@@ -529,7 +530,7 @@ static GroundBuffers ground_buffers(mot_ctx* c, const float4* in, long stride, b
   g.launch = nullptr;
   g.epoch = c->epoch;
   g.in = in; g.in_stride = stride; g.n = c->d_n; g.pairs = c->d_pairs; g.pair_count = c->d_pair_count; g.hg = c->d_hg; g.cell = c->d_cell; g.desc = c->d_desc;
-  g.ticket = c->d_ticket; g.elevated = c->d_elev; g.ground = c->d_ground; g.mask = want_mask ? c->d_mask : nullptr;
+  g.ticket = c->d_ticket; g.elevated = c->d_elev; g.elevated_packed = 0; g.ground = c->d_ground; g.mask = want_mask ? c->d_mask : nullptr;
   g.counts = c->d_counts; g.cap = c->cap; g.max_chunks = c->max_chunks;
   g.occ_list = planes ? c->d_occ_list : nullptr; g.occ_count = planes ? c->d_occ_count : nullptr; g.occ_chunks = c->occ_chunks;
   g.ecell = (planes && c->params.num_grid < MOT_MAX_GRID) ? c->d_ecell : nullptr;   // (a 256-cell grid uses all 65536 codes: no "outside" left)
@@ -685,6 +686,8 @@ RangeScope::RangeScope(const mot_ctx* c, const char* name) : on(false) {
 static void issue_frame_kernels(mot_ctx* c, int batch, int max_n, int run_tracker, bool want_ground, bool want_mask, bool from_block) {
   GroundBuffers g = ground_buffers(c, c->last_in, c->last_in_stride, want_mask, true);
   if (!want_ground) g.ground = nullptr;   // the ground cloud on demand (mot_get_ground re-runs the compaction)
+  c->elev_packed = MOT_PACKED_ELEVATED && !want_ground;   // the elevated-only compaction leaves 12-byte points; every reader below is told (cluster_buffers)
+  g.elevated_packed = c->elev_packed ? 1 : 0;
   if (from_block) g.launch = reinterpret_cast<const FrameLaunch*>(c->d_argblk + c->arg_off_launch);
   {
     RangeScope rs(c, "mot:ground");
@@ -1039,6 +1042,7 @@ extern "C" int mot_cluster(mot_ctx* c, const float* elev, int n, int32_t* grid, 
   int rc;
   if (n > 0) MOT_HIP(c, hipMemcpyAsync(c->d_elev, elev, (size_t)n * 16, hipMemcpyHostToDevice, c->stream));
   c->last_fused = false;   // slot 0 now holds this call's cloud: mot_get_ground must not re-run a fused batch's compaction over it
+  c->elev_packed = false;  // ... as float4 records
   if ((rc = set_count(c, 0, kCntElev, n))) return rc;
   ClusterBuffers cb = cluster_buffers(c);
   mot_launch_cluster(c->dp, cb, 1, n, c->stream);
@@ -1070,6 +1074,7 @@ extern "C" int mot_box_fit(mot_ctx* c, const float* elev, int n, const int32_t* 
   MOT_HIP(c, hipMemcpyAsync(c->d_grid, c->h_grid16.data(), (size_t)G * G * sizeof(GridLabel), hipMemcpyHostToDevice, c->stream));
   MOT_HIP(c, hipStreamSynchronize(c->stream));   // (h_grid16 is reused by the next call)
   c->last_fused = false;   // slot 0 now holds this call's cloud: mot_get_ground must not re-run a fused batch's compaction over it
+  c->elev_packed = false;
   if ((rc = set_count(c, 0, kCntElev, n))) return rc;
   if ((rc = set_count(c, 0, kCntClusters, num_cluster))) return rc;
   ClusterBuffers cb = cluster_buffers(c);
@@ -1139,7 +1144,7 @@ static int side_setup(mot_ctx* c, int slot, const mot_side_params* sp, SideDevPa
   d.center_y = (sp->cost_height / 2.0) * sp->cost_resolution - sp->cost_offset_y;   // map_center_y, :429
   d.height_limit = sp->height_limit; d.car_length = sp->car_length; d.car_width = sp->car_width;
   SideBuffers s;
-  s.elevated = c->d_elev + (size_t)slot * c->cap; s.grid = c->d_grid + (size_t)slot * MOT_MAX_GRID * MOT_MAX_GRID;
+  s.elevated = c->d_elev + (size_t)slot * c->cap; s.elevated_packed = c->elev_packed ? 1 : 0; s.grid = c->d_grid + (size_t)slot * MOT_MAX_GRID * MOT_MAX_GRID;
   s.counts = c->d_counts + (size_t)slot * kCountsStride; s.cell_first = c->d_side_cell; s.clustered = c->d_side_cloud;
   s.obstacles = c->d_side_obs; s.cost = c->d_side_cost; s.out_counts = c->d_side_counts; s.chunk_counts = c->d_side_chunks;
   s.max_clustered = c->cap; s.max_obstacles = MOT_MAX_GRID * MOT_MAX_GRID;
@@ -1200,6 +1205,7 @@ extern "C" int mot_cluster_products_host(mot_ctx* c, const float* elev, int n, c
   MOT_HIP(c, hipMemcpyAsync(c->d_grid, c->h_grid16.data(), (size_t)G * G * sizeof(GridLabel), hipMemcpyHostToDevice, c->stream));
   MOT_HIP(c, hipStreamSynchronize(c->stream));
   c->last_fused = false;   // slot 0 now holds this call's cloud: mot_get_ground must not re-run a fused batch's compaction over it
+  c->elev_packed = false;
   c->box_valid[0] = 0;
   int rc = set_count(c, 0, kCntElev, n);
   if (rc) return rc;
@@ -1252,6 +1258,7 @@ extern "C" int mot_cluster_node_frame(mot_ctx* c, const float* elev, int n, cons
   if ((rc = pinned_scratch(c, total, &pin))) return rc;
   if (n > 0) MOT_HIP(c, hipMemcpyAsync(c->d_elev, elev, (size_t)n * 16, hipMemcpyHostToDevice, c->stream));
   c->last_fused = false;   // slot 0 now holds this call's cloud
+  c->elev_packed = false;
   if ((rc = set_count(c, 0, kCntElev, n))) return rc;
   ClusterBuffers cb = cluster_buffers(c);
   mot_launch_cluster(c->dp, cb, 1, n, c->stream);
@@ -1305,7 +1312,7 @@ extern "C" int mot_get_ground(mot_ctx* c, int slot, float* elev, int* n_elev, fl
   if (n_ground) *n_ground = ng;
   if ((elev && ne > capacity_points) || (ground && ng > capacity_points) || (mask && c->h_n[slot] > capacity_points))
     return fail(c, MOT_E_CAPACITY, "more points resident than the caller's buffers hold (capacity_points)");
-  if ((ground || mask) && !c->ground_resident) {
+  if (((ground || mask) && !c->ground_resident) || (elev && c->elev_packed)) {   // (packed: the fused path left 12-byte points; the ABI's records are float4 with the input's 4th value)
     // The fused path left the ground cloud / mask out (mot_set_fused_outputs): materialise them for the whole last batch by
     // re-running the compaction with every output, from the batch's input, polar cells and thresholds — all still resident.
     // (No occupancy this time: the cluster stage has consumed it. The elevated cloud and the counts are rewritten with the
@@ -1315,7 +1322,7 @@ extern "C" int mot_get_ground(mot_ctx* c, int slot, float* elev, int* n_elev, fl
     GroundBuffers g = ground_buffers(c, c->last_in, c->last_in_stride, true, false);
     mot_launch_ground_kernel(2, c->dp, g, c->last_batch, c->last_max_n, c->stream);
     MOT_HIP(c, hipGetLastError());
-    c->ground_resident = true;
+    c->ground_resident = true; c->elev_packed = false;   // every slot's elevated cloud is float4 again (same points, same order: what the later stages hold stays valid)
   }
   if (elev && ne > 0) MOT_HIP(c, hipMemcpyAsync(elev, c->d_elev + (size_t)slot * c->cap, (size_t)ne * 16, hipMemcpyDeviceToHost, c->stream));
   if (ground && ng > 0) MOT_HIP(c, hipMemcpyAsync(ground, c->d_ground + (size_t)slot * c->cap, (size_t)ng * 16, hipMemcpyDeviceToHost, c->stream));
@@ -1337,7 +1344,7 @@ extern "C" int mot_ground_remove(mot_ctx* c, const float* xyzw, int n, float* el
   GroundBuffers g = ground_buffers(c, c->d_in, c->cap, true);
   mot_launch_ground(c->dp, g, 1, n, c->stream);
   MOT_HIP(c, hipGetLastError());
-  c->ground_resident = true; c->last_fused = false; c->label_state[0] = 2; c->box_valid[0] = 0;
+  c->ground_resident = true; c->last_fused = false; c->elev_packed = false; c->label_state[0] = 2; c->box_valid[0] = 0;
   return mot_get_ground(c, 0, elev, n_elev, ground, n_ground, mask, n);
 }
 
@@ -1357,6 +1364,7 @@ extern "C" int mot_ground_node_frame(mot_ctx* c, const float* xyzw, int n, const
   mot_launch_ground(c->dp, g, 1, n, c->stream);
   MOT_HIP(c, hipGetLastError());
   c->ground_resident = false;   // (no mask: a later mot_get_ground that asks for one answers MOT_E_STATE)
+  c->elev_packed = false;
   c->last_fused = false; c->label_state[0] = 2; c->box_valid[0] = 0;
   if ((rc = fetch_counts(c, 0))) return rc;
   const int ne = c->h_counts[kCntElev], ng = c->h_counts[kCntGround];
@@ -1403,7 +1411,7 @@ extern "C" int mot_ground_remove_pointcloud2(mot_ctx* c, const void* data, int n
   GroundBuffers g = ground_buffers(c, c->d_in, c->cap, true);
   mot_launch_ground(c->dp, g, 1, n, c->stream);
   MOT_HIP(c, hipGetLastError());
-  c->ground_resident = true; c->last_fused = false; c->label_state[0] = 2; c->box_valid[0] = 0;
+  c->ground_resident = true; c->last_fused = false; c->elev_packed = false; c->label_state[0] = 2; c->box_valid[0] = 0;
   return mot_get_ground(c, 0, elev, n_elev, ground, n_ground, mask, n);
 }
 
@@ -1423,6 +1431,8 @@ static int launch_one(mot_ctx* c, int id, int batch) {
   if (id == kK3 && (rc = next_epoch(c))) return rc;
   GroundBuffers g = ground_buffers(c, c->last_in, c->last_in_stride, (c->fused_outputs & MOT_OUT_MASK) != 0, true);   // as in the fused path: the compaction kernel leaves the occupancy lists
   if (!(c->fused_outputs & MOT_OUT_GROUND)) g.ground = nullptr;
+  g.elevated_packed = (MOT_PACKED_ELEVATED && !g.ground) ? 1 : 0;
+  if (id == kK3) c->elev_packed = g.elevated_packed != 0;
   if (id == kK3) c->ground_resident = (c->fused_outputs & (MOT_OUT_GROUND | MOT_OUT_MASK)) == (MOT_OUT_GROUND | MOT_OUT_MASK);
   ClusterBuffers cb = cluster_buffers(c);
   cb.occ_list = c->d_occ_list; cb.occ_count = c->d_occ_count; cb.ecell = g.ecell;

@@ -65,6 +65,21 @@ struct MotDevParams {
       t_ratio_max, min_len_ratio, t_pt_per_m3;
 };
 
+// The elevated cloud between the ground stage and the stages after it. Stage-wise entry points hold it as the ABI's float4 records; the FUSED
+// path's default (ground cloud / mask on demand) writes it PACKED, 12 bytes a point (x, y, z: nothing after groundRemove reads the 4th float —
+// the reference's elevatedCloud is PointCloud<PointXYZ>): 4 bytes less written by the compaction kernel and 4 less read by the label kernel per
+// elevated point, 0.19 of the 3.8 GB a 512-frame launch sequence moves (round 5). A slot's cloud starts at the same address either way
+// (elevated + slot * cap float4); `packed` travels with the buffer descriptors, every reader goes through mot_load_xyz.
+#ifndef MOT_PACKED_ELEVATED
+#define MOT_PACKED_ELEVATED 1
+#endif
+struct PackedXyz { float x, y, z; };
+static_assert(sizeof(PackedXyz) == 12, "12-byte points");
+MOT_HD float4 mot_load_xyz(const float4* slot_base, long i, int packed) {
+  if (packed) { const PackedXyz q = reinterpret_cast<const PackedXyz*>(slot_base)[i]; float4 r; r.x = q.x; r.y = q.y; r.z = q.z; r.w = 0.f; return r; }
+  return slot_base[i];
+}
+
 struct OccWord { unsigned word, a, b, pad; };   // word index in the bit-plane, its "seen >= 1" and "seen >= 2" bits
 
 // What changes from one launch sequence to the next without changing the launch geometry — the input cloud's address and the
@@ -91,6 +106,7 @@ struct GroundBuffers {
   int* ticket;             // [B], zero between launches (the workgroup drawing the last ticket re-arms it)
   unsigned epoch;          // launch epoch, 1..kDescEpochMask
   float4* elevated;        // [B][cap]
+  int elevated_packed;     // the elevated-only compaction writes 12-byte points (see PackedXyz)
   float4* ground;          // [B][cap]
   uint8_t* mask;           // [B][cap] or null
   int* counts;             // [B][kCountsStride]: n_elevated, n_ground, n_dropped, ...
@@ -165,6 +181,7 @@ struct BoxCandidate {          // per cluster, written by the box kernels
 typedef unsigned short GridLabel;
 struct ClusterBuffers {
   const float4* elevated;      // [B][cap]
+  int elevated_packed;         // 12-byte points (the fused path's default: see PackedXyz)
   long cap;
   int* counts;                 // [B][kCountsStride]
   unsigned* plane_a;           // [B][2048] cell seen >= 1   (filled by cart_occupancy_kernel: the stage-wise mot_cluster)
@@ -212,6 +229,7 @@ struct SideDevParams {
 };
 struct SideBuffers {
   const float4* elevated;   // the slot's elevated cloud
+  int elevated_packed;      // 12-byte points (see PackedXyz)
   const GridLabel* grid;    // the slot's label grid, x-major with stride num_grid
   const int* counts;        // the slot's counters (kCntElev)
   int* cell_first;          // [MOT_MAX_GRID^2] scratch: first point of every labelled cell

@@ -31,7 +31,7 @@ struct SidePoint { bool fc, fo; int xI, yI, lab; };
 __device__ __forceinline__ SidePoint side_point(const MotDevParams& p, const SideBuffers& s, int i, int n, bool want_first) {
   SidePoint r; r.fc = false; r.fo = false; r.xI = 0; r.yI = 0; r.lab = 0;
   if (i < n) {
-    const float4 q = s.elevated[i];
+    const float4 q = mot_load_xyz(s.elevated, i, s.elevated_packed);
     if (mot_cart_cell(p, q.x, q.y, &r.xI, &r.yI)) {
       r.lab = s.grid[r.xI * p.num_grid + r.yI];
       r.fc = r.lab != 0;
@@ -57,7 +57,7 @@ side_mark_kernel(MotDevParams p, SideDevParams sp, SideBuffers s) {
   // 0.23 ms cluster-node callback: profiles/r05_node_frame_trace.txt)
   int cell = -1, cost_at = -1;
   if (i < n) {
-    const float4 q = s.elevated[i];
+    const float4 q = mot_load_xyz(s.elevated, i, s.elevated_packed);
     int xI, yI;
     if (mot_cart_cell(p, q.x, q.y, &xI, &yI) && s.grid[xI * p.num_grid + yI] != 0) cell = xI * p.num_grid + yI;
     // createCostMap :431-452 (doubles; `int grid_y = ...` truncates toward zero; NaN / out-of-int values fail the range test)
@@ -198,7 +198,7 @@ box_markers_kernel(ClusterBuffers c, int slot, float* __restrict__ out) {
       int tile;
       field(j < nround ? j : 0, &m[u], &before[u], &tile);
       if (j >= nround) m[u] = 0ull;
-      q[u] = ((m[u] >> lane) & 1ull) ? pts[(long)tile * 64 + lane] : make_float4(0.f, 0.f, 0.f, 0.f);
+      q[u] = ((m[u] >> lane) & 1ull) ? mot_load_xyz(pts, (long)tile * 64 + lane, c.elevated_packed) : make_float4(0.f, 0.f, 0.f, 0.f);
     }
 #pragma unroll
     for (int u = 0; u < kMarkerDepth; u++)
