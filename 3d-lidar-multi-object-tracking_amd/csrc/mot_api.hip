@@ -107,6 +107,7 @@ struct mot_ctx {
     double timestamp = 0, egoVelo = 0, egoYaw = 0, egoPreYaw = 0;
     double rx = 0, ry = 0, ryaw = -M_PI / 2;   // running result of the ego-history replay (:137-151)
     double egoPoint[3] = {0, 0, 0};
+    double step_ego_yaw = 0;   // egoPoints_[0][2] of the last tracker step (the outputs of evicted tracks add it to their frozen yaw)
     int nt = 0;
   };
   std::vector<SlotEgo> ego;
@@ -1563,6 +1564,7 @@ static void prepare_track_args(mot_ctx* c, TrackFrameArgs* targs, int slot, int 
   if (run) e.tracks_restart = false;
   a.dt = (timestamp - e.timestamp) / 1000000.0;
   a.ego_yaw = e.egoPoint[2];
+  if (run) e.step_ego_yaw = e.egoPoint[2];
   if (run) { e.timestamp = timestamp; e.egoPreYaw = e.egoYaw; e.init = true; }
 }
 
@@ -1600,7 +1602,7 @@ extern "C" int mot_get_tracks(mot_ctx* c, int slot, mot_track* tracks, int max_t
     // One record per track EVER created, in the reference's index order (its output vectors are sized that way,
     // OT/tracking/imm_ukf_jpda.cpp:995-1041). A track that still owns a slot — alive, or dead since the last step only — has its
     // record there; of an evicted one (dead for longer) the position, lifetime_ and the static flag are kept: trackManage 0, not
-    // shown, v and yaw 0 (the reference reports the frozen state with the current ego yaw added; every consumer skips dead tracks).
+    // shown, the frozen speed, and the frozen yaw + the current ego yaw, as the reference reports them (every consumer skips dead tracks).
     // Only the slots up to the highest one in use are read back (slots are handed out lowest first).
     size_t hi = 0;
     for (size_t w = 0; w < usedW; w++) if (used[w]) hi = w * 64 + (63 - (size_t)__builtin_clzll(used[w])) + 1;
@@ -1624,6 +1626,13 @@ extern "C" int mot_get_tracks(mot_ctx* c, int slot, mot_track* tracks, int max_t
         memset(&o, 0, sizeof o);
         o.id = i; o.px = (float)pos[i].x; o.py = (float)pos[i].y; o.pz = (float)(-1.73 / 2);
         o.lifetime = tomb[i].lifetime; o.is_static = tomb[i].is_static;
+        // the reference goes on reporting a dead track's frozen speed, and its frozen yaw + the CURRENT ego yaw (:1012-1016)
+        o.v = tomb[i].v;
+        double tyaw = tomb[i].yaw + c->ego[slot].step_ego_yaw;
+        if (fabs(tyaw) > 64. * M_PI) { const double r = tyaw - trunc(tyaw / (2. * M_PI)) * (2. * M_PI); tyaw = fabs(r) <= 64. * M_PI ? r : NAN; }   // (wrap_pi of track.hip)
+        while (tyaw > M_PI) tyaw -= 2. * M_PI;
+        while (tyaw < -M_PI) tyaw += 2. * M_PI;
+        o.yaw = tyaw;
         tracks[i] = o;
       }
     }
@@ -1702,7 +1711,7 @@ struct SnapshotHeader {
   uint32_t magic, abi, header_bytes, track_bytes, record_bytes;   // 'MOTS', MOT_ABI_VERSION, sizeof(SnapshotHeader), sizeof(DevTrack), sizeof(mot_track)
   int32_t T, nt, nlive, nzomb, flags;
   uint8_t init, ego_called, tracks_restart, pad[5];
-  double timestamp, egoVelo, egoYaw, egoPreYaw, rx, ry, ryaw, egoPoint[3];
+  double timestamp, egoVelo, egoYaw, egoPreYaw, rx, ry, ryaw, egoPoint[3], step_ego_yaw;
   uint64_t total_bytes;
 };
 static size_t snapshot_bytes(size_t T, size_t nt) {
@@ -1743,6 +1752,7 @@ extern "C" int mot_stream_save(mot_ctx* c, int slot, void* blob, size_t capacity
   h.init = e.init; h.ego_called = e.ego_called; h.tracks_restart = e.tracks_restart;
   h.timestamp = e.timestamp; h.egoVelo = e.egoVelo; h.egoYaw = e.egoYaw; h.egoPreYaw = e.egoPreYaw; h.rx = e.rx; h.ry = e.ry; h.ryaw = e.ryaw;
   for (int k = 0; k < 3; k++) h.egoPoint[k] = e.egoPoint[k];
+  h.step_ego_yaw = e.step_ego_yaw;
   h.total_bytes = total;
   char* o = static_cast<char*>(blob);
   memcpy(o, &h, sizeof h); o += sizeof h;
@@ -1846,6 +1856,7 @@ extern "C" int mot_stream_load(mot_ctx* c, int slot, const void* blob, size_t by
   e.init = h.init != 0; e.ego_called = h.ego_called != 0; e.tracks_restart = h.tracks_restart != 0;
   e.timestamp = h.timestamp; e.egoVelo = h.egoVelo; e.egoYaw = h.egoYaw; e.egoPreYaw = h.egoPreYaw; e.rx = h.rx; e.ry = h.ry; e.ryaw = h.ryaw;
   for (int k = 0; k < 3; k++) e.egoPoint[k] = h.egoPoint[k];
+  e.step_ego_yaw = h.step_ego_yaw;
   e.nt = h.nt;
   c->ego[slot] = e;
   return MOT_OK;

@@ -258,7 +258,7 @@ constexpr int kGateWords = kMaxBoxesPerFrame / 64;  // gate bit-mask of one trac
 // index: the merged position (the over-segmentation merge tests EVERY track's last position against the visible boxes, dead
 // tracks included, :666-700), lifetime_ and the static flag (outputs), and the slot map — 28 bytes instead of ~2 KB.
 constexpr int kEverFactor = 64;   // default capacity of the per-ever-track arrays, as a multiple of max_tracks_total
-struct TrackTomb { int lifetime, is_static; };
+struct TrackTomb { int lifetime, is_static; double v, yaw; };   // v, yaw: x_merge_(2..3) as the filter left them — the reference keeps reporting them (yaw + the current ego yaw, imm_ukf_jpda.cpp:1012-1016)
 struct DevTrack {               // filter state of one track (the reference's class UKF, OT/include/ukf.h:15-263)
   double x[4][5];               // x_merge_, x_cv_, x_ctrv_, x_rm_
   double P[4][25];              // P_merge_, P_cv_, P_ctrv_, P_rm_ (row-major)

@@ -951,7 +951,7 @@ static __device__ void track_finish_body(const TrackBuffers& tb, const int b, co
     const int sl = zomb[z];
     const DevTrack* u = &tracks[sl];
     const int ref = u->ref_id;
-    TrackTomb tm; tm.lifetime = u->lifetime; tm.is_static = u->is_static;
+    TrackTomb tm; tm.lifetime = u->lifetime; tm.is_static = u->is_static; tm.v = u->x[0][2]; tm.yaw = u->x[0][3];
     tomb[ref] = tm;
     slot_of[ref] = -1;
     atomicAnd(&used[sl >> 6], ~(1ull << (sl & 63)));

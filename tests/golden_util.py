@@ -46,6 +46,11 @@ def check_tracker_frame(fx, f, out, state_fn, rtol=1e-4, atol=1e-9):
     live = fx["track_manage"][f][:n] > 0
     assert np.allclose(out["p"][live], fx["pos"][f][:n][live], rtol=rtol, atol=1e-6), f
     assert np.allclose(out["v_yaw"][live], fx["v_yaw"][f][:n][live], rtol=rtol, atol=1e-7), f
+    # dead tracks: the reference goes on reporting their frozen speed and (frozen yaw + the current ego yaw), imm_ukf_jpda.cpp:1012-1016 — so
+    # does the library, for tracks still in a slot and for evicted ones (round 5; until then evicted tracks reported zeros)
+    dead = ~live
+    assert np.allclose(out["v_yaw"][dead], fx["v_yaw"][f][:n][dead], rtol=max(rtol, 1e-6), atol=1e-6, equal_nan=True), (f, "dead tracks' v / yaw")
+    assert np.allclose(out["p"][dead][:, :2], fx["pos"][f][:n][dead][:, :2], rtol=max(rtol, 1e-6), atol=1e-6, equal_nan=True), (f, "dead tracks' position")
     for i in np.nonzero(live)[0]:
         s = state_fn(int(i))
         assert s["lifetime"] == fx["lifetime"][f][i], (f, i)

@@ -222,6 +222,9 @@ def long_run_bounded_slots(mot, oracle, lib_path=None, frames=1500, slots=16, sp
                 for i in np.nonzero(dead)[0][-64:]:
                     if SP.well_conditioned(T.state(int(i)), "wide") and taint.get(int(i), -1) < 0:
                         assert np.allclose(a["p"][i][:2], o["p"][i][:2], rtol=1e-2, atol=1e-4), (f, int(i), "position of a dead track")
+                        # ... and its frozen speed / (frozen yaw + the current ego yaw), which the reference keeps reporting (imm_ukf_jpda.cpp:1012-1016)
+                        dv = np.abs(a["v_yaw"][i] - o["v_yaw"][i]); dv[1] = min(dv[1], abs(2 * np.pi - dv[1]))   # (a yaw at +-pi may wrap either way)
+                        assert np.all(dv <= 1e-2 * np.maximum(np.abs(o["v_yaw"][i]), 1.0)), (f, int(i), "v / yaw of a dead track", a["v_yaw"][i], o["v_yaw"][i])
             stats["live_peak"] = max(stats.get("live_peak", 0), int(live.sum()))
         ever_total += o["n"] if o is not None else 0
         T.close()
