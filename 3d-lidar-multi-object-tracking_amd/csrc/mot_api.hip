@@ -473,7 +473,7 @@ extern "C" int mot_create(const mot_params* params, int device, int max_points, 
   c->max_points = max_points;
   c->cap = (max_points + 63) / 64 * 64;  // per-slot stride of every per-point buffer: keeps 16-byte vector loads aligned
   c->max_tracks_total = max_tracks_total;
-  {  // tracks EVER created per stream that the light arrays hold (28 bytes each); mot_params.max_tracks_ever, 0 = kEverFactor x the slots
+  {  // tracks EVER created per stream that the light arrays hold (44 bytes each); mot_params.max_tracks_ever, 0 = kEverFactor x the slots
     long e = params->max_tracks_ever > 0 ? (long)params->max_tracks_ever : (long)max_tracks_total * kEverFactor;
     if (e < max_tracks_total) e = max_tracks_total;
     if (e > (1l << 26)) e = 1l << 26;

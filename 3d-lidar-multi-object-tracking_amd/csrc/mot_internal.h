@@ -256,7 +256,7 @@ constexpr int kGateWords = kMaxBoxesPerFrame / 64;  // gate bit-mask of one trac
 // keeps its slot while it is alive and for one more step after it died (that step's outputs still show the dead track as the
 // reference would), then the slot is free again. What outlives the slot, per track EVER created, addressed by the reference's
 // index: the merged position (the over-segmentation merge tests EVERY track's last position against the visible boxes, dead
-// tracks included, :666-700), lifetime_ and the static flag (outputs), and the slot map — 28 bytes instead of ~2 KB.
+// tracks included, :666-700), lifetime_, the static flag and the frozen speed / yaw (outputs), and the slot map — 44 bytes instead of ~2 KB.
 constexpr int kEverFactor = 64;   // default capacity of the per-ever-track arrays, as a multiple of max_tracks_total
 struct TrackTomb { int lifetime, is_static; double v, yaw; };   // v, yaw: x_merge_(2..3) as the filter left them — the reference keeps reporting them (yaw + the current ego yaw, imm_ukf_jpda.cpp:1012-1016)
 struct DevTrack {               // filter state of one track (the reference's class UKF, OT/include/ukf.h:15-263)

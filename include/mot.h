@@ -129,7 +129,7 @@ typedef struct mot_params {
    * draw for a 1000-point cluster): pick the one the reference build you replace was compiled with and the boxes are
    * identical; pick the other and they still are, except with that probability (tests/test_oracle_vs_ref.py). */
   int32_t rng_mapping;
-  /* ---- track storage: how many tracks a stream may CREATE over its lifetime (the per-ever-track arrays: 28 bytes each);
+  /* ---- track storage: how many tracks a stream may CREATE over its lifetime (the per-ever-track arrays: 44 bytes each);
    * 0 (preset) = 64 x max_tracks_total. See mot_create. */
   int32_t max_tracks_ever;
 } mot_params;
@@ -170,7 +170,7 @@ int mot_params_preset(int preset, mot_params* out);
  * The reference never frees a track (targets_ only grows, OT/tracking/imm_ukf_jpda.cpp:972-989) and addresses tracks by their
  * index in that vector; here the filter state (~2 KB) of a track is evicted one step after the track died, while the index
  * keeps counting: ids, output order and every result stay those of the reference with unbounded memory. Per track EVER
- * created 28 bytes remain (its last position — the reference's merge step tests dead tracks' positions too — lifetime and
+ * created 44 bytes remain (its last position, frozen speed and yaw — the reference's merge step tests dead tracks' positions too — lifetime and
  * static flag): mot_params.max_tracks_ever of them, 64 x max_tracks_total by default. A birth that finds no slot or exceeds
  * that budget is dropped and reported (MOT_E_CAPACITY, sticky). */
 int mot_create(const mot_params* params, int device, int max_points, int max_batch,
@@ -349,7 +349,7 @@ int mot_get_boxes(mot_ctx* ctx, int slot, float* boxes, int max_boxes, int* n_bo
  * 64 x max_tracks_total). SIZE THE BUFFER FOR THAT: max_tracks >= max_tracks_ever never overflows; a long-running consumer either
  * creates the context with max_tracks_ever = its buffer size (ros/src/mot_ros_common.hpp does) or re-fetches with a larger buffer when
  * n_tracks > max_tracks (MOT_E_CAPACITY, nothing copied, n_tracks delivered — the step itself has run). The call costs a D2H copy
- * of 28 B x n_tracks + the live slots: consumers that only need the LIVE tracks every frame read mot_fetch_tracks_async /
+ * of 44 B x n_tracks + the live slots: consumers that only need the LIVE tracks every frame read mot_fetch_tracks_async /
  * mot_export_tracks[_packed]_dev instead, whose cost does not grow with the stream's age.
  * MOT_E_CAPACITY WITH the records delivered (n_tracks <= max_tracks) when births were dropped on this stream (no free track slot, or
  * max_tracks_ever tracks created): STICKY until mot_reset / mot_reset_slot / mot_reset_tracks_slot. */
