@@ -1013,11 +1013,12 @@ def main():
         G = ctx.params.num_grid
         BL = Bc  # frames per launch (one context)
         # algorithmic HBM bytes per launch (what a kernel must read and write once), at the last frame's counts
+        EB = 12.0 if args.outputs == "headline" else 16.0   # bytes of an elevated point between the stages: packed x, y, z unless the ground cloud is written too (mot_internal.h PackedXyz)
         alg_bytes = {"polar_minz_kernel": 16.0 * n_tot,
                      "polar_filter_kernel": 8.0 * 9600 * BL,
-                     "classify_compact_kernel": 16.0 * n_tot + 16.0 * ne_tot,   # the fused path's default: ground cloud and mask on demand (round 2: + 16 N_g + N)
+                     "classify_compact_kernel": 16.0 * n_tot + EB * ne_tot,   # the fused path's default: ground cloud and mask on demand (round 2: + 16 N_g + N); elevated points leave as 12 bytes (round 5)
                      "ccl_kernel": (2 * 2048 * 4 + 4.0 * G * G) * BL,
-                     "label_stats_kernel": (16.0 + 4.0) * ne_tot,   # points read, pixels written; the per-point labels are written on demand only (MOT_OUT_LABELS)
+                     "label_stats_kernel": (EB + 4.0) * ne_tot,   # points read, pixels written; the per-point labels are written on demand only (MOT_OUT_LABELS)
                      "cluster_index_kernel": 32.0 * ne_tot / 64,   # a 16-byte record per (tile, cluster) group read and written; at least one group per 64 points
                      "cluster_gather_kernel": (4.0 + 16.0 / 64) * ne_tot,   # the pixels, and the cluster-sorted group records
                      "cluster_rect_kernel": 4.0 * ne_tot / 8,
@@ -1081,7 +1082,7 @@ def main():
             # + 4 N_e + 0.5 MB of grid, box (16 + 4) N_e, 0.1 MB of polar grid = 48 N + 56 N_e + 0.6 MB — at this run's measured N, N_e
             n_f, ne_f = n_tot / BL, ne_tot / BL
             survey_bytes = 48.0 * n_f + 56.0 * ne_f + 0.6e6
-            own_bytes = frame_bytes + (16.0 * ng_tot + n_tot + 4.0 * ne_tot) / BL   # this implementation's own accounting + ground cloud, mask, labels
+            own_bytes = frame_bytes + (16.0 * ng_tot + n_tot + 4.0 * ne_tot + 2 * (16.0 - EB) * ne_tot) / BL   # this implementation's own accounting + ground cloud, mask, labels (+ float4 elevated points: written and read once)
             v_all = B * F * all_out["steps"] / all_out["dt"]
             out["all_outputs"] = {"value": round(v_all, 1), "unit": "frames/s", "steps": all_out["steps"], "ms_per_step": round(all_out["dt"] / all_out["steps"] * 1e3, 4),
                                   "vs_headline": round(v_all / (frames / dt), 4),
