@@ -135,8 +135,23 @@ polar_minz_kernel(MotDevParams p, GroundBuffers g) {
      // Written from THIS side of the transposition: a thread holds the cells of 8 consecutive points = one 16-byte store (from the
      // loading side it was 8 two-byte stores per thread, 128 bytes per wave instruction).
     static_assert(kGroundItems == 8, "one 16-byte store of 8 cells per thread");
-    unsigned short* __restrict__ cell16 = g.cell + (long)b * g.cap;
     const long i0 = base + (long)threadIdx.x * kGroundItems;
+#if MOT_CELL_CHANNEL_BYTE
+    // ... and since round 5 one BYTE: the channel (the atan), the compaction kernel recomputes the bin (mot_internal.h): an 8-byte store per thread
+    unsigned char* __restrict__ chan8 = reinterpret_cast<unsigned char*>(g.cell) + (long)b * g.cap;
+    unsigned ch[kGroundItems];
+#pragma unroll
+    for (int j = 0; j < kGroundItems; j++) ch[j] = (int)e[j].x >= 0 ? e[j].x / (unsigned)MOT_NUM_BIN : 0xffu;
+    if (i0 + kGroundItems <= n) {
+      uint2 v;
+      v.x = ch[0] | (ch[1] << 8) | (ch[2] << 16) | (ch[3] << 24); v.y = ch[4] | (ch[5] << 8) | (ch[6] << 16) | (ch[7] << 24);
+      *reinterpret_cast<uint2*>(chan8 + i0) = v;
+    } else {
+#pragma unroll
+      for (int j = 0; j < kGroundItems; j++) if (i0 + j < n) chan8[i0 + j] = (unsigned char)ch[j];
+    }
+#else
+    unsigned short* __restrict__ cell16 = g.cell + (long)b * g.cap;
     if (i0 + kGroundItems <= n) {
       uint4 v;
       v.x = (e[0].x & 0xffffu) | (e[1].x << 16); v.y = (e[2].x & 0xffffu) | (e[3].x << 16);   // -1 -> 0xffff
@@ -146,6 +161,7 @@ polar_minz_kernel(MotDevParams p, GroundBuffers g) {
 #pragma unroll
       for (int j = 0; j < kGroundItems; j++) if (i0 + j < n) cell16[i0 + j] = (unsigned short)e[j].x;
     }
+#endif
   }
   int cnt = 0;   // runs of a real cell among my 8 points
 #pragma unroll
@@ -369,6 +385,35 @@ __device__ __forceinline__ void classify_compact_body(const MotDevParams& p, con
     }
   }
   {  // polar cell of every point, as the min-z kernel found it (filterCloud + getCellIndexFromPoints + the node's crop)
+#if MOT_CELL_CHANNEL_BYTE
+    // its CHANNEL travels (one byte; 0xff: the point takes no part), the bin is recomputed from x, y with the same guarded expression
+    // (mot_polar_bin_try; the few undecided points go through ONE copy of the exact evaluation, as in the min-z kernel)
+    const unsigned char* __restrict__ chan8 = reinterpret_cast<const unsigned char*>(g.cell) + (long)b * g.cap;
+    unsigned undecided = 0;
+#pragma unroll
+    for (int k = 0; k < kCompactItems; k++) {
+      const long i = base + k * kCompactBlock + threadIdx.x;
+      const unsigned ch = (full || i < n) ? (unsigned)chan8[i] : 0xffu;
+      const int bin = mot_polar_bin_try(p, pt[k].x, pt[k].y);
+      cls[k] = (ch == 0xffu || bin == -1) ? -1 : (bin == -2 ? -2 : (int)ch * MOT_NUM_BIN + bin);
+      if (ch != 0xffu && bin == -2) undecided |= 1u << k;
+      if (ch == 0xffu) cls[k] = -1;
+    }
+    if (__ballot(undecided != 0)) {   // wave-uniform
+      while (undecided) {
+        const int k = __ffs(undecided) - 1;
+        undecided &= undecided - 1;
+        float qx = pt[0].x, qy = pt[0].y;
+#pragma unroll
+        for (int kk = 1; kk < kCompactItems; kk++) { qx = kk == k ? pt[kk].x : qx; qy = kk == k ? pt[kk].y : qy; }
+        const long i = base + k * kCompactBlock + threadIdx.x;
+        const int bin = mot_polar_bin_exact(p, qx, qy);
+        const int r = bin < 0 ? -1 : (int)chan8[i] * MOT_NUM_BIN + bin;
+#pragma unroll
+        for (int kk = 0; kk < kCompactItems; kk++) cls[kk] = kk == k ? r : cls[kk];
+      }
+    }
+#else
     const unsigned short* __restrict__ cell16 = g.cell + (long)b * g.cap;
     if (full) {   // (one 16-byte load per lane + a wave-private LDS transposition instead of these 8 two-byte loads, and the same for
                   // the mask bytes on the way out, measured no faster: 366-369 against 371 us — this kernel waits for HBM, not for its TA)
@@ -382,6 +427,7 @@ __device__ __forceinline__ void classify_compact_body(const MotDevParams& p, con
         cls[k] = c == 0xffffu ? -1 : (int)c;
       }
     }
+#endif
   }
   float hgv[kCompactItems];
 #pragma unroll

@@ -100,7 +100,8 @@ struct GroundBuffers {
   const int* n;            // [B] points per frame (device)
   uint2* pairs;            // [B][max_chunks][kGroundChunk] {polar cell, ordered-int key of a partial min z}
   int* pair_count;         // [B][max_chunks] entries each workgroup of the min-z kernel produced
-  unsigned short* cell;    // [B][cap] polar cell of every point (0xffff: takes no part), written by the min-z kernel, read by the compaction kernel
+  unsigned short* cell;    // [B][cap] polar cell of every point (0xffff: takes no part), written by the min-z kernel, read by the compaction kernel —
+                           // or, MOT_CELL_CHANNEL_BYTE (default): one BYTE per point in the same allocation, the point's polar channel (0xff: takes no part)
   float* hg;               // [B][9600] hGround of ground cells, -inf for non-ground cells
   unsigned long long* desc;  // [B][max_chunks]
   int* ticket;             // [B], zero between launches (the workgroup drawing the last ticket re-arms it)
@@ -446,6 +447,39 @@ MOT_HD int mot_polar_cell_fast(const MotDevParams& p, float x, float y, float di
   int cell = (bin_safe && ch_safe) ? (ch_in ? idx : -1) : -2;
   cell = (bin_safe && !bin_in) ? -1 : cell;
   return cell;
+}
+
+// ---- the BIN alone (round 5). The min-z kernel hands the compaction kernel one byte per point — the point's polar CHANNEL, whose atan is the
+// expensive half of the cell — and the compaction kernel recomputes the bin from x, y (a square root) instead of reading a two-byte cell:
+// one byte less written and one less read per input point (0.12 of the 3.6 GB a 512-frame launch sequence moves). Both kernels evaluate the bin
+// with the SAME guarded expression, so they agree by construction: where the guard holds the estimate's floor is the exact floor (the
+// claim of mot_polar_cell_fast, swept on the device with the channel guard switched off: tests/devcheck/sweep.hip what = 2), elsewhere
+// both take the exact evaluation below.
+#ifndef MOT_CELL_CHANNEL_BYTE
+#define MOT_CELL_CHANNEL_BYTE 1
+#endif
+MOT_HD int mot_polar_bin_exact(const MotDevParams& p, float x, float y) {   // the bin of mot_polar_cell_exact (same expressions), -1: outside rMin..rMax
+  float distance = sqrtf(x * x + y * y);
+  if (distance <= p.r_min || distance >= p.r_max) return -1;
+  float binP = (distance - p.r_min) / p.r_span;
+  float fb = floorf(binP * MOT_NUM_BIN);
+  if (!(fb >= 0.f && fb < (float)MOT_NUM_BIN)) return -1;
+  return (int)fb;
+}
+MOT_HD int mot_polar_bin_fast(const MotDevParams& p, float distance_approx) {   // the bin part of mot_polar_cell_fast: bin, -1 (outside), -2 (undecided)
+  const float tb = (distance_approx - p.r_min) * p.k_bin;
+  const float fb = floorf(tb), rb = tb - fb;
+  const bool bin_safe = rb > kCellGuard && rb < 1.f - kCellGuard;  // false on NaN
+  const bool bin_in = fb >= 0.f && fb < (float)MOT_NUM_BIN;
+  return bin_safe ? (bin_in ? (int)fb : -1) : -2;
+}
+MOT_HD int mot_polar_bin_try(const MotDevParams& p, float x, float y) {
+  const float d2 = x * x + y * y;
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(MOT_HIPEMU)
+  return mot_polar_bin_fast(p, __builtin_amdgcn_sqrtf(d2));
+#else
+  return mot_polar_bin_fast(p, sqrtf(d2));
+#endif
 }
 
 // the fast path with the hardware estimates; -2 = undecided (call mot_polar_cell_exact)

@@ -42,12 +42,12 @@ __device__ __forceinline__ float ulp_step(float f, int k) {   // k representable
 // mode 2: points ON the cell boundaries, moved by -3..+3 steps of 1..64 ulp in x and in y:
 //           polar: every channel spoke (k * 2 pi / 80) at random radii, and every bin ring (rMin + k * span / 120) at random angles
 //           Cartesian: every grid line x = -roi/2 + k * roi / G (and y), random along the line
-// what = 0 polar cell, 1 Cartesian cell
+// what = 0 polar cell, 1 Cartesian cell, 2 polar bin alone
 __global__ void MOT_LAUNCH_BOUNDS(256)
 sweep_kernel(MotDevParams p, int what, int mode, unsigned long long seed, unsigned long long count, int per_thread, SweepStats* out) {
   const unsigned long long t0 = ((unsigned long long)blockIdx.x * 256 + threadIdx.x) * (unsigned long long)per_thread;
   unsigned long long n_und = 0, n_bad = 0, n_pts = 0;
-  const float R = what == 0 ? 130.0f : 1.2f * p.roi_half;
+  const float R = what != 1 ? 130.0f : 1.2f * p.roi_half;
   const unsigned long long side = 1ull << 16;
   for (int j = 0; j < per_thread; j++) {
     const unsigned long long i = t0 + j;
@@ -61,7 +61,7 @@ sweep_kernel(MotDevParams p, int what, int mode, unsigned long long seed, unsign
     } else {
       // -3..+3 steps of 1, 2, 4, ... 64 ulp: from exactly on the boundary to just outside the guard band on either side
       const int dx = ((int)(h2 % 7) - 3) * (1 << (int)((h2 >> 3) % 7)), dy = ((int)((h2 >> 8) % 7) - 3) * (1 << (int)((h2 >> 11) % 7));
-      if (what == 0) {
+      if (what != 1) {
         if (h2 & (1ull << 40)) {   // a channel spoke
           const int k = (int)((h2 >> 16) % (MOT_NUM_CHANNEL + 1));
           const double a = -3.14159265358979323846 + k * (2 * 3.14159265358979323846 / MOT_NUM_CHANNEL);
@@ -83,6 +83,7 @@ sweep_kernel(MotDevParams p, int what, int mode, unsigned long long seed, unsign
     }
     int fast, exact;
     if (what == 0) { fast = mot_polar_cell_try(p, x, y); exact = mot_polar_cell_exact(p, x, y); }
+    else if (what == 2) { fast = mot_polar_bin_try(p, x, y); exact = mot_polar_bin_exact(p, x, y); }   // the bin alone (the compaction kernel's recomputation)
     else {
       fast = mot_cart_bit_try(p, x, y);
       int xI, yI;
@@ -106,7 +107,7 @@ sweep_kernel(MotDevParams p, int what, int mode, unsigned long long seed, unsign
 
 // dev_params: the context's MotDevParams (mot_debug_dev_params, mot_debug_api.h). Synchronous, on the null stream.
 extern "C" int mot_sweep_run(const void* dev_params, int what, int mode, unsigned long long seed, unsigned long long count, unsigned long long* stats8) {
-  if (!dev_params || !stats8 || what < 0 || what > 1 || mode < 0 || mode > 2) return 1;
+  if (!dev_params || !stats8 || what < 0 || what > 2 || mode < 0 || mode > 2) return 1;
   MotDevParams p;
   memcpy(&p, dev_params, sizeof p);
   SweepStats* d = nullptr;

@@ -27,8 +27,8 @@ def test_fast_cells_agree_with_exact_on_device(mot, hip_lib):
             dp = (C.c_char * 512)()
             assert hip_lib.mot_debug_dev_params(c._h, dp, C.c_size_t(512)) == 0
             st = (C.c_ulonglong * 8)()
-            for what, mode, count in ((0, 0, 1 << 30), (0, 1, 1 << 30), (0, 2, 1 << 29), (1, 0, 1 << 28), (1, 1, 1 << 28), (1, 2, 1 << 28)):
-                if preset == 1 and what == 0 and mode < 2:
+            for what, mode, count in ((0, 0, 1 << 30), (0, 1, 1 << 30), (0, 2, 1 << 29), (1, 0, 1 << 28), (1, 1, 1 << 28), (1, 2, 1 << 28), (2, 0, 1 << 29), (2, 1, 1 << 29), (2, 2, 1 << 29)):
+                if preset == 1 and what in (0, 2) and mode < 2:
                     continue   # the polar grid does not depend on the preset: boundaries only
                 rc = S.mot_sweep_run(dp, what, mode, C.c_ulonglong(1234567 + 17 * mode + preset), C.c_ulonglong(count), st)
                 assert rc == 0

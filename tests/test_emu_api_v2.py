@@ -165,7 +165,7 @@ def test_fast_path_sweeps_on_the_emulator(mot, emu):
         dp = (C.c_char * 512)()
         assert L.mot_debug_dev_params(c._h, dp, C.c_size_t(512)) == 0
         st = (C.c_ulonglong * 8)()
-        for what in (0, 1):
+        for what in (0, 1, 2):
             for mode in (0, 1, 2):
                 assert S.mot_sweep_run(dp, what, mode, C.c_ulonglong(7), C.c_ulonglong(200000), st) == 0
                 assert st[0] == 200000 and st[2] == 0, (what, mode, list(st))
