@@ -292,9 +292,11 @@ int mot_sequence_dev(mot_ctx* ctx, const float* d_xyzw, long frame_stride, const
  * besides what the next stage needs: flags = OR of MOT_OUT_GROUND / MOT_OUT_MASK / MOT_OUT_LABELS, default 0. The reference's own fused
  * precedent never touches groundCloud after groundRemove (OT0/src/main.cpp:63-79), and the ground cloud is a quarter of the
  * compaction kernel's HBM traffic. Nothing is lost with the default: mot_get_ground materialises the ground cloud / mask of
- * the LAST batch on demand (it re-runs the compaction from the batch's input, polar cells and thresholds, all still resident —
+ * the LAST batch on demand — and, since ABI v5, the ELEVATED cloud as float4 records too (between its stages the fused path keeps the
+ * elevated points as 12-byte {x, y, z}: nothing after groundRemove reads the 4th float). A mot_get_ground that asks for a cloud or the
+ * mask after a fused call re-runs the compaction from the batch's input, polar cells and thresholds, all still resident —
  * so with mot_frames_dev the caller's input buffer must be unchanged until then; a stage-wise mot_cluster / mot_box_fit /
- * mot_cluster_products_host in between takes slot 0 for itself and ends that possibility: MOT_E_STATE). Likewise the per-point cluster labels
+ * mot_cluster_products_host in between takes slot 0 for itself and ends that possibility: MOT_E_STATE. Likewise the per-point cluster labels
  * (getClusteredPoints, OT/src/cluster/box_fitting.cpp:46-72: the box stage itself works on a cluster-sorted index and never reads
  * them back): mot_get_clusters(point_label) computes them for the slot it is asked about, from the cells and the label grid still
  * resident. Sticky per context. The stage-wise mot_ground_remove / mot_cluster always deliver all their outputs
