@@ -687,8 +687,9 @@ RangeScope::RangeScope(const mot_ctx* c, const char* name) : on(false) {
 static void issue_frame_kernels(mot_ctx* c, int batch, int max_n, int run_tracker, bool want_ground, bool want_mask, bool from_block) {
   GroundBuffers g = ground_buffers(c, c->last_in, c->last_in_stride, want_mask, true);
   if (!want_ground) g.ground = nullptr;   // the ground cloud on demand (mot_get_ground re-runs the compaction)
-  c->elev_packed = MOT_PACKED_ELEVATED && !want_ground;   // the elevated-only compaction leaves 12-byte points; every reader below is told (cluster_buffers)
-  g.elevated_packed = c->elev_packed ? 1 : 0;
+  // (the elevated-only compaction leaves 12-byte points; c->elev_packed was set by the CALLER — launch_frames / mot_sequence_dev, which also run
+  // when a captured graph is replayed and this function is not — so that every reader built from cluster_buffers below is told)
+  g.elevated_packed = (MOT_PACKED_ELEVATED && !want_ground) ? 1 : 0;
   if (from_block) g.launch = reinterpret_cast<const FrameLaunch*>(c->d_argblk + c->arg_off_launch);
   {
     RangeScope rs(c, "mot:ground");
@@ -743,6 +744,7 @@ static int launch_frames(mot_ctx* c, int batch, int run_tracker, const double* t
   c->ground_resident = want_ground && want_mask; c->last_fused = true;
   c->label_state.assign(c->batch, (c->fused_outputs & MOT_OUT_LABELS) ? 1 : 0);
   c->box_valid.assign(c->batch, 1);
+  c->elev_packed = MOT_PACKED_ELEVATED && !want_ground;   // how this call's compaction kernel leaves the elevated clouds (host state: also on a graph replay)
 #ifndef MOT_HIPEMU
   // Few streams per launch = somebody waits for every frame: the sequence's 10-13 launches go out as ONE hipGraph launch, captured
   // once per launch geometry. What differs from call to call without changing the geometry (the cloud's address, the look-back
@@ -837,6 +839,7 @@ extern "C" int mot_sequence_dev(mot_ctx* c, const float* d_xyzw, long frame_stri
   c->ground_resident = want_ground && want_mask; c->last_fused = true;
   c->label_state.assign(c->batch, (c->fused_outputs & MOT_OUT_LABELS) ? 1 : 0);
   c->box_valid.assign(c->batch, 1);
+  c->elev_packed = MOT_PACKED_ELEVATED && !want_ground;   // how this call's compaction kernel leaves the elevated clouds (host state: also on a graph replay)
   issue_frame_kernels(c, K, max_n, 0, want_ground, want_mask, false);   // slots = frames; ends with the plain box_finalize_kernel
   const TrackBuffers base = track_buffers(c, true);
   RangeScope rt(c, "mot:tracker (sequence)");

@@ -139,6 +139,15 @@ def test_launch_graphs_equal_plain_launches(mot, hip_lib, oracle, synth):
             a.frames_dev(dev.ptr, stride * 4, n, **kw); g.frames_dev(dev.ptr, stride * 4, n, **kw)
             for s in range(2):
                 assert np.array_equal(a.get_boxes(s)["boxes"], g.get_boxes(s)["boxes"]), (f, s)
+                # what reads the resident elevated cloud AFTER the sequence (12-byte points since round 5; the previous frame's mot_get_ground
+                # left float4 records and the host-side layout flag with them: a graph REPLAY must set it again, it does not pass the launch code)
+                assert np.array_equal(a.box_markers(s).view(np.uint32), g.box_markers(s).view(np.uint32)), (f, s)
+                pa, pg = a.cluster_products(s), g.cluster_products(s)
+                assert all(np.array_equal(pa[k], pg[k]) for k in ("clustered", "obstacles", "cost_map")), (f, s)
+                if f % 2:   # the elevated cloud alone (no ground / mask with it)
+                    ea = a.get_ground(s, n_hint=n[s]); eg = np.empty((stride, 4), np.float32); ne = C.c_int(0)
+                    assert hip_lib.mot_get_ground(g._h, s, eg.ctypes.data_as(C.c_void_p), C.byref(ne), None, None, None, stride) == 0
+                    assert ne.value == ea["n_elevated"] and np.array_equal(eg[: ne.value], ea["elevated"]), (f, s)
                 ta, tg = a.get_tracks(s), g.get_tracks(s)
                 assert ta["n"] == tg["n"] and np.array_equal(ta["track_manage"], tg["track_manage"]) and np.array_equal(ta["p"], tg["p"]) and np.array_equal(ta["v_yaw"], tg["v_yaw"]), (f, s)
                 ga, gg = a.get_ground(s, n_hint=n[s]), g.get_ground(s, n_hint=n[s])
