@@ -44,12 +44,15 @@
 #define MOT_RECT_WAVES 4
 #endif
 
+// label kernel geometry: 256 threads x 8 points = 2048-point chunks (round 5; 512 x 4 until then: the same chunks and LDS tables, four waves per
+// workgroup with eight points' loads in flight each instead of eight waves with four — 151 against 155-159 us per 512 frames alone, +1.1 % on the
+// four-context line in an interleaved A/B: profiles/r05_label_geometry_ab.txt)
 #ifndef MOT_LABEL_BLOCK
-#define MOT_LABEL_BLOCK 512
+#define MOT_LABEL_BLOCK 256
 #endif
 constexpr int kLabelBlock = MOT_LABEL_BLOCK;
 #ifndef MOT_LABEL_ITEMS
-#define MOT_LABEL_ITEMS 4
+#define MOT_LABEL_ITEMS 8
 #endif
 constexpr int kLabelItems = MOT_LABEL_ITEMS;
 constexpr int kLabelChunk = kLabelBlock * kLabelItems;
