@@ -194,14 +194,30 @@ def test_tracker_random_and_degenerate_sequences(mot, hip_lib, oracle, preset):
     exact; continuous state to the 1e-4 bar while the filter is well conditioned (a diverging track amplifies last-bit
     differences by decades per frame — see well_conditioned). On the CPU the same sequences pass with the kernels' sin / cos /
     exp / atan2 / pow results moved by an ulp (MOT_EMU_PERTURB), i.e. they do not hang on the device math library's last bit."""
+    import tempfile
+    import oracle_lib as OL
     import test_emu_tracker_random as TR
     p = oracle.params(preset)
+    # preset 1 = object_tracking0's tracker, which reads its ego motion from two text files: the proxy routes it to the restatement, so here the
+    # reference's own build (oracle/_ref/libmot_ref0.so) is driven directly — the sequence's whole ego motion is known up front (round-4 review:
+    # this case never met the reference's code on the GPU box)
+    use_ref0 = preset == 1 and OL.ref0() is not None
     with mot.Context(mot.params(preset), max_points=4096, max_tracks_total=512) as c:
         for seed in range(1000 * preset, 1000 * preset + 14):
-            c.reset(); T = oracle.Tracker(p)
-            seq = TR.sequence(seed) if seed % 4 else TR.hostile_sequence(seed)
+            seq = list(TR.sequence(seed) if seed % 4 else TR.hostile_sequence(seed))
+            c.reset()
+            if use_ref0:
+                T = OL.Ref0Tracker(); T.reset(tempfile.mkdtemp(prefix="mot_ref0_"), [s[2] for s in seq], [s[3] for s in seq])
+                if hasattr(oracle, "_note"):
+                    oracle._note("Tracker", "reference build")
+            else:
+                T = oracle.Tracker(p)
             for f, (boxes, ts, v, yaw) in enumerate(seq):
-                c.ego_update(ts, v, yaw); T.ego_update(ts, v, yaw)
+                c.ego_update(ts, v, yaw)
+                if use_ref0:
+                    T.ego_update(ts)
+                else:
+                    T.ego_update(ts, v, yaw)
                 a = c.track_step(boxes, ts); o = T.step(boxes, ts)
                 assert a["n"] == o["n"], (seed, f)
                 for k in ("track_manage", "is_static", "is_vis", "lifetime"):
