@@ -89,7 +89,10 @@ __global__ void stats_init_kernel(ClusterBuffers c) {
 
 // ------------------------------------------------------------------------------------------ B1
 // getClusteredPoints :46-72 (label of every point) + the per-point loop of getBoundingBox :239-293
-constexpr int kGroupsPerWg = 512;   // (tile, cluster) groups a workgroup stages in LDS; any beyond go straight to global memory
+#ifndef MOT_LABEL_GROUPS
+#define MOT_LABEL_GROUPS 512
+#endif
+constexpr int kGroupsPerWg = MOT_LABEL_GROUPS;   // (tile, cluster) groups a workgroup stages in LDS; any beyond go straight to global memory
 __device__ __forceinline__ void stats_commit(ClusterStats* s, int count, int first, int rz, unsigned long long rmin, unsigned long long rmax, int groups) {
   atomicAdd(&s->count_groups, (unsigned long long)(unsigned)count | ((unsigned long long)(unsigned)groups << 32));
   atomicMin(&s->first, first);
@@ -98,6 +101,9 @@ __device__ __forceinline__ void stats_commit(ClusterStats* s, int count, int fir
   if (rmax != kArgmaxInit) atomicMax(&s->argmax, rmax);
 }
 
+#if defined(MOT_LABEL_WAVES) && !defined(MOT_HIPEMU)
+__attribute__((amdgpu_waves_per_eu(MOT_LABEL_WAVES, MOT_LABEL_WAVES)))
+#endif
 __global__ void MOT_LAUNCH_BOUNDS(kLabelBlock)
 label_stats_kernel(MotDevParams p, ClusterBuffers c) {
   constexpr int kWaves = kLabelBlock / 64, kPerWave = kGroupsPerWg / kWaves;
@@ -110,8 +116,12 @@ label_stats_kernel(MotDevParams p, ClusterBuffers c) {
   __shared__ unsigned long long s_tab_rmin[kWgClusters], s_tab_rmax[kWgClusters];
   __shared__ int s_wcount[kWaves], s_gbase;
   constexpr int kTilesPerChunk = kLabelChunk / 64;
-  __shared__ int s_slot[kGroupsPerWg];
-  __shared__ int s_tilecnt[kWgClusters][kTilesPerChunk + 1];   // +1: the 64 scanning threads walk different banks
+  // per (table slot, tile): the cluster's points in the tile, then {points, groups} of the cluster in the chunk's earlier tiles — < 2048 and < 32,
+  // 11 + 5 bits of a short; rows of 17 words: the 64 scanning threads walk different banks
+  constexpr int kTileRow = kTilesPerChunk + 2;
+  static_assert(kLabelChunk <= 2048 && kTilesPerChunk <= 32 && kWgClusters <= 127, "packing of s_tilecnt / s_slot");
+  __shared__ signed char s_slot[kGroupsPerWg];
+  __shared__ unsigned short s_tilecnt[kWgClusters][kTileRow];
   const int b = blockIdx.y;
   const int n = c.counts[b * kCountsStride + kCntElev];
   // (one workgroup per chunk of the largest possible frame; two thirds find nothing to do and leave. Fewer workgroups that loop
@@ -125,7 +135,7 @@ label_stats_kernel(MotDevParams p, ClusterBuffers c) {
     s_tab_label[threadIdx.x] = 0; s_tab_count[threadIdx.x] = 0; s_tab_first[threadIdx.x] = 0x7fffffff;
     s_tab_rz[threadIdx.x] = mot_float_key(-99.f); s_tab_rmin[threadIdx.x] = kArgminInit; s_tab_rmax[threadIdx.x] = kArgmaxInit;
   }
-  for (int i = threadIdx.x; i < kWgClusters * (kLabelChunk / 64 + 1); i += kLabelBlock) (&s_tilecnt[0][0])[i] = 0;
+  for (int i = threadIdx.x; i < kWgClusters * kTileRow / 2; i += kLabelBlock) reinterpret_cast<unsigned*>(&s_tilecnt[0][0])[i] = 0u;
   B1_T_BEGIN(c, b);
   const int num_cluster = c.counts[b * kCountsStride + kCntClusters];
   const float4* __restrict__ pts = c.elevated + (long)b * c.cap;
@@ -261,8 +271,8 @@ label_stats_kernel(MotDevParams p, ClusterBuffers c) {
     }
     // this group's points, filed under (table slot, tile of the chunk): the prefix over tiles below gives the number of the
     // cluster's points in earlier tiles of this chunk (the index kernel adds the earlier chunks' totals)
-    s_slot[e] = slot;
-    if (slot >= 0) s_tilecnt[slot][g.tile & (kTilesPerChunk - 1)] = cnt;
+    s_slot[e] = (signed char)slot;
+    if (slot >= 0) s_tilecnt[slot][g.tile & (kTilesPerChunk - 1)] = (unsigned short)cnt;
   }
   __syncthreads();
   B1_T(3);
@@ -272,7 +282,7 @@ label_stats_kernel(MotDevParams p, ClusterBuffers c) {
 #pragma unroll
     for (int t2 = 0; t2 < kTilesPerChunk; t2++) {
       const int v = s_tilecnt[threadIdx.x][t2];
-      s_tilecnt[threadIdx.x][t2] = run | (my_groups << 16);
+      s_tilecnt[threadIdx.x][t2] = (unsigned short)(run | (my_groups << 11));
       run += v; my_groups += v > 0 ? 1 : 0;
     }
   }
@@ -293,8 +303,8 @@ label_stats_kernel(MotDevParams p, ClusterBuffers c) {
     PointGroup g = s_groups[e];
     if (s_slot[e] >= 0) {
       const int pre = s_tilecnt[s_slot[e]][g.tile & (kTilesPerChunk - 1)];
-      g.tile |= (pre & 0xffff) << kGroupTileBits;   // < 2048 points per chunk
-      g.label |= (pre >> 16) << 16;                 // < 32 groups per chunk and cluster
+      g.tile |= (pre & 0x7ff) << kGroupTileBits;   // < 2048 points per chunk
+      g.label |= (pre >> 11) << 16;                // < 32 groups per chunk and cluster
     }
     if (gb + t < c.group_cap) out[gb + t] = g;
   }
