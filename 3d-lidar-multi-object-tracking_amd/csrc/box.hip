@@ -101,9 +101,6 @@ __device__ __forceinline__ void stats_commit(ClusterStats* s, int count, int fir
   if (rmax != kArgmaxInit) atomicMax(&s->argmax, rmax);
 }
 
-#if defined(MOT_LABEL_WAVES) && !defined(MOT_HIPEMU)
-__attribute__((amdgpu_waves_per_eu(MOT_LABEL_WAVES, MOT_LABEL_WAVES)))
-#endif
 __global__ void MOT_LAUNCH_BOUNDS(kLabelBlock)
 label_stats_kernel(MotDevParams p, ClusterBuffers c) {
   constexpr int kWaves = kLabelBlock / 64, kPerWave = kGroupsPerWg / kWaves;
@@ -179,16 +176,19 @@ label_stats_kernel(MotDevParams p, ClusterBuffers c) {
     int lab = labs[k];
     const float4 q = qs[k];
     if (lab < 0 || lab > num_cluster) lab = 0;
+    if (label && i < n) label[i] = lab;
+    if (lab > kMaxClusters) lab = 0;  // no statistics slot: box_finalize_kernel raises the capacity flag
+    unsigned long long active = __ballot(lab > 0);
+    if (k == 0) { B1_T(0); }
+    if (!active) continue;   // (wave-uniform) a tile without a point of any cluster: nothing below is ever read back — one tile in twelve of a street scene
     if (i < n) {
-      if (label) label[i] = lab;
       // picture pixel of the point (box_fitting.cpp:244-254, before the per-cluster re-centring): the rectangle branch of
       // the gather kernel works on these, read in cluster-sorted order, instead of fetching every point again
       const float roiX = q.x + p.roi_half, roiY = q.y + p.roi_half;
       const int picX = (int)floorf(roiX * p.pic_scale), y = (int)floorf(roiY * p.pic_scale);
       const int picY = (int)(p.pic_full - (float)y);
-      pix[i] = (int)((unsigned)((picX >= 0 && picX < 1024) ? picX : 0xffff) | ((unsigned)picY << 16));   // only points inside the ROI (0 <= picY <= 900) are ever read back
+      pix[i] = (int)((unsigned)((picX >= 0 && picX < 1024) ? picX : 0xffff) | ((unsigned)picY << 16));   // only points of a cluster (inside the ROI: 0 <= picY <= 900) are ever read back
     }
-    if (lab > kMaxClusters) lab = 0;  // no statistics slot: box_finalize_kernel raises the capacity flag
     // `if (pZ > maxZ) maxZ = pZ` (:286) keeps the FIRST of equal maxima, and equal maxima can differ only as -0 / +0: the keyed
     // maximum below folds both onto +0, so the (rare) zero heights leave the index of their first occurrence behind
     if (lab > 0 && q.z == 0.0f) atomicMin(&stats[lab - 1].first_zero, (int)i);
@@ -201,8 +201,6 @@ label_stats_kernel(MotDevParams p, ClusterBuffers c) {
     const int zkey = (q.z > -99.f) ? mot_float_key(q.z + 0.0f) : mot_float_key(-99.f);  // `pZ > maxZ`, maxZ = -99
     // (walking TWO tiles of the wave per trip of the loop below, so that their reduction chains overlap, measured 172-175 us against 165:
     // a tile that has run out of clusters rides along on an empty match, and tiles rarely hold equally many. profiles/r03_box_stage_experiments.txt)
-    unsigned long long active = __ballot(lab > 0);
-    if (k == 0) { B1_T(0); }
     const int tile = (int)((base + k * kLabelBlock + (threadIdx.x & ~63)) / 64);
     while (active) {  // one trip per distinct cluster among the 64 points of this wave
       const int leader = __ffsll(active) - 1;
@@ -212,7 +210,8 @@ label_stats_kernel(MotDevParams p, ClusterBuffers c) {
       const int rmin_k = wave_reduce_i32_id(mine ? kmin : kNoMin, OpMinI(), kNoMin);
       const int rmax_k = wave_reduce_i32_id(mine ? kmax : kNoMax, OpMaxI(), kNoMax);
       const int rz = wave_reduce_i32_id(mine ? zkey : kNoMax, OpMaxI(), kNoMax);   // every real key exceeds kNoMax
-      const unsigned long long at_min = __ballot(mine && kmin == rmin_k), at_max = __ballot(mine && kmax == rmax_k);
+      // (two compare masks ANDed in scalar registers; a ballot of `mine && ...` goes through a v_cndmask + v_cmp pair)
+      const unsigned long long at_min = __ballot(kmin == rmin_k) & mm, at_max = __ballot(kmax == rmax_k) & mm;
       if (lane == leader) {  // the leader is the lowest lane = the smallest index of the group
         const unsigned i0 = (unsigned)tile * 64u;
         // keys as this file's consumers decode them: high word = unsigned ordered slope, low word = index (min) / ~index (max)
