@@ -136,7 +136,8 @@ struct mot_ctx {
   // per-point cluster labels of a slot: 1 = in d_label; 0 = not computed, the slot's cloud and cells come from the fused compaction kernel;
   // 2 = not computed, the slot's cloud was uploaded by a stage-wise call (no cells). mot_get_clusters computes them on demand.
   std::vector<char> label_state;
-  bool elev_packed = false;           // the elevated clouds now resident are 12-byte points (the fused path's elevated-only compaction: mot_internal.h PackedXyz)
+  bool elev_packed = false;           // the last fused batch left its elevated clouds as 12-byte points (the elevated-only compaction: mot_internal.h PackedXyz)
+  std::vector<char> slot_float4;      // per slot: a stage-wise call has put float4 records there since (those calls write slot 0 only: the batch's other slots stay packed)
   std::vector<char> box_valid;        // per slot: the box stage's products (boxes, cluster order, groups) belong to the cloud now resident in the slot
   bool ground_resident = false;        // d_ground / d_mask hold the last batch's ground cloud and mask
   bool last_fused = false;             // the last ground launch was a fused one (input, cells and thresholds of the batch still resident)
@@ -328,9 +329,12 @@ static int arg_block_commit(mot_ctx* c, size_t off, size_t bytes) {
   return MOT_OK;
 }
 
-static ClusterBuffers cluster_buffers(mot_ctx* c) {
+// layout of the elevated cloud resident in `slot`
+static bool elev_packed_at(const mot_ctx* c, int slot) { return c->elev_packed && !c->slot_float4[slot]; }
+// slot < 0: a launch over the whole fused batch just issued; otherwise the slot a single-frame launch works on
+static ClusterBuffers cluster_buffers(mot_ctx* c, int slot = -1) {
   ClusterBuffers b;
-  b.elevated = c->d_elev; b.elevated_packed = c->elev_packed ? 1 : 0; b.cap = c->cap; b.counts = c->d_counts; b.plane_a = c->d_plane_a; b.plane_b = c->d_plane_b; b.ccl_parent = c->d_ccl_parent;
+  b.elevated = c->d_elev; b.elevated_packed = (slot < 0 ? c->elev_packed : elev_packed_at(c, slot)) ? 1 : 0; b.cap = c->cap; b.counts = c->d_counts; b.plane_a = c->d_plane_a; b.plane_b = c->d_plane_b; b.ccl_parent = c->d_ccl_parent;
   b.occ_list = nullptr; b.occ_count = nullptr; b.n_in = c->d_n; b.occ_chunks = c->occ_chunks;   // the fused path points these at the compaction kernel's lists
   b.grid = c->d_grid; b.label = c->d_label; b.stats = c->d_stats; b.cand = c->d_cand; b.boxes = c->d_boxes;
   b.box_cluster = c->d_box_cluster; b.rng = c->d_rng; b.poly = c->d_poly; b.groups = c->d_groups; b.group_cap = c->cap / 2; b.cluster_start = c->d_cluster_start; b.cluster_gstart = c->d_cluster_gstart; b.order = c->d_order; b.gsorted = c->d_gsorted;
@@ -458,6 +462,7 @@ static int create_impl(mot_ctx* c) {
   c->h_n.assign(B, 0);
   c->label_state.assign(B, 2);
   c->box_valid.assign(B, 0);
+  c->slot_float4.assign(B, 0);
   return MOT_OK;
 }
 
@@ -745,6 +750,7 @@ static int launch_frames(mot_ctx* c, int batch, int run_tracker, const double* t
   c->label_state.assign(c->batch, (c->fused_outputs & MOT_OUT_LABELS) ? 1 : 0);
   c->box_valid.assign(c->batch, 1);
   c->elev_packed = MOT_PACKED_ELEVATED && !want_ground;   // how this call's compaction kernel leaves the elevated clouds (host state: also on a graph replay)
+  std::fill(c->slot_float4.begin(), c->slot_float4.end(), 0);
 #ifndef MOT_HIPEMU
   // Few streams per launch = somebody waits for every frame: the sequence's 10-13 launches go out as ONE hipGraph launch, captured
   // once per launch geometry. What differs from call to call without changing the geometry (the cloud's address, the look-back
@@ -840,6 +846,7 @@ extern "C" int mot_sequence_dev(mot_ctx* c, const float* d_xyzw, long frame_stri
   c->label_state.assign(c->batch, (c->fused_outputs & MOT_OUT_LABELS) ? 1 : 0);
   c->box_valid.assign(c->batch, 1);
   c->elev_packed = MOT_PACKED_ELEVATED && !want_ground;   // how this call's compaction kernel leaves the elevated clouds (host state: also on a graph replay)
+  std::fill(c->slot_float4.begin(), c->slot_float4.end(), 0);
   issue_frame_kernels(c, K, max_n, 0, want_ground, want_mask, false);   // slots = frames; ends with the plain box_finalize_kernel
   const TrackBuffers base = track_buffers(c, true);
   RangeScope rt(c, "mot:tracker (sequence)");
@@ -1010,7 +1017,7 @@ extern "C" int mot_get_clusters(mot_ctx* c, int slot, int32_t* grid, int* num_cl
   if (grid) { c->h_grid16.resize((size_t)G * G); MOT_HIP(c, hipMemcpyAsync(c->h_grid16.data(), c->d_grid + (size_t)slot * MOT_MAX_GRID * MOT_MAX_GRID, (size_t)G * G * sizeof(GridLabel), hipMemcpyDeviceToHost, c->stream)); }
   if (point_label && ne > 0 && c->label_state[slot] != 1) {
     // the fused path left the per-point labels out (mot_set_fused_outputs): this slot's, from its cells and label grid
-    ClusterBuffers cb = cluster_buffers(c);
+    ClusterBuffers cb = cluster_buffers(c, slot);
     cb.ecell = (c->label_state[slot] == 0 && c->params.num_grid < MOT_MAX_GRID) ? c->d_ecell : nullptr;
     mot_launch_point_labels(c->dp, cb, slot, ne, c->stream);
     MOT_HIP(c, hipGetLastError());
@@ -1046,9 +1053,9 @@ extern "C" int mot_cluster(mot_ctx* c, const float* elev, int n, int32_t* grid, 
   int rc;
   if (n > 0) MOT_HIP(c, hipMemcpyAsync(c->d_elev, elev, (size_t)n * 16, hipMemcpyHostToDevice, c->stream));
   c->last_fused = false;   // slot 0 now holds this call's cloud: mot_get_ground must not re-run a fused batch's compaction over it
-  c->elev_packed = false;  // ... as float4 records
+  c->slot_float4[0] = 1;  // ... as float4 records
   if ((rc = set_count(c, 0, kCntElev, n))) return rc;
-  ClusterBuffers cb = cluster_buffers(c);
+  ClusterBuffers cb = cluster_buffers(c, 0);
   mot_launch_cluster(c->dp, cb, 1, n, c->stream);
   if (point_label) {  // getClusteredPoints' per-point lookup; the statistics it also gathers are discarded
     mot_launch_box_kernel(0, c->dp, cb, 1, n, c->stream);
@@ -1078,10 +1085,10 @@ extern "C" int mot_box_fit(mot_ctx* c, const float* elev, int n, const int32_t* 
   MOT_HIP(c, hipMemcpyAsync(c->d_grid, c->h_grid16.data(), (size_t)G * G * sizeof(GridLabel), hipMemcpyHostToDevice, c->stream));
   MOT_HIP(c, hipStreamSynchronize(c->stream));   // (h_grid16 is reused by the next call)
   c->last_fused = false;   // slot 0 now holds this call's cloud: mot_get_ground must not re-run a fused batch's compaction over it
-  c->elev_packed = false;
+  c->slot_float4[0] = 1;
   if ((rc = set_count(c, 0, kCntElev, n))) return rc;
   if ((rc = set_count(c, 0, kCntClusters, num_cluster))) return rc;
-  ClusterBuffers cb = cluster_buffers(c);
+  ClusterBuffers cb = cluster_buffers(c, 0);
   mot_launch_box(c->dp, cb, 1, n, c->stream);
   c->label_state[0] = 1; c->box_valid[0] = 1;
   MOT_HIP(c, hipGetLastError());
@@ -1099,7 +1106,7 @@ extern "C" int mot_box_fit_resident(mot_ctx* c, float* boxes, int max_boxes, int
   const int n = c->h_counts[kCntElev];
   if (n < 0 || n > c->cap) return fail(c, MOT_E_STATE, "mot_box_fit_resident: no cloud resident in slot 0");
   if (c->h_counts[kCntClusters] > kMaxClusters) return fail(c, MOT_E_CAPACITY, "more clusters than the library supports (4096)");
-  mot_launch_box(c->dp, cluster_buffers(c), 1, n, c->stream);
+  mot_launch_box(c->dp, cluster_buffers(c, 0), 1, n, c->stream);
   c->label_state[0] = 1; c->box_valid[0] = 1;
   MOT_HIP(c, hipGetLastError());
   return mot_get_boxes(c, 0, boxes, max_boxes, n_boxes, box_cluster, n_undefined);
@@ -1148,7 +1155,7 @@ static int side_setup(mot_ctx* c, int slot, const mot_side_params* sp, SideDevPa
   d.center_y = (sp->cost_height / 2.0) * sp->cost_resolution - sp->cost_offset_y;   // map_center_y, :429
   d.height_limit = sp->height_limit; d.car_length = sp->car_length; d.car_width = sp->car_width;
   SideBuffers s;
-  s.elevated = c->d_elev + (size_t)slot * c->cap; s.elevated_packed = c->elev_packed ? 1 : 0; s.grid = c->d_grid + (size_t)slot * MOT_MAX_GRID * MOT_MAX_GRID;
+  s.elevated = c->d_elev + (size_t)slot * c->cap; s.elevated_packed = elev_packed_at(c, slot) ? 1 : 0; s.grid = c->d_grid + (size_t)slot * MOT_MAX_GRID * MOT_MAX_GRID;
   s.counts = c->d_counts + (size_t)slot * kCountsStride; s.cell_first = c->d_side_cell; s.clustered = c->d_side_cloud;
   s.obstacles = c->d_side_obs; s.cost = c->d_side_cost; s.out_counts = c->d_side_counts; s.chunk_counts = c->d_side_chunks;
   s.max_clustered = c->cap; s.max_obstacles = MOT_MAX_GRID * MOT_MAX_GRID;
@@ -1209,7 +1216,7 @@ extern "C" int mot_cluster_products_host(mot_ctx* c, const float* elev, int n, c
   MOT_HIP(c, hipMemcpyAsync(c->d_grid, c->h_grid16.data(), (size_t)G * G * sizeof(GridLabel), hipMemcpyHostToDevice, c->stream));
   MOT_HIP(c, hipStreamSynchronize(c->stream));
   c->last_fused = false;   // slot 0 now holds this call's cloud: mot_get_ground must not re-run a fused batch's compaction over it
-  c->elev_packed = false;
+  c->slot_float4[0] = 1;
   c->box_valid[0] = 0;
   int rc = set_count(c, 0, kCntElev, n);
   if (rc) return rc;
@@ -1230,7 +1237,7 @@ extern "C" int mot_box_markers(mot_ctx* c, int slot, float* centroid_extent, int
   if (nb > max_boxes) return fail(c, MOT_E_CAPACITY, "more boxes than the caller's buffer holds");
   if (nb == 0 || !centroid_extent) return MOT_OK;
   if (!c->d_markers) MOT_HIP(c, hipMalloc(&c->d_markers, (size_t)kMaxBoxesPerFrame * 6 * sizeof(float)));
-  mot_launch_box_markers(cluster_buffers(c), slot, nb < kMaxBoxesPerFrame ? nb : kMaxBoxesPerFrame, c->d_markers, c->stream);
+  mot_launch_box_markers(cluster_buffers(c, slot), slot, nb < kMaxBoxesPerFrame ? nb : kMaxBoxesPerFrame, c->d_markers, c->stream);
   MOT_HIP(c, hipGetLastError());
   MOT_HIP(c, hipMemcpyAsync(centroid_extent, c->d_markers, (size_t)nb * 6 * sizeof(float), hipMemcpyDeviceToHost, c->stream));
   MOT_HIP(c, hipStreamSynchronize(c->stream));
@@ -1262,9 +1269,10 @@ extern "C" int mot_cluster_node_frame(mot_ctx* c, const float* elev, int n, cons
   if ((rc = pinned_scratch(c, total, &pin))) return rc;
   if (n > 0) MOT_HIP(c, hipMemcpyAsync(c->d_elev, elev, (size_t)n * 16, hipMemcpyHostToDevice, c->stream));
   c->last_fused = false;   // slot 0 now holds this call's cloud
-  c->elev_packed = false;
+  c->slot_float4[0] = 1;
+  s.elevated_packed = 0;   // (side_setup looked at slot 0 BEFORE the upload: after a fused batch on this context it saw 12-byte points there)
   if ((rc = set_count(c, 0, kCntElev, n))) return rc;
-  ClusterBuffers cb = cluster_buffers(c);
+  ClusterBuffers cb = cluster_buffers(c, 0);
   mot_launch_cluster(c->dp, cb, 1, n, c->stream);
   mot_launch_side_products(c->dp, d, s, n > 0 ? n : 1, c->stream);
   mot_launch_box(c->dp, cb, 1, n, c->stream);
@@ -1316,7 +1324,7 @@ extern "C" int mot_get_ground(mot_ctx* c, int slot, float* elev, int* n_elev, fl
   if (n_ground) *n_ground = ng;
   if ((elev && ne > capacity_points) || (ground && ng > capacity_points) || (mask && c->h_n[slot] > capacity_points))
     return fail(c, MOT_E_CAPACITY, "more points resident than the caller's buffers hold (capacity_points)");
-  if (((ground || mask) && !c->ground_resident) || (elev && c->elev_packed)) {   // (packed: the fused path left 12-byte points; the ABI's records are float4 with the input's 4th value)
+  if (((ground || mask) && !c->ground_resident) || (elev && elev_packed_at(c, slot))) {   // (packed: the fused path left 12-byte points; the ABI's records are float4 with the input's 4th value)
     // The fused path left the ground cloud / mask out (mot_set_fused_outputs): materialise them for the whole last batch by
     // re-running the compaction with every output, from the batch's input, polar cells and thresholds — all still resident.
     // (No occupancy this time: the cluster stage has consumed it. The elevated cloud and the counts are rewritten with the
@@ -1348,7 +1356,7 @@ extern "C" int mot_ground_remove(mot_ctx* c, const float* xyzw, int n, float* el
   GroundBuffers g = ground_buffers(c, c->d_in, c->cap, true);
   mot_launch_ground(c->dp, g, 1, n, c->stream);
   MOT_HIP(c, hipGetLastError());
-  c->ground_resident = true; c->last_fused = false; c->elev_packed = false; c->label_state[0] = 2; c->box_valid[0] = 0;
+  c->ground_resident = true; c->last_fused = false; c->slot_float4[0] = 1; c->label_state[0] = 2; c->box_valid[0] = 0;
   return mot_get_ground(c, 0, elev, n_elev, ground, n_ground, mask, n);
 }
 
@@ -1368,7 +1376,7 @@ extern "C" int mot_ground_node_frame(mot_ctx* c, const float* xyzw, int n, const
   mot_launch_ground(c->dp, g, 1, n, c->stream);
   MOT_HIP(c, hipGetLastError());
   c->ground_resident = false;   // (no mask: a later mot_get_ground that asks for one answers MOT_E_STATE)
-  c->elev_packed = false;
+  c->slot_float4[0] = 1;
   c->last_fused = false; c->label_state[0] = 2; c->box_valid[0] = 0;
   if ((rc = fetch_counts(c, 0))) return rc;
   const int ne = c->h_counts[kCntElev], ng = c->h_counts[kCntGround];
@@ -1415,7 +1423,7 @@ extern "C" int mot_ground_remove_pointcloud2(mot_ctx* c, const void* data, int n
   GroundBuffers g = ground_buffers(c, c->d_in, c->cap, true);
   mot_launch_ground(c->dp, g, 1, n, c->stream);
   MOT_HIP(c, hipGetLastError());
-  c->ground_resident = true; c->last_fused = false; c->elev_packed = false; c->label_state[0] = 2; c->box_valid[0] = 0;
+  c->ground_resident = true; c->last_fused = false; c->slot_float4[0] = 1; c->label_state[0] = 2; c->box_valid[0] = 0;
   return mot_get_ground(c, 0, elev, n_elev, ground, n_ground, mask, n);
 }
 
@@ -1436,7 +1444,7 @@ static int launch_one(mot_ctx* c, int id, int batch) {
   GroundBuffers g = ground_buffers(c, c->last_in, c->last_in_stride, (c->fused_outputs & MOT_OUT_MASK) != 0, true);   // as in the fused path: the compaction kernel leaves the occupancy lists
   if (!(c->fused_outputs & MOT_OUT_GROUND)) g.ground = nullptr;
   g.elevated_packed = (MOT_PACKED_ELEVATED && !g.ground) ? 1 : 0;
-  if (id == kK3) c->elev_packed = g.elevated_packed != 0;
+  if (id == kK3) { c->elev_packed = g.elevated_packed != 0; std::fill(c->slot_float4.begin(), c->slot_float4.end(), 0); }
   if (id == kK3) c->ground_resident = (c->fused_outputs & (MOT_OUT_GROUND | MOT_OUT_MASK)) == (MOT_OUT_GROUND | MOT_OUT_MASK);
   ClusterBuffers cb = cluster_buffers(c);
   cb.occ_list = c->d_occ_list; cb.occ_count = c->d_occ_count; cb.ecell = g.ecell;

@@ -296,7 +296,9 @@ int mot_sequence_dev(mot_ctx* ctx, const float* d_xyzw, long frame_stride, const
  * elevated points as 12-byte {x, y, z}: nothing after groundRemove reads the 4th float). A mot_get_ground that asks for a cloud or the
  * mask after a fused call re-runs the compaction from the batch's input, polar cells and thresholds, all still resident —
  * so with mot_frames_dev the caller's input buffer must be unchanged until then; a stage-wise mot_cluster / mot_box_fit /
- * mot_cluster_products_host in between takes slot 0 for itself and ends that possibility: MOT_E_STATE. Likewise the per-point cluster labels
+ * mot_cluster_products_host / mot_cluster_node_frame in between takes slot 0 for itself and ends that possibility: MOT_E_STATE (the batch's
+ * OTHER slots keep everything else readable after such a call — labels, side products, boxes, cubes: the library knows per slot which layout
+ * the elevated cloud has). Likewise the per-point cluster labels
  * (getClusteredPoints, OT/src/cluster/box_fitting.cpp:46-72: the box stage itself works on a cluster-sorted index and never reads
  * them back): mot_get_clusters(point_label) computes them for the slot it is asked about, from the cells and the label grid still
  * resident. Sticky per context. The stage-wise mot_ground_remove / mot_cluster always deliver all their outputs

@@ -1,0 +1,52 @@
+"""a stage-wise call after a fused batch (shared by the emulator test and the GPU test)"""
+import numpy as np
+import pytest
+
+
+def run(mot, lib, synth, oracle, upload=None, N=5000):
+    # upload(host array) -> pointer frames_dev takes (the emulator reads host memory: the array itself)
+    """The fused path leaves 12-byte elevated points (round 5); a stage-wise call puts float4 records into slot 0 only. Readers must take each
+    slot's cloud for what it is: the on-demand labels, side products and cubes of the batch's OTHER slots after such a call, slot 0's own
+    results, and mot_cluster_node_frame on a context that ran a fused batch before (its side products looked at the layout flag before the
+    upload)."""
+    B = 3; stride = ((N + 1023) // 1024) * 1024
+    p = oracle.params(0)
+    host = np.zeros((B, stride, 4), np.float32)
+    for s in range(B):
+        host[s, :N] = synth.make_cloud(N, 90 + s, s % 3)
+    o = [oracle.ground_remove(p, host[s, :N]) for s in range(B)]
+    want = [oracle.cluster(p, o[s]["elevated"]) for s in range(B)]
+    other = np.ascontiguousarray(o[1]["elevated"][::-1])   # the stage-wise call's cloud: slot 1's, backwards
+    ref_other = oracle.cluster(p, other)
+    ptr = upload(host) if upload else host.ctypes.data
+    for call in ("cluster", "box_fit", "products_host", "node_frame", "ground_remove"):
+        with mot.Context(**({"lib_path": lib} if lib else {}), max_points=stride, max_batch=B, max_tracks_total=64) as c:
+            c.frames_dev(ptr, stride * 4, [N] * B)
+            before = {s: (c.get_boxes(s)["boxes"], c.cluster_products(s), c.box_markers(s)) for s in (1, 2)}   # the batch's own answers, packed clouds
+            if call == "cluster":
+                got = c.cluster(other)
+                assert np.array_equal(got["grid"], ref_other["grid"]) and np.array_equal(got["point_label"], ref_other["point_label"])
+            elif call == "box_fit":
+                got = c.box_fit(other, ref_other["grid"], ref_other["num_cluster"])
+                assert np.array_equal(got["boxes"], oracle.box_fit(p, other, ref_other["grid"], ref_other["num_cluster"])["boxes"])
+            elif call == "products_host":
+                got = c.cluster_products_host(other, ref_other["grid"])
+                ref = oracle.cluster_products(p, other, ref_other["grid"])
+                assert np.array_equal(got["clustered"], ref["clustered"]) and np.array_equal(got["cost_map"], ref["cost_map"])
+            elif call == "node_frame":
+                got = c.cluster_node_frame(other)
+                ref = oracle.cluster_products(p, other, ref_other["grid"])
+                assert np.array_equal(got["clustered"], ref["clustered"]) and np.array_equal(got["obstacles"], ref["obstacles"]) and np.array_equal(got["cost_map"], ref["cost_map"])
+                assert np.array_equal(got["boxes"], oracle.box_fit(p, other, ref_other["grid"], ref_other["num_cluster"])["boxes"])
+            else:
+                got = c.ground_remove(host[0, :N])
+                assert np.array_equal(got["elevated"], o[0]["elevated"])
+            for s in (1, 2):   # the other slots still hold the fused batch's 12-byte points
+                cl = c.get_clusters(s, n_elevated=len(o[s]["elevated"]))
+                assert np.array_equal(cl["point_label"][: len(o[s]["elevated"])], want[s]["point_label"]), (call, s)
+                sp, mk = c.cluster_products(s), c.box_markers(s)
+                assert all(np.array_equal(sp[k], before[s][1][k]) for k in ("clustered", "obstacles", "cost_map")), (call, s)
+                assert np.array_equal(mk, before[s][2]) and np.array_equal(c.get_boxes(s)["boxes"], before[s][0]), (call, s)
+                with pytest.raises(mot.MotError) as e:   # their float4 records cannot be rebuilt any more (slot 0 of the batch is gone): an error, not 12-byte points read as 16
+                    c.get_ground(s, n_hint=N)
+                assert e.value.code == mot.MOT_E_STATE, (call, s)

@@ -199,6 +199,19 @@ def test_by_products_on_demand_equal_materialised(mot, hip_lib, oracle, synth):
         assert np.array_equal(got["grid"], ref["grid"]) and np.array_equal(got["point_label"], ref["point_label"])
 
 
+def test_stage_wise_call_after_a_fused_batch_leaves_the_other_slots_readable(mot, hip_lib, oracle, synth):
+    """tests/mixed_use_case.py on the device: the fused batch's 12-byte elevated points in slots 1, 2 stay readable (labels, side products, cubes)
+    after a stage-wise call has put float4 records into slot 0, and the node-frame call after a fused batch reads its own upload as float4"""
+    import mixed_use_case
+    bufs = []
+    def upload(host):
+        bufs.append(hiprt.DeviceBuffer(host)); return bufs[-1].ptr
+    try:
+        mixed_use_case.run(mot, None, synth, oracle, upload=upload, N=40000)
+    finally:
+        for d in bufs: d.free()
+
+
 def test_trace_ranges_on_the_device(mot, hip_lib, synth):
     """roctx stage ranges (mot_set_trace_ranges) change nothing but the markers: a frame with them on equals a frame with them off"""
     cloud = synth.make_cloud(30000, 2, 0)

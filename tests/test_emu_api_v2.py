@@ -234,6 +234,11 @@ def test_point_labels_on_demand_without_cells(mot, emu, synth, oracle):
         assert ref["num_cluster"] == want["num_cluster"]
 
 
+def test_stage_wise_call_after_a_fused_batch_leaves_the_other_slots_readable(mot, emu, synth, oracle):
+    import mixed_use_case
+    mixed_use_case.run(mot, emu[0], synth, oracle)
+
+
 def test_reset_tracks_slot_keeps_the_global_frame(mot, emu, oracle):
     """mot_reset_tracks_slot forgets a stream's tracks but not its ego dead reckoning: the origin of the global frame stays where it
     was (mot_reset_slot would re-origin it at the current pose), and the next tracker step seeds anew like the reference's first frame"""
