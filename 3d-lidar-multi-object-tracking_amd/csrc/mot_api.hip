@@ -140,6 +140,7 @@ struct mot_ctx {
   std::vector<char> slot_float4;      // per slot: a stage-wise call has put float4 records there since (those calls write slot 0 only: the batch's other slots stay packed)
   std::vector<char> box_valid;        // per slot: the box stage's products (boxes, cluster order, groups) belong to the cloud now resident in the slot
   bool ground_resident = false;        // d_ground / d_mask hold the last batch's ground cloud and mask
+  bool ground_all = false;             // ... of every slot of the last fused batch; false: of slot 0 only (a stage-wise mot_ground_remove* since)
   bool last_fused = false;             // the last ground launch was a fused one (input, cells and thresholds of the batch still resident)
   int* h_counts = nullptr;  // pinned [batch][4]
   int last_batch = 0, last_max_n = 0;
@@ -746,7 +747,7 @@ static int launch_frames(mot_ctx* c, int batch, int run_tracker, const double* t
     if ((rc = arg_block_commit(c, 0, (run_tracker || c->graph_mode) ? c->arg_bytes : batch * sizeof(int)))) return rc;
   }
   const bool want_ground = (c->fused_outputs & MOT_OUT_GROUND) != 0, want_mask = (c->fused_outputs & MOT_OUT_MASK) != 0;
-  c->ground_resident = want_ground && want_mask; c->last_fused = true;
+  c->ground_resident = want_ground && want_mask; c->ground_all = true; c->last_fused = true;
   c->label_state.assign(c->batch, (c->fused_outputs & MOT_OUT_LABELS) ? 1 : 0);
   c->box_valid.assign(c->batch, 1);
   c->elev_packed = MOT_PACKED_ELEVATED && !want_ground;   // how this call's compaction kernel leaves the elevated clouds (host state: also on a graph replay)
@@ -842,7 +843,7 @@ extern "C" int mot_sequence_dev(mot_ctx* c, const float* d_xyzw, long frame_stri
     if ((rc = arg_block_commit(c, 0, c->arg_bytes))) return rc;
   }
   const bool want_ground = (c->fused_outputs & MOT_OUT_GROUND) != 0, want_mask = (c->fused_outputs & MOT_OUT_MASK) != 0;
-  c->ground_resident = want_ground && want_mask; c->last_fused = true;
+  c->ground_resident = want_ground && want_mask; c->ground_all = true; c->last_fused = true;
   c->label_state.assign(c->batch, (c->fused_outputs & MOT_OUT_LABELS) ? 1 : 0);
   c->box_valid.assign(c->batch, 1);
   c->elev_packed = MOT_PACKED_ELEVATED && !want_ground;   // how this call's compaction kernel leaves the elevated clouds (host state: also on a graph replay)
@@ -1324,7 +1325,8 @@ extern "C" int mot_get_ground(mot_ctx* c, int slot, float* elev, int* n_elev, fl
   if (n_ground) *n_ground = ng;
   if ((elev && ne > capacity_points) || (ground && ng > capacity_points) || (mask && c->h_n[slot] > capacity_points))
     return fail(c, MOT_E_CAPACITY, "more points resident than the caller's buffers hold (capacity_points)");
-  if (((ground || mask) && !c->ground_resident) || (elev && elev_packed_at(c, slot))) {   // (packed: the fused path left 12-byte points; the ABI's records are float4 with the input's 4th value)
+  const bool have_ground = c->ground_resident && (c->ground_all || slot == 0);
+  if (((ground || mask) && !have_ground) || (elev && elev_packed_at(c, slot))) {   // (packed: the fused path left 12-byte points; the ABI's records are float4 with the input's 4th value)
     // The fused path left the ground cloud / mask out (mot_set_fused_outputs): materialise them for the whole last batch by
     // re-running the compaction with every output, from the batch's input, polar cells and thresholds — all still resident.
     // (No occupancy this time: the cluster stage has consumed it. The elevated cloud and the counts are rewritten with the
@@ -1334,7 +1336,7 @@ extern "C" int mot_get_ground(mot_ctx* c, int slot, float* elev, int* n_elev, fl
     GroundBuffers g = ground_buffers(c, c->last_in, c->last_in_stride, true, false);
     mot_launch_ground_kernel(2, c->dp, g, c->last_batch, c->last_max_n, c->stream);
     MOT_HIP(c, hipGetLastError());
-    c->ground_resident = true; c->elev_packed = false;   // every slot's elevated cloud is float4 again (same points, same order: what the later stages hold stays valid)
+    c->ground_resident = true; c->ground_all = true; c->elev_packed = false;   // every slot's elevated cloud is float4 again (same points, same order: what the later stages hold stays valid)
   }
   if (elev && ne > 0) MOT_HIP(c, hipMemcpyAsync(elev, c->d_elev + (size_t)slot * c->cap, (size_t)ne * 16, hipMemcpyDeviceToHost, c->stream));
   if (ground && ng > 0) MOT_HIP(c, hipMemcpyAsync(ground, c->d_ground + (size_t)slot * c->cap, (size_t)ng * 16, hipMemcpyDeviceToHost, c->stream));
@@ -1356,7 +1358,7 @@ extern "C" int mot_ground_remove(mot_ctx* c, const float* xyzw, int n, float* el
   GroundBuffers g = ground_buffers(c, c->d_in, c->cap, true);
   mot_launch_ground(c->dp, g, 1, n, c->stream);
   MOT_HIP(c, hipGetLastError());
-  c->ground_resident = true; c->last_fused = false; c->slot_float4[0] = 1; c->label_state[0] = 2; c->box_valid[0] = 0;
+  c->ground_resident = true; c->ground_all = false; c->last_fused = false; c->slot_float4[0] = 1; c->label_state[0] = 2; c->box_valid[0] = 0;
   return mot_get_ground(c, 0, elev, n_elev, ground, n_ground, mask, n);
 }
 
@@ -1423,7 +1425,7 @@ extern "C" int mot_ground_remove_pointcloud2(mot_ctx* c, const void* data, int n
   GroundBuffers g = ground_buffers(c, c->d_in, c->cap, true);
   mot_launch_ground(c->dp, g, 1, n, c->stream);
   MOT_HIP(c, hipGetLastError());
-  c->ground_resident = true; c->last_fused = false; c->slot_float4[0] = 1; c->label_state[0] = 2; c->box_valid[0] = 0;
+  c->ground_resident = true; c->ground_all = false; c->last_fused = false; c->slot_float4[0] = 1; c->label_state[0] = 2; c->box_valid[0] = 0;
   return mot_get_ground(c, 0, elev, n_elev, ground, n_ground, mask, n);
 }
 
@@ -1445,7 +1447,7 @@ static int launch_one(mot_ctx* c, int id, int batch) {
   if (!(c->fused_outputs & MOT_OUT_GROUND)) g.ground = nullptr;
   g.elevated_packed = (MOT_PACKED_ELEVATED && !g.ground) ? 1 : 0;
   if (id == kK3) { c->elev_packed = g.elevated_packed != 0; std::fill(c->slot_float4.begin(), c->slot_float4.end(), 0); }
-  if (id == kK3) c->ground_resident = (c->fused_outputs & (MOT_OUT_GROUND | MOT_OUT_MASK)) == (MOT_OUT_GROUND | MOT_OUT_MASK);
+  if (id == kK3) { c->ground_resident = (c->fused_outputs & (MOT_OUT_GROUND | MOT_OUT_MASK)) == (MOT_OUT_GROUND | MOT_OUT_MASK); c->ground_all = true; }
   ClusterBuffers cb = cluster_buffers(c);
   cb.occ_list = c->d_occ_list; cb.occ_count = c->d_occ_count; cb.ecell = g.ecell;
   if (!(c->fused_outputs & MOT_OUT_LABELS)) cb.label = nullptr;   // as in the fused path

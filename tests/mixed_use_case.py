@@ -50,3 +50,7 @@ def run(mot, lib, synth, oracle, upload=None, N=5000):
                 with pytest.raises(mot.MotError) as e:   # their float4 records cannot be rebuilt any more (slot 0 of the batch is gone): an error, not 12-byte points read as 16
                     c.get_ground(s, n_hint=N)
                 assert e.value.code == mot.MOT_E_STATE, (call, s)
+                # ... nor their ground cloud alone: after a stage-wise mot_ground_remove only slot 0's is resident
+                gb = np.zeros((N, 4), np.float32); ne, ng = mot.C.c_int(0), mot.C.c_int(0)
+                rc = c.lib.mot_get_ground(c._h, s, None, mot.C.byref(ne), gb.ctypes.data_as(mot.C.c_void_p), mot.C.byref(ng), None, N)
+                assert rc == mot.MOT_E_STATE, (call, s, rc)
