@@ -136,8 +136,8 @@ struct mot_ctx {
   // per-point cluster labels of a slot: 1 = in d_label; 0 = not computed, the slot's cloud and cells come from the fused compaction kernel;
   // 2 = not computed, the slot's cloud was uploaded by a stage-wise call (no cells). mot_get_clusters computes them on demand.
   std::vector<char> label_state;
-  bool elev_packed = false;           // the last fused batch left its elevated clouds as 12-byte points (the elevated-only compaction: mot_internal.h PackedXyz)
-  std::vector<char> slot_float4;      // per slot: a stage-wise call has put float4 records there since (those calls write slot 0 only: the batch's other slots stay packed)
+  bool elev_packed = false;           // the last fused batch left its elevated clouds as 12-byte points (the elevated-only compaction: mot_internal.h PackedXyz) ...
+  std::vector<char> slot_packed;      // ... and what each SLOT holds now: a fused call writes the slots of its batch, a stage-wise call float4 records into slot 0 only
   std::vector<char> box_valid;        // per slot: the box stage's products (boxes, cluster order, groups) belong to the cloud now resident in the slot
   bool ground_resident = false;        // d_ground / d_mask hold the last batch's ground cloud and mask
   bool ground_all = false;             // ... of every slot of the last fused batch; false: of slot 0 only (a stage-wise mot_ground_remove* since)
@@ -331,7 +331,15 @@ static int arg_block_commit(mot_ctx* c, size_t off, size_t bytes) {
 }
 
 // layout of the elevated cloud resident in `slot`
-static bool elev_packed_at(const mot_ctx* c, int slot) { return c->elev_packed && !c->slot_float4[slot]; }
+static bool elev_packed_at(const mot_ctx* c, int slot) { return c->slot_packed[slot] != 0; }
+// a fused call over slots 0..batch-1 was issued: what those slots hold from now on (the slots beyond keep what an earlier, larger batch left)
+static void mark_fused_slots(mot_ctx* c, int batch, bool want_ground, bool want_mask) {
+  c->ground_resident = want_ground && want_mask; c->ground_all = true; c->last_fused = true;
+  c->elev_packed = MOT_PACKED_ELEVATED && !want_ground;   // how this call's compaction kernel leaves the elevated clouds (host state: also on a graph replay)
+  for (int b = 0; b < batch; b++) {
+    c->label_state[b] = (c->fused_outputs & MOT_OUT_LABELS) ? 1 : 0; c->box_valid[b] = 1; c->slot_packed[b] = c->elev_packed ? 1 : 0;
+  }
+}
 // slot < 0: a launch over the whole fused batch just issued; otherwise the slot a single-frame launch works on
 static ClusterBuffers cluster_buffers(mot_ctx* c, int slot = -1) {
   ClusterBuffers b;
@@ -463,7 +471,7 @@ static int create_impl(mot_ctx* c) {
   c->h_n.assign(B, 0);
   c->label_state.assign(B, 2);
   c->box_valid.assign(B, 0);
-  c->slot_float4.assign(B, 0);
+  c->slot_packed.assign(B, 0);
   return MOT_OK;
 }
 
@@ -747,11 +755,7 @@ static int launch_frames(mot_ctx* c, int batch, int run_tracker, const double* t
     if ((rc = arg_block_commit(c, 0, (run_tracker || c->graph_mode) ? c->arg_bytes : batch * sizeof(int)))) return rc;
   }
   const bool want_ground = (c->fused_outputs & MOT_OUT_GROUND) != 0, want_mask = (c->fused_outputs & MOT_OUT_MASK) != 0;
-  c->ground_resident = want_ground && want_mask; c->ground_all = true; c->last_fused = true;
-  c->label_state.assign(c->batch, (c->fused_outputs & MOT_OUT_LABELS) ? 1 : 0);
-  c->box_valid.assign(c->batch, 1);
-  c->elev_packed = MOT_PACKED_ELEVATED && !want_ground;   // how this call's compaction kernel leaves the elevated clouds (host state: also on a graph replay)
-  std::fill(c->slot_float4.begin(), c->slot_float4.end(), 0);
+  mark_fused_slots(c, batch, want_ground, want_mask);
 #ifndef MOT_HIPEMU
   // Few streams per launch = somebody waits for every frame: the sequence's 10-13 launches go out as ONE hipGraph launch, captured
   // once per launch geometry. What differs from call to call without changing the geometry (the cloud's address, the look-back
@@ -843,11 +847,7 @@ extern "C" int mot_sequence_dev(mot_ctx* c, const float* d_xyzw, long frame_stri
     if ((rc = arg_block_commit(c, 0, c->arg_bytes))) return rc;
   }
   const bool want_ground = (c->fused_outputs & MOT_OUT_GROUND) != 0, want_mask = (c->fused_outputs & MOT_OUT_MASK) != 0;
-  c->ground_resident = want_ground && want_mask; c->ground_all = true; c->last_fused = true;
-  c->label_state.assign(c->batch, (c->fused_outputs & MOT_OUT_LABELS) ? 1 : 0);
-  c->box_valid.assign(c->batch, 1);
-  c->elev_packed = MOT_PACKED_ELEVATED && !want_ground;   // how this call's compaction kernel leaves the elevated clouds (host state: also on a graph replay)
-  std::fill(c->slot_float4.begin(), c->slot_float4.end(), 0);
+  mark_fused_slots(c, K, want_ground, want_mask);
   issue_frame_kernels(c, K, max_n, 0, want_ground, want_mask, false);   // slots = frames; ends with the plain box_finalize_kernel
   const TrackBuffers base = track_buffers(c, true);
   RangeScope rt(c, "mot:tracker (sequence)");
@@ -1054,7 +1054,7 @@ extern "C" int mot_cluster(mot_ctx* c, const float* elev, int n, int32_t* grid, 
   int rc;
   if (n > 0) MOT_HIP(c, hipMemcpyAsync(c->d_elev, elev, (size_t)n * 16, hipMemcpyHostToDevice, c->stream));
   c->last_fused = false;   // slot 0 now holds this call's cloud: mot_get_ground must not re-run a fused batch's compaction over it
-  c->slot_float4[0] = 1;  // ... as float4 records
+  c->slot_packed[0] = 0;  // ... as float4 records
   if ((rc = set_count(c, 0, kCntElev, n))) return rc;
   ClusterBuffers cb = cluster_buffers(c, 0);
   mot_launch_cluster(c->dp, cb, 1, n, c->stream);
@@ -1086,7 +1086,7 @@ extern "C" int mot_box_fit(mot_ctx* c, const float* elev, int n, const int32_t* 
   MOT_HIP(c, hipMemcpyAsync(c->d_grid, c->h_grid16.data(), (size_t)G * G * sizeof(GridLabel), hipMemcpyHostToDevice, c->stream));
   MOT_HIP(c, hipStreamSynchronize(c->stream));   // (h_grid16 is reused by the next call)
   c->last_fused = false;   // slot 0 now holds this call's cloud: mot_get_ground must not re-run a fused batch's compaction over it
-  c->slot_float4[0] = 1;
+  c->slot_packed[0] = 0;
   if ((rc = set_count(c, 0, kCntElev, n))) return rc;
   if ((rc = set_count(c, 0, kCntClusters, num_cluster))) return rc;
   ClusterBuffers cb = cluster_buffers(c, 0);
@@ -1217,7 +1217,7 @@ extern "C" int mot_cluster_products_host(mot_ctx* c, const float* elev, int n, c
   MOT_HIP(c, hipMemcpyAsync(c->d_grid, c->h_grid16.data(), (size_t)G * G * sizeof(GridLabel), hipMemcpyHostToDevice, c->stream));
   MOT_HIP(c, hipStreamSynchronize(c->stream));
   c->last_fused = false;   // slot 0 now holds this call's cloud: mot_get_ground must not re-run a fused batch's compaction over it
-  c->slot_float4[0] = 1;
+  c->slot_packed[0] = 0;
   c->box_valid[0] = 0;
   int rc = set_count(c, 0, kCntElev, n);
   if (rc) return rc;
@@ -1270,7 +1270,7 @@ extern "C" int mot_cluster_node_frame(mot_ctx* c, const float* elev, int n, cons
   if ((rc = pinned_scratch(c, total, &pin))) return rc;
   if (n > 0) MOT_HIP(c, hipMemcpyAsync(c->d_elev, elev, (size_t)n * 16, hipMemcpyHostToDevice, c->stream));
   c->last_fused = false;   // slot 0 now holds this call's cloud
-  c->slot_float4[0] = 1;
+  c->slot_packed[0] = 0;
   s.elevated_packed = 0;   // (side_setup looked at slot 0 BEFORE the upload: after a fused batch on this context it saw 12-byte points there)
   if ((rc = set_count(c, 0, kCntElev, n))) return rc;
   ClusterBuffers cb = cluster_buffers(c, 0);
@@ -1325,18 +1325,19 @@ extern "C" int mot_get_ground(mot_ctx* c, int slot, float* elev, int* n_elev, fl
   if (n_ground) *n_ground = ng;
   if ((elev && ne > capacity_points) || (ground && ng > capacity_points) || (mask && c->h_n[slot] > capacity_points))
     return fail(c, MOT_E_CAPACITY, "more points resident than the caller's buffers hold (capacity_points)");
-  const bool have_ground = c->ground_resident && (c->ground_all || slot == 0);
+  const bool have_ground = c->ground_resident && (c->ground_all ? slot < c->last_batch : slot == 0);   // (a slot beyond the last batch: whatever an earlier batch left is not vouched for)
   if (((ground || mask) && !have_ground) || (elev && elev_packed_at(c, slot))) {   // (packed: the fused path left 12-byte points; the ABI's records are float4 with the input's 4th value)
     // The fused path left the ground cloud / mask out (mot_set_fused_outputs): materialise them for the whole last batch by
     // re-running the compaction with every output, from the batch's input, polar cells and thresholds — all still resident.
     // (No occupancy this time: the cluster stage has consumed it. The elevated cloud and the counts are rewritten with the
     // same values.)
-    if (!c->last_fused || !c->last_in || c->last_batch < 1) return fail(c, MOT_E_STATE, "mot_get_ground: no ground result resident");
+    if (!c->last_fused || !c->last_in || c->last_batch < 1 || slot >= c->last_batch) return fail(c, MOT_E_STATE, "mot_get_ground: no ground result resident");
     if ((rc = next_epoch(c))) return rc;
     GroundBuffers g = ground_buffers(c, c->last_in, c->last_in_stride, true, false);
     mot_launch_ground_kernel(2, c->dp, g, c->last_batch, c->last_max_n, c->stream);
     MOT_HIP(c, hipGetLastError());
-    c->ground_resident = true; c->ground_all = true; c->elev_packed = false;   // every slot's elevated cloud is float4 again (same points, same order: what the later stages hold stays valid)
+    c->ground_resident = true; c->ground_all = true; c->elev_packed = false;
+    for (int b = 0; b < c->last_batch; b++) c->slot_packed[b] = 0;   // every slot's elevated cloud is float4 again (same points, same order: what the later stages hold stays valid)
   }
   if (elev && ne > 0) MOT_HIP(c, hipMemcpyAsync(elev, c->d_elev + (size_t)slot * c->cap, (size_t)ne * 16, hipMemcpyDeviceToHost, c->stream));
   if (ground && ng > 0) MOT_HIP(c, hipMemcpyAsync(ground, c->d_ground + (size_t)slot * c->cap, (size_t)ng * 16, hipMemcpyDeviceToHost, c->stream));
@@ -1358,7 +1359,7 @@ extern "C" int mot_ground_remove(mot_ctx* c, const float* xyzw, int n, float* el
   GroundBuffers g = ground_buffers(c, c->d_in, c->cap, true);
   mot_launch_ground(c->dp, g, 1, n, c->stream);
   MOT_HIP(c, hipGetLastError());
-  c->ground_resident = true; c->ground_all = false; c->last_fused = false; c->slot_float4[0] = 1; c->label_state[0] = 2; c->box_valid[0] = 0;
+  c->ground_resident = true; c->ground_all = false; c->last_fused = false; c->slot_packed[0] = 0; c->label_state[0] = 2; c->box_valid[0] = 0;
   return mot_get_ground(c, 0, elev, n_elev, ground, n_ground, mask, n);
 }
 
@@ -1378,7 +1379,7 @@ extern "C" int mot_ground_node_frame(mot_ctx* c, const float* xyzw, int n, const
   mot_launch_ground(c->dp, g, 1, n, c->stream);
   MOT_HIP(c, hipGetLastError());
   c->ground_resident = false;   // (no mask: a later mot_get_ground that asks for one answers MOT_E_STATE)
-  c->slot_float4[0] = 1;
+  c->slot_packed[0] = 0;
   c->last_fused = false; c->label_state[0] = 2; c->box_valid[0] = 0;
   if ((rc = fetch_counts(c, 0))) return rc;
   const int ne = c->h_counts[kCntElev], ng = c->h_counts[kCntGround];
@@ -1425,7 +1426,7 @@ extern "C" int mot_ground_remove_pointcloud2(mot_ctx* c, const void* data, int n
   GroundBuffers g = ground_buffers(c, c->d_in, c->cap, true);
   mot_launch_ground(c->dp, g, 1, n, c->stream);
   MOT_HIP(c, hipGetLastError());
-  c->ground_resident = true; c->ground_all = false; c->last_fused = false; c->slot_float4[0] = 1; c->label_state[0] = 2; c->box_valid[0] = 0;
+  c->ground_resident = true; c->ground_all = false; c->last_fused = false; c->slot_packed[0] = 0; c->label_state[0] = 2; c->box_valid[0] = 0;
   return mot_get_ground(c, 0, elev, n_elev, ground, n_ground, mask, n);
 }
 
@@ -1446,7 +1447,7 @@ static int launch_one(mot_ctx* c, int id, int batch) {
   GroundBuffers g = ground_buffers(c, c->last_in, c->last_in_stride, (c->fused_outputs & MOT_OUT_MASK) != 0, true);   // as in the fused path: the compaction kernel leaves the occupancy lists
   if (!(c->fused_outputs & MOT_OUT_GROUND)) g.ground = nullptr;
   g.elevated_packed = (MOT_PACKED_ELEVATED && !g.ground) ? 1 : 0;
-  if (id == kK3) { c->elev_packed = g.elevated_packed != 0; std::fill(c->slot_float4.begin(), c->slot_float4.end(), 0); }
+  if (id == kK3) { c->elev_packed = g.elevated_packed != 0; for (int b = 0; b < batch; b++) c->slot_packed[b] = c->elev_packed ? 1 : 0; }
   if (id == kK3) { c->ground_resident = (c->fused_outputs & (MOT_OUT_GROUND | MOT_OUT_MASK)) == (MOT_OUT_GROUND | MOT_OUT_MASK); c->ground_all = true; }
   ClusterBuffers cb = cluster_buffers(c);
   cb.occ_list = c->d_occ_list; cb.occ_count = c->d_occ_count; cb.ecell = g.ecell;
@@ -1456,7 +1457,7 @@ static int launch_one(mot_ctx* c, int id, int batch) {
     case kK2: mot_launch_ground_kernel(1, c->dp, g, batch, max_n, c->stream); break;
     case kK3: mot_launch_ground_kernel(2, c->dp, g, batch, max_n, c->stream); break;
     case kC2: mot_launch_cluster_kernel(1, c->dp, cb, batch, max_n, c->stream); break;
-    case kB1: mot_launch_box_kernel(0, c->dp, cb, batch, max_n, c->stream); c->label_state.assign(c->batch, cb.label ? 1 : 0); break;
+    case kB1: mot_launch_box_kernel(0, c->dp, cb, batch, max_n, c->stream); for (int b = 0; b < batch; b++) c->label_state[b] = cb.label ? 1 : 0; break;
     case kB2: mot_launch_box_kernel(1, c->dp, cb, batch, max_n, c->stream); break;
     case kB3: mot_launch_box_kernel(2, c->dp, cb, batch, max_n, c->stream); break;
     case kB2b: mot_launch_box_kernel(3, c->dp, cb, batch, max_n, c->stream); break;

@@ -19,7 +19,7 @@ def run(mot, lib, synth, oracle, upload=None, N=5000):
     other = np.ascontiguousarray(o[1]["elevated"][::-1])   # the stage-wise call's cloud: slot 1's, backwards
     ref_other = oracle.cluster(p, other)
     ptr = upload(host) if upload else host.ctypes.data
-    for call in ("cluster", "box_fit", "products_host", "node_frame", "ground_remove"):
+    for call in ("cluster", "box_fit", "products_host", "node_frame", "ground_remove", "smaller_fused_batch"):
         with mot.Context(**({"lib_path": lib} if lib else {}), max_points=stride, max_batch=B, max_tracks_total=64) as c:
             c.frames_dev(ptr, stride * 4, [N] * B)
             before = {s: (c.get_boxes(s)["boxes"], c.cluster_products(s), c.box_markers(s)) for s in (1, 2)}   # the batch's own answers, packed clouds
@@ -38,9 +38,15 @@ def run(mot, lib, synth, oracle, upload=None, N=5000):
                 ref = oracle.cluster_products(p, other, ref_other["grid"])
                 assert np.array_equal(got["clustered"], ref["clustered"]) and np.array_equal(got["obstacles"], ref["obstacles"]) and np.array_equal(got["cost_map"], ref["cost_map"])
                 assert np.array_equal(got["boxes"], oracle.box_fit(p, other, ref_other["grid"], ref_other["num_cluster"])["boxes"])
-            else:
+            elif call == "ground_remove":
                 got = c.ground_remove(host[0, :N])
                 assert np.array_equal(got["elevated"], o[0]["elevated"])
+            else:   # a fused call over slot 0 alone, with the ground cloud asked for (so it leaves float4 records): slots 1, 2 keep the first batch's 12-byte points
+                c.set_fused_outputs(mot.OUT_GROUND)
+                c.frames_dev(ptr, stride * 4, [N])
+                got = c.get_ground(0, n_hint=N)
+                assert np.array_equal(got["elevated"], o[0]["elevated"]) and np.array_equal(got["ground"], o[0]["ground"])
+                assert np.array_equal(c.get_clusters(0, n_elevated=len(o[0]["elevated"]))["point_label"][: len(o[0]["elevated"])], want[0]["point_label"])
             for s in (1, 2):   # the other slots still hold the fused batch's 12-byte points
                 cl = c.get_clusters(s, n_elevated=len(o[s]["elevated"]))
                 assert np.array_equal(cl["point_label"][: len(o[s]["elevated"])], want[s]["point_label"]), (call, s)
