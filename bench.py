@@ -748,8 +748,9 @@ def main():
     ap.add_argument("--scene", choices=("street", "plaza"), default="street",
                     help="street: the default workload (~17 live tracks per stream); plaza: the tracker-load scene, 50-65 live tracks per stream (the default run reports it as the dense_scene leg)")
     ap.add_argument("--no-dense-scene", action="store_true", help="skip the dense_scene leg (plaza scene, 512 streams) of the default run")
-    ap.add_argument("--issue-threads", type=int, default=0, help="0 (default): one host thread issues every context's launches, frame by frame, in a fixed order (also the order of the "
-                    "collectives on every rank); 1: a host thread per context (measured equal: the launch queues, not the host, hold the pace — profiles/r02_issue_threads_contexts_sweep.txt)")
+    ap.add_argument("--issue-threads", type=int, default=1, help="1 (default since round 5): a host thread per context issues its launches (the library calls release the GIL): +1.6 % over one "
+                    "thread in an interleaved A/B, profiles/r05_contexts_sweep.txt — equal in round 2, when a launch sequence took a third longer; 0: one host thread issues every context's "
+                    "launches, frame by frame, in a fixed order — what a run with the per-frame collective (N > 1, --force-gather) always does: the collectives' order on every rank")
     ap.add_argument("--phase", type=int, default=38, help="frames by which context c runs ahead of context c-1 within the (shared) sequences: at any instant the contexts' launches "
                     "read DISJOINT frames, so no context finds another's input in the 256 MiB Infinity Cache (0 = lock-step: every context on the same frame, round 2's layout)")
     ap.add_argument("--force-gather", action="store_true", help="run the per-frame RCCL all-gather of the track blocks even with one rank (exercises the N > 1 path on one GPU)")
