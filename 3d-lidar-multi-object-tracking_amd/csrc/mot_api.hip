@@ -1621,7 +1621,7 @@ extern "C" int mot_get_tracks(mot_ctx* c, int slot, mot_track* tracks, int max_t
     size_t hi = 0;
     for (size_t w = 0; w < usedW; w++) if (used[w]) hi = w * 64 + (63 - (size_t)__builtin_clzll(used[w])) + 1;
     if (hi > T) hi = T;
-    const size_t o_out = 0, o_slot = o_out + hi * sizeof(mot_track), o_tomb = o_slot + (size_t)n * sizeof(int), o_pos = (o_tomb + (size_t)n * sizeof(TrackTomb) + 15) & ~(size_t)15;
+    const size_t o_out = 0, o_slot = o_out + hi * sizeof(mot_track), o_tomb = (o_slot + (size_t)n * sizeof(int) + 15) & ~(size_t)15 /* TrackTomb holds doubles since round 5 */, o_pos = (o_tomb + (size_t)n * sizeof(TrackTomb) + 15) & ~(size_t)15;
     if ((rc = pinned_scratch(c, o_rec + o_pos + (size_t)n * sizeof(Vec2d), &pin))) return rc;   // (may move the scratch: `used` and `meta` are not read again)
     char* h = pin + o_rec;
     if (hi) MOT_HIP(c, hipMemcpyAsync(h + o_out, c->d_tout + (size_t)slot * T, hi * sizeof(mot_track), hipMemcpyDeviceToHost, c->stream));
