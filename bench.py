@@ -38,6 +38,7 @@ import numpy as np
 ROOT = os.path.dirname(os.path.abspath(__file__))
 PKG_DIR = os.path.join(ROOT, "3d-lidar-multi-object-tracking_amd")
 HBM_PEAK_GBS = 8000.0
+HBM_ACHIEVABLE_GBS = 6290.0   # /opt/skills/guides/MI355X_MICROARCH.md: "8.0 TB/s spec; 6.29 TB/s measured (float4 copy, 79%)"
 TRACK_RECORD_BYTES = 144
 GATHER_TRACKS = 64  # live tracks per stream in the fixed-slot blocks (BASELINE.json configs[3]: <= 64 tracks): host_boundary_pipelined's D2H block
 GATHER_RECORDS_PER_STREAM = 32   # capacity of the PACKED all-gathered block, records per stream on average (17-21 live per stream in the bench scenes)
@@ -209,7 +210,7 @@ def cpu_baseline(frames: np.ndarray, ego_v, ego_yaw, n_points: int, budget_s: fl
                   else "C restatement (oracle/_ref not present)", "workload": "the benched frames: stream 0 of this run, every frame"}
         first_bad = {}
         flags = {"clouds_bit_exact": True, "masks_equal_restatement": True, "label_grids_bit_exact": True, "boxes_bit_exact": True, "global_boxes_bit_exact": True, "track_sets_equal": True}
-        stats = {}
+        stats, mstats = {}, {}
         for f, (r, gres) in enumerate(zip(kept, gpu_results)):
             def bad(key):
                 flags[key] = False; first_bad.setdefault(key, f)
@@ -226,6 +227,9 @@ def cpu_baseline(frames: np.ndarray, ego_v, ego_yaw, n_points: int, budget_s: fl
             try:   # discrete outputs asserted; the state errors are collected and held against the reference's own noise floor on the same track-frame
                 SP.compare_tracks(gres["tracks"], r["tracks"], lambda i: gres["states"][i], lambda i: r["states"][i], f, rtol=float("inf"), stats=stats,
                                   criterion="narrow", floor=(lambda i, so, fl=r["floors"]: fl.get(i)) if r["replicas"] else None)
+                # the MEASURED conditioning (tests/seq_parity.py MEASURED_FLOOR): ill-conditioned iff the reference's own builds part by > 1e-5 on that track-frame
+                SP.compare_tracks(gres["tracks"], r["tracks"], lambda i: gres["states"][i], lambda i: r["states"][i], f, rtol=float("inf"), stats=mstats,
+                                  floor=(lambda i, so, fl=r["floors"]: fl.get(i)), measured=True)
             except (AssertionError, KeyError) as e:
                 bad("track_sets_equal"); first_bad.setdefault("track_detail", str(e)[:200])
         parity.update(flags)
@@ -237,8 +241,17 @@ def cpu_baseline(frames: np.ndarray, ego_v, ego_yaw, n_points: int, budget_s: fl
         # (states_explained_by_reference_noise says that the second clause was needed).
         within_well = stats.get("max_rel_state_err") is not None and stats["max_rel_state_err"] <= 1e-4 and stats.get("above_bar_well_conditioned", 0) == 0
         explained = fsum["track_frames_with_floor"] > 0 and fsum["above_1e-4_unexplained"] == 0
+        # states_within_bar (round 6: the MEASURED conditioning replaces the threshold criterion): every live track-frame on which the reference's own builds (libmot_ref.so against
+        # the C restatement and the -DEIGEN_DONT_VECTORIZE rebuild: fp64 addition order only) agree to 1e-5 is within 1e-4 — strictly, no exception; `measured` carries the counts,
+        # and how the track-frames on which they do NOT agree compare with the reference's own spread there. states_within_bar_threshold_criterion is round 5's rule, kept for comparison.
+        m = mstats.get("measured", {})
+        n_m = max(m.get("well_conditioned", 0) + m.get("ill_conditioned", 0), 1)
         parity["states_within_1e-4"] = bool(within_well and stats.get("above_bar", 0) == 0)
-        parity["states_within_bar"] = bool(within_well and (stats.get("above_bar", 0) == 0 or explained))
+        parity["states_within_bar"] = bool(bool(m) and m["above_bar_well_conditioned"] == 0 and m["max_err_well_conditioned"] <= 1e-4 and m["ill_without_replica"] == 0)
+        parity["conditioning"] = ("measured: a live track-frame is ill-conditioned iff the reference's own builds part by more than 1e-5 relative on it "
+                                  "(tests/seq_parity.py MEASURED_FLOOR, NoiseFloor); every other live track-frame is held to 1e-4 strictly")
+        parity["measured"] = dict(m, well_conditioned_fraction=round(m.get("well_conditioned", 0) / n_m, 5)) if m else None
+        parity["states_within_bar_threshold_criterion"] = bool(within_well and (stats.get("above_bar", 0) == 0 or explained))
         parity["states_explained_by_reference_noise"] = bool(within_well and stats.get("above_bar", 0) > 0 and explained)
         # the weakest statement, and the one the -m gpu sequence tests assert (assert_floor): every live track-frame — set aside or not — is within 1e-4 OR within
         # 10 x the difference between the reference's OWN builds on that very track-frame (a scene of 60 coasting pedestrian tracks has track-frames the narrow criterion
@@ -437,7 +450,7 @@ def dense_scene(mot, sdev, torch, device, N, stride, streams=512, contexts=4, st
             frames_host = seq[:, 0, :N].cpu().numpy()
             del seq
             _base, par = cpu_baseline(frames_host, ego_v, ego_yaw, N, budget_s=4.0, gpu_results=gpu_res, n_per_frame=n_seq[:, 0], lib=lib, quick=True)
-            keys = ("frames", "masks_boxes_bit_exact", "track_sets_equal", "states_within_1e-4", "states_within_bar", "states_explained_by_reference_noise",
+            keys = ("frames", "masks_boxes_bit_exact", "track_sets_equal", "states_within_1e-4", "states_within_bar", "conditioning", "measured", "states_within_bar_threshold_criterion", "states_explained_by_reference_noise",
                     "states_within_1e-4_or_reference_noise", "above_1e-4_worst_err_over_reference_noise", "track_frames_above_1e-4_not_set_aside", "max_rel_state_err",
                     "track_frames_above_1e-4", "track_frames_above_1e-4_unexplained", "set_aside_track_frames", "state_compares", "live_tracks_max", "tracks_ever", "boxes_total",
                     "first_mismatch_frame", "above_bar_detail", "noise_floor_ill_conditioned")
@@ -747,6 +760,9 @@ def main():
     ap.add_argument("--density", type=float, default=1.0, help="scene density (cars / pedestrians) of the synthetic street")
     ap.add_argument("--scene", choices=("street", "plaza"), default="street",
                     help="street: the default workload (~17 live tracks per stream); plaza: the tracker-load scene, 50-65 live tracks per stream (the default run reports it as the dense_scene leg)")
+    ap.add_argument("--point-order", choices=("beam", "firing", "random"), default="beam",
+                    help="order of a frame's points in memory: beam = beam-major (KITTI .bin files; the default workload), firing = azimuth-major (the 64 lasers of a firing "
+                         "together: the velodyne driver's `velodyne_points`, OT/src/groundremove/main.cpp:146), random = a seeded permutation per frame. Same point SETS per frame")
     ap.add_argument("--no-dense-scene", action="store_true", help="skip the dense_scene leg (plaza scene, 512 streams) of the default run")
     ap.add_argument("--issue-threads", type=int, default=1, help="1 (default since round 5): a host thread per context issues its launches (the library calls release the GIL): +1.6 % over one "
                     "thread in an interleaved A/B, profiles/r05_contexts_sweep.txt — equal in round 2, when a launch sequence took a third longer; 0: one host thread issues every context's "
@@ -847,7 +863,7 @@ def main():
         renderer = sdev.SequenceRenderer(f"cuda:{local}")
         while True:
             try:
-                seq_dev, n_seq, _objs, _path = renderer.render([1000 * rank + s for s in range(Bc)], F, N, stride, ego_v, ego_yaw, density=args.density, scene=args.scene)
+                seq_dev, n_seq, _objs, _path = renderer.render([1000 * rank + s for s in range(Bc)], F, N, stride, ego_v, ego_yaw, density=args.density, scene=args.scene, order=args.point_order)
                 break
             except RuntimeError as e:   # the sequences do not fit this device's free HBM: halve the streams and say so
                 if "out of memory" not in str(e).lower() or Bc < 2:
@@ -1066,10 +1082,13 @@ def main():
                        "frames_per_step_per_gpu": B * F, "contexts_per_gpu": NC, "frames_per_launch": BL, "context_phase_frames": args.phase,
                        "elevated_pts_per_frame": ne_tot // BL, "clusters_last_frame_stream0": cl0["num_cluster"], "boxes_last_frame_stream0": len(bx0["boxes"]),
                        "tracks_ever_stream0": int(tr0["n"]), "live_tracks_per_stream": {"mean": round(float(np.mean(live)), 1), "max": int(np.max(live)), "streams_sampled": len(live)},
-                       "render_s": round(render_s, 1), "scene": args.scene, "scene_density": args.density, "kitti": kitti,
+                       "render_s": round(render_s, 1), "scene": args.scene, "scene_density": args.density, "point_order": "as recorded" if kitti else args.point_order, "kitti": kitti,
                        "parallelism": f"stream-sharded x{world}" + (", all_gather of live-track records per frame (RCCL)" if world > 1 else "")},
             "roofline": {"bound": "hbm", "kernel": dom_kernel, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_src,
+                         "frac_of_achievable": round(achieved / HBM_ACHIEVABLE_GBS, 4), "achievable_peak": HBM_ACHIEVABLE_GBS,
+                         "traffic_ratio": round(traffic / alg_bytes[dom], 4) if traffic else None,
+                         "moved_GBps": round(traffic / (dom_ms * 1e-3) / 1e9, 1) if traffic and dom_ms > 0 else None,
                          "kernel_ms": {"mean": round(dom_ms, 5), "min": round(solo["min_ms"], 5), "max": round(solo["max_ms"], 5), "samples": solo["samples"],
                                        "how": "HIP event pairs around the kernel's launch on its own stream (mot_profile_kernel), the whole pipeline running on ONE context, "
                                               f"nothing else on the GPU; rocprofv3 summary of the same schedule: profiles/{RND}_kernel_trace_B512_1ctx.txt"},
@@ -1153,6 +1172,13 @@ def main():
           except Exception as e:   # the baseline and the parity check are reported, never allowed to cost the bench line
             import traceback
             out.setdefault("cpu_baseline", None); out["parity_check"] = {"error": traceback.format_exc()[-600:]}
+        # the two numbers that must be quoted with `value` (round-5 review, item 5), at the top level of the line:
+        #   value_all_outputs     the same run with every by-product of the reference written (ground cloud, mask, per-point labels)
+        #   value_pcie_inclusive  frames/s when the frames start in pinned HOST memory ("end-to-end includes H2D"): PCIe-bound
+        out["value_all_outputs"] = (out.get("all_outputs") or {}).get("value")
+        hb = out.get("host_boundary_pipelined") or {}
+        out["value_pcie_inclusive"] = hb.get("value")
+        out["value_pcie_inclusive_xyz12"] = (hb.get("xyz12") or {}).get("value")
         _JSON_OUT.write(json.dumps(out) + "\n"); _JSON_OUT.flush()
     if gather_on:
         dist.barrier()

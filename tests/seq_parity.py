@@ -178,6 +178,8 @@ class NoiseFloor:
         self.reps = {}
 
 
+MEASURED_FLOOR = 1e-5   # the MEASURED conditioning (round-5 review, item 1b): a live track-frame is ill-conditioned iff the reference's own builds — replicas that differ
+                        # from it in the order of fp64 additions only (NoiseFloor) — part by more than this on that very track-frame. On the complement the 1e-4 bar holds strictly.
 FLOOR_FACTOR = 10.0   # a set-aside track-frame is EXPLAINED when the device's error is within this factor of the reference's own noise there
 
 
@@ -189,12 +191,15 @@ def note_conditioning(o, state_orc, frame, taint, criterion="narrow"):
 
 
 def compare_tracks(a, o, state_dev, state_orc, where, rtol=RTOL, stats=None, skip_ill_conditioned=False, taint=None, frame=None,
-                   criterion="narrow", floor=None, assert_floor=False):
+                   criterion="narrow", floor=None, assert_floor=False, measured=False, assert_measured=False):
     """a: the library's tracks of one stream (Context.get_tracks), o: the oracle's. Discrete outputs exact, continuous <= rtol.
     taint / frame: see note_conditioning (when given, this call also records the current conditioning).
     criterion: which conditioning reasons set a track-frame's continuous state aside ("narrow" | "wide").
     floor: NoiseFloor.floor — when given, every set-aside track-frame (and every one above the bar) is held against the reference's
-    own noise there: `unexplained` counts those whose error exceeds both the bar and FLOOR_FACTOR x the floor (assert_floor: fail)."""
+    own noise there: `unexplained` counts those whose error exceeds both the bar and FLOOR_FACTOR x the floor (assert_floor: fail).
+    measured (needs floor): the MEASURED conditioning — the floor is taken on EVERY live track-frame; one where the reference's own builds part by more than
+    MEASURED_FLOOR (or differ in their NaN pattern, or no replica is left) is ill-conditioned, every other one is held to rtol STRICTLY, whatever the
+    threshold criterion says about it (stats["measured"]; assert_measured: fail on the first violation)."""
     assert a["n"] == o["n"], (where, a["n"], o["n"])
     for k in ("track_manage", "is_static", "is_vis"):
         assert np.array_equal(a[k], o[k]), (where, k, np.nonzero(a[k] != o[k])[0][:8])
@@ -211,6 +216,13 @@ def compare_tracks(a, o, state_dev, state_orc, where, rtol=RTOL, stats=None, ski
                 taint[int(i)] = frame + TAINT_FRAMES
             elif taint.get(int(i), -1) >= frame:
                 ill = True; why = ("recently_diverging",)
+        fl = None
+        m_ill = False
+        if measured and floor is not None:   # the MEASURED conditioning decides what is held to the bar strictly
+            fl = floor(int(i), so)
+            m_ill = fl is None or not np.isfinite(fl) or fl > MEASURED_FLOOR
+            ill = m_ill
+            why = ("reference_builds_part",) if m_ill else ()
         check = not (ill and skip_ill_conditioned)   # discrete outputs were compared above regardless
         sd = state_dev(int(i))
         assert sd["lifetime"] == so["lifetime"] and sd["track_manage"] == so["track_manage"], (where, int(i))
@@ -242,9 +254,26 @@ def compare_tracks(a, o, state_dev, state_orc, where, rtol=RTOL, stats=None, ski
                 if err / scale > w_i:
                     w_key = (k, int(np.argmax(np.abs(np.where(nan, 0.0, sd_k - so_k)))))
                 w_i = max(w_i, err / scale)
-        fl = None
-        if floor is not None and (ill or w_i > RTOL):
+        if floor is not None and fl is None and not measured and (ill or w_i > RTOL):
             fl = floor(int(i), so)
+        if measured and floor is not None:
+            if stats is not None:
+                m = stats.setdefault("measured", dict(well_conditioned=0, ill_conditioned=0, above_bar_well_conditioned=0, max_err_well_conditioned=0.0, above_bar_ill_conditioned=0,
+                                                      max_err_over_floor_ill_conditioned=0.0, ill_without_replica=0, max_floor_well_conditioned=0.0))
+                if m_ill:
+                    m["ill_conditioned"] += 1
+                    m["above_bar_ill_conditioned"] += int(w_i > RTOL)
+                    if fl is None:
+                        m["ill_without_replica"] += 1
+                    elif np.isfinite(fl) and fl > 0 and w_i > RTOL:
+                        m["max_err_over_floor_ill_conditioned"] = max(m["max_err_over_floor_ill_conditioned"], w_i / fl)
+                else:
+                    m["well_conditioned"] += 1
+                    m["above_bar_well_conditioned"] += int(w_i > RTOL)
+                    m["max_err_well_conditioned"] = max(m["max_err_well_conditioned"], w_i)
+                    m["max_floor_well_conditioned"] = max(m["max_floor_well_conditioned"], fl)
+            if assert_measured and not m_ill:
+                assert w_i <= RTOL, (where, int(i), "error", w_i, "on a track-frame where the reference's own builds agree to", fl)
         if fl is not None:
             explained = w_i <= RTOL or w_i <= FLOOR_FACTOR * fl
             if assert_floor:
@@ -299,7 +328,7 @@ def floor_summary(stats):
 
 
 def check_sequence(ctx, oracle, p, frame_ptr, host_frame, n_seq, stride, ego_v, ego_yaw, units, slots=None, rtol=RTOL,
-                   check_labels=True, frames=None, skip_ill_conditioned=False, noise_floor=False, mar_check=False):
+                   check_labels=True, frames=None, skip_ill_conditioned=False, noise_floor=False, mar_check=False, measured=False):
     """Runs frames 0..F-1 of every slot through ctx.frames_dev and compares each frame of the slots in `slots` with the oracle.
 
     frame_ptr(f) -> device (or, on the emulator, host) address of frame f's batch [B][stride] float4
@@ -310,8 +339,13 @@ def check_sequence(ctx, oracle, p, frame_ptr, host_frame, n_seq, stride, ego_v, 
     is instead held to FLOOR_FACTOR x the reference's own arithmetic noise on that track-frame (NoiseFloor: replicas of the reference
     tracker per slot), asserted. No conditioning memory (taint) here: on these streams every track-frame outside the narrow criterion
     meets the bar (profiles/r04_tracker_noise_floor.jsonl).
+    measured: the MEASURED conditioning instead of the threshold criterion (implies noise_floor): a live track-frame is ill-conditioned iff the
+    reference's own builds part by more than MEASURED_FLOOR on it; EVERY other live track-frame is held to rtol strictly (asserted), the ill-conditioned
+    ones to FLOOR_FACTOR x the floor measured there (asserted) — stats["measured"] carries the counts.
     mar_check: every cluster the restated box fit sends through the min-area-rectangle branch is cross-checked against the exhaustive
     integer oracle (tests/mar_check.py)."""
+    if measured:
+        noise_floor = skip_ill_conditioned = True
     F = len(n_seq) if frames is None else frames
     B = len(n_seq[0])
     slots = list(range(B)) if slots is None else list(slots)
@@ -368,7 +402,7 @@ def check_sequence(ctx, oracle, p, frame_ptr, host_frame, n_seq, stride, ego_v, 
                 if noise_floor:
                     floors[b].step(gb, float(ts[b]), float(ego_v[f]), float(ego_yaw[f]), o, f)
                 compare_tracks(at, o, lambda i: ctx.track_state(i, slot=b), T.state, where, rtol, stats, skip_ill_conditioned,
-                               criterion="narrow", floor=floors[b].floor if noise_floor else None, assert_floor=noise_floor)
+                               criterion="narrow", floor=floors[b].floor if noise_floor else None, assert_floor=noise_floor, measured=measured, assert_measured=measured)
                 stats["points"] += n; stats["elevated"] += len(g["elevated"]); stats["boxes"] += len(bx["boxes"]); stats["clusters"] += cl["num_cluster"]
     finally:
         for T in trackers.values():

@@ -24,6 +24,10 @@ def main():
     ap.add_argument("--units", type=float, nargs="+", default=[1e5, 0.1], help="timestamp step per stream (SURVEY.md H11: 1e5 us or 0.1 s)")
     ap.add_argument("--density", type=float, default=1.0)
     ap.add_argument("--preset", type=int, default=0)
+    ap.add_argument("--scene", choices=("street", "plaza"), default="street", help="plaza: the tracker-load scene (50-65 live tracks per stream: configs[3]'s '<= 64 tracks')")
+    ap.add_argument("--order", choices=("beam", "firing", "random"), default="beam", help="point order in memory (tools/synth/synth_dev.py)")
+    ap.add_argument("--measured", action="store_true", help="the MEASURED conditioning (tests/seq_parity.py MEASURED_FLOOR): every live track-frame on which the reference's own "
+                    "builds agree to 1e-5 is held to 1e-4 strictly")
     args = ap.parse_args()
     import torch
     from conftest import load_pkg, load_sub
@@ -39,16 +43,16 @@ def main():
     stride = ((N + 2047) // 2048) * 2048
     ego_v, ego_yaw = sdev.load_ego(F)
     t0 = time.time()
-    seq, n_seq, _objs, _path = sdev.SequenceRenderer("cuda:0").render(args.scenes, F, N, stride, ego_v, ego_yaw, density=args.density)
+    seq, n_seq, _objs, _path = sdev.SequenceRenderer("cuda:0").render(args.scenes, F, N, stride, ego_v, ego_yaw, density=args.density, scene=args.scene, order=args.order)
     n_seq = np.ascontiguousarray(n_seq, np.int32)
     t_render = time.time() - t0
     units = (args.units * S)[:S]
     p = O.params(args.preset)
     t0 = time.time()
     with mot.Context(mot.params(args.preset), max_points=stride, max_batch=S, max_tracks_total=1024) as c:
-        st = SP.check_sequence(c, O, p, lambda f: seq[f].data_ptr(), lambda f, b: seq[f, b].cpu().numpy(), n_seq, stride, ego_v, ego_yaw, units, skip_ill_conditioned=True, noise_floor=True, mar_check=True)
+        st = SP.check_sequence(c, O, p, lambda f: seq[f].data_ptr(), lambda f, b: seq[f, b].cpu().numpy(), n_seq, stride, ego_v, ego_yaw, units, skip_ill_conditioned=True, noise_floor=True, mar_check=True, measured=args.measured)
     st.update(render_s=round(t_render, 1), check_s=round(time.time() - t0, 1), points_per_frame=int(n_seq.mean()), scenes=args.scenes, units=units,
-              reference_tf=O.ref_tf() is not None,
+              reference_tf=O.ref_tf() is not None, scene=args.scene, point_order=args.order,
               oracle_used={f"{fn}: {who}": k for (fn, who), k in sorted(getattr(O, "used", {}).items())} or "restatement")
     if args.preset == 0:
         assert st["boxes"] > F and st["tracks_ever"] >= 20 and st["live_max"] >= 5, st   # the sequence really exercises the tracker

@@ -12,9 +12,11 @@ sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "emu
 import pytest
 
 
-@pytest.mark.parametrize("which", ["restatement", "reference build first"])
+@pytest.mark.parametrize("which", ["restatement", "reference build first", "reference build first, measured conditioning"])
 def test_sequence_checker_on_the_emulator(mot, synth, oracle, which):
-    """which: the oracle the checker is given — the restatement, or (as on the GPU box) oracle_lib.RefFirst"""
+    """which: the oracle the checker is given — the restatement, or (as on the GPU box) oracle_lib.RefFirst; "measured": the conditioning of
+    tests/test_sequence_gpu.py::test_154_frame_dense_scene_measured_conditioning (seq_parity.MEASURED_FLOOR)"""
+    measured = which.endswith("measured conditioning")
     import build_emu
     import seq_parity as SP
     lib = build_emu.build()
@@ -34,7 +36,10 @@ def test_sequence_checker_on_the_emulator(mot, synth, oracle, which):
     p = oracle.params(0)
     with mot.Context(lib_path=lib, max_points=stride, max_batch=B, max_tracks_total=256) as c:
         st = SP.check_sequence(c, oracle, p, lambda f: clouds[f].ctypes.data, lambda f, b: clouds[f, b], n_seq, stride, ego_v, ego_yaw, units=[1e5, 0.1],
-                               skip_ill_conditioned=True, noise_floor=True, mar_check=True)   # the GPU run's settings (tests/seq_parity_gpu_run.py)
+                               skip_ill_conditioned=True, noise_floor=True, mar_check=True, measured=measured)   # the GPU run's settings (tests/seq_parity_gpu_run.py)
+    if measured:
+        m = st["measured"]
+        assert m["well_conditioned"] + m["ill_conditioned"] == st["state_compares"] and m["above_bar_well_conditioned"] == 0 and m["ill_without_replica"] == 0, m
     assert st["frames"] == F and st["boxes"] > 0 and st["tracks_ever"] > 0 and st["max_rel_state_err"] <= SP.RTOL
     assert st["above_1e-4_unexplained"] == 0 and st["mar_clusters_cross_checked"] > 0
     assert st["tracker_oracle"].startswith("restatement" if which == "restatement" else "reference build")

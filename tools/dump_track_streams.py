@@ -2,7 +2,7 @@
 and produced — the boxes in the global frame (as track_prep_kernel handed them over), the track records and the full filter state of
 every live track — to gpurun_out/<out>.npz. The tracker depends on nothing else, so the reference-side analysis (noise floors of the
 reference's own arithmetic against the device's differences: tests/seq_parity.py NoiseFloor) can then run anywhere, repeatedly.
-  python tools/dump_track_streams.py OUT POINTS FRAMES PRESET UNIT SCENE [SCENE …]"""
+  python tools/dump_track_streams.py OUT POINTS FRAMES PRESET UNIT SCENE [SCENE …]      (MOT_DUMP_SCENE_KIND=plaza: the tracker-load scene)"""
 import ctypes as C, os, sys
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -15,10 +15,10 @@ import seq_parity as SP
 mot = load_pkg(); sdev = load_sub("synth_dev")
 stride = ((N + 2047) // 2048) * 2048
 ego_v, ego_yaw = sdev.load_ego(F)
-seq, n_seq, _o, _p = sdev.SequenceRenderer("cuda:0").render(scenes, F, N, stride, ego_v, ego_yaw)
+seq, n_seq, _o, _p = sdev.SequenceRenderer("cuda:0").render(scenes, F, N, stride, ego_v, ego_yaw, scene=os.environ.get("MOT_DUMP_SCENE_KIND", "street"))
 n_seq = np.ascontiguousarray(n_seq, np.int32)
 S = len(scenes)
-save = {"scenes": np.array(scenes), "ego_v": ego_v, "ego_yaw": ego_yaw, "unit": unit, "preset": preset, "points": N}
+save = {"scenes": np.array(scenes), "ego_v": ego_v, "ego_yaw": ego_yaw, "unit": unit, "preset": preset, "points": N, "kind": os.environ.get("MOT_DUMP_SCENE_KIND", "street")}
 with mot.Context(mot.params(preset), max_points=stride, max_batch=S, max_tracks_total=1024) as c:
     for f in range(F):
         ts = np.full(S, 1.0e9 + f * unit)

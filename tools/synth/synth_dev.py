@@ -177,9 +177,17 @@ class SequenceRenderer:
                                                C.c_ulonglong, C.c_void_p, C.c_void_p]
 
     def render(self, scene_ids, n_frames: int, n_points: int, stride: int, v=None, yaw=None, dt: float = 0.1, seed: int = 2025,
-               density: float = 1.0, oversample: float = 1.25, frame_chunk: int = 32, scene: str = "street"):
+               density: float = 1.0, oversample: float = 1.25, frame_chunk: int = 32, scene: str = "street", order: str = "beam"):
         """-> (clouds [F][S][stride][4] float32 on the device, n [F][S] int32 numpy, objects list). Every frame is thinned
-        uniformly (order preserved, beam-major) to n_points returns; a frame with fewer returns keeps them all."""
+        uniformly (order preserved) to n_points returns; a frame with fewer returns keeps them all.
+        order: the order of a frame's points in memory —
+          "beam"    beam-major (a laser's whole revolution, then the next laser): KITTI's .bin files
+          "firing"  azimuth-major (the 64 lasers of one firing, then the next azimuth step): what the velodyne driver's `velodyne_points`
+                    carries, the topic the reference's ground node subscribes to (OT/src/groundremove/main.cpp:146)
+          "random"  a seeded random permutation per frame (no locality at all: the worst case for anything that exploits the order)
+        The SET of points of a frame is the same for every order (the thinning selects by ray id, not by position)."""
+        if order not in ("beam", "firing", "random"):
+            raise ValueError(f"order: {order!r}")
         torch = self.torch
         if v is None or yaw is None:
             v, yaw = load_ego(n_frames)
@@ -212,7 +220,17 @@ class SequenceRenderer:
                 nt = torch.minimum(total, torch.full_like(total, n_points))
                 j = (c * nt) // total
                 jp = ((c - 1) * nt) // total
-                sel = valid & (j > jp)
+                sel = valid & (j > jp)           # which rays survive the thinning: decided in beam-major ray order, whatever the output order
+                if order != "beam":
+                    if order == "firing":        # ray = beam * n_az + a  ->  position a * 64 + beam
+                        perm = torch.arange(n_rays, device=self.device, dtype=torch.int64).view(64, n_az).t().reshape(-1)
+                        perm = perm[None].expand(fc, n_rays)
+                    else:
+                        gen = torch.Generator(device=self.device); gen.manual_seed(int(seed) * 1_000_003 + int(sid) * 1009 + f0)
+                        perm = torch.randperm(n_rays, device=self.device, generator=gen)[None].expand(fc, n_rays)   # (one permutation per scene and chunk of frames)
+                    raw = torch.gather(raw, 1, perm[:, :, None].expand(fc, n_rays, 4))
+                    sel = torch.gather(sel, 1, perm)
+                    j = torch.cumsum(sel.to(torch.int64), dim=1)   # output position (1-based) of every surviving ray in the new order
                 fidx = torch.arange(f0, f0 + fc, device=self.device, dtype=torch.int64)[:, None]
                 dest = ((fidx * S + si) * stride + (j - 1))[sel]
                 out.view(-1, 4)[dest] = raw[sel]
