@@ -17,6 +17,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libmot_hip.so")
 
 MOT_OK, MOT_E_ARG, MOT_E_CAPACITY, MOT_E_HIP, MOT_E_STATE = 0, 1, 2, 3, 4
+MOT_MAX_BOXES_PER_FRAME = 1024   # include/mot.h
 MOT_TRACKER_AUTO, MOT_TRACKER_SPLIT, MOT_TRACKER_STREAM = 0, 1, 2   # mot_set_tracker_mode (include/mot.h)
 PRESET_OBJECT_TRACKING, PRESET_OBJECT_TRACKING0 = 0, 1
 MASK_DROPPED, MASK_GROUND, MASK_ELEVATED = 0, 1, 2
@@ -78,7 +79,7 @@ EXPORTS = (
     "mot_track_steps_dev", "mot_profile_kernel", "mot_profile_read", "mot_get_params", "mot_set_fused_outputs", "mot_set_tracker_mode", "mot_set_trace_ranges", "mot_reset_tracks_slot", "mot_export_tracks_packed_dev", "mot_set_launch_graphs",
     "mot_cluster_node_frame", "mot_ground_node_frame",
 )
-ABI_VERSION = 5
+ABI_VERSION = 6
 OUT_GROUND, OUT_MASK, OUT_LABELS = 1, 2, 4
 
 _libs: dict[str, C.CDLL] = {}
@@ -230,7 +231,7 @@ class Context:
     def _ck_tracks(self, rc, n, cap):
         """mot_get_tracks / mot_track_step deliver the records AND report MOT_E_CAPACITY once a stream has used up max_tracks_total
         (sticky until reset): a soft condition here — the records are returned, `capacity_exceeded` says so"""
-        if rc == MOT_E_CAPACITY and n <= cap:
+        if rc == MOT_E_CAPACITY and 0 <= n <= cap:   # (n = -1: mot_track_step refused the frame — more than 1024 boxes — and did not run: an error like any other)
             return True
         self._ck(rc)
         return False
@@ -301,7 +302,7 @@ class Context:
         cap = self._track_buffer(slot, max_tracks)
         arr = (MotTrack * cap)(); nt = C.c_int(0)
         rc = self.lib.mot_track_step(self._h, slot, _vp(b), len(b), C.c_double(timestamp), arr, cap, C.byref(nt))
-        self._nt_hint[slot] = nt.value
+        self._nt_hint[slot] = max(nt.value, 0)
         if rc == MOT_E_CAPACITY and nt.value > cap and not max_tracks:   # the step has run; only the buffer was too small: fetch again
             return self.get_tracks(slot)
         full = self._ck_tracks(rc, nt.value, cap)
@@ -420,7 +421,7 @@ class Context:
         cap = self._track_buffer(slot, max_tracks)
         arr = (MotTrack * cap)(); nt = C.c_int(0)
         rc = self.lib.mot_get_tracks(self._h, slot, arr, cap, C.byref(nt))
-        self._nt_hint[slot] = nt.value
+        self._nt_hint[slot] = max(nt.value, 0)
         if rc == MOT_E_CAPACITY and nt.value > cap and not max_tracks:
             cap = nt.value + 256
             arr = (MotTrack * cap)()

@@ -141,6 +141,7 @@ struct mot_ctx {
   std::vector<char> box_valid;        // per slot: the box stage's products (boxes, cluster order, groups) belong to the cloud now resident in the slot
   bool ground_resident = false;        // d_ground / d_mask hold the last batch's ground cloud and mask
   bool ground_all = false;             // ... of every slot of the last fused batch; false: of slot 0 only (a stage-wise mot_ground_remove* since)
+  bool ground_foreign0 = false;        // a stage-wise cluster / box call has replaced slot 0's elevated cloud since the ground stage ran: d_ground / d_mask of slot 0 belong to ANOTHER cloud
   bool last_fused = false;             // the last ground launch was a fused one (input, cells and thresholds of the batch still resident)
   int* h_counts = nullptr;  // pinned [batch][4]
   int last_batch = 0, last_max_n = 0;
@@ -334,7 +335,7 @@ static int arg_block_commit(mot_ctx* c, size_t off, size_t bytes) {
 static bool elev_packed_at(const mot_ctx* c, int slot) { return c->slot_packed[slot] != 0; }
 // a fused call over slots 0..batch-1 was issued: what those slots hold from now on (the slots beyond keep what an earlier, larger batch left)
 static void mark_fused_slots(mot_ctx* c, int batch, bool want_ground, bool want_mask) {
-  c->ground_resident = want_ground && want_mask; c->ground_all = true; c->last_fused = true;
+  c->ground_resident = want_ground && want_mask; c->ground_all = true; c->last_fused = true; c->ground_foreign0 = false;
   c->elev_packed = MOT_PACKED_ELEVATED && !want_ground;   // how this call's compaction kernel leaves the elevated clouds (host state: also on a graph replay)
   for (int b = 0; b < batch; b++) {
     c->label_state[b] = (c->fused_outputs & MOT_OUT_LABELS) ? 1 : 0; c->box_valid[b] = 1; c->slot_packed[b] = c->elev_packed ? 1 : 0;
@@ -1054,6 +1055,7 @@ extern "C" int mot_cluster(mot_ctx* c, const float* elev, int n, int32_t* grid, 
   int rc;
   if (n > 0) MOT_HIP(c, hipMemcpyAsync(c->d_elev, elev, (size_t)n * 16, hipMemcpyHostToDevice, c->stream));
   c->last_fused = false;   // slot 0 now holds this call's cloud: mot_get_ground must not re-run a fused batch's compaction over it
+  c->ground_foreign0 = true;   // ... and slot 0's ground cloud / mask (if any) are another cloud's: mot_get_ground(0) answers MOT_E_STATE, as include/mot.h promises
   c->slot_packed[0] = 0;  // ... as float4 records
   if ((rc = set_count(c, 0, kCntElev, n))) return rc;
   ClusterBuffers cb = cluster_buffers(c, 0);
@@ -1086,6 +1088,7 @@ extern "C" int mot_box_fit(mot_ctx* c, const float* elev, int n, const int32_t* 
   MOT_HIP(c, hipMemcpyAsync(c->d_grid, c->h_grid16.data(), (size_t)G * G * sizeof(GridLabel), hipMemcpyHostToDevice, c->stream));
   MOT_HIP(c, hipStreamSynchronize(c->stream));   // (h_grid16 is reused by the next call)
   c->last_fused = false;   // slot 0 now holds this call's cloud: mot_get_ground must not re-run a fused batch's compaction over it
+  c->ground_foreign0 = true;   // ... and slot 0's ground cloud / mask (if any) are another cloud's: mot_get_ground(0) answers MOT_E_STATE, as include/mot.h promises
   c->slot_packed[0] = 0;
   if ((rc = set_count(c, 0, kCntElev, n))) return rc;
   if ((rc = set_count(c, 0, kCntClusters, num_cluster))) return rc;
@@ -1217,6 +1220,7 @@ extern "C" int mot_cluster_products_host(mot_ctx* c, const float* elev, int n, c
   MOT_HIP(c, hipMemcpyAsync(c->d_grid, c->h_grid16.data(), (size_t)G * G * sizeof(GridLabel), hipMemcpyHostToDevice, c->stream));
   MOT_HIP(c, hipStreamSynchronize(c->stream));
   c->last_fused = false;   // slot 0 now holds this call's cloud: mot_get_ground must not re-run a fused batch's compaction over it
+  c->ground_foreign0 = true;   // ... and slot 0's ground cloud / mask (if any) are another cloud's: mot_get_ground(0) answers MOT_E_STATE, as include/mot.h promises
   c->slot_packed[0] = 0;
   c->box_valid[0] = 0;
   int rc = set_count(c, 0, kCntElev, n);
@@ -1270,6 +1274,7 @@ extern "C" int mot_cluster_node_frame(mot_ctx* c, const float* elev, int n, cons
   if ((rc = pinned_scratch(c, total, &pin))) return rc;
   if (n > 0) MOT_HIP(c, hipMemcpyAsync(c->d_elev, elev, (size_t)n * 16, hipMemcpyHostToDevice, c->stream));
   c->last_fused = false;   // slot 0 now holds this call's cloud
+  c->ground_foreign0 = true;   // ... and slot 0's ground cloud / mask (if any) are another cloud's: mot_get_ground(0) answers MOT_E_STATE, as include/mot.h promises
   c->slot_packed[0] = 0;
   s.elevated_packed = 0;   // (side_setup looked at slot 0 BEFORE the upload: after a fused batch on this context it saw 12-byte points there)
   if ((rc = set_count(c, 0, kCntElev, n))) return rc;
@@ -1278,7 +1283,7 @@ extern "C" int mot_cluster_node_frame(mot_ctx* c, const float* elev, int n, cons
   mot_launch_side_products(c->dp, d, s, n > 0 ? n : 1, c->stream);
   mot_launch_box(c->dp, cb, 1, n, c->stream);
   mot_launch_box_markers(cb, 0, kMaxBoxesPerFrame, c->d_markers, c->stream);   // (the box count is still on the device: workgroups beyond it leave at once)
-  c->label_state[0] = 1; c->box_valid[0] = 1;
+  c->label_state[0] = 2; c->box_valid[0] = 0;   // until the device's flags say that the frame fit (set below); 2: no per-point labels vouched for, no cell codes either
   MOT_HIP(c, hipGetLastError());
   int* h = reinterpret_cast<int*>(pin);
   MOT_HIP(c, hipMemcpyAsync(h, c->d_counts, kCountsStride * sizeof(int), hipMemcpyDeviceToHost, c->stream));
@@ -1296,6 +1301,7 @@ extern "C" int mot_cluster_node_frame(mot_ctx* c, const float* elev, int n, cons
   }
   const int ncc = h[kCountsStride], nob = h[kCountsStride + 1], nb = h[kCntBoxes];
   if (ncc < 0 || ncc > n || nob < 0 || (size_t)nob > max_obs || nb < 0 || nb > kMaxBoxesPerFrame) return fail(c, MOT_E_STATE, "mot_cluster_node_frame: inconsistent counts");
+  c->label_state[0] = 1; c->box_valid[0] = 1;   // no overflow: slot 0 holds this cloud's labels and boxes (mot_box_markers / mot_get_boxes / mot_get_clusters may read them)
   if (ncc > 0) MOT_HIP(c, hipMemcpyAsync(pin + o_cc, c->d_side_cloud, (size_t)ncc * 16, hipMemcpyDeviceToHost, c->stream));
   if (nob > 0) MOT_HIP(c, hipMemcpyAsync(pin + o_ob, c->d_side_obs, (size_t)nob * 16, hipMemcpyDeviceToHost, c->stream));
   MOT_HIP(c, hipMemcpyAsync(pin + o_cm, c->d_side_cost, cost_cells * sizeof(int), hipMemcpyDeviceToHost, c->stream));
@@ -1325,6 +1331,8 @@ extern "C" int mot_get_ground(mot_ctx* c, int slot, float* elev, int* n_elev, fl
   if (n_ground) *n_ground = ng;
   if ((elev && ne > capacity_points) || (ground && ng > capacity_points) || (mask && c->h_n[slot] > capacity_points))
     return fail(c, MOT_E_CAPACITY, "more points resident than the caller's buffers hold (capacity_points)");
+  if (slot == 0 && c->ground_foreign0 && (elev || ground || mask))
+    return fail(c, MOT_E_STATE, "mot_get_ground: a stage-wise cluster / box call has put its own cloud into slot 0 since the ground stage ran: no ground result of that cloud is resident");
   const bool have_ground = c->ground_resident && (c->ground_all ? slot < c->last_batch : slot == 0);   // (a slot beyond the last batch: whatever an earlier batch left is not vouched for)
   if (((ground || mask) && !have_ground) || (elev && elev_packed_at(c, slot))) {   // (packed: the fused path left 12-byte points; the ABI's records are float4 with the input's 4th value)
     // The fused path left the ground cloud / mask out (mot_set_fused_outputs): materialise them for the whole last batch by
@@ -1359,7 +1367,7 @@ extern "C" int mot_ground_remove(mot_ctx* c, const float* xyzw, int n, float* el
   GroundBuffers g = ground_buffers(c, c->d_in, c->cap, true);
   mot_launch_ground(c->dp, g, 1, n, c->stream);
   MOT_HIP(c, hipGetLastError());
-  c->ground_resident = true; c->ground_all = false; c->last_fused = false; c->slot_packed[0] = 0; c->label_state[0] = 2; c->box_valid[0] = 0;
+  c->ground_resident = true; c->ground_all = false; c->last_fused = false; c->ground_foreign0 = false; c->slot_packed[0] = 0; c->label_state[0] = 2; c->box_valid[0] = 0;
   return mot_get_ground(c, 0, elev, n_elev, ground, n_ground, mask, n);
 }
 
@@ -1380,7 +1388,7 @@ extern "C" int mot_ground_node_frame(mot_ctx* c, const float* xyzw, int n, const
   MOT_HIP(c, hipGetLastError());
   c->ground_resident = false;   // (no mask: a later mot_get_ground that asks for one answers MOT_E_STATE)
   c->slot_packed[0] = 0;
-  c->last_fused = false; c->label_state[0] = 2; c->box_valid[0] = 0;
+  c->last_fused = false; c->ground_foreign0 = false; c->label_state[0] = 2; c->box_valid[0] = 0;
   if ((rc = fetch_counts(c, 0))) return rc;
   const int ne = c->h_counts[kCntElev], ng = c->h_counts[kCntGround];
   if (ne < 0 || ng < 0 || ne + ng > n) return fail(c, MOT_E_STATE, "mot_ground_node_frame: inconsistent counts");
@@ -1426,7 +1434,7 @@ extern "C" int mot_ground_remove_pointcloud2(mot_ctx* c, const void* data, int n
   GroundBuffers g = ground_buffers(c, c->d_in, c->cap, true);
   mot_launch_ground(c->dp, g, 1, n, c->stream);
   MOT_HIP(c, hipGetLastError());
-  c->ground_resident = true; c->ground_all = false; c->last_fused = false; c->slot_packed[0] = 0; c->label_state[0] = 2; c->box_valid[0] = 0;
+  c->ground_resident = true; c->ground_all = false; c->last_fused = false; c->ground_foreign0 = false; c->slot_packed[0] = 0; c->label_state[0] = 2; c->box_valid[0] = 0;
   return mot_get_ground(c, 0, elev, n_elev, ground, n_ground, mask, n);
 }
 
@@ -1721,8 +1729,11 @@ extern "C" int mot_reset_slot(mot_ctx* c, int slot) {
 // track-slot count (another GPU, another process, after a restart) and the stream continues bit for bit. The reference keeps this state
 // in file-scope globals (imm_ukf_jpda.cpp:19-24,56-70) and can neither save nor reset it (checkpoint / resume).
 // Layout: SnapshotHeader, then the arrays in the order written below; the per-ever-track arrays carry nt entries, not E.
+// The FORMAT has a version of its own (MOT_SNAPSHOT_FORMAT, include/mot.h), decoupled from the ABI version since ABI v6: a library whose entry points
+// grow keeps loading the snapshots it wrote before. Format 5 = what ABI v5 wrote (its `abi` field held 5). Snapshots of ABI v4 and older (no
+// step_ego_yaw, 16-byte tombs) are refused: INTEGRATION.md says so.
 struct SnapshotHeader {
-  uint32_t magic, abi, header_bytes, track_bytes, record_bytes;   // 'MOTS', MOT_ABI_VERSION, sizeof(SnapshotHeader), sizeof(DevTrack), sizeof(mot_track)
+  uint32_t magic, abi, header_bytes, track_bytes, record_bytes;   // 'MOTS', MOT_SNAPSHOT_FORMAT, sizeof(SnapshotHeader), sizeof(DevTrack), sizeof(mot_track)
   int32_t T, nt, nlive, nzomb, flags;
   uint8_t init, ego_called, tracks_restart, pad[5];
   double timestamp, egoVelo, egoYaw, egoPreYaw, rx, ry, ryaw, egoPoint[3], step_ego_yaw;
@@ -1761,7 +1772,7 @@ extern "C" int mot_stream_save(mot_ctx* c, int slot, void* blob, size_t capacity
   if (total > capacity) return fail(c, MOT_E_CAPACITY, "mot_stream_save: the blob is smaller than the snapshot (mot_stream_snapshot_size gives the upper bound)");
   SnapshotHeader h;
   memset(&h, 0, sizeof h);
-  h.magic = 0x53544f4du; h.abi = MOT_ABI_VERSION; h.header_bytes = sizeof(SnapshotHeader); h.track_bytes = sizeof(DevTrack); h.record_bytes = sizeof(mot_track);
+  h.magic = 0x53544f4du; h.abi = MOT_SNAPSHOT_FORMAT; h.header_bytes = sizeof(SnapshotHeader); h.track_bytes = sizeof(DevTrack); h.record_bytes = sizeof(mot_track);
   h.T = (int32_t)T; h.nt = (int32_t)nt; h.nlive = seeded ? meta[1] : 0; h.nzomb = seeded ? meta[2] : 0; h.flags = seeded ? meta[3] : 0;
   h.init = e.init; h.ego_called = e.ego_called; h.tracks_restart = e.tracks_restart;
   h.timestamp = e.timestamp; h.egoVelo = e.egoVelo; h.egoYaw = e.egoYaw; h.egoPreYaw = e.egoPreYaw; h.rx = e.rx; h.ry = e.ry; h.ryaw = e.ryaw;
@@ -1797,7 +1808,7 @@ extern "C" int mot_stream_load(mot_ctx* c, int slot, const void* blob, size_t by
   memcpy(&h, blob, sizeof h);
   // everything is checked before the slot is touched
   if (h.magic != 0x53544f4du || h.header_bytes != sizeof(SnapshotHeader)) return fail(c, MOT_E_ARG, "mot_stream_load: not a snapshot of this library");
-  if (h.abi != MOT_ABI_VERSION || h.track_bytes != sizeof(DevTrack) || h.record_bytes != sizeof(mot_track))
+  if (h.abi != MOT_SNAPSHOT_FORMAT || h.track_bytes != sizeof(DevTrack) || h.record_bytes != sizeof(mot_track))
     return fail(c, MOT_E_ARG, "mot_stream_load: the snapshot was written by another version of the library");
   if ((size_t)h.T != T) return fail(c, MOT_E_ARG, "mot_stream_load: the snapshot's track-slot count differs from this context's max_tracks_total");
   if (h.nt < 0 || h.nlive < 0 || h.nzomb < 0 || (size_t)h.nlive > T || (size_t)h.nzomb > T) return fail(c, MOT_E_ARG, "mot_stream_load: corrupt counters");
@@ -1882,7 +1893,9 @@ extern "C" int mot_track_step(mot_ctx* c, int slot, const float* boxes_global, i
   if (!c) return MOT_E_ARG;
   MOT_GUARD(c);
   if (slot < 0 || slot >= c->batch || m < 0 || (!boxes_global && m > 0) || !n_tracks) return fail(c, MOT_E_ARG, "mot_track_step: slot out of range, negative m, null boxes or null n_tracks");
-  if (m > kMaxBoxesPerFrame) return fail(c, MOT_E_CAPACITY, "more boxes in a frame than the library supports (1024)");
+  static_assert(kMaxBoxesPerFrame == MOT_MAX_BOXES_PER_FRAME, "mot.h documents the limit");
+  *n_tracks = -1;   // until the step has run (callers tell "refused" from "births dropped" by it: include/mot.h)
+  if (m > kMaxBoxesPerFrame) return fail(c, MOT_E_CAPACITY, "more boxes in a frame than the library supports (1024): the step was not taken");
   if (!c->ego[slot].ego_called) return fail(c, MOT_E_STATE, "mot_ego_update must precede mot_track_step (getOriginPoints precedes immUkfJpdaf, OT/tracking/main.cpp:74,166)");
   {
     char* blk; int rc;

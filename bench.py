@@ -403,14 +403,22 @@ def dense_scene(mot, sdev, torch, device, N, stride, streams=512, contexts=4, st
 
     def run(nf, extra=None):   # one issuing thread per context, as in the headline's loop (the library calls release the GIL): at 128 streams per
         import threading         # launch sequence ONE thread feeding four contexts in turn is the limit, not the GPU (423 / 384 k against 490 k measured)
+        errs = []
+        before = list(pos)
         def feed(ci):
-            for _ in range(nf + (extra[ci] if extra else 0)):
-                issue(ci)
+            try:
+                for _ in range(nf + (extra[ci] if extra else 0)):
+                    issue(ci)
+            except BaseException as e:
+                errs.append((ci, e))
         th = [threading.Thread(target=feed, args=(ci,)) for ci in range(contexts)]
         for t in th:
             t.start()
         for t in th:
             t.join()
+        if errs:
+            raise RuntimeError(f"dense_scene: context {errs[0][0]} failed while issuing: {errs[0][1]!r}") from errs[0][1]
+        assert all(pos[ci] - before[ci] == nf + (extra[ci] if extra else 0) for ci in range(contexts)), (before, pos)
 
     run(F, extra=[(phase * ci) % F for ci in range(contexts)])   # one untimed step + the contexts' phase offsets
     for c in ctxs:
@@ -910,24 +918,34 @@ def main():
         cx.frames_dev(frame_ptr[f], stride * 4, n_seq[f], run_tracker=True, timestamps=ts_f[f], ego_v=ev_f[f], ego_yaw=ey_f[f])
         pos[ci] += 1
 
+    thread_errors = []
+
     def run_context(ci, n_frames):
-        """--issue-threads 1: one host thread per context (the C calls release the GIL)"""
-        torch.cuda.set_device(local)
-        t_h = time.perf_counter()
-        for _ in range(n_frames):
-            issue_frame(ci)
-        busy[ci] = time.perf_counter() - t_h
+        """--issue-threads 1: one host thread per context (the C calls release the GIL). An exception ends the thread, is kept and re-raised by
+        run_frames after the join: a context that stopped issuing must never count as processed frames."""
+        try:
+            torch.cuda.set_device(local)
+            t_h = time.perf_counter()
+            for _ in range(n_frames):
+                issue_frame(ci)
+            busy[ci] = time.perf_counter() - t_h
+        except BaseException as e:
+            thread_errors.append((ci, e))
 
     def run_frames(n_frames, extra=None):
         """n_frames per context (+ extra[ci]: the phase offsets, issued first); one issuing thread interleaves the contexts frame by frame"""
         extra = extra or [0] * NC
         t_c = time.thread_time()
+        before = list(pos)
         if args.issue_threads and NC > 1 and not gather:
             th = [threading.Thread(target=run_context, args=(ci, n_frames + extra[ci])) for ci in range(NC)]
             for t in th:
                 t.start()
             for t in th:
                 t.join()
+            if thread_errors:
+                ci, e = thread_errors[0]
+                raise RuntimeError(f"context {ci} failed while issuing its launches: {e!r}") from e
         else:
             t_h = time.perf_counter()
             for ci in range(NC):
@@ -939,6 +957,7 @@ def main():
                 if gather:   # the frame tick's result blocks of every context cross GPUs in one RCCL all-gather over xGMI
                     gather.step(force_collective=True)
             busy[0] = time.perf_counter() - t_h
+        assert all(pos[ci] - before[ci] == n_frames + extra[ci] for ci in range(NC)), ("a context issued fewer frames than the line would count", before, pos)
         host_issue[0] = max(busy)
         host_cpu[0] = time.thread_time() - t_c
 

@@ -38,7 +38,9 @@
 extern "C" {
 #endif
 
-#define MOT_ABI_VERSION 5
+#define MOT_ABI_VERSION 6
+/* format of mot_stream_save's blobs: its own version since ABI v6 (5 = what ABI v5 wrote; blobs of ABI v4 and older are refused by mot_stream_load) */
+#define MOT_SNAPSHOT_FORMAT 5
 
 /* polar grid of the ground stage: compile-time in the reference too
  * (OT/include/ground_removal.h:16-17) */
@@ -258,7 +260,9 @@ int mot_ego_update(mot_ctx* ctx, int slot, double timestamp, double v_gps, doubl
 
 /* replaces immUkfJpdaf(bBoxes, timestamp, ...), OT/include/imm_ukf_jpda.h:19-22.
  * boxes_global: m x 8 x 3 floats in the global frame. tracks: capacity max_tracks records — one per track EVER created on the
- * stream (see mot_get_tracks for sizing and the two meanings of MOT_E_CAPACITY). */
+ * stream (see mot_get_tracks for sizing and the two meanings of MOT_E_CAPACITY). A THIRD one here: m > MOT_MAX_BOXES_PER_FRAME is
+ * refused before anything runs — the step has NOT been taken, *n_tracks = -1 says so (the other two deliver n_tracks >= 0). */
+#define MOT_MAX_BOXES_PER_FRAME 1024
 int mot_track_step(mot_ctx* ctx, int slot, const float* boxes_global, int m, double timestamp,
                    mot_track* tracks, int max_tracks, int* n_tracks);
 /* filter state of track `id` (reference index) on `slot` (parity/debug); MOT_E_STATE once the track has been dead for more than a step */

@@ -260,20 +260,23 @@ inline void immUkfJpdaf(std::vector<pcl::PointCloud<pcl::PointXYZ>> bBoxes, doub
   // dropped — every track slot alive at once, or the stream's max_tracks_ever budget (64 x max_tracks_total here) used up: the
   // reference would have grown for ever; this adapter publishes what came back and starts the stream's TRACKS over
   // (mot_reset_tracks_slot keeps the dead-reckoned ego pose, so the global frame stays continuous). It never throws for that.
+  // A frame the library REFUSES (more than MOT_MAX_BOXES_PER_FRAME boxes: the step is not taken, nt = -1) is an error of this call
+  // and throws like every other one — the stream's tracks are left alone.
   static std::vector<mot_track> tr;
   if (tr.size() < (size_t)config().max_tracks_total) tr.resize((size_t)config().max_tracks_total);
   int nt = 0;
   int rc = mot_track_step(context(), 0, boxes.data(), (int)bBoxes.size(), timestamp, tr.data(), (int)tr.size(), &nt);
-  if (rc == MOT_E_CAPACITY && (size_t)nt > tr.size()) {   // nothing was copied: fetch again with room for every record
+  if (rc == MOT_E_CAPACITY && nt > 0 && (size_t)nt > tr.size()) {   // nothing was copied: fetch again with room for every record
     tr.resize(2 * (size_t)nt);
     rc = mot_get_tracks(context(), 0, tr.data(), (int)tr.size(), &nt);
   }
-  if (rc == MOT_E_CAPACITY && (size_t)nt <= tr.size()) {
+  if (rc == MOT_E_CAPACITY && nt >= 0 && (size_t)nt <= tr.size()) {   // the step ran, the records are here: births were dropped
     std::fprintf(stderr, "mot_adapters: %s -- restarting the tracks of this stream\n", mot_last_error(context()));
     check(mot_reset_tracks_slot(context(), 0));
     rc = MOT_OK;
   }
   check(rc);
+  if (nt < 0) nt = 0;
   for (int i = 0; i < nt; i++) {
     targets.push_back(pcl::PointXYZ(tr[i].px, tr[i].py, tr[i].pz));
     targetVandYaw.push_back({tr[i].v, tr[i].yaw});

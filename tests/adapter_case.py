@@ -63,3 +63,17 @@ def run(driver, oracle, tmp_path, slots=24, ever=150, frames=420, seed=5, spots=
     assert all(x["n"] <= ever for x in out)
     assert max(x["n"] for x in out[-20:]) > 0   # still tracking at the end
     return restarts
+
+
+def run_refused(driver, tmp_path):
+    """round-5 advice: a frame with more boxes than the library takes (MOT_MAX_BOXES_PER_FRAME) is refused before the step runs — the adapter must THROW
+    for it (the reference's own immUkfJpdaf would have taken it: an error of this call, told loudly) and must NOT read it as "births dropped" and
+    wipe the stream's tracks, as it did while both came back as a bare MOT_E_CAPACITY."""
+    world = list(TC.blinking_world(3, 4, 12))
+    boxes, ts, v, yaw = world[-1]
+    one = np.zeros((1, 8, 3), np.float32); one[0, :, :2] = [[0, 0], [2, 0], [2, 1], [0, 1]] * 2; one[0, 4:, 2] = 1.0
+    world.append((np.concatenate([one + [3.0 * (k % 40), 3.0 * (k // 40), 0] for k in range(1025)]), ts + 1e5, v, yaw))
+    i, o = str(tmp_path / "boxes_refused.bin"), str(tmp_path / "out_refused.txt")
+    write_boxes(i, world)
+    r = subprocess.run([driver, i, o, "64", "4096"], capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0 and "more boxes in a frame" in r.stderr and "restarting the tracks" not in r.stderr, (r.returncode, r.stderr[-800:])

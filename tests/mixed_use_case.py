@@ -60,3 +60,40 @@ def run(mot, lib, synth, oracle, upload=None, N=5000):
                 gb = np.zeros((N, 4), np.float32); ne, ng = mot.C.c_int(0), mot.C.c_int(0)
                 rc = c.lib.mot_get_ground(c._h, s, None, mot.C.byref(ne), gb.ctypes.data_as(mot.C.c_void_p), mot.C.byref(ng), None, N)
                 assert rc == mot.MOT_E_STATE, (call, s, rc)
+
+
+def run_ground_after_takeover(mot, lib, synth, oracle, upload=None, N=5000):
+    """round-5 advice: after a fused batch that WROTE the ground cloud and the mask (mot_set_fused_outputs GROUND | MASK), a stage-wise cluster / box call
+    replaces slot 0's elevated cloud — mot_get_ground(0) must then answer MOT_E_STATE (it used to return the new elevated cloud next to the old batch's
+    ground cloud and mask); slot 1 keeps its own, complete ground result; a new ground stage on slot 0 makes it readable again."""
+    B = 2; stride = ((N + 1023) // 1024) * 1024
+    p = oracle.params(0)
+    host = np.zeros((B, stride, 4), np.float32)
+    for s in range(B):
+        host[s, :N] = synth.make_cloud(N, 70 + s, s)
+    o = [oracle.ground_remove(p, host[s, :N]) for s in range(B)]
+    other = np.ascontiguousarray(o[1]["elevated"][::-1])
+    ref_other = oracle.cluster(p, other)
+    ptr = upload(host) if upload else host.ctypes.data
+    for call in ("cluster", "box_fit", "products_host", "node_frame"):
+        with mot.Context(**({"lib_path": lib} if lib else {}), max_points=stride, max_batch=B, max_tracks_total=64) as c:
+            c.set_fused_outputs(mot.OUT_GROUND | mot.OUT_MASK)
+            c.frames_dev(ptr, stride * 4, [N] * B)
+            g0 = c.get_ground(0, n_hint=N)
+            assert np.array_equal(g0["ground"], o[0]["ground"]) and np.array_equal(g0["mask"], o[0]["mask"])
+            if call == "cluster":
+                c.cluster(other)
+            elif call == "box_fit":
+                c.box_fit(other, ref_other["grid"], ref_other["num_cluster"])
+            elif call == "products_host":
+                c.cluster_products_host(other, ref_other["grid"])
+            else:
+                c.cluster_node_frame(other)
+            with pytest.raises(mot.MotError) as e:
+                c.get_ground(0, n_hint=N)
+            assert e.value.code == mot.MOT_E_STATE, call
+            g1 = c.get_ground(1, n_hint=N)   # the other slot of the batch: float4 clouds and mask were written by the batch itself, nothing to rebuild
+            assert np.array_equal(g1["elevated"], o[1]["elevated"]) and np.array_equal(g1["ground"], o[1]["ground"]) and np.array_equal(g1["mask"], o[1]["mask"]), call
+            c.frames_dev(ptr, stride * 4, [N] * B)   # a new ground stage: slot 0 is the batch's again
+            g0 = c.get_ground(0, n_hint=N)
+            assert np.array_equal(g0["elevated"], o[0]["elevated"]) and np.array_equal(g0["ground"], o[0]["ground"]) and np.array_equal(g0["mask"], o[0]["mask"]), call

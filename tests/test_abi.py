@@ -21,7 +21,7 @@ def test_library_exports_every_declared_symbol(mot, hip_lib):
     missing = [n for n in names if not hasattr(hip_lib, n)]
     assert not missing, missing
     assert set(names) == set(mot.EXPORTS), set(names) ^ set(mot.EXPORTS)
-    assert hip_lib.mot_abi_version() == mot.ABI_VERSION == 5
+    assert hip_lib.mot_abi_version() == mot.ABI_VERSION == 6
 
 
 def test_presets_match_the_oracle_table(mot, hip_lib, oracle):

@@ -16,3 +16,4 @@ def test_adapter_tracker_outgrows_its_buffer_and_outlives_its_budget(oracle, tmp
     import build_emu
     driver = NB.adapter_driver(build_emu.build())
     adapter_case.run(driver, oracle, tmp_path)
+    adapter_case.run_refused(driver, tmp_path)

@@ -208,6 +208,7 @@ def test_stage_wise_call_after_a_fused_batch_leaves_the_other_slots_readable(mot
         bufs.append(hiprt.DeviceBuffer(host)); return bufs[-1].ptr
     try:
         mixed_use_case.run(mot, None, synth, oracle, upload=upload, N=40000)
+        mixed_use_case.run_ground_after_takeover(mot, None, synth, oracle, upload=upload, N=40000)
     finally:
         for d in bufs: d.free()
 

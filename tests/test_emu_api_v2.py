@@ -237,6 +237,7 @@ def test_point_labels_on_demand_without_cells(mot, emu, synth, oracle):
 def test_stage_wise_call_after_a_fused_batch_leaves_the_other_slots_readable(mot, emu, synth, oracle):
     import mixed_use_case
     mixed_use_case.run(mot, emu[0], synth, oracle)
+    mixed_use_case.run_ground_after_takeover(mot, emu[0], synth, oracle)
 
 
 def test_reset_tracks_slot_keeps_the_global_frame(mot, emu, oracle):

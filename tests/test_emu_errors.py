@@ -63,6 +63,14 @@ def test_calls_report_capacity_and_argument_errors(mot, emu, synth):
             ts = 1.0e9 + f * 1e5
             c.ego_update(ts, 0.0, 0.0); full |= c.track_step(boxes, ts)["capacity_exceeded"]
         assert full
+        # a frame with more boxes than the library takes is REFUSED before the step: n_tracks = -1, the stream's tracks untouched (round-5 advice: the
+        # adapter used to read it as "births dropped" and wiped the stream)
+        many = np.zeros((mot.MOT_MAX_BOXES_PER_FRAME + 1, 8, 3), np.float32)
+        arr = (mot.MotTrack * 64)(); nt = C.c_int(7)
+        assert L.mot_track_step(c._h, 0, many.ctypes.data_as(C.c_void_p), len(many), C.c_double(2.0e9), arr, 64, C.byref(nt)) == mot.MOT_E_CAPACITY and nt.value == -1
+        with pytest.raises(mot.MotError) as e:
+            c.track_step(many, 2.0e9)
+        assert e.value.code == mot.MOT_E_CAPACITY and "not taken" in str(e.value)
         # the context stays usable after an error
         c.reset()
         small = synth.make_cloud(1500, 1, 0)

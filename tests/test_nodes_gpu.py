@@ -47,3 +47,4 @@ def test_gpu_adapter_tracker_outgrows_its_buffer_and_outlives_its_budget(hip_lib
         pytest.skip("ros/bin/adapter_tracker_driver is not on this box")
     import adapter_case
     adapter_case.run(rec["adapter_tracker_driver"], oracle, tmp_path)
+    adapter_case.run_refused(rec["adapter_tracker_driver"], tmp_path)
