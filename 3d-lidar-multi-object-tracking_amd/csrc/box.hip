@@ -337,7 +337,7 @@ __global__ void MOT_LAUNCH_BOUNDS(kIndexBlock)
 cluster_index_kernel(ClusterBuffers c) {
   __shared__ int s_start[kMaxClusters + 1];
   __shared__ int s_part[kIndexWaves], s_gpart[kIndexWaves];
-  __shared__ uint2 s_raw[kGroupsLds];   // fast path: {cluster, points | groups << 16} tables [wg][64] then their prefixes; general path: group keys
+  __shared__ __attribute__((aligned(16))) uint2 s_raw[kGroupsLds];   // fast path: {cluster, points | groups << 16} tables [wg][64] then their prefixes; general path: group keys
   static_assert(kGroupsLds * sizeof(uint2) >= kIndexWgLds * kWgClusters * (sizeof(int2) + sizeof(int)), "LDS union too small");
   const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int num_cluster = min(c.counts[b * kCountsStride + kCntClusters], kMaxClusters);
@@ -448,6 +448,93 @@ cluster_index_kernel(ClusterBuffers c) {
     // and a group then sums over its own cluster's bucket only: sum of (groups per cluster)^2 instead of (groups per frame)^2.
     const bool bucketed = E <= kGroupsLds / 2 && num_cluster > 0 && cgstart[num_cluster] <= kGroupsLds / 2;
     uint2* s_buck = s_raw + kGroupsLds / 2;
+    if (!bucketed && num_cluster > 0) {
+      // Round 6: MANY groups — a cloud whose points come in no order at all (a merged or voxel-filtered cloud; bench.py --point-order random) puts
+      // every tile's 64 points into dozens of clusters: ~N_e groups per frame, and the sums over all groups below (quadratic, from L2 once the keys
+      // no longer fit in LDS) took 31 ms per 512 frames against 20 us (profiles/r06_point_order.md). Linear instead:
+      //   1. the groups are bucketed by cluster in GLOBAL scratch (the polygon pool: nothing uses it before the gather kernel; cap / 2 groups x 8 bytes
+      //      are exactly its cap ints), any order inside a bucket, the bucket bounds being the group starts computed above;
+      //   2. a wave per cluster ranks its bucket by TILE: a cluster has at most one group per tile, so a byte table tile -> points of that group
+      //      (2048 tiles per pass) and its prefix sums over 32-tile blocks give every group "groups / points of my cluster in earlier tiles" with
+      //      one table walk of at most 31 bytes — O(groups + tiles / 64) per cluster. Buckets of up to 64 groups are ranked in registers.
+      uint2* __restrict__ gbuck = reinterpret_cast<uint2*>(c.poly + (long)b * c.cap);   // {tile << 8 | points, index of the group}
+      for (int ci = tid; ci < num_cluster; ci += kIndexBlock) s_start[ci] = cgstart[ci];   // running fill position of every bucket
+      __syncthreads();
+      for (int e = tid; e < E; e += kIndexBlock) {
+        const PointGroup g = groups[e];
+        const int lab = g.label & kGroupLabelMask;
+        const int at = atomicAdd(&s_start[lab - 1], 1);
+        if (at < c.group_cap) gbuck[at] = make_uint2(((unsigned)(g.tile & kGroupTileMask) << 8) | (unsigned)__popcll(g.mask), (unsigned)e);
+      }
+      __syncthreads();   // (workgroup scope: the buckets are read back by this workgroup only)
+      constexpr int kWinTiles = 2048, kBlockTiles = 32;
+      static_assert(kIndexWaves * (kWinTiles + 2 * 64 * (int)sizeof(int)) <= kGroupsLds * (int)sizeof(uint2), "per-wave tile tables do not fit the LDS union");
+      unsigned char* const w_cnt = reinterpret_cast<unsigned char*>(s_raw) + wave * (kWinTiles + 2 * 64 * (int)sizeof(int));
+      int* const w_bp = reinterpret_cast<int*>(w_cnt + kWinTiles);   // [64] points, [64] groups before every 32-tile block
+      const int ntiles = (n + 63) / 64;
+      for (int ci = wave; ci < num_cluster; ci += kIndexWaves) {
+        const int f0 = cgstart[ci], f1 = min(cgstart[ci + 1], c.group_cap), m = f1 - f0;
+        if (m <= 0) continue;
+        if (m <= 64) {   // one group per lane, ranked against the others through the wave
+          const uint2 k = lane < m ? gbuck[f0 + lane] : make_uint2(0xffffffffu, 0u);
+          const int mytile = (int)(k.x >> 8), mycnt = (int)(k.x & 0xffu);
+          int before = 0, rank = 0;
+          for (int j = 0; j < m; j++) {
+            const int tj = wave_bcast_i32(mytile, j), cj = wave_bcast_i32(mycnt, j);
+            if (tj < mytile) { before += cj; rank++; }
+          }
+          if (lane < m) {
+            const PointGroup g = groups[k.y];
+            SortedGroup r; r.mask = g.mask; r.tile = mytile; r.before = before;
+            if (f0 + rank < c.group_cap) gsorted[f0 + rank] = r;
+          }
+          continue;
+        }
+        int base_pts = 0, base_grp = 0;
+        for (int t0 = 0; t0 < ntiles; t0 += kWinTiles) {
+          { uint4 z; z.x = z.y = z.z = z.w = 0u; reinterpret_cast<uint4*>(w_cnt)[2 * lane] = z; reinterpret_cast<uint4*>(w_cnt)[2 * lane + 1] = z; }
+          MOT_WAVE_SYNC();
+          for (int f = f0 + lane; f < f1; f += 64) {
+            const uint2 k = gbuck[f];
+            const int t = (int)(k.x >> 8) - t0;
+            if (t >= 0 && t < kWinTiles) w_cnt[t] = (unsigned char)(k.x & 0xffu);   // 1..64 points: a cluster meets a tile once
+          }
+          MOT_WAVE_SYNC();
+          int pts = 0, grp = 0;   // my 32-tile block
+#pragma unroll
+          for (int w = 0; w < kBlockTiles / 4; w++) {
+            const unsigned x = reinterpret_cast<const unsigned*>(w_cnt)[lane * (kBlockTiles / 4) + w];
+            pts += (int)((x & 0xffu) + ((x >> 8) & 0xffu) + ((x >> 16) & 0xffu) + (x >> 24));
+            grp += __popc((x + 0x7f7f7f7fu) & 0x80808080u);   // bytes != 0 (every byte < 128)
+          }
+          const int ip = wave_scan_incl_i32(pts), ig = wave_scan_incl_i32(grp);
+          w_bp[lane] = base_pts + ip - pts; w_bp[64 + lane] = base_grp + ig - grp;
+          MOT_WAVE_SYNC();
+          for (int f = f0 + lane; f < f1; f += 64) {
+            const uint2 k = gbuck[f];
+            const int tile = (int)(k.x >> 8), t = tile - t0;
+            if (t < 0 || t >= kWinTiles) continue;
+            const int blk = t / kBlockTiles, pos = t % kBlockTiles;
+            int before = w_bp[blk], rank = w_bp[64 + blk];
+            for (int w = 0; w * 4 < pos; w++) {
+              unsigned x = reinterpret_cast<const unsigned*>(w_cnt)[blk * (kBlockTiles / 4) + w];
+              if (pos - w * 4 < 4) x &= (1u << ((pos - w * 4) * 8)) - 1u;   // the bytes below my tile only
+              before += (int)((x & 0xffu) + ((x >> 8) & 0xffu) + ((x >> 16) & 0xffu) + (x >> 24));
+              rank += __popc((x + 0x7f7f7f7fu) & 0x80808080u);
+            }
+            const PointGroup g = groups[k.y];
+            SortedGroup r; r.mask = g.mask; r.tile = tile; r.before = before;
+            if (f0 + rank < c.group_cap) gsorted[f0 + rank] = r;
+          }
+          base_pts += wave_bcast_i32(ip, 63); base_grp += wave_bcast_i32(ig, 63);
+          MOT_WAVE_SYNC();
+        }
+      }
+      B1B_T(3);
+      B1B_T_VALUE(4, E); B1B_T_VALUE(5, nwg); B1B_T_VALUE(6, fast);
+      if (tid == 0) { c.counts[b * kCountsStride + kCntGroups] = 0; c.counts[b * kCountsStride + kCntIrregular] = 0; }  // re-arm
+      return;
+    }
     if (bucketed) for (int ci = tid; ci < num_cluster; ci += kIndexBlock) s_start[ci] = cgstart[ci];   // (the point starts in s_start are not read on this path) running fill position of every bucket
     __syncthreads();
     if (in_lds) for (int e = tid; e < E; e += kIndexBlock) {

@@ -636,6 +636,29 @@ void mot_launch_decode_pointcloud2(const void* data, int n, int step, int ox, in
   hipLaunchKernelGGL(decode_pointcloud2_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, (const unsigned char*)data, n, step, ox, oy, oz, ow, aligned, out);
 }
 
+// packed {x, y, z} records (12 bytes a point: mot_frames_host_xyz) -> float4, w = 1.0f, for a batch of frames. A thread expands four consecutive points:
+// three 16-byte loads, four 16-byte stores, both sides coalesced (48 B in, 64 B out per thread). Runs once per host-fed batch, under the next batch's
+// H2D copy; the points beyond a frame's n are expanded too (max_n per slot: the counts are not on the device yet) and never read.
+__global__ void MOT_LAUNCH_BOUNDS(256)
+expand_xyz12_kernel(const float* __restrict__ in, long in_stride, float4* __restrict__ out, long out_stride, int max_n) {
+  const int b = blockIdx.y;
+  const long i4 = ((long)blockIdx.x * 256 + threadIdx.x) * 4;
+  if (i4 >= max_n) return;
+  const float* __restrict__ src = in + (long)b * in_stride + i4 * 3;
+  float4* __restrict__ dst = out + (long)b * out_stride + i4;
+  if (i4 + 4 <= max_n && (((size_t)src & 15) == 0)) {
+    const float4 a = reinterpret_cast<const float4*>(src)[0], bq = reinterpret_cast<const float4*>(src)[1], cq = reinterpret_cast<const float4*>(src)[2];
+    dst[0] = make_float4(a.x, a.y, a.z, 1.0f); dst[1] = make_float4(a.w, bq.x, bq.y, 1.0f);
+    dst[2] = make_float4(bq.z, bq.w, cq.x, 1.0f); dst[3] = make_float4(cq.y, cq.z, cq.w, 1.0f);
+  } else {
+    for (int k = 0; k < 4 && i4 + k < max_n; k++) dst[k] = make_float4(src[3 * k], src[3 * k + 1], src[3 * k + 2], 1.0f);
+  }
+}
+void mot_launch_expand_xyz12(const float* in, long in_stride_floats, float4* out, long out_stride, int batch, int max_n, hipStream_t stream) {
+  if (max_n <= 0 || batch <= 0) return;
+  hipLaunchKernelGGL(expand_xyz12_kernel, dim3((max_n + 1023) / 1024, batch), dim3(256), 0, stream, in, in_stride_floats, out, out_stride, max_n);
+}
+
 // ------------------------------------------------------------------------------------------ host
 // (Capping the streaming kernels' workgroups per CU with a dynamic-LDS pad — so that they leave wave slots to the other contexts'
 // latency-bound kernels — changes nothing: 4 instead of 8 min-z workgroups per CU, 2 instead of 3 compaction workgroups, alone or

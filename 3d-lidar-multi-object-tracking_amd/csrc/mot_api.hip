@@ -152,6 +152,9 @@ struct mot_ctx {
   hipStream_t copy_stream = nullptr;
   bool copy_ready = false;             // copy stream, staging buffers and events all exist
   float4* d_stage[2] = {nullptr, nullptr};
+  float* d_stage12[2] = {nullptr, nullptr};        // mot_frames_host_xyz: where the packed {x, y, z} records land (12 bytes a point); expanded into d_stage[i] on the compute stream
+  hipEvent_t ev_expanded[2] = {nullptr, nullptr};  // the expansion kernel that read d_stage12[i] has run (compute stream)
+  bool stage12_used[2] = {false, false};
   hipEvent_t ev_copied[2] = {nullptr, nullptr};    // H2D of stage[i] complete (copy stream)
   hipEvent_t ev_consumed[2] = {nullptr, nullptr};  // last kernel reading stage[i] launched and done (compute stream)
   bool stage_used[2] = {false, false};
@@ -283,6 +286,8 @@ extern "C" void mot_destroy(mot_ctx* c) {
   if (c->copy_stream) { (void)hipStreamSynchronize(c->copy_stream); (void)hipStreamDestroy(c->copy_stream); }
   for (int i = 0; i < 2; i++) {
     if (c->d_stage[i]) (void)hipFree(c->d_stage[i]);
+    if (c->d_stage12[i]) (void)hipFree(c->d_stage12[i]);
+    if (c->ev_expanded[i]) (void)hipEventDestroy(c->ev_expanded[i]);
     if (c->ev_copied[i]) (void)hipEventDestroy(c->ev_copied[i]);
     if (c->ev_consumed[i]) (void)hipEventDestroy(c->ev_consumed[i]);
   }
@@ -912,6 +917,59 @@ extern "C" int mot_frames_host(mot_ctx* c, const float* h_xyzw, long frame_strid
   if ((rc = set_batch(c, n_points, batch, c->d_stage[s], c->cap, false))) return rc;
   rc = launch_frames(c, batch, run_tracker, timestamps, ego_v, ego_yaw);
   // (recorded after the whole sequence: the input is last read by the compaction kernel, but mot_time_stage may re-read it)
+  MOT_HIP(c, hipEventRecord(c->ev_consumed[s], c->stream));
+  c->stage_used[s] = true;
+  return rc;
+}
+
+// mot_frames_host for clouds WITHOUT a 4th value: packed {x, y, z} records, 12 bytes a point (include/mot.h). pcl::PointXYZ has no 4th value (its
+// padding float is 1.0f), the node shells repack the PointCloud2 payload anyway (ros/src/ground_node.cpp) — and the host link, not the GPU, bounds a
+// host-fed deployment: 25 % fewer bytes over PCIe. The records land in a 12-byte staging buffer (copy stream) and a small kernel on the compute
+// stream expands them to the float4 layout every kernel of the path reads (w = 1.0f: what fromROSMsg leaves in PointXYZ's padding and what the
+// PointCloud2 decoder writes for a cloud without a 4th field); 28 bytes of HBM traffic per point against 12 over a link ~100 x slower.
+extern "C" int mot_frames_host_xyz(mot_ctx* c, const float* h_xyz, long frame_stride, const int* n_points, int batch,
+                                   int run_tracker, const double* timestamps, const double* ego_v, const double* ego_yaw) {
+  if (!c) return MOT_E_ARG;
+  MOT_GUARD(c);
+  if (!h_xyz || !n_points) return fail(c, MOT_E_ARG, "null cloud or point-count pointer");
+  if (frame_stride < 0 || ((size_t)h_xyz & 3) != 0) return fail(c, MOT_E_ARG, "mot_frames_host_xyz: frame_stride (floats) must be non-negative, the cloud 4-byte aligned");
+  if (run_tracker && (!timestamps || !ego_v || !ego_yaw)) return fail(c, MOT_E_ARG, "run_tracker needs timestamps, ego_v and ego_yaw");
+  if (batch < 1 || batch > c->batch) return fail(c, MOT_E_ARG, "batch out of range");
+  int max_n = 0;
+  for (int b = 0; b < batch; b++) {
+    if (n_points[b] < 0) return fail(c, MOT_E_ARG, "negative point count");
+    if (n_points[b] > c->max_points) return fail(c, MOT_E_CAPACITY, "frame has more points than max_points");
+    if (batch > 1 && frame_stride / 3 < n_points[b]) return fail(c, MOT_E_ARG, "frame_stride is smaller than a frame");
+    if (n_points[b] > max_n) max_n = n_points[b];
+  }
+  int rc;
+  if ((rc = ensure_copy_path(c))) return rc;
+  for (int i = 0; i < 2; i++) {
+    if (!c->d_stage12[i]) MOT_HIP(c, hipMalloc(&c->d_stage12[i], (size_t)c->batch * c->cap * 3 * sizeof(float)));
+    if (!c->ev_expanded[i]) MOT_HIP(c, hipEventCreateWithFlags(&c->ev_expanded[i], hipEventDisableTiming));
+  }
+  const int s = c->stage_next;
+  c->stage_next ^= 1;
+  if (c->stage12_used[s]) MOT_HIP(c, hipStreamWaitEvent(c->copy_stream, c->ev_expanded[s], 0));   // the landing buffer is free once its last expansion has run
+  const size_t cap3 = (size_t)c->cap * 3;
+  if ((size_t)frame_stride == cap3) {   // host frames already at the staging stride: one copy for the whole batch
+    const size_t bytes = ((size_t)(batch - 1) * cap3 + (size_t)n_points[batch - 1] * 3) * sizeof(float);
+    if (bytes) MOT_HIP(c, hipMemcpyAsync(c->d_stage12[s], h_xyz, bytes, hipMemcpyHostToDevice, c->copy_stream));
+  } else {
+    for (int b = 0; b < batch; b++)
+      if (n_points[b] > 0)
+        MOT_HIP(c, hipMemcpyAsync(c->d_stage12[s] + (size_t)b * cap3, h_xyz + (size_t)b * frame_stride, (size_t)n_points[b] * 3 * sizeof(float),
+                                  hipMemcpyHostToDevice, c->copy_stream));
+  }
+  MOT_HIP(c, hipEventRecord(c->ev_copied[s], c->copy_stream));
+  MOT_HIP(c, hipStreamWaitEvent(c->stream, c->ev_copied[s], 0));
+  // (d_stage[s] was last read by the batch before the previous one, on this same stream: ordered)
+  mot_launch_expand_xyz12(c->d_stage12[s], (long)cap3, c->d_stage[s], c->cap, batch, max_n, c->stream);
+  MOT_HIP(c, hipGetLastError());
+  MOT_HIP(c, hipEventRecord(c->ev_expanded[s], c->stream));
+  c->stage12_used[s] = true;
+  if ((rc = set_batch(c, n_points, batch, c->d_stage[s], c->cap, false))) return rc;
+  rc = launch_frames(c, batch, run_tracker, timestamps, ego_v, ego_yaw);
   MOT_HIP(c, hipEventRecord(c->ev_consumed[s], c->stream));
   c->stage_used[s] = true;
   return rc;

@@ -639,31 +639,32 @@ def stage_wise_host_buffers(mot, device, seq_dev, n_seq, stride, ego_v, ego_yaw,
     return out
 
 
-def host_boundary_pipelined(mot, torch, device, seq_dev, n_seq, stride, n_points, ego_v, ego_yaw, contexts=4, slots=16, batches=48, lib=None):
+def host_boundary_pipelined(mot, torch, device, seq_dev, n_seq, stride, n_points, ego_v, ego_yaw, contexts=4, slots=16, batches=48, lib=None, xyz12=False):
     """PCIe-INCLUSIVE rate (never the headline value): every frame starts in page-locked HOST memory, as a message in the
     reference's nodes does (OT/src/groundremove/main.cpp:91-136). `contexts` contexts x `slots` streams; mot_frames_host copies
     batch k+1 on the context's copy stream while the kernels of batch k run; the live-track block of every batch comes back to
     pinned host memory. Wall clock over all batches / frames."""
     import ctypes as C
     F = min(8, seq_dev.shape[0])
-    nbytes = F * slots * stride * 16
+    W = 3 if xyz12 else 4
+    nbytes = F * slots * stride * 4 * W
     hp = C.c_void_p()
     assert lib.mot_host_alloc(C.c_size_t(nbytes), C.byref(hp)) == 0
-    pinned = np.ctypeslib.as_array(C.cast(hp, C.POINTER(C.c_float)), shape=(F, slots, stride, 4))
-    pinned[:] = seq_dev[:F, :slots].cpu().numpy()
+    pinned = np.ctypeslib.as_array(C.cast(hp, C.POINTER(C.c_float)), shape=(F, slots, stride, W))
+    pinned[:] = seq_dev[:F, :slots].cpu().numpy()[..., :W]
     K = GATHER_TRACKS
     tp = C.c_void_p(); cp = C.c_void_p()
     assert lib.mot_host_alloc(C.c_size_t(contexts * slots * K * TRACK_RECORD_BYTES), C.byref(tp)) == 0
     assert lib.mot_host_alloc(C.c_size_t(contexts * slots * 4), C.byref(cp)) == 0
     ctxs = [mot.Context(device=device, max_points=stride, max_batch=slots, max_tracks_total=256) for _ in range(contexts)]
-    frame_bytes = slots * stride * 16
+    frame_bytes = slots * stride * 4 * W
 
     def run(nb):
         for k in range(nb):
             f = k % F
             ts = [1.0e9 + k * 1e5] * slots
             for ci, cx in enumerate(ctxs):
-                cx.frames_host(hp.value + f * frame_bytes, stride * 4, n_seq[f, :slots], run_tracker=True, timestamps=ts,
+                (cx.frames_host_xyz if xyz12 else cx.frames_host)(hp.value + f * frame_bytes, stride * W, n_seq[f, :slots], run_tracker=True, timestamps=ts,
                                ego_v=[float(ego_v[k % len(ego_v)])] * slots, ego_yaw=[float(ego_yaw[k % len(ego_yaw)])] * slots)
                 cx.fetch_tracks_async(slots, tp.value + ci * slots * K * TRACK_RECORD_BYTES, K, cp.value + ci * slots * 4)
         for cx in ctxs:
@@ -680,7 +681,7 @@ def host_boundary_pipelined(mot, torch, device, seq_dev, n_seq, stride, n_points
     for q in (hp, tp, cp):
         lib.mot_host_free(q)
     frames = batches * contexts * slots
-    return {"value": round(frames / dt, 1), "unit": "frames/s", "h2d_GBps": round(frames * n_points * 16 / dt / 1e9, 2),
+    return {"value": round(frames / dt, 1), "unit": "frames/s", "h2d_GBps": round(frames * n_points * 4 * W / dt / 1e9, 2), "bytes_per_point_over_the_link": 4 * W,
             "contexts": contexts, "streams_per_context": slots, "batches": batches,
             "what": f"{contexts} contexts x {slots} streams, {batches} batches: frames in page-locked host memory -> H2D on a copy stream per context, "
                     "double-buffered staging (copy of batch k+1 under the kernels of batch k) -> ground/cluster/box/tracker -> live-track block "
@@ -1173,6 +1174,8 @@ def main():
                 print(f"stage_wise_host_buffers failed: {e}", file=sys.stderr)
             try:
                 out["host_boundary_pipelined"] = host_boundary_pipelined(mot, torch, local, seq_dev, n_seq, stride, N, ego_v, ego_yaw, lib=ctx.lib)
+                # the same with packed {x, y, z} records in host memory (mot_frames_host_xyz, ABI v6): what a host-fed deployment of PointXYZ clouds sees
+                out["host_boundary_pipelined"]["xyz12"] = host_boundary_pipelined(mot, torch, local, seq_dev, n_seq, stride, N, ego_v, ego_yaw, lib=ctx.lib, xyz12=True)
             except Exception as e:
                 out["host_boundary_pipelined"] = None
                 print(f"host_boundary_pipelined failed: {e}", file=sys.stderr)

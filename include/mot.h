@@ -337,6 +337,13 @@ int mot_set_tracker_mode(mot_ctx* ctx, int mode);
  * runtime and do not overlap. The host buffer may be reused after mot_wait_uploads (or mot_synchronize). */
 int mot_frames_host(mot_ctx* ctx, const float* h_xyzw, long frame_stride, const int* n_points, int batch,
                     int run_tracker, const double* timestamps, const double* ego_v, const double* ego_yaw);
+/* mot_frames_host for clouds WITHOUT a 4th value (ABI v6): h_xyz holds packed {x, y, z} records, 12 bytes a point, frame_stride FLOATS between the
+ * frames of the batch (>= 3 * n_points[b]; 3 * the context's point capacity = one copy for the whole batch). pcl::PointXYZ — what groundRemove is
+ * handed, OT/include/ground_removal.h:62-64 — has no 4th value, and the host link bounds a host-fed deployment: 25 % fewer bytes cross PCIe. The
+ * records are expanded on the device (w = 1.0f, PCL's padding value: mot_get_ground's float4 records carry it); every result equals mot_frames_host's
+ * on the same x, y, z. Same pipelining, same mot_wait_uploads. */
+int mot_frames_host_xyz(mot_ctx* ctx, const float* h_xyz, long frame_stride, const int* n_points, int batch,
+                        int run_tracker, const double* timestamps, const double* ego_v, const double* ego_yaw);
 int mot_wait_uploads(mot_ctx* ctx);
 int mot_host_alloc(size_t bytes, void** out);
 int mot_host_free(void* p);

@@ -141,7 +141,9 @@ class NoiseFloor:
         instance: which private copy of the reference builds to use (one per stream followed at the same time)."""
         self.reps, self.retired = {}, {}
         if primary_is_ref and "restatement" in kinds:
-            self.reps["restatement"] = oracle.Tracker(p)
+            # the C restatement ITSELF: when the checker was handed oracle_lib.RefFirst (the GPU suite), its Tracker() is another copy of the reference
+            # build — identical to the primary, a replica that measures nothing (round 6: the measured conditioning found out)
+            self.reps["restatement"] = getattr(oracle, "_b", oracle).Tracker(p)
         for k in [k for k in kinds if k not in ("restatement",) + (("ref",) if primary_is_ref else ())]:
             if p.seed_box_index == 1 and oracle.ref_variant(k, instance) is not None:   # (builds of package OT: preset 0 only)
                 t = oracle.RefTracker(oracle.ref_variant(k, instance)); t.reset(); self.reps[k] = t

@@ -67,6 +67,47 @@ def test_frames_host_equals_frames_dev(mot, emu, synth, oracle):
             assert cnt[s] == len(live) and np.array_equal(rec[s, : cnt[s], 0], live)
 
 
+def test_frames_host_xyz_equals_frames_host(mot, emu, synth, oracle):
+    """mot_frames_host_xyz (ABI v6): packed {x, y, z} records from host memory, expanded on the device with w = 1.0f — every result equals the float4
+    entry point's on the same x, y, z (dense and ragged strides, more calls than staging buffers), and the oracle's"""
+    lib, L = emu
+    B, N, stride = 3, 5000, 5120
+    p = oracle.params(0)
+    with mot.Context(lib_path=lib, max_points=stride, max_batch=B, max_tracks_total=128) as a, \
+         mot.Context(lib_path=lib, max_points=stride, max_batch=B, max_tracks_total=128) as b:
+        for f in range(5):
+            n = [N, N - 777, 64 + f]
+            host = np.zeros((B, stride, 4), np.float32)
+            for s in range(B):
+                host[s, : n[s]] = synth.make_cloud(N, 50 + s, f)[: n[s]]
+            host[..., 3] = 1.0
+            kw = dict(run_tracker=True, timestamps=[1.0e9 + f * 1e5] * B, ego_v=[1.0] * B, ego_yaw=[0.01 * f] * B)
+            a.frames_host(host.ctypes.data, stride * 4, n, **kw)
+            if f % 2 == 0:
+                xyz = np.ascontiguousarray(host[..., :3])
+                b.frames_host_xyz(xyz.ctypes.data, stride * 3, n, **kw)
+            else:
+                xyz = np.zeros((B, stride + 10, 3), np.float32); xyz[:, :stride] = host[..., :3]
+                b.frames_host_xyz(xyz.ctypes.data, (stride + 10) * 3, n, **kw)
+            a.wait_uploads(); b.wait_uploads()
+            for s in range(B):
+                ga, gb = a.get_ground(s, n_hint=n[s]), b.get_ground(s, n_hint=n[s])
+                assert np.array_equal(ga["elevated"].view(np.uint32), gb["elevated"].view(np.uint32)) and np.array_equal(ga["ground"].view(np.uint32), gb["ground"].view(np.uint32))
+                assert np.array_equal(ga["mask"], gb["mask"]) and (gb["elevated"][:, 3] == 1.0).all()
+                assert np.array_equal(a.get_boxes(s)["boxes"], b.get_boxes(s)["boxes"]) and np.array_equal(a.get_clusters(s)["grid"], b.get_clusters(s)["grid"])
+                ta, tb = a.get_tracks(s), b.get_tracks(s)
+                assert ta["n"] == tb["n"] and np.array_equal(ta["track_manage"], tb["track_manage"]) and np.array_equal(ta["p"], tb["p"])
+            g = oracle.ground_remove(p, host[0, : n[0]])
+            assert np.array_equal(b.get_ground(0, n_hint=n[0])["elevated"], g["elevated"])
+        # argument errors: before anything is queued
+        with pytest.raises(mot.MotError) as e:
+            b.frames_host_xyz(xyz.ctypes.data, 30, [100, 100])   # stride smaller than a frame
+        assert e.value.code == mot.MOT_E_ARG
+        with pytest.raises(mot.MotError) as e:
+            b.frames_host_xyz(xyz.ctypes.data, stride * 3, [stride + 1])
+        assert e.value.code == mot.MOT_E_CAPACITY
+
+
 def test_track_steps_dev_equals_track_step(mot, emu):
     lib, L = emu
     B = 3

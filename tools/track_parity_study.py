@@ -47,6 +47,9 @@ def load_stream(path, stream=None):
         scene, points, unit, preset, F = d[name + "/meta"]
         off = np.concatenate([[0], np.cumsum(d[name + "/n_boxes"])]); bx = d[name + "/boxes_global"]
         return name, float(unit), [bx[off[f]:off[f + 1]] for f in range(int(F))], d[name + "/ego_v"], d[name + "/ego_yaw"]
+    if "scenes" in d:    # tools/dump_track_streams.py (GPU box): what the device's tracker was fed on rendered streams
+        b = int(stream or 0); F = len(d["ego_v"])
+        return f"{os.path.basename(path)}:scene{int(d['scenes'][b])}", float(d["unit"]), [d[f"s{b}_f{f}_boxes_global"] for f in range(F)], d["ego_v"], d["ego_yaw"]
     F = len(d["n_boxes"])
     return os.path.basename(path), 1e5, [d[f"f{f}"] for f in range(F)], d["ego_v"], d["ego_yaw"]
 
