@@ -379,15 +379,25 @@ def tracker_stress(mot, torch, device, streams=128, loads=(8, 32, 64), frames=40
     return out
 
 
-def dense_scene(mot, sdev, torch, device, N, stride, streams=512, contexts=4, steps=2, phase=38, parity=True, lib=None):
-    """BASELINE.json configs[3] says "<= 64 tracks"; the street scene of the headline never shows the tracker more than ~25 at a time. This leg
-    is the SAME pipeline (ground removal -> clustering -> box fit -> tracker, inputs resident in HBM, `contexts` contexts, every stream a
-    154-frame sequence with the drive's ego motion) on the `plaza` scene of tools/synth/synth_dev.py: an open square of standing and strolling
-    people, 50-65 live tracks per stream throughout. Reported next to the headline, with its own parity check of stream 0 against the reference."""
+def workload_leg(mot, sdev, torch, device, N, stride, scene="plaza", order="beam", streams=2048, contexts=4, steps=6, phase=38, parity=True, parity_frames=154, lib=None,
+                 tracker_alone=True, kernels_alone=False):
+    """The headline's pipeline and harness (ground removal -> clustering -> box fit -> tracker, inputs resident in HBM, `contexts` contexts of
+    streams / contexts streams each — the contexts replay the SAME streams / contexts rendered scenes `phase` frames apart, like the headline — every
+    stream a 154-frame sequence with the drive's ego motion) on ANOTHER workload, reported next to the headline with its own parity check of stream 0
+    against the reference:
+      scene "plaza"            BASELINE.json configs[3] says "<= 64 tracks"; the street scene of the headline never shows the tracker more than ~25 at a time.
+                               An open square of standing and strolling people (tools/synth/synth_dev.py), 50-65 live tracks per stream throughout: `dense_scene`
+      order "firing"/"random"  the street scene with its points in azimuth-major order (the velodyne driver's `velodyne_points`, the topic the reference's ground
+                               node subscribes to: OT/src/groundremove/main.cpp:146) or in no order at all: `point_order` (the kernels exploit that a cell's /
+                               a cluster's points are neighbours in memory; correctness never depends on it)
+    Round 6: 4 x 512 streams and >= 6 timed steps for the dense scene (round 5 ran 4 x 128 and two steps: host-bound and volatile)."""
     F = 154
     ego_v, ego_yaw = sdev.load_ego(F)
     Bc = streams // contexts
-    seq, n_seq, _o, _p = sdev.SequenceRenderer(f"cuda:{device}").render([7000 + s for s in range(Bc)], F, N, stride, ego_v, ego_yaw, scene="plaza")
+    base = 7000 if scene == "plaza" else 0
+    t_r = time.perf_counter()
+    seq, n_seq, _o, _p = sdev.SequenceRenderer(f"cuda:{device}").render([base + s for s in range(Bc)], F, N, stride, ego_v, ego_yaw, scene=scene, order=order)
+    render_s = time.perf_counter() - t_r
     n_seq = np.ascontiguousarray(n_seq, np.int32)
     ctxs = [mot.Context(device=device, max_points=stride, max_batch=Bc, max_tracks_total=256) for _ in range(contexts)]
     ptr = [seq[f].data_ptr() for f in range(F)]
@@ -401,8 +411,8 @@ def dense_scene(mot, sdev, torch, device, N, stride, streams=512, contexts=4, st
         ctxs[ci].frames_dev(ptr[f], stride * 4, n_seq[f], run_tracker=True, timestamps=ts_f[f], ego_v=ev_f[f], ego_yaw=ey_f[f])
         pos[ci] += 1
 
-    def run(nf, extra=None):   # one issuing thread per context, as in the headline's loop (the library calls release the GIL): at 128 streams per
-        import threading         # launch sequence ONE thread feeding four contexts in turn is the limit, not the GPU (423 / 384 k against 490 k measured)
+    def run(nf, extra=None):   # one issuing thread per context, as in the headline's loop (the library calls release the GIL)
+        import threading
         errs = []
         before = list(pos)
         def feed(ci):
@@ -417,7 +427,7 @@ def dense_scene(mot, sdev, torch, device, N, stride, streams=512, contexts=4, st
         for t in th:
             t.join()
         if errs:
-            raise RuntimeError(f"dense_scene: context {errs[0][0]} failed while issuing: {errs[0][1]!r}") from errs[0][1]
+            raise RuntimeError(f"workload_leg: context {errs[0][0]} failed while issuing: {errs[0][1]!r}") from errs[0][1]
         assert all(pos[ci] - before[ci] == nf + (extra[ci] if extra else 0) for ci in range(contexts)), (before, pos)
 
     run(F, extra=[(phase * ci) % F for ci in range(contexts)])   # one untimed step + the contexts' phase offsets
@@ -430,34 +440,43 @@ def dense_scene(mot, sdev, torch, device, N, stride, streams=512, contexts=4, st
         c.synchronize()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
-    # the tracker's launches with the GPU to themselves (one context, the whole pipeline in place): HIP event pairs around the step
     c0 = ctxs[0]
-    c0.reset(); c0.profile_kernel(K_IDS["track_step_kernel"], 1)
-    live_hist = []
-    for f in range(60):
-        c0.frames_dev(ptr[f], stride * 4, n_seq[f], run_tracker=True, timestamps=ts_f[f], ego_v=ev_f[f], ego_yaw=ey_f[f])
-        if f in (20, 40, 59):
-            live_hist.append([int((c0.get_tracks(b)["track_manage"] > 0).sum()) for b in range(min(Bc, 16))])
-    trk = c0.profile_read(); c0.profile_kernel(0, 1)
-    nb = [len(c0.get_boxes(b)["boxes"]) for b in range(min(Bc, 16))]
-    ne = [c0.get_ground(b, want_clouds=False)["n_elevated"] for b in range(min(Bc, 16))]
+    out = {"value": round(streams * F * steps / dt, 1), "unit": "frames/s", "steps": steps, "ms_per_step": round(dt / steps * 1e3, 3), "streams": streams, "contexts": contexts,
+           "frames_per_launch": Bc, "frames_per_stream_per_step": F, "points_per_frame": N, "scene": scene, "point_order": order, "render_s": round(render_s, 1)}
+    if kernels_alone:   # every kernel of the sequence with the GPU to itself: one context, 30 frames, HIP event pairs (what moved between the point orders)
+        k_us = {}
+        for name, kid in K_IDS.items():
+            c0.reset(); c0.profile_kernel(kid, 1)
+            for f in range(30):
+                c0.frames_dev(ptr[f], stride * 4, n_seq[f], run_tracker=True, timestamps=ts_f[f], ego_v=ev_f[f], ego_yaw=ey_f[f])
+            r = c0.profile_read(); c0.profile_kernel(0, 1)
+            k_us[name] = round(r["mean_ms"] * 1e3, 1)
+        out["kernel_us_alone"] = dict(k_us, what=f"mean launch duration over 30 frames of one {Bc}-stream context with the GPU to itself (HIP event pairs); track_step_kernel = the tracker's launches together")
+    if tracker_alone:
+        # the tracker's launches with the GPU to themselves (one context, the whole pipeline in place): HIP event pairs around the step
+        c0.reset(); c0.profile_kernel(K_IDS["track_step_kernel"], 1)
+        live_hist = []
+        for f in range(60):
+            c0.frames_dev(ptr[f], stride * 4, n_seq[f], run_tracker=True, timestamps=ts_f[f], ego_v=ev_f[f], ego_yaw=ey_f[f])
+            if f in (20, 40, 59):
+                live_hist.append([int((c0.get_tracks(b)["track_manage"] > 0).sum()) for b in range(min(Bc, 16))])
+        trk = c0.profile_read(); c0.profile_kernel(0, 1)
+        nb = [len(c0.get_boxes(b)["boxes"]) for b in range(min(Bc, 16))]
+        ne = [c0.get_ground(b, want_clouds=False)["n_elevated"] for b in range(min(Bc, 16))]
+        live = np.array(live_hist)
+        out.update({"live_tracks_per_stream": {"mean": round(float(live.mean()), 1), "min": int(live.min()), "max": int(live.max()), "sampled": "16 streams at frames 20, 40, 59"},
+                    "boxes_per_frame_mean": round(float(np.mean(nb)), 1), "elevated_pts_per_frame": int(np.mean(ne)),
+                    "tracker_step_us_alone": {"mean": round(trk["mean_ms"] * 1e3, 1), "min": round(trk["min_ms"] * 1e3, 1), "max": round(trk["max_ms"] * 1e3, 1), "samples": trk["samples"],
+                                              "what": f"the tracker's launches of one {Bc}-stream context with the GPU to itself (the whole pipeline in place), HIP event pairs"}})
     for c in ctxs:
         c.close()
-    live = np.array(live_hist)
-    out = {"value": round(streams * F * steps / dt, 1), "unit": "frames/s", "steps": steps, "ms_per_step": round(dt / steps * 1e3, 3), "streams": streams, "contexts": contexts,
-           "frames_per_stream_per_step": F, "points_per_frame": N, "scene": "plaza",
-           "live_tracks_per_stream": {"mean": round(float(live.mean()), 1), "min": int(live.min()), "max": int(live.max()), "sampled": "16 streams at frames 20, 40, 59"},
-           "boxes_per_frame_mean": round(float(np.mean(nb)), 1), "elevated_pts_per_frame": int(np.mean(ne)),
-           "tracker_step_us_alone": {"mean": round(trk["mean_ms"] * 1e3, 1), "min": round(trk["min_ms"] * 1e3, 1), "max": round(trk["max_ms"] * 1e3, 1), "samples": trk["samples"],
-                                     "what": f"the tracker's launches of one {Bc}-stream context with the GPU to itself (the whole pipeline in place), HIP event pairs"},
-           "what": "the headline's pipeline and harness on the tracker-load scene (an open square of standing and strolling people instead of the street): what BASELINE.json configs[3]'s "
-                   "'<= 64 tracks' asks of the tracker, in the rendered workload itself (tracker_stress drives the tracker alone with synthetic boxes)"}
     if parity:
         try:
-            gpu_res = gpu_sequence_results(mot, device, seq, n_seq, stride, ego_v, ego_yaw, 0)
-            frames_host = seq[:, 0, :N].cpu().numpy()
+            PF = min(F, parity_frames)
+            gpu_res = gpu_sequence_results(mot, device, seq[:PF], n_seq[:PF], stride, ego_v[:PF], ego_yaw[:PF], 0)
+            frames_host = seq[:PF, 0, :N].cpu().numpy()
             del seq
-            _base, par = cpu_baseline(frames_host, ego_v, ego_yaw, N, budget_s=4.0, gpu_results=gpu_res, n_per_frame=n_seq[:, 0], lib=lib, quick=True)
+            _base, par = cpu_baseline(frames_host, ego_v[:PF], ego_yaw[:PF], N, budget_s=4.0, gpu_results=gpu_res, n_per_frame=n_seq[:PF, 0], lib=lib, quick=True)
             keys = ("frames", "masks_boxes_bit_exact", "track_sets_equal", "states_within_1e-4", "states_within_bar", "conditioning", "measured", "states_within_bar_threshold_criterion", "states_explained_by_reference_noise",
                     "states_within_1e-4_or_reference_noise", "above_1e-4_worst_err_over_reference_noise", "track_frames_above_1e-4_not_set_aside", "max_rel_state_err",
                     "track_frames_above_1e-4", "track_frames_above_1e-4_unexplained", "set_aside_track_frames", "state_compares", "live_tracks_max", "tracks_ever", "boxes_total",
@@ -466,6 +485,34 @@ def dense_scene(mot, sdev, torch, device, N, stride, streams=512, contexts=4, st
         except Exception:
             import traceback
             out["parity_check"] = {"error": traceback.format_exc()[-600:]}
+    return out
+
+
+def dense_scene(mot, sdev, torch, device, N, stride, streams=2048, contexts=4, steps=6, phase=38, parity=True, lib=None):
+    out = workload_leg(mot, sdev, torch, device, N, stride, scene="plaza", order="beam", streams=streams, contexts=contexts, steps=steps, phase=phase, parity=parity, lib=lib)
+    out["what"] = ("the headline's pipeline and harness on the tracker-load scene (an open square of standing and strolling people instead of the street): what BASELINE.json configs[3]'s "
+                   "'<= 64 tracks' asks of the tracker, in the rendered workload itself (tracker_stress drives the tracker alone with synthetic boxes); the headline's shape since round 6: "
+                   f"{contexts} contexts x {streams // contexts} streams, {steps} timed steps")
+    return out
+
+
+def point_order(mot, sdev, torch, device, N, stride, headline_value, streams=2048, contexts=4, steps=3, lib=None, parity=True):
+    """the headline's workload (street scene) with the points of every frame in firing (azimuth-major) and in random order: frames/s in the headline's shape,
+    every kernel alone, parity of stream 0's first 40 frames against the reference on the same clouds (box fitting depends on the order: SURVEY.md H9)"""
+    out = {"beam": {"value": headline_value, "what": "the headline itself: beam-major (KITTI .bin files)"}}
+    torch.cuda.empty_cache()
+    for order in ("firing", "random"):
+        try:
+            r = workload_leg(mot, sdev, torch, device, N, stride, scene="street", order=order, streams=streams, contexts=contexts, steps=steps, parity=parity, parity_frames=40, lib=lib,
+                             tracker_alone=False, kernels_alone=True)
+            r["vs_beam_major"] = round(r["value"] / headline_value, 4)
+            out[order] = r
+        except Exception as e:
+            out[order] = {"error": str(e)[:300]}
+        torch.cuda.empty_cache()
+    out["what"] = ("beam = beam-major (a laser's whole revolution, then the next laser: KITTI .bin files, the default workload); firing = azimuth-major (the 64 lasers of one firing together: "
+                   "what the velodyne driver publishes as `velodyne_points`, OT/src/groundremove/main.cpp:146); random = a seeded permutation per frame (no locality: the worst case). "
+                   "Same point sets per frame, same harness as the headline")
     return out
 
 
@@ -772,7 +819,8 @@ def main():
     ap.add_argument("--point-order", choices=("beam", "firing", "random"), default="beam",
                     help="order of a frame's points in memory: beam = beam-major (KITTI .bin files; the default workload), firing = azimuth-major (the 64 lasers of a firing "
                          "together: the velodyne driver's `velodyne_points`, OT/src/groundremove/main.cpp:146), random = a seeded permutation per frame. Same point SETS per frame")
-    ap.add_argument("--no-dense-scene", action="store_true", help="skip the dense_scene leg (plaza scene, 512 streams) of the default run")
+    ap.add_argument("--no-dense-scene", action="store_true", help="skip the dense_scene leg (plaza scene, the headline's shape) of the default run")
+    ap.add_argument("--no-point-order", action="store_true", help="skip the point_order leg (the headline's workload in firing and in random point order) of the default run")
     ap.add_argument("--issue-threads", type=int, default=1, help="1 (default since round 5): a host thread per context issues its launches (the library calls release the GIL): +1.6 % over one "
                     "thread in an interleaved A/B, profiles/r05_contexts_sweep.txt — equal in round 2, when a launch sequence took a third longer; 0: one host thread issues every context's "
                     "launches, frame by frame, in a fixed order — what a run with the per-frame collective (N > 1, --force-gather) always does: the collectives' order on every rank")
@@ -1183,11 +1231,18 @@ def main():
         torch.cuda.empty_cache()
         if not args.no_aux and not args.no_dense_scene and world == 1 and not kitti and args.scene == "street" and N == 120000:
             try:
-                out["dense_scene"] = dense_scene(mot, sdev, torch, local, N, stride, parity=not args.no_cpu_baseline, lib=mot.load_library(variant) if variant else mot.load_library())
+                out["dense_scene"] = dense_scene(mot, sdev, torch, local, N, stride, streams=B, contexts=NC, parity=not args.no_cpu_baseline, lib=mot.load_library(variant) if variant else mot.load_library())
                 out["dense_scene"]["vs_headline"] = round(out["dense_scene"]["value"] / out["value"], 4)
             except Exception as e:
                 out["dense_scene"] = None
                 print(f"dense_scene failed: {e}", file=sys.stderr)
+        if not args.no_aux and not args.no_point_order and world == 1 and not kitti and args.scene == "street" and args.point_order == "beam" and N == 120000:
+            try:
+                out["point_order"] = point_order(mot, sdev, torch, local, N, stride, out["value"], streams=B, contexts=NC, parity=not args.no_cpu_baseline,
+                                                 lib=mot.load_library(variant) if variant else mot.load_library())
+            except Exception as e:
+                out["point_order"] = None
+                print(f"point_order failed: {e}", file=sys.stderr)
         if frames_host is not None:
           try:
             out["cpu_baseline"], out["parity_check"] = cpu_baseline(frames_host, ego_v, ego_yaw, N, gpu_results=gpu_res, n_per_frame=n_seq[:, 0], lib=mot.load_library(variant) if variant else mot.load_library())
