@@ -78,6 +78,7 @@ EXPORTS = (
     "mot_reset_slot", "mot_stream_snapshot_size", "mot_stream_save", "mot_stream_load", "mot_frames_host", "mot_frames_host_xyz", "mot_wait_uploads", "mot_host_alloc", "mot_host_free", "mot_fetch_tracks_async",
     "mot_track_steps_dev", "mot_profile_kernel", "mot_profile_read", "mot_get_params", "mot_set_fused_outputs", "mot_set_tracker_mode", "mot_set_trace_ranges", "mot_reset_tracks_slot", "mot_export_tracks_packed_dev", "mot_set_launch_graphs",
     "mot_cluster_node_frame", "mot_ground_node_frame",
+    "mot_gather_unique_id", "mot_gather_create", "mot_gather_contribute", "mot_gather_result", "mot_gather_synchronize", "mot_gather_destroy", "mot_gather_last_error",
 )
 ABI_VERSION = 6
 OUT_GROUND, OUT_MASK, OUT_LABELS = 1, 2, 4
@@ -98,6 +99,7 @@ def load_library(path: str | None = None) -> C.CDLL:
     lib.mot_last_error.argtypes = [C.c_void_p]
     lib.mot_stream.restype = C.c_void_p
     lib.mot_destroy.restype = None
+    lib.mot_gather_last_error.restype = C.c_char_p
     lib.mot_host_alloc.argtypes = [C.c_size_t, C.POINTER(C.c_void_p)]
     lib.mot_host_free.argtypes = [C.c_void_p]
     if lib.mot_abi_version() != ABI_VERSION:
@@ -538,3 +540,53 @@ def getOriginPoints(timestamp, v_gps, yaw_gps):
 
 def immUkfJpdaf(bBoxes, timestamp):
     return default_context().track_step(bBoxes, timestamp)
+
+
+class NativeGather:
+    """include/mot.h mot_gather_*: the per-tick all-gather of the live-track blocks of a rank's contexts, issued from C (RCCL over xGMI on GPUs; a device copy
+    with one rank and no communicator). contribute(ci) is what context ci's issuing thread calls after its frame tick."""
+
+    def __init__(self, ctxs, batch: int, capacity_records: int, world: int = 1, rank: int = 0, unique_id: bytes | None = None):
+        self.ctxs, self.batch, self.cap, self.world, self.rank = list(ctxs), batch, capacity_records, world, rank
+        self.lib = self.ctxs[0].lib
+        arr = (C.c_void_p * len(self.ctxs))(*[cx._h for cx in self.ctxs])
+        self._g = C.c_void_p()
+        idb = (C.c_char * 128).from_buffer_copy(unique_id) if unique_id is not None else None
+        rc = self.lib.mot_gather_create(arr, len(self.ctxs), batch, capacity_records, world, rank, idb, C.byref(self._g))
+        if rc != MOT_OK:
+            raise MotError(rc, "mot_gather_create failed" + (" (no RCCL in this process)" if rc == MOT_E_STATE else ""))
+        self.block = ((batch * 4 + 15) & ~15) + capacity_records * C.sizeof(MotTrack)
+
+    @staticmethod
+    def unique_id(lib) -> bytes:
+        buf = (C.c_char * 128)()
+        rc = lib.mot_gather_unique_id(buf)
+        if rc != MOT_OK:
+            raise MotError(rc, "mot_gather_unique_id failed (no RCCL in this process)")
+        return bytes(buf.raw)
+
+    def _ck(self, rc):
+        if rc != MOT_OK:
+            raise MotError(rc, (self.lib.mot_gather_last_error(self._g) or b"").decode())
+
+    def contribute(self, ci: int):
+        self._ck(self.lib.mot_gather_contribute(self._g, ci))
+
+    def result(self):
+        """(device pointer of [world][n_ctx] packed blocks, block bytes, tick, hipEvent_t handle) of the last completed tick"""
+        d, nb, tick, ev = C.c_void_p(), C.c_long(), C.c_long(), C.c_void_p()
+        self._ck(self.lib.mot_gather_result(self._g, C.byref(d), C.byref(nb), C.byref(tick), C.byref(ev)))
+        return d.value, nb.value, tick.value, ev.value
+
+    def synchronize(self):
+        self._ck(self.lib.mot_gather_synchronize(self._g))
+
+    def close(self):
+        if self._g:
+            self.lib.mot_gather_destroy(self._g); self._g = C.c_void_p()
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()

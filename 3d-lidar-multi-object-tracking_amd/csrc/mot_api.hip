@@ -12,6 +12,7 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <condition_variable>
 #include <mutex>
 #include <random>
 #include <string>
@@ -141,6 +142,7 @@ struct mot_ctx {
   std::vector<char> box_valid;        // per slot: the box stage's products (boxes, cluster order, groups) belong to the cloud now resident in the slot
   bool ground_resident = false;        // d_ground / d_mask hold the last batch's ground cloud and mask
   bool ground_all = false;             // ... of every slot of the last fused batch; false: of slot 0 only (a stage-wise mot_ground_remove* since)
+  int dbg_skip = 0;                    // mot_debug_skip_kernels: MEASUREMENT ONLY (upper bounds of launch-fusion experiments); the results of a frame are then stale
   bool ground_foreign0 = false;        // a stage-wise cluster / box call has replaced slot 0's elevated cloud since the ground stage ran: d_ground / d_mask of slot 0 belong to ANOTHER cloud
   bool last_fused = false;             // the last ground launch was a fused one (input, cells and thresholds of the batch still resident)
   int* h_counts = nullptr;  // pinned [batch][4]
@@ -714,24 +716,24 @@ static void issue_frame_kernels(mot_ctx* c, int batch, int max_n, int run_tracke
   {
     RangeScope rs(c, "mot:ground");
     { ProfScope ps(c, kK1); mot_launch_ground_kernel(0, c->dp, g, batch, max_n, c->stream); }
-    { ProfScope ps(c, kK2); mot_launch_ground_kernel(1, c->dp, g, batch, max_n, c->stream); }
+    if (!(c->dbg_skip & 1)) { ProfScope ps(c, kK2); mot_launch_ground_kernel(1, c->dp, g, batch, max_n, c->stream); }
     { ProfScope ps(c, kK3); mot_launch_ground_kernel(2, c->dp, g, batch, max_n, c->stream); }
   }
   ClusterBuffers cb = cluster_buffers(c);
   cb.occ_list = c->d_occ_list; cb.occ_count = c->d_occ_count;   // the occupancy comes as the compaction kernel's per-chunk lists
   cb.ecell = g.ecell;                                            // ... and every elevated point's cell with it
   if (!(c->fused_outputs & MOT_OUT_LABELS)) cb.label = nullptr;  // per-point labels on demand (mot_get_clusters)
-  { RangeScope rs(c, "mot:cluster"); ProfScope ps(c, kC2); mot_launch_cluster(c->dp, cb, batch, max_n, c->stream, true); }
+  if (!(c->dbg_skip & 2)) { RangeScope rs(c, "mot:cluster"); ProfScope ps(c, kC2); mot_launch_cluster(c->dp, cb, batch, max_n, c->stream, true); }
   RangeScope rb(c, "mot:box");
   { ProfScope ps(c, kB1); mot_launch_box_kernel(0, c->dp, cb, batch, max_n, c->stream); }
-  { ProfScope ps(c, kB1b); mot_launch_box_kernel(4, c->dp, cb, batch, max_n, c->stream); }
+  if (!(c->dbg_skip & 4)) { ProfScope ps(c, kB1b); mot_launch_box_kernel(4, c->dp, cb, batch, max_n, c->stream); }
   { ProfScope ps(c, kB2); mot_launch_box_kernel(1, c->dp, cb, batch, max_n, c->stream); }
   { ProfScope ps(c, kB2b); mot_launch_box_kernel(3, c->dp, cb, batch, max_n, c->stream); }
   if (run_tracker) {   // the tracker's per-frame prologue rides at the tail of the box stage's last kernel (same geometry)
     const TrackBuffers tb = track_buffers(c, true);
-    { ProfScope ps(c, kB3); mot_launch_box_finalize_prep(c->dp, cb, tb, batch, c->stream); }
+    if (!(c->dbg_skip & 8)) { ProfScope ps(c, kB3); mot_launch_box_finalize_prep(c->dp, cb, tb, batch, c->stream); }
     if (rb.on) { (void)g_roctx.pop(); rb.on = false; }
-    { RangeScope rt(c, "mot:tracker"); ProfScope ps(c, kT1); mot_launch_track(tb, batch, c->stream, true); }
+    if (!(c->dbg_skip & 32)) { RangeScope rt(c, "mot:tracker"); ProfScope ps(c, kT1); mot_launch_track(tb, batch, c->stream, true); }
   } else {
     ProfScope ps(c, kB3); mot_launch_box_kernel(2, c->dp, cb, batch, max_n, c->stream);
   }
@@ -2016,6 +2018,189 @@ extern "C" int mot_export_tracks_packed_dev(mot_ctx* c, int batch, void* d_block
   return MOT_OK;
 }
 
+// ---------------------------------------------------------------------------------------- native per-tick gather of the live tracks (RCCL)
+// SURVEY.md 8(e) / BASELINE.json north_star: "frames shard naturally across the 8 x MI355X node with a trivial RCCL/xGMI gather of track outputs",
+// host code in C++. Until round 5 the collective lived in Python (multi.py: torch.distributed.all_gather_into_tensor), which put torch into the
+// data loop and tied every context of a rank to ONE issuing thread (the collectives' order). mot_gather does the same thing from C:
+//   * one object per rank over its contexts; two send / receive buffer pairs alternate (tick parity);
+//   * mot_gather_contribute(g, ci) is called by context ci's OWN issuing thread after its frame tick: it exports that context's packed live-track
+//     block (mot_export_tracks_packed_dev's kernel, on the context's stream) into its part of the send buffer and records an event; the thread that
+//     completes a tick — the last of the contexts to contribute — enqueues ONE ncclAllGather for all contexts on the gather's side stream behind
+//     those events. Ticks are collective-ordered by construction (tick t of every rank is its t-th collective); a context may run at most one
+//     tick ahead of the slowest (double buffering) — a faster thread waits on a condition variable, never the GPU;
+//   * nothing blocks the host on the GPU: stream / event waits only. RCCL is resolved at run time (dlopen: the library already in the process —
+//     torch's — or librccl.so), so libmot_hip.so has no link-time dependency on it; with one rank and no communicator the "collective" is a copy.
+// multi.py's TrackGatherAll stays as the test shim (gloo on CPU) and the reference the 1-rank GPU test compares this with.
+struct mot_gather {
+  std::vector<mot_ctx*> ctxs;
+  int nc = 0, batch = 0, cap = 0, world = 1, rank = 0, device = 0;
+  long block = 0;                       // bytes of one context's packed block
+  char* d_send[2] = {nullptr, nullptr};
+  char* d_recv[2] = {nullptr, nullptr};
+  hipStream_t side = nullptr;
+  std::vector<hipEvent_t> exported;     // [2][nc]
+  hipEvent_t done[2] = {nullptr, nullptr};
+  bool done_valid[2] = {false, false};
+  void* comm = nullptr;                 // ncclComm_t
+  std::mutex mu;
+  std::condition_variable cv;
+  std::vector<long> ticks;              // contributions per context so far
+  long completed = 0;                   // ticks whose collective has been enqueued
+  int pending[2] = {0, 0};              // contributions of the open tick with that parity
+  std::string err;
+};
+namespace {
+struct Rccl {
+  struct Id { char b[128]; };   // ncclUniqueId (passed by value)
+  int (*get_unique_id)(void*) = nullptr;
+  int (*comm_init_rank)(void**, int, Id, int) = nullptr;
+  int (*all_gather)(const void*, void*, size_t, int, void*, hipStream_t) = nullptr;
+  int (*comm_destroy)(void*) = nullptr;
+  const char* (*error_string)(int) = nullptr;
+  std::once_flag once;
+  bool ok = false;
+  void load() { std::call_once(once, [this] { find(); }); }
+  void find() {
+#ifndef MOT_HIPEMU
+    void* h = nullptr;
+    for (const char* name : {"librccl.so", "librccl.so.1"}) if ((h = dlopen(name, RTLD_LAZY | RTLD_NOLOAD | RTLD_GLOBAL))) break;   // the one the process already has (torch's)
+    if (!h) for (const char* name : {"librccl.so", "librccl.so.1", "/opt/rocm/lib/librccl.so"}) if ((h = dlopen(name, RTLD_LAZY | RTLD_GLOBAL))) break;
+    if (!h) return;
+    get_unique_id = reinterpret_cast<decltype(get_unique_id)>(dlsym(h, "ncclGetUniqueId"));
+    comm_init_rank = reinterpret_cast<decltype(comm_init_rank)>(dlsym(h, "ncclCommInitRank"));
+    all_gather = reinterpret_cast<decltype(all_gather)>(dlsym(h, "ncclAllGather"));
+    comm_destroy = reinterpret_cast<decltype(comm_destroy)>(dlsym(h, "ncclCommDestroy"));
+    error_string = reinterpret_cast<decltype(error_string)>(dlsym(h, "ncclGetErrorString"));
+    ok = get_unique_id && comm_init_rank && all_gather && comm_destroy;
+#endif
+  }
+};
+Rccl g_rccl;
+}  // namespace
+
+extern "C" int mot_gather_unique_id(void* id128) {
+  if (!id128) return MOT_E_ARG;
+  g_rccl.load();
+  if (!g_rccl.ok) return MOT_E_STATE;
+  return g_rccl.get_unique_id(id128) == 0 ? MOT_OK : MOT_E_HIP;
+}
+
+extern "C" int mot_gather_destroy(mot_gather* g) {
+  if (!g) return MOT_OK;
+  DevGuard guard_(g->device);
+  if (g->side) (void)hipStreamSynchronize(g->side);
+  if (g->comm && g_rccl.ok) (void)g_rccl.comm_destroy(g->comm);
+  for (int i = 0; i < 2; i++) {
+    if (g->d_send[i]) (void)hipFree(g->d_send[i]);
+    if (g->d_recv[i]) (void)hipFree(g->d_recv[i]);
+    if (g->done[i]) (void)hipEventDestroy(g->done[i]);
+  }
+  for (hipEvent_t e : g->exported) if (e) (void)hipEventDestroy(e);
+  if (g->side) (void)hipStreamDestroy(g->side);
+  delete g;
+  return MOT_OK;
+}
+
+#define MOT_GATHER_HIP(g, call)                                                    \
+  do {                                                                             \
+    hipError_t e_ = (call);                                                        \
+    if (e_ != hipSuccess) { (g)->err = std::string(#call) + ": " + hipGetErrorString(e_); return MOT_E_HIP; } \
+  } while (0)
+
+extern "C" const char* mot_gather_last_error(const mot_gather* g) { return g ? g->err.c_str() : "null gather"; }
+
+// ctxs[n_ctx]: this rank's contexts (same device, same max_batch >= batch); capacity_records: records a context's packed block holds (all its streams
+// together; the header carries the true counts, a receiver sees an overflow). unique_id: 128 bytes from mot_gather_unique_id on rank 0, handed to every
+// rank by the launcher (MPI, a file, torch.distributed's store ...); NULL with world == 1: no communicator, the tick's "collective" is a device copy.
+extern "C" int mot_gather_create(mot_ctx* const* ctxs, int n_ctx, int batch, int capacity_records, int world, int rank, const void* unique_id, mot_gather** out) {
+  if (!ctxs || n_ctx < 1 || !out || batch < 1 || capacity_records < 1 || world < 1 || rank < 0 || rank >= world || (world > 1 && !unique_id)) return MOT_E_ARG;
+  *out = nullptr;
+  for (int i = 0; i < n_ctx; i++) if (!ctxs[i] || ctxs[i]->device != ctxs[0]->device || batch > ctxs[i]->batch) return MOT_E_ARG;
+  mot_gather* g = new mot_gather;
+  g->ctxs.assign(ctxs, ctxs + n_ctx); g->nc = n_ctx; g->batch = batch; g->cap = capacity_records; g->world = world; g->rank = rank; g->device = ctxs[0]->device;
+  g->block = (((long)batch * 4 + 15) & ~15l) + (long)capacity_records * (long)sizeof(mot_track);
+  g->ticks.assign(n_ctx, 0);
+  g->exported.assign(2 * (size_t)n_ctx, nullptr);
+  DevGuard guard_(g->device);
+  auto bail = [&](int code) { mot_gather_destroy(g); return code; };
+  if (hipStreamCreateWithFlags(&g->side, hipStreamNonBlocking) != hipSuccess) return bail(MOT_E_HIP);
+  for (int i = 0; i < 2; i++) {
+    if (hipMalloc(&g->d_send[i], (size_t)n_ctx * g->block) != hipSuccess || hipMalloc(&g->d_recv[i], (size_t)world * n_ctx * g->block) != hipSuccess) return bail(MOT_E_HIP);
+    if (hipMemset(g->d_send[i], 0, (size_t)n_ctx * g->block) != hipSuccess || hipMemset(g->d_recv[i], 0, (size_t)world * n_ctx * g->block) != hipSuccess) return bail(MOT_E_HIP);
+    if (hipEventCreateWithFlags(&g->done[i], hipEventDisableTiming) != hipSuccess) return bail(MOT_E_HIP);
+    for (int ci = 0; ci < n_ctx; ci++) if (hipEventCreateWithFlags(&g->exported[(size_t)i * n_ctx + ci], hipEventDisableTiming) != hipSuccess) return bail(MOT_E_HIP);
+  }
+  if (unique_id) {
+    g_rccl.load();
+    if (!g_rccl.ok) return bail(MOT_E_STATE);   // no RCCL in this process / on this box
+    Rccl::Id id; memcpy(id.b, unique_id, sizeof id.b);
+    if (g_rccl.comm_init_rank(&g->comm, world, id, rank) != 0) return bail(MOT_E_HIP);
+  }
+  *out = g;
+  return MOT_OK;
+}
+
+// context ci's contribution to its next tick; thread-safe (one calling thread per context, or one for all). Returns once everything is queued.
+extern "C" int mot_gather_contribute(mot_gather* g, int ci) {
+  if (!g || ci < 0 || ci >= g->nc) return MOT_E_ARG;
+  DevGuard guard_(g->device);
+  mot_ctx* c = g->ctxs[ci];
+  long t;
+  {
+    std::unique_lock<std::mutex> lk(g->mu);
+    t = g->ticks[ci];
+    g->cv.wait(lk, [&] { return t < g->completed + 2; });   // at most one tick ahead of the slowest context: tick t's buffers are tick t-2's
+  }
+  const int i = (int)(t & 1);
+  // the collective of tick t-2 has read this send buffer (and the consumer of its receive buffer had until now)
+  if (g->done_valid[i]) MOT_GATHER_HIP(g, hipStreamWaitEvent(c->stream, g->done[i], 0));
+  const long head = ((long)g->batch * 4 + 15) & ~15l;
+  char* blk = g->d_send[i] + (size_t)ci * g->block;
+  mot_launch_export_tracks_packed(track_buffers(c, false), g->batch, reinterpret_cast<int*>(blk), reinterpret_cast<mot_track*>(blk + head), g->cap, c->stream);
+  MOT_GATHER_HIP(g, hipGetLastError());
+  MOT_GATHER_HIP(g, hipEventRecord(g->exported[(size_t)i * g->nc + ci], c->stream));
+  std::unique_lock<std::mutex> lk(g->mu);
+  g->ticks[ci] = t + 1;
+  if (++g->pending[i] < g->nc) return MOT_OK;
+  // this call completes tick t: ONE collective for every context of the rank, on the side stream, behind the exports
+  g->pending[i] = 0;
+  for (int k = 0; k < g->nc; k++) MOT_GATHER_HIP(g, hipStreamWaitEvent(g->side, g->exported[(size_t)i * g->nc + k], 0));
+  const size_t bytes = (size_t)g->nc * g->block;
+  if (g->comm) {
+    const int rc = g_rccl.all_gather(g->d_send[i], g->d_recv[i], bytes, /* ncclUint8 */ 1, g->comm, g->side);
+    if (rc != 0) { g->err = std::string("ncclAllGather: ") + (g_rccl.error_string ? g_rccl.error_string(rc) : "error"); return MOT_E_HIP; }
+  } else {
+    MOT_GATHER_HIP(g, hipMemcpyAsync(g->d_recv[i] + (size_t)g->rank * bytes, g->d_send[i], bytes, hipMemcpyDeviceToDevice, g->side));
+  }
+  MOT_GATHER_HIP(g, hipEventRecord(g->done[i], g->side));
+  g->done_valid[i] = true;
+  g->completed = t + 1;
+  lk.unlock();
+  g->cv.notify_all();
+  return MOT_OK;
+}
+
+// the receive buffer of the last COMPLETED tick: [world][n_ctx] packed blocks (mot_export_tracks_packed_dev's layout), valid on the device once the
+// side stream has run (mot_gather_synchronize, or a stream wait on the event behind *done_event) and REWRITTEN by the tick after next.
+extern "C" int mot_gather_result(mot_gather* g, const void** d_blocks, long* block_bytes, long* tick, void** done_event) {
+  if (!g) return MOT_E_ARG;
+  std::unique_lock<std::mutex> lk(g->mu);
+  if (g->completed < 1) return MOT_E_STATE;
+  const int i = (int)((g->completed - 1) & 1);
+  if (d_blocks) *d_blocks = g->d_recv[i];
+  if (block_bytes) *block_bytes = g->block;
+  if (tick) *tick = g->completed;
+  if (done_event) *done_event = (void*)g->done[i];
+  return MOT_OK;
+}
+
+extern "C" int mot_gather_synchronize(mot_gather* g) {
+  if (!g) return MOT_E_ARG;
+  DevGuard guard_(g->device);
+  MOT_GATHER_HIP(g, hipStreamSynchronize(g->side));
+  return MOT_OK;
+}
+
 extern "C" int mot_track_get_state(mot_ctx* c, int slot, int id, mot_track_state* o) {
   if (!c) return MOT_E_ARG;
   MOT_GUARD(c);
@@ -2064,6 +2249,14 @@ extern "C" int mot_debug_copy(mot_ctx* c, int which, int slot, void* dst, size_t
 }
 
 // test hook (mot_debug_api.h): the context's device parameters, for the fast-path sweeps of tests/devcheck (a library of their own)
+// MEASUREMENT ONLY (tools/, bench.py MOT_BENCH_SKIP): leaves launches of the fused sequence out — 1 polar_filter, 2 ccl, 4 cluster_index, 8 box_finalize_prep,
+// 32 the tracker — so that the cost of a launch boundary can be bounded before a fusion is built. The frame's results are stale / wrong while a bit is set.
+extern "C" int mot_debug_skip_kernels(mot_ctx* c, int mask) {
+  if (!c) return MOT_E_ARG;
+  c->dbg_skip = mask;
+  return MOT_OK;
+}
+
 extern "C" int mot_debug_dev_params(mot_ctx* c, void* dst, size_t bytes) {
   if (!c || !dst || bytes < sizeof(MotDevParams)) return MOT_E_ARG;
   memcpy(dst, &c->dp, sizeof(MotDevParams));

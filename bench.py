@@ -1024,6 +1024,10 @@ def main():
     phase = [(args.phase * ci) % F for ci in range(NC)]
     run_frames(args.warmup * F, extra=phase)   # (with --warmup 0 only the phase offsets are issued)
     sync_all()
+    skip = int(os.environ.get("MOT_BENCH_SKIP", "0"))   # EXPERIMENTS ONLY: launches of the sequence left out after the warm-up (mot_debug_skip_kernels): the bound of a fusion's gain
+    if skip:
+        for cx in ctxs:
+            assert cx.lib.mot_debug_skip_kernels(cx._h, skip) == 0
     # the host's own cost of one launch sequence: the first call after a synchronise finds empty queues, so nothing in it waits for
     # the GPU (inside the timed region the calls also absorb the back-pressure of full queues: host_issue_ms_per_step)
     t_u = time.perf_counter()
@@ -1134,7 +1138,7 @@ def main():
             "value": round(frames / dt, 1), "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(dt / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32/f64 (fp32 grid indices with fp64 intermediates, int32 grids/labels, fp64 tracker — the reference's types)",
-            "data": (("kitti" if kitti else "synthetic") + ("; DRY RUN: every rank on ONE device, gloo collectives — not a measurement" if args.shared_gpu_dryrun else "" if not variant else f"; EXPERIMENT BUILD {variant} — not the product library")), "inputs": "hbm-resident (rendered into HBM before the timed region; see host_boundary_pipelined for the PCIe-inclusive rate)",
+            "data": (("kitti" if kitti else "synthetic") + ("; DRY RUN: every rank on ONE device, gloo collectives — not a measurement" if args.shared_gpu_dryrun else "" if not variant else f"; EXPERIMENT BUILD {variant} — not the product library") + (f"; EXPERIMENT: launches skipped (mask {skip}) — not a measurement of the product" if skip else "")), "inputs": "hbm-resident (rendered into HBM before the timed region; see host_boundary_pipelined for the PCIe-inclusive rate)",
             "timed_region_s": round(dt, 3), "host_issue_ms_per_step": round(host_issue[0] / args.steps * 1e3, 3),
             "host_cpu_ms_per_step": round(host_cpu[0] / args.steps * 1e3, 3) if not (args.issue_threads and NC > 1) else None,
             "host_unblocked_us_per_launch_sequence": round(host_unblocked_us, 1),

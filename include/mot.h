@@ -265,6 +265,31 @@ int mot_ego_update(mot_ctx* ctx, int slot, double timestamp, double v_gps, doubl
 #define MOT_MAX_BOXES_PER_FRAME 1024
 int mot_track_step(mot_ctx* ctx, int slot, const float* boxes_global, int m, double timestamp,
                    mot_track* tracks, int max_tracks, int* n_tracks);
+/* ---- the per-tick gather of the live tracks across GPUs, native (ABI v6) ------------------------------------------------------------
+ * BASELINE.json's partitioning: sensor streams shard across the GPUs of a node, one process per GPU; the only exchange is ONE all-gather
+ * per frame tick of every rank's packed live-track blocks (mot_export_tracks_packed_dev's layout, one block per context) — RCCL over
+ * xGMI, enqueued from C on a side stream behind the contexts' export kernels: no host synchronisation, no Python / torch in the loop.
+ * RCCL is looked up at run time (the library already in the process, else librccl.so): MOT_E_STATE when there is none.
+ *   mot_gather_unique_id(id128)            rank 0: 128 bytes (ncclGetUniqueId) the launcher hands to every rank
+ *   mot_gather_create(ctxs, n_ctx, batch, capacity_records, world, rank, id128, &g)
+ *                                          this rank's contexts (one device); capacity_records = records ONE context's block holds for all its
+ *                                          `batch` streams together; id128 NULL with world 1: no communicator, the tick's collective is a copy
+ *   mot_gather_contribute(g, ci)           after context ci's frame tick, from ITS issuing thread (thread-safe: a thread per context, or one for
+ *                                          all): exports the block on the context's stream; the call that completes a tick enqueues the collective.
+ *                                          Every rank contributes every context once per tick; a context runs at most one tick ahead of the slowest
+ *   mot_gather_result(g, &d_blocks, &block_bytes, &tick, &done_event)
+ *                                          the last completed tick's receive buffer on the device, [world][n_ctx] blocks of block_bytes; complete
+ *                                          when done_event (a hipEvent_t) has fired / after mot_gather_synchronize; rewritten by the tick after next
+ *   mot_gather_synchronize / mot_gather_destroy / mot_gather_last_error */
+typedef struct mot_gather mot_gather;
+int mot_gather_unique_id(void* id128);
+int mot_gather_create(mot_ctx* const* ctxs, int n_ctx, int batch, int capacity_records, int world, int rank, const void* id128, mot_gather** out);
+int mot_gather_contribute(mot_gather* g, int ctx_index);
+int mot_gather_result(mot_gather* g, const void** d_blocks, long* block_bytes, long* tick, void** done_event);
+int mot_gather_synchronize(mot_gather* g);
+int mot_gather_destroy(mot_gather* g);
+const char* mot_gather_last_error(const mot_gather* g);
+
 /* filter state of track `id` (reference index) on `slot` (parity/debug); MOT_E_STATE once the track has been dead for more than a step */
 int mot_track_get_state(mot_ctx* ctx, int slot, int id, mot_track_state* out);
 
