@@ -827,6 +827,10 @@ def main():
     ap.add_argument("--phase", type=int, default=38, help="frames by which context c runs ahead of context c-1 within the (shared) sequences: at any instant the contexts' launches "
                     "read DISJOINT frames, so no context finds another's input in the 256 MiB Infinity Cache (0 = lock-step: every context on the same frame, round 2's layout)")
     ap.add_argument("--force-gather", action="store_true", help="run the per-frame RCCL all-gather of the track blocks even with one rank (exercises the N > 1 path on one GPU)")
+    ap.add_argument("--gather", choices=("native", "torch"), default="native", help="who issues the per-tick all-gather of the live-track blocks (N > 1, --force-gather): native = the library "
+                    "(include/mot.h mot_gather_*: ncclAllGather from C on its side stream, every context contributes from its OWN issuing thread — no torch in the data loop); torch = "
+                    "multi.TrackGatherAll (torch.distributed.all_gather_into_tensor, one issuing thread for all contexts: round 5's path, kept as the test shim and as the fall-back "
+                    "when no RCCL can be resolved)")
     ap.add_argument("--shared-gpu-dryrun", action="store_true", help="every rank on device 0, collectives over gloo: drives the N > 1 code path of this script (spawn, stream "
                     "sharding, packed gather, max over ranks, the JSON line) on a 1-GPU box. Not a measurement; the line says so")
     ap.add_argument("--outputs", choices=["headline", "all"], default="headline", help="all: the HEADLINE itself runs with every by-product of the reference written "
@@ -943,7 +947,21 @@ def main():
     if gather_on:   # RCCL builds the communicator at the first collective (~1 s): here, not inside the timed region, whatever --warmup is
         dist.all_reduce(torch.zeros(1, device="cuda"))
         torch.cuda.synchronize()
-    gather = multi.TrackGatherAll(ctxs, Bc, Bc * GATHER_RECORDS_PER_STREAM, world, "cuda") if gather_on else None
+    gather, native = None, None
+    gather_kind = None
+    if gather_on and args.gather == "native" and not args.shared_gpu_dryrun:
+        try:   # a communicator of the library's own: rank 0's ncclGetUniqueId travels over the launcher's process group once, before the timed region
+            uid = [mot.NativeGather.unique_id(ctx.lib) if rank == 0 else None]
+            if world > 1:
+                dist.broadcast_object_list(uid, src=0)
+            native = mot.NativeGather(ctxs, Bc, Bc * GATHER_RECORDS_PER_STREAM, world, rank, uid[0])
+            gather_kind = "native: mot_gather_* (ncclAllGather issued from C on the library's side stream; every context contributes from its own issuing thread)"
+        except Exception as e:
+            print(f"bench.py: native gather not available ({e}); using the torch shim", file=sys.stderr)
+            native = None
+    if gather_on and native is None:
+        gather = multi.TrackGatherAll(ctxs, Bc, Bc * GATHER_RECORDS_PER_STREAM, world, "cuda")
+        gather_kind = "torch shim: multi.TrackGatherAll (torch.distributed.all_gather_into_tensor; one issuing thread for all contexts)"
     torch.cuda.synchronize()
     frame_ptr = [seq_dev[f].data_ptr() for f in range(F)]
     ts_f = [np.full(Bc, 1.0e9 + f * 1.0e5, np.float64) for f in range(F)]   # microsecond stamps => dt = 0.1 s
@@ -959,24 +977,30 @@ def main():
     # processes exactly steps x F frames, in order, restarting its trackers (mot_reset) whenever it wraps to frame 0.
     pos = [0] * NC   # frames issued so far per context
 
-    def issue_frame(ci):
+    def issue_frame(ci, tick=False):
+        """tick: this frame is one of the run's frame ticks (the phase offsets and the untimed bookkeeping frames are not: every context, on every rank,
+        contributes to exactly the same number of ticks)"""
         cx = ctxs[ci]
         f = pos[ci] % F
         if f == 0:
             cx.reset()   # every stream starts its sequence over (stream-ordered, no host synchronisation)
         cx.frames_dev(frame_ptr[f], stride * 4, n_seq[f], run_tracker=True, timestamps=ts_f[f], ego_v=ev_f[f], ego_yaw=ey_f[f])
+        if native and tick:   # this context's live-track block of the tick; the contribution that completes the tick enqueues the rank's ONE all-gather (RCCL over xGMI)
+            native.contribute(ci)
         pos[ci] += 1
 
     thread_errors = []
 
-    def run_context(ci, n_frames):
+    def run_context(ci, n_frames, n_extra=0):
         """--issue-threads 1: one host thread per context (the C calls release the GIL). An exception ends the thread, is kept and re-raised by
         run_frames after the join: a context that stopped issuing must never count as processed frames."""
         try:
             torch.cuda.set_device(local)
             t_h = time.perf_counter()
-            for _ in range(n_frames):
+            for _ in range(n_extra):
                 issue_frame(ci)
+            for _ in range(n_frames):
+                issue_frame(ci, True)
             busy[ci] = time.perf_counter() - t_h
         except BaseException as e:
             thread_errors.append((ci, e))
@@ -987,7 +1011,7 @@ def main():
         t_c = time.thread_time()
         before = list(pos)
         if args.issue_threads and NC > 1 and not gather:
-            th = [threading.Thread(target=run_context, args=(ci, n_frames + extra[ci])) for ci in range(NC)]
+            th = [threading.Thread(target=run_context, args=(ci, n_frames, extra[ci])) for ci in range(NC)]
             for t in th:
                 t.start()
             for t in th:
@@ -1002,7 +1026,7 @@ def main():
                     issue_frame(ci)
             for _ in range(n_frames):
                 for ci in range(NC):
-                    issue_frame(ci)
+                    issue_frame(ci, True)
                 if gather:   # the frame tick's result blocks of every context cross GPUs in one RCCL all-gather over xGMI
                     gather.step(force_collective=True)
             busy[0] = time.perf_counter() - t_h
@@ -1020,6 +1044,8 @@ def main():
             cx.synchronize()
         if gather:
             gather.synchronize()
+        if native:
+            native.synchronize()
 
     phase = [(args.phase * ci) % F for ci in range(NC)]
     run_frames(args.warmup * F, extra=phase)   # (with --warmup 0 only the phase offsets are issued)
@@ -1155,7 +1181,7 @@ def main():
                        "elevated_pts_per_frame": ne_tot // BL, "clusters_last_frame_stream0": cl0["num_cluster"], "boxes_last_frame_stream0": len(bx0["boxes"]),
                        "tracks_ever_stream0": int(tr0["n"]), "live_tracks_per_stream": {"mean": round(float(np.mean(live)), 1), "max": int(np.max(live)), "streams_sampled": len(live)},
                        "render_s": round(render_s, 1), "scene": args.scene, "scene_density": args.density, "point_order": "as recorded" if kitti else args.point_order, "kitti": kitti,
-                       "parallelism": f"stream-sharded x{world}" + (", all_gather of live-track records per frame (RCCL)" if world > 1 else "")},
+                       "parallelism": f"stream-sharded x{world}" + (", all_gather of live-track records per frame (RCCL)" if world > 1 else ""), "gather": gather_kind},
             "roofline": {"bound": "hbm", "kernel": dom_kernel, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_src,
                          "frac_of_achievable": round(achieved / HBM_ACHIEVABLE_GBS, 4), "achievable_peak": HBM_ACHIEVABLE_GBS,
@@ -1200,6 +1226,8 @@ def main():
             except Exception as e:
                 print(f"isolated kernel timing failed: {e}", file=sys.stderr)
         frames_host = seq_dev[:, 0, :N].cpu().numpy() if (not args.no_cpu_baseline and world == 1) else None
+        if native:
+            native.close(); native = None
         for cx in ctxs:
             cx.close()
         gpu_res = None
@@ -1261,6 +1289,8 @@ def main():
         out["value_pcie_inclusive"] = hb.get("value")
         out["value_pcie_inclusive_xyz12"] = (hb.get("xyz12") or {}).get("value")
         _JSON_OUT.write(json.dumps(out) + "\n"); _JSON_OUT.flush()
+    if native:
+        native.close()
     if gather_on:
         dist.barrier()
         dist.destroy_process_group()

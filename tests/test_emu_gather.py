@@ -37,8 +37,10 @@ def decode(raw, world, nc, block, batch, cap):
     return out
 
 
-def test_native_gather_equals_the_python_shim_thread_per_context(mot, multi):
+def test_native_gather_equals_the_python_shim_thread_per_context(mot):
     import build_emu
+    from conftest import load_sub
+    multi = load_sub("multi")
     lib = build_emu.build()
     NC, B, CAP, F = 4, 3, 3 * 8, 14
     ctxs = [mot.Context(lib_path=lib, max_points=1024, max_batch=B, max_tracks_total=64) for _ in range(NC)]
@@ -48,18 +50,20 @@ def test_native_gather_equals_the_python_shim_thread_per_context(mot, multi):
             assert g.block == shim.block
             seen = {}
             barrier = threading.Barrier(NC + 1)
-            errs = []
+            emu_lock = threading.Lock()   # the emulator runs a kernel on the calling thread and is not re-entrant: library calls one at a time (the threads still
+            errs = []                     # reach contribute() in any order, and whoever completes the tick issues the collective)
 
             def feed(ci):
                 try:
                     for f in range(F):
                         cx = ctxs[ci]
                         ts = 1.0e9 + f * 1e5
-                        for s in range(B):
-                            cx.ego_update(ts, 1.0, 0.002 * f, s)
                         bx = np.stack([boxes(f + s, 4 + ci) for s in range(B)]).reshape(B, -1)
-                        cx.track_steps_dev(bx.ctypes.data, bx.shape[1], [4 + ci] * B, [ts] * B)
-                        g.contribute(ci)
+                        with emu_lock:
+                            for s in range(B):
+                                cx.ego_update(ts, 1.0, 0.002 * f, s)
+                            cx.track_steps_dev(bx.ctypes.data, bx.shape[1], [4 + ci] * B, [ts] * B)
+                            g.contribute(ci)
                         barrier.wait()   # the main thread reads this tick's result ...
                         barrier.wait()   # ... before anybody starts the tick after next (which rewrites its buffer)
                 except BaseException as e:

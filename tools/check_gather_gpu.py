@@ -74,5 +74,37 @@ for ci, cx in enumerate(ctxs):
     assert not trunc and np.array_equal(counts, packed[ci][0])
     for b in range(B):
         assert np.array_equal(recs[b], packed[ci][1][b]), (ci, b, "one-rank copy path differs from the collective's block")
-print("gather check ok: live tracks per slot", [int(x) for x in tgs[0].dst_cnt[0].cpu()])
+# ---- the NATIVE gather (include/mot.h mot_gather_*, ABI v6): the same tick issued from C — export kernels on the contexts' streams, ONE ncclAllGather on the
+# library's side stream over a one-rank RCCL communicator of its own (mot_gather_unique_id / ncclCommInitRank), a host thread PER CONTEXT contributing, no host
+# synchronisation inside the loop: its receive buffer must hold, byte for byte, what TrackGatherAll's collective delivered above
+import threading
+for cx in ctxs: cx.reset()
+uid = mot.NativeGather.unique_id(ctxs[0].lib)
+with mot.NativeGather(ctxs, B, B * 64, world=1, rank=0, unique_id=uid) as ng:
+    assert ng.block == tga.block
+    errs = []
+    def feed(ci):
+        try:
+            torch.cuda.set_device(0)
+            for f in range(6):
+                ts = np.full(B, 1.0e9 + f * 1e5)
+                ctxs[ci].frames_dev(frames[f].data_ptr() + ci * B * stride * 16, stride * 4, [N] * B, run_tracker=True, timestamps=ts, ego_v=np.zeros(B), ego_yaw=np.zeros(B))
+                ng.contribute(ci)
+        except BaseException as e:
+            errs.append(e)
+    th = [threading.Thread(target=feed, args=(ci,)) for ci in range(NC)]
+    for t in th: t.start()
+    for t in th: t.join()
+    assert not errs, errs
+    d, nb, tick, ev = ng.result()
+    ng.synchronize()
+    assert tick == 6 and nb == tga.block
+    import ctypes as C
+    raw = np.zeros(NC * nb, np.uint8)
+    assert ctxs[0].lib.mot_synchronize(ctxs[0]._h) == 0
+    hip = C.CDLL("libamdhip64.so")
+    assert hip.hipMemcpy(raw.ctypes.data_as(C.c_void_p), C.c_void_p(d), C.c_size_t(raw.nbytes), 2) == 0   # hipMemcpyDeviceToHost
+    ref = tga.recv[tga.last].cpu().numpy()
+    assert np.array_equal(raw, ref[: len(raw)]), "native gather's block differs from TrackGatherAll's"
+print("gather check ok: live tracks per slot", [int(x) for x in tgs[0].dst_cnt[0].cpu()], "| native gather (RCCL from C, a thread per context) equals the torch shim's block")
 dist.destroy_process_group()
