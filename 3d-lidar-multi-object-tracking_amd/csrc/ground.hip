@@ -636,6 +636,10 @@ void mot_launch_decode_pointcloud2(const void* data, int n, int step, int ox, in
   hipLaunchKernelGGL(decode_pointcloud2_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, (const unsigned char*)data, n, step, ox, oy, oz, ow, aligned, out);
 }
 
+// measurement only (mot_debug_skip_kernels): an empty launch with the geometry of the sequence's one-workgroup-per-frame kernels
+__global__ void MOT_LAUNCH_BOUNDS(256) noop_kernel(int) {}
+void mot_launch_noop(int batch, hipStream_t stream) { hipLaunchKernelGGL(noop_kernel, dim3(batch), dim3(256), 0, stream, 0); }
+
 // packed {x, y, z} records (12 bytes a point: mot_frames_host_xyz) -> float4, w = 1.0f, for a batch of frames. A thread expands four consecutive points:
 // three 16-byte loads, four 16-byte stores, both sides coalesced (48 B in, 64 B out per thread). Runs once per host-fed batch, under the next batch's
 // H2D copy; the points beyond a frame's n are expanded too (max_n per slot: the counts are not on the device yet) and never read.

@@ -723,6 +723,9 @@ static void issue_frame_kernels(mot_ctx* c, int batch, int max_n, int run_tracke
   cb.occ_list = c->d_occ_list; cb.occ_count = c->d_occ_count;   // the occupancy comes as the compaction kernel's per-chunk lists
   cb.ecell = g.ecell;                                            // ... and every elevated point's cell with it
   if (!(c->fused_outputs & MOT_OUT_LABELS)) cb.label = nullptr;  // per-point labels on demand (mot_get_clusters)
+  // MEASUREMENT ONLY (mot_debug_skip_kernels bits 8-11: a count): that many EXTRA launch boundaries — empty one-workgroup-per-frame kernels — in the middle of the
+  // sequence. What k more boundaries cost is what fusing k of the sequence's one-workgroup-per-frame launches away could at most win (profiles/r06_launch_boundaries.md).
+  for (int k = 0; k < ((c->dbg_skip >> 8) & 15); k++) mot_launch_noop(batch, c->stream);
   if (!(c->dbg_skip & 2)) { RangeScope rs(c, "mot:cluster"); ProfScope ps(c, kC2); mot_launch_cluster(c->dp, cb, batch, max_n, c->stream, true); }
   RangeScope rb(c, "mot:box");
   { ProfScope ps(c, kB1); mot_launch_box_kernel(0, c->dp, cb, batch, max_n, c->stream); }
@@ -2250,7 +2253,8 @@ extern "C" int mot_debug_copy(mot_ctx* c, int which, int slot, void* dst, size_t
 
 // test hook (mot_debug_api.h): the context's device parameters, for the fast-path sweeps of tests/devcheck (a library of their own)
 // MEASUREMENT ONLY (tools/, bench.py MOT_BENCH_SKIP): leaves launches of the fused sequence out — 1 polar_filter, 2 ccl, 4 cluster_index, 8 box_finalize_prep,
-// 32 the tracker — so that the cost of a launch boundary can be bounded before a fusion is built. The frame's results are stale / wrong while a bit is set.
+// 32 the tracker (the frame's results are stale / wrong while one of these bits is set: on a moving scene stale thresholds change the WORKLOAD, so these bound
+// nothing — profiles/r06_launch_boundaries.md); bits 8-11: a count of extra EMPTY launches per sequence (results unaffected): the cost of a launch boundary.
 extern "C" int mot_debug_skip_kernels(mot_ctx* c, int mask) {
   if (!c) return MOT_E_ARG;
   c->dbg_skip = mask;

@@ -1138,7 +1138,7 @@ def main():
                      "polar_filter_kernel": 8.0 * 9600 * BL,
                      "classify_compact_kernel": 16.0 * n_tot + EB * ne_tot,   # the fused path's default: ground cloud and mask on demand (round 2: + 16 N_g + N); elevated points leave as 12 bytes (round 5)
                      "ccl_kernel": (2 * 2048 * 4 + 4.0 * G * G) * BL,
-                     "label_stats_kernel": (EB + 4.0) * ne_tot,   # points read, pixels written; the per-point labels are written on demand only (MOT_OUT_LABELS)
+                     "label_stats_kernel": (EB + 2.0 + 4.0) * ne_tot,   # points and their 2-byte cells read, pixels written (18 N_e since round 6 — the cells were left out here); the per-point labels are written on demand only (MOT_OUT_LABELS)
                      "cluster_index_kernel": 32.0 * ne_tot / 64,   # a 16-byte record per (tile, cluster) group read and written; at least one group per 64 points
                      "cluster_gather_kernel": (4.0 + 16.0 / 64) * ne_tot,   # the pixels, and the cluster-sorted group records
                      "cluster_rect_kernel": 4.0 * ne_tot / 8,

@@ -5,7 +5,7 @@
 #   smoke                      __graft_entry__.smoke()
 #   bench[:tag[:bench args]]   python bench.py <args> > bench_<tag>.json        (tag default: "default")
 #   quick[:tag[:bench args]]   bench.py --steps 8 --warmup 1 --no-aux --no-cpu-baseline <args>, twice
-#   skip[:m1,m2,...]           bench.py with launches of the sequence left out (MOT_BENCH_SKIP masks: 1 filter, 2 ccl, 4 index, 8 finalize+prep, 32 tracker; 0 = the product): bounds of fusions
+#   skip[:m1,m2,...]           bench.py with MOT_BENCH_SKIP masks (mot_debug_skip_kernels): 256 * k = k extra EMPTY launches per sequence (the cost of a launch boundary; 0 = the product)
 #   traceo:ORDER               trace1 on firing / random point order (bench.py --point-order)
 #   trace1 / trace4            rocprofv3 --kernel-trace --stats of one context alone (B 512) / of the default 4-context line
 #   pmc[:CTR,CTR…]             one rocprofv3 --pmc pass per counter (default FETCH_SIZE,WRITE_SIZE), summarised
@@ -35,7 +35,7 @@ for step in "$@"; do
     quick) for r in 1 2; do timeout 300 python bench.py --steps 8 --warmup 1 --no-aux --no-cpu-baseline $a2 2>/dev/null | tee -a $O/quick_${a1:-default}.jsonl | head -c 260; echo; done ;;
     trace1) trace B512_1ctx --steps 3 --warmup 1 --batch 512 --contexts 1 ;;
     trace4) trace B2048_4ctx ;;
-    skip) for m in $(echo ${a1:-1,4,8,13,32} | tr , ' '); do for r in 1 2; do MOT_BENCH_SKIP=$m timeout 300 python bench.py --steps 8 --warmup 1 --no-aux --no-cpu-baseline --no-all-outputs 2>/dev/null | python -c "
+    skip) for m in $(echo ${a1:-0,256,768,1536} | tr , ' '); do for r in 1 2; do MOT_BENCH_SKIP=$m timeout 300 python bench.py --steps 8 --warmup 1 --no-aux --no-cpu-baseline --no-all-outputs 2>/dev/null | python -c "
 import sys, json
 d = json.loads(sys.stdin.readline()); print('skip mask %3d  %9.0f frames/s  %8.2f ms/step' % ($m, d['value'], d['ms_per_step']))" | tee -a $O/skip.txt; done; done ;;
     traceo) trace B512_1ctx_order_$a1 --steps 3 --warmup 1 --batch 512 --contexts 1 --point-order $a1 ;;
