@@ -132,11 +132,13 @@ struct PredictScratch {
     struct { double xo[3][5], Po[3][25]; };         // the mixing inputs, until the interaction step is done
     struct { double L[3][25], Ld[3][2]; };          // the Cholesky factors of the augmented covariances (5 x 5 block + two trailing
                                                     // diagonal entries), until the sigma points exist
-    struct { double K[3][10], Tc[3][10]; };         // the cross-correlations and gains
+    struct { double K[3][10]; };                    // the gains (after the last model's sums)
   };
+  double Tc[3][10];              // the cross-correlations: written by model m's sums while the factors of models m+1.. are still needed (round 6), so not a tenant of the union
   double xm[5], Pm[25];          // merged
   double mode[3], mm[3][3];
-  double Xs[3][75];              // predicted sigma points, 5 x 15 per model
+  // (Round 6: the predicted sigma points — 3 x 75 doubles, half of this structure — no longer pass through LDS: a lane computes ITS sigma point of a model and
+  // feeds it straight into that model's weighted sums, same lane in both roles. 465 -> 270 doubles per track: nine workgroups share a CU instead of five.)
   double z[3][2], S[3][4];
 };
 struct BbFlags { int is_vis, has_bbox, has_best, pad; double best_yaw; };
@@ -145,7 +147,11 @@ struct UpdateScratch {
   double xo[3][5], Po[3][25];    // updated state
   double xm[5];                  // merged state of the previous step
   double mode[3];
-  double Xs[3][64];              // exp() of the gated boxes 0..63 per model (before that: the two boxes of updateBB, as floats)
+  float bb[48];                  // the two boxes of updateBB (BBox_, bestBBox_), as floats
+  double cst[2 * kGroupLanes];   // the first 16 box centres of the frame (lane 0's ordered association scan reads them by index)
+  // (Round 6: the exp() of the gated boxes 0..63 per model — 3 x 64 doubles that shared their storage with the two arrays above — is no longer cached in LDS:
+  // a lane computes and re-uses the values of ITS boxes (lane, lane + 16, lane + 32, lane + 48) within one model's pass, four registers. 453 -> 317 doubles
+  // per track: seven workgroups share a CU instead of five.)
   double z[3][2], S[3][4], K[3][10];
   double pda[3][7];              // filterPDA's sums per model: eSum, sigmaX(0..1), sigmaP(0..3)
   BbFlags bbf;                   // isVisBB_, BBox_ set, bestBBox_ set, bestYaw_ while updateBB works on the boxes staged in Xs
@@ -178,7 +184,7 @@ __device__ void load_track(UpdateScratch* G, const DevTrack* t, bool act) {
     if (s < 12) G->S[s / 4][s % 4] = t->S[s / 4][s % 4];
     for (int e = s; e < 30; e += kGroupLanes) G->K[e / 10][e % 10] = t->K[e / 10][e % 10];
     // BBox_ / bestBBox_ for updateBB, as floats in the storage of the exp() cache (not needed before the PDA sums)
-    float* fb = reinterpret_cast<float*>(&G->Xs[0][0]);
+    float* fb = G->bb;
     for (int e = s; e < 24; e += kGroupLanes) { fb[e] = t->bbox[e]; fb[24 + e] = t->best_bbox[e]; }
     if (s == 0) { G->bbf.is_vis = t->is_vis; G->bbf.has_bbox = t->has_bbox; G->bbf.has_best = t->has_best; G->bbf.pad = 0; G->bbf.best_yaw = t->best_yaw; }
   }
@@ -273,70 +279,63 @@ __device__ __forceinline__ void process_imm_ukf(PredictScratch* G, double dt, bo
   MOT_WAVE_SYNC();
   GRP_T(18);
   // 15 sigma points of ONE model per pass, a lane each: Cv :573, Ctrv :539, randomMotion :602 (the model is uniform over the
-  // wave, so only that model's code runs in a pass)
-#pragma unroll 1
-  for (int m = 0; m < 3; m++) {
-    if (ok && s < 15) {
-      const int i = s;
-      const double sc = sqrt(-4.0 + 7.0);
-      const int col = i <= 7 ? i - 1 : i - 8;   // column of the augmented factor this sigma point moves along
-      double xa[7];
-#pragma unroll
-      for (int r = 0; r < 7; r++) {
-        const double base = r < 5 ? G->x[m][r] : 0.0;
-        double l = 0.0;
-        if (r < 5) l = (col >= 0 && col < 5) ? G->L[m][r * 5 + col] : 0.0;   // (the stored upper triangle is zero)
-        else if (r == 5) l = col == 5 ? G->Ld[m][0] : 0.0;
-        else l = col == 6 ? G->Ld[m][1] : 0.0;
-        if (i == 0) xa[r] = base;
-        else if (i <= 7) xa[r] = base + sc * l;
-        else xa[r] = base - sc * l;
-      }
-      const double p_x = xa[0], p_y = xa[1], v = xa[2], yaw = xa[3], yawd = xa[4], nu_a = xa[5], nu_yawdd = xa[6];
-      double sp[5];
-      if (m == 2) { sp[0] = p_x; sp[1] = p_y; sp[2] = v; sp[3] = yaw; sp[4] = yawd; }
-      else {
-        double px_p, py_p;
-        double sy, cy;   // every sin(yaw) / cos(yaw) of the reference's expressions: evaluated once
-        sincos(yaw, &sy, &cy);
-        if (m == 0) { px_p = p_x + v * cy * dt; py_p = p_y + v * sy * dt; }
-        else if (fabs(yawd) > 0.001) {
-          double s2, c2;
-          sincos(yaw + yawd * dt, &s2, &c2);
-          px_p = p_x + v / yawd * (s2 - sy);
-          py_p = p_y + v / yawd * (cy - c2);
-        } else { px_p = p_x + v * dt * cy; py_p = p_y + v * dt * sy; }
-        double v_p = v;
-        double yaw_p = m == 0 ? yaw : yaw + yawd * dt;
-        double yawd_p = yawd;
-        px_p = px_p + 0.5 * nu_a * dt * dt * cy;
-        py_p = py_p + 0.5 * nu_a * dt * dt * sy;
-        v_p = v_p + nu_a * dt;
-        yaw_p = yaw_p + 0.5 * nu_yawdd * dt * dt;
-        yawd_p = yawd_p + nu_yawdd * dt;
-        sp[0] = px_p; sp[1] = py_p; sp[2] = v_p; sp[3] = yaw_p; sp[4] = yawd_p;
-      }
-#pragma unroll
-      for (int r = 0; r < 5; r++) G->Xs[m][r * 15 + i] = sp[r];
-    }
-  }
-  MOT_WAVE_SYNC();
-  GRP_T(19);
-  // From here on a LANE IS A SIGMA POINT (15 of the group's 16 lanes; the 16th adds zeros): every weighted sum over the sigma points — the
-  // predicted mean :736-742, z / S / Tc of UpdateLidar :778-902, the predicted covariance :743-749 — is one reduction over the group's DPP row
-  // (row_sum_f64: every lane receives it). Until round 4 a lane was a MATRIX ENTRY that read its 15 (30) terms from LDS: 132 sums of 15 terms,
-  // ~2000 LDS reads per lane and step with the selects of the yaw row — the covariance alone took 9 of the prediction's 22 us, bound by LDS
-  // traffic and bank conflicts (profiles/r04_stream_kernel_phases.txt). The terms are the reference's, (w_i * d_r) * d_c; the ORDER of the
-  // additions is the row tree's, NOT the reference's (its loops add i = 0 .. 14 in turn, ukf.cpp:736-749): a last-bit deviation, see mot_wave.h
+  // wave, so only that model's code runs in a pass) — and, in the same pass, that model's weighted sums with A LANE AS A SIGMA POINT (15 of the group's 16
+  // lanes; the 16th adds zeros): every weighted sum over the sigma points — the predicted mean :736-742, z / S / Tc of UpdateLidar :778-902, the predicted
+  // covariance :743-749 — is one reduction over the group's DPP row (row_sum_f64: every lane receives it). Until round 4 a lane was a MATRIX ENTRY that read
+  // its 15 (30) terms from LDS: 132 sums of 15 terms, ~2000 LDS reads per lane and step with the selects of the yaw row — the covariance alone took 9 of the
+  // prediction's 22 us, bound by LDS traffic and bank conflicts (profiles/r04_stream_kernel_phases.txt). The terms are the reference's, (w_i * d_r) * d_c; the
+  // ORDER of the additions is the row tree's, NOT the reference's (its loops add i = 0 .. 14 in turn, ukf.cpp:736-749): a last-bit deviation, see mot_wave.h
   // (-DMOT_TRACK_SEQ_SUMS=1 restores the reference's order for the parity suites).
   {
     const double wi = s < 15 ? ukf_w(s) : 0.0;
     const bool on = ok && s < 15;
 #pragma unroll 1
     for (int m = 0; m < 3; m++) {
+      double sp[5] = {0.0, 0.0, 0.0, 0.0, 0.0};
+      if (on) {
+        const int i = s;
+        const double sc = sqrt(-4.0 + 7.0);
+        const int col = i <= 7 ? i - 1 : i - 8;   // column of the augmented factor this sigma point moves along
+        double xa[7];
+#pragma unroll
+        for (int r = 0; r < 7; r++) {
+          const double base = r < 5 ? G->x[m][r] : 0.0;
+          double l = 0.0;
+          if (r < 5) l = (col >= 0 && col < 5) ? G->L[m][r * 5 + col] : 0.0;   // (the stored upper triangle is zero)
+          else if (r == 5) l = col == 5 ? G->Ld[m][0] : 0.0;
+          else l = col == 6 ? G->Ld[m][1] : 0.0;
+          if (i == 0) xa[r] = base;
+          else if (i <= 7) xa[r] = base + sc * l;
+          else xa[r] = base - sc * l;
+        }
+        const double p_x = xa[0], p_y = xa[1], v = xa[2], yaw = xa[3], yawd = xa[4], nu_a = xa[5], nu_yawdd = xa[6];
+        if (m == 2) { sp[0] = p_x; sp[1] = p_y; sp[2] = v; sp[3] = yaw; sp[4] = yawd; }
+        else {
+          double px_p, py_p;
+          double sy, cy;   // every sin(yaw) / cos(yaw) of the reference's expressions: evaluated once
+          sincos(yaw, &sy, &cy);
+          if (m == 0) { px_p = p_x + v * cy * dt; py_p = p_y + v * sy * dt; }
+          else if (fabs(yawd) > 0.001) {
+            double s2, c2;
+            sincos(yaw + yawd * dt, &s2, &c2);
+            px_p = p_x + v / yawd * (s2 - sy);
+            py_p = p_y + v / yawd * (cy - c2);
+          } else { px_p = p_x + v * dt * cy; py_p = p_y + v * dt * sy; }
+          double v_p = v;
+          double yaw_p = m == 0 ? yaw : yaw + yawd * dt;
+          double yawd_p = yawd;
+          px_p = px_p + 0.5 * nu_a * dt * dt * cy;
+          py_p = py_p + 0.5 * nu_a * dt * dt * sy;
+          v_p = v_p + nu_a * dt;
+          yaw_p = yaw_p + 0.5 * nu_yawdd * dt * dt;
+          yawd_p = yawd_p + nu_yawdd * dt;
+          sp[0] = px_p; sp[1] = py_p; sp[2] = v_p; sp[3] = yaw_p; sp[4] = yawd_p;
+        }
+      }
+      MOT_WAVE_SYNC();   // every lane has read x[m] before lanes 0-4 overwrite it with the predicted mean below
       double X[5];
 #pragma unroll
-      for (int r = 0; r < 5; r++) X[r] = on ? G->Xs[m][r * 15 + s] : 0.0;
+      for (int r = 0; r < 5; r++) X[r] = on ? sp[r] : 0.0;
       double mean[5];
 #pragma unroll
       for (int r = 0; r < 5; r++) mean[r] = row_sum_f64(wi * X[r]);
@@ -378,6 +377,7 @@ __device__ __forceinline__ void process_imm_ukf(PredictScratch* G, double dt, bo
     }
   }
   MOT_WAVE_SYNC();
+  GRP_T(19);
   GRP_T(20);
   if (ok)
     for (int e = s; e < 30; e += kGroupLanes) {
@@ -689,7 +689,7 @@ __device__ void update_group(const TrackBuffers& tb, UpdateScratch* G, int b, in
   // memory again, a dependent round trip each
   Vec2d c_first; c_first.x = 0; c_first.y = 0;
   if (act && s < M) c_first = cp[s];
-  double* cstage = &G->Xs[1][0];   // (Xs[0] holds updateBB's two boxes until the exp() cache takes the storage)
+  double* cstage = G->cst;
   cstage[2 * s] = c_first.x; cstage[2 * s + 1] = c_first.y;
   MOT_WAVE_SYNC();
   // associateBB :416-463 + getNearestEuclidBBox :396-413 (int minDist, truncated on assignment)
@@ -713,7 +713,7 @@ __device__ void update_group(const TrackBuffers& tb, UpdateScratch* G, int b, in
       if (minBox < 0) minBox = first;  // minInd stays 0 = first gated box
       if (minDist < tp.distance_thres) {
         const float* bx = boxes + (long)minBox * 24;
-        float* fb = reinterpret_cast<float*>(&G->Xs[0][0]);
+        float* fb = G->bb;
         for (int h = 0; h < 2; h++)
           for (int q = 0; q < 4; q++) {
             fb[(h * 4 + q) * 3] = bx[3 * q];
@@ -726,9 +726,9 @@ __device__ void update_group(const TrackBuffers& tb, UpdateScratch* G, int b, in
   }
   MOT_WAVE_SYNC();
   {
-    float* fb = reinterpret_cast<float*>(&G->Xs[0][0]);
+    float* fb = G->bb;
     update_bb_group(tp, fb, fb + 24, &G->bbf, G->xm[3], act);
-    if (act) {   // the boxes and their flags go back to the track record before the exp() cache takes the storage
+    if (act) {   // the boxes and their flags go back to the track record
       for (int e = s; e < 24; e += kGroupLanes) { u->bbox[e] = fb[e]; u->best_bbox[e] = fb[24 + e]; }
       if (s == 0) { u->is_vis = G->bbf.is_vis; u->has_bbox = G->bbf.has_bbox; u->has_best = G->bbf.has_best; u->best_yaw = G->bbf.best_yaw; }
     }
@@ -772,7 +772,6 @@ __device__ void update_group(const TrackBuffers& tb, UpdateScratch* G, int b, in
   const int Mmax = wave_reduce_i32(Mg, OpMaxI());
   const double numMeas = nm;
   const double bpda = 2 * numMeas * (1 - tp.p_d * tp.p_g) / (tp.gamma_g * tp.p_d);
-  double* ecache = &G->Xs[0][0];   // exp() of the gated boxes 0..63 per model ([3][64]; the sigma points are not needed here)
   // (the first 16 boxes' centres are in registers, c_first; their gate word too)
   const unsigned long long gt0 = Mg > 0 ? gt[0] : 0ull;
 #pragma unroll 1
@@ -781,6 +780,7 @@ __device__ void update_group(const TrackBuffers& tb, UpdateScratch* G, int b, in
     if (upd) inv2(G->S[m], Si);
     const double zm0 = G->z[m][0], zm1 = G->z[m][1];
     double eS = 0;
+    double ec0 = 0, ec1 = 0, ec2 = 0, ec3 = 0;   // exp() of MY gated boxes among the first 64 (k0 = 0, 16, 32, 48), for the two passes below
     for (int k0 = 0; k0 < Mmax; k0 += kGroupLanes) {
       const int k = k0 + s;
       const bool g = k < Mg && (((k0 < 64 ? gt0 : gt[k0 >> 6]) >> (k & 63)) & 1ull);
@@ -791,8 +791,8 @@ __device__ void update_group(const TrackBuffers& tb, UpdateScratch* G, int b, in
         double h0 = -0.5 * d0, h1 = -0.5 * d1;
         double t0 = h0 * Si[0] + h1 * Si[2], t1 = h0 * Si[1] + h1 * Si[3];
         e = exp(t0 * d0 + t1 * d1);
-        if (k < 64) ecache[m * 64 + k] = e;
       }
+      if (k0 == 0) ec0 = e; else if (k0 == 16) ec1 = e; else if (k0 == 32) ec2 = e; else if (k0 == 48) ec3 = e;   // (k0 is uniform)
       eS += row_sum_f64(e);
     }
     double sxm[2] = {0, 0}, spm[4] = {0, 0, 0, 0};
@@ -806,7 +806,7 @@ __device__ void update_group(const TrackBuffers& tb, UpdateScratch* G, int b, in
           const Vec2d c = k0 == 0 ? c_first : cp[k];
           d[0] = c.x - zm0; d[1] = c.y - zm1;
           double e;
-          if (k < 64) e = ecache[m * 64 + k];
+          if (k0 < 64) e = k0 == 0 ? ec0 : k0 == 16 ? ec1 : k0 == 32 ? ec2 : ec3;
           else {
             double h0 = -0.5 * d[0], h1 = -0.5 * d[1];
             double t0 = h0 * Si[0] + h1 * Si[2], t1 = h0 * Si[1] + h1 * Si[3];
