@@ -885,17 +885,35 @@ __device__ void update_group(const TrackBuffers& tb, UpdateScratch* G, int b, in
   MOT_WAVE_SYNC();
 }
 
-__global__ void MOT_LAUNCH_BOUNDS2(kItemWaves * 64, MOT_UPDATE_WAVES)
-track_update_kernel(TrackBuffers tb) {
-  __shared__ UpdateScratch s_g[kItemWaves * kGroupsPerWave];
+// Two instantiations of the same code, chosen ON THE DEVICE by the launch's number of live tracks (both are launched; the one whose range does not hold
+// n_items leaves at once — an empty launch costs the sequence nothing, profiles/r06_launch_boundaries.md):
+//   track_update_kernel        2 waves per SIMD (234 VGPRs, no scratch): 4 workgroups = 32 tracks per CU — the faster code while one round holds the launch
+//   track_update_dense_kernel  3 waves per SIMD (168 VGPRs, 200 bytes of scratch per lane): 6 workgroups = 48 tracks per CU — slower per track, fewer rounds:
+//                              512 streams x 64 live tracks 275 -> 245 us, 512 x 32 127 -> 134 us (profiles/r06_tracker_occupancy_variants.txt)
+// Same arithmetic, same results (-ffp-contract=off: a spill changes no rounding).
+#ifndef MOT_UPDATE_DENSE_TRACKS
+#define MOT_UPDATE_DENSE_TRACKS 24576   // live tracks of a launch from which the dense instantiation runs
+#endif
+__device__ __forceinline__ void track_update_body(const TrackBuffers& tb, UpdateScratch* s_g, int lo, int hi) {
   const int wave = threadIdx.x >> 6, grp = ggroup();
   const int n = *tb.n_items;
+  if (n < lo || n >= hi) return;
   for (int i0 = (blockIdx.x * kItemWaves + wave) * kGroupsPerWave; i0 < n; i0 += gridDim.x * kItemWaves * kGroupsPerWave) {
     const bool act = i0 + grp < n;
     TrackItem it; it.b = 0; it.li = 0;
     if (act) it = tb.items[i0 + grp];
     update_group(tb, &s_g[wave * kGroupsPerWave + grp], it.b, it.li, act);
   }
+}
+__global__ void MOT_LAUNCH_BOUNDS2(kItemWaves * 64, MOT_UPDATE_WAVES)
+track_update_kernel(TrackBuffers tb, int lo, int hi) {
+  __shared__ UpdateScratch s_g[kItemWaves * kGroupsPerWave];
+  track_update_body(tb, s_g, lo, hi);
+}
+__global__ void MOT_LAUNCH_BOUNDS2(kItemWaves * 64, MOT_UPDATE_WAVES + 1)
+track_update_dense_kernel(TrackBuffers tb, int lo, int hi) {
+  __shared__ UpdateScratch s_g[kItemWaves * kGroupsPerWave];
+  track_update_body(tb, s_g, lo, hi);
 }
 
 // ---- T3: eviction, PD merge, PE birth, PF outputs, the live list of the next step — one workgroup per stream
@@ -1275,9 +1293,10 @@ void mot_launch_track(const TrackBuffers& t, int batch, hipStream_t stream, bool
 #ifdef MOT_HIPEMU
   const int item_groups = 2;   // the per-track kernels loop over the work list: any grid size gives the same result
 #else
-  int item_groups = batch * 8;   // 2 waves x 4 tracks each: one round covers 64 live tracks per stream; the chip holds 1280 such workgroups (5 per CU: the scratch above)
-  item_groups = item_groups < 16 ? 16 : (item_groups > 1280 ? 1280 : item_groups);
+  int item_groups = batch * 8;   // 2 waves x 4 tracks each: one round covers 64 live tracks per stream; the chip holds 1536 such workgroups of the prediction and of the
+  item_groups = item_groups < 16 ? 16 : (item_groups > 1536 ? 1536 : item_groups);   // dense update (6 per CU: 3 waves per SIMD), 1024 of the plain update (4 per CU)
 #endif
+  const bool two_updates = item_groups * 8 > MOT_UPDATE_DENSE_TRACKS / 2;   // (a launch this small never reaches the dense range: one update launch)
 #ifndef MOT_STREAM_KERNEL_MAX_BATCH
 #define MOT_STREAM_KERNEL_MAX_BATCH 32
 #endif
@@ -1287,6 +1306,7 @@ void mot_launch_track(const TrackBuffers& t, int batch, hipStream_t stream, bool
   }
   if (!prep_done) hipLaunchKernelGGL(track_prep_kernel, dim3(batch), dim3(256), 0, stream, t);   // (fused path: done at the tail of the box stage)
   hipLaunchKernelGGL(track_predict_kernel, dim3(item_groups), dim3(kItemWaves * 64), 0, stream, t);
-  hipLaunchKernelGGL(track_update_kernel, dim3(item_groups), dim3(kItemWaves * 64), 0, stream, t);
+  hipLaunchKernelGGL(track_update_kernel, dim3(item_groups < 1024 ? item_groups : 1024), dim3(kItemWaves * 64), 0, stream, t, 0, two_updates ? MOT_UPDATE_DENSE_TRACKS : 0x7fffffff);
+  if (two_updates) hipLaunchKernelGGL(track_update_dense_kernel, dim3(item_groups), dim3(kItemWaves * 64), 0, stream, t, MOT_UPDATE_DENSE_TRACKS, 0x7fffffff);
   hipLaunchKernelGGL(track_finish_kernel, dim3(batch), dim3(kTrackBlock), 0, stream, t);
 }

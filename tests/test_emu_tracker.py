@@ -153,3 +153,18 @@ def test_sum_order_knob():
     for name in res["tree"]:
         assert res["tree"][name] <= 1e-6 and res["seq"][name] <= 1e-6, res
     assert sum(res["seq"].values()) <= sum(res["tree"].values()), res
+
+
+def test_dense_update_instantiation_is_chosen_by_the_live_track_count():
+    """track_update_kernel / track_update_dense_kernel (round 6: the same code at 2 / 3 waves per SIMD; both are launched, the live-track count of the launch decides
+    on the device which one works): with the threshold pulled down to 4 tracks (-DMOT_UPDATE_DENSE_TRACKS=4) the golden sequences cross it back and forth —
+    frames below it go through the plain kernel, frames above through the dense one, every track through exactly one: the results are those of the default build,
+    to the last bit of the probe's figures."""
+    import subprocess
+    probe = os.path.join(os.path.dirname(os.path.abspath(__file__)), "sum_order_probe.py")
+    res = {}
+    for tag, defs in (("default", ""), ("dense from 4 tracks", "-DMOT_UPDATE_DENSE_TRACKS=4")):
+        r = subprocess.run([sys.executable, probe], capture_output=True, text=True, env=dict(os.environ, MOT_EMU_DEFINES=defs), timeout=1500)
+        assert r.returncode == 0, r.stderr[-2000:]
+        res[tag] = {ln.split()[0]: float(ln.split()[1]) for ln in r.stdout.splitlines() if ln.strip()}
+    assert res["default"] and res["default"] == res["dense from 4 tracks"], res

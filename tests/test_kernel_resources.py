@@ -25,8 +25,11 @@ def test_no_kernel_spills_and_the_streaming_kernels_keep_their_occupancy():
     for k in ("polar_minz_kernel", "classify_compact_elevated_kernel", "ccl_kernel", "label_stats_kernel", "cluster_gather_kernel", "track_predict_kernel",
               "track_update_kernel", "track_finish_kernel", "track_step_stream_kernel", "box_markers_kernel", "side_scatter_kernel"):
         assert k in rows, (k, sorted(rows))
-    spilled = {k: v["scratch"] for k, v in rows.items() if v["scratch"] != 0}
+    # (track_update_dense_kernel is the ONE kernel that spills, by design: the same code as track_update_kernel held to 3 waves per SIMD for launches
+    # with more than 24 k live tracks, chosen on the device — profiles/r06_tracker_occupancy_variants.txt)
+    spilled = {k: v["scratch"] for k, v in rows.items() if v["scratch"] != 0 and k != "track_update_dense_kernel"}
     assert not spilled, spilled
+    assert rows["track_update_dense_kernel"]["waves"] >= 3 and rows["track_update_dense_kernel"]["scratch"] <= 256, rows["track_update_dense_kernel"]
     # the streaming kernels are latency hiders: 8 (7) waves per SIMD is what their block sizes and LDS budgets assume
     # (label_stats_kernel: 256 threads x 8 points since round 5, LDS-bound, each wave with twice the loads in flight: 151 against 155-159 us per
     # 512 frames, profiles/r05_label_geometry_ab.txt; its per-tile counts and slot numbers packed into shorts / bytes put a SIXTH workgroup on
