@@ -47,12 +47,13 @@ def test_154_frame_dense_scene_measured_conditioning(hip_lib):
     print("dense scene, measured conditioning:", m, {k: st.get(k) for k in ("live_max", "tracks_ever", "state_compares", "noise_floor_replicas")})
 
 
-@pytest.mark.parametrize("order", ["firing", "random"])
-def test_sequence_point_orders(hip_lib, order):
+@pytest.mark.parametrize("order,points,frames,preset", [("firing", 120000, 40, 0), ("random", 120000, 40, 0), ("firing", 200000, 16, 0), ("random", 60000, 24, 1)])
+def test_sequence_point_orders(hip_lib, order, points, frames, preset):
     """the same pipeline on azimuth-major (the velodyne driver's `velodyne_points`: OT/src/groundremove/main.cpp:146) and randomly permuted clouds: every
-    output against the oracle on the same clouds (box fitting depends on the point order, SURVEY.md H9: the oracle sees the same order)"""
-    st = _run("--points", 120000, "--frames", 40, "--scenes", 5, "--units", 1e5, "--order", order)
-    assert st["frames"] == 40 and st["point_order"] == order and st["boxes"] > 40
+    output against the oracle on the same clouds (box fitting depends on the point order, SURVEY.md H9: the oracle sees the same order) — also at
+    configs[4]'s 200 k points and with object_tracking0's constants (preset 1)"""
+    st = _run("--points", points, "--frames", frames, "--scenes", 5, "--units", 1e5, "--order", order, "--preset", preset)
+    assert st["frames"] == frames and st["point_order"] == order and st["boxes"] > frames // 2
 
 
 def test_sequence_kitti_preset(hip_lib):
