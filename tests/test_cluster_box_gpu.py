@@ -81,6 +81,15 @@ def test_shuffled_many_clusters(ctx, oracle):
     assert r["num_cluster"] >= 40 and len(b["boxes"]) >= 10
 
 
+def test_unordered_cloud_beyond_one_tile_window(mot, hip_lib, oracle):
+    """138 000 elevated points in no order on the MI355X: the index kernel's many-groups path, two windows of its per-cluster tile table (round 6)"""
+    p = oracle.params(0)
+    cloud = shuffled_many_clusters_cloud(60, 2300, seed=4)
+    with mot.Context(max_points=294912) as c:
+        r, b = _stage_parity(c, oracle, p, cloud)
+    assert r["num_cluster"] == 60 and len(b["boxes"]) > 0
+
+
 def test_many_clusters_per_tile(ctx, oracle):
     p = oracle.params(0)
     _stage_parity(ctx, oracle, p, interleaved_clusters_cloud())
