@@ -1,9 +1,9 @@
 """Where do the tracker's above-1e-4 track-frames on a dense scene come from?  (round-5 review, item 1c.)  CPU only.
 
-  python tools/track_parity_study.py boxes [plaza|street] [scene id] [frames]    render the scene with tools/synth/synth_cpu.py (numpy mirror of the GPU
+  python tests/track_parity_study.py boxes [plaza|street] [scene id] [frames]    render the scene with tools/synth/synth_cpu.py (numpy mirror of the GPU
                                                                                    ray caster), run the REFERENCE's own ground removal -> clustering -> box fit
                                                                                    (oracle/_ref) on every frame -> gpurun_out/study_boxes_<scene>_<id>.npz
-  python tools/track_parity_study.py run FIXTURE [stream]                        replay a box stream (the file above, or a stream of tests/golden/track_boxes.npz)
+  python tests/track_parity_study.py run FIXTURE [stream]                        replay a box stream (the file above, or a stream of tests/golden/track_boxes.npz)
                                                                                    through: the reference build (primary), its replicas (C restatement, -DEIGEN_DONT_VECTORIZE
                                                                                    rebuild: the measured conditioning), and the DEVICE code on the emulator in four builds —
                                                                                    default (tree sums, host libm), -DMOT_TRACK_SEQ_SUMS=1, libm perturbed by an ulp, both.
@@ -11,7 +11,7 @@ Per build: track-frames above 1e-4 in total, on the measured-well-conditioned co
 error / floor ratio. Test infrastructure: imports the oracle."""
 import ctypes as C, importlib, json, os, sys
 import numpy as np
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))   # (lives in tests/ because it calls the oracle: test infrastructure, like everything that does)
 sys.path[:0] = [os.path.join(ROOT, "tests"), os.path.join(ROOT, "tests", "emu"), os.path.join(ROOT, "tools", "synth")]
 import oracle_lib as O
 import seq_parity as SP

@@ -1,6 +1,6 @@
 """numpy mirror of tools/synth/synth.hip's ray caster (same scene generators, same geometry; its own noise stream, so NOT bit-equal to
 the GPU renderer's frames): lets the tracker studies that need a rendered street / plaza sequence run on a box without a GPU
-(tools/track_parity_study.py). BENCH / TEST DATA GENERATOR, not product code."""
+(tests/track_parity_study.py). BENCH / TEST DATA GENERATOR, not product code."""
 from __future__ import annotations
 
 import numpy as np
