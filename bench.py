@@ -1288,6 +1288,9 @@ def main():
         hb = out.get("host_boundary_pipelined") or {}
         out["value_pcie_inclusive"] = hb.get("value")
         out["value_pcie_inclusive_xyz12"] = (hb.get("xyz12") or {}).get("value")
+        #   value_firing_order    the same workload with every frame's points in the velodyne driver's firing order (the reference's default input topic); value_dense_scene: 62 live tracks per stream
+        out["value_firing_order"] = ((out.get("point_order") or {}).get("firing") or {}).get("value")
+        out["value_dense_scene"] = (out.get("dense_scene") or {}).get("value")
         _JSON_OUT.write(json.dumps(out) + "\n"); _JSON_OUT.flush()
     if native:
         native.close()
