@@ -2104,6 +2104,7 @@ extern "C" int mot_gather_destroy(mot_gather* g) {
   return MOT_OK;
 }
 
+// (an error leaves the open tick half-contributed: the gather is then unusable — destroy it; mot_gather_last_error is meant for the thread that got the error)
 #define MOT_GATHER_HIP(g, call)                                                    \
   do {                                                                             \
     hipError_t e_ = (call);                                                        \
@@ -2149,14 +2150,16 @@ extern "C" int mot_gather_contribute(mot_gather* g, int ci) {
   DevGuard guard_(g->device);
   mot_ctx* c = g->ctxs[ci];
   long t;
+  bool wait_done;
   {
     std::unique_lock<std::mutex> lk(g->mu);
     t = g->ticks[ci];
     g->cv.wait(lk, [&] { return t < g->completed + 2; });   // at most one tick ahead of the slowest context: tick t's buffers are tick t-2's
+    wait_done = g->done_valid[(int)(t & 1)];                 // (tick t-2 has been enqueued by now: its event is the one recorded in done[i])
   }
   const int i = (int)(t & 1);
   // the collective of tick t-2 has read this send buffer (and the consumer of its receive buffer had until now)
-  if (g->done_valid[i]) MOT_GATHER_HIP(g, hipStreamWaitEvent(c->stream, g->done[i], 0));
+  if (wait_done) MOT_GATHER_HIP(g, hipStreamWaitEvent(c->stream, g->done[i], 0));
   const long head = ((long)g->batch * 4 + 15) & ~15l;
   char* blk = g->d_send[i] + (size_t)ci * g->block;
   mot_launch_export_tracks_packed(track_buffers(c, false), g->batch, reinterpret_cast<int*>(blk), reinterpret_cast<mot_track*>(blk + head), g->cap, c->stream);
