@@ -496,7 +496,7 @@ def dense_scene(mot, sdev, torch, device, N, stride, streams=2048, contexts=4, s
     return out
 
 
-def point_order(mot, sdev, torch, device, N, stride, headline_value, streams=2048, contexts=4, steps=3, lib=None, parity=True):
+def point_order(mot, sdev, torch, device, N, stride, headline_value, streams=2048, contexts=4, steps=5, lib=None, parity=True):
     """the headline's workload (street scene) with the points of every frame in firing (azimuth-major) and in random order: frames/s in the headline's shape,
     every kernel alone, parity of stream 0's first 40 frames against the reference on the same clouds (box fitting depends on the order: SURVEY.md H9)"""
     out = {"beam": {"value": headline_value, "what": "the headline itself: beam-major (KITTI .bin files)"}}
