@@ -439,8 +439,6 @@ cluster_index_kernel(ClusterBuffers c) {
       if (slot < c.group_cap) gsorted[slot] = r;
     }
   } else {
-    uint2* s_key = s_raw;   // {cluster, tile << 8 | points}
-    const bool in_lds = E <= kGroupsLds;
     // Round 5: a frame lands here as soon as ONE 2048-point chunk holds more than 64 clusters — an open square with 60-90 people in view does it
     // on every frame (bench.py's dense_scene leg), and city scenes with a few hundred small clusters will — and the sums below over ALL groups
     // made this kernel the slowest of the sequence there (78 us per 128 frames against 6). When the groups fit half of the LDS array they
@@ -535,27 +533,23 @@ cluster_index_kernel(ClusterBuffers c) {
       if (tid == 0) { c.counts[b * kCountsStride + kCntGroups] = 0; c.counts[b * kCountsStride + kCntIrregular] = 0; }  // re-arm
       return;
     }
-    if (bucketed) for (int ci = tid; ci < num_cluster; ci += kIndexBlock) s_start[ci] = cgstart[ci];   // (the point starts in s_start are not read on this path) running fill position of every bucket
+    // few groups (<= kGroupsLds / 2: crowds, city clutter in beam / firing order): buckets in LDS, a group sums over its own cluster's bucket
+    // (with no cluster at all there is no group: the loops below do not run)
+    for (int ci = tid; ci < num_cluster; ci += kIndexBlock) s_start[ci] = cgstart[ci];   // (the point starts in s_start are not read on this path) running fill position of every bucket
     __syncthreads();
-    if (in_lds) for (int e = tid; e < E; e += kIndexBlock) {
+    for (int e = tid; e < E; e += kIndexBlock) {
       PointGroup g = groups[e];
       const uint2 key = make_uint2((unsigned)(g.label & kGroupLabelMask), ((unsigned)(g.tile & kGroupTileMask) << 8) | (unsigned)__popcll(g.mask));
-      if (bucketed) { const int at = atomicAdd(&s_start[(int)key.x - 1], 1); if (at < kGroupsLds / 2) s_buck[at] = key; }
-      else s_key[e] = key;
+      const int at = atomicAdd(&s_start[(int)key.x - 1], 1);
+      if (at < kGroupsLds / 2) s_buck[at] = key;
     }
     __syncthreads();
     for (int e = tid; e < E; e += kIndexBlock) {
       const PointGroup g = groups[e];
       const int gtile = g.tile & kGroupTileMask, lab = g.label & kGroupLabelMask;
       int before = 0, rank = 0;  // points / groups of the same cluster in earlier tiles
-      if (bucketed) {
-        const int f0 = cgstart[lab - 1], f1 = min(cgstart[lab], kGroupsLds / 2);
-        for (int f = f0; f < f1; f++) { const uint2 q = s_buck[f]; if ((int)(q.y >> 8) < gtile) { before += (int)(q.y & 0xffu); rank++; } }
-      } else if (in_lds) {
-        for (int f = 0; f < E; f++) { uint2 q = s_key[f]; if ((int)q.x == lab && (int)(q.y >> 8) < gtile) { before += (int)(q.y & 0xffu); rank++; } }
-      } else {  // more groups than fit in LDS (heavily interleaved clusters): same sums straight from L2
-        for (int f = 0; f < E; f++) { PointGroup h = groups[f]; if ((h.label & kGroupLabelMask) == lab && (h.tile & kGroupTileMask) < gtile) { before += __popcll(h.mask); rank++; } }
-      }
+      const int f0 = cgstart[lab - 1], f1 = min(cgstart[lab], kGroupsLds / 2);
+      for (int f = f0; f < f1; f++) { const uint2 q = s_buck[f]; if ((int)(q.y >> 8) < gtile) { before += (int)(q.y & 0xffu); rank++; } }
       const int slot = cgstart[lab - 1] + rank;
       SortedGroup r; r.mask = g.mask; r.tile = gtile; r.before = before;
       if (slot < c.group_cap) gsorted[slot] = r;
