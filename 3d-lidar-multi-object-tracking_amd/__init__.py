@@ -75,7 +75,7 @@ EXPORTS = (
     "mot_track_step", "mot_track_get_state", "mot_frames_dev", "mot_sequence_dev", "mot_get_ground", "mot_get_clusters",
     "mot_get_boxes", "mot_get_tracks", "mot_export_tracks_dev", "mot_side_params_default", "mot_cluster_products", "mot_cluster_products_host", "mot_box_markers", "mot_decode_pointcloud2_dev", "mot_time_stage",
     "mot_ground_remove_pointcloud2", "mot_box_fit_resident", "mot_frame_pointcloud2",
-    "mot_reset_slot", "mot_stream_snapshot_size", "mot_stream_save", "mot_stream_load", "mot_frames_host", "mot_frames_host_xyz", "mot_wait_uploads", "mot_host_alloc", "mot_host_free", "mot_fetch_tracks_async",
+    "mot_reset_slot", "mot_stream_snapshot_size", "mot_stream_save", "mot_stream_load", "mot_frames_host", "mot_frames_host_xyz", "mot_frames_host_pointcloud2", "mot_wait_uploads", "mot_host_alloc", "mot_host_free", "mot_fetch_tracks_async",
     "mot_track_steps_dev", "mot_profile_kernel", "mot_profile_read", "mot_get_params", "mot_set_fused_outputs", "mot_set_tracker_mode", "mot_set_trace_ranges", "mot_reset_tracks_slot", "mot_export_tracks_packed_dev", "mot_set_launch_graphs",
     "mot_cluster_node_frame", "mot_ground_node_frame",
     "mot_gather_unique_id", "mot_gather_create", "mot_gather_contribute", "mot_gather_result", "mot_gather_synchronize", "mot_gather_destroy", "mot_gather_last_error",
@@ -451,6 +451,16 @@ class Context:
         ey = np.ascontiguousarray(ego_yaw if ego_yaw is not None else np.zeros(B), np.float64)
         self._ck(self.lib.mot_frames_host_xyz(self._h, C.c_void_p(h_ptr), C.c_long(frame_stride_floats), _vp(n), B,
                                               int(run_tracker), _vp(ts), _vp(ev), _vp(ey)))
+
+    def frames_host_pointcloud2(self, payloads, n_points, point_step: int, off_x: int, off_y: int, off_z: int, off_w: int = -1, run_tracker: bool = False,
+                                timestamps=None, ego_v=None, ego_yaw=None):
+        """frames_host for one sensor_msgs/PointCloud2 payload per stream (payloads: host addresses, or numpy uint8 arrays kept alive by the caller until wait_uploads)"""
+        n = np.ascontiguousarray(n_points, np.int32); B = len(n)
+        ptrs = (C.c_void_p * B)(*[(p.ctypes.data if hasattr(p, "ctypes") else int(p)) if p is not None else None for p in payloads])
+        ts = np.ascontiguousarray(timestamps if timestamps is not None else np.zeros(B), np.float64)
+        ev = np.ascontiguousarray(ego_v if ego_v is not None else np.zeros(B), np.float64)
+        ey = np.ascontiguousarray(ego_yaw if ego_yaw is not None else np.zeros(B), np.float64)
+        self._ck(self.lib.mot_frames_host_pointcloud2(self._h, ptrs, _vp(n), B, point_step, off_x, off_y, off_z, off_w, int(run_tracker), _vp(ts), _vp(ev), _vp(ey)))
 
     def wait_uploads(self):
         self._ck(self.lib.mot_wait_uploads(self._h))

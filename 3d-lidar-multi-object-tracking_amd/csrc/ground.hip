@@ -630,6 +630,28 @@ decode_pointcloud2_kernel(const unsigned char* __restrict__ data, int n, int ste
   out[i] = make_float4(field(ox), field(oy), field(oz), ow >= 0 ? field(ow) : 1.0f);
 }
 
+// the same for a BATCH of payloads laid out slot by slot (mot_frames_host_pointcloud2): raw_stride bytes / out_stride float4 between the slots; every slot is
+// decoded up to max_n records (the counts are not on the device yet; what lies beyond a slot's n is never read)
+__global__ void MOT_LAUNCH_BOUNDS(256)
+decode_pointcloud2_batch_kernel(const unsigned char* __restrict__ data, long raw_stride, int max_n, int step, int ox, int oy, int oz, int ow, int aligned,
+                                float4* __restrict__ out, long out_stride) {
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= max_n) return;
+  const unsigned char* rec = data + (long)blockIdx.y * raw_stride + i * step;
+  auto field = [&](int off) -> float {
+    unsigned u;
+    if (aligned) u = *reinterpret_cast<const unsigned*>(rec + off);
+    else u = (unsigned)rec[off] | ((unsigned)rec[off + 1] << 8) | ((unsigned)rec[off + 2] << 16) | ((unsigned)rec[off + 3] << 24);
+    return __uint_as_float(u);
+  };
+  out[(long)blockIdx.y * out_stride + i] = make_float4(field(ox), field(oy), field(oz), ow >= 0 ? field(ow) : 1.0f);
+}
+void mot_launch_decode_pointcloud2_batch(const void* data, long raw_stride, int batch, int max_n, int step, int ox, int oy, int oz, int ow, float4* out, long out_stride, hipStream_t stream) {
+  if (max_n <= 0 || batch <= 0) return;
+  const int aligned = (((size_t)data | (size_t)raw_stride | (size_t)step | (size_t)ox | (size_t)oy | (size_t)oz | (size_t)(ow >= 0 ? ow : 0)) & 3) == 0;
+  hipLaunchKernelGGL(decode_pointcloud2_batch_kernel, dim3((max_n + 255) / 256, batch), dim3(256), 0, stream, (const unsigned char*)data, raw_stride, max_n, step, ox, oy, oz, ow, aligned, out, out_stride);
+}
+
 void mot_launch_decode_pointcloud2(const void* data, int n, int step, int ox, int oy, int oz, int ow, float4* out, hipStream_t stream) {
   if (n <= 0) return;
   const int aligned = (((size_t)data | (size_t)step | (size_t)ox | (size_t)oy | (size_t)oz | (size_t)(ow >= 0 ? ow : 0)) & 3) == 0;

@@ -154,6 +154,8 @@ struct mot_ctx {
   hipStream_t copy_stream = nullptr;
   bool copy_ready = false;             // copy stream, staging buffers and events all exist
   float4* d_stage[2] = {nullptr, nullptr};
+  unsigned char* d_stage_raw[2] = {nullptr, nullptr};   // mot_frames_host_pointcloud2: where the raw message payloads land (grow-only, batch x cap x point_step bytes)
+  size_t stage_raw_bytes = 0;
   float* d_stage12[2] = {nullptr, nullptr};        // mot_frames_host_xyz: where the packed {x, y, z} records land (12 bytes a point); expanded into d_stage[i] on the compute stream
   hipEvent_t ev_expanded[2] = {nullptr, nullptr};  // the expansion kernel that read d_stage12[i] has run (compute stream)
   bool stage12_used[2] = {false, false};
@@ -289,6 +291,7 @@ extern "C" void mot_destroy(mot_ctx* c) {
   for (int i = 0; i < 2; i++) {
     if (c->d_stage[i]) (void)hipFree(c->d_stage[i]);
     if (c->d_stage12[i]) (void)hipFree(c->d_stage12[i]);
+    if (c->d_stage_raw[i]) (void)hipFree(c->d_stage_raw[i]);
     if (c->ev_expanded[i]) (void)hipEventDestroy(c->ev_expanded[i]);
     if (c->ev_copied[i]) (void)hipEventDestroy(c->ev_copied[i]);
     if (c->ev_consumed[i]) (void)hipEventDestroy(c->ev_consumed[i]);
@@ -970,6 +973,59 @@ extern "C" int mot_frames_host_xyz(mot_ctx* c, const float* h_xyz, long frame_st
   MOT_HIP(c, hipStreamWaitEvent(c->stream, c->ev_copied[s], 0));
   // (d_stage[s] was last read by the batch before the previous one, on this same stream: ordered)
   mot_launch_expand_xyz12(c->d_stage12[s], (long)cap3, c->d_stage[s], c->cap, batch, max_n, c->stream);
+  MOT_HIP(c, hipGetLastError());
+  MOT_HIP(c, hipEventRecord(c->ev_expanded[s], c->stream));
+  c->stage12_used[s] = true;
+  if ((rc = set_batch(c, n_points, batch, c->d_stage[s], c->cap, false))) return rc;
+  rc = launch_frames(c, batch, run_tracker, timestamps, ego_v, ego_yaw);
+  MOT_HIP(c, hipEventRecord(c->ev_consumed[s], c->stream));
+  c->stage_used[s] = true;
+  return rc;
+}
+
+// mot_frames_host for sensor_msgs/PointCloud2 payloads as they arrive — one message per sensor stream, each in its own host buffer (include/mot.h): what a
+// node that fuses several lidars holds in its callbacks (fromROSMsg, OT/src/groundremove/main.cpp:100, for every one of them). The raw records cross PCIe
+// on the copy stream (point_step bytes a point: 16 for kitti2bag's x, y, z, intensity; 22-32 for a velodyne driver's records with ring / time) and are
+// unpacked on the device under the next batch's copy — no host-side repacking. off_w >= 0: the float32 field that becomes the 4th value of the ground /
+// elevated records (intensity); -1: 1.0f, as fromROSMsg into PointXYZ leaves it.
+extern "C" int mot_frames_host_pointcloud2(mot_ctx* c, const void* const* h_payloads, const int* n_points, int batch, int point_step, int off_x, int off_y,
+                                           int off_z, int off_w, int run_tracker, const double* timestamps, const double* ego_v, const double* ego_yaw) {
+  if (!c) return MOT_E_ARG;
+  MOT_GUARD(c);
+  if (!h_payloads || !n_points) return fail(c, MOT_E_ARG, "null payload list or point-count pointer");
+  if (batch < 1 || batch > c->batch) return fail(c, MOT_E_ARG, "batch out of range");
+  if (point_step < 12 || point_step > 4096) return fail(c, MOT_E_ARG, "PointCloud2 payload: point_step must be 12 .. 4096");
+  const int offs[4] = {off_x, off_y, off_z, off_w};
+  for (int k = 0; k < 4; k++)
+    if ((k < 3 || offs[k] >= 0) && (offs[k] < 0 || offs[k] + 4 > point_step)) return fail(c, MOT_E_ARG, "field offset outside the point record");
+  if (off_w < -1) return fail(c, MOT_E_ARG, "off_w must be -1 (no 4th field) or a field offset");
+  if (run_tracker && (!timestamps || !ego_v || !ego_yaw)) return fail(c, MOT_E_ARG, "run_tracker needs timestamps, ego_v and ego_yaw");
+  int max_n = 0;
+  for (int b = 0; b < batch; b++) {
+    if (n_points[b] < 0 || (n_points[b] > 0 && !h_payloads[b])) return fail(c, MOT_E_ARG, "negative point count or null payload");
+    if (n_points[b] > c->max_points) return fail(c, MOT_E_CAPACITY, "frame has more points than max_points");
+    if (n_points[b] > max_n) max_n = n_points[b];
+  }
+  int rc;
+  if ((rc = ensure_copy_path(c))) return rc;
+  const size_t slot_bytes = ((size_t)c->cap * (size_t)point_step + 15) & ~(size_t)15, need = (size_t)c->batch * slot_bytes;
+  if (need > c->stage_raw_bytes) {   // (grow-only; a larger point_step than any before: both buffers are replaced once nothing reads them)
+    MOT_HIP(c, hipStreamSynchronize(c->copy_stream)); MOT_HIP(c, hipStreamSynchronize(c->stream));
+    for (int i = 0; i < 2; i++) { if (c->d_stage_raw[i]) { MOT_HIP(c, hipFree(c->d_stage_raw[i])); c->d_stage_raw[i] = nullptr; } }
+    c->stage_raw_bytes = 0;
+    for (int i = 0; i < 2; i++) MOT_HIP(c, hipMalloc(&c->d_stage_raw[i], need));
+    c->stage_raw_bytes = need;
+  }
+  for (int i = 0; i < 2; i++) if (!c->ev_expanded[i]) MOT_HIP(c, hipEventCreateWithFlags(&c->ev_expanded[i], hipEventDisableTiming));
+  const int s = c->stage_next;
+  c->stage_next ^= 1;
+  if (c->stage12_used[s]) MOT_HIP(c, hipStreamWaitEvent(c->copy_stream, c->ev_expanded[s], 0));   // (shared with the 12-byte path: "the landing buffer of parity s has been unpacked")
+  for (int b = 0; b < batch; b++)
+    if (n_points[b] > 0)
+      MOT_HIP(c, hipMemcpyAsync(c->d_stage_raw[s] + (size_t)b * slot_bytes, h_payloads[b], (size_t)n_points[b] * (size_t)point_step, hipMemcpyHostToDevice, c->copy_stream));
+  MOT_HIP(c, hipEventRecord(c->ev_copied[s], c->copy_stream));
+  MOT_HIP(c, hipStreamWaitEvent(c->stream, c->ev_copied[s], 0));
+  mot_launch_decode_pointcloud2_batch(c->d_stage_raw[s], (long)slot_bytes, batch, max_n, point_step, off_x, off_y, off_z, off_w, c->d_stage[s], c->cap, c->stream);
   MOT_HIP(c, hipGetLastError());
   MOT_HIP(c, hipEventRecord(c->ev_expanded[s], c->stream));
   c->stage12_used[s] = true;

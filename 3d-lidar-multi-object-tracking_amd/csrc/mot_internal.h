@@ -342,6 +342,7 @@ void mot_launch_export_tracks_packed(const TrackBuffers& t, int batch, int* head
 void mot_launch_ground(const MotDevParams& p, const GroundBuffers& g, int batch, int max_n, hipStream_t stream);
 void mot_launch_noop(int batch, hipStream_t stream);   // measurement only: an empty one-workgroup-per-frame launch (mot_debug_skip_kernels)
 void mot_launch_expand_xyz12(const float* in, long in_stride_floats, float4* out, long out_stride, int batch, int max_n, hipStream_t stream);
+void mot_launch_decode_pointcloud2_batch(const void* data, long raw_stride, int batch, int max_n, int step, int ox, int oy, int oz, int ow, float4* out, long out_stride, hipStream_t stream);
 void mot_launch_decode_pointcloud2(const void* data, int n, int step, int ox, int oy, int oz, int ow, float4* out, hipStream_t stream);
 // single kernels, for per-kernel timing (mot_time_stage): which = 0 min-z, 1 polar filter, 2 classify+compact
 void mot_launch_ground_kernel(int which, const MotDevParams& p, const GroundBuffers& g, int batch, int max_n,

@@ -369,6 +369,13 @@ int mot_frames_host(mot_ctx* ctx, const float* h_xyzw, long frame_stride, const 
  * on the same x, y, z. Same pipelining, same mot_wait_uploads. */
 int mot_frames_host_xyz(mot_ctx* ctx, const float* h_xyz, long frame_stride, const int* n_points, int batch,
                         int run_tracker, const double* timestamps, const double* ego_v, const double* ego_yaw);
+/* mot_frames_host for sensor_msgs/PointCloud2 payloads as they arrive (ABI v6): h_payloads[b] = the `data` of stream b's message (n_points[b] records of
+ * point_step bytes, little-endian float32 fields at off_x / off_y / off_z; off_w = the float32 field that becomes the 4th value of the output records —
+ * intensity — or -1: 1.0f, what fromROSMsg into PointXYZ leaves, OT/src/groundremove/main.cpp:100). One message per sensor stream, each in its own host
+ * buffer: the raw records cross PCIe (copy stream, double-buffered) and are unpacked on the device; no host-side repacking, any point_step 12 .. 4096
+ * (16: kitti2bag's x, y, z, intensity; 22-32: a velodyne driver's records with ring / time). Same pipelining as mot_frames_host, same mot_wait_uploads. */
+int mot_frames_host_pointcloud2(mot_ctx* ctx, const void* const* h_payloads, const int* n_points, int batch, int point_step, int off_x, int off_y,
+                                int off_z, int off_w, int run_tracker, const double* timestamps, const double* ego_v, const double* ego_yaw);
 int mot_wait_uploads(mot_ctx* ctx);
 int mot_host_alloc(size_t bytes, void** out);
 int mot_host_free(void* p);

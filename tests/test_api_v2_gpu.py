@@ -126,6 +126,43 @@ def test_frames_host_xyz_equals_frames_host_and_oracle(mot, hip_lib, oracle, syn
     assert hip_lib.mot_host_free(hp) == 0 and hip_lib.mot_host_free(hq) == 0
 
 
+@pytest.mark.parametrize("step,ox,oy,oz,ow", [(16, 0, 4, 8, 12), (32, 0, 4, 8, 16), (22, 10, 2, 6, -1)])
+def test_frames_host_pointcloud2_equals_frames_host_and_oracle(mot, hip_lib, oracle, synth, step, ox, oy, oz, ow):
+    """mot_frames_host_pointcloud2 on the MI355X: one PointCloud2 payload per stream (aligned and unaligned records) against the float4 entry point and the oracle"""
+    from test_emu_api_v2 import pointcloud2_payload
+    B, N, stride = 4, 60000, 61440
+    p = oracle.params(0)
+    hp = C.c_void_p()
+    assert hip_lib.mot_host_alloc(C.c_size_t(B * stride * 16), C.byref(hp)) == 0
+    pin4 = np.ctypeslib.as_array(C.cast(hp, C.POINTER(C.c_float)), shape=(B, stride, 4))
+    with mot.Context(max_points=stride, max_batch=B, max_tracks_total=256) as a, mot.Context(max_points=stride, max_batch=B, max_tracks_total=256) as b:
+        for f in range(4):
+            n = [N, N - 1234, 2048, 7]
+            host = np.zeros((B, stride, 4), np.float32)
+            for s in range(B):
+                host[s, : n[s]] = synth.make_cloud(N, 30 + s, f)[: n[s]]
+            if ow < 0:
+                host[..., 3] = 1.0
+            kw = dict(run_tracker=True, timestamps=[1.0e9 + f * 1e5] * B, ego_v=[2.0] * B, ego_yaw=[0.002 * f] * B)
+            a.wait_uploads(); b.wait_uploads()
+            pin4[:] = host
+            payloads = [pointcloud2_payload(host[s, : n[s]], step, ox, oy, oz, ow, 5 * f + s) for s in range(B)]
+            a.frames_host(hp.value, stride * 4, n, **kw)
+            b.frames_host_pointcloud2(payloads, n, step, ox, oy, oz, ow, **kw)
+            b.wait_uploads()
+            for s in range(B):
+                ga, gb = a.get_ground(s, n_hint=n[s]), b.get_ground(s, n_hint=n[s])
+                assert np.array_equal(ga["elevated"].view(np.uint32), gb["elevated"].view(np.uint32)) and np.array_equal(ga["ground"].view(np.uint32), gb["ground"].view(np.uint32))
+                assert np.array_equal(ga["mask"], gb["mask"]) and np.array_equal(a.get_boxes(s)["boxes"], b.get_boxes(s)["boxes"])
+                ta, tb = a.get_tracks(s), b.get_tracks(s)
+                assert ta["n"] == tb["n"] and np.array_equal(ta["track_manage"], tb["track_manage"]) and np.array_equal(ta["p"], tb["p"])
+            g = oracle.ground_remove(p, host[0, : n[0]]); cl = oracle.cluster(p, g["elevated"])
+            bx = oracle.box_fit(p, g["elevated"], cl["grid"], cl["num_cluster"])["boxes"]
+            assert np.array_equal(b.get_ground(0, n_hint=n[0])["elevated"].view(np.uint32), g["elevated"].view(np.uint32))
+            assert np.array_equal(b.get_clusters(0)["grid"], cl["grid"]) and np.array_equal(b.get_boxes(0)["boxes"], bx)
+    assert hip_lib.mot_host_free(hp) == 0
+
+
 def test_track_steps_dev_equals_track_step(mot, hip_lib):
     B = 8
     rng = np.random.default_rng(5)

@@ -108,6 +108,49 @@ def test_frames_host_xyz_equals_frames_host(mot, emu, synth, oracle):
         assert e.value.code == mot.MOT_E_CAPACITY
 
 
+def pointcloud2_payload(cloud, step, ox, oy, oz, ow, seed):
+    """a sensor_msgs/PointCloud2 `data` block: records of `step` bytes with float32 fields at the given offsets, everything else random bytes"""
+    n = len(cloud)
+    raw = np.random.default_rng(seed).integers(0, 256, size=(n, step), dtype=np.uint8)
+    for off, col in ((ox, 0), (oy, 1), (oz, 2)) + (((ow, 3),) if ow >= 0 else ()):
+        raw[:, off:off + 4] = np.ascontiguousarray(cloud[:, col], np.float32).view(np.uint8).reshape(n, 4)
+    return np.ascontiguousarray(raw.reshape(-1))
+
+
+@pytest.mark.parametrize("step,ox,oy,oz,ow", [(16, 0, 4, 8, 12), (32, 0, 4, 8, 16), (22, 0, 4, 8, 12), (22, 10, 2, 6, -1), (12, 0, 4, 8, -1)])
+def test_frames_host_pointcloud2_equals_frames_host(mot, emu, synth, oracle, step, ox, oy, oz, ow):
+    """mot_frames_host_pointcloud2 (ABI v6): one PointCloud2 payload per stream, each in its own host buffer, any point_step (16: kitti2bag; 32 / 22: a velodyne
+    driver's records, the second one with unaligned fields), unpacked on the device — every result equals mot_frames_host's on the decoded clouds"""
+    lib, L = emu
+    B, N, stride = 3, 4000, 4096
+    with mot.Context(lib_path=lib, max_points=stride, max_batch=B, max_tracks_total=128) as a, \
+         mot.Context(lib_path=lib, max_points=stride, max_batch=B, max_tracks_total=128) as b:
+        for f in range(4):   # more calls than staging buffers
+            n = [N, N - 555, 0 if f == 2 else 40 + f]
+            host = np.zeros((B, stride, 4), np.float32)
+            for s in range(B):
+                host[s, : n[s]] = synth.make_cloud(N, 60 + s, f)[: n[s]]
+            if ow < 0:
+                host[..., 3] = 1.0
+            kw = dict(run_tracker=True, timestamps=[1.0e9 + f * 1e5] * B, ego_v=[1.0] * B, ego_yaw=[0.01 * f] * B)
+            a.frames_host(host.ctypes.data, stride * 4, n, **kw)
+            payloads = [pointcloud2_payload(host[s, : n[s]], step, ox, oy, oz, ow, 7 * f + s) if n[s] else None for s in range(B)]
+            b.frames_host_pointcloud2(payloads, n, step, ox, oy, oz, ow, **kw)
+            a.wait_uploads(); b.wait_uploads()
+            for s in range(B):
+                ga, gb = a.get_ground(s, n_hint=max(n[s], 1)), b.get_ground(s, n_hint=max(n[s], 1))
+                assert np.array_equal(ga["elevated"].view(np.uint32), gb["elevated"].view(np.uint32)) and np.array_equal(ga["ground"].view(np.uint32), gb["ground"].view(np.uint32))
+                assert np.array_equal(ga["mask"], gb["mask"]) and np.array_equal(a.get_boxes(s)["boxes"], b.get_boxes(s)["boxes"])
+                ta, tb = a.get_tracks(s), b.get_tracks(s)
+                assert ta["n"] == tb["n"] and np.array_equal(ta["track_manage"], tb["track_manage"]) and np.array_equal(ta["p"], tb["p"])
+        with pytest.raises(mot.MotError) as e:
+            b.frames_host_pointcloud2(payloads, n, step, ox, step - 2, oz, ow)   # a field that sticks out of the record
+        assert e.value.code == mot.MOT_E_ARG
+        with pytest.raises(mot.MotError) as e:
+            b.frames_host_pointcloud2(payloads, [stride + 1, 1, 1], step, ox, oy, oz, ow)
+        assert e.value.code == mot.MOT_E_CAPACITY
+
+
 def test_track_steps_dev_equals_track_step(mot, emu):
     lib, L = emu
     B = 3
