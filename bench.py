@@ -865,6 +865,10 @@ def main():
     # one hardware queue per context stream (HIP's default is 4 queues per process, shared with its own null stream:
     # with 4 contexts two of them would share a queue and serialise — measured 319 k vs 402 k frames/s)
     os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+    # kernel arguments in device memory (a HIP runtime switch, not ours): the launch-bound legs — one sensor, frame by frame — run 13 % faster with it
+    # (0.208 -> 0.181 ms per frame, 5.4 -> 6.2 k frames/s back to back: profiles/r06_dev_kernarg.txt); the four-context headline does not notice. INTEGRATION.md says so
+    # to whoever deploys the node shells; a caller's own setting wins
+    os.environ.setdefault("HIP_FORCE_DEV_KERNARG", "1")
     import torch  # torch first: it brings its own HIP runtime, which libmot_hip.so then shares
     import torch.distributed as dist
 
