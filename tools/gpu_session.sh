@@ -6,6 +6,7 @@
 #   bench[:tag[:bench args]]   python bench.py <args> > bench_<tag>.json        (tag default: "default")
 #   quick[:tag[:bench args]]   bench.py --steps 8 --warmup 1 --no-aux --no-cpu-baseline <args>, twice
 #   skip[:m1,m2,...]           bench.py with MOT_BENCH_SKIP masks (mot_debug_skip_kernels): 256 * k = k extra EMPTY launches per sequence (the cost of a launch boundary; 0 = the product)
+#   timeline                   tools/timeline_stats.py on the timed region of a 4-step four-context run under rocprofv3 --kernel-trace
 #   traceo:ORDER               trace1 on firing / random point order (bench.py --point-order)
 #   trace1 / trace4            rocprofv3 --kernel-trace --stats of one context alone (B 512) / of the default 4-context line
 #   pmc[:CTR,CTR…]             one rocprofv3 --pmc pass per counter (default FETCH_SIZE,WRITE_SIZE), summarised
@@ -38,6 +39,8 @@ for step in "$@"; do
     skip) for m in $(echo ${a1:-0,256,768,1536} | tr , ' '); do for r in 1 2; do MOT_BENCH_SKIP=$m timeout 300 python bench.py --steps 8 --warmup 1 --no-aux --no-cpu-baseline --no-all-outputs 2>/dev/null | python -c "
 import sys, json
 d = json.loads(sys.stdin.readline()); print('skip mask %3d  %9.0f frames/s  %8.2f ms/step' % ($m, d['value'], d['ms_per_step']))" | tee -a $O/skip.txt; done; done ;;
+    timeline) timeout -k 5 600 rocprofv3 --kernel-trace -d $O/prof_tl -o kt -- python bench.py --steps 4 --warmup 1 --no-aux --no-cpu-baseline --no-all-outputs > $O/bench_under_rocprof_tl.json 2> $O/prof_tl.log
+              python tools/timeline_stats.py $(find $O/prof_tl -name 'kt_results.db' | head -1) 0.42 0.96 | tee $O/timeline_stats.txt; rm -rf $O/prof_tl ;;
     traceo) trace B512_1ctx_order_$a1 --steps 3 --warmup 1 --batch 512 --contexts 1 --point-order $a1 ;;
     pmc) for ctr in $(echo ${a1:-FETCH_SIZE,WRITE_SIZE} | tr , ' '); do
            timeout -k 5 170 rocprofv3 --kernel-trace --pmc $ctr -d $O/pmc_$ctr -o p -- python bench.py --steps 1 --warmup 0 --frames 12 --no-aux --no-cpu-baseline --no-all-outputs --batch 512 --contexts 1 > $O/pmc_$ctr.log 2>&1; echo "$ctr rc=$?"

@@ -5,8 +5,12 @@ import numpy as np
 db = sqlite3.connect(sys.argv[1]); c = db.cursor()
 rows = c.execute("select name,stream_id,start,end from kernels order by start").fetchall()
 rows = [r for r in rows if not r[0].startswith('__amd') and 'synth' not in r[0] and 'at::' not in r[0] and 'rocprim' not in r[0] and not r[0].startswith('void')]
-# the timed region: the last 60 % of the pipeline kernels
-n = len(rows); rows = rows[int(0.35 * n): int(0.95 * n)]
+# the window, as fractions of the pipeline's kernels in start order (argv 2, 3; default 0.35 .. 0.95). bench.py's kernels come in this order: warm-up steps (all contexts),
+# the untimed bookkeeping frames (ONE context at a time: F - 1 frames each — inside round 5's default window, which is why its figures were diluted by "1 kernel running"),
+# the timed steps (all contexts), the single-context pass. With --steps 4 --warmup 1 the timed region is kernels 0.34 .. 0.99: pass 0.42 0.96.
+n = len(rows)
+lo, hi = (float(sys.argv[2]), float(sys.argv[3])) if len(sys.argv) > 3 else (0.35, 0.95)
+rows = rows[int(lo * n): int(hi * n)]
 t0, t1 = rows[0][2], max(r[3] for r in rows)
 print("window %.1f ms, %d kernels" % ((t1 - t0) / 1e6, len(rows)))
 streams = sorted(set(r[1] for r in rows))
